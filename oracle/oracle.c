@@ -1,0 +1,441 @@
+/*
+ * oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, CPU restatement of the slam6D ICP correspondence hot path of
+ * JMUWRobotics/3DTK, used as the parity checker for the HIP implementation in
+ * 3dtk_amd/csrc.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library.  The product (lib3dtk_hip.so) never
+ * links, loads or calls anything in this directory.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).  All arithmetic is fp64 with the reference's
+ * left-to-right association; build with -ffp-contract=off (the reference is
+ * compiled -O3 without -march=native, i.e. no FMA contraction on x86-64).
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks this file
+ * against the reference's own translation units (kdIndexed.cc, icp6Dquat.cc,
+ * icp6Dsvd.cc, icp6Dapx.cc, icp6Dnapx.cc) built by oracle/build_ref.sh into
+ * oracle/_ref/, against the known-answer tests of testing/kdtree/, and against
+ * the committed fixtures under tests/golden/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* 4x4 column-major helpers (include/slam6d/globals.icc)               */
+/* ------------------------------------------------------------------ */
+
+/* globals.icc:388-395 */
+static double m3det(const double *M)
+{
+  return (M[0] * (M[4] * M[8] - M[7] * M[5])
+        - M[1] * (M[3] * M[8] - M[6] * M[5])
+        + M[2] * (M[3] * M[7] - M[6] * M[4]));
+}
+
+/* globals.icc:715-730 (M4_submat) */
+static void m4_submat(const double *Min, double *Mout, int i, int j)
+{
+  for (int di = 0; di < 3; di++)
+    for (int dj = 0; dj < 3; dj++) {
+      int si = di + ((di >= i) ? 1 : 0);
+      int sj = dj + ((dj >= j) ? 1 : 0);
+      Mout[di * 3 + dj] = Min[si * 4 + sj];
+    }
+}
+
+/* globals.icc:738-751 (M4det) */
+static double m4det(const double *M)
+{
+  double det, result = 0, i = 1.0;
+  double sub[9];
+  for (int n = 0; n < 4; n++, i *= -1.0) {
+    m4_submat(M, sub, 0, n);
+    det = m3det(sub);
+    result += M[n] * det * i;
+  }
+  return result;
+}
+
+/* globals.icc:762-785 (M4inv): singular -> identity, returns 0 */
+int orc_m4inv(const double *Min, double *Mout)
+{
+  double mdet = m4det(Min);
+  if (fabs(mdet) < 0.00000000000005) {
+    for (int k = 0; k < 16; k++) Mout[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    return 0;
+  }
+  double tmp[9];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      int sign = 1 - ((i + j) % 2) * 2;
+      m4_submat(Min, tmp, i, j);
+      Mout[i + j * 4] = (m3det(tmp) * sign) / mdet;
+    }
+  return 1;
+}
+
+/* globals.icc:298-328 (MMult) */
+void orc_mmult(const double *M1, const double *M2, double *Mout)
+{
+  double r[16];
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 4; rr++)
+      r[c * 4 + rr] = M1[rr] * M2[c * 4] + M1[4 + rr] * M2[c * 4 + 1]
+                    + M1[8 + rr] * M2[c * 4 + 2] + M1[12 + rr] * M2[c * 4 + 3];
+  memcpy(Mout, r, sizeof r);
+}
+
+/* globals.icc:1477-1490 (transform3, out-of-place) */
+static inline void xf3(const double *a, const double *p, double *o)
+{
+  o[0] = p[0] * a[0] + p[1] * a[4] + p[2] * a[8] + a[12];
+  o[1] = p[0] * a[1] + p[1] * a[5] + p[2] * a[9] + a[13];
+  o[2] = p[0] * a[2] + p[1] * a[6] + p[2] * a[10] + a[14];
+}
+
+/* globals.icc:1454-1463 (transform3, in place: (x*a0+y*a4+z*a8) then +a12) */
+static inline void xf3_inplace(const double *a, double *p)
+{
+  double x = p[0] * a[0] + p[1] * a[4] + p[2] * a[8];
+  double y = p[0] * a[1] + p[1] * a[5] + p[2] * a[9];
+  double z = p[0] * a[2] + p[1] * a[6] + p[2] * a[10];
+  p[0] = x + a[12];
+  p[1] = y + a[13];
+  p[2] = z + a[14];
+}
+
+/* globals.icc:1465-1475 (transform3normal) */
+static inline void xf3normal(const double *a, double *n)
+{
+  double x = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
+  double y = n[0] * a[4] + n[1] * a[5] + n[2] * a[6];
+  double z = n[0] * a[8] + n[1] * a[9] + n[2] * a[10];
+  n[0] = x; n[1] = y; n[2] = z;
+}
+
+/* scan.cc:851-875 (Scan::transformReduced): serial in-place pass */
+void orc_transform_points(const double *alignxf, double *xyz, size_t n)
+{
+  for (size_t i = 0; i < n; i++) xf3_inplace(alignxf, xyz + 3 * i);
+}
+
+/* scan.cc:866-870: normals */
+void orc_transform_normals(const double *alignxf, double *nrm, size_t n)
+{
+  for (size_t i = 0; i < n; i++) xf3normal(alignxf, nrm + 3 * i);
+}
+
+/* globals.icc:237-245 (Dist2) */
+static inline double dist2(const double *x1, const double *x2)
+{
+  double dx = x2[0] - x1[0];
+  double dy = x2[1] - x1[1];
+  double dz = x2[2] - x1[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+/* ------------------------------------------------------------------ */
+/* kd-tree: pointer tree exactly as KDTreeImpl (kdTreeImpl.h)          */
+/* ------------------------------------------------------------------ */
+
+typedef struct orc_node {
+  int npts;                 /* kdTreeImpl.h:221-224 */
+  int isleaf;
+  double center[3], dx, dy, dz, r;
+  int splitaxis;
+  double splitval;
+  struct orc_node *child1, *child2;
+  int *p;                   /* leaf: copy of the index run */
+} orc_node;
+
+typedef struct orc_tree {
+  const double *xyz;        /* borrowed [M][3] */
+  size_t M;
+  int *indices;             /* permuted in place by create */
+  orc_node *root;
+  long n_internal, n_leaves, max_depth;
+} orc_tree;
+
+typedef struct {
+  const double *p;          /* query (tree frame) */
+  const double *dir;
+  int closest;              /* -1 = none */
+  double closest_d2;
+  long n_int, n_leaf, n_pts;
+} orc_params;               /* kdparams.h:22-98, the fields the 1-NN uses */
+
+/* kdTreeImpl.h:82-201 (KDTreeImpl::create) */
+static orc_node *create(orc_tree *t, int *indices, size_t n, unsigned bucket, long depth)
+{
+  const double *pts = t->xyz;
+  orc_node *nd = (orc_node *)calloc(1, sizeof *nd);
+  if (depth > t->max_depth) t->max_depth = depth;
+
+  double mins[3], maxs[3], centroid[3];
+  for (int i = 0; i < 3; i++) {
+    mins[i] = maxs[i] = centroid[i] = pts[3 * (size_t)indices[0] + i];
+  }
+  for (size_t i = 1; i < n; i++)
+    for (int j = 0; j < 3; j++) {
+      double v = pts[3 * (size_t)indices[i] + j];
+      mins[j] = (v < mins[j]) ? v : mins[j];   /* std::min(mins, v) */
+      maxs[j] = (maxs[j] < v) ? v : maxs[j];   /* std::max(maxs, v) */
+      centroid[j] += v;
+    }
+  for (int i = 0; i < 3; i++) centroid[i] /= n;
+
+  if (n > 0 && n <= bucket) {                  /* :114-123 */
+    nd->npts = (int)n; nd->isleaf = 1;
+    nd->p = (int *)malloc(n * sizeof(int));
+    memcpy(nd->p, indices, n * sizeof(int));
+    t->n_leaves++;
+    return nd;
+  }
+  nd->npts = 0; nd->isleaf = 0;
+  for (int i = 0; i < 3; i++) nd->center[i] = 0.5 * (mins[i] + maxs[i]);
+  nd->dx = 0.5 * (maxs[0] - mins[0]);
+  nd->dy = 0.5 * (maxs[1] - mins[1]);
+  nd->dz = 0.5 * (maxs[2] - mins[2]);
+  nd->r = sqrt(nd->dx * nd->dx + nd->dy * nd->dy + nd->dz * nd->dz);
+
+  if (nd->dx > nd->dy) {                       /* :138-150 */
+    nd->splitaxis = (nd->dx > nd->dz) ? 0 : 2;
+  } else {
+    nd->splitaxis = (nd->dy > nd->dz) ? 1 : 2;
+  }
+  double mx = nd->dx > nd->dy ? nd->dx : nd->dy;   /* std::max(std::max(dx,dy),dz) */
+  mx = mx > nd->dz ? mx : nd->dz;
+  if (fabs(mx) < 0.01) {                       /* :153-162 */
+    nd->npts = (int)n; nd->isleaf = 1;
+    nd->p = (int *)malloc(n * sizeof(int));
+    memcpy(nd->p, indices, n * sizeof(int));
+    t->n_leaves++;
+    return nd;
+  }
+  nd->splitval = centroid[nd->splitaxis];      /* :170 */
+  int ax = nd->splitaxis;
+  int *left = indices, *right = indices + n - 1;
+  while (1) {                                  /* :172-182 */
+    while (pts[3 * (size_t)*left + ax] < nd->splitval) left++;
+    while (pts[3 * (size_t)*right + ax] >= nd->splitval) right--;
+    if (right < left) break;
+    int tmp = *left; *left = *right; *right = tmp;
+  }
+  t->n_internal++;
+  nd->child1 = create(t, indices, (size_t)(left - indices), bucket, depth + 1);
+  nd->child2 = create(t, left, n - (size_t)(left - indices), bucket, depth + 1);
+  return nd;
+}
+
+static void destroy(orc_node *nd)
+{
+  if (!nd) return;
+  if (nd->isleaf) { free(nd->p); }
+  else { destroy(nd->child1); destroy(nd->child2); }
+  free(nd);
+}
+
+/* kd.cc:46-49 / kdIndexed.cc ctor; xyz is borrowed and must outlive the tree */
+orc_tree *orc_tree_create(const double *xyz, size_t M, int bucket)
+{
+  if (M == 0) return NULL;                     /* kdTreeImpl.h:86-88 throws */
+  orc_tree *t = (orc_tree *)calloc(1, sizeof *t);
+  t->xyz = xyz; t->M = M;
+  t->indices = (int *)malloc(M * sizeof(int));
+  for (size_t i = 0; i < M; i++) t->indices[i] = (int)i;
+  t->root = create(t, t->indices, M, (unsigned)bucket, 1);
+  return t;
+}
+
+void orc_tree_destroy(orc_tree *t)
+{
+  if (!t) return;
+  destroy(t->root); free(t->indices); free(t);
+}
+
+void orc_tree_stats(const orc_tree *t, long *out3)
+{
+  out3[0] = t->n_internal; out3[1] = t->n_leaves; out3[2] = t->max_depth;
+}
+
+/* post-build permutation == concatenation of the leaves left to right */
+void orc_tree_perm(const orc_tree *t, int *out) { memcpy(out, t->indices, t->M * sizeof(int)); }
+
+/* kdTreeImpl.h:345-383 (_FindClosest) */
+static void find_closest(const orc_tree *t, const orc_node *nd, orc_params *pa)
+{
+  if (nd->isleaf) {
+    pa->n_leaf++;
+    for (int i = 0; i < nd->npts; i++) {
+      double d2 = dist2(pa->p, t->xyz + 3 * (size_t)nd->p[i]);
+      pa->n_pts++;
+      if (d2 < pa->closest_d2) { pa->closest_d2 = d2; pa->closest = nd->p[i]; }
+    }
+    return;
+  }
+  pa->n_int++;
+  double a = fabs(pa->p[0] - nd->center[0]) - nd->dx;
+  double b = fabs(pa->p[1] - nd->center[1]) - nd->dy;
+  double c = fabs(pa->p[2] - nd->center[2]) - nd->dz;
+  double ab = (a < b) ? b : a;                  /* std::max */
+  double approx = (ab < c) ? c : ab;
+  if (approx >= 0 && approx * approx >= pa->closest_d2) return;
+
+  double myd = nd->splitval - pa->p[nd->splitaxis];
+  if (myd >= 0.0) {
+    find_closest(t, nd->child1, pa);
+    if (myd * myd < pa->closest_d2) find_closest(t, nd->child2, pa);
+  } else {
+    find_closest(t, nd->child2, pa);
+    if (myd * myd < pa->closest_d2) find_closest(t, nd->child1, pa);
+  }
+}
+
+/* kdTreeImpl.h:390-425 (_FindClosestAlongDir) */
+static void find_closest_dir(const orc_tree *t, const orc_node *nd, orc_params *pa)
+{
+  if (nd->isleaf) {
+    pa->n_leaf++;
+    for (int i = 0; i < nd->npts; i++) {
+      const double *x = t->xyz + 3 * (size_t)nd->p[i];
+      double v[3] = { pa->p[0] - x[0], pa->p[1] - x[1], pa->p[2] - x[2] };
+      double len2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      double dot = v[0] * pa->dir[0] + v[1] * pa->dir[1] + v[2] * pa->dir[2];
+      double d2 = len2 - dot * dot;
+      pa->n_pts++;
+      if (d2 < pa->closest_d2) { pa->closest_d2 = d2; pa->closest = nd->p[i]; }
+    }
+    return;
+  }
+  pa->n_int++;
+  double v[3] = { pa->p[0] - nd->center[0], pa->p[1] - nd->center[1], pa->p[2] - nd->center[2] };
+  double len2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  double dot = v[0] * pa->dir[0] + v[1] * pa->dir[1] + v[2] * pa->dir[2];
+  double d2c = len2 - dot * dot;
+  double lim = nd->r + sqrt(pa->closest_d2);
+  if (d2c > lim * lim) return;
+  if (pa->p[nd->splitaxis] < nd->splitval) {
+    find_closest_dir(t, nd->child1, pa);
+    find_closest_dir(t, nd->child2, pa);
+  } else {
+    find_closest_dir(t, nd->child2, pa);
+    find_closest_dir(t, nd->child1, pa);
+  }
+}
+
+/* kd.cc:78-87 (KDtree::FindClosest), batched.  idx = -1 when none.
+ * counters (nullable) accumulates {internal nodes, leaves, leaf points}.   */
+void orc_find_closest(const orc_tree *t, const double *q, size_t K, double maxdist2,
+                      int32_t *idx, double *d2, long *counters, int nthreads)
+{
+  long c0 = 0, c1 = 0, c2 = 0;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+:c0,c1,c2)
+#endif
+  for (long i = 0; i < (long)K; i++) {
+    orc_params pa; memset(&pa, 0, sizeof pa);
+    pa.p = q + 3 * i; pa.closest = -1; pa.closest_d2 = maxdist2;
+    find_closest(t, t->root, &pa);
+    idx[i] = pa.closest;
+    if (d2) d2[i] = pa.closest_d2;
+    c0 += pa.n_int; c1 += pa.n_leaf; c2 += pa.n_pts;
+  }
+  if (counters) { counters[0] += c0; counters[1] += c1; counters[2] += c2; }
+}
+
+/* kd.cc:89-100 (KDtree::FindClosestAlongDir), batched, one dir per query */
+void orc_find_closest_along_dir(const orc_tree *t, const double *q, const double *dir, size_t K,
+                                double maxdist2, int32_t *idx, double *d2)
+{
+  for (size_t i = 0; i < K; i++) {
+    orc_params pa; memset(&pa, 0, sizeof pa);
+    pa.p = q + 3 * i; pa.dir = dir + 3 * i; pa.closest = -1; pa.closest_d2 = maxdist2;
+    find_closest_dir(t, t->root, &pa);
+    idx[i] = pa.closest;
+    if (d2) d2[i] = pa.closest_d2;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* SearchTree::getPtPairs, DataXYZ overload (searchTree.cc:92-189)     */
+/* ------------------------------------------------------------------ */
+/*
+ * pairing_mode: 0 CLOSEST_POINT, 1 CLOSEST_POINT_ALONG_NORMAL_SIMPLE,
+ *               2 CLOSEST_PLANE_SIMPLE        (include/slam6d/pairingMode.h:4-8)
+ * rnd > 1 is not restated (std::rand() from threads is unreproducible,
+ * SURVEY N-d); callers pass rnd <= 1.
+ * Outputs (all caller-allocated, sized end-start): idx (model index per query
+ * or -1), and compact pair lists p1 (model point in world frame), p2 (data
+ * point), pn (normalised data normal) in query order.  sum / centroid_* are
+ * accumulated into, not zeroed (searchTree.cc:165-177).  Returns pair count.
+ */
+size_t orc_get_pt_pairs(const orc_tree *t, const double *source_alignxf,
+                        const double *xyz_r, const double *normal_r,
+                        size_t start, size_t end, int pairing_mode, double maxdist2,
+                        int32_t *idx, double *p1, double *p2, double *pn,
+                        double *sum, double *centroid_m, double *centroid_d)
+{
+  double inv[16];
+  orc_m4inv(source_alignxf, inv);              /* :110 */
+  size_t np = 0;
+  for (size_t i = start; i < end; i++) {
+    double tt[3] = { xyz_r[3 * i], xyz_r[3 * i + 1], xyz_r[3 * i + 2] };
+    double s[3], normal[3] = { 0, 0, 0 };
+    xf3(inv, tt, s);                           /* :122 */
+    if (pairing_mode != 0) {                   /* :126-131 */
+      normal[0] = normal_r[3 * i]; normal[1] = normal_r[3 * i + 1]; normal[2] = normal_r[3 * i + 2];
+      double len = sqrt(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2]);
+      normal[0] /= len; normal[1] /= len; normal[2] /= len;   /* Normalize3 globals.icc:262-270 */
+    }
+    orc_params pa; memset(&pa, 0, sizeof pa);
+    pa.p = s; pa.closest = -1; pa.closest_d2 = maxdist2;
+    if (pairing_mode == 1) {                   /* :133-141 */
+      double nd[3] = { normal[0], normal[1], normal[2] };
+      xf3normal(inv, nd);
+      /* the reference rotates `normal` itself in place, so the PtPair keeps the rotated one */
+      normal[0] = nd[0]; normal[1] = nd[1]; normal[2] = nd[2];
+      pa.dir = normal;
+      find_closest_dir(t, t->root, &pa);
+    } else {
+      find_closest(t, t->root, &pa);           /* :143 */
+    }
+    if (idx) idx[i - start] = pa.closest;
+    if (pa.closest < 0) continue;
+    xf3(source_alignxf, t->xyz + 3 * (size_t)pa.closest, s);   /* :147 */
+    if (pairing_mode == 2) {                   /* :149-162 */
+      double tmp[3] = { s[0] - tt[0], s[1] - tt[1], s[2] - tt[2] };
+      double dot = normal[0] * tmp[0] + normal[1] * tmp[1] + normal[2] * tmp[2];
+      s[0] = normal[0] * dot + tt[0];
+      s[1] = normal[1] * dot + tt[1];
+      s[2] = normal[2] * dot + tt[2];
+    }
+    centroid_m[0] += s[0]; centroid_m[1] += s[1]; centroid_m[2] += s[2];
+    centroid_d[0] += tt[0]; centroid_d[1] += tt[1]; centroid_d[2] += tt[2];
+    double d0 = s[0] - tt[0], d1 = s[1] - tt[1], d2 = s[2] - tt[2];
+    *sum += d0 * d0 + d1 * d1 + d2 * d2;        /* Len2, :172-177 */
+    if (p1) { p1[3 * np] = s[0]; p1[3 * np + 1] = s[1]; p1[3 * np + 2] = s[2]; }
+    if (p2) { p2[3 * np] = tt[0]; p2[3 * np + 1] = tt[1]; p2[3 * np + 2] = tt[2]; }
+    if (pn) { pn[3 * np] = normal[0]; pn[3 * np + 1] = normal[1]; pn[3 * np + 2] = normal[2]; }
+    np++;
+  }
+  return np;
+}
+
+/* ------------------------------------------------------------------ */
+/* timing helper for bench.py's cpu_baseline leg ("port" kind)          */
+/* ------------------------------------------------------------------ */
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

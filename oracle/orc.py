@@ -1,0 +1,229 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes faces of the CPU oracle (oracle/liboracle.so,
+built from oracle/oracle.c) and of the reference's own translation units
+(oracle/_ref/libref3dtk.so, built by oracle/build_ref.sh where /root/reference
+exists).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+import this module; the product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_long)
+_up = C.POINTER(C.c_uint)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def build(force=False):
+    """Compile liboracle.so (always possible) and oracle/_ref (only where the
+    reference checkout is present).  Building the checker is not using it."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref = os.environ.get("TDTK_REF", "/root/reference")
+    refso = os.path.join(_HERE, "_ref", "libref3dtk.so")
+    if os.path.isdir(os.path.join(ref, "src", "slam6d")):
+        drv = os.path.join(_HERE, "ref_driver.cc")
+        if force or not os.path.exists(refso) or os.path.getmtime(refso) < os.path.getmtime(drv):
+            subprocess.check_call([os.path.join(_HERE, "build_ref.sh"), ref], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.orc_tree_create.restype = C.c_void_p
+        L.orc_tree_create.argtypes = [_dp, C.c_size_t, C.c_int]
+        L.orc_tree_destroy.argtypes = [C.c_void_p]
+        L.orc_tree_stats.argtypes = [C.c_void_p, _lp]
+        L.orc_tree_perm.argtypes = [C.c_void_p, _ip]
+        L.orc_find_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, _dp, _lp, C.c_int]
+        L.orc_find_closest_along_dir.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, _ip, _dp]
+        L.orc_get_pt_pairs.restype = C.c_size_t
+        L.orc_get_pt_pairs.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_size_t, C.c_size_t, C.c_int,
+                                       C.c_double, _ip, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_m4inv.restype = C.c_int
+        L.orc_m4inv.argtypes = [_dp, _dp]
+        L.orc_mmult.argtypes = [_dp, _dp, _dp]
+        L.orc_transform_points.argtypes = [_dp, _dp, C.c_size_t]
+        L.orc_transform_normals.argtypes = [_dp, _dp, C.c_size_t]
+        L.orc_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref3dtk.so"))
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        build()
+        R = C.CDLL(os.path.join(_HERE, "_ref", "libref3dtk.so"))
+        R.ref_kdi_create.restype = C.c_void_p
+        R.ref_kdi_create.argtypes = [_dp, C.c_size_t, C.c_int]
+        R.ref_kdi_destroy.argtypes = [C.c_void_p]
+        R.ref_kdi_find_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, C.c_int]
+        R.ref_kdi_find_closest_along_dir.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, _ip]
+        R.ref_align.restype = C.c_double
+        R.ref_align.argtypes = [C.c_int, C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp]
+        R.ref_align_parallel.restype = C.c_double
+        R.ref_align_parallel.argtypes = [C.c_int, _up, _dp, _dp, _dp, _dp, _dp]
+        R.ref_apx_align_parallel.restype = C.c_double
+        R.ref_apx_align_parallel.argtypes = [_up, _dp, _dp, _dp, _dp, _dp, _dp]
+        R.ref_host_threads.restype = C.c_int
+        _ref = R
+    return _ref
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Tree:
+    """Oracle pointer kd-tree (KDTreeImpl::create restated, kdTreeImpl.h:82-201)."""
+
+    def __init__(self, xyz, bucket=20):
+        self.xyz = _c(xyz).reshape(-1, 3)
+        self.M = self.xyz.shape[0]
+        self.h = lib().orc_tree_create(_d(self.xyz), self.M, int(bucket))
+        if not self.h:
+            raise RuntimeError("cannot create kdtree with zero points")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_tree_destroy(self.h)
+            self.h = None
+
+    def stats(self):
+        s = (C.c_long * 3)()
+        lib().orc_tree_stats(self.h, s)
+        return {"internal": s[0], "leaves": s[1], "depth": s[2]}
+
+    def perm(self):
+        out = np.empty(self.M, np.int32)
+        lib().orc_tree_perm(self.h, _i(out))
+        return out
+
+    def find_closest(self, q, maxdist2, nthreads=1, want_counters=False):
+        q = _c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        cnt = (C.c_long * 3)(0, 0, 0)
+        lib().orc_find_closest(self.h, _d(q), len(q), float(maxdist2), _i(idx), _d(d2), cnt, int(nthreads))
+        if want_counters:
+            return idx, d2, (cnt[0], cnt[1], cnt[2])
+        return idx, d2
+
+    def find_closest_along_dir(self, q, dirs, maxdist2):
+        q = _c(q).reshape(-1, 3)
+        dirs = _c(dirs).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        lib().orc_find_closest_along_dir(self.h, _d(q), _d(dirs), len(q), float(maxdist2), _i(idx), _d(d2))
+        return idx, d2
+
+    def get_pt_pairs(self, source_alignxf, xyz_r, normal_r=None, start=0, end=None, mode=0,
+                     maxdist2=625.0):
+        """SearchTree::getPtPairs (searchTree.cc:92-189).  Returns dict with idx, p1, p2,
+        pn, n, sum, centroid_m / centroid_d (un-normalised sums, as the reference leaves them)."""
+        xyz_r = _c(xyz_r).reshape(-1, 3)
+        end = len(xyz_r) if end is None else end
+        n = end - start
+        A = _c(source_alignxf).reshape(16)
+        nr = _c(normal_r).reshape(-1, 3) if normal_r is not None else None
+        idx = np.empty(n, np.int32)
+        p1 = np.empty((n, 3)); p2 = np.empty((n, 3)); pn = np.zeros((n, 3))
+        s = C.c_double(0.0)
+        cm = np.zeros(3); cd = np.zeros(3)
+        k = lib().orc_get_pt_pairs(self.h, _d(A), _d(xyz_r), _d(nr), start, end, int(mode), float(maxdist2),
+                                   _i(idx), _d(p1), _d(p2), _d(pn), C.byref(s), _d(cm), _d(cd))
+        return dict(idx=idx, p1=p1[:k].copy(), p2=p2[:k].copy(), pn=pn[:k].copy(), n=int(k),
+                    sum=s.value, centroid_m=cm, centroid_d=cd)
+
+
+def m4inv(A):
+    A = _c(A).reshape(16)
+    out = np.empty(16)
+    ok = lib().orc_m4inv(_d(A), _d(out))
+    return out, bool(ok)
+
+
+def mmult(A, B):
+    A = _c(A).reshape(16); B = _c(B).reshape(16)
+    out = np.empty(16)
+    lib().orc_mmult(_d(A), _d(B), _d(out))
+    return out
+
+
+def transform_points(alignxf, xyz):
+    """in place, Scan::transformReduced (scan.cc:851-875)"""
+    A = _c(alignxf).reshape(16)
+    assert xyz.dtype == np.float64 and xyz.flags.c_contiguous
+    lib().orc_transform_points(_d(A), _d(xyz), xyz.size // 3)
+
+
+def transform_normals(alignxf, nrm):
+    A = _c(alignxf).reshape(16)
+    assert nrm.dtype == np.float64 and nrm.flags.c_contiguous
+    lib().orc_transform_normals(_d(A), _d(nrm), nrm.size // 3)
+
+
+class RefTree:
+    """The reference's own KDtreeIndexed (compiled from /root/reference)."""
+
+    def __init__(self, xyz, bucket=20):
+        self.xyz = _c(xyz).reshape(-1, 3)
+        self.h = ref().ref_kdi_create(_d(self.xyz), len(self.xyz), int(bucket))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            ref().ref_kdi_destroy(self.h)
+            self.h = None
+
+    def find_closest(self, q, maxdist2, nthreads=1):
+        q = _c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        ref().ref_kdi_find_closest(self.h, _d(q), len(q), float(maxdist2), _i(idx), int(nthreads))
+        return idx
+
+    def find_closest_along_dir(self, q, dirs, maxdist2):
+        q = _c(q).reshape(-1, 3); dirs = _c(dirs).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        ref().ref_kdi_find_closest_along_dir(self.h, _d(q), _d(dirs), len(q), float(maxdist2), _i(idx))
+        return idx
+
+
+def ref_align(algo, p1, p2, cm, cd, nrm=None):
+    p1 = _c(p1); p2 = _c(p2)
+    out = np.empty(16)
+    err = ref().ref_align(int(algo), len(p1), _d(p1), _d(p2), _d(_c(nrm)) if nrm is not None else None,
+                          _d(_c(cm)), _d(_c(cd)), _d(out))
+    return out, err
+
+
+def ref_align_parallel(algo, n, s, cm, cd, Si):
+    T = 8
+    n = np.ascontiguousarray(n, np.uint32); assert len(n) == T
+    out = np.empty(16)
+    err = ref().ref_align_parallel(int(algo), n.ctypes.data_as(_up), _d(_c(s)), _d(_c(cm)), _d(_c(cd)),
+                                   _d(_c(Si)), _d(out))
+    return out, err
