@@ -1,0 +1,19 @@
+"""3dtk_amd -- MI355X-native slam6D ICP correspondence + alignment hot path.
+
+This package is a thin host-side mirror of the reference's interface for this path
+(``KDtree`` / ``SearchTree.getPtPairs`` / ``icp6Dminimizer`` / ``icp6D`` / ``Graph`` /
+``lum6DEuler``; same names, argument meaning and error behaviour) over the C ABI of
+``lib3dtk_hip.so`` (include/tdtk_hip.h).  All compute happens in the hand-written HIP
+kernels of ``3dtk_amd/csrc``; there is no CPU fallback: if the extension is missing or no
+gfx950 device is present, the compute entry points raise.
+
+The directory name starts with a digit, so import it with
+``importlib.import_module("3dtk_amd")`` (tests/conftest.py and bench.py do).
+"""
+from ._capi import (TdtkError, lib, build_extension, device_count, version, PairSums,  # noqa: F401
+                    ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX, CLOSEST_POINT,
+                    CLOSEST_POINT_ALONG_NORMAL_SIMPLE, CLOSEST_PLANE_SIMPLE,
+                    WANT_APX, WANT_NAPX, WANT_LUM)
+from .slam6d import (KDtree, Scan, icp6Dminimizer, icp6D_QUAT, icp6D_SVD, icp6D_APX,  # noqa: F401
+                     icp6D_NAPX, icp6D, Graph, lum6DEuler, M4inv, MMult, M4identity,
+                     EulerToMatrix4, Matrix4ToEuler, host_tree_layout)

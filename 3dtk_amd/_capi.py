@@ -1,0 +1,143 @@
+"""ctypes binding of lib3dtk_hip.so (include/tdtk_hip.h).  Plumbing only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib3dtk_hip.so")
+
+ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX = 1, 2, 6, 10
+CLOSEST_POINT, CLOSEST_POINT_ALONG_NORMAL_SIMPLE, CLOSEST_PLANE_SIMPLE = 0, 1, 2
+WANT_APX, WANT_NAPX, WANT_LUM = 1, 2, 4
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class TdtkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tdtk error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PairSums(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n", C.c_uint64), ("sum", C.c_double),
+                ("centroid_m", C.c_double * 3), ("centroid_d", C.c_double * 3),
+                ("Si", C.c_double * 9), ("apx_A", C.c_double * 6), ("apx_B", C.c_double * 3),
+                ("napx_A", C.c_double * 21), ("napx_B", C.c_double * 6), ("napx_sum", C.c_double),
+                ("lum", C.c_double * 15), ("lum_sumd2", C.c_double)]
+
+
+class TreeInfo(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("n_internal", C.c_uint64), ("n_leaves", C.c_uint64),
+                ("max_depth", C.c_uint32), ("max_leaf_points", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double)]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("algo", C.c_int), ("pairing_mode", C.c_int), ("max_num_iterations", C.c_int),
+                ("max_dist_match2", C.c_double), ("epsilon_icp", C.c_double), ("quiet", C.c_int)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("last_pairs", C.c_uint64),
+                ("last_rms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double)]
+
+
+# every symbol include/tdtk_hip.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "tdtk_last_error", "tdtk_device_count", "tdtk_version", "tdtk_tree_create", "tdtk_tree_destroy",
+    "tdtk_tree_get_info", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
+    "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
+    "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
+    "tdtk_lum_link", "tdtk_solve_spd", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
+]
+
+
+def build_extension(force=False):
+    """Compile 3dtk_amd/csrc for gfx950 into 3dtk_amd/lib3dtk_hip.so (in-tree)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src, "-j4"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise TdtkError(-2, "lib3dtk_hip.so is not built (run __graft_entry__.build()); "
+                            "there is no CPU fallback")
+    L = C.CDLL(_SO)
+    L.tdtk_last_error.restype = C.c_char_p
+    L.tdtk_version.restype = C.c_char_p
+    L.tdtk_tree_create.argtypes = [_dp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tdtk_tree_destroy.argtypes = [C.c_void_p]
+    L.tdtk_tree_destroy.restype = None
+    L.tdtk_tree_get_info.argtypes = [C.c_void_p, C.POINTER(TreeInfo)]
+    L.tdtk_find_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, _dp]
+    L.tdtk_find_closest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p]
+    L.tdtk_find_closest_along_dir.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, _ip, _dp]
+    L.tdtk_get_pt_pairs.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                    C.c_double, C.c_uint32, _dp, _ip, _dp, _dp, _dp, C.POINTER(PairSums)]
+    L.tdtk_scan_create.argtypes = [_dp, _dp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    L.tdtk_scan_destroy.argtypes = [C.c_void_p]
+    L.tdtk_scan_destroy.restype = None
+    L.tdtk_scan_size.argtypes = [C.c_void_p]
+    L.tdtk_scan_size.restype = C.c_size_t
+    L.tdtk_scan_transform.argtypes = [C.c_void_p, _dp]
+    L.tdtk_scan_download.argtypes = [C.c_void_p, _dp, _dp]
+    L.tdtk_scan_pairs.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_int, C.c_double, C.c_uint32, _dp, _ip,
+                                  C.POINTER(PairSums)]
+    L.tdtk_align.argtypes = [C.c_int, C.POINTER(PairSums), _dp, _dp]
+    L.tdtk_icp_match.argtypes = [C.c_void_p, _dp, C.c_void_p, _dp, _dp, C.POINTER(IcpParams),
+                                 C.POINTER(IcpResult), _dp, C.c_int]
+    L.tdtk_lum_link.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_double, _dp, _dp, _u64p, _dp]
+    L.tdtk_solve_spd.argtypes = [_dp, _dp, C.c_int, _dp]
+    L.tdtk_last_kernel_ms.argtypes = [_dp]
+    L.tdtk_count_visits.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _u64p]
+    L.tdtk_host_tree_layout.argtypes = [_dp, C.c_size_t, C.c_int, _ip, _u64p]
+    L.tdtk_host_m4inv.argtypes = [_dp, _dp]
+    L.tdtk_host_mmult.argtypes = [_dp, _dp, _dp]
+    L.tdtk_host_mmult.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise TdtkError(rc, lib().tdtk_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(lib().tdtk_device_count())
+
+
+def version():
+    return lib().tdtk_version().decode()
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a

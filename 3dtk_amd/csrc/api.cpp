@@ -1,0 +1,954 @@
+// C ABI of lib3dtk_hip.so (include/tdtk_hip.h): handles, workspaces, host orchestration of
+// the kernels in kernels.hip.  There is NO CPU fallback in this library: without a HIP device
+// every compute entry point fails with TDTK_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace tdtk;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void tdtk::set_error(const std::string& s) { g_err = s; }
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+      return TDTK_EDEVICE;                                                                   \
+    }                                                                                        \
+  } while (0)
+
+static double now_ms()
+{
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------
+// per-thread, per-device context: stream, events, growable workspaces
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= cap) return TDTK_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return TDTK_ENOMEM; }
+    cap = want;
+    return TDTK_OK;
+  }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
+       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_COUNT };
+
+struct Ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  DevBuf ws[WS_COUNT];
+  double* h_pin = nullptr;  // pinned staging for the per-iteration sums
+  double last_nn_ms = 0.0;
+  bool ev_pending = false;
+};
+
+static thread_local std::map<int, std::unique_ptr<Ctx>> g_ctx;
+
+static int get_ctx(int device, Ctx** out)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available (lib3dtk_hip has no CPU fallback)");
+    return TDTK_EDEVICE;
+  }
+  if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return TDTK_EINVAL; }
+  HIPCHK(hipSetDevice(device));
+  auto it = g_ctx.find(device);
+  if (it == g_ctx.end()) {
+    std::unique_ptr<Ctx> c(new Ctx);
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->e0));
+    HIPCHK(hipEventCreate(&c->e1));
+    HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
+    it = g_ctx.emplace(device, std::move(c)).first;
+  }
+  *out = it->second.get();
+  return TDTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct tdtk_tree {
+  int device = 0;
+  size_t M = 0;
+  int bucket = 0;
+  TreeDev dev{};
+  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr;
+  std::vector<double> xyz_h;  // caller-order copy (host pair lists of tdtk_get_pt_pairs)
+  double bbmin[3], bbmax[3], centre[3];
+  tdtk_tree_info info{};
+};
+
+struct tdtk_scan {
+  int device = 0;
+  size_t N = 0;
+  double *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
+  int32_t* d_order = nullptr;    // sorted position -> caller index
+  std::vector<int32_t> order_h;
+};
+
+// ------------------------------------------------------------------------------------------
+// host-side spatial ordering (Morton code on the batch's own bounding box).  One-time per scan;
+// deterministic (ties broken by caller index), so repeated runs reduce in the same order.
+// ------------------------------------------------------------------------------------------
+static inline uint64_t spread10(uint64_t v)
+{
+  v &= 0x3FF;
+  v = (v | (v << 16)) & 0x30000FFull;
+  v = (v | (v << 8)) & 0x300F00Full;
+  v = (v | (v << 4)) & 0x30C30C3ull;
+  v = (v | (v << 2)) & 0x9249249ull;
+  return v;
+}
+
+static void morton_order(const double* xyz, size_t n, std::vector<int32_t>& order)
+{
+  order.resize(n);
+  if (!n) return;
+  double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+  for (size_t i = 1; i < n; i++)
+    for (int a = 0; a < 3; a++) {
+      const double v = xyz[3 * i + a];
+      if (v < lo[a]) lo[a] = v;
+      if (v > hi[a]) hi[a] = v;
+    }
+  double sc[3];
+  for (int a = 0; a < 3; a++) {
+    const double ext = hi[a] - lo[a];
+    sc[a] = (ext > 0 && std::isfinite(ext)) ? 1023.999 / ext : 0.0;
+  }
+  std::vector<uint64_t> keys(n);
+  for (size_t i = 0; i < n; i++) {
+    uint64_t c[3];
+    for (int a = 0; a < 3; a++) {
+      double f = (xyz[3 * i + a] - lo[a]) * sc[a];
+      if (!(f >= 0)) f = 0;
+      if (f > 1023) f = 1023;
+      c[a] = (uint64_t)f;
+    }
+    const uint64_t code = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+    keys[i] = (code << 32) | (uint64_t)i;
+  }
+  std::sort(keys.begin(), keys.end());
+  for (size_t i = 0; i < n; i++) order[i] = (int32_t)(keys[i] & 0xFFFFFFFFull);
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* tdtk_last_error(void) { return g_err.c_str(); }
+const char* tdtk_version(void) { return "3dtk_amd 0.1 (gfx950)"; }
+
+int tdtk_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- tree ------------------------------------------------------------------------------
+int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, tdtk_tree** out)
+{
+  if (!out) { set_error("out is NULL"); return TDTK_EINVAL; }
+  *out = nullptr;
+  if (!xyz || M == 0) { set_error("cannot create kdtree with zero points"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+
+  const double t0 = now_ms();
+  HostTree H;
+  std::string err;
+  if (!build_tree(xyz, M, bucket_size, H, err)) { set_error(err); return TDTK_EINVAL; }
+  const double t1 = now_ms();
+
+  std::unique_ptr<tdtk_tree> t(new tdtk_tree);
+  t->device = device; t->M = M; t->bucket = bucket_size;
+  t->xyz_h.assign(xyz, xyz + 3 * M);
+  for (int a = 0; a < 3; a++) {
+    t->bbmin[a] = H.bbmin[a]; t->bbmax[a] = H.bbmax[a];
+    t->centre[a] = 0.5 * (H.bbmin[a] + H.bbmax[a]);
+  }
+  size_t bytes = 0;
+  if (!H.nodes.empty()) {
+    HIPCHK(hipMalloc(&t->d_nodes, H.nodes.size() * sizeof(KdNode)));
+    HIPCHK(hipMemcpy(t->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&t->d_r, H.node_r.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(t->d_r, H.node_r.data(), H.node_r.size() * sizeof(double), hipMemcpyHostToDevice));
+    bytes += H.nodes.size() * (sizeof(KdNode) + sizeof(double));
+  }
+  HIPCHK(hipMalloc(&t->d_pts, H.pts.size() * sizeof(KdPoint)));
+  HIPCHK(hipMemcpy(t->d_pts, H.pts.data(), H.pts.size() * sizeof(KdPoint), hipMemcpyHostToDevice));
+  bytes += H.pts.size() * sizeof(KdPoint);
+  if (H.table_mode) {
+    HIPCHK(hipMalloc(&t->d_leaf, H.leaf_tab.size() * sizeof(LeafEntry)));
+    HIPCHK(hipMemcpy(t->d_leaf, H.leaf_tab.data(), H.leaf_tab.size() * sizeof(LeafEntry), hipMemcpyHostToDevice));
+    bytes += H.leaf_tab.size() * sizeof(LeafEntry);
+  }
+  t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
+  t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
+  t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
+  t->dev.node_r = static_cast<const double*>(t->d_r);
+  t->dev.root_ref = H.root_ref;
+  t->dev.cb = (uint32_t)H.cb;
+  t->dev.cmask = (H.cb >= 32) ? 0xFFFFFFFFu : ((1u << H.cb) - 1u);
+  const double t2 = now_ms();
+
+  t->info.n_points = M;
+  t->info.n_internal = H.n_internal;
+  t->info.n_leaves = H.n_leaves;
+  t->info.max_depth = H.max_depth;
+  t->info.max_leaf_points = H.max_leaf_points;
+  t->info.device_bytes = bytes;
+  t->info.build_ms = t1 - t0;
+  t->info.upload_ms = t2 - t1;
+  *out = t.release();
+  return TDTK_OK;
+}
+
+void tdtk_tree_destroy(tdtk_tree* t)
+{
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  if (t->d_nodes) (void)hipFree(t->d_nodes);
+  if (t->d_pts) (void)hipFree(t->d_pts);
+  if (t->d_leaf) (void)hipFree(t->d_leaf);
+  if (t->d_r) (void)hipFree(t->d_r);
+  delete t;
+}
+
+int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info)
+{
+  if (!t || !info) { set_error("NULL argument"); return TDTK_EINVAL; }
+  *info = t->info;
+  return TDTK_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// internal: one search pass over SoA queries
+// ------------------------------------------------------------------------------------------
+static int prepare_overflow(Ctx* c, const tdtk_tree* t, uint32_t grid, SearchArgs& a)
+{
+  const int need = (int)t->info.max_depth - 1 - search_lds_depth();
+  a.ovf_m2 = nullptr; a.ovf_ref = nullptr;
+  if (need > 0) {
+    const size_t lanes = (size_t)grid * search_block();
+    int rc = c->ws[WS_OVF_M2].ensure(lanes * need * sizeof(double));
+    if (rc) return rc;
+    rc = c->ws[WS_OVF_REF].ensure(lanes * need * sizeof(uint32_t));
+    if (rc) return rc;
+    a.ovf_m2 = c->ws[WS_OVF_M2].as<double>();
+    a.ovf_ref = c->ws[WS_OVF_REF].as<uint32_t>();
+  }
+  return TDTK_OK;
+}
+
+static int run_search(Ctx* c, const tdtk_tree* t, SearchArgs& a, int dirmode, bool count, hipStream_t s,
+                      bool timed)
+{
+  a.T = t->dev;
+  const uint32_t grid = search_grid(a.n);
+  int rc = prepare_overflow(c, t, grid, a);
+  if (rc) return rc;
+  if (timed) HIPCHK(hipEventRecord(c->e0, s));
+  HIPCHK(launch_search(a, grid, dirmode, count, s));
+  if (timed) { HIPCHK(hipEventRecord(c->e1, s)); c->ev_pending = true; }
+  return TDTK_OK;
+}
+
+static int collect_ms(Ctx* c, double* ms)
+{
+  if (c->ev_pending) {
+    HIPCHK(hipEventSynchronize(c->e1));
+    float f = 0;
+    HIPCHK(hipEventElapsedTime(&f, c->e0, c->e1));
+    c->last_nn_ms = f;
+    c->ev_pending = false;
+  }
+  if (ms) *ms = c->last_nn_ms;
+  return TDTK_OK;
+}
+
+// acc[ACC_TOTAL] (sums about `shift`) -> the reference's quantities
+static void finish_sums(const double* acc, const double shift[3], size_t nq, unsigned want, tdtk_pair_sums* o)
+{
+  std::memset(o, 0, sizeof *o);
+  o->n_queries = nq;
+  const double n = acc[ACC_N];
+  o->n = (uint64_t)(n + 0.5);
+  o->sum = acc[ACC_SUM];
+  o->lum_sumd2 = acc[ACC_SUM];
+  if (o->n == 0) return;
+  const double* Sm = acc + ACC_SM;
+  const double* Sd = acc + ACC_SD;
+  double wm[3], wd[3];
+  for (int a = 0; a < 3; a++) {
+    wm[a] = Sm[a] / n; wd[a] = Sd[a] / n;
+    o->centroid_m[a] = shift[a] + wm[a];
+    o->centroid_d[a] = shift[a] + wd[a];
+  }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) o->Si[a * 3 + b] = acc[ACC_P + a * 3 + b] - Sm[a] * Sd[b] / n;
+  if (want & TDTK_WANT_APX) {
+    double D2[3][3], Dc[3][3], E[3][3];
+    const double* dd = acc + ACC_DD;
+    D2[0][0] = dd[0]; D2[0][1] = D2[1][0] = dd[1]; D2[0][2] = D2[2][0] = dd[2];
+    D2[1][1] = dd[3]; D2[1][2] = D2[2][1] = dd[4]; D2[2][2] = dd[5];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        Dc[a][b] = D2[a][b] - Sd[a] * Sd[b] / n;
+        // E[a][b] = sum (p1-p2)_a (p2-cd)_b
+        E[a][b] = acc[ACC_P + a * 3 + b] - D2[a][b] - (Sm[a] - Sd[a]) * Sd[b] / n;
+      }
+    o->apx_A[0] = Dc[1][1] + Dc[2][2];
+    o->apx_A[1] = -Dc[0][1];
+    o->apx_A[2] = -Dc[0][2];
+    o->apx_A[3] = Dc[0][0] + Dc[2][2];
+    o->apx_A[4] = -Dc[1][2];
+    o->apx_A[5] = Dc[0][0] + Dc[1][1];
+    o->apx_B[0] = E[2][1] - E[1][2];
+    o->apx_B[1] = E[0][2] - E[2][0];
+    o->apx_B[2] = E[1][0] - E[0][1];
+  }
+  if (want & TDTK_WANT_NAPX) {
+    // c_true = (p2 - cd) x n = u0 - w x n,  w = cd - shift  ->  v_true = L v0,
+    // L = [[I, -W], [0, I]], W = [w]x
+    double A0[6][6], L[6][6], T1[6][6];
+    int q = 0;
+    for (int r = 0; r < 6; r++)
+      for (int s = r; s < 6; s++) { A0[r][s] = A0[s][r] = acc[ACC_NA + q]; q++; }
+    for (int r = 0; r < 6; r++)
+      for (int s = 0; s < 6; s++) L[r][s] = (r == s) ? 1.0 : 0.0;
+    const double* w = wd;
+    L[0][4] = w[2];  L[0][5] = -w[1];
+    L[1][3] = -w[2]; L[1][5] = w[0];
+    L[2][3] = w[1];  L[2][4] = -w[0];
+    for (int r = 0; r < 6; r++)
+      for (int s = 0; s < 6; s++) {
+        double v = 0;
+        for (int k = 0; k < 6; k++) v += L[r][k] * A0[k][s];
+        T1[r][s] = v;
+      }
+    q = 0;
+    for (int r = 0; r < 6; r++)
+      for (int s = r; s < 6; s++) {
+        double v = 0;
+        for (int k = 0; k < 6; k++) v += T1[r][k] * L[s][k];
+        o->napx_A[q++] = v;
+      }
+    for (int r = 0; r < 6; r++) {
+      double v = 0;
+      for (int k = 0; k < 6; k++) v += L[r][k] * acc[ACC_NB + k];
+      o->napx_B[r] = v;
+    }
+    o->napx_sum = acc[ACC_NS];
+  }
+  if (want & TDTK_WANT_LUM)
+    for (int k = 0; k < 15; k++) o->lum[k] = acc[ACC_L + k];
+}
+
+// search + accumulate over a resident scan.  acc_out (host, ACC_TOTAL) receives raw columns.
+static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, int pmode,
+                     double maxd2, unsigned want, const double* lum_D, const double* pending,
+                     bool do_search, double* acc_out, double shift_out[3])
+{
+  hipStream_t s = c->stream;
+  const size_t N = data->N;
+  int rc = c->ws[WS_KPOS].ensure(N * sizeof(int));
+  if (rc) return rc;
+  Mat4 A, inv;
+  std::memcpy(A.m, A16, sizeof A.m);
+  m4inv(A16, inv.m);  // searchTree.cc:110
+  if (do_search) {
+    SearchArgs sa{};
+    sa.x = data->x; sa.y = data->y; sa.z = data->z;
+    sa.nx = data->nx; sa.ny = data->ny; sa.nz = data->nz;
+    sa.n = N;
+    sa.has_pending = pending ? 1 : 0;
+    if (pending) std::memcpy(sa.pending.m, pending, sizeof sa.pending.m);
+    sa.inv = inv; sa.has_inv = 1;
+    sa.maxd2 = maxd2;
+    sa.kpos = c->ws[WS_KPOS].as<int>();
+    sa.d2 = nullptr;
+    rc = run_search(c, model, sa, pmode == 1 ? 1 : 0, false, s, true);
+    if (rc) return rc;
+  }
+  AccumArgs aa{};
+  aa.T = model->dev;
+  aa.x = data->x; aa.y = data->y; aa.z = data->z;
+  aa.nx = data->nx; aa.ny = data->ny; aa.nz = data->nz;
+  aa.kpos = c->ws[WS_KPOS].as<int>();
+  aa.n = N;
+  aa.A = A; aa.inv = inv;
+  // sums are taken about the model box centre mapped to the world: keeps the raw second
+  // moments small so the centred covariance survives the subtraction in fp64
+  double sh[3];
+  sh[0] = model->centre[0] * A16[0] + model->centre[1] * A16[4] + model->centre[2] * A16[8] + A16[12];
+  sh[1] = model->centre[0] * A16[1] + model->centre[1] * A16[5] + model->centre[2] * A16[9] + A16[13];
+  sh[2] = model->centre[0] * A16[2] + model->centre[1] * A16[6] + model->centre[2] * A16[10] + A16[14];
+  for (int k = 0; k < 3; k++) { aa.shift[k] = sh[k]; shift_out[k] = sh[k]; }
+  aa.has_D = lum_D ? 1 : 0;
+  if (lum_D) std::memcpy(aa.D, lum_D, sizeof aa.D);
+  const uint32_t grid = accum_grid(N);
+  rc = c->ws[WS_PART].ensure((size_t)grid * ACC_TOTAL * sizeof(double));
+  if (rc) return rc;
+  rc = c->ws[WS_OUT].ensure(ACC_TOTAL * sizeof(double));
+  if (rc) return rc;
+  aa.partials = c->ws[WS_PART].as<double>();
+  HIPCHK(launch_accum(aa, grid, want, pmode, c->ws[WS_OUT].as<double>(), s));
+  HIPCHK(hipMemcpyAsync(c->h_pin, c->ws[WS_OUT].p, ACC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
+  return TDTK_OK;
+}
+
+static int scan_idx_to_host(Ctx* c, const tdtk_tree* model, tdtk_scan* data, int32_t* idx_out)
+{
+  const size_t N = data->N;
+  int rc = c->ws[WS_IDX].ensure(N * sizeof(int32_t));
+  if (rc) return rc;
+  HIPCHK(launch_scatter_idx(c->ws[WS_KPOS].as<int>(), nullptr, data->d_order, model->dev.pts, N,
+                            c->ws[WS_IDX].as<int32_t>(), nullptr, c->stream));
+  HIPCHK(hipMemcpyAsync(idx_out, c->ws[WS_IDX].p, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return TDTK_OK;
+}
+
+extern "C" {
+
+// ---- find closest ----------------------------------------------------------------------
+int tdtk_find_closest_dev(const tdtk_tree* t, const double* d_q, size_t K, double maxdist2,
+                          int32_t* d_idx, double* d_d2, int presorted, void* stream)
+{
+  if (!t || (!d_q && K)) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(t->device, &c);
+  if (rc) return rc;
+  if (K == 0) return TDTK_OK;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  int ids[] = {WS_QX, WS_QY, WS_QZ};
+  for (int id : ids)
+    if ((rc = c->ws[id].ensure(K * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_KPOS].ensure(K * sizeof(int)))) return rc;
+  if ((rc = c->ws[WS_D2].ensure(K * sizeof(double)))) return rc;
+  const int32_t* order = nullptr;
+  if (!presorted) {
+    if ((rc = c->ws[WS_ORDER].ensure(K * sizeof(int32_t)))) return rc;
+    if ((rc = c->ws[WS_CELL].ensure(K * sizeof(uint32_t)))) return rc;
+    if ((rc = c->ws[WS_HIST].ensure(32768 * sizeof(uint32_t)))) return rc;
+    BinArgs b{};
+    b.q = d_q; b.dir = nullptr; b.n = K;
+    for (int a = 0; a < 3; a++) {
+      b.lo[a] = t->bbmin[a];
+      const double ext = t->bbmax[a] - t->bbmin[a];
+      b.scale[a] = (ext > 0) ? 32.0 / ext : 0.0;
+    }
+    b.hist = c->ws[WS_HIST].as<uint32_t>();
+    b.cell = c->ws[WS_CELL].as<uint32_t>();
+    b.sx = c->ws[WS_QX].as<double>(); b.sy = c->ws[WS_QY].as<double>(); b.sz = c->ws[WS_QZ].as<double>();
+    b.order = c->ws[WS_ORDER].as<int32_t>();
+    HIPCHK(launch_bin(b, s));
+    order = b.order;
+  } else {
+    HIPCHK(launch_split_soa(d_q, K, c->ws[WS_QX].as<double>(), c->ws[WS_QY].as<double>(),
+                            c->ws[WS_QZ].as<double>(), s));
+  }
+  SearchArgs sa{};
+  sa.x = c->ws[WS_QX].as<double>(); sa.y = c->ws[WS_QY].as<double>(); sa.z = c->ws[WS_QZ].as<double>();
+  sa.n = K; sa.maxd2 = maxdist2;
+  sa.kpos = c->ws[WS_KPOS].as<int>();
+  sa.d2 = c->ws[WS_D2].as<double>();
+  rc = run_search(c, t, sa, 0, false, s, true);
+  if (rc) return rc;
+  HIPCHK(launch_scatter_idx(sa.kpos, sa.d2, order, t->dev.pts, K, d_idx, d_d2, s));
+  if (!stream) HIPCHK(hipStreamSynchronize(s));
+  return TDTK_OK;
+}
+
+int tdtk_find_closest(const tdtk_tree* t, const double* q, size_t K, double maxdist2, int32_t* idx,
+                      double* d2)
+{
+  if (!t || (!q && K) || (!idx && K)) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(t->device, &c);
+  if (rc) return rc;
+  if (K == 0) return TDTK_OK;
+  if ((rc = c->ws[WS_TMPA].ensure(3 * K * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_IDX].ensure(K * sizeof(int32_t)))) return rc;
+  if ((rc = c->ws[WS_TMPB].ensure(K * sizeof(double)))) return rc;
+  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, q, 3 * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  rc = tdtk_find_closest_dev(t, c->ws[WS_TMPA].as<double>(), K, maxdist2, c->ws[WS_IDX].as<int32_t>(),
+                             c->ws[WS_TMPB].as<double>(), 0, c->stream);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(idx, c->ws[WS_IDX].p, K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (d2) HIPCHK(hipMemcpyAsync(d2, c->ws[WS_TMPB].p, K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return TDTK_OK;
+}
+
+int tdtk_find_closest_along_dir(const tdtk_tree* t, const double* q, const double* dir, size_t K,
+                                double maxdist2, int32_t* idx, double* d2)
+{
+  if (!t || ((!q || !dir || !idx) && K)) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(t->device, &c);
+  if (rc) return rc;
+  if (K == 0) return TDTK_OK;
+  hipStream_t s = c->stream;
+  int dbl[] = {WS_QX, WS_QY, WS_QZ, WS_DX, WS_DY, WS_DZ, WS_D2, WS_TMPB};
+  for (int id : dbl)
+    if ((rc = c->ws[id].ensure(K * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_TMPA].ensure(6 * K * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_KPOS].ensure(K * sizeof(int)))) return rc;
+  if ((rc = c->ws[WS_IDX].ensure(K * sizeof(int32_t)))) return rc;
+  if ((rc = c->ws[WS_ORDER].ensure(K * sizeof(int32_t)))) return rc;
+  if ((rc = c->ws[WS_CELL].ensure(K * sizeof(uint32_t)))) return rc;
+  if ((rc = c->ws[WS_HIST].ensure(32768 * sizeof(uint32_t)))) return rc;
+  double* dq = c->ws[WS_TMPA].as<double>();
+  double* dd = dq + 3 * K;
+  HIPCHK(hipMemcpyAsync(dq, q, 3 * K * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dd, dir, 3 * K * sizeof(double), hipMemcpyHostToDevice, s));
+  BinArgs b{};
+  b.q = dq; b.dir = dd; b.n = K;
+  for (int a = 0; a < 3; a++) {
+    b.lo[a] = t->bbmin[a];
+    const double ext = t->bbmax[a] - t->bbmin[a];
+    b.scale[a] = (ext > 0) ? 32.0 / ext : 0.0;
+  }
+  b.hist = c->ws[WS_HIST].as<uint32_t>();
+  b.cell = c->ws[WS_CELL].as<uint32_t>();
+  b.sx = c->ws[WS_QX].as<double>(); b.sy = c->ws[WS_QY].as<double>(); b.sz = c->ws[WS_QZ].as<double>();
+  b.sdx = c->ws[WS_DX].as<double>(); b.sdy = c->ws[WS_DY].as<double>(); b.sdz = c->ws[WS_DZ].as<double>();
+  b.order = c->ws[WS_ORDER].as<int32_t>();
+  HIPCHK(launch_bin(b, s));
+  SearchArgs sa{};
+  sa.x = b.sx; sa.y = b.sy; sa.z = b.sz;
+  sa.nx = b.sdx; sa.ny = b.sdy; sa.nz = b.sdz;
+  sa.n = K; sa.maxd2 = maxdist2;
+  sa.kpos = c->ws[WS_KPOS].as<int>();
+  sa.d2 = c->ws[WS_D2].as<double>();
+  rc = run_search(c, t, sa, 2, false, s, true);
+  if (rc) return rc;
+  HIPCHK(launch_scatter_idx(sa.kpos, sa.d2, b.order, t->dev.pts, K, c->ws[WS_IDX].as<int32_t>(),
+                            c->ws[WS_TMPB].as<double>(), s));
+  HIPCHK(hipMemcpyAsync(idx, c->ws[WS_IDX].p, K * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (d2) HIPCHK(hipMemcpyAsync(d2, c->ws[WS_TMPB].p, K * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return TDTK_OK;
+}
+
+int tdtk_count_visits(const tdtk_tree* t, const double* q, size_t K, double maxdist2, uint64_t counters[3])
+{
+  if (!t || !q || !counters) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(t->device, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  int ids[] = {WS_QX, WS_QY, WS_QZ};
+  for (int id : ids)
+    if ((rc = c->ws[id].ensure(K * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_TMPA].ensure(3 * K * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_KPOS].ensure(K * sizeof(int)))) return rc;
+  if ((rc = c->ws[WS_CNT].ensure(3 * sizeof(unsigned long long)))) return rc;
+  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, q, 3 * K * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(c->ws[WS_CNT].p, 0, 3 * sizeof(unsigned long long), s));
+  HIPCHK(launch_split_soa(c->ws[WS_TMPA].as<double>(), K, c->ws[WS_QX].as<double>(),
+                          c->ws[WS_QY].as<double>(), c->ws[WS_QZ].as<double>(), s));
+  SearchArgs sa{};
+  sa.x = c->ws[WS_QX].as<double>(); sa.y = c->ws[WS_QY].as<double>(); sa.z = c->ws[WS_QZ].as<double>();
+  sa.n = K; sa.maxd2 = maxdist2;
+  sa.kpos = c->ws[WS_KPOS].as<int>();
+  sa.counters = c->ws[WS_CNT].as<unsigned long long>();
+  rc = run_search(c, t, sa, 0, true, s, false);
+  if (rc) return rc;
+  unsigned long long h[3];
+  HIPCHK(hipMemcpyAsync(h, c->ws[WS_CNT].p, sizeof h, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int k = 0; k < 3; k++) counters[k] = h[k];
+  return TDTK_OK;
+}
+
+int tdtk_last_kernel_ms(double* nn_ms)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("no device"); return TDTK_EDEVICE; }
+  Ctx* c;
+  int rc = get_ctx(dev, &c);
+  if (rc) return rc;
+  return collect_ms(c, nn_ms);
+}
+
+// ---- resident scan ---------------------------------------------------------------------
+int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device, tdtk_scan** out)
+{
+  if (!out) { set_error("out is NULL"); return TDTK_EINVAL; }
+  *out = nullptr;
+  if (!xyz && N) { set_error("NULL points"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  std::unique_ptr<tdtk_scan> sc(new tdtk_scan);
+  sc->device = device; sc->N = N;
+  if (N == 0) { *out = sc.release(); return TDTK_OK; }
+  morton_order(xyz, N, sc->order_h);
+  std::vector<double> buf(N);
+  auto up = [&](const double* src, int comp, double** dst) -> int {
+    for (size_t j = 0; j < N; j++) buf[j] = src[3 * (size_t)sc->order_h[j] + comp];
+    HIPCHK(hipMalloc((void**)dst, N * sizeof(double)));
+    HIPCHK(hipMemcpy(*dst, buf.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    return TDTK_OK;
+  };
+  if ((rc = up(xyz, 0, &sc->x)) || (rc = up(xyz, 1, &sc->y)) || (rc = up(xyz, 2, &sc->z))) return rc;
+  if (nrm)
+    if ((rc = up(nrm, 0, &sc->nx)) || (rc = up(nrm, 1, &sc->ny)) || (rc = up(nrm, 2, &sc->nz))) return rc;
+  HIPCHK(hipMalloc((void**)&sc->d_order, N * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(sc->d_order, sc->order_h.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+  *out = sc.release();
+  return TDTK_OK;
+}
+
+void tdtk_scan_destroy(tdtk_scan* s)
+{
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  double* p[] = {s->x, s->y, s->z, s->nx, s->ny, s->nz};
+  for (double* q : p)
+    if (q) (void)hipFree(q);
+  if (s->d_order) (void)hipFree(s->d_order);
+  delete s;
+}
+
+size_t tdtk_scan_size(const tdtk_scan* s) { return s ? s->N : 0; }
+
+int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16])
+{
+  if (!s || !alignxf) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(s->device, &c);
+  if (rc) return rc;
+  Mat4 A;
+  std::memcpy(A.m, alignxf, sizeof A.m);
+  HIPCHK(launch_transform(s->x, s->y, s->z, s->nx, s->ny, s->nz, s->N, A, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return TDTK_OK;
+}
+
+int tdtk_scan_download(const tdtk_scan* s, double* xyz_out, double* nrm_out)
+{
+  if (!s || !xyz_out) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(s->device, &c);
+  if (rc) return rc;
+  const size_t N = s->N;
+  std::vector<double> buf(N);
+  auto down = [&](const double* src, int comp, double* dst) -> int {
+    HIPCHK(hipMemcpy(buf.data(), src, N * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t j = 0; j < N; j++) dst[3 * (size_t)s->order_h[j] + comp] = buf[j];
+    return TDTK_OK;
+  };
+  if ((rc = down(s->x, 0, xyz_out)) || (rc = down(s->y, 1, xyz_out)) || (rc = down(s->z, 2, xyz_out))) return rc;
+  if (nrm_out && s->nx)
+    if ((rc = down(s->nx, 0, nrm_out)) || (rc = down(s->ny, 1, nrm_out)) || (rc = down(s->nz, 2, nrm_out))) return rc;
+  return TDTK_OK;
+}
+
+int tdtk_scan_pairs(const tdtk_tree* model, const double A[16], tdtk_scan* data, int pmode, double maxd2,
+                    uint32_t want, const double* lum_D, int32_t* idx_out, tdtk_pair_sums* sums)
+{
+  if (!model || !A || !data || !sums) { set_error("NULL argument"); return TDTK_EINVAL; }
+  if (pmode < 0 || pmode > 2) { set_error("bad pairing mode"); return TDTK_EINVAL; }
+  if ((pmode != 0 || (want & TDTK_WANT_NAPX)) && !data->nx) {
+    set_error("this pairing mode / minimizer needs normals");
+    return TDTK_EINVAL;
+  }
+  if (model->device != data->device) { set_error("tree and scan live on different devices"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(model->device, &c);
+  if (rc) return rc;
+  std::memset(sums, 0, sizeof *sums);
+  sums->n_queries = data->N;
+  if (data->N == 0) return TDTK_OK;
+  double acc[ACC_TOTAL], shift[3];
+  rc = scan_pass(c, model, A, data, pmode, maxd2, want, lum_D, nullptr, true, acc, shift);
+  if (rc) return rc;
+  finish_sums(acc, shift, data->N, want, sums);
+  if (lum_D) sums->lum_sumd2 = acc[ACC_LSS];  // second-pass residual rides here (see tdtk_lum_link)
+  if (idx_out) rc = scan_idx_to_host(c, model, data, idx_out);
+  collect_ms(c, nullptr);
+  return rc;
+}
+
+int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_r, const double* normal_r,
+                      size_t start, size_t end, int rnd, int pmode, double maxd2, uint32_t want,
+                      const double* lum_D, int32_t* idx_out, double* p1_out, double* p2_out,
+                      double* pn_out, tdtk_pair_sums* sums)
+{
+  if (!t || !A || !xyz_r || !sums || end < start) { set_error("bad argument"); return TDTK_EINVAL; }
+  if (rnd > 1) {
+    set_error("rnd > 1 (std::rand() sub-sampling) is not reproducible and not supported on the device path");
+    return TDTK_EUNSUP;
+  }
+  const size_t n = end - start;
+  tdtk_scan* sc = nullptr;
+  int rc = tdtk_scan_create(xyz_r + 3 * start, normal_r ? normal_r + 3 * start : nullptr, n, t->device, &sc);
+  if (rc) return rc;
+  std::vector<int32_t> idx_local;
+  int32_t* idx = idx_out;
+  const bool want_pairs = p1_out || p2_out || pn_out;
+  if (!idx && want_pairs) { idx_local.resize(n); idx = idx_local.data(); }
+  rc = tdtk_scan_pairs(t, A, sc, pmode, maxd2, want, lum_D, idx, sums);
+  tdtk_scan_destroy(sc);
+  if (rc) return rc;
+  if (want_pairs) {
+    // the PtPair(s, t, normal) list of searchTree.cc:179-180, in query order (host, optional)
+    double inv[16];
+    m4inv(A, inv);
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+      if (idx[i] < 0) continue;
+      const double* cpt = t->xyz_h.data() + 3 * (size_t)idx[i];
+      const double* tt = xyz_r + 3 * (start + i);
+      double s[3], nn[3] = {0, 0, 0};
+      s[0] = cpt[0] * A[0] + cpt[1] * A[4] + cpt[2] * A[8] + A[12];
+      s[1] = cpt[0] * A[1] + cpt[1] * A[5] + cpt[2] * A[9] + A[13];
+      s[2] = cpt[0] * A[2] + cpt[1] * A[6] + cpt[2] * A[10] + A[14];
+      if (normal_r && (pmode != 0 || (want & TDTK_WANT_NAPX))) {
+        const double* nr = normal_r + 3 * (start + i);
+        const double len = std::sqrt(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+        nn[0] = nr[0] / len; nn[1] = nr[1] / len; nn[2] = nr[2] / len;
+        if (pmode == 1) {
+          const double x = nn[0] * inv[0] + nn[1] * inv[1] + nn[2] * inv[2];
+          const double y = nn[0] * inv[4] + nn[1] * inv[5] + nn[2] * inv[6];
+          const double z = nn[0] * inv[8] + nn[1] * inv[9] + nn[2] * inv[10];
+          nn[0] = x; nn[1] = y; nn[2] = z;
+        }
+        if (pmode == 2) {
+          const double e[3] = {s[0] - tt[0], s[1] - tt[1], s[2] - tt[2]};
+          const double dot = nn[0] * e[0] + nn[1] * e[1] + nn[2] * e[2];
+          s[0] = nn[0] * dot + tt[0]; s[1] = nn[1] * dot + tt[1]; s[2] = nn[2] * dot + tt[2];
+        }
+      }
+      if (p1_out) { p1_out[3 * k] = s[0]; p1_out[3 * k + 1] = s[1]; p1_out[3 * k + 2] = s[2]; }
+      if (p2_out) { p2_out[3 * k] = tt[0]; p2_out[3 * k + 1] = tt[1]; p2_out[3 * k + 2] = tt[2]; }
+      if (pn_out) { pn_out[3 * k] = nn[0]; pn_out[3 * k + 1] = nn[1]; pn_out[3 * k + 2] = nn[2]; }
+      k++;
+    }
+  }
+  return TDTK_OK;
+}
+
+// ---- host-only diagnostics -----------------------------------------------------------------
+int tdtk_host_tree_layout(const double* xyz, size_t M, int bucket_size, int32_t* perm_out, uint64_t stats[4])
+{
+  HostTree H;
+  std::string err;
+  if (!build_tree(xyz, M, bucket_size, H, err)) { set_error(err); return TDTK_EINVAL; }
+  if (perm_out)
+    for (size_t k = 0; k < M; k++) perm_out[k] = H.pts[k].orig;
+  if (stats) { stats[0] = H.n_internal; stats[1] = H.n_leaves; stats[2] = H.max_depth; stats[3] = H.max_leaf_points; }
+  return TDTK_OK;
+}
+int tdtk_host_m4inv(const double in[16], double out[16]) { return m4inv(in, out); }
+void tdtk_host_mmult(const double a[16], const double b[16], double out[16]) { mmult(a, b, out); }
+
+// ---- minimizers / solves ------------------------------------------------------------------
+int tdtk_align(int algo, const tdtk_pair_sums* sums, double alignxf[16], double* rms)
+{
+  if (!sums || !alignxf) { set_error("NULL argument"); return TDTK_EINVAL; }
+  std::string err;
+  int rc = align_from_sums(algo, *sums, alignxf, rms, err);
+  if (rc) set_error(err);
+  return rc;
+}
+
+int tdtk_solve_spd(const double* G, const double* B, int n, double* x)
+{
+  if (!G || !B || !x || n <= 0) { set_error("bad argument"); return TDTK_EINVAL; }
+  std::vector<double> xs(n);
+  if (!solve_spd_dense(n, G, B, xs.data(), 0.00001)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+  std::memcpy(x, xs.data(), sizeof(double) * n);
+  return TDTK_OK;
+}
+
+// ---- icp6D::match -----------------------------------------------------------------------------
+int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
+                   double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm,
+                   tdtk_icp_result* res, double* trace, int trace_cap)
+{
+  if (!model || !model_dalignxf || !data || !prm || !res) { set_error("NULL argument"); return TDTK_EINVAL; }
+  if (prm->max_dist_match2 < 0.0 || prm->max_num_iterations < 0) {
+    set_error("ERROR [ICP6D]: max_dist_match and max_num_iterations have to be >= 0");  // icp6D.cc:67-78
+    return TDTK_EINVAL;
+  }
+  const int algo = prm->algo;
+  if (algo != TDTK_ALGO_QUAT && algo != TDTK_ALGO_SVD && algo != TDTK_ALGO_APX && algo != TDTK_ALGO_NAPX) {
+    set_error("This parallel minimization algorithm is not implemented !!!");  // icp6D.cc:215-218
+    return TDTK_EINVAL;
+  }
+  const int pmode = prm->pairing_mode;
+  if ((pmode != 0 || algo == TDTK_ALGO_NAPX) && !data->nx) { set_error("normals required"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(model->device, &c);
+  if (rc) return rc;
+  std::memset(res, 0, sizeof *res);
+  if (prm->max_num_iterations == 0 || data->N == 0) return TDTK_OK;  // icp6D.cc:112-114
+
+  const unsigned want = (algo == TDTK_ALGO_APX) ? TDTK_WANT_APX : (algo == TDTK_ALGO_NAPX ? TDTK_WANT_NAPX : 0u);
+  double ret = 0.0, prev_ret = 0.0, prev_prev_ret = 0.0;
+  double alignxf[16], pend[16];
+  bool have_pending = false;
+  double nn_total = 0.0;
+  const double t0 = now_ms();
+  int iter = 0;
+  int converged = 0;
+  for (iter = 0; iter < prm->max_num_iterations; iter++) {
+    prev_prev_ret = prev_ret;
+    prev_ret = ret;
+    double acc[ACC_TOTAL], shift[3];
+    // the previous iteration's alignxf is applied to the points inside the search kernel
+    rc = scan_pass(c, model, model_dalignxf, data, pmode, prm->max_dist_match2, want, nullptr,
+                   have_pending ? pend : nullptr, true, acc, shift);
+    if (rc) return rc;
+    have_pending = false;
+    double ms = 0;
+    collect_ms(c, &ms);
+    nn_total += ms;
+    tdtk_pair_sums sums;
+    finish_sums(acc, shift, data->N, want, &sums);
+    res->last_pairs = sums.n;
+    if (sums.n > 3) {  // icp6D.cc:235-243 (serial branch semantics)
+      std::string err;
+      double rms = 0;
+      rc = align_from_sums(algo, sums, alignxf, &rms, err);
+      if (rc == TDTK_ESOLVE) {
+        // the reference prints and keeps going with ret = -1 and the unchanged alignxf buffer
+        ret = -1.0;
+        m4identity(alignxf);
+      } else if (rc) { set_error(err); return rc; }
+      else ret = rms;
+    } else {
+      break;
+    }
+    if (!prm->quiet) {
+      static const char* tag[] = {"", "QUAT", "SVD", "", "", "", "APX", "", "", "", "APX"};
+      std::printf("%s RMS point-to-%s error = %10.7f  using %6llu points\n", tag[algo],
+                  algo == TDTK_ALGO_NAPX ? "plane" : "point", ret, (unsigned long long)sums.n);
+    }
+    if (trace && iter < trace_cap) {
+      double* row = trace + (size_t)iter * 18;
+      row[0] = (double)sums.n; row[1] = ret;
+      std::memcpy(row + 2, alignxf, sizeof alignxf);
+    }
+    res->last_rms = ret;
+    // CurrentScan->transform(alignxf, ...): points lazily (next search or epilogue), matrices now
+    std::memcpy(pend, alignxf, sizeof pend);
+    have_pending = true;
+    if (data_transMat) mmult(alignxf, data_transMat, data_transMat);  // scan.cc:878-898
+    if (data_dalignxf) mmult(alignxf, data_dalignxf, data_dalignxf);
+    if ((std::fabs(ret - prev_ret) < prm->epsilon_icp && std::fabs(ret - prev_prev_ret) < prm->epsilon_icp) ||
+        iter == prm->max_num_iterations - 1) {
+      converged = (iter != prm->max_num_iterations - 1) ? 1 : 0;
+      break;
+    }
+  }
+  if (have_pending) {
+    Mat4 P;
+    std::memcpy(P.m, pend, sizeof P.m);
+    HIPCHK(launch_transform(data->x, data->y, data->z, data->nx, data->ny, data->nz, data->N, P, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  res->iterations = iter;
+  res->converged = converged;
+  res->total_ms = now_ms() - t0;
+  res->nn_ms = nn_total;
+  if (!prm->quiet) std::printf("TIME  %ld   ITER %d\n", (long)res->total_ms, iter);
+  return TDTK_OK;
+}
+
+// ---- lum6DEuler::covarianceEuler -----------------------------------------------------------
+int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_scan* second, double maxd2,
+                  double C[36], double CD[6], uint64_t* m_out, double* ss_out)
+{
+  if (!first || !first_dalignxf || !second || !C || !CD) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(first->device, &c);
+  if (rc) return rc;
+  std::memset(C, 0, 36 * sizeof(double));
+  std::memset(CD, 0, 6 * sizeof(double));
+  if (m_out) *m_out = 0;
+  if (ss_out) *ss_out = 0;
+  if (second->N == 0) return TDTK_OK;
+  double acc[ACC_TOTAL], shift[3];
+  rc = scan_pass(c, first, first_dalignxf, second, 0, maxd2, TDTK_WANT_LUM, nullptr, nullptr, true, acc, shift);
+  if (rc) return rc;
+  collect_ms(c, nullptr);
+  const uint64_t m = (uint64_t)(acc[ACC_N] + 0.5);
+  if (m_out) *m_out = m;
+  if (m <= 2) return TDTK_OK;  // "This case should not occur": zeros (lum6Deuler.cc:234-249)
+  const double* L = acc + ACC_L;
+  const double sx = L[0], sy = L[1], sz = L[2], xpy = L[3], xpz = L[4], ypz = L[5], xy = L[6], xz = L[7], yz = L[8];
+  double MM[36] = {0};
+  auto M = [&](int r, int col) -> double& { return MM[(r - 1) * 6 + (col - 1)]; };  // 1-based like newmat
+  M(1, 1) = M(2, 2) = M(3, 3) = (double)m;
+  M(4, 4) = ypz; M(5, 5) = xpy; M(6, 6) = xpz;
+  M(1, 5) = M(5, 1) = -sy; M(1, 6) = M(6, 1) = sz;
+  M(2, 4) = M(4, 2) = -sz; M(2, 5) = M(5, 2) = sx;
+  M(3, 4) = M(4, 3) = sy;  M(3, 6) = M(6, 3) = -sx;
+  M(4, 5) = M(5, 4) = -xz; M(4, 6) = M(6, 4) = -xy; M(5, 6) = M(6, 5) = -yz;
+  const double* MZ = L + 9;
+  double MMi[36], D[6];
+  if (!invert_dense(6, MM, MMi)) { set_error("singular link matrix"); return TDTK_ESOLVE; }
+  for (int r = 0; r < 6; r++) {
+    double v = 0;
+    for (int k = 0; k < 6; k++) v += MMi[r * 6 + k] * MZ[k];
+    D[r] = v;
+  }
+  // second pass over the same correspondences (kpos is still in the workspace)
+  double acc2[ACC_TOTAL];
+  rc = scan_pass(c, first, first_dalignxf, second, 0, maxd2, TDTK_WANT_LUM, D, nullptr, false, acc2, shift);
+  if (rc) return rc;
+  double ss = acc2[ACC_LSS] / (2.0 * (double)m - 3.0);
+  if (ss_out) *ss_out = ss;
+  if (ss < 0.0000000000001) return TDTK_OK;  // lum6Deuler.cc:215-226: zeros
+  ss = 1.0 / ss;
+  for (int k = 0; k < 36; k++) C[k] = MM[k] * ss;
+  for (int k = 0; k < 6; k++) CD[k] = MZ[k] * ss;
+  return TDTK_OK;
+}
+
+}  // extern "C"

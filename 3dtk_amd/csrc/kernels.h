@@ -1,0 +1,95 @@
+// Kernel argument blocks and launcher prototypes shared by kernels.hip and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tdtk_internal.h"
+
+namespace tdtk {
+
+struct Mat4 {
+  double m[16];
+};
+
+struct TreeDev {
+  const KdNode* nodes;
+  const KdPoint* pts;
+  const LeafEntry* leaf_tab;  // non-null only in table mode
+  const double* node_r;       // FindClosestAlongDir only
+  uint32_t root_ref;
+  uint32_t cb, cmask;
+};
+
+struct SearchArgs {
+  TreeDev T;
+  double *x, *y, *z;     // queries, SoA, spatially sorted; written when has_pending
+  double *nx, *ny, *nz;  // normals / directions (nullable)
+  size_t n;
+  Mat4 pending;  // alignxf to apply in place before searching (ICP loop)
+  Mat4 inv;      // M4inv(Source->dalignxf): world -> tree frame
+  int has_pending, has_inv;
+  double maxd2;
+  int* kpos;    // out: position of the hit in the leaf-ordered point array, or -1
+  double* d2;   // out, nullable
+  double* ovf_m2;  // stack overflow area (nullable when max_depth-1 <= LDS depth)
+  uint32_t* ovf_ref;
+  unsigned long long* counters;  // COUNT instantiation only
+};
+
+// accumulator columns
+enum {
+  ACC_N = 0,
+  ACC_SUM = 1,
+  ACC_SM = 2,    // 3: sum (m - shift)
+  ACC_SD = 5,    // 3: sum (d - shift)
+  ACC_P = 8,     // 9: sum (m - shift)_a (d - shift)_b
+  ACC_DD = 17,   // 6: sum (d - shift)_a (d - shift)_b, upper       [APX]
+  ACC_NA = 23,   // 21: sum v v^T upper, v = [(d-shift) x n ; n]    [NAPX]
+  ACC_NB = 44,   // 6: sum v
+  ACC_NS = 50,   // 1: sum ((p1-p2).n)^2
+  ACC_L = 51,    // 15: lum6DEuler sums                              [LUM]
+  ACC_LSS = 66,  // 1: residual^2 against D (second pass)
+  ACC_TOTAL = 67
+};
+
+struct AccumArgs {
+  TreeDev T;
+  const double *x, *y, *z;
+  const double *nx, *ny, *nz;
+  const int* kpos;
+  size_t n;
+  Mat4 A;    // Source->dalignxf
+  Mat4 inv;  // its inverse (pairing mode 1 keeps the rotated normal)
+  double shift[3];
+  double D[6];
+  int has_D;
+  double* partials;  // [grid][ACC_TOTAL]
+};
+
+struct BinArgs {
+  const double* q;    // [n][3]
+  const double* dir;  // [n][3] nullable
+  size_t n;
+  double lo[3], scale[3];
+  uint32_t* hist;  // 32768
+  uint32_t* cell;  // [n]
+  double *sx, *sy, *sz, *sdx, *sdy, *sdz;
+  int32_t* order;  // sorted position -> original index
+};
+
+uint32_t search_grid(size_t n);
+int search_lds_depth();
+int search_block();
+uint32_t accum_grid(size_t n);
+
+hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool count, hipStream_t s);
+hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pmode, double* d_out,
+                        hipStream_t s);
+hipError_t launch_transform(double* x, double* y, double* z, double* nx, double* ny, double* nz,
+                            size_t n, const Mat4& A, hipStream_t s);
+hipError_t launch_bin(const BinArgs& b, hipStream_t s);
+hipError_t launch_split_soa(const double* q, size_t n, double* x, double* y, double* z, hipStream_t s);
+hipError_t launch_scatter_idx(const int* kpos, const double* d2s, const int32_t* order,
+                              const KdPoint* pts, size_t n, int32_t* idx_out, double* d2_out,
+                              hipStream_t s);
+
+}  // namespace tdtk

@@ -1,0 +1,700 @@
+// lib3dtk_hip.so -- gfx950 kernels of the slam6D correspondence + accumulation hot path.
+//
+// Written for CDNA4 directly (wave64, 256 CUs in 8 XCDs, 160 KB LDS/CU); no CUDA shims, no
+// dual paths.  Everything is fp64 with FMA contraction off (-ffp-contract=off) and the
+// reference's association, because the deliverable is the reference's *indices*, bit for bit.
+//
+// Kernel inventory (DESIGN.md has the roofline of each):
+//   k_search      one lane = one query: near-first DFS over the BFS-flattened tree with an
+//                 explicit per-lane stack in LDS (+ HBM overflow), leaf buckets scanned as
+//                 32-byte records.  Optionally applies the pending ICP transform in place
+//                 first and maps the query into the tree frame.      [hot: ~all the time]
+//   k_search_dir  FindClosestAlongDir variant (bounding-sphere pruning only).
+//   k_accum       streams (query, hit) pairs and reduces the pair sums with wave64
+//                 shuffles -> LDS -> one partial row per workgroup.
+//   k_final       fixed-order reduction of the partial rows (deterministic).
+//   k_transform   Scan::transformReduced on the resident scan.
+//   k_bin_*       counting sort of an unsorted query batch into spatial order.
+//   k_scatter_idx sorted-position hits -> caller-order model indices.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace tdtk {
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+// transform3 (globals.icc:1477-1490): ((x*a0 + y*a4) + z*a8) + a12
+__device__ __forceinline__ void dev_xf3(const Mat4& A, double x, double y, double z, double& ox,
+                                        double& oy, double& oz)
+{
+  ox = x * A.m[0] + y * A.m[4] + z * A.m[8] + A.m[12];
+  oy = x * A.m[1] + y * A.m[5] + z * A.m[9] + A.m[13];
+  oz = x * A.m[2] + y * A.m[6] + z * A.m[10] + A.m[14];
+}
+// in-place transform3 (globals.icc:1454-1463): (x*a0 + y*a4 + z*a8), then + a12
+__device__ __forceinline__ void dev_xf3_inplace(const Mat4& A, double& x, double& y, double& z)
+{
+  const double xn = x * A.m[0] + y * A.m[4] + z * A.m[8];
+  const double yn = x * A.m[1] + y * A.m[5] + z * A.m[9];
+  const double zn = x * A.m[2] + y * A.m[6] + z * A.m[10];
+  x = xn + A.m[12];
+  y = yn + A.m[13];
+  z = zn + A.m[14];
+}
+// transform3normal (globals.icc:1465-1475): multiplies by the transposed rotation block
+__device__ __forceinline__ void dev_xf3normal(const Mat4& A, double& x, double& y, double& z)
+{
+  const double xn = x * A.m[0] + y * A.m[1] + z * A.m[2];
+  const double yn = x * A.m[4] + y * A.m[5] + z * A.m[6];
+  const double zn = x * A.m[8] + y * A.m[9] + z * A.m[10];
+  x = xn; y = yn; z = zn;
+}
+
+// XCD-aware work assignment: workgroup b runs on XCD b % 8 (observed dispatch order, used for
+// speed only).  Giving XCD x the x-th contiguous eighth of the spatially sorted queries keeps
+// each XCD's private 4 MB L2 on one eighth of the leaves instead of all of them.
+__device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t nb)
+{
+  const uint32_t per = nb >> 3;  // nb is a multiple of 8 (launcher guarantees)
+  return (b & 7u) * per + (b >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-lane DFS stack: first SD entries in LDS ([level][lane] so a wave's pushes at one level
+// are bank-conflict free), deeper entries in an HBM overflow area ([level][global lane]).
+// An entry is (far child ref, myd^2); it is only pushed if myd^2 < closest_d2 at push time --
+// closest_d2 never grows, so the reference's test after the near child returns
+// (kdTreeImpl.h:373,378) would fail for every entry we skip.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD>
+struct LaneStack {
+  double* l_m2;    // &lds_m2[0][lane]
+  uint32_t* l_ref; // &lds_ref[0][lane]
+  double* g_m2;    // overflow, may be null when the tree is shallow
+  uint32_t* g_ref;
+  size_t gstride;
+  int sp;
+  __device__ __forceinline__ void push(uint32_t ref, double m2)
+  {
+    if (sp < SD) {
+      l_m2[sp * BLOCK] = m2;
+      l_ref[sp * BLOCK] = ref;
+    } else {
+      g_m2[(size_t)(sp - SD) * gstride] = m2;
+      g_ref[(size_t)(sp - SD) * gstride] = ref;
+    }
+    ++sp;
+  }
+  __device__ __forceinline__ void top(uint32_t& ref, double& m2) const
+  {
+    const int s = sp;
+    if (s < SD) {
+      m2 = l_m2[s * BLOCK];
+      ref = l_ref[s * BLOCK];
+    } else {
+      m2 = g_m2[(size_t)(s - SD) * gstride];
+      ref = g_ref[(size_t)(s - SD) * gstride];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// 1-NN within radius: exact replay of KDTreeImpl::_FindClosest (kdTreeImpl.h:345-383)
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD, bool COUNT>
+__device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, const double qy,
+                                          const double qz, double& best, int& bk,
+                                          LaneStack<BLOCK, SD>& st, unsigned long long* cnt)
+{
+  uint32_t cur = T.root_ref;
+  st.sp = 0;
+  unsigned c_int = 0, c_leaf = 0, c_pts = 0;
+  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+
+  for (;;) {
+    // ---- phase 1: walk internal nodes until this lane holds a leaf (or is finished) ----
+    while (!(cur & REF_LEAF)) {
+      const double4 n0 = nodes[(size_t)cur * 2];      // cx cy cz hx
+      const double4 n1 = nodes[(size_t)cur * 2 + 1];  // hy hz splitval {c1,c2}
+      if (COUNT) ++c_int;
+      const double ax = fabs(qx - n0.x) - n0.w;
+      const double ay = fabs(qy - n0.y) - n1.x;
+      const double az = fabs(qz - n0.z) - n1.y;
+      const double ab = (ax < ay) ? ay : ax;  // std::max(ax, ay)
+      const double ap = (ab < az) ? az : ab;
+      uint32_t next = REF_DONE;
+      bool need_pop = false;
+      if (ap >= 0.0 && ap * ap >= best) {  // kdTreeImpl.h:362-368
+        need_pop = true;
+      } else {
+        const uint32_t c1 = (uint32_t)__double2loint(n1.w);
+        const uint32_t c2 = (uint32_t)__double2hiint(n1.w);
+        const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
+        const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
+        const double myd = n1.z - qa;  // splitval - p[axis]
+        const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
+        const bool first = (myd >= 0.0);
+        next = first ? r1 : r2;
+        const uint32_t far = first ? r2 : r1;
+        const double m2 = myd * myd;
+        if (m2 < best) st.push(far, m2);
+      }
+      if (need_pop) {
+        next = REF_DONE;
+        while (st.sp > 0) {
+          --st.sp;
+          uint32_t r; double m2;
+          st.top(r, m2);
+          if (m2 < best) { next = r; break; }
+        }
+      }
+      cur = next;
+    }
+    if (cur == REF_DONE) break;
+
+    // ---- phase 2: scan the leaf bucket in stored order, strict '<' (kdTreeImpl.h:351-357)
+    {
+      const uint32_t v = cur & REF_VAL;
+      int start, count;
+      if (T.leaf_tab) {
+        const LeafEntry le = T.leaf_tab[v];
+        start = le.start; count = le.count;
+      } else {
+        start = (int)(v >> T.cb);
+        count = (int)(v & T.cmask);
+      }
+      if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
+      const double4* __restrict__ P = pts + start;
+      int i = 0;
+      for (; i + 4 <= count; i += 4) {
+        const double4 p0 = P[i], p1 = P[i + 1], p2 = P[i + 2], p3 = P[i + 3];
+        double dx, dy, dz;
+        dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
+        const double d0 = dx * dx + dy * dy + dz * dz;
+        dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
+        const double d1 = dx * dx + dy * dy + dz * dz;
+        dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
+        const double d3 = dx * dx + dy * dy + dz * dz;
+        if (d0 < best) { best = d0; bk = start + i; }
+        if (d1 < best) { best = d1; bk = start + i + 1; }
+        if (d2 < best) { best = d2; bk = start + i + 2; }
+        if (d3 < best) { best = d3; bk = start + i + 3; }
+      }
+      for (; i < count; i++) {
+        const double4 p = P[i];
+        const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; bk = start + i; }
+      }
+    }
+    // pop the next pending far child that still passes sqr(myd) < closest_d2
+    cur = REF_DONE;
+    while (st.sp > 0) {
+      --st.sp;
+      uint32_t r; double m2;
+      st.top(r, m2);
+      if (m2 < best) { cur = r; break; }
+    }
+    if (cur == REF_DONE) break;
+  }
+  if (COUNT && cnt) {
+    atomicAdd(&cnt[0], (unsigned long long)c_int);
+    atomicAdd(&cnt[1], (unsigned long long)c_leaf);
+    atomicAdd(&cnt[2], (unsigned long long)c_pts);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// nearest point to a line: exact replay of _FindClosestAlongDir (kdTreeImpl.h:390-425).
+// No split-plane pruning in the reference: both children are always visited, near side first.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD>
+__device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx, const double qy,
+                                              const double qz, const double ux, const double uy,
+                                              const double uz, double& best, int& bk,
+                                              LaneStack<BLOCK, SD>& st)
+{
+  uint32_t cur = T.root_ref;
+  st.sp = 0;
+  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+  for (;;) {
+    while (!(cur & REF_LEAF)) {
+      const double4 n0 = nodes[(size_t)cur * 2];
+      const double4 n1 = nodes[(size_t)cur * 2 + 1];
+      const double r = T.node_r[cur];
+      const double vx = qx - n0.x, vy = qy - n0.y, vz = qz - n0.z;
+      const double len2 = vx * vx + vy * vy + vz * vz;
+      const double dot = vx * ux + vy * uy + vz * uz;
+      const double d2c = len2 - dot * dot;
+      const double lim = r + __dsqrt_rn(best);
+      uint32_t next = REF_DONE;
+      if (d2c > lim * lim) {
+        if (st.sp > 0) { --st.sp; double m2; st.top(next, m2); }
+      } else {
+        const uint32_t c1 = (uint32_t)__double2loint(n1.w);
+        const uint32_t c2 = (uint32_t)__double2hiint(n1.w);
+        const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
+        const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
+        const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
+        const bool first = (qa < n1.z);  // p[axis] < splitval -> child1 first
+        next = first ? r1 : r2;
+        st.push(first ? r2 : r1, 0.0);
+      }
+      cur = next;
+    }
+    if (cur == REF_DONE) break;
+    {
+      const uint32_t v = cur & REF_VAL;
+      int start, count;
+      if (T.leaf_tab) {
+        const LeafEntry le = T.leaf_tab[v];
+        start = le.start; count = le.count;
+      } else {
+        start = (int)(v >> T.cb);
+        count = (int)(v & T.cmask);
+      }
+      const double4* __restrict__ P = pts + start;
+      for (int i = 0; i < count; i++) {
+        const double4 p = P[i];
+        const double vx = qx - p.x, vy = qy - p.y, vz = qz - p.z;
+        const double len2 = vx * vx + vy * vy + vz * vz;
+        const double dot = vx * ux + vy * uy + vz * uz;
+        const double d = len2 - dot * dot;
+        if (d < best) { best = d; bk = start + i; }
+      }
+    }
+    cur = REF_DONE;
+    if (st.sp > 0) { --st.sp; double m2; st.top(cur, m2); }
+    if (cur == REF_DONE) break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_search: the hot kernel
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD, bool COUNT, int DIRMODE>
+__global__ void __launch_bounds__(BLOCK) k_search(const SearchArgs a)
+{
+  __shared__ double lds_m2[SD][BLOCK];
+  __shared__ uint32_t lds_ref[SD][BLOCK];
+
+  const uint32_t nb = gridDim.x;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
+  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;  // for the overflow slot only
+
+  LaneStack<BLOCK, SD> st;
+  st.l_m2 = &lds_m2[0][threadIdx.x];
+  st.l_ref = &lds_ref[0][threadIdx.x];
+  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
+  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
+  st.gstride = (size_t)nb * BLOCK;
+  st.sp = 0;
+
+  // each workgroup owns a contiguous slab of the sorted queries and walks it BLOCK at a time
+  const size_t per = (a.n + nb - 1) / nb;
+  const size_t lo = (size_t)chunk * per;
+  size_t hi = lo + per;
+  if (hi > a.n) hi = a.n;
+
+  for (size_t base = lo; base < hi; base += BLOCK) {
+    const size_t i = base + threadIdx.x;
+    if (i >= hi) continue;
+    double tx = a.x[i], ty = a.y[i], tz = a.z[i];
+    double ux = 0, uy = 0, uz = 0;
+    if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
+      dev_xf3_inplace(a.pending, tx, ty, tz);
+      a.x[i] = tx; a.y[i] = ty; a.z[i] = tz;
+      if (a.nx) {
+        double px = a.nx[i], py = a.ny[i], pz = a.nz[i];
+        dev_xf3normal(a.pending, px, py, pz);
+        a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
+      }
+    }
+    double sx = tx, sy = ty, sz = tz;
+    if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, sx, sy, sz);  // searchTree.cc:122
+    if (DIRMODE) {
+      ux = a.nx[i]; uy = a.ny[i]; uz = a.nz[i];
+      if (DIRMODE == 2) {  // raw directions supplied by the caller (FindClosestAlongDir API)
+      } else {             // searchTree.cc:126-135: Normalize3 then rotate into the tree frame
+        const double len = __dsqrt_rn(ux * ux + uy * uy + uz * uz);
+        ux /= len; uy /= len; uz /= len;
+        if (a.has_inv) dev_xf3normal(a.inv, ux, uy, uz);
+      }
+    }
+    double best = a.maxd2;
+    int bk = -1;
+    if (DIRMODE) kd_search_dir<BLOCK, SD>(a.T, sx, sy, sz, ux, uy, uz, best, bk, st);
+    else kd_search<BLOCK, SD, COUNT>(a.T, sx, sy, sz, best, bk, st, a.counters);
+    a.kpos[i] = bk;
+    if (a.d2) a.d2[i] = best;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pair-sum accumulation
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+  return v;
+}
+
+// acc layout (doubles): see kernels.h ACC_*
+template <int BLOCK, unsigned WANT, int PMODE>
+__global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
+{
+  constexpr int NW = BLOCK / WAVE;
+  __shared__ double red[NW][ACC_TOTAL];
+
+  double acc[ACC_TOTAL];
+#pragma unroll
+  for (int k = 0; k < ACC_TOTAL; k++) acc[k] = 0.0;
+
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(a.T.pts);
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += stride) {
+    const int k = a.kpos[i];
+    if (k < 0) continue;
+    const double tx = a.x[i], ty = a.y[i], tz = a.z[i];
+    const double4 c = pts[k];
+    double mx, my, mz;
+    dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);  // searchTree.cc:147
+    double nxv = 0, nyv = 0, nzv = 0;
+    if (PMODE != 0 || (WANT & TDTK_WANT_NAPX)) {
+      nxv = a.nx[i]; nyv = a.ny[i]; nzv = a.nz[i];
+      const double len = __dsqrt_rn(nxv * nxv + nyv * nyv + nzv * nzv);
+      nxv /= len; nyv /= len; nzv /= len;
+      if (PMODE == 1) dev_xf3normal(a.inv, nxv, nyv, nzv);  // the reference keeps the rotated one
+    }
+    if (PMODE == 2) {  // searchTree.cc:149-162: project the hit onto the data point's plane
+      const double ex = mx - tx, ey = my - ty, ez = mz - tz;
+      const double dot = nxv * ex + nyv * ey + nzv * ez;
+      mx = nxv * dot + tx; my = nyv * dot + ty; mz = nzv * dot + tz;
+    }
+    const double px = mx - tx, py = my - ty, pz = mz - tz;  // p1 - p2
+    acc[ACC_N] += 1.0;
+    acc[ACC_SUM] += px * px + py * py + pz * pz;
+    const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
+    const double d0 = tx - a.shift[0], d1 = ty - a.shift[1], d2 = tz - a.shift[2];
+    acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
+    acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
+    acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
+    acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
+    acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+    if (WANT & TDTK_WANT_APX) {
+      acc[ACC_DD + 0] += d0 * d0; acc[ACC_DD + 1] += d0 * d1; acc[ACC_DD + 2] += d0 * d2;
+      acc[ACC_DD + 3] += d1 * d1; acc[ACC_DD + 4] += d1 * d2; acc[ACC_DD + 5] += d2 * d2;
+    }
+    if (WANT & TDTK_WANT_NAPX) {
+      // v = [ (d - shift) x n ; n ],  A0 += v v^T (upper), B0 += v, sum += ((p1-p2).n)^2
+      double v[6];
+      v[0] = d1 * nzv - d2 * nyv;
+      v[1] = d2 * nxv - d0 * nzv;
+      v[2] = d0 * nyv - d1 * nxv;
+      v[3] = nxv; v[4] = nyv; v[5] = nzv;
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int s = r; s < 6; s++) acc[ACC_NA + (q++)] += v[r] * v[s];
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[ACC_NB + r] += v[r];
+      const double dd = px * nxv + py * nyv + pz * nzv;
+      acc[ACC_NS] += dd * dd;
+    }
+    if (WANT & TDTK_WANT_LUM) {
+      // lum6Deuler.cc:143-175, ak = p1 (model, world), bk = p2 (data)
+      const double x = (mx + tx) / 2.0, y = (my + ty) / 2.0, z = (mz + tz) / 2.0;
+      const double dx = mx - tx, dy = my - ty, dz = mz - tz;
+      acc[ACC_L + 0] += x; acc[ACC_L + 1] += y; acc[ACC_L + 2] += z;
+      acc[ACC_L + 3] += x * x + y * y;
+      acc[ACC_L + 4] += x * x + z * z;
+      acc[ACC_L + 5] += y * y + z * z;
+      acc[ACC_L + 6] += x * y; acc[ACC_L + 7] += x * z; acc[ACC_L + 8] += y * z;
+      acc[ACC_L + 9] += dx; acc[ACC_L + 10] += dy; acc[ACC_L + 11] += dz;
+      acc[ACC_L + 12] += -z * dy + y * dz;
+      acc[ACC_L + 13] += -y * dx + x * dy;
+      acc[ACC_L + 14] += z * dx - x * dz;
+      if (a.has_D) {  // second pass: residual against the solved D (lum6Deuler.cc:199-210)
+        const double e0 = dx - (a.D[0] - y * a.D[4] + z * a.D[5]);
+        const double e1 = dy - (a.D[1] - z * a.D[3] + x * a.D[4]);
+        const double e2 = dz - (a.D[2] + y * a.D[3] - x * a.D[5]);
+        acc[ACC_LSS] += e0 * e0 + e1 * e1 + e2 * e2;
+      }
+    }
+  }
+
+  // wave64 shuffle reduction, then across the block's waves through LDS
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+#pragma unroll
+  for (int k = 0; k < ACC_TOTAL; k++) {
+    const bool used = (k < ACC_DD) || ((WANT & TDTK_WANT_APX) && k >= ACC_DD && k < ACC_NA) ||
+                      ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
+                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L);
+    if (!used) continue;
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
+    const bool used = (k < ACC_DD) || ((WANT & TDTK_WANT_APX) && k >= ACC_DD && k < ACC_NA) ||
+                      ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
+                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L);
+    double s = 0.0;
+    if (used)
+      for (int w = 0; w < NW; w++) s += red[w][k];
+    a.partials[(size_t)blockIdx.x * ACC_TOTAL + k] = s;
+  }
+}
+
+// fixed-order reduction of the per-workgroup rows: one thread per accumulator column
+__global__ void k_final(const double* __restrict__ partials, int rows, double* __restrict__ out)
+{
+  const int k = threadIdx.x;
+  if (k >= ACC_TOTAL) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; r++) s += partials[(size_t)r * ACC_TOTAL + k];
+  out[k] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// resident-scan transform (Scan::transformReduced, scan.cc:851-875)
+// ------------------------------------------------------------------------------------------
+__global__ void k_transform(double* __restrict__ x, double* __restrict__ y, double* __restrict__ z,
+                            double* __restrict__ nx, double* __restrict__ ny,
+                            double* __restrict__ nz, size_t n, const Mat4 A)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double px = x[i], py = y[i], pz = z[i];
+    dev_xf3_inplace(A, px, py, pz);
+    x[i] = px; y[i] = py; z[i] = pz;
+    if (nx) {
+      double ax = nx[i], ay = ny[i], az = nz[i];
+      dev_xf3normal(A, ax, ay, az);
+      nx[i] = ax; ny[i] = ay; nz[i] = az;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// spatial binning of an unsorted device-resident query batch (counting sort on a 32^3 grid
+// over the tree's root box, cells visited in Morton order).  Order inside a cell is arbitrary:
+// every query is independent and results are written back by original index.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread5(uint32_t v)
+{
+  // 5 bits -> every third bit
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6) | ((v & 16u) << 8);
+}
+__device__ __forceinline__ uint32_t cell_of(const BinArgs& b, double x, double y, double z)
+{
+  double fx = (x - b.lo[0]) * b.scale[0], fy = (y - b.lo[1]) * b.scale[1], fz = (z - b.lo[2]) * b.scale[2];
+  fx = fmin(fmax(fx, 0.0), 31.0); fy = fmin(fmax(fy, 0.0), 31.0); fz = fmin(fmax(fz, 0.0), 31.0);
+  return spread5((uint32_t)fx) | (spread5((uint32_t)fy) << 1) | (spread5((uint32_t)fz) << 2);
+}
+__global__ void k_bin_count(const BinArgs b)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
+    const uint32_t c = cell_of(b, b.q[3 * i], b.q[3 * i + 1], b.q[3 * i + 2]);
+    b.cell[i] = c;
+    atomicAdd(&b.hist[c], 1u);
+  }
+}
+// exclusive scan of the 32768 counters by one 1024-thread workgroup (32 per thread)
+__global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* __restrict__ hist)
+{
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  uint32_t loc[32];
+  uint32_t s = 0;
+  for (int k = 0; k < 32; k++) { loc[k] = s; s += hist[t * 32 + k]; }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = (t >= off) ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const uint32_t base = (t == 0) ? 0u : part[t - 1];
+  for (int k = 0; k < 32; k++) hist[t * 32 + k] = base + loc[k];
+}
+__global__ void k_bin_scatter(const BinArgs b)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
+    const uint32_t pos = atomicAdd(&b.hist[b.cell[i]], 1u);
+    b.sx[pos] = b.q[3 * i]; b.sy[pos] = b.q[3 * i + 1]; b.sz[pos] = b.q[3 * i + 2];
+    if (b.dir) { b.sdx[pos] = b.dir[3 * i]; b.sdy[pos] = b.dir[3 * i + 1]; b.sdz[pos] = b.dir[3 * i + 2]; }
+    b.order[pos] = (int32_t)i;
+  }
+}
+// AoS -> SoA without reordering (presorted batches)
+__global__ void k_split_soa(const double* __restrict__ q, size_t n, double* __restrict__ x,
+                            double* __restrict__ y, double* __restrict__ z)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    x[i] = q[3 * i]; y[i] = q[3 * i + 1]; z[i] = q[3 * i + 2];
+  }
+}
+
+// sorted-position hit -> caller-order model index (+ distance)
+__global__ void k_scatter_idx(const int* __restrict__ kpos, const double* __restrict__ d2s,
+                              const int32_t* __restrict__ order, const KdPoint* __restrict__ pts,
+                              size_t n, int32_t* __restrict__ idx_out, double* __restrict__ d2_out)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const int k = kpos[j];
+    const size_t dst = order ? (size_t)order[j] : j;
+    if (idx_out) idx_out[dst] = (k >= 0) ? pts[k].orig : -1;
+    if (d2_out) d2_out[dst] = d2s[j];
+  }
+}
+
+// compact pair list in caller order is produced on the host from idx (cheap, optional path)
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int g_num_cu = 0;
+static int num_cu()
+{
+  if (!g_num_cu) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cu = p.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+constexpr int SEARCH_BLOCK = 256;
+constexpr int SEARCH_SD = 8;
+
+uint32_t search_grid(size_t n)
+{
+  // slabs of the sorted queries: enough workgroups to fill 256 CUs several times over so the
+  // tail is short, multiple of 8 for the XCD mapping, never more than one slab per 256 queries
+  size_t want = (n + SEARCH_BLOCK - 1) / SEARCH_BLOCK;
+  size_t cap = (size_t)num_cu() * 16;
+  size_t nb = want < cap ? want : cap;
+  nb = (nb + 7) & ~(size_t)7;
+  if (nb < 8) nb = 8;
+  return (uint32_t)nb;
+}
+int search_lds_depth() { return SEARCH_SD; }
+int search_block() { return SEARCH_BLOCK; }
+
+hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool count, hipStream_t s)
+{
+  if (a.n == 0) return hipSuccess;
+  dim3 g(grid), b(SEARCH_BLOCK);
+  if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, false, 1>), g, b, 0, s, a);
+  else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, false, 2>), g, b, 0, s, a);
+  else if (count) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, true, 0>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, false, 0>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+constexpr int ACC_BLOCK = 256;
+uint32_t accum_grid(size_t n)
+{
+  size_t want = (n + ACC_BLOCK - 1) / ACC_BLOCK;
+  size_t cap = (size_t)num_cu() * 4;
+  size_t nb = want < cap ? want : cap;
+  return (uint32_t)(nb ? nb : 1);
+}
+
+template <unsigned WANT>
+static void launch_accum_w(const AccumArgs& a, uint32_t grid, int pmode, hipStream_t s)
+{
+  dim3 g(grid), b(ACC_BLOCK);
+  if (pmode == 0) hipLaunchKernelGGL((k_accum<ACC_BLOCK, WANT, 0>), g, b, 0, s, a);
+  else if (pmode == 1) hipLaunchKernelGGL((k_accum<ACC_BLOCK, WANT, 1>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_accum<ACC_BLOCK, WANT, 2>), g, b, 0, s, a);
+}
+
+hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pmode, double* d_out,
+                        hipStream_t s)
+{
+  switch (want & 7u) {
+    case 0: launch_accum_w<0>(a, grid, pmode, s); break;
+    case 1: launch_accum_w<1>(a, grid, pmode, s); break;
+    case 2: launch_accum_w<2>(a, grid, pmode, s); break;
+    case 3: launch_accum_w<3>(a, grid, pmode, s); break;
+    case 4: launch_accum_w<4>(a, grid, pmode, s); break;
+    case 5: launch_accum_w<5>(a, grid, pmode, s); break;
+    case 6: launch_accum_w<6>(a, grid, pmode, s); break;
+    default: launch_accum_w<7>(a, grid, pmode, s); break;
+  }
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(128), 0, s, a.partials, (int)grid, d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform(double* x, double* y, double* z, double* nx, double* ny, double* nz,
+                            size_t n, const Mat4& A, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  size_t cap = (size_t)num_cu() * 8;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(k_transform, dim3((uint32_t)nb), dim3(256), 0, s, x, y, z, nx, ny, nz, n, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_bin(const BinArgs& b, hipStream_t s)
+{
+  if (!b.n) return hipSuccess;
+  size_t nb = (b.n + 255) / 256;
+  size_t cap = (size_t)num_cu() * 8;
+  if (nb > cap) nb = cap;
+  hipError_t e = hipMemsetAsync(b.hist, 0, 32768 * sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bin_count, dim3((uint32_t)nb), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, b.hist);
+  hipLaunchKernelGGL(k_bin_scatter, dim3((uint32_t)nb), dim3(256), 0, s, b);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_soa(const double* q, size_t n, double* x, double* y, double* z, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  size_t cap = (size_t)num_cu() * 8;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(k_split_soa, dim3((uint32_t)nb), dim3(256), 0, s, q, n, x, y, z);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_idx(const int* kpos, const double* d2s, const int32_t* order,
+                              const KdPoint* pts, size_t n, int32_t* idx_out, double* d2_out,
+                              hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  size_t cap = (size_t)num_cu() * 8;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(k_scatter_idx, dim3((uint32_t)nb), dim3(256), 0, s, kpos, d2s, order, pts, n,
+                     idx_out, d2_out);
+  return hipGetLastError();
+}
+
+}  // namespace tdtk

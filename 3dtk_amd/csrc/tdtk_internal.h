@@ -1,0 +1,78 @@
+// Internal structures of lib3dtk_hip.so (not part of the C ABI).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "tdtk_hip.h"
+
+namespace tdtk {
+
+// ---- flattened kd-tree, breadth-first -------------------------------------------------
+// One 64-byte record per INTERNAL node (two per 128-byte cache line).  Leaves have no
+// record: a child reference that points to a leaf carries (start,count) of the leaf's run
+// in the permuted point array, so visiting a leaf costs no dependent node load.
+//
+// child reference (32 bit):  bit31 = leaf flag, bit30 = one bit of the split axis
+// (c1 carries axis bit 0, c2 carries axis bit 1), bits[29:0] = value.
+//   internal: value = index of the node record
+//   leaf    : value = (start << cb) | count          (packed mode, cb = count bits)
+//             value = leaf id into leaf_tab[]        (table mode, when it does not fit)
+struct alignas(64) KdNode {
+  double cx, cy, cz;  // box centre      node.center   (kdTreeImpl.h:128-130)
+  double hx, hy, hz;  // half extents    node.dx/dy/dz (kdTreeImpl.h:132-134)
+  double splitval;    //                 node.splitval (kdTreeImpl.h:170)
+  uint32_t c1, c2;    // child refs      node.child1/child2
+};
+static_assert(sizeof(KdNode) == 64, "KdNode must be 64 bytes");
+
+// model point in leaf order (the reference's post-partition pointer order), 32 bytes so a
+// 128-byte line holds exactly four points and a point never straddles lines.
+struct alignas(32) KdPoint {
+  double x, y, z;
+  int32_t orig;  // index into the caller's xyz
+  int32_t pad;
+};
+static_assert(sizeof(KdPoint) == 32, "KdPoint must be 32 bytes");
+
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_AXIS = 0x40000000u;
+constexpr uint32_t REF_VAL = 0x3FFFFFFFu;
+constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+
+struct LeafEntry {
+  int32_t start, count;
+};
+
+struct HostTree {
+  std::vector<KdNode> nodes;
+  std::vector<double> node_r;  // bounding-sphere radius per node (FindClosestAlongDir)
+  std::vector<KdPoint> pts;    // leaf order
+  std::vector<LeafEntry> leaf_tab;  // always filled (table mode uses it on the device)
+  uint32_t root_ref = 0;
+  int cb = 0;              // count bits in packed leaf refs
+  bool table_mode = false; // leaf refs index leaf_tab
+  double bbmin[3], bbmax[3];
+  uint64_t n_internal = 0, n_leaves = 0;
+  uint32_t max_depth = 0, max_leaf_points = 0;
+};
+
+// Builds the identical tree to KDTreeImpl::create (kdTreeImpl.h:82-201).  Returns false on
+// M == 0 (the reference throws).  threads <= 1 builds serially.
+bool build_tree(const double* xyz, size_t M, int bucket, HostTree& out, std::string& err);
+
+// ---- host 4x4 helpers (bit-exact restatements of globals.icc formulas) -----------------
+int m4inv(const double* Min, double* Mout);                      // globals.icc:762-785
+void mmult(const double* M1, const double* M2, double* Mout);    // globals.icc:298-328
+void m4identity(double* M);
+
+// ---- minimizers ------------------------------------------------------------------------
+int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], double* rms,
+                    std::string& err);
+bool invert_dense(int n, const double* A, double* Ainv);  // LU with partial pivoting
+bool solve_spd_dense(int n, const double* G, const double* B, double* x, double drop);
+
+void set_error(const std::string& s);
+
+}  // namespace tdtk

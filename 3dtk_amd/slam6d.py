@@ -1,0 +1,471 @@
+"""Host-side mirror of the reference's slam6d interface for the ICP hot path.
+
+Same class / method names and argument meaning as the reference (file:line cited per
+item); the bodies only marshal numpy arrays into the C ABI of lib3dtk_hip.so.  Nothing
+here computes correspondences or sums on the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import (lib, check, dptr, iptr, f64, PairSums, IcpParams, IcpResult, TreeInfo,
+                    ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX, WANT_APX, WANT_NAPX, WANT_LUM)
+
+
+# ---------------------------------------------------------------------------------------
+# include/slam6d/globals.icc helpers
+# ---------------------------------------------------------------------------------------
+def M4identity():
+    return np.eye(4).reshape(16).copy()
+
+
+def M4inv(M):
+    """globals.icc:762-785 (bit-exact host restatement inside the library)."""
+    M = f64(M, 16)
+    out = np.empty(16)
+    lib().tdtk_host_m4inv(dptr(M), dptr(out))
+    return out
+
+
+def MMult(M1, M2):
+    """globals.icc:298-328, column-major M1*M2."""
+    M1 = f64(M1, 16); M2 = f64(M2, 16)
+    out = np.empty(16)
+    lib().tdtk_host_mmult(dptr(M1), dptr(M2), dptr(out))
+    return out
+
+
+def EulerToMatrix4(rPos, rPosTheta):
+    """globals.icc:501-531."""
+    sx, cx = math.sin(rPosTheta[0]), math.cos(rPosTheta[0])
+    sy, cy = math.sin(rPosTheta[1]), math.cos(rPosTheta[1])
+    sz, cz = math.sin(rPosTheta[2]), math.cos(rPosTheta[2])
+    a = np.zeros(16)
+    a[0] = cy * cz
+    a[1] = sx * sy * cz + cx * sz
+    a[2] = -cx * sy * cz + sx * sz
+    a[4] = -cy * sz
+    a[5] = -sx * sy * sz + cx * cz
+    a[6] = cx * sy * sz + sx * cz
+    a[8] = sy
+    a[9] = -sx * cy
+    a[10] = cx * cy
+    a[12], a[13], a[14] = rPos[0], rPos[1], rPos[2]
+    a[15] = 1
+    return a
+
+
+def Matrix4ToEuler(alignxf):
+    """globals.icc:541-576.  Returns (rPosTheta, rPos)."""
+    th = [0.0, 0.0, 0.0]
+    if alignxf[0] > 0.0:
+        th[1] = math.asin(alignxf[8])
+    else:
+        th[1] = math.pi - math.asin(alignxf[8])
+    Cc = math.cos(th[1])
+    if abs(Cc) > 0.005:
+        th[0] = math.atan2(-alignxf[9] / Cc, alignxf[10] / Cc)
+        th[2] = math.atan2(-alignxf[4] / Cc, alignxf[0] / Cc)
+    else:
+        th[0] = 0.0
+        th[2] = math.atan2(alignxf[1], alignxf[5])
+    return np.array(th), np.array([alignxf[12], alignxf[13], alignxf[14]])
+
+
+def host_tree_layout(xyz, bucketSize=20):
+    """Host tree builder only (no device): leaf-order permutation + stats."""
+    xyz = f64(xyz).reshape(-1, 3)
+    perm = np.empty(len(xyz), np.int32)
+    st = (C.c_uint64 * 4)()
+    check(lib().tdtk_host_tree_layout(dptr(xyz), len(xyz), int(bucketSize), iptr(perm), st))
+    return perm, dict(internal=st[0], leaves=st[1], depth=st[2], max_leaf=st[3])
+
+
+def _sums_dict(s):
+    return dict(n_queries=int(s.n_queries), n=int(s.n), sum=s.sum,
+                centroid_m=np.array(s.centroid_m), centroid_d=np.array(s.centroid_d),
+                Si=np.array(s.Si), apx_A=np.array(s.apx_A), apx_B=np.array(s.apx_B),
+                napx_A=np.array(s.napx_A), napx_B=np.array(s.napx_B), napx_sum=s.napx_sum,
+                lum=np.array(s.lum), lum_sumd2=s.lum_sumd2)
+
+
+# ---------------------------------------------------------------------------------------
+# KDtree : SearchTree   (include/slam6d/kd.h, src/slam6d/kd.cc, searchTree.cc)
+# ---------------------------------------------------------------------------------------
+class KDtree:
+    """KDtree(pts, n, bucketSize) (kd.cc:46-49).  pts is copied and uploaded."""
+
+    def __init__(self, pts, bucketSize=20, device=0):
+        pts = f64(pts).reshape(-1, 3)
+        if len(pts) == 0:
+            raise RuntimeError("cannot create kdtree with zero points")  # kdTreeImpl.h:86-88
+        self.n = len(pts)
+        self.device = device
+        h = C.c_void_p()
+        check(lib().tdtk_tree_create(dptr(pts), len(pts), int(bucketSize), int(device), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().tdtk_tree_destroy(h)
+            self._h = None
+
+    def info(self):
+        ti = TreeInfo()
+        check(lib().tdtk_tree_get_info(self._h, C.byref(ti)))
+        return {k: getattr(ti, k) for k, _ in TreeInfo._fields_}
+
+    def FindClosest(self, p, maxdist2, threadNum=0):
+        """kd.cc:78-87.  Returns the index of the closest point or None (reference: NULL)."""
+        idx, _ = self.FindClosestBatch(np.asarray(p, dtype=np.float64).reshape(1, 3), maxdist2)
+        return None if idx[0] < 0 else int(idx[0])
+
+    def FindClosestBatch(self, q, maxdist2):
+        q = f64(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        check(lib().tdtk_find_closest(self._h, dptr(q), len(q), float(maxdist2), iptr(idx), dptr(d2)))
+        return idx, d2
+
+    def FindClosestAlongDir(self, p, direction, maxdist2, threadNum=0):
+        """kd.cc:89-100."""
+        idx, _ = self.FindClosestAlongDirBatch(np.asarray(p, float).reshape(1, 3),
+                                               np.asarray(direction, float).reshape(1, 3), maxdist2)
+        return None if idx[0] < 0 else int(idx[0])
+
+    def FindClosestAlongDirBatch(self, q, dirs, maxdist2):
+        q = f64(q).reshape(-1, 3); dirs = f64(dirs).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        check(lib().tdtk_find_closest_along_dir(self._h, dptr(q), dptr(dirs), len(q), float(maxdist2),
+                                                iptr(idx), dptr(d2)))
+        return idx, d2
+
+    def count_visits(self, q, maxdist2):
+        q = f64(q).reshape(-1, 3)
+        cnt = (C.c_uint64 * 3)()
+        check(lib().tdtk_count_visits(self._h, dptr(q), len(q), float(maxdist2), cnt))
+        return int(cnt[0]), int(cnt[1]), int(cnt[2])
+
+    def getPtPairs(self, source_alignxf, xyz_r, normal_r=None, startindex=0, endindex=None,
+                   thread_num=0, rnd=0, max_dist_match2=625.0, pairing_mode=0, want=0, lum_D=None,
+                   want_pairs=True):
+        """SearchTree::getPtPairs, DataXYZ overload (searchTree.cc:92-189).  Returns a dict with
+        idx, the compact pair list p1/p2/pn and the merged sums (see tdtk_pair_sums)."""
+        xyz_r = f64(xyz_r).reshape(-1, 3)
+        endindex = len(xyz_r) if endindex is None else endindex
+        n = endindex - startindex
+        A = f64(source_alignxf, 16)
+        nr = f64(normal_r).reshape(-1, 3) if normal_r is not None else None
+        idx = np.empty(n, np.int32)
+        p1 = np.empty((n, 3)) if want_pairs else None
+        p2 = np.empty((n, 3)) if want_pairs else None
+        pn = np.empty((n, 3)) if want_pairs else None
+        s = PairSums()
+        D = f64(lum_D, 6) if lum_D is not None else None
+        check(lib().tdtk_get_pt_pairs(self._h, dptr(A), dptr(xyz_r), dptr(nr), startindex, endindex,
+                                      int(rnd), int(pairing_mode), float(max_dist_match2), int(want),
+                                      dptr(D), iptr(idx), dptr(p1), dptr(p2), dptr(pn), C.byref(s)))
+        out = _sums_dict(s)
+        out["idx"] = idx
+        out["_raw"] = s
+        if want_pairs:
+            k = out["n"]
+            out["p1"], out["p2"], out["pn"] = p1[:k], p2[:k], pn[:k]
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+# Scan  (include/slam6d/scan.h, src/slam6d/scan.cc, basicScan.cc) -- the 6 functions of the path
+# ---------------------------------------------------------------------------------------
+class Scan:
+    """Resident scan: "xyz reduced original" (host, tree input), "xyz reduced" (device),
+    transMatOrg / transMat / dalignxf (basicScan.cc:175-197, scan.cc:878-898)."""
+
+    allScans = []
+
+    def __init__(self, rPos, rPosTheta, points, normals=None, bucketSize=20, device=0):
+        self.device = device
+        self.bucketSize = bucketSize
+        self.rPos = np.array(rPos, dtype=np.float64)
+        self.rPosTheta = np.array(rPosTheta, dtype=np.float64)
+        self.transMatOrg = EulerToMatrix4(self.rPos, self.rPosTheta)
+        self.transMat = M4identity()
+        self.dalignxf = M4identity()
+        self._transformMatrix(self.transMatOrg)     # basicScan.cc:188
+        self.dalignxf = M4identity()                # basicScan.cc:192
+        pts = f64(points).reshape(-1, 3)
+        self._h = C.c_void_p()
+        nr = f64(normals).reshape(-1, 3) if normals is not None else None
+        check(lib().tdtk_scan_create(dptr(pts), dptr(nr), len(pts), int(device), C.byref(self._h)))
+        self.n = len(pts)
+        # calcReducedOnDemandPrivate (basicScan.cc:730-737): transformReduced(transMatOrg) then
+        # copyReducedToOriginal
+        check(lib().tdtk_scan_transform(self._h, dptr(self.transMatOrg)))
+        self.xyz_reduced_original = self.get_xyz_reduced()
+        self.kd = None
+        self.frames = []  # (transMat copy, type)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().tdtk_scan_destroy(h)
+            self._h = None
+
+    # accessors named as in scan.h
+    def get_transMat(self): return self.transMat
+    def get_transMatOrg(self): return self.transMatOrg
+    def getDAlign(self): return self.dalignxf
+    def get_rPos(self): return self.rPos
+    def get_rPosTheta(self): return self.rPosTheta
+
+    def get_xyz_reduced(self, with_normals=False):
+        out = np.empty((self.n, 3))
+        check(lib().tdtk_scan_download(self._h, dptr(out), None))
+        return out
+
+    def getSearchTree(self):
+        """scan.cc:268-306 -> basicScan.cc:702-728: lazily built over "xyz reduced original"."""
+        if self.kd is None:
+            self.kd = KDtree(self.xyz_reduced_original, self.bucketSize, self.device)
+        return self.kd
+
+    def _transformMatrix(self, alignxf):
+        """Scan::transformMatrix (scan.cc:878-898)."""
+        self.transMat = MMult(alignxf, self.transMat)
+        self.rPosTheta, self.rPos = Matrix4ToEuler(self.transMat)
+        self.dalignxf = MMult(alignxf, self.dalignxf)
+
+    def transform(self, alignxf, type="ICP", islum=0):
+        """Scan::transform (scan.cc:918-1009): transformReduced on the device + matrices."""
+        alignxf = f64(alignxf, 16)
+        check(lib().tdtk_scan_transform(self._h, dptr(alignxf)))
+        self._transformMatrix(alignxf)
+        if type != "INVALID" and islum != -1:
+            self.frames.append((self.transMat.copy(), type))
+
+    def transformToEuler(self, rP, rPT, type="LUM", islum=1):
+        """scan.cc:1061-1083."""
+        tinv = M4inv(self.transMat)
+        self.transform(tinv, "INVALID")
+        self.transform(EulerToMatrix4(rP, rPT), type, islum)
+
+    def mergeCoordinatesWithRoboterPosition(self, prevScan):
+        """scan.cc:826-833 (pose extrapolation)."""
+        tempMat = M4inv(prevScan.get_transMatOrg())
+        deltaMat = MMult(prevScan.get_transMat(), tempMat)
+        self.transform(deltaMat, "INVALID")
+
+    @staticmethod
+    def getPtPairs(Source, Target, thread_num=0, rnd=0, max_dist_match2=625.0, pairing_mode=0,
+                   want=0, lum_D=None, want_idx=False):
+        """Scan::getPtPairs (scan.cc:1220-1260): whole-scan pass, centroids normalised."""
+        if rnd > 1:
+            raise capi.TdtkError(-5, "rnd > 1 is not supported on the device path")
+        s = PairSums()
+        idx = np.empty(Target.n, np.int32) if want_idx else None
+        D = f64(lum_D, 6) if lum_D is not None else None
+        tree = Source.getSearchTree()
+        check(lib().tdtk_scan_pairs(tree._h, dptr(Source.dalignxf), Target._h, int(pairing_mode),
+                                    float(max_dist_match2), int(want), dptr(D), iptr(idx), C.byref(s)))
+        out = _sums_dict(s)
+        out["_raw"] = s
+        if want_idx:
+            out["idx"] = idx
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+# icp6Dminimizer family (include/slam6d/icp6Dminimizer.h:31-88)
+# ---------------------------------------------------------------------------------------
+class icp6Dminimizer:
+    algo = 0
+
+    def __init__(self, quiet=False):
+        self.quiet = quiet
+
+    def getAlgorithmID(self):
+        return self.algo
+
+    def Align_Parallel(self, sums):
+        """Align_Parallel with the merged sums (slot 0 semantics).  Returns (rms, alignxf)."""
+        raw = sums["_raw"] if isinstance(sums, dict) else sums
+        out = np.empty(16)
+        rms = C.c_double(0.0)
+        rc = lib().tdtk_align(int(self.algo), C.byref(raw), dptr(out), C.byref(rms))
+        if rc == -4:       # "Couldn't find transform." -> the reference returns -1.0
+            return -1.0, out
+        check(rc)
+        return rms.value, out
+
+
+class icp6D_QUAT(icp6Dminimizer):   # src/slam6d/icp6Dquat.cc, -a 1
+    algo = ALGO_QUAT
+
+
+class icp6D_SVD(icp6Dminimizer):    # src/slam6d/icp6Dsvd.cc, -a 2
+    algo = ALGO_SVD
+
+
+class icp6D_APX(icp6Dminimizer):    # src/slam6d/icp6Dapx.cc, -a 6
+    algo = ALGO_APX
+
+
+class icp6D_NAPX(icp6Dminimizer):   # src/slam6d/icp6Dnapx.cc, -a 10
+    algo = ALGO_NAPX
+
+
+# ---------------------------------------------------------------------------------------
+# icp6D (include/slam6d/icp6D.h, src/slam6d/icp6D.cc)
+# ---------------------------------------------------------------------------------------
+class icp6D:
+    def __init__(self, my_icp6Dminimizer, max_dist_match=25.0, max_num_iterations=50, quiet=False,
+                 meta=False, rnd=1, eP=True, anim=-1, epsilonICP=0.0000001, nns_method=0):
+        if max_dist_match < 0.0:
+            raise ValueError("ERROR [ICP6D]: first parameter (max_dist_match) has to be >= 0,")
+        if max_num_iterations < 0:
+            raise ValueError("ERROR [ICP6D]: second parameter (max_num_iterations)has to be >= 0.")
+        if rnd > 1:
+            raise capi.TdtkError(-5, "rnd > 1 is not supported on the device path")
+        self.my_icp6Dminimizer = my_icp6Dminimizer
+        self.max_dist_match2 = max_dist_match * max_dist_match
+        self.max_num_iterations = max_num_iterations
+        self.quiet = quiet
+        self.eP = eP
+        self.epsilonICP = epsilonICP
+        self.nr_pointPair = 0
+        self.last = None
+
+    def match(self, PreviousScan, CurrentScan, pairing_mode=0):
+        """icp6D::match (icp6D.cc:104-285).  Returns the number of iterations done."""
+        CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))  # transform(id, ICP, 0)
+        tree = PreviousScan.getSearchTree()
+        prm = IcpParams(int(self.my_icp6Dminimizer.getAlgorithmID()), int(pairing_mode),
+                        int(self.max_num_iterations), float(self.max_dist_match2),
+                        float(self.epsilonICP), 1 if self.quiet else 0)
+        res = IcpResult()
+        cap = max(1, self.max_num_iterations)
+        trace = np.zeros((cap, 18))
+        tm = CurrentScan.transMat.copy()
+        da = CurrentScan.dalignxf.copy()
+        check(lib().tdtk_icp_match(tree._h, dptr(PreviousScan.dalignxf), CurrentScan._h, dptr(tm),
+                                   dptr(da), C.byref(prm), C.byref(res), dptr(trace), cap))
+        CurrentScan.transMat = tm
+        CurrentScan.dalignxf = da
+        CurrentScan.rPosTheta, CurrentScan.rPos = Matrix4ToEuler(tm)
+        CurrentScan.frames.append((tm.copy(), "ICP"))
+        self.nr_pointPair = int(res.last_pairs)
+        nrows = min(cap, res.iterations + 1)
+        self.last = dict(iterations=res.iterations, converged=bool(res.converged),
+                         pairs=int(res.last_pairs), rms=res.last_rms, total_ms=res.total_ms,
+                         nn_ms=res.nn_ms, trace=trace[:nrows].copy())
+        return res.iterations
+
+    def doICP(self, allScans, pairing_mode=0):
+        """icp6D::doICP (icp6D.cc:374-437), non-meta branch."""
+        for i in range(1, len(allScans)):
+            prev, cur = allScans[i - 1], allScans[i]
+            if self.eP:
+                cur.mergeCoordinatesWithRoboterPosition(prev)
+            self.match(prev, cur, pairing_mode)
+
+
+# ---------------------------------------------------------------------------------------
+# Graph (src/slam6d/graph.cc:30-180)
+# ---------------------------------------------------------------------------------------
+class Graph:
+    def __init__(self, nodes=0, cldist2=None, loopsize=None, scans=None, links=None):
+        self.frm, self.to = [], []
+        self.nrScans = nodes
+        if links is not None:
+            for a, b in links:
+                self.frm.append(int(a)); self.to.append(int(b))
+            return
+        for i in range(nodes - 1):                  # graph.cc:115-118
+            self.frm.append(i); self.to.append(i + 1)
+        if cldist2 is not None:                     # graph.cc:121-130
+            for j in range(nodes):
+                for k in range(j + 1, nodes):
+                    d = scans[k].get_rPos() - scans[j].get_rPos()
+                    d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+                    if abs(k - j) > loopsize and d2 < cldist2:
+                        self.frm.append(j); self.to.append(k)
+
+    def getNrScans(self): return self.nrScans
+    def getNrLinks(self): return len(self.frm)
+    def getLink(self, i, fromTo): return self.frm[i] if fromTo == 0 else self.to[i]
+
+
+# ---------------------------------------------------------------------------------------
+# lum6DEuler (src/slam6d/lum6Deuler.cc) -- single-process form; graphslam.py shards links
+# ---------------------------------------------------------------------------------------
+def covarianceEuler(first, second, max_dist_match2):
+    """lum6DEuler::covarianceEuler (lum6Deuler.cc:94-251) -> (C 6x6, CD 6, m, ss)."""
+    Cm = np.zeros(36); CD = np.zeros(6)
+    m = C.c_uint64(0); ss = C.c_double(0.0)
+    tree = first.getSearchTree()
+    check(lib().tdtk_lum_link(tree._h, dptr(first.dalignxf), second._h, float(max_dist_match2),
+                              dptr(Cm), dptr(CD), C.byref(m), C.byref(ss)))
+    return Cm.reshape(6, 6), CD, int(m.value), ss.value
+
+
+def solveSparseCholesky(G, B):
+    """graphSlam6D::solveSparseCholesky(GraphMatrix*, B) (graphSlam6D.cc:345-379)."""
+    G = f64(G); B = f64(B)
+    n = len(B)
+    x = np.empty(n)
+    check(lib().tdtk_solve_spd(dptr(G), dptr(B), n, dptr(x)))
+    return x
+
+
+def lum_pose_update(scan, Xi):
+    """Per-scan pose correction of lum6DEuler::doGraphSlam6D (lum6Deuler.cc:378-448):
+    result = Ha^-1 * X_i, new pose = old - result.  Returns (rPos, rPosTheta, |dxyz|)."""
+    xa, ya, za = scan.get_rPos()
+    tx, ty = scan.get_rPosTheta()[0], scan.get_rPosTheta()[1]
+    ctx, stx, cty, sty = math.cos(tx), math.sin(tx), math.cos(ty), math.sin(ty)
+    Ha = np.eye(6)
+    Ha[0, 4] = -za * ctx + ya * stx
+    Ha[0, 5] = ya * cty * ctx + za * stx * cty
+    Ha[1, 3] = za
+    Ha[1, 4] = -xa * stx
+    Ha[1, 5] = -xa * ctx * cty + za * sty
+    Ha[2, 3] = -ya
+    Ha[2, 4] = xa * ctx
+    Ha[2, 5] = -xa * cty * stx - ya * sty
+    Ha[3, 5] = sty
+    Ha[4, 4] = stx
+    Ha[4, 5] = ctx * cty
+    Ha[5, 4] = ctx
+    Ha[5, 5] = -stx * cty
+    result = np.linalg.solve(Ha, Xi)
+    rPos = scan.get_rPos() - result[:3]
+    rPosTheta = scan.get_rPosTheta() - result[3:]
+    return rPos, rPosTheta, float(np.sqrt(result[0] ** 2 + result[1] ** 2 + result[2] ** 2))
+
+
+class lum6DEuler:
+    """lum6DEuler (-G 1).  doGraphSlam6D follows lum6Deuler.cc:314-477; the link loop of
+    FillGB3D (lum6Deuler.cc:265-303) is sharded over ranks when a process group is given."""
+
+    def __init__(self, my_icp, mdm=25.0, max_dist_match_LUM=25.0, max_num_iterations=50, quiet=True,
+                 epsilonLUM=0.5, group=None):
+        self.my_icp = my_icp
+        self.max_dist_match2_LUM = max_dist_match_LUM * max_dist_match_LUM
+        self.quiet = quiet
+        self.epsilonLUM = epsilonLUM
+        self.group = group
+
+    def doGraphSlam6D(self, gr, allScans, nrIt):
+        from .graphslam import lum_iteration
+        if gr.getNrScans() <= 0:
+            raise RuntimeError("Zero scans in graph")
+        ret = float("inf")
+        it = 0
+        while it < nrIt and ret > self.epsilonLUM:
+            ret = lum_iteration(gr, allScans, self.max_dist_match2_LUM, self.group)
+            it += 1
+        return ret

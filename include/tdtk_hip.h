@@ -1,0 +1,207 @@
+/*
+ * tdtk_hip.h -- C ABI of lib3dtk_hip.so, the MI355X (gfx950) implementation of
+ * 3DTK's slam6D ICP correspondence + alignment hot path.
+ *
+ * Plain C types only; caller owns every host buffer; the library never frees
+ * caller memory; no exception crosses this boundary: every function returns
+ * TDTK_OK (0) or a negative TDTK_E* code and tdtk_last_error() gives the text
+ * (per calling thread).  Handles are opaque; functions are re-entrant across
+ * handles.  All floating point is fp64 with FMA contraction off, so that
+ * correspondence indices are bit-exact with the reference KDtree.
+ *
+ * 4x4 matrices are column-major ("OpenGL order", translation in [12..14]) as
+ * everywhere in the reference (include/slam6d/globals.icc:298-328).
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the JMUWRobotics/3DTK checkout).  The reference-side bindings that call
+ * these are shown in INTEGRATION.md.
+ */
+#ifndef TDTK_HIP_H
+#define TDTK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDTK_OK 0
+#define TDTK_EINVAL (-1)   /* bad argument (NULL, zero points, bucket < 1 ...)        */
+#define TDTK_EDEVICE (-2)  /* no usable gfx950 device / HIP runtime error             */
+#define TDTK_ENOMEM (-3)   /* host or device allocation failed                        */
+#define TDTK_ESOLVE (-4)   /* minimizer could not be solved (Cholesky failed, ...)    */
+#define TDTK_EUNSUP (-5)   /* valid in the reference but not supported here (rnd > 1) */
+
+typedef struct tdtk_tree tdtk_tree; /* model-scan search tree, resident in HBM   */
+typedef struct tdtk_scan tdtk_scan; /* data-scan points (+normals), resident in HBM */
+
+/* include/slam6d/pairingMode.h:4-8 */
+enum {
+  TDTK_CLOSEST_POINT = 0,
+  TDTK_CLOSEST_POINT_ALONG_NORMAL_SIMPLE = 1,
+  TDTK_CLOSEST_PLANE_SIMPLE = 2
+};
+
+/* minimizer ids == icp6Dminimizer::getAlgorithmID() / the -a values that reach
+ * them (src/slam6d/slam6D.cc:696-727)                                          */
+enum { TDTK_ALGO_QUAT = 1, TDTK_ALGO_SVD = 2, TDTK_ALGO_APX = 6, TDTK_ALGO_NAPX = 10 };
+
+/* which accumulator blocks tdtk_scan_pairs / tdtk_get_pt_pairs should fill */
+#define TDTK_WANT_BASE 0u  /* n, sum, centroids, Si: always                              */
+#define TDTK_WANT_APX 1u   /* A[6], B[3] of icp6D_APX (src/slam6d/icp6Dapx.cc:203-245)   */
+#define TDTK_WANT_NAPX 2u  /* A[21], B[6], sum of icp6D_NAPX (icp6Dnapx.cc:53-95)        */
+#define TDTK_WANT_LUM 4u   /* the 15 sums + ss of lum6DEuler::covarianceEuler            */
+
+/* Merged per-call sums: what T OpenMP threads' (n, sum, centroid_m, centroid_d, Si)
+ * of src/slam6d/icp6D.cc:129-192 add up to; feed slot 0 of Align_Parallel with it. */
+typedef struct tdtk_pair_sums {
+  uint64_t n_queries;    /* queries issued                                             */
+  uint64_t n;            /* pairs found (pairs.size())                                  */
+  double sum;            /* sum |p1-p2|^2              searchTree.cc:172-177            */
+  double centroid_m[3];  /* mean of p1 (model, world)  scan.cc:1253-1259 (normalised)   */
+  double centroid_d[3];  /* mean of p2 (data)                                           */
+  double Si[9];          /* sum (p1-cm)[a]*(p2-cd)[b] at [a*3+b]   icp6D.cc:170-191     */
+  double apx_A[6];       /* A00 A01 A02 A11 A12 A22 about centroid_d (icp6Dapx.cc:203)  */
+  double apx_B[3];
+  double napx_A[21];     /* upper triangle row-major, about centroid_d                  */
+  double napx_B[6];
+  double napx_sum;       /* sum ((p1-p2).n)^2                                           */
+  double lum[15];        /* sx sy sz xpy xpz ypz xy xz yz MZ[0..5]  lum6Deuler.cc:143-175 */
+  double lum_sumd2;      /* sum |p1-p2|^2 (== sum), kept for the ss identity check      */
+} tdtk_pair_sums;
+
+typedef struct tdtk_tree_info {
+  uint64_t n_points, n_internal, n_leaves;
+  uint32_t max_depth, max_leaf_points;
+  uint64_t device_bytes;
+  double build_ms, upload_ms;
+} tdtk_tree_info;
+
+typedef struct tdtk_icp_params {
+  int algo;                /* TDTK_ALGO_*                           slam6D.cc:696-727   */
+  int pairing_mode;        /* TDTK_CLOSEST_*                        slam6D.cc:756-763   */
+  int max_num_iterations;  /* -i                                    icp6D.cc:122        */
+  double max_dist_match2;  /* sqr(-d)                               icp6D.cc:80         */
+  double epsilon_icp;      /* --epsICP                              icp6D.cc:266-267    */
+  int quiet;               /* 0: print the reference's per-iteration RMS line           */
+} tdtk_icp_params;
+
+typedef struct tdtk_icp_result {
+  int iterations;          /* value icp6D::match returns (icp6D.cc:284)                 */
+  int converged;           /* 1 if the epsilon test fired, 0 if the cap / too few pairs */
+  uint64_t last_pairs;     /* nr_pointPair                                              */
+  double last_rms;         /* last `ret`                                                */
+  double total_ms;         /* wall time of the loop (the reference's "TIME" line)       */
+  double nn_ms;            /* of which: device time in the correspondence kernel        */
+} tdtk_icp_result;
+
+/* ---- library ------------------------------------------------------------ */
+const char* tdtk_last_error(void);
+int tdtk_device_count(void);
+const char* tdtk_version(void);
+
+/* ---- model tree: replaces KDtree::KDtree(double**, int, int) (src/slam6d/kd.cc:46-49,
+ * KDTreeImpl::create include/slam6d/kdTreeImpl.h:82-201) as created by
+ * BasicScan::createSearchTreePrivate (src/slam6d/basicScan.cc:702-728).
+ * xyz = "xyz reduced original" [M][3] row-major in the tree frame; it is COPIED
+ * (the reference tree borrows it).  Builds the identical tree (same split rule,
+ * same partition order), lays it out breadth-first and uploads it.             */
+int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, tdtk_tree** out);
+void tdtk_tree_destroy(tdtk_tree* t);
+int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info);
+
+/* ---- batched KDtree::FindClosest (kd.cc:78-87; _FindClosest kdTreeImpl.h:345-383).
+ * q [K][3] in the tree frame, host memory.  idx[k] = index into the xyz given to
+ * tdtk_tree_create, or -1 (the reference returns NULL).  d2 nullable.           */
+int tdtk_find_closest(const tdtk_tree* t, const double* q, size_t K, double maxdist2,
+                      int32_t* idx, double* d2);
+/* same with device pointers (inputs already resident in HBM); stream = hipStream_t or NULL.
+ * presorted != 0 promises that q is already spatially ordered (skips the binning pass). */
+int tdtk_find_closest_dev(const tdtk_tree* t, const double* d_q, size_t K, double maxdist2,
+                          int32_t* d_idx, double* d_d2, int presorted, void* stream);
+
+/* batched KDtree::FindClosestAlongDir (kd.cc:89-100; kdTreeImpl.h:390-425) */
+int tdtk_find_closest_along_dir(const tdtk_tree* t, const double* q, const double* dir, size_t K,
+                                double maxdist2, int32_t* idx, double* d2);
+
+/* ---- SearchTree::getPtPairs, DataXYZ overload (src/slam6d/searchTree.cc:92-189), fused
+ * with the per-thread Si pass of icp6D::match (icp6D.cc:170-191) and the APX/NAPX/LUM
+ * pair loops.  Host buffers.  xyz_r = Target "xyz reduced" [*][3]; normal_r nullable
+ * unless pairing_mode != 0 or TDTK_WANT_NAPX.  rnd must be <= 1 (TDTK_EUNSUP otherwise,
+ * SURVEY N-d).  idx_out (nullable) [end-start]: model index per query or -1.
+ * p1_out/p2_out/pn_out (nullable, [end-start][3]): compact pair list in query order, the
+ * PtPair(s, t, normal) the reference pushes (for unmodified minimizers).
+ * sums is overwritten (the reference accumulates into sum/centroids; callers add).     */
+int tdtk_get_pt_pairs(const tdtk_tree* t, const double source_alignxf[16], const double* xyz_r,
+                      const double* normal_r, size_t start, size_t end, int rnd, int pairing_mode,
+                      double max_dist_match2, uint32_t want, const double* lum_D /*[6] or NULL*/,
+                      int32_t* idx_out, double* p1_out, double* p2_out, double* pn_out,
+                      tdtk_pair_sums* sums);
+
+/* ---- device-resident data scan: replaces the "xyz reduced"/"normal reduced" arrays of
+ * BasicScan (src/slam6d/basicScan.cc:532-668) for the duration of matching.  Points are
+ * copied, spatially reordered once (results are reported in the caller's order).        */
+int tdtk_scan_create(const double* xyz_reduced, const double* normal_reduced /*nullable*/, size_t N,
+                     int device, tdtk_scan** out);
+void tdtk_scan_destroy(tdtk_scan* s);
+size_t tdtk_scan_size(const tdtk_scan* s);
+/* Scan::transformReduced (src/slam6d/scan.cc:851-875): in-place transform3 of every point
+ * (and transform3normal of every normal), incremental, same arithmetic.                 */
+int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16]);
+/* copy the current points (caller's order) back, e.g. after matching */
+int tdtk_scan_download(const tdtk_scan* s, double* xyz_out, double* normal_out /*nullable*/);
+
+/* Scan::getPtPairs (scan.cc:1220-1260) over a resident scan: whole-scan pass + sums. */
+int tdtk_scan_pairs(const tdtk_tree* model, const double source_alignxf[16], tdtk_scan* data,
+                    int pairing_mode, double max_dist_match2, uint32_t want,
+                    const double* lum_D /*[6] or NULL*/, int32_t* idx_out /*host, nullable*/,
+                    tdtk_pair_sums* sums);
+
+/* ---- minimizers: icp6Dminimizer::Align_Parallel with the merged sums in slot 0
+ * (icp6Dquat.cc:515-634, icp6Dsvd.cc:170-280, icp6Dapx.cc:136-307, icp6Dnapx.cc:34-149),
+ * serial-Align semantics (S normalised by 1/n; SVD reflection fix).  Returns the RMS the
+ * reference returns (`ret`) through *rms.                                               */
+int tdtk_align(int algo, const tdtk_pair_sums* sums, double alignxf[16], double* rms);
+
+/* ---- icp6D::match (src/slam6d/icp6D.cc:104-285), device-resident loop.
+ * model_dalignxf = PreviousScan->dalignxf.  data is moved in place exactly like
+ * CurrentScan->transform(alignxf, ...) per iteration; data_transMat / data_dalignxf
+ * (in/out) get alignxf premultiplied per iteration (Scan::transformMatrix, scan.cc:878-898).
+ * trace (nullable, capacity trace_cap rows of 18 doubles): per iteration
+ * {pairs, rms, alignxf[16]}.                                                             */
+int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
+                   double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm,
+                   tdtk_icp_result* res, double* trace, int trace_cap);
+
+/* ---- lum6DEuler::covarianceEuler (src/slam6d/lum6Deuler.cc:94-251) for one link:
+ * first = model tree + its dalignxf, second = resident data scan.  C[36] row-major, CD[6].
+ * Returns the pair count through *m; C/CD are zero if m <= 2 or ss < 1e-13.              */
+int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_scan* second,
+                  double max_dist_match2, double C[36], double CD[6], uint64_t* m, double* ss);
+
+/* graphSlam6D::solveSparseCholesky(GraphMatrix*, B) (src/slam6d/graphSlam6D.cc:345-379,
+ * 477-503): dense SPD solve of G x = B (G row-major n x n, entries with |v| <= 1e-5
+ * dropped like convertToCS does).  x may alias B.                                       */
+int tdtk_solve_spd(const double* G, const double* B, int n, double* x);
+
+/* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
+ * traversal counters of the last counting run.                                          */
+int tdtk_last_kernel_ms(double* nn_ms);
+int tdtk_count_visits(const tdtk_tree* t, const double* q, size_t K, double maxdist2,
+                      uint64_t counters[3] /* internal nodes, leaves, leaf points */);
+
+/* ---- host-only diagnostics (no device needed; used by the CPU test tier) ----------------
+ * tdtk_host_tree_layout: run the host tree builder only.  perm_out [M] = caller indices in
+ * leaf order (== the reference's post-build pointer order); stats = {internal nodes, leaves,
+ * max depth, max leaf points}.  tdtk_host_m4inv / tdtk_host_mmult: the bit-exact M4inv /
+ * MMult (globals.icc:762-785, 298-328) used for every query transform.                      */
+int tdtk_host_tree_layout(const double* xyz, size_t M, int bucket_size, int32_t* perm_out,
+                          uint64_t stats[4]);
+int tdtk_host_m4inv(const double in[16], double out[16]);
+void tdtk_host_mmult(const double a[16], const double b[16], double out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDTK_HIP_H */
