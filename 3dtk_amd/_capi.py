@@ -70,6 +70,21 @@ def build_extension(force=False):
 _lib = None
 
 
+def _init_torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  When a process uses both torch
+    (device tensors, torch.distributed/RCCL) and this library, torch's runtime has to attach
+    to the GPU first; the reverse order leaves torch with "No HIP GPUs are available".  torch is
+    plumbing here, so initialise it up front when it is importable (TDTK_NO_TORCH=1 skips)."""
+    if os.environ.get("TDTK_NO_TORCH") == "1":
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # torch absent or CPU-only: nothing to order
+        pass
+
+
 def lib():
     """The loaded C-ABI library.  Fails loudly when the HIP extension has not been built."""
     global _lib
@@ -78,6 +93,7 @@ def lib():
     if not os.path.exists(_SO):
         raise TdtkError(-2, "lib3dtk_hip.so is not built (run __graft_entry__.build()); "
                             "there is no CPU fallback")
+    _init_torch_runtime_first()
     L = C.CDLL(_SO)
     L.tdtk_last_error.restype = C.c_char_p
     L.tdtk_version.restype = C.c_char_p

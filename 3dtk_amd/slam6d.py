@@ -183,7 +183,12 @@ class KDtree:
 # ---------------------------------------------------------------------------------------
 class Scan:
     """Resident scan: "xyz reduced original" (host, tree input), "xyz reduced" (device),
-    transMatOrg / transMat / dalignxf (basicScan.cc:175-197, scan.cc:878-898)."""
+    transMatOrg / transMat / dalignxf (basicScan.cc:175-197, scan.cc:878-898).
+
+    The device copy of the points and the search tree are materialised on first use, so a rank
+    that only needs a scan's pose (multi-GPU graph-SLAM) never uploads it; transforms issued
+    before materialisation are queued and replayed in order (the motion is incremental and in
+    place in the reference, SURVEY N-a)."""
 
     allScans = []
 
@@ -197,15 +202,12 @@ class Scan:
         self.dalignxf = M4identity()
         self._transformMatrix(self.transMatOrg)     # basicScan.cc:188
         self.dalignxf = M4identity()                # basicScan.cc:192
-        pts = f64(points).reshape(-1, 3)
-        self._h = C.c_void_p()
-        nr = f64(normals).reshape(-1, 3) if normals is not None else None
-        check(lib().tdtk_scan_create(dptr(pts), dptr(nr), len(pts), int(device), C.byref(self._h)))
-        self.n = len(pts)
-        # calcReducedOnDemandPrivate (basicScan.cc:730-737): transformReduced(transMatOrg) then
-        # copyReducedToOriginal
-        check(lib().tdtk_scan_transform(self._h, dptr(self.transMatOrg)))
-        self.xyz_reduced_original = self.get_xyz_reduced()
+        self._local = f64(points).reshape(-1, 3)
+        self._local_n = f64(normals).reshape(-1, 3) if normals is not None else None
+        self.n = len(self._local)
+        self._h = None
+        self._queue = []
+        self._orig = None
         self.kd = None
         self.frames = []  # (transMat copy, type)
 
@@ -222,10 +224,44 @@ class Scan:
     def get_rPos(self): return self.rPos
     def get_rPosTheta(self): return self.rPosTheta
 
-    def get_xyz_reduced(self, with_normals=False):
+    def _upload(self):
+        h = C.c_void_p()
+        check(lib().tdtk_scan_create(dptr(self._local), dptr(self._local_n), self.n, int(self.device),
+                                     C.byref(h)))
+        # calcReducedOnDemandPrivate (basicScan.cc:730-737): transformReduced(transMatOrg)
+        check(lib().tdtk_scan_transform(h, dptr(self.transMatOrg)))
+        return h
+
+    @property
+    def handle(self):
+        """device-resident "xyz reduced" (materialised on first use)"""
+        if self._h is None:
+            self._h = self._upload()
+            if self._orig is None:
+                self._orig = self._download(self._h)     # copyReducedToOriginal
+            for A in self._queue:
+                check(lib().tdtk_scan_transform(self._h, dptr(A)))
+            self._queue = []
+        return self._h
+
+    def _download(self, h):
         out = np.empty((self.n, 3))
-        check(lib().tdtk_scan_download(self._h, dptr(out), None))
+        check(lib().tdtk_scan_download(h, dptr(out), None))
         return out
+
+    @property
+    def xyz_reduced_original(self):
+        if self._orig is None:
+            if self._h is not None or not self._queue:
+                _ = self.handle
+            else:   # only the tree is needed here: do not keep a moved copy resident
+                h = self._upload()
+                self._orig = self._download(h)
+                lib().tdtk_scan_destroy(h)
+        return self._orig
+
+    def get_xyz_reduced(self):
+        return self._download(self.handle)
 
     def getSearchTree(self):
         """scan.cc:268-306 -> basicScan.cc:702-728: lazily built over "xyz reduced original"."""
@@ -241,8 +277,11 @@ class Scan:
 
     def transform(self, alignxf, type="ICP", islum=0):
         """Scan::transform (scan.cc:918-1009): transformReduced on the device + matrices."""
-        alignxf = f64(alignxf, 16)
-        check(lib().tdtk_scan_transform(self._h, dptr(alignxf)))
+        alignxf = f64(alignxf, 16).copy()
+        if self._h is not None:
+            check(lib().tdtk_scan_transform(self._h, dptr(alignxf)))
+        else:
+            self._queue.append(alignxf)
         self._transformMatrix(alignxf)
         if type != "INVALID" and islum != -1:
             self.frames.append((self.transMat.copy(), type))
@@ -269,7 +308,7 @@ class Scan:
         idx = np.empty(Target.n, np.int32) if want_idx else None
         D = f64(lum_D, 6) if lum_D is not None else None
         tree = Source.getSearchTree()
-        check(lib().tdtk_scan_pairs(tree._h, dptr(Source.dalignxf), Target._h, int(pairing_mode),
+        check(lib().tdtk_scan_pairs(tree._h, dptr(Source.dalignxf), Target.handle, int(pairing_mode),
                                     float(max_dist_match2), int(want), dptr(D), iptr(idx), C.byref(s)))
         out = _sums_dict(s)
         out["_raw"] = s
@@ -351,7 +390,7 @@ class icp6D:
         trace = np.zeros((cap, 18))
         tm = CurrentScan.transMat.copy()
         da = CurrentScan.dalignxf.copy()
-        check(lib().tdtk_icp_match(tree._h, dptr(PreviousScan.dalignxf), CurrentScan._h, dptr(tm),
+        check(lib().tdtk_icp_match(tree._h, dptr(PreviousScan.dalignxf), CurrentScan.handle, dptr(tm),
                                    dptr(da), C.byref(prm), C.byref(res), dptr(trace), cap))
         CurrentScan.transMat = tm
         CurrentScan.dalignxf = da
@@ -407,7 +446,7 @@ def covarianceEuler(first, second, max_dist_match2):
     Cm = np.zeros(36); CD = np.zeros(6)
     m = C.c_uint64(0); ss = C.c_double(0.0)
     tree = first.getSearchTree()
-    check(lib().tdtk_lum_link(tree._h, dptr(first.dalignxf), second._h, float(max_dist_match2),
+    check(lib().tdtk_lum_link(tree._h, dptr(first.dalignxf), second.handle, float(max_dist_match2),
                               dptr(Cm), dptr(CD), C.byref(m), C.byref(ss)))
     return Cm.reshape(6, 6), CD, int(m.value), ss.value
 

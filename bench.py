@@ -1,0 +1,304 @@
+#!/usr/bin/env python
+"""bench.py -- the driver's measurement contract for the slam6D ICP hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+
+N = 1  workload "icp"  = BASELINE.json configs[1]: synthetic 1M-vs-1M point-to-point ICP
+       (D = T_gt^-1 (M + N(0,1)), shuffled; -a 1 -d 25 -b 20).
+       One step = one full icp6D::match iteration on the resident scan: apply the previous
+       alignxf to the 1M data points, 1M kd-tree FindClosest, fused pair sums, D2H of 67 doubles,
+       closed-form solve.  value = NN correspondences (queries) per second, whole job.
+N > 1  workload "graphslam" = configs[3]: 64 scans x 1M points on a closed loop, one step =
+       one lum6DEuler iteration (-G 1): links dealt round-robin to the ranks, one whole-scan
+       correspondence pass + two reductions per link, ONE all-reduce of the dense normal
+       equations over RCCL, redundant solve, pose update.  Total work is fixed -> "strong".
+       (--workload graphslam --gpus 1 gives the 1-GPU point of that curve.)
+
+Rank 0 prints ONE JSON line (metric/value/.../roofline/cpu_baseline).  Inputs are resident in
+HBM when the timed region starts; the oracle is only used for the cpu_baseline leg and for a
+parity spot-check outside the timed region.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes_per_query(n_int, n_pts):
+    """24 B query + 64 B per internal node visited + 24 B per leaf point tested +
+    4 B index out (properties of tree/query/radius, independent of the implementation)."""
+    return 24.0 + 64.0 * n_int + 24.0 * n_pts + 4.0
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------------------------
+def make_icp_pair(n, seed=42):
+    from oracle import orc      # input generator only (the K5 stream of the golden vectors)
+    m = orc.gen_mt64_uniform(seed, 3 * n, -1000.0, 1000.0).reshape(n, 3).copy()
+    rng = np.random.default_rng(seed + 1)
+    tdtk = importlib.import_module("3dtk_amd")
+    T = tdtk.EulerToMatrix4([10.0, -5.0, 3.0], [0.02, -0.03, 0.05])
+    Tinv = tdtk.M4inv(T)
+    R = np.array([[Tinv[0], Tinv[4], Tinv[8]], [Tinv[1], Tinv[5], Tinv[9]], [Tinv[2], Tinv[6], Tinv[10]]])
+    d = (m + rng.normal(0.0, 1.0, m.shape))[rng.permutation(n)]
+    d = d @ R.T + Tinv[12:15]
+    return m, np.ascontiguousarray(d), T
+
+
+def make_graphslam_scans(nscans, npts, seed=7):
+    """one world cloud in a 4000x4000x2000 box, scans = points within range
+    1500 of poses on a closed circle (radius 800, tangential heading), exactly npts each, in the
+    scan frame, + N(0,1) noise; initial poses = truth + accumulated odometry drift."""
+    rng = np.random.default_rng(seed)
+    nworld = 4 * npts
+    world = np.empty((nworld, 3))
+    world[:, 0] = rng.uniform(-2000, 2000, nworld)
+    world[:, 1] = rng.uniform(-1000, 1000, nworld)     # y is "up" in 3DTK's left-handed frame
+    world[:, 2] = rng.uniform(-2000, 2000, nworld)
+    tdtk = importlib.import_module("3dtk_amd")
+    out = []
+    drift_p = np.zeros(3); drift_t = 0.0
+    for k in range(nscans):
+        ang = 2 * math.pi * k / nscans
+        pos = np.array([800 * math.cos(ang), 0.0, 800 * math.sin(ang)])
+        theta = np.array([0.0, -ang, 0.0])
+        d = world - pos
+        sel = np.flatnonzero(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2] < 1500.0 ** 2)
+        if len(sel) < npts:
+            raise RuntimeError("world cloud too sparse for %d points per scan" % npts)
+        sel = rng.choice(sel, npts, replace=False)
+        T = tdtk.EulerToMatrix4(pos, theta)
+        Ti = tdtk.M4inv(T)
+        R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+        loc = world[sel] @ R.T + Ti[12:15] + rng.normal(0.0, 1.0, (npts, 3))
+        if k > 0:
+            drift_p = drift_p + rng.normal(0.0, 0.3, 3)
+            drift_t = drift_t + rng.normal(0.0, math.radians(0.01))
+        out.append((pos + drift_p, theta + np.array([0.0, drift_t, 0.0]), np.ascontiguousarray(loc)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def dist_setup(ngpus):
+    import torch
+    rank, world, local = 0, 1, 0
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if world != ngpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (ngpus, world))
+    return rank, world, local
+
+
+def barrier_sync(world):
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, local):
+    if world == 1:
+        return x
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", local))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline_nn(model, queries, maxd2, budget_s=12.0):
+    """The reference's KDtreeIndexed::FindClosest (oracle/_ref, kind "reference") or the C
+    restatement (kind "port") on this box's host cores, bounded sample of the same workload."""
+    from oracle import orc
+    if orc.have_ref():
+        kind, tree = "reference", orc.RefTree(model, 20)
+        threads = min(int(orc.ref().ref_host_threads()), 512)
+        run = lambda q, nt: tree.find_closest(q, maxd2, nt)
+    else:
+        kind, tree = "port", orc.Tree(model, 20)
+        threads = int(orc.lib().orc_max_threads())
+        run = lambda q, nt: tree.find_closest(q, maxd2, nt)
+    run(queries[:20000], threads)                       # warm
+    t0 = time.perf_counter(); run(queries[:200000], 1); t1 = time.perf_counter() - t0
+    one = 200000 / t1
+    reps, t_all = 0, 0.0
+    while t_all < budget_s and reps < 8:
+        t0 = time.perf_counter(); run(queries, threads); t_all += time.perf_counter() - t0; reps += 1
+    allc = reps * len(queries) / t_all
+    return {"value": allc, "unit": "NN correspondences/s", "cores": threads, "kind": kind,
+            "one_thread_value": one,
+            "sample": "%d passes of KDtreeIndexed::FindClosest over the same %d queries with %d OpenMP threads "
+                      "(static chunks, threadNum = thread id) + 200k queries on 1 thread; NN search only "
+                      "(the dominant share of getPtPairs; pair sums/solve excluded)" % (reps, len(queries), threads)}
+
+
+# --------------------------------------------------------------------------------------------
+def bench_icp(args, rank, world, local):
+    tdtk = importlib.import_module("3dtk_amd")
+    n = args.points
+    m, d, T = make_icp_pair(n)
+    model = tdtk.Scan([0, 0, 0], [0, 0, 0], m, device=local)
+    data = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
+    tree = model.getSearchTree()
+    info = tree.info()
+    _ = data.handle
+    mini = tdtk.icp6D_QUAT(True)
+    # warm-up: W untimed iterations of the same loop (also brings the pose close to T)
+    icp_w = tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0)
+    icp_w.match(model, data)
+    icp = tdtk.icp6D(mini, 25.0, args.steps, quiet=True, epsilonICP=-1.0)   # eps < 0: exactly K steps
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    it = icp.match(model, data)
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, world, local)
+    steps = it + 1
+    assert steps == args.steps, (steps, args.steps)
+    last = icp.last
+    pose_err = float(np.abs(data.get_transMat() - T).max())
+
+    # algorithmic bytes of THIS query set (visit counters are exact properties of tree+queries)
+    cur = data.get_xyz_reduced()
+    samp = cur[:: max(1, n // 200000)]
+    c_int, c_leaf, c_pts = tree.count_visits(samp, 625.0)
+    bq = algorithmic_bytes_per_query(c_int / len(samp), c_pts / len(samp))
+    k_ms = last["nn_ms"] / steps                          # HIP-event time of k_search, per launch
+    achieved = bq * n / (k_ms * 1e-3) / 1e9
+    # parity spot check outside the timed region
+    from oracle import orc
+    oi, _ = orc.Tree(m, 20).find_closest(cur[:20000], 625.0)
+    gi, _ = tree.FindClosestBatch(cur[:20000], 625.0)
+    assert np.array_equal(oi, gi), "parity spot-check failed"
+
+    out = {
+        "metric": "NN correspondences/sec (1M-vs-1M pairwise ICP, full iteration)",
+        "value": n * steps / dt, "unit": "NN correspondences/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: synthetic %d-vs-%d uniform pair, point-to-point ICP (-a 1 -d 25 -b 20), "
+                               "1xMI355X, device-resident icp6D::match" % (n, n),
+                   "points": n, "bucket": 20, "max_dist_match": 25.0, "minimizer": "QUAT",
+                   "tree": {"internal": info["n_internal"], "leaves": info["n_leaves"], "depth": info["max_depth"]},
+                   "tree_build_ms": info["build_ms"], "tree_upload_ms": info["upload_ms"]},
+        "icp_iters_per_s": steps / dt,
+        "pairs_last": last["pairs"], "rms_last": last["rms"], "pose_max_abs_err": pose_err,
+        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": k_ms, "bytes_per_query": bq,
+                     "visits_per_query": {"internal": c_int / len(samp), "leaves": c_leaf / len(samp), "points": c_pts / len(samp)},
+                     "nn_per_s_kernel_only": n / (k_ms * 1e-3)},
+    }
+    if rank == 0 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0)
+    return out
+
+
+def bench_graphslam(args, rank, world, local):
+    tdtk = importlib.import_module("3dtk_amd")
+    gs = importlib.import_module("3dtk_amd.graphslam")
+    sl = importlib.import_module("3dtk_amd.slam6d")
+    import torch
+    nscans, npts = args.scans, args.points
+    raw = make_graphslam_scans(nscans, npts)
+    scans = [tdtk.Scan(p, th, loc, device=local) for (p, th, loc) in raw]
+    del raw
+    g0 = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)
+    nlinks = g0.getNrLinks()
+    mine = gs.shard_links(nlinks, rank, world)
+    for i in mine:                                      # materialise what this rank touches
+        scans[g0.getLink(i, 0)].getSearchTree()
+        _ = scans[g0.getLink(i, 1)].handle
+    dev = torch.device("cuda", local) if world > 1 else None
+    nn_ms = [0.0]
+
+    def link_fn(a, b, md2):
+        r = sl.covarianceEuler(a, b, md2)
+        ms = C.c_double(0.0)
+        tdtk.lib().tdtk_last_kernel_ms(C.byref(ms))
+        nn_ms[0] += ms.value
+        return r
+
+    def step():
+        gr = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)   # slam6D.cc:525-532: fresh Graph + 1 LUM iteration
+        return gs.lum_iteration(gr, scans, 625.0, None, link_fn, dev), gr.getNrLinks()
+
+    for _ in range(args.warmup):
+        step()
+    nn_ms[0] = 0.0
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    links_done = 0
+    for _ in range(args.steps):
+        ret, nl = step()
+        links_done += nl
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, local)
+    queries = links_done * npts                         # one whole-scan NN pass per link
+    my_launches = sum(1 for _ in range(args.steps)) * len(mine)
+    k_ms = nn_ms[0] / max(1, my_launches)
+    out = {
+        "metric": "NN correspondences/sec (graph-SLAM lum6DEuler iteration, links sharded)",
+        "value": queries / dt, "unit": "NN correspondences/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[3]: synthetic %d scans x %d pts, graph-SLAM -G 1 (lum6DEuler) one iteration per "
+                               "step, %d links round-robin over %d ranks, one fp64 all-reduce of %d doubles"
+                               % (nscans, npts, nlinks, world, (6 * (nscans - 1)) ** 2 + 6 * (nscans - 1)),
+                   "scans": nscans, "points": npts, "links": nlinks},
+        "lum_iters_per_s": args.steps / dt, "last_ret": ret,
+        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": None, "traffic": None, "kernel_ms": k_ms},
+    }
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["auto", "icp", "graphslam"], default="auto")
+    ap.add_argument("--points", type=int, default=1000000)
+    ap.add_argument("--scans", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+    capi = importlib.import_module("3dtk_amd._capi")
+    if not os.path.exists(os.path.join(ROOT, "3dtk_amd", "lib3dtk_hip.so")):
+        capi.build_extension()
+    rank, world, local = dist_setup(args.gpus)
+    wl = args.workload
+    if wl == "auto":
+        wl = "icp" if world == 1 else "graphslam"
+    if wl == "graphslam" and args.steps == 100 and args.warmup == 10:
+        args.steps, args.warmup = 5, 1                 # a LUM step is ~70 whole-scan passes
+    res = bench_icp(args, rank, world, local) if wl == "icp" else bench_graphslam(args, rank, world, local)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

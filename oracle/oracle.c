@@ -439,3 +439,57 @@ int orc_max_threads(void)
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ */
+/* input recipes for the golden vectors             */
+/* ------------------------------------------------------------------ */
+/* The 64-bit Mersenne Twister (Matsumoto & Nishimura, public algorithm ==
+ * std::mt19937_64) followed by std::uniform_real_distribution<double>(lo,hi)
+ * exactly as libstdc++ evaluates it for a 64-bit engine: one draw u per value,
+ * c = (double)u / 2^64 (clamped below 1), value = c*(hi-lo) + lo.            */
+void orc_gen_mt64_uniform(uint64_t seed, size_t n, double lo, double hi, double *out)
+{
+  enum { NN = 312, MM = 156 };
+  static const uint64_t MAT = 0xB5026F5AA96619E9ULL, UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL;
+  uint64_t mt[NN];
+  int mti;
+  mt[0] = seed;
+  for (mti = 1; mti < NN; mti++)
+    mt[mti] = 6364136223846793005ULL * (mt[mti - 1] ^ (mt[mti - 1] >> 62)) + (uint64_t)mti;
+  for (size_t k = 0; k < n; k++) {
+    if (mti >= NN) {
+      int i;
+      for (i = 0; i < NN - MM; i++) {
+        uint64_t x = (mt[i] & UM) | (mt[i + 1] & LM);
+        mt[i] = mt[i + MM] ^ (x >> 1) ^ ((x & 1ULL) ? MAT : 0ULL);
+      }
+      for (; i < NN - 1; i++) {
+        uint64_t x = (mt[i] & UM) | (mt[i + 1] & LM);
+        mt[i] = mt[i + (MM - NN)] ^ (x >> 1) ^ ((x & 1ULL) ? MAT : 0ULL);
+      }
+      uint64_t x = (mt[NN - 1] & UM) | (mt[0] & LM);
+      mt[NN - 1] = mt[MM - 1] ^ (x >> 1) ^ ((x & 1ULL) ? MAT : 0ULL);
+      mti = 0;
+    }
+    uint64_t x = mt[mti++];
+    x ^= (x >> 29) & 0x5555555555555555ULL;
+    x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+    x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+    x ^= (x >> 43);
+    double c = (double)x / 18446744073709551616.0;
+    if (c >= 1.0) c = nextafter(1.0, 0.0);
+    out[k] = c * (hi - lo) + lo;
+  }
+}
+
+/* XOR hash of SURVEY 8(c) K5 over the FOUND correspondences: h ^= idx*1315423911 + i
+ * (queries without a partner are skipped; reproduces 0x5cdee3d50429c / 0x34a9be6b29435) */
+uint64_t orc_k5_hash(const int32_t *idx, size_t n)
+{
+  uint64_t h = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (idx[i] < 0) continue;
+    h ^= (uint64_t)idx[i] * 1315423911ULL + (uint64_t)i;
+  }
+  return h;
+}

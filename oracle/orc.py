@@ -65,6 +65,9 @@ def lib():
         L.orc_transform_points.argtypes = [_dp, _dp, C.c_size_t]
         L.orc_transform_normals.argtypes = [_dp, _dp, C.c_size_t]
         L.orc_max_threads.restype = C.c_int
+        L.orc_gen_mt64_uniform.argtypes = [C.c_uint64, C.c_size_t, C.c_double, C.c_double, _dp]
+        L.orc_k5_hash.restype = C.c_uint64
+        L.orc_k5_hash.argtypes = [_ip, C.c_size_t]
         _lib = L
     return _lib
 
@@ -227,3 +230,15 @@ def ref_align_parallel(algo, n, s, cm, cd, Si):
     err = ref().ref_align_parallel(int(algo), n.ctypes.data_as(_up), _d(_c(s)), _d(_c(cm)), _d(_c(cd)),
                                    _d(_c(Si)), _d(out))
     return out, err
+
+
+def gen_mt64_uniform(seed, n, lo, hi):
+    """std::mt19937_64(seed) + std::uniform_real_distribution<double>(lo, hi), n draws."""
+    out = np.empty(n)
+    lib().orc_gen_mt64_uniform(int(seed), n, float(lo), float(hi), _d(out))
+    return out
+
+
+def k5_hash(idx):
+    idx = np.ascontiguousarray(idx, np.int32)
+    return int(lib().orc_k5_hash(_i(idx), len(idx)))

@@ -1,0 +1,144 @@
+"""Generates the golden fixtures in this directory.  Run ONCE in the build container, where
+/root/reference exists:   python tests/golden/make_golden.py
+It reads reference *data files* (dat/scan00?.3d/.pose) and calls the reference's own compiled
+translation units through oracle/_ref (oracle/build_ref.sh); it commits only numbers.
+
+Fixtures written:
+  dat_scans.npz     the three bundled uos scans (float64, as strtod parses them) + poses
+  k4_random.npz     testing/kdtree/kdtree_indexed_random.cc recipe: 10 000 pts in [-10,10]^3,
+                    100 queries x maxdist2 in {0.5,...,5.0}; expected = reference KDtreeIndexed
+                    (cross-checked against brute force, first strictly smaller d2 wins)
+  k5_hashes.json    1M-vs-1M K5 stream (mt19937_64(42), U(-1000,1000)): found counts + XOR
+                    hashes of the reference KDtreeIndexed for maxdist2 = 625 and 1e18, tree stats
+  k6_minimizers.json  reference icp6D_{QUAT,SVD,APX,NAPX}::Align on a synthetic rigid motion
+  b1_dat_icp.json   sequential ICP on dat/ (-d 25 -i 50, QUAT): per-iteration pairs / RMS /
+                    alignxf and final transMat, computed with the oracle loop + the REFERENCE
+                    minimizer; cross-checked against SURVEY appendix B1
+  b4_dat_lum.json   LUM link systems at the B1 final poses (-D 25)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import orc, icp_oracle as io  # noqa: E402
+
+REF = os.environ.get("TDTK_REF", "/root/reference")
+
+
+def brute(m, q, maxd2):
+    out = np.full(len(q), -1, np.int32)
+    for i, p in enumerate(q):
+        d = m - p
+        d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+        j = int(np.argmin(d2))            # first minimum == first strictly smaller
+        if d2[j] < maxd2:
+            out[i] = j
+    return out
+
+
+def main():
+    assert orc.have_ref() or os.path.isdir(REF), "needs the reference checkout"
+    orc.build()
+
+    # ---- dat scans ------------------------------------------------------------------
+    scans, poses = {}, {}
+    for k in range(3):
+        scans["scan%03d" % k] = io.read_uos(os.path.join(REF, "dat", "scan%03d.3d" % k))
+        rP, rPT = io.read_pose(os.path.join(REF, "dat", "scan%03d.pose" % k))
+        poses["pose%03d" % k] = np.concatenate([rP, rPT])
+        print("scan", k, scans["scan%03d" % k].shape, poses["pose%03d" % k])
+    np.savez_compressed(os.path.join(HERE, "dat_scans.npz"), **scans, **poses)
+
+    # ---- K4 ---------------------------------------------------------------------------
+    rng = np.random.RandomState(42)
+    m = rng.uniform(-10, 10, (10000, 3))
+    qs, exp, mds = [], [], []
+    R = orc.RefTree(m, 20)
+    for j in range(1, 11):
+        md2 = 0.5 * j
+        q = rng.uniform(-10, 10, (100, 3))
+        e = R.find_closest(q, md2)
+        assert np.array_equal(e, brute(m, q, md2)), "reference tree != brute force"
+        qs.append(q); exp.append(e); mds.append(md2)
+    np.savez_compressed(os.path.join(HERE, "k4_random.npz"), model=m, queries=np.array(qs),
+                        expected=np.array(exp), maxdist2=np.array(mds))
+
+    # ---- K5 ---------------------------------------------------------------------------
+    M = 1000000
+    stream = orc.gen_mt64_uniform(42, 6 * M, -1000, 1000)
+    m5 = stream[:3 * M].reshape(M, 3).copy()
+    q5 = stream[3 * M:].reshape(M, 3).copy()
+    R5 = orc.RefTree(m5, 20)
+    T5 = orc.Tree(m5, 20)
+    k5 = {"M": M, "seed": 42, "lo": -1000, "hi": 1000, "bucket": 20, "tree": T5.stats(), "cases": []}
+    for md2 in (625.0, 1e18):
+        e = R5.find_closest(q5, md2, 8)
+        oi, _, cnt = T5.find_closest(q5, md2, 8, True)
+        assert np.array_equal(e, oi)
+        k5["cases"].append({"maxdist2": md2, "found": int((e >= 0).sum()), "hash": "0x%x" % orc.k5_hash(e),
+                            "visits_per_query": [c / M for c in cnt],
+                            "first32": e[:32].tolist(), "last32": e[-32:].tolist()})
+        print("K5", k5["cases"][-1]["maxdist2"], k5["cases"][-1]["found"], k5["cases"][-1]["hash"])
+    json.dump(k5, open(os.path.join(HERE, "k5_hashes.json"), "w"), indent=1)
+
+    # ---- K6 minimizers -----------------------------------------------------------------
+    d = orc.gen_mt64_uniform(7, 3000, -100, 100).reshape(1000, 3)
+    T = io.euler_to_matrix4([1.5, -2.0, 0.7], [0.02, -0.03, 0.05])
+    mm = d.copy(); orc.transform_points(T, mm)
+    nr = orc.gen_mt64_uniform(8, 3000, -1, 1).reshape(1000, 3)
+    nr /= np.linalg.norm(nr, axis=1)[:, None]
+    cm, cd = mm.mean(axis=0), d.mean(axis=0)
+    k6 = {"seed_points": 7, "seed_normals": 8, "rPos": [1.5, -2.0, 0.7], "rPosTheta": [0.02, -0.03, 0.05], "algos": {}}
+    for algo in (1, 2, 6, 10):
+        a, err = orc.ref_align(algo, mm, d, cm, cd, nr if algo == 10 else None)
+        k6["algos"][str(algo)] = {"alignxf": a.tolist(), "rms": err}
+        print("K6", algo, err, a[12:15], a[0])
+    # a noisy, non-exact case as well
+    noise = orc.gen_mt64_uniform(9, 3000, -0.5, 0.5).reshape(1000, 3)
+    mn = mm + noise
+    cmn = mn.mean(axis=0)
+    k6["noisy"] = {"seed_noise": 9, "algos": {}}
+    for algo in (1, 2, 6, 10):
+        a, err = orc.ref_align(algo, mn, d, cmn, cd, nr if algo == 10 else None)
+        k6["noisy"]["algos"][str(algo)] = {"alignxf": a.tolist(), "rms": err}
+    json.dump(k6, open(os.path.join(HERE, "k6_minimizers.json"), "w"), indent=1)
+
+    # ---- B1: dat sequential ICP (oracle loop + REFERENCE minimizer) --------------------
+    def ref_align_fn(algo, p1, p2, cm, cd, pn):
+        a, err = orc.ref_align(algo, p1, p2, cm, cd, pn)
+        return err, a
+    S = [io.OScan(poses["pose%03d" % k][:3], poses["pose%03d" % k][3:], scans["scan%03d" % k]) for k in range(3)]
+    b1 = {"params": {"algo": 1, "max_dist_match": 25.0, "max_num_iterations": 50, "epsilonICP": 1e-5, "eP": True},
+          "pairs": []}
+    for i in (1, 2):
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        it, tr = io.match(S[i - 1], S[i], 1, 625.0, 50, 1e-5, 0, ref_align_fn)
+        b1["pairs"].append({"prev": i - 1, "cur": i, "iter": it,
+                            "trace": [[int(n), float(r)] for n, r, _ in tr],
+                            "alignxf": [a.tolist() for _, _, a in tr],
+                            "final_transMat": S[i].transMat.tolist()})
+        print("B1 pair", i, "ITER", it, tr[0][:2], tr[-1][:2], S[i].transMat[12:15])
+    json.dump(b1, open(os.path.join(HERE, "b1_dat_icp.json"), "w"), indent=1)
+
+    # ---- B4: LUM link systems at the B1 final poses -----------------------------------
+    b4 = {"max_dist_match_LUM": 25.0, "links": []}
+    for (a, b) in ((0, 1), (1, 2)):
+        C, CD, m_, ss, D = io.covariance_euler(S[a], S[b], 625.0)
+        b4["links"].append({"first": a, "second": b, "m": int(m_), "ss": float(ss), "D": D.tolist(),
+                            "C": C.tolist(), "CD": CD.tolist()})
+        print("B4 link", a, b, m_, ss, D[:3], CD[:3])
+    links = [(0, 1), (1, 2)]
+    ret, G, B, X = io.lum_iteration(links, S, 625.0)
+    b4["one_iteration"] = {"ret": float(ret), "X": X.tolist(),
+                           "poses_after": [np.concatenate([s.rPos, s.rPosTheta]).tolist() for s in S]}
+    print("B4 lum iteration ret", ret)
+    json.dump(b4, open(os.path.join(HERE, "b4_dat_lum.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,343 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs, against the committed golden fixtures (generated with the reference's own TUs), and --
+at BASELINE.json's full 1M-vs-1M size -- through hashes and size-independent properties.
+
+Bar: correspondence indices and squared distances BIT-EXACT; sums / poses within the tolerance
+BASELINE.json states (1e-5 relative on the pose; we assert much tighter where the arithmetic
+allows)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+
+POSE_RTOL = 1e-5          # BASELINE.json north_star: pose within 1e-5 relative
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+# ---- known-answer tests of testing/kdtree/kdtree.cc:20-99 through the C ABI -------------------
+@pytest.mark.parametrize("pts,want", [
+    ([[2.0, 0.0, 0.0]], None), ([[1.99999999999, 0.0, 0.0]], 0), ([[1.5, 0.0, 0.0], [1.0, 0.0, 0.0]], 1)])
+def test_kat_find_closest(tdtk, gpu, pts, want):
+    assert tdtk.KDtree(np.array(pts)).FindClosest([0.0, 0.0, 0.0], 4.0) == want
+
+
+@pytest.mark.parametrize("pts,want", [
+    ([[1.0, 2.0, 0.0]], None), ([[1.0, 1.99999999999, 0.0]], 0),
+    ([[0.5, 0.1, 0.0], [1.0, 0.0, 0.0]], 1), ([[-1.0, 0.0, 0.0]], 0)])
+def test_kat_find_closest_along_dir(tdtk, gpu, pts, want):
+    assert tdtk.KDtree(np.array(pts)).FindClosestAlongDir([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], 4.0) == want
+
+
+def test_errors(tdtk, gpu):
+    with pytest.raises(RuntimeError):
+        tdtk.KDtree(np.zeros((0, 3)))                     # kdTreeImpl.h:86-88
+    kd = tdtk.KDtree(np.random.default_rng(0).uniform(-1, 1, (50, 3)))
+    idx, d2 = kd.FindClosestBatch(np.zeros((0, 3)), 1.0)   # empty batch
+    assert len(idx) == 0
+    with pytest.raises(tdtk.TdtkError) as e:
+        kd.getPtPairs(tdtk.M4identity(), np.zeros((4, 3)), rnd=5)
+    assert e.value.code == -5                             # rnd > 1 unsupported (SURVEY N-d)
+    with pytest.raises(tdtk.TdtkError):
+        kd.getPtPairs(tdtk.M4identity(), np.zeros((4, 3)), pairing_mode=2)   # needs normals
+
+
+def _clouds():
+    rng = np.random.default_rng(3)
+    uni = rng.uniform(-100, 100, (30000, 3))
+    dup = uni.copy(); dup[1000:1400] = dup[0:400]
+    clu = np.concatenate([rng.normal(c, 0.003, (300, 3)) for c in rng.uniform(-50, 50, (40, 3))])
+    plane = rng.uniform(-100, 100, (20000, 3)); plane[:, 2] = 0.0
+    tiny = rng.uniform(-1, 1, (7, 3))
+    grid = np.stack(np.meshgrid(*[np.arange(12.0)] * 3), -1).reshape(-1, 3)
+    line = np.zeros((5000, 3)); line[:, 0] = np.sort(rng.uniform(0, 1e4, 5000)) ** 2 / 1e4   # skewed -> deep tree
+    return {"uniform": uni, "duplicates": dup, "clusters": clu, "plane": plane, "tiny": tiny, "grid": grid,
+            "line": line}
+
+
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "tiny", "grid", "line"])
+@pytest.mark.parametrize("bucket", [1, 20])
+def test_find_closest_bit_exact(tdtk, orc, gpu, name, bucket):
+    m = _clouds()[name]
+    rng = np.random.default_rng(11)
+    q = np.concatenate([m[rng.integers(0, len(m), 4000)] + rng.normal(0, 0.5, (4000, 3)), m[:700],
+                        rng.uniform(-120, 120, (2000, 3))])
+    if name == "grid":
+        q = np.concatenate([q, m[:700] + 0.5])
+    kd, T = tdtk.KDtree(m, bucket), orc.Tree(m, bucket)
+    inf = kd.info(); st = T.stats()
+    assert (inf["n_internal"], inf["n_leaves"], inf["max_depth"]) == (st["internal"], st["leaves"], st["depth"])
+    for md2 in (0.25, 25.0, 1e18):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2)
+        assert np.array_equal(idx, oi), (name, bucket, md2)
+        assert np.array_equal(d2, od2)
+        assert kd.count_visits(q, md2) == T.find_closest(q, md2, 1, True)[2]    # same traversal, node for node
+    d = rng.normal(size=(len(q), 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    idx, d2 = kd.FindClosestAlongDirBatch(q[:1500], d[:1500], 4.0)
+    oi, od2 = T.find_closest_along_dir(q[:1500], d[:1500], 4.0)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+
+
+def test_leaf_table_mode(tdtk, orc, gpu):
+    """bits(M) + bits(max leaf) > 30 switches child references to the leaf table."""
+    rng = np.random.default_rng(5)
+    m = rng.uniform(-1000, 1000, (1100000, 3))
+    m[5000:5600] = m[4999]                               # a 601-point degenerate bucket
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    assert kd.info()["max_leaf_points"] >= 601
+    q = np.concatenate([rng.uniform(-1000, 1000, (20000, 3)), m[4990:5010] + 0.001])
+    for md2 in (625.0, 1e18):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+
+
+def test_k4_fixture(tdtk, gpu):
+    z = np.load(os.path.join(G, "k4_random.npz"))
+    kd = tdtk.KDtree(z["model"], 20)
+    for q, e, md2 in zip(z["queries"], z["expected"], z["maxdist2"]):
+        assert np.array_equal(kd.FindClosestBatch(q, md2)[0], e)
+
+
+@pytest.fixture(scope="module")
+def k5(orc):
+    k = json.load(open(os.path.join(G, "k5_hashes.json")))
+    M = k["M"]
+    s = orc.gen_mt64_uniform(k["seed"], 6 * M, k["lo"], k["hi"])
+    return k, s[:3 * M].reshape(M, 3).copy(), s[3 * M:].reshape(M, 3).copy()
+
+
+def test_k5_full_size_hashes(tdtk, orc, gpu, k5):
+    """BASELINE configs[1] size: 1M-vs-1M, hashes of the REFERENCE KDtree's index stream."""
+    k, m, q = k5
+    kd = tdtk.KDtree(m, k["bucket"])
+    inf = kd.info()
+    assert (inf["n_internal"], inf["n_leaves"], inf["max_depth"]) == (k["tree"]["internal"], k["tree"]["leaves"], k["tree"]["depth"])
+    for c in k["cases"]:
+        idx, d2 = kd.FindClosestBatch(q, c["maxdist2"])
+        assert int((idx >= 0).sum()) == c["found"]
+        assert "0x%x" % orc.k5_hash(idx) == c["hash"]
+        assert idx[:32].tolist() == c["first32"] and idx[-32:].tolist() == c["last32"]
+        cnt = kd.count_visits(q, c["maxdist2"])
+        np.testing.assert_allclose(np.array(cnt) / k["M"], c["visits_per_query"], rtol=1e-12)
+        # size-independent properties: reported d2 is the true distance to the reported point,
+        # nothing within the radius is closer (brute force on a sample), strict '<' radius
+        f = idx >= 0
+        dd = m[idx[f]] - q[f]
+        assert np.array_equal(dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1] + dd[:, 2] * dd[:, 2], d2[f])
+        assert (d2[f] < c["maxdist2"]).all() and (d2[~f] == c["maxdist2"]).all()
+        for i in np.random.default_rng(1).integers(0, k["M"], 300):
+            e = m - q[i]
+            b2 = (e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1] + e[:, 2] * e[:, 2]).min()
+            assert (b2 == d2[i]) if b2 < c["maxdist2"] else (idx[i] == -1)
+
+
+def test_k5_idempotence_and_presorted_device_path(tdtk, gpu, k5):
+    """Querying the model with itself returns every point (d2 == 0); the device-pointer entry
+    (inputs resident in HBM) gives the same answers with and without its own binning pass."""
+    import ctypes as C
+    import torch
+    k, m, q = k5
+    kd = tdtk.KDtree(m, 20)
+    idx, d2 = kd.FindClosestBatch(m, 1e-9)
+    assert np.array_equal(idx, np.arange(len(m), dtype=np.int32)) and (d2 == 0).all()
+    tq = torch.from_numpy(q).cuda()
+    out_i = torch.empty(len(q), dtype=torch.int32, device="cuda")
+    out_d = torch.empty(len(q), dtype=torch.float64, device="cuda")
+    ref_idx, ref_d2 = kd.FindClosestBatch(q, 625.0)
+    for presorted in (0, 1):
+        out_i.fill_(-7)
+        rc = tdtk.lib().tdtk_find_closest_dev(kd._h, C.c_void_p(tq.data_ptr()), len(q), 625.0,
+                                              C.c_void_p(out_i.data_ptr()), C.c_void_p(out_d.data_ptr()),
+                                              presorted, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out_i.cpu().numpy(), ref_idx) and np.array_equal(out_d.cpu().numpy(), ref_d2)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_get_pt_pairs_vs_oracle(tdtk, orc, gpu, mode):
+    """SearchTree::getPtPairs with a non-trivial Source->dalignxf: indices and the PtPair list
+    bit-exact, the fused sums to rounding."""
+    rng = np.random.default_rng(8)
+    m = rng.uniform(-200, 200, (60000, 3)); m[100:160] = m[0:60]
+    A = tdtk.EulerToMatrix4([12.0, -7.0, 3.0], [0.03, -0.02, 0.04])
+    d = m[rng.permutation(len(m))[:40000]].copy(); orc.transform_points(A, d)
+    d += rng.normal(0, 0.4, d.shape)
+    nr = rng.normal(size=d.shape)
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    md2 = 4.0 if mode != 1 else 0.5
+    got = kd.getPtPairs(A, d, nr, 100, 39000, max_dist_match2=md2, pairing_mode=mode,
+                        want=tdtk.WANT_APX | tdtk.WANT_NAPX | tdtk.WANT_LUM)
+    ref = T.get_pt_pairs(A, d, nr, 100, 39000, mode, md2)
+    assert got["n"] == ref["n"] and got["n"] > 1000
+    assert np.array_equal(got["idx"], ref["idx"])
+    assert np.array_equal(got["p1"], ref["p1"]) and np.array_equal(got["p2"], ref["p2"])
+    assert np.array_equal(got["pn"], ref["pn"])
+    n = ref["n"]
+    assert _rel(got["sum"], ref["sum"]) < 1e-12
+    assert _rel(got["centroid_m"], ref["centroid_m"] / n) < 1e-13
+    assert _rel(got["centroid_d"], ref["centroid_d"] / n) < 1e-13
+    cm, cd = ref["p1"].mean(0), ref["p2"].mean(0)
+    Si = (ref["p1"] - cm).T @ (ref["p2"] - cd)
+    assert _rel(got["Si"], Si.reshape(9)) < 1e-11
+    # APX / NAPX / LUM blocks against direct evaluation on the oracle's pair list
+    p12, p2c, pn = ref["p1"] - ref["p2"], ref["p2"] - cd, ref["pn"]
+    A6 = [(p2c[:, 1] ** 2 + p2c[:, 2] ** 2).sum(), -(p2c[:, 0] * p2c[:, 1]).sum(), -(p2c[:, 0] * p2c[:, 2]).sum(),
+          (p2c[:, 0] ** 2 + p2c[:, 2] ** 2).sum(), -(p2c[:, 1] * p2c[:, 2]).sum(), (p2c[:, 0] ** 2 + p2c[:, 1] ** 2).sum()]
+    B3 = [(p12[:, 2] * p2c[:, 1] - p12[:, 1] * p2c[:, 2]).sum(), (p12[:, 0] * p2c[:, 2] - p12[:, 2] * p2c[:, 0]).sum(),
+          (p12[:, 1] * p2c[:, 0] - p12[:, 0] * p2c[:, 1]).sum()]
+    assert _rel(got["apx_A"], A6) < 1e-11 and np.abs(np.array(got["apx_B"]) - B3).max() < 1e-7 * np.abs(A6).max() ** 0.5
+    v = np.hstack([np.cross(p2c, pn), pn])
+    AA = v.T @ v
+    assert _rel(got["napx_A"], AA[np.triu_indices(6)]) < 1e-10
+    assert np.abs(np.array(got["napx_B"]) - v.sum(0)).max() < 1e-8 * np.abs(AA).max() ** 0.5
+    assert _rel(got["napx_sum"], ((p12 * pn).sum(1) ** 2).sum()) < 1e-11
+    u = (ref["p1"] + ref["p2"]) / 2.0
+    x, y, z = u.T; dx, dy, dz = p12.T
+    lum = [x.sum(), y.sum(), z.sum(), (x * x + y * y).sum(), (x * x + z * z).sum(), (y * y + z * z).sum(),
+           (x * y).sum(), (x * z).sum(), (y * z).sum(), dx.sum(), dy.sum(), dz.sum(),
+           (-z * dy + y * dz).sum(), (-y * dx + x * dy).sum(), (z * dx - x * dz).sum()]
+    assert np.abs((np.array(got["lum"]) - lum) / (np.abs(lum) + np.abs(lum).max() * 1e-6)).max() < 1e-9
+
+
+def test_scan_transform_bit_exact(tdtk, orc, gpu):
+    rng = np.random.default_rng(2)
+    p = rng.uniform(-500, 500, (50000, 3)); nr = rng.normal(size=p.shape)
+    s = tdtk.Scan([1.0, 2.0, 3.0], [0.1, -0.2, 0.3], p, nr)
+    from oracle import icp_oracle as io
+    o = io.OScan([1.0, 2.0, 3.0], [0.1, -0.2, 0.3], p, nr)
+    assert np.array_equal(s.get_xyz_reduced(), o.xyz)
+    for k in range(3):          # incremental, in place, k-fold (SURVEY N-a)
+        A = tdtk.EulerToMatrix4([0.3 * k, -0.1, 0.2], [0.01, 0.02 * k, -0.01])
+        s.transform(A); o.transform(A)
+    assert np.array_equal(s.get_xyz_reduced(), o.xyz)
+    assert np.array_equal(s.transMat, o.transMat) and np.array_equal(s.dalignxf, o.dalignxf)
+    out = np.empty((50000, 3)); on = np.empty((50000, 3))
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    assert tdtk.lib().tdtk_scan_download(s.handle, out.ctypes.data_as(dp), on.ctypes.data_as(dp)) == 0
+    assert np.array_equal(on, o.normals)
+
+
+def _dat_scans(cls, z, **kw):
+    return [cls(z["pose%03d" % k][:3], z["pose%03d" % k][3:], z["scan%03d" % k], **kw) for k in range(3)]
+
+
+def test_dat_sequential_icp_matches_reference_trace(tdtk, gpu):
+    """`bin/slam6D -d 25 -i 50 dat` (QUAT, --epsICP 1e-5): per-iteration pair counts exact, RMS
+    and the final 6-DoF pose within 1e-5 relative of the trace generated with the reference's
+    own minimizer TU (tests/golden/b1_dat_icp.json)."""
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    S = _dat_scans(tdtk.Scan, z)
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 50, quiet=True, epsilonICP=1e-5)
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        it = icp.match(S[i - 1], S[i])
+        tr = icp.last["trace"]
+        assert it == pr["iter"]
+        assert [int(r[0]) for r in tr] == [t[0] for t in pr["trace"]]
+        np.testing.assert_allclose(tr[:, 1], [t[1] for t in pr["trace"]], rtol=1e-9)
+        assert _rel(S[i].get_transMat(), pr["final_transMat"]) < POSE_RTOL
+        assert _rel(S[i].get_transMat(), pr["final_transMat"]) < 1e-9     # what we actually reach
+
+
+@pytest.mark.parametrize("algo", [1, 2, 6])
+def test_icp_vs_oracle_loop(tdtk, orc, gpu, algo):
+    """icp6D::match for QUAT / SVD / APX against the oracle loop on the bundled scans."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    S, O = _dat_scans(tdtk.Scan, z), _dat_scans(io.OScan, z)
+    cls = {1: tdtk.icp6D_QUAT, 2: tdtk.icp6D_SVD, 6: tdtk.icp6D_APX}[algo]
+    icp = tdtk.icp6D(cls(True), 25.0, 12, quiet=True, epsilonICP=1e-5)
+    S[1].mergeCoordinatesWithRoboterPosition(S[0]); O[1].mergeCoordinatesWithRoboterPosition(O[0])
+    it = icp.match(S[0], S[1])
+    oit, otr = io.match(O[0], O[1], algo, 625.0, 12, 1e-5)
+    assert it == oit
+    assert [int(r[0]) for r in icp.last["trace"]] == [t[0] for t in otr]
+    np.testing.assert_allclose(icp.last["trace"][:, 1], [t[1] for t in otr], rtol=1e-9)
+    assert _rel(S[1].get_transMat(), O[1].transMat) < 1e-9
+    assert np.abs(S[1].get_xyz_reduced() - O[1].xyz).max() < 1e-8
+
+
+def test_icp_point_to_plane_napx(tdtk, orc, gpu):
+    """-a 10 (icp6D_NAPX, the 6x6 point-to-plane system) with -z style plane projection."""
+    from oracle import icp_oracle as io
+    rng = np.random.default_rng(4)
+    g = np.stack(np.meshgrid(np.linspace(-50, 50, 120), np.linspace(-50, 50, 120)), -1).reshape(-1, 2)
+    m = np.concatenate([np.c_[g, 0.02 * g[:, 0] * np.sin(g[:, 1] / 9)], np.c_[g[:, 0], np.full(len(g), 50.0), g[:, 1] + 50],
+                        np.c_[np.full(len(g), -50.0), g[:, 0], g[:, 1] + 50]])
+    nrm = np.concatenate([np.tile([0, 0, 1.0], (len(g), 1)), np.tile([0, 1.0, 0], (len(g), 1)), np.tile([1.0, 0, 0], (len(g), 1))])
+    T = io.euler_to_matrix4([0.4, -0.3, 0.2], [0.004, -0.003, 0.005])
+    inv, _ = orc.m4inv(T)
+    d = m + rng.normal(0, 0.01, m.shape); orc.transform_points(inv, d)
+    dn = nrm.copy(); orc.transform_normals(inv, dn)
+    S = [tdtk.Scan([0, 0, 0], [0, 0, 0], m, nrm), tdtk.Scan([0, 0, 0], [0, 0, 0], d, dn)]
+    O = [io.OScan([0, 0, 0], [0, 0, 0], m, nrm), io.OScan([0, 0, 0], [0, 0, 0], d, dn)]
+    icp = tdtk.icp6D(tdtk.icp6D_NAPX(True), 3.0, 8, quiet=True, epsilonICP=1e-9)
+    it = icp.match(S[0], S[1], pairing_mode=2)
+    oit, otr = io.match(O[0], O[1], 10, 9.0, 8, 1e-9, 2)
+    assert it == oit and [int(r[0]) for r in icp.last["trace"]] == [t[0] for t in otr]
+    np.testing.assert_allclose(icp.last["trace"][:, 1], [t[1] for t in otr], rtol=1e-7, atol=1e-12)
+    assert _rel(S[1].get_transMat(), O[1].transMat) < 1e-8
+
+
+def test_lum_links_and_iteration_vs_fixture(tdtk, gpu):
+    """lum6DEuler::covarianceEuler per link and one doGraphSlam6D iteration on dat/ at the B1
+    final poses (tests/golden/b4_dat_lum.json)."""
+    from importlib import import_module
+    sl = import_module("3dtk_amd.slam6d")
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    b4 = json.load(open(os.path.join(G, "b4_dat_lum.json")))
+    S = _dat_scans(tdtk.Scan, z)
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        for a in pr["alignxf"]:
+            S[i].transform(np.array(a))
+    for L in b4["links"]:
+        Cm, CD, m, ss = sl.covarianceEuler(S[L["first"]], S[L["second"]], 625.0)
+        assert m == L["m"]
+        assert abs(ss - L["ss"]) < 1e-10 * L["ss"]
+        np.testing.assert_allclose(Cm, L["C"], rtol=1e-9, atol=1e-5)
+        np.testing.assert_allclose(CD, L["CD"], rtol=1e-7, atol=1e-7)
+    g = tdtk.Graph(3)
+    assert list(zip(g.frm, g.to)) == [(0, 1), (1, 2)]
+    ret = tdtk.lum6DEuler(None, 25.0, 25.0).doGraphSlam6D(g, S, 1)
+    assert abs(ret - b4["one_iteration"]["ret"]) < 1e-6 * max(1.0, b4["one_iteration"]["ret"])
+    for s, want in zip(S, b4["one_iteration"]["poses_after"]):
+        got = np.concatenate([s.get_rPos(), s.get_rPosTheta()])
+        assert np.abs(got - want).max() <= POSE_RTOL * np.abs(want).max() + 1e-12
+
+
+def test_full_size_icp_recovers_pose(tdtk, orc, gpu, k5):
+    """BASELINE configs[1]: synthetic 1M-vs-1M point-to-point ICP.  Pose
+    recovered to the noise floor; first-iteration pair count equals the oracle's."""
+    from oracle import icp_oracle as io
+    k, m, _ = k5
+    rng = np.random.default_rng(9)
+    T = io.euler_to_matrix4([10.0, -5.0, 3.0], [0.02, -0.03, 0.05])
+    inv, _ = orc.m4inv(T)
+    d = (m + rng.normal(0, 1.0, m.shape))[rng.permutation(len(m))]
+    orc.transform_points(inv, d)
+    ms, ds = tdtk.Scan([0, 0, 0], [0, 0, 0], m), tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+    first = tdtk.Scan.getPtPairs(ms, ds, max_dist_match2=625.0, want_idx=True)
+    oi, _ = orc.Tree(m, 20).find_closest(d, 625.0, 8)
+    assert np.array_equal(first["idx"], oi) and first["n"] == int((oi >= 0).sum())
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 100, quiet=True, epsilonICP=1e-5)
+    it = icp.match(ms, ds)
+    assert it < 99
+    assert np.abs(ds.get_transMat() - T).max() < 5e-3           # noise floor of sigma=1 on 1M points
+    assert icp.last["rms"] < 2.0

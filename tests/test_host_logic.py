@@ -1,0 +1,267 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/tdtk_hip.h declares, the
+host-side logic (tree construction order, 4x4 helpers, minimizer solves, SPD solve, graph
+construction, link sharding + all-reduce) is right -- and the compute entry points fail loudly
+when there is no GPU (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
+
+
+def test_library_exports_every_declared_symbol(tdtk):
+    hdr = open(os.path.join(ROOT, "include", "tdtk_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tdtk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = tdtk.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    capi = sys.modules["3dtk_amd._capi"]
+    assert declared == set(capi.EXPORTS)
+    assert "gfx950" in tdtk.version()
+
+
+def test_struct_layout_matches_header(tdtk):
+    capi = sys.modules["3dtk_amd._capi"]
+    # 2 u64 + (1+3+3+9+6+3+21+6+1+15+1) doubles
+    assert C.sizeof(capi.PairSums) == 16 + 8 * 69
+    assert C.sizeof(capi.IcpParams) == 40 and C.sizeof(capi.IcpResult) == 40
+
+
+def _clouds():
+    rng = np.random.default_rng(3)
+    uni = rng.uniform(-100, 100, (30000, 3))
+    dup = uni.copy(); dup[1000:1400] = dup[0:400]
+    clu = np.concatenate([rng.normal(c, 0.003, (300, 3)) for c in rng.uniform(-50, 50, (40, 3))])
+    plane = rng.uniform(-100, 100, (20000, 3)); plane[:, 2] = 0.0
+    tiny = rng.uniform(-1, 1, (7, 3))
+    one = np.array([[1.0, 2.0, 3.0]])
+    return {"uniform": uni, "duplicates": dup, "clusters": clu, "plane": plane, "tiny": tiny, "one": one}
+
+
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "tiny", "one"])
+@pytest.mark.parametrize("bucket", [1, 5, 20])
+def test_host_tree_layout_equals_oracle(tdtk, orc, name, bucket):
+    """Same tree as KDTreeImpl::create: identical leaf-order permutation and node counts."""
+    m = _clouds()[name]
+    perm, st = tdtk.host_tree_layout(m, bucket)
+    T = orc.Tree(m, bucket)
+    assert np.array_equal(perm, T.perm())
+    o = T.stats()
+    assert (st["internal"], st["leaves"], st["depth"]) == (o["internal"], o["leaves"], o["depth"])
+
+
+def test_host_tree_errors(tdtk):
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.host_tree_layout(np.zeros((0, 3)), 20)          # "cannot create kdtree with zero points"
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.host_tree_layout(np.zeros((5, 3)), 0)
+
+
+def test_m4inv_mmult_bit_exact(tdtk, orc):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        A = tdtk.EulerToMatrix4(rng.uniform(-500, 500, 3), rng.uniform(-3, 3, 3))
+        B = tdtk.EulerToMatrix4(rng.uniform(-500, 500, 3), rng.uniform(-3, 3, 3))
+        assert np.array_equal(tdtk.M4inv(A), orc.m4inv(A)[0])
+        assert np.array_equal(tdtk.MMult(A, B), orc.mmult(A, B))
+    assert np.array_equal(tdtk.M4inv(np.zeros(16)), np.eye(4).reshape(16))   # singular -> identity
+
+
+def _sums_from_pairs(capi, p1, p2, pn=None):
+    n = len(p1)
+    s = capi.PairSums()
+    s.n = n; s.n_queries = n
+    s.sum = float(((p1 - p2) ** 2).sum())
+    cm, cd = p1.mean(0), p2.mean(0)
+    for k in range(3):
+        s.centroid_m[k] = cm[k]; s.centroid_d[k] = cd[k]
+    Si = (p1 - cm).T @ (p2 - cd)
+    for k in range(9):
+        s.Si[k] = Si.reshape(9)[k]
+    p12, p2c = p1 - p2, p2 - cd
+    A = [(p2c[:, 1] ** 2 + p2c[:, 2] ** 2).sum(), -(p2c[:, 0] * p2c[:, 1]).sum(), -(p2c[:, 0] * p2c[:, 2]).sum(),
+         (p2c[:, 0] ** 2 + p2c[:, 2] ** 2).sum(), -(p2c[:, 1] * p2c[:, 2]).sum(), (p2c[:, 0] ** 2 + p2c[:, 1] ** 2).sum()]
+    B = [(p12[:, 2] * p2c[:, 1] - p12[:, 1] * p2c[:, 2]).sum(), (p12[:, 0] * p2c[:, 2] - p12[:, 2] * p2c[:, 0]).sum(),
+         (p12[:, 1] * p2c[:, 0] - p12[:, 0] * p2c[:, 1]).sum()]
+    for k in range(6):
+        s.apx_A[k] = A[k]
+    for k in range(3):
+        s.apx_B[k] = B[k]
+    if pn is not None:
+        v = np.hstack([np.cross(p2c, pn), pn])
+        AA = v.T @ v
+        q = 0
+        for r in range(6):
+            for c in range(r, 6):
+                s.napx_A[q] = AA[r, c]; q += 1
+        for r in range(6):
+            s.napx_B[r] = v[:, r].sum()
+        s.napx_sum = float((((p1 - p2) * pn).sum(1) ** 2).sum())
+    return s
+
+
+def test_align_against_reference_fixture(tdtk, orc):
+    """tdtk_align (Jacobi / Cholesky solves of the product) vs the reference's Align outputs."""
+    from oracle import icp_oracle as io
+    capi = sys.modules["3dtk_amd._capi"]
+    k6 = json.load(open(os.path.join(G, "k6_minimizers.json")))
+    d = orc.gen_mt64_uniform(k6["seed_points"], 3000, -100, 100).reshape(1000, 3)
+    T = io.euler_to_matrix4(k6["rPos"], k6["rPosTheta"])
+    mm = d.copy(); orc.transform_points(T, mm)
+    nr = orc.gen_mt64_uniform(k6["seed_normals"], 3000, -1, 1).reshape(1000, 3)
+    nr /= np.linalg.norm(nr, axis=1)[:, None]
+    noisy = mm + orc.gen_mt64_uniform(k6["noisy"]["seed_noise"], 3000, -0.5, 0.5).reshape(1000, 3)
+    for pm, exp in ((mm, k6["algos"]), (noisy, k6["noisy"]["algos"])):
+        s = _sums_from_pairs(capi, pm, d, nr)
+        for algo, cls in ((1, tdtk.icp6D_QUAT), (2, tdtk.icp6D_SVD), (6, tdtk.icp6D_APX), (10, tdtk.icp6D_NAPX)):
+            rms, a = cls(True).Align_Parallel(s)
+            np.testing.assert_allclose(a, exp[str(algo)]["alignxf"], rtol=0, atol=5e-9, err_msg=str(algo))
+            assert abs(rms - exp[str(algo)]["rms"]) <= 1e-9 * max(1.0, abs(rms))
+
+
+def test_align_degenerate_cases(tdtk):
+    capi = sys.modules["3dtk_amd._capi"]
+    rng = np.random.default_rng(1)
+    # coplanar + reflection-prone input: SVD must still return a proper rotation (icp6Dsvd.cc:103-116)
+    p2 = rng.uniform(-10, 10, (50, 3)); p2[:, 2] = 0
+    p1 = p2 * np.array([1, 1, -1]) + rng.normal(0, 1e-3, p2.shape)
+    s = _sums_from_pairs(capi, p1, p2)
+    _, a = tdtk.icp6D_SVD(True).Align_Parallel(s)
+    R = np.array([[a[0], a[4], a[8]], [a[1], a[5], a[9]], [a[2], a[6], a[10]]])
+    assert abs(np.linalg.det(R) - 1) < 1e-9
+    # APX with all data points identical -> Cholesky fails -> -1.0 ("Couldn't find transform.")
+    p2 = np.tile([[1.0, 2.0, 3.0]], (10, 1)); p1 = p2 + 0.1
+    rms, _ = tdtk.icp6D_APX(True).Align_Parallel(_sums_from_pairs(capi, p1, p2))
+    assert rms == -1.0
+
+
+def test_solve_spd(tdtk):
+    from importlib import import_module
+    sl = import_module("3dtk_amd.slam6d")
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(60, 60)); Gm = A @ A.T + 60 * np.eye(60)
+    Gm[np.abs(Gm) < 0.5] = 1e-6                                  # below the 1e-5 filter -> dropped
+    Gm = (Gm + Gm.T) / 2
+    B = rng.normal(size=60)
+    x = sl.solveSparseCholesky(Gm, B)
+    Gf = np.where(np.abs(Gm) > 1e-5, Gm, 0.0)
+    np.testing.assert_allclose(x, np.linalg.solve(Gf, B), rtol=1e-9, atol=1e-12)
+    with pytest.raises(tdtk.TdtkError):
+        sl.solveSparseCholesky(-np.eye(4), np.ones(4))
+
+
+def test_no_cpu_fallback(tdtk):
+    """Without a GPU every compute entry point must fail with TDTK_EDEVICE, not compute."""
+    if tdtk.device_count() > 0:
+        pytest.skip("a GPU is present")
+    pts = np.random.default_rng(0).uniform(-1, 1, (100, 3))
+    with pytest.raises(tdtk.TdtkError) as e:
+        tdtk.KDtree(pts)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(tdtk.TdtkError) as e:
+        _ = tdtk.Scan([0, 0, 0], [0, 0, 0], pts).handle      # residency is lazy: first use uploads
+    assert e.value.code == -2
+
+
+def test_euler_roundtrip_and_graph(tdtk):
+    from oracle import icp_oracle as io
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        p, th = rng.uniform(-100, 100, 3), rng.uniform(-1.5, 1.5, 3)
+        A = tdtk.EulerToMatrix4(p, th)
+        assert np.array_equal(A, io.euler_to_matrix4(p, th))
+        th2, p2 = tdtk.Matrix4ToEuler(A)
+        np.testing.assert_allclose(th2, th, atol=1e-12); np.testing.assert_allclose(p2, p)
+
+    class P:
+        def __init__(self, p): self.p = np.array(p, float)
+        def get_rPos(self): return self.p
+    scans = [P([800 * np.cos(a), 0, 800 * np.sin(a)]) for a in np.linspace(0, 2 * np.pi, 16, endpoint=False)]
+    g = tdtk.Graph(16, 500.0 ** 2, 5, scans)
+    links = list(zip(g.frm, g.to))
+    assert links == io.graph_links(scans, 500.0 ** 2, 5)
+    assert links[:15] == [(i, i + 1) for i in range(15)] and (0, 15) in links
+
+
+_GLOO_WORKER = textwrap.dedent("""
+    import importlib, os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    gs = importlib.import_module("3dtk_amd.graphslam")
+    from oracle import icp_oracle as io
+    rng = np.random.default_rng(0)
+    world = rng.uniform(-60, 60, (6000, 3))
+    poses = [([4.0 * k, 0.5 * k, -0.3 * k], [0.01 * k, -0.02 * k, 0.015 * k]) for k in range(5)]
+    scans = []
+    for k, (p, th) in enumerate(poses):
+        T = io.euler_to_matrix4(p, th)
+        inv, _ = io.orc.m4inv(T)
+        loc = world.copy(); io.orc.transform_points(inv, loc)
+        drift = ([p[0] + 0.3 * k, p[1] - 0.2 * k, p[2] + 0.1 * k], [th[0], th[1] + 0.002 * k, th[2]])
+        scans.append(io.OScan(drift[0], drift[1], loc + rng.normal(0, 0.02, loc.shape)))
+    links = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (0, 3), (1, 4)]
+    class Gr:
+        def getNrScans(self): return 5
+        def getNrLinks(self): return len(links)
+        def getLink(self, i, ft): return links[i][ft]
+    link_fn = lambda a, b, md2: io.covariance_euler(a, b, md2)[:2]
+    ret = gs.lum_iteration(Gr(), scans, 9.0, None, link_fn, None, io.solve_sparse_cholesky)
+    out = np.concatenate([[ret]] + [np.concatenate([s.rPos, s.rPosTheta]) for s in scans])
+    np.save(os.path.join(%(tmp)r, "rank%%d.npy" %% dist.get_rank()), out)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_lum_links_sharded_over_two_ranks_gloo(tmp_path, orc):
+    """world_size-2 gloo run of the sharded FillGB3D + all-reduce: both ranks end with the same
+    poses, equal to the single-process oracle LUM iteration."""
+    from oracle import icp_oracle as io
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT, "tmp": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    np.testing.assert_allclose(r0, r1, rtol=0, atol=1e-12)
+    # single-process oracle on the same data
+    rng = np.random.default_rng(0)
+    world = rng.uniform(-60, 60, (6000, 3))
+    poses = [([4.0 * k, 0.5 * k, -0.3 * k], [0.01 * k, -0.02 * k, 0.015 * k]) for k in range(5)]
+    scans = []
+    for k, (p, th) in enumerate(poses):
+        T = io.euler_to_matrix4(p, th)
+        inv, _ = orc.m4inv(T)
+        loc = world.copy(); orc.transform_points(inv, loc)
+        drift = ([p[0] + 0.3 * k, p[1] - 0.2 * k, p[2] + 0.1 * k], [th[0], th[1] + 0.002 * k, th[2]])
+        scans.append(io.OScan(drift[0], drift[1], loc + rng.normal(0, 0.02, loc.shape)))
+    links = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (0, 3), (1, 4)]
+    ret, _, _, _ = io.lum_iteration(links, scans, 9.0)
+    single = np.concatenate([[ret]] + [np.concatenate([s.rPos, s.rPosTheta]) for s in scans])
+    np.testing.assert_allclose(r0, single, rtol=1e-9, atol=1e-10)
+    # the iteration must actually pull the drifted poses towards the truth
+    assert abs(scans[4].rPos[0] - 16.0) < abs(16.0 + 1.2 - 16.0)
+
+
+def test_shard_links_partition(tdtk):
+    from importlib import import_module
+    gs = import_module("3dtk_amd.graphslam")
+    for world in (1, 2, 4, 8):
+        got = sorted(sum((gs.shard_links(71, r, world) for r in range(world)), []))
+        assert got == list(range(71))
+        sizes = [len(gs.shard_links(71, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,193 @@
+"""CPU tier: pin the oracle (oracle/oracle.c + oracle/icp_oracle.py) against
+  * the reference's own known-answer tests (testing/kdtree/kdtree.cc:20-99),
+  * the reference's own translation units built into oracle/_ref (when present),
+  * the committed golden fixtures (tests/golden/, generated with oracle/_ref).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+
+
+def _need_ref(orc):
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built (no reference checkout on this box)")
+
+
+# ---- KATs of testing/kdtree/kdtree.cc ------------------------------------------------------
+KAT_CLOSEST = [
+    ([[2.0, 0.0, 0.0]], None),                       # find_closest1: exactly maxdist2 away -> NULL
+    ([[1.99999999999, 0.0, 0.0]], 0),                # find_closest2
+    ([[1.5, 0.0, 0.0], [1.0, 0.0, 0.0]], 1),         # find_closest3
+]
+KAT_DIR = [
+    ([[1.0, 2.0, 0.0]], None),                       # find_closest_along_dir1
+    ([[1.0, 1.99999999999, 0.0]], 0),
+    ([[0.5, 0.1, 0.0], [1.0, 0.0, 0.0]], 1),
+    ([[-1.0, 0.0, 0.0]], 0),
+]
+
+
+@pytest.mark.parametrize("pts,want", KAT_CLOSEST)
+def test_kat_find_closest(orc, pts, want):
+    t = orc.Tree(np.array(pts), 20)
+    idx, _ = t.find_closest(np.zeros((1, 3)), 4.0)
+    assert idx[0] == (-1 if want is None else want)
+    if orc.have_ref():
+        assert orc.RefTree(np.array(pts), 20).find_closest(np.zeros((1, 3)), 4.0)[0] == idx[0]
+
+
+@pytest.mark.parametrize("pts,want", KAT_DIR)
+def test_kat_find_closest_along_dir(orc, pts, want):
+    t = orc.Tree(np.array(pts), 20)
+    idx, _ = t.find_closest_along_dir(np.zeros((1, 3)), np.array([[1.0, 0.0, 0.0]]), 4.0)
+    assert idx[0] == (-1 if want is None else want)
+    if orc.have_ref():
+        r = orc.RefTree(np.array(pts), 20).find_closest_along_dir(np.zeros((1, 3)), np.array([[1.0, 0, 0]]), 4.0)
+        assert r[0] == idx[0]
+
+
+def _clouds():
+    rng = np.random.default_rng(3)
+    uni = rng.uniform(-100, 100, (30000, 3))
+    dup = uni.copy(); dup[1000:1400] = dup[0:400]            # exact duplicates -> ties
+    clu = np.concatenate([rng.normal(c, 0.003, (300, 3)) for c in rng.uniform(-50, 50, (40, 3))])  # <0.01 boxes
+    plane = rng.uniform(-100, 100, (20000, 3)); plane[:, 2] = 0.0
+    tiny = rng.uniform(-1, 1, (7, 3))
+    grid = np.stack(np.meshgrid(*[np.arange(12.0)] * 3), -1).reshape(-1, 3)      # many equal distances
+    return {"uniform": uni, "duplicates": dup, "clusters": clu, "plane": plane, "tiny": tiny, "grid": grid}
+
+
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "tiny", "grid"])
+@pytest.mark.parametrize("bucket", [1, 20])
+def test_oracle_tree_equals_reference(orc, name, bucket):
+    _need_ref(orc)
+    m = _clouds()[name]
+    rng = np.random.default_rng(11)
+    q = np.concatenate([m[rng.integers(0, len(m), 2000)] + rng.normal(0, 0.5, (2000, 3)),
+                        m[:500],                                     # exact hits (d2 == 0, ties on dups)
+                        rng.uniform(-120, 120, (1500, 3))])
+    if name == "grid":
+        q = np.concatenate([q, m[:500] + 0.5])                      # equidistant to 8 corners
+    T, R = orc.Tree(m, bucket), orc.RefTree(m, bucket)
+    for md2 in (0.25, 25.0, 1e18):
+        a, _ = T.find_closest(q, md2)
+        b = R.find_closest(q, md2)
+        assert np.array_equal(a, b), (name, bucket, md2)
+    d = rng.normal(size=(len(q), 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    a, _ = T.find_closest_along_dir(q[:800], d[:800], 4.0)
+    assert np.array_equal(a, R.find_closest_along_dir(q[:800], d[:800], 4.0))
+
+
+def test_k4_fixture(orc):
+    z = np.load(os.path.join(G, "k4_random.npz"))
+    T = orc.Tree(z["model"], 20)
+    for q, e, md2 in zip(z["queries"], z["expected"], z["maxdist2"]):
+        assert np.array_equal(T.find_closest(q, md2)[0], e)
+
+
+def test_k5_hashes(orc):
+    k5 = json.load(open(os.path.join(G, "k5_hashes.json")))
+    M = k5["M"]
+    s = orc.gen_mt64_uniform(k5["seed"], 6 * M, k5["lo"], k5["hi"])
+    m, q = s[:3 * M].reshape(M, 3).copy(), s[3 * M:].reshape(M, 3).copy()
+    T = orc.Tree(m, k5["bucket"])
+    assert T.stats() == k5["tree"]
+    for c in k5["cases"]:
+        idx, _, cnt = T.find_closest(q, c["maxdist2"], min(8, orc.lib().orc_max_threads()), True)
+        assert int((idx >= 0).sum()) == c["found"]
+        assert "0x%x" % orc.k5_hash(idx) == c["hash"]
+        assert idx[:32].tolist() == c["first32"] and idx[-32:].tolist() == c["last32"]
+        np.testing.assert_allclose(np.array(cnt) / M, c["visits_per_query"], rtol=1e-12)
+
+
+def test_k6_minimizers(orc):
+    from oracle import icp_oracle as io
+    k6 = json.load(open(os.path.join(G, "k6_minimizers.json")))
+    d = orc.gen_mt64_uniform(k6["seed_points"], 3000, -100, 100).reshape(1000, 3)
+    T = io.euler_to_matrix4(k6["rPos"], k6["rPosTheta"])
+    mm = d.copy(); orc.transform_points(T, mm)
+    nr = orc.gen_mt64_uniform(k6["seed_normals"], 3000, -1, 1).reshape(1000, 3)
+    nr /= np.linalg.norm(nr, axis=1)[:, None]
+    cd = d.mean(axis=0)
+    for tag, pm in (("clean", mm), ("noisy", mm + orc.gen_mt64_uniform(k6["noisy"]["seed_noise"], 3000, -0.5, 0.5).reshape(1000, 3))):
+        exp = k6["algos"] if tag == "clean" else k6["noisy"]["algos"]
+        cm = pm.mean(axis=0)
+        for algo in (1, 2, 6, 10):
+            rms, a = io.align(algo, pm, d, cm, cd, nr)
+            np.testing.assert_allclose(a, exp[str(algo)]["alignxf"], rtol=0, atol=2e-9, err_msg="%s %d" % (tag, algo))
+            assert abs(rms - exp[str(algo)]["rms"]) <= 1e-9 * max(1.0, abs(rms))
+
+
+def test_align_parallel_quat_vs_reference(orc):
+    _need_ref(orc)
+    from oracle import icp_oracle as io
+    rng = np.random.default_rng(5)
+    d = rng.uniform(-100, 100, (8000, 3))
+    T = io.euler_to_matrix4([3, -2, 1], [0.03, 0.01, -0.02])
+    m = d.copy(); orc.transform_points(T, m); m += rng.normal(0, 0.3, m.shape)
+    n = np.full(8, 1000, np.uint32)
+    cm = np.array([m[i * 1000:(i + 1) * 1000].mean(0) for i in range(8)])
+    cd = np.array([d[i * 1000:(i + 1) * 1000].mean(0) for i in range(8)])
+    s = np.array([((m[i * 1000:(i + 1) * 1000] - d[i * 1000:(i + 1) * 1000]) ** 2).sum() for i in range(8)])
+    Si = np.array([((m[i * 1000:(i + 1) * 1000] - cm[i]).T @ (d[i * 1000:(i + 1) * 1000] - cd[i])).reshape(9)
+                   for i in range(8)])
+    ra, re = orc.ref_align_parallel(1, n, s, cm, cd, Si)
+    rms, a = io.align_parallel_quat(n, s, cm, cd, Si)
+    np.testing.assert_allclose(a, ra, atol=1e-10)
+    assert abs(rms - re) < 1e-12 * re
+
+
+def test_m4inv_mmult_roundtrip(orc):
+    from oracle import icp_oracle as io
+    A = io.euler_to_matrix4([10, -5, 3], [0.02, -0.03, 0.05])
+    inv, ok = orc.m4inv(A)
+    assert ok
+    np.testing.assert_allclose(orc.mmult(A, inv), np.eye(4).reshape(16), atol=1e-12)
+    sing, ok = orc.m4inv(np.zeros(16))
+    assert not ok and np.array_equal(sing, np.eye(4).reshape(16))     # globals.icc:765-769
+
+
+def test_b1_dat_icp_trace(orc):
+    """The oracle loop with the numpy minimizer reproduces the committed trace that was
+    generated with the REFERENCE minimizer (and SURVEY appendix B1)."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    S = [io.OScan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], z["scan%03d" % k]) for k in range(3)]
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        it, tr = io.match(S[i - 1], S[i], 1, 625.0, 50, 1e-5)
+        assert it == pr["iter"]
+        assert [t[0] for t in tr] == [t[0] for t in pr["trace"]]
+        np.testing.assert_allclose([t[1] for t in tr], [t[1] for t in pr["trace"]], rtol=1e-10)
+        np.testing.assert_allclose(S[i].transMat, pr["final_transMat"], rtol=1e-9, atol=1e-9)
+    # SURVEY appendix B1 known answers
+    assert b1["pairs"][0]["trace"][0][0] == 73343 and abs(b1["pairs"][0]["trace"][0][1] - 5.9733177799) < 1e-9
+    assert b1["pairs"][0]["iter"] == 38 and b1["pairs"][1]["iter"] == 49
+
+
+def test_b4_lum_links(orc):
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    b4 = json.load(open(os.path.join(G, "b4_dat_lum.json")))
+    S = [io.OScan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], z["scan%03d" % k]) for k in range(3)]
+    for pr in b1["pairs"]:       # replay the recorded alignxf sequence (bit-identical point motion)
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        for a in pr["alignxf"]:
+            S[i].transform(np.array(a))
+    for L in b4["links"]:
+        C, CD, m, ss, D = io.covariance_euler(S[L["first"]], S[L["second"]], 625.0)
+        assert m == L["m"]
+        np.testing.assert_allclose(ss, L["ss"], rtol=1e-10)
+        np.testing.assert_allclose(C, L["C"], rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(CD, L["CD"], rtol=1e-8, atol=1e-8)
+    # SURVEY appendix B4
+    assert b4["links"][0]["m"] == 73335 and abs(b4["links"][0]["ss"] - 17.34408661) < 1e-7
