@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -109,7 +110,41 @@ struct LaneStack {
 // ------------------------------------------------------------------------------------------
 // 1-NN within radius: exact replay of KDTreeImpl::_FindClosest (kdTreeImpl.h:345-383)
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, bool COUNT>
+typedef const double __attribute__((address_space(4))) * const_d_ptr;  // constant AS -> s_load
+typedef const uint32_t __attribute__((address_space(4))) * const_u_ptr;
+
+// one internal node of _FindClosest (kdTreeImpl.h:360-382).  Returns the near child, or sets
+// need_pop when the box test prunes the node.  Inlined twice: once with the node in SGPRs
+// (wave-uniform visit) and once with per-lane VGPR values.
+template <int BLOCK, int SD>
+__device__ __forceinline__ uint32_t visit_node(const double cx, const double cy, const double cz,
+                                               const double hx, const double hy, const double hz,
+                                               const double splitval, const uint32_t c1,
+                                               const uint32_t c2, const double qx, const double qy,
+                                               const double qz, const double best,
+                                               LaneStack<BLOCK, SD>& st, bool& need_pop)
+{
+  const double ax = fabs(qx - cx) - hx;
+  const double ay = fabs(qy - cy) - hy;
+  const double az = fabs(qz - cz) - hz;
+  const double ab = (ax < ay) ? ay : ax;  // std::max(ax, ay)
+  const double ap = (ab < az) ? az : ab;
+  if (ap >= 0.0 && ap * ap >= best) {  // kdTreeImpl.h:362-368
+    need_pop = true;
+    return REF_DONE;
+  }
+  const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
+  const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
+  const double myd = splitval - qa;  // kdTreeImpl.h:371
+  const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
+  const bool first = (myd >= 0.0);
+  const uint32_t far = first ? r2 : r1;
+  const double m2 = myd * myd;
+  if (m2 < best) st.push(far, m2);
+  return first ? r1 : r2;
+}
+
+template <int BLOCK, int SD, bool COUNT, bool UNI>
 __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, const double qy,
                                           const double qz, double& best, int& bk,
                                           LaneStack<BLOCK, SD>& st, unsigned long long* cnt)
@@ -123,30 +158,29 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
   for (;;) {
     // ---- phase 1: walk internal nodes until this lane holds a leaf (or is finished) ----
     while (!(cur & REF_LEAF)) {
-      const double4 n0 = nodes[(size_t)cur * 2];      // cx cy cz hx
-      const double4 n1 = nodes[(size_t)cur * 2 + 1];  // hy hz splitval {c1,c2}
       if (COUNT) ++c_int;
-      const double ax = fabs(qx - n0.x) - n0.w;
-      const double ay = fabs(qy - n0.y) - n1.x;
-      const double az = fabs(qz - n0.z) - n1.y;
-      const double ab = (ax < ay) ? ay : ax;  // std::max(ax, ay)
-      const double ap = (ab < az) ? az : ab;
-      uint32_t next = REF_DONE;
       bool need_pop = false;
-      if (ap >= 0.0 && ap * ap >= best) {  // kdTreeImpl.h:362-368
-        need_pop = true;
+      uint32_t next;
+      bool uniform = false;
+      uint32_t ucur = 0;
+      if (UNI) {
+        // spatially sorted queries walk the same upper nodes: when every active lane of the
+        // wave holds the same node, fetch its 64 bytes once through the scalar cache (one
+        // s_load_dwordx16, operands stay in SGPRs) instead of 64 lanes x 4 vector loads
+        ucur = __builtin_amdgcn_readfirstlane(cur);
+        uniform = __all(cur == ucur);
+      }
+      if (UNI && uniform) {
+        const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+        const_u_ptr su = (const_u_ptr)(sn + 7);
+        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx,
+                                     qy, qz, best, st, need_pop);
       } else {
-        const uint32_t c1 = (uint32_t)__double2loint(n1.w);
-        const uint32_t c2 = (uint32_t)__double2hiint(n1.w);
-        const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
-        const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
-        const double myd = n1.z - qa;  // splitval - p[axis]
-        const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
-        const bool first = (myd >= 0.0);
-        next = first ? r1 : r2;
-        const uint32_t far = first ? r2 : r1;
-        const double m2 = myd * myd;
-        if (m2 < best) st.push(far, m2);
+        const double4 n0 = nodes[(size_t)cur * 2];      // cx cy cz hx
+        const double4 n1 = nodes[(size_t)cur * 2 + 1];  // hy hz splitval {c1,c2}
+        next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z,
+                                     (uint32_t)__double2loint(n1.w), (uint32_t)__double2hiint(n1.w),
+                                     qx, qy, qz, best, st, need_pop);
       }
       if (need_pop) {
         next = REF_DONE;
@@ -161,7 +195,9 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
     }
     if (cur == REF_DONE) break;
 
-    // ---- phase 2: scan the leaf bucket in stored order, strict '<' (kdTreeImpl.h:351-357)
+    // ---- phase 2: scan the leaf bucket in stored order, strict '<' (kdTreeImpl.h:351-357).
+    // Four points per round trip; the last group re-reads the final point instead of running a
+    // scalar tail (a repeated point can never pass the strict '<' a second time).
     {
       const uint32_t v = cur & REF_VAL;
       int start, count;
@@ -174,9 +210,10 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
       }
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
       const double4* __restrict__ P = pts + start;
-      int i = 0;
-      for (; i + 4 <= count; i += 4) {
-        const double4 p0 = P[i], p1 = P[i + 1], p2 = P[i + 2], p3 = P[i + 3];
+      const int last = count - 1;
+      for (int i = 0; i < count; i += 4) {
+        const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
+        const double4 p0 = P[i], p1 = P[i1], p2 = P[i2], p3 = P[i3];
         double dx, dy, dz;
         dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
         const double d0 = dx * dx + dy * dy + dz * dz;
@@ -187,15 +224,9 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
         dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
         const double d3 = dx * dx + dy * dy + dz * dz;
         if (d0 < best) { best = d0; bk = start + i; }
-        if (d1 < best) { best = d1; bk = start + i + 1; }
-        if (d2 < best) { best = d2; bk = start + i + 2; }
-        if (d3 < best) { best = d3; bk = start + i + 3; }
-      }
-      for (; i < count; i++) {
-        const double4 p = P[i];
-        const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-        const double d = dx * dx + dy * dy + dz * dz;
-        if (d < best) { best = d; bk = start + i; }
+        if (d1 < best) { best = d1; bk = start + i1; }
+        if (d2 < best) { best = d2; bk = start + i2; }
+        if (d3 < best) { best = d3; bk = start + i3; }
       }
     }
     // pop the next pending far child that still passes sqr(myd) < closest_d2
@@ -284,8 +315,8 @@ __device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx,
 // ------------------------------------------------------------------------------------------
 // k_search: the hot kernel
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, bool COUNT, int DIRMODE>
-__global__ void __launch_bounds__(BLOCK) k_search(const SearchArgs a)
+template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
 {
   __shared__ double lds_m2[SD][BLOCK];
   __shared__ uint32_t lds_ref[SD][BLOCK];
@@ -336,7 +367,7 @@ __global__ void __launch_bounds__(BLOCK) k_search(const SearchArgs a)
     double best = a.maxd2;
     int bk = -1;
     if (DIRMODE) kd_search_dir<BLOCK, SD>(a.T, sx, sy, sz, ux, uy, uz, best, bk, st);
-    else kd_search<BLOCK, SD, COUNT>(a.T, sx, sy, sz, best, bk, st, a.counters);
+    else kd_search<BLOCK, SD, COUNT, UNI>(a.T, sx, sy, sz, best, bk, st, a.counters);
     a.kpos[i] = bk;
     if (a.d2) a.d2[i] = best;
   }
@@ -460,14 +491,20 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   }
 }
 
-// fixed-order reduction of the per-workgroup rows: one thread per accumulator column
-__global__ void k_final(const double* __restrict__ partials, int rows, double* __restrict__ out)
+// fixed-order reduction of the per-workgroup rows: one 256-thread workgroup per accumulator
+// column; thread t adds rows t, t+256, ... then wave64 shuffles and a 4-entry LDS pass.  The
+// association is fixed by (rows, 256), so repeated runs give bit-identical sums.
+__global__ void __launch_bounds__(256) k_final(const double* __restrict__ partials, int rows,
+                                               double* __restrict__ out)
 {
-  const int k = threadIdx.x;
-  if (k >= ACC_TOTAL) return;
+  __shared__ double red[4];
+  const int k = blockIdx.x;
   double s = 0.0;
-  for (int r = 0; r < rows; r++) s += partials[(size_t)r * ACC_TOTAL + k];
-  out[k] = s;
+  for (int r = threadIdx.x; r < rows; r += 256) s += partials[(size_t)r * ACC_TOTAL + k];
+  s = wave_sum(s);
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[k] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -587,7 +624,24 @@ static int num_cu()
 }
 
 constexpr int SEARCH_BLOCK = 256;
-constexpr int SEARCH_SD = 8;
+constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest LDS stack in use
+
+// Tuning variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>, default below):
+//   0: LDS stack 8 deep, vector node loads, default occupancy      (the first working kernel)
+//   1: LDS stack 4 deep, 8 waves/SIMD
+//   2: LDS stack 8 deep + wave-uniform scalar node loads
+//   3: LDS stack 4 deep, 8 waves/SIMD + wave-uniform scalar node loads
+//   4: LDS stack 4 deep, default occupancy + wave-uniform scalar node loads
+static int search_variant()
+{
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TDTK_SEARCH_VARIANT");
+    v = e ? atoi(e) : 4;
+    if (v < 0 || v > 4) v = 4;
+  }
+  return v;
+}
 
 uint32_t search_grid(size_t n)
 {
@@ -600,17 +654,25 @@ uint32_t search_grid(size_t n)
   if (nb < 8) nb = 8;
   return (uint32_t)nb;
 }
-int search_lds_depth() { return SEARCH_SD; }
+int search_lds_depth() { return SEARCH_SD_MIN; }
 int search_block() { return SEARCH_BLOCK; }
 
 hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool count, hipStream_t s)
 {
   if (a.n == 0) return hipSuccess;
   dim3 g(grid), b(SEARCH_BLOCK);
-  if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, false, 1>), g, b, 0, s, a);
-  else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, false, 2>), g, b, 0, s, a);
-  else if (count) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, true, 0>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, SEARCH_SD, false, 0>), g, b, 0, s, a);
+  if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 1, false, 1>), g, b, 0, s, a);
+  else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
+  else if (count) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
+  else {
+    switch (search_variant()) {
+      case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
+      case 1: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, false, 8>), g, b, 0, s, a); break;
+      case 2: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, true, 1>), g, b, 0, s, a); break;
+      case 3: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 8>), g, b, 0, s, a); break;
+      default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
+    }
+  }
   return hipGetLastError();
 }
 
@@ -645,7 +707,7 @@ hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pm
     case 6: launch_accum_w<6>(a, grid, pmode, s); break;
     default: launch_accum_w<7>(a, grid, pmode, s); break;
   }
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(128), 0, s, a.partials, (int)grid, d_out);
+  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, a.partials, (int)grid, d_out);
   return hipGetLastError();
 }
 

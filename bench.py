@@ -36,6 +36,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch from the committed PMC passes of this same command
+    (profiles/r01_pmc_bench.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled
+    per the gfx950 correction, calibrated on k_transform's known 24 MB stream)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")))
+        k = j["kernels"][kernel]
+        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
+    except Exception:
+        return None
+
+
 def algorithmic_bytes_per_query(n_int, n_pts):
     """24 B query + 64 B per internal node visited + 24 B per leaf point tested +
     4 B index out (properties of tree/query/radius, independent of the implementation)."""
@@ -46,9 +58,8 @@ def algorithmic_bytes_per_query(n_int, n_pts):
 # synthetic inputs
 # --------------------------------------------------------------------------------------------
 def make_icp_pair(n, seed=42):
-    from oracle import orc      # input generator only (the K5 stream of the golden vectors)
-    m = orc.gen_mt64_uniform(seed, 3 * n, -1000.0, 1000.0).reshape(n, 3).copy()
-    rng = np.random.default_rng(seed + 1)
+    rng = np.random.default_rng(seed)
+    m = rng.uniform(-1000.0, 1000.0, (n, 3))
     tdtk = importlib.import_module("3dtk_amd")
     T = tdtk.EulerToMatrix4([10.0, -5.0, 3.0], [0.02, -0.03, 0.05])
     Tinv = tdtk.M4inv(T)
@@ -126,7 +137,7 @@ def max_over_ranks(x, world, local):
     return float(t.item())
 
 
-def cpu_baseline_nn(model, queries, maxd2, budget_s=12.0):
+def cpu_baseline_nn(model, queries, maxd2, budget_s=10.0):
     """The reference's KDtreeIndexed::FindClosest (oracle/_ref, kind "reference") or the C
     restatement (kind "port") on this box's host cores, bounded sample of the same workload."""
     from oracle import orc
@@ -142,7 +153,7 @@ def cpu_baseline_nn(model, queries, maxd2, budget_s=12.0):
     t0 = time.perf_counter(); run(queries[:200000], 1); t1 = time.perf_counter() - t0
     one = 200000 / t1
     reps, t_all = 0, 0.0
-    while t_all < budget_s and reps < 8:
+    while t_all < budget_s and reps < 400:
         t0 = time.perf_counter(); run(queries, threads); t_all += time.perf_counter() - t0; reps += 1
     allc = reps * len(queries) / t_all
     return {"value": allc, "unit": "NN correspondences/s", "cores": threads, "kind": kind,
@@ -178,11 +189,26 @@ def bench_icp(args, rank, world, local):
     last = icp.last
     pose_err = float(np.abs(data.get_transMat() - T).max())
 
-    # algorithmic bytes of THIS query set (visit counters are exact properties of tree+queries)
+    # Algorithmic bytes of exactly the timed launches: replay the recorded alignxf sequence on a
+    # 1-in-10 sub-sample (same incremental device transform) and count, per timed iteration, the
+    # internal nodes / leaf points the reference traversal visits (exact properties of tree +
+    # queries + radius, independent of the implementation).
+    sub = np.ascontiguousarray(d[::10])
+    rep = tdtk.Scan([0, 0, 0], [0, 0, 0], sub, device=local)
+    seq = [r[2:] for r in icp_w.last["trace"]] + [r[2:] for r in last["trace"]]
+    n_warm = len(icp_w.last["trace"])
+    bqs, vis = [], []
+    for j in range(n_warm + steps):
+        if j >= n_warm:
+            c_int, c_leaf, c_pts = tree.count_visits(rep.get_xyz_reduced(), 625.0)
+            vis.append((c_int / len(sub), c_leaf / len(sub), c_pts / len(sub)))
+            bqs.append(algorithmic_bytes_per_query(vis[-1][0], vis[-1][2]))
+        rep.transform(seq[j])
+    bq = float(np.mean(bqs))
+    vis = np.mean(np.array(vis), axis=0)
+    c_int, c_leaf, c_pts = vis * len(sub)
+    samp = sub
     cur = data.get_xyz_reduced()
-    samp = cur[:: max(1, n // 200000)]
-    c_int, c_leaf, c_pts = tree.count_visits(samp, 625.0)
-    bq = algorithmic_bytes_per_query(c_int / len(samp), c_pts / len(samp))
     k_ms = last["nn_ms"] / steps                          # HIP-event time of k_search, per launch
     achieved = bq * n / (k_ms * 1e-3) / 1e9
     # parity spot check outside the timed region
@@ -204,7 +230,7 @@ def bench_icp(args, rank, world, local):
         "icp_iters_per_s": steps / dt,
         "pairs_last": last["pairs"], "rms_last": last["rms"], "pose_max_abs_err": pose_err,
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_search"),
                      "kernel_ms": k_ms, "bytes_per_query": bq,
                      "visits_per_query": {"internal": c_int / len(samp), "leaves": c_leaf / len(samp), "points": c_pts / len(samp)},
                      "nn_per_s_kernel_only": n / (k_ms * 1e-3)},

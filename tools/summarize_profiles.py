@@ -1,0 +1,55 @@
+"""Turn the rocprofv3 CSVs merged back under gpurun_out/<tag>/ into the small, tracked
+summaries under profiles/:  python tools/summarize_profiles.py <tag> <round-prefix>"""
+import collections, csv, json, os, sys
+tag, pre = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+
+def short(n):
+    n = n.split("(")[0].replace("void ", "").replace("tdtk::", "")
+    if n.startswith("k_search<"):
+        a = [t.strip() for t in n[len("k_search<"):-1].split(",")]
+        # <BLOCK, SD, COUNT, DIRMODE, UNI, WPS>
+        if a[2] == "true":
+            return "k_search_count(instrumented, not timed)"
+        if a[3] != "0":
+            return "k_search_dir"
+        return "k_search"
+    return n
+
+# --- kernel stats (from the kernel trace of the --stats run)
+rows = list(csv.DictReader(open(os.path.join(src, "stats", "p_kernel_trace.csv"))))
+agg = collections.defaultdict(list)
+for r in rows:
+    agg[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+tot = sum(sum(v) for v in agg.values())
+with open(os.path.join("profiles", pre + "_kernel_stats.csv"), "w") as f:
+    f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        f.write("%s,%d,%.3f,%.3f,%.3f,%.3f,%.2f\n" % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
+stats_file = os.path.join(src, "stats", "p_kernel_stats.csv")
+if os.path.exists(stats_file):
+    open(os.path.join("profiles", pre + "_rocprofv3_kernel_stats_raw.csv"), "w").write(open(stats_file).read())
+
+# --- PMC passes
+pmc = {"command": "python bench.py --steps 100 --warmup 10 --no-cpu", "kernels": {},
+       "note": "per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE "
+               "reads 1/2 of the streamed bytes (calibrated: k_transform reads 3 x 8 MB = 23437.5 KiB, reports ~11738)"}
+for p in ("fetch", "write", "sq1", "sq2"):
+    fn = os.path.join(src, p, "p_counter_collection.csv")
+    if not os.path.exists(fn):
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in acc.items():
+        name = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
+        pmc["kernels"].setdefault(k, {})[name] = sum(v) / len(v)
+        pmc["kernels"][k]["dispatches_" + p] = len(v)
+json.dump(pmc, open(os.path.join("profiles", pre + "_pmc_bench.json"), "w"), indent=1, sort_keys=True)
+for p in ("stats",):
+    fn = os.path.join(src, p + ".json")
+    if os.path.exists(fn):
+        open(os.path.join("profiles", pre + "_bench_under_rocprof.json"), "w").write(open(fn).read())
+print(open(os.path.join("profiles", pre + "_kernel_stats.csv")).read())
+print(json.dumps(pmc["kernels"].get("k_search", {}), indent=1))
