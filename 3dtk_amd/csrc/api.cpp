@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -719,21 +720,42 @@ int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_
                       double* pn_out, tdtk_pair_sums* sums)
 {
   if (!t || !A || !xyz_r || !sums || end < start) { set_error("bad argument"); return TDTK_EINVAL; }
+  // rnd > 1: "take about 1/rnd-th of the numbers only" (searchTree.cc:118, globals.icc:607-610):
+  // one std::rand() per candidate, consumed in index order like a serial (non-OpenMP) reference
+  // build does.  The keep-mask is drawn on the host; only the kept queries go to the GPU.
+  std::vector<double> kept_xyz, kept_nrm;
+  std::vector<size_t> kept_pos;
+  const double* q_xyz = xyz_r + 3 * start;
+  const double* q_nrm = normal_r ? normal_r + 3 * start : nullptr;
+  size_t n = end - start;
+  const size_t n_all = n;
   if (rnd > 1) {
-    set_error("rnd > 1 (std::rand() sub-sampling) is not reproducible and not supported on the device path");
-    return TDTK_EUNSUP;
+    for (size_t i = 0; i < n_all; i++) {
+      const int r = (int)((double)rnd * (double)std::rand() / (RAND_MAX + 1.0));
+      if (r != 0) continue;
+      kept_pos.push_back(i);
+      for (int k = 0; k < 3; k++) kept_xyz.push_back(q_xyz[3 * i + k]);
+      if (q_nrm) for (int k = 0; k < 3; k++) kept_nrm.push_back(q_nrm[3 * i + k]);
+    }
+    n = kept_pos.size();
+    q_xyz = kept_xyz.data();
+    if (q_nrm) q_nrm = kept_nrm.data();
+    if (idx_out) for (size_t i = 0; i < n_all; i++) idx_out[i] = -1;
   }
-  const size_t n = end - start;
   tdtk_scan* sc = nullptr;
-  int rc = tdtk_scan_create(xyz_r + 3 * start, normal_r ? normal_r + 3 * start : nullptr, n, t->device, &sc);
+  int rc = tdtk_scan_create(q_xyz, q_nrm, n, t->device, &sc);
   if (rc) return rc;
   std::vector<int32_t> idx_local;
-  int32_t* idx = idx_out;
+  int32_t* idx = nullptr;
   const bool want_pairs = p1_out || p2_out || pn_out;
-  if (!idx && want_pairs) { idx_local.resize(n); idx = idx_local.data(); }
+  if (rnd > 1 || (!idx_out && want_pairs)) { idx_local.resize(n ? n : 1); idx = idx_local.data(); }
+  else idx = idx_out;
   rc = tdtk_scan_pairs(t, A, sc, pmode, maxd2, want, lum_D, idx, sums);
   tdtk_scan_destroy(sc);
   if (rc) return rc;
+  sums->n_queries = n;
+  if (rnd > 1 && idx_out)
+    for (size_t i = 0; i < n; i++) idx_out[kept_pos[i]] = idx[i];
   if (want_pairs) {
     // the PtPair(s, t, normal) list of searchTree.cc:179-180, in query order (host, optional)
     double inv[16];
@@ -742,13 +764,13 @@ int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_
     for (size_t i = 0; i < n; i++) {
       if (idx[i] < 0) continue;
       const double* cpt = t->xyz_h.data() + 3 * (size_t)idx[i];
-      const double* tt = xyz_r + 3 * (start + i);
+      const double* tt = q_xyz + 3 * i;
       double s[3], nn[3] = {0, 0, 0};
       s[0] = cpt[0] * A[0] + cpt[1] * A[4] + cpt[2] * A[8] + A[12];
       s[1] = cpt[0] * A[1] + cpt[1] * A[5] + cpt[2] * A[9] + A[13];
       s[2] = cpt[0] * A[2] + cpt[1] * A[6] + cpt[2] * A[10] + A[14];
-      if (normal_r && (pmode != 0 || (want & TDTK_WANT_NAPX))) {
-        const double* nr = normal_r + 3 * (start + i);
+      if (q_nrm && (pmode != 0 || (want & TDTK_WANT_NAPX))) {
+        const double* nr = q_nrm + 3 * i;
         const double len = std::sqrt(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
         nn[0] = nr[0] / len; nn[1] = nr[1] / len; nn[2] = nr[2] / len;
         if (pmode == 1) {

@@ -31,7 +31,7 @@ extern "C" {
 #define TDTK_EDEVICE (-2)  /* no usable gfx950 device / HIP runtime error             */
 #define TDTK_ENOMEM (-3)   /* host or device allocation failed                        */
 #define TDTK_ESOLVE (-4)   /* minimizer could not be solved (Cholesky failed, ...)    */
-#define TDTK_EUNSUP (-5)   /* valid in the reference but not supported here (rnd > 1) */
+#define TDTK_EUNSUP (-5)   /* valid in the reference but not supported on this entry point */
 
 typedef struct tdtk_tree tdtk_tree; /* model-scan search tree, resident in HBM   */
 typedef struct tdtk_scan tdtk_scan; /* data-scan points (+normals), resident in HBM */
@@ -128,8 +128,9 @@ int tdtk_find_closest_along_dir(const tdtk_tree* t, const double* q, const doubl
 /* ---- SearchTree::getPtPairs, DataXYZ overload (src/slam6d/searchTree.cc:92-189), fused
  * with the per-thread Si pass of icp6D::match (icp6D.cc:170-191) and the APX/NAPX/LUM
  * pair loops.  Host buffers.  xyz_r = Target "xyz reduced" [*][3]; normal_r nullable
- * unless pairing_mode != 0 or TDTK_WANT_NAPX.  rnd must be <= 1 (TDTK_EUNSUP otherwise,
- * SURVEY N-d).  idx_out (nullable) [end-start]: model index per query or -1.
+ * unless pairing_mode != 0 or TDTK_WANT_NAPX.  rnd > 1 draws the reference's keep-mask on the
+ * host (one std::rand() per candidate in index order, i.e. serial-build semantics; SURVEY N-d)
+ * and sends only the kept queries.  idx_out (nullable) [end-start]: model index per query or -1.
  * p1_out/p2_out/pn_out (nullable, [end-start][3]): compact pair list in query order, the
  * PtPair(s, t, normal) the reference pushes (for unmodified minimizers).
  * sums is overwritten (the reference accumulates into sum/centroids; callers add).     */

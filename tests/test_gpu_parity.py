@@ -44,8 +44,8 @@ def test_errors(tdtk, gpu):
     idx, d2 = kd.FindClosestBatch(np.zeros((0, 3)), 1.0)   # empty batch
     assert len(idx) == 0
     with pytest.raises(tdtk.TdtkError) as e:
-        kd.getPtPairs(tdtk.M4identity(), np.zeros((4, 3)), rnd=5)
-    assert e.value.code == -5                             # rnd > 1 unsupported (SURVEY N-d)
+        tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 5, rnd=5)  # resident-scan loop: rnd > 1 unsupported
+    assert e.value.code == -5
     with pytest.raises(tdtk.TdtkError):
         kd.getPtPairs(tdtk.M4identity(), np.zeros((4, 3)), pairing_mode=2)   # needs normals
 
@@ -213,6 +213,28 @@ def test_get_pt_pairs_vs_oracle(tdtk, orc, gpu, mode):
            (x * y).sum(), (x * z).sum(), (y * z).sum(), dx.sum(), dy.sum(), dz.sum(),
            (-z * dy + y * dz).sum(), (-y * dx + x * dy).sum(), (z * dx - x * dz).sum()]
     assert np.abs((np.array(got["lum"]) - lum) / (np.abs(lum) + np.abs(lum).max() * 1e-6)).max() < 1e-9
+
+
+def test_get_pt_pairs_rnd_subsampling(tdtk, orc, gpu):
+    """-R 5 (README config 1): keep-mask = (int)(rnd*rand()/(RAND_MAX+1.0)) == 0 per candidate in
+    index order (searchTree.cc:118, globals.icc:607-610), serial-build semantics."""
+    import ctypes as C
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    rng = np.random.default_rng(12)
+    m = rng.uniform(-50, 50, (20000, 3))
+    q = m[rng.permutation(len(m))[:9000]] + rng.normal(0, 0.2, (9000, 3))
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    libc.srand(1234)
+    got = kd.getPtPairs(tdtk.M4identity(), q, rnd=5, max_dist_match2=4.0)
+    libc.srand(1234)
+    keep = np.array([int(5.0 * libc.rand() / (2147483647 + 1.0)) == 0 for _ in range(len(q))])
+    assert 0.15 < keep.mean() < 0.25
+    ref = T.get_pt_pairs(np.eye(4).reshape(16), q[keep], maxdist2=4.0)
+    assert got["n"] == ref["n"] and got["n_queries"] == int(keep.sum())
+    assert np.array_equal(got["idx"][keep], ref["idx"]) and (got["idx"][~keep] == -1).all()
+    assert np.array_equal(got["p1"], ref["p1"]) and np.array_equal(got["p2"], ref["p2"])
+    assert abs(got["sum"] - ref["sum"]) <= 1e-12 * ref["sum"]
 
 
 def test_scan_transform_bit_exact(tdtk, orc, gpu):

@@ -265,3 +265,23 @@ def test_shard_links_partition(tdtk):
         assert got == list(range(71))
         sizes = [len(gs.shard_links(71, r, world)) for r in range(world)]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_adapter_compiles_against_reference_headers(tmp_path):
+    """adapters/hip_search_tree.{h,cc} (the SearchTree binding INTEGRATION.md describes) must
+    compile against the reference's own headers.  Only possible where the checkout exists."""
+    ref = os.environ.get("TDTK_REF", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "include", "slam6d")):
+        pytest.skip("no reference checkout on this box")
+    inc = tmp_path / "slam6d"
+    inc.mkdir()
+    (inc / "hip_search_tree.h").write_text(open(os.path.join(ROOT, "adapters", "hip_search_tree.h")).read())
+    obj = tmp_path / "hst.o"
+    cmd = ["g++", "-std=c++17", "-c", "-fopenmp", "-DMAX_OPENMP_NUM_THREADS=8", "-DOPENMP_NUM_THREADS=8",
+           "-I" + str(tmp_path), "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "adapters", "hip_search_tree.cc"), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    syms = subprocess.run(["nm", "-C", str(obj)], capture_output=True, text=True).stdout
+    for want in ("HipSearchTree::getPtPairs", "HipSearchTree::FindClosest", "tdtk_get_pt_pairs", "tdtk_tree_create"):
+        assert want in syms
