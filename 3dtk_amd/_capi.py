@@ -53,7 +53,7 @@ EXPORTS = [
     "tdtk_tree_get_info", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
-    "tdtk_lum_link", "tdtk_solve_spd", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_lum_link", "tdtk_lum_links", "tdtk_lum_update_poses", "tdtk_solve_spd", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
 ]
 
@@ -120,6 +120,9 @@ def lib():
     L.tdtk_icp_match.argtypes = [C.c_void_p, _dp, C.c_void_p, _dp, _dp, C.POINTER(IcpParams),
                                  C.POINTER(IcpResult), _dp, C.c_int]
     L.tdtk_lum_link.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_double, _dp, _dp, _u64p, _dp]
+    L.tdtk_lum_links.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, C.POINTER(C.c_void_p), C.c_double, _dp,
+                                 _dp, _u64p, _dp]
+    L.tdtk_lum_update_poses.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_void_p), _dp, _dp]
     L.tdtk_solve_spd.argtypes = [_dp, _dp, C.c_int, _dp]
     L.tdtk_last_kernel_ms.argtypes = [_dp]
     L.tdtk_count_visits.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _u64p]

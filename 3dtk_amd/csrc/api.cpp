@@ -973,4 +973,157 @@ int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_
   return TDTK_OK;
 }
 
+// ---- batched links + native pose update (graph-SLAM inner loop without per-link round trips) ----
+int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                   tdtk_scan* const* second, double maxd2, double* C, double* CD, uint64_t* m_out, double* ss_out)
+{
+  if (nlinks < 0 || (nlinks && (!first || !first_dalignxf || !second || !C || !CD))) { set_error("bad argument"); return TDTK_EINVAL; }
+  if (nlinks == 0) return TDTK_OK;
+  Ctx* c;
+  int rc = get_ctx(first[0]->device, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  if ((rc = c->ws[WS_TMPB].ensure((size_t)nlinks * ACC_TOTAL * sizeof(double)))) return rc;
+  double* d_out = c->ws[WS_TMPB].as<double>();
+  std::vector<double> shifts(3 * (size_t)nlinks);
+  size_t maxN = 0;
+  for (int i = 0; i < nlinks; i++) {
+    if (!first[i] || !second[i]) { set_error("NULL link member"); return TDTK_EINVAL; }
+    if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
+    maxN = std::max(maxN, second[i]->N);
+  }
+  if ((rc = c->ws[WS_KPOS].ensure(maxN * sizeof(int)))) return rc;
+  const uint32_t agrid = accum_grid(maxN);
+  if ((rc = c->ws[WS_PART].ensure((size_t)agrid * ACC_TOTAL * sizeof(double)))) return rc;
+  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
+  for (int i = 0; i < nlinks; i++) {
+    const tdtk_tree* t = first[i];
+    tdtk_scan* data = second[i];
+    if (data->N == 0) continue;
+    const double* A16 = first_dalignxf + 16 * (size_t)i;
+    Mat4 A, inv;
+    std::memcpy(A.m, A16, sizeof A.m);
+    m4inv(A16, inv.m);
+    SearchArgs sa{};
+    sa.x = data->x; sa.y = data->y; sa.z = data->z;
+    sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
+    sa.kpos = c->ws[WS_KPOS].as<int>();
+    rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1);
+    if (rc) return rc;
+    AccumArgs aa{};
+    aa.T = t->dev;
+    aa.x = data->x; aa.y = data->y; aa.z = data->z;
+    aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
+    for (int k = 0; k < 3; k++) {
+      aa.shift[k] = t->centre[0] * A16[k] + t->centre[1] * A16[4 + k] + t->centre[2] * A16[8 + k] + A16[12 + k];
+      shifts[3 * i + k] = aa.shift[k];
+    }
+    aa.partials = c->ws[WS_PART].as<double>();
+    HIPCHK(launch_accum(aa, accum_grid(data->N), TDTK_WANT_LUM, 0, d_out + (size_t)i * ACC_TOTAL, s));
+  }
+  std::vector<double> acc((size_t)nlinks * ACC_TOTAL);
+  HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  collect_ms(c, nullptr);
+  for (int i = 0; i < nlinks; i++) {
+    double* Ci = C + 36 * (size_t)i;
+    double* CDi = CD + 6 * (size_t)i;
+    std::memset(Ci, 0, 36 * sizeof(double));
+    std::memset(CDi, 0, 6 * sizeof(double));
+    const double* a = acc.data() + (size_t)i * ACC_TOTAL;
+    const uint64_t m = (uint64_t)(a[ACC_N] + 0.5);
+    if (m_out) m_out[i] = m;
+    if (ss_out) ss_out[i] = 0.0;
+    if (m <= 2) continue;
+    const double* L = a + ACC_L;
+    double MM[36] = {0};
+    auto M = [&](int r, int col) -> double& { return MM[(r - 1) * 6 + (col - 1)]; };
+    M(1, 1) = M(2, 2) = M(3, 3) = (double)m;
+    M(4, 4) = L[5]; M(5, 5) = L[3]; M(6, 6) = L[4];
+    M(1, 5) = M(5, 1) = -L[1]; M(1, 6) = M(6, 1) = L[2];
+    M(2, 4) = M(4, 2) = -L[2]; M(2, 5) = M(5, 2) = L[0];
+    M(3, 4) = M(4, 3) = L[1];  M(3, 6) = M(6, 3) = -L[0];
+    M(4, 5) = M(5, 4) = -L[7]; M(4, 6) = M(6, 4) = -L[6]; M(5, 6) = M(6, 5) = -L[8];
+    const double* MZ = L + 9;
+    double MMi[36], D[6];
+    if (!invert_dense(6, MM, MMi)) { set_error("singular link matrix"); return TDTK_ESOLVE; }
+    double dmz = 0.0;
+    for (int r = 0; r < 6; r++) {
+      double v = 0;
+      for (int k = 0; k < 6; k++) v += MMi[r * 6 + k] * MZ[k];
+      D[r] = v;
+      dmz += v * MZ[r];
+    }
+    // sum |delta - A(u) D|^2 = sum|delta|^2 - 2 D.MZ + D.MM.D = sum|delta|^2 - D.MZ for MM D = MZ
+    double ss = (a[ACC_SUM] - dmz) / (2.0 * (double)m - 3.0);
+    if (ss_out) ss_out[i] = ss;
+    if (ss < 0.0000000000001) continue;
+    ss = 1.0 / ss;
+    for (int k = 0; k < 36; k++) Ci[k] = MM[k] * ss;
+    for (int k = 0; k < 6; k++) CDi[k] = MZ[k] * ss;
+  }
+  return TDTK_OK;
+}
+
+int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double* dalignxf, double* rPos,
+                          double* rPosTheta, tdtk_scan* const* scans, double* xf_out, double* ret)
+{
+  if (nscans <= 0 || !X || !transMat || !dalignxf || !rPos || !rPosTheta) { set_error("bad argument"); return TDTK_EINVAL; }
+  double sum_position_diff = 0.0;
+  Ctx* c = nullptr;
+  for (int i = 1; i < nscans; i++) {
+    double* tm = transMat + 16 * (size_t)i;
+    double* da = dalignxf + 16 * (size_t)i;
+    double* rp = rPos + 3 * (size_t)i;
+    double* rt = rPosTheta + 3 * (size_t)i;
+    const double xa = rp[0], ya = rp[1], za = rp[2];
+    const double ctx = std::cos(rt[0]), stx = std::sin(rt[0]), cty = std::cos(rt[1]), sty = std::sin(rt[1]);
+    double Ha[36] = {0}, Hi[36];
+    for (int k = 0; k < 6; k++) Ha[k * 6 + k] = 1.0;
+    Ha[0 * 6 + 4] = -za * ctx + ya * stx;
+    Ha[0 * 6 + 5] = ya * cty * ctx + za * stx * cty;
+    Ha[1 * 6 + 3] = za;
+    Ha[1 * 6 + 4] = -xa * stx;
+    Ha[1 * 6 + 5] = -xa * ctx * cty + za * sty;
+    Ha[2 * 6 + 3] = -ya;
+    Ha[2 * 6 + 4] = xa * ctx;
+    Ha[2 * 6 + 5] = -xa * cty * stx - ya * sty;
+    Ha[3 * 6 + 5] = sty;
+    Ha[4 * 6 + 4] = stx;
+    Ha[4 * 6 + 5] = ctx * cty;
+    Ha[5 * 6 + 4] = ctx;
+    Ha[5 * 6 + 5] = -stx * cty;
+    if (!invert_dense(6, Ha, Hi)) { set_error("singular pose Jacobian"); return TDTK_ESOLVE; }
+    const double* Xi = X + 6 * (size_t)(i - 1);
+    double result[6];
+    for (int r = 0; r < 6; r++) {
+      double v = 0;
+      for (int k = 0; k < 6; k++) v += Hi[r * 6 + k] * Xi[k];
+      result[r] = v;
+    }
+    double nP[3], nT[3];
+    for (int k = 0; k < 3; k++) { nP[k] = rp[k] - result[k]; nT[k] = rt[k] - result[k + 3]; }
+    // Scan::transformToEuler (scan.cc:1061-1083)
+    double tinv[16], axf[16];
+    m4inv(tm, tinv);
+    mmult(tinv, tm, tm); matrix4_to_euler(tm, rt, rp); mmult(tinv, da, da);   // transform(tinv, INVALID)
+    euler_to_matrix4(nP, nT, axf);
+    mmult(axf, tm, tm); matrix4_to_euler(tm, rt, rp); mmult(axf, da, da);     // transform(alignxf, LUM, ..)
+    if (xf_out) { std::memcpy(xf_out + 32 * (size_t)i, tinv, sizeof tinv); std::memcpy(xf_out + 32 * (size_t)i + 16, axf, sizeof axf); }
+    if (scans && scans[i] && scans[i]->N) {
+      if (!c) { int rc = get_ctx(scans[i]->device, &c); if (rc) return rc; }
+      tdtk_scan* sc = scans[i];
+      Mat4 A1, A2;
+      std::memcpy(A1.m, tinv, sizeof tinv);
+      std::memcpy(A2.m, axf, sizeof axf);
+      HIPCHK(launch_transform(sc->x, sc->y, sc->z, sc->nx, sc->ny, sc->nz, sc->N, A1, c->stream));
+      HIPCHK(launch_transform(sc->x, sc->y, sc->z, sc->nx, sc->ny, sc->nz, sc->N, A2, c->stream));
+    }
+    sum_position_diff += std::sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
+  }
+  if (c) HIPCHK(hipStreamSynchronize(c->stream));
+  if (ret) *ret = sum_position_diff / (double)nscans;
+  return TDTK_OK;
+}
+
 }  // extern "C"

@@ -15,6 +15,46 @@ void m4identity(double* M)
   for (int k = 0; k < 16; k++) M[k] = (k % 5 == 0) ? 1.0 : 0.0;
 }
 
+// globals.icc:501-531
+void euler_to_matrix4(const double* rPos, const double* th, double* a)
+{
+  const double sx = std::sin(th[0]), cx = std::cos(th[0]);
+  const double sy = std::sin(th[1]), cy = std::cos(th[1]);
+  const double sz = std::sin(th[2]), cz = std::cos(th[2]);
+  a[0] = cy * cz;
+  a[1] = sx * sy * cz + cx * sz;
+  a[2] = -cx * sy * cz + sx * sz;
+  a[3] = 0.0;
+  a[4] = -cy * sz;
+  a[5] = -sx * sy * sz + cx * cz;
+  a[6] = cx * sy * sz + sx * cz;
+  a[7] = 0.0;
+  a[8] = sy;
+  a[9] = -sx * cy;
+  a[10] = cx * cy;
+  a[11] = 0.0;
+  a[12] = rPos[0]; a[13] = rPos[1]; a[14] = rPos[2];
+  a[15] = 1;
+}
+
+// globals.icc:541-576
+void matrix4_to_euler(const double* a, double* th, double* rPos)
+{
+  if (a[0] > 0.0) th[1] = std::asin(a[8]);
+  else th[1] = M_PI - std::asin(a[8]);
+  const double C = std::cos(th[1]);
+  if (std::fabs(C) > 0.005) {
+    double trX = a[10] / C, trY = -a[9] / C;
+    th[0] = std::atan2(trY, trX);
+    trX = a[0] / C; trY = -a[4] / C;
+    th[2] = std::atan2(trY, trX);
+  } else {
+    th[0] = 0.0;
+    th[2] = std::atan2(a[1], a[5]);
+  }
+  if (rPos) { rPos[0] = a[12]; rPos[1] = a[13]; rPos[2] = a[14]; }
+}
+
 namespace {
 // 3x3 minor of a 4x4 (row r and column c removed), laid out like M4_submat does
 // (globals.icc:715-730: out[di*3+dj] = in[si*4+sj]).
@@ -113,28 +153,40 @@ bool invert_dense(int n, const double* A, double* Ainv)
   return true;
 }
 
-// Cholesky A = L L^T on a dense row-major copy; fails when a pivot drops below `floor`
-// (the reference's choldc gives up at 1e-7, globals.icc:820-848).
+// dot product of two contiguous rows with 8 independent partial sums: legal to vectorise without
+// -ffast-math (the association is fixed by the code), ~8x the throughput of the serial chain
+static inline double dot8(const double* __restrict__ a, const double* __restrict__ b, int n)
+{
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    s0 += a[k] * b[k];         s1 += a[k + 1] * b[k + 1];
+    s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3];
+    s4 += a[k + 4] * b[k + 4]; s5 += a[k + 5] * b[k + 5];
+    s6 += a[k + 6] * b[k + 6]; s7 += a[k + 7] * b[k + 7];
+  }
+  double t = 0;
+  for (; k < n; k++) t += a[k] * b[k];
+  return (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) + t;
+}
+
+// Cholesky A = L L^T on a dense row-major copy (row-oriented: every inner product runs over two
+// contiguous rows); fails when a pivot drops below `floor` (the reference's choldc gives up at
+// 1e-7, globals.icc:820-848).
 static bool cholesky_solve(int n, std::vector<double>& a, const double* b, double* x, double floor)
 {
-  for (int j = 0; j < n; j++) {
-    double d = a[(size_t)j * n + j];
-    for (int k = 0; k < j; k++) d -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
-    if (!(d >= floor)) return false;
-    d = std::sqrt(d);
-    a[(size_t)j * n + j] = d;
-    for (int i = j + 1; i < n; i++) {
-      double s = a[(size_t)i * n + j];
-      for (int k = 0; k < j; k++) s -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
-      a[(size_t)i * n + j] = s / d;
+  for (int i = 0; i < n; i++) {
+    double* ri = &a[(size_t)i * n];
+    for (int j = 0; j < i; j++) {
+      const double* rj = &a[(size_t)j * n];
+      ri[j] = (ri[j] - dot8(ri, rj, j)) / rj[j];
     }
+    const double d = ri[i] - dot8(ri, ri, i);
+    if (!(d >= floor)) return false;
+    ri[i] = std::sqrt(d);
   }
   std::vector<double> y(n);
-  for (int i = 0; i < n; i++) {
-    double s = b[i];
-    for (int k = 0; k < i; k++) s -= a[(size_t)i * n + k] * y[k];
-    y[i] = s / a[(size_t)i * n + i];
-  }
+  for (int i = 0; i < n; i++) y[i] = (b[i] - dot8(&a[(size_t)i * n], y.data(), i)) / a[(size_t)i * n + i];
   for (int i = n - 1; i >= 0; i--) {
     double s = y[i];
     for (int k = i + 1; k < n; k++) s -= a[(size_t)k * n + i] * x[k];

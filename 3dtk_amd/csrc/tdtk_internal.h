@@ -66,6 +66,8 @@ bool build_tree(const double* xyz, size_t M, int bucket, HostTree& out, std::str
 int m4inv(const double* Min, double* Mout);                      // globals.icc:762-785
 void mmult(const double* M1, const double* M2, double* Mout);    // globals.icc:298-328
 void m4identity(double* M);
+void euler_to_matrix4(const double* rPos, const double* rPosTheta, double* alignxf);  // globals.icc:501-531
+void matrix4_to_euler(const double* alignxf, double* rPosTheta, double* rPos);        // globals.icc:541-576
 
 // ---- minimizers ------------------------------------------------------------------------
 int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], double* rms,

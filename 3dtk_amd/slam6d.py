@@ -425,13 +425,14 @@ class Graph:
             return
         for i in range(nodes - 1):                  # graph.cc:115-118
             self.frm.append(i); self.to.append(i + 1)
-        if cldist2 is not None:                     # graph.cc:121-130
-            for j in range(nodes):
-                for k in range(j + 1, nodes):
-                    d = scans[k].get_rPos() - scans[j].get_rPos()
-                    d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
-                    if abs(k - j) > loopsize and d2 < cldist2:
-                        self.frm.append(j); self.to.append(k)
+        if cldist2 is not None:                     # graph.cc:121-130, (j, k) in row-major order
+            P = np.stack([np.asarray(s.get_rPos(), dtype=np.float64) for s in scans[:nodes]])
+            d = P[None, :, :] - P[:, None, :]
+            d2 = d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1] + d[:, :, 2] * d[:, :, 2]   # Dist2
+            jj, kk = np.nonzero(np.triu((d2 < cldist2), 1) &
+                                ((np.arange(nodes)[None, :] - np.arange(nodes)[:, None]) > loopsize))
+            for j, k in zip(jj.tolist(), kk.tolist()):
+                self.frm.append(j); self.to.append(k)
 
     def getNrScans(self): return self.nrScans
     def getNrLinks(self): return len(self.frm)
@@ -498,13 +499,16 @@ class lum6DEuler:
         self.epsilonLUM = epsilonLUM
         self.group = group
 
-    def doGraphSlam6D(self, gr, allScans, nrIt):
-        from .graphslam import lum_iteration
+    def doGraphSlam6D(self, gr, allScans, nrIt, native=True, device=None):
+        from .graphslam import lum_iteration, lum_iteration_native
         if gr.getNrScans() <= 0:
             raise RuntimeError("Zero scans in graph")
         ret = float("inf")
         it = 0
         while it < nrIt and ret > self.epsilonLUM:
-            ret = lum_iteration(gr, allScans, self.max_dist_match2_LUM, self.group)
+            if native:
+                ret = lum_iteration_native(gr, allScans, self.max_dist_match2_LUM, self.group, device)
+            else:
+                ret = lum_iteration(gr, allScans, self.max_dist_match2_LUM, self.group, None, device)
             it += 1
         return ret

@@ -106,7 +106,7 @@ def make_graphslam_scans(nscans, npts, seed=7):
 def dist_setup(ngpus):
     import torch
     rank, world, local = 0, 1, 0
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
@@ -121,8 +121,8 @@ def dist_setup(ngpus):
 
 def barrier_sync(world):
     import torch
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -255,19 +255,17 @@ def bench_graphslam(args, rank, world, local):
     for i in mine:                                      # materialise what this rank touches
         scans[g0.getLink(i, 0)].getSearchTree()
         _ = scans[g0.getLink(i, 1)].handle
-    dev = torch.device("cuda", local) if world > 1 else None
+    import torch.distributed as tdist
+    dev = torch.device("cuda", local) if (tdist.is_available() and tdist.is_initialized()) else None
     nn_ms = [0.0]
-
-    def link_fn(a, b, md2):
-        r = sl.covarianceEuler(a, b, md2)
-        ms = C.c_double(0.0)
-        tdtk.lib().tdtk_last_kernel_ms(C.byref(ms))
-        nn_ms[0] += ms.value
-        return r
 
     def step():
         gr = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)   # slam6D.cc:525-532: fresh Graph + 1 LUM iteration
-        return gs.lum_iteration(gr, scans, 625.0, None, link_fn, dev), gr.getNrLinks()
+        r = gs.lum_iteration_native(gr, scans, 625.0, None, dev)
+        ms = C.c_double(0.0)
+        tdtk.lib().tdtk_last_kernel_ms(C.byref(ms))       # the last link's k_search of this rank
+        nn_ms[0] += ms.value
+        return r, gr.getNrLinks()
 
     for _ in range(args.warmup):
         step()
@@ -276,13 +274,15 @@ def bench_graphslam(args, rank, world, local):
     t0 = time.perf_counter()
     links_done = 0
     for _ in range(args.steps):
+        ts = time.perf_counter()
         ret, nl = step()
         links_done += nl
+        if os.environ.get("TDTK_BENCH_VERBOSE"):
+            print("step %.2f ms ret %.4f" % ((time.perf_counter() - ts) * 1e3, ret), file=sys.stderr)
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, local)
     queries = links_done * npts                         # one whole-scan NN pass per link
-    my_launches = sum(1 for _ in range(args.steps)) * len(mine)
-    k_ms = nn_ms[0] / max(1, my_launches)
+    k_ms = nn_ms[0] / max(1, args.steps)                # one sampled k_search launch per step
     out = {
         "metric": "NN correspondences/sec (graph-SLAM lum6DEuler iteration, links sharded)",
         "value": queries / dt, "unit": "NN correspondences/s",
@@ -317,12 +317,12 @@ def main():
     if wl == "auto":
         wl = "icp" if world == 1 else "graphslam"
     if wl == "graphslam" and args.steps == 100 and args.warmup == 10:
-        args.steps, args.warmup = 5, 1                 # a LUM step is ~70 whole-scan passes
+        args.steps, args.warmup = 10, 3                # a LUM step is ~84 whole-scan passes
     res = bench_icp(args, rank, world, local) if wl == "icp" else bench_graphslam(args, rank, world, local)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -181,6 +181,25 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
 int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_scan* second,
                   double max_dist_match2, double C[36], double CD[6], uint64_t* m, double* ss);
 
+/* lum6DEuler::FillGB3D's link loop (src/slam6d/lum6Deuler.cc:265-303) for a batch of links on one
+ * device: all correspondence passes and reductions are enqueued back to back and synchronised
+ * once.  first[i] / first_dalignxf[i*16] / second[i] describe link i.  ss is evaluated from the
+ * normal equations (sum|d|^2 - D.MZ, exact for the solved D) instead of a second pass over the
+ * pairs; tdtk_lum_link keeps the reference's two-pass form.  Outputs are per link.          */
+int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                   tdtk_scan* const* second, double max_dist_match2, double* C /*[nlinks][36]*/,
+                   double* CD /*[nlinks][6]*/, uint64_t* m /*[nlinks]*/, double* ss /*[nlinks]*/);
+
+/* Pose update of lum6DEuler::doGraphSlam6D (lum6Deuler.cc:378-473) for scans 1..n-1:
+ * result = Ha^-1 * X_i, pose -= result, Scan::transformToEuler (scan.cc:1061-1083: transform by
+ * M4inv(transMat), then by EulerToMatrix4(new pose)).  transMat/dalignxf/rPos/rPosTheta are
+ * [n][16]/[n][16]/[n][3]/[n][3], updated in place; scans[i] (nullable) are moved on the device;
+ * xf_out (nullable, [n][32]) receives the two matrices applied to scan i so that a caller can
+ * queue them for scans that are not resident.  *ret = sum |dxyz| / n  (lum6Deuler.cc:470-473). */
+int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double* dalignxf,
+                          double* rPos, double* rPosTheta, tdtk_scan* const* scans, double* xf_out,
+                          double* ret);
+
 /* graphSlam6D::solveSparseCholesky(GraphMatrix*, B) (src/slam6d/graphSlam6D.cc:345-379,
  * 477-503): dense SPD solve of G x = B (G row-major n x n, entries with |v| <= 1e-5
  * dropped like convertToCS does).  x may alias B.                                       */

@@ -342,11 +342,22 @@ def test_lum_links_and_iteration_vs_fixture(tdtk, gpu):
         np.testing.assert_allclose(CD, L["CD"], rtol=1e-7, atol=1e-7)
     g = tdtk.Graph(3)
     assert list(zip(g.frm, g.to)) == [(0, 1), (1, 2)]
-    ret = tdtk.lum6DEuler(None, 25.0, 25.0).doGraphSlam6D(g, S, 1)
+    # two more copies of the scans at the same poses: python-orchestrated path vs batched native path
+    S2 = _dat_scans(tdtk.Scan, z)
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S2[i].mergeCoordinatesWithRoboterPosition(S2[i - 1])
+        for a in pr["alignxf"]:
+            S2[i].transform(np.array(a))
+    ret = tdtk.lum6DEuler(None, 25.0, 25.0).doGraphSlam6D(g, S, 1, native=False)
+    ret2 = tdtk.lum6DEuler(None, 25.0, 25.0).doGraphSlam6D(g, S2, 1, native=True)
     assert abs(ret - b4["one_iteration"]["ret"]) < 1e-6 * max(1.0, b4["one_iteration"]["ret"])
-    for s, want in zip(S, b4["one_iteration"]["poses_after"]):
+    assert abs(ret2 - ret) < 1e-9
+    for s, s2, want in zip(S, S2, b4["one_iteration"]["poses_after"]):
         got = np.concatenate([s.get_rPos(), s.get_rPosTheta()])
         assert np.abs(got - want).max() <= POSE_RTOL * np.abs(want).max() + 1e-12
+        assert np.abs(np.concatenate([s2.get_rPos(), s2.get_rPosTheta()]) - got).max() < 1e-9
+        assert np.abs(s2.get_xyz_reduced() - s.get_xyz_reduced()).max() < 1e-7
 
 
 def test_full_size_icp_recovers_pose(tdtk, orc, gpu, k5):
