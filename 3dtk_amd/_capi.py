@@ -55,6 +55,7 @@ EXPORTS = [
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_lum_update_poses", "tdtk_solve_spd", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
+    "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
 ]
 
 
@@ -130,6 +131,11 @@ def lib():
     L.tdtk_host_m4inv.argtypes = [_dp, _dp]
     L.tdtk_host_mmult.argtypes = [_dp, _dp, _dp]
     L.tdtk_host_mmult.restype = None
+    L.tdtk_io_read_uos.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(_dp), C.POINTER(C.c_size_t)]
+    L.tdtk_io_free.argtypes = [C.c_void_p]
+    L.tdtk_io_free.restype = None
+    L.tdtk_io_read_pose.argtypes = [C.c_char_p, _dp, _dp]
+    L.tdtk_io_write_frames.argtypes = [C.c_char_p, _dp, C.POINTER(C.c_int), C.c_size_t, C.c_int]
     _lib = L
     return L
 

@@ -10,6 +10,7 @@ import math
 import numpy as np
 
 from . import _capi as capi
+_dp_type = lambda: C.POINTER(C.c_double)()
 from ._capi import (lib, check, dptr, iptr, f64, PairSums, IcpParams, IcpResult, TreeInfo,
                     ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX, WANT_APX, WANT_NAPX, WANT_LUM)
 
@@ -317,6 +318,82 @@ class Scan:
         return out
 
 
+class MetaScan:
+    """MetaScan (src/slam6d/metaScan.cc:27-107) + KDtreeMetaManaged (src/slam6d/kdMeta.cc:34-134):
+    one search tree over the CURRENT "xyz reduced" points of several scans, addressed in
+    concatenation order (prepareTempIndices, kdMeta.cc:60-79), bucket size of the first scan
+    (kdMeta.cc:45-46).  Its dalignxf stays identity (Scan base ctor, scan.cc:193)."""
+
+    def __init__(self, scans, nns_method=0):
+        self.m_scans = list(scans)
+        self.dalignxf = M4identity()
+        self.transMat = M4identity()
+        self.kd = None
+        self.device = self.m_scans[0].device if self.m_scans else 0
+
+    def size(self): return len(self.m_scans)
+    def getScan(self, i): return self.m_scans[i]
+    def getDAlign(self): return self.dalignxf
+
+    def getSearchTree(self):
+        if self.kd is None:
+            pts = np.concatenate([s.get_xyz_reduced() for s in self.m_scans])
+            self.kd = KDtree(pts, self.m_scans[0].bucketSize, self.device)
+        return self.kd
+
+
+def read_uos(path, range_max=0.0, range_min=0.0):
+    """uos ASCII reader + PointFilter range (-m / -M); see tdtk_io_read_uos."""
+    p = _dp_type()
+    n = C.c_size_t(0)
+    check(lib().tdtk_io_read_uos(str(path).encode(), float(range_max), float(range_min), C.byref(p), C.byref(n)))
+    try:
+        out = np.ctypeslib.as_array(p, shape=(max(1, n.value) * 3,))[:n.value * 3].copy().reshape(-1, 3)
+    finally:
+        lib().tdtk_io_free(p)
+    return out
+
+
+def read_pose(path):
+    rP = np.empty(3); rT = np.empty(3)
+    check(lib().tdtk_io_read_pose(str(path).encode(), dptr(rP), dptr(rT)))
+    return rP, rT
+
+
+ALGO_TYPE = {"INVALID": 0, "ICP": 1, "ICPINACTIVE": 2, "LUM": 3, "ELCH": 4}   # scan.h:126
+
+
+def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSize=20, device=0):
+    """Scan::openDirectory for the uos format (src/slam6d/scan.cc / basicScan.cc:39-122):
+    scanNNN.3d + scanNNN.pose, NNN = start..end."""
+    import os
+    scans = []
+    i = start
+    while end < 0 or i <= end:
+        f3d = os.path.join(path, "scan%03d.3d" % i)
+        fpose = os.path.join(path, "scan%03d.pose" % i)
+        if not (os.path.exists(f3d) and os.path.exists(fpose)):
+            break
+        rP, rT = read_pose(fpose)
+        s = Scan(rP, rT, read_uos(f3d, range_max, range_min), bucketSize=bucketSize, device=device)
+        s.identifier = "%03d" % i
+        s.path = path
+        scans.append(s)
+        i += 1
+    return scans
+
+
+def saveFrames(scan, path=None, append=False):
+    """BasicScan::saveFrames (basicScan.cc:902-917): scanNNN.frames"""
+    import os
+    fn = path or os.path.join(scan.path, "scan%s.frames" % scan.identifier)
+    mats = np.ascontiguousarray(np.array([m for m, _ in scan.frames], dtype=np.float64).reshape(-1, 16))
+    types = (C.c_int * len(scan.frames))(*[ALGO_TYPE.get(t, 0) for _, t in scan.frames])
+    check(lib().tdtk_io_write_frames(str(fn).encode(), dptr(mats) if len(scan.frames) else None, types,
+                                     len(scan.frames), 1 if append else 0))
+    return fn
+
+
 # ---------------------------------------------------------------------------------------
 # icp6Dminimizer family (include/slam6d/icp6Dminimizer.h:31-88)
 # ---------------------------------------------------------------------------------------
@@ -362,17 +439,19 @@ class icp6D_NAPX(icp6Dminimizer):   # src/slam6d/icp6Dnapx.cc, -a 10
 # ---------------------------------------------------------------------------------------
 class icp6D:
     def __init__(self, my_icp6Dminimizer, max_dist_match=25.0, max_num_iterations=50, quiet=False,
-                 meta=False, rnd=1, eP=True, anim=-1, epsilonICP=0.0000001, nns_method=0):
+                 meta=False, rnd=1, eP=True, anim=-1, epsilonICP=0.0000001, nns_method=0,
+                 max_num_metascans=-1):
         if max_dist_match < 0.0:
             raise ValueError("ERROR [ICP6D]: first parameter (max_dist_match) has to be >= 0,")
         if max_num_iterations < 0:
             raise ValueError("ERROR [ICP6D]: second parameter (max_num_iterations)has to be >= 0.")
-        if rnd > 1:
-            raise capi.TdtkError(-5, "rnd > 1 is not supported on the device path")
+        self.rnd = rnd
         self.my_icp6Dminimizer = my_icp6Dminimizer
         self.max_dist_match2 = max_dist_match * max_dist_match
         self.max_num_iterations = max_num_iterations
         self.quiet = quiet
+        self.meta = meta
+        self.max_num_metascans = max_num_metascans
         self.eP = eP
         self.epsilonICP = epsilonICP
         self.nr_pointPair = 0
@@ -380,6 +459,8 @@ class icp6D:
 
     def match(self, PreviousScan, CurrentScan, pairing_mode=0):
         """icp6D::match (icp6D.cc:104-285).  Returns the number of iterations done."""
+        if self.rnd > 1:
+            return self._match_stepped(PreviousScan, CurrentScan, pairing_mode)
         CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))  # transform(id, ICP, 0)
         tree = PreviousScan.getSearchTree()
         prm = IcpParams(int(self.my_icp6Dminimizer.getAlgorithmID()), int(pairing_mode),
@@ -403,13 +484,53 @@ class icp6D:
                          nn_ms=res.nn_ms, trace=trace[:nrows].copy())
         return res.iterations
 
+    def _match_stepped(self, PreviousScan, CurrentScan, pairing_mode=0):
+        """The same loop driven from the host, one SearchTree::getPtPairs call per iteration: what
+        an unmodified reference icp6D::match does on top of HipSearchTree.  Only used for -R (rnd > 1),
+        whose keep-mask is drawn on the host (the resident loop has no per-iteration host input)."""
+        CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))
+        tree = PreviousScan.getSearchTree()
+        algo = self.my_icp6Dminimizer.getAlgorithmID()
+        want = WANT_APX if algo == ALGO_APX else (WANT_NAPX if algo == ALGO_NAPX else 0)
+        ret = prev_ret = prev_prev_ret = 0.0
+        trace = []
+        it = 0
+        for it in range(self.max_num_iterations):
+            prev_prev_ret, prev_ret = prev_ret, ret
+            r = tree.getPtPairs(PreviousScan.dalignxf, CurrentScan.get_xyz_reduced(), None, 0, None, 0, self.rnd,
+                                self.max_dist_match2, pairing_mode, want, None, want_pairs=False)
+            self.nr_pointPair = r["n"]
+            if r["n"] > 3:
+                ret, alignxf = self.my_icp6Dminimizer.Align_Parallel(r)
+            else:
+                break
+            trace.append(np.concatenate([[r["n"], ret], alignxf]))
+            CurrentScan.transform(alignxf, "ICP", -1)
+            if (abs(ret - prev_ret) < self.epsilonICP and abs(ret - prev_prev_ret) < self.epsilonICP) or \
+                    it == self.max_num_iterations - 1:
+                break
+        CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))
+        self.last = dict(iterations=it, converged=it != self.max_num_iterations - 1, pairs=self.nr_pointPair,
+                         rms=ret, total_ms=0.0, nn_ms=0.0, trace=np.array(trace))
+        return it
+
     def doICP(self, allScans, pairing_mode=0):
-        """icp6D::doICP (icp6D.cc:374-437), non-meta branch."""
-        for i in range(1, len(allScans)):
-            prev, cur = allScans[i - 1], allScans[i]
-            if self.eP:
-                cur.mergeCoordinatesWithRoboterPosition(prev)
-            self.match(prev, cur, pairing_mode)
+        """icp6D::doICP (icp6D.cc:374-437): sequential matching against the previous scan, or
+        (meta) against a MetaScan of all / the last max_num_metascans processed scans."""
+        meta_scans, my_MetaScan = [], None
+        for i in range(len(allScans)):
+            cur = allScans[i]
+            if i > 0:
+                prev = allScans[i - 1]
+                if self.eP:
+                    cur.mergeCoordinatesWithRoboterPosition(prev)
+                self.match(my_MetaScan if self.meta else prev, cur, pairing_mode)
+            if self.meta and i != len(allScans) - 1:
+                meta_scans.append(cur)
+                if self.max_num_metascans > 0:
+                    while len(meta_scans) > self.max_num_metascans:
+                        meta_scans.pop(0)
+                my_MetaScan = MetaScan(meta_scans)
 
 
 # ---------------------------------------------------------------------------------------
@@ -512,3 +633,53 @@ class lum6DEuler:
                 ret = lum_iteration(gr, allScans, self.max_dist_match2_LUM, self.group, None, device)
             it += 1
         return ret
+
+
+def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_graphSlam6D, nrIt, epsilonSLAM,
+                          mdml, eP=True, max_num_metascans=-1):
+    """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) without loop closing (my_loopSlam6D == NULL)
+    and without the -DlastSLAM pass: sequential ICP, loop detection by pose distance, and rounds of
+    { fresh Graph(i+1, cldist^2, loopsize); one doGraphSlam6D iteration } until ret <= epsilonSLAM
+    or nrIt rounds."""
+    cldist2 = cldist * cldist
+    metas = []
+    n = len(allScans)
+    loop_detection = 0
+    rounds = 0
+
+    def global_rounds(nodes):
+        nonlocal rounds
+        j = 0
+        while True:
+            gr = Graph(nodes, cldist2, loopsize, allScans)
+            ret = my_graphSlam6D.doGraphSlam6D(gr, allScans, 1)
+            j += 1
+            rounds += 1
+            if not (j < nrIt and ret > epsilonSLAM):
+                return ret
+
+    for i in range(1, n):
+        if eP:
+            allScans[i].mergeCoordinatesWithRoboterPosition(allScans[i - 1])
+        if my_icp6D is not None:
+            if meta_icp:
+                metas.append(allScans[i - 1])
+                if max_num_metascans > 0:
+                    while len(metas) > max_num_metascans:
+                        metas.pop(0)
+                my_icp6D.match(MetaScan(metas), allScans[i])
+            else:
+                my_icp6D.match(allScans[i - 1], allScans[i])
+        if loop_detection == 1:
+            loop_detection = 2
+        for j in range(0, i - loopsize):
+            d = allScans[j].get_rPos() - allScans[i].get_rPos()
+            if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cldist2:
+                loop_detection = 1
+        if loop_detection == 2:
+            loop_detection = 0
+            if my_graphSlam6D is not None and mdml > 0:
+                global_rounds(i + 1)
+    if my_graphSlam6D is not None and mdml > 0.0:
+        global_rounds(n)
+    return rounds

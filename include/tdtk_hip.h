@@ -211,6 +211,16 @@ int tdtk_last_kernel_ms(double* nn_ms);
 int tdtk_count_visits(const tdtk_tree* t, const double* q, size_t K, double maxdist2,
                       uint64_t counters[3] /* internal nodes, leaves, leaf points */);
 
+/* ---- on-disk formats either side of the path (host only): uos ASCII scans with the -m/-M range
+ * filter (src/scanio/helper.cc:564-880, src/slam6d/pointfilter.cc:162-188), .pose files
+ * (helper.cc:192-234) and .frames files (src/slam6d/basicScan.cc:902-917).                  */
+int tdtk_io_read_uos(const char* path, double range_max, double range_min, double** xyz_out,
+                     size_t* n_out);
+void tdtk_io_free(void* p);
+int tdtk_io_read_pose(const char* path, double rPos[3], double rPosTheta[3]);
+int tdtk_io_write_frames(const char* path, const double* transMats, const int* types, size_t count,
+                         int append);
+
 /* ---- host-only diagnostics (no device needed; used by the CPU test tier) ----------------
  * tdtk_host_tree_layout: run the host tree builder only.  perm_out [M] = caller indices in
  * leaf order (== the reference's post-build pointer order); stats = {internal nodes, leaves,

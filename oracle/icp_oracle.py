@@ -258,9 +258,39 @@ class OScan:
         self.transform(orc.mmult(prev.transMat, tmp))
 
 
-def get_pt_pairs(source, target, maxdist2, mode=0):
+def rand_keep_mask(n, rnd):
+    """`if (rnd > 1 && rand(rnd) != 0) continue;` (searchTree.cc:118) with rand(int) of
+    globals.icc:607-610, one libc rand() per candidate in index order (serial build)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.rand.restype = ctypes.c_int
+    return np.array([int(float(rnd) * float(libc.rand()) / (2147483647 + 1.0)) == 0 for _ in range(n)], dtype=bool)
+
+
+class MetaOScan:
+    """MetaScan + KDtreeMetaManaged (metaScan.cc:27-107, kdMeta.cc:34-134): tree over the current
+    points of the member scans in concatenation order, identity dalignxf."""
+
+    def __init__(self, scans):
+        self.scans = list(scans)
+        self.dalignxf = np.eye(4).reshape(16).copy()
+        self.kd = None
+
+    def tree(self):
+        if self.kd is None:
+            self._pts = np.ascontiguousarray(np.concatenate([s.xyz for s in self.scans]))
+            self.kd = orc.Tree(self._pts, self.scans[0].bucket)
+        return self.kd
+
+
+def get_pt_pairs(source, target, maxdist2, mode=0, rnd=0):
     """Scan::getPtPairs (scan.cc:1220-1260): whole scan, centroids normalised"""
-    r = source.tree().get_pt_pairs(source.dalignxf, target.xyz, target.normals, 0, None, mode, maxdist2)
+    xyz, nrm = target.xyz, target.normals
+    if rnd > 1:
+        keep = rand_keep_mask(len(xyz), rnd)
+        xyz = np.ascontiguousarray(xyz[keep])
+        nrm = None if nrm is None else np.ascontiguousarray(nrm[keep])
+    r = source.tree().get_pt_pairs(source.dalignxf, xyz, nrm, 0, None, mode, maxdist2)
     if r["n"]:
         r["cm"] = r["centroid_m"] / r["n"]
         r["cd"] = r["centroid_d"] / r["n"]
@@ -270,7 +300,7 @@ def get_pt_pairs(source, target, maxdist2, mode=0):
 
 
 def match(prev, cur, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsilonICP=1e-7, mode=0,
-          align_fn=None):
+          align_fn=None, rnd=0):
     """icp6D::match (icp6D.cc:104-285), serial-branch semantics (icp6D.cc:225-246).
     Returns (iter, trace) with trace rows (pairs, rms, alignxf[16])."""
     align_fn = align_fn or align
@@ -281,7 +311,7 @@ def match(prev, cur, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsil
     it = 0
     for it in range(max_num_iterations):
         prev_prev_ret, prev_ret = prev_ret, ret
-        r = get_pt_pairs(prev, cur, max_dist_match2, mode)
+        r = get_pt_pairs(prev, cur, max_dist_match2, mode, rnd)
         if r["n"] > 3:
             ret, alignxf = align_fn(algo, r["p1"], r["p2"], r["cm"], r["cd"], r["pn"])
         else:
@@ -292,6 +322,26 @@ def match(prev, cur, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsil
                 it == max_num_iterations - 1:
             break
     return it, trace
+
+
+def do_icp(scans, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsilonICP=1e-7, meta=False,
+           rnd=0, eP=True, max_num_metascans=-1):
+    """icp6D::doICP (icp6D.cc:374-437) -> list of (iter, trace) per matched scan"""
+    out = []
+    metas, my_meta = [], None
+    for i, cur in enumerate(scans):
+        if i > 0:
+            if eP:
+                cur.mergeCoordinatesWithRoboterPosition(scans[i - 1])
+            out.append(match(my_meta if meta else scans[i - 1], cur, algo, max_dist_match2, max_num_iterations,
+                             epsilonICP, 0, None, rnd))
+        if meta and i != len(scans) - 1:
+            metas.append(cur)
+            if max_num_metascans > 0:
+                while len(metas) > max_num_metascans:
+                    metas.pop(0)
+            my_meta = MetaOScan(metas)
+    return out
 
 
 # ---------------------------------------------------------------------------------------

@@ -43,8 +43,9 @@ def test_errors(tdtk, gpu):
     kd = tdtk.KDtree(np.random.default_rng(0).uniform(-1, 1, (50, 3)))
     idx, d2 = kd.FindClosestBatch(np.zeros((0, 3)), 1.0)   # empty batch
     assert len(idx) == 0
-    with pytest.raises(tdtk.TdtkError) as e:
-        tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 5, rnd=5)  # resident-scan loop: rnd > 1 unsupported
+    with pytest.raises(tdtk.TdtkError) as e:                # resident-scan pass: rnd > 1 unsupported
+        tdtk.Scan.getPtPairs(tdtk.Scan([0, 0, 0], [0, 0, 0], np.zeros((4, 3))),
+                             tdtk.Scan([0, 0, 0], [0, 0, 0], np.zeros((4, 3))), rnd=5)
     assert e.value.code == -5
     with pytest.raises(tdtk.TdtkError):
         kd.getPtPairs(tdtk.M4identity(), np.zeros((4, 3)), pairing_mode=2)   # needs normals
@@ -379,3 +380,52 @@ def test_full_size_icp_recovers_pose(tdtk, orc, gpu, k5):
     assert it < 99
     assert np.abs(ds.get_transMat() - T).max() < 5e-3           # noise floor of sigma=1 on 1M points
     assert icp.last["rms"] < 2.0
+
+
+def _range_filter(p, rmax):
+    return np.ascontiguousarray(p[p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1] + p[:, 2] * p[:, 2] < rmax * rmax])
+
+
+@pytest.mark.parametrize("rnd", [1, 5])
+def test_config1_metascan_dat(tdtk, orc, gpu, rnd, tmp_path):
+    """BASELINE configs[0]: `slam6D -m 500 -R 5 -d 25.0 --metascan dat` (plumbing).  -R 5 draws
+    std::rand() per candidate, so the comparison seeds libc identically for both runs (serial-build
+    semantics); rnd=1 runs the device-resident loop against the MetaScan tree."""
+    import ctypes as C
+    from oracle import icp_oracle as io
+    libc = C.CDLL(None)
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    pts = [_range_filter(z["scan%03d" % k], 500.0) for k in range(3)]
+    assert [len(p) for p in pts] != [81360] * 3                      # the filter bites
+    S = [tdtk.Scan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], pts[k]) for k in range(3)]
+    O = [io.OScan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], pts[k]) for k in range(3)]
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 50, quiet=True, meta=True, rnd=rnd, epsilonICP=1e-5)
+    libc.srand(42)
+    traces = []
+    orig_match = icp.match
+
+    def rec(a, b, pm=0):
+        r = orig_match(a, b, pm)
+        traces.append((r, icp.last["trace"].copy()))
+        return r
+    icp.match = rec
+    icp.doICP(S)
+    libc.srand(42)
+    want = io.do_icp(O, 1, 625.0, 50, 1e-5, True, rnd, True)
+    assert len(traces) == len(want) == 2
+    for (it, tr), (oit, otr) in zip(traces, want):
+        assert it == oit
+        assert [int(r[0]) for r in tr] == [t[0] for t in otr]
+        np.testing.assert_allclose(tr[:, 1], [t[1] for t in otr], rtol=1e-9)
+    for s, o in zip(S, O):
+        assert _rel(s.get_transMat(), o.transMat) < 1e-9
+    # second match ran against a MetaScan of two scans (concatenated, current poses)
+    assert traces[1][1][0][0] > traces[0][1][0][0] * 0.5
+    # .frames output (N2): 16 entries at 6 significant digits + AlgoType per line
+    S[1].identifier, S[1].path = "001", str(tmp_path)
+    fn = tdtk.saveFrames(S[1])
+    lines = open(fn).read().strip().split("\n")
+    assert len(lines) == len(S[1].frames)
+    last = [float(t) for t in lines[-1].split()]
+    assert len(last) == 17 and int(last[16]) == 1
+    np.testing.assert_allclose(last[:16], S[1].get_transMat(), rtol=2e-5, atol=1e-6)

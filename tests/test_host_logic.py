@@ -285,3 +285,36 @@ def test_adapter_compiles_against_reference_headers(tmp_path):
     syms = subprocess.run(["nm", "-C", str(obj)], capture_output=True, text=True).stdout
     for want in ("HipSearchTree::getPtPairs", "HipSearchTree::FindClosest", "tdtk_get_pt_pairs", "tdtk_tree_create"):
         assert want in syms
+
+
+def test_scan_io_uos_pose_frames(tdtk, tmp_path):
+    """uos reader (header line, comments, blank lines, CRLF, -m/-M range filter), .pose reader
+    (deg -> rad with rad()), .frames writer (default-ostream formatting + AlgoType)."""
+    f = tmp_path / "scan000.3d"
+    f.write_text("3\n# a comment\n1.5 2 -3\r\n\n10.1 0 0 # trailing comment\n  600 1 1\n0.1 0.1 0.1\n")
+    p = tdtk.read_uos(f)
+    assert np.array_equal(p, [[1.5, 2, -3], [10.1, 0, 0], [600, 1, 1], [0.1, 0.1, 0.1]])
+    assert np.array_equal(tdtk.read_uos(f, 500.0), [[1.5, 2, -3], [10.1, 0, 0], [0.1, 0.1, 0.1]])
+    assert np.array_equal(tdtk.read_uos(f, 500.0, 1.0), [[1.5, 2, -3], [10.1, 0, 0]])
+    bad = tmp_path / "bad.3d"
+    bad.write_text("1 2 3\n4 5\n")
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.read_uos(bad)
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.read_uos(tmp_path / "missing.3d")
+    (tmp_path / "scan000.pose").write_text("-3.10605 -7.50803 156.917\n1.35694 -0.852409 -0.56224\n")
+    rP, rT = tdtk.read_pose(tmp_path / "scan000.pose")
+    assert np.array_equal(rP, [-3.10605, -7.50803, 156.917])
+    assert np.array_equal(rT, [(2 * np.pi * a) / 360 for a in (1.35694, -0.852409, -0.56224)])
+
+    class S:
+        pass
+    s = S()
+    s.identifier, s.path = "000", str(tmp_path)
+    M = np.eye(4).reshape(16).copy(); M[12:15] = [1234.56789, -0.000123456789, 1e-7]
+    s.frames = [(np.eye(4).reshape(16), "ICP"), (M, "LUM"), (M, "INVALID")]
+    fn = tdtk.saveFrames(s)
+    lines = open(fn).read().split("\n")
+    assert lines[0] == "1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1 1"
+    assert lines[1] == "1 0 0 0 0 1 0 0 0 0 1 0 1234.57 -0.000123457 1e-07 1 3"
+    assert lines[2].endswith(" 0") and lines[3] == ""
