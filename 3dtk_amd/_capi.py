@@ -10,7 +10,7 @@ _SO = os.path.join(_HERE, "lib3dtk_hip.so")
 
 ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX = 1, 2, 6, 10
 CLOSEST_POINT, CLOSEST_POINT_ALONG_NORMAL_SIMPLE, CLOSEST_PLANE_SIMPLE = 0, 1, 2
-WANT_APX, WANT_NAPX, WANT_LUM = 1, 2, 4
+WANT_APX, WANT_NAPX, WANT_LUM, WANT_GAPX = 1, 2, 4, 8
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -28,7 +28,9 @@ class PairSums(C.Structure):
                 ("centroid_m", C.c_double * 3), ("centroid_d", C.c_double * 3),
                 ("Si", C.c_double * 9), ("apx_A", C.c_double * 6), ("apx_B", C.c_double * 3),
                 ("napx_A", C.c_double * 21), ("napx_B", C.c_double * 6), ("napx_sum", C.c_double),
-                ("lum", C.c_double * 15), ("lum_sumd2", C.c_double)]
+                ("lum", C.c_double * 15), ("lum_sumd2", C.c_double),
+                ("gapx_MkMkt", C.c_double * 9), ("gapx_DkDkt", C.c_double * 9), ("gapx_MkDkt", C.c_double * 9),
+                ("gapx_DkMkt", C.c_double * 9), ("gapx_Ak1", C.c_double * 3), ("gapx_Ak2", C.c_double * 3)]
 
 
 class TreeInfo(C.Structure):
@@ -53,7 +55,8 @@ EXPORTS = [
     "tdtk_tree_get_info", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
-    "tdtk_lum_link", "tdtk_lum_links", "tdtk_lum_update_poses", "tdtk_solve_spd", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_solve_spd",
+    "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
     "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
 ]
@@ -124,7 +127,11 @@ def lib():
     L.tdtk_lum_links.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, C.POINTER(C.c_void_p), C.c_double, _dp,
                                  _dp, _u64p, _dp]
     L.tdtk_lum_update_poses.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_void_p), _dp, _dp]
+    L.tdtk_links_pair_sums.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, C.POINTER(C.c_void_p), C.c_double,
+                                       C.c_uint32, C.POINTER(PairSums)]
     L.tdtk_solve_spd.argtypes = [_dp, _dp, C.c_int, _dp]
+    L.tdtk_solve_chol_upper.argtypes = [_dp, _dp, C.c_int, _dp]
+    L.tdtk_invert.argtypes = [_dp, C.c_int, _dp]
     L.tdtk_last_kernel_ms.argtypes = [_dp]
     L.tdtk_count_visits.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _u64p]
     L.tdtk_host_tree_layout.argtypes = [_dp, C.c_size_t, C.c_int, _ip, _u64p]

@@ -381,6 +381,45 @@ static void finish_sums(const double* acc, const double shift[3], size_t nq, uns
   }
   if (want & TDTK_WANT_LUM)
     for (int k = 0; k < 15; k++) o->lum[k] = acc[ACC_L + k];
+  if (want & TDTK_WANT_GAPX) {
+    // a = p1 - cm, b = p2 - cm (BOTH about centroid_m, gapx6D.cc:185-191); w = cm - shift = Sm/n
+    double MM[3][3], DD[3][3], Saa[3][3], Sbb[3][3], Sab[3][3], Sb[3];
+    const double* mm = acc + ACC_MM;
+    const double* dd = acc + ACC_DD;
+    MM[0][0] = mm[0]; MM[0][1] = MM[1][0] = mm[1]; MM[0][2] = MM[2][0] = mm[2];
+    MM[1][1] = mm[3]; MM[1][2] = MM[2][1] = mm[4]; MM[2][2] = mm[5];
+    DD[0][0] = dd[0]; DD[0][1] = DD[1][0] = dd[1]; DD[0][2] = DD[2][0] = dd[2];
+    DD[1][1] = dd[3]; DD[1][2] = DD[2][1] = dd[4]; DD[2][2] = dd[5];
+    for (int i = 0; i < 3; i++) {
+      Sb[i] = Sd[i] - Sm[i];
+      for (int j = 0; j < 3; j++) {
+        Saa[i][j] = MM[i][j] - n * wm[i] * wm[j];
+        Sbb[i][j] = DD[i][j] - wm[i] * Sd[j] - wm[j] * Sd[i] + n * wm[i] * wm[j];
+        Sab[i][j] = acc[ACC_P + i * 3 + j] - wm[i] * Sd[j];
+      }
+    }
+    auto sym = [](const double S[3][3], double* o9) {
+      o9[0] = S[1][1] + S[2][2]; o9[1] = -S[0][1]; o9[2] = -S[0][2];
+      o9[3] = -S[0][1]; o9[4] = S[0][0] + S[2][2]; o9[5] = -S[1][2];
+      o9[6] = -S[0][2]; o9[7] = -S[1][2]; o9[8] = S[0][0] + S[1][1];
+    };
+    sym(Saa, o->gapx_MkMkt);
+    sym(Sbb, o->gapx_DkDkt);
+    // sum(p1 - cm) is zero by construction; the literal "+ p1y + p2y" terms leave sum(p2 - cm)
+    const double d11 = Sab[1][1] + Sb[2], d22 = Sab[0][0] + Sb[2], d33 = Sab[0][0] + Sb[1];
+    double* A = o->gapx_MkDkt;
+    A[0] = d11; A[1] = -Sab[1][0]; A[2] = -Sab[2][0];
+    A[3] = -Sab[1][0]; A[4] = d22; A[5] = -Sab[2][1];
+    A[6] = -Sab[2][0]; A[7] = -Sab[2][1]; A[8] = d33;
+    double* Bm = o->gapx_DkMkt;
+    Bm[0] = d11; Bm[1] = -Sab[0][1]; Bm[2] = -Sab[0][2];
+    Bm[3] = -Sab[0][1]; Bm[4] = d22; Bm[5] = -Sab[1][2];
+    Bm[6] = -Sab[0][2]; Bm[7] = -Sab[1][2]; Bm[8] = d33;
+    o->gapx_Ak2[0] = Sab[2][1] - Sab[1][2];
+    o->gapx_Ak2[1] = Sab[0][2] - Sab[2][0];
+    o->gapx_Ak2[2] = Sab[1][0] - Sab[0][1];
+    for (int k = 0; k < 3; k++) o->gapx_Ak1[k] = -o->gapx_Ak2[k];
+  }
 }
 
 // search + accumulate over a resident scan.  acc_out (host, ACC_TOTAL) receives raw columns.
@@ -970,6 +1009,81 @@ int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_
   ss = 1.0 / ss;
   for (int k = 0; k < 36; k++) C[k] = MM[k] * ss;
   for (int k = 0; k < 6; k++) CD[k] = MZ[k] * ss;
+  return TDTK_OK;
+}
+
+// ---- batched whole-scan passes over a list of links --------------------------------------------
+int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                         tdtk_scan* const* second, double maxd2, uint32_t want, tdtk_pair_sums* sums)
+{
+  if (nlinks < 0 || (nlinks && (!first || !first_dalignxf || !second || !sums))) { set_error("bad argument"); return TDTK_EINVAL; }
+  if (nlinks == 0) return TDTK_OK;
+  if (want & TDTK_WANT_NAPX) { set_error("NAPX needs normals: use tdtk_scan_pairs"); return TDTK_EUNSUP; }
+  Ctx* c;
+  int rc = get_ctx(first[0]->device, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  if ((rc = c->ws[WS_TMPB].ensure((size_t)nlinks * ACC_TOTAL * sizeof(double)))) return rc;
+  double* d_out = c->ws[WS_TMPB].as<double>();
+  std::vector<double> shifts(3 * (size_t)nlinks);
+  size_t maxN = 0;
+  for (int i = 0; i < nlinks; i++) {
+    if (!first[i] || !second[i]) { set_error("NULL link member"); return TDTK_EINVAL; }
+    if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
+    maxN = std::max(maxN, second[i]->N);
+  }
+  if ((rc = c->ws[WS_KPOS].ensure(maxN * sizeof(int)))) return rc;
+  if ((rc = c->ws[WS_PART].ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
+  for (int i = 0; i < nlinks; i++) {
+    const tdtk_tree* t = first[i];
+    tdtk_scan* data = second[i];
+    const double* A16 = first_dalignxf + 16 * (size_t)i;
+    for (int k = 0; k < 3; k++)
+      shifts[3 * i + k] = t->centre[0] * A16[k] + t->centre[1] * A16[4 + k] + t->centre[2] * A16[8 + k] + A16[12 + k];
+    if (data->N == 0) continue;
+    Mat4 A, inv;
+    std::memcpy(A.m, A16, sizeof A.m);
+    m4inv(A16, inv.m);
+    SearchArgs sa{};
+    sa.x = data->x; sa.y = data->y; sa.z = data->z;
+    sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
+    sa.kpos = c->ws[WS_KPOS].as<int>();
+    rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1);
+    if (rc) return rc;
+    AccumArgs aa{};
+    aa.T = t->dev;
+    aa.x = data->x; aa.y = data->y; aa.z = data->z;
+    aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
+    for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * i + k];
+    aa.partials = c->ws[WS_PART].as<double>();
+    HIPCHK(launch_accum(aa, accum_grid(data->N), want, 0, d_out + (size_t)i * ACC_TOTAL, s));
+  }
+  std::vector<double> acc((size_t)nlinks * ACC_TOTAL);
+  HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  collect_ms(c, nullptr);
+  for (int i = 0; i < nlinks; i++)
+    finish_sums(acc.data() + (size_t)i * ACC_TOTAL, shifts.data() + 3 * i, second[i]->N, want, sums + i);
+  return TDTK_OK;
+}
+
+int tdtk_solve_chol_upper(const double* G, const double* B, int n, double* x)
+{
+  if (!G || !B || !x || n <= 0) { set_error("bad argument"); return TDTK_EINVAL; }
+  std::vector<double> S((size_t)n * n);
+  for (int i = 0; i < n; i++)
+    for (int j = i; j < n; j++) S[(size_t)i * n + j] = S[(size_t)j * n + i] = G[(size_t)i * n + j];
+  std::vector<double> xs(n);
+  if (!solve_spd_dense(n, S.data(), B, xs.data(), 0.00001)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+  std::memcpy(x, xs.data(), sizeof(double) * n);
+  return TDTK_OK;
+}
+
+int tdtk_invert(const double* A, int n, double* Ainv)
+{
+  if (!A || !Ainv || n <= 0) { set_error("bad argument"); return TDTK_EINVAL; }
+  if (!invert_dense(n, A, Ainv)) { set_error("singular matrix"); return TDTK_ESOLVE; }
   return TDTK_OK;
 }
 

@@ -48,7 +48,8 @@ enum {
   ACC_NS = 50,   // 1: sum ((p1-p2).n)^2
   ACC_L = 51,    // 15: lum6DEuler sums                              [LUM]
   ACC_LSS = 66,  // 1: residual^2 against D (second pass)
-  ACC_TOTAL = 67
+  ACC_MM = 67,   // 6: sum (m - shift)_a (m - shift)_b, upper       [GAPX, with ACC_DD]
+  ACC_TOTAL = 73
 };
 
 struct AccumArgs {

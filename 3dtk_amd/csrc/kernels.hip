@@ -425,7 +425,11 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
     acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
     acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
     acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
-    if (WANT & TDTK_WANT_APX) {
+    if (WANT & TDTK_WANT_GAPX) {
+      acc[ACC_MM + 0] += m0 * m0; acc[ACC_MM + 1] += m0 * m1; acc[ACC_MM + 2] += m0 * m2;
+      acc[ACC_MM + 3] += m1 * m1; acc[ACC_MM + 4] += m1 * m2; acc[ACC_MM + 5] += m2 * m2;
+    }
+    if (WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) {
       acc[ACC_DD + 0] += d0 * d0; acc[ACC_DD + 1] += d0 * d1; acc[ACC_DD + 2] += d0 * d2;
       acc[ACC_DD + 3] += d1 * d1; acc[ACC_DD + 4] += d1 * d2; acc[ACC_DD + 5] += d2 * d2;
     }
@@ -472,18 +476,20 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
 #pragma unroll
   for (int k = 0; k < ACC_TOTAL; k++) {
-    const bool used = (k < ACC_DD) || ((WANT & TDTK_WANT_APX) && k >= ACC_DD && k < ACC_NA) ||
+    const bool used = (k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
                       ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
-                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L);
+                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L && k < ACC_MM) ||
+                      ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM);
     if (!used) continue;
     const double s = wave_sum(acc[k]);
     if (lane == 0) red[wv][k] = s;
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
-    const bool used = (k < ACC_DD) || ((WANT & TDTK_WANT_APX) && k >= ACC_DD && k < ACC_NA) ||
+    const bool used = (k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
                       ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
-                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L);
+                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L && k < ACC_MM) ||
+                      ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM);
     double s = 0.0;
     if (used)
       for (int w = 0; w < NW; w++) s += red[w][k];
@@ -697,6 +703,9 @@ static void launch_accum_w(const AccumArgs& a, uint32_t grid, int pmode, hipStre
 hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pmode, double* d_out,
                         hipStream_t s)
 {
+  if (want & TDTK_WANT_GAPX) {
+    launch_accum_w<TDTK_WANT_GAPX>(a, grid, pmode, s);
+  } else
   switch (want & 7u) {
     case 0: launch_accum_w<0>(a, grid, pmode, s); break;
     case 1: launch_accum_w<1>(a, grid, pmode, s); break;

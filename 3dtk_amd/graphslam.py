@@ -135,6 +135,104 @@ def lum_iteration_native(gr, allScans, max_dist_match2, group=None, device=None)
     return ret.value
 
 
+def compute_rt(x, dx):
+    """icp6D_APX::computeRt (src/slam6d/icp6Dapx.cc:310-335): small-angle rotation from the three
+    solved sines + translation dx, column-major."""
+    import math
+    sx, sy, sz = x[0], x[1], x[2]
+    cx, cy, cz = math.sqrt(1.0 - sx * sx), math.sqrt(1.0 - sy * sy), math.sqrt(1.0 - sz * sz)
+    a = np.zeros(16)
+    a[0] = cy * cz; a[1] = sx * sy * cz + cx * sz; a[2] = -cx * sy * cz + sx * sz
+    a[4] = -cy * sz; a[5] = -sx * sy * sz + cx * cz; a[6] = cx * sy * sz + sx * cz
+    a[8] = sy; a[9] = -sx * cy; a[10] = cx * cy
+    a[12], a[13], a[14] = dx[0], dx[1], dx[2]
+    a[15] = 1
+    return a
+
+
+def gapx_iteration(gr, allScans, max_dist_match2, T, group=None, device=None):
+    """One iteration of gapx6D::doGraphSlam6D (src/slam6d/gapx6D.cc:323-542), links sharded like
+    FillGB3D: each rank evaluates its links' genBArotForLinkedPair blocks on the GPU (one batched
+    call), a single all-reduce combines the dense rotation system (B | A) together with the per-link
+    centroids the translation step needs, then every rank solves redundantly.  T is the reference's
+    translation vector, which keeps accumulating over the iterations of one call."""
+    import ctypes as C
+    from ._capi import lib, check, dptr, PairSums, WANT_GAPX
+    rank, world = 0, 1
+    if group is not None or _dist_ready():
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    nscans = gr.getNrScans()
+    n = nscans - 1
+    nlinks = gr.getNrLinks()
+    mine = shard_links(nlinks, rank, world)
+    nl = len(mine)
+    B = np.zeros((3 * n, 3 * n)); A = np.zeros(3 * n)
+    cent = np.zeros((nlinks, 7))            # cm[3], cd[3], non-empty flag
+    if nl:
+        first = (C.c_void_p * nl)(*[allScans[gr.getLink(i, 0)].getSearchTree()._h for i in mine])
+        second = (C.c_void_p * nl)(*[allScans[gr.getLink(i, 1)].handle for i in mine])
+        dal = np.ascontiguousarray(np.stack([allScans[gr.getLink(i, 0)].dalignxf for i in mine]))
+        sums = (PairSums * nl)()
+        check(lib().tdtk_links_pair_sums(nl, first, dptr(dal), second, float(max_dist_match2), WANT_GAPX, sums))
+        for k, i in enumerate(mine):
+            s = sums[k]
+            f, sx = gr.getLink(i, 0), gr.getLink(i, 1)
+            cent[i, :3] = s.centroid_m; cent[i, 3:6] = s.centroid_d
+            if s.n <= 1:                      # "Error: Link ... is empty" (gapx6D.cc:424-431)
+                continue
+            cent[i, 6] = 1.0
+            a, b = f - 1, sx - 1
+            if f != 0:
+                A[a * 3:a * 3 + 3] += np.array(s.gapx_Ak1)
+                B[a * 3:a * 3 + 3, a * 3:a * 3 + 3] += np.array(s.gapx_MkMkt).reshape(3, 3)
+                B[a * 3:a * 3 + 3, b * 3:b * 3 + 3] += np.array(s.gapx_DkMkt).reshape(3, 3)
+                B[b * 3:b * 3 + 3, a * 3:a * 3 + 3] += np.array(s.gapx_MkDkt).reshape(3, 3)
+            A[b * 3:b * 3 + 3] += np.array(s.gapx_Ak2)
+            B[b * 3:b * 3 + 3, b * 3:b * 3 + 3] += np.array(s.gapx_DkDkt).reshape(3, 3)
+    if group is not None or _dist_ready():
+        import torch
+        import torch.distributed as dist
+        flat = torch.from_numpy(np.concatenate([B.reshape(-1), A, cent.reshape(-1)]))
+        if device is not None:
+            flat = flat.to(device)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat = flat.cpu().numpy()
+        m = 3 * n
+        B = flat[:m * m].reshape(m, m).copy(); A = flat[m * m:m * m + m].copy()
+        cent = flat[m * m + m:].reshape(nlinks, 7).copy()
+    sum_position_diff = float(cent[:, 6].sum())          # genBArotForLinkedPair returns 1.0 per link (sic)
+    X = np.empty(3 * n)
+    check(lib().tdtk_solve_chol_upper(dptr(np.ascontiguousarray(B)), dptr(A), 3 * n, dptr(X)))
+    # translation system (genBAtransForLinkedPair, gapx6D.cc:76-137)
+    Bt = np.zeros((n, n)); At = np.zeros(3 * n)
+
+    def rot_apply(x, p):
+        a = compute_rt(x, (0.0, 0.0, 0.0))
+        xn = p[0] * a[0] + p[1] * a[4] + p[2] * a[8]
+        yn = p[0] * a[1] + p[1] * a[5] + p[2] * a[9]
+        zn = p[0] * a[2] + p[1] * a[6] + p[2] * a[10]
+        return np.array([xn + a[12], yn + a[13], zn + a[14]])           # Point::transform
+    for i in range(nlinks):
+        f, sx = gr.getLink(i, 0), gr.getLink(i, 1)
+        x = X[(f - 1) * 3:(f - 1) * 3 + 3] if f != 0 else np.zeros(3)
+        Ak1 = rot_apply(x, cent[i, :3]) - rot_apply(X[(sx - 1) * 3:(sx - 1) * 3 + 3], cent[i, 3:6])
+        if f != 0:
+            At[(f - 1) * 3:(f - 1) * 3 + 3] -= Ak1
+            Bt[f - 1, f - 1] += 1
+            Bt[f - 1, sx - 1] -= 1; Bt[sx - 1, f - 1] -= 1
+        At[(sx - 1) * 3:(sx - 1) * 3 + 3] += Ak1
+        Bt[sx - 1, sx - 1] += 1
+    Bti = np.empty((n, n))
+    check(lib().tdtk_invert(dptr(np.ascontiguousarray(Bt)), n, dptr(Bti)))
+    T += (Bti @ At.reshape(n, 3)).reshape(-1)
+    for i in range(1, nscans):
+        dx = T[(i - 1) * 3:(i - 1) * 3 + 3]
+        allScans[i].transform(compute_rt(X[(i - 1) * 3:(i - 1) * 3 + 3], dx), "LUM", 1 if i < nscans - 1 else 2)
+        sum_position_diff += float(np.sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]))
+    return sum_position_diff / nscans
+
+
 def _dist_ready():
     try:
         import torch.distributed as dist

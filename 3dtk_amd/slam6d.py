@@ -89,7 +89,10 @@ def _sums_dict(s):
                 centroid_m=np.array(s.centroid_m), centroid_d=np.array(s.centroid_d),
                 Si=np.array(s.Si), apx_A=np.array(s.apx_A), apx_B=np.array(s.apx_B),
                 napx_A=np.array(s.napx_A), napx_B=np.array(s.napx_B), napx_sum=s.napx_sum,
-                lum=np.array(s.lum), lum_sumd2=s.lum_sumd2)
+                lum=np.array(s.lum), lum_sumd2=s.lum_sumd2,
+                gapx_MkMkt=np.array(s.gapx_MkMkt).reshape(3, 3), gapx_DkDkt=np.array(s.gapx_DkDkt).reshape(3, 3),
+                gapx_MkDkt=np.array(s.gapx_MkDkt).reshape(3, 3), gapx_DkMkt=np.array(s.gapx_DkMkt).reshape(3, 3),
+                gapx_Ak1=np.array(s.gapx_Ak1), gapx_Ak2=np.array(s.gapx_Ak2))
 
 
 # ---------------------------------------------------------------------------------------
@@ -631,6 +634,30 @@ class lum6DEuler:
                 ret = lum_iteration_native(gr, allScans, self.max_dist_match2_LUM, self.group, device)
             else:
                 ret = lum_iteration(gr, allScans, self.max_dist_match2_LUM, self.group, None, device)
+            it += 1
+        return ret
+
+
+class gapx6D:
+    """gapx6D (-G 4, src/slam6d/gapx6D.cc): graph-SLAM with the small-angle (APX) linearisation:
+    a 3(n-1) rotation system from per-link second moments, then translations from the link
+    Laplacian.  Same link sharding / single all-reduce as lum6DEuler."""
+
+    def __init__(self, my_icp=None, mdm=25.0, max_dist_match_LUM=25.0, max_num_iterations=50, quiet=True,
+                 epsilonLUM=0.5, group=None):
+        self.my_icp = my_icp
+        self.max_dist_match2_LUM = max_dist_match_LUM * max_dist_match_LUM
+        self.epsilonLUM = epsilonLUM
+        self.group = group
+
+    def doGraphSlam6D(self, gr, allScans, nrIt, device=None):
+        from .graphslam import gapx_iteration
+        n = gr.getNrScans() - 1
+        T = np.zeros(3 * n)                 # not reset between iterations (gapx6D.cc:356,463-468)
+        ret = float("inf")
+        it = 0
+        while it < nrIt and ret > self.epsilonLUM:
+            ret = gapx_iteration(gr, allScans, self.max_dist_match2_LUM, T, self.group, device)
             it += 1
         return ret
 

@@ -52,6 +52,7 @@ enum { TDTK_ALGO_QUAT = 1, TDTK_ALGO_SVD = 2, TDTK_ALGO_APX = 6, TDTK_ALGO_NAPX 
 #define TDTK_WANT_APX 1u   /* A[6], B[3] of icp6D_APX (src/slam6d/icp6Dapx.cc:203-245)   */
 #define TDTK_WANT_NAPX 2u  /* A[21], B[6], sum of icp6D_NAPX (icp6Dnapx.cc:53-95)        */
 #define TDTK_WANT_LUM 4u   /* the 15 sums + ss of lum6DEuler::covarianceEuler            */
+#define TDTK_WANT_GAPX 8u  /* the per-link blocks of gapx6D::genBArotForLinkedPair (alone) */
 
 /* Merged per-call sums: what T OpenMP threads' (n, sum, centroid_m, centroid_d, Si)
  * of src/slam6d/icp6D.cc:129-192 add up to; feed slot 0 of Align_Parallel with it. */
@@ -69,6 +70,10 @@ typedef struct tdtk_pair_sums {
   double napx_sum;       /* sum ((p1-p2).n)^2                                           */
   double lum[15];        /* sx sy sz xpy xpz ypz xy xz yz MZ[0..5]  lum6Deuler.cc:143-175 */
   double lum_sumd2;      /* sum |p1-p2|^2 (== sum), kept for the ss identity check      */
+  /* gapx6D::genBArotForLinkedPair (src/slam6d/gapx6D.cc:153-310), both points centred on
+   * centroid_m, including the literal `p1x*p2x + p1y + p2y` diagonal terms (gapx6D.cc:208-210) */
+  double gapx_MkMkt[9], gapx_DkDkt[9], gapx_MkDkt[9], gapx_DkMkt[9];   /* row-major 3x3 */
+  double gapx_Ak1[3], gapx_Ak2[3];
 } tdtk_pair_sums;
 
 typedef struct tdtk_tree_info {
@@ -190,6 +195,12 @@ int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* firs
                    tdtk_scan* const* second, double max_dist_match2, double* C /*[nlinks][36]*/,
                    double* CD /*[nlinks][6]*/, uint64_t* m /*[nlinks]*/, double* ss /*[nlinks]*/);
 
+/* Batched Scan::getPtPairs over a list of links (first[i] = model tree + dalignxf, second[i] =
+ * resident data scan) with any accumulator blocks: one sync for the whole batch.  sums[nlinks]. */
+int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                         tdtk_scan* const* second, double max_dist_match2, uint32_t want,
+                         tdtk_pair_sums* sums);
+
 /* Pose update of lum6DEuler::doGraphSlam6D (lum6Deuler.cc:378-473) for scans 1..n-1:
  * result = Ha^-1 * X_i, pose -= result, Scan::transformToEuler (scan.cc:1061-1083: transform by
  * M4inv(transMat), then by EulerToMatrix4(new pose)).  transMat/dalignxf/rPos/rPosTheta are
@@ -204,6 +215,11 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
  * 477-503): dense SPD solve of G x = B (G row-major n x n, entries with |v| <= 1e-5
  * dropped like convertToCS does).  x may alias B.                                       */
 int tdtk_solve_spd(const double* G, const double* B, int n, double* x);
+/* graphSlam6D::solveSparseCholesky(const Matrix&, B) (graphSlam6D.cc:302-343) as gapx6D calls it on
+ * a matrix that is not exactly symmetric: CSparse's cs_cholsol reads the UPPER triangle only.   */
+int tdtk_solve_chol_upper(const double* G, const double* B, int n, double* x);
+/* dense inverse (newmat `.i()`), row-major n x n */
+int tdtk_invert(const double* A, int n, double* Ainv);
 
 /* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
  * traversal counters of the last counting run.                                          */

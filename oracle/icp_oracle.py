@@ -447,6 +447,106 @@ def lum_iteration(links, scans, maxdist2):
 
 
 # ---------------------------------------------------------------------------------------
+# gapx6D (-G 4), src/slam6d/gapx6D.cc
+# ---------------------------------------------------------------------------------------
+def compute_rt(x, dx):
+    """icp6D_APX::computeRt (icp6Dapx.cc:310-335)"""
+    a = np.zeros(16)
+    R = _apx_rotation(x)
+    for r in range(3):
+        for c in range(3):
+            a[c * 4 + r] = R[r, c]
+    a[12:15] = dx
+    a[15] = 1
+    return a
+
+
+def gapx_link_blocks(p1, p2, cm):
+    """gapx6D::genBArotForLinkedPair (gapx6D.cc:153-310): the per-link sums, literally (including
+    `p1x*p2x + p1y + p2y`), both points centred on centroids_m."""
+    a = p1 - cm
+    b = p2 - cm
+    p1x, p1y, p1z = a.T
+    p2x, p2y, p2z = b.T
+    MkMkt = np.array([[(p1y * p1y + p1z * p1z).sum(), -(p1x * p1y).sum(), -(p1x * p1z).sum()],
+                      [-(p1x * p1y).sum(), (p1x * p1x + p1z * p1z).sum(), -(p1y * p1z).sum()],
+                      [-(p1x * p1z).sum(), -(p1y * p1z).sum(), (p1x * p1x + p1y * p1y).sum()]])
+    DkDkt = np.array([[(p2y * p2y + p2z * p2z).sum(), -(p2x * p2y).sum(), -(p2x * p2z).sum()],
+                      [-(p2x * p2y).sum(), (p2x * p2x + p2z * p2z).sum(), -(p2y * p2z).sum()],
+                      [-(p2x * p2z).sum(), -(p2y * p2z).sum(), (p2x * p2x + p2y * p2y).sum()]])
+    d11 = (p1y * p2y + p1z + p2z).sum()       # p1yp2yp1zp2z  (sic)
+    d22 = (p1x * p2x + p1z + p2z).sum()       # p1xp2xp1zp2z
+    d33 = (p1x * p2x + p1y + p2y).sum()       # p1xp2xp1yp2y
+    MkDkt = np.array([[d11, -(p1y * p2x).sum(), -(p1z * p2x).sum()],
+                      [-(p1y * p2x).sum(), d22, -(p1z * p2y).sum()],
+                      [-(p1z * p2x).sum(), -(p1z * p2y).sum(), d33]])
+    DkMkt = np.array([[d11, -(p2y * p1x).sum(), -(p2z * p1x).sum()],
+                      [-(p2y * p1x).sum(), d22, -(p2z * p1y).sum()],
+                      [-(p2z * p1x).sum(), -(p2z * p1y).sum(), d33]])
+    Ak1 = -np.array([((p1z - p2z) * p2y - (p1y - p2y) * p2z).sum(), ((p1x - p2x) * p2z - (p1z - p2z) * p2x).sum(),
+                     ((p1y - p2y) * p2x - (p1x - p2x) * p2y).sum()])
+    Ak2 = np.array([((p1z - p2z) * p1y - (p1y - p2y) * p1z).sum(), ((p1x - p2x) * p1z - (p1z - p2z) * p1x).sum(),
+                    ((p1y - p2y) * p1x - (p1x - p2x) * p1y).sum()])
+    return MkMkt, DkDkt, MkDkt, DkMkt, Ak1, Ak2
+
+
+def solve_chol_upper(G, B):
+    """solveSparseCholesky(const Matrix&, B) (graphSlam6D.cc:302-343): entries |v| <= 1e-5 dropped,
+    cs_cholsol reads the upper triangle of the (not exactly symmetric) matrix only."""
+    U = np.triu(np.where(np.abs(G) > 0.00001, G, 0.0))
+    S = U + np.triu(U, 1).T
+    L = np.linalg.cholesky(S)
+    return np.linalg.solve(L.T, np.linalg.solve(L, B))
+
+
+def gapx_iteration(links, scans, maxdist2, T=None):
+    """one iteration of gapx6D::doGraphSlam6D (gapx6D.cc:323-542).  T (translation vector) keeps
+    accumulating across iterations of one call, as the reference's does.  Returns (ret, T, X)."""
+    n = len(scans) - 1
+    B = np.zeros((3 * n, 3 * n)); A = np.zeros(3 * n)
+    T = np.zeros(3 * n) if T is None else T
+    cms, cds = [], []
+    sum_position_diff = 0.0
+    for (f, sx) in links:
+        r = get_pt_pairs(scans[f], scans[sx], maxdist2)
+        cms.append(r["cm"]); cds.append(r["cd"])
+        if r["n"] <= 1:
+            continue
+        MkMkt, DkDkt, MkDkt, DkMkt, Ak1, Ak2 = gapx_link_blocks(r["p1"], r["p2"], r["cm"])
+        a, b = f - 1, sx - 1
+        if f != 0:
+            A[a * 3:a * 3 + 3] += Ak1
+            B[a * 3:a * 3 + 3, a * 3:a * 3 + 3] += MkMkt
+            B[a * 3:a * 3 + 3, b * 3:b * 3 + 3] += DkMkt
+            B[b * 3:b * 3 + 3, a * 3:a * 3 + 3] += MkDkt
+        A[b * 3:b * 3 + 3] += Ak2
+        B[b * 3:b * 3 + 3, b * 3:b * 3 + 3] += DkDkt
+        sum_position_diff += 1.0                         # genBArotForLinkedPair returns 1.0 (sic)
+    X = solve_chol_upper(B, A)
+    Bt = np.zeros((n, n)); A = np.zeros(3 * n)
+    for (f, sx), cm, cd in zip(links, cms, cds):         # genBAtransForLinkedPair (gapx6D.cc:76-137)
+        x = X[(f - 1) * 3:(f - 1) * 3 + 3] if f != 0 else np.zeros(3)
+        pm = cm.copy(); orc.transform_points(compute_rt(x, np.zeros(3)), pm.reshape(1, 3))
+        pd = cd.copy(); orc.transform_points(compute_rt(X[(sx - 1) * 3:(sx - 1) * 3 + 3], np.zeros(3)), pd.reshape(1, 3))
+        Ak1 = pm - pd
+        if f != 0:
+            A[(f - 1) * 3:(f - 1) * 3 + 3] -= Ak1
+            Bt[f - 1, f - 1] += 1
+            Bt[f - 1, sx - 1] -= 1; Bt[sx - 1, f - 1] -= 1   # SymmetricMatrix: one stored element
+        A[(sx - 1) * 3:(sx - 1) * 3 + 3] += Ak1
+        Bt[sx - 1, sx - 1] += 1
+    Bti = np.linalg.inv(Bt)
+    for i in range(n):
+        for j in range(n):
+            T[i * 3:i * 3 + 3] += A[j * 3:j * 3 + 3] * Bti[i, j]
+    for i in range(1, len(scans)):
+        dx = T[(i - 1) * 3:(i - 1) * 3 + 3]
+        scans[i].transform(compute_rt(X[(i - 1) * 3:(i - 1) * 3 + 3], dx))
+        sum_position_diff += float(np.sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]))
+    return sum_position_diff / len(scans), T, X
+
+
+# ---------------------------------------------------------------------------------------
 # uos ASCII + .pose readers (src/scanio/helper.cc:192-234, 564-700): fixture generation only
 # ---------------------------------------------------------------------------------------
 def read_uos(path):

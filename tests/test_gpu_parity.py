@@ -429,3 +429,35 @@ def test_config1_metascan_dat(tdtk, orc, gpu, rnd, tmp_path):
     last = [float(t) for t in lines[-1].split()]
     assert len(last) == 17 and int(last[16]) == 1
     np.testing.assert_allclose(last[:16], S[1].get_transMat(), rtol=2e-5, atol=1e-6)
+
+
+def test_gapx6d_links_and_iterations(tdtk, orc, gpu):
+    """-G 4 (gapx6D): per-link genBArotForLinkedPair blocks (literal formulas incl. the
+    `p1x*p2x + p1y + p2y` terms) and two doGraphSlam6D iterations vs the oracle restatement."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    S, O = _dat_scans(tdtk.Scan, z), _dat_scans(io.OScan, z)
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1]); O[i].mergeCoordinatesWithRoboterPosition(O[i - 1])
+        for a in pr["alignxf"][:8]:                       # not fully converged: leaves something to do
+            S[i].transform(np.array(a)); O[i].transform(np.array(a))
+    r = tdtk.Scan.getPtPairs(S[0], S[1], max_dist_match2=625.0, want=tdtk.WANT_GAPX)
+    o = io.get_pt_pairs(O[0], O[1], 625.0)
+    blocks = io.gapx_link_blocks(o["p1"], o["p2"], o["cm"])
+    for name, want in zip(("gapx_MkMkt", "gapx_DkDkt", "gapx_MkDkt", "gapx_DkMkt", "gapx_Ak1", "gapx_Ak2"), blocks):
+        scale = max(np.abs(blocks[0]).max(), 1.0)
+        assert np.abs(r[name] - want).max() < 1e-9 * scale, name
+    links = [(0, 1), (1, 2), (0, 2)]
+    g = tdtk.Graph(3, links=links)
+    g.nrScans = 3
+    gx = tdtk.gapx6D(None, 25.0, 25.0, epsilonLUM=-1.0)
+    ret = gx.doGraphSlam6D(g, S, 2)
+    T = None
+    for _ in range(2):
+        oret, T, X = io.gapx_iteration(links, O, 625.0, T)
+    assert abs(ret - oret) < 1e-7 * max(1.0, abs(oret))
+    for s, o in zip(S, O):
+        assert _rel(s.get_transMat(), o.transMat) < POSE_RTOL
+        assert _rel(s.get_transMat(), o.transMat) < 1e-8
