@@ -75,6 +75,20 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t nb)
 // closest_d2 never grows, so the reference's test after the near child returns
 // (kdTreeImpl.h:373,378) would fail for every entry we skip.
 // ------------------------------------------------------------------------------------------
+// the overflow path lives in its own (rarely called) functions so that the compiler keeps the
+// common case as plain ds_write / ds_read instead of merging both into flat_store / flat_load
+__device__ __noinline__ void stack_spill(double* g_m2, uint32_t* g_ref, size_t off, uint32_t ref, double m2)
+{
+  g_m2[off] = m2;
+  g_ref[off] = ref;
+}
+__device__ __noinline__ void stack_fill(const double* g_m2, const uint32_t* g_ref, size_t off, uint32_t& ref,
+                                        double& m2)
+{
+  m2 = g_m2[off];
+  ref = g_ref[off];
+}
+
 template <int BLOCK, int SD>
 struct LaneStack {
   double* l_m2;    // &lds_m2[0][lane]
@@ -85,24 +99,22 @@ struct LaneStack {
   int sp;
   __device__ __forceinline__ void push(uint32_t ref, double m2)
   {
-    if (sp < SD) {
+    if (__builtin_expect(sp < SD, 1)) {
       l_m2[sp * BLOCK] = m2;
       l_ref[sp * BLOCK] = ref;
     } else {
-      g_m2[(size_t)(sp - SD) * gstride] = m2;
-      g_ref[(size_t)(sp - SD) * gstride] = ref;
+      stack_spill(g_m2, g_ref, (size_t)(sp - SD) * gstride, ref, m2);
     }
     ++sp;
   }
   __device__ __forceinline__ void top(uint32_t& ref, double& m2) const
   {
     const int s = sp;
-    if (s < SD) {
+    if (__builtin_expect(s < SD, 1)) {
       m2 = l_m2[s * BLOCK];
       ref = l_ref[s * BLOCK];
     } else {
-      m2 = g_m2[(size_t)(s - SD) * gstride];
-      ref = g_ref[(size_t)(s - SD) * gstride];
+      stack_fill(g_m2, g_ref, (size_t)(s - SD) * gstride, ref, m2);
     }
   }
 };
@@ -247,6 +259,230 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
 }
 
 // ------------------------------------------------------------------------------------------
+// Wave-cooperative variant of the same traversal.  The per-lane logic (and therefore every
+// comparison, every visit, every tie) is unchanged; what changes is WHO issues the loads.
+// Measured on MI355X (tools/ubench/gather.hip): a wave-level 16-B-per-lane gather costs ~18
+// CU-cycles when the lanes touch <= 4 cache lines and 150 when they touch 64, and k_search is bound
+// by the number of such instructions (7.6 M per 1M queries x ~25 cycles = the kernel time).
+// Spatially sorted queries make the lanes of a wave want only a handful of DISTINCT nodes /
+// buckets at any step, so: the wave elects the distinct references (ballot + readlane), fetches
+// each record ONCE with one coalesced instruction (4 lanes per 64-B node, 2 lanes per 32-B point)
+// into a per-wave LDS staging area, and every lane then reads its own record from LDS
+// (ds_read_b128, broadcast when lanes share it).  All 64 lanes stay in the loops as helpers; a
+// lane's own work is predicated.  Buckets larger than COOP_LEAF_CAP use the per-lane path.
+// ------------------------------------------------------------------------------------------
+constexpr int COOP_NODE_SLOTS = 16;  // 16 x 64 B  = 32 staging units
+constexpr int COOP_LEAF_SLOTS = 4;
+constexpr int COOP_LEAF_CAP = 24;    // 4 x 24 x 32 B = 96 staging units (default bucket size is 20)
+constexpr int COOP_STAGE_UNITS = 96; // double4 (32 B) units per wave = 3 KB
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int BLOCK, int SD>
+__device__ __forceinline__ void kd_search_coop(const TreeDev& T, const bool valid, const double qx,
+                                               const double qy, const double qz, double& best, int& bk,
+                                               LaneStack<BLOCK, SD>& st, double4* __restrict__ stage)
+{
+  const unsigned lane = threadIdx.x & (WAVE - 1);
+  uint32_t cur = valid ? T.root_ref : REF_DONE;
+  st.sp = 0;
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+  const double2* __restrict__ nodes16 = reinterpret_cast<const double2*>(T.nodes);
+  const double2* __restrict__ pts16 = reinterpret_cast<const double2*>(T.pts);
+  double2* stage16 = reinterpret_cast<double2*>(stage);
+
+  for (;;) {
+    // ---- phase 1: every lane that holds an internal node advances by one node per iteration ----
+    for (;;) {
+      const bool need = !(cur & REF_LEAF);
+      const unsigned long long needm = __ballot(need);
+      if (needm == 0) break;
+      bool need_pop = false;
+      uint32_t next = cur;
+      const int leader0 = __builtin_ctzll(needm);
+      const uint32_t ucur = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader0);
+      if (__ballot(need && cur != ucur) == 0) {
+        // all needing lanes hold the same node: scalar-cache path, node stays in SGPRs
+        if (need) {
+          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+          const_u_ptr su = (const_u_ptr)(sn + 7);
+          next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx, qy,
+                                       qz, best, st, need_pop);
+        }
+      } else {
+        unsigned long long pend = needm;
+        while (pend) {
+          int myslot = -1;
+          uint32_t slotv = 0;  // lane k keeps the node index of slot k
+          int k = 0;
+          while (pend && k < COOP_NODE_SLOTS) {
+            const int leader = __builtin_ctzll(pend);
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader);
+            const unsigned long long eq = __ballot(need && cur == v) & pend;
+            if ((eq >> lane) & 1ull) myslot = k;
+            if ((int)lane == k) slotv = v;
+            pend &= ~eq;
+            ++k;
+          }
+          // one coalesced fetch: lane l brings 16 B number (l & 3) of slot (l >> 2)
+          const int fs = (int)(lane >> 2);
+          const uint32_t fnode = (uint32_t)__shfl((int)slotv, fs, WAVE);
+          if (fs < k) stage16[lane] = nodes16[(size_t)fnode * 4 + (lane & 3)];
+          wave_lds_sync();
+          if (myslot >= 0) {
+            const double4 n0 = stage[myslot * 2];
+            const double4 n1 = stage[myslot * 2 + 1];
+            next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z,
+                                         (uint32_t)__double2loint(n1.w), (uint32_t)__double2hiint(n1.w), qx, qy,
+                                         qz, best, st, need_pop);
+          }
+          wave_lds_sync();
+        }
+      }
+      if (need_pop) {
+        next = REF_DONE;
+        while (st.sp > 0) {
+          --st.sp;
+          uint32_t r; double m2;
+          st.top(r, m2);
+          if (m2 < best) { next = r; break; }
+        }
+      }
+      cur = next;
+    }
+
+    // ---- phase 2: every lane now holds a bucket or is finished ----
+    const bool hasleaf = (cur != REF_DONE);
+    if (__ballot(hasleaf) == 0) break;
+    int start = 0, count = 0;
+    if (hasleaf) {
+      const uint32_t v = cur & REF_VAL;
+      if (T.leaf_tab) {
+        const LeafEntry le = T.leaf_tab[v];
+        start = le.start; count = le.count;
+      } else {
+        start = (int)(v >> T.cb);
+        count = (int)(v & T.cmask);
+      }
+    }
+    const bool small = hasleaf && count <= COOP_LEAF_CAP;
+    unsigned long long pend = __ballot(small);
+    while (pend) {
+      int myslot = -1;
+      int k = 0;
+      while (pend && k < COOP_LEAF_SLOTS) {
+        const int leader = __builtin_ctzll(pend);
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader);
+        const int s_k = __builtin_amdgcn_readlane(start, leader);
+        const int c_k = __builtin_amdgcn_readlane(count, leader);
+        const unsigned long long eq = __ballot(small && cur == v) & pend;
+        if ((eq >> lane) & 1ull) myslot = k;
+        // the whole bucket in one coalesced instruction: lane l brings 16 B number l
+        if ((int)lane < 2 * c_k) stage16[k * (COOP_LEAF_CAP * 2) + lane] = pts16[(size_t)s_k * 2 + lane];
+        pend &= ~eq;
+        ++k;
+      }
+      wave_lds_sync();
+      if (myslot >= 0) {
+        const double4* __restrict__ P = stage + myslot * COOP_LEAF_CAP;
+        const int last = count - 1;
+        for (int i = 0; i < count; i += 4) {  // stored order, strict '<' (kdTreeImpl.h:351-357)
+          const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
+          const double4 p0 = P[i], p1 = P[i1], p2 = P[i2], p3 = P[i3];
+          double dx, dy, dz;
+          dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
+          const double d0 = dx * dx + dy * dy + dz * dz;
+          dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
+          const double d1 = dx * dx + dy * dy + dz * dz;
+          dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
+          const double d3 = dx * dx + dy * dy + dz * dz;
+          if (d0 < best) { best = d0; bk = start + i; }
+          if (d1 < best) { best = d1; bk = start + i1; }
+          if (d2 < best) { best = d2; bk = start + i2; }
+          if (d3 < best) { best = d3; bk = start + i3; }
+        }
+      }
+      wave_lds_sync();
+    }
+    if (hasleaf && !small) {  // oversized (degenerate) bucket: per-lane scan straight from memory
+      const double4* __restrict__ P = pts + start;
+      for (int i = 0; i < count; i++) {
+        const double4 p = P[i];
+        const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; bk = start + i; }
+      }
+    }
+    if (hasleaf) {  // pop the next pending far child that still passes sqr(myd) < closest_d2
+      cur = REF_DONE;
+      while (st.sp > 0) {
+        --st.sp;
+        uint32_t r; double m2;
+        st.top(r, m2);
+        if (m2 < best) { cur = r; break; }
+      }
+    }
+  }
+}
+
+template <int BLOCK, int SD, int WPS>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_coop(const SearchArgs a)
+{
+  __shared__ double lds_m2[SD][BLOCK];
+  __shared__ uint32_t lds_ref[SD][BLOCK];
+  __shared__ double4 lds_stage[BLOCK / WAVE][COOP_STAGE_UNITS];
+
+  const uint32_t nb = gridDim.x;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
+  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  LaneStack<BLOCK, SD> st;
+  st.l_m2 = &lds_m2[0][threadIdx.x];
+  st.l_ref = &lds_ref[0][threadIdx.x];
+  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
+  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
+  st.gstride = (size_t)nb * BLOCK;
+  st.sp = 0;
+  double4* stage = &lds_stage[threadIdx.x / WAVE][0];
+
+  const size_t per = (a.n + nb - 1) / nb;
+  const size_t lo = (size_t)chunk * per;
+  size_t hi = lo + per;
+  if (hi > a.n) hi = a.n;
+  for (size_t base = lo; base < hi; base += BLOCK) {  // uniform per workgroup: no lane leaves early
+    const size_t i = base + threadIdx.x;
+    const bool valid = i < hi;
+    double tx = 0, ty = 0, tz = 0;
+    if (valid) {
+      tx = a.x[i]; ty = a.y[i]; tz = a.z[i];
+      if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
+        dev_xf3_inplace(a.pending, tx, ty, tz);
+        a.x[i] = tx; a.y[i] = ty; a.z[i] = tz;
+        if (a.nx) {
+          double px = a.nx[i], py = a.ny[i], pz = a.nz[i];
+          dev_xf3normal(a.pending, px, py, pz);
+          a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
+        }
+      }
+    }
+    double sx = tx, sy = ty, sz = tz;
+    if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, sx, sy, sz);  // searchTree.cc:122
+    double best = a.maxd2;
+    int bk = -1;
+    kd_search_coop<BLOCK, SD>(a.T, valid, sx, sy, sz, best, bk, st, stage);
+    if (valid) {
+      a.kpos[i] = bk;
+      if (a.d2) a.d2[i] = best;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // nearest point to a line: exact replay of _FindClosestAlongDir (kdTreeImpl.h:390-425).
 // No split-plane pruning in the reference: both children are always visited, near side first.
 // ------------------------------------------------------------------------------------------
@@ -370,6 +606,153 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
     else kd_search<BLOCK, SD, COUNT, UNI>(a.T, sx, sy, sz, best, bk, st, a.counters);
     a.kpos[i] = bk;
     if (a.d2) a.d2[i] = best;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_search_refill: same per-lane traversal, but a wave owns QPW consecutive (sorted) queries and a
+// lane that finishes its query immediately takes the next one of the wave's slab ("persistent
+// lanes").  Motivation (PMC, profiles/r01_pmc_bench.json): k_search issues ~6800 VALU
+// instructions per wave for ~1400 per lane-query -- the SIMDs are ~85 % busy issuing mostly
+// masked-off fp64 instructions, because queries of one wave need different numbers of buckets
+// (1..8) and the wave runs as long as its slowest lane.  Refilling keeps the lanes occupied.
+// Results are written by query index, so the processing order is irrelevant.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD, int QPW, int THRESH, int WPS>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
+{
+  __shared__ double lds_m2[SD][BLOCK];
+  __shared__ uint32_t lds_ref[SD][BLOCK];
+
+  const uint32_t nb = gridDim.x;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
+  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned lane = threadIdx.x & (WAVE - 1);
+  LaneStack<BLOCK, SD> st;
+  st.l_m2 = &lds_m2[0][threadIdx.x];
+  st.l_ref = &lds_ref[0][threadIdx.x];
+  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
+  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
+  st.gstride = (size_t)nb * BLOCK;
+  st.sp = 0;
+
+  const TreeDev& T = a.T;
+  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+
+  const size_t wave_id = (size_t)chunk * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  size_t next_q = wave_id * QPW;  // wave-uniform
+  size_t end_q = next_q + QPW;
+  if (end_q > a.n) end_q = a.n;
+
+  uint32_t cur = REF_DONE;
+  double best = 0.0, qx = 0, qy = 0, qz = 0;
+  int bk = -1;
+  size_t qi = 0;
+  bool have = false;
+
+  for (;;) {
+    // ---- retire finished queries, hand out new ones ----
+    const bool idle = (cur == REF_DONE);
+    if (idle && have) {
+      a.kpos[qi] = bk;
+      if (a.d2) a.d2[qi] = best;
+      have = false;
+    }
+    const unsigned long long idlem = __ballot(idle);
+    const unsigned long long activem = __ballot(!idle);
+    if (next_q < end_q && (activem == 0 || __popcll(idlem) >= THRESH)) {
+      const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
+      const size_t mine = next_q + rank;
+      if (idle && mine < end_q) {
+        double tx = a.x[mine], ty = a.y[mine], tz = a.z[mine];
+        if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
+          dev_xf3_inplace(a.pending, tx, ty, tz);
+          a.x[mine] = tx; a.y[mine] = ty; a.z[mine] = tz;
+          if (a.nx) {
+            double px = a.nx[mine], py = a.ny[mine], pz = a.nz[mine];
+            dev_xf3normal(a.pending, px, py, pz);
+            a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz;
+          }
+        }
+        qx = tx; qy = ty; qz = tz;
+        if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
+        qi = mine; have = true;
+        cur = T.root_ref; best = a.maxd2; bk = -1; st.sp = 0;
+      }
+      next_q += (size_t)__popcll(idlem);
+    }
+    if (__ballot(cur != REF_DONE) == 0) {
+      if (next_q >= end_q) break;
+      continue;
+    }
+
+    // ---- phase 1: walk internal nodes until this lane holds a bucket (or is finished) ----
+    while (!(cur & REF_LEAF)) {
+      bool need_pop = false;
+      uint32_t next;
+      const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
+      if (__all(cur == ucur)) {
+        const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+        const_u_ptr su = (const_u_ptr)(sn + 7);
+        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx, qy, qz,
+                                     best, st, need_pop);
+      } else {
+        const double4 n0 = nodes[(size_t)cur * 2];
+        const double4 n1 = nodes[(size_t)cur * 2 + 1];
+        next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
+                                     (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
+      }
+      if (need_pop) {
+        next = REF_DONE;
+        while (st.sp > 0) {
+          --st.sp;
+          uint32_t r; double m2;
+          st.top(r, m2);
+          if (m2 < best) { next = r; break; }
+        }
+      }
+      cur = next;
+    }
+
+    // ---- phase 2: scan the bucket, then pop ----
+    if (cur != REF_DONE) {
+      const uint32_t v = cur & REF_VAL;
+      int start, count;
+      if (T.leaf_tab) {
+        const LeafEntry le = T.leaf_tab[v];
+        start = le.start; count = le.count;
+      } else {
+        start = (int)(v >> T.cb);
+        count = (int)(v & T.cmask);
+      }
+      const double4* __restrict__ P = pts + start;
+      const int last = count - 1;
+      for (int i = 0; i < count; i += 4) {
+        const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
+        const double4 p0 = P[i], p1 = P[i1], p2 = P[i2], p3 = P[i3];
+        double dx, dy, dz;
+        dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
+        const double d0 = dx * dx + dy * dy + dz * dz;
+        dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
+        const double d1 = dx * dx + dy * dy + dz * dz;
+        dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
+        const double d3 = dx * dx + dy * dy + dz * dz;
+        if (d0 < best) { best = d0; bk = start + i; }
+        if (d1 < best) { best = d1; bk = start + i1; }
+        if (d2 < best) { best = d2; bk = start + i2; }
+        if (d3 < best) { best = d3; bk = start + i3; }
+      }
+      cur = REF_DONE;
+      while (st.sp > 0) {
+        --st.sp;
+        uint32_t r; double m2;
+        st.top(r, m2);
+        if (m2 < best) { cur = r; break; }
+      }
+    }
   }
 }
 
@@ -638,13 +1021,17 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 //   2: LDS stack 8 deep + wave-uniform scalar node loads
 //   3: LDS stack 4 deep, 8 waves/SIMD + wave-uniform scalar node loads
 //   4: LDS stack 4 deep, default occupancy + wave-uniform scalar node loads
+//   5: wave-cooperative fetches (distinct nodes / buckets loaded once per wave into LDS)
+//   6: same, capped at 6 waves/SIMD worth of registers
+//   7..12: persistent lanes (k_search_refill): QPW / refill threshold = 256/1, 256/16, 256/32,
+//          512/16, 128/16, 1024/16
 static int search_variant()
 {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("TDTK_SEARCH_VARIANT");
-    v = e ? atoi(e) : 4;
-    if (v < 0 || v > 4) v = 4;
+    v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
+    if (v < -2 || v > 18) v = -2;
   }
   return v;
 }
@@ -660,6 +1047,13 @@ uint32_t search_grid(size_t n)
   if (nb < 8) nb = 8;
   return (uint32_t)nb;
 }
+static uint32_t refill_grid(size_t n, int qpw)
+{
+  size_t waves = (n + qpw - 1) / qpw;
+  size_t nb = (waves + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE);
+  nb = (nb + 7) & ~(size_t)7;
+  return (uint32_t)(nb < 8 ? 8 : nb);
+}
 int search_lds_depth() { return SEARCH_SD_MIN; }
 int search_block() { return SEARCH_BLOCK; }
 
@@ -671,11 +1065,29 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
   else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
   else if (count) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
   else {
-    switch (search_variant()) {
+    int v = search_variant();
+    // persistent lanes pay off once there are enough queries to keep every SIMD supplied with
+    // several 256-query waves; small batches keep one query per lane
+    if (v == -2) v = (a.n >= (size_t)262144) ? 8 : 4;
+    switch (v) {
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
       case 1: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, false, 8>), g, b, 0, s, a); break;
       case 2: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, true, 1>), g, b, 0, s, a); break;
       case 3: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 8>), g, b, 0, s, a); break;
+      case 7: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 1, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
+      case 9: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 32, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
+      case 10: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 512, 16, 1>), dim3(refill_grid(a.n, 512)), b, 0, s, a); break;
+      case 11: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 128, 16, 1>), dim3(refill_grid(a.n, 128)), b, 0, s, a); break;
+      case 12: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 1024, 16, 1>), dim3(refill_grid(a.n, 1024)), b, 0, s, a); break;
+      case 13: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 192, 8, 1>), dim3(refill_grid(a.n, 192)), b, 0, s, a); break;
+      case 14: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 192, 16, 1>), dim3(refill_grid(a.n, 192)), b, 0, s, a); break;
+      case 15: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 8, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
+      case 16: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 320, 16, 1>), dim3(refill_grid(a.n, 320)), b, 0, s, a); break;
+      case 17: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 7>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
+      case 18: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 384, 16, 1>), dim3(refill_grid(a.n, 384)), b, 0, s, a); break;
+      case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
+      case 6: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 6>), g, b, 0, s, a); break;
       default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
     }
   }

@@ -461,3 +461,50 @@ def test_gapx6d_links_and_iterations(tdtk, orc, gpu):
     for s, o in zip(S, O):
         assert _rel(s.get_transMat(), o.transMat) < POSE_RTOL
         assert _rel(s.get_transMat(), o.transMat) < 1e-8
+
+
+def test_concurrent_host_threads(tdtk, orc, gpu):
+    """The reference drives a tree from several OpenMP threads at once (disjoint query ranges in
+    icp6D::match, different links in FillGB3D).  The C ABI keeps a stream + workspace per calling
+    thread, so concurrent calls on shared handles must give the single-threaded answers."""
+    import threading
+    rng = np.random.default_rng(21)
+    m = rng.uniform(-300, 300, (200000, 3))
+    q = rng.uniform(-300, 300, (120000, 3))
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    want_idx, want_d2 = T.find_closest(q, 400.0, 8)
+    chunks = np.array_split(np.arange(len(q)), 6)
+    out = [None] * len(chunks)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                out[k] = kd.FindClosestBatch(q[chunks[k]], 400.0)
+                r = kd.getPtPairs(tdtk.M4identity(), q, None, int(chunks[k][0]), int(chunks[k][-1]) + 1,
+                                  max_dist_match2=400.0, want_pairs=False)
+                assert np.array_equal(r["idx"], want_idx[chunks[k]])
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(chunks))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k, c in enumerate(chunks):
+        assert np.array_equal(out[k][0], want_idx[c]) and np.array_equal(out[k][1], want_d2[c])
+
+
+def test_large_scan_4m_points(tdtk, orc, gpu):
+    """Towards configs[4] (~10M points per scan): a 4M-point model, 24-bit point indices, deeper
+    tree; indices bit-exact on a query sample, whole-scan pass consistent with it."""
+    rng = np.random.default_rng(31)
+    M = 4000000
+    m = rng.uniform(-3000, 3000, (M, 3))
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    inf, st = kd.info(), T.stats()
+    assert (inf["n_internal"], inf["n_leaves"], inf["max_depth"]) == (st["internal"], st["leaves"], st["depth"])
+    q = m[rng.integers(0, M, 300000)] + rng.normal(0, 5.0, (300000, 3))
+    for md2 in (100.0, 1e18):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
