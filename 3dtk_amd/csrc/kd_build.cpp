@@ -75,7 +75,10 @@ bool build_tree(const double* xyz, size_t M, int bucket, HostTree& T, std::strin
 {
   if (!xyz || M == 0) { err = "cannot create kdtree with zero points"; return false; }
   if (bucket < 1) { err = "bucket size must be >= 1"; return false; }
-  if (M > (size_t)REF_VAL) { err = "model scan too large for 30-bit references"; return false; }
+  if (M > (size_t)REF_VAL || M * sizeof(KdPoint) >= (1ull << 32)) {
+    err = "model scan too large (30-bit references / 32-bit byte offsets: < 2^27 points)";
+    return false;
+  }
 
   std::vector<uint32_t> perm(M);
   std::iota(perm.begin(), perm.end(), 0u);

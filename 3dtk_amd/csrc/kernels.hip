@@ -698,8 +698,11 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx, qy, qz,
                                      best, st, need_pop);
       } else {
-        const double4 n0 = nodes[(size_t)cur * 2];
-        const double4 n1 = nodes[(size_t)cur * 2 + 1];
+        // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no
+        // 64-bit address arithmetic on the vector ALU (the node array is < 4 GB by construction)
+        const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
+        const double4 n0 = *reinterpret_cast<const double4*>(np_);
+        const double4 n1 = *reinterpret_cast<const double4*>(np_ + 32);
         next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
                                      (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
       }
@@ -726,11 +729,15 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         start = (int)(v >> T.cb);
         count = (int)(v & T.cmask);
       }
-      const double4* __restrict__ P = pts + start;
-      const int last = count - 1;
-      for (int i = 0; i < count; i += 4) {
-        const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
-        const double4 p0 = P[i], p1 = P[i1], p2 = P[i2], p3 = P[i3];
+      const char* pb = reinterpret_cast<const char*>(pts);
+      const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
+      const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
+      for (uint32_t o = o0; o <= olast; o += 128u) {           // 4 points per round trip
+        const uint32_t o1 = min(o + 32u, olast), o2 = min(o + 64u, olast), o3 = min(o + 96u, olast);
+        const double4 p0 = *reinterpret_cast<const double4*>(pb + o);
+        const double4 p1 = *reinterpret_cast<const double4*>(pb + o1);
+        const double4 p2 = *reinterpret_cast<const double4*>(pb + o2);
+        const double4 p3 = *reinterpret_cast<const double4*>(pb + o3);
         double dx, dy, dz;
         dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
         const double d0 = dx * dx + dy * dy + dz * dz;
@@ -740,10 +747,10 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         const double d2 = dx * dx + dy * dy + dz * dz;
         dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
         const double d3 = dx * dx + dy * dy + dz * dz;
-        if (d0 < best) { best = d0; bk = start + i; }
-        if (d1 < best) { best = d1; bk = start + i1; }
-        if (d2 < best) { best = d2; bk = start + i2; }
-        if (d3 < best) { best = d3; bk = start + i3; }
+        if (d0 < best) { best = d0; bk = (int)(o >> 5); }
+        if (d1 < best) { best = d1; bk = (int)(o1 >> 5); }
+        if (d2 < best) { best = d2; bk = (int)(o2 >> 5); }
+        if (d3 < best) { best = d3; bk = (int)(o3 >> 5); }
       }
       cur = REF_DONE;
       while (st.sp > 0) {
@@ -1031,7 +1038,7 @@ static int search_variant()
   if (v < 0) {
     const char* e = getenv("TDTK_SEARCH_VARIANT");
     v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-    if (v < -2 || v > 18) v = -2;
+    if (v < -2 || v > 21) v = -2;
   }
   return v;
 }
@@ -1054,6 +1061,13 @@ static uint32_t refill_grid(size_t n, int qpw)
   nb = (nb + 7) & ~(size_t)7;
   return (uint32_t)(nb < 8 ? 8 : nb);
 }
+static uint32_t refill_grid_b(size_t n, int qpw, int block)
+{
+  size_t waves = (n + qpw - 1) / qpw;
+  size_t nb = (waves + (block / WAVE) - 1) / (block / WAVE);
+  nb = (nb + 7) & ~(size_t)7;
+  return (uint32_t)(nb < 8 ? 8 : nb);
+}
 int search_lds_depth() { return SEARCH_SD_MIN; }
 int search_block() { return SEARCH_BLOCK; }
 
@@ -1068,7 +1082,7 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
     int v = search_variant();
     // persistent lanes pay off once there are enough queries to keep every SIMD supplied with
     // several 256-query waves; small batches keep one query per lane
-    if (v == -2) v = (a.n >= (size_t)262144) ? 8 : 4;
+    if (v == -2) v = (a.n >= (size_t)262144) ? 20 : 4;
     switch (v) {
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
       case 1: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, false, 8>), g, b, 0, s, a); break;
@@ -1086,6 +1100,9 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
       case 16: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 320, 16, 1>), dim3(refill_grid(a.n, 320)), b, 0, s, a); break;
       case 17: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 7>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
       case 18: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 384, 16, 1>), dim3(refill_grid(a.n, 384)), b, 0, s, a); break;
+      case 19: hipLaunchKernelGGL((k_search_refill<64, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 64)), dim3(64), 0, s, a); break;
+      case 20: hipLaunchKernelGGL((k_search_refill<128, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 128)), dim3(128), 0, s, a); break;
+      case 21: hipLaunchKernelGGL((k_search_refill<64, 8, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 64)), dim3(64), 0, s, a); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 6: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 6>), g, b, 0, s, a); break;
       default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;

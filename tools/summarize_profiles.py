@@ -7,6 +7,8 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(n):
     n = n.split("(")[0].replace("void ", "").replace("tdtk::", "")
+    if n.startswith("k_search_refill<"):
+        return "k_search"
     if n.startswith("k_search<"):
         a = [t.strip() for t in n[len("k_search<"):-1].split(",")]
         # <BLOCK, SD, COUNT, DIRMODE, UNI, WPS>
