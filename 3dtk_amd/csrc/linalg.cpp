@@ -170,27 +170,43 @@ static inline double dot8(const double* __restrict__ a, const double* __restrict
   return (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) + t;
 }
 
-// Cholesky A = L L^T on a dense row-major copy (row-oriented: every inner product runs over two
-// contiguous rows); fails when a pivot drops below `floor` (the reference's choldc gives up at
-// 1e-7, globals.icc:820-848).
+// Cholesky A = L L^T on a dense row-major copy, row-oriented (every inner product runs over two
+// contiguous rows) and envelope-aware: fill-in stays right of each row's first non-zero, so the
+// products start there.  The graph-SLAM matrix is a chain of 6x6 blocks plus a few loop-closure
+// blocks; its envelope is a small fraction of the square (what CSparse exploits in the reference).
+// Fails when a pivot drops below `floor` (the reference's choldc gives up at 1e-7,
+// globals.icc:820-848).
 static bool cholesky_solve(int n, std::vector<double>& a, const double* b, double* x, double floor)
 {
+  std::vector<int> first(n);
+  for (int i = 0; i < n; i++) {
+    int f = 0;
+    while (f < i && a[(size_t)i * n + f] == 0.0) ++f;
+    first[i] = f;
+  }
   for (int i = 0; i < n; i++) {
     double* ri = &a[(size_t)i * n];
-    for (int j = 0; j < i; j++) {
+    const int fi = first[i];
+    for (int j = fi; j < i; j++) {
       const double* rj = &a[(size_t)j * n];
-      ri[j] = (ri[j] - dot8(ri, rj, j)) / rj[j];
+      const int k0 = fi > first[j] ? fi : first[j];
+      ri[j] = (ri[j] - (k0 < j ? dot8(ri + k0, rj + k0, j - k0) : 0.0)) / rj[j];
     }
-    const double d = ri[i] - dot8(ri, ri, i);
+    const double d = ri[i] - dot8(ri + fi, ri + fi, i - fi);
     if (!(d >= floor)) return false;
     ri[i] = std::sqrt(d);
   }
   std::vector<double> y(n);
-  for (int i = 0; i < n; i++) y[i] = (b[i] - dot8(&a[(size_t)i * n], y.data(), i)) / a[(size_t)i * n + i];
-  for (int i = n - 1; i >= 0; i--) {
-    double s = y[i];
-    for (int k = i + 1; k < n; k++) s -= a[(size_t)k * n + i] * x[k];
-    x[i] = s / a[(size_t)i * n + i];
+  for (int i = 0; i < n; i++) {
+    const int fi = first[i];
+    y[i] = (b[i] - dot8(&a[(size_t)i * n + fi], y.data() + fi, i - fi)) / a[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) x[i] = y[i];
+  for (int i = n - 1; i >= 0; i--) {   // back substitution, column sweep over the envelope
+    x[i] /= a[(size_t)i * n + i];
+    const double xi = x[i];
+    const double* ri = &a[(size_t)i * n];
+    for (int k = first[i]; k < i; k++) x[k] -= ri[k] * xi;
   }
   return true;
 }

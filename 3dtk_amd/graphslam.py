@@ -15,9 +15,21 @@ import numpy as np
 from . import slam6d as _s
 
 
-def shard_links(nlinks, rank, world):
-    """Round-robin (links have equal cost when scans have equal size)."""
-    return list(range(rank, nlinks, world))
+def shard_links(gr, rank, world):
+    """Which links of `gr` this rank evaluates.  Links cost the same when scans have equal size, so
+    the odometry chain (links 0..n-2, always present) is dealt round-robin; loop-closure links are
+    keyed by their end points, (from + to) % world, so that a closure appearing or disappearing
+    between LUM rounds (the Graph is rebuilt from the current poses every round,
+    src/slam6d/slam6D.cc:501-532) does not reshuffle every other link -- and with it every
+    resident tree and scan -- across the ranks."""
+    chain = gr.getNrScans() - 1
+    mine = []
+    for i in range(gr.getNrLinks()):
+        f, t = gr.getLink(i, 0), gr.getLink(i, 1)
+        owner = (i % world) if (i < chain and t == f + 1) else ((f + t) % world)
+        if owner == rank:
+            mine.append(i)
+    return mine
 
 
 def fill_GB(gr, allScans, max_dist_match2, link_fn, rank=0, world=1):
@@ -25,7 +37,7 @@ def fill_GB(gr, allScans, max_dist_match2, link_fn, rank=0, world=1):
     n = gr.getNrScans() - 1
     G = np.zeros((6 * n, 6 * n))
     B = np.zeros(6 * n)
-    for i in shard_links(gr.getNrLinks(), rank, world):
+    for i in shard_links(gr, rank, world):
         fa, fb = gr.getLink(i, 0), gr.getLink(i, 1)
         a, b = fa - 1, fb - 1
         Cab, CDab = link_fn(allScans[fa], allScans[fb], max_dist_match2)[:2]
@@ -89,7 +101,7 @@ def lum_iteration_native(gr, allScans, max_dist_match2, group=None, device=None)
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     nscans = gr.getNrScans()
     n = nscans - 1
-    mine = shard_links(gr.getNrLinks(), rank, world)
+    mine = shard_links(gr, rank, world)
     nl = len(mine)
     G = np.zeros((6 * n, 6 * n))
     B = np.zeros(6 * n)
@@ -165,7 +177,7 @@ def gapx_iteration(gr, allScans, max_dist_match2, T, group=None, device=None):
     nscans = gr.getNrScans()
     n = nscans - 1
     nlinks = gr.getNrLinks()
-    mine = shard_links(nlinks, rank, world)
+    mine = shard_links(gr, rank, world)
     nl = len(mine)
     B = np.zeros((3 * n, 3 * n)); A = np.zeros(3 * n)
     cent = np.zeros((nlinks, 7))            # cm[3], cd[3], non-empty flag

@@ -251,7 +251,7 @@ def bench_graphslam(args, rank, world, local):
     del raw
     g0 = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)
     nlinks = g0.getNrLinks()
-    mine = gs.shard_links(nlinks, rank, world)
+    mine = gs.shard_links(g0, rank, world)
     for i in mine:                                      # materialise what this rank touches
         scans[g0.getLink(i, 0)].getSearchTree()
         _ = scans[g0.getLink(i, 1)].handle

@@ -260,11 +260,28 @@ def test_lum_links_sharded_over_two_ranks_gloo(tmp_path, orc):
 def test_shard_links_partition(tdtk):
     from importlib import import_module
     gs = import_module("3dtk_amd.graphslam")
+    n = 64
+    chain = [(i, i + 1) for i in range(n - 1)]
+    closures = [(j, k) for j in range(n) for k in range(j + 1, n) if k - j >= 58]
+    g = tdtk.Graph(n, links=chain + closures)
+    g.nrScans = n
     for world in (1, 2, 4, 8):
-        got = sorted(sum((gs.shard_links(71, r, world) for r in range(world)), []))
-        assert got == list(range(71))
-        sizes = [len(gs.shard_links(71, r, world)) for r in range(world)]
-        assert max(sizes) - min(sizes) <= 1
+        shards = [gs.shard_links(g, r, world) for r in range(world)]
+        assert sorted(sum(shards, [])) == list(range(g.getNrLinks()))       # a partition
+        sizes = [len(x) for x in shards]
+        assert max(sizes) - min(sizes) <= 4
+    # a closure that appears between rounds must not move any other link to another rank
+    g2 = tdtk.Graph(n, links=chain + closures[:5] + [(2, 57)] + closures[5:])
+    g2.nrScans = n
+    for world in (2, 8):
+        owner = {}
+        for r in range(world):
+            for i in gs.shard_links(g, r, world):
+                owner[(g.getLink(i, 0), g.getLink(i, 1))] = r
+        for r in range(world):
+            for i in gs.shard_links(g2, r, world):
+                key = (g2.getLink(i, 0), g2.getLink(i, 1))
+                assert owner.get(key, r) == r
 
 
 def test_adapter_compiles_against_reference_headers(tmp_path):
