@@ -122,52 +122,6 @@ struct tdtk_scan {
 };
 
 // ------------------------------------------------------------------------------------------
-// host-side spatial ordering (Morton code on the batch's own bounding box).  One-time per scan;
-// deterministic (ties broken by caller index), so repeated runs reduce in the same order.
-// ------------------------------------------------------------------------------------------
-static inline uint64_t spread10(uint64_t v)
-{
-  v &= 0x3FF;
-  v = (v | (v << 16)) & 0x30000FFull;
-  v = (v | (v << 8)) & 0x300F00Full;
-  v = (v | (v << 4)) & 0x30C30C3ull;
-  v = (v | (v << 2)) & 0x9249249ull;
-  return v;
-}
-
-static void morton_order(const double* xyz, size_t n, std::vector<int32_t>& order)
-{
-  order.resize(n);
-  if (!n) return;
-  double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
-  for (size_t i = 1; i < n; i++)
-    for (int a = 0; a < 3; a++) {
-      const double v = xyz[3 * i + a];
-      if (v < lo[a]) lo[a] = v;
-      if (v > hi[a]) hi[a] = v;
-    }
-  double sc[3];
-  for (int a = 0; a < 3; a++) {
-    const double ext = hi[a] - lo[a];
-    sc[a] = (ext > 0 && std::isfinite(ext)) ? 1023.999 / ext : 0.0;
-  }
-  std::vector<uint64_t> keys(n);
-  for (size_t i = 0; i < n; i++) {
-    uint64_t c[3];
-    for (int a = 0; a < 3; a++) {
-      double f = (xyz[3 * i + a] - lo[a]) * sc[a];
-      if (!(f >= 0)) f = 0;
-      if (f > 1023) f = 1023;
-      c[a] = (uint64_t)f;
-    }
-    const uint64_t code = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
-    keys[i] = (code << 32) | (uint64_t)i;
-  }
-  std::sort(keys.begin(), keys.end());
-  for (size_t i = 0; i < n; i++) order[i] = (int32_t)(keys[i] & 0xFFFFFFFFull);
-}
-
-// ------------------------------------------------------------------------------------------
 extern "C" {
 
 const char* tdtk_last_error(void) { return g_err.c_str(); }
@@ -659,25 +613,54 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
   if (!out) { set_error("out is NULL"); return TDTK_EINVAL; }
   *out = nullptr;
   if (!xyz && N) { set_error("NULL points"); return TDTK_EINVAL; }
+  if (N >= (1ull << 32)) { set_error("scan too large"); return TDTK_EINVAL; }
   Ctx* c;
   int rc = get_ctx(device, &c);
   if (rc) return rc;
   std::unique_ptr<tdtk_scan> sc(new tdtk_scan);
   sc->device = device; sc->N = N;
   if (N == 0) { *out = sc.release(); return TDTK_OK; }
-  morton_order(xyz, N, sc->order_h);
-  std::vector<double> buf(N);
-  auto up = [&](const double* src, int comp, double** dst) -> int {
-    for (size_t j = 0; j < N; j++) buf[j] = src[3 * (size_t)sc->order_h[j] + comp];
-    HIPCHK(hipMalloc((void**)dst, N * sizeof(double)));
-    HIPCHK(hipMemcpy(*dst, buf.data(), N * sizeof(double), hipMemcpyHostToDevice));
-    return TDTK_OK;
-  };
-  if ((rc = up(xyz, 0, &sc->x)) || (rc = up(xyz, 1, &sc->y)) || (rc = up(xyz, 2, &sc->z))) return rc;
-  if (nrm)
-    if ((rc = up(nrm, 0, &sc->nx)) || (rc = up(nrm, 1, &sc->ny)) || (rc = up(nrm, 2, &sc->nz))) return rc;
+  hipStream_t s = c->stream;
+  // bounding box on the host (one streaming pass), everything else on the device
+  double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+  for (size_t i = 1; i < N; i++)
+    for (int a = 0; a < 3; a++) {
+      const double v = xyz[3 * i + a];
+      if (v < lo[a]) lo[a] = v;
+      if (v > hi[a]) hi[a] = v;
+    }
+  double scl[3];
+  for (int a = 0; a < 3; a++) {
+    const double ext = hi[a] - lo[a];
+    scl[a] = (ext > 0 && std::isfinite(ext)) ? 1023.999 / ext : 0.0;
+  }
+  const size_t tmp_bytes = morton_sort_temp_bytes(N);
+  if ((rc = c->ws[WS_TMPA].ensure(3 * N * sizeof(double)))) return rc;        // AoS staging
+  if ((rc = c->ws[WS_CELL].ensure(2 * N * sizeof(uint32_t)))) return rc;      // keys a|b
+  if ((rc = c->ws[WS_ORDER].ensure(N * sizeof(uint32_t)))) return rc;         // idx a
+  if ((rc = c->ws[WS_TMPB].ensure(tmp_bytes + 256))) return rc;
+  double* d_aos = c->ws[WS_TMPA].as<double>();
+  uint32_t* keys_a = c->ws[WS_CELL].as<uint32_t>();
+  uint32_t* keys_b = keys_a + N;
+  uint32_t* idx_a = c->ws[WS_ORDER].as<uint32_t>();
   HIPCHK(hipMalloc((void**)&sc->d_order, N * sizeof(int32_t)));
-  HIPCHK(hipMemcpy(sc->d_order, sc->order_h.data(), N * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&sc->x, N * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&sc->y, N * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&sc->z, N * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d_aos, xyz, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(launch_morton_order(d_aos, N, lo, scl, keys_a, idx_a, keys_b, reinterpret_cast<uint32_t*>(sc->d_order),
+                             c->ws[WS_TMPB].p, tmp_bytes, s));
+  HIPCHK(launch_gather_soa(d_aos, reinterpret_cast<const uint32_t*>(sc->d_order), N, sc->x, sc->y, sc->z, s));
+  if (nrm) {
+    HIPCHK(hipMalloc((void**)&sc->nx, N * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&sc->ny, N * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&sc->nz, N * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(d_aos, nrm, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_gather_soa(d_aos, reinterpret_cast<const uint32_t*>(sc->d_order), N, sc->nx, sc->ny, sc->nz, s));
+  }
+  sc->order_h.resize(N);
+  HIPCHK(hipMemcpyAsync(sc->order_h.data(), sc->d_order, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   *out = sc.release();
   return TDTK_OK;
 }

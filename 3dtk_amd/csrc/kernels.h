@@ -93,4 +93,11 @@ hipError_t launch_scatter_idx(const int* kpos, const double* d2s, const int32_t*
                               const KdPoint* pts, size_t n, int32_t* idx_out, double* d2_out,
                               hipStream_t s);
 
+size_t morton_sort_temp_bytes(size_t n);
+hipError_t launch_morton_order(const double* d_xyz, size_t n, const double lo[3], const double sc[3],
+                               uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
+                               size_t tmp_bytes, hipStream_t s);
+hipError_t launch_gather_soa(const double* d_src, const uint32_t* order, size_t n, double* x, double* y, double* z,
+                             hipStream_t s);
+
 }  // namespace tdtk
