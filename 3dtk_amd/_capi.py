@@ -52,7 +52,7 @@ class IcpResult(C.Structure):
 # every symbol include/tdtk_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "tdtk_last_error", "tdtk_device_count", "tdtk_version", "tdtk_tree_create", "tdtk_tree_destroy",
-    "tdtk_tree_get_info", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
+    "tdtk_tree_get_info", "tdtk_tree_verify", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_solve_spd",
@@ -105,6 +105,7 @@ def lib():
     L.tdtk_tree_destroy.argtypes = [C.c_void_p]
     L.tdtk_tree_destroy.restype = None
     L.tdtk_tree_get_info.argtypes = [C.c_void_p, C.POINTER(TreeInfo)]
+    L.tdtk_tree_verify.argtypes = [C.c_void_p, _u64p]
     L.tdtk_find_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, _dp]
     L.tdtk_find_closest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]

@@ -145,51 +145,83 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
   if (rc) return rc;
 
   const double t0 = now_ms();
-  HostTree H;
-  std::string err;
-  if (!build_tree(xyz, M, bucket_size, H, err)) { set_error(err); return TDTK_EINVAL; }
-  const double t1 = now_ms();
-
   std::unique_ptr<tdtk_tree> t(new tdtk_tree);
   t->device = device; t->M = M; t->bucket = bucket_size;
   t->xyz_h.assign(xyz, xyz + 3 * M);
-  for (int a = 0; a < 3; a++) {
-    t->bbmin[a] = H.bbmin[a]; t->bbmax[a] = H.bbmax[a];
-    t->centre[a] = 0.5 * (H.bbmin[a] + H.bbmax[a]);
+  if (bucket_size < 1) { set_error("bucket size must be >= 1"); return TDTK_EINVAL; }
+  if (M > (size_t)REF_VAL || M * sizeof(KdPoint) >= (1ull << 32)) {
+    set_error("model scan too large (30-bit references / 32-bit byte offsets: < 2^27 points)");
+    return TDTK_EINVAL;
   }
+  // root bounding box (binning of unsorted query batches, accumulation shift)
+  for (int a = 0; a < 3; a++) t->bbmin[a] = t->bbmax[a] = xyz[a];
+  for (size_t i = 1; i < M; i++)
+    for (int a = 0; a < 3; a++) {
+      const double v = xyz[3 * i + a];
+      if (v < t->bbmin[a]) t->bbmin[a] = v;
+      if (t->bbmax[a] < v) t->bbmax[a] = v;
+    }
+  for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
   size_t bytes = 0;
-  if (!H.nodes.empty()) {
-    HIPCHK(hipMalloc(&t->d_nodes, H.nodes.size() * sizeof(KdNode)));
-    HIPCHK(hipMemcpy(t->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&t->d_r, H.node_r.size() * sizeof(double)));
-    HIPCHK(hipMemcpy(t->d_r, H.node_r.data(), H.node_r.size() * sizeof(double), hipMemcpyHostToDevice));
-    bytes += H.nodes.size() * (sizeof(KdNode) + sizeof(double));
+  double build_ms = 0.0, upload_ms = 0.0;
+  const char* host_env = getenv("TDTK_HOST_BUILD");
+  if (host_env && host_env[0] == '1') {
+    // host construction (kd_build.cpp), kept as the cross-check of the device builder
+    HostTree H;
+    std::string err;
+    if (!build_tree(xyz, M, bucket_size, H, err)) { set_error(err); return TDTK_EINVAL; }
+    const double t1 = now_ms();
+    build_ms = t1 - t0;
+    if (!H.nodes.empty()) {
+      HIPCHK(hipMalloc(&t->d_nodes, H.nodes.size() * sizeof(KdNode)));
+      HIPCHK(hipMemcpy(t->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice));
+      HIPCHK(hipMalloc(&t->d_r, H.node_r.size() * sizeof(double)));
+      HIPCHK(hipMemcpy(t->d_r, H.node_r.data(), H.node_r.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc(&t->d_pts, H.pts.size() * sizeof(KdPoint)));
+    HIPCHK(hipMemcpy(t->d_pts, H.pts.data(), H.pts.size() * sizeof(KdPoint), hipMemcpyHostToDevice));
+    if (H.table_mode) {
+      HIPCHK(hipMalloc(&t->d_leaf, H.leaf_tab.size() * sizeof(LeafEntry)));
+      HIPCHK(hipMemcpy(t->d_leaf, H.leaf_tab.data(), H.leaf_tab.size() * sizeof(LeafEntry), hipMemcpyHostToDevice));
+    }
+    t->dev.root_ref = H.root_ref;
+    t->dev.cb = (uint32_t)H.cb;
+    t->info.n_internal = H.n_internal; t->info.n_leaves = H.n_leaves;
+    t->info.max_depth = H.max_depth; t->info.max_leaf_points = H.max_leaf_points;
+    upload_ms = now_ms() - t1;
+  } else {
+    // device construction (build.hip): upload the points once, build level by level
+    if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, xyz, 3 * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double t1 = now_ms();
+    upload_ms = t1 - t0;
+    DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->stream);
+    if (r.err != hipSuccess) {
+      set_error(r.degenerate ? std::string("degenerate split (non-finite coordinates?)")
+                             : std::string("device tree build: ") + hipGetErrorString(r.err));
+      return r.degenerate ? TDTK_EINVAL : TDTK_EDEVICE;
+    }
+    t->d_nodes = r.nodes; t->d_r = r.node_r; t->d_pts = r.pts;
+    if (r.table_mode) t->d_leaf = r.leaf_tab;
+    else (void)hipFree(r.leaf_tab);
+    t->dev.root_ref = r.root_ref;
+    t->dev.cb = (uint32_t)r.cb;
+    t->info.n_internal = r.n_internal; t->info.n_leaves = r.n_leaves;
+    t->info.max_depth = r.max_depth; t->info.max_leaf_points = r.max_leaf;
+    build_ms = now_ms() - t1;
   }
-  HIPCHK(hipMalloc(&t->d_pts, H.pts.size() * sizeof(KdPoint)));
-  HIPCHK(hipMemcpy(t->d_pts, H.pts.data(), H.pts.size() * sizeof(KdPoint), hipMemcpyHostToDevice));
-  bytes += H.pts.size() * sizeof(KdPoint);
-  if (H.table_mode) {
-    HIPCHK(hipMalloc(&t->d_leaf, H.leaf_tab.size() * sizeof(LeafEntry)));
-    HIPCHK(hipMemcpy(t->d_leaf, H.leaf_tab.data(), H.leaf_tab.size() * sizeof(LeafEntry), hipMemcpyHostToDevice));
-    bytes += H.leaf_tab.size() * sizeof(LeafEntry);
-  }
+  bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(double)) + M * sizeof(KdPoint);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
   t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
   t->dev.node_r = static_cast<const double*>(t->d_r);
-  t->dev.root_ref = H.root_ref;
-  t->dev.cb = (uint32_t)H.cb;
-  t->dev.cmask = (H.cb >= 32) ? 0xFFFFFFFFu : ((1u << H.cb) - 1u);
-  const double t2 = now_ms();
+  t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
 
   t->info.n_points = M;
-  t->info.n_internal = H.n_internal;
-  t->info.n_leaves = H.n_leaves;
-  t->info.max_depth = H.max_depth;
-  t->info.max_leaf_points = H.max_leaf_points;
   t->info.device_bytes = bytes;
-  t->info.build_ms = t1 - t0;
-  t->info.upload_ms = t2 - t1;
+  t->info.build_ms = build_ms;
+  t->info.upload_ms = upload_ms;
   *out = t.release();
   return TDTK_OK;
 }
@@ -811,6 +843,60 @@ int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_
       if (p2_out) { p2_out[3 * k] = tt[0]; p2_out[3 * k + 1] = tt[1]; p2_out[3 * k + 2] = tt[2]; }
       if (pn_out) { pn_out[3 * k] = nn[0]; pn_out[3 * k + 1] = nn[1]; pn_out[3 * k + 2] = nn[2]; }
       k++;
+    }
+  }
+  return TDTK_OK;
+}
+
+// ---- diagnostics: is the resident tree bit-identical to the host builder's? ----------------------
+int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
+{
+  if (!t || !mismatches) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(t->device, &c);
+  if (rc) return rc;
+  HostTree H;
+  std::string err;
+  if (!build_tree(t->xyz_h.data(), t->M, t->bucket, H, err)) { set_error(err); return TDTK_EINVAL; }
+  std::vector<KdNode> nodes(H.nodes.size());
+  std::vector<double> rr(H.nodes.size());
+  std::vector<KdPoint> pts(t->M);
+  mismatches[0] = mismatches[1] = mismatches[2] = mismatches[3] = 0;
+  if (H.n_internal != t->info.n_internal || H.n_leaves != t->info.n_leaves || H.max_depth != t->info.max_depth ||
+      H.max_leaf_points != t->info.max_leaf_points || H.root_ref != t->dev.root_ref || (uint32_t)H.cb != t->dev.cb ||
+      H.table_mode != (t->d_leaf != nullptr))
+    mismatches[3] = 1;
+  if (mismatches[3] == 0) {
+    if (!nodes.empty()) {
+      HIPCHK(hipMemcpy(nodes.data(), t->d_nodes, nodes.size() * sizeof(KdNode), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(rr.data(), t->d_r, rr.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(pts.data(), t->d_pts, pts.size() * sizeof(KdPoint), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nodes.size(); i++) {
+      const KdNode &a = nodes[i], &b = H.nodes[i];
+      // == on doubles: +0 and -0 compare equal (the sign of a zero box centre never decides anything)
+      if (!(a.cx == b.cx && a.cy == b.cy && a.cz == b.cz && a.hx == b.hx && a.hy == b.hy && a.hz == b.hz &&
+            a.splitval == b.splitval && a.c1 == b.c1 && a.c2 == b.c2))
+        mismatches[0]++;
+      if (rr[i] != H.node_r[i]) mismatches[1]++;
+    }
+    for (size_t i = 0; i < pts.size(); i++)
+      if (!(pts[i].x == H.pts[i].x && pts[i].y == H.pts[i].y && pts[i].z == H.pts[i].z && pts[i].orig == H.pts[i].orig))
+        mismatches[2]++;
+    if (H.table_mode) {
+      std::vector<LeafEntry> lt(H.leaf_tab.size());
+      HIPCHK(hipMemcpy(lt.data(), t->d_leaf, lt.size() * sizeof(LeafEntry), hipMemcpyDeviceToHost));
+      // leaf ids may be numbered differently; compare through the references instead
+      auto leaf_of = [&](const std::vector<LeafEntry>& tab, uint32_t ref) { return tab[ref & REF_VAL]; };
+      for (size_t i = 0; i < nodes.size(); i++)
+        for (int k = 0; k < 2; k++) {
+          const uint32_t ra = k ? nodes[i].c2 : nodes[i].c1, rb = k ? H.nodes[i].c2 : H.nodes[i].c1;
+          if ((ra & REF_LEAF) != (rb & REF_LEAF)) continue;
+          if (ra & REF_LEAF) {
+            const LeafEntry x = leaf_of(lt, ra), y = leaf_of(H.leaf_tab, rb);
+            if (x.start != y.start || x.count != y.count) mismatches[3]++;
+          }
+        }
     }
   }
   return TDTK_OK;

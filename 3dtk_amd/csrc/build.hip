@@ -1,0 +1,426 @@
+// GPU construction of the model-scan search tree.
+//
+// Same tree as KDTreeImpl::create (include/slam6d/kdTreeImpl.h:82-201) and therefore the same
+// flattened layout kd_build.cpp produces on the host -- node for node, bucket for bucket (the
+// test compares the two bitwise) -- but built level by level on the device:
+//
+//   * the points travel with the permutation (SoA in run order), so every pass is a coalesced
+//     stream instead of an indirect gather;
+//   * k_measure: one wavefront per (node, axis).  Bounding box by wave reduction; the centroid is
+//     an ORDER-DEPENDENT fp64 sum in the reference (first point, then += the rest left to right,
+//     kdTreeImpl.h:94-111), so it is reproduced as exactly that chain: 64 coalesced values per
+//     step, parked in LDS and folded in run order.  This chain is the critical path (1M dependent
+//     adds at the root; it halves per level);
+//   * the in-place Hoare partition (kdTreeImpl.h:172-182) is order-equivalent to: elements already
+//     on their side stay, the k-th misplaced element from the left swaps with the k-th misplaced
+//     element from the right.  That is three prefix sums (rocPRIM) + a swap kernel per level for
+//     ALL nodes of the level at once.
+//
+// One small D2H (the number of internal nodes of the level) per level is the only host sync.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+
+#include "kernels.h"
+
+namespace tdtk {
+
+#define WAVE 64
+
+struct BSeg {
+  uint32_t start, n;
+  int32_t parent;   // node index, -1 for the root
+  uint32_t side;    // 0 -> c1, 1 -> c2
+};
+struct BMeas {
+  double lo[3], hi[3], mean[3];
+};
+
+// ---- per node: bounding box + the reference's left-to-right fp64 sum ----------------------------
+// One wavefront per (node, axis).  Each step the wave loads 64 consecutive values (one coalesced
+// 512-B instruction, the next chunk prefetched while the current one is folded), updates the
+// bounding box per lane, and parks the chunk in LDS.  The sum -- a strictly serial chain of fp64
+// adds in run order, the critical path of the whole build -- then reads the values back one by
+// one at a wave-uniform address (LDS broadcast, in-order returns, so the reads pipeline ahead of
+// the chain) and the vector ALU issues nothing but the dependent v_add_f64 chain.
+__global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, uint32_t nseg,
+                                                 const double* __restrict__ cx, const double* __restrict__ cy,
+                                                 const double* __restrict__ cz, BMeas* __restrict__ out)
+{
+  __shared__ double stage[256 / WAVE][2][WAVE];
+  // wave-uniform by construction; readfirstlane tells the compiler so
+  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const int lane = threadIdx.x & (WAVE - 1);
+  if (w >= 3u * nseg) return;
+  const uint32_t sgi = w / 3u, ax = w % 3u;
+  const uint32_t s = __builtin_amdgcn_readfirstlane(segs[sgi].start);
+  const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
+  const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + s;
+  double(*buf)[WAVE] = stage[threadIdx.x / WAVE];
+
+  const double first = arr[0];
+  double lo = first, hi = first;
+  double sum = first;  // the sum starts from the first point (kdTreeImpl.h:97-101) ...
+  double v = ((uint32_t)lane < n) ? arr[lane] : first;
+  int cur = 0;
+  for (uint32_t base = 0; base < n; base += WAVE, cur ^= 1) {
+    const uint32_t cnt = (n - base < WAVE) ? (n - base) : WAVE;
+    lo = (v < lo) ? v : lo;  // lanes past the end carry `first`, harmless for min/max
+    hi = (hi < v) ? v : hi;
+    buf[cur][lane] = v;
+    const uint32_t nb = base + WAVE;
+    const double vnext = (nb + lane < n) ? arr[nb + lane] : first;  // prefetch the next chunk
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double* __restrict__ b = buf[cur];
+    if (cnt == WAVE && base != 0) {
+#pragma unroll
+      for (int k = 0; k < WAVE; k++) sum += b[k];
+    } else {
+      for (uint32_t k = (base == 0) ? 1u : 0u; k < cnt; k++) sum += b[k];  // ... and adds the rest in order
+    }
+    v = vnext;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double t;
+    t = __shfl_xor(lo, off, WAVE); lo = (t < lo) ? t : lo;
+    t = __shfl_xor(hi, off, WAVE); hi = (hi < t) ? t : hi;
+  }
+  if (lane == 0) {
+    out[sgi].lo[ax] = lo;
+    out[sgi].hi[ax] = hi;
+    out[sgi].mean[ax] = sum / (double)n;
+  }
+}
+
+// ---- per node: leaf or internal, split axis / value (kdTreeImpl.h:113-170) ----------------------
+__global__ void k_decide(const BSeg* __restrict__ segs, uint32_t nseg, const BMeas* __restrict__ meas,
+                         uint32_t bucket, uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
+                         double* __restrict__ splitval)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const BMeas m = meas[i];
+  const double hx = 0.5 * (m.hi[0] - m.lo[0]), hy = 0.5 * (m.hi[1] - m.lo[1]), hz = 0.5 * (m.hi[2] - m.lo[2]);
+  int ax;
+  if (hx > hy) ax = (hx > hz) ? 0 : 2;
+  else ax = (hy > hz) ? 1 : 2;
+  const double mx = fmax(fmax(hx, hy), hz);
+  const bool leaf = (segs[i].n <= bucket) || (fabs(mx) < 0.01);
+  kind[i] = leaf ? 0u : 1u;
+  axis[i] = (uint32_t)ax;
+  splitval[i] = m.mean[ax];
+}
+
+// ---- per node: write the record / register the bucket, hook it into its parent ------------------
+__global__ void k_emit(const BSeg* __restrict__ segs, uint32_t nseg, const BMeas* __restrict__ meas,
+                       const uint32_t* __restrict__ kind, const uint32_t* __restrict__ axis,
+                       const double* __restrict__ splitval, const uint32_t* __restrict__ irank,
+                       uint32_t node_base, uint32_t leaf_base, KdNode* __restrict__ nodes,
+                       double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                       uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const BSeg sg = segs[i];
+  uint32_t ref;
+  if (kind[i]) {
+    const BMeas m = meas[i];
+    const uint32_t me = node_base + irank[i];
+    KdNode nd;
+    nd.cx = 0.5 * (m.lo[0] + m.hi[0]);
+    nd.cy = 0.5 * (m.lo[1] + m.hi[1]);
+    nd.cz = 0.5 * (m.lo[2] + m.hi[2]);
+    nd.hx = 0.5 * (m.hi[0] - m.lo[0]);
+    nd.hy = 0.5 * (m.hi[1] - m.lo[1]);
+    nd.hz = 0.5 * (m.hi[2] - m.lo[2]);
+    nd.splitval = splitval[i];
+    nd.c1 = (axis[i] & 1u) ? REF_AXIS : 0u;
+    nd.c2 = (axis[i] & 2u) ? REF_AXIS : 0u;
+    nodes[me] = nd;
+    node_r[me] = __dsqrt_rn(nd.hx * nd.hx + nd.hy * nd.hy + nd.hz * nd.hz);
+    ref = me;
+  } else {
+    const uint32_t id = leaf_base + (i - irank[i]);  // every node is either internal or a bucket
+    leaf_tab[id].start = (int32_t)sg.start;
+    leaf_tab[id].count = (int32_t)sg.n;
+    atomicMax(max_leaf, sg.n);
+    ref = REF_LEAF | id;
+  }
+  if (sg.parent < 0) *root_ref = ref;
+  else {
+    uint32_t* slot = sg.side ? &nodes[sg.parent].c2 : &nodes[sg.parent].c1;
+    *slot = (*slot & REF_AXIS) | ref;
+  }
+}
+
+// ---- per element: "< splitval" flag (0 outside internal nodes) ----------------------------------
+__global__ void k_flags(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+                        const uint32_t* __restrict__ axis, const double* __restrict__ splitval,
+                        const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
+                        uint32_t M, uint32_t* __restrict__ f)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  uint32_t v = 0;
+  if (p < M) {
+    const uint32_t sg = seg_of[p];
+    if (sg != 0xFFFFFFFFu && kind[sg]) {
+      const uint32_t ax = axis[sg];
+      const double c = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
+      v = (c < splitval[sg]) ? 1u : 0u;
+    }
+  }
+  f[p] = v;  // index M is a zero terminator so the exclusive scan also yields the grand total
+}
+
+// ---- per element: misplaced on the left / on the right of its node's split position --------------
+__global__ void k_misplaced(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+                            const BSeg* __restrict__ segs, const uint32_t* __restrict__ f,
+                            const uint32_t* __restrict__ F, uint32_t M, uint32_t* __restrict__ isL,
+                            uint32_t* __restrict__ isR)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  uint32_t l = 0, r = 0;
+  if (p < M) {
+    const uint32_t sg = seg_of[p];
+    if (sg != 0xFFFFFFFFu && kind[sg]) {
+      const uint32_t s = segs[sg].start, n = segs[sg].n;
+      const uint32_t nleft = F[s + n] - F[s];
+      const bool left_region = (p - s) < nleft;
+      l = (left_region && !f[p]) ? 1u : 0u;
+      r = (!left_region && f[p]) ? 1u : 0u;
+    }
+  }
+  isL[p] = l;
+  isR[p] = r;
+}
+
+// k-th misplaced from the left pairs with the k-th misplaced from the right end
+__global__ void k_swaplist(const uint32_t* __restrict__ seg_of, const BSeg* __restrict__ segs,
+                           const uint32_t* __restrict__ isL, const uint32_t* __restrict__ isR,
+                           const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t M,
+                           uint32_t* __restrict__ posL, uint32_t* __restrict__ posR)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  if (isL[p]) posL[A[p]] = p;
+  if (isR[p]) {
+    const uint32_t sg = seg_of[p];
+    const uint32_t s = segs[sg].start, n = segs[sg].n;
+    const uint32_t total = B[s + n] - B[s];
+    const uint32_t kfwd = B[p] - B[s];
+    posR[B[s] + (total - 1u - kfwd)] = p;
+  }
+}
+
+__global__ void k_swap(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR, uint32_t nswap,
+                       uint32_t* __restrict__ perm, double* __restrict__ cx, double* __restrict__ cy,
+                       double* __restrict__ cz)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nswap) return;
+  const uint32_t a = posL[c], b = posR[c];
+  const uint32_t pa = perm[a], pb = perm[b];
+  perm[a] = pb; perm[b] = pa;
+  double t;
+  t = cx[a]; cx[a] = cx[b]; cx[b] = t;
+  t = cy[a]; cy[a] = cy[b]; cy[b] = t;
+  t = cz[a]; cz[a] = cz[b]; cz[b] = t;
+}
+
+// ---- next level: two children per internal node; relabel the elements ---------------------------
+__global__ void k_children(const BSeg* __restrict__ segs, uint32_t nseg, const uint32_t* __restrict__ kind,
+                           const uint32_t* __restrict__ irank, const uint32_t* __restrict__ F, uint32_t node_base,
+                           BSeg* __restrict__ next, uint32_t* __restrict__ err)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg || !kind[i]) return;
+  const BSeg sg = segs[i];
+  const uint32_t nleft = F[sg.start + sg.n] - F[sg.start];
+  if (nleft == 0 || nleft == sg.n) atomicExch(err, 1u);  // degenerate split (non-finite input)
+  const uint32_t me = node_base + irank[i];
+  next[2 * irank[i]] = {sg.start, nleft, (int32_t)me, 0u};
+  next[2 * irank[i] + 1] = {sg.start + nleft, sg.n - nleft, (int32_t)me, 1u};
+}
+__global__ void k_relabel(const BSeg* __restrict__ segs, const uint32_t* __restrict__ kind,
+                          const uint32_t* __restrict__ irank, const uint32_t* __restrict__ F, uint32_t M,
+                          uint32_t* __restrict__ seg_of)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const uint32_t sg = seg_of[p];
+  if (sg == 0xFFFFFFFFu) return;
+  if (!kind[sg]) { seg_of[p] = 0xFFFFFFFFu; return; }
+  const uint32_t s = segs[sg].start, n = segs[sg].n;
+  const uint32_t nleft = F[s + n] - F[s];
+  seg_of[p] = 2u * irank[sg] + (((p - s) < nleft) ? 0u : 1u);
+}
+
+__global__ void k_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
+                       uint32_t* __restrict__ seg_of, double* __restrict__ cx, double* __restrict__ cy,
+                       double* __restrict__ cz)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  perm[p] = p; seg_of[p] = 0;
+  cx[p] = xyz[3 * (size_t)p]; cy[p] = xyz[3 * (size_t)p + 1]; cz[p] = xyz[3 * (size_t)p + 2];
+}
+__global__ void k_points(const uint32_t* __restrict__ perm, const double* __restrict__ cx,
+                         const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M,
+                         KdPoint* __restrict__ pts)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  KdPoint q;
+  q.x = cx[p]; q.y = cy[p]; q.z = cz[p]; q.orig = (int32_t)perm[p]; q.pad = 0;
+  pts[p] = q;
+}
+// packed bucket references (start << cb | count) when they fit in 30 bits (same rule as kd_build.cpp)
+__global__ void k_pack_refs(KdNode* __restrict__ nodes, uint32_t nnodes, const LeafEntry* __restrict__ leaf_tab,
+                            uint32_t cb, uint32_t* __restrict__ root_ref)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  auto pack = [&](uint32_t ref) -> uint32_t {
+    if (!(ref & REF_LEAF)) return ref;
+    const LeafEntry le = leaf_tab[ref & REF_VAL];
+    return (ref & (REF_LEAF | REF_AXIS)) | ((uint32_t)le.start << cb) | (uint32_t)le.count;
+  };
+  if (i < nnodes) {
+    nodes[i].c1 = pack(nodes[i].c1);
+    nodes[i].c2 = pack(nodes[i].c2);
+  }
+  if (i == 0) *root_ref = pack(*root_ref);
+}
+
+static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+static inline int bits_for(uint64_t v)
+{
+  int b = 0;
+  while (v) { ++b; v >>= 1; }
+  return b;
+}
+
+#define BCHK(expr)                                 \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) { res.err = _e; goto fail; } \
+  } while (0)
+
+// Builds on `s`; on success the caller owns res.{nodes,node_r,pts,leaf_tab} (hipMalloc'ed).
+DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hipStream_t s)
+{
+  DevBuildResult res{};
+  const uint32_t M = (uint32_t)M_;
+  char* arena = nullptr;
+  KdNode* nodes = nullptr; double* node_r = nullptr; LeafEntry* leaf_tab = nullptr; KdPoint* pts = nullptr;
+  uint32_t node_count = 0, leaf_count = 0, depth = 0, nseg = 1;
+  // ---- one arena for every temporary ----
+  size_t scan_tmp = 0;
+  {
+    uint32_t* z = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, z, z, 0u, (size_t)M + 1, rocprim::plus<uint32_t>(), s);
+  }
+  const size_t n1 = (size_t)M + 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_perm = take(4 * n1), o_segof = take(4 * n1), o_cx = take(8 * n1), o_cy = take(8 * n1), o_cz = take(8 * n1);
+  const size_t o_f = take(4 * n1), o_F = take(4 * n1), o_isL = take(4 * n1), o_isR = take(4 * n1), o_A = take(4 * n1),
+               o_B = take(4 * n1), o_posL = take(4 * n1), o_posR = take(4 * n1);
+  const size_t o_segA = take(sizeof(BSeg) * n1), o_segB = take(sizeof(BSeg) * n1), o_meas = take(sizeof(BMeas) * n1);
+  const size_t o_kind = take(4 * n1), o_axis = take(4 * n1), o_split = take(8 * n1), o_irank = take(4 * n1);
+  const size_t o_tmp = take(scan_tmp + 256), o_small = take(256);
+  BCHK(hipMalloc((void**)&arena, off));
+  BCHK(hipMalloc((void**)&nodes, sizeof(KdNode) * n1));
+  BCHK(hipMalloc((void**)&node_r, sizeof(double) * n1));
+  BCHK(hipMalloc((void**)&leaf_tab, sizeof(LeafEntry) * n1));
+  BCHK(hipMalloc((void**)&pts, sizeof(KdPoint) * n1));
+  {
+    uint32_t* perm = (uint32_t*)(arena + o_perm); uint32_t* seg_of = (uint32_t*)(arena + o_segof);
+    double *cx = (double*)(arena + o_cx), *cy = (double*)(arena + o_cy), *cz = (double*)(arena + o_cz);
+    uint32_t *f = (uint32_t*)(arena + o_f), *F = (uint32_t*)(arena + o_F), *isL = (uint32_t*)(arena + o_isL),
+             *isR = (uint32_t*)(arena + o_isR), *A = (uint32_t*)(arena + o_A), *B = (uint32_t*)(arena + o_B),
+             *posL = (uint32_t*)(arena + o_posL), *posR = (uint32_t*)(arena + o_posR);
+    BSeg* segs = (BSeg*)(arena + o_segA); BSeg* next = (BSeg*)(arena + o_segB);
+    BMeas* meas = (BMeas*)(arena + o_meas);
+    uint32_t *kind = (uint32_t*)(arena + o_kind), *axis = (uint32_t*)(arena + o_axis), *irank = (uint32_t*)(arena + o_irank);
+    double* splitval = (double*)(arena + o_split);
+    void* tmp = arena + o_tmp;
+    uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
+    BCHK(hipMemsetAsync(small, 0, 256, s));
+    const BSeg root = {0u, M, -1, 0u};
+    BCHK(hipMemcpyAsync(segs, &root, sizeof root, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz);
+
+    while (nseg > 0) {
+      ++depth;
+      hipLaunchKernelGGL(k_measure, dim3(cdiv((size_t)nseg * 3 * WAVE, 256)), dim3(256), 0, s, segs, nseg, cx, cy, cz, meas);
+      hipLaunchKernelGGL(k_decide, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, (uint32_t)bucket, kind,
+                         axis, splitval);
+      size_t st = scan_tmp;
+      BCHK(hipMemsetAsync(kind + nseg, 0, 4, s));
+      BCHK(rocprim::exclusive_scan(tmp, st, kind, irank, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), s));
+      uint32_t n_internal = 0;
+      BCHK(hipMemcpyAsync(&n_internal, irank + nseg, 4, hipMemcpyDeviceToHost, s));
+      BCHK(hipStreamSynchronize(s));
+      hipLaunchKernelGGL(k_emit, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, kind, axis, splitval, irank,
+                         node_count, leaf_count, nodes, node_r, leaf_tab, small + 0, small + 1);
+      if (n_internal) {
+        hipLaunchKernelGGL(k_flags, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy, cz, M, f);
+        st = scan_tmp;
+        BCHK(rocprim::exclusive_scan(tmp, st, f, F, 0u, n1, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(k_misplaced, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, segs, f, F, M, isL, isR);
+        st = scan_tmp;
+        BCHK(rocprim::exclusive_scan(tmp, st, isL, A, 0u, n1, rocprim::plus<uint32_t>(), s));
+        st = scan_tmp;
+        BCHK(rocprim::exclusive_scan(tmp, st, isR, B, 0u, n1, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, isL, isR, A, B, M, posL, posR);
+        // every element is misplaced at most once per level, so M bounds the swap count; the
+        // exact count sits in A[M] -- launch over M and let the kernel read it from there
+        uint32_t nswap = 0;
+        BCHK(hipMemcpyAsync(&nswap, A + M, 4, hipMemcpyDeviceToHost, s));
+        BCHK(hipStreamSynchronize(s));
+        if (nswap)
+          hipLaunchKernelGGL(k_swap, dim3(cdiv(nswap, 256)), dim3(256), 0, s, posL, posR, nswap, perm, cx, cy, cz);
+        hipLaunchKernelGGL(k_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, kind, irank, F, node_count,
+                           next, small + 2);
+        hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, F, M, seg_of);
+      }
+      node_count += n_internal;
+      leaf_count += nseg - n_internal;
+      nseg = 2 * n_internal;
+      BSeg* t = segs; segs = next; next = t;
+    }
+    uint32_t h_small[3];
+    BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    if (h_small[2]) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
+    res.max_leaf = h_small[1];
+    res.cb = bits_for(res.max_leaf);
+    res.table_mode = (bits_for(M) + res.cb) > 30;
+    hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
+    if (!res.table_mode)
+      hipLaunchKernelGGL(k_pack_refs, dim3(cdiv(node_count ? node_count : 1, 256)), dim3(256), 0, s, nodes, node_count,
+                         leaf_tab, (uint32_t)res.cb, small + 0);
+    BCHK(hipMemcpyAsync(&res.root_ref, small + 0, 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    BCHK(hipGetLastError());
+  }
+  (void)hipFree(arena);
+  res.nodes = nodes; res.node_r = node_r; res.leaf_tab = leaf_tab; res.pts = pts;
+  res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
+  return res;
+fail:
+  if (arena) (void)hipFree(arena);
+  if (nodes) (void)hipFree(nodes);
+  if (node_r) (void)hipFree(node_r);
+  if (leaf_tab) (void)hipFree(leaf_tab);
+  if (pts) (void)hipFree(pts);
+  if (res.err == hipSuccess) res.err = hipErrorUnknown;
+  return res;
+}
+
+}  // namespace tdtk

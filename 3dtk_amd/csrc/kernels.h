@@ -93,6 +93,21 @@ hipError_t launch_scatter_idx(const int* kpos, const double* d2s, const int32_t*
                               const KdPoint* pts, size_t n, int32_t* idx_out, double* d2_out,
                               hipStream_t s);
 
+struct DevBuildResult {
+  hipError_t err;
+  bool degenerate;
+  KdNode* nodes;
+  double* node_r;
+  LeafEntry* leaf_tab;
+  KdPoint* pts;
+  uint32_t root_ref;
+  int cb;
+  bool table_mode;
+  uint32_t n_internal, n_leaves, max_depth, max_leaf;
+};
+// level-synchronous construction of the reference's kd-tree on the device (build.hip)
+DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, hipStream_t s);
+
 size_t morton_sort_temp_bytes(size_t n);
 hipError_t launch_morton_order(const double* d_xyz, size_t n, const double lo[3], const double sc[3],
                                uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,

@@ -122,6 +122,12 @@ class KDtree:
         check(lib().tdtk_tree_get_info(self._h, C.byref(ti)))
         return {k: getattr(ti, k) for k, _ in TreeInfo._fields_}
 
+    def verify(self):
+        """Compare the resident (device-built) tree with the host builder's, bit for bit."""
+        mm = (C.c_uint64 * 4)()
+        check(lib().tdtk_tree_verify(self._h, mm))
+        return [int(v) for v in mm]
+
     def FindClosest(self, p, maxdist2, threadNum=0):
         """kd.cc:78-87.  Returns the index of the closest point or None (reference: NULL)."""
         idx, _ = self.FindClosestBatch(np.asarray(p, dtype=np.float64).reshape(1, 3), maxdist2)

@@ -115,6 +115,9 @@ const char* tdtk_version(void);
 int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, tdtk_tree** out);
 void tdtk_tree_destroy(tdtk_tree* t);
 int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info);
+/* diagnostic: rebuild the tree with the host builder and compare it with the resident one (built on
+ * the device unless TDTK_HOST_BUILD=1).  mismatches = {node records, node radii, points, structure}. */
+int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4]);
 
 /* ---- batched KDtree::FindClosest (kd.cc:78-87; _FindClosest kdTreeImpl.h:345-383).
  * q [K][3] in the tree frame, host memory.  idx[k] = index into the xyz given to

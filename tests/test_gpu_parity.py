@@ -508,3 +508,23 @@ def test_large_scan_4m_points(tdtk, orc, gpu):
         idx, d2 = kd.FindClosestBatch(q, md2)
         oi, od2 = T.find_closest(q, md2, 8)
         assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+
+
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "tiny", "grid", "line"])
+@pytest.mark.parametrize("bucket", [1, 7, 20])
+def test_device_tree_build_equals_host_build(tdtk, gpu, name, bucket):
+    """The tree built level by level on the GPU (build.hip) is the host builder's tree
+    (kd_build.cpp == KDTreeImpl::create), record for record."""
+    kd = tdtk.KDtree(_clouds()[name], bucket)
+    assert kd.verify() == [0, 0, 0, 0]
+
+
+def test_device_tree_build_full_size(tdtk, gpu, k5):
+    k, m, _ = k5
+    kd = tdtk.KDtree(m, 20)
+    inf = kd.info()
+    assert (inf["n_internal"], inf["n_leaves"], inf["max_depth"]) == (k["tree"]["internal"], k["tree"]["leaves"], k["tree"]["depth"])
+    assert kd.verify() == [0, 0, 0, 0]
+    rng = np.random.default_rng(5)
+    big = rng.uniform(-1000, 1000, (1100000, 3)); big[5000:5600] = big[4999]       # leaf-table mode
+    assert tdtk.KDtree(big, 20).verify() == [0, 0, 0, 0]
