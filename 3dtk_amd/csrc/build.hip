@@ -380,13 +380,15 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hip
         hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, isL, isR, A, B, M, posL, posR);
         // every element is misplaced at most once per level, so M bounds the swap count; the
         // exact count sits in A[M] -- launch over M and let the kernel read it from there
-        uint32_t nswap = 0;
-        BCHK(hipMemcpyAsync(&nswap, A + M, 4, hipMemcpyDeviceToHost, s));
-        BCHK(hipStreamSynchronize(s));
-        if (nswap)
-          hipLaunchKernelGGL(k_swap, dim3(cdiv(nswap, 256)), dim3(256), 0, s, posL, posR, nswap, perm, cx, cy, cz);
+        uint32_t nswap = 0, bad = 0;
         hipLaunchKernelGGL(k_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, kind, irank, F, node_count,
                            next, small + 2);
+        BCHK(hipMemcpyAsync(&nswap, A + M, 4, hipMemcpyDeviceToHost, s));
+        BCHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
+        BCHK(hipStreamSynchronize(s));
+        if (bad || depth > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
+        if (nswap)
+          hipLaunchKernelGGL(k_swap, dim3(cdiv(nswap, 256)), dim3(256), 0, s, posL, posR, nswap, perm, cx, cy, cz);
         hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, F, M, seg_of);
       }
       node_count += n_internal;

@@ -1022,23 +1022,20 @@ static int num_cu()
 constexpr int SEARCH_BLOCK = 256;
 constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest LDS stack in use
 
-// Tuning variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>, default below):
-//   0: LDS stack 8 deep, vector node loads, default occupancy      (the first working kernel)
-//   1: LDS stack 4 deep, 8 waves/SIMD
-//   2: LDS stack 8 deep + wave-uniform scalar node loads
-//   3: LDS stack 4 deep, 8 waves/SIMD + wave-uniform scalar node loads
-//   4: LDS stack 4 deep, default occupancy + wave-uniform scalar node loads
-//   5: wave-cooperative fetches (distinct nodes / buckets loaded once per wave into LDS)
-//   6: same, capped at 6 waves/SIMD worth of registers
-//   7..12: persistent lanes (k_search_refill): QPW / refill threshold = 256/1, 256/16, 256/32,
-//          512/16, 128/16, 1024/16
+// Variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>); the default picks by batch size.
+// The full ladder that was measured is in DESIGN.md section 6.
+//   0: the first working kernel (LDS stack 8 deep, per-lane node loads)
+//   4: + 4-deep LDS stack, wave-uniform scalar node loads          (default below 256K queries)
+//   5: wave-cooperative LDS staging of distinct nodes / buckets    (kept as a measured negative)
+//   8: persistent lanes, 256 queries per wave, 256-thread workgroups
+//  20: persistent lanes, 256 queries per wave, 128-thread workgroups (default from 256K queries)
 static int search_variant()
 {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("TDTK_SEARCH_VARIANT");
     v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-    if (v < -2 || v > 21) v = -2;
+    if (v != 0 && v != 4 && v != 5 && v != 8 && v != 20) v = -2;
   }
   return v;
 }
@@ -1085,26 +1082,9 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
     if (v == -2) v = (a.n >= (size_t)262144) ? 20 : 4;
     switch (v) {
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
-      case 1: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, false, 8>), g, b, 0, s, a); break;
-      case 2: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, true, 1>), g, b, 0, s, a); break;
-      case 3: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 8>), g, b, 0, s, a); break;
-      case 7: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 1, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
       case 8: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
-      case 9: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 32, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
-      case 10: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 512, 16, 1>), dim3(refill_grid(a.n, 512)), b, 0, s, a); break;
-      case 11: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 128, 16, 1>), dim3(refill_grid(a.n, 128)), b, 0, s, a); break;
-      case 12: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 1024, 16, 1>), dim3(refill_grid(a.n, 1024)), b, 0, s, a); break;
-      case 13: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 192, 8, 1>), dim3(refill_grid(a.n, 192)), b, 0, s, a); break;
-      case 14: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 192, 16, 1>), dim3(refill_grid(a.n, 192)), b, 0, s, a); break;
-      case 15: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 8, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
-      case 16: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 320, 16, 1>), dim3(refill_grid(a.n, 320)), b, 0, s, a); break;
-      case 17: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 7>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
-      case 18: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 384, 16, 1>), dim3(refill_grid(a.n, 384)), b, 0, s, a); break;
-      case 19: hipLaunchKernelGGL((k_search_refill<64, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 64)), dim3(64), 0, s, a); break;
       case 20: hipLaunchKernelGGL((k_search_refill<128, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 128)), dim3(128), 0, s, a); break;
-      case 21: hipLaunchKernelGGL((k_search_refill<64, 8, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 64)), dim3(64), 0, s, a); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
-      case 6: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 6>), g, b, 0, s, a); break;
       default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
     }
   }

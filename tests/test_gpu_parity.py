@@ -528,3 +528,27 @@ def test_device_tree_build_full_size(tdtk, gpu, k5):
     rng = np.random.default_rng(5)
     big = rng.uniform(-1000, 1000, (1100000, 3)); big[5000:5600] = big[4999]       # leaf-table mode
     assert tdtk.KDtree(big, 20).verify() == [0, 0, 0, 0]
+
+
+def test_tree_edge_cases(tdtk, orc, gpu):
+    """One point, two points, all-identical points (one degenerate bucket larger than the bucket size),
+    non-finite coordinates (the reference would recurse on an empty side; we return an error)."""
+    for pts in ([[1.0, 2.0, 3.0]], [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0]], np.tile([[5.0, 5.0, 5.0]], (100, 1)),
+                np.arange(90, dtype=float).reshape(30, 3)):
+        pts = np.asarray(pts, float)
+        for bucket in (1, 20):
+            kd, T = tdtk.KDtree(pts, bucket), orc.Tree(pts, bucket)
+            assert kd.verify() == [0, 0, 0, 0]
+            q = np.concatenate([pts[:5] + 0.25, pts[:3]])
+            for md2 in (0.01, 1e18):
+                idx, d2 = kd.FindClosestBatch(q, md2)
+                oi, od2 = T.find_closest(q, md2)
+                assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+    bad = np.random.default_rng(0).uniform(-1, 1, (200, 3)); bad[17, 1] = np.nan
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.KDtree(bad, 5)
+    # an empty resident scan is legal and pairs with nothing
+    m = tdtk.Scan([0, 0, 0], [0, 0, 0], np.random.default_rng(1).uniform(-1, 1, (50, 3)))
+    e = tdtk.Scan([0, 0, 0], [0, 0, 0], np.zeros((0, 3)))
+    r = tdtk.Scan.getPtPairs(m, e, max_dist_match2=1.0)
+    assert r["n"] == 0 and r["n_queries"] == 0
