@@ -108,7 +108,6 @@ struct tdtk_tree {
   int bucket = 0;
   TreeDev dev{};
   void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr;
-  std::vector<double> xyz_h;  // caller-order copy (host pair lists of tdtk_get_pt_pairs)
   double bbmin[3], bbmax[3], centre[3];
   tdtk_tree_info info{};
 };
@@ -147,7 +146,6 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
   const double t0 = now_ms();
   std::unique_ptr<tdtk_tree> t(new tdtk_tree);
   t->device = device; t->M = M; t->bucket = bucket_size;
-  t->xyz_h.assign(xyz, xyz + 3 * M);
   if (bucket_size < 1) { set_error("bucket size must be >= 1"); return TDTK_EINVAL; }
   if (M > (size_t)REF_VAL || M * sizeof(KdPoint) >= (1ull << 32)) {
     set_error("model scan too large (30-bit references / 32-bit byte offsets: < 2^27 points)");
@@ -805,46 +803,51 @@ int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_
   if (rnd > 1 || (!idx_out && want_pairs)) { idx_local.resize(n ? n : 1); idx = idx_local.data(); }
   else idx = idx_out;
   rc = tdtk_scan_pairs(t, A, sc, pmode, maxd2, want, lum_D, idx, sums);
-  tdtk_scan_destroy(sc);
-  if (rc) return rc;
+  if (rc) { tdtk_scan_destroy(sc); return rc; }
   sums->n_queries = n;
+  if (want_pairs && n && sums->n) {
+    // the PtPair(s, t, normal) list of searchTree.cc:147-180 in query order, built on the device:
+    // found flags (caller order) -> prefix sum -> one kernel writes the compact lists
+    Ctx* c;
+    if ((rc = get_ctx(t->device, &c))) { tdtk_scan_destroy(sc); return rc; }
+    hipStream_t s = c->stream;
+    const size_t np = sums->n;
+    const size_t tmpb = scan_u32_temp_bytes(n + 1);
+    if ((rc = c->ws[WS_CELL].ensure(2 * (n + 1) * sizeof(uint32_t))) || (rc = c->ws[WS_TMPB].ensure(tmpb + 256)) ||
+        (rc = c->ws[WS_TMPA].ensure(9 * np * sizeof(double)))) { tdtk_scan_destroy(sc); return rc; }
+    uint32_t* flags = c->ws[WS_CELL].as<uint32_t>();
+    uint32_t* slot = flags + (n + 1);
+    double* d_p1 = c->ws[WS_TMPA].as<double>();
+    double* d_p2 = d_p1 + 3 * np;
+    double* d_pn = d_p2 + 3 * np;
+    auto bail = [&](int code) { tdtk_scan_destroy(sc); return code; };
+    if (hipMemsetAsync(flags + n, 0, sizeof(uint32_t), s) != hipSuccess) return bail(TDTK_EDEVICE);
+    if (launch_found_flags(c->ws[WS_KPOS].as<int>(), sc->d_order, n, flags, s) != hipSuccess) return bail(TDTK_EDEVICE);
+    if (launch_scan_u32(flags, slot, n + 1, c->ws[WS_TMPB].p, tmpb, s) != hipSuccess) return bail(TDTK_EDEVICE);
+    PairListArgs pa{};
+    pa.T = t->dev;
+    pa.x = sc->x; pa.y = sc->y; pa.z = sc->z;
+    const bool use_n = sc->nx && (pmode != 0 || (want & TDTK_WANT_NAPX));
+    pa.nx = use_n ? sc->nx : nullptr; pa.ny = use_n ? sc->ny : nullptr; pa.nz = use_n ? sc->nz : nullptr;
+    pa.kpos = c->ws[WS_KPOS].as<int>();
+    pa.order = sc->d_order; pa.slot = slot; pa.n = n;
+    std::memcpy(pa.A.m, A, sizeof pa.A.m);
+    m4inv(A, pa.inv.m);
+    pa.p1 = p1_out ? d_p1 : nullptr; pa.p2 = p2_out ? d_p2 : nullptr; pa.pn = pn_out ? d_pn : nullptr;
+    if (pn_out && !use_n && hipMemsetAsync(d_pn, 0, 3 * np * sizeof(double), s) != hipSuccess) return bail(TDTK_EDEVICE);
+    if (use_n || !pn_out) { /* kernel writes pn when normals take part */ }
+    else pa.pn = nullptr;
+    if (launch_pair_list(pa, pmode, s) != hipSuccess) return bail(TDTK_EDEVICE);
+    bool ok = true;
+    if (p1_out) ok &= hipMemcpyAsync(p1_out, d_p1, 3 * np * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (p2_out) ok &= hipMemcpyAsync(p2_out, d_p2, 3 * np * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (pn_out) ok &= hipMemcpyAsync(pn_out, d_pn, 3 * np * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok &= hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) { set_error("pair list copy failed"); return bail(TDTK_EDEVICE); }
+  }
+  tdtk_scan_destroy(sc);
   if (rnd > 1 && idx_out)
     for (size_t i = 0; i < n; i++) idx_out[kept_pos[i]] = idx[i];
-  if (want_pairs) {
-    // the PtPair(s, t, normal) list of searchTree.cc:179-180, in query order (host, optional)
-    double inv[16];
-    m4inv(A, inv);
-    size_t k = 0;
-    for (size_t i = 0; i < n; i++) {
-      if (idx[i] < 0) continue;
-      const double* cpt = t->xyz_h.data() + 3 * (size_t)idx[i];
-      const double* tt = q_xyz + 3 * i;
-      double s[3], nn[3] = {0, 0, 0};
-      s[0] = cpt[0] * A[0] + cpt[1] * A[4] + cpt[2] * A[8] + A[12];
-      s[1] = cpt[0] * A[1] + cpt[1] * A[5] + cpt[2] * A[9] + A[13];
-      s[2] = cpt[0] * A[2] + cpt[1] * A[6] + cpt[2] * A[10] + A[14];
-      if (q_nrm && (pmode != 0 || (want & TDTK_WANT_NAPX))) {
-        const double* nr = q_nrm + 3 * i;
-        const double len = std::sqrt(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
-        nn[0] = nr[0] / len; nn[1] = nr[1] / len; nn[2] = nr[2] / len;
-        if (pmode == 1) {
-          const double x = nn[0] * inv[0] + nn[1] * inv[1] + nn[2] * inv[2];
-          const double y = nn[0] * inv[4] + nn[1] * inv[5] + nn[2] * inv[6];
-          const double z = nn[0] * inv[8] + nn[1] * inv[9] + nn[2] * inv[10];
-          nn[0] = x; nn[1] = y; nn[2] = z;
-        }
-        if (pmode == 2) {
-          const double e[3] = {s[0] - tt[0], s[1] - tt[1], s[2] - tt[2]};
-          const double dot = nn[0] * e[0] + nn[1] * e[1] + nn[2] * e[2];
-          s[0] = nn[0] * dot + tt[0]; s[1] = nn[1] * dot + tt[1]; s[2] = nn[2] * dot + tt[2];
-        }
-      }
-      if (p1_out) { p1_out[3 * k] = s[0]; p1_out[3 * k + 1] = s[1]; p1_out[3 * k + 2] = s[2]; }
-      if (p2_out) { p2_out[3 * k] = tt[0]; p2_out[3 * k + 1] = tt[1]; p2_out[3 * k + 2] = tt[2]; }
-      if (pn_out) { pn_out[3 * k] = nn[0]; pn_out[3 * k + 1] = nn[1]; pn_out[3 * k + 2] = nn[2]; }
-      k++;
-    }
-  }
   return TDTK_OK;
 }
 
@@ -855,12 +858,20 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
   Ctx* c;
   int rc = get_ctx(t->device, &c);
   if (rc) return rc;
+  // recover the caller's array from the resident points (each carries its caller index)
+  std::vector<KdPoint> pts(t->M);
+  HIPCHK(hipMemcpy(pts.data(), t->d_pts, pts.size() * sizeof(KdPoint), hipMemcpyDeviceToHost));
+  std::vector<double> xyz(3 * t->M);
+  for (size_t k = 0; k < t->M; k++) {
+    const size_t o = (size_t)pts[k].orig;
+    if (o >= t->M) { mismatches[0] = mismatches[1] = mismatches[2] = 0; mismatches[3] = 1; return TDTK_OK; }
+    xyz[3 * o] = pts[k].x; xyz[3 * o + 1] = pts[k].y; xyz[3 * o + 2] = pts[k].z;
+  }
   HostTree H;
   std::string err;
-  if (!build_tree(t->xyz_h.data(), t->M, t->bucket, H, err)) { set_error(err); return TDTK_EINVAL; }
+  if (!build_tree(xyz.data(), t->M, t->bucket, H, err)) { set_error(err); return TDTK_EINVAL; }
   std::vector<KdNode> nodes(H.nodes.size());
   std::vector<double> rr(H.nodes.size());
-  std::vector<KdPoint> pts(t->M);
   mismatches[0] = mismatches[1] = mismatches[2] = mismatches[3] = 0;
   if (H.n_internal != t->info.n_internal || H.n_leaves != t->info.n_leaves || H.max_depth != t->info.max_depth ||
       H.max_leaf_points != t->info.max_leaf_points || H.root_ref != t->dev.root_ref || (uint32_t)H.cb != t->dev.cb ||
@@ -871,7 +882,6 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
       HIPCHK(hipMemcpy(nodes.data(), t->d_nodes, nodes.size() * sizeof(KdNode), hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(rr.data(), t->d_r, rr.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
-    HIPCHK(hipMemcpy(pts.data(), t->d_pts, pts.size() * sizeof(KdPoint), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < nodes.size(); i++) {
       const KdNode &a = nodes[i], &b = H.nodes[i];
       // == on doubles: +0 and -0 compare equal (the sign of a zero box centre never decides anything)

@@ -77,6 +77,17 @@ struct BinArgs {
   int32_t* order;  // sorted position -> original index
 };
 
+struct PairListArgs {
+  TreeDev T;
+  const double *x, *y, *z, *nx, *ny, *nz;  // resident (sorted) scan; normals nullable
+  const int* kpos;
+  const int32_t* order;    // sorted position -> caller index
+  const uint32_t* slot;    // exclusive scan of the found flags, caller order
+  size_t n;
+  Mat4 A, inv;
+  double *p1, *p2, *pn;    // [pairs][3], nullable
+};
+
 uint32_t search_grid(size_t n);
 int search_lds_depth();
 int search_block();
@@ -107,6 +118,11 @@ struct DevBuildResult {
 };
 // level-synchronous construction of the reference's kd-tree on the device (build.hip)
 DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, hipStream_t s);
+
+hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s);
+hipError_t launch_pair_list(const PairListArgs& a, int pmode, hipStream_t s);
+size_t scan_u32_temp_bytes(size_t n);
+hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* tmp, size_t tmp_bytes, hipStream_t s);
 
 size_t morton_sort_temp_bytes(size_t n);
 hipError_t launch_morton_order(const double* d_xyz, size_t n, const double lo[3], const double sc[3],

@@ -1001,7 +1001,48 @@ __global__ void k_scatter_idx(const int* __restrict__ kpos, const double* __rest
   }
 }
 
-// compact pair list in caller order is produced on the host from idx (cheap, optional path)
+// ---- compact PtPair list (searchTree.cc:147-180) in the caller's query order ----------------------
+// found flags in caller order -> exclusive scan (rocPRIM, sort.hip) -> this kernel writes
+// p1 = transform3(dalignxf, closest) [projected onto the data point's plane in mode 2],
+// p2 = data point, pn = the normal the reference stores in the pair.
+__global__ void k_found_flags(const int* __restrict__ kpos, const int32_t* __restrict__ order, size_t n,
+                              uint32_t* __restrict__ flags)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+    flags[order[j]] = (kpos[j] >= 0) ? 1u : 0u;
+}
+
+template <int PMODE>
+__global__ void k_pair_list(const PairListArgs a)
+{
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(a.T.pts);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += stride) {
+    const int k = a.kpos[j];
+    if (k < 0) continue;
+    const size_t slot = a.slot[a.order[j]];
+    const double tx = a.x[j], ty = a.y[j], tz = a.z[j];
+    const double4 c = pts[k];
+    double mx, my, mz;
+    dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);
+    double nxv = 0, nyv = 0, nzv = 0;
+    if (a.nx) {
+      nxv = a.nx[j]; nyv = a.ny[j]; nzv = a.nz[j];
+      const double len = __dsqrt_rn(nxv * nxv + nyv * nyv + nzv * nzv);
+      nxv /= len; nyv /= len; nzv /= len;
+      if (PMODE == 1) dev_xf3normal(a.inv, nxv, nyv, nzv);
+    }
+    if (PMODE == 2) {
+      const double ex = mx - tx, ey = my - ty, ez = mz - tz;
+      const double dot = nxv * ex + nyv * ey + nzv * ez;
+      mx = nxv * dot + tx; my = nyv * dot + ty; mz = nzv * dot + tz;
+    }
+    if (a.p1) { a.p1[3 * slot] = mx; a.p1[3 * slot + 1] = my; a.p1[3 * slot + 2] = mz; }
+    if (a.p2) { a.p2[3 * slot] = tx; a.p2[3 * slot + 1] = ty; a.p2[3 * slot + 2] = tz; }
+    if (a.pn) { a.pn[3 * slot] = nxv; a.pn[3 * slot + 1] = nyv; a.pn[3 * slot + 2] = nzv; }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // launchers
@@ -1161,6 +1202,27 @@ hipError_t launch_split_soa(const double* q, size_t n, double* x, double* y, dou
   size_t cap = (size_t)num_cu() * 8;
   if (nb > cap) nb = cap;
   hipLaunchKernelGGL(k_split_soa, dim3((uint32_t)nb), dim3(256), 0, s, q, n, x, y, z);
+  return hipGetLastError();
+}
+
+hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_found_flags, dim3((uint32_t)nb), dim3(256), 0, s, kpos, order, n, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_pair_list(const PairListArgs& a, int pmode, hipStream_t s)
+{
+  if (!a.n) return hipSuccess;
+  size_t nb = (a.n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  dim3 g((uint32_t)nb), b(256);
+  if (pmode == 1) hipLaunchKernelGGL(k_pair_list<1>, g, b, 0, s, a);
+  else if (pmode == 2) hipLaunchKernelGGL(k_pair_list<2>, g, b, 0, s, a);
+  else hipLaunchKernelGGL(k_pair_list<0>, g, b, 0, s, a);
   return hipGetLastError();
 }
 

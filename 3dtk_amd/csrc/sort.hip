@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "kernels.h"
 
@@ -48,6 +49,19 @@ __global__ void k_gather_soa(const double* __restrict__ src, const uint32_t* __r
     const size_t i = order[j];
     x[j] = src[3 * i]; y[j] = src[3 * i + 1]; z[j] = src[3 * i + 2];
   }
+}
+
+size_t scan_u32_temp_bytes(size_t n)
+{
+  size_t tmp = 0;
+  uint32_t* p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, tmp, p, p, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  return tmp;
+}
+hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* tmp, size_t tmp_bytes, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
 }
 
 size_t morton_sort_temp_bytes(size_t n)
