@@ -62,7 +62,7 @@ struct DevBuf {
 };
 
 enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
-       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_COUNT };
+       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_COUNT };
 
 struct Ctx {
   int device = -1;
@@ -637,6 +637,63 @@ int tdtk_last_kernel_ms(double* nn_ms)
   return collect_ms(c, nn_ms);
 }
 
+// ---- octree reduction ("-r <voxelSize>", centre mode) -----------------------------------
+// Scan::calcReducedPoints (scan.cc:577-603) with reduction_nrpts == 0: BOctTree(xyz, n, voxelSize)
+// then GetOctTreeCenter.  See reduce.hip.
+int tdtk_reduce_octree(const double* xyz, size_t n, double voxel_size, int device, double* out_xyz, size_t* n_out)
+{
+  if (!n_out) { set_error("n_out is NULL"); return TDTK_EINVAL; }
+  *n_out = 0;
+  if (n == 0) return TDTK_OK;   // an empty root has no occupied child (Boctree.h:1268-1300)
+  if (!xyz || !out_xyz) { set_error("NULL points"); return TDTK_EINVAL; }
+  if (!(voxel_size > 0)) { set_error("voxel size must be > 0"); return TDTK_EINVAL; }
+  if (n >= (1ull << 32) - 1) { set_error("scan too large"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const size_t sort_tmp = oct_sort_temp_bytes(n), scan_tmp = scan_u32_temp_bytes(n + 1);
+  const size_t tmpb = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+  if ((rc = c->ws[WS_TMPA].ensure(6 * n * sizeof(double)))) return rc;          // points in | centres out
+  if ((rc = c->ws[WS_QX].ensure(2 * n * sizeof(uint64_t)))) return rc;          // keys a|b
+  if ((rc = c->ws[WS_CELL].ensure(2 * (n + 1) * sizeof(uint32_t)))) return rc;  // flags | slots
+  if ((rc = c->ws[WS_TMPB].ensure(tmpb + 256))) return rc;
+  if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
+  double* d_in = c->ws[WS_TMPA].as<double>();
+  double* d_out = d_in + 3 * n;
+  double* d_box = c->ws[WS_BOX].as<double>();
+  uint64_t* keys_a = c->ws[WS_QX].as<uint64_t>();
+  uint64_t* keys_b = keys_a + n;
+  uint32_t* flags = c->ws[WS_CELL].as<uint32_t>();
+  uint32_t* slot = flags + (n + 1);
+  HIPCHK(hipMemcpyAsync(d_in, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(launch_bbox(d_in, n, d_box + 8, d_box, s));
+  HIPCHK(hipMemcpyAsync(c->h_pin, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const double* b = c->h_pin;
+  // root cube, Boctree.h:248-255
+  OctRoot R;
+  for (int a = 0; a < 3; a++) R.center[a] = 0.5 * (b[a] + b[3 + a]);
+  R.size = std::max(std::max(0.5 * (b[3] - b[0]), 0.5 * (b[4] - b[1])), 0.5 * (b[5] - b[2]));
+  R.size += 1.0;
+  if (!std::isfinite(R.size)) { set_error("non-finite coordinates"); return TDTK_EINVAL; }
+  // the root's children exist unconditionally (:257-268); a child is a leaf once its size <= voxelSize (:1166)
+  R.depth = 1;
+  for (double sz = R.size / 2.0; sz > voxel_size; sz /= 2.0) R.depth++;
+  if (3 * R.depth > 63) { set_error("voxel size too small for this extent (more than 21 octree levels)"); return TDTK_EINVAL; }
+  HIPCHK(launch_oct_keys_sorted(d_in, n, R, keys_a, keys_b, c->ws[WS_TMPB].p, sort_tmp, s));
+  HIPCHK(launch_oct_heads(keys_b, n, flags, s));
+  HIPCHK(launch_scan_u32(flags, slot, n + 1, c->ws[WS_TMPB].p, scan_tmp, s));
+  HIPCHK(launch_oct_centres(keys_b, flags, slot, n, R, d_out, s));
+  uint32_t cells = 0;
+  HIPCHK(hipMemcpyAsync(&cells, slot + n, sizeof cells, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemcpyAsync(out_xyz, d_out, 3 * (size_t)cells * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n_out = cells;
+  return TDTK_OK;
+}
+
 // ---- resident scan ---------------------------------------------------------------------
 int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device, tdtk_scan** out)
 {
@@ -651,24 +708,13 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
   sc->device = device; sc->N = N;
   if (N == 0) { *out = sc.release(); return TDTK_OK; }
   hipStream_t s = c->stream;
-  // bounding box on the host (one streaming pass), everything else on the device
-  double lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
-  for (size_t i = 1; i < N; i++)
-    for (int a = 0; a < 3; a++) {
-      const double v = xyz[3 * i + a];
-      if (v < lo[a]) lo[a] = v;
-      if (v > hi[a]) hi[a] = v;
-    }
-  double scl[3];
-  for (int a = 0; a < 3; a++) {
-    const double ext = hi[a] - lo[a];
-    scl[a] = (ext > 0 && std::isfinite(ext)) ? 1023.999 / ext : 0.0;
-  }
   const size_t tmp_bytes = morton_sort_temp_bytes(N);
   if ((rc = c->ws[WS_TMPA].ensure(3 * N * sizeof(double)))) return rc;        // AoS staging
   if ((rc = c->ws[WS_CELL].ensure(2 * N * sizeof(uint32_t)))) return rc;      // keys a|b
   if ((rc = c->ws[WS_ORDER].ensure(N * sizeof(uint32_t)))) return rc;         // idx a
   if ((rc = c->ws[WS_TMPB].ensure(tmp_bytes + 256))) return rc;
+  if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
+  double* d_box = c->ws[WS_BOX].as<double>();
   double* d_aos = c->ws[WS_TMPA].as<double>();
   uint32_t* keys_a = c->ws[WS_CELL].as<uint32_t>();
   uint32_t* keys_b = keys_a + N;
@@ -678,7 +724,8 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
   HIPCHK(hipMalloc((void**)&sc->y, N * sizeof(double)));
   HIPCHK(hipMalloc((void**)&sc->z, N * sizeof(double)));
   HIPCHK(hipMemcpyAsync(d_aos, xyz, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(launch_morton_order(d_aos, N, lo, scl, keys_a, idx_a, keys_b, reinterpret_cast<uint32_t*>(sc->d_order),
+  HIPCHK(launch_bbox(d_aos, N, d_box + 8, d_box, s));
+  HIPCHK(launch_morton_order(d_aos, N, d_box, keys_a, idx_a, keys_b, reinterpret_cast<uint32_t*>(sc->d_order),
                              c->ws[WS_TMPB].p, tmp_bytes, s));
   HIPCHK(launch_gather_soa(d_aos, reinterpret_cast<const uint32_t*>(sc->d_order), N, sc->x, sc->y, sc->z, s));
   if (nrm) {

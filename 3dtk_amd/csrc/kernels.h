@@ -125,9 +125,22 @@ size_t scan_u32_temp_bytes(size_t n);
 hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* tmp, size_t tmp_bytes, hipStream_t s);
 
 size_t morton_sort_temp_bytes(size_t n);
-hipError_t launch_morton_order(const double* d_xyz, size_t n, const double lo[3], const double sc[3],
-                               uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
+hipError_t launch_morton_order(const double* d_xyz, size_t n, const double* d_box, uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
                                size_t tmp_bytes, hipStream_t s);
+// reduce.hip: bounding box + octree-centre reduction
+struct OctRoot {
+  double center[3];
+  double size;   // half edge of the root cube (largest half extent + 1.0)
+  int depth;     // halvings until size <= voxelSize (>= 1)
+};
+size_t bbox_temp_bytes();
+hipError_t launch_bbox(const double* d_xyz, size_t n, double* d_partial, double* d_box, hipStream_t s);
+size_t oct_sort_temp_bytes(size_t n);
+hipError_t launch_oct_keys_sorted(const double* d_xyz, size_t n, const OctRoot& R, uint64_t* keys_a,
+                                  uint64_t* keys_b, void* tmp, size_t tmp_bytes, hipStream_t s);
+hipError_t launch_oct_heads(const uint64_t* keys, size_t n, uint32_t* flags, hipStream_t s);
+hipError_t launch_oct_centres(const uint64_t* keys, const uint32_t* flags, const uint32_t* slot, size_t n,
+                              const OctRoot& R, double* out, hipStream_t s);
 hipError_t launch_gather_soa(const double* d_src, const uint32_t* order, size_t n, double* x, double* y, double* z,
                              hipStream_t s);
 

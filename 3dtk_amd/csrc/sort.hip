@@ -23,10 +23,15 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
   return v;
 }
 
-__global__ void k_morton_keys(const double* __restrict__ xyz, size_t n, double lx, double ly, double lz,
-                              double sx, double sy, double sz, uint32_t* __restrict__ keys,
-                              uint32_t* __restrict__ idx)
+// box = device-resident (min xyz, max xyz) from launch_bbox
+__global__ void k_morton_keys(const double* __restrict__ xyz, size_t n, const double* __restrict__ box,
+                              uint32_t* __restrict__ keys, uint32_t* __restrict__ idx)
 {
+  const double lx = box[0], ly = box[1], lz = box[2];
+  const double ex = box[3] - lx, ey = box[4] - ly, ez = box[5] - lz;
+  const double sx = (ex > 0 && isfinite(ex)) ? 1023.999 / ex : 0.0;
+  const double sy = (ey > 0 && isfinite(ey)) ? 1023.999 / ey : 0.0;
+  const double sz = (ez > 0 && isfinite(ez)) ? 1023.999 / ez : 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double f0 = (xyz[3 * i] - lx) * sx, f1 = (xyz[3 * i + 1] - ly) * sy, f2 = (xyz[3 * i + 2] - lz) * sz;
@@ -73,15 +78,13 @@ size_t morton_sort_temp_bytes(size_t n)
 }
 
 // keys_a/idx_a are filled, sorted into keys_b/idx_b
-hipError_t launch_morton_order(const double* d_xyz, size_t n, const double lo[3], const double sc[3],
-                               uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
+hipError_t launch_morton_order(const double* d_xyz, size_t n, const double* d_box, uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
                                size_t tmp_bytes, hipStream_t s)
 {
   if (!n) return hipSuccess;
   size_t nb = (n + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_morton_keys, dim3((uint32_t)nb), dim3(256), 0, s, d_xyz, n, lo[0], lo[1], lo[2], sc[0],
-                     sc[1], sc[2], keys_a, idx_a);
+  hipLaunchKernelGGL(k_morton_keys, dim3((uint32_t)nb), dim3(256), 0, s, d_xyz, n, d_box, keys_a, idx_a);
   hipError_t e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, idx_a, idx_b, n, 0, 30, s);
   if (e != hipSuccess) return e;
   return hipGetLastError();

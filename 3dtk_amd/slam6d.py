@@ -363,6 +363,18 @@ def read_uos(path, range_max=0.0, range_min=0.0):
     return out
 
 
+def calcReducedPoints(xyz, voxelSize, device=0):
+    """Scan::calcReducedPoints, centre mode (scan.cc:577-603): octree reduction `-r voxelSize` on the
+    device (tdtk_reduce_octree).  voxelSize <= 0 keeps every point, as scan.cc:497-558 does."""
+    xyz = f64(xyz).reshape(-1, 3)
+    if voxelSize <= 0 or len(xyz) == 0:
+        return xyz.copy()
+    out = np.empty_like(xyz)
+    m = C.c_size_t(0)
+    check(lib().tdtk_reduce_octree(dptr(xyz), len(xyz), float(voxelSize), int(device), dptr(out), C.byref(m)))
+    return out[:m.value].copy()
+
+
 def read_pose(path):
     rP = np.empty(3); rT = np.empty(3)
     check(lib().tdtk_io_read_pose(str(path).encode(), dptr(rP), dptr(rT)))
@@ -372,9 +384,9 @@ def read_pose(path):
 ALGO_TYPE = {"INVALID": 0, "ICP": 1, "ICPINACTIVE": 2, "LUM": 3, "ELCH": 4}   # scan.h:126
 
 
-def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSize=20, device=0):
+def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSize=20, device=0, red=-1.0):
     """Scan::openDirectory for the uos format (src/slam6d/scan.cc / basicScan.cc:39-122):
-    scanNNN.3d + scanNNN.pose, NNN = start..end."""
+    scanNNN.3d + scanNNN.pose, NNN = start..end; red = -r voxel size (setReductionParameter)."""
     import os
     scans = []
     i = start
@@ -384,7 +396,10 @@ def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSiz
         if not (os.path.exists(f3d) and os.path.exists(fpose)):
             break
         rP, rT = read_pose(fpose)
-        s = Scan(rP, rT, read_uos(f3d, range_max, range_min), bucketSize=bucketSize, device=device)
+        pts = read_uos(f3d, range_max, range_min)
+        if red > 0:
+            pts = calcReducedPoints(pts, red, device)
+        s = Scan(rP, rT, pts, bucketSize=bucketSize, device=device)
         s.identifier = "%03d" % i
         s.path = path
         scans.append(s)

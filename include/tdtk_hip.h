@@ -224,6 +224,14 @@ int tdtk_solve_chol_upper(const double* G, const double* B, int n, double* x);
 /* dense inverse (newmat `.i()`), row-major n x n */
 int tdtk_invert(const double* A, int n, double* Ainv);
 
+/* ---- octree reduction, "-r <voxelSize>" with the default centre mode: replaces
+ * Scan::calcReducedPoints (src/slam6d/scan.cc:577-603, reduction_nrpts == 0) = BOctTree<double>(pts,
+ * n, voxelSize) (include/slam6d/Boctree.h:222-270) + GetOctTreeCenter (:928-948).  out_xyz has room
+ * for n points; *n_out = number of occupied leaf cells; centres come out in the reference's
+ * depth-first child order (that order feeds the kd-tree build, so it matters).               */
+int tdtk_reduce_octree(const double* xyz, size_t n, double voxel_size, int device, double* out_xyz,
+                       size_t* n_out);
+
 /* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
  * traversal counters of the last counting run.                                          */
 int tdtk_last_kernel_ms(double* nn_ms);

@@ -493,3 +493,91 @@ uint64_t orc_k5_hash(const int32_t *idx, size_t n)
   }
   return h;
 }
+
+/* ---- octree reduction, centre mode ("-r <voxelSize>") -------------------------------------
+ * PARITY UNPINNED: include/slam6d/Boctree.h needs boost/interprocess/offset_ptr.hpp, which this
+ * image does not have, so the reference octree cannot be compiled into oracle/_ref and the
+ * reference holds no golden vector for it.  This is a restatement by reading:
+ *   BOctTree(P* const* pts, int n, T voxelSize)   Boctree.h:222-270  (root cube: bbox centre,
+ *       half size = largest half extent + 1.0; the root is always split)
+ *   countPointsAndQueueFast / branch              Boctree.h:1163-1195, 1268-1300 (occupied octants in
+ *       index order; a child is a leaf once its half size <= voxelSize)
+ *   childIndex                                    Boctree.h:1353-1355 (strict >)
+ *   childcenter                                   Boctree.h:612-657  (centre -/+ size/2.0)
+ *   GetOctTreeCenter                              Boctree.h:928-948  (DFS, child index order, emits the
+ *       leaf cell's centre)
+ * as used by Scan::calcReducedPoints, src/slam6d/scan.cc:577-603 (reduction_nrpts == 0).
+ * Recursive with explicit index lists, i.e. structured like the reference, unlike the sort-based
+ * device path it checks. */
+typedef struct {
+  const double *xyz;
+  double voxel;
+  double *out;
+  size_t n_out;
+} oct_ctx;
+
+static void oct_childcenter(const double *pc, double *cc, double size, int i)
+{
+  cc[0] = (i & 1) ? pc[0] + size / 2.0 : pc[0] - size / 2.0;
+  cc[1] = (i & 2) ? pc[1] + size / 2.0 : pc[1] - size / 2.0;
+  cc[2] = (i & 4) ? pc[2] + size / 2.0 : pc[2] - size / 2.0;
+}
+
+/* split the points of one cell (centre c, half size `size`) over its octants */
+static void oct_split(oct_ctx *C, uint32_t *idx, size_t n, const double *c, double size)
+{
+  size_t cnt[8] = {0}, off[9];
+  unsigned char *ci = (unsigned char *)malloc(n ? n : 1);
+  for (size_t k = 0; k < n; k++) {
+    const double *p = C->xyz + 3 * (size_t)idx[k];
+    ci[k] = (unsigned char)((p[0] > c[0]) | ((p[1] > c[1]) << 1) | ((p[2] > c[2]) << 2));
+    cnt[ci[k]]++;
+  }
+  off[0] = 0;
+  for (int j = 0; j < 8; j++) off[j + 1] = off[j] + cnt[j];
+  uint32_t *tmp = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  size_t pos[8];
+  for (int j = 0; j < 8; j++) pos[j] = off[j];
+  for (size_t k = 0; k < n; k++) tmp[pos[ci[k]]++] = idx[k];
+  memcpy(idx, tmp, n * sizeof(uint32_t));
+  free(tmp);
+  free(ci);
+  const double size_new = size / 2.0;
+  for (int j = 0; j < 8; j++) {
+    if (!cnt[j]) continue;
+    double cc[3];
+    oct_childcenter(c, cc, size, j);
+    if (size_new <= C->voxel) {                 /* branch(): leaf */
+      double *o = C->out + 3 * C->n_out++;
+      o[0] = cc[0]; o[1] = cc[1]; o[2] = cc[2];
+    } else {
+      oct_split(C, idx + off[j], cnt[j], cc, size_new);
+    }
+  }
+}
+
+/* out has room for n points; returns the number of leaf cells */
+size_t orc_octree_center(const double *xyz, size_t n, double voxel, double *out)
+{
+  if (n == 0) return 0;
+  double mins[3], maxs[3], center[3];
+  for (int a = 0; a < 3; a++) {
+    mins[a] = maxs[a] = xyz[a];
+    for (size_t j = 1; j < n; j++) {
+      const double v = xyz[3 * j + a];
+      mins[a] = v < mins[a] ? v : mins[a];
+      maxs[a] = maxs[a] < v ? v : maxs[a];
+    }
+    center[a] = 0.5 * (mins[a] + maxs[a]);
+  }
+  double size = 0.5 * (maxs[0] - mins[0]);
+  if (size < 0.5 * (maxs[1] - mins[1])) size = 0.5 * (maxs[1] - mins[1]);
+  if (size < 0.5 * (maxs[2] - mins[2])) size = 0.5 * (maxs[2] - mins[2]);
+  size += 1.0;
+  uint32_t *idx = (uint32_t *)malloc(n * sizeof(uint32_t));
+  for (size_t k = 0; k < n; k++) idx[k] = (uint32_t)k;
+  oct_ctx C = {xyz, voxel, out, 0};
+  oct_split(&C, idx, n, center, size);
+  free(idx);
+  return C.n_out;
+}

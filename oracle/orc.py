@@ -66,6 +66,8 @@ def lib():
         L.orc_transform_normals.argtypes = [_dp, _dp, C.c_size_t]
         L.orc_max_threads.restype = C.c_int
         L.orc_gen_mt64_uniform.argtypes = [C.c_uint64, C.c_size_t, C.c_double, C.c_double, _dp]
+        L.orc_octree_center.restype = C.c_size_t
+        L.orc_octree_center.argtypes = [_dp, C.c_size_t, C.c_double, _dp]
         L.orc_k5_hash.restype = C.c_uint64
         L.orc_k5_hash.argtypes = [_ip, C.c_size_t]
         _lib = L
@@ -242,3 +244,11 @@ def gen_mt64_uniform(seed, n, lo, hi):
 def k5_hash(idx):
     idx = np.ascontiguousarray(idx, np.int32)
     return int(lib().orc_k5_hash(_i(idx), len(idx)))
+
+
+def octree_center(xyz, voxel):
+    """Octree-centre reduction (parity unpinned, see oracle.c); returns [cells, 3] in DFS order."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    m = lib().orc_octree_center(_d(xyz), len(xyz), float(voxel), _d(out))
+    return out[:m].copy()

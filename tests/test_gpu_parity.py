@@ -552,3 +552,69 @@ def test_tree_edge_cases(tdtk, orc, gpu):
     e = tdtk.Scan([0, 0, 0], [0, 0, 0], np.zeros((0, 3)))
     r = tdtk.Scan.getPtPairs(m, e, max_dist_match2=1.0)
     assert r["n"] == 0 and r["n_queries"] == 0
+
+
+# ---- octree reduction (-r), centre mode ------------------------------------------------------
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "tiny", "grid", "line"])
+@pytest.mark.parametrize("voxel", [0.5, 10.0, 1e6])
+def test_octree_reduction_equals_oracle(tdtk, orc, gpu, name, voxel):
+    """tdtk_reduce_octree (key sort on the device) == the recursive restatement of
+    BOctTree + GetOctTreeCenter: same cells, same centres bit for bit, same depth-first order."""
+    pts = _clouds()[name]
+    got = tdtk.calcReducedPoints(pts, voxel)
+    want = orc.octree_center(pts, voxel)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_octree_reduction_dat_and_icp(tdtk, orc, gpu):
+    """-r 10 on the bundled scans, then the pairwise ICP of scan001 onto scan000 on the reduced clouds
+    against the numpy restatement run on the oracle's reduced clouds."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    S, O = [], []
+    for k in range(2):
+        pose, pts = z["pose%03d" % k], z["scan%03d" % k]
+        got = tdtk.calcReducedPoints(pts, 10.0)
+        want = orc.octree_center(pts, 10.0)
+        assert np.array_equal(got, want) and 0 < len(got) < len(pts)
+        S.append(tdtk.Scan(pose[:3], pose[3:], got))
+        O.append(io.OScan(pose[:3], pose[3:], want))
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 30, quiet=True, epsilonICP=1e-5)
+    it = icp.match(S[0], S[1])
+    oit, otr = io.match(O[0], O[1], 1, 625.0, 30, 1e-5)
+    assert it == oit
+    assert np.allclose(S[1].transMat, O[1].transMat, rtol=1e-9, atol=1e-9)
+
+
+def test_octree_reduction_full_size_properties(tdtk, orc, gpu, k5):
+    """1M points, voxel 25: equals the oracle; every input point lies in exactly the emitted cell its
+    own descent names (checked through the cell containing it), cells are unique and sorted DFS."""
+    _, m, _ = k5
+    got = tdtk.calcReducedPoints(m, 25.0)
+    want = orc.octree_center(m, 25.0)
+    assert np.array_equal(got, want)
+    assert len(np.unique(got, axis=0)) == len(got)
+    # leaf half size: root = 1000-ish + 1, halved until <= 25
+    lo, hi = m.min(0), m.max(0)
+    size = (0.5 * (hi - lo)).max() + 1.0
+    while size > 25.0:
+        size /= 2.0
+    kd = tdtk.KDtree(got, 20)
+    idx, d2 = kd.FindClosestBatch(m[:200000], 1e18)
+    assert np.all(np.abs(m[:200000] - got[idx]).max(1) <= size)
+    # idempotent at the same voxel only in cell count terms: reducing the centres keeps one per cell
+    again = tdtk.calcReducedPoints(got, 25.0)
+    assert len(again) <= len(got)
+
+
+def test_octree_reduction_edge_cases(tdtk, orc, gpu):
+    one = np.array([[3.0, -2.0, 7.5]])
+    assert np.array_equal(tdtk.calcReducedPoints(one, 10.0), orc.octree_center(one, 10.0))
+    same = np.tile([[5.0, 5.0, 5.0]], (1000, 1))
+    g = tdtk.calcReducedPoints(same, 0.1)
+    assert len(g) == 1 and np.array_equal(g, orc.octree_center(same, 0.1))
+    assert len(tdtk.calcReducedPoints(np.zeros((0, 3)), 10.0)) == 0
+    assert len(tdtk.calcReducedPoints(same, -1.0)) == 1000            # no reduction requested
+    far = np.array([[0.0, 0.0, 0.0], [1e9, 1e9, 1e9]])
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calcReducedPoints(far, 1e-3)                             # > 21 levels

@@ -335,3 +335,33 @@ def test_scan_io_uos_pose_frames(tdtk, tmp_path):
     assert lines[0] == "1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1 1"
     assert lines[1] == "1 0 0 0 0 1 0 0 0 0 1 0 1234.57 -0.000123457 1e-07 1 3"
     assert lines[2].endswith(" 0") and lines[3] == ""
+
+
+def test_oracle_octree_center_against_grid_formulation(orc):
+    """The recursive octree restatement (oracle.c, parity unpinned: Boctree.h is not buildable here)
+    checked against an independent closed-form formulation: occupied cells of the regular 2^D grid over
+    the root cube, ordered by their (x lowest) Morton code = depth-first child order."""
+    rng = np.random.default_rng(11)
+    one = np.array([[4.0, -2.0, 8.0]])   # a point on the split planes goes to the lower child (strict >)
+    assert np.array_equal(orc.octree_center(one, 5.0), one - 0.5)
+    for n, voxel in ((2000, 3.0), (50000, 10.0), (3000, 1e6)):
+        pts = rng.uniform(-300, 500, (n, 3)) * np.array([1.0, 0.5, 0.1])
+        got = orc.octree_center(pts, voxel)
+        lo, hi = pts.min(0), pts.max(0)
+        c = 0.5 * (lo + hi)
+        size = (0.5 * (hi - lo)).max() + 1.0
+        D, s = 1, size / 2.0
+        while s > voxel:
+            s /= 2.0; D += 1
+        cell = np.floor((pts - (c - size)) / (2.0 * size / 2 ** D)).astype(np.int64)
+        assert cell.min() >= 0 and cell.max() < 2 ** D
+        code = np.zeros(n, np.int64)
+        for b in range(D):
+            for a in range(3):
+                code |= ((cell[:, a] >> b) & 1) << (3 * b + a)
+        ucode, first = np.unique(code, return_index=True)
+        ucell = cell[first]
+        want = (c - size) + (2 * ucell + 1) * (size / 2 ** D)
+        assert got.shape == want.shape
+        assert np.allclose(got, want, rtol=0, atol=1e-9 * size)
+    assert len(orc.octree_center(np.zeros((0, 3)), 1.0)) == 0
