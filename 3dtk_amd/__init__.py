@@ -17,4 +17,5 @@ from ._capi import (TdtkError, lib, build_extension, device_count, version, Pair
 from .slam6d import (KDtree, Scan, icp6Dminimizer, icp6D_QUAT, icp6D_SVD, icp6D_APX,  # noqa: F401
                      icp6D_NAPX, icp6D, Graph, lum6DEuler, gapx6D, M4inv, MMult, M4identity,
                      EulerToMatrix4, Matrix4ToEuler, host_tree_layout, MetaScan, read_uos, read_pose,
-                     openDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints)
+                     openDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints,
+                     computeGraph6Dautomatic, matchGraph6Dautomatic_clpairs)

@@ -683,6 +683,58 @@ class gapx6D:
         return ret
 
 
+def computeGraph6Dautomatic(allScans, clpairs, max_dist_match2_LUM=625.0, group=None, device=None):
+    """graphSlam6D::computeGraph6Dautomatic / the graph step of matchGraph6Dautomatic(allScans, nrIt,
+    clpairs, loopsize) (src/slam6d/graphSlam6D.cc:82-133, 136-180): a link (j, k) for every ordered pair
+    j != k whose closest-point pairing within max_dist_match2_LUM has more than clpairs pairs.  The
+    n(n-1) pairings are independent: they go through the batched link entry point, sharded over
+    ranks like the LUM links; links are added in the serial build's (j-major) order."""
+    from .graphslam import _dist_ready
+    n = len(allScans)
+    cand = [(j, k) for j in range(n) for k in range(n) if j != k]
+    rank, world = 0, 1
+    if group is not None or _dist_ready():
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = [i for i, (j, k) in enumerate(cand) if (j + k) % world == rank]
+    counts = np.zeros(len(cand))
+    if mine:
+        nl = len(mine)
+        first = (C.c_void_p * nl)(*[allScans[cand[i][0]].getSearchTree()._h for i in mine])
+        second = (C.c_void_p * nl)(*[allScans[cand[i][1]].handle for i in mine])
+        dal = np.ascontiguousarray(np.stack([allScans[cand[i][0]].dalignxf for i in mine]))
+        sums = (PairSums * nl)()
+        check(lib().tdtk_links_pair_sums(nl, first, dptr(dal), second, float(max_dist_match2_LUM), 0, sums))
+        for q, i in enumerate(mine):
+            counts[i] = sums[q].n
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(counts)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        counts = t.cpu().numpy()
+    gr = Graph(0, links=[cand[i] for i in range(len(cand)) if counts[i] > clpairs])
+    gr.nrScans = n
+    gr.pair_counts = {cand[i]: int(counts[i]) for i in range(len(cand))}
+    return gr
+
+
+def matchGraph6Dautomatic_clpairs(my_graphSlam6D, allScans, nrIt, clpairs, loopsize=0):
+    """graphSlam6D::matchGraph6Dautomatic(allScans, nrIt, clpairs, loopsize) (graphSlam6D.cc:82-133):
+    rebuild the clpairs graph and run one global iteration until the pose change is <= 0.001 or nrIt
+    rounds.  Returns the number of rounds."""
+    i = 0
+    while True:
+        i += 1
+        gr = computeGraph6Dautomatic(allScans, clpairs, my_graphSlam6D.max_dist_match2_LUM,
+                                     getattr(my_graphSlam6D, "group", None))
+        ret = my_graphSlam6D.doGraphSlam6D(gr, allScans, 1)
+        if not (ret > 0.001 and i < nrIt):
+            return i
+
+
 def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_graphSlam6D, nrIt, epsilonSLAM,
                           mdml, eP=True, max_num_metascans=-1):
     """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) without loop closing (my_loopSlam6D == NULL)

@@ -360,6 +360,22 @@ def graph_links(scans, cldist2=None, loopsize=None):
     return links
 
 
+def graph_links_clpairs(scans, clpairs, maxdist2):
+    """the graph step of graphSlam6D::matchGraph6Dautomatic(allScans, nrIt, clpairs, loopsize)
+    (graphSlam6D.cc:82-133), serial order: link (j, k), j != k, when more than clpairs pairs.
+    -> (links, {(j, k): pair count})"""
+    links, counts = [], {}
+    for j in range(len(scans)):
+        for k in range(len(scans)):
+            if j == k:
+                continue
+            m = get_pt_pairs(scans[j], scans[k], maxdist2)["n"]
+            counts[(j, k)] = m
+            if m > clpairs:
+                links.append((j, k))
+    return links, counts
+
+
 def covariance_euler(first, second, maxdist2):
     """lum6DEuler::covarianceEuler (lum6Deuler.cc:94-251) -> (C, CD, m, ss, D)"""
     r = get_pt_pairs(first, second, maxdist2)

@@ -618,3 +618,29 @@ def test_octree_reduction_edge_cases(tdtk, orc, gpu):
     far = np.array([[0.0, 0.0, 0.0], [1e9, 1e9, 1e9]])
     with pytest.raises(tdtk.TdtkError):
         tdtk.calcReducedPoints(far, 1e-3)                             # > 21 levels
+
+
+def test_clpairs_graph_and_lum_round(tdtk, orc, gpu):
+    """graphSlam6D::matchGraph6Dautomatic(allScans, nrIt, clpairs, loopsize): the all-ordered-pairs graph
+    (pair counts exact) and one LUM iteration over it -- links in both directions and links that end at
+    the fixed scan 0 -- against the numpy restatement."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    S, O = _dat_scans(tdtk.Scan, z), _dat_scans(io.OScan, z)
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1]); O[i].mergeCoordinatesWithRoboterPosition(O[i - 1])
+        for a in pr["alignxf"]:
+            S[i].transform(np.array(a)); O[i].transform(np.array(a))
+    links, counts = io.graph_links_clpairs(O, 30000, 625.0)
+    gr = tdtk.computeGraph6Dautomatic(S, 30000, 625.0)
+    assert gr.pair_counts == counts
+    assert list(zip(gr.frm, gr.to)) == links and 0 < len(links) < 6
+    gr_all = tdtk.computeGraph6Dautomatic(S, 100, 625.0)
+    assert gr_all.getNrLinks() == 6
+    ret = tdtk.lum6DEuler(None, 25.0, 25.0).doGraphSlam6D(gr_all, S, 1)
+    oret = io.lum_iteration(list(zip(gr_all.frm, gr_all.to)), O, 625.0)[0]
+    assert abs(ret - oret) < 1e-7 * max(1.0, oret)
+    for s, o in zip(S, O):
+        assert np.abs(s.get_rPos() - o.rPos).max() < 1e-7 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-9
