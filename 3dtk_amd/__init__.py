@@ -13,8 +13,10 @@ The directory name starts with a digit, so import it with
 from ._capi import (TdtkError, lib, build_extension, device_count, version, PairSums,  # noqa: F401
                     ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX, CLOSEST_POINT,
                     CLOSEST_POINT_ALONG_NORMAL_SIMPLE, CLOSEST_PLANE_SIMPLE,
-                    WANT_APX, WANT_NAPX, WANT_LUM, WANT_GAPX)
+                    WANT_APX, WANT_NAPX, WANT_LUM, WANT_GAPX, WANT_MOM2,
+                    ALGO_ORTHO, ALGO_DUAL, ALGO_HELIX, ALGO_LUMEULER, ALGO_LUMQUAT, ALGO_QUAT_SCALE)
 from .slam6d import (KDtree, Scan, icp6Dminimizer, icp6D_QUAT, icp6D_SVD, icp6D_APX,  # noqa: F401
+                     icp6D_ORTHO, icp6D_DUAL, icp6D_HELIX, icp6D_LUMEULER, icp6D_LUMQUAT, icp6D_QUAT_SCALE,
                      icp6D_NAPX, icp6D, Graph, lum6DEuler, gapx6D, M4inv, MMult, M4identity,
                      EulerToMatrix4, Matrix4ToEuler, host_tree_layout, MetaScan, read_uos, read_pose,
                      openDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints,

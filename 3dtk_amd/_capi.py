@@ -9,8 +9,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "lib3dtk_hip.so")
 
 ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX = 1, 2, 6, 10
+ALGO_ORTHO, ALGO_DUAL, ALGO_HELIX, ALGO_LUMEULER, ALGO_LUMQUAT, ALGO_QUAT_SCALE = 3, 4, 5, 7, 8, 9
 CLOSEST_POINT, CLOSEST_POINT_ALONG_NORMAL_SIMPLE, CLOSEST_PLANE_SIMPLE = 0, 1, 2
-WANT_APX, WANT_NAPX, WANT_LUM, WANT_GAPX = 1, 2, 4, 8
+WANT_APX, WANT_NAPX, WANT_LUM, WANT_GAPX, WANT_MOM2 = 1, 2, 4, 8, 16
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -30,7 +31,8 @@ class PairSums(C.Structure):
                 ("napx_A", C.c_double * 21), ("napx_B", C.c_double * 6), ("napx_sum", C.c_double),
                 ("lum", C.c_double * 15), ("lum_sumd2", C.c_double),
                 ("gapx_MkMkt", C.c_double * 9), ("gapx_DkDkt", C.c_double * 9), ("gapx_MkDkt", C.c_double * 9),
-                ("gapx_DkMkt", C.c_double * 9), ("gapx_Ak1", C.c_double * 3), ("gapx_Ak2", C.c_double * 3)]
+                ("gapx_DkMkt", C.c_double * 9), ("gapx_Ak1", C.c_double * 3), ("gapx_Ak2", C.c_double * 3),
+                ("mom_mm", C.c_double * 6), ("mom_dd", C.c_double * 6)]
 
 
 class TreeInfo(C.Structure):

@@ -365,6 +365,17 @@ static void finish_sums(const double* acc, const double shift[3], size_t nq, uns
   }
   if (want & TDTK_WANT_LUM)
     for (int k = 0; k < 15; k++) o->lum[k] = acc[ACC_L + k];
+  if (want & TDTK_WANT_MOM2) {
+    // second moments about the respective centroids
+    const double* mm = acc + ACC_MM;
+    const double* dd = acc + ACC_DD;
+    int q = 0;
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++, q++) {
+        o->mom_mm[q] = mm[q] - Sm[a] * Sm[b] / n;
+        o->mom_dd[q] = dd[q] - Sd[a] * Sd[b] / n;
+      }
+  }
   if (want & TDTK_WANT_GAPX) {
     // a = p1 - cm, b = p2 - cm (BOTH about centroid_m, gapx6D.cc:185-191); w = cm - shift = Sm/n
     double MM[3][3], DD[3][3], Saa[3][3], Sbb[3][3], Sab[3][3], Sb[3];
@@ -1003,8 +1014,14 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
     return TDTK_EINVAL;
   }
   const int algo = prm->algo;
-  if (algo != TDTK_ALGO_QUAT && algo != TDTK_ALGO_SVD && algo != TDTK_ALGO_APX && algo != TDTK_ALGO_NAPX) {
-    set_error("This parallel minimization algorithm is not implemented !!!");  // icp6D.cc:215-218
+  if (algo < TDTK_ALGO_QUAT || algo > TDTK_ALGO_NAPX) {
+    set_error("This minimization algorithm is not implemented");
+    return TDTK_EINVAL;
+  }
+  const bool serial_only = algo == TDTK_ALGO_ORTHO || algo == TDTK_ALGO_DUAL || algo == TDTK_ALGO_HELIX ||
+                           algo == TDTK_ALGO_LUMEULER || algo == TDTK_ALGO_LUMQUAT || algo == TDTK_ALGO_QUAT_SCALE;
+  if ((algo == TDTK_ALGO_LUMEULER || algo == TDTK_ALGO_LUMQUAT) && !data_transMat) {
+    set_error("LUMEULER / LUMQUAT need the current scan's transMat");
     return TDTK_EINVAL;
   }
   const int pmode = prm->pairing_mode;
@@ -1015,7 +1032,8 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   std::memset(res, 0, sizeof *res);
   if (prm->max_num_iterations == 0 || data->N == 0) return TDTK_OK;  // icp6D.cc:112-114
 
-  const unsigned want = (algo == TDTK_ALGO_APX) ? TDTK_WANT_APX : (algo == TDTK_ALGO_NAPX ? TDTK_WANT_NAPX : 0u);
+  const unsigned want = (algo == TDTK_ALGO_APX) ? TDTK_WANT_APX
+                        : (algo == TDTK_ALGO_NAPX ? TDTK_WANT_NAPX : (serial_only ? TDTK_WANT_MOM2 : 0u));
   double ret = 0.0, prev_ret = 0.0, prev_prev_ret = 0.0;
   double alignxf[16], pend[16];
   bool have_pending = false;
@@ -1041,6 +1059,8 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
     if (sums.n > 3) {  // icp6D.cc:235-243 (serial branch semantics)
       std::string err;
       double rms = 0;
+      // getAlgorithmID() 3 / 8: alignxf enters as CurrentScan->get_transMat() (icp6D.cc:237-241)
+      if (data_transMat) std::memcpy(alignxf, data_transMat, sizeof alignxf);
       rc = align_from_sums(algo, sums, alignxf, &rms, err);
       if (rc == TDTK_ESOLVE) {
         // the reference prints and keeps going with ret = -1 and the unchanged alignxf buffer
@@ -1052,7 +1072,8 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
       break;
     }
     if (!prm->quiet) {
-      static const char* tag[] = {"", "QUAT", "SVD", "", "", "", "APX", "", "", "", "APX"};
+      static const char* tag[] = {"", "QUAT", "SVD", "ORTHO", "DUALQUAT", "HELIX", "APX", "LUMEULER", "LUMQUAT",
+                                  "QUAT SCALE", "APX"};
       std::printf("%s RMS point-to-%s error = %10.7f  using %6llu points\n", tag[algo],
                   algo == TDTK_ALGO_NAPX ? "plane" : "point", ret, (unsigned long long)sums.n);
     }

@@ -1053,7 +1053,7 @@ static int num_cu()
   if (!g_num_cu) {
     hipDeviceProp_t p;
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cu = p.multiProcessorCount;
     if (g_num_cu <= 0) g_num_cu = 256;
   }
@@ -1153,7 +1153,7 @@ static void launch_accum_w(const AccumArgs& a, uint32_t grid, int pmode, hipStre
 hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pmode, double* d_out,
                         hipStream_t s)
 {
-  if (want & TDTK_WANT_GAPX) {
+  if (want & (TDTK_WANT_GAPX | TDTK_WANT_MOM2)) {  // both are the MM + DD columns on top of the base block
     launch_accum_w<TDTK_WANT_GAPX>(a, grid, pmode, s);
   } else
   switch (want & 7u) {

@@ -338,11 +338,427 @@ static void apx_rotation(const double x[3], double R[3][3])
   R[2][0] = -cx * sy * cz + sx * sz; R[2][1] = cx * sy * sz + sx * cz; R[2][2] = cx * cy;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The serial-only minimizers (-a 3,4,5,7,8,9).  Each of them is a sum over the pairs of
+// products of two linear forms of w = (p1 ; p2), so all of them follow from the second-moment
+// matrix of w.  The device accumulates it in shifted form; here it is n, the two centroids, the
+// centred cross block Si and the centred diagonal blocks mom_mm / mom_dd (TDTK_WANT_MOM2).
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct Mom {
+  double n, mu[6], C[6][6];
+  explicit Mom(const tdtk_pair_sums& s)
+  {
+    n = (double)s.n;
+    for (int a = 0; a < 3; a++) { mu[a] = s.centroid_m[a]; mu[3 + a] = s.centroid_d[a]; }
+    int q = 0;
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++, q++) {
+        C[a][b] = C[b][a] = s.mom_mm[q];
+        C[3 + a][3 + b] = C[3 + b][3 + a] = s.mom_dd[q];
+      }
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) C[a][3 + b] = C[3 + b][a] = s.Si[a * 3 + b];
+  }
+  // sum over pairs of (a.w)
+  double lin(const double a[6]) const
+  {
+    double v = 0;
+    for (int i = 0; i < 6; i++) v += a[i] * mu[i];
+    return n * v;
+  }
+  // sum over pairs of (a.w)(b.w)
+  double quad(const double a[6], const double b[6]) const
+  {
+    double v = 0, am = 0, bm = 0;
+    for (int i = 0; i < 6; i++) {
+      double r = 0;
+      for (int j = 0; j < 6; j++) r += C[i][j] * b[j];
+      v += a[i] * r;
+      am += a[i] * mu[i];
+      bm += b[i] * mu[i];
+    }
+    return v + n * am * bm;
+  }
+};
+
+// solve the n x n system A x = b (what newmat's A.i() * b amounts to)
+bool solve_dense(int n, const double* A, const double* b, double* x)
+{
+  std::vector<double> inv((size_t)n * n);
+  if (!invert_dense(n, A, inv.data())) return false;
+  for (int i = 0; i < n; i++) {
+    double v = 0;
+    for (int j = 0; j < n; j++) v += inv[(size_t)i * n + j] * b[j];
+    x[i] = v;
+  }
+  return true;
+}
+
+void skew(const double v[3], double S[3][3])
+{
+  S[0][0] = 0;     S[0][1] = -v[2]; S[0][2] = v[1];
+  S[1][0] = v[2];  S[1][1] = 0;     S[1][2] = -v[0];
+  S[2][0] = -v[1]; S[2][1] = v[0];  S[2][2] = 0;
+}
+
+void rt_to_gl(const double R[3][3], const double t[3], double* xf)
+{
+  m4identity(xf);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) xf[c * 4 + r] = R[r][c];
+  for (int r = 0; r < 3; r++) xf[12 + r] = t[r];
+}
+
+// the row-major 4x4 pose matrix of icp6Dlumeuler.cc:144-156 / 184-196
+void euler_T(const double x[3], const double th[3], double T[16])
+{
+  const double cx = std::cos(th[0]), cy = std::cos(th[1]), cz = std::cos(th[2]);
+  const double sx = std::sin(th[0]), sy = std::sin(th[1]), sz = std::sin(th[2]);
+  for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  T[3] = x[0]; T[7] = x[1]; T[11] = x[2];
+  T[0] = cy * cz;                 T[1] = -cy * sz;                T[2] = sy;
+  T[4] = cz * sx * sy + cx * sz;  T[5] = cx * cz - sx * sy * sz;  T[6] = -cy * sx;
+  T[8] = sx * sz - cx * cz * sy;  T[9] = cz * sx + cx * sy * sz;  T[10] = cx * cy;
+}
+
+// (p*p - q.q) I + 2 q q^T + 2 p [q]x with translation x (icp6Dlumquat.cc:168-180, 190-203), row-major
+void quat_T(const double x[3], double p, const double q[3], double T[16])
+{
+  double Cq[3][3];
+  skew(q, Cq);
+  const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+  for (int i = 0; i < 16; i++) T[i] = 0.0;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) T[r * 4 + c] = (r == c ? (p * p - qq) : 0.0) + 2.0 * q[r] * q[c] + 2.0 * p * Cq[r][c];
+    T[r * 4 + 3] = x[r];
+  }
+  T[15] = 1.0;
+}
+
+// T_inc = T1 * T2^-1 (row-major 4x4) written out column-major
+bool tinc_to_gl(const double T1[16], const double T2[16], double* xf)
+{
+  double T2i[16], Ti[16];
+  if (!invert_dense(4, T2, T2i)) return false;
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      double v = 0;
+      for (int k = 0; k < 4; k++) v += T1[r * 4 + k] * T2i[k * 4 + c];
+      Ti[r * 4 + c] = v;
+    }
+  m4identity(xf);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) xf[c * 4 + r] = Ti[r * 4 + c];
+    xf[12 + r] = Ti[r * 4 + 3];
+  }
+  return true;
+}
+
+// Matrix4ToQuat, globals.icc:1032-1075
+void matrix4_to_quat(const double* mat, double quat[4], double t[3])
+{
+  double S, X, Y, Z, W;
+  const double T = 1 + mat[0] + mat[5] + mat[10];
+  if (T > 0.00000001) {
+    S = std::sqrt(T) * 2;
+    X = (mat[9] - mat[6]) / S; Y = (mat[2] - mat[8]) / S; Z = (mat[4] - mat[1]) / S; W = 0.25 * S;
+  } else if (mat[0] > mat[5] && mat[0] > mat[10]) {
+    S = std::sqrt(1.0 + mat[0] - mat[5] - mat[10]) * 2;
+    X = 0.25 * S; Y = (mat[4] + mat[1]) / S; Z = (mat[2] + mat[8]) / S; W = (mat[9] - mat[6]) / S;
+  } else if (mat[5] > mat[10]) {
+    S = std::sqrt(1.0 + mat[5] - mat[0] - mat[10]) * 2;
+    X = (mat[4] + mat[1]) / S; Y = 0.25 * S; Z = (mat[9] + mat[6]) / S; W = (mat[2] - mat[8]) / S;
+  } else {
+    S = std::sqrt(1.0 + mat[10] - mat[0] - mat[5]) * 2;
+    X = (mat[2] + mat[8]) / S; Y = (mat[9] + mat[6]) / S; Z = 0.25 * S; W = (mat[4] - mat[1]) / S;
+  }
+  quat[0] = W; quat[1] = -X; quat[2] = -Y; quat[3] = -Z;
+  const double l = std::sqrt(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+  for (int i = 0; i < 4; i++) quat[i] /= l;
+  t[0] = mat[12]; t[1] = mat[13]; t[2] = mat[14];
+}
+
+// unit basis forms: e(i) picks w_i; P1 = w[0..2], P2 = w[3..5]
+struct Form {
+  double a[6];
+  Form() { for (double& v : a) v = 0; }
+  static Form e(int i, double f = 1.0) { Form r; r.a[i] = f; return r; }
+  Form operator+(const Form& o) const { Form r; for (int i = 0; i < 6; i++) r.a[i] = a[i] + o.a[i]; return r; }
+  Form operator-(const Form& o) const { Form r; for (int i = 0; i < 6; i++) r.a[i] = a[i] - o.a[i]; return r; }
+  Form operator*(double f) const { Form r; for (int i = 0; i < 6; i++) r.a[i] = a[i] * f; return r; }
+};
+
+int align_serial_only(int algo, const tdtk_pair_sums& s, const double pose[16], double alignxf[16], std::string& err)
+{
+  const Mom M(s);
+  const double n = M.n;
+  const double* cm = s.centroid_m;
+  const double* cd = s.centroid_d;
+  auto Q = [&](const Form& a, const Form& b) { return M.quad(a.a, b.a); };
+  auto L = [&](const Form& a) { return M.lin(a.a); };
+  double R[3][3];
+
+  if (algo == TDTK_ALGO_ORTHO) {
+    // icp6Dortho.cc:86-121: H = sum m' d'^T, R = H (H^T H)^(-1/2)
+    double H[3][3], HH[3][3], V[3][3], w[3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) H[i][j] = s.Si[i * 3 + j];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) HH[i][j] = H[0][i] * H[0][j] + H[1][i] * H[1][j] + H[2][i] * H[2][j];
+    jacobi_eigen<3>(HH, V, w);
+    double P[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int k = 0; k < 3; k++) {
+      if (!(w[k] > 0)) { err = "ORTHO: singular correlation matrix"; return TDTK_ESOLVE; }
+      const double f = 1.0 / std::sqrt(w[k]);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) P[i][j] += V[i][k] * V[j][k] * f;
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[i][j] = H[i][0] * P[0][j] + H[i][1] * P[1][j] + H[i][2] * P[2][j];
+    compose(R, cm, cd, alignxf);
+    return TDTK_OK;
+  }
+
+  if (algo == TDTK_ALGO_DUAL) {
+    // icp6Ddual.cc:71-121.  X = sum m d^T (raw), cr = sum m x d
+    double X[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) X[i][j] = Q(Form::e(i), Form::e(3 + j));
+    const double tr = X[0][0] + X[1][1] + X[2][2];
+    const double cr[3] = {X[1][2] - X[2][1], X[2][0] - X[0][2], X[0][1] - X[1][0]};
+    double C1[4][4] = {}, C2[4][4] = {};
+    C1[0][0] = tr;
+    for (int i = 0; i < 3; i++) {
+      C1[0][1 + i] = -cr[i];
+      C1[1 + i][0] = -cr[i];
+      for (int j = 0; j < 3; j++) C1[1 + i][1 + j] = X[i][j] + X[j][i] - (i == j ? tr : 0.0);
+    }
+    double sm[3], sd[3], smd[3];
+    for (int i = 0; i < 3; i++) { sm[i] = n * cm[i]; sd[i] = n * cd[i]; smd[i] = sm[i] + sd[i]; }
+    double Sk[3][3];
+    skew(smd, Sk);
+    for (int i = 0; i < 3; i++) {
+      C2[0][1 + i] = sm[i] - sd[i];
+      C2[1 + i][0] = sd[i] - sm[i];
+      for (int j = 0; j < 3; j++) C2[1 + i][1 + j] = -Sk[i][j];
+    }
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) { C1[i][j] *= -2.0; C2[i][j] *= 2.0; }
+    double A[4][4], V[4][4], w[4];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double v = 0;
+        for (int k = 0; k < 4; k++) v += C2[k][i] * C2[k][j];
+        A[i][j] = (v * 1.0 / (2.0 * n) - C1[i][j] - C1[j][i]) * 0.5;
+      }
+    jacobi_eigen<4>(A, V, w);
+    int best = 0;   // SVD(A): first column of U = the direction of the largest singular value
+    for (int k = 1; k < 4; k++)
+      if (std::fabs(w[k]) > std::fabs(w[best])) best = k;
+    const double qd[4] = {V[0][best], V[1][best], V[2][best], V[3][best]};
+    const double q[3] = {qd[1], qd[2], qd[3]};
+    double Cq[3][3];
+    skew(q, Cq);
+    double sv[4];
+    for (int i = 0; i < 4; i++) {
+      double v = 0;
+      for (int k = 0; k < 4; k++) v += C2[i][k] * qd[k];
+      sv[i] = v * (-1.0) / (2.0 * n);
+    }
+    double Qm[4][4];
+    Qm[0][0] = qd[0];
+    for (int i = 0; i < 3; i++) {
+      Qm[0][1 + i] = q[i];
+      Qm[1 + i][0] = -q[i];
+      for (int j = 0; j < 3; j++) Qm[1 + i][1 + j] = (i == j ? qd[0] : 0.0) + Cq[i][j];
+    }
+    double t[3];
+    for (int i = 0; i < 3; i++) t[i] = Qm[1 + i][0] * sv[0] + Qm[1 + i][1] * sv[1] + Qm[1 + i][2] * sv[2] + Qm[1 + i][3] * sv[3];
+    const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[i][j] = (i == j ? (qd[0] * qd[0] - qq) : 0.0) + q[i] * q[j] * 2.0 + Cq[i][j] * qd[0] * 2.0;
+    rt_to_gl(R, t, alignxf);
+    return TDTK_OK;
+  }
+
+  if (algo == TDTK_ALGO_HELIX) {
+    // icp6Dhelix.cc:69-141
+    const Form x2 = Form::e(3), y2 = Form::e(4), z2 = Form::e(5);
+    const Form dX = Form::e(3) - Form::e(0), dY = Form::e(4) - Form::e(1), dZ = Form::e(5) - Form::e(2);
+    double B[36] = {};
+    auto set = [&](int r, int c, double v) { B[r * 6 + c] = B[c * 6 + r] = v; };
+    set(3, 3, n); set(4, 4, n); set(5, 5, n);
+    set(0, 4, -L(z2)); set(1, 3, L(z2));
+    set(0, 5, L(y2));  set(2, 3, -L(y2));
+    set(2, 4, L(x2));  set(1, 5, -L(x2));
+    set(0, 1, -Q(y2, x2)); set(0, 2, -Q(z2, x2)); set(1, 2, -Q(z2, y2));
+    set(0, 0, Q(z2, z2) + Q(y2, y2)); set(1, 1, Q(z2, z2) + Q(x2, x2)); set(2, 2, Q(x2, x2) + Q(y2, y2));
+    const double bd[6] = {-Q(z2, dY) + Q(y2, dZ), Q(z2, dX) - Q(x2, dZ), -Q(y2, dX) + Q(x2, dY), L(dX), L(dY), L(dZ)};
+    double ccs[6];
+    if (!solve_dense(6, B, bd, ccs)) { err = "HELIX: singular system"; return TDTK_ESOLVE; }
+    // computeRt, icp6Dhelix.cc:144-206
+    const double c[3] = {-ccs[0], -ccs[1], -ccs[2]}, cs[3] = {-ccs[3], -ccs[4], -ccs[5]};
+    const double CLength = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const double rotationCheck = c[0] * cs[0] + c[1] * cs[1] + c[2] * cs[2];
+    const double angle = std::atan(CLength);
+    const double g[3] = {c[0] / CLength, c[1] / CLength, c[2] / CLength};
+    const double sinAngle = std::sin(-angle / 2);
+    const double b0 = std::cos(-angle / 2), b1 = g[0] * sinAngle, b2 = g[1] * sinAngle, b3 = g[2] * sinAngle;
+    R[0][0] = b0 * b0 + b1 * b1 - b2 * b2 - b3 * b3; R[0][1] = 2 * (b1 * b2 + b0 * b3); R[0][2] = 2 * (b1 * b3 - b0 * b2);
+    R[1][0] = 2 * (b1 * b2 - b0 * b3); R[1][1] = b0 * b0 - b1 * b1 + b2 * b2 - b3 * b3; R[1][2] = 2 * (b2 * b3 + b0 * b1);
+    R[2][0] = 2 * (b1 * b3 + b0 * b2); R[2][1] = 2 * (b2 * b3 - b0 * b1); R[2][2] = b0 * b0 - b1 * b1 - b2 * b2 + b3 * b3;
+    const double den = b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[i][j] /= den;
+    const double skewValue = rotationCheck / (CLength * CLength);
+    double gs[3];
+    for (int i = 0; i < 3; i++) gs[i] = (cs[i] - c[i] * skewValue) / CLength;
+    const double pT[3] = {g[1] * gs[2] - g[2] * gs[1], g[2] * gs[0] - g[0] * gs[2], g[0] * gs[1] - g[1] * gs[0]};
+    double t[3];
+    for (int i = 0; i < 3; i++)
+      t[i] = -(R[i][0] * pT[0] + R[i][1] * pT[1] + R[i][2] * pT[2]) + g[i] * (skewValue * angle) + pT[i];
+    rt_to_gl(R, t, alignxf);
+    return TDTK_OK;
+  }
+
+  if (algo == TDTK_ALGO_LUMEULER) {
+    // icp6Dlumeuler.cc:47-229
+    double rPos[3], rPosTheta[3];
+    matrix4_to_euler(pose, rPosTheta, rPos);
+    const Form x = (Form::e(0) + Form::e(3)) * 0.5, y = (Form::e(1) + Form::e(4)) * 0.5, z = (Form::e(2) + Form::e(5)) * 0.5;
+    const Form dx = Form::e(0) - Form::e(3), dy = Form::e(1) - Form::e(4), dz = Form::e(2) - Form::e(5);
+    const double MZ[6] = {L(dx), L(dy), L(dz), -Q(z, dy) + Q(y, dz), -Q(y, dx) + Q(x, dy), Q(z, dx) - Q(x, dz)};
+    double MM[36] = {};
+    auto set = [&](int r, int c, double v) { MM[r * 6 + c] = MM[c * 6 + r] = v; };
+    const double xx = Q(x, x), yy = Q(y, y), zz = Q(z, z);
+    set(0, 0, n); set(1, 1, n); set(2, 2, n);
+    set(3, 3, yy + zz); set(4, 4, xx + yy); set(5, 5, xx + zz);
+    set(0, 4, -L(y)); set(0, 5, L(z));
+    set(1, 3, -L(z)); set(1, 4, L(x));
+    set(2, 3, L(y));  set(2, 5, -L(x));
+    set(3, 4, -Q(x, z)); set(3, 5, -Q(x, y)); set(4, 5, -Q(y, z));
+    double Ehat[6];
+    if (!solve_dense(6, MM, MZ, Ehat)) { err = "LUMEULER: singular system"; return TDTK_ESOLVE; }
+    const double cosx = std::cos(rPosTheta[0]), cosy = std::cos(rPosTheta[1]);
+    const double sinx = std::sin(rPosTheta[0]), siny = std::sin(rPosTheta[1]);
+    const double tx = rPos[0], ty = rPos[1], tz = rPos[2];
+    double T1[16], T2[16];
+    euler_T(rPos, rPosTheta, T1);
+    double H[36];
+    for (int i = 0; i < 36; i++) H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    H[0 * 6 + 4] = -tz * cosx + ty * sinx; H[0 * 6 + 5] = ty * cosx * cosy + tz * cosy * sinx;
+    H[1 * 6 + 3] = tz; H[1 * 6 + 4] = -tx * sinx; H[1 * 6 + 5] = -tx * cosx * cosy + tz * siny;
+    H[2 * 6 + 3] = -ty; H[2 * 6 + 4] = tx * cosx; H[2 * 6 + 5] = -tx * cosy * sinx - ty * siny;
+    H[3 * 6 + 5] = siny; H[4 * 6 + 4] = sinx; H[4 * 6 + 5] = cosx * cosy; H[5 * 6 + 4] = cosx; H[5 * 6 + 5] = -cosy * sinx;
+    double HE[6];
+    if (!solve_dense(6, H, Ehat, HE)) { err = "LUMEULER: singular pose Jacobian"; return TDTK_ESOLVE; }
+    const double X[6] = {rPos[0] - HE[0], rPos[1] - HE[1], rPos[2] - HE[2],
+                         rPosTheta[0] - HE[3], rPosTheta[1] - HE[4], rPosTheta[2] - HE[5]};
+    euler_T(X, X + 3, T2);
+    if (!tinc_to_gl(T1, T2, alignxf)) { err = "LUMEULER: singular pose"; return TDTK_ESOLVE; }
+    return TDTK_OK;
+  }
+
+  if (algo == TDTK_ALGO_LUMQUAT) {
+    // icp6Dlumquat.cc:40-231; x is p1.x, not the midpoint (icp6Dlumquat.cc:90, sic)
+    double quat[4], t[3];
+    matrix4_to_quat(pose, quat, t);
+    const Form x = Form::e(0), y = (Form::e(1) + Form::e(4)) * 0.5, z = (Form::e(2) + Form::e(5)) * 0.5;
+    const Form dx = Form::e(0) - Form::e(3), dy = Form::e(1) - Form::e(4), dz = Form::e(2) - Form::e(5);
+    const double MZ[7] = {L(dx), L(dy), L(dz), Q(x, dx) + Q(y, dy) + Q(z, dz), Q(z, dy) - Q(y, dz),
+                          Q(x, dz) - Q(z, dx), Q(y, dx) - Q(x, dy)};
+    double MM[49] = {};
+    auto set = [&](int r, int c, double v) { MM[r * 7 + c] = MM[c * 7 + r] = v; };
+    const double xx = Q(x, x), yy = Q(y, y), zz = Q(z, z), sx = L(x), sy = L(y), sz = L(z);
+    set(0, 0, n); set(1, 1, n); set(2, 2, n);
+    set(3, 3, xx + yy + zz); set(4, 4, yy + zz); set(5, 5, xx + zz); set(6, 6, xx + yy);
+    set(0, 3, sx); set(0, 5, -sz); set(0, 6, sy);
+    set(1, 3, sy); set(1, 4, sz);  set(1, 6, -sx);
+    set(2, 3, sz); set(2, 4, -sy); set(2, 5, sx);
+    set(4, 5, -Q(x, y)); set(4, 6, -Q(x, z)); set(5, 6, -Q(y, z));
+    double Ehat[7];
+    if (!solve_dense(7, MM, MZ, Ehat)) { err = "LUMQUAT: singular system"; return TDTK_ESOLVE; }
+    const double p = quat[0], q = quat[1], r = quat[2], sq = quat[3];
+    const double X0 = t[0], Y0 = t[1], Z0 = t[2];
+    const double U[4][4] = {{p, q, r, sq}, {q, -p, sq, -r}, {r, -sq, -p, q}, {sq, r, -q, -p}};
+    const double T[3][4] = {
+        {p * X0 + sq * Y0 - r * Z0, q * X0 + r * Y0 + sq * Z0, r * X0 - q * Y0 + p * Z0, sq * X0 - p * Y0 - q * Z0},
+        {-sq * X0 + p * Y0 + q * Z0, -r * X0 + q * Y0 - p * Z0, q * X0 + r * Y0 + sq * Z0, p * X0 + sq * Y0 - r * Z0},
+        {r * X0 - q * Y0 + p * Z0, -sq * X0 + p * Y0 + q * Z0, -p * X0 - sq * Y0 + r * Z0, q * X0 + r * Y0 - sq * Z0}};
+    double H[49] = {};
+    for (int i = 0; i < 3; i++) {
+      H[i * 7 + i] = 1.0;
+      for (int j = 0; j < 4; j++) H[i * 7 + 3 + j] = T[i][j] * (-2.0);
+    }
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) H[(3 + i) * 7 + 3 + j] = U[i][j] * 2.0;
+    double HE[7];
+    if (!solve_dense(7, H, Ehat, HE)) { err = "LUMQUAT: singular pose Jacobian"; return TDTK_ESOLVE; }
+    const double Xhat[7] = {X0, Y0, Z0, p, q, r, sq};
+    double X[7];
+    for (int i = 0; i < 7; i++) X[i] = Xhat[i] - HE[i];
+    double T1[16], T2[16];
+    const double qv1[3] = {q, r, sq};
+    quat_T(t, p, qv1, T1);
+    quat_T(X, X[3], X + 4, T2);
+    if (!tinc_to_gl(T1, T2, alignxf)) { err = "LUMQUAT: singular pose"; return TDTK_ESOLVE; }
+    return TDTK_OK;
+  }
+
+  if (algo == TDTK_ALGO_QUAT_SCALE) {
+    // icp6Dquatscale.cc:37-161: Horn's quaternion + scale = sqrt(sum |m'|^2 / sum |d'|^2)
+    double S[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) S[i][j] = s.Si[j * 3 + i] / n;
+    const double tr = S[0][0] + S[1][1] + S[2][2];
+    double Qm[4][4], V[4][4], w[4];
+    Qm[0][0] = tr;
+    Qm[0][1] = Qm[1][0] = S[1][2] - S[2][1];
+    Qm[0][2] = Qm[2][0] = S[2][0] - S[0][2];
+    Qm[0][3] = Qm[3][0] = S[0][1] - S[1][0];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Qm[i + 1][j + 1] = S[i][j] + S[j][i] - (i == j ? tr : 0.0);
+    jacobi_eigen<4>(Qm, V, w);
+    int best = 0;
+    for (int k = 1; k < 4; k++)
+      if (w[k] > w[best]) best = k;
+    double q[4] = {V[0][best], V[1][best], V[2][best], V[3][best]};
+    const double len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (double& v : q) v /= len;
+    const double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+    R[0][0] = q00 + q11 - q22 - q33; R[1][1] = q00 - q11 + q22 - q33; R[2][2] = q00 - q11 - q22 + q33;
+    R[0][1] = 2.0 * (q[1] * q[2] - q[0] * q[3]); R[1][0] = 2.0 * (q[1] * q[2] + q[0] * q[3]);
+    R[0][2] = 2.0 * (q[1] * q[3] + q[0] * q[2]); R[2][0] = 2.0 * (q[1] * q[3] - q[0] * q[2]);
+    R[1][2] = 2.0 * (q[2] * q[3] - q[0] * q[1]); R[2][1] = 2.0 * (q[2] * q[3] + q[0] * q[1]);
+    const double smm = s.mom_mm[0] + s.mom_mm[3] + s.mom_mm[5], sdd = s.mom_dd[0] + s.mom_dd[3] + s.mom_dd[5];
+    if (!(sdd > 0)) { err = "QUAT_SCALE: degenerate data cloud"; return TDTK_ESOLVE; }
+    const double scale = std::sqrt(smm / sdd);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R[i][j] *= scale;
+    compose(R, cm, cd, alignxf);
+    return TDTK_OK;
+  }
+  err = "This minimization algorithm is not implemented";
+  return TDTK_EINVAL;
+}
+
+}  // namespace
+
 int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], double* rms, std::string& err)
 {
+  double pose[16];
+  std::memcpy(pose, alignxf, sizeof pose);   // LUMEULER / LUMQUAT: the current scan's transMat (icp6D.cc:237-241)
   m4identity(alignxf);
   if (s.n == 0) { err = "no point pairs"; if (rms) *rms = 0; return TDTK_ESOLVE; }
   const double n = (double)s.n;
+  if (algo == TDTK_ALGO_ORTHO || algo == TDTK_ALGO_DUAL || algo == TDTK_ALGO_HELIX || algo == TDTK_ALGO_LUMEULER ||
+      algo == TDTK_ALGO_LUMQUAT || algo == TDTK_ALGO_QUAT_SCALE) {
+    if (rms) *rms = std::sqrt(s.sum / n);
+    return align_serial_only(algo, s, pose, alignxf, err);
+  }
   const double* cm = s.centroid_m;
   const double* cd = s.centroid_d;
   double R[3][3];

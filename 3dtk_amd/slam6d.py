@@ -430,10 +430,13 @@ class icp6Dminimizer:
     def getAlgorithmID(self):
         return self.algo
 
-    def Align_Parallel(self, sums):
-        """Align_Parallel with the merged sums (slot 0 semantics).  Returns (rms, alignxf)."""
+    want = 0    # accumulator block the minimizer needs on top of the base sums
+
+    def Align_Parallel(self, sums, pose=None):
+        """Align_Parallel with the merged sums (slot 0 semantics).  Returns (rms, alignxf).
+        pose = the current scan's transMat, read by LUMEULER / LUMQUAT (icp6D.cc:237-241)."""
         raw = sums["_raw"] if isinstance(sums, dict) else sums
-        out = np.empty(16)
+        out = np.eye(4).reshape(16).copy() if pose is None else f64(pose).copy()
         rms = C.c_double(0.0)
         rc = lib().tdtk_align(int(self.algo), C.byref(raw), dptr(out), C.byref(rms))
         if rc == -4:       # "Couldn't find transform." -> the reference returns -1.0
@@ -452,10 +455,44 @@ class icp6D_SVD(icp6Dminimizer):    # src/slam6d/icp6Dsvd.cc, -a 2
 
 class icp6D_APX(icp6Dminimizer):    # src/slam6d/icp6Dapx.cc, -a 6
     algo = ALGO_APX
+    want = WANT_APX
 
 
 class icp6D_NAPX(icp6Dminimizer):   # src/slam6d/icp6Dnapx.cc, -a 10
     algo = ALGO_NAPX
+    want = WANT_NAPX
+
+
+# The minimizers the reference only has as serial Align.  getAlgorithmID() here is the -a value
+# (the reference's icp6D_LUMEULER answers 3, like ORTHO: include/slam6d/icp6Dlumeuler.h:33).
+class icp6D_ORTHO(icp6Dminimizer):       # src/slam6d/icp6Dortho.cc, -a 3
+    algo = capi.ALGO_ORTHO
+    want = capi.WANT_MOM2
+
+
+class icp6D_DUAL(icp6Dminimizer):        # src/slam6d/icp6Ddual.cc, -a 4
+    algo = capi.ALGO_DUAL
+    want = capi.WANT_MOM2
+
+
+class icp6D_HELIX(icp6Dminimizer):       # src/slam6d/icp6Dhelix.cc, -a 5
+    algo = capi.ALGO_HELIX
+    want = capi.WANT_MOM2
+
+
+class icp6D_LUMEULER(icp6Dminimizer):    # src/slam6d/icp6Dlumeuler.cc, -a 7
+    algo = capi.ALGO_LUMEULER
+    want = capi.WANT_MOM2
+
+
+class icp6D_LUMQUAT(icp6Dminimizer):     # src/slam6d/icp6Dlumquat.cc, -a 8
+    algo = capi.ALGO_LUMQUAT
+    want = capi.WANT_MOM2
+
+
+class icp6D_QUAT_SCALE(icp6Dminimizer):  # src/slam6d/icp6Dquatscale.cc, -a 9
+    algo = capi.ALGO_QUAT_SCALE
+    want = capi.WANT_MOM2
 
 
 # ---------------------------------------------------------------------------------------
@@ -515,7 +552,7 @@ class icp6D:
         CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))
         tree = PreviousScan.getSearchTree()
         algo = self.my_icp6Dminimizer.getAlgorithmID()
-        want = WANT_APX if algo == ALGO_APX else (WANT_NAPX if algo == ALGO_NAPX else 0)
+        want = self.my_icp6Dminimizer.want
         ret = prev_ret = prev_prev_ret = 0.0
         trace = []
         it = 0
@@ -525,7 +562,7 @@ class icp6D:
                                 self.max_dist_match2, pairing_mode, want, None, want_pairs=False)
             self.nr_pointPair = r["n"]
             if r["n"] > 3:
-                ret, alignxf = self.my_icp6Dminimizer.Align_Parallel(r)
+                ret, alignxf = self.my_icp6Dminimizer.Align_Parallel(r, CurrentScan.transMat)
             else:
                 break
             trace.append(np.concatenate([[r["n"], ret], alignxf]))

@@ -9,8 +9,18 @@
 #define __ICP6D_HIP_H__
 
 #include "slam6d/icp6D.h"
+#include "slam6d/icp6Dlumeuler.h"
 #include "slam6d/hip_search_tree.h"
 #include "tdtk_hip.h"
+
+// the -a id tdtk_icp_match expects.  getAlgorithmID() is not unique in the reference (icp6D_LUMEULER
+// answers 3 like icp6D_ORTHO, include/slam6d/icp6Dlumeuler.h:33), so the class decides.
+static inline int hip_algo_id(icp6Dminimizer* m)
+{
+  if (dynamic_cast<icp6D_LUMEULER*>(m)) return TDTK_ALGO_LUMEULER;
+  const int id = m->getAlgorithmID();      // 1 QUAT 2 SVD 3 ORTHO 4 DUAL 5 HELIX 6 APX 8 LUMQUAT 9 QUAT_SCALE 10 NAPX
+  return (id >= 1 && id <= 10 && id != 7) ? id : 0;
+}
 
 class icp6D_hip : public icp6D {
 public:
@@ -21,8 +31,8 @@ public:
     // the model tree lives in the scan (Scan::getSearchTree, scan.cc:268); it is a HipSearchTree
     // when the scan was configured with nns_type HipKD
     HipSearchTree* hst = dynamic_cast<HipSearchTree*>(PreviousScan->getSearchTree());
-    const int algo = my_icp6Dminimizer->getAlgorithmID();
-    if (!hst || rnd > 1 || !(algo == 1 || algo == 2 || algo == 6 || algo == 10))
+    const int algo = hip_algo_id(my_icp6Dminimizer);
+    if (!hst || rnd > 1 || algo == 0)
       return icp6D::match(PreviousScan, CurrentScan, pairing_mode);     // CPU path of the reference
 
     double id[16];

@@ -43,9 +43,15 @@ enum {
   TDTK_CLOSEST_PLANE_SIMPLE = 2
 };
 
-/* minimizer ids == icp6Dminimizer::getAlgorithmID() / the -a values that reach
- * them (src/slam6d/slam6D.cc:696-727)                                          */
-enum { TDTK_ALGO_QUAT = 1, TDTK_ALGO_SVD = 2, TDTK_ALGO_APX = 6, TDTK_ALGO_NAPX = 10 };
+/* minimizer ids == the -a values of src/slam6d/slam6D.cc:696-727.  QUAT / SVD / APX / NAPX are the ones
+ * an OpenMP build of the reference can run (Align_Parallel, icp6D.cc:201-219); the other six exist only
+ * as serial Align (icp6Dortho.cc, icp6Ddual.cc, icp6Dhelix.cc, icp6Dlumeuler.cc, icp6Dlumquat.cc,
+ * icp6Dquatscale.cc) and are computed here from the second-moment block TDTK_WANT_MOM2.      */
+enum {
+  TDTK_ALGO_QUAT = 1, TDTK_ALGO_SVD = 2, TDTK_ALGO_ORTHO = 3, TDTK_ALGO_DUAL = 4, TDTK_ALGO_HELIX = 5,
+  TDTK_ALGO_APX = 6, TDTK_ALGO_LUMEULER = 7, TDTK_ALGO_LUMQUAT = 8, TDTK_ALGO_QUAT_SCALE = 9,
+  TDTK_ALGO_NAPX = 10
+};
 
 /* which accumulator blocks tdtk_scan_pairs / tdtk_get_pt_pairs should fill */
 #define TDTK_WANT_BASE 0u  /* n, sum, centroids, Si: always                              */
@@ -53,6 +59,9 @@ enum { TDTK_ALGO_QUAT = 1, TDTK_ALGO_SVD = 2, TDTK_ALGO_APX = 6, TDTK_ALGO_NAPX 
 #define TDTK_WANT_NAPX 2u  /* A[21], B[6], sum of icp6D_NAPX (icp6Dnapx.cc:53-95)        */
 #define TDTK_WANT_LUM 4u   /* the 15 sums + ss of lum6DEuler::covarianceEuler            */
 #define TDTK_WANT_GAPX 8u  /* the per-link blocks of gapx6D::genBArotForLinkedPair (alone) */
+#define TDTK_WANT_MOM2 16u /* centred second moments of p1 and of p2 (alone): with n, centroids and
+                            * Si they are the full second-moment matrix of (p1 ; p2), from which
+                            * every minimizer that is quadratic in the pairs follows            */
 
 /* Merged per-call sums: what T OpenMP threads' (n, sum, centroid_m, centroid_d, Si)
  * of src/slam6d/icp6D.cc:129-192 add up to; feed slot 0 of Align_Parallel with it. */
@@ -74,6 +83,8 @@ typedef struct tdtk_pair_sums {
    * centroid_m, including the literal `p1x*p2x + p1y + p2y` diagonal terms (gapx6D.cc:208-210) */
   double gapx_MkMkt[9], gapx_DkDkt[9], gapx_MkDkt[9], gapx_DkMkt[9];   /* row-major 3x3 */
   double gapx_Ak1[3], gapx_Ak2[3];
+  double mom_mm[6];      /* sum (p1-cm)(p1-cm)^T: xx xy xz yy yz zz        [TDTK_WANT_MOM2]   */
+  double mom_dd[6];      /* sum (p2-cd)(p2-cd)^T                                              */
 } tdtk_pair_sums;
 
 typedef struct tdtk_tree_info {
@@ -169,8 +180,11 @@ int tdtk_scan_pairs(const tdtk_tree* model, const double source_alignxf[16], tdt
 
 /* ---- minimizers: icp6Dminimizer::Align_Parallel with the merged sums in slot 0
  * (icp6Dquat.cc:515-634, icp6Dsvd.cc:170-280, icp6Dapx.cc:136-307, icp6Dnapx.cc:34-149),
- * serial-Align semantics (S normalised by 1/n; SVD reflection fix).  Returns the RMS the
- * reference returns (`ret`) through *rms.                                               */
+ * serial-Align semantics (S normalised by 1/n; SVD reflection fix), and the serial-only
+ * ORTHO / DUAL / HELIX / LUMEULER / LUMQUAT / QUAT_SCALE from sums filled with TDTK_WANT_MOM2.
+ * alignxf is in/out: LUMEULER and LUMQUAT read the current scan's transMat from it
+ * (icp6D.cc:237-241); the others ignore the input.  Returns the RMS the reference returns
+ * (`ret`) through *rms.                                                                  */
 int tdtk_align(int algo, const tdtk_pair_sums* sums, double alignxf[16], double* rms);
 
 /* ---- icp6D::match (src/slam6d/icp6D.cc:104-285), device-resident loop.

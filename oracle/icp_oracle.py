@@ -104,11 +104,215 @@ def _choldc_solve(A, B):
 # ---------------------------------------------------------------------------------------
 # icp6Dminimizer::Align (serial), from explicit pair lists p1 (model), p2 (data)
 # ---------------------------------------------------------------------------------------
-def align(algo, p1, p2, cm, cd, pn=None):
-    """Returns (rms, alignxf).  algo: 1 QUAT, 2 SVD, 6 APX, 10 NAPX."""
+def matrix4_to_quat(mat):
+    """Matrix4ToQuat (globals.icc:1032-1075) -> (quat[4] = (W, -X, -Y, -Z) normalised, t[3])"""
+    T = 1 + mat[0] + mat[5] + mat[10]
+    if T > 0.00000001:
+        S = math.sqrt(T) * 2
+        X = (mat[9] - mat[6]) / S; Y = (mat[2] - mat[8]) / S; Z = (mat[4] - mat[1]) / S; W = 0.25 * S
+    elif mat[0] > mat[5] and mat[0] > mat[10]:
+        S = math.sqrt(1.0 + mat[0] - mat[5] - mat[10]) * 2
+        X = 0.25 * S; Y = (mat[4] + mat[1]) / S; Z = (mat[2] + mat[8]) / S; W = (mat[9] - mat[6]) / S
+    elif mat[5] > mat[10]:
+        S = math.sqrt(1.0 + mat[5] - mat[0] - mat[10]) * 2
+        X = (mat[4] + mat[1]) / S; Y = 0.25 * S; Z = (mat[9] + mat[6]) / S; W = (mat[2] - mat[8]) / S
+    else:
+        S = math.sqrt(1.0 + mat[10] - mat[0] - mat[5]) * 2
+        X = (mat[2] + mat[8]) / S; Y = (mat[9] + mat[6]) / S; Z = 0.25 * S; W = (mat[4] - mat[1]) / S
+    q = np.array([W, -X, -Y, -Z])
+    return q / math.sqrt(float(q @ q)), np.array(mat[12:15], float)
+
+
+def _skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], float)
+
+
+def _rt_to_gl(R, t):
+    a = np.zeros(16)
+    for r in range(3):
+        for c in range(3):
+            a[c * 4 + r] = R[r, c]
+    a[12:15] = t
+    a[15] = 1.0
+    return a
+
+
+def _euler_T(x, th):
+    """the 4x4 pose matrix both LUMEULER blocks write out (icp6Dlumeuler.cc:144-156, 184-196)"""
+    cx, cy, cz = math.cos(th[0]), math.cos(th[1]), math.cos(th[2])
+    sx, sy, sz = math.sin(th[0]), math.sin(th[1]), math.sin(th[2])
+    T = np.eye(4)
+    T[:3, 3] = x
+    T[0, :3] = [cy * cz, -cy * sz, sy]
+    T[1, :3] = [cz * sx * sy + cx * sz, cx * cz - sx * sy * sz, -cy * sx]
+    T[2, :3] = [sx * sz - cx * cz * sy, cz * sx + cx * sy * sz, cx * cy]
+    return T
+
+
+def _quat_T(x, p, qv):
+    """(p*p - q.q) I + 2 q q^T + 2 p [q]x with translation x (icp6Dlumquat.cc:168-180, 190-203)"""
+    T = np.zeros((4, 4))
+    T[:3, :3] = np.eye(3) * (p * p - float(qv @ qv)) + 2 * np.outer(qv, qv) + 2 * p * _skew(qv)
+    T[:3, 3] = x
+    T[3, 3] = 1
+    return T
+
+
+def _align_serial_only(algo, p1, p2, cm, cd, pose):
+    """The minimizers that exist only as serial Align: -a 3 ORTHO, 4 DUAL, 5 HELIX, 7 LUMEULER,
+    8 LUMQUAT, 9 QUAT_SCALE (slam6D.cc:703-723).  pose = alignxf on entry (current transMat for 7/8)."""
+    n = len(p1)
+    s = float(((p1 - p2) ** 2).sum())
+    rms = math.sqrt(s / n)
+    if algo == 3:   # icp6Dortho.cc:40-157
+        H = (p1 - cm).T @ (p2 - cd)
+        w, V = np.linalg.eigh(H.T @ H)
+        R = H @ sum(np.outer(V[:, k], V[:, k]) / math.sqrt(w[k]) for k in range(3))
+        return rms, _rt_to_gl(R, cm - R @ cd)
+    if algo == 4:   # icp6Ddual.cc:41-152
+        C1 = np.zeros((4, 4)); C2 = np.zeros((4, 4))
+        md = p1.T @ p2                                   # sum m d^T
+        cr = np.cross(p1, p2).sum(axis=0)                # m^T [d]x = (m x d)^T ; [m]x d = m x d
+        C1[0, 0] = np.trace(md)
+        C1[0, 1:] = -cr
+        C1[1:, 0] = -cr
+        C1[1:, 1:] = md + md.T - np.trace(md) * np.eye(3)   # m d^T + [m]x [d]x
+        sm, sd = p1.sum(axis=0), p2.sum(axis=0)
+        C2[0, 1:] = sm - sd
+        C2[1:, 0] = sd - sm
+        C2[1:, 1:] = -_skew(sd) - _skew(sm)
+        C1 = C1 * (-2); C2 = C2 * 2
+        A = (C2.T @ C2 / (2 * n) - C1 - C1.T) * 0.5
+        U, D, Vt = np.linalg.svd(A)
+        qdot = U[:, 0]
+        q = qdot[1:]
+        Cq = _skew(q)
+        sv = C2 @ qdot * (-1.0) / (2 * n)
+        Q = np.zeros((4, 4))
+        Q[0, 0] = qdot[0]; Q[0, 1:] = q; Q[1:, 0] = -q; Q[1:, 1:] = np.eye(3) * qdot[0] + Cq
+        t = (Q @ sv)[1:]
+        R = np.eye(3) * (qdot[0] * qdot[0] - float(q @ q)) + 2 * np.outer(q, q) + 2 * qdot[0] * Cq
+        return rms, _rt_to_gl(R, t)
+    if algo == 5:   # icp6Dhelix.cc:48-206
+        x2, y2, z2 = p2[:, 0], p2[:, 1], p2[:, 2]
+        dist = p2 - p1
+        B = np.zeros((6, 6))
+        B[3, 3] = B[4, 4] = B[5, 5] = n
+        B[0, 4] = B[4, 0] = (-z2).sum(); B[1, 3] = B[3, 1] = z2.sum()
+        B[0, 5] = B[5, 0] = y2.sum();    B[2, 3] = B[3, 2] = (-y2).sum()
+        B[2, 4] = B[4, 2] = x2.sum();    B[1, 5] = B[5, 1] = (-x2).sum()
+        B[0, 1] = B[1, 0] = (y2 * -x2).sum(); B[0, 2] = B[2, 0] = (-z2 * x2).sum(); B[1, 2] = B[2, 1] = (z2 * -y2).sum()
+        B[0, 0] = (z2 * z2 + y2 * y2).sum(); B[1, 1] = (z2 * z2 + x2 * x2).sum(); B[2, 2] = (x2 * x2 + y2 * y2).sum()
+        bd = np.array([(-z2 * dist[:, 1] + y2 * dist[:, 2]).sum(), (z2 * dist[:, 0] - x2 * dist[:, 2]).sum(),
+                       (-y2 * dist[:, 0] + x2 * dist[:, 1]).sum(), dist[:, 0].sum(), dist[:, 1].sum(), dist[:, 2].sum()])
+        ccs = np.linalg.solve(B, bd)
+        c, cs = -ccs[:3], -ccs[3:]
+        CLength = math.sqrt(float(c @ c))
+        rotationCheck = float(c @ cs)
+        angle = math.atan(CLength)
+        g = c / CLength
+        sinA = math.sin(-angle / 2)
+        b0, b1, b2, b3 = math.cos(-angle / 2), g[0] * sinA, g[1] * sinA, g[2] * sinA
+        R = np.array([[b0 * b0 + b1 * b1 - b2 * b2 - b3 * b3, 2 * (b1 * b2 + b0 * b3), 2 * (b1 * b3 - b0 * b2)],
+                      [2 * (b1 * b2 - b0 * b3), b0 * b0 - b1 * b1 + b2 * b2 - b3 * b3, 2 * (b2 * b3 + b0 * b1)],
+                      [2 * (b1 * b3 + b0 * b2), 2 * (b2 * b3 - b0 * b1), b0 * b0 - b1 * b1 - b2 * b2 + b3 * b3]])
+        R = R / (b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3)
+        skew = rotationCheck / (CLength * CLength)
+        gs = (cs - c * skew) / CLength
+        pT = np.cross(g, gs)
+        t = R @ -pT + g * (skew * angle) + pT
+        return rms, _rt_to_gl(R, t)
+    if algo == 7:   # icp6Dlumeuler.cc:42-229
+        rPosTheta, rPos = matrix4_to_euler(pose)
+        u = (p1 + p2) / 2.0
+        d = p1 - p2
+        x, y, z = u[:, 0], u[:, 1], u[:, 2]
+        dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+        MZ = np.array([dx.sum(), dy.sum(), dz.sum(), (-z * dy + y * dz).sum(), (-y * dx + x * dy).sum(),
+                       (z * dx - x * dz).sum()])
+        MM = np.zeros((6, 6))
+        MM[0, 0] = MM[1, 1] = MM[2, 2] = n
+        MM[3, 3] = (y * y + z * z).sum(); MM[4, 4] = (x * x + y * y).sum(); MM[5, 5] = (x * x + z * z).sum()
+        MM[0, 4] = MM[4, 0] = -y.sum(); MM[0, 5] = MM[5, 0] = z.sum()
+        MM[1, 3] = MM[3, 1] = -z.sum(); MM[1, 4] = MM[4, 1] = x.sum()
+        MM[2, 3] = MM[3, 2] = y.sum();  MM[2, 5] = MM[5, 2] = -x.sum()
+        MM[3, 4] = MM[4, 3] = -(x * z).sum(); MM[3, 5] = MM[5, 3] = -(x * y).sum(); MM[4, 5] = MM[5, 4] = -(y * z).sum()
+        Ehat = np.linalg.solve(MM, MZ)
+        cx, cy = math.cos(rPosTheta[0]), math.cos(rPosTheta[1])
+        sx, sy = math.sin(rPosTheta[0]), math.sin(rPosTheta[1])
+        tx, ty, tz = rPos
+        T1 = _euler_T(rPos, rPosTheta)
+        H = np.eye(6)
+        H[0, 4] = -tz * cx + ty * sx; H[0, 5] = ty * cx * cy + tz * cy * sx
+        H[1, 3] = tz; H[1, 4] = -tx * sx; H[1, 5] = -tx * cx * cy + tz * sy
+        H[2, 3] = -ty; H[2, 4] = tx * cx; H[2, 5] = -tx * cy * sx - ty * sy
+        H[3, 5] = sy; H[4, 4] = sx; H[4, 5] = cx * cy; H[5, 4] = cx; H[5, 5] = -cy * sx
+        X = np.concatenate([rPos, rPosTheta]) - np.linalg.solve(H, Ehat)
+        T2 = _euler_T(X[:3], X[3:])
+        Tinc = T1 @ np.linalg.inv(T2)
+        return rms, _rt_to_gl(Tinc[:3, :3], Tinc[:3, 3])
+    if algo == 8:   # icp6Dlumquat.cc:40-231
+        quat, t = matrix4_to_quat(pose)
+        x = (p1[:, 0] + p1[:, 0]) / 2.0            # sic: p1.x twice (icp6Dlumquat.cc:90)
+        y = (p1[:, 1] + p2[:, 1]) / 2.0
+        z = (p1[:, 2] + p2[:, 2]) / 2.0
+        d = p1 - p2
+        dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+        MZ = np.array([dx.sum(), dy.sum(), dz.sum(), (x * dx + y * dy + z * dz).sum(), (z * dy - y * dz).sum(),
+                       (x * dz - z * dx).sum(), (y * dx - x * dy).sum()])
+        MM = np.zeros((7, 7))
+        MM[0, 0] = MM[1, 1] = MM[2, 2] = n
+        MM[3, 3] = (x * x + y * y + z * z).sum(); MM[4, 4] = (y * y + z * z).sum()
+        MM[5, 5] = (x * x + z * z).sum(); MM[6, 6] = (x * x + y * y).sum()
+        sx, sy, sz = x.sum(), y.sum(), z.sum()
+        MM[0, 3] = MM[3, 0] = sx; MM[0, 5] = MM[5, 0] = -sz; MM[0, 6] = MM[6, 0] = sy
+        MM[1, 3] = MM[3, 1] = sy; MM[1, 4] = MM[4, 1] = sz;  MM[1, 6] = MM[6, 1] = -sx
+        MM[2, 3] = MM[3, 2] = sz; MM[2, 4] = MM[4, 2] = -sy; MM[2, 5] = MM[5, 2] = sx
+        MM[4, 5] = MM[5, 4] = -(x * y).sum(); MM[4, 6] = MM[6, 4] = -(x * z).sum(); MM[5, 6] = MM[6, 5] = -(y * z).sum()
+        Ehat = np.linalg.solve(MM, MZ)
+        p, q, r, sq = quat
+        X0, Y0, Z0 = t
+        U = np.array([[p, q, r, sq], [q, -p, sq, -r], [r, -sq, -p, q], [sq, r, -q, -p]])
+        T = np.array([[p * X0 + sq * Y0 - r * Z0, q * X0 + r * Y0 + sq * Z0, r * X0 - q * Y0 + p * Z0, sq * X0 - p * Y0 - q * Z0],
+                      [-sq * X0 + p * Y0 + q * Z0, -r * X0 + q * Y0 - p * Z0, q * X0 + r * Y0 + sq * Z0, p * X0 + sq * Y0 - r * Z0],
+                      [r * X0 - q * Y0 + p * Z0, -sq * X0 + p * Y0 + q * Z0, -p * X0 - sq * Y0 + r * Z0, q * X0 + r * Y0 - sq * Z0]])
+        H = np.zeros((7, 7))
+        H[:3, :3] = np.eye(3); H[:3, 3:] = T * (-2); H[3:, 3:] = U * 2
+        Xhat = np.array([X0, Y0, Z0, p, q, r, sq])
+        T1 = _quat_T(t, p, np.array([q, r, sq]))
+        X = Xhat - np.linalg.solve(H, Ehat)
+        T2 = _quat_T(X[:3], X[3], X[4:7])
+        Tinc = T1 @ np.linalg.inv(T2)
+        return rms, _rt_to_gl(Tinc[:3, :3], Tinc[:3, 3])
+    if algo == 9:   # icp6Dquatscale.cc:37-161
+        S = (p2.T @ p1) / n - np.outer(cd, cm)
+        tr = np.trace(S)
+        Q = np.zeros((4, 4))
+        Q[0, 0] = tr
+        Q[0, 1] = Q[1, 0] = S[1, 2] - S[2, 1]
+        Q[0, 2] = Q[2, 0] = S[2, 0] - S[0, 2]
+        Q[0, 3] = Q[3, 0] = S[0, 1] - S[1, 0]
+        Q[1:, 1:] = S + S.T - tr * np.eye(3)
+        w, V = np.linalg.eigh(Q)
+        q = V[:, np.argmax(w)]
+        q = q / np.linalg.norm(q)
+        q0, q1, q2, q3 = q
+        R = np.array([[q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, 2 * (q1 * q2 - q0 * q3), 2 * (q1 * q3 + q0 * q2)],
+                      [2 * (q1 * q2 + q0 * q3), q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, 2 * (q2 * q3 - q0 * q1)],
+                      [2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3]])
+        scale = math.sqrt(float(((p1 - cm) ** 2).sum()) / float(((p2 - cd) ** 2).sum()))
+        return rms, _rt_to_gl(R * scale, cm - scale * (R @ cd))
+    raise ValueError("algo")
+
+
+def align(algo, p1, p2, cm, cd, pn=None, pose=None):
+    """Returns (rms, alignxf).  algo = the -a id: 1 QUAT, 2 SVD, 6 APX, 10 NAPX (these four also exist as
+    Align_Parallel) and the serial-only 3 ORTHO, 4 DUAL, 5 HELIX, 7 LUMEULER, 8 LUMQUAT, 9 QUAT_SCALE."""
     n = len(p1)
     cm = np.asarray(cm, float)
     cd = np.asarray(cd, float)
+    if algo in (3, 4, 5, 7, 8, 9):
+        return _align_serial_only(algo, p1, p2, cm, cd, pose)
     if algo == 1:   # icp6Dquat.cc:38-144
         s = float(((p1 - p2) ** 2).sum())
         S = (p2.T @ p1) / n - np.outer(cd, cm)        # S[i][j] = sum p2_i p1_j / n - cd_i cm_j
@@ -313,7 +517,10 @@ def match(prev, cur, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsil
         prev_prev_ret, prev_ret = prev_ret, ret
         r = get_pt_pairs(prev, cur, max_dist_match2, mode, rnd)
         if r["n"] > 3:
-            ret, alignxf = align_fn(algo, r["p1"], r["p2"], r["cm"], r["cd"], r["pn"])
+            if algo in (3, 7, 8):   # getAlgorithmID() 3 / 8: alignxf enters as the scan's transMat (icp6D.cc:237-241)
+                ret, alignxf = align_fn(algo, r["p1"], r["p2"], r["cm"], r["cd"], r["pn"], cur.transMat.copy())
+            else:
+                ret, alignxf = align_fn(algo, r["p1"], r["p2"], r["cm"], r["cd"], r["pn"])
         else:
             break
         trace.append((r["n"], ret, alignxf.copy()))

@@ -90,6 +90,8 @@ def ref():
         R.ref_kdi_find_closest_along_dir.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, _ip]
         R.ref_align.restype = C.c_double
         R.ref_align.argtypes = [C.c_int, C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp]
+        R.ref_align_inout.restype = C.c_double
+        R.ref_align_inout.argtypes = [C.c_int, C.c_size_t, _dp, _dp, _dp, _dp, _dp]
         R.ref_align_parallel.restype = C.c_double
         R.ref_align_parallel.argtypes = [C.c_int, _up, _dp, _dp, _dp, _dp, _dp]
         R.ref_apx_align_parallel.restype = C.c_double
@@ -217,8 +219,13 @@ class RefTree:
         return idx
 
 
-def ref_align(algo, p1, p2, cm, cd, nrm=None):
+def ref_align(algo, p1, p2, cm, cd, nrm=None, pose=None):
+    """reference Align by -a id; pose = alignxf on entry (used by 7 LUMEULER / 8 LUMQUAT)"""
     p1 = _c(p1); p2 = _c(p2)
+    if int(algo) in (3, 4, 5, 7, 8, 9):
+        out = np.eye(4).reshape(16).copy() if pose is None else _c(pose).copy()
+        err = ref().ref_align_inout(int(algo), len(p1), _d(p1), _d(p2), _d(_c(cm)), _d(_c(cd)), _d(out))
+        return out, err
     out = np.empty(16)
     err = ref().ref_align(int(algo), len(p1), _d(p1), _d(p2), _d(_c(nrm)) if nrm is not None else None,
                           _d(_c(cm)), _d(_c(cd)), _d(out))

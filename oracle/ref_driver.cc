@@ -3,7 +3,8 @@
  *
  * A thin extern "C" face over the *reference's own* translation units
  * (src/slam6d/kdIndexed.cc, icp6Dquat.cc, icp6Dsvd.cc + vendored newmat,
- * icp6Dapx.cc, icp6Dnapx.cc), compiled where they lie under $REF by
+ * icp6Dapx.cc, icp6Dnapx.cc, icp6Dortho.cc, icp6Ddual.cc, icp6Dhelix.cc,
+ * icp6Dlumeuler.cc, icp6Dlumquat.cc, icp6Dquatscale.cc), compiled where they lie under $REF by
  * oracle/build_ref.sh into oracle/_ref/libref3dtk.so.  Nothing from the
  * reference is copied into this repository; this file only #includes the
  * reference headers at build time.  Used to (a) pin oracle/oracle.c and the
@@ -26,6 +27,12 @@
 #include "slam6d/icp6Dsvd.h"
 #include "slam6d/icp6Dapx.h"
 #include "slam6d/icp6Dnapx.h"
+#include "slam6d/icp6Dortho.h"
+#include "slam6d/icp6Ddual.h"
+#include "slam6d/icp6Dhelix.h"
+#include "slam6d/icp6Dlumeuler.h"
+#include "slam6d/icp6Dlumquat.h"
+#include "slam6d/icp6Dquatscale.h"
 
 struct RefTree {
   std::vector<double*> ptrs;
@@ -113,6 +120,25 @@ double ref_align(int algo, size_t n, const double* p1, const double* p2, const d
     case 2: { icp6D_SVD m(true); return m.Align(pairs, alignxf, cm, cd); }
     case 6: { icp6D_APX m(true); return m.Align(pairs, alignxf, cm, cd); }
     case 10: { icp6D_NAPX m(true); return m.Align(pairs, alignxf, cm, cd); }
+  }
+  return -2.0;
+}
+
+/* the serial-only minimizers, by their -a id (slam6D.cc:703-723): 3 ORTHO, 4 DUAL, 5 HELIX, 7 LUMEULER,
+ * 8 LUMQUAT, 9 QUAT_SCALE.  alignxf is in/out: icp6D::match hands LUMEULER / LUMQUAT the current scan's
+ * transMat in it (icp6D.cc:237-241).                                                                  */
+double ref_align_inout(int algo, size_t n, const double* p1, const double* p2, const double* cm,
+                       const double* cd, double* alignxf)
+{
+  std::vector<PtPair> pairs;
+  fill_pairs(pairs, n, p1, p2, nullptr);
+  switch (algo) {
+    case 3: { icp6D_ORTHO m(true); return m.Align(pairs, alignxf, cm, cd); }
+    case 4: { icp6D_DUAL m(true); return m.Align(pairs, alignxf, cm, cd); }
+    case 5: { icp6D_HELIX m(true); return m.Align(pairs, alignxf, cm, cd); }
+    case 7: { icp6D_LUMEULER m(true); return m.Align(pairs, alignxf, cm, cd); }
+    case 8: { icp6D_LUMQUAT m(true); return m.Align(pairs, alignxf, cm, cd); }
+    case 9: { icp6D_QUAT_SCALE m(true); return m.Align(pairs, alignxf, cm, cd); }
   }
   return -2.0;
 }

@@ -15,6 +15,8 @@ Fixtures written:
                     alignxf and final transMat, computed with the oracle loop + the REFERENCE
                     minimizer; cross-checked against SURVEY appendix B1
   b4_dat_lum.json   LUM link systems at the B1 final poses (-D 25)
+  k6_serial_minimizers.json  reference icp6D_{ORTHO,DUAL,HELIX,LUMEULER,LUMQUAT,QUAT_SCALE}::Align
+                    (-a 3,4,5,7,8,9) on the K6 clouds; `python make_golden.py k6s` regenerates only this
 """
 import json
 import os
@@ -41,9 +43,33 @@ def brute(m, q, maxd2):
     return out
 
 
+def gen_k6_serial():
+    """K6 clouds through the reference's serial-only minimizers.  LUMEULER / LUMQUAT receive the current
+    scan pose in alignxf (icp6D.cc:237-241); QUAT_SCALE gets a cloud that really is scaled."""
+    d = orc.gen_mt64_uniform(7, 3000, -100, 100).reshape(1000, 3)
+    T = io.euler_to_matrix4([1.5, -2.0, 0.7], [0.02, -0.03, 0.05])
+    mm = d.copy(); orc.transform_points(T, mm)
+    noise = orc.gen_mt64_uniform(9, 3000, -0.5, 0.5).reshape(1000, 3)
+    pose = io.euler_to_matrix4([10.0, -5.0, 3.0], [0.01, 0.02, -0.03])
+    out = {"seed_points": 7, "seed_noise": 9, "rPos": [1.5, -2.0, 0.7], "rPosTheta": [0.02, -0.03, 0.05],
+           "pose": pose.tolist(), "scale_case": 1.02, "cases": {}}
+    cd = d.mean(axis=0)
+    for tag, pm in (("clean", mm), ("noisy", mm + noise), ("scaled", 1.02 * mm + noise)):
+        cm = pm.mean(axis=0)
+        out["cases"][tag] = {}
+        for algo in (3, 4, 5, 7, 8, 9):
+            a, err = orc.ref_align(algo, pm, d, cm, cd, None, pose)
+            out["cases"][tag][str(algo)] = {"alignxf": a.tolist(), "rms": err}
+            print("K6s", tag, algo, err, a[12:15], a[0])
+    json.dump(out, open(os.path.join(HERE, "k6_serial_minimizers.json"), "w"), indent=1)
+
+
 def main():
     assert orc.have_ref() or os.path.isdir(REF), "needs the reference checkout"
     orc.build()
+    if sys.argv[1:] == ["k6s"]:
+        return gen_k6_serial()
+    gen_k6_serial()
 
     # ---- dat scans ------------------------------------------------------------------
     scans, poses = {}, {}
@@ -109,8 +135,8 @@ def main():
     json.dump(k6, open(os.path.join(HERE, "k6_minimizers.json"), "w"), indent=1)
 
     # ---- B1: dat sequential ICP (oracle loop + REFERENCE minimizer) --------------------
-    def ref_align_fn(algo, p1, p2, cm, cd, pn):
-        a, err = orc.ref_align(algo, p1, p2, cm, cd, pn)
+    def ref_align_fn(algo, p1, p2, cm, cd, pn, pose=None):
+        a, err = orc.ref_align(algo, p1, p2, cm, cd, pn, pose)
         return err, a
     S = [io.OScan(poses["pose%03d" % k][:3], poses["pose%03d" % k][3:], scans["scan%03d" % k]) for k in range(3)]
     b1 = {"params": {"algo": 1, "max_dist_match": 25.0, "max_num_iterations": 50, "epsilonICP": 1e-5, "eP": True},

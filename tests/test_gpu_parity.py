@@ -281,22 +281,26 @@ def test_dat_sequential_icp_matches_reference_trace(tdtk, gpu):
         assert _rel(S[i].get_transMat(), pr["final_transMat"]) < 1e-9     # what we actually reach
 
 
-@pytest.mark.parametrize("algo", [1, 2, 6])
+@pytest.mark.parametrize("algo", [1, 2, 6, 3, 4, 5, 7, 8, 9])
 def test_icp_vs_oracle_loop(tdtk, orc, gpu, algo):
-    """icp6D::match for QUAT / SVD / APX against the oracle loop on the bundled scans."""
+    """icp6D::match for every point-to-point minimizer (-a 1..9) against the oracle loop on the bundled
+    scans: QUAT / SVD / APX (the OpenMP-capable ones) and ORTHO / DUAL / HELIX / LUMEULER / LUMQUAT /
+    QUAT_SCALE, which the device loop computes from the second-moment block."""
     from oracle import icp_oracle as io
     z = np.load(os.path.join(G, "dat_scans.npz"))
     S, O = _dat_scans(tdtk.Scan, z), _dat_scans(io.OScan, z)
-    cls = {1: tdtk.icp6D_QUAT, 2: tdtk.icp6D_SVD, 6: tdtk.icp6D_APX}[algo]
+    cls = {1: tdtk.icp6D_QUAT, 2: tdtk.icp6D_SVD, 6: tdtk.icp6D_APX, 3: tdtk.icp6D_ORTHO, 4: tdtk.icp6D_DUAL,
+           5: tdtk.icp6D_HELIX, 7: tdtk.icp6D_LUMEULER, 8: tdtk.icp6D_LUMQUAT, 9: tdtk.icp6D_QUAT_SCALE}[algo]
     icp = tdtk.icp6D(cls(True), 25.0, 12, quiet=True, epsilonICP=1e-5)
     S[1].mergeCoordinatesWithRoboterPosition(S[0]); O[1].mergeCoordinatesWithRoboterPosition(O[0])
     it = icp.match(S[0], S[1])
     oit, otr = io.match(O[0], O[1], algo, 625.0, 12, 1e-5)
     assert it == oit
     assert [int(r[0]) for r in icp.last["trace"]] == [t[0] for t in otr]
-    np.testing.assert_allclose(icp.last["trace"][:, 1], [t[1] for t in otr], rtol=1e-9)
-    assert _rel(S[1].get_transMat(), O[1].transMat) < 1e-9
-    assert np.abs(S[1].get_xyz_reduced() - O[1].xyz).max() < 1e-8
+    tol = 1e-9 if algo in (1, 2, 6) else 1e-7
+    np.testing.assert_allclose(icp.last["trace"][:, 1], [t[1] for t in otr], rtol=tol)
+    assert _rel(S[1].get_transMat(), O[1].transMat) < tol
+    assert np.abs(S[1].get_xyz_reduced() - O[1].xyz).max() < (1e-8 if algo in (1, 2, 6) else 1e-5)
 
 
 def test_icp_point_to_plane_napx(tdtk, orc, gpu):

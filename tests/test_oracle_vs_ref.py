@@ -123,6 +123,33 @@ def test_k6_minimizers(orc):
             assert abs(rms - exp[str(algo)]["rms"]) <= 1e-9 * max(1.0, abs(rms))
 
 
+def _k6s_inputs(orc):
+    from oracle import icp_oracle as io
+    k = json.load(open(os.path.join(G, "k6_serial_minimizers.json")))
+    d = orc.gen_mt64_uniform(k["seed_points"], 3000, -100, 100).reshape(1000, 3)
+    T = io.euler_to_matrix4(k["rPos"], k["rPosTheta"])
+    mm = d.copy(); orc.transform_points(T, mm)
+    noise = orc.gen_mt64_uniform(k["seed_noise"], 3000, -0.5, 0.5).reshape(1000, 3)
+    clouds = {"clean": mm, "noisy": mm + noise, "scaled": k["scale_case"] * mm + noise}
+    return k, d, clouds
+
+
+def test_k6_serial_only_minimizers(orc):
+    """numpy restatements of ORTHO / DUAL / HELIX / LUMEULER / LUMQUAT / QUAT_SCALE (-a 3,4,5,7,8,9) against
+    the fixture generated with the reference's own TUs."""
+    from oracle import icp_oracle as io
+    k, d, clouds = _k6s_inputs(orc)
+    pose = np.array(k["pose"])
+    cd = d.mean(axis=0)
+    for tag, pm in clouds.items():
+        cm = pm.mean(axis=0)
+        for algo in (3, 4, 5, 7, 8, 9):
+            exp = k["cases"][tag][str(algo)]
+            rms, a = io.align(algo, pm, d, cm, cd, None, pose)
+            np.testing.assert_allclose(a, exp["alignxf"], rtol=0, atol=5e-9, err_msg="%s %d" % (tag, algo))
+            assert abs(rms - exp["rms"]) <= 1e-9 * max(1.0, abs(rms))
+
+
 def test_align_parallel_quat_vs_reference(orc):
     _need_ref(orc)
     from oracle import icp_oracle as io
