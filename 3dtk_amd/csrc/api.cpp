@@ -1326,12 +1326,41 @@ int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* firs
   return TDTK_OK;
 }
 
+// FillGB3D's scatter (lum6Deuler.cc:285-300) over ALL links in link order + solveSparseCholesky
+// (graphSlam6D.cc:345-379).  Links whose blocks are all zero (m <= 2) contribute nothing, as there.
+int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, const double* C, const double* CD,
+                            int nscans, double* X, double* G_out, double* B_out)
+{
+  if (nlinks < 0 || nscans < 2 || !X || (nlinks && (!from || !to || !C || !CD))) { set_error("bad argument"); return TDTK_EINVAL; }
+  const int n = nscans - 1, N = 6 * n;
+  std::vector<double> G((size_t)N * N, 0.0), B((size_t)N, 0.0);
+  for (int l = 0; l < nlinks; l++) {
+    const int a = from[l] - 1, b = to[l] - 1;
+    if (a >= n || b >= n || a < -1 || b < -1) { set_error("link endpoint out of range"); return TDTK_EINVAL; }
+    const double* Cab = C + 36 * (size_t)l;
+    const double* CDab = CD + 6 * (size_t)l;
+    auto add = [&](int r, int c, double sgn) {
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) G[(size_t)(r * 6 + i) * N + (c * 6 + j)] += sgn * Cab[i * 6 + j];
+    };
+    if (a >= 0) { for (int i = 0; i < 6; i++) B[a * 6 + i] += CDab[i]; add(a, a, 1.0); }
+    if (b >= 0) { for (int i = 0; i < 6; i++) B[b * 6 + i] -= CDab[i]; add(b, b, 1.0); }
+    if (a >= 0 && b >= 0) { add(a, b, -1.0); add(b, a, -1.0); }
+  }
+  if (G_out) std::memcpy(G_out, G.data(), sizeof(double) * G.size());
+  if (B_out) std::memcpy(B_out, B.data(), sizeof(double) * B.size());
+  if (!solve_spd_dense(N, G.data(), B.data(), X, 0.00001)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+  return TDTK_OK;
+}
+
 int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double* dalignxf, double* rPos,
                           double* rPosTheta, tdtk_scan* const* scans, double* xf_out, double* ret)
 {
   if (nscans <= 0 || !X || !transMat || !dalignxf || !rPos || !rPosTheta) { set_error("bad argument"); return TDTK_EINVAL; }
   double sum_position_diff = 0.0;
   Ctx* c = nullptr;
+  std::vector<Xf2Desc> moves;
+  size_t max_n = 0;
   for (int i = 1; i < nscans; i++) {
     double* tm = transMat + 16 * (size_t)i;
     double* da = dalignxf + 16 * (size_t)i;
@@ -1374,15 +1403,25 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
     if (scans && scans[i] && scans[i]->N) {
       if (!c) { int rc = get_ctx(scans[i]->device, &c); if (rc) return rc; }
       tdtk_scan* sc = scans[i];
-      Mat4 A1, A2;
-      std::memcpy(A1.m, tinv, sizeof tinv);
-      std::memcpy(A2.m, axf, sizeof axf);
-      HIPCHK(launch_transform(sc->x, sc->y, sc->z, sc->nx, sc->ny, sc->nz, sc->N, A1, c->stream));
-      HIPCHK(launch_transform(sc->x, sc->y, sc->z, sc->nx, sc->ny, sc->nz, sc->N, A2, c->stream));
+      if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
+      Xf2Desc d;
+      d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
+      std::memcpy(d.A1.m, tinv, sizeof tinv);
+      std::memcpy(d.A2.m, axf, sizeof axf);
+      moves.push_back(d);
+      if (sc->N > max_n) max_n = sc->N;
     }
     sum_position_diff += std::sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
   }
-  if (c) HIPCHK(hipStreamSynchronize(c->stream));
+  if (c && !moves.empty()) {
+    // every resident scan moved by (tinv, then axf) in one launch
+    const size_t bytes = moves.size() * sizeof(Xf2Desc);
+    int rc = c->ws[WS_TMPB].ensure(bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, moves.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_transform2_batch(c->ws[WS_TMPB].as<Xf2Desc>(), (int)moves.size(), max_n, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   if (ret) *ret = sum_position_diff / (double)nscans;
   return TDTK_OK;
 }

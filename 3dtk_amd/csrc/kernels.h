@@ -127,6 +127,14 @@ hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* tm
 size_t morton_sort_temp_bytes(size_t n);
 hipError_t launch_morton_order(const double* d_xyz, size_t n, const double* d_box, uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
                                size_t tmp_bytes, hipStream_t s);
+// one resident scan moved by two consecutive in-place transforms (Scan::transformToEuler)
+struct Xf2Desc {
+  double *x, *y, *z, *nx, *ny, *nz;
+  size_t n;
+  Mat4 A1, A2;
+};
+hipError_t launch_transform2_batch(const Xf2Desc* d_desc, int count, size_t max_n, hipStream_t s);
+
 // reduce.hip: bounding box + octree-centre reduction
 struct OctRoot {
   double center[3];

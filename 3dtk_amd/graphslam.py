@@ -89,10 +89,42 @@ def lum_iteration(gr, allScans, max_dist_match2, group=None, link_fn=None, devic
     return sum_position_diff / nscans
 
 
+def lum_reduce_solve(gr, mine, Cm, CD, world=1, group=None, device=None):
+    """The exchange step of the sharded FillGB3D: this rank's per-link blocks (Cm [len(mine), 36],
+    CD [len(mine), 6]) go into a zero [nlinks, 42] buffer, ONE all-reduce makes every link's block
+    known everywhere (each link has exactly one owner, so the sum is exact), then every rank runs the
+    same scatter-in-link-order + SPD solve (tdtk_lum_assemble_solve).  Returns X [6(n-1)]."""
+    from ._capi import lib, check, dptr, iptr
+    nscans, nlinks = gr.getNrScans(), gr.getNrLinks()
+    blocks = np.zeros((nlinks, 42))                 # [C 36 | CD 6] per link
+    if len(mine):
+        blocks[mine, :36] = Cm
+        blocks[mine, 36:] = CD
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(blocks)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        blocks = t.cpu().numpy()
+    frm = np.ascontiguousarray([gr.getLink(i, 0) for i in range(nlinks)], dtype=np.int32)
+    to = np.ascontiguousarray([gr.getLink(i, 1) for i in range(nlinks)], dtype=np.int32)
+    Call = np.ascontiguousarray(blocks[:, :36])
+    CDall = np.ascontiguousarray(blocks[:, 36:])
+    X = np.empty(6 * (nscans - 1))
+    check(lib().tdtk_lum_assemble_solve(nlinks, iptr(frm), iptr(to), dptr(Call), dptr(CDall), nscans, dptr(X),
+                                        None, None))
+    return X
+
+
 def lum_iteration_native(gr, allScans, max_dist_match2, group=None, device=None):
     """Same iteration with the host work in the library: all of this rank's links in ONE batched
-    call (tdtk_lum_links: kernels enqueued back to back, one sync), the all-reduce, the SPD solve,
-    and the native pose update (tdtk_lum_update_poses) that also moves the resident scans."""
+    call (tdtk_lum_links: kernels enqueued back to back, one sync); ONE all-reduce of the per-link
+    blocks (42 doubles per link, zeros for links other ranks own, so the sum is exact and the result
+    does not depend on the number of ranks); scatter into G / B in link order + SPD solve
+    (tdtk_lum_assemble_solve); native pose update (tdtk_lum_update_poses) that also moves the
+    resident scans."""
     import ctypes as C
     from ._capi import lib, check, dptr
     rank, world = 0, 1
@@ -101,33 +133,18 @@ def lum_iteration_native(gr, allScans, max_dist_match2, group=None, device=None)
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     nscans = gr.getNrScans()
     n = nscans - 1
+    nlinks = gr.getNrLinks()
     mine = shard_links(gr, rank, world)
     nl = len(mine)
-    G = np.zeros((6 * n, 6 * n))
-    B = np.zeros(6 * n)
+    Cm = np.empty((nl, 36)); CD = np.empty((nl, 6))
     if nl:
         first = (C.c_void_p * nl)(*[allScans[gr.getLink(i, 0)].getSearchTree()._h for i in mine])
         second = (C.c_void_p * nl)(*[allScans[gr.getLink(i, 1)].handle for i in mine])
         dal = np.ascontiguousarray(np.stack([allScans[gr.getLink(i, 0)].dalignxf for i in mine]))
-        Cm = np.empty((nl, 36)); CD = np.empty((nl, 6))
         m = (C.c_uint64 * nl)(); ss = np.empty(nl)
         check(lib().tdtk_lum_links(nl, first, dptr(dal), second, float(max_dist_match2), dptr(Cm), dptr(CD),
                                    m, dptr(ss)))
-        for k, i in enumerate(mine):
-            a, b = gr.getLink(i, 0) - 1, gr.getLink(i, 1) - 1
-            Cab = Cm[k].reshape(6, 6)
-            if a >= 0:
-                B[a * 6:a * 6 + 6] += CD[k]
-                G[a * 6:a * 6 + 6, a * 6:a * 6 + 6] += Cab
-            if b >= 0:
-                B[b * 6:b * 6 + 6] -= CD[k]
-                G[b * 6:b * 6 + 6, b * 6:b * 6 + 6] += Cab
-            if a >= 0 and b >= 0:
-                G[a * 6:a * 6 + 6, b * 6:b * 6 + 6] -= Cab
-                G[b * 6:b * 6 + 6, a * 6:a * 6 + 6] -= Cab
-    if group is not None or _dist_ready():
-        G, B = allreduce_GB(G, B, group, device)
-    X = _s.solveSparseCholesky(G, B)
+    X = lum_reduce_solve(gr, mine, Cm, CD, world, group, device)
     tm = np.ascontiguousarray(np.stack([s.transMat for s in allScans[:nscans]]))
     da = np.ascontiguousarray(np.stack([s.dalignxf for s in allScans[:nscans]]))
     rp = np.ascontiguousarray(np.stack([s.rPos for s in allScans[:nscans]]))

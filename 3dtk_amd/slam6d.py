@@ -114,7 +114,10 @@ class KDtree:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().tdtk_tree_destroy(h)
+            try:
+                lib().tdtk_tree_destroy(h)
+            except Exception:      # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     def info(self):
@@ -224,7 +227,10 @@ class Scan:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().tdtk_scan_destroy(h)
+            try:
+                lib().tdtk_scan_destroy(h)
+            except Exception:      # interpreter shutdown
+                pass
             self._h = None
 
     # accessors named as in scan.h

@@ -316,8 +316,8 @@ def bench_graphslam(args, rank, world, local):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="default: 100 (icp) / 10 (graphslam)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 10 (icp) / 3 (graphslam)")
     ap.add_argument("--workload", choices=["auto", "icp", "graphslam"], default="auto")
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--scans", type=int, default=64)
@@ -330,8 +330,12 @@ def main():
     wl = args.workload
     if wl == "auto":
         wl = "icp" if world == 1 else "graphslam"
-    if wl == "graphslam" and args.steps == 100 and args.warmup == 10:
-        args.steps, args.warmup = 10, 3                # a LUM step is ~84 whole-scan passes
+    # explicit --steps / --warmup are always honoured; the defaults depend on the workload
+    # (a LUM step is ~84 whole-scan passes, an ICP step is one)
+    if args.steps is None:
+        args.steps = 100 if wl == "icp" else 10
+    if args.warmup is None:
+        args.warmup = 10 if wl == "icp" else 3
     res = bench_icp(args, rank, world, local) if wl == "icp" else bench_graphslam(args, rank, world, local)
     if rank == 0:
         print(json.dumps(res))

@@ -218,6 +218,15 @@ int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double
                          tdtk_scan* const* second, double max_dist_match2, uint32_t want,
                          tdtk_pair_sums* sums);
 
+/* FillGB3D's scatter-add of every link's (C, CD) into the dense G (6(n-1))^2 / B 6(n-1), in link order
+ * (lum6Deuler.cc:285-300), then graphSlam6D::solveSparseCholesky (graphSlam6D.cc:345-379) -> X.
+ * from/to are scan numbers (0 = the fixed scan).  With links sharded over ranks, all-reduce the
+ * per-link blocks (42 doubles each, zeros for links a rank does not own) and call this on every
+ * rank: the result does not depend on the number of ranks.  G_out / B_out nullable.            */
+int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, const double* C /*[nlinks][36]*/,
+                            const double* CD /*[nlinks][6]*/, int nscans, double* X /*[6(nscans-1)]*/,
+                            double* G_out, double* B_out);
+
 /* Pose update of lum6DEuler::doGraphSlam6D (lum6Deuler.cc:378-473) for scans 1..n-1:
  * result = Ha^-1 * X_i, pose -= result, Scan::transformToEuler (scan.cc:1061-1083: transform by
  * M4inv(transMat), then by EulerToMatrix4(new pose)).  transMat/dalignxf/rPos/rPosTheta are

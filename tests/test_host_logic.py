@@ -254,6 +254,14 @@ _GLOO_WORKER = textwrap.dedent("""
         def getNrLinks(self): return len(links)
         def getLink(self, i, ft): return links[i][ft]
     link_fn = lambda a, b, md2: io.covariance_euler(a, b, md2)[:2]
+    # the exchange step of the native path: per-link blocks, one all-reduce, C-side scatter + solve
+    rank, wsz = dist.get_rank(), dist.get_world_size()
+    mine = gs.shard_links(Gr(), rank, wsz)
+    blk = [link_fn(scans[links[i][0]], scans[links[i][1]], 9.0) for i in mine]
+    Cm = np.array([b[0].reshape(36) for b in blk]).reshape(len(mine), 36)
+    CD = np.array([b[1] for b in blk]).reshape(len(mine), 6)
+    X = gs.lum_reduce_solve(Gr(), mine, Cm, CD, wsz)
+    np.save(os.path.join(%(tmp)r, "X%%d.npy" %% rank), X)
     ret = gs.lum_iteration(Gr(), scans, 9.0, None, link_fn, None, io.solve_sparse_cholesky)
     out = np.concatenate([[ret]] + [np.concatenate([s.rPos, s.rPosTheta]) for s in scans])
     np.save(os.path.join(%(tmp)r, "rank%%d.npy" %% dist.get_rank()), out)
@@ -286,7 +294,11 @@ def test_lum_links_sharded_over_two_ranks_gloo(tmp_path, orc):
         drift = ([p[0] + 0.3 * k, p[1] - 0.2 * k, p[2] + 0.1 * k], [th[0], th[1] + 0.002 * k, th[2]])
         scans.append(io.OScan(drift[0], drift[1], loc + rng.normal(0, 0.02, loc.shape)))
     links = [(0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (0, 3), (1, 4)]
-    ret, _, _, _ = io.lum_iteration(links, scans, 9.0)
+    ret, _, _, Xo = io.lum_iteration(links, scans, 9.0)
+    # per-link all-reduce + tdtk_lum_assemble_solve: bit-identical on both ranks, equal to the oracle's X
+    X0, X1 = np.load(tmp_path / "X0.npy"), np.load(tmp_path / "X1.npy")
+    assert np.array_equal(X0, X1)
+    np.testing.assert_allclose(X0, Xo, rtol=1e-8, atol=1e-11)
     single = np.concatenate([[ret]] + [np.concatenate([s.rPos, s.rPosTheta]) for s in scans])
     np.testing.assert_allclose(r0, single, rtol=1e-9, atol=1e-10)
     # the iteration must actually pull the drifted poses towards the truth
@@ -401,3 +413,37 @@ def test_oracle_octree_center_against_grid_formulation(orc):
         assert got.shape == want.shape
         assert np.allclose(got, want, rtol=0, atol=1e-9 * size)
     assert len(orc.octree_center(np.zeros((0, 3)), 1.0)) == 0
+
+
+def test_lum_assemble_solve_matches_dense_fill(tdtk):
+    """tdtk_lum_assemble_solve == FillGB3D's scatter (numpy restatement) + dense solve, including links
+    that start or end at the fixed scan 0 and links in both directions."""
+    capi = sys.modules["3dtk_amd._capi"]
+    rng = np.random.default_rng(4)
+    nscans = 6
+    links = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 5), (3, 0), (5, 2), (1, 4)]
+    Cs, CDs = [], []
+    for _ in links:
+        A = rng.normal(size=(6, 6))
+        Cs.append(A @ A.T + 6 * np.eye(6)); CDs.append(rng.normal(size=6))
+    n = nscans - 1
+    G = np.zeros((6 * n, 6 * n)); B = np.zeros(6 * n)
+    for (fa, fb), Cab, CDab in zip(links, Cs, CDs):
+        a, b = fa - 1, fb - 1
+        if a >= 0:
+            B[a * 6:a * 6 + 6] += CDab; G[a * 6:a * 6 + 6, a * 6:a * 6 + 6] += Cab
+        if b >= 0:
+            B[b * 6:b * 6 + 6] -= CDab; G[b * 6:b * 6 + 6, b * 6:b * 6 + 6] += Cab
+        if a >= 0 and b >= 0:
+            G[a * 6:a * 6 + 6, b * 6:b * 6 + 6] -= Cab; G[b * 6:b * 6 + 6, a * 6:a * 6 + 6] -= Cab
+    frm = np.array([l[0] for l in links], np.int32); to = np.array([l[1] for l in links], np.int32)
+    Call = np.ascontiguousarray(np.array(Cs).reshape(len(links), 36)); CDall = np.ascontiguousarray(np.array(CDs))
+    X = np.empty(6 * n); Go = np.empty((6 * n, 6 * n)); Bo = np.empty(6 * n)
+    capi.check(capi.lib().tdtk_lum_assemble_solve(len(links), capi.iptr(frm), capi.iptr(to), capi.dptr(Call),
+                                                  capi.dptr(CDall), nscans, capi.dptr(X), capi.dptr(Go), capi.dptr(Bo)))
+    assert np.array_equal(Go, G) and np.array_equal(Bo, B)
+    np.testing.assert_allclose(X, np.linalg.solve(np.where(np.abs(G) > 1e-5, G, 0.0), B), rtol=1e-10, atol=1e-12)
+    with pytest.raises(tdtk.TdtkError):
+        bad = np.array([7] + [0] * (len(links) - 1), np.int32)
+        capi.check(capi.lib().tdtk_lum_assemble_solve(len(links), capi.iptr(bad), capi.iptr(to), capi.dptr(Call),
+                                                      capi.dptr(CDall), nscans, capi.dptr(X), None, None))
