@@ -251,6 +251,15 @@ def bench_icp(args, rank, world, local):
     }
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0)
+    if world == 1 and args.workload == "auto" and not args.no_graphslam_base:
+        # the 1-GPU point of the graph-SLAM strong-scaling curve (the N>1 runs of this script measure
+        # configs[3]); reported beside the headline so scaling can be read against the same workload
+        del model, data, tree
+        import copy
+        ga = copy.copy(args); ga.steps, ga.warmup = 10, 3
+        g1 = bench_graphslam(ga, rank, world, local)
+        out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s")}
+        out["graphslam_1gpu"]["workload"] = g1["config"]["workload"]
     return out
 
 
@@ -303,8 +312,8 @@ def bench_graphslam(args, rank, world, local):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "configs[3]: synthetic %d scans x %d pts, graph-SLAM -G 1 (lum6DEuler) one iteration per "
-                               "step, %d links round-robin over %d ranks, one fp64 all-reduce of %d doubles"
-                               % (nscans, npts, nlinks, world, (6 * (nscans - 1)) ** 2 + 6 * (nscans - 1)),
+                               "step, %d links dealt over %d ranks, one fp64 all-reduce of %d doubles (42 per link)"
+                               % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
         "lum_iters_per_s": args.steps / dt, "last_ret": ret,
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -322,6 +331,8 @@ def main():
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--scans", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-graphslam-base", action="store_true",
+                    help="N=1 only: skip the extra 1-GPU graph-SLAM measurement (the base of the N>1 curve)")
     args = ap.parse_args()
     capi = importlib.import_module("3dtk_amd._capi")
     if not os.path.exists(os.path.join(ROOT, "3dtk_amd", "lib3dtk_hip.so")):
