@@ -32,7 +32,7 @@ class PairSums(C.Structure):
                 ("lum", C.c_double * 15), ("lum_sumd2", C.c_double),
                 ("gapx_MkMkt", C.c_double * 9), ("gapx_DkDkt", C.c_double * 9), ("gapx_MkDkt", C.c_double * 9),
                 ("gapx_DkMkt", C.c_double * 9), ("gapx_Ak1", C.c_double * 3), ("gapx_Ak2", C.c_double * 3),
-                ("mom_mm", C.c_double * 6), ("mom_dd", C.c_double * 6)]
+                ("mom_mm", C.c_double * 6), ("mom_dd", C.c_double * 6), ("lum_udot", C.c_double)]
 
 
 class TreeInfo(C.Structure):
@@ -57,7 +57,7 @@ EXPORTS = [
     "tdtk_tree_get_info", "tdtk_tree_verify", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
-    "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_solve_spd",
+    "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_scans_transform2", "tdtk_solve_spd",
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
     "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
@@ -142,6 +142,7 @@ def lib():
     L.tdtk_host_mmult.argtypes = [_dp, _dp, _dp]
     L.tdtk_host_mmult.restype = None
     L.tdtk_lum_assemble_solve.argtypes = [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, _dp, _dp]
+    L.tdtk_scans_transform2.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, _dp]
     L.tdtk_reduce_octree.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp, C.POINTER(C.c_size_t)]
     L.tdtk_io_read_uos.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(_dp), C.POINTER(C.c_size_t)]
     L.tdtk_io_free.argtypes = [C.c_void_p]

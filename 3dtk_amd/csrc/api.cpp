@@ -363,8 +363,10 @@ static void finish_sums(const double* acc, const double shift[3], size_t nq, uns
     }
     o->napx_sum = acc[ACC_NS];
   }
-  if (want & TDTK_WANT_LUM)
+  if (want & TDTK_WANT_LUM) {
     for (int k = 0; k < 15; k++) o->lum[k] = acc[ACC_L + k];
+    o->lum_udot = acc[ACC_LU];
+  }
   if (want & TDTK_WANT_MOM2) {
     // second moments about the respective centroids
     const double* mm = acc + ACC_MM;
@@ -1353,6 +1355,37 @@ int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, 
   return TDTK_OK;
 }
 
+// many resident scans moved in place by A1 and then (optionally) A2, one launch
+int tdtk_scans_transform2(int count, tdtk_scan* const* scans, const double* A1, const double* A2)
+{
+  if (count < 0 || (count && (!scans || !A1))) { set_error("bad argument"); return TDTK_EINVAL; }
+  Ctx* c = nullptr;
+  std::vector<Xf2Desc> moves;
+  size_t max_n = 0;
+  for (int i = 0; i < count; i++) {
+    tdtk_scan* sc = scans[i];
+    if (!sc || !sc->N) continue;
+    if (!c) { int rc = get_ctx(sc->device, &c); if (rc) return rc; }
+    if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
+    Xf2Desc d;
+    d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
+    std::memcpy(d.A1.m, A1 + 16 * (size_t)i, sizeof d.A1.m);
+    d.has2 = A2 ? 1 : 0;
+    if (A2) std::memcpy(d.A2.m, A2 + 16 * (size_t)i, sizeof d.A2.m);
+    else m4identity(d.A2.m);
+    moves.push_back(d);
+    if (sc->N > max_n) max_n = sc->N;
+  }
+  if (!c || moves.empty()) return TDTK_OK;
+  const size_t bytes = moves.size() * sizeof(Xf2Desc);
+  int rc = c->ws[WS_TMPB].ensure(bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, moves.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(launch_transform2_batch(c->ws[WS_TMPB].as<Xf2Desc>(), (int)moves.size(), max_n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return TDTK_OK;
+}
+
 int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double* dalignxf, double* rPos,
                           double* rPosTheta, tdtk_scan* const* scans, double* xf_out, double* ret)
 {
@@ -1408,6 +1441,7 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
       d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
       std::memcpy(d.A1.m, tinv, sizeof tinv);
       std::memcpy(d.A2.m, axf, sizeof axf);
+      d.has2 = 1;
       moves.push_back(d);
       if (sc->N > max_n) max_n = sc->N;
     }

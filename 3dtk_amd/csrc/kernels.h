@@ -48,8 +48,9 @@ enum {
   ACC_NS = 50,   // 1: sum ((p1-p2).n)^2
   ACC_L = 51,    // 15: lum6DEuler sums                              [LUM]
   ACC_LSS = 66,  // 1: residual^2 against D (second pass)
-  ACC_MM = 67,   // 6: sum (m - shift)_a (m - shift)_b, upper       [GAPX, with ACC_DD]
-  ACC_TOTAL = 73
+  ACC_MM = 67,   // 6: sum (m - shift)_a (m - shift)_b, upper       [GAPX / MOM2, with ACC_DD]
+  ACC_LU = 73,   // 1: sum u.delta, u = (p1+p2)/2, delta = p1-p2     [LUM; lum6DQuat's MZ(4)]
+  ACC_TOTAL = 74
 };
 
 struct AccumArgs {
@@ -132,6 +133,7 @@ struct Xf2Desc {
   double *x, *y, *z, *nx, *ny, *nz;
   size_t n;
   Mat4 A1, A2;
+  int has2;   // apply A2 after A1
 };
 hipError_t launch_transform2_batch(const Xf2Desc* d_desc, int count, size_t max_n, hipStream_t s);
 

@@ -853,6 +853,7 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
       acc[ACC_L + 12] += -z * dy + y * dz;
       acc[ACC_L + 13] += -y * dx + x * dy;
       acc[ACC_L + 14] += z * dx - x * dz;
+      acc[ACC_LU] += x * dx + y * dy + z * dz;   // lum6Dquat.cc:163
       if (a.has_D) {  // second pass: residual against the solved D (lum6Deuler.cc:199-210)
         const double e0 = dx - (a.D[0] - y * a.D[4] + z * a.D[5]);
         const double e1 = dy - (a.D[1] - z * a.D[3] + x * a.D[4]);
@@ -868,8 +869,8 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   for (int k = 0; k < ACC_TOTAL; k++) {
     const bool used = (k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
                       ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
-                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L && k < ACC_MM) ||
-                      ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM);
+                      ((WANT & TDTK_WANT_LUM) && ((k >= ACC_L && k < ACC_MM) || k == ACC_LU)) ||
+                      ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM && k < ACC_LU);
     if (!used) continue;
     const double s = wave_sum(acc[k]);
     if (lane == 0) red[wv][k] = s;
@@ -878,8 +879,8 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
     const bool used = (k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
                       ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
-                      ((WANT & TDTK_WANT_LUM) && k >= ACC_L && k < ACC_MM) ||
-                      ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM);
+                      ((WANT & TDTK_WANT_LUM) && ((k >= ACC_L && k < ACC_MM) || k == ACC_LU)) ||
+                      ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM && k < ACC_LU);
     double s = 0.0;
     if (used)
       for (int w = 0; w < NW; w++) s += red[w][k];
@@ -934,12 +935,12 @@ __global__ void __launch_bounds__(256) k_transform2_batch(const Xf2Desc* __restr
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
     double px = d.x[i], py = d.y[i], pz = d.z[i];
     dev_xf3_inplace(d.A1, px, py, pz);
-    dev_xf3_inplace(d.A2, px, py, pz);
+    if (d.has2) dev_xf3_inplace(d.A2, px, py, pz);
     d.x[i] = px; d.y[i] = py; d.z[i] = pz;
     if (d.nx) {
       double ax = d.nx[i], ay = d.ny[i], az = d.nz[i];
       dev_xf3normal(d.A1, ax, ay, az);
-      dev_xf3normal(d.A2, ax, ay, az);
+      if (d.has2) dev_xf3normal(d.A2, ax, ay, az);
       d.nx[i] = ax; d.ny[i] = ay; d.nz[i] = az;
     }
   }

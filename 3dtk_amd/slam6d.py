@@ -75,6 +75,65 @@ def Matrix4ToEuler(alignxf):
     return np.array(th), np.array([alignxf[12], alignxf[13], alignxf[14]])
 
 
+def QuatToMatrix4(quat, t=None):
+    """globals.icc:988-1022"""
+    q11, q22, q33 = quat[1] * quat[1], quat[2] * quat[2], quat[3] * quat[3]
+    q03, q13, q23 = quat[0] * quat[3], quat[1] * quat[3], quat[2] * quat[3]
+    q02, q12, q01 = quat[0] * quat[2], quat[1] * quat[2], quat[0] * quat[1]
+    m = np.zeros(16)
+    m[0] = 1 - 2 * (q22 + q33); m[5] = 1 - 2 * (q11 + q33); m[10] = 1 - 2 * (q11 + q22)
+    m[4] = 2.0 * (q12 - q03); m[1] = 2.0 * (q12 + q03)
+    m[8] = 2.0 * (q13 + q02); m[2] = 2.0 * (q13 - q02)
+    m[9] = 2.0 * (q23 - q01); m[6] = 2.0 * (q23 + q01)
+    if t is not None:
+        m[12:15] = t
+    m[15] = 1.0
+    return m
+
+
+def Matrix4ToQuat(mat):
+    """globals.icc:1032-1075 -> (quat[4] normalised, t[3])"""
+    T = 1 + mat[0] + mat[5] + mat[10]
+    if T > 0.00000001:
+        S = math.sqrt(T) * 2
+        X = (mat[9] - mat[6]) / S; Y = (mat[2] - mat[8]) / S; Z = (mat[4] - mat[1]) / S; W = 0.25 * S
+    elif mat[0] > mat[5] and mat[0] > mat[10]:
+        S = math.sqrt(1.0 + mat[0] - mat[5] - mat[10]) * 2
+        X = 0.25 * S; Y = (mat[4] + mat[1]) / S; Z = (mat[2] + mat[8]) / S; W = (mat[9] - mat[6]) / S
+    elif mat[5] > mat[10]:
+        S = math.sqrt(1.0 + mat[5] - mat[0] - mat[10]) * 2
+        X = (mat[4] + mat[1]) / S; Y = 0.25 * S; Z = (mat[9] + mat[6]) / S; W = (mat[2] - mat[8]) / S
+    else:
+        S = math.sqrt(1.0 + mat[10] - mat[0] - mat[5]) * 2
+        X = (mat[2] + mat[8]) / S; Y = (mat[9] + mat[6]) / S; Z = 0.25 * S; W = (mat[4] - mat[1]) / S
+    q = np.array([W, -X, -Y, -Z])
+    return q / math.sqrt(float(q @ q)), np.array(mat[12:15], dtype=np.float64)
+
+
+def transform_many(scans, A1, A2=None, type="LUM"):
+    """Scan::transform for many scans at once: scan i is moved by A1[i], then A2[i] (the two steps of
+    transformToEuler / transformToQuat).  Matrices and frames are updated per scan exactly as
+    Scan::transform does (the first step is the INVALID-type one when A2 is given); the resident point
+    sets move in ONE launch (tdtk_scans_transform2); non-resident scans queue the matrices."""
+    res = [i for i, s in enumerate(scans) if s._h is not None]
+    if res:
+        hs = (C.c_void_p * len(res))(*[scans[i]._h for i in res])
+        a1 = np.ascontiguousarray(np.stack([f64(A1[i], 16) for i in res]))
+        a2 = np.ascontiguousarray(np.stack([f64(A2[i], 16) for i in res])) if A2 is not None else None
+        check(lib().tdtk_scans_transform2(len(res), hs, dptr(a1), dptr(a2) if a2 is not None else None))
+    for i, s in enumerate(scans):
+        a = f64(A1[i], 16).copy()
+        if s._h is None:
+            s._queue.append(a)
+        s._transformMatrix(a)
+        if A2 is not None:
+            b = f64(A2[i], 16).copy()
+            if s._h is None:
+                s._queue.append(b)
+            s._transformMatrix(b)
+        s.frames.append((s.transMat.copy(), type))
+
+
 def host_tree_layout(xyz, bucketSize=20):
     """Host tree builder only (no device): leaf-order permutation + stats."""
     xyz = f64(xyz).reshape(-1, 3)
@@ -307,6 +366,16 @@ class Scan:
         tinv = M4inv(self.transMat)
         self.transform(tinv, "INVALID")
         self.transform(EulerToMatrix4(rP, rPT), type, islum)
+
+    def get_rPosQuat(self):
+        """rQuat, kept equal to Matrix4ToQuat(transMat) by Scan::transformMatrix (scan.cc:886)."""
+        return Matrix4ToQuat(self.transMat)[0]
+
+    def transformToQuat(self, rP, rPQ, type="LUM", islum=1):
+        """scan.cc:1093-1104."""
+        tinv = M4inv(self.transMat)
+        self.transform(tinv, "INVALID")
+        self.transform(QuatToMatrix4(rPQ, rP), type, islum)
 
     def mergeCoordinatesWithRoboterPosition(self, prevScan):
         """scan.cc:826-833 (pose extrapolation)."""
@@ -698,6 +767,50 @@ class lum6DEuler:
                 ret = lum_iteration_native(gr, allScans, self.max_dist_match2_LUM, self.group, device)
             else:
                 ret = lum_iteration(gr, allScans, self.max_dist_match2_LUM, self.group, None, device)
+            it += 1
+        return ret
+
+
+class lum6DQuat:
+    """lum6DQuat (-G 2, src/slam6d/lum6Dquat.cc): LUM with 7 unknowns per scan (translation +
+    quaternion).  Links sharded / reduced like lum6DEuler."""
+
+    def __init__(self, my_icp=None, mdm=25.0, max_dist_match_LUM=25.0, max_num_iterations=50, quiet=True,
+                 epsilonLUM=0.5, group=None):
+        self.my_icp = my_icp
+        self.max_dist_match2_LUM = max_dist_match_LUM * max_dist_match_LUM
+        self.epsilonLUM = epsilonLUM
+        self.group = group
+
+    def doGraphSlam6D(self, gr, allScans, nrIt, device=None):
+        from .graphslam import lumquat_iteration
+        ret = float("inf")
+        it = 0
+        while it < nrIt and ret > self.epsilonLUM:
+            ret = lumquat_iteration(gr, allScans, self.max_dist_match2_LUM, self.group, device)
+            it += 1
+        return ret
+
+
+class ghelix6DQ2:
+    """ghelix6DQ2 (-G 3, src/slam6d/ghelix6DQ2.cc): simultaneous registration with the helical-motion
+    linearisation; B and bd are zeroed once per doGraphSlam6D call, not per iteration (:329-330)."""
+
+    def __init__(self, my_icp=None, mdm=25.0, max_dist_match_LUM=25.0, max_num_iterations=50, quiet=True,
+                 epsilonLUM=0.5, group=None):
+        self.my_icp = my_icp
+        self.max_dist_match2_LUM = max_dist_match_LUM * max_dist_match_LUM
+        self.epsilonLUM = epsilonLUM
+        self.group = group
+
+    def doGraphSlam6D(self, gr, allScans, nrIt, device=None):
+        from .graphslam import ghelix_iteration
+        n = gr.getNrScans() - 1
+        state = (np.zeros((6 * n, 6 * n)), np.zeros(6 * n))
+        ret = float("inf")
+        it = 0
+        while it < nrIt and ret > self.epsilonLUM:
+            ret = ghelix_iteration(gr, allScans, self.max_dist_match2_LUM, state, self.group, device)
             it += 1
         return ret
 

@@ -85,6 +85,7 @@ typedef struct tdtk_pair_sums {
   double gapx_Ak1[3], gapx_Ak2[3];
   double mom_mm[6];      /* sum (p1-cm)(p1-cm)^T: xx xy xz yy yz zz        [TDTK_WANT_MOM2]   */
   double mom_dd[6];      /* sum (p2-cd)(p2-cd)^T                                              */
+  double lum_udot;       /* sum u.delta (lum6DQuat's MZ(4), lum6Dquat.cc:163)     [TDTK_WANT_LUM]  */
 } tdtk_pair_sums;
 
 typedef struct tdtk_tree_info {
@@ -217,6 +218,12 @@ int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* firs
 int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
                          tdtk_scan* const* second, double max_dist_match2, uint32_t want,
                          tdtk_pair_sums* sums);
+
+/* Scan::transform for many resident scans at once: scan i is moved in place by A1[i] and then by A2[i]
+ * (A2 nullable), e.g. Scan::transformToEuler / transformToQuat (scan.cc:1061-1104) = M4inv(transMat) then
+ * the new pose; one kernel launch for all of them.                                               */
+int tdtk_scans_transform2(int count, tdtk_scan* const* scans, const double* A1 /*[count][16]*/,
+                          const double* A2 /*[count][16] or NULL*/);
 
 /* FillGB3D's scatter-add of every link's (C, CD) into the dense G (6(n-1))^2 / B 6(n-1), in link order
  * (lum6Deuler.cc:285-300), then graphSlam6D::solveSparseCholesky (graphSlam6D.cc:345-379) -> X.

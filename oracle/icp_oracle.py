@@ -123,6 +123,21 @@ def matrix4_to_quat(mat):
     return q / math.sqrt(float(q @ q)), np.array(mat[12:15], float)
 
 
+def quat_to_matrix4(quat, t):
+    """QuatToMatrix4 (globals.icc:988-1022), column-major"""
+    q11, q22, q33 = quat[1] * quat[1], quat[2] * quat[2], quat[3] * quat[3]
+    q03, q13, q23 = quat[0] * quat[3], quat[1] * quat[3], quat[2] * quat[3]
+    q02, q12, q01 = quat[0] * quat[2], quat[1] * quat[2], quat[0] * quat[1]
+    m = np.zeros(16)
+    m[0] = 1 - 2 * (q22 + q33); m[5] = 1 - 2 * (q11 + q33); m[10] = 1 - 2 * (q11 + q22)
+    m[4] = 2.0 * (q12 - q03); m[1] = 2.0 * (q12 + q03)
+    m[8] = 2.0 * (q13 + q02); m[2] = 2.0 * (q13 - q02)
+    m[9] = 2.0 * (q23 - q01); m[6] = 2.0 * (q23 + q01)
+    m[12:15] = t
+    m[15] = 1.0
+    return m
+
+
 def _skew(v):
     return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], float)
 
@@ -461,6 +476,16 @@ class OScan:
         tmp, _ok = orc.m4inv(prev.transMatOrg)
         self.transform(orc.mmult(prev.transMat, tmp))
 
+    def get_rPosQuat(self):
+        """rQuat = Matrix4ToQuat(transMat), kept current by Scan::transformMatrix (scan.cc:886)"""
+        return matrix4_to_quat(self.transMat)[0]
+
+    def transformToQuat(self, rP, rPQ, *_):
+        """scan.cc:1093-1104"""
+        tinv, _ok = orc.m4inv(self.transMat)
+        self.transform(tinv)
+        self.transform(quat_to_matrix4(rPQ, rP))
+
 
 def rand_keep_mask(n, rnd):
     """`if (rnd > 1 && rand(rnd) != 0) continue;` (searchTree.cc:118) with rand(int) of
@@ -667,6 +692,158 @@ def lum_iteration(links, scans, maxdist2):
         scans[i].transformToEuler(rP, rPT)
         tot += dl
     return tot / len(scans), G, B, X
+
+
+# ---------------------------------------------------------------------------------------
+# lum6DQuat (-G 2), src/slam6d/lum6Dquat.cc   (parity unpinned: the TU needs scan.h -> Boost)
+# ---------------------------------------------------------------------------------------
+def covariance_quat(first, second, maxdist2):
+    """lum6DQuat::covarianceQuat (lum6Dquat.cc:81-248) -> (C 7x7, CD 7, m, ss)"""
+    r = get_pt_pairs(first, second, maxdist2)
+    m = r["n"]
+    C = np.zeros((7, 7)); CD = np.zeros(7)
+    if m <= 2:
+        return C, CD, m, 0.0
+    a, b = r["p1"], r["p2"]
+    u = (a + b) / 2.0
+    x, y, z = u[:, 0], u[:, 1], u[:, 2]
+    d = a - b
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    sx, sy, sz = x.sum(), y.sum(), z.sum()
+    MZ = np.array([dx.sum(), dy.sum(), dz.sum(), (x * dx + y * dy + z * dz).sum(), (z * dy - y * dz).sum(),
+                   (x * dz - z * dx).sum(), (y * dx - x * dy).sum()])
+    MM = np.zeros((7, 7))
+    MM[0, 0] = MM[1, 1] = MM[2, 2] = m
+    MM[3, 3] = (x * x + y * y + z * z).sum(); MM[4, 4] = (y * y + z * z).sum()
+    MM[5, 5] = (x * x + z * z).sum(); MM[6, 6] = (x * x + y * y).sum()
+    MM[0, 3] = MM[3, 0] = sx; MM[0, 5] = MM[5, 0] = -sz; MM[0, 6] = MM[6, 0] = sy
+    MM[1, 3] = MM[3, 1] = sy; MM[1, 4] = MM[4, 1] = sz;  MM[1, 6] = MM[6, 1] = -sx
+    MM[2, 3] = MM[3, 2] = sz; MM[2, 4] = MM[4, 2] = -sy; MM[2, 5] = MM[5, 2] = sx
+    MM[4, 5] = MM[5, 4] = -(x * y).sum(); MM[4, 6] = MM[6, 4] = -(x * z).sum(); MM[5, 6] = MM[6, 5] = -(y * z).sum()
+    D = np.linalg.solve(MM, MZ)
+    e0 = dx - (D[0] + x * D[3] - z * D[5] + y * D[6])
+    e1 = dy - (D[1] + y * D[3] + z * D[4] - x * D[6])
+    e2 = dz - (D[2] + z * D[3] - y * D[4] + x * D[5])
+    ss = float((e0 * e0 + e1 * e1 + e2 * e2).sum()) / (2 * m - 3)
+    ssi = 1.0 / ss
+    return MM * ssi, MZ * ssi, m, ss
+
+
+def lumquat_pose_update(scan, Xi):
+    """lum6Dquat.cc:347-432 -> (rPos, rPosQuat normalised, |dxyz|)"""
+    xa, ya, za = scan.get_rPos()
+    p, q, r, s = scan.get_rPosQuat()
+    px, py, pz = p * xa, p * ya, p * za
+    qx, qy, qz = q * xa, q * ya, q * za
+    rx, ry, rz = r * xa, r * ya, r * za
+    sx, sy, sz = s * xa, s * ya, s * za
+    Ha = np.eye(7)
+    Ha[3, 3] = 2 * p; Ha[4, 3] = 2 * q; Ha[5, 3] = 2 * r; Ha[6, 3] = 2 * s
+    Ha[3, 4] = 2 * q; Ha[4, 4] = -2 * p; Ha[5, 4] = -2 * s; Ha[6, 4] = 2 * r
+    Ha[3, 5] = 2 * r; Ha[4, 5] = 2 * s; Ha[5, 5] = -2 * p; Ha[6, 5] = -2 * q
+    Ha[3, 6] = 2 * s; Ha[4, 6] = -2 * r; Ha[5, 6] = 2 * q; Ha[6, 6] = -2 * p
+    Ha[0, 3] = -2 * (px + sy - rz); Ha[1, 3] = -2 * (-sx + py + qz); Ha[2, 3] = -2 * (rx - qy + pz)
+    Ha[0, 4] = -2 * (qx + ry + sz); Ha[1, 4] = -2 * (-rx + qy - pz); Ha[2, 4] = -2 * (-sx + py + qz)
+    Ha[0, 5] = -2 * (rx - qy + pz); Ha[1, 5] = -2 * (qx + ry + sz);  Ha[2, 5] = -2 * (-px - sy + rz)
+    Ha[0, 6] = -2 * (sx - py - qz); Ha[1, 6] = -2 * (px + sy - rz);  Ha[2, 6] = -2 * (qx + ry + sz)
+    result = np.linalg.solve(Ha, Xi)
+    rPos = scan.get_rPos() - result[:3]
+    quat = np.array([p, q, r, s]) - result[3:]
+    quat = quat / math.sqrt(float(quat @ quat))
+    return rPos, quat, float(np.linalg.norm(result[:3]))
+
+
+def lumquat_iteration(links, scans, maxdist2):
+    """one iteration of lum6DQuat::doGraphSlam6D (lum6Dquat.cc:319-481); FillGB3D (:248-276) ASSIGNS the
+    off-diagonal blocks (`= -Cab`), so of several links between the same two scans the last one wins there."""
+    n = len(scans) - 1
+    G = np.zeros((7 * n, 7 * n)); B = np.zeros(7 * n)
+    for (fa, fb) in links:
+        a, b = fa - 1, fb - 1
+        Cab, CDab = covariance_quat(scans[fa], scans[fb], maxdist2)[:2]
+        if a >= 0:
+            B[a * 7:a * 7 + 7] += CDab; G[a * 7:a * 7 + 7, a * 7:a * 7 + 7] += Cab
+        if b >= 0:
+            B[b * 7:b * 7 + 7] -= CDab; G[b * 7:b * 7 + 7, b * 7:b * 7 + 7] += Cab
+        if a >= 0 and b >= 0:
+            G[a * 7:a * 7 + 7, b * 7:b * 7 + 7] = -Cab; G[b * 7:b * 7 + 7, a * 7:a * 7 + 7] = -Cab
+    X = solve_sparse_cholesky(G, B)
+    tot = 0.0
+    for i in range(1, len(scans)):
+        rP, rQ, dl = lumquat_pose_update(scans[i], X[(i - 1) * 7:(i - 1) * 7 + 7])
+        scans[i].transformToQuat(rP, rQ)
+        tot += dl
+    return tot / len(scans), G, B, X
+
+
+# ---------------------------------------------------------------------------------------
+# ghelix6DQ2 (-G 3), src/slam6d/ghelix6DQ2.cc   (parity unpinned, as above)
+# ---------------------------------------------------------------------------------------
+def helix_compute_rt(ccs):
+    """icp6D_HELIX::computeRt (icp6Dhelix.cc:144-206) for one 6-vector"""
+    c, cs = -ccs[:3], -ccs[3:]
+    CLength = math.sqrt(float(c @ c))
+    rotationCheck = float(c @ cs)
+    angle = math.atan(CLength)
+    g = c / CLength
+    sinA = math.sin(-angle / 2)
+    b0, b1, b2, b3 = math.cos(-angle / 2), g[0] * sinA, g[1] * sinA, g[2] * sinA
+    R = np.array([[b0 * b0 + b1 * b1 - b2 * b2 - b3 * b3, 2 * (b1 * b2 + b0 * b3), 2 * (b1 * b3 - b0 * b2)],
+                  [2 * (b1 * b2 - b0 * b3), b0 * b0 - b1 * b1 + b2 * b2 - b3 * b3, 2 * (b2 * b3 + b0 * b1)],
+                  [2 * (b1 * b3 + b0 * b2), 2 * (b2 * b3 - b0 * b1), b0 * b0 - b1 * b1 - b2 * b2 + b3 * b3]])
+    R = R / (b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3)
+    skew = rotationCheck / (CLength * CLength)
+    gs = (cs - c * skew) / CLength
+    pT = np.cross(g, gs)
+    t = R @ -pT + g * (skew * angle) + pT
+    return _rt_to_gl(R, t)
+
+
+def ghelix_link_blocks(p1, p2):
+    """the per-link sums of ghelix6DQ2::genBBdForLinkedPair (ghelix6DQ2.cc:88-150):
+    -> (n, Blk 6x6 symmetric, bd1 6, bd2 6)"""
+    n = len(p1)
+    x2, y2, z2 = p2[:, 0], p2[:, 1], p2[:, 2]
+    b40, b50, b42 = (-z2).sum(), y2.sum(), x2.sum()
+    Blk = np.zeros((6, 6))
+    Blk[3, 3] = Blk[4, 4] = Blk[5, 5] = n
+    Blk[0, 4] = Blk[4, 0] = b40;  Blk[1, 3] = Blk[3, 1] = -b40
+    Blk[0, 5] = Blk[5, 0] = b50;  Blk[2, 3] = Blk[3, 2] = -b50
+    Blk[2, 4] = Blk[4, 2] = b42;  Blk[1, 5] = Blk[5, 1] = -b42
+    Blk[0, 1] = Blk[1, 0] = (y2 * -x2).sum(); Blk[0, 2] = Blk[2, 0] = (-z2 * x2).sum(); Blk[1, 2] = Blk[2, 1] = (z2 * -y2).sum()
+    Blk[0, 0] = (z2 * z2 + y2 * y2).sum(); Blk[1, 1] = (z2 * z2 + x2 * x2).sum(); Blk[2, 2] = (x2 * x2 + y2 * y2).sum()
+    d = p1 - p2
+    bd1 = np.array([(-p1[:, 2] * d[:, 1] + p1[:, 1] * d[:, 2]).sum(), (p1[:, 2] * d[:, 0] - p1[:, 0] * d[:, 2]).sum(),
+                    (-p1[:, 1] * d[:, 0] + p1[:, 0] * d[:, 1]).sum(), d[:, 0].sum(), d[:, 1].sum(), d[:, 2].sum()])
+    bd2 = np.array([(-z2 * -d[:, 1] + y2 * -d[:, 2]).sum(), (z2 * -d[:, 0] - x2 * -d[:, 2]).sum(),
+                    (-y2 * -d[:, 0] + x2 * -d[:, 1]).sum(), -d[:, 0].sum(), -d[:, 1].sum(), -d[:, 2].sum()])
+    return n, Blk, bd1, bd2
+
+
+def ghelix_iteration(links, scans, maxdist2, B=None, bd=None):
+    """one iteration of ghelix6DQ2::doGraphSlam6D (ghelix6DQ2.cc:330-449).  B and bd persist across
+    the iterations of one call (they are zeroed before the loop only, :329-330): pass them back in."""
+    n = len(scans) - 1
+    if B is None:
+        B = np.zeros((6 * n, 6 * n)); bd = np.zeros(6 * n)
+    for (fa, fb) in links:
+        r = get_pt_pairs(scans[fa], scans[fb], maxdist2)
+        if r["n"] <= 1:
+            continue
+        m, Blk, bd1, bd2 = ghelix_link_blocks(r["p1"], r["p2"])
+        a, b = (fa - 1) * 6, (fb - 1) * 6
+        if fa != 0:
+            B[a:a + 6, a:a + 6] += Blk; bd[a:a + 6] += bd1
+        B[b:b + 6, b:b + 6] += Blk; bd[b:b + 6] += bd2
+        if fa != 0:
+            B[a:a + 6, b:b + 6] -= Blk; B[b:b + 6, a:a + 6] -= Blk
+    ccs = solve_sparse_cholesky(B, bd)
+    tot = 0.0
+    for i in range(1, len(scans)):
+        axf = helix_compute_rt(ccs[(i - 1) * 6:(i - 1) * 6 + 6])
+        scans[i].transform(axf)
+        tot += math.sqrt(axf[12] ** 2 + axf[13] ** 2 + axf[14] ** 2)
+    return tot / len(scans), B, bd, ccs
 
 
 # ---------------------------------------------------------------------------------------

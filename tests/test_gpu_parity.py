@@ -648,3 +648,74 @@ def test_clpairs_graph_and_lum_round(tdtk, orc, gpu):
     assert abs(ret - oret) < 1e-7 * max(1.0, oret)
     for s, o in zip(S, O):
         assert np.abs(s.get_rPos() - o.rPos).max() < 1e-7 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-9
+
+
+def _dat_after_icp(tdtk, cls_list):
+    """the bundled scans at the B1 final poses, one copy per class in cls_list"""
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    out = []
+    for cls in cls_list:
+        S = _dat_scans(cls, z)
+        for pr in b1["pairs"]:
+            i = pr["cur"]
+            S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+            for a in pr["alignxf"]:
+                S[i].transform(np.array(a))
+        out.append(S)
+    return out
+
+
+def test_lum6DQuat_iterations_vs_oracle(tdtk, orc, gpu):
+    """-G 2: two lum6DQuat::doGraphSlam6D iterations on dat/ (chain + one closure) against the numpy
+    restatement: ret, poses and moved points."""
+    from oracle import icp_oracle as io
+    S, O = _dat_after_icp(tdtk, [tdtk.Scan, io.OScan])
+    links = [(0, 1), (1, 2), (0, 2)]
+    gr = tdtk.Graph(3, links=links); gr.nrScans = 3
+    slam = tdtk.lum6DQuat(None, 25.0, 25.0, epsilonLUM=-1.0)
+    for _ in range(2):
+        ret = slam.doGraphSlam6D(gr, S, 1)
+        oret = io.lumquat_iteration(links, O, 625.0)[0]
+        assert abs(ret - oret) < 1e-7 * max(1.0, oret)
+    for s, o in zip(S, O):
+        assert _rel(s.get_transMat(), o.transMat) < 1e-8
+        assert np.abs(s.get_xyz_reduced() - o.xyz).max() < 1e-6
+        assert np.abs(s.get_rPosQuat() - o.get_rPosQuat()).max() < 1e-9
+
+
+def test_ghelix6DQ2_iterations_vs_oracle(tdtk, orc, gpu):
+    """-G 3: ghelix6DQ2::doGraphSlam6D with nrIt = 2 (B and bd carried from the first iteration into the
+    second, as the reference does) against the numpy restatement."""
+    from oracle import icp_oracle as io
+    S, O = _dat_after_icp(tdtk, [tdtk.Scan, io.OScan])
+    links = [(0, 1), (1, 2), (0, 2)]
+    gr = tdtk.Graph(3, links=links); gr.nrScans = 3
+    ret = tdtk.ghelix6DQ2(None, 25.0, 25.0, epsilonLUM=-1.0).doGraphSlam6D(gr, S, 2)
+    Bm = bd = None
+    for _ in range(2):
+        oret, Bm, bd, _ccs = io.ghelix_iteration(links, O, 625.0, Bm, bd)
+    assert abs(ret - oret) < 1e-6 * max(1.0, oret)
+    for s, o in zip(S, O):
+        assert _rel(s.get_transMat(), o.transMat) < 1e-7
+        assert np.abs(s.get_xyz_reduced() - o.xyz).max() < 1e-5
+
+
+def test_scans_transform2_equals_two_transforms(tdtk, gpu):
+    """tdtk_scans_transform2 (one launch, both matrices) == Scan::transform twice, bit for bit."""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-500, 500, (5000, 3)); nrm = rng.normal(size=(5000, 3))
+    A = [tdtk.EulerToMatrix4(rng.uniform(-50, 50, 3), rng.uniform(-1, 1, 3)) for _ in range(4)]
+    a = [tdtk.Scan([1, 2, 3], [0.1, 0.2, 0.3], pts, nrm) for _ in range(2)]
+    b = [tdtk.Scan([1, 2, 3], [0.1, 0.2, 0.3], pts, nrm) for _ in range(2)]
+    for s in a + b:
+        _ = s.handle
+    from importlib import import_module
+    sl = import_module("3dtk_amd.slam6d")
+    sl.transform_many(a, [A[0], A[1]], [A[2], A[3]], "LUM")
+    b[0].transform(A[0], "INVALID"); b[0].transform(A[2], "LUM")
+    b[1].transform(A[1], "INVALID"); b[1].transform(A[3], "LUM")
+    for x, y in zip(a, b):
+        assert np.array_equal(x.get_xyz_reduced(), y.get_xyz_reduced())
+        assert np.array_equal(x.transMat, y.transMat) and np.array_equal(x.dalignxf, y.dalignxf)
+        assert len(x.frames) == len(y.frames)
