@@ -719,3 +719,43 @@ def test_scans_transform2_equals_two_transforms(tdtk, gpu):
         assert np.array_equal(x.get_xyz_reduced(), y.get_xyz_reduced())
         assert np.array_equal(x.transMat, y.transMat) and np.array_equal(x.dalignxf, y.dalignxf)
         assert len(x.frames) == len(y.frames)
+
+
+def test_ten_million_point_model_with_normals(tdtk, orc, gpu):
+    """configs[4] scale: a 10M-point model (leaf-table / packed reference limits, 24-bit indices and beyond),
+    the device-built tree against the host builder, indices bit-exact on a query sample; a 2M-point scan
+    with normals: whole-scan pass and the point-to-plane (NAPX) step equal to the oracle's, and a
+    point-to-point ICP that recovers the known motion."""
+    from oracle import icp_oracle as io
+    rng = np.random.default_rng(77)
+    M = 10_000_000
+    m = rng.uniform(-2000, 2000, (M, 3))
+    kd = tdtk.KDtree(m, 20)
+    assert kd.verify() == [0, 0, 0, 0]
+    T = orc.Tree(m, 20)
+    inf, st = kd.info(), T.stats()
+    assert (inf["n_internal"], inf["n_leaves"], inf["max_depth"]) == (st["internal"], st["leaves"], st["depth"])
+    q = m[rng.integers(0, M, 300000)] + rng.normal(0, 4.0, (300000, 3))
+    idx, d2 = kd.FindClosestBatch(q, 400.0)
+    oi, od2 = T.find_closest(q, 400.0, 8)
+    assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+    del kd
+    # a 2M-point scan of the same surface sample, moved by a small rigid motion
+    sel = rng.choice(M, 2_000_000, replace=False)
+    Tgt = io.euler_to_matrix4([3.0, -2.0, 1.5], [0.004, -0.003, 0.005])
+    inv, _ = orc.m4inv(Tgt)
+    d = m[sel] + rng.normal(0, 0.3, (len(sel), 3))
+    orc.transform_points(inv, d)
+    nrm = rng.normal(size=(len(sel), 3)); nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], m)
+    S1 = tdtk.Scan([0, 0, 0], [0, 0, 0], d, nrm)
+    r = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 400.0, 2, tdtk.WANT_NAPX)    # CLOSEST_PLANE_SIMPLE, as -a 10 is meant to run
+    o = T.get_pt_pairs(np.eye(4).reshape(16), d, nrm, 0, None, 2, 400.0)
+    assert r["n"] == o["n"] and abs(r["sum"] - o["sum"]) < 1e-9 * o["sum"]
+    rms, a = tdtk.icp6D_NAPX(True).Align_Parallel(r)
+    orms, oa = io.align(10, o["p1"], o["p2"], o["centroid_m"] / o["n"], o["centroid_d"] / o["n"], o["pn"])
+    assert abs(rms - orms) < 1e-9 * orms and np.abs(a - oa).max() < 1e-8
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 20.0, 15, quiet=True, epsilonICP=1e-6)
+    icp.match(S0, S1)
+    assert np.abs(S1.get_transMat() - Tgt).max() < 5e-3
+    assert np.abs(S1.get_transMat()[:12] - Tgt[:12]).max() < 1e-5
