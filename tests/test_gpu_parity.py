@@ -759,3 +759,53 @@ def test_ten_million_point_model_with_normals(tdtk, orc, gpu):
     icp.match(S0, S1)
     assert np.abs(S1.get_transMat() - Tgt).max() < 5e-3
     assert np.abs(S1.get_transMat()[:12] - Tgt[:12]).max() < 1e-5
+
+
+def test_config3_shape_graphslam_sharded(tdtk, orc, gpu):
+    """configs[3] at reduced size (16 scans x 40K points on a closed circle, chain + loop closures): one
+    lum6DEuler iteration of the native path against the numpy restatement, and the sharded exchange
+    emulated for 2, 4 and 8 ranks on this one GPU -- every rank's links through tdtk_lum_links, blocks
+    summed as the all-reduce would, C-side scatter + solve -- gives bit-identical X for every rank count."""
+    import sys
+    from importlib import import_module
+    from oracle import icp_oracle as io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    gs = import_module("3dtk_amd.graphslam")
+    capi = import_module("3dtk_amd._capi")
+    import ctypes as C
+    raw = bench.make_graphslam_scans(16, 40000, seed=11)
+    S = [tdtk.Scan(p, th, loc) for (p, th, loc) in raw]
+    O = [io.OScan(p, th, loc) for (p, th, loc) in raw]
+    gr = tdtk.Graph(16, 700.0 ** 2, 5, S)
+    links = list(zip(gr.frm, gr.to))
+    assert links == io.graph_links(O, 700.0 ** 2, 5) and len(links) > 15
+    # emulated ranks
+    def blocks_for(world):
+        out = np.zeros((len(links), 42))
+        for r in range(world):
+            mine = gs.shard_links(gr, r, world)
+            if not mine:
+                continue
+            nl = len(mine)
+            first = (C.c_void_p * nl)(*[S[links[i][0]].getSearchTree()._h for i in mine])
+            second = (C.c_void_p * nl)(*[S[links[i][1]].handle for i in mine])
+            dal = np.ascontiguousarray(np.stack([S[links[i][0]].dalignxf for i in mine]))
+            Cm = np.empty((nl, 36)); CD = np.empty((nl, 6)); m = (C.c_uint64 * nl)(); ss = np.empty(nl)
+            capi.check(capi.lib().tdtk_lum_links(nl, first, capi.dptr(dal), second, 625.0, capi.dptr(Cm), capi.dptr(CD),
+                                                 m, capi.dptr(ss)))
+            part = np.zeros((len(links), 42)); part[mine, :36] = Cm; part[mine, 36:] = CD
+            out = out + part                     # what the all-reduce does: every link has one owner
+        return out
+    Xs = []
+    for world in (1, 2, 4, 8):
+        b = blocks_for(world)
+        Xs.append(gs.lum_reduce_solve(gr, list(range(len(links))), b[:, :36], b[:, 36:], 1))
+    for X in Xs[1:]:
+        assert np.array_equal(X, Xs[0])
+    ret = gs.lum_iteration_native(gr, S, 625.0)
+    oret, _, _, Xo = io.lum_iteration(links, O, 625.0)
+    np.testing.assert_allclose(Xs[0], Xo, rtol=1e-6, atol=1e-9)
+    assert abs(ret - oret) < 1e-7 * max(1.0, oret)
+    for s, o in zip(S, O):
+        assert np.abs(s.get_rPos() - o.rPos).max() < 1e-6 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-9
