@@ -11,6 +11,7 @@ doubles, 1.1 MB for 64 scans -- latency-bound, so it is a single flat buffer, no
 Every rank then solves the small SPD system redundantly and moves its own replicas.
 """
 import math
+import os
 
 import numpy as np
 
@@ -102,7 +103,7 @@ def lum_reduce_solve(gr, mine, Cm, CD, world=1, group=None, device=None):
     if len(mine):
         blocks[mine, :36] = Cm
         blocks[mine, 36:] = CD
-    if world > 1:
+    if world > 1 or (os.environ.get("TDTK_FORCE_ALLREDUCE") and _dist_ready()):   # the env knob: 1-rank RCCL smoke test
         import torch
         import torch.distributed as dist
         t = torch.from_numpy(blocks)

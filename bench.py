@@ -103,6 +103,21 @@ def make_graphslam_scans(nscans, npts, seed=7):
 
 
 # --------------------------------------------------------------------------------------------
+class _stdout_to_stderr:
+    """fd-level redirect: RCCL prints its version banner to stdout when the communicator comes up
+    (NCCL_DEBUG=VERSION is set on the pool); stdout must carry the one JSON line only."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def dist_setup(ngpus):
     import torch
     rank, world, local = 0, 1, 0
@@ -111,7 +126,10 @@ def dist_setup(ngpus):
         rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.barrier()                      # brings the communicator (and its banner) up now
+            torch.cuda.synchronize()
     else:
         torch.cuda.set_device(0)
     if world != ngpus:
