@@ -151,19 +151,18 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
     set_error("model scan too large (30-bit references / 32-bit byte offsets: < 2^27 points)");
     return TDTK_EINVAL;
   }
-  // root bounding box (binning of unsorted query batches, accumulation shift)
-  for (int a = 0; a < 3; a++) t->bbmin[a] = t->bbmax[a] = xyz[a];
-  for (size_t i = 1; i < M; i++)
-    for (int a = 0; a < 3; a++) {
-      const double v = xyz[3 * i + a];
-      if (v < t->bbmin[a]) t->bbmin[a] = v;
-      if (t->bbmax[a] < v) t->bbmax[a] = v;
-    }
-  for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
   size_t bytes = 0;
   double build_ms = 0.0, upload_ms = 0.0;
   const char* host_env = getenv("TDTK_HOST_BUILD");
   if (host_env && host_env[0] == '1') {
+    // root bounding box (binning of unsorted query batches, accumulation shift)
+    for (int a = 0; a < 3; a++) t->bbmin[a] = t->bbmax[a] = xyz[a];
+    for (size_t i = 1; i < M; i++)
+      for (int a = 0; a < 3; a++) {
+        const double v = xyz[3 * i + a];
+        if (v < t->bbmin[a]) t->bbmin[a] = v;
+        if (t->bbmax[a] < v) t->bbmax[a] = v;
+      }
     // host construction (kd_build.cpp), kept as the cross-check of the device builder
     HostTree H;
     std::string err;
@@ -190,8 +189,14 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
   } else {
     // device construction (build.hip): upload the points once, build level by level
     if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
+    if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
+    double* d_box = c->ws[WS_BOX].as<double>();
     HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, xyz, 3 * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // root bounding box (binning of unsorted query batches, accumulation shift): min / max on the device
+    HIPCHK(launch_bbox(c->ws[WS_TMPA].as<double>(), M, d_box + 8, d_box, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[a]; t->bbmax[a] = c->h_pin[3 + a]; }
     const double t1 = now_ms();
     upload_ms = t1 - t0;
     DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->stream);
@@ -209,6 +214,7 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
     t->info.max_depth = r.max_depth; t->info.max_leaf_points = r.max_leaf;
     build_ms = now_ms() - t1;
   }
+  for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
   bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(double)) + M * sizeof(KdPoint);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
