@@ -809,3 +809,49 @@ def test_config3_shape_graphslam_sharded(tdtk, orc, gpu):
     assert abs(ret - oret) < 1e-7 * max(1.0, oret)
     for s, o in zip(S, O):
         assert np.abs(s.get_rPos() - o.rPos).max() < 1e-6 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-9
+
+
+def test_find_closest_randomized_shapes(tdtk, orc, gpu):
+    """Seeded random clouds of random size, bucket size, quantisation (forcing exact duplicates and
+    equidistant candidates), anisotropy and search radius; queries on, near and far from the cloud.
+    Indices and squared distances bit-exact against the oracle in every case; the device-built tree equals the
+    host builder's."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 2000, 9000]))
+        scale = rng.choice([1.0, 100.0, 1e4]) * np.array([1.0, rng.choice([1.0, 0.1, 1e-3]), rng.choice([1.0, 0.5])])
+        pts = rng.normal(0, 1, (n, 3)) * scale + rng.uniform(-1e3, 1e3, 3)
+        q_step = rng.choice([0.0, 0.0, 0.5, 8.0])
+        if q_step > 0:
+            pts = np.round(pts / q_step) * q_step                # duplicates and lattice ties
+        bucket = int(rng.choice([1, 2, 5, 20, 64]))
+        kd, T = tdtk.KDtree(pts, bucket), orc.Tree(pts, bucket)
+        assert kd.verify() == [0, 0, 0, 0], case
+        k = 400
+        q = np.concatenate([pts[rng.integers(0, n, k)],                                   # on the points
+                            pts[rng.integers(0, n, k)] + rng.normal(0, 0.3, (k, 3)) * scale.max() * 0.01,
+                            pts[rng.integers(0, n, k)] + (np.round(rng.normal(0, 2, (k, 3))) * (q_step if q_step else 1.0)),
+                            rng.uniform(-3e4, 3e4, (k, 3))])                               # far away
+        for md2 in (float(rng.choice([1e-6, 1.0, 100.0])), 1e18):
+            idx, d2 = kd.FindClosestBatch(q, md2)
+            oi, od2 = T.find_closest(q, md2)
+            assert np.array_equal(idx, oi), (case, n, bucket, q_step, md2)
+            assert np.array_equal(d2[idx >= 0], od2[oi >= 0])
+
+
+def test_big_batch_kernel_on_lattice_ties(tdtk, orc, gpu):
+    """The persistent-lane kernel (batches of 256K queries and more) on a lattice cloud where most queries
+    have several equidistant candidates: the first-visited one must win, as in the reference."""
+    rng = np.random.default_rng(77)
+    pts = np.round(rng.uniform(-40, 40, (60000, 3)))             # many exact duplicates, unit lattice
+    kd, T = tdtk.KDtree(pts, 10), orc.Tree(pts, 10)
+    q = np.round(rng.uniform(-45, 45, (300000, 3)) * 2) / 2      # on lattice points and exactly between them
+    for md2 in (0.75, 4.0, 1e18):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi) and np.array_equal(d2[idx >= 0], od2[oi >= 0])
+    S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], pts, bucketSize=10)
+    S1 = tdtk.Scan([0.5, 0, 0], [0, 0, 0], q)
+    r = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 4.0, 0, 0, None, True)
+    o = orc.Tree(pts, 10).get_pt_pairs(np.eye(4).reshape(16), q + np.array([0.5, 0, 0]), None, 0, None, 0, 4.0)
+    assert r["n"] == o["n"] and np.array_equal(r["idx"], o["idx"])
