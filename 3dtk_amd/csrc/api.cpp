@@ -110,6 +110,16 @@ struct tdtk_tree {
   void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr;
   double bbmin[3], bbmax[3], centre[3];
   tdtk_tree_info info{};
+  tdtk_tree() = default;
+  tdtk_tree(const tdtk_tree&) = delete;
+  tdtk_tree& operator=(const tdtk_tree&) = delete;
+  ~tdtk_tree()   // also the error paths of tdtk_tree_create: nothing stays allocated on the device
+  {
+    (void)hipSetDevice(device);
+    void* p[] = {d_nodes, d_pts, d_leaf, d_r};
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  }
 };
 
 struct tdtk_scan {
@@ -118,6 +128,17 @@ struct tdtk_scan {
   double *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
   int32_t* d_order = nullptr;    // sorted position -> caller index
   std::vector<int32_t> order_h;
+  tdtk_scan() = default;
+  tdtk_scan(const tdtk_scan&) = delete;
+  tdtk_scan& operator=(const tdtk_scan&) = delete;
+  ~tdtk_scan()
+  {
+    (void)hipSetDevice(device);
+    double* p[] = {x, y, z, nx, ny, nz};
+    for (double* q : p)
+      if (q) (void)hipFree(q);
+    if (d_order) (void)hipFree(d_order);
+  }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -232,13 +253,7 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
 
 void tdtk_tree_destroy(tdtk_tree* t)
 {
-  if (!t) return;
-  (void)hipSetDevice(t->device);
-  if (t->d_nodes) (void)hipFree(t->d_nodes);
-  if (t->d_pts) (void)hipFree(t->d_pts);
-  if (t->d_leaf) (void)hipFree(t->d_leaf);
-  if (t->d_r) (void)hipFree(t->d_r);
-  delete t;
+  delete t;   // ~tdtk_tree releases the device arrays
 }
 
 int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info)
@@ -763,13 +778,7 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
 
 void tdtk_scan_destroy(tdtk_scan* s)
 {
-  if (!s) return;
-  (void)hipSetDevice(s->device);
-  double* p[] = {s->x, s->y, s->z, s->nx, s->ny, s->nz};
-  for (double* q : p)
-    if (q) (void)hipFree(q);
-  if (s->d_order) (void)hipFree(s->d_order);
-  delete s;
+  delete s;   // ~tdtk_scan releases the device arrays
 }
 
 size_t tdtk_scan_size(const tdtk_scan* s) { return s ? s->N : 0; }
