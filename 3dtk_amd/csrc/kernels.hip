@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
   return first ? r1 : r2;
 }
 
-template <int BLOCK, int SD, bool COUNT, bool UNI>
+template <int BLOCK, int SD, bool COUNT, bool UNI, int PTS = 4>
 __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, const double qy,
                                           const double qz, double& best, int& bk,
                                           LaneStack<BLOCK, SD>& st, unsigned long long* cnt)
@@ -223,22 +223,22 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
       const double4* __restrict__ P = pts + start;
       const int last = count - 1;
-      for (int i = 0; i < count; i += 4) {
-        const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
-        const double4 p0 = P[i], p1 = P[i1], p2 = P[i2], p3 = P[i3];
-        double dx, dy, dz;
-        dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
-        const double d0 = dx * dx + dy * dy + dz * dz;
-        dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
-        const double d1 = dx * dx + dy * dy + dz * dz;
-        dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
-        const double d3 = dx * dx + dy * dy + dz * dz;
-        if (d0 < best) { best = d0; bk = start + i; }
-        if (d1 < best) { best = d1; bk = start + i1; }
-        if (d2 < best) { best = d2; bk = start + i2; }
-        if (d3 < best) { best = d3; bk = start + i3; }
+      // PTS points per round trip (small batches run one wave per SIMD: nothing else hides the latency,
+      // so they keep more loads in flight)
+      for (int i = 0; i < count; i += PTS) {
+        int id[PTS];
+        double4 p[PTS];
+        double d[PTS];
+#pragma unroll
+        for (int j = 0; j < PTS; j++) { id[j] = min(i + j, last); p[j] = P[id[j]]; }
+#pragma unroll
+        for (int j = 0; j < PTS; j++) {
+          const double dx = p[j].x - qx, dy = p[j].y - qy, dz = p[j].z - qz;
+          d[j] = dx * dx + dy * dy + dz * dz;
+        }
+#pragma unroll
+        for (int j = 0; j < PTS; j++)
+          if (d[j] < best) { best = d[j]; bk = start + id[j]; }
       }
     }
     // pop the next pending far child that still passes sqr(myd) < closest_d2
@@ -551,7 +551,7 @@ __device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx,
 // ------------------------------------------------------------------------------------------
 // k_search: the hot kernel
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS>
+template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -603,9 +603,132 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
     double best = a.maxd2;
     int bk = -1;
     if (DIRMODE) kd_search_dir<BLOCK, SD>(a.T, sx, sy, sz, ux, uy, uz, best, bk, st);
-    else kd_search<BLOCK, SD, COUNT, UNI>(a.T, sx, sy, sz, best, bk, st, a.counters);
+    else kd_search<BLOCK, SD, COUNT, UNI, PTS>(a.T, sx, sy, sz, best, bk, st, a.counters);
     a.kpos[i] = bk;
     if (a.d2) a.d2[i] = best;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_search_g8: eight lanes per query, for batches too small to fill the machine with one lane per
+// query (a bundled 81K-point scan gives 1.2 waves per SIMD; the kernel then runs as long as the
+// dependent-load chain of its slowest lane, ~0.7 us a step under 64-way address divergence).
+// The eight lanes of a group hold the same query and walk the same nodes (their loads hit one line,
+// so a wave touches 8 lines per instruction instead of 64), keep one stack per group in LDS, and
+// scan a bucket eight points at a time: lane j takes point i+j and the group takes the minimum,
+// lowest index first among equals -- which is what the serial strict '<' scan in stored order
+// returns.  Same visiting order as k_search, hence the same indices.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD>
+__global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
+{
+  constexpr int GS = 8, NG = BLOCK / GS;
+  __shared__ double lds_m2[SD][NG];
+  __shared__ uint32_t lds_ref[SD][NG];
+
+  const uint32_t nb = gridDim.x;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
+  const int grp = threadIdx.x / GS, sub = threadIdx.x & (GS - 1);
+  const size_t gg = (size_t)blockIdx.x * NG + grp;     // overflow slot of the group
+
+  LaneStack<NG, SD> st;
+  st.l_m2 = &lds_m2[0][grp];
+  st.l_ref = &lds_ref[0][grp];
+  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gg : nullptr;
+  st.g_ref = a.ovf_ref ? a.ovf_ref + gg : nullptr;
+  st.gstride = (size_t)nb * NG;
+  st.sp = 0;
+
+  const TreeDev& T = a.T;
+  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+
+  const size_t per = (a.n + nb - 1) / nb;
+  const size_t lo = (size_t)chunk * per;
+  size_t hi = lo + per;
+  if (hi > a.n) hi = a.n;
+
+  for (size_t base = lo; base < hi; base += NG) {
+    const size_t i = base + grp;
+    if (i >= hi) continue;
+    double tx = a.x[i], ty = a.y[i], tz = a.z[i];
+    if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875); every lane computes, one writes
+      dev_xf3_inplace(a.pending, tx, ty, tz);
+      if (sub == 0) { a.x[i] = tx; a.y[i] = ty; a.z[i] = tz; }
+      if (a.nx && sub == 0) {
+        double px = a.nx[i], py = a.ny[i], pz = a.nz[i];
+        dev_xf3normal(a.pending, px, py, pz);
+        a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
+      }
+    }
+    double qx = tx, qy = ty, qz = tz;
+    if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
+    double best = a.maxd2;
+    int bk = -1;
+    uint32_t cur = T.root_ref;
+    st.sp = 0;
+    for (;;) {
+      while (!(cur & REF_LEAF)) {
+        bool need_pop = false;
+        const double4 n0 = nodes[(size_t)cur * 2];
+        const double4 n1 = nodes[(size_t)cur * 2 + 1];
+        uint32_t next = visit_node<NG, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
+                                           (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
+        if (need_pop) {
+          next = REF_DONE;
+          while (st.sp > 0) {
+            --st.sp;
+            uint32_t r; double m2;
+            st.top(r, m2);
+            if (m2 < best) { next = r; break; }
+          }
+        }
+        cur = next;
+      }
+      if (cur == REF_DONE) break;
+      {
+        const uint32_t v = cur & REF_VAL;
+        int start, count;
+        if (T.leaf_tab) {
+          const LeafEntry le = T.leaf_tab[v];
+          start = le.start; count = le.count;
+        } else {
+          start = (int)(v >> T.cb);
+          count = (int)(v & T.cmask);
+        }
+        const double4* __restrict__ P = pts + start;
+        const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        for (int j0 = 0; j0 < count; j0 += GS) {
+          const int j = j0 + sub;
+          double d = inf;
+          if (j < count) {
+            const double4 p = P[j];
+            const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+            d = dx * dx + dy * dy + dz * dz;
+          }
+          int jj = j;
+#pragma unroll
+          for (int o = 1; o < GS; o <<= 1) {           // group minimum, lowest index among equals
+            const double od = __shfl_xor(d, o, GS);
+            const int oj = __shfl_xor(jj, o, GS);
+            if (od < d || (od == d && oj < jj)) { d = od; jj = oj; }
+          }
+          if (d < best) { best = d; bk = start + jj; }
+        }
+      }
+      cur = REF_DONE;
+      while (st.sp > 0) {
+        --st.sp;
+        uint32_t r; double m2;
+        st.top(r, m2);
+        if (m2 < best) { cur = r; break; }
+      }
+      if (cur == REF_DONE) break;
+    }
+    if (sub == 0) {
+      a.kpos[i] = bk;
+      if (a.d2) a.d2[i] = best;
+    }
   }
 }
 
@@ -1089,9 +1212,10 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 // Variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>); the default picks by batch size.
 // The full ladder that was measured is in DESIGN.md section 6.
 //   0: the first working kernel (LDS stack 8 deep, per-lane node loads)
-//   4: + 4-deep LDS stack, wave-uniform scalar node loads          (default below 256K queries)
+//   4: + 4-deep LDS stack, wave-uniform scalar node loads          (default for 128K..256K queries)
 //   5: wave-cooperative LDS staging of distinct nodes / buckets    (kept as a measured negative)
 //   8: persistent lanes, 256 queries per wave, 256-thread workgroups
+//   9: eight lanes per query (k_search_g8)                         (default below 128K queries)
 //  20: persistent lanes, 256 queries per wave, 128-thread workgroups (default from 256K queries)
 static int search_variant()
 {
@@ -1099,7 +1223,7 @@ static int search_variant()
   if (v < 0) {
     const char* e = getenv("TDTK_SEARCH_VARIANT");
     v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-    if (v != 0 && v != 4 && v != 5 && v != 8 && v != 20) v = -2;
+    if (v != 0 && v != 4 && v != 5 && v != 9 && v != 8 && v != 20) v = -2;
   }
   return v;
 }
@@ -1129,6 +1253,14 @@ static uint32_t refill_grid_b(size_t n, int qpw, int block)
   nb = (nb + 7) & ~(size_t)7;
   return (uint32_t)(nb < 8 ? 8 : nb);
 }
+static uint32_t g8_grid(size_t n)
+{
+  size_t nb = (n + 31) / 32;            // 32 queries (groups of 8 lanes) per 256-thread workgroup
+  const size_t cap = (size_t)num_cu() * 32;
+  if (nb > cap) nb = cap;
+  nb = (nb + 7) & ~(size_t)7;
+  return (uint32_t)(nb < 8 ? 8 : nb);
+}
 int search_lds_depth() { return SEARCH_SD_MIN; }
 int search_block() { return SEARCH_BLOCK; }
 
@@ -1143,12 +1275,13 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
     int v = search_variant();
     // persistent lanes pay off once there are enough queries to keep every SIMD supplied with
     // several 256-query waves; small batches keep one query per lane
-    if (v == -2) v = (a.n >= (size_t)262144) ? 20 : 4;
+    if (v == -2) v = (a.n >= (size_t)262144) ? 20 : ((a.n >= (size_t)131072) ? 4 : 9);
     switch (v) {
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
       case 8: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
       case 20: hipLaunchKernelGGL((k_search_refill<128, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 128)), dim3(128), 0, s, a); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
+      case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
       default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
     }
   }
