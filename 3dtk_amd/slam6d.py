@@ -650,23 +650,49 @@ class icp6D:
                          rms=ret, total_ms=0.0, nn_ms=0.0, trace=np.array(trace))
         return it
 
-    def doICP(self, allScans, pairing_mode=0):
+    def doICP(self, allScans, pairing_mode=0, prefetch=True):
         """icp6D::doICP (icp6D.cc:374-437): sequential matching against the previous scan, or
-        (meta) against a MetaScan of all / the last max_num_metascans processed scans."""
-        meta_scans, my_MetaScan = [], None
-        for i in range(len(allScans)):
-            cur = allScans[i]
-            if i > 0:
-                prev = allScans[i - 1]
-                if self.eP:
-                    cur.mergeCoordinatesWithRoboterPosition(prev)
-                self.match(my_MetaScan if self.meta else prev, cur, pairing_mode)
-            if self.meta and i != len(allScans) - 1:
-                meta_scans.append(cur)
-                if self.max_num_metascans > 0:
-                    while len(meta_scans) > self.max_num_metascans:
-                        meta_scans.pop(0)
-                my_MetaScan = MetaScan(meta_scans)
+        (meta) against a MetaScan of all / the last max_num_metascans processed scans.
+
+        prefetch: while scan i is matched against scan i-1, a second host thread (its own HIP stream; the
+        library is thread-safe per handle) uploads scan i+1 and builds its search tree, so the per-scan
+        preparation hides behind the previous match instead of adding to it.  The tree is built over
+        "xyz reduced original", which no ICP step touches, so the result is unchanged."""
+        pool = None
+        if prefetch and not self.meta and len(allScans) > 2:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(1)
+
+        def prep(s):
+            _ = s.handle
+            s.getSearchTree()
+
+        pending = {}
+        try:
+            meta_scans, my_MetaScan = [], None
+            for i in range(len(allScans)):
+                cur = allScans[i]
+                if pool is not None:
+                    if i in pending:
+                        pending.pop(i).result()
+                    if i + 1 < len(allScans):
+                        pending[i + 1] = pool.submit(prep, allScans[i + 1])
+                if i > 0:
+                    prev = allScans[i - 1]
+                    if self.eP:
+                        cur.mergeCoordinatesWithRoboterPosition(prev)
+                    self.match(my_MetaScan if self.meta else prev, cur, pairing_mode)
+                if self.meta and i != len(allScans) - 1:
+                    meta_scans.append(cur)
+                    if self.max_num_metascans > 0:
+                        while len(meta_scans) > self.max_num_metascans:
+                            meta_scans.pop(0)
+                    my_MetaScan = MetaScan(meta_scans)
+        finally:
+            for f in pending.values():
+                f.result()
+            if pool is not None:
+                pool.shutdown()
 
 
 # ---------------------------------------------------------------------------------------

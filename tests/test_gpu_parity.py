@@ -855,3 +855,18 @@ def test_big_batch_kernel_on_lattice_ties(tdtk, orc, gpu):
     r = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 4.0, 0, 0, None, True)
     o = orc.Tree(pts, 10).get_pt_pairs(np.eye(4).reshape(16), q + np.array([0.5, 0, 0]), None, 0, None, 0, 4.0)
     assert r["n"] == o["n"] and np.array_equal(r["idx"], o["idx"])
+
+
+def test_doicp_prefetch_is_transparent(tdtk, gpu):
+    """icp6D::doICP with the next scan uploaded and its tree built on a second host thread while the current
+    pair is matched: poses and moved points bit-identical to the serial order."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    raw = bench.make_graphslam_scans(6, 30000, seed=3)
+    out = []
+    for pf in (False, True):
+        scans = [tdtk.Scan(p, th, loc) for (p, th, loc) in raw]
+        tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 20, quiet=True, epsilonICP=1e-6).doICP(scans, prefetch=pf)
+        out.append((np.stack([s.transMat for s in scans]), scans[-1].get_xyz_reduced(), [len(s.frames) for s in scans]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
