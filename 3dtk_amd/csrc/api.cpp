@@ -485,11 +485,10 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   const uint32_t grid = accum_grid(N);
   rc = c->ws[WS_PART].ensure((size_t)grid * ACC_TOTAL * sizeof(double));
   if (rc) return rc;
-  rc = c->ws[WS_OUT].ensure(ACC_TOTAL * sizeof(double));
-  if (rc) return rc;
   aa.partials = c->ws[WS_PART].as<double>();
-  HIPCHK(launch_accum(aa, grid, want, pmode, c->ws[WS_OUT].as<double>(), s));
-  HIPCHK(hipMemcpyAsync(c->h_pin, c->ws[WS_OUT].p, ACC_TOTAL * sizeof(double), hipMemcpyDeviceToHost, s));
+  // k_final stores the 74 sums straight into pinned host memory (device-visible): no copy-engine hop
+  // between the last kernel and the host solve, which matters when an iteration is ~100 us
+  HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s));
   HIPCHK(hipStreamSynchronize(s));
   std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
   return TDTK_OK;
