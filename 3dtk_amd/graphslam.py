@@ -157,13 +157,15 @@ def lum_iteration_native(gr, allScans, max_dist_match2, group=None, device=None)
     ret = C.c_double(0.0)
     check(lib().tdtk_lum_update_poses(nscans, dptr(X), dptr(tm), dptr(da), dptr(rp), dptr(rt), hs, dptr(xf),
                                       C.byref(ret)))
+    # tm / da / rp / rt / xf are fresh arrays of this call and nothing below writes into them again (every
+    # later pose update makes new arrays), so the scans keep row views instead of copies
     for i in range(1, nscans):
         s = allScans[i]
-        s.transMat, s.dalignxf, s.rPos, s.rPosTheta = tm[i].copy(), da[i].copy(), rp[i].copy(), rt[i].copy()
+        s.transMat, s.dalignxf, s.rPos, s.rPosTheta = tm[i], da[i], rp[i], rt[i]
         if s._h is None:                       # not resident on this rank: replay later, in order
-            s._queue.append(xf[i, :16].copy())
-            s._queue.append(xf[i, 16:].copy())
-        s.frames.append((s.transMat.copy(), "LUM"))
+            s._queue.append(xf[i, :16])
+            s._queue.append(xf[i, 16:])
+        s.frames.append((tm[i], "LUM"))
     return ret.value
 
 
