@@ -840,6 +840,46 @@ int tdtk_scan_pairs(const tdtk_tree* model, const double A[16], tdtk_scan* data,
   return rc;
 }
 
+// icp6D::Point_Point_Error (icp6D.cc:293-367)
+int tdtk_point_point_error(const tdtk_tree* model, const double A[16], tdtk_scan* data, double max_dist_match,
+                           double scale_max, uint64_t* np_out, double* error_out)
+{
+  if (!model || !A || !data || !error_out) { set_error("NULL argument"); return TDTK_EINVAL; }
+  if (model->device != data->device) { set_error("tree and scan live on different devices"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(model->device, &c);
+  if (rc) return rc;
+  if (np_out) *np_out = 0;
+  *error_out = 0.0;
+  const size_t N = data->N;
+  if (N == 0) { *error_out = std::nan(""); return TDTK_OK; }   // 0 / 0 in the reference
+  hipStream_t s = c->stream;
+  if ((rc = c->ws[WS_KPOS].ensure(N * sizeof(int)))) return rc;
+  Mat4 Am, inv;
+  std::memcpy(Am.m, A, sizeof Am.m);
+  m4inv(A, inv.m);
+  SearchArgs sa{};
+  sa.x = data->x; sa.y = data->y; sa.z = data->z;
+  sa.n = N; sa.inv = inv; sa.has_inv = 1;
+  sa.maxd2 = max_dist_match * max_dist_match;
+  sa.kpos = c->ws[WS_KPOS].as<int>();
+  if ((rc = run_search(c, model, sa, 0, false, s, true))) return rc;
+  AccumArgs aa{};
+  aa.T = model->dev;
+  aa.x = data->x; aa.y = data->y; aa.z = data->z;
+  aa.kpos = sa.kpos; aa.n = N; aa.A = Am; aa.inv = inv;
+  const uint32_t grid = accum_grid(N);
+  if ((rc = c->ws[WS_PART].ensure((size_t)grid * ACC_TOTAL * sizeof(double)))) return rc;
+  const double scale = std::log(scale_max) / (max_dist_match * max_dist_match);   // icp6D.cc:299
+  HIPCHK(launch_pp_error(aa, grid, scale, c->ws[WS_PART].as<double>(), c->h_pin, s));
+  HIPCHK(hipStreamSynchronize(s));
+  collect_ms(c, nullptr);
+  const double se = c->h_pin[0], cn = c->h_pin[1];
+  if (np_out) *np_out = (uint64_t)(cn + 0.5);
+  *error_out = (-0.39894228 * se) / cn;   // error -= 0.39894228 * exp(dist * scale) per pair; error / nr_ppairs
+  return TDTK_OK;
+}
+
 int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_r, const double* normal_r,
                       size_t start, size_t end, int rnd, int pmode, double maxd2, uint32_t want,
                       const double* lum_D, int32_t* idx_out, double* p1_out, double* p2_out,

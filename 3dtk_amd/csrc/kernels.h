@@ -120,6 +120,7 @@ struct DevBuildResult {
 // level-synchronous construction of the reference's kd-tree on the device (build.hip)
 DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, hipStream_t s);
 
+hipError_t launch_pp_error(const AccumArgs& a, uint32_t grid, double scale, double* d_partial, double* d_out, hipStream_t s);
 hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s);
 hipError_t launch_pair_list(const PairListArgs& a, int pmode, hipStream_t s);
 size_t scan_u32_temp_bytes(size_t n);

@@ -1372,6 +1372,48 @@ hipError_t launch_split_soa(const double* q, size_t n, double* x, double* y, dou
   return hipGetLastError();
 }
 
+// icp6D::Point_Point_Error (icp6D.cc:293-367): sum over the pairs of exp(|p1 - p2|^2 * scale), p1 = model point
+// mapped to the world, p2 = data point.  partial[block] rows, then a fixed-order fold by one workgroup.
+__global__ void __launch_bounds__(256) k_pp_error(const AccumArgs a, double scale, double* __restrict__ partial)
+{
+  __shared__ double red[2][4];
+  double se = 0.0, cn = 0.0;
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(a.T.pts);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+    const int k = a.kpos[i];
+    if (k < 0) continue;
+    const double4 c = pts[k];
+    double mx, my, mz;
+    dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);
+    const double px = mx - a.x[i], py = my - a.y[i], pz = mz - a.z[i];
+    se += exp((px * px + py * py + pz * pz) * scale);
+    cn += 1.0;
+  }
+  se = wave_sum(se); cn = wave_sum(cn);
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if (lane == 0) { red[0][wv] = se; red[1][wv] = cn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void __launch_bounds__(64) k_pp_final(const double* __restrict__ partial, int rows, double* __restrict__ out)
+{
+  if (threadIdx.x == 0) {
+    double se = 0.0, cn = 0.0;
+    for (int r = 0; r < rows; r++) { se += partial[2 * r]; cn += partial[2 * r + 1]; }
+    out[0] = se; out[1] = cn;
+  }
+}
+hipError_t launch_pp_error(const AccumArgs& a, uint32_t grid, double scale, double* d_partial, double* d_out, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pp_error, dim3(grid), dim3(256), 0, s, a, scale, d_partial);
+  hipLaunchKernelGGL(k_pp_final, dim3(1), dim3(64), 0, s, d_partial, (int)grid, d_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s)
 {
   if (!n) return hipSuccess;

@@ -650,6 +650,17 @@ class icp6D:
                          rms=ret, total_ms=0.0, nn_ms=0.0, trace=np.array(trace))
         return it
 
+    def Point_Point_Error(self, PreviousScan, CurrentScan, max_dist_match, scale_max=None):
+        """icp6D::Point_Point_Error (icp6D.cc:293-367) -> (error, number of pairs)."""
+        if scale_max is None:
+            scale_max = 0.000001          # include/slam6d/icp6D.h default
+        err = C.c_double(0.0)
+        npairs = C.c_uint64(0)
+        check(lib().tdtk_point_point_error(PreviousScan.getSearchTree()._h, dptr(PreviousScan.dalignxf),
+                                           CurrentScan.handle, float(max_dist_match), float(scale_max),
+                                           C.byref(npairs), C.byref(err)))
+        return err.value, int(npairs.value)
+
     def doICP(self, allScans, pairing_mode=0, prefetch=True):
         """icp6D::doICP (icp6D.cc:374-437): sequential matching against the previous scan, or
         (meta) against a MetaScan of all / the last max_num_metascans processed scans.

@@ -179,6 +179,11 @@ int tdtk_scan_pairs(const tdtk_tree* model, const double source_alignxf[16], tdt
                     const double* lum_D /*[6] or NULL*/, int32_t* idx_out /*host, nullable*/,
                     tdtk_pair_sums* sums);
 
+/* icp6D::Point_Point_Error (src/slam6d/icp6D.cc:293-367): the closest-point pairs of the scan within
+ * max_dist_match of the model, error = -0.39894228 * mean exp(|p1-p2|^2 * log(scale_max) / max_dist_match^2). */
+int tdtk_point_point_error(const tdtk_tree* model, const double source_alignxf[16], tdtk_scan* data,
+                           double max_dist_match, double scale_max, uint64_t* np_out /*nullable*/, double* error_out);
+
 /* ---- minimizers: icp6Dminimizer::Align_Parallel with the merged sums in slot 0
  * (icp6Dquat.cc:515-634, icp6Dsvd.cc:170-280, icp6Dapx.cc:136-307, icp6Dnapx.cc:34-149),
  * serial-Align semantics (S normalised by 1/n; SVD reflection fix), and the serial-only

@@ -556,6 +556,17 @@ def match(prev, cur, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsil
     return it, trace
 
 
+def point_point_error(prev, cur, max_dist_match, scale_max):
+    """icp6D::Point_Point_Error (icp6D.cc:293-367), serial branch -> (error, number of pairs)"""
+    scale = math.log(scale_max) / (max_dist_match * max_dist_match)
+    r = get_pt_pairs(prev, cur, max_dist_match * max_dist_match)
+    d = ((r["p1"] - r["p2"]) ** 2).sum(axis=1)
+    error = 0.0
+    for v in d:                              # error -= 0.39894228 * exp(dist * scale), in pair order
+        error -= 0.39894228 * math.exp(v * scale)
+    return error / r["n"], r["n"]
+
+
 def do_icp(scans, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsilonICP=1e-7, meta=False,
            rnd=0, eP=True, max_num_metascans=-1):
     """icp6D::doICP (icp6D.cc:374-437) -> list of (iter, trace) per matched scan"""

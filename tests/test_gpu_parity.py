@@ -870,3 +870,20 @@ def test_doicp_prefetch_is_transparent(tdtk, gpu):
         tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 20, quiet=True, epsilonICP=1e-6).doICP(scans, prefetch=pf)
         out.append((np.stack([s.transMat for s in scans]), scans[-1].get_xyz_reduced(), [len(s.frames) for s in scans]))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+def test_point_point_error(tdtk, orc, gpu):
+    """icp6D::Point_Point_Error on the bundled pair, before and after matching."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    S, O = _dat_scans(tdtk.Scan, z), _dat_scans(io.OScan, z)
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 10, quiet=True, epsilonICP=1e-5)
+    for scale_max in (0.000001, 0.01):
+        e, n = icp.Point_Point_Error(S[0], S[1], 25.0, scale_max)
+        oe, on = io.point_point_error(O[0], O[1], 25.0, scale_max)
+        assert n == on and abs(e - oe) <= 1e-11 * abs(oe)
+    S[1].mergeCoordinatesWithRoboterPosition(S[0]); O[1].mergeCoordinatesWithRoboterPosition(O[0])
+    icp.match(S[0], S[1]); io.match(O[0], O[1], 1, 625.0, 10, 1e-5)
+    e, n = icp.Point_Point_Error(S[0], S[1], 20.0, 0.001)
+    oe, on = io.point_point_error(O[0], O[1], 20.0, 0.001)
+    assert n == on and abs(e - oe) <= 1e-9 * abs(oe)
