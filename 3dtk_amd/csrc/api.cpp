@@ -1514,4 +1514,326 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
   return TDTK_OK;
 }
 
+// ---- graph-SLAM back-ends (-G 1..4): per-link blocks, scatter + solve + pose update ------------------
+// One pair of entry points for lum6DEuler (lum6Deuler.cc), lum6DQuat (lum6Dquat.cc), ghelix6DQ2
+// (ghelix6DQ2.cc) and gapx6D (gapx6D.cc).  A rank computes the blocks of its links (device passes batched, one
+// sync), the blocks of all links are exchanged (one all-reduce: every link has one owner, the others hold zeros)
+// and every rank runs tdtk_graph_solve_update on the complete set: scatter in link order, solve, pose update.
+static const int kGraphBlock[5] = {0, 42, 56, 43, 49};
+
+int tdtk_graph_block_doubles(int backend)
+{
+  if (backend < 1 || backend > 4) return 0;
+  return kGraphBlock[backend];
+}
+
+int tdtk_graph_link_blocks(int backend, int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                           tdtk_scan* const* second, double maxd2, double* blocks)
+{
+  if (backend < 1 || backend > 4) { set_error("unknown graph back-end"); return TDTK_EINVAL; }
+  if (nlinks < 0 || (nlinks && (!first || !first_dalignxf || !second || !blocks))) { set_error("bad argument"); return TDTK_EINVAL; }
+  if (nlinks == 0) return TDTK_OK;
+  const int Bn = kGraphBlock[backend];
+  std::memset(blocks, 0, sizeof(double) * (size_t)nlinks * Bn);
+  if (backend == TDTK_GRAPH_LUMEULER) {
+    std::vector<double> C((size_t)nlinks * 36), CD((size_t)nlinks * 6);
+    int rc = tdtk_lum_links(nlinks, first, first_dalignxf, second, maxd2, C.data(), CD.data(), nullptr, nullptr);
+    if (rc) return rc;
+    for (int i = 0; i < nlinks; i++) {
+      std::memcpy(blocks + (size_t)i * Bn, C.data() + (size_t)i * 36, 36 * sizeof(double));
+      std::memcpy(blocks + (size_t)i * Bn + 36, CD.data() + (size_t)i * 6, 6 * sizeof(double));
+    }
+    return TDTK_OK;
+  }
+  const uint32_t want = (backend == TDTK_GRAPH_LUMQUAT) ? TDTK_WANT_LUM
+                        : (backend == TDTK_GRAPH_GHELIX ? TDTK_WANT_MOM2 : TDTK_WANT_GAPX);
+  std::vector<tdtk_pair_sums> sums((size_t)nlinks);
+  int rc = tdtk_links_pair_sums(nlinks, first, first_dalignxf, second, maxd2, want, sums.data());
+  if (rc) return rc;
+  for (int i = 0; i < nlinks; i++) {
+    const tdtk_pair_sums& s = sums[i];
+    double* b = blocks + (size_t)i * Bn;
+    const double m = (double)s.n;
+    if (backend == TDTK_GRAPH_LUMQUAT) {
+      // lum6DQuat::covarianceQuat (lum6Dquat.cc:81-248); ss from the normal equations (MM D = MZ)
+      if (s.n <= 2) continue;
+      const double* L = s.lum;
+      const double sx = L[0], sy = L[1], sz = L[2], xpy = L[3], xpz = L[4], ypz = L[5], xy = L[6], xz = L[7], yz = L[8];
+      const double MZ[7] = {L[9], L[10], L[11], s.lum_udot, -L[12], -L[14], -L[13]};
+      double MM[49] = {0};
+      auto set = [&](int r, int c, double v) { MM[r * 7 + c] = MM[c * 7 + r] = v; };
+      set(0, 0, m); set(1, 1, m); set(2, 2, m);
+      set(3, 3, (xpy + xpz + ypz) / 2.0); set(4, 4, ypz); set(5, 5, xpz); set(6, 6, xpy);
+      set(0, 3, sx); set(0, 5, -sz); set(0, 6, sy);
+      set(1, 3, sy); set(1, 4, sz);  set(1, 6, -sx);
+      set(2, 3, sz); set(2, 4, -sy); set(2, 5, sx);
+      set(4, 5, -xy); set(4, 6, -xz); set(5, 6, -yz);
+      double MMi[49], D[7], dmz = 0.0;
+      if (!invert_dense(7, MM, MMi)) { set_error("singular link matrix"); return TDTK_ESOLVE; }
+      for (int r = 0; r < 7; r++) {
+        double v = 0;
+        for (int k = 0; k < 7; k++) v += MMi[r * 7 + k] * MZ[k];
+        D[r] = v;
+        dmz += v * MZ[r];
+      }
+      const double ss = (s.sum - dmz) / (2.0 * m - 3.0);
+      for (int k = 0; k < 49; k++) b[k] = MM[k] / ss;
+      for (int k = 0; k < 7; k++) b[49 + k] = MZ[k] / ss;
+    } else if (backend == TDTK_GRAPH_GHELIX) {
+      // ghelix6DQ2::genBBdForLinkedPair (ghelix6DQ2.cc:88-150): raw moments of p2, antisymmetric part of sum p1 p2^T
+      if (s.n <= 1) continue;
+      const double* cm = s.centroid_m;
+      const double* cd = s.centroid_d;
+      double DD[3][3], X[3][3];
+      const double* dd = s.mom_dd;
+      const double ddm[3][3] = {{dd[0], dd[1], dd[2]}, {dd[1], dd[3], dd[4]}, {dd[2], dd[4], dd[5]}};
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+          DD[r][c] = ddm[r][c] + m * cd[r] * cd[c];
+          X[r][c] = s.Si[r * 3 + c] + m * cm[r] * cd[c];
+        }
+      const double s2[3] = {m * cd[0], m * cd[1], m * cd[2]};
+      double* Blk = b + 1;
+      auto set = [&](int r, int c, double v) { Blk[r * 6 + c] = Blk[c * 6 + r] = v; };
+      set(3, 3, m); set(4, 4, m); set(5, 5, m);
+      set(0, 4, -s2[2]); set(1, 3, s2[2]);
+      set(0, 5, s2[1]);  set(2, 3, -s2[1]);
+      set(2, 4, s2[0]);  set(1, 5, -s2[0]);
+      set(0, 1, -DD[0][1]); set(0, 2, -DD[0][2]); set(1, 2, -DD[1][2]);
+      set(0, 0, DD[2][2] + DD[1][1]); set(1, 1, DD[2][2] + DD[0][0]); set(2, 2, DD[0][0] + DD[1][1]);
+      double* bd1 = b + 37;
+      bd1[0] = X[2][1] - X[1][2]; bd1[1] = X[0][2] - X[2][0]; bd1[2] = X[1][0] - X[0][1];
+      for (int k = 0; k < 3; k++) bd1[3 + k] = m * (cm[k] - cd[k]);
+      b[0] = 1.0;
+    } else {
+      // gapx6D::genBArotForLinkedPair (gapx6D.cc:153-310); the centroids feed the translation step for
+      // every link, also the "empty" ones (gapx6D.cc:424-431)
+      for (int k = 0; k < 3; k++) { b[1 + k] = s.centroid_m[k]; b[4 + k] = s.centroid_d[k]; }
+      if (s.n <= 1) continue;
+      b[0] = 1.0;
+      std::memcpy(b + 7, s.gapx_MkMkt, 9 * sizeof(double));
+      std::memcpy(b + 16, s.gapx_DkDkt, 9 * sizeof(double));
+      std::memcpy(b + 25, s.gapx_MkDkt, 9 * sizeof(double));
+      std::memcpy(b + 34, s.gapx_DkMkt, 9 * sizeof(double));
+      std::memcpy(b + 43, s.gapx_Ak1, 3 * sizeof(double));
+      std::memcpy(b + 46, s.gapx_Ak2, 3 * sizeof(double));
+    }
+  }
+  return TDTK_OK;
+}
+
+// Scan::transform(A1) [then Scan::transform(A2)] for scans 1..nscans-1: matrices as Scan::transformMatrix
+// (scan.cc:878-898), resident point sets in one launch.  A1 / A2 are [nscans][16]; A2 nullable.
+static int apply_scan_moves(int nscans, const double* A1, const double* A2, double* transMat, double* dalignxf,
+                            double* rPos, double* rPosTheta, tdtk_scan* const* scans, double* xf_out)
+{
+  for (int i = 1; i < nscans; i++) {
+    double* tm = transMat + 16 * (size_t)i;
+    double* da = dalignxf + 16 * (size_t)i;
+    const double* a1 = A1 + 16 * (size_t)i;
+    mmult(a1, tm, tm); matrix4_to_euler(tm, rPosTheta + 3 * (size_t)i, rPos + 3 * (size_t)i); mmult(a1, da, da);
+    if (A2) {
+      const double* a2 = A2 + 16 * (size_t)i;
+      mmult(a2, tm, tm); matrix4_to_euler(tm, rPosTheta + 3 * (size_t)i, rPos + 3 * (size_t)i); mmult(a2, da, da);
+    }
+    if (xf_out) {
+      std::memcpy(xf_out + 32 * (size_t)i, a1, 16 * sizeof(double));
+      if (A2) std::memcpy(xf_out + 32 * (size_t)i + 16, A2 + 16 * (size_t)i, 16 * sizeof(double));
+      else m4identity(xf_out + 32 * (size_t)i + 16);
+    }
+  }
+  if (!scans) return TDTK_OK;
+  return tdtk_scans_transform2(nscans - 1, scans + 1, A1 + 16, A2 ? A2 + 16 : nullptr);
+}
+
+int tdtk_graph_solve_update(int backend, int nlinks, const int32_t* from, const int32_t* to, const double* blocks,
+                            int nscans, double* transMat, double* dalignxf, double* rPos, double* rPosTheta,
+                            tdtk_scan* const* scans, double* state, double* xf_out, double* ret)
+{
+  if (backend < 1 || backend > 4) { set_error("unknown graph back-end"); return TDTK_EINVAL; }
+  if (nlinks < 0 || nscans < 2 || !transMat || !dalignxf || !rPos || !rPosTheta || (nlinks && (!from || !to || !blocks))) {
+    set_error("bad argument");
+    return TDTK_EINVAL;
+  }
+  const int n = nscans - 1, Bn = kGraphBlock[backend];
+  for (int l = 0; l < nlinks; l++)
+    if (from[l] < 0 || to[l] < 0 || from[l] >= nscans || to[l] >= nscans) { set_error("link endpoint out of range"); return TDTK_EINVAL; }
+
+  if (backend == TDTK_GRAPH_LUMEULER) {
+    std::vector<double> C((size_t)nlinks * 36), CD((size_t)nlinks * 6), X((size_t)6 * n);
+    for (int i = 0; i < nlinks; i++) {
+      std::memcpy(C.data() + (size_t)i * 36, blocks + (size_t)i * Bn, 36 * sizeof(double));
+      std::memcpy(CD.data() + (size_t)i * 6, blocks + (size_t)i * Bn + 36, 6 * sizeof(double));
+    }
+    int rc = tdtk_lum_assemble_solve(nlinks, from, to, C.data(), CD.data(), nscans, X.data(), nullptr, nullptr);
+    if (rc) return rc;
+    return tdtk_lum_update_poses(nscans, X.data(), transMat, dalignxf, rPos, rPosTheta, scans, xf_out, ret);
+  }
+
+  std::vector<double> A1((size_t)nscans * 16, 0.0), A2;
+  double sum_position_diff = 0.0;
+
+  if (backend == TDTK_GRAPH_LUMQUAT) {
+    // FillGB3D (lum6Dquat.cc:248-276): diagonal blocks accumulate, off-diagonal blocks are ASSIGNED
+    const int N = 7 * n;
+    std::vector<double> G((size_t)N * N, 0.0), B((size_t)N, 0.0), X((size_t)N);
+    for (int l = 0; l < nlinks; l++) {
+      const int a = from[l] - 1, b = to[l] - 1;
+      const double* Cab = blocks + (size_t)l * Bn;
+      const double* CDab = Cab + 49;
+      auto blk = [&](int r, int c, double sgn, bool assign) {
+        for (int i = 0; i < 7; i++)
+          for (int j = 0; j < 7; j++) {
+            double& g = G[(size_t)(r * 7 + i) * N + (c * 7 + j)];
+            g = assign ? sgn * Cab[i * 7 + j] : g + sgn * Cab[i * 7 + j];
+          }
+      };
+      if (a >= 0) { for (int i = 0; i < 7; i++) B[a * 7 + i] += CDab[i]; blk(a, a, 1.0, false); }
+      if (b >= 0) { for (int i = 0; i < 7; i++) B[b * 7 + i] -= CDab[i]; blk(b, b, 1.0, false); }
+      if (a >= 0 && b >= 0) { blk(a, b, -1.0, true); blk(b, a, -1.0, true); }
+    }
+    if (!solve_spd_dense(N, G.data(), B.data(), X.data(), 0.00001)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+    A2.assign((size_t)nscans * 16, 0.0);
+    for (int i = 1; i < nscans; i++) {
+      // lum6Dquat.cc:347-441
+      const double* tm = transMat + 16 * (size_t)i;
+      double quat[4], tq[3];
+      matrix4_to_quat_t(tm, quat, tq);                    // rQuat follows transMat (scan.cc:886)
+      const double xa = rPos[3 * i], ya = rPos[3 * i + 1], za = rPos[3 * i + 2];
+      const double p = quat[0], q = quat[1], r = quat[2], s = quat[3];
+      const double px = p * xa, py = p * ya, pz = p * za, qx = q * xa, qy = q * ya, qz = q * za;
+      const double rx = r * xa, ry = r * ya, rz = r * za, sx = s * xa, sy = s * ya, sz = s * za;
+      double Ha[49] = {0}, Hi[49];
+      for (int k = 0; k < 7; k++) Ha[k * 7 + k] = 1.0;
+      auto H = [&](int rr, int cc) -> double& { return Ha[rr * 7 + cc]; };
+      H(3, 3) = 2 * p; H(4, 3) = 2 * q; H(5, 3) = 2 * r; H(6, 3) = 2 * s;
+      H(3, 4) = 2 * q; H(4, 4) = -2 * p; H(5, 4) = -2 * s; H(6, 4) = 2 * r;
+      H(3, 5) = 2 * r; H(4, 5) = 2 * s; H(5, 5) = -2 * p; H(6, 5) = -2 * q;
+      H(3, 6) = 2 * s; H(4, 6) = -2 * r; H(5, 6) = 2 * q; H(6, 6) = -2 * p;
+      H(0, 3) = -2 * (px + sy - rz); H(1, 3) = -2 * (-sx + py + qz); H(2, 3) = -2 * (rx - qy + pz);
+      H(0, 4) = -2 * (qx + ry + sz); H(1, 4) = -2 * (-rx + qy - pz); H(2, 4) = -2 * (-sx + py + qz);
+      H(0, 5) = -2 * (rx - qy + pz); H(1, 5) = -2 * (qx + ry + sz);  H(2, 5) = -2 * (-px - sy + rz);
+      H(0, 6) = -2 * (sx - py - qz); H(1, 6) = -2 * (px + sy - rz);  H(2, 6) = -2 * (qx + ry + sz);
+      if (!invert_dense(7, Ha, Hi)) { set_error("singular pose Jacobian"); return TDTK_ESOLVE; }
+      double result[7];
+      for (int rr = 0; rr < 7; rr++) {
+        double v = 0;
+        for (int k = 0; k < 7; k++) v += Hi[rr * 7 + k] * X[(size_t)(i - 1) * 7 + k];
+        result[rr] = v;
+      }
+      const double nP[3] = {xa - result[0], ya - result[1], za - result[2]};
+      double nQ[4] = {p - result[3], q - result[4], r - result[5], s - result[6]};
+      const double ql = std::sqrt(nQ[0] * nQ[0] + nQ[1] * nQ[1] + nQ[2] * nQ[2] + nQ[3] * nQ[3]);   // Normalize4
+      for (double& v : nQ) v /= ql;
+      m4inv(tm, A1.data() + 16 * (size_t)i);                // Scan::transformToQuat (scan.cc:1093-1104)
+      quat_to_matrix4(nQ, nP, A2.data() + 16 * (size_t)i);
+      sum_position_diff += std::sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
+    }
+  } else if (backend == TDTK_GRAPH_GHELIX) {
+    // state = B (N x N) | bd (N), zeroed by the caller once per doGraphSlam6D call (ghelix6DQ2.cc:329-330)
+    if (!state) { set_error("ghelix6DQ2 needs its state vector"); return TDTK_EINVAL; }
+    const int N = 6 * n;
+    double* B = state;
+    double* bd = state + (size_t)N * N;
+    for (int l = 0; l < nlinks; l++) {
+      const double* b = blocks + (size_t)l * Bn;
+      if (b[0] == 0.0) continue;
+      const int fa = from[l], fb = to[l];
+      if (fb == 0) { set_error("ghelix6DQ2: a link must not end at the fixed scan 0"); return TDTK_EINVAL; }
+      const double* Blk = b + 1;
+      const double* bd1 = b + 37;
+      const int a = (fa - 1) * 6, c = (fb - 1) * 6;
+      auto add = [&](int r0, int c0, double sgn) {
+        for (int i = 0; i < 6; i++)
+          for (int j = 0; j < 6; j++) B[(size_t)(r0 + i) * N + (c0 + j)] += sgn * Blk[i * 6 + j];
+      };
+      if (fa != 0) { add(a, a, 1.0); for (int i = 0; i < 6; i++) bd[a + i] += bd1[i]; }
+      add(c, c, 1.0);
+      for (int i = 0; i < 6; i++) bd[c + i] -= bd1[i];        // bd2 == -bd1 term by term (:126-138)
+      if (fa != 0) { add(a, c, -1.0); add(c, a, -1.0); }
+    }
+    std::vector<double> ccs((size_t)N);
+    if (!solve_spd_dense(N, B, bd, ccs.data(), 0.00001)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+    for (int i = 1; i < nscans; i++) {
+      double* a1 = A1.data() + 16 * (size_t)i;
+      helix_compute_rt(ccs.data() + (size_t)(i - 1) * 6, a1);
+      sum_position_diff += std::sqrt(a1[12] * a1[12] + a1[13] * a1[13] + a1[14] * a1[14]);
+    }
+  } else {
+    // gapx6D::doGraphSlam6D (gapx6D.cc:323-542).  state = T (3n), kept over the iterations of one call
+    if (!state) { set_error("gapx6D needs its translation state vector"); return TDTK_EINVAL; }
+    const int N = 3 * n;
+    std::vector<double> B((size_t)N * N, 0.0), A((size_t)N, 0.0), X((size_t)N);
+    for (int l = 0; l < nlinks; l++) {
+      const double* b = blocks + (size_t)l * Bn;
+      if (b[0] == 0.0) continue;
+      sum_position_diff += 1.0;                            // genBArotForLinkedPair returns 1.0 per link (sic)
+      const int f = from[l], sx = to[l];
+      if (sx == 0) { set_error("gapx6D: a link must not end at the fixed scan 0"); return TDTK_EINVAL; }
+      const int a = (f - 1) * 3, c = (sx - 1) * 3;
+      auto add = [&](int r0, int c0, const double* M9) {
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) B[(size_t)(r0 + i) * N + (c0 + j)] += M9[i * 3 + j];
+      };
+      if (f != 0) {
+        for (int i = 0; i < 3; i++) A[a + i] += b[43 + i];
+        add(a, a, b + 7); add(a, c, b + 34); add(c, a, b + 25);
+      }
+      for (int i = 0; i < 3; i++) A[c + i] += b[46 + i];
+      add(c, c, b + 16);
+    }
+    {   // cs_cholsol reads the upper triangle only (see tdtk_solve_chol_upper)
+      std::vector<double> S((size_t)N * N);
+      for (int i = 0; i < N; i++)
+        for (int j = i; j < N; j++) S[(size_t)i * N + j] = S[(size_t)j * N + i] = B[(size_t)i * N + j];
+      if (!solve_spd_dense(N, S.data(), A.data(), X.data(), 0.00001)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+    }
+    // translation system (genBAtransForLinkedPair, gapx6D.cc:76-137)
+    std::vector<double> Bt((size_t)n * n, 0.0), At((size_t)N, 0.0), Bti((size_t)n * n);
+    auto rot_apply = [&](const double* x, const double* p, double* out) {
+      double a16[16];
+      const double zero[3] = {0, 0, 0};
+      apx_compute_rt(x, zero, a16);
+      out[0] = (p[0] * a16[0] + p[1] * a16[4] + p[2] * a16[8]) + a16[12];    // Point::transform
+      out[1] = (p[0] * a16[1] + p[1] * a16[5] + p[2] * a16[9]) + a16[13];
+      out[2] = (p[0] * a16[2] + p[1] * a16[6] + p[2] * a16[10]) + a16[14];
+    };
+    for (int l = 0; l < nlinks; l++) {
+      const double* b = blocks + (size_t)l * Bn;
+      const int f = from[l], sx = to[l];
+      if (sx == 0) { set_error("gapx6D: a link must not end at the fixed scan 0"); return TDTK_EINVAL; }
+      const double zero[3] = {0, 0, 0};
+      double r1[3], r2[3];
+      rot_apply(f != 0 ? X.data() + (size_t)(f - 1) * 3 : zero, b + 1, r1);
+      rot_apply(X.data() + (size_t)(sx - 1) * 3, b + 4, r2);
+      const double Ak1[3] = {r1[0] - r2[0], r1[1] - r2[1], r1[2] - r2[2]};
+      if (f != 0) {
+        for (int i = 0; i < 3; i++) At[(size_t)(f - 1) * 3 + i] -= Ak1[i];
+        Bt[(size_t)(f - 1) * n + (f - 1)] += 1.0;
+        Bt[(size_t)(f - 1) * n + (sx - 1)] -= 1.0;
+        Bt[(size_t)(sx - 1) * n + (f - 1)] -= 1.0;
+      }
+      for (int i = 0; i < 3; i++) At[(size_t)(sx - 1) * 3 + i] += Ak1[i];
+      Bt[(size_t)(sx - 1) * n + (sx - 1)] += 1.0;
+    }
+    if (!invert_dense(n, Bt.data(), Bti.data())) { set_error("singular translation system"); return TDTK_ESOLVE; }
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        double v = 0;
+        for (int j = 0; j < n; j++) v += Bti[(size_t)i * n + j] * At[(size_t)j * 3 + k];
+        state[(size_t)i * 3 + k] += v;
+      }
+    for (int i = 1; i < nscans; i++) {
+      const double* dx = state + (size_t)(i - 1) * 3;
+      apx_compute_rt(X.data() + (size_t)(i - 1) * 3, dx, A1.data() + 16 * (size_t)i);
+      sum_position_diff += std::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+    }
+  }
+  int rc = apply_scan_moves(nscans, A1.data(), A2.empty() ? nullptr : A2.data(), transMat, dalignxf, rPos, rPosTheta,
+                            scans, xf_out);
+  if (rc) return rc;
+  if (ret) *ret = sum_position_diff / (double)nscans;
+  return TDTK_OK;
+}
+
 }  // extern "C"

@@ -481,6 +481,70 @@ void matrix4_to_quat(const double* mat, double quat[4], double t[3])
   t[0] = mat[12]; t[1] = mat[13]; t[2] = mat[14];
 }
 
+}  // namespace (helpers above are used below through the exported wrappers as well)
+
+// icp6D_HELIX::computeRt (icp6Dhelix.cc:144-206) for one scan's six unknowns
+void helix_compute_rt(const double ccs[6], double* alignxf)
+{
+  double R[3][3];
+  const double c[3] = {-ccs[0], -ccs[1], -ccs[2]}, cs[3] = {-ccs[3], -ccs[4], -ccs[5]};
+  const double CLength = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  const double rotationCheck = c[0] * cs[0] + c[1] * cs[1] + c[2] * cs[2];
+  const double angle = std::atan(CLength);
+  const double g[3] = {c[0] / CLength, c[1] / CLength, c[2] / CLength};
+  const double sinAngle = std::sin(-angle / 2);
+  const double b0 = std::cos(-angle / 2), b1 = g[0] * sinAngle, b2 = g[1] * sinAngle, b3 = g[2] * sinAngle;
+  R[0][0] = b0 * b0 + b1 * b1 - b2 * b2 - b3 * b3; R[0][1] = 2 * (b1 * b2 + b0 * b3); R[0][2] = 2 * (b1 * b3 - b0 * b2);
+  R[1][0] = 2 * (b1 * b2 - b0 * b3); R[1][1] = b0 * b0 - b1 * b1 + b2 * b2 - b3 * b3; R[1][2] = 2 * (b2 * b3 + b0 * b1);
+  R[2][0] = 2 * (b1 * b3 + b0 * b2); R[2][1] = 2 * (b2 * b3 - b0 * b1); R[2][2] = b0 * b0 - b1 * b1 - b2 * b2 + b3 * b3;
+  const double den = b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[i][j] /= den;
+  const double skewValue = rotationCheck / (CLength * CLength);
+  double gs[3];
+  for (int i = 0; i < 3; i++) gs[i] = (cs[i] - c[i] * skewValue) / CLength;
+  const double pT[3] = {g[1] * gs[2] - g[2] * gs[1], g[2] * gs[0] - g[0] * gs[2], g[0] * gs[1] - g[1] * gs[0]};
+  double t[3];
+  for (int i = 0; i < 3; i++)
+    t[i] = -(R[i][0] * pT[0] + R[i][1] * pT[1] + R[i][2] * pT[2]) + g[i] * (skewValue * angle) + pT[i];
+  m4identity(alignxf);
+  for (int r = 0; r < 3; r++) {
+    for (int cc = 0; cc < 3; cc++) alignxf[cc * 4 + r] = R[r][cc];
+    alignxf[12 + r] = t[r];
+  }
+}
+
+// Matrix4ToQuat / QuatToMatrix4 (globals.icc:1032-1075, 988-1022)
+void matrix4_to_quat_t(const double* mat, double quat[4], double t[3]);
+void quat_to_matrix4(const double quat[4], const double t[3], double* mat)
+{
+  const double q11 = quat[1] * quat[1], q22 = quat[2] * quat[2], q33 = quat[3] * quat[3];
+  const double q03 = quat[0] * quat[3], q13 = quat[1] * quat[3], q23 = quat[2] * quat[3];
+  const double q02 = quat[0] * quat[2], q12 = quat[1] * quat[2], q01 = quat[0] * quat[1];
+  mat[0] = 1 - 2 * (q22 + q33); mat[5] = 1 - 2 * (q11 + q33); mat[10] = 1 - 2 * (q11 + q22);
+  mat[4] = 2.0 * (q12 - q03); mat[1] = 2.0 * (q12 + q03);
+  mat[8] = 2.0 * (q13 + q02); mat[2] = 2.0 * (q13 - q02);
+  mat[9] = 2.0 * (q23 - q01); mat[6] = 2.0 * (q23 + q01);
+  mat[3] = mat[7] = mat[11] = 0.0;
+  mat[12] = t ? t[0] : 0.0; mat[13] = t ? t[1] : 0.0; mat[14] = t ? t[2] : 0.0;
+  mat[15] = 1.0;
+}
+
+// icp6D_APX::computeRt (icp6Dapx.cc:310-335): small-angle rotation from the three solved sines + dx
+void apx_compute_rt(const double x[3], const double dx[3], double* a)
+{
+  const double sx = x[0], sy = x[1], sz = x[2];
+  const double cx = std::sqrt(1.0 - sx * sx), cy = std::sqrt(1.0 - sy * sy), cz = std::sqrt(1.0 - sz * sz);
+  for (int i = 0; i < 16; i++) a[i] = 0.0;
+  a[0] = cy * cz; a[1] = sx * sy * cz + cx * sz; a[2] = -cx * sy * cz + sx * sz;
+  a[4] = -cy * sz; a[5] = -sx * sy * sz + cx * cz; a[6] = cx * sy * sz + sx * cz;
+  a[8] = sy; a[9] = -sx * cy; a[10] = cx * cy;
+  a[12] = dx[0]; a[13] = dx[1]; a[14] = dx[2];
+  a[15] = 1.0;
+}
+
+namespace {
+
 // unit basis forms: e(i) picks w_i; P1 = w[0..2], P2 = w[3..5]
 struct Form {
   double a[6];
@@ -599,28 +663,7 @@ int align_serial_only(int algo, const tdtk_pair_sums& s, const double pose[16], 
     const double bd[6] = {-Q(z2, dY) + Q(y2, dZ), Q(z2, dX) - Q(x2, dZ), -Q(y2, dX) + Q(x2, dY), L(dX), L(dY), L(dZ)};
     double ccs[6];
     if (!solve_dense(6, B, bd, ccs)) { err = "HELIX: singular system"; return TDTK_ESOLVE; }
-    // computeRt, icp6Dhelix.cc:144-206
-    const double c[3] = {-ccs[0], -ccs[1], -ccs[2]}, cs[3] = {-ccs[3], -ccs[4], -ccs[5]};
-    const double CLength = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-    const double rotationCheck = c[0] * cs[0] + c[1] * cs[1] + c[2] * cs[2];
-    const double angle = std::atan(CLength);
-    const double g[3] = {c[0] / CLength, c[1] / CLength, c[2] / CLength};
-    const double sinAngle = std::sin(-angle / 2);
-    const double b0 = std::cos(-angle / 2), b1 = g[0] * sinAngle, b2 = g[1] * sinAngle, b3 = g[2] * sinAngle;
-    R[0][0] = b0 * b0 + b1 * b1 - b2 * b2 - b3 * b3; R[0][1] = 2 * (b1 * b2 + b0 * b3); R[0][2] = 2 * (b1 * b3 - b0 * b2);
-    R[1][0] = 2 * (b1 * b2 - b0 * b3); R[1][1] = b0 * b0 - b1 * b1 + b2 * b2 - b3 * b3; R[1][2] = 2 * (b2 * b3 + b0 * b1);
-    R[2][0] = 2 * (b1 * b3 + b0 * b2); R[2][1] = 2 * (b2 * b3 - b0 * b1); R[2][2] = b0 * b0 - b1 * b1 - b2 * b2 + b3 * b3;
-    const double den = b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) R[i][j] /= den;
-    const double skewValue = rotationCheck / (CLength * CLength);
-    double gs[3];
-    for (int i = 0; i < 3; i++) gs[i] = (cs[i] - c[i] * skewValue) / CLength;
-    const double pT[3] = {g[1] * gs[2] - g[2] * gs[1], g[2] * gs[0] - g[0] * gs[2], g[0] * gs[1] - g[1] * gs[0]};
-    double t[3];
-    for (int i = 0; i < 3; i++)
-      t[i] = -(R[i][0] * pT[0] + R[i][1] * pT[1] + R[i][2] * pT[2]) + g[i] * (skewValue * angle) + pT[i];
-    rt_to_gl(R, t, alignxf);
+    helix_compute_rt(ccs, alignxf);
     return TDTK_OK;
   }
 
@@ -746,6 +789,8 @@ int align_serial_only(int algo, const tdtk_pair_sums& s, const double pose[16], 
 }
 
 }  // namespace
+
+void matrix4_to_quat_t(const double* mat, double quat[4], double t[3]) { matrix4_to_quat(mat, quat, t); }
 
 int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], double* rms, std::string& err)
 {

@@ -75,6 +75,11 @@ int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], doubl
 bool invert_dense(int n, const double* A, double* Ainv);  // LU with partial pivoting
 bool solve_spd_dense(int n, const double* G, const double* B, double* x, double drop);
 
+void helix_compute_rt(const double ccs[6], double* alignxf);                 // icp6Dhelix.cc:144-206
+void matrix4_to_quat_t(const double* mat, double quat[4], double t[3]);       // globals.icc:1032-1075
+void quat_to_matrix4(const double quat[4], const double t[3], double* mat);   // globals.icc:988-1022
+void apx_compute_rt(const double x[3], const double dx[3], double* alignxf);  // icp6Dapx.cc:310-335
+
 void set_error(const std::string& s);
 
 }  // namespace tdtk

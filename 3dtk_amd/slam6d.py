@@ -842,8 +842,8 @@ class ghelix6DQ2:
 
     def doGraphSlam6D(self, gr, allScans, nrIt, device=None):
         from .graphslam import ghelix_iteration
-        n = gr.getNrScans() - 1
-        state = (np.zeros((6 * n, 6 * n)), np.zeros(6 * n))
+        from .graphslam import graph_state
+        state = graph_state(3, gr.getNrScans())
         ret = float("inf")
         it = 0
         while it < nrIt and ret > self.epsilonLUM:

@@ -224,6 +224,25 @@ int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double
                          tdtk_scan* const* second, double max_dist_match2, uint32_t want,
                          tdtk_pair_sums* sums);
 
+/* ---- graph-SLAM back-ends by their -G id (src/slam6d/slam6D.cc:784-804): lum6DEuler 1 (lum6Deuler.cc),
+ * lum6DQuat 2 (lum6Dquat.cc), ghelix6DQ2 3 (ghelix6DQ2.cc), gapx6D 4 (gapx6D.cc).
+ * tdtk_graph_link_blocks: the per-link quantities of this rank's links (covarianceEuler / covarianceQuat /
+ *   genBBdForLinkedPair / genBArotForLinkedPair), tdtk_graph_block_doubles(backend) doubles per link; device
+ *   passes batched, one sync.
+ * tdtk_graph_solve_update: given the blocks of ALL links (after the all-reduce; zeros for links nobody could
+ *   fill), the scatter in link order (FillGB3D and its counterparts), the solve, and the pose update of scans
+ *   1..nscans-1: transMat / dalignxf [nscans][16], rPos / rPosTheta [nscans][3] are updated in place, resident
+ *   scans (scans[i] may be NULL) are moved, xf_out [nscans][32] (nullable) receives the one or two transforms
+ *   applied per scan.  state: ghelix6DQ2's B | bd ((6n)^2 + 6n doubles, zeroed once per doGraphSlam6D call),
+ *   gapx6D's T (3n, likewise); NULL for the LUM back-ends.  *ret = what doGraphSlam6D's loop tests.       */
+enum { TDTK_GRAPH_LUMEULER = 1, TDTK_GRAPH_LUMQUAT = 2, TDTK_GRAPH_GHELIX = 3, TDTK_GRAPH_GAPX = 4 };
+int tdtk_graph_block_doubles(int backend);
+int tdtk_graph_link_blocks(int backend, int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                           tdtk_scan* const* second, double max_dist_match2, double* blocks);
+int tdtk_graph_solve_update(int backend, int nlinks, const int32_t* from, const int32_t* to, const double* blocks,
+                            int nscans, double* transMat, double* dalignxf, double* rPos, double* rPosTheta,
+                            tdtk_scan* const* scans, double* state, double* xf_out, double* ret);
+
 /* Scan::transform for many resident scans at once: scan i is moved in place by A1[i] and then by A2[i]
  * (A2 nullable), e.g. Scan::transformToEuler / transformToQuat (scan.cc:1061-1104) = M4inv(transMat) then
  * the new pose; one kernel launch for all of them.                                               */

@@ -887,3 +887,36 @@ def test_point_point_error(tdtk, orc, gpu):
     e, n = icp.Point_Point_Error(S[0], S[1], 20.0, 0.001)
     oe, on = io.point_point_error(O[0], O[1], 20.0, 0.001)
     assert n == on and abs(e - oe) <= 1e-9 * abs(oe)
+
+
+@pytest.mark.parametrize("backend", [1, 2, 3, 4])
+def test_graph_backends_blocks_are_rank_count_independent(tdtk, gpu, backend):
+    """tdtk_graph_link_blocks per link does not depend on which other links share the batch, so any dealing of
+    the links over ranks reproduces the single-rank blocks bit for bit (what makes X independent of N)."""
+    import ctypes as C, sys
+    from importlib import import_module
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    gs = import_module("3dtk_amd.graphslam"); capi = import_module("3dtk_amd._capi")
+    raw = bench.make_graphslam_scans(8, 20000, seed=5)
+    S = [tdtk.Scan(p, th, loc) for (p, th, loc) in raw]
+    gr = tdtk.Graph(8, 900.0 ** 2, 3, S)
+    nl = gr.getNrLinks()
+    Bn = capi.lib().tdtk_graph_block_doubles(backend)
+    def blocks(idx):
+        n = len(idx)
+        first = (C.c_void_p * n)(*[S[gr.getLink(i, 0)].getSearchTree()._h for i in idx])
+        second = (C.c_void_p * n)(*[S[gr.getLink(i, 1)].handle for i in idx])
+        dal = np.ascontiguousarray(np.stack([S[gr.getLink(i, 0)].dalignxf for i in idx]))
+        out = np.empty((n, Bn))
+        capi.check(capi.lib().tdtk_graph_link_blocks(backend, n, first, capi.dptr(dal), second, 625.0, capi.dptr(out)))
+        return out
+    full = blocks(list(range(nl)))
+    for world in (2, 3):
+        part = np.zeros_like(full)
+        for r in range(world):
+            mine = gs.shard_links(gr, r, world)
+            if mine:
+                part[mine] = blocks(mine)
+        assert np.array_equal(part, full)
+    assert np.abs(full).sum() > 0
