@@ -134,6 +134,26 @@ def transform_many(scans, A1, A2=None, type="LUM"):
         s.frames.append((s.transMat.copy(), type))
 
 
+def prepare_scans(scans, trees=True, threads=4):
+    """Upload the scans and (trees=True) build their search trees on `threads` host threads, each with its
+    own HIP stream.  A tree build is mostly a serial fp64 chain that occupies three wavefronts, so several
+    of them run side by side on one GPU at almost no cost to each other."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def prep(s):
+        _ = s.handle
+        if trees:
+            s.getSearchTree()
+    scans = list(scans)
+    if threads <= 1 or len(scans) <= 1:
+        for s in scans:
+            prep(s)
+        return
+    with ThreadPoolExecutor(threads) as pool:
+        for f in [pool.submit(prep, s) for s in scans]:
+            f.result()
+
+
 def host_tree_layout(xyz, bucketSize=20):
     """Host tree builder only (no device): leaf-order permutation + stats."""
     xyz = f64(xyz).reshape(-1, 3)

@@ -293,9 +293,12 @@ def bench_graphslam(args, rank, world, local):
     g0 = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)
     nlinks = g0.getNrLinks()
     mine = gs.shard_links(g0, rank, world)
-    for i in mine:                                      # materialise what this rank touches
-        scans[g0.getLink(i, 0)].getSearchTree()
-        _ = scans[g0.getLink(i, 1)].handle
+    # materialise what this rank touches (trees of the link sources, points of the link targets),
+    # several at a time: a tree build keeps only a few wavefronts busy
+    need_tree = sorted({g0.getLink(i, 0) for i in mine})
+    need_pts = sorted({g0.getLink(i, 1) for i in mine} - set(need_tree))
+    tdtk.prepare_scans([scans[k] for k in need_tree], trees=True, threads=8)
+    tdtk.prepare_scans([scans[k] for k in need_pts], trees=False, threads=8)
     import torch.distributed as tdist
     dev = torch.device("cuda", local) if (tdist.is_available() and tdist.is_initialized()) else None
     nn_ms = [0.0]
