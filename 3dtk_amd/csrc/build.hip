@@ -179,8 +179,7 @@ __global__ void k_flags(const uint32_t* __restrict__ seg_of, const uint32_t* __r
 // ---- per element: misplaced on the left / on the right of its node's split position --------------
 __global__ void k_misplaced(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
                             const BSeg* __restrict__ segs, const uint32_t* __restrict__ f,
-                            const uint32_t* __restrict__ F, uint32_t M, uint32_t* __restrict__ isL,
-                            uint32_t* __restrict__ isR)
+                            const uint32_t* __restrict__ F, uint32_t M, unsigned long long* __restrict__ LR)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > M) return;
@@ -195,34 +194,35 @@ __global__ void k_misplaced(const uint32_t* __restrict__ seg_of, const uint32_t*
       r = (!left_region && f[p]) ? 1u : 0u;
     }
   }
-  isL[p] = l;
-  isR[p] = r;
+  LR[p] = (unsigned long long)l | ((unsigned long long)r << 32);   // one scan serves both counts
 }
 
 // k-th misplaced from the left pairs with the k-th misplaced from the right end
 __global__ void k_swaplist(const uint32_t* __restrict__ seg_of, const BSeg* __restrict__ segs,
-                           const uint32_t* __restrict__ isL, const uint32_t* __restrict__ isR,
-                           const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t M,
-                           uint32_t* __restrict__ posL, uint32_t* __restrict__ posR)
+                           const unsigned long long* __restrict__ LR, const unsigned long long* __restrict__ AB,
+                           uint32_t M, uint32_t* __restrict__ posL, uint32_t* __restrict__ posR)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
-  if (isL[p]) posL[A[p]] = p;
-  if (isR[p]) {
+  const unsigned long long lr = LR[p];
+  if ((uint32_t)lr) posL[(uint32_t)AB[p]] = p;
+  if ((uint32_t)(lr >> 32)) {
     const uint32_t sg = seg_of[p];
     const uint32_t s = segs[sg].start, n = segs[sg].n;
-    const uint32_t total = B[s + n] - B[s];
-    const uint32_t kfwd = B[p] - B[s];
-    posR[B[s] + (total - 1u - kfwd)] = p;
+    const uint32_t Bs = (uint32_t)(AB[s] >> 32);
+    const uint32_t total = (uint32_t)(AB[s + n] >> 32) - Bs;
+    const uint32_t kfwd = (uint32_t)(AB[p] >> 32) - Bs;
+    posR[Bs + (total - 1u - kfwd)] = p;
   }
 }
 
-__global__ void k_swap(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR, uint32_t nswap,
-                       uint32_t* __restrict__ perm, double* __restrict__ cx, double* __restrict__ cy,
-                       double* __restrict__ cz)
+// launched over M/2 slots (an element is misplaced at most once per level); the count sits on the device
+__global__ void k_swap(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
+                       const unsigned long long* __restrict__ nswap_ptr, uint32_t* __restrict__ perm,
+                       double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz)
 {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nswap) return;
+  if (c >= (uint32_t)*nswap_ptr) return;
   const uint32_t a = posL[c], b = posR[c];
   const uint32_t pa = perm[a], pb = perm[b];
   perm[a] = pb; perm[b] = pa;
@@ -323,13 +323,17 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hip
   {
     uint32_t* z = nullptr;
     (void)rocprim::exclusive_scan(nullptr, scan_tmp, z, z, 0u, (size_t)M + 1, rocprim::plus<uint32_t>(), s);
+    unsigned long long* z8 = nullptr;
+    size_t t8 = 0;
+    (void)rocprim::exclusive_scan(nullptr, t8, z8, z8, 0ull, (size_t)M + 1, rocprim::plus<unsigned long long>(), s);
+    if (t8 > scan_tmp) scan_tmp = t8;
   }
   const size_t n1 = (size_t)M + 1;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_perm = take(4 * n1), o_segof = take(4 * n1), o_cx = take(8 * n1), o_cy = take(8 * n1), o_cz = take(8 * n1);
-  const size_t o_f = take(4 * n1), o_F = take(4 * n1), o_isL = take(4 * n1), o_isR = take(4 * n1), o_A = take(4 * n1),
-               o_B = take(4 * n1), o_posL = take(4 * n1), o_posR = take(4 * n1);
+  const size_t o_f = take(4 * n1), o_F = take(4 * n1), o_isL = take(8 * n1), o_A = take(8 * n1),
+               o_posL = take(4 * n1), o_posR = take(4 * n1);
   const size_t o_segA = take(sizeof(BSeg) * n1), o_segB = take(sizeof(BSeg) * n1), o_meas = take(sizeof(BMeas) * n1);
   const size_t o_kind = take(4 * n1), o_axis = take(4 * n1), o_split = take(8 * n1), o_irank = take(4 * n1);
   const size_t o_tmp = take(scan_tmp + 256), o_small = take(256);
@@ -341,9 +345,9 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hip
   {
     uint32_t* perm = (uint32_t*)(arena + o_perm); uint32_t* seg_of = (uint32_t*)(arena + o_segof);
     double *cx = (double*)(arena + o_cx), *cy = (double*)(arena + o_cy), *cz = (double*)(arena + o_cz);
-    uint32_t *f = (uint32_t*)(arena + o_f), *F = (uint32_t*)(arena + o_F), *isL = (uint32_t*)(arena + o_isL),
-             *isR = (uint32_t*)(arena + o_isR), *A = (uint32_t*)(arena + o_A), *B = (uint32_t*)(arena + o_B),
+    uint32_t *f = (uint32_t*)(arena + o_f), *F = (uint32_t*)(arena + o_F),
              *posL = (uint32_t*)(arena + o_posL), *posR = (uint32_t*)(arena + o_posR);
+    unsigned long long *LR = (unsigned long long*)(arena + o_isL), *AB = (unsigned long long*)(arena + o_A);
     BSeg* segs = (BSeg*)(arena + o_segA); BSeg* next = (BSeg*)(arena + o_segB);
     BMeas* meas = (BMeas*)(arena + o_meas);
     uint32_t *kind = (uint32_t*)(arena + o_kind), *axis = (uint32_t*)(arena + o_axis), *irank = (uint32_t*)(arena + o_irank);
@@ -363,34 +367,26 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hip
       size_t st = scan_tmp;
       BCHK(hipMemsetAsync(kind + nseg, 0, 4, s));
       BCHK(rocprim::exclusive_scan(tmp, st, kind, irank, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), s));
-      uint32_t n_internal = 0;
-      BCHK(hipMemcpyAsync(&n_internal, irank + nseg, 4, hipMemcpyDeviceToHost, s));
-      BCHK(hipStreamSynchronize(s));
       hipLaunchKernelGGL(k_emit, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, kind, axis, splitval, irank,
                          node_count, leaf_count, nodes, node_r, leaf_tab, small + 0, small + 1);
-      if (n_internal) {
-        hipLaunchKernelGGL(k_flags, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy, cz, M, f);
-        st = scan_tmp;
-        BCHK(rocprim::exclusive_scan(tmp, st, f, F, 0u, n1, rocprim::plus<uint32_t>(), s));
-        hipLaunchKernelGGL(k_misplaced, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, segs, f, F, M, isL, isR);
-        st = scan_tmp;
-        BCHK(rocprim::exclusive_scan(tmp, st, isL, A, 0u, n1, rocprim::plus<uint32_t>(), s));
-        st = scan_tmp;
-        BCHK(rocprim::exclusive_scan(tmp, st, isR, B, 0u, n1, rocprim::plus<uint32_t>(), s));
-        hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, isL, isR, A, B, M, posL, posR);
-        // every element is misplaced at most once per level, so M bounds the swap count; the
-        // exact count sits in A[M] -- launch over M and let the kernel read it from there
-        uint32_t nswap = 0, bad = 0;
-        hipLaunchKernelGGL(k_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, kind, irank, F, node_count,
-                           next, small + 2);
-        BCHK(hipMemcpyAsync(&nswap, A + M, 4, hipMemcpyDeviceToHost, s));
-        BCHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
-        BCHK(hipStreamSynchronize(s));
-        if (bad || depth > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
-        if (nswap)
-          hipLaunchKernelGGL(k_swap, dim3(cdiv(nswap, 256)), dim3(256), 0, s, posL, posR, nswap, perm, cx, cy, cz);
-        hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, F, M, seg_of);
-      }
+      // the partition pass is enqueued unconditionally (with no internal node at this level it moves nothing),
+      // so the level needs a single round trip to the host: the number of internal nodes and the error flag
+      hipLaunchKernelGGL(k_flags, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy, cz, M, f);
+      st = scan_tmp;
+      BCHK(rocprim::exclusive_scan(tmp, st, f, F, 0u, n1, rocprim::plus<uint32_t>(), s));
+      hipLaunchKernelGGL(k_misplaced, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, segs, f, F, M, LR);
+      st = scan_tmp;
+      BCHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+      hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
+      hipLaunchKernelGGL(k_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, kind, irank, F, node_count,
+                         next, small + 2);
+      hipLaunchKernelGGL(k_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
+      hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, F, M, seg_of);
+      uint32_t n_internal = 0, bad = 0;
+      BCHK(hipMemcpyAsync(&n_internal, irank + nseg, 4, hipMemcpyDeviceToHost, s));
+      BCHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
+      BCHK(hipStreamSynchronize(s));
+      if (bad || depth > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
       node_count += n_internal;
       leaf_count += nseg - n_internal;
       nseg = 2 * n_internal;
