@@ -1,11 +1,14 @@
 """TEST INFRASTRUCTURE ONLY: numpy restatement of the tiny algebra around the hot path --
-icp6Dminimizer::Align for QUAT / SVD / APX / NAPX, the icp6D::match loop (serial-branch
-semantics), lum6DEuler::covarianceEuler / doGraphSlam6D, Graph, and the uos / .pose readers.
+icp6Dminimizer::Align for all ten -a minimizers, the icp6D::match loop (serial-branch
+semantics), the graph back-ends lum6DEuler / lum6DQuat / ghelix6DQ2 / gapx6D, Graph (also the
+clpairs variant), Point_Point_Error, and the uos / .pose readers.
 The heavy per-point work is done by oracle/oracle.c (oracle/orc.py).
 
-Each function cites the reference file:line it follows.  Pinned by
-tests/test_oracle_vs_ref.py against the reference's own minimizer TUs (oracle/_ref) and
-against the committed fixtures in tests/golden/.
+Each function cites the reference file:line it follows.  PINNED by tests/test_oracle_vs_ref.py
+against the reference's own minimizer TUs (oracle/_ref) and the committed fixtures in
+tests/golden/: the ten minimizers and the match loop.  PARITY UNPINNED (their TUs need Boost /
+SuiteSparse, so they cannot be compiled here; restated by reading): the graph back-ends, the
+sparse solve, the clpairs graph, Point_Point_Error.
 
 The eigen / SVD / Cholesky kernels use numpy.linalg (LAPACK) where the reference uses a
 closed-form quartic + LU (icp6Dquat.cc:405-513), newmat SVD and Numerical-Recipes Cholesky:

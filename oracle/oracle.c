@@ -12,11 +12,13 @@
  * left-to-right association; build with -ffp-contract=off (the reference is
  * compiled -O3 without -march=native, i.e. no FMA contraction on x86-64).
  *
- * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks this file
- * against the reference's own translation units (kdIndexed.cc, icp6Dquat.cc,
- * icp6Dsvd.cc, icp6Dapx.cc, icp6Dnapx.cc) built by oracle/build_ref.sh into
- * oracle/_ref/, against the known-answer tests of testing/kdtree/, and against
- * the committed fixtures under tests/golden/.
+ * Parity status: PINNED for the tree, the searches, getPtPairs and the 4x4
+ * helpers: tests/test_oracle_vs_ref.py checks this file against the reference's
+ * own translation units (kdIndexed.cc and the minimizer TUs) built by
+ * oracle/build_ref.sh into oracle/_ref/, against the known-answer tests of
+ * testing/kdtree/, and against the committed fixtures under tests/golden/.
+ * PARITY UNPINNED for orc_octree_center (Boctree.h cannot be compiled here; see
+ * the comment at that function).
  */
 #include <math.h>
 #include <stdint.h>
