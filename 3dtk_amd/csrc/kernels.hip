@@ -619,10 +619,10 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
 // lowest index first among equals -- which is what the serial strict '<' scan in stored order
 // returns.  Same visiting order as k_search, hence the same indices.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD>
+template <int BLOCK, int SD, int GS = 8>
 __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
 {
-  constexpr int GS = 8, NG = BLOCK / GS;
+  constexpr int NG = BLOCK / GS;
   __shared__ double lds_m2[SD][NG];
   __shared__ uint32_t lds_ref[SD][NG];
 
@@ -1212,10 +1212,10 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 // Variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>); the default picks by batch size.
 // The full ladder that was measured is in DESIGN.md section 6.
 //   0: the first working kernel (LDS stack 8 deep, per-lane node loads)
-//   4: + 4-deep LDS stack, wave-uniform scalar node loads          (default for 128K..256K queries)
+//   4: + 4-deep LDS stack, wave-uniform scalar node loads          (default for 96K..256K queries)
 //   5: wave-cooperative LDS staging of distinct nodes / buckets    (kept as a measured negative)
 //   8: persistent lanes, 256 queries per wave, 256-thread workgroups
-//   9: eight lanes per query (k_search_g8)                         (default below 128K queries)
+//   9 / 10 / 11: eight / four / sixteen lanes per query (k_search_g8); four is the default below 96K queries
 //  20: persistent lanes, 256 queries per wave, 128-thread workgroups (default from 256K queries)
 static int search_variant()
 {
@@ -1223,7 +1223,7 @@ static int search_variant()
   if (v < 0) {
     const char* e = getenv("TDTK_SEARCH_VARIANT");
     v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-    if (v != 0 && v != 4 && v != 5 && v != 9 && v != 8 && v != 20) v = -2;
+    if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20) v = -2;
   }
   return v;
 }
@@ -1275,13 +1275,15 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
     int v = search_variant();
     // persistent lanes pay off once there are enough queries to keep every SIMD supplied with
     // several 256-query waves; small batches keep one query per lane
-    if (v == -2) v = (a.n >= (size_t)262144) ? 20 : ((a.n >= (size_t)131072) ? 4 : 9);
+    if (v == -2) v = (a.n >= (size_t)262144) ? 20 : ((a.n >= (size_t)98304) ? 4 : 10);
     switch (v) {
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
       case 8: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
       case 20: hipLaunchKernelGGL((k_search_refill<128, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 128)), dim3(128), 0, s, a); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
+      case 10: hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid(a.n) / 2 < 8 ? 8 : (g8_grid(a.n) / 2 + 7) / 8 * 8), dim3(256), 0, s, a); break;
+      case 11: hipLaunchKernelGGL((k_search_g8<256, 16, 16>), dim3(g8_grid(a.n) * 2), dim3(256), 0, s, a); break;
       default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
     }
   }
