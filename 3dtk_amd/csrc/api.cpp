@@ -64,6 +64,13 @@ struct DevBuf {
 enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
        WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_COUNT };
 
+// an auxiliary stream with the buffers one whole-scan pass needs: batches of links over small scans run several
+// passes side by side (one pass of an 80K-point scan occupies a fraction of the machine and is latency-bound)
+struct Lane {
+  hipStream_t s = nullptr;
+  DevBuf kpos, part, ovf_m2, ovf_ref;
+};
+
 struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
@@ -72,6 +79,7 @@ struct Ctx {
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
   double last_nn_ms = 0.0;
   bool ev_pending = false;
+  std::vector<std::unique_ptr<Lane>> lanes;
 };
 
 static thread_local std::map<int, std::unique_ptr<Ctx>> g_ctx;
@@ -268,20 +276,24 @@ int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info)
 // ------------------------------------------------------------------------------------------
 // internal: one search pass over SoA queries
 // ------------------------------------------------------------------------------------------
-static int prepare_overflow(Ctx* c, const tdtk_tree* t, uint32_t grid, SearchArgs& a)
+static int prepare_overflow_in(DevBuf& bm2, DevBuf& bref, const tdtk_tree* t, uint32_t grid, SearchArgs& a)
 {
   const int need = (int)t->info.max_depth - 1 - search_lds_depth();
   a.ovf_m2 = nullptr; a.ovf_ref = nullptr;
   if (need > 0) {
     const size_t lanes = (size_t)grid * search_block();
-    int rc = c->ws[WS_OVF_M2].ensure(lanes * need * sizeof(double));
+    int rc = bm2.ensure(lanes * need * sizeof(double));
     if (rc) return rc;
-    rc = c->ws[WS_OVF_REF].ensure(lanes * need * sizeof(uint32_t));
+    rc = bref.ensure(lanes * need * sizeof(uint32_t));
     if (rc) return rc;
-    a.ovf_m2 = c->ws[WS_OVF_M2].as<double>();
-    a.ovf_ref = c->ws[WS_OVF_REF].as<uint32_t>();
+    a.ovf_m2 = bm2.as<double>();
+    a.ovf_ref = bref.as<uint32_t>();
   }
   return TDTK_OK;
+}
+static int prepare_overflow(Ctx* c, const tdtk_tree* t, uint32_t grid, SearchArgs& a)
+{
+  return prepare_overflow_in(c->ws[WS_OVF_M2], c->ws[WS_OVF_REF], t, grid, a);
 }
 
 static int run_search(Ctx* c, const tdtk_tree* t, SearchArgs& a, int dirmode, bool count, hipStream_t s,
@@ -1216,28 +1228,45 @@ int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_
 }
 
 // ---- batched whole-scan passes over a list of links --------------------------------------------
-int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
-                         tdtk_scan* const* second, double maxd2, uint32_t want, tdtk_pair_sums* sums)
+// search + sums of every link, kernels enqueued back to back, one host sync.  Links over small scans are dealt to
+// up to 8 auxiliary streams (each pass alone leaves most of the machine idle); big scans keep the one stream.
+// acc: [nlinks][ACC_TOTAL] raw columns; shifts: [nlinks][3].
+static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                             tdtk_scan* const* second, double maxd2, unsigned want, std::vector<double>& acc,
+                             std::vector<double>& shifts)
 {
-  if (nlinks < 0 || (nlinks && (!first || !first_dalignxf || !second || !sums))) { set_error("bad argument"); return TDTK_EINVAL; }
-  if (nlinks == 0) return TDTK_OK;
-  if (want & TDTK_WANT_NAPX) { set_error("NAPX needs normals: use tdtk_scan_pairs"); return TDTK_EUNSUP; }
-  Ctx* c;
-  int rc = get_ctx(first[0]->device, &c);
-  if (rc) return rc;
   hipStream_t s = c->stream;
+  int rc;
   if ((rc = c->ws[WS_TMPB].ensure((size_t)nlinks * ACC_TOTAL * sizeof(double)))) return rc;
   double* d_out = c->ws[WS_TMPB].as<double>();
-  std::vector<double> shifts(3 * (size_t)nlinks);
+  shifts.assign(3 * (size_t)nlinks, 0.0);
   size_t maxN = 0;
   for (int i = 0; i < nlinks; i++) {
     if (!first[i] || !second[i]) { set_error("NULL link member"); return TDTK_EINVAL; }
     if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
     maxN = std::max(maxN, second[i]->N);
   }
-  if ((rc = c->ws[WS_KPOS].ensure(maxN * sizeof(int)))) return rc;
-  if ((rc = c->ws[WS_PART].ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+  int max_lanes = 8;
+  if (const char* e = getenv("TDTK_LINK_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));
+  // small scans: a pass is latency-bound, 8 side by side; big scans: 4, so the thin tail of one search and the
+  // small sum kernels overlap with the next search (16 x 1M, 18 links: 4.8 -> 3.4 ms)
+  const int L = (nlinks > 1) ? std::min(nlinks, std::min(max_lanes, maxN <= (size_t)262144 ? 8 : 4)) : 1;
   HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
+  if (L > 1) {
+    while ((int)c->lanes.size() < L) {
+      std::unique_ptr<Lane> ln(new Lane);
+      HIPCHK(hipStreamCreateWithFlags(&ln->s, hipStreamNonBlocking));
+      c->lanes.push_back(std::move(ln));
+    }
+    HIPCHK(hipStreamSynchronize(s));   // d_out is zeroed before any lane writes into it
+    for (int l = 0; l < L; l++) {
+      if ((rc = c->lanes[l]->kpos.ensure(maxN * sizeof(int)))) return rc;
+      if ((rc = c->lanes[l]->part.ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+    }
+  } else {
+    if ((rc = c->ws[WS_KPOS].ensure(maxN * sizeof(int)))) return rc;
+    if ((rc = c->ws[WS_PART].ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+  }
   for (int i = 0; i < nlinks; i++) {
     const tdtk_tree* t = first[i];
     tdtk_scan* data = second[i];
@@ -1248,24 +1277,51 @@ int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double
     Mat4 A, inv;
     std::memcpy(A.m, A16, sizeof A.m);
     m4inv(A16, inv.m);
+    Lane* ln = (L > 1) ? c->lanes[i % L].get() : nullptr;
+    hipStream_t ls = ln ? ln->s : s;
     SearchArgs sa{};
     sa.x = data->x; sa.y = data->y; sa.z = data->z;
     sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
-    sa.kpos = c->ws[WS_KPOS].as<int>();
-    rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1);
-    if (rc) return rc;
+    sa.kpos = ln ? ln->kpos.as<int>() : c->ws[WS_KPOS].as<int>();
+    if (ln) {
+      sa.T = t->dev;
+      const uint32_t grid = search_grid(sa.n);
+      if ((rc = prepare_overflow_in(ln->ovf_m2, ln->ovf_ref, t, grid, sa))) return rc;
+      const bool timed = (i == nlinks - 1);      // tdtk_last_kernel_ms: this search, running beside the other lanes'
+      if (timed) HIPCHK(hipEventRecord(c->e0, ls));
+      HIPCHK(launch_search(sa, grid, 0, false, ls));
+      if (timed) { HIPCHK(hipEventRecord(c->e1, ls)); c->ev_pending = true; }
+    } else {
+      if ((rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1))) return rc;
+    }
     AccumArgs aa{};
     aa.T = t->dev;
     aa.x = data->x; aa.y = data->y; aa.z = data->z;
     aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
     for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * i + k];
-    aa.partials = c->ws[WS_PART].as<double>();
-    HIPCHK(launch_accum(aa, accum_grid(data->N), want, 0, d_out + (size_t)i * ACC_TOTAL, s));
+    aa.partials = ln ? ln->part.as<double>() : c->ws[WS_PART].as<double>();
+    HIPCHK(launch_accum(aa, accum_grid(data->N), want, 0, d_out + (size_t)i * ACC_TOTAL, ls));
   }
-  std::vector<double> acc((size_t)nlinks * ACC_TOTAL);
+  for (int l = 0; l < L && L > 1; l++) HIPCHK(hipStreamSynchronize(c->lanes[l]->s));
+  acc.assign((size_t)nlinks * ACC_TOTAL, 0.0);
   HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   collect_ms(c, nullptr);
+  return TDTK_OK;
+}
+
+int tdtk_links_pair_sums(int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                         tdtk_scan* const* second, double maxd2, uint32_t want, tdtk_pair_sums* sums)
+{
+  if (nlinks < 0 || (nlinks && (!first || !first_dalignxf || !second || !sums))) { set_error("bad argument"); return TDTK_EINVAL; }
+  if (nlinks == 0) return TDTK_OK;
+  if (want & TDTK_WANT_NAPX) { set_error("NAPX needs normals: use tdtk_scan_pairs"); return TDTK_EUNSUP; }
+  if (!first[0]) { set_error("NULL link member"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(first[0]->device, &c);
+  if (rc) return rc;
+  std::vector<double> acc, shifts;
+  if ((rc = links_device_pass(c, nlinks, first, first_dalignxf, second, maxd2, want, acc, shifts))) return rc;
   for (int i = 0; i < nlinks; i++)
     finish_sums(acc.data() + (size_t)i * ACC_TOTAL, shifts.data() + 3 * i, second[i]->N, want, sums + i);
   return TDTK_OK;
@@ -1296,52 +1352,12 @@ int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* firs
 {
   if (nlinks < 0 || (nlinks && (!first || !first_dalignxf || !second || !C || !CD))) { set_error("bad argument"); return TDTK_EINVAL; }
   if (nlinks == 0) return TDTK_OK;
+  if (!first[0]) { set_error("NULL link member"); return TDTK_EINVAL; }
   Ctx* c;
   int rc = get_ctx(first[0]->device, &c);
   if (rc) return rc;
-  hipStream_t s = c->stream;
-  if ((rc = c->ws[WS_TMPB].ensure((size_t)nlinks * ACC_TOTAL * sizeof(double)))) return rc;
-  double* d_out = c->ws[WS_TMPB].as<double>();
-  std::vector<double> shifts(3 * (size_t)nlinks);
-  size_t maxN = 0;
-  for (int i = 0; i < nlinks; i++) {
-    if (!first[i] || !second[i]) { set_error("NULL link member"); return TDTK_EINVAL; }
-    if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
-    maxN = std::max(maxN, second[i]->N);
-  }
-  if ((rc = c->ws[WS_KPOS].ensure(maxN * sizeof(int)))) return rc;
-  const uint32_t agrid = accum_grid(maxN);
-  if ((rc = c->ws[WS_PART].ensure((size_t)agrid * ACC_TOTAL * sizeof(double)))) return rc;
-  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
-  for (int i = 0; i < nlinks; i++) {
-    const tdtk_tree* t = first[i];
-    tdtk_scan* data = second[i];
-    if (data->N == 0) continue;
-    const double* A16 = first_dalignxf + 16 * (size_t)i;
-    Mat4 A, inv;
-    std::memcpy(A.m, A16, sizeof A.m);
-    m4inv(A16, inv.m);
-    SearchArgs sa{};
-    sa.x = data->x; sa.y = data->y; sa.z = data->z;
-    sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
-    sa.kpos = c->ws[WS_KPOS].as<int>();
-    rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1);
-    if (rc) return rc;
-    AccumArgs aa{};
-    aa.T = t->dev;
-    aa.x = data->x; aa.y = data->y; aa.z = data->z;
-    aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
-    for (int k = 0; k < 3; k++) {
-      aa.shift[k] = t->centre[0] * A16[k] + t->centre[1] * A16[4 + k] + t->centre[2] * A16[8 + k] + A16[12 + k];
-      shifts[3 * i + k] = aa.shift[k];
-    }
-    aa.partials = c->ws[WS_PART].as<double>();
-    HIPCHK(launch_accum(aa, accum_grid(data->N), TDTK_WANT_LUM, 0, d_out + (size_t)i * ACC_TOTAL, s));
-  }
-  std::vector<double> acc((size_t)nlinks * ACC_TOTAL);
-  HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  collect_ms(c, nullptr);
+  std::vector<double> acc, shifts;
+  if ((rc = links_device_pass(c, nlinks, first, first_dalignxf, second, maxd2, TDTK_WANT_LUM, acc, shifts))) return rc;
   for (int i = 0; i < nlinks; i++) {
     double* Ci = C + 36 * (size_t)i;
     double* CDi = CD + 6 * (size_t)i;
