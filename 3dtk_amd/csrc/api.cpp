@@ -1246,11 +1246,11 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
     maxN = std::max(maxN, second[i]->N);
   }
-  int max_lanes = 8;
-  if (const char* e = getenv("TDTK_LINK_LANES")) max_lanes = std::max(1, std::min(16, atoi(e)));
+  int max_lanes = 8, forced = 0;
+  if (const char* e = getenv("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));
   // small scans: a pass is latency-bound, 8 side by side; big scans: 4, so the thin tail of one search and the
   // small sum kernels overlap with the next search (16 x 1M, 18 links: 4.8 -> 3.4 ms)
-  const int L = (nlinks > 1) ? std::min(nlinks, std::min(max_lanes, maxN <= (size_t)262144 ? 8 : 4)) : 1;
+  const int L = (nlinks > 1) ? std::min(nlinks, forced ? forced : std::min(max_lanes, maxN <= (size_t)262144 ? 8 : 4)) : 1;
   HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
   if (L > 1) {
     while ((int)c->lanes.size() < L) {
