@@ -949,7 +949,7 @@ def matchGraph6Dautomatic_clpairs(my_graphSlam6D, allScans, nrIt, clpairs, loops
 
 
 def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_graphSlam6D, nrIt, epsilonSLAM,
-                          mdml, eP=True, max_num_metascans=-1):
+                          mdml, eP=True, max_num_metascans=-1, prefetch=True):
     """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) without loop closing (my_loopSlam6D == NULL)
     and without the -DlastSLAM pass: sequential ICP, loop detection by pose distance, and rounds of
     { fresh Graph(i+1, cldist^2, loopsize); one doGraphSlam6D iteration } until ret <= epsilonSLAM
@@ -971,28 +971,48 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
             if not (j < nrIt and ret > epsilonSLAM):
                 return ret
 
-    for i in range(1, n):
-        if eP:
-            allScans[i].mergeCoordinatesWithRoboterPosition(allScans[i - 1])
-        if my_icp6D is not None:
-            if meta_icp:
-                metas.append(allScans[i - 1])
-                if max_num_metascans > 0:
-                    while len(metas) > max_num_metascans:
-                        metas.pop(0)
-                my_icp6D.match(MetaScan(metas), allScans[i])
-            else:
-                my_icp6D.match(allScans[i - 1], allScans[i])
-        if loop_detection == 1:
-            loop_detection = 2
-        for j in range(0, i - loopsize):
-            d = allScans[j].get_rPos() - allScans[i].get_rPos()
-            if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cldist2:
-                loop_detection = 1
-        if loop_detection == 2:
-            loop_detection = 0
-            if my_graphSlam6D is not None and mdml > 0:
-                global_rounds(i + 1)
+    # the next scan is uploaded and its tree built on a second host thread while the current one is matched
+    # (see icp6D.doICP); scan i+1 is not part of the graph of scans 0..i, so the global rounds do not touch it
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(1) if (prefetch and n > 2) else None
+
+    def prep(s):
+        _ = s.handle
+        s.getSearchTree()
+    pending = {}
+    try:
+        for i in range(1, n):
+            if pool is not None:
+                if i in pending:
+                    pending.pop(i).result()
+                if i + 1 < n:
+                    pending[i + 1] = pool.submit(prep, allScans[i + 1])
+            if eP:
+                allScans[i].mergeCoordinatesWithRoboterPosition(allScans[i - 1])
+            if my_icp6D is not None:
+                if meta_icp:
+                    metas.append(allScans[i - 1])
+                    if max_num_metascans > 0:
+                        while len(metas) > max_num_metascans:
+                            metas.pop(0)
+                    my_icp6D.match(MetaScan(metas), allScans[i])
+                else:
+                    my_icp6D.match(allScans[i - 1], allScans[i])
+            if loop_detection == 1:
+                loop_detection = 2
+            for j in range(0, i - loopsize):
+                d = allScans[j].get_rPos() - allScans[i].get_rPos()
+                if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cldist2:
+                    loop_detection = 1
+            if loop_detection == 2:
+                loop_detection = 0
+                if my_graphSlam6D is not None and mdml > 0:
+                    global_rounds(i + 1)
+    finally:
+        for f in pending.values():
+            f.result()
+        if pool is not None:
+            pool.shutdown()
     if my_graphSlam6D is not None and mdml > 0.0:
         global_rounds(n)
     return rounds
