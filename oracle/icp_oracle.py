@@ -708,6 +708,44 @@ def lum_iteration(links, scans, maxdist2):
     return tot / len(scans), G, B, X
 
 
+def match_graph6d_automatic(cldist, loopsize, scans, algo, max_dist_match2, max_it, epsilonICP, nrIt, epsilonSLAM,
+                            mdml2, eP=True):
+    """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) with my_loopSlam6D == NULL, lum6DEuler as the
+    graph back-end, no meta scans: sequential ICP, loop detection by pose distance, rounds of
+    { Graph(i+1, cldist^2, loopsize); one LUM iteration } until ret <= epsilonSLAM or nrIt rounds.
+    Returns the number of global rounds."""
+    cldist2 = cldist * cldist
+    n = len(scans)
+    loop_detection = 0
+    rounds = 0
+
+    def global_rounds(nodes):
+        nonlocal rounds
+        j = 0
+        while True:
+            links = graph_links(scans[:nodes], cldist2, loopsize)
+            ret = lum_iteration(links, scans[:nodes], mdml2)[0]
+            j += 1
+            rounds += 1
+            if not (j < nrIt and ret > epsilonSLAM):
+                return ret
+    for i in range(1, n):
+        if eP:
+            scans[i].mergeCoordinatesWithRoboterPosition(scans[i - 1])
+        match(scans[i - 1], scans[i], algo, max_dist_match2, max_it, epsilonICP)
+        if loop_detection == 1:
+            loop_detection = 2
+        for j in range(0, i - loopsize):
+            d = scans[j].get_rPos() - scans[i].get_rPos()
+            if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cldist2:
+                loop_detection = 1
+        if loop_detection == 2:
+            loop_detection = 0
+            global_rounds(i + 1)
+    global_rounds(n)
+    return rounds
+
+
 # ---------------------------------------------------------------------------------------
 # lum6DQuat (-G 2), src/slam6d/lum6Dquat.cc   (parity unpinned: the TU needs scan.h -> Boost)
 # ---------------------------------------------------------------------------------------

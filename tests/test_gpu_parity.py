@@ -920,3 +920,24 @@ def test_graph_backends_blocks_are_rank_count_independent(tdtk, gpu, backend):
                 part[mine] = blocks(mine)
         assert np.array_equal(part, full)
     assert np.abs(full).sum() > 0
+
+
+def test_match_graph6d_automatic(tdtk, orc, gpu):
+    """matchGraph6Dautomatic (slam6D.cc:387-548, no ELCH): sequential ICP along a closed circle of scans, loop
+    detection, global LUM rounds -- with the next scan prefetched on a second thread -- against the numpy
+    restatement: same number of rounds, poses within tolerance."""
+    import sys
+    from oracle import icp_oracle as io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    raw = bench.make_graphslam_scans(10, 15000, seed=21)
+    S = [tdtk.Scan(p, th, loc) for (p, th, loc) in raw]
+    O = [io.OScan(p, th, loc) for (p, th, loc) in raw]
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 30, quiet=True, epsilonICP=1e-5)
+    slam = tdtk.lum6DEuler(icp, 25.0, 25.0, epsilonLUM=0.5)
+    rounds = tdtk.matchGraph6Dautomatic(900.0, 4, S, icp, False, slam, 5, 0.05, 25.0, eP=False)
+    orounds = io.match_graph6d_automatic(900.0, 4, O, 1, 625.0, 30, 1e-5, 5, 0.05, 625.0, eP=False)
+    assert rounds == orounds and rounds >= 2
+    for s, o in zip(S, O):
+        assert np.abs(s.get_rPos() - o.rPos).max() < 1e-5 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-7
+        assert np.abs(s.get_xyz_reduced() - o.xyz).max() < 1e-4
