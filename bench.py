@@ -278,6 +278,8 @@ def bench_icp(args, rank, world, local):
         g1 = bench_graphslam(ga, rank, world, local)
         out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s")}
         out["graphslam_1gpu"]["workload"] = g1["config"]["workload"]
+        out["scaling_note"] = ("N>1 runs of this script measure configs[3] (graph-SLAM, links sharded); its 1-GPU point is "
+                               "graphslam_1gpu here, not `value` (configs[1], which BASELINE.json fixes to one GPU)")
     return out
 
 
@@ -337,6 +339,8 @@ def bench_graphslam(args, rank, world, local):
                                % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
         "lum_iters_per_s": args.steps / dt, "last_ret": ret,
+        "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
+                        "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": None, "traffic": None, "kernel_ms": k_ms},
     }
