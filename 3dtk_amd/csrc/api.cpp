@@ -62,7 +62,7 @@ struct DevBuf {
 };
 
 enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
-       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_COUNT };
+       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COUNT };
 
 // an auxiliary stream with the buffers one whole-scan pass needs: batches of links over small scans run several
 // passes side by side (one pass of an 80K-point scan occupies a fraction of the machine and is latency-bound)
@@ -228,15 +228,15 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
     for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[a]; t->bbmax[a] = c->h_pin[3 + a]; }
     const double t1 = now_ms();
     upload_ms = t1 - t0;
-    DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->stream);
+    if ((rc = c->ws[WS_ARENA].ensure(device_build_arena_bytes(M)))) return rc;
+    DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream);
     if (r.err != hipSuccess) {
       set_error(r.degenerate ? std::string("degenerate split (non-finite coordinates?)")
                              : std::string("device tree build: ") + hipGetErrorString(r.err));
       return r.degenerate ? TDTK_EINVAL : TDTK_EDEVICE;
     }
     t->d_nodes = r.nodes; t->d_r = r.node_r; t->d_pts = r.pts;
-    if (r.table_mode) t->d_leaf = r.leaf_tab;
-    else (void)hipFree(r.leaf_tab);
+    t->d_leaf = r.leaf_tab;   // non-null only in table mode
     t->dev.root_ref = r.root_ref;
     t->dev.cb = (uint32_t)r.cb;
     t->info.n_internal = r.n_internal; t->info.n_leaves = r.n_leaves;

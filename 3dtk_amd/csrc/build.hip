@@ -310,38 +310,32 @@ static inline int bits_for(uint64_t v)
     if (_e != hipSuccess) { res.err = _e; goto fail; } \
   } while (0)
 
-// Builds on `s`; on success the caller owns res.{nodes,node_r,pts,leaf_tab} (hipMalloc'ed).
-DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hipStream_t s)
+// bytes of scratch a build over M points needs (every temporary, and the node / bucket records while their
+// number is still unknown)
+static size_t build_layout(size_t M, size_t* offs, size_t* scan_tmp_out);
+size_t device_build_arena_bytes(size_t M) { return build_layout(M, nullptr, nullptr); }
+
+// Builds on `s` inside the caller's scratch `arena_` (>= device_build_arena_bytes(M), reused from build to build:
+// no hipMalloc / hipFree of hundreds of MB per tree, and no device-wide sync from hipFree while another thread's
+// kernels run).  On success the caller owns res.{nodes,node_r,pts,leaf_tab}, hipMalloc'ed at their exact sizes.
+DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, void* arena_, hipStream_t s)
 {
   DevBuildResult res{};
   const uint32_t M = (uint32_t)M_;
-  char* arena = nullptr;
+  char* arena = static_cast<char*>(arena_);
   KdNode* nodes = nullptr; double* node_r = nullptr; LeafEntry* leaf_tab = nullptr; KdPoint* pts = nullptr;
+  KdNode* f_nodes = nullptr; double* f_r = nullptr; LeafEntry* f_leaf = nullptr;
   uint32_t node_count = 0, leaf_count = 0, depth = 0, nseg = 1;
-  // ---- one arena for every temporary ----
   size_t scan_tmp = 0;
-  {
-    uint32_t* z = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, scan_tmp, z, z, 0u, (size_t)M + 1, rocprim::plus<uint32_t>(), s);
-    unsigned long long* z8 = nullptr;
-    size_t t8 = 0;
-    (void)rocprim::exclusive_scan(nullptr, t8, z8, z8, 0ull, (size_t)M + 1, rocprim::plus<unsigned long long>(), s);
-    if (t8 > scan_tmp) scan_tmp = t8;
-  }
+  size_t O[32];
+  (void)build_layout(M_, O, &scan_tmp);
   const size_t n1 = (size_t)M + 1;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_perm = take(4 * n1), o_segof = take(4 * n1), o_cx = take(8 * n1), o_cy = take(8 * n1), o_cz = take(8 * n1);
-  const size_t o_f = take(4 * n1), o_F = take(4 * n1), o_isL = take(8 * n1), o_A = take(8 * n1),
-               o_posL = take(4 * n1), o_posR = take(4 * n1);
-  const size_t o_segA = take(sizeof(BSeg) * n1), o_segB = take(sizeof(BSeg) * n1), o_meas = take(sizeof(BMeas) * n1);
-  const size_t o_kind = take(4 * n1), o_axis = take(4 * n1), o_split = take(8 * n1), o_irank = take(4 * n1);
-  const size_t o_tmp = take(scan_tmp + 256), o_small = take(256);
-  BCHK(hipMalloc((void**)&arena, off));
-  BCHK(hipMalloc((void**)&nodes, sizeof(KdNode) * n1));
-  BCHK(hipMalloc((void**)&node_r, sizeof(double) * n1));
-  BCHK(hipMalloc((void**)&leaf_tab, sizeof(LeafEntry) * n1));
-  BCHK(hipMalloc((void**)&pts, sizeof(KdPoint) * n1));
+  const size_t o_perm = O[0], o_segof = O[1], o_cx = O[2], o_cy = O[3], o_cz = O[4], o_f = O[5], o_F = O[6], o_isL = O[7],
+               o_A = O[8], o_posL = O[9], o_posR = O[10], o_segA = O[11], o_segB = O[12], o_meas = O[13], o_kind = O[14],
+               o_axis = O[15], o_split = O[16], o_irank = O[17], o_tmp = O[18], o_small = O[19], o_nodes = O[20],
+               o_r = O[21], o_leaf = O[22];
+  nodes = (KdNode*)(arena + o_nodes); node_r = (double*)(arena + o_r); leaf_tab = (LeafEntry*)(arena + o_leaf);
+  BCHK(hipMalloc((void**)&pts, sizeof(KdPoint) * (size_t)M));
   {
     uint32_t* perm = (uint32_t*)(arena + o_perm); uint32_t* seg_of = (uint32_t*)(arena + o_segof);
     double *cx = (double*)(arena + o_cx), *cy = (double*)(arena + o_cy), *cz = (double*)(arena + o_cz);
@@ -404,21 +398,56 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, hip
       hipLaunchKernelGGL(k_pack_refs, dim3(cdiv(node_count ? node_count : 1, 256)), dim3(256), 0, s, nodes, node_count,
                          leaf_tab, (uint32_t)res.cb, small + 0);
     BCHK(hipMemcpyAsync(&res.root_ref, small + 0, 4, hipMemcpyDeviceToHost, s));
+    // the records move out of the scratch into allocations of their exact size
+    if (node_count) {
+      BCHK(hipMalloc((void**)&f_nodes, sizeof(KdNode) * (size_t)node_count));
+      BCHK(hipMalloc((void**)&f_r, sizeof(double) * (size_t)node_count));
+      BCHK(hipMemcpyAsync(f_nodes, nodes, sizeof(KdNode) * (size_t)node_count, hipMemcpyDeviceToDevice, s));
+      BCHK(hipMemcpyAsync(f_r, node_r, sizeof(double) * (size_t)node_count, hipMemcpyDeviceToDevice, s));
+    }
+    if (res.table_mode) {
+      BCHK(hipMalloc((void**)&f_leaf, sizeof(LeafEntry) * (size_t)leaf_count));
+      BCHK(hipMemcpyAsync(f_leaf, leaf_tab, sizeof(LeafEntry) * (size_t)leaf_count, hipMemcpyDeviceToDevice, s));
+    }
     BCHK(hipStreamSynchronize(s));
     BCHK(hipGetLastError());
   }
-  (void)hipFree(arena);
-  res.nodes = nodes; res.node_r = node_r; res.leaf_tab = leaf_tab; res.pts = pts;
+  res.nodes = f_nodes; res.node_r = f_r; res.leaf_tab = f_leaf; res.pts = pts;
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
   return res;
 fail:
-  if (arena) (void)hipFree(arena);
-  if (nodes) (void)hipFree(nodes);
-  if (node_r) (void)hipFree(node_r);
-  if (leaf_tab) (void)hipFree(leaf_tab);
+  if (f_nodes) (void)hipFree(f_nodes);
+  if (f_r) (void)hipFree(f_r);
+  if (f_leaf) (void)hipFree(f_leaf);
   if (pts) (void)hipFree(pts);
   if (res.err == hipSuccess) res.err = hipErrorUnknown;
   return res;
+}
+
+static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
+{
+  size_t scan_tmp = 0;
+  {
+    uint32_t* z = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, z, z, 0u, M + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    unsigned long long* z8 = nullptr;
+    size_t t8 = 0;
+    (void)rocprim::exclusive_scan(nullptr, t8, z8, z8, 0ull, M + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
+    if (t8 > scan_tmp) scan_tmp = t8;
+  }
+  const size_t n1 = M + 1;
+  size_t off = 0;
+  int k = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; if (O) O[k] = o; k++; return o; };
+  take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1); take(8 * n1);      // perm segof cx cy cz
+  take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1);                    // f F LR AB
+  take(4 * n1); take(4 * n1);                                                // posL posR
+  take(sizeof(BSeg) * n1); take(sizeof(BSeg) * n1); take(sizeof(BMeas) * n1);
+  take(4 * n1); take(4 * n1); take(8 * n1); take(4 * n1);                    // kind axis split irank
+  take(scan_tmp + 256); take(256);                                          // tmp small
+  take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // nodes node_r leaf_tab
+  if (scan_tmp_out) *scan_tmp_out = scan_tmp;
+  return off;
 }
 
 }  // namespace tdtk

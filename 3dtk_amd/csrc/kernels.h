@@ -118,7 +118,8 @@ struct DevBuildResult {
   uint32_t n_internal, n_leaves, max_depth, max_leaf;
 };
 // level-synchronous construction of the reference's kd-tree on the device (build.hip)
-DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, hipStream_t s);
+size_t device_build_arena_bytes(size_t M);
+DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s);
 
 hipError_t launch_pp_error(const AccumArgs& a, uint32_t grid, double scale, double* d_partial, double* d_out, hipStream_t s);
 hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s);
