@@ -136,13 +136,18 @@ struct tdtk_scan {
   double *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
   int32_t* d_order = nullptr;    // sorted position -> caller index
   std::vector<int32_t> order_h;
+  // "xyz reduced original" (basicScan.cc:739-757 copyReducedToOriginal): once tdtk_scan_mark_original has been
+  // called, the first operation that moves the points first saves them here (a device-to-device copy), so the
+  // scan's search tree can still be built later without the points ever visiting the host
+  bool track_original = false;
+  double *ox = nullptr, *oy = nullptr, *oz = nullptr;
   tdtk_scan() = default;
   tdtk_scan(const tdtk_scan&) = delete;
   tdtk_scan& operator=(const tdtk_scan&) = delete;
   ~tdtk_scan()
   {
     (void)hipSetDevice(device);
-    double* p[] = {x, y, z, nx, ny, nz};
+    double* p[] = {x, y, z, nx, ny, nz, ox, oy, oz};
     for (double* q : p)
       if (q) (void)hipFree(q);
     if (d_order) (void)hipFree(d_order);
@@ -162,7 +167,74 @@ int tdtk_device_count(void)
   return n;
 }
 
+// copy-on-first-write of a tracked scan's original points; called by everything that moves a resident scan
+static int scan_keep_original(Ctx* c, tdtk_scan* s)
+{
+  if (!s || !s->track_original || s->ox || s->N == 0) return TDTK_OK;
+  const size_t b = s->N * sizeof(double);
+  HIPCHK(hipMalloc((void**)&s->ox, b));
+  HIPCHK(hipMalloc((void**)&s->oy, b));
+  HIPCHK(hipMalloc((void**)&s->oz, b));
+  HIPCHK(hipMemcpyAsync(s->ox, s->x, b, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s->oy, s->y, b, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s->oz, s->z, b, hipMemcpyDeviceToDevice, c->stream));
+  return TDTK_OK;
+}
+
 // ---- tree ------------------------------------------------------------------------------
+// device construction (build.hip) over the [M][3] points already sitting in c->ws[WS_TMPA]
+static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_size, double t0)
+{
+  int rc;
+  if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
+  double* d_box = c->ws[WS_BOX].as<double>();
+  // root bounding box (binning of unsorted query batches, accumulation shift): min / max on the device
+  HIPCHK(launch_bbox(c->ws[WS_TMPA].as<double>(), M, d_box + 8, d_box, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pin, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[a]; t->bbmax[a] = c->h_pin[3 + a]; }
+  const double t1 = now_ms();
+  t->info.upload_ms = t1 - t0;
+  if ((rc = c->ws[WS_ARENA].ensure(device_build_arena_bytes(M)))) return rc;
+  DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream);
+  if (r.err != hipSuccess) {
+    set_error(r.degenerate ? std::string("degenerate split (non-finite coordinates?)")
+                           : std::string("device tree build: ") + hipGetErrorString(r.err));
+    return r.degenerate ? TDTK_EINVAL : TDTK_EDEVICE;
+  }
+  t->d_nodes = r.nodes; t->d_r = r.node_r; t->d_pts = r.pts;
+  t->d_leaf = r.leaf_tab;   // non-null only in table mode
+  t->dev.root_ref = r.root_ref;
+  t->dev.cb = (uint32_t)r.cb;
+  t->info.n_internal = r.n_internal; t->info.n_leaves = r.n_leaves;
+  t->info.max_depth = r.max_depth; t->info.max_leaf_points = r.max_leaf;
+  t->info.build_ms = now_ms() - t1;
+  return TDTK_OK;
+}
+
+static void tree_finish(tdtk_tree* t, size_t M)
+{
+  for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
+  t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
+  t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
+  t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
+  t->dev.node_r = static_cast<const double*>(t->d_r);
+  t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
+  t->info.n_points = M;
+  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(double)) + M * sizeof(KdPoint) +
+                         (t->d_leaf ? t->info.n_leaves * sizeof(LeafEntry) : 0);
+}
+
+static int tree_check_args(size_t M, int bucket_size)
+{
+  if (bucket_size < 1) { set_error("bucket size must be >= 1"); return TDTK_EINVAL; }
+  if (M > (size_t)REF_VAL || M * sizeof(KdPoint) >= (1ull << 32)) {
+    set_error("model scan too large (30-bit references / 32-bit byte offsets: < 2^27 points)");
+    return TDTK_EINVAL;
+  }
+  return TDTK_OK;
+}
+
 int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, tdtk_tree** out)
 {
   if (!out) { set_error("out is NULL"); return TDTK_EINVAL; }
@@ -175,13 +247,7 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
   const double t0 = now_ms();
   std::unique_ptr<tdtk_tree> t(new tdtk_tree);
   t->device = device; t->M = M; t->bucket = bucket_size;
-  if (bucket_size < 1) { set_error("bucket size must be >= 1"); return TDTK_EINVAL; }
-  if (M > (size_t)REF_VAL || M * sizeof(KdPoint) >= (1ull << 32)) {
-    set_error("model scan too large (30-bit references / 32-bit byte offsets: < 2^27 points)");
-    return TDTK_EINVAL;
-  }
-  size_t bytes = 0;
-  double build_ms = 0.0, upload_ms = 0.0;
+  if ((rc = tree_check_args(M, bucket_size))) return rc;
   const char* host_env = getenv("TDTK_HOST_BUILD");
   if (host_env && host_env[0] == '1') {
     // root bounding box (binning of unsorted query batches, accumulation shift)
@@ -197,7 +263,7 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
     std::string err;
     if (!build_tree(xyz, M, bucket_size, H, err)) { set_error(err); return TDTK_EINVAL; }
     const double t1 = now_ms();
-    build_ms = t1 - t0;
+    t->info.build_ms = t1 - t0;
     if (!H.nodes.empty()) {
       HIPCHK(hipMalloc(&t->d_nodes, H.nodes.size() * sizeof(KdNode)));
       HIPCHK(hipMemcpy(t->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice));
@@ -214,47 +280,40 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
     t->dev.cb = (uint32_t)H.cb;
     t->info.n_internal = H.n_internal; t->info.n_leaves = H.n_leaves;
     t->info.max_depth = H.max_depth; t->info.max_leaf_points = H.max_leaf_points;
-    upload_ms = now_ms() - t1;
+    t->info.upload_ms = now_ms() - t1;
   } else {
     // device construction (build.hip): upload the points once, build level by level
     if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
-    if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
-    double* d_box = c->ws[WS_BOX].as<double>();
     HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, xyz, 3 * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    // root bounding box (binning of unsorted query batches, accumulation shift): min / max on the device
-    HIPCHK(launch_bbox(c->ws[WS_TMPA].as<double>(), M, d_box + 8, d_box, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pin, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[a]; t->bbmax[a] = c->h_pin[3 + a]; }
-    const double t1 = now_ms();
-    upload_ms = t1 - t0;
-    if ((rc = c->ws[WS_ARENA].ensure(device_build_arena_bytes(M)))) return rc;
-    DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream);
-    if (r.err != hipSuccess) {
-      set_error(r.degenerate ? std::string("degenerate split (non-finite coordinates?)")
-                             : std::string("device tree build: ") + hipGetErrorString(r.err));
-      return r.degenerate ? TDTK_EINVAL : TDTK_EDEVICE;
-    }
-    t->d_nodes = r.nodes; t->d_r = r.node_r; t->d_pts = r.pts;
-    t->d_leaf = r.leaf_tab;   // non-null only in table mode
-    t->dev.root_ref = r.root_ref;
-    t->dev.cb = (uint32_t)r.cb;
-    t->info.n_internal = r.n_internal; t->info.n_leaves = r.n_leaves;
-    t->info.max_depth = r.max_depth; t->info.max_leaf_points = r.max_leaf;
-    build_ms = now_ms() - t1;
+    if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
   }
-  for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
-  bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(double)) + M * sizeof(KdPoint);
-  t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
-  t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
-  t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
-  t->dev.node_r = static_cast<const double*>(t->d_r);
-  t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
+  tree_finish(t.get(), M);
+  *out = t.release();
+  return TDTK_OK;
+}
 
-  t->info.n_points = M;
-  t->info.device_bytes = bytes;
-  t->info.build_ms = build_ms;
-  t->info.upload_ms = upload_ms;
+// KDtree over the points of a resident scan as they are now, in the caller's order -- what BasicScan builds
+// over "xyz reduced original" (basicScan.cc:702-728) when it is called before the scan has been moved: no trip
+// of the points through the host.
+int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree** out)
+{
+  if (!out) { set_error("out is NULL"); return TDTK_EINVAL; }
+  *out = nullptr;
+  if (!scan || scan->N == 0) { set_error("cannot create kdtree with zero points"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(scan->device, &c);
+  if (rc) return rc;
+  const double t0 = now_ms();
+  const size_t M = scan->N;
+  std::unique_ptr<tdtk_tree> t(new tdtk_tree);
+  t->device = scan->device; t->M = M; t->bucket = bucket_size;
+  if ((rc = tree_check_args(M, bucket_size))) return rc;
+  if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
+  const bool saved = scan->ox != nullptr;   // moved since tdtk_scan_mark_original: the saved points are the original
+  HIPCHK(launch_unsort_aos(saved ? scan->ox : scan->x, saved ? scan->oy : scan->y, saved ? scan->oz : scan->z,
+                           scan->d_order, M, c->ws[WS_TMPA].as<double>(), c->stream));
+  if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
+  tree_finish(t.get(), M);
   *out = t.release();
   return TDTK_OK;
 }
@@ -800,10 +859,39 @@ int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16])
   Ctx* c;
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
+  if ((rc = scan_keep_original(c, s))) return rc;
   Mat4 A;
   std::memcpy(A.m, alignxf, sizeof A.m);
   HIPCHK(launch_transform(s->x, s->y, s->z, s->nx, s->ny, s->nz, s->N, A, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return TDTK_OK;
+}
+
+int tdtk_scan_mark_original(tdtk_scan* s)
+{
+  if (!s) { set_error("NULL argument"); return TDTK_EINVAL; }
+  (void)hipSetDevice(s->device);
+  double* p[] = {s->ox, s->oy, s->oz};
+  for (double* q : p)
+    if (q) (void)hipFree(q);
+  s->ox = s->oy = s->oz = nullptr;
+  s->track_original = true;
+  return TDTK_OK;
+}
+
+int tdtk_scan_download_original(const tdtk_scan* s, double* xyz_out)
+{
+  if (!s || !xyz_out) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(s->device, &c);
+  if (rc) return rc;
+  const size_t N = s->N;
+  std::vector<double> buf(N);
+  const double* src[3] = {s->ox ? s->ox : s->x, s->ox ? s->oy : s->y, s->ox ? s->oz : s->z};
+  for (int comp = 0; comp < 3; comp++) {
+    HIPCHK(hipMemcpy(buf.data(), src[comp], N * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t j = 0; j < N; j++) xyz_out[3 * (size_t)s->order_h[j] + comp] = buf[j];
+  }
   return TDTK_OK;
 }
 
@@ -1100,6 +1188,7 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   std::memset(res, 0, sizeof *res);
   if (prm->max_num_iterations == 0 || data->N == 0) return TDTK_OK;  // icp6D.cc:112-114
 
+  if ((rc = scan_keep_original(c, data))) return rc;   // the loop moves the scan in place
   const unsigned want = (algo == TDTK_ALGO_APX) ? TDTK_WANT_APX
                         : (algo == TDTK_ALGO_NAPX ? TDTK_WANT_NAPX : (serial_only ? TDTK_WANT_MOM2 : 0u));
   double ret = 0.0, prev_ret = 0.0, prev_prev_ret = 0.0;
@@ -1437,6 +1526,7 @@ int tdtk_scans_transform2(int count, tdtk_scan* const* scans, const double* A1, 
     if (!sc || !sc->N) continue;
     if (!c) { int rc = get_ctx(sc->device, &c); if (rc) return rc; }
     if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
+    { int rk = scan_keep_original(c, sc); if (rk) return rk; }
     Xf2Desc d;
     d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
     std::memcpy(d.A1.m, A1 + 16 * (size_t)i, sizeof d.A1.m);
@@ -1507,6 +1597,7 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
       if (!c) { int rc = get_ctx(scans[i]->device, &c); if (rc) return rc; }
       tdtk_scan* sc = scans[i];
       if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
+      { int rk = scan_keep_original(c, sc); if (rk) return rk; }
       Xf2Desc d;
       d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
       std::memcpy(d.A1.m, tinv, sizeof tinv);

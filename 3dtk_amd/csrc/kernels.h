@@ -153,6 +153,8 @@ hipError_t launch_oct_keys_sorted(const double* d_xyz, size_t n, const OctRoot& 
 hipError_t launch_oct_heads(const uint64_t* keys, size_t n, uint32_t* flags, hipStream_t s);
 hipError_t launch_oct_centres(const uint64_t* keys, const uint32_t* flags, const uint32_t* slot, size_t n,
                               const OctRoot& R, double* out, hipStream_t s);
+hipError_t launch_unsort_aos(const double* x, const double* y, const double* z, const int32_t* order, size_t n,
+                             double* out, hipStream_t s);
 hipError_t launch_gather_soa(const double* d_src, const uint32_t* order, size_t n, double* x, double* y, double* z,
                              hipStream_t s);
 

@@ -90,6 +90,26 @@ hipError_t launch_morton_order(const double* d_xyz, size_t n, const double* d_bo
   return hipGetLastError();
 }
 
+// the inverse of the Morton gather: sorted SoA back to the caller's order, AoS (input of the tree builder)
+__global__ void k_unsort_aos(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                             const int32_t* __restrict__ order, size_t n, double* __restrict__ out)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const size_t i = (size_t)order[j];
+    out[3 * i] = x[j]; out[3 * i + 1] = y[j]; out[3 * i + 2] = z[j];
+  }
+}
+hipError_t launch_unsort_aos(const double* x, const double* y, const double* z, const int32_t* order, size_t n,
+                             double* out, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_unsort_aos, dim3((uint32_t)nb), dim3(256), 0, s, x, y, z, order, n, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_soa(const double* d_src, const uint32_t* order, size_t n, double* x, double* y, double* z,
                              hipStream_t s)
 {

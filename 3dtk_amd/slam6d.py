@@ -190,6 +190,17 @@ class KDtree:
         check(lib().tdtk_tree_create(dptr(pts), len(pts), int(bucketSize), int(device), C.byref(h)))
         self._h = h
 
+    @classmethod
+    def from_scan(cls, scan_handle, n, bucketSize=20, device=0):
+        """the tree over a resident scan's original points, built device to device (tdtk_tree_create_from_scan)"""
+        self = cls.__new__(cls)
+        self.n = n
+        self.device = device
+        h = C.c_void_p()
+        check(lib().tdtk_tree_create_from_scan(scan_handle, int(bucketSize), C.byref(h)))
+        self._h = h
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
@@ -323,8 +334,10 @@ class Scan:
         h = C.c_void_p()
         check(lib().tdtk_scan_create(dptr(self._local), dptr(self._local_n), self.n, int(self.device),
                                      C.byref(h)))
-        # calcReducedOnDemandPrivate (basicScan.cc:730-737): transformReduced(transMatOrg)
+        # calcReducedOnDemandPrivate (basicScan.cc:730-737): transformReduced(transMatOrg), then
+        # copyReducedToOriginal: from here on the library keeps the original through any later move
         check(lib().tdtk_scan_transform(h, dptr(self.transMatOrg)))
+        check(lib().tdtk_scan_mark_original(h))
         return h
 
     @property
@@ -332,8 +345,6 @@ class Scan:
         """device-resident "xyz reduced" (materialised on first use)"""
         if self._h is None:
             self._h = self._upload()
-            if self._orig is None:
-                self._orig = self._download(self._h)     # copyReducedToOriginal
             for A in self._queue:
                 check(lib().tdtk_scan_transform(self._h, dptr(A)))
             self._queue = []
@@ -348,7 +359,9 @@ class Scan:
     def xyz_reduced_original(self):
         if self._orig is None:
             if self._h is not None or not self._queue:
-                _ = self.handle
+                out = np.empty((self.n, 3))
+                check(lib().tdtk_scan_download_original(self.handle, dptr(out)))
+                self._orig = out
             else:   # only the tree is needed here: do not keep a moved copy resident
                 h = self._upload()
                 self._orig = self._download(h)
@@ -361,7 +374,10 @@ class Scan:
     def getSearchTree(self):
         """scan.cc:268-306 -> basicScan.cc:702-728: lazily built over "xyz reduced original"."""
         if self.kd is None:
-            self.kd = KDtree(self.xyz_reduced_original, self.bucketSize, self.device)
+            if self._h is None and self._queue:     # never resident, already moved: go through a temporary upload
+                self.kd = KDtree(self.xyz_reduced_original, self.bucketSize, self.device)
+            else:                                   # device to device, from the (saved) original points
+                self.kd = KDtree.from_scan(self.handle, self.n, self.bucketSize, self.device)
         return self.kd
 
     def _transformMatrix(self, alignxf):

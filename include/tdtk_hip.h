@@ -125,6 +125,10 @@ const char* tdtk_version(void);
  * (the reference tree borrows it).  Builds the identical tree (same split rule,
  * same partition order), lays it out breadth-first and uploads it.             */
 int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, tdtk_tree** out);
+/* The same tree over the points of a resident scan as they are now, in the caller's order: what BasicScan
+ * builds over "xyz reduced original" (src/slam6d/basicScan.cc:702-728) when asked before the scan has been moved;
+ * the points never visit the host.                                                                    */
+int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree** out);
 void tdtk_tree_destroy(tdtk_tree* t);
 int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info);
 /* diagnostic: rebuild the tree with the host builder and compare it with the resident one (built on
@@ -172,6 +176,13 @@ size_t tdtk_scan_size(const tdtk_scan* s);
 int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16]);
 /* copy the current points (caller's order) back, e.g. after matching */
 int tdtk_scan_download(const tdtk_scan* s, double* xyz_out, double* normal_out /*nullable*/);
+
+/* "xyz reduced original" (BasicScan::copyReducedToOriginal, src/slam6d/basicScan.cc:739-757): after
+ * tdtk_scan_mark_original the points as they are now count as the original; the first call that moves the scan
+ * (tdtk_scan_transform, tdtk_icp_match, the pose updates) first saves them on the device, so that
+ * tdtk_tree_create_from_scan / tdtk_scan_download_original keep answering with the original.            */
+int tdtk_scan_mark_original(tdtk_scan* s);
+int tdtk_scan_download_original(const tdtk_scan* s, double* xyz_out);
 
 /* Scan::getPtPairs (scan.cc:1220-1260) over a resident scan: whole-scan pass + sums. */
 int tdtk_scan_pairs(const tdtk_tree* model, const double source_alignxf[16], tdtk_scan* data,
