@@ -867,6 +867,8 @@ int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16])
   return TDTK_OK;
 }
 
+static int scan_to_host(Ctx* c, const tdtk_scan* s, const double* x, const double* y, const double* z, double* out);
+
 int tdtk_scan_mark_original(tdtk_scan* s)
 {
   if (!s) { set_error("NULL argument"); return TDTK_EINVAL; }
@@ -885,13 +887,19 @@ int tdtk_scan_download_original(const tdtk_scan* s, double* xyz_out)
   Ctx* c;
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
+  return scan_to_host(c, s, s->ox ? s->ox : s->x, s->ox ? s->oy : s->y, s->ox ? s->oz : s->z, xyz_out);
+}
+
+// sorted SoA -> caller-order AoS on the device, then one contiguous copy to the host
+static int scan_to_host(Ctx* c, const tdtk_scan* s, const double* x, const double* y, const double* z, double* out)
+{
   const size_t N = s->N;
-  std::vector<double> buf(N);
-  const double* src[3] = {s->ox ? s->ox : s->x, s->ox ? s->oy : s->y, s->ox ? s->oz : s->z};
-  for (int comp = 0; comp < 3; comp++) {
-    HIPCHK(hipMemcpy(buf.data(), src[comp], N * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t j = 0; j < N; j++) xyz_out[3 * (size_t)s->order_h[j] + comp] = buf[j];
-  }
+  if (!N) return TDTK_OK;
+  int rc = c->ws[WS_TMPA].ensure(3 * N * sizeof(double));
+  if (rc) return rc;
+  HIPCHK(launch_unsort_aos(x, y, z, s->d_order, N, c->ws[WS_TMPA].as<double>(), c->stream));
+  HIPCHK(hipMemcpyAsync(out, c->ws[WS_TMPA].p, 3 * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return TDTK_OK;
 }
 
@@ -901,17 +909,9 @@ int tdtk_scan_download(const tdtk_scan* s, double* xyz_out, double* nrm_out)
   Ctx* c;
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
-  const size_t N = s->N;
-  std::vector<double> buf(N);
-  auto down = [&](const double* src, int comp, double* dst) -> int {
-    HIPCHK(hipMemcpy(buf.data(), src, N * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t j = 0; j < N; j++) dst[3 * (size_t)s->order_h[j] + comp] = buf[j];
-    return TDTK_OK;
-  };
-  if ((rc = down(s->x, 0, xyz_out)) || (rc = down(s->y, 1, xyz_out)) || (rc = down(s->z, 2, xyz_out))) return rc;
-  if (nrm_out && s->nx)
-    if ((rc = down(s->nx, 0, nrm_out)) || (rc = down(s->ny, 1, nrm_out)) || (rc = down(s->nz, 2, nrm_out))) return rc;
-  return TDTK_OK;
+  if ((rc = scan_to_host(c, s, s->x, s->y, s->z, xyz_out))) return rc;
+  if (nrm_out && s->nx) rc = scan_to_host(c, s, s->nx, s->ny, s->nz, nrm_out);
+  return rc;
 }
 
 int tdtk_scan_pairs(const tdtk_tree* model, const double A[16], tdtk_scan* data, int pmode, double maxd2,
