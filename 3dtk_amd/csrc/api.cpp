@@ -135,7 +135,6 @@ struct tdtk_scan {
   size_t N = 0;
   double *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
   int32_t* d_order = nullptr;    // sorted position -> caller index
-  std::vector<int32_t> order_h;
   // "xyz reduced original" (basicScan.cc:739-757 copyReducedToOriginal): once tdtk_scan_mark_original has been
   // called, the first operation that moves the points first saves them here (a device-to-device copy), so the
   // scan's search tree can still be built later without the points ever visiting the host
@@ -839,8 +838,6 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
     HIPCHK(hipMemcpyAsync(d_aos, nrm, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(launch_gather_soa(d_aos, reinterpret_cast<const uint32_t*>(sc->d_order), N, sc->nx, sc->ny, sc->nz, s));
   }
-  sc->order_h.resize(N);
-  HIPCHK(hipMemcpyAsync(sc->order_h.data(), sc->d_order, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   *out = sc.release();
   return TDTK_OK;
