@@ -53,7 +53,7 @@ class IcpResult(C.Structure):
 
 # every symbol include/tdtk_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "tdtk_last_error", "tdtk_device_count", "tdtk_version", "tdtk_tree_create", "tdtk_tree_create_from_scan", "tdtk_scan_mark_original", "tdtk_scan_download_original", "tdtk_tree_destroy",
+    "tdtk_last_error", "tdtk_device_count", "tdtk_version", "tdtk_tree_create", "tdtk_tree_create_from_scan", "tdtk_tree_create_from_scans", "tdtk_scan_mark_original", "tdtk_scan_download_original", "tdtk_tree_destroy",
     "tdtk_tree_get_info", "tdtk_tree_verify", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
@@ -149,6 +149,7 @@ def lib():
                                           C.POINTER(C.c_void_p), _dp, _dp, _dp]
     L.tdtk_scan_mark_original.argtypes = [C.c_void_p]
     L.tdtk_scan_download_original.argtypes = [C.c_void_p, _dp]
+    L.tdtk_tree_create_from_scans.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.tdtk_tree_create_from_scan.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.tdtk_point_point_error.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_uint64), _dp]
     L.tdtk_scans_transform2.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, _dp]

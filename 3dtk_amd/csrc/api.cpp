@@ -317,6 +317,40 @@ int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree
   return TDTK_OK;
 }
 
+// KDtreeMetaManaged (src/slam6d/kdMeta.cc:34-134): one tree over the CURRENT points of several resident scans,
+// concatenated in the order given, each scan in its caller's order (prepareTempIndices, kdMeta.cc:60-79)
+int tdtk_tree_create_from_scans(tdtk_scan* const* scans, int nscans, int bucket_size, tdtk_tree** out)
+{
+  if (!out) { set_error("out is NULL"); return TDTK_EINVAL; }
+  *out = nullptr;
+  if (!scans || nscans <= 0 || !scans[0]) { set_error("cannot create kdtree with zero points"); return TDTK_EINVAL; }
+  size_t M = 0;
+  for (int i = 0; i < nscans; i++) {
+    if (!scans[i]) { set_error("NULL scan"); return TDTK_EINVAL; }
+    if (scans[i]->device != scans[0]->device) { set_error("scans live on different devices"); return TDTK_EINVAL; }
+    M += scans[i]->N;
+  }
+  if (M == 0) { set_error("cannot create kdtree with zero points"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(scans[0]->device, &c);
+  if (rc) return rc;
+  const double t0 = now_ms();
+  std::unique_ptr<tdtk_tree> t(new tdtk_tree);
+  t->device = scans[0]->device; t->M = M; t->bucket = bucket_size;
+  if ((rc = tree_check_args(M, bucket_size))) return rc;
+  if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
+  size_t off = 0;
+  for (int i = 0; i < nscans; i++) {
+    const tdtk_scan* sc = scans[i];
+    HIPCHK(launch_unsort_aos(sc->x, sc->y, sc->z, sc->d_order, sc->N, c->ws[WS_TMPA].as<double>() + 3 * off, c->stream));
+    off += sc->N;
+  }
+  if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
+  tree_finish(t.get(), M);
+  *out = t.release();
+  return TDTK_OK;
+}
+
 void tdtk_tree_destroy(tdtk_tree* t)
 {
   delete t;   // ~tdtk_tree releases the device arrays

@@ -456,9 +456,15 @@ class MetaScan:
     def getDAlign(self): return self.dalignxf
 
     def getSearchTree(self):
-        if self.kd is None:
-            pts = np.concatenate([s.get_xyz_reduced() for s in self.m_scans])
-            self.kd = KDtree(pts, self.m_scans[0].bucketSize, self.device)
+        if self.kd is None:   # device to device: the scans' current points never visit the host
+            hs = (C.c_void_p * len(self.m_scans))(*[s.handle for s in self.m_scans])
+            kd = KDtree.__new__(KDtree)
+            kd.n = sum(s.n for s in self.m_scans)
+            kd.device = self.device
+            h = C.c_void_p()
+            check(lib().tdtk_tree_create_from_scans(hs, len(self.m_scans), int(self.m_scans[0].bucketSize), C.byref(h)))
+            kd._h = h
+            self.kd = kd
         return self.kd
 
 

@@ -129,6 +129,10 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
  * builds over "xyz reduced original" (src/slam6d/basicScan.cc:702-728) when asked before the scan has been moved;
  * the points never visit the host.                                                                    */
 int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree** out);
+/* KDtreeMetaManaged (src/slam6d/kdMeta.cc:34-134) for a MetaScan: one tree over the CURRENT points of several
+ * resident scans, concatenated in the order given (prepareTempIndices, kdMeta.cc:60-79); indices returned by
+ * searches on it count through that concatenation.                                                    */
+int tdtk_tree_create_from_scans(tdtk_scan* const* scans, int nscans, int bucket_size, tdtk_tree** out);
 void tdtk_tree_destroy(tdtk_tree* t);
 int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info);
 /* diagnostic: rebuild the tree with the host builder and compare it with the resident one (built on
