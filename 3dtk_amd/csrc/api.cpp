@@ -47,6 +47,10 @@ static double now_ms()
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
   int ensure(size_t bytes)
   {
     if (bytes <= cap) return TDTK_OK;
@@ -69,6 +73,7 @@ enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS
 struct Lane {
   hipStream_t s = nullptr;
   DevBuf kpos, part, ovf_m2, ovf_ref;
+  ~Lane() { if (s) (void)hipStreamDestroy(s); }
 };
 
 struct Ctx {
@@ -80,6 +85,16 @@ struct Ctx {
   double last_nn_ms = 0.0;
   bool ev_pending = false;
   std::vector<std::unique_ptr<Lane>> lanes;
+  // a context dies with its host thread (worker threads of a prefetch pool come and go): give everything back
+  ~Ctx()
+  {
+    if (device >= 0) (void)hipSetDevice(device);
+    lanes.clear();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (h_pin) (void)hipHostFree(h_pin);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
 };
 
 static thread_local std::map<int, std::unique_ptr<Ctx>> g_ctx;
