@@ -80,6 +80,10 @@ bool build_tree(const double* xyz, size_t M, int bucket, HostTree& T, std::strin
     return false;
   }
 
+  // the reference recurses on an empty side and throws for NaN / inf input; here it is an error up front
+  for (size_t i = 0; i < 3 * M; i++)
+    if (!std::isfinite(xyz[i])) { err = "degenerate split (non-finite coordinates?)"; return false; }
+
   std::vector<uint32_t> perm(M);
   std::iota(perm.begin(), perm.end(), 0u);
 
@@ -130,6 +134,12 @@ bool build_tree(const double* xyz, size_t M, int bucket, HostTree& T, std::strin
     nd.splitval = e.mean[axis];
     nd.c1 = (axis & 1) ? REF_AXIS : 0u;
     nd.c2 = (axis & 2) ? REF_AXIS : 0u;
+    // the inward scans of split_run stop only at a point on the other side of the split value: one
+    // "< splitval" and one ">= splitval" point must exist (NaN / inf coordinates break exactly this)
+    if (!(nd.splitval > e.lo[axis] && nd.splitval <= e.hi[axis]) || !std::isfinite(nd.hx + nd.hy + nd.hz)) {
+      err = "degenerate split (non-finite coordinates?)";
+      return false;
+    }
     const uint32_t nleft = split_run(xyz, run, w.n, axis, nd.splitval);
     if (nleft == 0 || nleft == w.n) {
       // cannot happen for finite input with extent >= 0.01 (mean lies strictly inside);

@@ -66,6 +66,11 @@ def test_host_tree_errors(tdtk):
         tdtk.host_tree_layout(np.zeros((0, 3)), 20)          # "cannot create kdtree with zero points"
     with pytest.raises(tdtk.TdtkError):
         tdtk.host_tree_layout(np.zeros((5, 3)), 0)
+    # non-finite coordinates: an error, not an endless partition scan
+    for v in (np.nan, np.inf, -np.inf):
+        bad = np.random.default_rng(0).uniform(-1, 1, (200, 3)); bad[17, 1] = v
+        with pytest.raises(tdtk.TdtkError):
+            tdtk.host_tree_layout(bad, 5)
 
 
 def test_m4inv_mmult_bit_exact(tdtk, orc):
