@@ -7,7 +7,7 @@
 # headers: only TUs that compile as-is with this image's g++ are built
 # (kdIndexed.cc, icp6Dquat.cc, icp6Dsvd.cc + vendored newmat, icp6Dapx.cc,
 # icp6Dnapx.cc, icp6Dortho.cc, icp6Ddual.cc, icp6Dhelix.cc, icp6Dlumeuler.cc,
-# icp6Dlumquat.cc, icp6Dquatscale.cc).  Flags mirror the reference CMakeLists.txt:306-342 (-O3,
+# icp6Dlumquat.cc, icp6Dquatscale.cc; the vendored ANN library).  Flags mirror the reference CMakeLists.txt:306-342 (-O3,
 # OpenMP, no -march, no -ffast-math).
 set -euo pipefail
 REF="${1:-${REF:-/root/reference}}"
@@ -36,7 +36,16 @@ for f in newmat1 newmat2 newmat3 newmat4 newmat5 newmat6 newmat7 newmat8 newmate
     g++ -O2 -fPIC -w -c "$NM/$f.cpp" -o "$OUT/obj/nm_$f.o" &
   fi
 done
+# vendored ANN 1.1.1 (list = 3rdparty/ann/CMakeLists.txt): the k-NN under Scan::calcNormals (normals.cc:35-111)
+ANN="$REF/3rdparty/ann/ann_1.1.1_modified"
+for f in ANN brute kd_tree kd_util kd_split kd_dump kd_search kd_pr_search kd_fix_rad_search bd_tree bd_search \
+         bd_pr_search bd_fix_rad_search perf; do
+  if [ ! -f "$OUT/obj/ann_$f.o" ]; then
+    g++ -O3 -fPIC -w -I"$ANN/include" -c "$ANN/src/$f.cpp" -o "$OUT/obj/ann_$f.o" &
+  fi
+done
 wait
 g++ $F $INC -c "$HERE/ref_driver.cc" -o "$OUT/obj/ref_driver.o"
+g++ $F $INC -I"$ANN/include" -c "$HERE/ref_ann_driver.cc" -o "$OUT/obj/ref_ann_driver.o"
 g++ -shared -fopenmp -o "$OUT/libref3dtk.so" "$OUT"/obj/*.o
 echo "built $OUT/libref3dtk.so"

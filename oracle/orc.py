@@ -29,14 +29,14 @@ def build(force=False):
     """Compile liboracle.so (always possible) and oracle/_ref (only where the
     reference checkout is present).  Building the checker is not using it."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("oracle.c", "oracle_normals.c"))
+    if force or not os.path.exists(so) or os.path.getmtime(so) < src:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     ref = os.environ.get("TDTK_REF", "/root/reference")
     refso = os.path.join(_HERE, "_ref", "libref3dtk.so")
     if os.path.isdir(os.path.join(ref, "src", "slam6d")):
-        drv = os.path.join(_HERE, "ref_driver.cc")
-        if force or not os.path.exists(refso) or os.path.getmtime(refso) < os.path.getmtime(drv):
+        drv = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_driver.cc", "ref_ann_driver.cc", "build_ref.sh"))
+        if force or not os.path.exists(refso) or os.path.getmtime(refso) < drv:
             subprocess.check_call([os.path.join(_HERE, "build_ref.sh"), ref], stdout=subprocess.DEVNULL)
 
 
@@ -70,6 +70,20 @@ def lib():
         L.orc_octree_center.argtypes = [_dp, C.c_size_t, C.c_double, _dp]
         L.orc_k5_hash.restype = C.c_uint64
         L.orc_k5_hash.argtypes = [_ip, C.c_size_t]
+        L.orc_ann_create.restype = C.c_void_p
+        L.orc_ann_create.argtypes = [_dp, C.c_int]
+        L.orc_ann_destroy.argtypes = [C.c_void_p]
+        L.orc_ann_stats.argtypes = [C.c_void_p, _lp]
+        L.orc_ann_structure.restype = C.c_long
+        L.orc_ann_structure.argtypes = [C.c_void_p, _ip, _dp, _ip, _lp]
+        L.orc_ann_nodes.argtypes = [C.c_void_p, _ip, _ip, _dp, _ip]
+        L.orc_ann_ksearch.restype = C.c_int
+        L.orc_ann_ksearch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_double, _ip, _dp, _lp]
+        L.orc_eigen3.restype = C.c_int
+        L.orc_eigen3.argtypes = [_dp, _dp, _dp]
+        L.orc_normals_apx_knn.restype = C.c_int
+        L.orc_normals_apx_knn.argtypes = [_dp, C.c_int, C.c_int, _dp, C.c_double, _dp, _ip]
+        L.orc_normals_from_knn.argtypes = [_dp, C.c_int, C.c_int, _ip, _dp, _dp]
         _lib = L
     return _lib
 
@@ -97,6 +111,15 @@ def ref():
         R.ref_apx_align_parallel.restype = C.c_double
         R.ref_apx_align_parallel.argtypes = [_up, _dp, _dp, _dp, _dp, _dp, _dp]
         R.ref_host_threads.restype = C.c_int
+        R.ref_ann_create.restype = C.c_void_p
+        R.ref_ann_create.argtypes = [_dp, C.c_int]
+        R.ref_ann_destroy.argtypes = [C.c_void_p]
+        R.ref_ann_ksearch.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_double, _ip, _dp]
+        R.ref_ann_stats.argtypes = [C.c_void_p, _lp]
+        R.ref_ann_structure.restype = C.c_long
+        R.ref_ann_structure.argtypes = [C.c_void_p, _ip, _dp, _ip, _lp]
+        R.ref_eigen3.argtypes = [_dp, _dp, _dp]
+        R.ref_normals_apx_knn.argtypes = [_dp, C.c_int, C.c_int, _dp, C.c_double, _dp]
         _ref = R
     return _ref
 
@@ -259,3 +282,99 @@ def octree_center(xyz, voxel):
     out = np.empty_like(xyz)
     m = lib().orc_octree_center(_d(xyz), len(xyz), float(voxel), _d(out))
     return out[:m].copy()
+
+
+# ---- normals: ANN kd-tree, approximate k-NN, PCA (oracle_normals.c / ref_ann_driver.cc) -------------
+class AnnTree:
+    """The ANN kd-tree calculateNormalsApxKNN builds (bucket size 1, sliding midpoint).
+    which="oracle": restatement in oracle_normals.c; which="ref": the vendored library itself."""
+
+    def __init__(self, xyz, which="oracle"):
+        self.xyz = _c(xyz).reshape(-1, 3)
+        self.n = len(self.xyz)
+        self.L = lib() if which == "oracle" else ref()
+        self.p = "orc_ann_" if which == "oracle" else "ref_ann_"
+        self.which = which
+        self.h = getattr(self.L, self.p + "create")(_d(self.xyz), self.n)
+        if not self.h:
+            raise RuntimeError("cannot create an ANN tree with zero points")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.L, self.p + "destroy")(self.h)
+            self.h = None
+
+    def stats(self):
+        """depth, leaves, splitting nodes"""
+        s = (C.c_long * 6)()
+        getattr(self.L, self.p + "stats")(self.h, s)
+        return (s[0], s[1], s[2]) if self.which == "oracle" else (s[0], s[1], s[3])
+
+    def structure(self):
+        """pre-order (cut_dim per splitting node, cut_val per splitting node, point per leaf)"""
+        cd = np.empty(max(self.n, 1), np.int32)
+        cv = np.empty(max(self.n, 1), np.float64)
+        lp = np.empty(self.n, np.int32)
+        nl = C.c_long(0)
+        ns = getattr(self.L, self.p + "structure")(self.h, _i(cd), _d(cv), _i(lp), C.byref(nl))
+        if ns < 0:
+            raise RuntimeError("leaf with more than one point")
+        return cd[:ns].copy(), cv[:ns].copy(), lp[:nl.value].copy()
+
+    def nodes(self):
+        """oracle only: flat splitting nodes (cut_dim, child[2], (cut_val, lo, hi)), root reference"""
+        ns = self.stats()[2]
+        cd = np.empty(max(ns, 1), np.int32)
+        ch = np.empty((max(ns, 1), 2), np.int32)
+        cv = np.empty((max(ns, 1), 3), np.float64)
+        root = np.zeros(1, np.int32)
+        lib().orc_ann_nodes(self.h, _i(cd), _i(ch), _d(cv), _i(root))
+        return cd[:ns], ch[:ns], cv[:ns], int(root[0])
+
+    def ksearch(self, q, k, eps, want_visits=False):
+        q = _c(q).reshape(-1, 3)
+        idx = np.empty((len(q), k), np.int32)
+        dist = np.empty((len(q), k), np.float64)
+        if self.which == "oracle":
+            vis = (C.c_long * 2)(0, 0)
+            if lib().orc_ann_ksearch(self.h, _d(q), len(q), int(k), float(eps), _i(idx), _d(dist), vis):
+                raise RuntimeError("Requesting more near neighbors than data points")
+            if want_visits:
+                return idx, dist, (vis[0], vis[1])
+        else:
+            if k > self.n:
+                raise RuntimeError("Requesting more near neighbors than data points")   # the library abort()s
+            ref().ref_ann_ksearch(self.h, _d(q), len(q), int(k), float(eps), _i(idx), _d(dist))
+        return idx, dist
+
+
+def eigen3(A, which="oracle"):
+    """newmat EigenValues(SymmetricMatrix, D, U) of a 3x3: (ascending eigenvalues, eigenvectors in columns)."""
+    a = _c(A).reshape(9)
+    d = np.empty(3)
+    u = np.empty(9)
+    (lib().orc_eigen3 if which == "oracle" else ref().ref_eigen3)(_d(a), _d(d), _d(u))
+    return d, u.reshape(3, 3)
+
+
+def normals_apx_knn(xyz, k, rPos, eps, which="oracle", want_knn=False):
+    """calculateNormalsApxKNN (normals.cc:35-111)."""
+    xyz = _c(xyz).reshape(-1, 3)
+    rp = _c(rPos)
+    out = np.empty_like(xyz)
+    if which == "oracle":
+        knn = np.empty((len(xyz), k), np.int32) if want_knn else None
+        if lib().orc_normals_apx_knn(_d(xyz), len(xyz), int(k), _d(rp), float(eps), _d(out), _i(knn)):
+            raise RuntimeError("Requesting more near neighbors than data points")
+        return (out, knn) if want_knn else out
+    ref().ref_normals_apx_knn(_d(xyz), len(xyz), int(k), _d(rp), float(eps), _d(out))
+    return out
+
+
+def normals_from_knn(xyz, knn, rPos):
+    xyz = _c(xyz).reshape(-1, 3)
+    knn = np.ascontiguousarray(knn, np.int32)
+    rp = _c(rPos)
+    out = np.empty_like(xyz)
+    lib().orc_normals_from_knn(_d(xyz), len(xyz), knn.shape[1], _i(knn), _d(rp), _d(out))
+    return out

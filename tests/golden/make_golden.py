@@ -17,6 +17,10 @@ Fixtures written:
   b4_dat_lum.json   LUM link systems at the B1 final poses (-D 25)
   k6_serial_minimizers.json  reference icp6D_{ORTHO,DUAL,HELIX,LUMEULER,LUMQUAT,QUAT_SCALE}::Align
                     (-a 3,4,5,7,8,9) on the K6 clouds; `python make_golden.py k6s` regenerates only this
+  k7_ann_normals.npz  Scan::calcNormals = calculateNormalsApxKNN(k = 10, eps = 1.0): the vendored ANN library's
+                    k-NN lists and the normals (real annkSearch + real newmat EigenValues through
+                    oracle/ref_ann_driver.cc) for the first 6000 points of dat/scan000 and for a seeded noisy
+                    plane; `python make_golden.py k7` regenerates only this
 """
 import json
 import os
@@ -64,11 +68,35 @@ def gen_k6_serial():
     json.dump(out, open(os.path.join(HERE, "k6_serial_minimizers.json"), "w"), indent=1)
 
 
+def k7_clouds():
+    """The two K7 clouds: a slice of the bundled scan (needs dat_scans.npz) and a seeded noisy plane."""
+    z = np.load(os.path.join(HERE, "dat_scans.npz"))
+    u = orc.gen_mt64_uniform(11, 9000, -1.0, 1.0).reshape(3000, 3)
+    plane = np.stack([300.0 * u[:, 0], 300.0 * u[:, 1], 40.0 + 0.1 * 300.0 * u[:, 0] + 0.5 * u[:, 2]], axis=1)
+    return {"dat": np.ascontiguousarray(z["scan000"][:6000]), "plane": plane}
+
+
+def gen_k7_ann():
+    out = {}
+    rPos = np.array([0.0, 0.0, 0.0])
+    for tag, pts in k7_clouds().items():
+        t = orc.AnnTree(pts, "ref")
+        idx, dist = t.ksearch(pts, 10, 1.0)
+        nrm = orc.normals_apx_knn(pts, 10, rPos, 1.0, "ref")
+        out[tag + "_knn"] = idx
+        out[tag + "_normals"] = nrm
+        out[tag + "_stats"] = np.array(t.stats())
+        print("K7", tag, pts.shape, t.stats(), "knn hash", hex(int(orc.k5_hash(idx.reshape(-1)))))
+    np.savez_compressed(os.path.join(HERE, "k7_ann_normals.npz"), **out)
+
+
 def main():
     assert orc.have_ref() or os.path.isdir(REF), "needs the reference checkout"
     orc.build()
     if sys.argv[1:] == ["k6s"]:
         return gen_k6_serial()
+    if sys.argv[1:] == ["k7"]:
+        return gen_k7_ann()
     gen_k6_serial()
 
     # ---- dat scans ------------------------------------------------------------------
@@ -164,6 +192,7 @@ def main():
                            "poses_after": [np.concatenate([s.rPos, s.rPosTheta]).tolist() for s in S]}
     print("B4 lum iteration ret", ret)
     json.dump(b4, open(os.path.join(HERE, "b4_dat_lum.json"), "w"), indent=1)
+    gen_k7_ann()      # after dat_scans.npz has been written
 
 
 if __name__ == "__main__":

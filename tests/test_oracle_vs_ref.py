@@ -218,3 +218,76 @@ def test_b4_lum_links(orc):
         np.testing.assert_allclose(CD, L["CD"], rtol=1e-8, atol=1e-8)
     # SURVEY appendix B4
     assert b4["links"][0]["m"] == 73335 and abs(b4["links"][0]["ss"] - 17.34408661) < 1e-7
+
+
+# ---- normals: ANN kd-tree + approximate k-NN + PCA (oracle_normals.c) ---------------------------
+def _ann_clouds():
+    rng = np.random.default_rng(0)
+    c = {"uniform": rng.uniform(-100, 100, (5000, 3))}
+    p = rng.uniform(-50, 50, (4000, 3)); p[:, 2] = 0.01 * p[:, 0] + rng.normal(0, 0.05, 4000)
+    c["plane"] = p
+    c["lattice"] = np.stack(np.meshgrid(np.arange(12.0), np.arange(12.0), np.arange(12.0)), -1).reshape(-1, 3)
+    d = rng.uniform(-1, 1, (300, 3))
+    c["duplicates"] = np.concatenate([d, d, d[:100]])
+    c["tiny"] = rng.uniform(-1, 1, (11, 3))
+    c["line"] = np.outer(np.arange(200.0), [1.0, 0.0, 0.0])
+    c["clusters"] = np.concatenate([rng.normal(m, 0.5, (400, 3)) for m in ((0, 0, 0), (50, 0, 0), (0, 80, 5))])
+    return c
+
+
+@pytest.mark.parametrize("name", ["uniform", "plane", "lattice", "duplicates", "tiny", "line", "clusters"])
+def test_ann_oracle_equals_vendored_library(orc, name):
+    """Tree (pre-order cut dimensions and leaf points), k-NN lists (indices in list order, distances) and
+    normals of the restatement == the vendored ANN 1.1.1 + newmat, bit for bit."""
+    _need_ref(orc)
+    p = _ann_clouds()[name]
+    a, b = orc.AnnTree(p, "oracle"), orc.AnnTree(p, "ref")
+    assert a.stats() == b.stats()
+    sa, sb = a.structure(), b.structure()
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[2], sb[2])
+    assert np.allclose(sa[1], sb[1], rtol=1e-13, atol=0)            # dumped with 15 digits
+    rng = np.random.default_rng(1)
+    q = np.concatenate([p, p[:500] + rng.normal(0, 3, (min(500, len(p)), 3))])
+    for k, eps in ((10, 1.0), (10, 0.0), (1, 1.0), (5, 0.3), (len(p) if len(p) < 20 else 16, 2.0)):
+        i1, d1 = a.ksearch(q, k, eps)
+        i2, d2 = b.ksearch(q, k, eps)
+        assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    rp = [1.0, 2.0, 3.0]
+    assert np.array_equal(orc.normals_apx_knn(p, 10, rp, 1.0), orc.normals_apx_knn(p, 10, rp, 1.0, "ref"))
+
+
+def test_eigen3_equals_newmat(orc):
+    _need_ref(orc)
+    rng = np.random.default_rng(2)
+    for trial in range(300):
+        X = rng.normal(size=(10, 3)) * rng.uniform(0.01, 100, 3)
+        if trial % 5 == 0:
+            X[:, 2] = 0.0                                            # exactly planar neighbourhoods
+        if trial % 7 == 0:
+            X[:, 1] = X[:, 0]
+        A = X.T @ X
+        d1, u1 = orc.eigen3(A)
+        d2, u2 = orc.eigen3(A, "ref")
+        assert np.array_equal(d1, d2) and np.array_equal(u1, u2)
+
+
+def test_ann_oracle_against_golden(orc):
+    """K7 fixture (generated with the vendored ANN + newmat): k-NN lists and normals of the restatement."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    z = np.load(os.path.join(G, "k7_ann_normals.npz"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    for tag, pts in mg.k7_clouds().items():
+        t = orc.AnnTree(pts)
+        assert tuple(z[tag + "_stats"]) == t.stats()
+        idx, _ = t.ksearch(pts, 10, 1.0)
+        assert np.array_equal(idx, z[tag + "_knn"])
+        nrm, knn = orc.normals_apx_knn(pts, 10, [0.0, 0.0, 0.0], 1.0, want_knn=True)
+        assert np.array_equal(knn, z[tag + "_knn"]) and np.array_equal(nrm, z[tag + "_normals"])
+        assert np.array_equal(orc.normals_from_knn(pts, knn, [0.0, 0.0, 0.0]), nrm)
+
+
+def test_ann_search_errors(orc):
+    t = orc.AnnTree(np.random.default_rng(0).uniform(-1, 1, (5, 3)))
+    with pytest.raises(RuntimeError):
+        t.ksearch(np.zeros((1, 3)), 6, 1.0)          # "Requesting more near neighbors than data points"
