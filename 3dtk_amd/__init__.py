@@ -18,6 +18,6 @@ from ._capi import (TdtkError, lib, build_extension, device_count, version, Pair
 from .slam6d import (KDtree, Scan, icp6Dminimizer, icp6D_QUAT, icp6D_SVD, icp6D_APX,  # noqa: F401
                      icp6D_ORTHO, icp6D_DUAL, icp6D_HELIX, icp6D_LUMEULER, icp6D_LUMQUAT, icp6D_QUAT_SCALE,
                      icp6D_NAPX, icp6D, Graph, lum6DEuler, lum6DQuat, ghelix6DQ2, gapx6D, QuatToMatrix4, Matrix4ToQuat, M4inv, MMult, M4identity,
-                     EulerToMatrix4, Matrix4ToEuler, host_tree_layout, MetaScan, read_uos, read_pose,
+                     EulerToMatrix4, Matrix4ToEuler, host_tree_layout, calculateNormalsApxKNN, MetaScan, read_uos, read_pose,
                      openDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints,
                      computeGraph6Dautomatic, matchGraph6Dautomatic_clpairs, prepare_scans)

@@ -59,7 +59,7 @@ EXPORTS = [
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_point_point_error",
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
-    "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
     "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
 ]
@@ -154,6 +154,8 @@ def lib():
     L.tdtk_point_point_error.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_uint64), _dp]
     L.tdtk_scans_transform2.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, _dp]
     L.tdtk_reduce_octree.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp, C.POINTER(C.c_size_t)]
+    L.tdtk_normals_apx_knn.argtypes = [_dp, C.c_size_t, C.c_int, _dp, C.c_double, C.c_int, _dp, _ip]
+    L.tdtk_scan_calc_normals.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.tdtk_io_read_uos.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(_dp), C.POINTER(C.c_size_t)]
     L.tdtk_io_free.argtypes = [C.c_void_p]
     L.tdtk_io_free.restype = None

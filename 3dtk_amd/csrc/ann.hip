@@ -1,0 +1,811 @@
+// Scan::calcNormals on the GPU: calculateNormalsApxKNN(normals, points, k = 10, rPos, eps = 1.0)
+// (src/slam6d/scan.cc:398-427, src/slam6d/normals.cc:35-111).
+//
+// The reference answers "the k approximate nearest neighbours of every point of the scan" with the ANN 1.1.1
+// library: a kd-tree with ONE point per leaf built by the sliding-midpoint rule, searched with a (1+eps) error
+// bound.  With eps = 1 the neighbour lists are far from the exact ones and depend on the shape of that very tree
+// and on the order in which it is walked, so the same tree is built here and walked in the same order:
+//
+//   build (3rdparty/ann/ann_1.1.1_modified/src/kd_tree.cpp:319-404, kd_split.cpp:146-213, kd_util.cpp:225-319)
+//     level by level for every cell of the level at once while cells are large -- point min/max per cell by one
+//     wavefront, the library's two in-place Hoare passes (annPlaneSplit: "< cv | >= cv", then "== cv | > cv" on the
+//     right part) each as "the k-th misplaced element from the left swaps with the k-th misplaced from the right
+//     end" (prefix sums + one swap kernel), which reproduces the permutation and therefore which of several points
+//     ON the cutting plane goes to which side -- and, once a cell holds <= ANN_SMALL points, the rest of its
+//     subtree by ONE thread running the library's recursion as written.
+//     Bucket size 1 means a cell of n points always yields n-1 splitting nodes: the node that separates positions
+//     p and p+1 of the final point order gets index p, so no node allocation or compaction is needed.
+//   search + PCA (kd_search.cpp:89-210, pr_queue_k.h:66-115, normals.cc:64-105)
+//     one thread per scan point, in leaf order so that neighbouring lanes walk neighbouring paths; the k best are a
+//     sorted list in registers; the far-child stack lives in LDS with a spill area in global memory; then the
+//     neighbour mean, covariance, newmat's tred2/tql2 (evalue.cpp:24-156) on the 3x3, the flip towards the sensor.
+//
+// All fp64, no contraction: neighbour lists and normals are bit-identical to the library's.
+#include <cfloat>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+
+#include "kernels.h"
+
+namespace tdtk {
+
+#define WAVE 64
+#define ANN_SMALL 32u         // cells up to this size are finished by one thread
+#define ANN_ERR 0.001         // kd_split.cpp:34
+#define A_LEAF 0x20000000u    // child reference: leaf flag | position (29 bits); c0 bits 30..31 = cutting dimension
+#define A_VAL 0x1FFFFFFFu
+#define NOSEG 0xFFFFFFFFu
+
+struct ASeg {
+  uint32_t start, n;
+  int32_t parent;   // node index, -1 for the root
+  uint32_t side;    // 0 -> low child, 1 -> high child
+  uint32_t depth, pad;
+  double blo[3], bhi[3];   // the cell (kd_tree.cpp:346-357), not the points' own bounding box
+};
+struct AMeas { double mn[3], mx[3]; };
+struct ADec { double cv; uint32_t cd, mode, n_lo, slot0, slot1, pad; };   // mode 0 midpoint, 1 slid to min, 2 slid to max
+
+static __device__ __forceinline__ double coord_of(const double* __restrict__ cx, const double* __restrict__ cy,
+                                                  const double* __restrict__ cz, uint32_t ax, uint32_t p)
+{
+  return (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
+}
+
+// cutting dimension / value of sl_midpt_split (kd_split.cpp:158-209) from the cell and the points' min/max
+static __device__ __forceinline__ void sl_midpt_rule(const double* blo, const double* bhi, const double* mn,
+                                                     const double* mx, uint32_t& cd, double& cv, uint32_t& mode)
+{
+  double max_length = bhi[0] - blo[0];
+#pragma unroll
+  for (int d = 1; d < 3; d++) {
+    const double length = bhi[d] - blo[d];
+    if (length > max_length) max_length = length;
+  }
+  double max_spread = -1;
+  cd = 0;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if ((bhi[d] - blo[d]) >= (1 - ANN_ERR) * max_length) {
+      const double spr = mx[d] - mn[d];
+      if (spr > max_spread) { max_spread = spr; cd = (uint32_t)d; }
+    }
+  }
+  const double lo = (cd == 0) ? blo[0] : ((cd == 1) ? blo[1] : blo[2]);
+  const double hi = (cd == 0) ? bhi[0] : ((cd == 1) ? bhi[1] : bhi[2]);
+  const double pmn = (cd == 0) ? mn[0] : ((cd == 1) ? mn[1] : mn[2]);
+  const double pmx = (cd == 0) ? mx[0] : ((cd == 1) ? mx[1] : mx[2]);
+  const double ideal = (lo + hi) / 2;
+  if (ideal < pmn) { cv = pmn; mode = 1; }
+  else if (ideal > pmx) { cv = pmx; mode = 2; }
+  else { cv = ideal; mode = 0; }
+}
+static __device__ __forceinline__ uint32_t sl_midpt_nlo(uint32_t mode, uint32_t n, uint32_t br1, uint32_t br2)
+{
+  if (mode == 1) return 1u;           // kd_split.cpp:208-212
+  if (mode == 2) return n - 1u;
+  if (br1 > n / 2) return br1;
+  if (br2 < n / 2) return br2;
+  return n / 2;
+}
+
+// ---- level-parallel part -----------------------------------------------------------------------
+__global__ void k_ann_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
+                           uint32_t* __restrict__ seg_of, double* __restrict__ cx, double* __restrict__ cy,
+                           double* __restrict__ cz, uint32_t* __restrict__ bad)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const double x = xyz[3 * (size_t)p], y = xyz[3 * (size_t)p + 1], z = xyz[3 * (size_t)p + 2];
+  perm[p] = p; seg_of[p] = (M > ANN_SMALL) ? 0u : NOSEG;
+  cx[p] = x; cy[p] = y; cz[p] = z;
+  if (!(isfinite(x) && isfinite(y) && isfinite(z))) atomicOr(bad, 1u);
+}
+
+// the root cell = annEnclRect of all points (kd_tree.cpp:381-385); small[4] counts the small cells
+__global__ void k_ann_root(const double* __restrict__ box, uint32_t M, ASeg* __restrict__ segs,
+                           ASeg* __restrict__ small_list, uint32_t* __restrict__ small, double* __restrict__ bb)
+{
+  ASeg r;
+  r.start = 0; r.n = M; r.parent = -1; r.side = 0; r.depth = 0; r.pad = 0;
+  for (int d = 0; d < 3; d++) { r.blo[d] = box[d]; r.bhi[d] = box[3 + d]; bb[d] = box[d]; bb[3 + d] = box[3 + d]; }
+  if (M > ANN_SMALL) segs[0] = r;
+  else if (M > 1) { small_list[0] = r; small[4] = 1; }
+  else small[0] = A_LEAF | 0u;     // a single point: the root is its leaf
+}
+
+// one wavefront per cell: min / max of its points along the three axes
+__global__ void __launch_bounds__(256) k_ann_measure(const ASeg* __restrict__ segs, uint32_t nseg,
+                                                     const double* __restrict__ cx, const double* __restrict__ cy,
+                                                     const double* __restrict__ cz, AMeas* __restrict__ out)
+{
+  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (w >= nseg) return;
+  const uint32_t s = __builtin_amdgcn_readfirstlane(segs[w].start);
+  const uint32_t n = __builtin_amdgcn_readfirstlane(segs[w].n);
+  double mn[3] = {cx[s], cy[s], cz[s]}, mx[3] = {mn[0], mn[1], mn[2]};
+  for (uint32_t i = lane; i < n; i += WAVE) {
+    const double v[3] = {cx[s + i], cy[s + i], cz[s + i]};
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      double t;
+      t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
+      t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
+    }
+  if (lane == 0)
+    for (int d = 0; d < 3; d++) { out[w].mn[d] = mn[d]; out[w].mx[d] = mx[d]; }
+}
+
+__global__ void k_ann_decide(const ASeg* __restrict__ segs, uint32_t nseg, const AMeas* __restrict__ meas,
+                             ADec* __restrict__ dec)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const ASeg sg = segs[i];
+  const AMeas m = meas[i];
+  ADec d;
+  sl_midpt_rule(sg.blo, sg.bhi, m.mn, m.mx, d.cd, d.cv, d.mode);
+  d.n_lo = 0; d.slot0 = d.slot1 = NOSEG; d.pad = 0;
+  dec[i] = d;
+}
+
+// pass 1: "< cv" belongs left of br1.  pass 2 (positions >= br1 only): "<= cv", i.e. "== cv", belongs left of br2
+template <int PASS>
+__global__ void k_ann_flags(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
+                            const ADec* __restrict__ dec, const uint32_t* __restrict__ br1,
+                            const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
+                            uint32_t M, uint32_t* __restrict__ f)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  uint32_t v = 0;
+  if (p < M) {
+    const uint32_t sg = seg_of[p];
+    if (sg != NOSEG) {
+      const double c = coord_of(cx, cy, cz, dec[sg].cd, p);
+      if (PASS == 1) v = (c < dec[sg].cv) ? 1u : 0u;
+      else v = ((p - segs[sg].start) >= br1[sg] && c <= dec[sg].cv) ? 1u : 0u;
+    }
+  }
+  f[p] = v;   // index M is a zero terminator: the exclusive scan then also yields every cell's total
+}
+
+// per cell: number of flagged elements = F[s+n] - F[s]
+template <int PASS>
+__global__ void k_ann_breaks(const ASeg* __restrict__ segs, uint32_t nseg, const uint32_t* __restrict__ F,
+                             uint32_t* __restrict__ br1, uint32_t* __restrict__ br2)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const uint32_t cnt = F[segs[i].start + segs[i].n] - F[segs[i].start];
+  if (PASS == 1) br1[i] = cnt;
+  else br2[i] = br1[i] + cnt;
+}
+
+template <int PASS>
+__global__ void k_ann_misplaced(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
+                                const uint32_t* __restrict__ br1, const uint32_t* __restrict__ br2,
+                                const uint32_t* __restrict__ f, uint32_t M, unsigned long long* __restrict__ LR)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  uint32_t l = 0, r = 0;
+  if (p < M) {
+    const uint32_t sg = seg_of[p];
+    if (sg != NOSEG) {
+      const uint32_t rel = p - segs[sg].start;
+      if (PASS == 1) {
+        const bool left_region = rel < br1[sg];
+        l = (left_region && !f[p]) ? 1u : 0u;
+        r = (!left_region && f[p]) ? 1u : 0u;
+      } else if (rel >= br1[sg]) {
+        const bool left_region = rel < br2[sg];
+        l = (left_region && !f[p]) ? 1u : 0u;
+        r = (!left_region && f[p]) ? 1u : 0u;
+      }
+    }
+  }
+  LR[p] = (unsigned long long)l | ((unsigned long long)r << 32);
+}
+
+// k-th misplaced from the left pairs with the k-th misplaced from the right END of the cell
+__global__ void k_ann_swaplist(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
+                               const unsigned long long* __restrict__ LR, const unsigned long long* __restrict__ AB,
+                               uint32_t M, uint32_t* __restrict__ posL, uint32_t* __restrict__ posR)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const unsigned long long lr = LR[p];
+  if ((uint32_t)lr) posL[(uint32_t)AB[p]] = p;
+  if ((uint32_t)(lr >> 32)) {
+    const uint32_t sg = seg_of[p];
+    const uint32_t s = segs[sg].start, n = segs[sg].n;
+    const uint32_t Bs = (uint32_t)(AB[s] >> 32);
+    const uint32_t total = (uint32_t)(AB[s + n] >> 32) - Bs;
+    const uint32_t kfwd = (uint32_t)(AB[p] >> 32) - Bs;
+    posR[Bs + (total - 1u - kfwd)] = p;
+  }
+}
+__global__ void k_ann_swap(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
+                           const unsigned long long* __restrict__ nswap_ptr, uint32_t* __restrict__ perm,
+                           double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (uint32_t)*nswap_ptr) return;
+  const uint32_t a = posL[c], b = posR[c];
+  const uint32_t pa = perm[a], pb = perm[b];
+  perm[a] = pb; perm[b] = pa;
+  double t;
+  t = cx[a]; cx[a] = cx[b]; cx[b] = t;
+  t = cy[a]; cy[a] = cy[b]; cy[b] = t;
+  t = cz[a]; cz[a] = cz[b]; cz[b] = t;
+}
+
+static __device__ __forceinline__ void ann_hook(AnnNode* __restrict__ nodes, uint32_t* __restrict__ root_ref,
+                                                int32_t parent, uint32_t side, uint32_t ref)
+{
+  if (parent < 0) *root_ref = ref;
+  else if (side) nodes[parent].c1 = ref;
+  else nodes[parent].c0 = (nodes[parent].c0 & 0xC0000000u) | ref;
+}
+
+// per cell: n_lo, the splitting node, the two child cells (leaf / small cell / cell of the next level).
+// small: [0] root_ref [1] max depth [2] err [3] cells of the next level [4] small cells
+__global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADec* __restrict__ dec,
+                               const uint32_t* __restrict__ br1, const uint32_t* __restrict__ br2,
+                               AnnNode* __restrict__ nodes, ASeg* __restrict__ next, ASeg* __restrict__ small_list,
+                               uint32_t* __restrict__ small)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const ASeg sg = segs[i];
+  ADec d = dec[i];
+  const uint32_t n_lo = sl_midpt_nlo(d.mode, sg.n, br1[i], br2[i]);
+  if (n_lo == 0 || n_lo >= sg.n) { atomicExch(small + 2, 1u); return; }   // cannot happen for finite input
+  const uint32_t me = sg.start + n_lo - 1u;
+  AnnNode nd;
+  nd.cut_val = d.cv;
+  nd.lo = (d.cd == 0) ? sg.blo[0] : ((d.cd == 1) ? sg.blo[1] : sg.blo[2]);
+  nd.hi = (d.cd == 0) ? sg.bhi[0] : ((d.cd == 1) ? sg.bhi[1] : sg.bhi[2]);
+  nd.c0 = d.cd << 30; nd.c1 = 0;
+  uint32_t slot[2] = {NOSEG, NOSEG};
+  for (uint32_t side = 0; side < 2; side++) {
+    ASeg ch = sg;
+    ch.start = side ? sg.start + n_lo : sg.start;
+    ch.n = side ? sg.n - n_lo : n_lo;
+    ch.parent = (int32_t)me; ch.side = side; ch.depth = sg.depth + 1;
+    if (side) { if (d.cd == 0) ch.blo[0] = d.cv; else if (d.cd == 1) ch.blo[1] = d.cv; else ch.blo[2] = d.cv; }
+    else { if (d.cd == 0) ch.bhi[0] = d.cv; else if (d.cd == 1) ch.bhi[1] = d.cv; else ch.bhi[2] = d.cv; }
+    if (ch.n == 1) {
+      if (side) nd.c1 = A_LEAF | ch.start; else nd.c0 |= A_LEAF | ch.start;
+      atomicMax(small + 1, ch.depth);
+    } else if (ch.n <= ANN_SMALL) {
+      small_list[atomicAdd(small + 4, 1u)] = ch;
+    } else {
+      slot[side] = atomicAdd(small + 3, 1u);
+      next[slot[side]] = ch;
+    }
+  }
+  nodes[me] = nd;     // children that are cells hook themselves in later (they run after this kernel)
+  ann_hook(nodes, small + 0, sg.parent, sg.side, me);
+  d.n_lo = n_lo; d.slot0 = slot[0]; d.slot1 = slot[1];
+  dec[i] = d;
+}
+__global__ void k_ann_relabel(const ASeg* __restrict__ segs, const ADec* __restrict__ dec, uint32_t M,
+                              uint32_t* __restrict__ seg_of)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const uint32_t sg = seg_of[p];
+  if (sg == NOSEG) return;
+  seg_of[p] = ((p - segs[sg].start) < dec[sg].n_lo) ? dec[sg].slot0 : dec[sg].slot1;
+}
+
+// ---- small cells: the library's recursion as written, one thread per cell -----------------------
+struct AFrame { uint32_t start, n; int32_t parent; uint32_t side, depth; double blo[3], bhi[3]; };
+
+__global__ void __launch_bounds__(64) k_ann_small(const ASeg* __restrict__ small_list, uint32_t nsmall,
+                                                  uint32_t* __restrict__ perm, double* __restrict__ cx,
+                                                  double* __restrict__ cy, double* __restrict__ cz,
+                                                  AnnNode* __restrict__ nodes, uint32_t* __restrict__ small)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsmall) return;
+  AFrame st[ANN_SMALL + 2];
+  int sp = 0;
+  {
+    const ASeg sg = small_list[i];
+    AFrame& f = st[sp++];
+    f.start = sg.start; f.n = sg.n; f.parent = sg.parent; f.side = sg.side; f.depth = sg.depth;
+    for (int d = 0; d < 3; d++) { f.blo[d] = sg.blo[d]; f.bhi[d] = sg.bhi[d]; }
+  }
+  uint32_t maxdepth = 0;
+  while (sp > 0) {
+    const AFrame f = st[--sp];
+    const uint32_t s = f.start, n = f.n;
+    if (n == 1) {
+      ann_hook(nodes, small + 0, f.parent, f.side, A_LEAF | s);
+      maxdepth = (f.depth > maxdepth) ? f.depth : maxdepth;
+      continue;
+    }
+    // annSpread / annMinMax over the cell's points (kd_util.cpp:225-262)
+    double mn[3] = {cx[s], cy[s], cz[s]}, mx[3] = {mn[0], mn[1], mn[2]};
+    for (uint32_t k = 1; k < n; k++) {
+      const double v[3] = {cx[s + k], cy[s + k], cz[s + k]};
+#pragma unroll
+      for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
+    }
+    uint32_t cd, mode;
+    double cv;
+    sl_midpt_rule(f.blo, f.bhi, mn, mx, cd, cv, mode);
+    double* __restrict__ ca = (cd == 0) ? cx : ((cd == 1) ? cy : cz);
+    auto swap_pts = [&](uint32_t a, uint32_t b) {
+      const uint32_t pa = perm[a]; perm[a] = perm[b]; perm[b] = pa;
+      double t;
+      t = cx[a]; cx[a] = cx[b]; cx[b] = t;
+      t = cy[a]; cy[a] = cy[b]; cy[b] = t;
+      t = cz[a]; cz[a] = cz[b]; cz[b] = t;
+    };
+    // annPlaneSplit (kd_util.cpp:291-319)
+    int l = 0, r = (int)n - 1;
+    for (;;) {
+      while (l < (int)n && ca[s + l] < cv) l++;
+      while (r >= 0 && ca[s + r] >= cv) r--;
+      if (l > r) break;
+      swap_pts(s + l, s + r);
+      l++; r--;
+    }
+    const int br1 = l;
+    r = (int)n - 1;
+    for (;;) {
+      while (l < (int)n && ca[s + l] <= cv) l++;
+      while (r >= br1 && ca[s + r] > cv) r--;
+      if (l > r) break;
+      swap_pts(s + l, s + r);
+      l++; r--;
+    }
+    const int br2 = l;
+    const uint32_t n_lo = sl_midpt_nlo(mode, n, (uint32_t)br1, (uint32_t)br2);
+    if (n_lo == 0 || n_lo >= n) { atomicExch(small + 2, 1u); return; }
+    const uint32_t me = s + n_lo - 1u;
+    AnnNode nd;
+    nd.cut_val = cv;
+    nd.lo = (cd == 0) ? f.blo[0] : ((cd == 1) ? f.blo[1] : f.blo[2]);
+    nd.hi = (cd == 0) ? f.bhi[0] : ((cd == 1) ? f.bhi[1] : f.bhi[2]);
+    nd.c0 = cd << 30; nd.c1 = 0;
+    nodes[me] = nd;
+    ann_hook(nodes, small + 0, f.parent, f.side, me);
+    // high child first so that the low child is handled next, as the recursion does (order is immaterial)
+    for (int side = 1; side >= 0; side--) {
+      AFrame& c = st[sp++];
+      c = f;
+      c.start = side ? s + n_lo : s;
+      c.n = side ? n - n_lo : n_lo;
+      c.parent = (int32_t)me; c.side = (uint32_t)side; c.depth = f.depth + 1;
+      if (side) { if (cd == 0) c.blo[0] = cv; else if (cd == 1) c.blo[1] = cv; else c.blo[2] = cv; }
+      else { if (cd == 0) c.bhi[0] = cv; else if (cd == 1) c.bhi[1] = cv; else c.bhi[2] = cv; }
+    }
+  }
+  atomicMax(small + 1, maxdepth);
+}
+
+__global__ void k_ann_points(const uint32_t* __restrict__ perm, const double* __restrict__ cx,
+                             const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M,
+                             KdPoint* __restrict__ pts)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  KdPoint q;
+  q.x = cx[p]; q.y = cy[p]; q.z = cz[p]; q.orig = (int32_t)perm[p]; q.pad = 0;
+  pts[p] = q;
+}
+
+static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+#define ACHK(expr)                                       \
+  do {                                                   \
+    hipError_t _e = (expr);                              \
+    if (_e != hipSuccess) { res.err = _e; return res; }  \
+  } while (0)
+
+static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
+{
+  size_t scan_tmp = 0;
+  {
+    uint32_t* z = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, z, z, 0u, M + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    unsigned long long* z8 = nullptr;
+    size_t t8 = 0;
+    (void)rocprim::exclusive_scan(nullptr, t8, z8, z8, 0ull, M + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
+    if (t8 > scan_tmp) scan_tmp = t8;
+  }
+  const size_t n1 = M + 1, nlarge = M / (ANN_SMALL + 1) + 2, nsmall = M / 2 + 2;
+  size_t off = 0;
+  int k = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; if (O) O[k] = o; k++; return o; };
+  take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1); take(8 * n1);      // 0 perm 1 segof 2 cx 3 cy 4 cz
+  take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1);                    // 5 f 6 F 7 LR 8 AB
+  take(4 * n1); take(4 * n1);                                                // 9 posL 10 posR
+  take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nsmall);   // 11 segA 12 segB 13 small cells
+  take(sizeof(AMeas) * nlarge); take(sizeof(ADec) * nlarge); take(4 * nlarge); take(4 * nlarge);   // 14 meas 15 dec 16 br1 17 br2
+  take(scan_tmp + 256); take(256);                                           // 18 tmp 19 small
+  take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
+  if (scan_tmp_out) *scan_tmp_out = scan_tmp;
+  return off;
+}
+size_t ann_build_arena_bytes(size_t M) { return ann_layout(M, nullptr, nullptr); }
+
+// Builds on `s` inside the caller's scratch.  nodes (M-1 records, may be null for M == 1), pts (M records) and
+// bb (6 doubles) are caller-owned device memory and are final when this returns.
+AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnNode* nodes, KdPoint* pts,
+                              double* bb, hipStream_t s)
+{
+  AnnBuildResult res{};
+  const uint32_t M = (uint32_t)M_;
+  char* arena = static_cast<char*>(arena_);
+  size_t scan_tmp = 0;
+  size_t O[32];
+  (void)ann_layout(M_, O, &scan_tmp);
+  const size_t n1 = (size_t)M + 1;
+  uint32_t* perm = (uint32_t*)(arena + O[0]); uint32_t* seg_of = (uint32_t*)(arena + O[1]);
+  double *cx = (double*)(arena + O[2]), *cy = (double*)(arena + O[3]), *cz = (double*)(arena + O[4]);
+  uint32_t *f = (uint32_t*)(arena + O[5]), *F = (uint32_t*)(arena + O[6]);
+  unsigned long long *LR = (unsigned long long*)(arena + O[7]), *AB = (unsigned long long*)(arena + O[8]);
+  uint32_t *posL = (uint32_t*)(arena + O[9]), *posR = (uint32_t*)(arena + O[10]);
+  ASeg *segs = (ASeg*)(arena + O[11]), *next = (ASeg*)(arena + O[12]), *small_list = (ASeg*)(arena + O[13]);
+  AMeas* meas = (AMeas*)(arena + O[14]); ADec* dec = (ADec*)(arena + O[15]);
+  uint32_t *br1 = (uint32_t*)(arena + O[16]), *br2 = (uint32_t*)(arena + O[17]);
+  void* tmp = arena + O[18];
+  uint32_t* small = (uint32_t*)(arena + O[19]);
+  double* partial = (double*)(arena + O[20]); double* box = (double*)(arena + O[21]);
+
+  ACHK(hipMemsetAsync(small, 0, 256, s));
+  hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2);
+  ACHK(launch_bbox(d_xyz, M, partial, box, s));
+  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb);
+  uint32_t nseg = (M > ANN_SMALL) ? 1u : 0u, level = 0;
+  {
+    uint32_t bad = 0;
+    ACHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
+    ACHK(hipStreamSynchronize(s));
+    if (bad) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
+  }
+  while (nseg > 0) {
+    ++level;
+    hipLaunchKernelGGL(k_ann_measure, dim3(cdiv((size_t)nseg * WAVE, 256)), dim3(256), 0, s, segs, nseg, cx, cy, cz, meas);
+    hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, dec);
+    ACHK(hipMemsetAsync(small + 3, 0, 4, s));
+    // the library's first Hoare pass, then its second one on what lies right of br1
+    for (int pass = 1; pass <= 2; pass++) {
+      if (pass == 1)
+        hipLaunchKernelGGL(k_ann_flags<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, br1, cx, cy, cz, M, f);
+      else
+        hipLaunchKernelGGL(k_ann_flags<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, br1, cx, cy, cz, M, f);
+      size_t st = scan_tmp;
+      ACHK(rocprim::exclusive_scan(tmp, st, f, F, 0u, n1, rocprim::plus<uint32_t>(), s));
+      if (pass == 1) {
+        hipLaunchKernelGGL(k_ann_breaks<1>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, F, br1, br2);
+        hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, br1, br2, f, M, LR);
+      } else {
+        hipLaunchKernelGGL(k_ann_breaks<2>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, F, br1, br2);
+        hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, br1, br2, f, M, LR);
+      }
+      st = scan_tmp;
+      ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+      hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
+      hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
+    }
+    hipLaunchKernelGGL(k_ann_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, dec, br1, br2, nodes, next,
+                       small_list, small);
+    hipLaunchKernelGGL(k_ann_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, dec, M, seg_of);
+    uint32_t h[2] = {0, 0};   // err, cells of the next level
+    ACHK(hipMemcpyAsync(h, small + 2, 8, hipMemcpyDeviceToHost, s));
+    ACHK(hipStreamSynchronize(s));
+    if (h[0] || level > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
+    nseg = h[1];
+    ASeg* t = segs; segs = next; next = t;
+  }
+  uint32_t h_small[5];
+  ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+  ACHK(hipStreamSynchronize(s));
+  if (h_small[4])
+    hipLaunchKernelGGL(k_ann_small, dim3(cdiv(h_small[4], 64)), dim3(64), 0, s, small_list, h_small[4], perm, cx, cy, cz,
+                       nodes, small);
+  hipLaunchKernelGGL(k_ann_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
+  ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+  ACHK(hipStreamSynchronize(s));
+  ACHK(hipGetLastError());
+  if (h_small[2]) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
+  res.root_ref = h_small[0];
+  res.max_depth = h_small[1];
+  res.levels = level;
+  return res;
+}
+
+// ---- search + PCA -------------------------------------------------------------------------------
+// newmat's EigenValues on a symmetric 3x3 (evalue.cpp:24-156, 283-284; sort.cpp:190-222): tred2, tql2, ascending
+// sort.  z holds the matrix (lower triangle used) on entry and the eigenvectors (columns) on exit.
+static __device__ __forceinline__ double nm_sign(double x, double y) { return (y >= 0) ? x : -x; }
+
+static __device__ void eigen3_newmat(double z[3][3], double D[3])
+{
+  double E[3];
+  const double tol = DBL_MIN / DBL_EPSILON;
+  // tred2, n = 3
+#pragma unroll
+  for (int i = 2; i > 0; i--) {
+    double f = z[i][i - 1], g = 0.0;
+#pragma unroll
+    for (int k = 0; k < i - 1; k++) g += z[i][k] * z[i][k];
+    double h = g + f * f;
+    if (g <= tol) { E[i] = f; h = 0.0; }
+    else {
+      g = nm_sign(-__dsqrt_rn(h), f); E[i] = g; h -= f * g;
+      z[i][i - 1] = f - g; f = 0.0;
+#pragma unroll
+      for (int j = 0; j < i; j++) {
+        z[j][i] = z[i][j] / h; g = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) g += z[j][k] * z[i][k];
+#pragma unroll
+        for (int k = j; k < i; k++) g += z[k][j] * z[i][k];
+        E[j] = g / h; f += g * z[j][i];
+      }
+      const double hh = f / (h + h);
+#pragma unroll
+      for (int j = 0; j < i; j++) {
+        f = z[i][j]; g = E[j] - hh * f; E[j] = g;
+#pragma unroll
+        for (int k = 0; k <= j; k++) z[j][k] -= (f * E[k] + g * z[i][k]);
+      }
+    }
+    D[i] = h;
+  }
+  D[0] = 0.0; E[0] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (D[i] != 0.0) {
+#pragma unroll
+      for (int j = 0; j < i; j++) {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) g += z[i][k] * z[k][j];
+#pragma unroll
+        for (int k = 0; k < i; k++) z[k][j] -= g * z[k][i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < i; j++) { z[i][j] = 0.0; z[j][i] = 0.0; }
+    D[i] = z[i][i]; z[i][i] = 1.0;
+  }
+  // tql2, n = 3
+  const double eps = DBL_EPSILON;
+  E[0] = E[1]; E[1] = E[2];
+  double b = 0.0, f = 0.0;
+  E[2] = 0.0;
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    double h = eps * (fabs(D[l]) + fabs(E[l]));
+    if (b < h) b = h;
+    int m = 3;
+#pragma unroll
+    for (int mm = 2; mm >= 0; mm--)
+      if (mm >= l && fabs(E[mm]) <= b) m = mm;     // first m >= l with |E[m]| <= b (E[2] == 0 ends it)
+    for (int j = 0; j < 30; j++) {
+      if (m == l) break;
+      double g = D[l];
+      const double dl1 = (l == 0) ? D[1] : D[2];   // l < m <= 2 here
+      double p = (dl1 - g) / (2.0 * E[l]), r = __dsqrt_rn(p * p + 1.0);
+      D[l] = E[l] / (p < 0.0 ? p - r : p + r);
+      const double hh = g - D[l];
+      f += hh;
+#pragma unroll
+      for (int i = 1; i < 3; i++) if (i > l) D[i] -= hh;
+      p = (m == 1) ? D[1] : D[2];
+      double c = 1.0, s = 0.0;
+#pragma unroll
+      for (int i = 1; i >= 0; i--) {
+        if (i <= m - 1 && i >= l) {
+          const double ei = E[i], di = D[i];
+          g = c * ei; h = c * p;
+          if (fabs(p) >= fabs(ei)) {
+            c = ei / p; r = __dsqrt_rn(c * c + 1.0);
+            E[i + 1] = s * p * r; s = c / r; c = 1.0 / r;
+          } else {
+            c = p / ei; r = __dsqrt_rn(c * c + 1.0);
+            E[i + 1] = s * ei * r; s = 1.0 / r; c /= r;
+          }
+          p = c * di - s * g; D[i + 1] = h + s * (c * g + s * di);
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            h = z[k][i + 1];
+            z[k][i + 1] = s * z[k][i] + c * h;
+            z[k][i] = c * z[k][i] - s * h;
+          }
+        }
+      }
+      E[l] = s * p; D[l] = c * p;
+      if (fabs(E[l]) <= b) break;
+    }
+    D[l] += f;     // (30 sweeps without convergence throw in the reference; unreachable for a 3x3)
+  }
+  // SortSV ascending: selection sort, columns follow
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    int k = i;
+    double p = D[i];
+#pragma unroll
+    for (int j = i + 1; j < 3; j++) if (D[j] < p) { k = j; p = D[j]; }
+    if (k != i) {
+#pragma unroll
+      for (int kk = 1; kk < 3; kk++)
+        if (kk == k) {
+          D[kk] = D[i]; D[i] = p;
+#pragma unroll
+          for (int j = 0; j < 3; j++) { const double t = z[j][i]; z[j][i] = z[j][kk]; z[j][kk] = t; }
+        }
+    }
+  }
+}
+
+#define ANN_LDS_STACK 12   // far-child entries per thread kept in LDS; deeper ones spill to global memory
+
+// One thread per scan point (grid-stride over leaf positions).  KMAX >= k; the list keeps KMAX - k sentinels
+// (key -1) in front so that every register index is static.
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_ann_normals(const AnnNode* __restrict__ nodes, uint32_t root_ref,
+                                                     const KdPoint* __restrict__ pts, uint32_t n, int k,
+                                                     double max_err, const double* __restrict__ bb, double rx,
+                                                     double ry, double rz, uint32_t* __restrict__ spill_ref,
+                                                     double* __restrict__ spill_bd, uint32_t spill_depth,
+                                                     double* __restrict__ normals, int32_t* __restrict__ knn_out)
+{
+  __shared__ uint32_t s_ref[ANN_LDS_STACK][256];
+  __shared__ double s_bd[ANN_LDS_STACK][256];
+  const uint32_t T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, tx = threadIdx.x;
+  (void)spill_depth;
+  const double blo[3] = {bb[0], bb[1], bb[2]}, bhi[3] = {bb[3], bb[4], bb[5]};
+  for (uint32_t qi = tid; qi < n; qi += T) {
+    const KdPoint qp = pts[qi];
+    const double q[3] = {qp.x, qp.y, qp.z};
+    double key[KMAX];
+    uint32_t info[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) { key[j] = (j < KMAX - k) ? -1.0 : DBL_MAX; info[j] = 0xFFFFFFFFu; }
+    // annBoxDistance (kd_util.cpp:127-150)
+    double bd = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      if (q[d] < blo[d]) { const double t = blo[d] - q[d]; bd = bd + t * t; }
+      else if (q[d] > bhi[d]) { const double t = q[d] - bhi[d]; bd = bd + t * t; }
+    }
+    uint32_t cur = root_ref;
+    int sp = 0;
+    for (;;) {
+      while (!(cur & A_LEAF)) {                      // ANNkd_split::ann_search (kd_search.cpp:128-170)
+        const AnnNode nd = nodes[cur & A_VAL];
+        const uint32_t cd = nd.c0 >> 30;
+        const double qd = (cd == 0) ? q[0] : ((cd == 1) ? q[1] : q[2]);
+        const double cut_diff = qd - nd.cut_val;
+        const bool low = cut_diff < 0;
+        double box_diff = low ? (nd.lo - qd) : (qd - nd.hi);
+        if (box_diff < 0) box_diff = 0;
+        const double fbd = bd + (cut_diff * cut_diff - box_diff * box_diff);
+        const uint32_t c0 = nd.c0 & (A_LEAF | A_VAL), c1 = nd.c1;
+        const uint32_t far = low ? c1 : c0;
+        // the reference tests "box_dist * max_err < max_key()" after the near subtree; the k-th key only ever
+        // shrinks, so a far child failing now fails then too and need not be remembered
+        if (fbd * max_err < key[KMAX - 1]) {
+          if (sp < ANN_LDS_STACK) { s_ref[sp][tx] = far; s_bd[sp][tx] = fbd; }
+          else { spill_ref[(size_t)(sp - ANN_LDS_STACK) * T + tid] = far; spill_bd[(size_t)(sp - ANN_LDS_STACK) * T + tid] = fbd; }
+          sp++;
+        }
+        cur = low ? c0 : c1;
+      }
+      {                                              // ANNkd_leaf::ann_search, one point (kd_search.cpp:177-210)
+        const uint32_t pos = cur & A_VAL;
+        const KdPoint p = pts[pos];
+        const double t0 = q[0] - p.x, t1 = q[1] - p.y, t2 = q[2] - p.z;
+        const double dist = (t0 * t0 + t1 * t1) + t2 * t2;
+        if (!(dist > key[KMAX - 1])) {               // no partial sum exceeded the k-th key
+          // ANNmin_k::insert (pr_queue_k.h:100-114): behind every key <= dist, the last one drops out
+          double ck = dist;
+          uint32_t ci = pos;
+          bool shifting = false;
+#pragma unroll
+          for (int j = 0; j < KMAX; j++) {
+            shifting = shifting || (key[j] > ck);
+            if (shifting) {
+              const double tk = key[j]; key[j] = ck; ck = tk;
+              const uint32_t ti = info[j]; info[j] = ci; ci = ti;
+            }
+          }
+        }
+      }
+      bool done = false;
+      for (;;) {
+        if (sp == 0) { done = true; break; }
+        sp--;
+        if (sp < ANN_LDS_STACK) { cur = s_ref[sp][tx]; bd = s_bd[sp][tx]; }
+        else { cur = spill_ref[(size_t)(sp - ANN_LDS_STACK) * T + tid]; bd = spill_bd[(size_t)(sp - ANN_LDS_STACK) * T + tid]; }
+        if (bd * max_err < key[KMAX - 1]) break;
+      }
+      if (done) break;
+    }
+    // ---- normals.cc:64-105 ----
+    double mean[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < KMAX; j++)
+      if (j >= KMAX - k) {
+        const KdPoint p = pts[info[j]];
+        mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
+        if (knn_out) knn_out[(size_t)qp.orig * k + (j - (KMAX - k))] = p.orig;
+      }
+    mean[0] /= k; mean[1] /= k; mean[2] /= k;
+    // A << 1.0 / k * X.t() * X: (s * X^T) * X summed in list order, element (c, r), c <= r, kept
+    const double sc = 1.0 / k;
+    double z[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int j = 0; j < KMAX; j++)
+      if (j >= KMAX - k) {
+        const KdPoint p = pts[info[j]];
+        const double x[3] = {p.x - mean[0], p.y - mean[1], p.z - mean[2]};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c <= r; c++) z[r][c] += (sc * x[c]) * x[r];
+      }
+    z[0][1] = z[1][0]; z[0][2] = z[2][0]; z[1][2] = z[2][1];
+    double D[3];
+    eigen3_newmat(z, D);
+    double nv[3] = {z[0][0], z[1][0], z[2][0]};
+    double pv[3] = {q[0] - rx, q[1] - ry, q[2] - rz};
+    const double pl = 1.0 / __dsqrt_rn((pv[0] * pv[0] + pv[1] * pv[1]) + pv[2] * pv[2]);   // "v / norm" is v * (1 / norm) in newmat
+    pv[0] *= pl; pv[1] *= pl; pv[2] *= pl;
+    const double angle = (nv[0] * pv[0] + nv[1] * pv[1]) + nv[2] * pv[2];
+    if (angle < 0) { nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0; }
+    const double nl = 1.0 / __dsqrt_rn((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+    normals[3 * (size_t)qp.orig] = nv[0] * nl;
+    normals[3 * (size_t)qp.orig + 1] = nv[1] * nl;
+    normals[3 * (size_t)qp.orig + 2] = nv[2] * nl;
+  }
+}
+
+uint32_t ann_search_threads(size_t n)
+{
+  const size_t blocks = (n + 255) / 256;
+  return (uint32_t)((blocks < 1024 ? blocks : 1024) * 256);
+}
+size_t ann_spill_entries(size_t n, uint32_t max_depth)
+{
+  const size_t d = (max_depth + 1 > ANN_LDS_STACK) ? (max_depth + 1 - ANN_LDS_STACK) : 0;
+  return d * (size_t)ann_search_threads(n);
+}
+
+hipError_t launch_ann_normals(const AnnNode* nodes, uint32_t root_ref, const KdPoint* pts, size_t n, int k, double eps,
+                              const double* d_bb, const double rPos[3], uint32_t* spill_ref, double* spill_bd,
+                              uint32_t max_depth, double* d_normals, int32_t* d_knn, hipStream_t s)
+{
+  const uint32_t T = ann_search_threads(n);
+  const double max_err = (1.0 + eps) * (1.0 + eps);    // ANN_POW(1.0 + eps), kd_search.cpp:108
+  const dim3 grid(T / 256), block(256);
+#define ANN_LAUNCH(KM)                                                                                               \
+  hipLaunchKernelGGL(k_ann_normals<KM>, grid, block, 0, s, nodes, root_ref, pts, (uint32_t)n, k, max_err, d_bb, rPos[0], \
+                     rPos[1], rPos[2], spill_ref, spill_bd, max_depth, d_normals, d_knn)
+  if (k <= 10) ANN_LAUNCH(10);
+  else if (k <= 16) ANN_LAUNCH(16);
+  else if (k <= 32) ANN_LAUNCH(32);
+  else return hipErrorInvalidValue;
+#undef ANN_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace tdtk

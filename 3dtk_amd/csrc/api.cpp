@@ -846,6 +846,93 @@ int tdtk_reduce_octree(const double* xyz, size_t n, double voxel_size, int devic
   return TDTK_OK;
 }
 
+// ---- normals (Scan::calcNormals -> calculateNormalsApxKNN, scan.cc:398-427, normals.cc:35-111) ----------------
+// d_xyz: [n][3] in the caller's order (the ANN tree starts from the identity permutation, kd_tree.cpp:259-262);
+// d_normals [n][3] and d_knn (nullable, [n][k]) come back in the caller's order.
+static int normals_on_device(Ctx* c, const double* d_xyz, size_t n, int k, const double rPos[3], double eps,
+                             double* d_normals, int32_t* d_knn)
+{
+  int rc;
+  hipStream_t s = c->stream;
+  if ((rc = c->ws[WS_ARENA].ensure(ann_build_arena_bytes(n)))) return rc;
+  if ((rc = c->ws[WS_QX].ensure((n ? n : 1) * sizeof(AnnNode)))) return rc;
+  if ((rc = c->ws[WS_QY].ensure(n * sizeof(KdPoint)))) return rc;
+  if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
+  AnnNode* nodes = c->ws[WS_QX].as<AnnNode>();
+  KdPoint* pts = c->ws[WS_QY].as<KdPoint>();
+  double* d_bb = c->ws[WS_BOX].as<double>();
+  AnnBuildResult r = ann_build_tree(d_xyz, n, c->ws[WS_ARENA].p, nodes, pts, d_bb, s);
+  if (r.err != hipSuccess) {
+    if (r.degenerate) { set_error("non-finite coordinates"); return TDTK_EINVAL; }
+    set_error(std::string("ann_build_tree: ") + hipGetErrorString(r.err));
+    return TDTK_EDEVICE;
+  }
+  const size_t spill = ann_spill_entries(n, r.max_depth);
+  if ((rc = c->ws[WS_OVF_REF].ensure((spill + 1) * sizeof(uint32_t)))) return rc;
+  if ((rc = c->ws[WS_OVF_M2].ensure((spill + 1) * sizeof(double)))) return rc;
+  HIPCHK(launch_ann_normals(nodes, r.root_ref, pts, n, k, eps, d_bb, rPos, c->ws[WS_OVF_REF].as<uint32_t>(),
+                            c->ws[WS_OVF_M2].as<double>(), r.max_depth, d_normals, d_knn, s));
+  return TDTK_OK;
+}
+
+static int normals_check_args(size_t n, int k, const double* rPos, double eps)
+{
+  if (!rPos) { set_error("rPos is NULL"); return TDTK_EINVAL; }
+  if (n == 0) { set_error("Could not calculate normals, XYZ data is empty"); return TDTK_EINVAL; }   // scan.cc:408-409
+  if (k < 1 || k > 32) { set_error("k must be in 1..32"); return TDTK_EINVAL; }
+  if ((size_t)k > n) { set_error("Requesting more near neighbors than data points"); return TDTK_EINVAL; }   // kd_search.cpp:103-105
+  if (!(eps >= 0) || !std::isfinite(eps)) { set_error("eps must be >= 0"); return TDTK_EINVAL; }
+  if (n >= (1ull << 29)) { set_error("scan too large (29-bit point positions)"); return TDTK_EINVAL; }
+  return TDTK_OK;
+}
+
+int tdtk_normals_apx_knn(const double* xyz, size_t n, int k, const double rPos[3], double eps, int device,
+                         double* normals_out, int32_t* knn_out)
+{
+  int rc;
+  if ((rc = normals_check_args(n, k, rPos, eps))) return rc;
+  if (!xyz || !normals_out) { set_error("NULL points"); return TDTK_EINVAL; }
+  Ctx* c;
+  if ((rc = get_ctx(device, &c))) return rc;
+  hipStream_t s = c->stream;
+  if ((rc = c->ws[WS_TMPA].ensure(6 * n * sizeof(double)))) return rc;   // points in | normals out
+  if (knn_out && (rc = c->ws[WS_IDX].ensure(n * (size_t)k * sizeof(int32_t)))) return rc;
+  double* d_in = c->ws[WS_TMPA].as<double>();
+  double* d_nrm = d_in + 3 * n;
+  int32_t* d_knn = knn_out ? c->ws[WS_IDX].as<int32_t>() : nullptr;
+  HIPCHK(hipMemcpyAsync(d_in, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
+  if ((rc = normals_on_device(c, d_in, n, k, rPos, eps, d_nrm, d_knn))) return rc;
+  HIPCHK(hipMemcpyAsync(normals_out, d_nrm, 3 * n * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (knn_out) HIPCHK(hipMemcpyAsync(knn_out, d_knn, n * (size_t)k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return TDTK_OK;
+}
+
+int tdtk_scan_calc_normals(tdtk_scan* sc, int k, const double rPos[3], double eps)
+{
+  if (!sc) { set_error("NULL argument"); return TDTK_EINVAL; }
+  int rc;
+  if ((rc = normals_check_args(sc->N, k, rPos, eps))) return rc;
+  Ctx* c;
+  if ((rc = get_ctx(sc->device, &c))) return rc;
+  hipStream_t s = c->stream;
+  const size_t n = sc->N;
+  if ((rc = c->ws[WS_TMPA].ensure(6 * n * sizeof(double)))) return rc;
+  double* d_in = c->ws[WS_TMPA].as<double>();
+  double* d_nrm = d_in + 3 * n;
+  // the resident points back in the caller's order, the normals back into the resident order
+  HIPCHK(launch_unsort_aos(sc->x, sc->y, sc->z, sc->d_order, n, d_in, s));
+  if ((rc = normals_on_device(c, d_in, n, k, rPos, eps, d_nrm, nullptr))) return rc;
+  if (!sc->nx) {
+    HIPCHK(hipMalloc((void**)&sc->nx, n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&sc->ny, n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&sc->nz, n * sizeof(double)));
+  }
+  HIPCHK(launch_gather_soa(d_nrm, reinterpret_cast<const uint32_t*>(sc->d_order), n, sc->nx, sc->ny, sc->nz, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return TDTK_OK;
+}
+
 // ---- resident scan ---------------------------------------------------------------------
 int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device, tdtk_scan** out)
 {

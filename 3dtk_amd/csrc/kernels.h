@@ -121,6 +121,25 @@ struct DevBuildResult {
 size_t device_build_arena_bytes(size_t M);
 DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s);
 
+// ---- normals: the ANN kd-tree (one point per leaf, sliding midpoint) + approximate k-NN + PCA (ann.hip) -------
+struct AnnNode {          // 32 B: one splitting node (ANNkd_split: cut_val, cd_bnds[2], child[2], cut_dim)
+  double cut_val, lo, hi;
+  uint32_t c0, c1;        // child references: bit 29 = leaf, bits 0..28 = node index / point position; c0 bits 30..31 = cut_dim
+};
+struct AnnBuildResult {
+  hipError_t err;
+  bool degenerate;
+  uint32_t root_ref, max_depth, levels;
+};
+size_t ann_build_arena_bytes(size_t M);
+AnnBuildResult ann_build_tree(const double* d_xyz, size_t M, void* arena, AnnNode* nodes, KdPoint* pts, double* bb,
+                              hipStream_t s);
+uint32_t ann_search_threads(size_t n);
+size_t ann_spill_entries(size_t n, uint32_t max_depth);
+hipError_t launch_ann_normals(const AnnNode* nodes, uint32_t root_ref, const KdPoint* pts, size_t n, int k, double eps,
+                              const double* d_bb, const double rPos[3], uint32_t* spill_ref, double* spill_bd,
+                              uint32_t max_depth, double* d_normals, int32_t* d_knn, hipStream_t s);
+
 hipError_t launch_pp_error(const AccumArgs& a, uint32_t grid, double scale, double* d_partial, double* d_out, hipStream_t s);
 hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s);
 hipError_t launch_pair_list(const PairListArgs& a, int pmode, hipStream_t s);

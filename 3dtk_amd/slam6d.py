@@ -323,6 +323,19 @@ class Scan:
                 pass
             self._h = None
 
+    K_NEIGHBOURS = 10     # scan.cc:418
+
+    def calcNormals(self):
+        """Scan::calcNormals (scan.cc:398-427): normals of the scan-local points from their K_NEIGHBOURS
+        approximate neighbours (eps = 1.0), oriented with get_rPos().  Before the scan goes resident they become its
+        "normal" array (transformed with the points afterwards, basicScan.cc:730-737); on a resident scan the
+        normals are recomputed from the points where they currently are."""
+        if self._h is None:
+            self._local_n = calculateNormalsApxKNN(self._local, self.K_NEIGHBOURS, self.rPos, 1.0, self.device)
+        else:
+            check(lib().tdtk_scan_calc_normals(self._h, self.K_NEIGHBOURS, dptr(self.rPos), 1.0))
+        return self
+
     # accessors named as in scan.h
     def get_transMat(self): return self.transMat
     def get_transMatOrg(self): return self.transMatOrg
@@ -490,6 +503,17 @@ def calcReducedPoints(xyz, voxelSize, device=0):
     m = C.c_size_t(0)
     check(lib().tdtk_reduce_octree(dptr(xyz), len(xyz), float(voxelSize), int(device), dptr(out), C.byref(m)))
     return out[:m.value].copy()
+
+
+def calculateNormalsApxKNN(points, k, rPos, eps, device=0, want_knn=False):
+    """normals.cc:35-111 (calculateNormalsApxKNN(normals, points, k, rPos, eps)) on the device: returns the
+    [n][3] normals (and, with want_knn, the [n][k] neighbour lists of the ANN search, nearest first)."""
+    xyz = f64(points).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    knn = np.empty((len(xyz), int(k)), np.int32) if want_knn else None
+    check(lib().tdtk_normals_apx_knn(dptr(xyz), len(xyz), int(k), dptr(f64(rPos)), float(eps), int(device),
+                                     dptr(out), iptr(knn)))
+    return (out, knn) if want_knn else out
 
 
 def read_pose(path):

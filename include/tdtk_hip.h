@@ -301,6 +301,21 @@ int tdtk_invert(const double* A, int n, double* Ainv);
 int tdtk_reduce_octree(const double* xyz, size_t n, double voxel_size, int device, double* out_xyz,
                        size_t* n_out);
 
+/* ---- point normals, "-z" / "-a 10" / pairing modes 1 and 2: replaces Scan::calcNormals
+ * (src/slam6d/scan.cc:398-427) = calculateNormalsApxKNN(normals, points, k, rPos, eps)
+ * (src/slam6d/normals.cc:35-111; the reference calls it with k = 10, eps = 1.0).  For every point: its k
+ * (1+eps)-approximate nearest neighbours exactly as the ANN 1.1.1 kd-tree (bucket size 1, sliding midpoint)
+ * returns them -- the same tree is built and walked in the same order on the device --, their mean and
+ * covariance, the eigenvector of the smallest eigenvalue (newmat tred2/tql2 arithmetic), flipped so that it
+ * points away from rPos... i.e. n . (p - rPos) >= 0, normalised.  Lists and normals are bit-identical to the
+ * library's.  normals_out [n][3]; knn_out (nullable) [n][k] neighbour indices in list order (nearest first).
+ * Errors: n == 0 ("XYZ data is empty", scan.cc:408), k > n (ANN aborts: kd_search.cpp:103), k > 32,
+ * non-finite coordinates.                                                                     */
+int tdtk_normals_apx_knn(const double* xyz, size_t n, int k, const double rPos[3], double eps, int device,
+                         double* normals_out, int32_t* knn_out);
+/* the same for a resident scan, from its current points; the result becomes its "normal reduced" */
+int tdtk_scan_calc_normals(tdtk_scan* s, int k, const double rPos[3], double eps);
+
 /* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
  * traversal counters of the last counting run.                                          */
 int tdtk_last_kernel_ms(double* nn_ms);

@@ -941,3 +941,120 @@ def test_match_graph6d_automatic(tdtk, orc, gpu):
     for s, o in zip(S, O):
         assert np.abs(s.get_rPos() - o.rPos).max() < 1e-5 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-7
         assert np.abs(s.get_xyz_reduced() - o.xyz).max() < 1e-4
+
+
+# ---- normals: Scan::calcNormals = calculateNormalsApxKNN(k = 10, eps = 1.0) -----------------------------
+def _normal_clouds():
+    rng = np.random.default_rng(5)
+    c = dict(_clouds())
+    p = rng.uniform(-300, 300, (40000, 3)); p[:, 2] = 40.0 + 0.1 * p[:, 0] + rng.normal(0, 0.5, len(p))
+    c["noisy_plane"] = p
+    # a room seen from inside: four walls and a floor, duplicates where they meet
+    u, v = rng.uniform(-500, 500, 12000), rng.uniform(0, 250, 12000)
+    walls = [np.stack([u[:3000], np.full(3000, 500.0), v[:3000]], 1), np.stack([u[3000:6000], np.full(3000, -500.0), v[3000:6000]], 1),
+             np.stack([np.full(3000, 500.0), u[6000:9000], v[6000:9000]], 1), np.stack([np.full(3000, -500.0), u[9000:], v[9000:]], 1),
+             np.stack([u[:4000], u[4000:8000], np.zeros(4000)], 1)]
+    c["room"] = np.concatenate(walls) + rng.normal(0, 0.3, (16000, 3))
+    c["eleven"] = rng.uniform(-1, 1, (11, 3))
+    c["exp_line"] = np.outer(2.0 ** np.arange(60), [1.0, 0.5, 0.25])     # every split slides: a 59-deep comb
+    return c
+
+
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "grid", "line", "noisy_plane", "room",
+                                  "eleven", "exp_line"])
+def test_normals_equal_oracle(tdtk, orc, gpu, name):
+    """tdtk_normals_apx_knn == the restatement of calculateNormalsApxKNN (itself bit-identical to the vendored
+    ANN + newmat): neighbour lists in list order and normals, bit for bit."""
+    pts = _normal_clouds()[name]
+    rPos = np.array([3.0, -2.0, 10.0])
+    want, wknn = orc.normals_apx_knn(pts, 10, rPos, 1.0, want_knn=True)
+    got, gknn = tdtk.calculateNormalsApxKNN(pts, 10, rPos, 1.0, want_knn=True)
+    assert np.array_equal(gknn, wknn)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("k,eps", [(1, 1.0), (5, 0.3), (10, 0.0), (16, 2.0), (32, 1.0)])
+def test_normals_other_k_eps(tdtk, orc, gpu, k, eps):
+    pts = _normal_clouds()["room"][:6000]
+    want, wknn = orc.normals_apx_knn(pts, k, [0.0, 0.0, 100.0], eps, want_knn=True)
+    got, gknn = tdtk.calculateNormalsApxKNN(pts, k, [0.0, 0.0, 100.0], eps, want_knn=True)
+    assert np.array_equal(gknn, wknn) and np.array_equal(got, want, equal_nan=True)
+
+
+def test_normals_golden_and_reference_library(tdtk, orc, gpu):
+    """K7 fixture (vendored ANN + newmat, generated in the build container) and, where oracle/_ref travelled,
+    the library itself."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    z = np.load(os.path.join(G, "k7_ann_normals.npz"))
+    for tag, pts in mg.k7_clouds().items():
+        got, knn = tdtk.calculateNormalsApxKNN(pts, 10, [0.0, 0.0, 0.0], 1.0, want_knn=True)
+        assert np.array_equal(knn, z[tag + "_knn"]) and np.array_equal(got, z[tag + "_normals"])
+        if orc.have_ref():
+            assert np.array_equal(got, orc.normals_apx_knn(pts, 10, [0.0, 0.0, 0.0], 1.0, "ref"))
+
+
+def test_normals_dat_scan_and_resident(tdtk, orc, gpu):
+    """A whole bundled scan (81 360 points); Scan.calcNormals before going resident == the oracle's normals
+    moved with the points; on a resident scan == the oracle on the downloaded points."""
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    pts = z["scan001"]
+    pose = z["pose001"]
+    want = orc.normals_apx_knn(pts, 10, pose[:3], 1.0)
+    sc = tdtk.Scan(pose[:3], pose[3:], pts).calcNormals()
+    assert np.array_equal(sc._local_n, want)
+    # resident: points have moved to the global frame; recompute there
+    h = sc.handle
+    xyz = np.empty_like(pts); nrm = np.empty_like(pts)
+    from importlib import import_module
+    cap = import_module("3dtk_amd._capi")
+    cap.check(cap.lib().tdtk_scan_download(h, cap.dptr(xyz), cap.dptr(nrm)))
+    moved = want.copy(); orc.transform_normals(sc.transMatOrg, moved)
+    assert np.allclose(nrm, moved, rtol=0, atol=1e-15)
+    sc.calcNormals()
+    cap.check(cap.lib().tdtk_scan_download(h, cap.dptr(xyz), cap.dptr(nrm)))
+    assert np.array_equal(nrm, orc.normals_apx_knn(xyz, 10, sc.rPos, 1.0))
+
+
+def test_normals_feed_point_to_plane_pairs(tdtk, orc, gpu):
+    """the computed normals drive pairing mode 2 and the NAPX minimizer (-a 10 -z) like supplied ones"""
+    rng = np.random.default_rng(8)
+    m = _normal_clouds()["room"]
+    T = tdtk.EulerToMatrix4([2.0, -1.0, 0.5], [0.01, -0.02, 0.015])
+    d = m[rng.permutation(len(m))[:8000]] + rng.normal(0, 0.05, (8000, 3))
+    nrm = tdtk.calculateNormalsApxKNN(d, 10, [0.0, 0.0, 100.0], 1.0)
+    assert np.array_equal(nrm, orc.normals_apx_knn(d, 10, [0.0, 0.0, 100.0], 1.0))
+    kd, Tm = tdtk.KDtree(m), orc.Tree(m)
+    r = kd.getPtPairs(T, d, normal_r=nrm, pairing_mode=2, max_dist_match2=400.0)
+    o = Tm.get_pt_pairs(T, d, nrm, 0, len(d), 2, 400.0)
+    assert r["n"] == o["n"] and np.array_equal(r["idx"], o["idx"])
+
+
+def test_normals_errors(tdtk, gpu):
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calculateNormalsApxKNN(np.zeros((0, 3)), 10, [0, 0, 0], 1.0)           # scan.cc:408
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calculateNormalsApxKNN(np.zeros((5, 3)), 10, [0, 0, 0], 1.0)           # k > n: the library aborts
+    bad = np.random.default_rng(0).uniform(-1, 1, (200, 3)); bad[17, 1] = np.nan
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calculateNormalsApxKNN(bad, 10, [0, 0, 0], 1.0)
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calculateNormalsApxKNN(np.zeros((50, 3)), 33, [0, 0, 0], 1.0)
+
+
+def test_normals_full_size(tdtk, orc, gpu):
+    """1M points (BASELINE configs' scan size): list hash and normals against the oracle on a 1M cloud would take
+    the CPU minutes, so: the oracle on a 200k sub-cloud bit for bit, and at 1M the size-independent properties --
+    unit length, orientation towards the sensor, self as first neighbour, normals close to the plane's."""
+    rng = np.random.default_rng(21)
+    p = rng.uniform(-1000, 1000, (1000000, 3)); p[:, 2] = 0.05 * p[:, 0] + rng.normal(0, 1.0, len(p))
+    sub = p[:200000]
+    want, wk = orc.normals_apx_knn(sub, 10, [0.0, 0.0, 500.0], 1.0, want_knn=True)
+    got, gk = tdtk.calculateNormalsApxKNN(sub, 10, [0.0, 0.0, 500.0], 1.0, want_knn=True)
+    assert np.array_equal(gk, wk) and np.array_equal(got, want)
+    n, knn = tdtk.calculateNormalsApxKNN(p, 10, [0.0, 0.0, 500.0], 1.0, want_knn=True)
+    assert np.abs(np.linalg.norm(n, axis=1) - 1.0).max() < 1e-14
+    assert (np.einsum("ij,ij->i", n, p - np.array([0.0, 0.0, 500.0])) >= 0).all()
+    assert np.array_equal(knn[:, 0], np.arange(len(p)))
+    assert (np.abs(n[:, 2]) > 0.5).mean() > 0.95        # a slightly tilted plane, noise ~ half the point spacing
