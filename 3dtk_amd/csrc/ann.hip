@@ -46,6 +46,9 @@ struct ASeg {
   double blo[3], bhi[3];   // the cell (kd_tree.cpp:346-357), not the points' own bounding box
 };
 struct AMeas { double mn[3], mx[3]; };
+struct AMeasU { unsigned long long mn[3], mx[3]; };   // order-preserving integer images of the doubles (enc_f64)
+#define ENC_PINF 0xFFF0000000000000ull   // enc(+inf)
+#define ENC_NINF 0x000FFFFFFFFFFFFFull   // enc(-inf)
 struct ADec { double cv; uint32_t cd, mode, n_lo, slot0, slot1, pad; };   // mode 0 midpoint, 1 slid to min, 2 slid to max
 
 static __device__ __forceinline__ double coord_of(const double* __restrict__ cx, const double* __restrict__ cy,
@@ -106,8 +109,10 @@ __global__ void k_ann_init(const double* __restrict__ xyz, uint32_t M, uint32_t*
 
 // the root cell = annEnclRect of all points (kd_tree.cpp:381-385); small[4] counts the small cells
 __global__ void k_ann_root(const double* __restrict__ box, uint32_t M, ASeg* __restrict__ segs,
-                           ASeg* __restrict__ small_list, uint32_t* __restrict__ small, double* __restrict__ bb)
+                           ASeg* __restrict__ small_list, uint32_t* __restrict__ small, double* __restrict__ bb,
+                           AMeasU* __restrict__ meas)
 {
+  for (int d = 0; d < 3; d++) { meas[0].mn[d] = ENC_PINF; meas[0].mx[d] = ENC_NINF; }
   ASeg r;
   r.start = 0; r.n = M; r.parent = -1; r.side = 0; r.depth = 0; r.pad = 0;
   for (int d = 0; d < 3; d++) { r.blo[d] = box[d]; r.bhi[d] = box[3 + d]; bb[d] = box[d]; bb[3 + d] = box[3 + d]; }
@@ -116,41 +121,106 @@ __global__ void k_ann_root(const double* __restrict__ box, uint32_t M, ASeg* __r
   else small[0] = A_LEAF | 0u;     // a single point: the root is its leaf
 }
 
-// one wavefront per cell: min / max of its points along the three axes
-__global__ void __launch_bounds__(256) k_ann_measure(const ASeg* __restrict__ segs, uint32_t nseg,
-                                                     const double* __restrict__ cx, const double* __restrict__ cy,
-                                                     const double* __restrict__ cz, AMeas* __restrict__ out)
+// Point min / max of every cell of the level.  A wavefront takes 64 consecutive positions; cells are contiguous
+// runs of positions (at least ANN_SMALL + 1 long), so the wave sees at most a few of them: one reduction and six
+// atomics per run.  min / max do not depend on the order, unlike the centroid sum of the search tree's builder.
+static __device__ __forceinline__ unsigned long long enc_f64(double v)
 {
-  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
-  const uint32_t lane = threadIdx.x & (WAVE - 1);
-  if (w >= nseg) return;
-  const uint32_t s = __builtin_amdgcn_readfirstlane(segs[w].start);
-  const uint32_t n = __builtin_amdgcn_readfirstlane(segs[w].n);
-  double mn[3] = {cx[s], cy[s], cz[s]}, mx[3] = {mn[0], mn[1], mn[2]};
-  for (uint32_t i = lane; i < n; i += WAVE) {
-    const double v[3] = {cx[s + i], cy[s + i], cz[s + i]};
-#pragma unroll
-    for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      double t;
-      t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
-      t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
-    }
-  if (lane == 0)
-    for (int d = 0; d < 3; d++) { out[w].mn[d] = mn[d]; out[w].mx[d] = mx[d]; }
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static __device__ __forceinline__ double dec_f64(unsigned long long e)
+{
+  return __longlong_as_double((long long)((e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e));
 }
 
-__global__ void k_ann_decide(const ASeg* __restrict__ segs, uint32_t nseg, const AMeas* __restrict__ meas,
+#define MEAS_ITERS 16   // a wavefront covers 64 * MEAS_ITERS consecutive positions
+
+static __device__ __forceinline__ void meas_flush(AMeasU* __restrict__ out, uint32_t sg, const double* mn, const double* mx)
+{
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    atomicMin(&out[sg].mn[d], enc_f64(mn[d]));
+    atomicMax(&out[sg].mx[d], enc_f64(mx[d]));
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict__ seg_of, uint32_t M,
+                                                     const double* __restrict__ cx, const double* __restrict__ cy,
+                                                     const double* __restrict__ cz, AMeasU* __restrict__ out)
+{
+  __shared__ uint32_t s_seg[4];
+  __shared__ double s_mn[4][3], s_mx[4][3];
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const uint32_t base = (blockIdx.x * 4u + wv) * (WAVE * MEAS_ITERS);
+  // the run the wave is in the middle of (wave-uniform): merged with what follows while the cell stays the same
+  uint32_t pend = NOSEG;
+  double pmn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, pmx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    const uint32_t sg = (p < M) ? seg_of[p] : NOSEG;
+    double v[3] = {0, 0, 0};
+    if (sg != NOSEG) { v[0] = cx[p]; v[1] = cy[p]; v[2] = cz[p]; }
+    unsigned long long todo = __ballot(sg != NOSEG);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t cur = __shfl(sg, leader, WAVE);
+      const bool mine = (sg == cur);
+      double mn[3], mx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) { mn[d] = mine ? v[d] : HUGE_VAL; mx[d] = mine ? v[d] : -HUGE_VAL; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          double t;
+          t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
+          t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
+        }
+      if (cur != pend) {
+        if (pend != NOSEG && lane == 0) meas_flush(out, pend, pmn, pmx);
+        pend = cur;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { pmn[d] = mn[d]; pmx[d] = mx[d]; }
+      } else {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { pmn[d] = (mn[d] < pmn[d]) ? mn[d] : pmn[d]; pmx[d] = (pmx[d] < mx[d]) ? mx[d] : pmx[d]; }
+      }
+      todo &= ~__ballot(mine);
+    }
+  }
+  // the four waves of the block cover adjacent ranges: merge equal cells before touching memory
+  if (lane == 0) {
+    s_seg[wv] = pend;
+    for (int d = 0; d < 3; d++) { s_mn[wv][d] = pmn[d]; s_mx[wv][d] = pmx[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t cur = NOSEG;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int w = 0; w < 4; w++) {
+      const uint32_t sg = s_seg[w];
+      if (sg == NOSEG) continue;
+      if (sg != cur) {
+        if (cur != NOSEG) meas_flush(out, cur, mn, mx);
+        cur = sg;
+        for (int d = 0; d < 3; d++) { mn[d] = s_mn[w][d]; mx[d] = s_mx[w][d]; }
+      } else {
+        for (int d = 0; d < 3; d++) { mn[d] = (s_mn[w][d] < mn[d]) ? s_mn[w][d] : mn[d]; mx[d] = (mx[d] < s_mx[w][d]) ? s_mx[w][d] : mx[d]; }
+      }
+    }
+    if (cur != NOSEG) meas_flush(out, cur, mn, mx);
+  }
+}
+
+__global__ void k_ann_decide(const ASeg* __restrict__ segs, uint32_t nseg, const AMeasU* __restrict__ meas,
                              ADec* __restrict__ dec)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
   const ASeg sg = segs[i];
-  const AMeas m = meas[i];
+  AMeas m;
+  for (int d = 0; d < 3; d++) { m.mn[d] = dec_f64(meas[i].mn[d]); m.mx[d] = dec_f64(meas[i].mx[d]); }
   ADec d;
   sl_midpt_rule(sg.blo, sg.bhi, m.mn, m.mx, d.cd, d.cv, d.mode);
   d.n_lo = 0; d.slot0 = d.slot1 = NOSEG; d.pad = 0;
@@ -262,7 +332,7 @@ static __device__ __forceinline__ void ann_hook(AnnNode* __restrict__ nodes, uin
 __global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADec* __restrict__ dec,
                                const uint32_t* __restrict__ br1, const uint32_t* __restrict__ br2,
                                AnnNode* __restrict__ nodes, ASeg* __restrict__ next, ASeg* __restrict__ small_list,
-                               uint32_t* __restrict__ small)
+                               uint32_t* __restrict__ small, AMeasU* __restrict__ meas_next)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
@@ -292,6 +362,7 @@ __global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADe
     } else {
       slot[side] = atomicAdd(small + 3, 1u);
       next[slot[side]] = ch;
+      for (int a = 0; a < 3; a++) { meas_next[slot[side]].mn[a] = ENC_PINF; meas_next[slot[side]].mx[a] = ENC_NINF; }
     }
   }
   nodes[me] = nd;     // children that are cells hook themselves in later (they run after this kernel)
@@ -435,9 +506,10 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1);                    // 5 f 6 F 7 LR 8 AB
   take(4 * n1); take(4 * n1);                                                // 9 posL 10 posR
   take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nsmall);   // 11 segA 12 segB 13 small cells
-  take(sizeof(AMeas) * nlarge); take(sizeof(ADec) * nlarge); take(4 * nlarge); take(4 * nlarge);   // 14 meas 15 dec 16 br1 17 br2
+  take(sizeof(AMeasU) * nlarge); take(sizeof(ADec) * nlarge); take(4 * nlarge); take(4 * nlarge);   // 14 meas 15 dec 16 br1 17 br2
   take(scan_tmp + 256); take(256);                                           // 18 tmp 19 small
   take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
+  take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
@@ -461,7 +533,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   unsigned long long *LR = (unsigned long long*)(arena + O[7]), *AB = (unsigned long long*)(arena + O[8]);
   uint32_t *posL = (uint32_t*)(arena + O[9]), *posR = (uint32_t*)(arena + O[10]);
   ASeg *segs = (ASeg*)(arena + O[11]), *next = (ASeg*)(arena + O[12]), *small_list = (ASeg*)(arena + O[13]);
-  AMeas* meas = (AMeas*)(arena + O[14]); ADec* dec = (ADec*)(arena + O[15]);
+  AMeasU* meas = (AMeasU*)(arena + O[14]); AMeasU* meas_next = (AMeasU*)(arena + O[22]); ADec* dec = (ADec*)(arena + O[15]);
   uint32_t *br1 = (uint32_t*)(arena + O[16]), *br2 = (uint32_t*)(arena + O[17]);
   void* tmp = arena + O[18];
   uint32_t* small = (uint32_t*)(arena + O[19]);
@@ -470,7 +542,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   ACHK(hipMemsetAsync(small, 0, 256, s));
   hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2);
   ACHK(launch_bbox(d_xyz, M, partial, box, s));
-  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb);
+  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas);
   uint32_t nseg = (M > ANN_SMALL) ? 1u : 0u, level = 0;
   {
     uint32_t bad = 0;
@@ -480,7 +552,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   }
   while (nseg > 0) {
     ++level;
-    hipLaunchKernelGGL(k_ann_measure, dim3(cdiv((size_t)nseg * WAVE, 256)), dim3(256), 0, s, segs, nseg, cx, cy, cz, meas);
+    hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas);
     hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, dec);
     ACHK(hipMemsetAsync(small + 3, 0, 4, s));
     // the library's first Hoare pass, then its second one on what lies right of br1
@@ -504,7 +576,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
       hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
     }
     hipLaunchKernelGGL(k_ann_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, dec, br1, br2, nodes, next,
-                       small_list, small);
+                       small_list, small, meas_next);
     hipLaunchKernelGGL(k_ann_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, dec, M, seg_of);
     uint32_t h[2] = {0, 0};   // err, cells of the next level
     ACHK(hipMemcpyAsync(h, small + 2, 8, hipMemcpyDeviceToHost, s));
@@ -512,6 +584,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
     if (h[0] || level > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
     nseg = h[1];
     ASeg* t = segs; segs = next; next = t;
+    AMeasU* tm = meas; meas = meas_next; meas_next = tm;
   }
   uint32_t h_small[5];
   ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));

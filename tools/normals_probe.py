@@ -29,6 +29,14 @@ for r in range(a.reps):
     n = tdtk.calculateNormalsApxKNN(p, 10, rp, 1.0)
     dt = time.perf_counter() - t
     print("n=%d %s: %.2f ms  (%.3g points/s)" % (a.n, a.shape, 1e3 * dt, a.n / dt), flush=True)
+sc = tdtk.Scan([0, 0, 0], [0, 0, 0], p)
+_ = sc.handle
+sc.rPos = np.array(rp)
+for r in range(a.reps):
+    t = time.perf_counter()
+    sc.calcNormals()
+    dt = time.perf_counter() - t
+    print("resident scan n=%d: %.2f ms  (%.3g points/s)" % (a.n, 1e3 * dt, a.n / dt), flush=True)
 if a.cpu:
     from oracle import orc
     t = time.perf_counter()
