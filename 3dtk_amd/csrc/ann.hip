@@ -11,8 +11,8 @@
 //     wavefront, the library's two in-place Hoare passes (annPlaneSplit: "< cv | >= cv", then "== cv | > cv" on the
 //     right part) each as "the k-th misplaced element from the left swaps with the k-th misplaced from the right
 //     end" (prefix sums + one swap kernel), which reproduces the permutation and therefore which of several points
-//     ON the cutting plane goes to which side -- and, once a cell holds <= ANN_SMALL points, the rest of its
-//     subtree by ONE thread running the library's recursion as written.
+//     ON the cutting plane goes to which side -- and, once a cell holds <= 64 points, the rest of its subtree by
+//     ONE wavefront (a lane per point, ballots instead of prefix sums) without leaving the registers.
 //     Bucket size 1 means a cell of n points always yields n-1 splitting nodes: the node that separates positions
 //     p and p+1 of the final point order gets index p, so no node allocation or compaction is needed.
 //   search + PCA (kd_search.cpp:89-210, pr_queue_k.h:66-115, normals.cc:64-105)
@@ -32,7 +32,7 @@
 namespace tdtk {
 
 #define WAVE 64
-#define ANN_SMALL 32u         // cells up to this size are finished by one thread
+#define ANN_SMALL 64u         // cells up to this size are finished by one wavefront
 #define ANN_ERR 0.001         // kd_split.cpp:34
 #define A_LEAF 0x20000000u    // child reference: leaf flag | position (29 bits); c0 bits 30..31 = cutting dimension
 #define A_VAL 0x1FFFFFFFu
@@ -380,92 +380,125 @@ __global__ void k_ann_relabel(const ASeg* __restrict__ segs, const ADec* __restr
   seg_of[p] = ((p - segs[sg].start) < dec[sg].n_lo) ? dec[sg].slot0 : dec[sg].slot1;
 }
 
-// ---- small cells: the library's recursion as written, one thread per cell -----------------------
-struct AFrame { uint32_t start, n; int32_t parent; uint32_t side, depth; double blo[3], bhi[3]; };
+// ---- small cells: one wavefront per cell, one lane per point --------------------------------------
+// Once a cell holds <= 64 points its whole subtree is built by one wavefront without leaving the registers: every
+// lane carries one point and the description of the sub-cell it currently belongs to (a contiguous range of lanes,
+// its box, its parent), and all sub-cells of a level are split at once -- point min / max by a segmented shuffle
+// reduction, the two Hoare passes of annPlaneSplit by ballots (rank among the misplaced of the own sub-cell) and
+// one exchange through LDS to find the partner lane.  Same permutation, same nodes as the recursion.
+static __device__ __forceinline__ double sel3(const double* a, uint32_t d) { return (d == 0) ? a[0] : ((d == 1) ? a[1] : a[2]); }
+static __device__ __forceinline__ void put3(double* a, uint32_t d, double v) { if (d == 0) a[0] = v; else if (d == 1) a[1] = v; else a[2] = v; }
 
-__global__ void __launch_bounds__(64) k_ann_small(const ASeg* __restrict__ small_list, uint32_t nsmall,
-                                                  uint32_t* __restrict__ perm, double* __restrict__ cx,
-                                                  double* __restrict__ cy, double* __restrict__ cz,
-                                                  AnnNode* __restrict__ nodes, uint32_t* __restrict__ small)
+// the k-th misplaced lane from the left end of a sub-cell swaps with the k-th misplaced lane from its right end
+static __device__ __forceinline__ uint32_t hoare_partner(bool ML, bool MR, unsigned long long mask, uint32_t cs, uint32_t lane,
+                                                        volatile uint32_t* slotL, volatile uint32_t* slotR)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nsmall) return;
-  AFrame st[ANN_SMALL + 2];
-  int sp = 0;
-  {
-    const ASeg sg = small_list[i];
-    AFrame& f = st[sp++];
-    f.start = sg.start; f.n = sg.n; f.parent = sg.parent; f.side = sg.side; f.depth = sg.depth;
-    for (int d = 0; d < 3; d++) { f.blo[d] = sg.blo[d]; f.bhi[d] = sg.bhi[d]; }
-  }
+  const unsigned long long bML = __ballot(ML) & mask, bMR = __ballot(MR) & mask;
+  const unsigned long long below = (1ull << lane) - 1ull, above = (~0ull << lane) << 1;
+  const uint32_t kL = (uint32_t)__popcll(bML & below), kR = (uint32_t)__popcll(bMR & above);
+  if (ML) slotL[cs + kL] = lane;
+  if (MR) slotR[cs + kR] = lane;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t partner = lane;
+  if (ML) partner = slotR[cs + kL];
+  if (MR) partner = slotL[cs + kR];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return partner;
+}
+
+__global__ void __launch_bounds__(256) k_ann_small(const ASeg* __restrict__ small_list, uint32_t nsmall,
+                                                   uint32_t* __restrict__ perm, double* __restrict__ cx,
+                                                   double* __restrict__ cy, double* __restrict__ cz,
+                                                   AnnNode* __restrict__ nodes, uint32_t* __restrict__ small)
+{
+  __shared__ uint32_t s_slot[4][2][WAVE];
+  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (w >= nsmall) return;
+  volatile uint32_t* slotL = s_slot[threadIdx.x / WAVE][0];
+  volatile uint32_t* slotR = s_slot[threadIdx.x / WAVE][1];
+  const ASeg sg = small_list[w];
+  const uint32_t S = sg.start, N = sg.n;
+  bool active = lane < N;
+  double x = 0, y = 0, z = 0;
+  uint32_t pm = 0;
+  if (active) { x = cx[S + lane]; y = cy[S + lane]; z = cz[S + lane]; pm = perm[S + lane]; }
+  // the sub-cell this lane's point is in
+  uint32_t cs = 0, cn = N, side = sg.side, depth = sg.depth, pcd = 0;
+  int32_t parent = sg.parent;
+  bool top = true;
+  double blo[3] = {sg.blo[0], sg.blo[1], sg.blo[2]}, bhi[3] = {sg.bhi[0], sg.bhi[1], sg.bhi[2]};
   uint32_t maxdepth = 0;
-  while (sp > 0) {
-    const AFrame f = st[--sp];
-    const uint32_t s = f.start, n = f.n;
-    if (n == 1) {
-      ann_hook(nodes, small + 0, f.parent, f.side, A_LEAF | s);
-      maxdepth = (f.depth > maxdepth) ? f.depth : maxdepth;
-      continue;
+  for (;;) {
+    if (active && cn == 1) {                    // a leaf: hook it into its splitting node
+      const uint32_t ref = A_LEAF | (S + lane);
+      if (top) ann_hook(nodes, small + 0, parent, side, ref);
+      else if (side) nodes[parent].c1 = ref;
+      else nodes[parent].c0 = (pcd << 30) | ref;
+      maxdepth = (depth > maxdepth) ? depth : maxdepth;
+      active = false;
     }
-    // annSpread / annMinMax over the cell's points (kd_util.cpp:225-262)
-    double mn[3] = {cx[s], cy[s], cz[s]}, mx[3] = {mn[0], mn[1], mn[2]};
-    for (uint32_t k = 1; k < n; k++) {
-      const double v[3] = {cx[s + k], cy[s + k], cz[s + k]};
+    if (!__ballot(active)) break;
+    const unsigned long long mask = ((cn >= 64u) ? ~0ull : ((1ull << cn) - 1ull)) << cs;
+    const uint32_t rel = lane - cs, seg_end = cs + cn;
+    // annSpread / annMinMax of every sub-cell (kd_util.cpp:225-262): segmented reduction, then the head's value
+    double mn[3] = {x, y, z}, mx[3] = {x, y, z};
 #pragma unroll
-      for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
-    }
+    for (int off = 1; off < WAVE; off <<= 1)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double a = __shfl_down(mn[d], off, WAVE), b = __shfl_down(mx[d], off, WAVE);
+        if (lane + off < seg_end) { mn[d] = (a < mn[d]) ? a : mn[d]; mx[d] = (mx[d] < b) ? b : mx[d]; }
+      }
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = __shfl(mn[d], cs, WAVE); mx[d] = __shfl(mx[d], cs, WAVE); }
     uint32_t cd, mode;
     double cv;
-    sl_midpt_rule(f.blo, f.bhi, mn, mx, cd, cv, mode);
-    double* __restrict__ ca = (cd == 0) ? cx : ((cd == 1) ? cy : cz);
-    auto swap_pts = [&](uint32_t a, uint32_t b) {
-      const uint32_t pa = perm[a]; perm[a] = perm[b]; perm[b] = pa;
-      double t;
-      t = cx[a]; cx[a] = cx[b]; cx[b] = t;
-      t = cy[a]; cy[a] = cy[b]; cy[b] = t;
-      t = cz[a]; cz[a] = cz[b]; cz[b] = t;
-    };
-    // annPlaneSplit (kd_util.cpp:291-319)
-    int l = 0, r = (int)n - 1;
-    for (;;) {
-      while (l < (int)n && ca[s + l] < cv) l++;
-      while (r >= 0 && ca[s + r] >= cv) r--;
-      if (l > r) break;
-      swap_pts(s + l, s + r);
-      l++; r--;
+    sl_midpt_rule(blo, bhi, mn, mx, cd, cv, mode);
+    // annPlaneSplit (kd_util.cpp:291-319), first pass: "< cv" | ">= cv"
+    double c = (cd == 0) ? x : ((cd == 1) ? y : z);
+    const bool f = active && (c < cv);
+    const uint32_t br1 = (uint32_t)__popcll(__ballot(f) & mask);
+    {
+      const bool left_region = rel < br1;
+      const uint32_t partner = hoare_partner(active && left_region && !f, active && !left_region && f, mask, cs, lane, slotL, slotR);
+      x = __shfl(x, partner, WAVE); y = __shfl(y, partner, WAVE); z = __shfl(z, partner, WAVE); pm = __shfl(pm, partner, WAVE);
     }
-    const int br1 = l;
-    r = (int)n - 1;
-    for (;;) {
-      while (l < (int)n && ca[s + l] <= cv) l++;
-      while (r >= br1 && ca[s + r] > cv) r--;
-      if (l > r) break;
-      swap_pts(s + l, s + r);
-      l++; r--;
+    // second pass on [br1, n): "== cv" | "> cv"
+    c = (cd == 0) ? x : ((cd == 1) ? y : z);
+    const bool g = active && (rel >= br1) && (c <= cv);
+    const uint32_t br2 = br1 + (uint32_t)__popcll(__ballot(g) & mask);
+    {
+      const bool in2 = active && (rel >= br1);
+      const bool left_region = rel < br2;
+      const uint32_t partner = hoare_partner(in2 && left_region && !g, in2 && !left_region && g, mask, cs, lane, slotL, slotR);
+      x = __shfl(x, partner, WAVE); y = __shfl(y, partner, WAVE); z = __shfl(z, partner, WAVE); pm = __shfl(pm, partner, WAVE);
     }
-    const int br2 = l;
-    const uint32_t n_lo = sl_midpt_nlo(mode, n, (uint32_t)br1, (uint32_t)br2);
-    if (n_lo == 0 || n_lo >= n) { atomicExch(small + 2, 1u); return; }
-    const uint32_t me = s + n_lo - 1u;
-    AnnNode nd;
-    nd.cut_val = cv;
-    nd.lo = (cd == 0) ? f.blo[0] : ((cd == 1) ? f.blo[1] : f.blo[2]);
-    nd.hi = (cd == 0) ? f.bhi[0] : ((cd == 1) ? f.bhi[1] : f.bhi[2]);
-    nd.c0 = cd << 30; nd.c1 = 0;
-    nodes[me] = nd;
-    ann_hook(nodes, small + 0, f.parent, f.side, me);
-    // high child first so that the low child is handled next, as the recursion does (order is immaterial)
-    for (int side = 1; side >= 0; side--) {
-      AFrame& c = st[sp++];
-      c = f;
-      c.start = side ? s + n_lo : s;
-      c.n = side ? n - n_lo : n_lo;
-      c.parent = (int32_t)me; c.side = (uint32_t)side; c.depth = f.depth + 1;
-      if (side) { if (cd == 0) c.blo[0] = cv; else if (cd == 1) c.blo[1] = cv; else c.blo[2] = cv; }
-      else { if (cd == 0) c.bhi[0] = cv; else if (cd == 1) c.bhi[1] = cv; else c.bhi[2] = cv; }
+    const uint32_t n_lo = sl_midpt_nlo(mode, cn, br1, br2);
+    if (active && (n_lo == 0 || n_lo >= cn)) atomicExch(small + 2, 1u);    // cannot happen for finite input
+    if (__ballot(active && (n_lo == 0 || n_lo >= cn))) return;
+    const uint32_t me = S + cs + n_lo - 1u;
+    if (active && lane == cs) {                 // the sub-cell's first lane writes its splitting node ...
+      AnnNode* nd = nodes + me;
+      nd->cut_val = cv; nd->lo = sel3(blo, cd); nd->hi = sel3(bhi, cd);
+      if (top) { nd->c0 = cd << 30; nd->c1 = 0; ann_hook(nodes, small + 0, parent, side, me); }
+      else if (side) nodes[parent].c1 = me;     // ... and hooks it in (the child words are written by the children only)
+      else nodes[parent].c0 = (pcd << 30) | me;
+    }
+    if (active) {
+      const bool go_hi = rel >= n_lo;           // kd_tree.cpp:346-357
+      if (go_hi) { put3(blo, cd, cv); cs += n_lo; cn -= n_lo; }
+      else { put3(bhi, cd, cv); cn = n_lo; }
+      parent = (int32_t)me; side = go_hi ? 1u : 0u; pcd = cd; depth++;
+      top = false;
     }
   }
-  atomicMax(small + 1, maxdepth);
+  if (lane < N) { cx[S + lane] = x; cy[S + lane] = y; cz[S + lane] = z; perm[S + lane] = pm; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t t = __shfl_xor(maxdepth, off, WAVE); maxdepth = (t > maxdepth) ? t : maxdepth; }
+  if (lane == 0) atomicMax(small + 1, maxdepth);
 }
 
 __global__ void k_ann_points(const uint32_t* __restrict__ perm, const double* __restrict__ cx,
@@ -590,7 +623,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
   ACHK(hipStreamSynchronize(s));
   if (h_small[4])
-    hipLaunchKernelGGL(k_ann_small, dim3(cdiv(h_small[4], 64)), dim3(64), 0, s, small_list, h_small[4], perm, cx, cy, cz,
+    hipLaunchKernelGGL(k_ann_small, dim3(cdiv((size_t)h_small[4] * WAVE, 256)), dim3(256), 0, s, small_list, h_small[4], perm, cx, cy, cz,
                        nodes, small);
   hipLaunchKernelGGL(k_ann_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
   ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
