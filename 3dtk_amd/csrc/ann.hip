@@ -156,11 +156,24 @@ __global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict_
   // the run the wave is in the middle of (wave-uniform): merged with what follows while the cell stays the same
   uint32_t pend = NOSEG;
   double pmn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, pmx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+  // all loads of the wave's range are issued up front (positions outside any cell cost a label only)
+  uint32_t sgs[MEAS_ITERS];
+  double vs[MEAS_ITERS][3];
+#pragma unroll
   for (int it = 0; it < MEAS_ITERS; it++) {
     const uint32_t p = base + (uint32_t)it * WAVE + lane;
-    const uint32_t sg = (p < M) ? seg_of[p] : NOSEG;
-    double v[3] = {0, 0, 0};
-    if (sg != NOSEG) { v[0] = cx[p]; v[1] = cy[p]; v[2] = cz[p]; }
+    sgs[it] = (p < M) ? seg_of[p] : NOSEG;
+  }
+#pragma unroll
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    vs[it][0] = vs[it][1] = vs[it][2] = 0;
+    if (sgs[it] != NOSEG) { vs[it][0] = cx[p]; vs[it][1] = cy[p]; vs[it][2] = cz[p]; }
+  }
+#pragma unroll
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    const uint32_t sg = sgs[it];
+    const double v[3] = {vs[it][0], vs[it][1], vs[it][2]};
     unsigned long long todo = __ballot(sg != NOSEG);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;

@@ -269,6 +269,22 @@ def bench_icp(args, rank, world, local):
     }
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0)
+    if world == 1 and not args.no_normals:
+        # Scan::calcNormals (k = 10, eps = 1.0) on the resident data scan: tree build + k-NN + PCA
+        t_n = []
+        for _ in range(4):
+            tn0 = time.perf_counter(); data.calcNormals(); t_n.append(time.perf_counter() - tn0)
+        out["normals_1gpu"] = {"value": n / min(t_n), "unit": "points/s", "ms": min(t_n) * 1e3, "points": n, "k": 10, "eps": 1.0,
+                               "what": "tdtk_scan_calc_normals on the resident scan: ANN-tree build, approximate 10-NN, "
+                                       "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat"}
+        if not args.no_cpu:
+            from oracle import orc as _orc
+            ns = min(n, 100000)
+            which = "ref" if _orc.have_ref() else "oracle"
+            tc0 = time.perf_counter(); _orc.normals_apx_knn(cur[:ns], 10, [0.0, 0.0, 0.0], 1.0, which); tc = time.perf_counter() - tc0
+            out["normals_1gpu"]["cpu_baseline"] = {"value": ns / tc, "unit": "points/s", "cores": 1,
+                                                   "kind": "reference" if which == "ref" else "port",
+                                                   "sample": "first %d points of the scan (the reference's calcNormals is serial)" % ns}
     if world == 1 and args.workload == "auto" and not args.no_graphslam_base:
         # the 1-GPU point of the graph-SLAM strong-scaling curve (the N>1 runs of this script measure
         # configs[3]); reported beside the headline so scaling can be read against the same workload
@@ -356,6 +372,7 @@ def main():
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--scans", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-normals", action="store_true", help="N=1 only: skip the calcNormals measurement")
     ap.add_argument("--no-graphslam-base", action="store_true",
                     help="N=1 only: skip the extra 1-GPU graph-SLAM measurement (the base of the N>1 curve)")
     args = ap.parse_args()
