@@ -1058,3 +1058,23 @@ def test_normals_full_size(tdtk, orc, gpu):
     assert (np.einsum("ij,ij->i", n, p - np.array([0.0, 0.0, 500.0])) >= 0).all()
     assert np.array_equal(knn[:, 0], np.arange(len(p)))
     assert (np.abs(n[:, 2]) > 0.5).mean() > 0.95        # a slightly tilted plane, noise ~ half the point spacing
+
+
+def test_normals_10m_properties(tdtk, gpu):
+    """A 10M-point scan (configs[4]'s scan size): the size-independent properties of the ANN answer -- every list
+    sorted, the query itself first, and the library's guarantee that the i-th reported neighbour is at most
+    (1 + eps) times farther than the true i-th nearest neighbour (checked against brute force on a sample) -- plus
+    unit normals oriented towards the sensor."""
+    rng = np.random.default_rng(33)
+    n = 10000000
+    p = rng.uniform(-3000, 3000, (n, 3)); p[:, 2] = 0.02 * p[:, 1] + rng.normal(0, 2.0, n)
+    rp = np.array([0.0, 0.0, 800.0])
+    nrm, knn = tdtk.calculateNormalsApxKNN(p, 10, rp, 1.0, want_knn=True)
+    assert np.array_equal(knn[:, 0], np.arange(n, dtype=np.int32))
+    assert np.abs(np.linalg.norm(nrm, axis=1) - 1.0).max() < 1e-14
+    assert (np.einsum("ij,ij->i", nrm, p - rp) >= 0).all()
+    for i in rng.integers(0, n, 200):
+        d2 = ((p - p[i]) ** 2).sum(axis=1)
+        true = np.sort(np.partition(d2, 10)[:10])
+        got = d2[knn[i]]
+        assert (np.diff(got) >= 0).all() and (got <= 4.0 * true * (1 + 1e-12)).all() and (got >= true).all()
