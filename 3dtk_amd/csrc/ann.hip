@@ -110,9 +110,10 @@ __global__ void k_ann_init(const double* __restrict__ xyz, uint32_t M, uint32_t*
 // the root cell = annEnclRect of all points (kd_tree.cpp:381-385); small[4] counts the small cells
 __global__ void k_ann_root(const double* __restrict__ box, uint32_t M, ASeg* __restrict__ segs,
                            ASeg* __restrict__ small_list, uint32_t* __restrict__ small, double* __restrict__ bb,
-                           AMeasU* __restrict__ meas)
+                           AMeasU* __restrict__ meas, unsigned long long* __restrict__ cnt)
 {
   for (int d = 0; d < 3; d++) { meas[0].mn[d] = ENC_PINF; meas[0].mx[d] = ENC_NINF; }
+  cnt[0] = 0ull;
   ASeg r;
   r.start = 0; r.n = M; r.parent = -1; r.side = 0; r.depth = 0; r.pad = 0;
   for (int d = 0; d < 3; d++) { r.blo[d] = box[d]; r.bhi[d] = box[3 + d]; bb[d] = box[d]; bb[3 + d] = box[3 + d]; }
@@ -240,43 +241,71 @@ __global__ void k_ann_decide(const ASeg* __restrict__ segs, uint32_t nseg, const
   dec[i] = d;
 }
 
-// pass 1: "< cv" belongs left of br1.  pass 2 (positions >= br1 only): "<= cv", i.e. "== cv", belongs left of br2
-template <int PASS>
-__global__ void k_ann_flags(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
-                            const ADec* __restrict__ dec, const uint32_t* __restrict__ br1,
-                            const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
-                            uint32_t M, uint32_t* __restrict__ f)
+// Per cell: how many of its points lie below the cutting plane (-> br1) and how many on it (br2 = br1 + that):
+// all annPlaneSplit's breaks need, and independent of the order of the points.  Same run-wise reduction as
+// k_ann_measure; one 64-bit atomicAdd per run (low word "< cv", high word "== cv").
+__global__ void __launch_bounds__(256) k_ann_count(const uint32_t* __restrict__ seg_of, uint32_t M,
+                                                   const ADec* __restrict__ dec, const double* __restrict__ cx,
+                                                   const double* __restrict__ cy, const double* __restrict__ cz,
+                                                   unsigned long long* __restrict__ cnt)
 {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > M) return;
-  uint32_t v = 0;
-  if (p < M) {
-    const uint32_t sg = seg_of[p];
+  __shared__ uint32_t s_seg[4];
+  __shared__ unsigned long long s_cnt[4];
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const uint32_t base = (blockIdx.x * 4u + wv) * (WAVE * MEAS_ITERS);
+  uint32_t sgs[MEAS_ITERS];
+#pragma unroll
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    sgs[it] = (p < M) ? seg_of[p] : NOSEG;
+  }
+  uint32_t pend = NOSEG;
+  unsigned long long pcnt = 0;
+#pragma unroll
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    const uint32_t sg = sgs[it];
+    bool lt = false, eq = false;
     if (sg != NOSEG) {
-      const double c = coord_of(cx, cy, cz, dec[sg].cd, p);
-      if (PASS == 1) v = (c < dec[sg].cv) ? 1u : 0u;
-      else v = ((p - segs[sg].start) >= br1[sg] && c <= dec[sg].cv) ? 1u : 0u;
+      const double c = coord_of(cx, cy, cz, dec[sg].cd, p), cv = dec[sg].cv;
+      lt = c < cv; eq = (c <= cv) && !lt;
+    }
+    unsigned long long todo = __ballot(sg != NOSEG);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t cur = __shfl(sg, leader, WAVE);
+      const bool mine = (sg == cur);
+      const unsigned long long add = (unsigned long long)__popcll(__ballot(mine && lt)) |
+                                     ((unsigned long long)__popcll(__ballot(mine && eq)) << 32);
+      if (cur != pend) {
+        if (pend != NOSEG && lane == 0) atomicAdd(&cnt[pend], pcnt);
+        pend = cur; pcnt = add;
+      } else pcnt += add;
+      todo &= ~__ballot(mine);
     }
   }
-  f[p] = v;   // index M is a zero terminator: the exclusive scan then also yields every cell's total
+  if (lane == 0) { s_seg[wv] = pend; s_cnt[wv] = pcnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t cur = NOSEG;
+    unsigned long long acc = 0;
+    for (int w = 0; w < 4; w++) {
+      if (s_seg[w] == NOSEG) continue;
+      if (s_seg[w] != cur) {
+        if (cur != NOSEG) atomicAdd(&cnt[cur], acc);
+        cur = s_seg[w]; acc = s_cnt[w];
+      } else acc += s_cnt[w];
+    }
+    if (cur != NOSEG) atomicAdd(&cnt[cur], acc);
+  }
 }
 
-// per cell: number of flagged elements = F[s+n] - F[s]
-template <int PASS>
-__global__ void k_ann_breaks(const ASeg* __restrict__ segs, uint32_t nseg, const uint32_t* __restrict__ F,
-                             uint32_t* __restrict__ br1, uint32_t* __restrict__ br2)
-{
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
-  const uint32_t cnt = F[segs[i].start + segs[i].n] - F[segs[i].start];
-  if (PASS == 1) br1[i] = cnt;
-  else br2[i] = br1[i] + cnt;
-}
-
+// pass 1: "< cv" belongs left of br1.  pass 2 (positions >= br1 only): "<= cv", i.e. "== cv", belongs left of br2
 template <int PASS>
 __global__ void k_ann_misplaced(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
-                                const uint32_t* __restrict__ br1, const uint32_t* __restrict__ br2,
-                                const uint32_t* __restrict__ f, uint32_t M, unsigned long long* __restrict__ LR)
+                                const ADec* __restrict__ dec, const unsigned long long* __restrict__ cnt,
+                                const double* __restrict__ cx, const double* __restrict__ cy,
+                                const double* __restrict__ cz, uint32_t M, unsigned long long* __restrict__ LR)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > M) return;
@@ -285,18 +314,21 @@ __global__ void k_ann_misplaced(const uint32_t* __restrict__ seg_of, const ASeg*
     const uint32_t sg = seg_of[p];
     if (sg != NOSEG) {
       const uint32_t rel = p - segs[sg].start;
+      const unsigned long long cn = cnt[sg];
+      const uint32_t br1 = (uint32_t)cn, br2 = br1 + (uint32_t)(cn >> 32);
+      const double c = coord_of(cx, cy, cz, dec[sg].cd, p), cv = dec[sg].cv;
       if (PASS == 1) {
-        const bool left_region = rel < br1[sg];
-        l = (left_region && !f[p]) ? 1u : 0u;
-        r = (!left_region && f[p]) ? 1u : 0u;
-      } else if (rel >= br1[sg]) {
-        const bool left_region = rel < br2[sg];
-        l = (left_region && !f[p]) ? 1u : 0u;
-        r = (!left_region && f[p]) ? 1u : 0u;
+        const bool left_region = rel < br1, f = c < cv;
+        l = (left_region && !f) ? 1u : 0u;
+        r = (!left_region && f) ? 1u : 0u;
+      } else if (rel >= br1) {
+        const bool left_region = rel < br2, g = c <= cv;
+        l = (left_region && !g) ? 1u : 0u;
+        r = (!left_region && g) ? 1u : 0u;
       }
     }
   }
-  LR[p] = (unsigned long long)l | ((unsigned long long)r << 32);
+  LR[p] = (unsigned long long)l | ((unsigned long long)r << 32);   // index M is a zero terminator (totals)
 }
 
 // k-th misplaced from the left pairs with the k-th misplaced from the right END of the cell
@@ -343,15 +375,16 @@ static __device__ __forceinline__ void ann_hook(AnnNode* __restrict__ nodes, uin
 // per cell: n_lo, the splitting node, the two child cells (leaf / small cell / cell of the next level).
 // small: [0] root_ref [1] max depth [2] err [3] cells of the next level [4] small cells
 __global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADec* __restrict__ dec,
-                               const uint32_t* __restrict__ br1, const uint32_t* __restrict__ br2,
-                               AnnNode* __restrict__ nodes, ASeg* __restrict__ next, ASeg* __restrict__ small_list,
-                               uint32_t* __restrict__ small, AMeasU* __restrict__ meas_next)
+                               const unsigned long long* __restrict__ cnt, AnnNode* __restrict__ nodes,
+                               ASeg* __restrict__ next, ASeg* __restrict__ small_list, uint32_t* __restrict__ small,
+                               AMeasU* __restrict__ meas_next, unsigned long long* __restrict__ cnt_next)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
   const ASeg sg = segs[i];
   ADec d = dec[i];
-  const uint32_t n_lo = sl_midpt_nlo(d.mode, sg.n, br1[i], br2[i]);
+  const uint32_t br1 = (uint32_t)cnt[i], br2 = br1 + (uint32_t)(cnt[i] >> 32);
+  const uint32_t n_lo = sl_midpt_nlo(d.mode, sg.n, br1, br2);
   if (n_lo == 0 || n_lo >= sg.n) { atomicExch(small + 2, 1u); return; }   // cannot happen for finite input
   const uint32_t me = sg.start + n_lo - 1u;
   AnnNode nd;
@@ -376,6 +409,7 @@ __global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADe
       slot[side] = atomicAdd(small + 3, 1u);
       next[slot[side]] = ch;
       for (int a = 0; a < 3; a++) { meas_next[slot[side]].mn[a] = ENC_PINF; meas_next[slot[side]].mx[a] = ENC_NINF; }
+      cnt_next[slot[side]] = 0ull;
     }
   }
   nodes[me] = nd;     // children that are cells hook themselves in later (they run after this kernel)
@@ -549,10 +583,10 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   int k = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; if (O) O[k] = o; k++; return o; };
   take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1); take(8 * n1);      // 0 perm 1 segof 2 cx 3 cy 4 cz
-  take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1);                    // 5 f 6 F 7 LR 8 AB
+  take(256); take(256); take(8 * n1); take(8 * n1);                          // 5, 6 unused 7 LR 8 AB
   take(4 * n1); take(4 * n1);                                                // 9 posL 10 posR
   take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nsmall);   // 11 segA 12 segB 13 small cells
-  take(sizeof(AMeasU) * nlarge); take(sizeof(ADec) * nlarge); take(4 * nlarge); take(4 * nlarge);   // 14 meas 15 dec 16 br1 17 br2
+  take(sizeof(AMeasU) * nlarge); take(sizeof(ADec) * nlarge); take(8 * nlarge); take(8 * nlarge);   // 14 meas 15 dec 16 counts 17 counts of the next level
   take(scan_tmp + 256); take(256);                                           // 18 tmp 19 small
   take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
   take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
@@ -575,12 +609,11 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   const size_t n1 = (size_t)M + 1;
   uint32_t* perm = (uint32_t*)(arena + O[0]); uint32_t* seg_of = (uint32_t*)(arena + O[1]);
   double *cx = (double*)(arena + O[2]), *cy = (double*)(arena + O[3]), *cz = (double*)(arena + O[4]);
-  uint32_t *f = (uint32_t*)(arena + O[5]), *F = (uint32_t*)(arena + O[6]);
   unsigned long long *LR = (unsigned long long*)(arena + O[7]), *AB = (unsigned long long*)(arena + O[8]);
   uint32_t *posL = (uint32_t*)(arena + O[9]), *posR = (uint32_t*)(arena + O[10]);
   ASeg *segs = (ASeg*)(arena + O[11]), *next = (ASeg*)(arena + O[12]), *small_list = (ASeg*)(arena + O[13]);
   AMeasU* meas = (AMeasU*)(arena + O[14]); AMeasU* meas_next = (AMeasU*)(arena + O[22]); ADec* dec = (ADec*)(arena + O[15]);
-  uint32_t *br1 = (uint32_t*)(arena + O[16]), *br2 = (uint32_t*)(arena + O[17]);
+  unsigned long long *cnt = (unsigned long long*)(arena + O[16]), *cnt_next = (unsigned long long*)(arena + O[17]);
   void* tmp = arena + O[18];
   uint32_t* small = (uint32_t*)(arena + O[19]);
   double* partial = (double*)(arena + O[20]); double* box = (double*)(arena + O[21]);
@@ -588,7 +621,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   ACHK(hipMemsetAsync(small, 0, 256, s));
   hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2);
   ACHK(launch_bbox(d_xyz, M, partial, box, s));
-  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas);
+  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt);
   uint32_t nseg = (M > ANN_SMALL) ? 1u : 0u, level = 0;
   {
     uint32_t bad = 0;
@@ -601,28 +634,20 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
     hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas);
     hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, dec);
     ACHK(hipMemsetAsync(small + 3, 0, 4, s));
+    hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
     // the library's first Hoare pass, then its second one on what lies right of br1
     for (int pass = 1; pass <= 2; pass++) {
       if (pass == 1)
-        hipLaunchKernelGGL(k_ann_flags<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, br1, cx, cy, cz, M, f);
+        hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
       else
-        hipLaunchKernelGGL(k_ann_flags<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, br1, cx, cy, cz, M, f);
+        hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
       size_t st = scan_tmp;
-      ACHK(rocprim::exclusive_scan(tmp, st, f, F, 0u, n1, rocprim::plus<uint32_t>(), s));
-      if (pass == 1) {
-        hipLaunchKernelGGL(k_ann_breaks<1>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, F, br1, br2);
-        hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, br1, br2, f, M, LR);
-      } else {
-        hipLaunchKernelGGL(k_ann_breaks<2>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, F, br1, br2);
-        hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, br1, br2, f, M, LR);
-      }
-      st = scan_tmp;
       ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
       hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
       hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
     }
-    hipLaunchKernelGGL(k_ann_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, dec, br1, br2, nodes, next,
-                       small_list, small, meas_next);
+    hipLaunchKernelGGL(k_ann_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, dec, cnt, nodes, next,
+                       small_list, small, meas_next, cnt_next);
     hipLaunchKernelGGL(k_ann_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, dec, M, seg_of);
     uint32_t h[2] = {0, 0};   // err, cells of the next level
     ACHK(hipMemcpyAsync(h, small + 2, 8, hipMemcpyDeviceToHost, s));
@@ -631,6 +656,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
     nseg = h[1];
     ASeg* t = segs; segs = next; next = t;
     AMeasU* tm = meas; meas = meas_next; meas_next = tm;
+    unsigned long long* tc = cnt; cnt = cnt_next; cnt_next = tc;
   }
   uint32_t h_small[5];
   ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
