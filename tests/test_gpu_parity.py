@@ -1078,3 +1078,26 @@ def test_normals_10m_properties(tdtk, gpu):
         true = np.sort(np.partition(d2, 10)[:10])
         got = d2[knn[i]]
         assert (np.diff(got) >= 0).all() and (got <= 4.0 * true * (1 + 1e-12)).all() and (got >= true).all()
+
+
+@pytest.mark.parametrize("algo,mode", [(1, 2), (10, 2), (1, 1)])
+def test_dat_icp_with_computed_normals(tdtk, orc, gpu, algo, mode):
+    """slam6D -z (point-to-plane pairs, mode 2) / --normal_shoot-simple (mode 1) on the bundled scans: the normals
+    come from Scan::calcNormals on the device (oracle side: the restated calculateNormalsApxKNN), then the pairwise
+    ICP of scan001 onto scan000 -- pair counts per iteration exact, pose within tolerance."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    S, O = [], []
+    for k in range(2):
+        pts, pose = z["scan%03d" % k], z["pose%03d" % k]
+        s = tdtk.Scan(pose[:3], pose[3:], pts).calcNormals()
+        on = orc.normals_apx_knn(pts, 10, pose[:3], 1.0)
+        assert np.array_equal(s._local_n, on)
+        S.append(s); O.append(io.OScan(pose[:3], pose[3:], pts, on))
+    mini = tdtk.icp6D_QUAT(True) if algo == 1 else tdtk.icp6D_NAPX(True)
+    icp = tdtk.icp6D(mini, 25.0, 15, quiet=True, epsilonICP=1e-5)
+    it = icp.match(S[0], S[1], pairing_mode=mode)
+    oit, otr = io.match(O[0], O[1], algo, 625.0, 15, 1e-5, mode)
+    assert it == oit and [int(r[0]) for r in icp.last["trace"]] == [t[0] for t in otr]
+    np.testing.assert_allclose(icp.last["trace"][:, 1], [t[1] for t in otr], rtol=1e-7)
+    assert _rel(S[1].get_transMat(), O[1].transMat) < 1e-7
