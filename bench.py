@@ -125,11 +125,17 @@ def dist_setup(ngpus):
         import torch.distributed as dist
         rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
-        torch.cuda.set_device(local)
-        with _stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-            dist.barrier()                      # brings the communicator (and its banner) up now
-            torch.cuda.synchronize()
+        if os.environ.get("TDTK_BENCH_BACKEND") == "gloo":
+            # test rig only (tests/test_gpu_parity.py): several ranks sharing the GPUs that exist, exchange over gloo
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            with _stdout_to_stderr():
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+                dist.barrier()                      # brings the communicator (and its banner) up now
+                torch.cuda.synchronize()
     else:
         torch.cuda.set_device(0)
     if world != ngpus:
@@ -150,7 +156,8 @@ def max_over_ranks(x, world, local):
         return x
     import torch
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", local))
+    on_gpu = dist.get_backend() != "gloo"
+    t = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", local) if on_gpu else None)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -318,7 +325,8 @@ def bench_graphslam(args, rank, world, local):
     tdtk.prepare_scans([scans[k] for k in need_tree], trees=True, threads=8)
     tdtk.prepare_scans([scans[k] for k in need_pts], trees=False, threads=8)
     import torch.distributed as tdist
-    dev = torch.device("cuda", local) if (tdist.is_available() and tdist.is_initialized()) else None
+    dev = torch.device("cuda", local) if (tdist.is_available() and tdist.is_initialized()
+                                           and tdist.get_backend() != "gloo") else None
     nn_ms = [0.0]
 
     def step():

@@ -1101,3 +1101,25 @@ def test_dat_icp_with_computed_normals(tdtk, orc, gpu, algo, mode):
     assert it == oit and [int(r[0]) for r in icp.last["trace"]] == [t[0] for t in otr]
     np.testing.assert_allclose(icp.last["trace"][:, 1], [t[1] for t in otr], rtol=1e-7)
     assert _rel(S[1].get_transMat(), O[1].transMat) < 1e-7
+
+
+def test_bench_graphslam_two_ranks_on_this_box(gpu):
+    """bench.py's N > 1 leg end to end (torch.distributed.run, links dealt over the ranks, per-link exchange, every
+    rank solving and moving its resident scans), with both ranks sharing this box's GPU and gloo carrying the exchange
+    (RCCL refuses two ranks on one device): the iteration's result equals the one-process run bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    common = ["--workload", "graphslam", "--scans", "12", "--points", "60000", "--steps", "3", "--warmup", "1"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, TDTK_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.join(root, "bench.py"),
+                          "--gpus", "2"] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and a["config"]["links"] == b["config"]["links"]
+    assert a["last_ret"] == b["last_ret"]
