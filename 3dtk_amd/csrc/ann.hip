@@ -154,9 +154,6 @@ __global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict_
   __shared__ double s_mn[4][3], s_mx[4][3];
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const uint32_t base = (blockIdx.x * 4u + wv) * (WAVE * MEAS_ITERS);
-  // the run the wave is in the middle of (wave-uniform): merged with what follows while the cell stays the same
-  uint32_t pend = NOSEG;
-  double pmn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, pmx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
   // all loads of the wave's range are issued up front (positions outside any cell cost a label only)
   uint32_t sgs[MEAS_ITERS];
   double vs[MEAS_ITERS][3];
@@ -171,38 +168,52 @@ __global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict_
     vs[it][0] = vs[it][1] = vs[it][2] = 0;
     if (sgs[it] != NOSEG) { vs[it][0] = cx[p]; vs[it][1] = cy[p]; vs[it][2] = cz[p]; }
   }
+  // the run the wave is in the middle of (`pend`, wave-uniform) is kept as PER-LANE partial min / max: while whole
+  // rows of 64 positions stay inside it nothing crosses lanes; the shuffle reduction runs once, when the run ends
+  uint32_t pend = NOSEG;
+  double amn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, amx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+  auto reduce_lanes = [&](double* mn, double* mx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        double t;
+        t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
+        t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
+      }
+  };
 #pragma unroll
   for (int it = 0; it < MEAS_ITERS; it++) {
     const uint32_t sg = sgs[it];
     const double v[3] = {vs[it][0], vs[it][1], vs[it][2]};
+    if (pend != NOSEG && __ballot(sg == pend) == ~0ull) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) { amn[d] = (v[d] < amn[d]) ? v[d] : amn[d]; amx[d] = (amx[d] < v[d]) ? v[d] : amx[d]; }
+      continue;
+    }
     unsigned long long todo = __ballot(sg != NOSEG);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
       const uint32_t cur = __shfl(sg, leader, WAVE);
       const bool mine = (sg == cur);
-      double mn[3], mx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) { mn[d] = mine ? v[d] : HUGE_VAL; mx[d] = mine ? v[d] : -HUGE_VAL; }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          double t;
-          t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
-          t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
-        }
       if (cur != pend) {
-        if (pend != NOSEG && lane == 0) meas_flush(out, pend, pmn, pmx);
+        if (pend != NOSEG) {
+          reduce_lanes(amn, amx);
+          if (lane == 0) meas_flush(out, pend, amn, amx);
+        }
         pend = cur;
 #pragma unroll
-        for (int d = 0; d < 3; d++) { pmn[d] = mn[d]; pmx[d] = mx[d]; }
-      } else {
+        for (int d = 0; d < 3; d++) { amn[d] = HUGE_VAL; amx[d] = -HUGE_VAL; }
+      }
+      if (mine) {
 #pragma unroll
-        for (int d = 0; d < 3; d++) { pmn[d] = (mn[d] < pmn[d]) ? mn[d] : pmn[d]; pmx[d] = (pmx[d] < mx[d]) ? mx[d] : pmx[d]; }
+        for (int d = 0; d < 3; d++) { amn[d] = (v[d] < amn[d]) ? v[d] : amn[d]; amx[d] = (amx[d] < v[d]) ? v[d] : amx[d]; }
       }
       todo &= ~__ballot(mine);
     }
   }
+  double pmn[3] = {amn[0], amn[1], amn[2]}, pmx[3] = {amx[0], amx[1], amx[2]};
+  if (pend != NOSEG) reduce_lanes(pmn, pmx);
   // the four waves of the block cover adjacent ranges: merge equal cells before touching memory
   if (lane == 0) {
     s_seg[wv] = pend;
