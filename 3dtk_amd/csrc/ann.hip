@@ -37,6 +37,7 @@ namespace tdtk {
 #define A_LEAF 0x20000000u    // child reference: leaf flag | position (29 bits); c0 bits 30..31 = cutting dimension
 #define A_VAL 0x1FFFFFFFu
 #define NOSEG 0xFFFFFFFFu
+#define ANN_MAX_LEVELS 4096
 
 struct ASeg {
   uint32_t start, n;
@@ -110,8 +111,9 @@ __global__ void k_ann_init(const double* __restrict__ xyz, uint32_t M, uint32_t*
 // the root cell = annEnclRect of all points (kd_tree.cpp:381-385); small[4] counts the small cells
 __global__ void k_ann_root(const double* __restrict__ box, uint32_t M, ASeg* __restrict__ segs,
                            ASeg* __restrict__ small_list, uint32_t* __restrict__ small, double* __restrict__ bb,
-                           AMeasU* __restrict__ meas, unsigned long long* __restrict__ cnt)
+                           AMeasU* __restrict__ meas, unsigned long long* __restrict__ cnt, uint32_t* __restrict__ lvl)
 {
+  lvl[0] = (M > ANN_SMALL) ? 1u : 0u;
   for (int d = 0; d < 3; d++) { meas[0].mn[d] = ENC_PINF; meas[0].mx[d] = ENC_NINF; }
   cnt[0] = 0ull;
   ASeg r;
@@ -238,11 +240,11 @@ __global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict_
   }
 }
 
-__global__ void k_ann_decide(const ASeg* __restrict__ segs, uint32_t nseg, const AMeasU* __restrict__ meas,
-                             ADec* __restrict__ dec)
+__global__ void k_ann_decide(const ASeg* __restrict__ segs, const uint32_t* __restrict__ nseg_ptr,
+                             const AMeasU* __restrict__ meas, ADec* __restrict__ dec)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
+  if (i >= *nseg_ptr) return;       // the number of cells of this level is known on the device only
   const ASeg sg = segs[i];
   AMeas m;
   for (int d = 0; d < 3; d++) { m.mn[d] = dec_f64(meas[i].mn[d]); m.mx[d] = dec_f64(meas[i].mx[d]); }
@@ -385,13 +387,13 @@ static __device__ __forceinline__ void ann_hook(AnnNode* __restrict__ nodes, uin
 
 // per cell: n_lo, the splitting node, the two child cells (leaf / small cell / cell of the next level).
 // small: [0] root_ref [1] max depth [2] err [3] cells of the next level [4] small cells
-__global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADec* __restrict__ dec,
+__global__ void k_ann_children(const ASeg* __restrict__ segs, const uint32_t* __restrict__ nseg_ptr, ADec* __restrict__ dec,
                                const unsigned long long* __restrict__ cnt, AnnNode* __restrict__ nodes,
                                ASeg* __restrict__ next, ASeg* __restrict__ small_list, uint32_t* __restrict__ small,
                                AMeasU* __restrict__ meas_next, unsigned long long* __restrict__ cnt_next)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
+  if (i >= nseg_ptr[0]) return;     // nseg_ptr[1] counts the cells of the next level
   const ASeg sg = segs[i];
   ADec d = dec[i];
   const uint32_t br1 = (uint32_t)cnt[i], br2 = br1 + (uint32_t)(cnt[i] >> 32);
@@ -417,7 +419,7 @@ __global__ void k_ann_children(const ASeg* __restrict__ segs, uint32_t nseg, ADe
     } else if (ch.n <= ANN_SMALL) {
       small_list[atomicAdd(small + 4, 1u)] = ch;
     } else {
-      slot[side] = atomicAdd(small + 3, 1u);
+      slot[side] = atomicAdd(const_cast<uint32_t*>(nseg_ptr) + 1, 1u);
       next[slot[side]] = ch;
       for (int a = 0; a < 3; a++) { meas_next[slot[side]].mn[a] = ENC_PINF; meas_next[slot[side]].mx[a] = ENC_NINF; }
       cnt_next[slot[side]] = 0ull;
@@ -601,6 +603,7 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(scan_tmp + 256); take(256);                                           // 18 tmp 19 small
   take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
   take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
+  take(4 * (ANN_MAX_LEVELS + 2));                                            // 23 cells per level
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
@@ -629,45 +632,55 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   uint32_t* small = (uint32_t*)(arena + O[19]);
   double* partial = (double*)(arena + O[20]); double* box = (double*)(arena + O[21]);
 
+  uint32_t* lvl = (uint32_t*)(arena + O[23]);
   ACHK(hipMemsetAsync(small, 0, 256, s));
+  ACHK(hipMemsetAsync(lvl, 0, 4 * (ANN_MAX_LEVELS + 2), s));
   hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2);
   ACHK(launch_bbox(d_xyz, M, partial, box, s));
-  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt);
-  uint32_t nseg = (M > ANN_SMALL) ? 1u : 0u, level = 0;
-  {
+  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt, lvl);
+  // Levels are enqueued without waiting for their cell counts (those stay on the device: lvl[]); the host looks
+  // at them only after a batch -- the first batch is as deep as a balanced tree gets down to 64-point cells, then
+  // two levels at a time.  A level enqueued past the last one finds no cell and costs a few empty launches.
+  uint32_t level = 0, more = (M > ANN_SMALL) ? 1u : 0u;
+  uint32_t batch = 1;
+  for (size_t c = ANN_SMALL; c < M_; c <<= 1) batch++;
+  const size_t nlarge = M_ / (ANN_SMALL + 1) + 2;
+  while (more) {
+    for (uint32_t b = 0; b < batch && level < ANN_MAX_LEVELS; b++, level++) {
+      const size_t bound = (level < 31 && ((size_t)1 << level) < nlarge) ? ((size_t)1 << level) : nlarge;
+      hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas);
+      hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, dec);
+      hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
+      // the library's first Hoare pass, then its second one on what lies right of br1
+      for (int pass = 1; pass <= 2; pass++) {
+        if (pass == 1)
+          hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
+        else
+          hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
+        size_t st = scan_tmp;
+        ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+        hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
+        hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
+      }
+      hipLaunchKernelGGL(k_ann_children, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, dec, cnt, nodes, next,
+                         small_list, small, meas_next, cnt_next);
+      hipLaunchKernelGGL(k_ann_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, dec, M, seg_of);
+      ASeg* t = segs; segs = next; next = t;
+      AMeasU* tm = meas; meas = meas_next; meas_next = tm;
+      unsigned long long* tc = cnt; cnt = cnt_next; cnt_next = tc;
+    }
+    uint32_t bad = 0;
+    ACHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
+    ACHK(hipMemcpyAsync(&more, lvl + level, 4, hipMemcpyDeviceToHost, s));
+    ACHK(hipStreamSynchronize(s));
+    if (bad || (more && level >= ANN_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
+    batch = 2;
+  }
+  if (M <= ANN_SMALL) {     // no level ran: the finiteness flag of k_ann_init has not been looked at yet
     uint32_t bad = 0;
     ACHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
     ACHK(hipStreamSynchronize(s));
     if (bad) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
-  }
-  while (nseg > 0) {
-    ++level;
-    hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas);
-    hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, dec);
-    ACHK(hipMemsetAsync(small + 3, 0, 4, s));
-    hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
-    // the library's first Hoare pass, then its second one on what lies right of br1
-    for (int pass = 1; pass <= 2; pass++) {
-      if (pass == 1)
-        hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
-      else
-        hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
-      size_t st = scan_tmp;
-      ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
-      hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
-      hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
-    }
-    hipLaunchKernelGGL(k_ann_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, dec, cnt, nodes, next,
-                       small_list, small, meas_next, cnt_next);
-    hipLaunchKernelGGL(k_ann_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, dec, M, seg_of);
-    uint32_t h[2] = {0, 0};   // err, cells of the next level
-    ACHK(hipMemcpyAsync(h, small + 2, 8, hipMemcpyDeviceToHost, s));
-    ACHK(hipStreamSynchronize(s));
-    if (h[0] || level > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
-    nseg = h[1];
-    ASeg* t = segs; segs = next; next = t;
-    AMeasU* tm = meas; meas = meas_next; meas_next = tm;
-    unsigned long long* tc = cnt; cnt = cnt_next; cnt_next = tc;
   }
   uint32_t h_small[5];
   ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
