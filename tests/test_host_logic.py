@@ -355,6 +355,15 @@ def test_adapter_compiles_against_reference_headers(tmp_path):
     syms = subprocess.run(["nm", "-C", str(obj)], capture_output=True, text=True).stdout
     for want in ("HipSearchTree::getPtPairs", "HipSearchTree::FindClosest", "tdtk_get_pt_pairs", "tdtk_tree_create"):
         assert want in syms
+    # adapters/normals_hip.h: the calculateNormalsApxKNN-shaped binding (needs slam6d/point.h only)
+    src = tmp_path / "nrm.cc"
+    src.write_text('#include "normals_hip.h"\nvoid use(std::vector<Point>& n, const std::vector<Point>& p, const double* r)'
+                   ' { calculateNormalsApxKNN_hip(n, p, 10, r, 1.0); }\n')
+    obj2 = tmp_path / "nrm.o"
+    r = subprocess.run(["g++", "-std=c++17", "-c", "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "adapters"), str(src), "-o", str(obj2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "tdtk_normals_apx_knn" in subprocess.run(["nm", "-C", str(obj2)], capture_output=True, text=True).stdout
 
 
 def test_scan_io_uos_pose_frames(tdtk, tmp_path):
