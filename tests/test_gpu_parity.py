@@ -1123,3 +1123,22 @@ def test_bench_graphslam_two_ranks_on_this_box(gpu):
     b = json.loads(two.stdout.strip().splitlines()[-1])
     assert b["n_gpus"] == 2 and a["config"]["links"] == b["config"]["links"]
     assert a["last_ret"] == b["last_ret"]
+
+
+@pytest.mark.parametrize("name", ["one", "two", "identical70", "identical64", "two_values", "axis_ties"])
+def test_normals_degenerate_clouds(tdtk, orc, gpu, name):
+    """Clouds on which every split of the ANN tree is a tie-break: a single point, two points, all points identical
+    (one global level + wave-built cells / wave-built only), two distinct positions repeated, and integer
+    coordinates with many equal values per axis (every cutting plane passes through points)."""
+    rng = np.random.default_rng(12)
+    pts = {"one": np.array([[1.0, 2.0, 3.0]]), "two": np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0]]),
+           "identical70": np.tile([[5.0, -5.0, 2.5]], (70, 1)), "identical64": np.tile([[5.0, -5.0, 2.5]], (64, 1)),
+           "two_values": np.repeat(np.array([[0.0, 0.0, 0.0], [3.0, 1.0, 2.0]]), 150, axis=0)[rng.permutation(300)],
+           "axis_ties": rng.integers(0, 6, (5000, 3)).astype(float)}[name]
+    k = min(10, len(pts))
+    want, wknn = orc.normals_apx_knn(pts, k, [0.5, 0.25, -1.0], 1.0, want_knn=True)
+    got, gknn = tdtk.calculateNormalsApxKNN(pts, k, [0.5, 0.25, -1.0], 1.0, want_knn=True)
+    assert np.array_equal(gknn, wknn)
+    assert np.array_equal(got, want, equal_nan=True)
+    if orc.have_ref():
+        assert np.array_equal(want, orc.normals_apx_knn(pts, k, [0.5, 0.25, -1.0], 1.0, "ref"), equal_nan=True)
