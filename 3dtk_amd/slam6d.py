@@ -794,6 +794,37 @@ class Graph:
             for j, k in zip(jj.tolist(), kk.tolist()):
                 self.frm.append(j); self.to.append(k)
 
+    @classmethod
+    def from_netfile(cls, netfile):
+        """Graph(const std::string &netfile) (graph.cc:52-74, slam6D -n): "<scans> <links>" then one "from to" pair per
+        link; the scan count is NOT taken from the file but accumulated by addLink."""
+        g = cls(0, links=[])
+        tok = open(netfile).read().split()
+        if len(tok) < 2:
+            raise RuntimeError("Error while reading network structure")
+        nlinks = int(tok[1])
+        if len(tok) < 2 + 2 * nlinks:
+            raise RuntimeError("Error while reading network structure")        # the reference exit(1)s
+        for j in range(nlinks):
+            g.addLink(int(tok[2 + 2 * j]), int(tok[3 + 2 * j]))
+        return g
+
+    @classmethod
+    def chain(cls, nScans, loop=False):
+        """Graph(int nScans, bool loop) (graph.cc:84-105): minimally connected, optionally closed"""
+        n = nScans if loop else nScans - 1
+        g = cls(0, links=[(i, (i + 1 if i != n - 1 else 0) if loop else i + 1) for i in range(n)])
+        g.nrScans = nScans
+        return g
+
+    def addLink(self, i, j):
+        """graph.cc:157-174: an end point seen for the first time counts as a new scan (i == j counts twice)"""
+        if not any(f == i or t == i for f, t in zip(self.frm, self.to)):
+            self.nrScans += 1
+        if not any(f == j or t == j for f, t in zip(self.frm, self.to)):
+            self.nrScans += 1
+        self.frm.append(int(i)); self.to.append(int(j))
+
     def getNrScans(self): return self.nrScans
     def getNrLinks(self): return len(self.frm)
     def getLink(self, i, fromTo): return self.frm[i] if fromTo == 0 else self.to[i]
@@ -847,7 +878,16 @@ def lum_pose_update(scan, Xi):
     return rPos, rPosTheta, float(np.sqrt(result[0] ** 2 + result[1] ** 2 + result[2] ** 2))
 
 
-class lum6DEuler:
+class _graphSlam6D_setters:
+    def set_mdmll(self, mdmll):
+        """graphSlam6D::set_mdmll (graphSlam6D.cc:425-427): slam6D.cc:818-821 runs a second doGraphSlam6D with it"""
+        self.max_dist_match2_LUM = mdmll * mdmll
+
+    def set_quiet(self, quiet):
+        self.quiet = quiet
+
+
+class lum6DEuler(_graphSlam6D_setters):
     """lum6DEuler (-G 1).  doGraphSlam6D follows lum6Deuler.cc:314-477; the link loop of
     FillGB3D (lum6Deuler.cc:265-303) is sharded over ranks when a process group is given."""
 
@@ -874,7 +914,7 @@ class lum6DEuler:
         return ret
 
 
-class lum6DQuat:
+class lum6DQuat(_graphSlam6D_setters):
     """lum6DQuat (-G 2, src/slam6d/lum6Dquat.cc): LUM with 7 unknowns per scan (translation +
     quaternion).  Links sharded / reduced like lum6DEuler."""
 
@@ -895,7 +935,7 @@ class lum6DQuat:
         return ret
 
 
-class ghelix6DQ2:
+class ghelix6DQ2(_graphSlam6D_setters):
     """ghelix6DQ2 (-G 3, src/slam6d/ghelix6DQ2.cc): simultaneous registration with the helical-motion
     linearisation; B and bd are zeroed once per doGraphSlam6D call, not per iteration (:329-330)."""
 
@@ -918,7 +958,7 @@ class ghelix6DQ2:
         return ret
 
 
-class gapx6D:
+class gapx6D(_graphSlam6D_setters):
     """gapx6D (-G 4, src/slam6d/gapx6D.cc): graph-SLAM with the small-angle (APX) linearisation:
     a 3(n-1) rotation system from per-link second moments, then translations from the link
     Laplacian.  Same link sharding / single all-reduce as lum6DEuler."""

@@ -461,3 +461,29 @@ def test_lum_assemble_solve_matches_dense_fill(tdtk):
         bad = np.array([7] + [0] * (len(links) - 1), np.int32)
         capi.check(capi.lib().tdtk_lum_assemble_solve(len(links), capi.iptr(bad), capi.iptr(to), capi.dptr(Call),
                                                       capi.dptr(CDall), nscans, capi.dptr(X), None, None))
+
+
+def test_graph_netfile_chain_addlink(tdtk, tmp_path):
+    """Graph(netfile) (slam6D -n, graph.cc:52-74), Graph(n, loop) (:84-105), addLink's scan counting (:157-174)"""
+    f = tmp_path / "net"
+    f.write_text("4\n4\n0 1\n1 2\n2 3\n3 0\nignored 9 9\n")
+    g = tdtk.Graph.from_netfile(str(f))
+    assert g.getNrScans() == 4 and g.getNrLinks() == 4
+    assert [(g.getLink(i, 0), g.getLink(i, 1)) for i in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 0)]
+    bad = tmp_path / "bad"
+    bad.write_text("3 5\n0 1\n")
+    with pytest.raises(RuntimeError):
+        tdtk.Graph.from_netfile(str(bad))
+    c = tdtk.Graph.chain(5)
+    assert c.getNrScans() == 5 and [(c.getLink(i, 0), c.getLink(i, 1)) for i in range(c.getNrLinks())] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    l = tdtk.Graph.chain(4, loop=True)
+    assert l.getNrScans() == 4 and [(l.getLink(i, 0), l.getLink(i, 1)) for i in range(l.getNrLinks())] == [(0, 1), (1, 2), (2, 3), (3, 0)]
+    a = tdtk.Graph(0, links=[])
+    a.addLink(7, 7)                      # counted twice, as written
+    assert a.getNrScans() == 2
+    a.addLink(7, 2)
+    assert a.getNrScans() == 3 and a.getNrLinks() == 2
+    for cls in (tdtk.lum6DEuler, tdtk.lum6DQuat, tdtk.ghelix6DQ2, tdtk.gapx6D):
+        b = cls(None, 25.0, 25.0)
+        b.set_mdmll(10.0)
+        assert b.max_dist_match2_LUM == 100.0
