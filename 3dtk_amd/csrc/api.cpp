@@ -1052,7 +1052,7 @@ int tdtk_scan_pairs(const tdtk_tree* model, const double A[16], tdtk_scan* data,
 {
   if (!model || !A || !data || !sums) { set_error("NULL argument"); return TDTK_EINVAL; }
   if (pmode < 0 || pmode > 2) { set_error("bad pairing mode"); return TDTK_EINVAL; }
-  if ((pmode != 0 || (want & TDTK_WANT_NAPX)) && !data->nx) {
+  if ((pmode != 0 || (want & TDTK_WANT_NAPX)) && data->N && !data->nx) {   // an empty scan pairs with nothing
     set_error("this pairing mode / minimizer needs normals");
     return TDTK_EINVAL;
   }
@@ -1119,6 +1119,10 @@ int tdtk_get_pt_pairs(const tdtk_tree* t, const double A[16], const double* xyz_
                       double* pn_out, tdtk_pair_sums* sums)
 {
   if (!t || !A || !xyz_r || !sums || end < start) { set_error("bad argument"); return TDTK_EINVAL; }
+  if ((pmode == 1 || pmode == 2 || (want & TDTK_WANT_NAPX)) && !normal_r) {
+    set_error("this pairing mode / minimizer needs normals");
+    return TDTK_EINVAL;
+  }
   // rnd > 1: "take about 1/rnd-th of the numbers only" (searchTree.cc:118, globals.icc:607-610):
   // one std::rand() per candidate, consumed in index order like a serial (non-OpenMP) reference
   // build does.  The keep-mask is drawn on the host; only the kept queries go to the GPU.

@@ -1142,3 +1142,13 @@ def test_normals_degenerate_clouds(tdtk, orc, gpu, name):
     assert np.array_equal(got, want, equal_nan=True)
     if orc.have_ref():
         assert np.array_equal(want, orc.normals_apx_knn(pts, k, [0.5, 0.25, -1.0], 1.0, "ref"), equal_nan=True)
+
+
+def test_get_pt_pairs_empty_range_with_normals(tdtk, gpu):
+    """startindex == endindex in the plane / normal-shooting modes: no query, no pair, no error (searchTree.cc:112)"""
+    rng = np.random.default_rng(0)
+    m = rng.uniform(-1, 1, (100, 3)); q = rng.uniform(-1, 1, (10, 3)); nr = np.tile([0.0, 0.0, 1.0], (10, 1))
+    kd = tdtk.KDtree(m)
+    for mode in (0, 1, 2):
+        r = kd.getPtPairs(tdtk.M4identity(), q, nr, 4, 4, pairing_mode=mode)
+        assert r["n"] == 0 and len(r["idx"]) == 0

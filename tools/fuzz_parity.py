@@ -1,0 +1,95 @@
+"""GPU box: randomized differential run of the HIP path against the CPU oracle -- many small clouds of awkward shapes
+(duplicates, lattices, collinear / coplanar points, huge dynamic range, tiny sizes) through calcNormals (k-NN lists
+and normals bit for bit) and through the search tree (FindClosest indices / distances bit for bit).
+usage: python tools/fuzz_parity.py [--seconds 120] [--seed 0]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from importlib import import_module  # noqa: E402
+
+tdtk = import_module("3dtk_amd")
+from oracle import orc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+
+
+def cloud():
+    n = int(rng.choice([1, 2, 3, 7, 10, 11, 33, 64, 65, 66, 128, 129, 300, 1000, 4097, 20000]))
+    kind = rng.integers(0, 9)
+    if kind == 0:
+        p = rng.uniform(-100, 100, (n, 3))
+    elif kind == 1:
+        p = rng.integers(-4, 5, (n, 3)).astype(float)                       # lattice, many duplicates
+    elif kind == 2:
+        p = rng.uniform(-100, 100, (n, 3)); p[:, rng.integers(0, 3)] = rng.choice([0.0, 1.5, -7.25])   # coplanar
+    elif kind == 3:
+        p = np.outer(rng.uniform(-50, 50, n), rng.normal(size=3))           # collinear
+    elif kind == 4:
+        p = rng.normal(0, 1, (n, 3)) * (10.0 ** rng.integers(-6, 7, (n, 1)))   # huge dynamic range
+    elif kind == 5:
+        b = rng.uniform(-10, 10, (max(1, n // 3), 3)); p = b[rng.integers(0, len(b), n)]   # every point repeated
+    elif kind == 6:
+        p = np.round(rng.uniform(-20, 20, (n, 3)), 1)                       # one decimal: ties on every axis
+    elif kind == 7:
+        p = np.concatenate([rng.normal(c, 1e-3, (n // 4 + 1, 3)) for c in rng.uniform(-50, 50, (4, 3))])[:n]
+    else:
+        p = np.cumsum(rng.exponential(1.0, (n, 3)) ** 3, axis=0)            # skewed: deep sliding splits
+    return np.ascontiguousarray(p[rng.permutation(len(p))], dtype=np.float64)
+
+
+t0 = time.time()
+runs = fails = 0
+while time.time() - t0 < a.seconds:
+    p = cloud()
+    n = len(p)
+    runs += 1
+    # normals
+    k = int(min(n, rng.choice([1, 3, 10, 10, 10, 16, 32])))
+    eps = float(rng.choice([0.0, 0.5, 1.0, 1.0, 3.0]))
+    rp = rng.uniform(-10, 10, 3)
+    want, wk = orc.normals_apx_knn(p, k, rp, eps, want_knn=True)
+    got, gk = tdtk.calculateNormalsApxKNN(p, k, rp, eps, want_knn=True)
+    if not (np.array_equal(gk, wk) and np.array_equal(got, want, equal_nan=True)):
+        fails += 1
+        np.save("gpurun_out/fuzz_fail_normals_%d.npy" % runs, p)
+        print("NORMALS MISMATCH run %d n=%d k=%d eps=%g knn_equal=%s" % (runs, n, k, eps, np.array_equal(gk, wk)), flush=True)
+    # search tree
+    bucket = int(rng.choice([1, 2, 5, 20, 20]))
+    q = np.concatenate([p[rng.integers(0, n, min(n, 500))] + rng.normal(0, rng.choice([0.0, 1e-3, 1.0]), (min(n, 500), 3)),
+                        rng.uniform(p.min() - 1, p.max() + 1, (50, 3))])
+    md2 = float(rng.choice([1e-6, 0.25, 25.0, 1e18]))
+    kd, T = tdtk.KDtree(p, bucket), orc.Tree(p, bucket)
+    gi, gd = kd.FindClosestBatch(q, md2)
+    oi, od = T.find_closest(q, md2)
+    if not (np.array_equal(gi, oi) and np.array_equal(gd, od)) or kd.verify() != [0, 0, 0, 0]:
+        fails += 1
+        np.save("gpurun_out/fuzz_fail_search_%d.npy" % runs, p)
+        print("SEARCH MISMATCH run %d n=%d bucket=%d md2=%g" % (runs, n, bucket, md2), flush=True)
+    # SearchTree::getPtPairs through the C ABI: random pose, the three pairing modes, a query sub-range
+    mode = int(rng.integers(0, 3))
+    A = tdtk.EulerToMatrix4(rng.uniform(-1, 1, 3), rng.uniform(-0.05, 0.05, 3))
+    nq = len(q)
+    nrm = rng.normal(size=(nq, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    lo = int(rng.integers(0, nq // 2 + 1)); hi = int(rng.integers(lo, nq + 1))
+    md2p = float(rng.choice([0.25, 25.0, 1e6]))
+    r = kd.getPtPairs(A, q, nrm, lo, hi, max_dist_match2=md2p, pairing_mode=mode)
+    o = T.get_pt_pairs(A, q, nrm, lo, hi, mode, md2p)
+    ok = r["n"] == o["n"] and np.array_equal(r["idx"], o["idx"])
+    if ok and o["n"]:
+        ok = np.array_equal(r["p1"], o["p1"][:o["n"]]) and np.array_equal(r["p2"], o["p2"][:o["n"]]) and \
+            abs(r["sum"] - o["sum"]) <= 1e-9 * max(1e-300, abs(o["sum"]))
+    if not ok:
+        fails += 1
+        np.save("gpurun_out/fuzz_fail_pairs_%d.npy" % runs, p)
+        print("PAIRS MISMATCH run %d n=%d mode=%d range=[%d,%d) md2=%g n=%s/%s" % (runs, n, mode, lo, hi, md2p, r["n"], o["n"]), flush=True)
+print("fuzz: %d clouds, %d mismatches, %.0f s, seed %d" % (runs, fails, time.time() - t0, a.seed))
+sys.exit(1 if fails else 0)
