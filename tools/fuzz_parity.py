@@ -91,5 +91,39 @@ while time.time() - t0 < a.seconds:
         fails += 1
         np.save("gpurun_out/fuzz_fail_pairs_%d.npy" % runs, p)
         print("PAIRS MISMATCH run %d n=%d mode=%d range=[%d,%d) md2=%g n=%s/%s" % (runs, n, mode, lo, hi, md2p, r["n"], o["n"]), flush=True)
+    # octree reduction (-r): same cells, same centres, same order
+    vox = float(rng.choice([0.3, 2.0, 15.0, 1e5]))
+    ext = float(np.abs(p).max()) + 1.0
+    if ext / vox < 2.0 ** 20:                      # the 21-level key limit of tdtk_reduce_octree
+        gr_, or_ = tdtk.calcReducedPoints(p, vox), orc.octree_center(p, vox)
+        if not (gr_.shape == or_.shape and np.array_equal(gr_, or_)):
+            fails += 1
+            np.save("gpurun_out/fuzz_fail_octree_%d.npy" % runs, p)
+            print("OCTREE MISMATCH run %d n=%d voxel=%g" % (runs, n, vox), flush=True)
+    # one in ten: a short ICP (well-conditioned cloud, random minimizer) against the oracle loop
+    if runs % 10 == 0:
+        from oracle import icp_oracle as io
+        nm = int(rng.choice([200, 1500, 6000]))
+        m = rng.uniform(-60, 60, (nm, 3)); m[:, 2] *= 0.3
+        Tg = io.euler_to_matrix4(rng.uniform(-0.8, 0.8, 3), rng.uniform(-0.02, 0.02, 3))
+        inv, _ = orc.m4inv(Tg)
+        d = m[rng.permutation(nm)[: max(50, nm // 2)]] + rng.normal(0, 0.02, (max(50, nm // 2), 3)); orc.transform_points(inv, d)
+        algo = int(rng.choice([1, 2, 6, 3, 4, 5, 7, 8, 9]))
+        cls = {1: tdtk.icp6D_QUAT, 2: tdtk.icp6D_SVD, 6: tdtk.icp6D_APX, 3: tdtk.icp6D_ORTHO, 4: tdtk.icp6D_DUAL,
+               5: tdtk.icp6D_HELIX, 7: tdtk.icp6D_LUMEULER, 8: tdtk.icp6D_LUMQUAT, 9: tdtk.icp6D_QUAT_SCALE}[algo]
+        S = [tdtk.Scan([0, 0, 0], [0, 0, 0], m), tdtk.Scan([0, 0, 0], [0, 0, 0], d)]
+        O = [io.OScan([0, 0, 0], [0, 0, 0], m), io.OScan([0, 0, 0], [0, 0, 0], d)]
+        icp = tdtk.icp6D(cls(True), 5.0, 10, quiet=True, epsilonICP=1e-6)
+        it = icp.match(S[0], S[1])
+        oit, otr = io.match(O[0], O[1], algo, 25.0, 10, 1e-6)
+        tol = 1e-8 if algo in (1, 2, 6) else 1e-6
+        ok = it == oit and [int(r[0]) for r in icp.last["trace"]] == [t[0] for t in otr] and \
+            np.abs(S[1].get_transMat() - O[1].transMat).max() <= tol * max(1.0, np.abs(O[1].transMat).max())
+        if not ok:
+            fails += 1
+            np.save("gpurun_out/fuzz_fail_icp_%d.npy" % runs, m)
+            print("ICP MISMATCH run %d algo=%d nm=%d it=%s/%s pairs=%s/%s dT=%g" % (
+                runs, algo, nm, it, oit, [int(r[0]) for r in icp.last["trace"]][:4], [t[0] for t in otr][:4],
+                np.abs(S[1].get_transMat() - O[1].transMat).max()), flush=True)
 print("fuzz: %d clouds, %d mismatches, %.0f s, seed %d" % (runs, fails, time.time() - t0, a.seed))
 sys.exit(1 if fails else 0)
