@@ -584,19 +584,15 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
 {
   size_t scan_tmp = 0;
   {
-    uint32_t* z = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, scan_tmp, z, z, 0u, M + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
     unsigned long long* z8 = nullptr;
-    size_t t8 = 0;
-    (void)rocprim::exclusive_scan(nullptr, t8, z8, z8, 0ull, M + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
-    if (t8 > scan_tmp) scan_tmp = t8;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, z8, z8, 0ull, M + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
   }
   const size_t n1 = M + 1, nlarge = M / (ANN_SMALL + 1) + 2, nsmall = M / 2 + 2;
   size_t off = 0;
   int k = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; if (O) O[k] = o; k++; return o; };
   take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1); take(8 * n1);      // 0 perm 1 segof 2 cx 3 cy 4 cz
-  take(256); take(256); take(8 * n1); take(8 * n1);                          // 5, 6 unused 7 LR 8 AB
+  take(256); take(256); take(8 * n1); take(8 * n1);                          // 5, 6 spare 7 LR 8 AB
   take(4 * n1); take(4 * n1);                                                // 9 posL 10 posR
   take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nlarge); take(sizeof(ASeg) * nsmall);   // 11 segA 12 segB 13 small cells
   take(sizeof(AMeasU) * nlarge); take(sizeof(ADec) * nlarge); take(8 * nlarge); take(8 * nlarge);   // 14 meas 15 dec 16 counts 17 counts of the next level
