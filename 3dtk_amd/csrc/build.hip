@@ -27,6 +27,7 @@
 namespace tdtk {
 
 #define WAVE 64
+#define MEAS_STAGE 4     // chunks of 64 values parked in LDS together (k_measure)
 
 struct BSeg {
   uint32_t start, n;
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
                                                  const double* __restrict__ cx, const double* __restrict__ cy,
                                                  const double* __restrict__ cz, BMeas* __restrict__ out)
 {
-  __shared__ double stage[256 / WAVE][2][WAVE];
+  __shared__ double stage[256 / WAVE][2][MEAS_STAGE * WAVE];
   // wave-uniform by construction; readfirstlane tells the compiler so
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
   const int lane = threadIdx.x & (WAVE - 1);
@@ -57,50 +58,54 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
   const uint32_t s = __builtin_amdgcn_readfirstlane(segs[sgi].start);
   const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
   const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + s;
-  double(*buf)[WAVE] = stage[threadIdx.x / WAVE];
+  double(*buf)[MEAS_STAGE * WAVE] = stage[threadIdx.x / WAVE];
 
   const double first = arr[0];
   double lo = first, hi = first;
   double sum = first;  // the sum starts from the first point (kdTreeImpl.h:97-101) ...
-  // MEAS_AHEAD chunks of 64 values are in flight from memory at any time (folding one chunk takes ~0.2 us of
-  // dependent adds, a cached global load about as long)
-  constexpr int MEAS_AHEAD = 4;
-  double vq[MEAS_AHEAD];
+  // A stage = MEAS_STAGE chunks of 64 values: loaded from memory one stage ahead, parked in LDS together, folded as
+  // one run of 256 dependent adds.  The per-stage costs (LDS write, fence, the first reads' round trip) are paid once
+  // per 256 adds; within the run 32 LDS values are requested ahead of the chain (left to itself the compiler keeps
+  // two reads outstanding and every other add waits a full LDS round trip).
+  double vq[MEAS_STAGE];
 #pragma unroll
-  for (int j = 0; j < MEAS_AHEAD; j++) vq[j] = ((uint32_t)(j * WAVE + lane) < n) ? arr[j * WAVE + lane] : first;
+  for (int j = 0; j < MEAS_STAGE; j++) vq[j] = ((uint32_t)(j * WAVE + lane) < n) ? arr[j * WAVE + lane] : first;
   int cur = 0;
-  for (uint32_t base0 = 0; base0 < n; base0 += WAVE * MEAS_AHEAD) {
+  for (uint32_t base = 0; base < n; base += WAVE * MEAS_STAGE, cur ^= 1) {
+    const uint32_t cnt = (n - base < WAVE * MEAS_STAGE) ? (n - base) : WAVE * MEAS_STAGE;
 #pragma unroll
-    for (int j = 0; j < MEAS_AHEAD; j++) {
-      const uint32_t base = base0 + (uint32_t)j * WAVE;
-      if (base < n) {     // wave-uniform
-        const uint32_t cnt = (n - base < WAVE) ? (n - base) : WAVE;
-        const double v = vq[j];
-        lo = (v < lo) ? v : lo;  // lanes past the end carry `first`, harmless for min/max
-        hi = (hi < v) ? v : hi;
-        buf[cur][lane] = v;
-        const uint32_t nb = base + WAVE * MEAS_AHEAD;
-        vq[j] = (nb + lane < n) ? arr[nb + lane] : first;   // this slot's next chunk
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const double* __restrict__ b = buf[cur];
-        if (cnt == WAVE && base != 0) {
-          // 32 LDS values requested ahead of the chain: left to itself the compiler keeps two reads outstanding and
-          // every other dependent v_add_f64 stalls on a fresh LDS round trip (root chain of 1M values: 9.6 -> 6.0 ms)
-          constexpr int PF = 32;
-          double r[PF];
+    for (int j = 0; j < MEAS_STAGE; j++) {
+      const double v = vq[j];
+      lo = (v < lo) ? v : lo;  // lanes past the end carry `first`, harmless for min/max
+      hi = (hi < v) ? v : hi;
+      buf[cur][j * WAVE + lane] = v;
+      const uint32_t nb = base + WAVE * MEAS_STAGE + (uint32_t)j * WAVE;
+      vq[j] = (nb + lane < n) ? arr[nb + lane] : first;   // the next stage
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double* __restrict__ b = buf[cur];
+    if (cnt == WAVE * MEAS_STAGE && base != 0) {
+      constexpr int PF = 32;
+      double r[PF];
 #pragma unroll
-          for (int q = 0; q < PF; q++) r[q] = b[q];
+      for (int q = 0; q < PF; q++) r[q] = b[q];
 #pragma unroll
-          for (int k = 0; k < WAVE; k++) {
-            sum += r[k % PF];
-            if (k + PF < WAVE) r[k % PF] = b[k + PF];
-          }
-        } else {
-          for (uint32_t k = (base == 0) ? 1u : 0u; k < cnt; k++) sum += b[k];  // ... and adds the rest in order
-        }
-        cur ^= 1;
+      for (int k = 0; k < WAVE * MEAS_STAGE; k++) {
+        sum += r[k % PF];
+        if (k + PF < WAVE * MEAS_STAGE) r[k % PF] = b[k + PF];
       }
+    } else {
+      // first stage of a node (the sum starts FROM the first point) and the ragged last one: 16 values per round trip
+      uint32_t k = (base == 0) ? 1u : 0u;
+      for (; k + 16 <= cnt; k += 16) {
+        double r[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) r[q] = b[k + q];
+#pragma unroll
+        for (int q = 0; q < 16; q++) sum += r[q];
+      }
+      for (; k < cnt; k++) sum += b[k];  // ... and adds the rest in order
     }
   }
 #pragma unroll
