@@ -18,6 +18,7 @@
 //
 // One small D2H (the number of internal nodes of the level) per level is the only host sync.
 #include <cstring>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
@@ -37,6 +38,10 @@ struct BSeg {
 struct BMeas {
   double lo[3], hi[3], mean[3];
 };
+// what the host used to carry from level to level now stays on the device: nodes of the level, first node index
+// and first bucket index of the level (lvl[L+1] is written by k_emit of level L)
+struct BLevel { uint32_t nseg, node_base, leaf_base; };
+#define BUILD_MAX_LEVELS 4096
 
 // ---- per node: bounding box + the reference's left-to-right fp64 sum ----------------------------
 // One wavefront per (node, axis).  Each step the wave loads 64 consecutive values (one coalesced
@@ -45,7 +50,7 @@ struct BMeas {
 // adds in run order, the critical path of the whole build -- then reads the values back one by
 // one at a wave-uniform address (LDS broadcast, in-order returns, so the reads pipeline ahead of
 // the chain) and the vector ALU issues nothing but the dependent v_add_f64 chain.
-__global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, uint32_t nseg,
+__global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
                                                  const double* __restrict__ cx, const double* __restrict__ cy,
                                                  const double* __restrict__ cz, BMeas* __restrict__ out)
 {
@@ -53,7 +58,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
   // wave-uniform by construction; readfirstlane tells the compiler so
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
   const int lane = threadIdx.x & (WAVE - 1);
-  if (w >= 3u * nseg) return;
+  if (w >= 3u * lv->nseg) return;
   const uint32_t sgi = w / 3u, ax = w % 3u;
   const uint32_t s = __builtin_amdgcn_readfirstlane(segs[sgi].start);
   const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
@@ -122,12 +127,14 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
 }
 
 // ---- per node: leaf or internal, split axis / value (kdTreeImpl.h:113-170) ----------------------
-__global__ void k_decide(const BSeg* __restrict__ segs, uint32_t nseg, const BMeas* __restrict__ meas,
-                         uint32_t bucket, uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
-                         double* __restrict__ splitval)
+__global__ void k_decide(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t bound,
+                         const BMeas* __restrict__ meas, uint32_t bucket, uint32_t* __restrict__ kind,
+                         uint32_t* __restrict__ axis, double* __restrict__ splitval, uint32_t* __restrict__ nleft)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
+  if (i > bound) return;
+  if (i >= lv->nseg) { kind[i] = 0u; return; }   // zero padding: the rank scan runs over `bound + 1` entries
+  nleft[i] = 0u;                                 // filled by k_count
   const BMeas m = meas[i];
   const double hx = 0.5 * (m.hi[0] - m.lo[0]), hy = 0.5 * (m.hi[1] - m.lo[1]), hz = 0.5 * (m.hi[2] - m.lo[2]);
   int ax;
@@ -141,14 +148,18 @@ __global__ void k_decide(const BSeg* __restrict__ segs, uint32_t nseg, const BMe
 }
 
 // ---- per node: write the record / register the bucket, hook it into its parent ------------------
-__global__ void k_emit(const BSeg* __restrict__ segs, uint32_t nseg, const BMeas* __restrict__ meas,
+__global__ void k_emit(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, const BMeas* __restrict__ meas,
                        const uint32_t* __restrict__ kind, const uint32_t* __restrict__ axis,
                        const double* __restrict__ splitval, const uint32_t* __restrict__ irank,
-                       uint32_t node_base, uint32_t leaf_base, KdNode* __restrict__ nodes,
-                       double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                       KdNode* __restrict__ nodes, double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
                        uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nseg = lv[0].nseg, node_base = lv[0].node_base, leaf_base = lv[0].leaf_base;
+  if (i == 0) {   // the next level: two children per internal node of this one
+    const uint32_t n_internal = irank[nseg];
+    lv[1].nseg = 2u * n_internal; lv[1].node_base = node_base + n_internal; lv[1].leaf_base = leaf_base + (nseg - n_internal);
+  }
   if (i >= nseg) return;
   const BSeg sg = segs[i];
   uint32_t ref;
@@ -182,30 +193,58 @@ __global__ void k_emit(const BSeg* __restrict__ segs, uint32_t nseg, const BMeas
   }
 }
 
-// ---- per element: "< splitval" flag (0 outside internal nodes) ----------------------------------
-__global__ void k_flags(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
-                        const uint32_t* __restrict__ axis, const double* __restrict__ splitval,
-                        const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
-                        uint32_t M, uint32_t* __restrict__ f)
+// ---- per node: how many of its points lie below the split value (the position of the split) ---------------
+// Order-independent, so no prefix sum is needed for it: a wave covers 1024 consecutive positions, nodes are
+// contiguous runs of positions, one 32-bit atomicAdd per run.
+#define CNT_ITERS 16
+__global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+                                               const uint32_t* __restrict__ axis, const double* __restrict__ splitval,
+                                               const double* __restrict__ cx, const double* __restrict__ cy,
+                                               const double* __restrict__ cz, uint32_t M, uint32_t* __restrict__ nleft)
 {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > M) return;
-  uint32_t v = 0;
-  if (p < M) {
-    const uint32_t sg = seg_of[p];
-    if (sg != 0xFFFFFFFFu && kind[sg]) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t base = (blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE) * (WAVE * CNT_ITERS);
+  uint32_t sgs[CNT_ITERS];
+#pragma unroll
+  for (int it = 0; it < CNT_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    uint32_t sg = (p < M) ? seg_of[p] : 0xFFFFFFFFu;
+    if (sg != 0xFFFFFFFFu && !kind[sg]) sg = 0xFFFFFFFFu;
+    sgs[it] = sg;
+  }
+  uint32_t pend = 0xFFFFFFFFu, pcnt = 0;
+#pragma unroll
+  for (int it = 0; it < CNT_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    const uint32_t sg = sgs[it];
+    bool lt = false;
+    if (sg != 0xFFFFFFFFu) {
       const uint32_t ax = axis[sg];
       const double c = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
-      v = (c < splitval[sg]) ? 1u : 0u;
+      lt = c < splitval[sg];
+    }
+    unsigned long long todo = __ballot(sg != 0xFFFFFFFFu);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t cur = __shfl(sg, leader, WAVE);
+      const bool mine = (sg == cur);
+      const uint32_t add = (uint32_t)__popcll(__ballot(mine && lt));
+      if (cur != pend) {
+        if (pend != 0xFFFFFFFFu && lane == 0) atomicAdd(&nleft[pend], pcnt);
+        pend = cur; pcnt = add;
+      } else pcnt += add;
+      todo &= ~__ballot(mine);
     }
   }
-  f[p] = v;  // index M is a zero terminator so the exclusive scan also yields the grand total
+  if (pend != 0xFFFFFFFFu && lane == 0) atomicAdd(&nleft[pend], pcnt);
 }
 
 // ---- per element: misplaced on the left / on the right of its node's split position --------------
 __global__ void k_misplaced(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
-                            const BSeg* __restrict__ segs, const uint32_t* __restrict__ f,
-                            const uint32_t* __restrict__ F, uint32_t M, unsigned long long* __restrict__ LR)
+                            const BSeg* __restrict__ segs, const uint32_t* __restrict__ axis,
+                            const double* __restrict__ splitval, const uint32_t* __restrict__ nleft,
+                            const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
+                            uint32_t M, unsigned long long* __restrict__ LR)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > M) return;
@@ -213,14 +252,15 @@ __global__ void k_misplaced(const uint32_t* __restrict__ seg_of, const uint32_t*
   if (p < M) {
     const uint32_t sg = seg_of[p];
     if (sg != 0xFFFFFFFFu && kind[sg]) {
-      const uint32_t s = segs[sg].start, n = segs[sg].n;
-      const uint32_t nleft = F[s + n] - F[s];
-      const bool left_region = (p - s) < nleft;
-      l = (left_region && !f[p]) ? 1u : 0u;
-      r = (!left_region && f[p]) ? 1u : 0u;
+      const uint32_t ax = axis[sg];
+      const double c = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
+      const bool f = c < splitval[sg];
+      const bool left_region = (p - segs[sg].start) < nleft[sg];
+      l = (left_region && !f) ? 1u : 0u;
+      r = (!left_region && f) ? 1u : 0u;
     }
   }
-  LR[p] = (unsigned long long)l | ((unsigned long long)r << 32);   // one scan serves both counts
+  LR[p] = (unsigned long long)l | ((unsigned long long)r << 32);   // one scan serves both counts; index M = 0 (totals)
 }
 
 // k-th misplaced from the left pairs with the k-th misplaced from the right end
@@ -259,21 +299,24 @@ __global__ void k_swap(const uint32_t* __restrict__ posL, const uint32_t* __rest
 }
 
 // ---- next level: two children per internal node; relabel the elements ---------------------------
-__global__ void k_children(const BSeg* __restrict__ segs, uint32_t nseg, const uint32_t* __restrict__ kind,
-                           const uint32_t* __restrict__ irank, const uint32_t* __restrict__ F, uint32_t node_base,
+__global__ void k_children(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind,
+                           const uint32_t* __restrict__ irank, const uint32_t* __restrict__ nleft_,
                            BSeg* __restrict__ next, uint32_t* __restrict__ err)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg || !kind[i]) return;
+  if (i >= lv->nseg || !kind[i]) return;
   const BSeg sg = segs[i];
-  const uint32_t nleft = F[sg.start + sg.n] - F[sg.start];
-  if (nleft == 0 || nleft == sg.n) atomicExch(err, 1u);  // degenerate split (non-finite input)
-  const uint32_t me = node_base + irank[i];
+  uint32_t nleft = nleft_[i];
+  if (nleft == 0 || nleft >= sg.n) {   // degenerate split (non-finite input): flag it, and keep the children valid
+    atomicExch(err, 1u);               // ranges -- more levels of this batch are already enqueued behind this one
+    nleft = (nleft == 0) ? 1u : sg.n - 1u;
+  }
+  const uint32_t me = lv->node_base + irank[i];
   next[2 * irank[i]] = {sg.start, nleft, (int32_t)me, 0u};
   next[2 * irank[i] + 1] = {sg.start + nleft, sg.n - nleft, (int32_t)me, 1u};
 }
 __global__ void k_relabel(const BSeg* __restrict__ segs, const uint32_t* __restrict__ kind,
-                          const uint32_t* __restrict__ irank, const uint32_t* __restrict__ F, uint32_t M,
+                          const uint32_t* __restrict__ irank, const uint32_t* __restrict__ nleft, uint32_t M,
                           uint32_t* __restrict__ seg_of)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,9 +324,7 @@ __global__ void k_relabel(const BSeg* __restrict__ segs, const uint32_t* __restr
   const uint32_t sg = seg_of[p];
   if (sg == 0xFFFFFFFFu) return;
   if (!kind[sg]) { seg_of[p] = 0xFFFFFFFFu; return; }
-  const uint32_t s = segs[sg].start, n = segs[sg].n;
-  const uint32_t nleft = F[s + n] - F[s];
-  seg_of[p] = 2u * irank[sg] + (((p - s) < nleft) ? 0u : 1u);
+  seg_of[p] = 2u * irank[sg] + (((p - segs[sg].start) < nleft[sg]) ? 0u : 1u);
 }
 
 __global__ void k_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
@@ -351,7 +392,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   char* arena = static_cast<char*>(arena_);
   KdNode* nodes = nullptr; double* node_r = nullptr; LeafEntry* leaf_tab = nullptr; KdPoint* pts = nullptr;
   KdNode* f_nodes = nullptr; double* f_r = nullptr; LeafEntry* f_leaf = nullptr;
-  uint32_t node_count = 0, leaf_count = 0, depth = 0, nseg = 1;
+  uint32_t node_count = 0, leaf_count = 0, depth = 0;
   size_t scan_tmp = 0;
   size_t O[32];
   (void)build_layout(M_, O, &scan_tmp);
@@ -359,14 +400,15 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   const size_t o_perm = O[0], o_segof = O[1], o_cx = O[2], o_cy = O[3], o_cz = O[4], o_f = O[5], o_F = O[6], o_isL = O[7],
                o_A = O[8], o_posL = O[9], o_posR = O[10], o_segA = O[11], o_segB = O[12], o_meas = O[13], o_kind = O[14],
                o_axis = O[15], o_split = O[16], o_irank = O[17], o_tmp = O[18], o_small = O[19], o_nodes = O[20],
-               o_r = O[21], o_leaf = O[22];
+               o_r = O[21], o_leaf = O[22], o_lvl = O[23];
+  (void)o_f; (void)o_F;
   nodes = (KdNode*)(arena + o_nodes); node_r = (double*)(arena + o_r); leaf_tab = (LeafEntry*)(arena + o_leaf);
   BCHK(hipMalloc((void**)&pts, sizeof(KdPoint) * (size_t)M));
   {
     uint32_t* perm = (uint32_t*)(arena + o_perm); uint32_t* seg_of = (uint32_t*)(arena + o_segof);
     double *cx = (double*)(arena + o_cx), *cy = (double*)(arena + o_cy), *cz = (double*)(arena + o_cz);
-    uint32_t *f = (uint32_t*)(arena + o_f), *F = (uint32_t*)(arena + o_F),
-             *posL = (uint32_t*)(arena + o_posL), *posR = (uint32_t*)(arena + o_posR);
+    uint32_t *nleft = (uint32_t*)(arena + o_F), *posL = (uint32_t*)(arena + o_posL), *posR = (uint32_t*)(arena + o_posR);
+    BLevel* lvl = (BLevel*)(arena + o_lvl);
     unsigned long long *LR = (unsigned long long*)(arena + o_isL), *AB = (unsigned long long*)(arena + o_A);
     BSeg* segs = (BSeg*)(arena + o_segA); BSeg* next = (BSeg*)(arena + o_segB);
     BMeas* meas = (BMeas*)(arena + o_meas);
@@ -375,42 +417,65 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     void* tmp = arena + o_tmp;
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
     BCHK(hipMemsetAsync(small, 0, 256, s));
+    BCHK(hipMemsetAsync(lvl, 0, sizeof(BLevel) * (BUILD_MAX_LEVELS + 2), s));
     const BSeg root = {0u, M, -1, 0u};
+    const BLevel l0 = {1u, 0u, 0u};
     BCHK(hipMemcpyAsync(segs, &root, sizeof root, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(lvl, &l0, sizeof l0, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz);
 
-    while (nseg > 0) {
-      ++depth;
-      hipLaunchKernelGGL(k_measure, dim3(cdiv((size_t)nseg * 3 * WAVE, 256)), dim3(256), 0, s, segs, nseg, cx, cy, cz, meas);
-      hipLaunchKernelGGL(k_decide, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, (uint32_t)bucket, kind,
-                         axis, splitval);
-      size_t st = scan_tmp;
-      BCHK(hipMemsetAsync(kind + nseg, 0, 4, s));
-      BCHK(rocprim::exclusive_scan(tmp, st, kind, irank, 0u, (size_t)nseg + 1, rocprim::plus<uint32_t>(), s));
-      hipLaunchKernelGGL(k_emit, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, meas, kind, axis, splitval, irank,
-                         node_count, leaf_count, nodes, node_r, leaf_tab, small + 0, small + 1);
-      // the partition pass is enqueued unconditionally (with no internal node at this level it moves nothing),
-      // so the level needs a single round trip to the host: the number of internal nodes and the error flag
-      hipLaunchKernelGGL(k_flags, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy, cz, M, f);
-      st = scan_tmp;
-      BCHK(rocprim::exclusive_scan(tmp, st, f, F, 0u, n1, rocprim::plus<uint32_t>(), s));
-      hipLaunchKernelGGL(k_misplaced, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, segs, f, F, M, LR);
-      st = scan_tmp;
-      BCHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
-      hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
-      hipLaunchKernelGGL(k_children, dim3(cdiv(nseg, 256)), dim3(256), 0, s, segs, nseg, kind, irank, F, node_count,
-                         next, small + 2);
-      hipLaunchKernelGGL(k_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
-      hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, F, M, seg_of);
-      uint32_t n_internal = 0, bad = 0;
-      BCHK(hipMemcpyAsync(&n_internal, irank + nseg, 4, hipMemcpyDeviceToHost, s));
+    // Levels are enqueued in batches; how many nodes a level has, and where its node / bucket records start, is
+    // known on the device only (lvl[]).  The host looks once after a first batch as deep as a balanced tree gets
+    // down to bucket-sized nodes, then every two levels; per-node kernels are launched over an upper bound of the
+    // level's node count (what the last look saw, doubled per level since) and return past the real count.
+    uint32_t level = 0, known = 1, known_at = 0;
+    uint32_t batch = 1;
+    for (size_t c = (size_t)(bucket > 0 ? bucket : 1); c < M_; c <<= 1) batch++;
+    for (;;) {
+      for (uint32_t b = 0; b < batch && level < BUILD_MAX_LEVELS; b++, level++) {
+        size_t bound = (size_t)known << ((level - known_at) < 31 ? (level - known_at) : 31);
+        if (bound > M) bound = M;
+        if (bound < 1) bound = 1;
+        const BLevel* lv = lvl + level;
+        hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas);
+        hipLaunchKernelGGL(k_decide, dim3(cdiv(bound + 1, 256)), dim3(256), 0, s, segs, lv, (uint32_t)bound, meas,
+                           (uint32_t)bucket, kind, axis, splitval, nleft);
+        size_t st = scan_tmp;
+        BCHK(rocprim::exclusive_scan(tmp, st, kind, irank, 0u, bound + 1, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(k_emit, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, kind, axis, splitval,
+                           irank, nodes, node_r, leaf_tab, small + 0, small + 1);
+        // the partition pass (with no internal node at this level it moves nothing)
+        hipLaunchKernelGGL(k_count, dim3(cdiv(M, 256 * CNT_ITERS)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy,
+                           cz, M, nleft);
+        hipLaunchKernelGGL(k_misplaced, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, segs, axis, splitval, nleft,
+                           cx, cy, cz, M, LR);
+        st = scan_tmp;
+        BCHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+        hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
+        hipLaunchKernelGGL(k_children, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, kind, irank, nleft, next,
+                           small + 2);
+        hipLaunchKernelGGL(k_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
+        hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, nleft, M, seg_of);
+        BSeg* t = segs; segs = next; next = t;
+      }
+      uint32_t bad = 0;
+      BLevel nx = {0u, 0u, 0u};
       BCHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
+      BCHK(hipMemcpyAsync(&nx, lvl + level, sizeof nx, hipMemcpyDeviceToHost, s));
       BCHK(hipStreamSynchronize(s));
-      if (bad || depth > 4096) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
-      node_count += n_internal;
-      leaf_count += nseg - n_internal;
-      nseg = 2 * n_internal;
-      BSeg* t = segs; segs = next; next = t;
+      if (bad || (nx.nseg && level >= BUILD_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
+      if (nx.nseg == 0) break;
+      known = nx.nseg; known_at = level;
+      batch = 2;
+    }
+    {
+      // the first level without nodes: its counters are the totals, its index the depth of the tree
+      std::vector<BLevel> hl(level + 1);
+      BCHK(hipMemcpyAsync(hl.data(), lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
+      BCHK(hipStreamSynchronize(s));
+      depth = 0;
+      while (depth < level && hl[depth].nseg) depth++;
+      node_count = hl[depth].node_base; leaf_count = hl[depth].leaf_base;
     }
     uint32_t h_small[3];
     BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
@@ -472,6 +537,7 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(4 * n1); take(4 * n1); take(8 * n1); take(4 * n1);                    // kind axis split irank
   take(scan_tmp + 256); take(256);                                          // tmp small
   take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // nodes node_r leaf_tab
+  take(sizeof(BLevel) * (BUILD_MAX_LEVELS + 2));                            // 23 per-level counters
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
