@@ -28,7 +28,7 @@
 namespace tdtk {
 
 #define WAVE 64
-#define MEAS_STAGE 4     // chunks of 64 values parked in LDS together (k_measure)
+#define MEAS_STAGE 8     // chunks of 64 values parked in LDS together (k_measure)
 
 struct BSeg {
   uint32_t start, n;
