@@ -272,17 +272,27 @@ __global__ void __launch_bounds__(256) k_ann_count(const uint32_t* __restrict__ 
     const uint32_t p = base + (uint32_t)it * WAVE + lane;
     sgs[it] = (p < M) ? seg_of[p] : NOSEG;
   }
+  // phase by phase, MEAS_ITERS independent loads deep: the cell's decision, then the coordinate it asks for
+  uint32_t cds[MEAS_ITERS];
+  double cvs[MEAS_ITERS], cs[MEAS_ITERS];
+#pragma unroll
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    cds[it] = 0; cvs[it] = 0.0;
+    if (sgs[it] != NOSEG) { cds[it] = dec[sgs[it]].cd; cvs[it] = dec[sgs[it]].cv; }
+  }
+#pragma unroll
+  for (int it = 0; it < MEAS_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    cs[it] = 0.0;
+    if (sgs[it] != NOSEG) cs[it] = coord_of(cx, cy, cz, cds[it], p);
+  }
   uint32_t pend = NOSEG;
   unsigned long long pcnt = 0;
 #pragma unroll
   for (int it = 0; it < MEAS_ITERS; it++) {
-    const uint32_t p = base + (uint32_t)it * WAVE + lane;
     const uint32_t sg = sgs[it];
-    bool lt = false, eq = false;
-    if (sg != NOSEG) {
-      const double c = coord_of(cx, cy, cz, dec[sg].cd, p), cv = dec[sg].cv;
-      lt = c < cv; eq = (c <= cv) && !lt;
-    }
+    const bool lt = (sg != NOSEG) && (cs[it] < cvs[it]);
+    const bool eq = (sg != NOSEG) && (cs[it] <= cvs[it]) && !lt;
     unsigned long long todo = __ballot(sg != NOSEG);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;

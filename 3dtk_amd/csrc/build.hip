@@ -227,7 +227,7 @@ __global__ void k_emit(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, c
 // ---- per node: how many of its points lie below the split value (the position of the split) ---------------
 // Order-independent, so no prefix sum is needed for it: a wave covers 1024 consecutive positions, nodes are
 // contiguous runs of positions, one 32-bit atomicAdd per run.
-#define CNT_ITERS 16
+#define CNT_ITERS 8
 __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
                                                const uint32_t* __restrict__ axis, const double* __restrict__ splitval,
                                                const double* __restrict__ cx, const double* __restrict__ cy,
@@ -235,25 +235,34 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ seg_
 {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t base = (blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE) * (WAVE * CNT_ITERS);
-  uint32_t sgs[CNT_ITERS];
+  // the loads of all CNT_ITERS rows are issued phase by phase (label -> node kind / axis / split value -> coordinate),
+  // each phase CNT_ITERS independent loads deep: with 80 waves for an 81K-point scan the kernel is pure latency
+  uint32_t sgs[CNT_ITERS], axs[CNT_ITERS];
+  double svs[CNT_ITERS], cs[CNT_ITERS];
 #pragma unroll
   for (int it = 0; it < CNT_ITERS; it++) {
     const uint32_t p = base + (uint32_t)it * WAVE + lane;
-    uint32_t sg = (p < M) ? seg_of[p] : 0xFFFFFFFFu;
-    if (sg != 0xFFFFFFFFu && !kind[sg]) sg = 0xFFFFFFFFu;
-    sgs[it] = sg;
+    sgs[it] = (p < M) ? seg_of[p] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int it = 0; it < CNT_ITERS; it++)
+    if (sgs[it] != 0xFFFFFFFFu && !kind[sgs[it]]) sgs[it] = 0xFFFFFFFFu;
+#pragma unroll
+  for (int it = 0; it < CNT_ITERS; it++) {
+    axs[it] = 0; svs[it] = 0.0;
+    if (sgs[it] != 0xFFFFFFFFu) { axs[it] = axis[sgs[it]]; svs[it] = splitval[sgs[it]]; }
+  }
+#pragma unroll
+  for (int it = 0; it < CNT_ITERS; it++) {
+    const uint32_t p = base + (uint32_t)it * WAVE + lane;
+    cs[it] = 0.0;
+    if (sgs[it] != 0xFFFFFFFFu) cs[it] = (axs[it] == 0) ? cx[p] : ((axs[it] == 1) ? cy[p] : cz[p]);
   }
   uint32_t pend = 0xFFFFFFFFu, pcnt = 0;
 #pragma unroll
   for (int it = 0; it < CNT_ITERS; it++) {
-    const uint32_t p = base + (uint32_t)it * WAVE + lane;
     const uint32_t sg = sgs[it];
-    bool lt = false;
-    if (sg != 0xFFFFFFFFu) {
-      const uint32_t ax = axis[sg];
-      const double c = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
-      lt = c < splitval[sg];
-    }
+    const bool lt = (sg != 0xFFFFFFFFu) && (cs[it] < svs[it]);
     unsigned long long todo = __ballot(sg != 0xFFFFFFFFu);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
