@@ -18,12 +18,15 @@ from oracle import orc  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--big", action="store_true", help="clouds of 30K..400K points (fewer rounds)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 
 
 def cloud():
     n = int(rng.choice([1, 2, 3, 7, 10, 11, 33, 64, 65, 66, 128, 129, 300, 1000, 4097, 20000]))
+    if a.big:
+        n = int(rng.choice([30000, 65537, 131072, 200001, 400000]))
     kind = rng.integers(0, 9)
     if kind == 0:
         p = rng.uniform(-100, 100, (n, 3))
