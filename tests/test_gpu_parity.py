@@ -1152,3 +1152,16 @@ def test_get_pt_pairs_empty_range_with_normals(tdtk, gpu):
     for mode in (0, 1, 2):
         r = kd.getPtPairs(tdtk.M4identity(), q, nr, 4, 4, pairing_mode=mode)
         assert r["n"] == 0 and len(r["idx"]) == 0
+
+
+@pytest.mark.parametrize("n", [1000, 1001, 2])
+def test_find_closest_dev_odd_and_tiny_batches(tdtk, orc, gpu, n):
+    """regression: batches whose size is not a multiple of the grouped kernel's lanes-per-query, and a 2-query batch
+    (a KAT-sized call), through every host-buffer entry point that bins queries"""
+    rng = np.random.default_rng(n)
+    m = rng.uniform(-10, 10, (5000, 3))
+    kd, T = tdtk.KDtree(m, 5), orc.Tree(m, 5)
+    q = m[rng.integers(0, len(m), n)] + rng.normal(0, 0.3, (n, 3))
+    gi, gd = kd.FindClosestBatch(q, 4.0)
+    oi, od = T.find_closest(q, 4.0)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
