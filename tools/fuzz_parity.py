@@ -128,5 +128,39 @@ while time.time() - t0 < a.seconds:
             print("ICP MISMATCH run %d algo=%d nm=%d it=%s/%s pairs=%s/%s dT=%g" % (
                 runs, algo, nm, it, oit, [int(r[0]) for r in icp.last["trace"]][:4], [t[0] for t in otr][:4],
                 np.abs(S[1].get_transMat() - O[1].transMat).max()), flush=True)
+    # one in twenty: a random life of two resident scans (moves before / after going resident, tree built late,
+    # pose extrapolation, whole-scan pair passes) against the oracle's host-side scans -- points bit for bit
+    if runs % 20 == 0 and n >= 33:
+        from oracle import icp_oracle as io
+        ra, rb = rng.uniform(-5, 5, 3), rng.uniform(-0.2, 0.2, 3)
+        qa = p[rng.permutation(n)[: max(10, n // 2)]] + rng.normal(0, 0.1, (max(10, n // 2), 3))
+        S = [tdtk.Scan([0, 0, 0], [0, 0, 0], p, bucketSize=int(bucket)), tdtk.Scan(ra, rb, qa)]
+        O = [io.OScan([0, 0, 0], [0, 0, 0], p, None, int(bucket)), io.OScan(ra, rb, qa)]
+        ok = True
+        for step in range(int(rng.integers(3, 9))):
+            op = int(rng.integers(0, 6))
+            k = int(rng.integers(0, 2))
+            if op == 0:
+                X = tdtk.EulerToMatrix4(rng.uniform(-1, 1, 3), rng.uniform(-0.05, 0.05, 3))
+                S[k].transform(X); O[k].transform(X)
+            elif op == 1:
+                _ = S[k].handle                       # go resident now
+            elif op == 2:
+                S[1].mergeCoordinatesWithRoboterPosition(S[0]); O[1].mergeCoordinatesWithRoboterPosition(O[0])
+            elif op == 3:
+                r = tdtk.Scan.getPtPairs(S[0], S[1], max_dist_match2=md2p)
+                o = io.get_pt_pairs(O[0], O[1], md2p)
+                ok = ok and r["n"] == o["n"] and abs(r["sum"] - o["sum"]) <= 1e-9 * max(1e-300, abs(o["sum"]))
+            elif op == 4:
+                rP, rT = rng.uniform(-3, 3, 3), rng.uniform(-0.1, 0.1, 3)
+                S[k].transformToEuler(rP, rT); O[k].transformToEuler(rP, rT)
+            else:
+                ok = ok and np.array_equal(S[k].get_xyz_reduced(), O[k].xyz)
+        for k in range(2):
+            ok = ok and np.array_equal(S[k].get_xyz_reduced(), O[k].xyz) and np.array_equal(S[k].get_transMat(), O[k].transMat)
+        if not ok:
+            fails += 1
+            np.save("gpurun_out/fuzz_fail_life_%d.npy" % runs, p)
+            print("SCAN LIFE MISMATCH run %d n=%d" % (runs, n), flush=True)
 print("fuzz: %d clouds, %d mismatches, %.0f s, seed %d" % (runs, fails, time.time() - t0, a.seed))
 sys.exit(1 if fails else 0)
