@@ -583,3 +583,96 @@ size_t orc_octree_center(const double *xyz, size_t n, double voxel, double *out)
   free(idx);
   return C.n_out;
 }
+
+/* ------------------------------------------------------------------ */
+/* Packet traversal study (analysis / test infrastructure only): G consecutive queries walk the tree TOGETHER, a    */
+/* node is visited if any of them needs it, every query prunes with its own current best.  The reference's answer   */
+/* for a query is argmin over points with d2 < maxdist2 of (d2, position in the query's own near-first depth-first  */
+/* order); the walk order of the packet differs from that order, so (a) pruning is relaxed to strict '>' (a subtree  */
+/* at exactly the current best distance may hold the tie that comes first) and (b) ties are broken by the path key: */
+/* bit (63 - level) = 1 where the path takes the query's FAR child, then the position inside the bucket.            */
+/* Returns the same indices as orc_find_closest (checked in tests); counts what a wave-wide walk would touch.       */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  const orc_tree *t;
+  const double *q;      /* G queries */
+  int G;
+  double maxd2;
+  double best[64];
+  int bk[64];
+  unsigned long long key[64], bkey[64];
+  int bpos[64];
+  long n_int, n_leaf, n_pts, lane_pts;
+} pk_state;
+
+static void pk_visit(pk_state *S, const orc_node *nd, unsigned long long mask, int depth)
+{
+  if (nd->isleaf) {
+    S->n_leaf++;
+    S->n_pts += nd->npts;
+    for (int i = 0; i < nd->npts; i++)
+      for (int l = 0; l < S->G; l++) {
+        if (!((mask >> l) & 1ull)) continue;
+        S->lane_pts++;
+        const double d2 = dist2(S->q + 3 * l, S->t->xyz + 3 * (size_t)nd->p[i]);
+        int take = 0;
+        if (d2 < S->best[l]) take = 1;
+        else if (d2 == S->best[l] && S->bk[l] >= 0 &&
+                 (S->key[l] < S->bkey[l] || (S->key[l] == S->bkey[l] && i < S->bpos[l]))) take = 1;
+        if (take) { S->best[l] = d2; S->bk[l] = nd->p[i]; S->bkey[l] = S->key[l]; S->bpos[l] = i; }
+      }
+    return;
+  }
+  S->n_int++;
+  unsigned long long m = 0, near1 = 0;
+  double m2[64];
+  for (int l = 0; l < S->G; l++) {
+    if (!((mask >> l) & 1ull)) continue;
+    const double *p = S->q + 3 * l;
+    double a = fabs(p[0] - nd->center[0]) - nd->dx;
+    double b = fabs(p[1] - nd->center[1]) - nd->dy;
+    double c = fabs(p[2] - nd->center[2]) - nd->dz;
+    double ab = (a < b) ? b : a;
+    double approx = (ab < c) ? c : ab;
+    if (approx >= 0 && approx * approx > S->best[l]) continue;        /* relaxed: '>' where the reference has '>=' */
+    m |= 1ull << l;
+    const double myd = nd->splitval - p[nd->splitaxis];
+    m2[l] = myd * myd;
+    if (myd >= 0.0) near1 |= 1ull << l;
+  }
+  if (!m) return;
+  const int first_is_1 = __builtin_popcountll(near1 & m) * 2 >= __builtin_popcountll(m);
+  for (int pass = 0; pass < 2; pass++) {
+    const int c1 = (pass == 0) ? first_is_1 : !first_is_1;            /* this pass walks child1? */
+    unsigned long long sub = 0;
+    for (int l = 0; l < S->G; l++) {
+      if (!((m >> l) & 1ull)) continue;
+      const int is_near = (((near1 >> l) & 1ull) != 0) == (c1 != 0);
+      if (!is_near && m2[l] > S->best[l]) continue;                   /* relaxed plane test, with the CURRENT best */
+      sub |= 1ull << l;
+      const unsigned long long bit = 1ull << (63 - depth);
+      S->key[l] = (S->key[l] & ~((bit << 1) - 1ull)) | (is_near ? 0ull : bit);
+    }
+    if (sub) pk_visit(S, c1 ? nd->child1 : nd->child2, sub, depth + 1);
+  }
+}
+
+/* q: K queries in the order in which they are grouped (G <= 64 consecutive ones form a packet);
+ * counters[0..3] += nodes, buckets, bucket points the packets touch, and point tests summed over lanes */
+int orc_packet_find_closest(const orc_tree *t, const double *q, size_t K, int G, double maxdist2, int32_t *idx,
+                            double *d2, long *counters)
+{
+  if (G < 1 || G > 64 || t->max_depth > 63) return -1;
+  pk_state S;
+  S.t = t; S.maxd2 = maxdist2;
+  S.n_int = S.n_leaf = S.n_pts = S.lane_pts = 0;
+  for (size_t base = 0; base < K; base += (size_t)G) {
+    S.G = (int)((K - base < (size_t)G) ? (K - base) : (size_t)G);
+    S.q = q + 3 * base;
+    for (int l = 0; l < S.G; l++) { S.best[l] = maxdist2; S.bk[l] = -1; S.key[l] = 0; S.bkey[l] = 0; S.bpos[l] = 0; }
+    pk_visit(&S, t->root, (S.G == 64) ? ~0ull : ((1ull << S.G) - 1ull), 0);
+    for (int l = 0; l < S.G; l++) { idx[base + l] = S.bk[l]; if (d2) d2[base + l] = S.best[l]; }
+  }
+  if (counters) { counters[0] += S.n_int; counters[1] += S.n_leaf; counters[2] += S.n_pts; counters[3] += S.lane_pts; }
+  return 0;
+}

@@ -70,6 +70,8 @@ def lib():
         L.orc_octree_center.argtypes = [_dp, C.c_size_t, C.c_double, _dp]
         L.orc_k5_hash.restype = C.c_uint64
         L.orc_k5_hash.argtypes = [_ip, C.c_size_t]
+        L.orc_packet_find_closest.restype = C.c_int
+        L.orc_packet_find_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, C.c_double, _ip, _dp, _lp]
         L.orc_ann_create.restype = C.c_void_p
         L.orc_ann_create.argtypes = [_dp, C.c_int]
         L.orc_ann_destroy.argtypes = [C.c_void_p]
@@ -162,6 +164,17 @@ class Tree:
         if want_counters:
             return idx, d2, (cnt[0], cnt[1], cnt[2])
         return idx, d2
+
+    def packet_find_closest(self, q, maxdist2, group=64):
+        """Analysis only (oracle.c, "Packet traversal study"): `group` consecutive queries walk the tree together;
+        returns (idx, d2, (nodes, buckets, bucket points, point tests summed over lanes) touched by the packets)."""
+        q = _c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        cnt = (C.c_long * 4)(0, 0, 0, 0)
+        if lib().orc_packet_find_closest(self.h, _d(q), len(q), int(group), float(maxdist2), _i(idx), _d(d2), cnt):
+            raise RuntimeError("packet study: group must be 1..64 and the tree at most 63 levels deep")
+        return idx, d2, (cnt[0], cnt[1], cnt[2], cnt[3])
 
     def find_closest_along_dir(self, q, dirs, maxdist2):
         q = _c(q).reshape(-1, 3)

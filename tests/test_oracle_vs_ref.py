@@ -291,3 +291,23 @@ def test_ann_search_errors(orc):
     t = orc.AnnTree(np.random.default_rng(0).uniform(-1, 1, (5, 3)))
     with pytest.raises(RuntimeError):
         t.ksearch(np.zeros((1, 3)), 6, 1.0)          # "Requesting more near neighbors than data points"
+
+
+@pytest.mark.parametrize("group", [64, 7, 1])
+def test_visiting_order_free_traversal_is_exact(orc, group):
+    """The reference's answer is argmin over points with d2 < maxdist2 of (d2, rank in the query's own near-first
+    depth-first order).  A walk in ANY other order returns the same index if it prunes with strict '>' and breaks
+    exact distance ties by the path key (far-child bits, most significant = root) and the position in the bucket --
+    shown here with several queries walking the tree together on clouds where ties are the rule."""
+    rng = np.random.default_rng(group)
+    g = np.stack(np.meshgrid(np.arange(14.0), np.arange(14.0), np.arange(14.0)), -1).reshape(-1, 3)
+    d = rng.uniform(-10, 10, (1500, 3))
+    clouds = {"lattice": (g, np.concatenate([g[:1500] + 0.5, g[:1500] + [0.5, 0, 0], g[:800], g[:800] + [0, 0.5, 0.5]]), 4.0),
+              "duplicates": (np.concatenate([d, d, d]), np.concatenate([d, d + rng.normal(0, 0.3, d.shape)]), 1.0),
+              "uniform": (rng.uniform(-50, 50, (20000, 3)), rng.uniform(-55, 55, (4000, 3)), 25.0)}
+    for name, (m, q, md2) in clouds.items():
+        for bucket in (1, 20):
+            T = orc.Tree(m, bucket)
+            oi, od = T.find_closest(q, md2)
+            pi, pd, _ = T.packet_find_closest(q, md2, group)
+            assert np.array_equal(pi, oi) and np.array_equal(pd, od), (name, bucket)
