@@ -562,7 +562,7 @@ static void finish_sums(const double* acc, const double shift[3], size_t nq, uns
 // search + accumulate over a resident scan.  acc_out (host, ACC_TOTAL) receives raw columns.
 static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, int pmode,
                      double maxd2, unsigned want, const double* lum_D, const double* pending,
-                     bool do_search, double* acc_out, double shift_out[3])
+                     bool do_search, double* acc_out, double shift_out[3], bool warm = false)
 {
   hipStream_t s = c->stream;
   const size_t N = data->N;
@@ -581,6 +581,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.inv = inv; sa.has_inv = 1;
     sa.maxd2 = maxd2;
     sa.kpos = c->ws[WS_KPOS].as<int>();
+    sa.warm = (warm && pmode != 1) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
     sa.d2 = nullptr;
     rc = run_search(c, model, sa, pmode == 1 ? 1 : 0, false, s, true);
     if (rc) return rc;
@@ -1335,13 +1336,15 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   const double t0 = now_ms();
   int iter = 0;
   int converged = 0;
+  const char* warm_env = getenv("TDTK_WARM_START");
+  const bool warm_ok = !(warm_env && warm_env[0] == '0');
   for (iter = 0; iter < prm->max_num_iterations; iter++) {
     prev_prev_ret = prev_ret;
     prev_ret = ret;
     double acc[ACC_TOTAL], shift[3];
     // the previous iteration's alignxf is applied to the points inside the search kernel
     rc = scan_pass(c, model, model_dalignxf, data, pmode, prm->max_dist_match2, want, nullptr,
-                   have_pending ? pend : nullptr, true, acc, shift);
+                   have_pending ? pend : nullptr, true, acc, shift, iter > 0 && warm_ok);
     if (rc) return rc;
     have_pending = false;
     double ms = 0;

@@ -28,6 +28,8 @@ struct SearchArgs {
   Mat4 inv;      // M4inv(Source->dalignxf): world -> tree frame
   int has_pending, has_inv;
   double maxd2;
+  int warm;     // kpos holds the previous pass's hits of the SAME queries in the SAME tree: start each search with
+                // a radius just above the distance to that point (see warm_radius in kernels.hip)
   int* kpos;    // out: position of the hit in the leaf-ordered point array, or -1
   double* d2;   // out, nullable
   double* ovf_m2;  // stack overflow area (nullable when max_depth-1 <= LDS depth)

@@ -156,6 +156,28 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
   return first ? r1 : r2;
 }
 
+// Warm start of a repeated pass (ICP iteration i+1 over the scan iteration i has just searched): the previous hit is a
+// real point of the tree, so the nearest point is at most that far away, and starting with closest_d2 one ulp ABOVE
+// its squared distance (instead of maxdist2) cannot lose it: every test of the traversal prunes only what lies at
+// or beyond closest_d2, the walk order is unchanged, and whatever the reference would have visited before reaching a
+// point at that distance it still visits.  Same index, same d2 -- from a radius of a few units instead of 25.
+static __device__ __forceinline__ double warm_radius(const SearchArgs& a, const size_t i, const double qx, const double qy,
+                                                     const double qz)
+{
+  double best = a.maxd2;
+  if (a.warm) {
+    const int kp = a.kpos[i];
+    if (kp >= 0) {
+      const double4 p = reinterpret_cast<const double4*>(a.T.pts)[kp];
+      const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+      const double d = dx * dx + dy * dy + dz * dz;
+      const double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
+      if (up < best) best = up;
+    }
+  }
+  return best;
+}
+
 template <int BLOCK, int SD, bool COUNT, bool UNI, int PTS = 4>
 __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, const double qy,
                                           const double qz, double& best, int& bk,
@@ -600,7 +622,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
         if (a.has_inv) dev_xf3normal(a.inv, ux, uy, uz);
       }
     }
-    double best = a.maxd2;
+    double best = DIRMODE ? a.maxd2 : warm_radius(a, i, sx, sy, sz);
     int bk = -1;
     if (DIRMODE) kd_search_dir<BLOCK, SD>(a.T, sx, sy, sz, ux, uy, uz, best, bk, st);
     else kd_search<BLOCK, SD, COUNT, UNI, PTS>(a.T, sx, sy, sz, best, bk, st, a.counters);
@@ -663,7 +685,7 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
     }
     double qx = tx, qy = ty, qz = tz;
     if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
-    double best = a.maxd2;
+    double best = warm_radius(a, i, qx, qy, qz);
     int bk = -1;
     uint32_t cur = T.root_ref;
     st.sp = 0;
@@ -801,7 +823,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         qx = tx; qy = ty; qz = tz;
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
         qi = mine; have = true;
-        cur = T.root_ref; best = a.maxd2; bk = -1; st.sp = 0;
+        cur = T.root_ref; best = warm_radius(a, mine, qx, qy, qz); bk = -1; st.sp = 0;
       }
       next_q += (size_t)__popcll(idlem);
     }
