@@ -17,6 +17,10 @@ Fixtures written:
   b4_dat_lum.json   LUM link systems at the B1 final poses (-D 25)
   k6_serial_minimizers.json  reference icp6D_{ORTHO,DUAL,HELIX,LUMEULER,LUMQUAT,QUAT_SCALE}::Align
                     (-a 3,4,5,7,8,9) on the K6 clouds; `python make_golden.py k6s` regenerates only this
+  b1_dat_icp_idx.json  the correspondence indices behind B1 (SURVEY 8(c) "still to generate"): the stored alignxf
+                    sequence is replayed and at every iteration the REFERENCE KDtreeIndexed answers the whole data
+                    scan; per iteration the XOR hash of the index array, for the first and last iteration of each pair
+                    also the first / last 100 indices; `python make_golden.py b1idx` regenerates only this
   k7_ann_normals.npz  Scan::calcNormals = calculateNormalsApxKNN(k = 10, eps = 1.0): the vendored ANN library's
                     k-NN lists and the normals (real annkSearch + real newmat EigenValues through
                     oracle/ref_ann_driver.cc) for the first 6000 points of dat/scan000 and for a seeded noisy
@@ -90,9 +94,37 @@ def gen_k7_ann():
     np.savez_compressed(os.path.join(HERE, "k7_ann_normals.npz"), **out)
 
 
+def gen_b1_idx():
+    """Needs dat_scans.npz and b1_dat_icp.json (written by the full run)."""
+    z = np.load(os.path.join(HERE, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(HERE, "b1_dat_icp.json")))
+    S = [io.OScan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], z["scan%03d" % k]) for k in range(3)]
+    out = {"maxdist2": 625.0, "pairs": []}
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        R = orc.RefTree(S[i - 1].xyz_orig, 20)                 # the tree lives in the frame of "xyz reduced original"
+        inv, _ = orc.m4inv(S[i - 1].dalignxf)                  # searchTree.cc:110,122
+        rows = []
+        for it, a in enumerate(pr["alignxf"]):
+            q = S[i].xyz.copy(); orc.transform_points(inv, q)
+            idx = R.find_closest(q, 625.0, 8)
+            row = {"found": int((idx >= 0).sum()), "hash": "0x%x" % orc.k5_hash(idx)}
+            if it in (0, len(pr["alignxf"]) - 1):
+                row["first100"] = idx[:100].tolist(); row["last100"] = idx[-100:].tolist()
+            assert row["found"] == pr["trace"][it][0], (row["found"], pr["trace"][it][0])
+            rows.append(row)
+            S[i].transform(np.array(a))
+        out["pairs"].append({"prev": i - 1, "cur": i, "iterations": rows})
+        print("B1idx pair", i, len(rows), rows[0]["hash"], rows[-1]["hash"])
+    json.dump(out, open(os.path.join(HERE, "b1_dat_icp_idx.json"), "w"), indent=1)
+
+
 def main():
     assert orc.have_ref() or os.path.isdir(REF), "needs the reference checkout"
     orc.build()
+    if sys.argv[1:] == ["b1idx"]:
+        return gen_b1_idx()
     if sys.argv[1:] == ["k6s"]:
         return gen_k6_serial()
     if sys.argv[1:] == ["k7"]:
@@ -193,6 +225,7 @@ def main():
     print("B4 lum iteration ret", ret)
     json.dump(b4, open(os.path.join(HERE, "b4_dat_lum.json"), "w"), indent=1)
     gen_k7_ann()      # after dat_scans.npz has been written
+    gen_b1_idx()
 
 
 if __name__ == "__main__":

@@ -1165,3 +1165,23 @@ def test_find_closest_dev_odd_and_tiny_batches(tdtk, orc, gpu, n):
     gi, gd = kd.FindClosestBatch(q, 4.0)
     oi, od = T.find_closest(q, 4.0)
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_b1_correspondence_indices_every_iteration(tdtk, orc, gpu):
+    """B1 replayed on resident scans: at every one of the 39 + 50 ICP iterations the whole-scan pass returns exactly
+    the index array the REFERENCE KDtreeIndexed returned (hash per iteration, first / last 100 indices at the ends;
+    tests/golden/b1_dat_icp_idx.json)."""
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    bi = json.load(open(os.path.join(G, "b1_dat_icp_idx.json")))
+    S = _dat_scans(tdtk.Scan, z)
+    for pr, pi in zip(b1["pairs"], bi["pairs"]):
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        for it, a in enumerate(pr["alignxf"]):
+            r = tdtk.Scan.getPtPairs(S[i - 1], S[i], max_dist_match2=625.0, want_idx=True)
+            row = pi["iterations"][it]
+            assert r["n"] == row["found"] and "0x%x" % orc.k5_hash(r["idx"]) == row["hash"], (i, it)
+            if "first100" in row:
+                assert r["idx"][:100].tolist() == row["first100"] and r["idx"][-100:].tolist() == row["last100"]
+            S[i].transform(np.array(a))

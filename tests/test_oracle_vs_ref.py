@@ -311,3 +311,25 @@ def test_visiting_order_free_traversal_is_exact(orc, group):
             oi, od = T.find_closest(q, md2)
             pi, pd, _ = T.packet_find_closest(q, md2, group)
             assert np.array_equal(pi, oi) and np.array_equal(pd, od), (name, bucket)
+
+
+def test_b1_correspondence_indices_oracle(orc):
+    """B1 replayed on the oracle: at every ICP iteration the index array of the whole data scan hashes to what the
+    REFERENCE KDtreeIndexed returned (tests/golden/b1_dat_icp_idx.json), first / last 100 indices included."""
+    from oracle import icp_oracle as io
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    bi = json.load(open(os.path.join(G, "b1_dat_icp_idx.json")))
+    S = [io.OScan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], z["scan%03d" % k]) for k in range(3)]
+    for pr, pi in zip(b1["pairs"], bi["pairs"]):
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        inv, _ = orc.m4inv(S[i - 1].dalignxf)
+        for it, a in enumerate(pr["alignxf"]):
+            q = S[i].xyz.copy(); orc.transform_points(inv, q)
+            idx, _ = S[i - 1].tree().find_closest(q, 625.0)
+            row = pi["iterations"][it]
+            assert int((idx >= 0).sum()) == row["found"] and "0x%x" % orc.k5_hash(idx) == row["hash"], (i, it)
+            if "first100" in row:
+                assert idx[:100].tolist() == row["first100"] and idx[-100:].tolist() == row["last100"]
+            S[i].transform(np.array(a))
