@@ -487,3 +487,25 @@ def test_graph_netfile_chain_addlink(tdtk, tmp_path):
         b = cls(None, 25.0, 25.0)
         b.set_mdmll(10.0)
         assert b.max_dist_match2_LUM == 100.0
+
+
+def test_product_and_bench_keep_clear_of_the_oracle():
+    """oracle/ is test infrastructure: nothing under 3dtk_amd/, include/ or adapters/ may mention it, the shared
+    library must not link it, and bench.py may import it only inside its cpu_baseline legs."""
+    import re
+    for top in ("3dtk_amd", "include", "adapters"):
+        for dp, _dn, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".cc")) or f == "Makefile":
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    assert not re.search(r"\boracle\b|liboracle|libref3dtk", txt), os.path.join(dp, f)
+    so = os.path.join(ROOT, "3dtk_amd", "lib3dtk_hip.so")
+    if os.path.exists(so):
+        needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+        assert "liboracle" not in needed and "libref3dtk" not in needed
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)from oracle import", src, re.M):
+        head = src[:m.start()]
+        fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
+        ctx = head[head.rfind("\ndef "):]
+        assert fn == "cpu_baseline_nn" or "no_cpu" in ctx[ctx.rfind("if "):], (fn, m.group(0))
