@@ -1114,9 +1114,13 @@ def test_bench_graphslam_two_ranks_on_this_box(gpu):
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port on this box
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, TDTK_BENCH_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.join(root, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                           "--gpus", "2"] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
