@@ -281,7 +281,11 @@ def test_lum_links_sharded_over_two_ranks_gloo(tmp_path, orc):
     from oracle import icp_oracle as io
     script = tmp_path / "w.py"
     script.write_text(_GLOO_WORKER % {"root": ROOT, "tmp": str(tmp_path)})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port on this box
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
