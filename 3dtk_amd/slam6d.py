@@ -525,9 +525,15 @@ def read_pose(path):
 ALGO_TYPE = {"INVALID": 0, "ICP": 1, "ICPINACTIVE": 2, "LUM": 3, "ELCH": 4}   # scan.h:126
 
 
-def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSize=20, device=0, red=-1.0):
+def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSize=20, device=0, red=-1.0,
+                  use_normals=False):
     """Scan::openDirectory for the uos format (src/slam6d/scan.cc / basicScan.cc:39-122):
-    scanNNN.3d + scanNNN.pose, NNN = start..end; red = -r voxel size (setReductionParameter)."""
+    scanNNN.3d + scanNNN.pose, NNN = start..end; red = -r voxel size (setReductionParameter).
+    use_normals = what slam6D.cc:688-692 asks for with -z / --normal_shoot-simple (PointType::USE_NORMAL): every
+    scan gets Scan::calcNormals.  Not together with red > 0: the reference's centre-mode octree reduction does not
+    carry normals (it copies POINTDIM values out of a 3-element centre, Boctree.h:928-941)."""
+    if use_normals and red > 0:
+        raise ValueError("normals are not carried through the octree reduction (see DESIGN.md section 9)")
     import os
     scans = []
     i = start
@@ -541,6 +547,8 @@ def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSiz
         if red > 0:
             pts = calcReducedPoints(pts, red, device)
         s = Scan(rP, rT, pts, bucketSize=bucketSize, device=device)
+        if use_normals:
+            s.calcNormals()
         s.identifier = "%03d" % i
         s.path = path
         scans.append(s)

@@ -1189,3 +1189,24 @@ def test_b1_correspondence_indices_every_iteration(tdtk, orc, gpu):
             if "first100" in row:
                 assert r["idx"][:100].tolist() == row["first100"] and r["idx"][-100:].tolist() == row["last100"]
             S[i].transform(np.array(a))
+
+
+def test_open_directory_with_normals(tdtk, orc, gpu, tmp_path):
+    """openDirectory(..., use_normals=True): uos files on disk -> range filter -> Scan::calcNormals per scan, equal to
+    the oracle on the same filtered points; refused together with -r (the reference cannot carry them either)."""
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    for k in range(2):
+        pts, pose = z["scan%03d" % k][:5000], z["pose%03d" % k]
+        with open(tmp_path / ("scan%03d.3d" % k), "w") as f:
+            for p in pts:
+                f.write("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
+        with open(tmp_path / ("scan%03d.pose" % k), "w") as f:
+            f.write("%r %r %r\n%r %r %r\n" % (*[float(v) for v in pose[:3]], *[float(np.degrees(v)) for v in pose[3:]]))
+    scans = tdtk.openDirectory(str(tmp_path), 0, 1, range_max=500.0, use_normals=True)
+    assert len(scans) == 2
+    for k, s in enumerate(scans):
+        pts = _range_filter(z["scan%03d" % k][:5000], 500.0)
+        assert np.array_equal(s._local, pts)
+        assert np.array_equal(s._local_n, orc.normals_apx_knn(pts, 10, s.rPos, 1.0))
+    with pytest.raises(ValueError):
+        tdtk.openDirectory(str(tmp_path), 0, 1, red=10.0, use_normals=True)
