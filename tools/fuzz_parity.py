@@ -162,5 +162,39 @@ while time.time() - t0 < a.seconds:
             fails += 1
             np.save("gpurun_out/fuzz_fail_life_%d.npy" % runs, p)
             print("SCAN LIFE MISMATCH run %d n=%d" % (runs, n), flush=True)
+    # one in forty: a small pose graph (chain + a closure) through one iteration of each graph-SLAM back-end
+    if runs % 40 == 0:
+        from oracle import icp_oracle as io
+        nsc = int(rng.integers(4, 7))
+        world = rng.uniform(-40, 40, (3000, 3)); world[:, 2] *= 0.4
+        poses = [(np.array([3.0 * k, 0.4 * k, -0.2 * k]) + rng.normal(0, 0.2, 3), rng.normal(0, 0.01, 3) + [0.0, 0.0, 0.01 * k])
+                 for k in range(nsc)]
+        raws = []
+        for (pp, th) in poses:
+            inv, _ = orc.m4inv(io.euler_to_matrix4(pp, th))
+            loc = world[rng.permutation(len(world))[:2000]].copy(); orc.transform_points(inv, loc)
+            drift = (pp + rng.normal(0, 0.15, 3), th + rng.normal(0, 0.003, 3))
+            raws.append((drift[0], drift[1], loc + rng.normal(0, 0.02, loc.shape)))
+        links = [(k, k + 1) for k in range(nsc - 1)] + [(0, nsc - 1)] + ([(1, nsc - 1)] if rng.random() < 0.5 else [])
+        for name in ("lum6DEuler", "lum6DQuat", "ghelix6DQ2", "gapx6D"):
+            S = [tdtk.Scan(p_, t_, l_) for (p_, t_, l_) in raws]
+            O = [io.OScan(p_, t_, l_) for (p_, t_, l_) in raws]
+            gr = tdtk.Graph(nsc, links=links)
+            ret = getattr(tdtk, name)(None, 5.0, 5.0, epsilonLUM=-1.0).doGraphSlam6D(gr, S, 1)
+            if name == "lum6DEuler":
+                oret = io.lum_iteration(links, O, 25.0)[0]
+            elif name == "lum6DQuat":
+                oret = io.lumquat_iteration(links, O, 25.0)
+                oret = oret[0] if isinstance(oret, tuple) else oret
+            elif name == "ghelix6DQ2":
+                oret = io.ghelix_iteration(links, O, 25.0)[0]
+            else:
+                oret = io.gapx_iteration(links, O, 25.0)[0]
+            ok = abs(ret - oret) <= 1e-6 * max(1.0, abs(oret))
+            for s_, o_ in zip(S, O):
+                ok = ok and np.abs(s_.get_transMat() - o_.transMat).max() <= 1e-6 * max(1.0, np.abs(o_.transMat).max())
+            if not ok:
+                fails += 1
+                print("GRAPH MISMATCH run %d %s scans=%d links=%d ret %g / %g" % (runs, name, nsc, len(links), ret, oret), flush=True)
 print("fuzz: %d clouds, %d mismatches, %.0f s, seed %d" % (runs, fails, time.time() - t0, a.seed))
 sys.exit(1 if fails else 0)
