@@ -648,6 +648,8 @@ class icp6D_QUAT_SCALE(icp6Dminimizer):  # src/slam6d/icp6Dquatscale.cc, -a 9
 # icp6D (include/slam6d/icp6D.h, src/slam6d/icp6D.cc)
 # ---------------------------------------------------------------------------------------
 class icp6D:
+    prefetch_depth = 2      # scans prepared ahead of the one being matched in doICP (own host threads / streams)
+
     def __init__(self, my_icp6Dminimizer, max_dist_match=25.0, max_num_iterations=50, quiet=False,
                  meta=False, rnd=1, eP=True, anim=-1, epsilonICP=0.0000001, nns_method=0,
                  max_num_metascans=-1):
@@ -746,7 +748,7 @@ class icp6D:
         pool = None
         if prefetch and not self.meta and len(allScans) > 2:
             from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(1)
+            pool = ThreadPoolExecutor(self.prefetch_depth)
 
         def prep(s):
             _ = s.handle
@@ -760,8 +762,11 @@ class icp6D:
                 if pool is not None:
                     if i in pending:
                         pending.pop(i).result()
-                    if i + 1 < len(allScans):
-                        pending[i + 1] = pool.submit(prep, allScans[i + 1])
+                    # a tree build is a chain of dependent adds on a few wavefronts: two of them in flight (scans
+                    # i+1, i+2) cost the running match nothing and take the build off the critical path
+                    for j in range(i + 1, min(i + 1 + self.prefetch_depth, len(allScans))):
+                        if j not in pending and allScans[j]._h is None:
+                            pending[j] = pool.submit(prep, allScans[j])
                 if i > 0:
                     prev = allScans[i - 1]
                     if self.eP:
@@ -1068,7 +1073,8 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
     # the next scan is uploaded and its tree built on a second host thread while the current one is matched
     # (see icp6D.doICP); scan i+1 is not part of the graph of scans 0..i, so the global rounds do not touch it
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(1) if (prefetch and n > 2) else None
+    depth = icp6D.prefetch_depth
+    pool = ThreadPoolExecutor(depth) if (prefetch and n > 2) else None
 
     def prep(s):
         _ = s.handle
@@ -1079,8 +1085,9 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
             if pool is not None:
                 if i in pending:
                     pending.pop(i).result()
-                if i + 1 < n:
-                    pending[i + 1] = pool.submit(prep, allScans[i + 1])
+                for j in range(i + 1, min(i + 1 + depth, n)):
+                    if j not in pending and allScans[j]._h is None:
+                        pending[j] = pool.submit(prep, allScans[j])
             if eP:
                 allScans[i].mergeCoordinatesWithRoboterPosition(allScans[i - 1])
             if my_icp6D is not None:
