@@ -648,7 +648,7 @@ class icp6D_QUAT_SCALE(icp6Dminimizer):  # src/slam6d/icp6Dquatscale.cc, -a 9
 # icp6D (include/slam6d/icp6D.h, src/slam6d/icp6D.cc)
 # ---------------------------------------------------------------------------------------
 class icp6D:
-    prefetch_depth = 2      # scans prepared ahead of the one being matched in doICP (own host threads / streams)
+    prefetch_depth = 3      # scans prepared ahead of the one being matched in doICP (own host threads / streams)
 
     def __init__(self, my_icp6Dminimizer, max_dist_match=25.0, max_num_iterations=50, quiet=False,
                  meta=False, rnd=1, eP=True, anim=-1, epsilonICP=0.0000001, nns_method=0,
