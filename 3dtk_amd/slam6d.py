@@ -134,13 +134,17 @@ def transform_many(scans, A1, A2=None, type="LUM"):
         s.frames.append((s.transMat.copy(), type))
 
 
-def prepare_scans(scans, trees=True, threads=4):
+def prepare_scans(scans, trees=True, threads=4, normals=False):
     """Upload the scans and (trees=True) build their search trees on `threads` host threads, each with its
     own HIP stream.  A tree build is mostly a serial fp64 chain that occupies three wavefronts, so several
-    of them run side by side on one GPU at almost no cost to each other."""
+    of them run side by side on one GPU at almost no cost to each other.  normals=True first runs
+    Scan::calcNormals on every scan that has none (its ANN-tree build is a few hundred short launches: the same
+    argument holds)."""
     from concurrent.futures import ThreadPoolExecutor
 
     def prep(s):
+        if normals and s._local_n is None and s._h is None:
+            s.calcNormals()
         _ = s.handle
         if trees:
             s.getSearchTree()

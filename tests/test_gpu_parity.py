@@ -1210,3 +1210,15 @@ def test_open_directory_with_normals(tdtk, orc, gpu, tmp_path):
         assert np.array_equal(s._local_n, orc.normals_apx_knn(pts, 10, s.rPos, 1.0))
     with pytest.raises(ValueError):
         tdtk.openDirectory(str(tmp_path), 0, 1, red=10.0, use_normals=True)
+
+
+def test_prepare_scans_with_normals_concurrently(tdtk, orc, gpu):
+    """prepare_scans(normals=True) on 4 host threads: normals, upload and tree of several scans side by side -- the
+    same normals as the oracle, the same trees as a serial preparation."""
+    rng = np.random.default_rng(9)
+    clouds = [rng.uniform(-50, 50, (6000, 3)) * [1.0, 1.0, 0.1] + rng.normal(0, 0.05, (6000, 3)) for _ in range(6)]
+    S = [tdtk.Scan([0.5 * k, 0, 2.0], [0, 0, 0.01 * k], c) for k, c in enumerate(clouds)]
+    tdtk.prepare_scans(S, trees=True, threads=4, normals=True)
+    for k, s in enumerate(S):
+        assert np.array_equal(s._local_n, orc.normals_apx_knn(clouds[k], 10, s.rPos, 1.0))
+        assert s.getSearchTree().verify() == [0, 0, 0, 0]
