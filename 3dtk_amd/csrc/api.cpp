@@ -5,7 +5,6 @@
 
 #include <algorithm>
 #include <chrono>
-#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,9 +81,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   DevBuf ws[WS_COUNT];
-  double* h_pin = nullptr;  // pinned staging for the per-iteration sums (+ the completion mark behind them)
-  double poll_seq = 0.0;
-  bool ticket_ready = false;
+  double* h_pin = nullptr;  // pinned staging for the per-iteration sums
   double last_nn_ms = 0.0;
   bool ev_pending = false;
   std::vector<std::unique_ptr<Lane>> lanes;
@@ -611,30 +608,8 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   aa.partials = c->ws[WS_PART].as<double>();
   // k_final stores the 74 sums straight into pinned host memory (device-visible): no copy-engine hop
   // between the last kernel and the host solve, which matters when an iteration is ~100 us
-  // The host does not go to sleep in hipStreamSynchronize between two ICP iterations: the last workgroup of k_final
-  // writes a sequence mark behind the sums and the host spins on it (bounded; then the ordinary synchronize).
-  static const bool poll = [] { const char* e = getenv("TDTK_POLL"); return !(e && e[0] == '0'); }();
-  if (poll) {
-    if ((rc = c->ws[WS_CNT].ensure(256))) return rc;
-    if (!c->ticket_ready) {
-      HIPCHK(hipMemsetAsync(c->ws[WS_CNT].p, 0, 256, s));
-      c->ticket_ready = true;
-    }
-    c->poll_seq += 1.0;
-    volatile double* mark = c->h_pin + ACC_TOTAL;
-    HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s, c->ws[WS_CNT].as<unsigned int>() + 32, c->poll_seq));
-    const double t_end = now_ms() + 2.0;
-    bool seen = false;
-    for (int spin = 0;; spin++) {
-      if (*mark == c->poll_seq) { seen = true; break; }
-      if ((spin & 1023) == 1023 && now_ms() > t_end) break;
-    }
-    if (!seen) HIPCHK(hipStreamSynchronize(s));
-    std::atomic_thread_fence(std::memory_order_acquire);
-  } else {
-    HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s));
-    HIPCHK(hipStreamSynchronize(s));
-  }
+  HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s));
+  HIPCHK(hipStreamSynchronize(s));
   std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
   return TDTK_OK;
 }

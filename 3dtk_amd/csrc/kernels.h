@@ -97,9 +97,8 @@ int search_block();
 uint32_t accum_grid(size_t n);
 
 hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool count, hipStream_t s);
-// ticket / done_mark (nullable / ignored): the last workgroup of k_final stores done_mark into d_out[ACC_TOTAL] behind all sums
 hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pmode, double* d_out,
-                        hipStream_t s, unsigned int* ticket = nullptr, double done_mark = 0.0);
+                        hipStream_t s);
 hipError_t launch_transform(double* x, double* y, double* z, double* nx, double* ny, double* nz,
                             size_t n, const Mat4& A, hipStream_t s);
 hipError_t launch_bin(const BinArgs& b, hipStream_t s);

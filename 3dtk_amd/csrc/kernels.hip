@@ -1037,8 +1037,7 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
 // column; thread t adds rows t, t+256, ... then wave64 shuffles and a 4-entry LDS pass.  The
 // association is fixed by (rows, 256), so repeated runs give bit-identical sums.
 __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partials, int rows,
-                                               double* __restrict__ out, unsigned int* __restrict__ ticket,
-                                               double done_mark)
+                                               double* __restrict__ out)
 {
   __shared__ double red[4];
   const int k = blockIdx.x;
@@ -1047,18 +1046,7 @@ __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partia
   s = wave_sum(s);
   if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    out[k] = ((red[0] + red[1]) + red[2]) + red[3];
-    if (ticket) {
-      // `out` is host memory the CPU polls: the workgroup that finishes last publishes the mark behind all sums
-      __threadfence_system();
-      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-        *ticket = 0u;
-        __threadfence_system();
-        out[ACC_TOTAL] = done_mark;
-      }
-    }
-  }
+  if (threadIdx.x == 0) out[k] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1343,7 +1331,7 @@ static void launch_accum_w(const AccumArgs& a, uint32_t grid, int pmode, hipStre
 }
 
 hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pmode, double* d_out,
-                        hipStream_t s, unsigned int* ticket, double done_mark)
+                        hipStream_t s)
 {
   if (want & (TDTK_WANT_GAPX | TDTK_WANT_MOM2)) {  // both are the MM + DD columns on top of the base block
     launch_accum_w<TDTK_WANT_GAPX>(a, grid, pmode, s);
@@ -1358,7 +1346,7 @@ hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pm
     case 6: launch_accum_w<6>(a, grid, pmode, s); break;
     default: launch_accum_w<7>(a, grid, pmode, s); break;
   }
-  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, a.partials, (int)grid, d_out, ticket, done_mark);
+  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, a.partials, (int)grid, d_out);
   return hipGetLastError();
 }
 
