@@ -148,9 +148,10 @@ static __device__ __forceinline__ void meas_flush(AMeasU* __restrict__ out, uint
   }
 }
 
-__global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict__ seg_of, uint32_t M,
+__global__ void __launch_bounds__(256) k_ann_measure(uint32_t* __restrict__ seg_of, uint32_t M,
                                                      const double* __restrict__ cx, const double* __restrict__ cy,
-                                                     const double* __restrict__ cz, AMeasU* __restrict__ out)
+                                                     const double* __restrict__ cz, AMeasU* __restrict__ out,
+                                                     const ASeg* __restrict__ prev_segs, const ADec* __restrict__ prev_dec)
 {
   __shared__ uint32_t s_seg[4];
   __shared__ double s_mn[4][3], s_mx[4][3];
@@ -163,6 +164,19 @@ __global__ void __launch_bounds__(256) k_ann_measure(const uint32_t* __restrict_
   for (int it = 0; it < MEAS_ITERS; it++) {
     const uint32_t p = base + (uint32_t)it * WAVE + lane;
     sgs[it] = (p < M) ? seg_of[p] : NOSEG;
+  }
+  if (prev_segs) {
+    // the labels still name the cells of the previous level: move every position to the child cell it fell into
+    // (k_ann_children left the children's slots in dec) -- what a separate relabel pass over all positions did
+#pragma unroll
+    for (int it = 0; it < MEAS_ITERS; it++) {
+      const uint32_t p = base + (uint32_t)it * WAVE + lane;
+      if (sgs[it] != NOSEG) {
+        const uint32_t sg = sgs[it];
+        sgs[it] = ((p - prev_segs[sg].start) < prev_dec[sg].n_lo) ? prev_dec[sg].slot0 : prev_dec[sg].slot1;
+        seg_of[p] = sgs[it];
+      }
+    }
   }
 #pragma unroll
   for (int it = 0; it < MEAS_ITERS; it++) {
@@ -440,16 +454,6 @@ __global__ void k_ann_children(const ASeg* __restrict__ segs, const uint32_t* __
   d.n_lo = n_lo; d.slot0 = slot[0]; d.slot1 = slot[1];
   dec[i] = d;
 }
-__global__ void k_ann_relabel(const ASeg* __restrict__ segs, const ADec* __restrict__ dec, uint32_t M,
-                              uint32_t* __restrict__ seg_of)
-{
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= M) return;
-  const uint32_t sg = seg_of[p];
-  if (sg == NOSEG) return;
-  seg_of[p] = ((p - segs[sg].start) < dec[sg].n_lo) ? dec[sg].slot0 : dec[sg].slot1;
-}
-
 // ---- small cells: one wavefront per cell, one lane per point --------------------------------------
 // Once a cell holds <= 64 points its whole subtree is built by one wavefront without leaving the registers: every
 // lane carries one point and the description of the sub-cell it currently belongs to (a contiguous range of lanes,
@@ -654,7 +658,8 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   while (more) {
     for (uint32_t b = 0; b < batch && level < ANN_MAX_LEVELS; b++, level++) {
       const size_t bound = (level < 31 && ((size_t)1 << level) < nlarge) ? ((size_t)1 << level) : nlarge;
-      hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas);
+      hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas,
+                         level ? (const ASeg*)next : (const ASeg*)nullptr, level ? (const ADec*)dec : (const ADec*)nullptr);
       hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, dec);
       hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
       // the library's first Hoare pass, then its second one on what lies right of br1
@@ -670,7 +675,6 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
       }
       hipLaunchKernelGGL(k_ann_children, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, dec, cnt, nodes, next,
                          small_list, small, meas_next, cnt_next);
-      hipLaunchKernelGGL(k_ann_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, dec, M, seg_of);
       ASeg* t = segs; segs = next; next = t;
       AMeasU* tm = meas; meas = meas_next; meas_next = tm;
       unsigned long long* tc = cnt; cnt = cnt_next; cnt_next = tc;
