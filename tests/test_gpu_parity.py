@@ -1222,3 +1222,16 @@ def test_prepare_scans_with_normals_concurrently(tdtk, orc, gpu):
     for k, s in enumerate(S):
         assert np.array_equal(s._local_n, orc.normals_apx_knn(clouds[k], 10, s.rPos, 1.0))
         assert s.getSearchTree().verify() == [0, 0, 0, 0]
+
+
+def test_randomized_differential_run(gpu):
+    """20 s of tools/fuzz_parity.py (random awkward clouds through normals, search + tree verification, getPtPairs,
+    octree reduction, short ICP loops, scan lives, pose graphs -- each against the oracle)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "20", "--seed", "101"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert " 0 mismatches" in r.stdout
