@@ -48,7 +48,8 @@ class IcpParams(C.Structure):
 
 class IcpResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("last_pairs", C.c_uint64),
-                ("last_rms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double)]
+                ("last_rms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double),
+                ("sums_ms", C.c_double)]
 
 
 # every symbol include/tdtk_hip.h declares (tests check that the library exports all of them)
@@ -60,7 +61,9 @@ EXPORTS = [
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_point_point_error",
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_last_timings", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
+    "tdtk_host_euler_to_matrix4", "tdtk_host_matrix4_to_euler", "tdtk_host_quat_to_matrix4", "tdtk_host_matrix4_to_quat",
     "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
 ]
 
@@ -138,10 +141,17 @@ def lib():
     L.tdtk_invert.argtypes = [_dp, C.c_int, _dp]
     L.tdtk_last_kernel_ms.argtypes = [_dp]
     L.tdtk_count_visits.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _u64p]
+    L.tdtk_last_timings.argtypes = [_dp]
+    L.tdtk_visit_counting.argtypes = [C.c_int, C.c_int]
+    L.tdtk_visit_counters.argtypes = [C.c_int, _u64p]
+    L.tdtk_measure_bandwidth.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_int, _dp]
     L.tdtk_host_tree_layout.argtypes = [_dp, C.c_size_t, C.c_int, _ip, _u64p]
     L.tdtk_host_m4inv.argtypes = [_dp, _dp]
     L.tdtk_host_mmult.argtypes = [_dp, _dp, _dp]
     L.tdtk_host_mmult.restype = None
+    for f in ("tdtk_host_euler_to_matrix4", "tdtk_host_matrix4_to_euler", "tdtk_host_quat_to_matrix4", "tdtk_host_matrix4_to_quat"):
+        getattr(L, f).argtypes = [_dp, _dp, _dp]
+        getattr(L, f).restype = None
     L.tdtk_lum_assemble_solve.argtypes = [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, _dp, _dp]
     L.tdtk_graph_block_doubles.argtypes = [C.c_int]
     L.tdtk_graph_link_blocks.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), _dp, C.POINTER(C.c_void_p), C.c_double, _dp]

@@ -70,8 +70,28 @@ enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS
 
 // an auxiliary stream with the buffers one whole-scan pass needs: batches of links over small scans run several
 // passes side by side (one pass of an 80K-point scan occupies a fraction of the machine and is latency-bound)
+// draw counters of the work-queue search kernel: two sets of 8 that alternate from launch to launch on one stream
+// (each launch zeroes the set of the next one, kernels.hip)
+struct QueueCtr {
+  DevBuf buf;
+  int parity = 0;
+  int attach(SearchArgs& a)
+  {
+    if (!buf.p) {
+      int rc = buf.ensure(64 * sizeof(uint32_t));
+      if (rc) return rc;
+      if (hipMemset(buf.p, 0, 64 * sizeof(uint32_t)) != hipSuccess) { set_error("hipMemset failed"); return TDTK_EDEVICE; }
+    }
+    a.q_ctr = buf.as<uint32_t>() + 32 * parity;
+    a.q_ctr_next = buf.as<uint32_t>() + 32 * (parity ^ 1);
+    parity ^= 1;
+    return TDTK_OK;
+  }
+};
+
 struct Lane {
   hipStream_t s = nullptr;
+  QueueCtr qc;
   DevBuf kpos, part, ovf_m2, ovf_ref;
   ~Lane() { if (s) (void)hipStreamDestroy(s); }
 };
@@ -79,12 +99,19 @@ struct Lane {
 struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;   // around the search kernel of the last pass
+  hipEvent_t e2 = nullptr, e3 = nullptr;   // around the pair-sum kernels behind it (k_accum + k_final, or k_final alone)
+  hipEvent_t e_user = nullptr;             // fence between a caller's stream and this context's stream
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
-  double last_nn_ms = 0.0;
-  bool ev_pending = false;
+  double last_nn_ms = 0.0, last_sums_ms = 0.0;
+  bool ev_pending = false, ev2_pending = false;
+  // tdtk_visit_counting: every search of this thread runs its instrumented instantiation and adds to d_counters
+  bool counting = false;
+  DevBuf d_counters;
+  uint64_t counted_queries = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
+  QueueCtr qc;       // for launches on `stream` (a caller's stream gets its launches ordered behind it, see run_search)
   // a context dies with its host thread (worker threads of a prefetch pool come and go): give everything back
   ~Ctx()
   {
@@ -92,6 +119,9 @@ struct Ctx {
     lanes.clear();
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    if (e3) (void)hipEventDestroy(e3);
+    if (e_user) (void)hipEventDestroy(e_user);
     if (h_pin) (void)hipHostFree(h_pin);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -115,6 +145,9 @@ static int get_ctx(int device, Ctx** out)
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->e0));
     HIPCHK(hipEventCreate(&c->e1));
+    HIPCHK(hipEventCreate(&c->e2));
+    HIPCHK(hipEventCreate(&c->e3));
+    HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
     it = g_ctx.emplace(device, std::move(c)).first;
   }
@@ -383,12 +416,14 @@ int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info)
 // ------------------------------------------------------------------------------------------
 // internal: one search pass over SoA queries
 // ------------------------------------------------------------------------------------------
-static int prepare_overflow_in(DevBuf& bm2, DevBuf& bref, const tdtk_tree* t, uint32_t grid, SearchArgs& a)
+// the spill area behind the LDS stacks: [level][lane] for as many lanes as ANY search kernel may launch for this
+// batch size (every kernel indexes it with its own grid, all of them <= search_max_lanes)
+static int prepare_overflow_in(DevBuf& bm2, DevBuf& bref, const tdtk_tree* t, size_t nq, SearchArgs& a)
 {
   const int need = (int)t->info.max_depth - 1 - search_lds_depth();
   a.ovf_m2 = nullptr; a.ovf_ref = nullptr;
   if (need > 0) {
-    const size_t lanes = (size_t)grid * search_block();
+    const size_t lanes = search_max_lanes(nq);
     int rc = bm2.ensure(lanes * need * sizeof(double));
     if (rc) return rc;
     rc = bref.ensure(lanes * need * sizeof(uint32_t));
@@ -398,9 +433,9 @@ static int prepare_overflow_in(DevBuf& bm2, DevBuf& bref, const tdtk_tree* t, ui
   }
   return TDTK_OK;
 }
-static int prepare_overflow(Ctx* c, const tdtk_tree* t, uint32_t grid, SearchArgs& a)
+static int prepare_overflow(Ctx* c, const tdtk_tree* t, size_t nq, SearchArgs& a)
 {
-  return prepare_overflow_in(c->ws[WS_OVF_M2], c->ws[WS_OVF_REF], t, grid, a);
+  return prepare_overflow_in(c->ws[WS_OVF_M2], c->ws[WS_OVF_REF], t, nq, a);
 }
 
 static int run_search(Ctx* c, const tdtk_tree* t, SearchArgs& a, int dirmode, bool count, hipStream_t s,
@@ -408,15 +443,27 @@ static int run_search(Ctx* c, const tdtk_tree* t, SearchArgs& a, int dirmode, bo
 {
   a.T = t->dev;
   const uint32_t grid = search_grid(a.n);
-  int rc = prepare_overflow(c, t, grid, a);
+  int rc = prepare_overflow(c, t, a.n, a);
   if (rc) return rc;
+  if (c->counting && dirmode == 0 && !count) {
+    count = true;
+    a.counters = c->d_counters.as<unsigned long long>();
+    c->counted_queries += a.n;
+  }
+  if (dirmode == 0 && search_uses_queue(a.n)) {
+    if (s != c->stream) {   // the counters belong to this context's stream: order a caller's stream behind it
+      HIPCHK(hipEventRecord(c->e_user, c->stream));
+      HIPCHK(hipStreamWaitEvent(s, c->e_user, 0));
+    }
+    if ((rc = c->qc.attach(a))) return rc;
+  }
   if (timed) HIPCHK(hipEventRecord(c->e0, s));
   HIPCHK(launch_search(a, grid, dirmode, count, s));
   if (timed) { HIPCHK(hipEventRecord(c->e1, s)); c->ev_pending = true; }
   return TDTK_OK;
 }
 
-static int collect_ms(Ctx* c, double* ms)
+static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
 {
   if (c->ev_pending) {
     HIPCHK(hipEventSynchronize(c->e1));
@@ -425,8 +472,26 @@ static int collect_ms(Ctx* c, double* ms)
     c->last_nn_ms = f;
     c->ev_pending = false;
   }
+  if (c->ev2_pending) {
+    HIPCHK(hipEventSynchronize(c->e3));
+    float f = 0;
+    HIPCHK(hipEventElapsedTime(&f, c->e2, c->e3));
+    c->last_sums_ms = f;
+    c->ev2_pending = false;
+  }
   if (ms) *ms = c->last_nn_ms;
+  if (sums_ms) *sums_ms = c->last_sums_ms;
   return TDTK_OK;
+}
+
+static bool fuse_enabled()
+{
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TDTK_FUSE_SUMS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
 }
 
 // acc[ACC_TOTAL] (sums about `shift`) -> the reference's quantities
@@ -571,6 +636,16 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   Mat4 A, inv;
   std::memcpy(A.m, A16, sizeof A.m);
   m4inv(A16, inv.m);  // searchTree.cc:110
+  // sums are taken about the model box centre mapped to the world: keeps the raw second
+  // moments small so the centred covariance survives the subtraction in fp64
+  double sh[3];
+  sh[0] = model->centre[0] * A16[0] + model->centre[1] * A16[4] + model->centre[2] * A16[8] + A16[12];
+  sh[1] = model->centre[0] * A16[1] + model->centre[1] * A16[5] + model->centre[2] * A16[9] + A16[13];
+  sh[2] = model->centre[0] * A16[2] + model->centre[1] * A16[6] + model->centre[2] * A16[10] + A16[14];
+  for (int k = 0; k < 3; k++) shift_out[k] = sh[k];
+  // the base block (n, sum, centroids, Si) of a closest-point pass comes out of the search kernel itself when the
+  // batch is large enough for the persistent-lane kernel (retire-time accumulation, kernels.hip)
+  const bool fused = do_search && pmode == 0 && (want & ~TDTK_WANT_BASE) == 0 && !lum_D && fuse_enabled() && search_can_fuse(N);
   if (do_search) {
     SearchArgs sa{};
     sa.x = data->x; sa.y = data->y; sa.z = data->z;
@@ -583,8 +658,25 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.kpos = c->ws[WS_KPOS].as<int>();
     sa.warm = (warm && pmode != 1) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
     sa.d2 = nullptr;
+    uint32_t rows = 0;
+    if (fused) {
+      rows = search_fused_rows(N);
+      if ((rc = c->ws[WS_PART].ensure((size_t)rows * ACC_TOTAL * sizeof(double)))) return rc;
+      sa.fuse = 1; sa.A = A;
+      for (int k = 0; k < 3; k++) sa.shift[k] = sh[k];
+      sa.partials = c->ws[WS_PART].as<double>();
+    }
     rc = run_search(c, model, sa, pmode == 1 ? 1 : 0, false, s, true);
     if (rc) return rc;
+    if (fused) {
+      HIPCHK(hipEventRecord(c->e2, s));
+      HIPCHK(launch_final(sa.partials, rows, c->h_pin, s));
+      HIPCHK(hipEventRecord(c->e3, s));
+      c->ev2_pending = true;
+      HIPCHK(hipStreamSynchronize(s));
+      std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
+      return TDTK_OK;
+    }
   }
   AccumArgs aa{};
   aa.T = model->dev;
@@ -593,13 +685,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   aa.kpos = c->ws[WS_KPOS].as<int>();
   aa.n = N;
   aa.A = A; aa.inv = inv;
-  // sums are taken about the model box centre mapped to the world: keeps the raw second
-  // moments small so the centred covariance survives the subtraction in fp64
-  double sh[3];
-  sh[0] = model->centre[0] * A16[0] + model->centre[1] * A16[4] + model->centre[2] * A16[8] + A16[12];
-  sh[1] = model->centre[0] * A16[1] + model->centre[1] * A16[5] + model->centre[2] * A16[9] + A16[13];
-  sh[2] = model->centre[0] * A16[2] + model->centre[1] * A16[6] + model->centre[2] * A16[10] + A16[14];
-  for (int k = 0; k < 3; k++) { aa.shift[k] = sh[k]; shift_out[k] = sh[k]; }
+  for (int k = 0; k < 3; k++) aa.shift[k] = sh[k];
   aa.has_D = lum_D ? 1 : 0;
   if (lum_D) std::memcpy(aa.D, lum_D, sizeof aa.D);
   const uint32_t grid = accum_grid(N);
@@ -608,7 +694,10 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   aa.partials = c->ws[WS_PART].as<double>();
   // k_final stores the 74 sums straight into pinned host memory (device-visible): no copy-engine hop
   // between the last kernel and the host solve, which matters when an iteration is ~100 us
+  HIPCHK(hipEventRecord(c->e2, s));
   HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s));
+  HIPCHK(hipEventRecord(c->e3, s));
+  c->ev2_pending = true;
   HIPCHK(hipStreamSynchronize(s));
   std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
   return TDTK_OK;
@@ -674,6 +763,12 @@ int tdtk_find_closest_dev(const tdtk_tree* t, const double* d_q, size_t K, doubl
   if (rc) return rc;
   HIPCHK(launch_scatter_idx(sa.kpos, sa.d2, order, t->dev.pts, K, d_idx, d_d2, s));
   if (!stream) HIPCHK(hipStreamSynchronize(s));
+  else {
+    // the kernels queued on the caller's stream use this thread's workspaces: whatever this thread's own stream
+    // does next (any later tdtk call) waits for them, so the buffers are never overwritten under a running kernel
+    HIPCHK(hipEventRecord(c->e_user, s));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->e_user, 0));
+  }
   return TDTK_OK;
 }
 
@@ -788,6 +883,78 @@ int tdtk_last_kernel_ms(double* nn_ms)
   int rc = get_ctx(dev, &c);
   if (rc) return rc;
   return collect_ms(c, nn_ms);
+}
+
+int tdtk_last_timings(double out[2])
+{
+  if (!out) { set_error("NULL argument"); return TDTK_EINVAL; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("no device"); return TDTK_EDEVICE; }
+  Ctx* c;
+  int rc = get_ctx(dev, &c);
+  if (rc) return rc;
+  return collect_ms(c, &out[0], &out[1]);
+}
+
+// every FindClosest pass this thread runs on `device` from now on uses the instrumented instantiation of the
+// kernel it would have used (same traversal, same warm radius, same results) and adds to the counters
+int tdtk_visit_counting(int device, int on)
+{
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  if (on) {
+    if ((rc = c->d_counters.ensure(4 * sizeof(unsigned long long)))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemset(c->d_counters.p, 0, 4 * sizeof(unsigned long long)));
+    c->counted_queries = 0;
+  }
+  c->counting = on != 0;
+  return TDTK_OK;
+}
+
+int tdtk_visit_counters(int device, uint64_t out[4])
+{
+  if (!out) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  out[0] = out[1] = out[2] = 0; out[3] = c->counted_queries;
+  if (!c->d_counters.p) return TDTK_OK;
+  HIPCHK(hipDeviceSynchronize());   // link passes run on auxiliary streams
+  unsigned long long h[3];
+  HIPCHK(hipMemcpy(h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; k++) out[k] = h[k];
+  return TDTK_OK;
+}
+
+// measured roofline denominators: kind 0 = HBM stream copy (16 B per lane, `bytes` read + `bytes`
+// written per pass, the buffers far beyond the 256 MB Infinity Cache when bytes >= 1 GB); kind 1 = repeated reads of
+// a buffer that fits the L2s (bytes <= 16 MB: every workgroup sweeps its own XCD-local slice); GB/s of the best pass.
+int tdtk_measure_bandwidth(int device, int kind, size_t bytes, int reps, double* gbs)
+{
+  if (!gbs || bytes < 4096 || reps < 1 || kind < 0 || kind > 1) { set_error("bad argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  bytes &= ~(size_t)4095;
+  DevBuf a, b;
+  if ((rc = a.ensure(bytes))) return rc;
+  if (kind == 0 && (rc = b.ensure(bytes))) return rc;
+  HIPCHK(hipMemsetAsync(a.p, 1, bytes, c->stream));
+  double best = 0.0;
+  for (int r = 0; r < reps + 1; r++) {
+    HIPCHK(hipEventRecord(c->e0, c->stream));
+    double moved = 0.0;
+    HIPCHK(launch_bandwidth(kind, a.p, b.p, bytes, &moved, c->stream));
+    HIPCHK(hipEventRecord(c->e1, c->stream));
+    HIPCHK(hipEventSynchronize(c->e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->e0, c->e1));
+    if (r > 0 && ms > 0) best = std::max(best, moved / (ms * 1e-3) / 1e9);
+  }
+  *gbs = best;
+  return TDTK_OK;
 }
 
 // ---- octree reduction ("-r <voxelSize>", centre mode) -----------------------------------
@@ -1277,6 +1444,10 @@ int tdtk_host_tree_layout(const double* xyz, size_t M, int bucket_size, int32_t*
 }
 int tdtk_host_m4inv(const double in[16], double out[16]) { return m4inv(in, out); }
 void tdtk_host_mmult(const double a[16], const double b[16], double out[16]) { mmult(a, b, out); }
+void tdtk_host_euler_to_matrix4(const double rPos[3], const double rPosTheta[3], double out[16]) { euler_to_matrix4(rPos, rPosTheta, out); }
+void tdtk_host_matrix4_to_euler(const double in[16], double rPosTheta[3], double rPos[3]) { matrix4_to_euler(in, rPosTheta, rPos); }
+void tdtk_host_quat_to_matrix4(const double quat[4], const double t[3], double out[16]) { quat_to_matrix4(quat, t, out); }
+void tdtk_host_matrix4_to_quat(const double in[16], double quat[4], double t[3]) { matrix4_to_quat_t(in, quat, t); }
 
 // ---- minimizers / solves ------------------------------------------------------------------
 int tdtk_align(int algo, const tdtk_pair_sums* sums, double alignxf[16], double* rms)
@@ -1332,7 +1503,7 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   double ret = 0.0, prev_ret = 0.0, prev_prev_ret = 0.0;
   double alignxf[16], pend[16];
   bool have_pending = false;
-  double nn_total = 0.0;
+  double nn_total = 0.0, sums_total = 0.0;
   const double t0 = now_ms();
   int iter = 0;
   int converged = 0;
@@ -1347,9 +1518,10 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
                    have_pending ? pend : nullptr, true, acc, shift, iter > 0 && warm_ok);
     if (rc) return rc;
     have_pending = false;
-    double ms = 0;
-    collect_ms(c, &ms);
+    double ms = 0, sms = 0;
+    collect_ms(c, &ms, &sms);
     nn_total += ms;
+    sums_total += sms;
     tdtk_pair_sums sums;
     finish_sums(acc, shift, data->N, want, &sums);
     res->last_pairs = sums.n;
@@ -1401,6 +1573,7 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   res->converged = converged;
   res->total_ms = now_ms() - t0;
   res->nn_ms = nn_total;
+  res->sums_ms = sums_total;
   if (!prm->quiet) std::printf("TIME  %ld   ITER %d\n", (long)res->total_ms, iter);
   return TDTK_OK;
 }
@@ -1515,10 +1688,12 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     if (ln) {
       sa.T = t->dev;
       const uint32_t grid = search_grid(sa.n);
-      if ((rc = prepare_overflow_in(ln->ovf_m2, ln->ovf_ref, t, grid, sa))) return rc;
+      if ((rc = prepare_overflow_in(ln->ovf_m2, ln->ovf_ref, t, sa.n, sa))) return rc;
+      if (search_uses_queue(sa.n) && (rc = ln->qc.attach(sa))) return rc;
+      if (c->counting) { sa.counters = c->d_counters.as<unsigned long long>(); c->counted_queries += sa.n; }
       const bool timed = (i == nlinks - 1);      // tdtk_last_kernel_ms: this search, running beside the other lanes'
       if (timed) HIPCHK(hipEventRecord(c->e0, ls));
-      HIPCHK(launch_search(sa, grid, 0, false, ls));
+      HIPCHK(launch_search(sa, grid, 0, c->counting, ls));
       if (timed) { HIPCHK(hipEventRecord(c->e1, ls)); c->ev_pending = true; }
     } else {
       if ((rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1))) return rc;
@@ -1823,7 +1998,12 @@ int tdtk_graph_link_blocks(int backend, int nlinks, const tdtk_tree* const* firs
         D[r] = v;
         dmz += v * MZ[r];
       }
-      const double ss = (s.sum - dmz) / (2.0 * m - 3.0);
+      // the reference sums squared residuals (lum6Dquat.cc:199-214), which cannot go negative; the normal-equation
+      // form can by rounding when the link is (nearly) perfectly aligned: clamp, and leave a zero block where the
+      // division would blow up (the guard lum6DEuler has at lum6Deuler.cc:215-226)
+      double ss = (s.sum - dmz) / (2.0 * m - 3.0);
+      if (ss < 0.0) ss = 0.0;
+      if (ss < 0.0000000000001) continue;
       for (int k = 0; k < 49; k++) b[k] = MM[k] / ss;
       for (int k = 0; k < 7; k++) b[49 + k] = MZ[k] / ss;
     } else if (backend == TDTK_GRAPH_GHELIX) {

@@ -34,7 +34,17 @@ struct SearchArgs {
   double* d2;   // out, nullable
   double* ovf_m2;  // stack overflow area (nullable when max_depth-1 <= LDS depth)
   uint32_t* ovf_ref;
-  unsigned long long* counters;  // COUNT instantiation only
+  unsigned long long* counters;  // COUNT instantiations only: internal nodes, buckets, bucket points visited
+  int qpw;      // persistent-lane kernels: consecutive sorted queries per wave (set by launch_search)
+  int slab;     // work-queue kernel: queries per draw (set by launch_search)
+  uint32_t* q_ctr;       // work-queue kernel: 8 draw counters of THIS launch (zero on entry) ...
+  uint32_t* q_ctr_next;  // ... and the 8 of the next launch on the same stream, zeroed by this one
+  // fused retire-time accumulation of the base pair sums (k_search_refill<.., FUSE>): fuse != 0, A = Source->dalignxf,
+  // shift as in AccumArgs, partials [search_fused_rows(n)][ACC_TOTAL]
+  int fuse;
+  Mat4 A;
+  double shift[3];
+  double* partials;
 };
 
 // accumulator columns
@@ -92,6 +102,12 @@ struct PairListArgs {
 };
 
 uint32_t search_grid(size_t n);
+size_t search_max_lanes(size_t n);     // most lanes any search kernel launches for n queries (stack overflow area)
+bool search_uses_queue(size_t n);      // does it get the work-queue kernel (needs q_ctr / q_ctr_next)?
+bool search_can_fuse(size_t n);        // does a batch of n queries get the kernel that can fuse the base sums?
+uint32_t search_fused_rows(size_t n);  // rows of partials the fused kernel writes
+hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
+hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);
 int search_lds_depth();
 int search_block();
 uint32_t accum_grid(size_t n);

@@ -754,8 +754,22 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
   }
 }
 
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
+{
+  unsigned long long t = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, WAVE);
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------
-// k_search_refill: same per-lane traversal, but a wave owns QPW consecutive (sorted) queries and a
+// k_search_refill: same per-lane traversal, but a wave owns a.qpw consecutive (sorted) queries and a
 // lane that finishes its query immediately takes the next one of the wave's slab ("persistent
 // lanes").  Motivation (PMC, profiles/r01_pmc_bench.json): k_search issues ~6800 VALU
 // instructions per wave for ~1400 per lane-query -- the SIMDs are ~85 % busy issuing mostly
@@ -763,7 +777,19 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
 // (1..8) and the wave runs as long as its slowest lane.  Refilling keeps the lanes occupied.
 // Results are written by query index, so the processing order is irrelevant.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, int QPW, int THRESH, int WPS>
+// COUNT: also tally the internal nodes / buckets / bucket points each query visits (the traversal is the same one,
+// so the counts are those of exactly this launch: warm radius, fused transform and all).
+// FUSE: retire-time accumulation of the base pair sums (n, sum|p1-p2|^2, sum p1, sum p2, sum p1 p2^T about
+// `shift`): a lane that finishes a query has the hit in hand and its bucket still in L1/L2, so the separate
+// k_accum pass over (x, y, z, kpos, pts[kpos]) disappears.  Per-lane fp64 accumulators in registers (their order
+// is the lane's retire order, which is a function of the traversal alone -> run-to-run bit-identical), one wave
+// reduction at the end, one row per workgroup for k_final.  Pairing mode 0 / base block only.
+// DYN: the wave does not own a fixed slab; it draws `a.slab` consecutive sorted queries at a time from a work queue
+// (one atomic counter per eighth of the scan, starting with the eighth of the XCD the wave really runs on and moving
+// on to the others when that is empty).  A statically assigned slab ends with a drain -- the last lanes of every
+// 256-query slab finish alone -- which is where most of the idle lane-slots of the static kernel were; with the queue
+// a wave drains once, at the end of the launch, and the tail of the launch is balanced by construction.
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, bool FUSE, bool DYN>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -785,16 +811,35 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
 
-  const size_t wave_id = (size_t)chunk * (BLOCK / WAVE) + threadIdx.x / WAVE;
-  size_t next_q = wave_id * QPW;  // wave-uniform
-  size_t end_q = next_q + QPW;
-  if (end_q > a.n) end_q = a.n;
+  size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
+  uint32_t xq = 0, tried = 0, nslab = 0, per_x = 0;
+  if (DYN) {
+    next_q = end_q = 0;
+    nslab = (uint32_t)((a.n + (size_t)a.slab - 1) / (size_t)a.slab);
+    per_x = (nslab + 7u) >> 3;
+    xq = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]: speed only
+    // the counters of the NEXT launch on this stream (the two sets alternate): nobody reads them during this one
+    if (blockIdx.x == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
+  } else {
+    // a wave owns qpw consecutive sorted queries (256 unless the batch is so large that the grid is capped)
+    const size_t wave_id = (size_t)chunk * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    next_q = wave_id * (size_t)a.qpw;
+    end_q = next_q + (size_t)a.qpw;
+    if (next_q > a.n) next_q = a.n;
+    if (end_q > a.n) end_q = a.n;
+  }
 
   uint32_t cur = REF_DONE;
   double best = 0.0, qx = 0, qy = 0, qz = 0;
   int bk = -1;
   size_t qi = 0;
   bool have = false;
+  unsigned c_int = 0, c_leaf = 0, c_pts = 0;
+  double acc[FUSE ? ACC_DD : 1];
+  if (FUSE) {
+#pragma unroll
+    for (int k = 0; k < ACC_DD; k++) acc[k] = 0.0;
+  }
 
   for (;;) {
     // ---- retire finished queries, hand out new ones ----
@@ -803,10 +848,44 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       a.kpos[qi] = bk;
       if (a.d2) a.d2[qi] = best;
       have = false;
+      if (FUSE && bk >= 0) {
+        const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];   // the (already moved) data point, world frame
+        const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)bk << 5));
+        double mx, my, mz;
+        dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);  // searchTree.cc:147
+        const double px = mx - tx, py = my - ty, pz = mz - tz;
+        acc[ACC_N] += 1.0;
+        acc[ACC_SUM] += px * px + py * py + pz * pz;
+        const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
+        const double d0 = tx - a.shift[0], d1 = ty - a.shift[1], d2 = tz - a.shift[2];
+        acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
+        acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
+        acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
+        acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
+        acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+      }
     }
     const unsigned long long idlem = __ballot(idle);
     const unsigned long long activem = __ballot(!idle);
-    if (next_q < end_q && (activem == 0 || __popcll(idlem) >= THRESH)) {
+    const bool fill = (activem == 0 || __popcll(idlem) >= THRESH);
+    if (DYN && fill && next_q >= end_q) {
+      while (tried < 8u) {
+        uint32_t sl = 0;
+        if (lane == 0) sl = atomicAdd(&a.q_ctr[xq], 1u);
+        sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
+        const uint32_t lo = xq * per_x;
+        const uint32_t cnt = (lo < nslab) ? min(per_x, nslab - lo) : 0u;
+        if (sl < cnt) {
+          next_q = (size_t)(lo + sl) * (size_t)a.slab;
+          end_q = next_q + (size_t)a.slab;
+          if (end_q > a.n) end_q = a.n;
+          break;
+        }
+        xq = (xq + 1u) & 7u;
+        ++tried;
+      }
+    }
+    if (next_q < end_q && fill) {
       const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
       const size_t mine = next_q + rank;
       if (idle && mine < end_q) {
@@ -828,12 +907,13 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       next_q += (size_t)__popcll(idlem);
     }
     if (__ballot(cur != REF_DONE) == 0) {
-      if (next_q >= end_q) break;
+      if (next_q >= end_q && (!DYN || tried >= 8u)) break;
       continue;
     }
 
     // ---- phase 1: walk internal nodes until this lane holds a bucket (or is finished) ----
     while (!(cur & REF_LEAF)) {
+      if (COUNT) ++c_int;
       bool need_pop = false;
       uint32_t next;
       const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
@@ -874,6 +954,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         start = (int)(v >> T.cb);
         count = (int)(v & T.cmask);
       }
+      if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
@@ -906,17 +987,37 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       }
     }
   }
+  if (COUNT && a.counters) {
+    const unsigned long long s_int = wave_sum_u(c_int), s_leaf = wave_sum_u(c_leaf), s_pts = wave_sum_u(c_pts);
+    if (lane == 0) {
+      atomicAdd(&a.counters[0], s_int);
+      atomicAdd(&a.counters[1], s_leaf);
+      atomicAdd(&a.counters[2], s_pts);
+    }
+  }
+  if (FUSE) {
+    // wave64 reduction, then across the workgroup's waves through LDS: one row of ACC_TOTAL per workgroup
+    constexpr int NW = BLOCK / WAVE;
+    __shared__ double red[NW][ACC_DD];
+    const int wv = threadIdx.x / WAVE;
+#pragma unroll
+    for (int k = 0; k < ACC_DD; k++) {
+      const double s = wave_sum(acc[k]);
+      if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
+      double s = 0.0;
+      if (k < ACC_DD)
+        for (int w = 0; w < NW; w++) s += red[w][k];
+      a.partials[(size_t)blockIdx.x * ACC_TOTAL + k] = s;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // pair-sum accumulation
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-  return v;
-}
 
 // acc layout (doubles): see kernels.h ACC_*
 template <int BLOCK, unsigned WANT, int PMODE>
@@ -1238,14 +1339,15 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 //   5: wave-cooperative LDS staging of distinct nodes / buckets    (kept as a measured negative)
 //   8: persistent lanes, 256 queries per wave, 256-thread workgroups
 //   9 / 10 / 11: eight / four / sixteen lanes per query (k_search_g8); four is the default below 96K queries
-//  20: persistent lanes, 256 queries per wave, 128-thread workgroups (default from 256K queries)
+//  20: persistent lanes, 256 queries per wave, 128-thread workgroups
+//  30: persistent lanes fed from a work queue (k_search_refill<.., DYN>): resident waves draw 64-query slabs
 static int search_variant()
 {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("TDTK_SEARCH_VARIANT");
     v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-    if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20) v = -2;
+    if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30) v = -2;
   }
   return v;
 }
@@ -1261,19 +1363,48 @@ uint32_t search_grid(size_t n)
   if (nb < 8) nb = 8;
   return (uint32_t)nb;
 }
-static uint32_t refill_grid(size_t n, int qpw)
+// persistent-lane grids: one wave per `qpw` consecutive sorted queries (256 by default), never more lanes than
+// search_grid() launches -- the stack overflow area is sized for that many -- so a batch beyond the cap gives
+// every wave a longer slab instead of adding waves (qpw is a kernel argument)
+static int refill_qpw_env()
 {
-  size_t waves = (n + qpw - 1) / qpw;
-  size_t nb = (waves + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE);
-  nb = (nb + 7) & ~(size_t)7;
-  return (uint32_t)(nb < 8 ? 8 : nb);
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TDTK_REFILL_QPW");
+    v = e ? atoi(e) : 256;
+    if (v < 64) v = 64;
+    v = (v + 63) & ~63;
+  }
+  return v;
 }
-static uint32_t refill_grid_b(size_t n, int qpw, int block)
+static uint32_t refill_grid_b(size_t n, int block, int* qpw_out)
 {
+  const size_t wpb = (size_t)block / WAVE;
+  size_t qpw = (size_t)refill_qpw_env();
   size_t waves = (n + qpw - 1) / qpw;
-  size_t nb = (waves + (block / WAVE) - 1) / (block / WAVE);
+  size_t nb = (waves + wpb - 1) / wpb;
   nb = (nb + 7) & ~(size_t)7;
-  return (uint32_t)(nb < 8 ? 8 : nb);
+  if (nb < 8) nb = 8;
+  size_t cap = ((size_t)num_cu() * 16 * SEARCH_BLOCK / block) & ~(size_t)7;
+  if (cap < 8) cap = 8;
+  if (nb > cap) {
+    nb = cap;
+    waves = nb * wpb;
+    qpw = (n + waves - 1) / waves;
+    qpw = (qpw + 63) & ~(size_t)63;
+  }
+  *qpw_out = (int)qpw;
+  return (uint32_t)nb;
+}
+size_t search_max_lanes(size_t n)
+{
+  int q;
+  const size_t a = (size_t)search_grid(n) * SEARCH_BLOCK;
+  const size_t b = (size_t)refill_grid_b(n, 128, &q) * 128;
+  const size_t c = (size_t)refill_grid_b(n, SEARCH_BLOCK, &q) * SEARCH_BLOCK;
+  const size_t d = (size_t)num_cu() * 4 * 8 * WAVE;     // the work-queue kernel: at most every wave slot of the chip
+  const size_t m1 = a > b ? a : b, m2 = c > d ? c : d;
+  return m1 > m2 ? m1 : m2;
 }
 static uint32_t g8_grid(size_t n)
 {
@@ -1286,22 +1417,116 @@ static uint32_t g8_grid(size_t n)
 int search_lds_depth() { return SEARCH_SD_MIN; }
 int search_block() { return SEARCH_BLOCK; }
 
-hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool count, hipStream_t s)
+static int refill_thresh_env()
 {
-  if (a.n == 0) return hipSuccess;
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TDTK_REFILL_THRESH");
+    v = e ? atoi(e) : 16;
+    if (v != 8 && v != 16 && v != 32) v = 16;
+  }
+  return v;
+}
+// which kernel a batch of n queries gets (TDTK_SEARCH_VARIANT overrides)
+static int pick_variant(size_t n)
+{
+  int v = search_variant();
+  // persistent lanes pay off once there are enough queries to keep every SIMD supplied with
+  // several 256-query waves; small batches keep one query per lane
+  if (v == -2) v = (n >= (size_t)262144) ? 20 : ((n >= (size_t)98304) ? 4 : 10);
+  return v;
+}
+bool search_can_fuse(size_t n) { return pick_variant(n) == 20; }
+bool search_uses_queue(size_t n) { return pick_variant(n) == 30; }
+uint32_t search_fused_rows(size_t n)
+{
+  int q;
+  return refill_grid_b(n, 128, &q);
+}
+
+template <bool COUNT, bool FUSE>
+static void launch_refill128(SearchArgs& a, hipStream_t s)
+{
+  int qpw;
+  const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
+  a.qpw = qpw;
+  switch (refill_thresh_env()) {
+    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
+  }
+}
+
+// work-queue kernel: as many waves as stay resident (TDTK_STREAM_WPS per SIMD, default 7 = what the registers allow),
+// never more waves than there are slabs to draw
+static int stream_slab_env()
+{
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TDTK_STREAM_SLAB");
+    v = e ? atoi(e) : 64;
+    if (v < 16) v = 16;
+  }
+  return v;
+}
+static uint32_t stream_grid(size_t n)
+{
+  static int wps = -1;
+  if (wps < 0) {
+    const char* e = getenv("TDTK_STREAM_WPS");
+    wps = e ? atoi(e) : 7;
+    if (wps < 1) wps = 1;
+    if (wps > 8) wps = 8;
+  }
+  size_t waves = (size_t)num_cu() * 4 * (size_t)wps;
+  const size_t slabs = (n + (size_t)stream_slab_env() - 1) / (size_t)stream_slab_env();
+  if (waves > slabs) waves = slabs;
+  size_t nb = (waves + 1) / 2;          // 128-thread workgroups
+  return (uint32_t)(nb ? nb : 1);
+}
+template <bool COUNT>
+static void launch_stream128(SearchArgs& a, hipStream_t s)
+{
+  a.slab = stream_slab_env();
+  const uint32_t nb = stream_grid(a.n);
+  switch (refill_thresh_env()) {
+    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
+  }
+}
+
+// a.fuse != 0 (only where search_can_fuse(a.n)): the base pair sums come out of the search itself, one row of
+// ACC_TOTAL per workgroup in a.partials (search_fused_rows(a.n) rows) -- follow with launch_final.
+hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, bool count, hipStream_t s)
+{
+  if (a_in.n == 0) return hipSuccess;
+  SearchArgs a = a_in;
   dim3 g(grid), b(SEARCH_BLOCK);
   if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 1, false, 1>), g, b, 0, s, a);
   else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
-  else if (count) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
   else {
-    int v = search_variant();
-    // persistent lanes pay off once there are enough queries to keep every SIMD supplied with
-    // several 256-query waves; small batches keep one query per lane
-    if (v == -2) v = (a.n >= (size_t)262144) ? 20 : ((a.n >= (size_t)98304) ? 4 : 10);
+    const int v = pick_variant(a.n);
+    if (a.fuse && v != 20) return hipErrorInvalidValue;
+    if (v == 30 && (!a.q_ctr || !a.q_ctr_next)) return hipErrorInvalidValue;
+    if (count) {
+      // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
+      if (v == 20) { if (a.fuse) launch_refill128<true, true>(a, s); else launch_refill128<true, false>(a, s); }
+      else if (v == 30) launch_stream128<true>(a, s);
+      else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
+      return hipGetLastError();
+    }
     switch (v) {
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
-      case 8: hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 256, 16, 1>), dim3(refill_grid(a.n, 256)), b, 0, s, a); break;
-      case 20: hipLaunchKernelGGL((k_search_refill<128, 4, 256, 16, 1>), dim3(refill_grid_b(a.n, 256, 128)), dim3(128), 0, s, a); break;
+      case 8: {
+        int qpw;
+        const uint32_t nb = refill_grid_b(a.n, SEARCH_BLOCK, &qpw);
+        a.qpw = qpw;
+        hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 16, 1, false, false, false>), dim3(nb), b, 0, s, a);
+        break;
+      }
+      case 30: launch_stream128<false>(a, s); break;
+      case 20: if (a.fuse) launch_refill128<false, true>(a, s); else launch_refill128<false, false>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
       case 10: hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid(a.n) / 2 < 8 ? 8 : (g8_grid(a.n) / 2 + 7) / 8 * 8), dim3(256), 0, s, a); break;
@@ -1309,6 +1534,57 @@ hipError_t launch_search(const SearchArgs& a, uint32_t grid, int dirmode, bool c
       default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
     }
   }
+  return hipGetLastError();
+}
+
+// ---- measured roofline denominators (tdtk_measure_bandwidth) ---------------------------------------------
+__global__ void __launch_bounds__(256) k_bw_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16)
+{
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+// every XCD (workgroup b runs on XCD b % 8) sweeps its own eighth of the buffer `sweeps` times; a workgroup moves on
+// to the portion another workgroup of its XCD read in the previous sweep, so the lines come from the XCD's L2, not
+// from the CU's vector L1
+__global__ void __launch_bounds__(256) k_bw_l2(const float4* __restrict__ src, size_t slice16, int sweeps, float* __restrict__ sink)
+{
+  const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const float4* __restrict__ base = src + (size_t)x * slice16;
+  const size_t portion = slice16 / per_xcd;   // float4 elements per workgroup per sweep (multiple of 256 by construction)
+  float acc = 0.f;
+  for (int k = 0; k < sweeps; k++) {
+    const size_t p0 = (size_t)((j + (uint32_t)k * 37u) % per_xcd) * portion;
+    for (size_t i = threadIdx.x; i < portion; i += 256) {
+      const float4 v = base[p0 + i];
+      acc += v.x + v.y + v.z + v.w;
+    }
+  }
+  if (acc == 123.456f) sink[0] = acc;   // never true for the memset pattern; keeps the loads alive
+}
+hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s)
+{
+  if (kind == 0) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_bw_copy, dim3((uint32_t)num_cu() * 8), dim3(256), 0, s, (const float4*)a, (float4*)b, n16);
+    *moved_bytes = 2.0 * (double)(n16 * 16);
+  } else {
+    const uint32_t per_xcd = (uint32_t)num_cu();        // 8 workgroups per CU in all
+    const uint32_t nb = per_xcd * 8;
+    size_t slice16 = bytes / 16 / 8;
+    size_t portion = slice16 / per_xcd;
+    portion &= ~(size_t)255;
+    if (portion < 256) return hipErrorInvalidValue;
+    slice16 = portion * per_xcd;
+    const int sweeps = 64;
+    hipLaunchKernelGGL(k_bw_l2, dim3(nb), dim3(256), 0, s, (const float4*)a, slice16, sweeps, (float*)a);
+    *moved_bytes = (double)nb * (double)portion * 16.0 * sweeps;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, partials, (int)rows, d_out);
   return hipGetLastError();
 }
 

@@ -411,8 +411,43 @@ class Scan:
         else:
             self._queue.append(alignxf)
         self._transformMatrix(alignxf)
-        if type != "INVALID" and islum != -1:
-            self.frames.append((self.transMat.copy(), type))
+        self._addFrames(type, islum)
+
+    def addFrame(self, type):
+        """Scan::addFrame: the scan's CURRENT transMat with the given type"""
+        self.frames.append((self.transMat.copy(), type))
+
+    def _addFrames(self, type, islum):
+        """frame bookkeeping of Scan::transform (scan.cc:945-1008).  islum 0 writes a frame to EVERY scan of
+        Scan.allScans (this scan: `type`; the scans before it: ICPINACTIVE; the scans after it: INVALID -- or
+        ICPINACTIVE throughout when this scan is the first), so that all .frames files keep the same length, which
+        `show` animations rely on; 1: this scan only; 2: this scan and scan 0, INVALID for the scans after it.
+        A scan that is not registered in Scan.allScans (stand-alone use) only ever writes its own frame."""
+        if type == "INVALID" or islum == -1:
+            return
+        scans = Scan.allScans
+        if islum == 1 or not any(sc is self for sc in scans):
+            self.addFrame(type)
+            return
+        found = 0
+        if islum == 0:
+            for i, sc in enumerate(scans):
+                if sc is self:
+                    found = i
+                    sc.addFrame(type)
+                else:
+                    sc.addFrame("ICPINACTIVE" if found == 0 else "INVALID")
+        elif islum == 2:
+            for i, sc in enumerate(scans):
+                if sc is self:
+                    found = i
+                    self.addFrame(type)
+                    scans[0].addFrame(type)
+                    continue
+                if found != 0:
+                    sc.addFrame("INVALID")
+        else:
+            raise ValueError("invalid point transformation mode")
 
     def transformToEuler(self, rP, rPT, type="LUM", islum=1):
         """scan.cc:1061-1083."""
@@ -557,6 +592,7 @@ def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSiz
         s.path = path
         scans.append(s)
         i += 1
+    Scan.allScans = scans          # the static Scan::allScans the frame bookkeeping of Scan::transform walks
     return scans
 
 
@@ -677,7 +713,9 @@ class icp6D:
         """icp6D::match (icp6D.cc:104-285).  Returns the number of iterations done."""
         if self.rnd > 1:
             return self._match_stepped(PreviousScan, CurrentScan, pairing_mode)
-        CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))  # transform(id, ICP, 0)
+        CurrentScan._addFrames("ICP", 0)          # transform(id, ICP, 0), icp6D.cc:109
+        if self.max_num_iterations == 0:          # icp6D.cc:112-114
+            return 0
         tree = PreviousScan.getSearchTree()
         prm = IcpParams(int(self.my_icp6Dminimizer.getAlgorithmID()), int(pairing_mode),
                         int(self.max_num_iterations), float(self.max_dist_match2),
@@ -689,22 +727,30 @@ class icp6D:
         da = CurrentScan.dalignxf.copy()
         check(lib().tdtk_icp_match(tree._h, dptr(PreviousScan.dalignxf), CurrentScan.handle, dptr(tm),
                                    dptr(da), C.byref(prm), C.byref(res), dptr(trace), cap))
+        # frames as the reference's loop writes them (anim = -1): one after iteration 0 (transform(alignxf, ICP, 0),
+        # icp6D.cc:258-264), one when the loop ends by convergence or at the cap (transform(id, ICP, 0),
+        # :266-279) -- none on the "<= 3 pairs" break (:235-243 fall through to the end of the function)
+        few_pairs = int(res.last_pairs) <= 3
+        if not (few_pairs and res.iterations == 0):
+            CurrentScan.transMat = MMult(trace[0, 2:], CurrentScan.transMat)
+            CurrentScan._addFrames("ICP", 0)
         CurrentScan.transMat = tm
         CurrentScan.dalignxf = da
         CurrentScan.rPosTheta, CurrentScan.rPos = Matrix4ToEuler(tm)
-        CurrentScan.frames.append((tm.copy(), "ICP"))
+        if not few_pairs:
+            CurrentScan._addFrames("ICP", 0)
         self.nr_pointPair = int(res.last_pairs)
         nrows = min(cap, res.iterations + 1)
         self.last = dict(iterations=res.iterations, converged=bool(res.converged),
                          pairs=int(res.last_pairs), rms=res.last_rms, total_ms=res.total_ms,
-                         nn_ms=res.nn_ms, trace=trace[:nrows].copy())
+                         nn_ms=res.nn_ms, sums_ms=res.sums_ms, trace=trace[:nrows].copy())
         return res.iterations
 
     def _match_stepped(self, PreviousScan, CurrentScan, pairing_mode=0):
         """The same loop driven from the host, one SearchTree::getPtPairs call per iteration: what
         an unmodified reference icp6D::match does on top of HipSearchTree.  Only used for -R (rnd > 1),
         whose keep-mask is drawn on the host (the resident loop has no per-iteration host input)."""
-        CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))
+        CurrentScan._addFrames("ICP", 0)
         tree = PreviousScan.getSearchTree()
         algo = self.my_icp6Dminimizer.getAlgorithmID()
         want = self.my_icp6Dminimizer.want
@@ -721,11 +767,11 @@ class icp6D:
             else:
                 break
             trace.append(np.concatenate([[r["n"], ret], alignxf]))
-            CurrentScan.transform(alignxf, "ICP", -1)
+            CurrentScan.transform(alignxf, "ICP", 0 if it == 0 else -1)
             if (abs(ret - prev_ret) < self.epsilonICP and abs(ret - prev_prev_ret) < self.epsilonICP) or \
                     it == self.max_num_iterations - 1:
+                CurrentScan._addFrames("ICP", 0)
                 break
-        CurrentScan.frames.append((CurrentScan.transMat.copy(), "ICP"))
         self.last = dict(iterations=it, converged=it != self.max_num_iterations - 1, pairs=self.nr_pointPair,
                          rms=ret, total_ms=0.0, nn_ms=0.0, trace=np.array(trace))
         return it

@@ -111,6 +111,7 @@ typedef struct tdtk_icp_result {
   double last_rms;         /* last `ret`                                                */
   double total_ms;         /* wall time of the loop (the reference's "TIME" line)       */
   double nn_ms;            /* of which: device time in the correspondence kernel        */
+  double sums_ms;          /* and in the pair-sum kernels behind it (k_final alone when the sums are fused) */
 } tdtk_icp_result;
 
 /* ---- library ------------------------------------------------------------ */
@@ -145,7 +146,10 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4]);
 int tdtk_find_closest(const tdtk_tree* t, const double* q, size_t K, double maxdist2,
                       int32_t* idx, double* d2);
 /* same with device pointers (inputs already resident in HBM); stream = hipStream_t or NULL.
- * presorted != 0 promises that q is already spatially ordered (skips the binning pass). */
+ * presorted != 0 promises that q is already spatially ordered (skips the binning pass).
+ * With a caller's stream the call returns with the work queued on it; the kernels use the calling thread's
+ * workspaces, so later tdtk calls of this thread are ordered behind them (stream-wait on an event), but the
+ * caller must not issue a second tdtk_find_closest_dev on ANOTHER stream before the first has finished. */
 int tdtk_find_closest_dev(const tdtk_tree* t, const double* d_q, size_t K, double maxdist2,
                           int32_t* d_idx, double* d_d2, int presorted, void* stream);
 
@@ -319,6 +323,18 @@ int tdtk_scan_calc_normals(tdtk_scan* s, int k, const double rPos[3], double eps
 /* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
  * traversal counters of the last counting run.                                          */
 int tdtk_last_kernel_ms(double* nn_ms);
+/* out[0] = search kernel, out[1] = pair-sum kernels of the last pass on this thread (HIP events on the stream
+ * the kernels were launched on) */
+int tdtk_last_timings(double out[2]);
+/* on != 0: every FindClosest pass of the calling thread on `device` runs the instrumented instantiation of the
+ * kernel it would have used (identical traversal and results, slower) and adds to four counters, zeroed here;
+ * tdtk_visit_counters reads {internal nodes, buckets, bucket points visited, queries issued} -- the exact
+ * n_int / n_pts of SURVEY 8(d)'s algorithmic bytes for exactly the launches that ran (warm radius included). */
+int tdtk_visit_counting(int device, int on);
+int tdtk_visit_counters(int device, uint64_t out[4]);
+/* measured roofline denominators: kind 0 = HBM stream copy over `bytes` (read + written per pass), kind 1 =
+ * repeated reads of an L2-resident buffer (bytes <= 16 MB); best of `reps` passes in GB/s */
+int tdtk_measure_bandwidth(int device, int kind, size_t bytes, int reps, double* gbs);
 int tdtk_count_visits(const tdtk_tree* t, const double* q, size_t K, double maxdist2,
                       uint64_t counters[3] /* internal nodes, leaves, leaf points */);
 
@@ -341,6 +357,12 @@ int tdtk_host_tree_layout(const double* xyz, size_t M, int bucket_size, int32_t*
                           uint64_t stats[4]);
 int tdtk_host_m4inv(const double in[16], double out[16]);
 void tdtk_host_mmult(const double a[16], const double b[16], double out[16]);
+/* the pose conversions the pose updates use: EulerToMatrix4 / Matrix4ToEuler (globals.icc:501-576),
+ * QuatToMatrix4 / Matrix4ToQuat (globals.icc:988-1075) */
+void tdtk_host_euler_to_matrix4(const double rPos[3], const double rPosTheta[3], double out[16]);
+void tdtk_host_matrix4_to_euler(const double in[16], double rPosTheta[3], double rPos[3]);
+void tdtk_host_quat_to_matrix4(const double quat[4], const double t[3], double out[16]);
+void tdtk_host_matrix4_to_quat(const double in[16], double quat[4], double t[3]);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,22 @@ def ref():
         R.ref_ann_structure.argtypes = [C.c_void_p, _ip, _dp, _ip, _lp]
         R.ref_eigen3.argtypes = [_dp, _dp, _dp]
         R.ref_normals_apx_knn.argtypes = [_dp, C.c_int, C.c_int, _dp, C.c_double, _dp]
+        R.ref_M4inv.restype = C.c_int
+        R.ref_M4inv.argtypes = [_dp, _dp]
+        R.ref_MMult.argtypes = [_dp, _dp, _dp]
+        R.ref_transform3_inplace.argtypes = [_dp, _dp, C.c_size_t]
+        R.ref_transform3.argtypes = [_dp, _dp, _dp, C.c_size_t]
+        R.ref_transform3normal.argtypes = [_dp, _dp, C.c_size_t]
+        R.ref_EulerToMatrix4.argtypes = [_dp, _dp, _dp]
+        R.ref_Matrix4ToEuler.argtypes = [_dp, _dp, _dp]
+        R.ref_QuatToMatrix4.argtypes = [_dp, _dp, _dp]
+        R.ref_Matrix4ToQuat.argtypes = [_dp, _dp, _dp]
+        R.ref_Dist2.restype = C.c_double
+        R.ref_Dist2.argtypes = [_dp, _dp]
+        R.ref_newmat_inverse_solve.restype = C.c_int
+        R.ref_newmat_inverse_solve.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+        R.ref_lum_covariance_euler.restype = C.c_int
+        R.ref_lum_covariance_euler.argtypes = [C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp]
         _ref = R
     return _ref
 
@@ -391,3 +407,79 @@ def normals_from_knn(xyz, knn, rPos):
     out = np.empty_like(xyz)
     lib().orc_normals_from_knn(_d(xyz), len(xyz), knn.shape[1], _i(knn), _d(rp), _d(out))
     return out
+
+
+# ---- the reference's own globals.icc primitives and newmat inverse (oracle/_ref) ---------------------------
+def ref_m4inv_raw(A):
+    """-> (Mout, return value of M4inv)"""
+    out = np.empty(16)
+    rc = ref().ref_M4inv(_d(_c(A).reshape(16)), _d(out))
+    return out, rc
+
+
+def ref_mmult(A, B):
+    out = np.empty(16)
+    ref().ref_MMult(_d(_c(A).reshape(16)), _d(_c(B).reshape(16)), _d(out))
+    return out
+
+
+def ref_transform3_inplace(A, pts):
+    p = _c(pts).reshape(-1, 3).copy()
+    ref().ref_transform3_inplace(_d(_c(A).reshape(16)), _d(p), len(p))
+    return p
+
+
+def ref_transform3(A, pts):
+    p = _c(pts).reshape(-1, 3)
+    out = np.empty_like(p)
+    ref().ref_transform3(_d(_c(A).reshape(16)), _d(p), _d(out), len(p))
+    return out
+
+
+def ref_transform3normal(A, nrm):
+    p = _c(nrm).reshape(-1, 3).copy()
+    ref().ref_transform3normal(_d(_c(A).reshape(16)), _d(p), len(p))
+    return p
+
+
+def ref_euler_to_matrix4(rPos, rPosTheta):
+    out = np.empty(16)
+    ref().ref_EulerToMatrix4(_d(_c(rPos)), _d(_c(rPosTheta)), _d(out))
+    return out
+
+
+def ref_matrix4_to_euler(A):
+    th, pos = np.empty(3), np.empty(3)
+    ref().ref_Matrix4ToEuler(_d(_c(A).reshape(16)), _d(th), _d(pos))
+    return th, pos
+
+
+def ref_quat_to_matrix4(quat, t):
+    out = np.empty(16)
+    ref().ref_QuatToMatrix4(_d(_c(quat)), _d(_c(t)), _d(out))
+    return out
+
+
+def ref_matrix4_to_quat(A):
+    q, t = np.empty(4), np.empty(3)
+    ref().ref_Matrix4ToQuat(_d(_c(A).reshape(16)), _d(q), _d(t))
+    return q, t
+
+
+def ref_newmat_inverse_solve(A, b=None):
+    """newmat's A.i() and A.i() * b -> (Ainv, x)"""
+    A = _c(A); n = A.shape[0]
+    Ai = np.empty((n, n)); x = np.empty(n) if b is not None else None
+    rc = ref().ref_newmat_inverse_solve(n, _d(A), _d(_c(b)) if b is not None else None, _d(Ai), _d(x))
+    if rc:
+        raise RuntimeError("newmat: singular matrix")
+    return Ai, x
+
+
+def ref_lum_covariance_euler(p1, p2):
+    """lum6DEuler::covarianceEuler's arithmetic on an explicit pair list with the reference's newmat -> (C, CD, ss, D)"""
+    p1, p2 = _c(p1).reshape(-1, 3), _c(p2).reshape(-1, 3)
+    Cm, CD, D = np.empty(36), np.empty(6), np.empty(6)
+    ss = C.c_double(0.0)
+    ref().ref_lum_covariance_euler(len(p1), _d(p1), _d(p2), _d(Cm), _d(CD), C.byref(ss), _d(D))
+    return Cm.reshape(6, 6), CD, ss.value, D

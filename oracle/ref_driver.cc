@@ -33,6 +33,8 @@
 #include "slam6d/icp6Dlumeuler.h"
 #include "slam6d/icp6Dlumquat.h"
 #include "slam6d/icp6Dquatscale.h"
+#include "slam6d/globals.icc"
+#include "newmat/newmatap.h"
 
 struct RefTree {
   std::vector<double*> ptrs;
@@ -178,6 +180,109 @@ double ref_apx_align_parallel(const unsigned int* n, const double* sum, const do
   omp_set_num_threads(OPENMP_NUM_THREADS);
   icp6D_APX q(true);
   return q.Align_Parallel(OPENMP_NUM_THREADS, nn, ss, m, d, pairs, alignxf);
+}
+
+/* ---- the 4x4 / pose primitives of include/slam6d/globals.icc, as the reference compiles them ------------
+ * (A12: M4inv :762-785, MMult :298-328, transform3 :1454-1490, transform3normal :1465-1475,
+ * EulerToMatrix4 :501-531, Matrix4ToEuler :540-576, QuatToMatrix4 :988-1022, Matrix4ToQuat :1032-1075)      */
+int ref_M4inv(const double* in, double* out) { return M4inv(in, out); }
+void ref_MMult(const double* a, const double* b, double* out) { MMult(a, b, out); }
+void ref_transform3_inplace(const double* alignxf, double* pts, size_t n)
+{
+  for (size_t i = 0; i < n; i++) transform3(alignxf, pts + 3 * i);
+}
+void ref_transform3(const double* alignxf, const double* in, double* out, size_t n)
+{
+  for (size_t i = 0; i < n; i++) transform3(alignxf, in + 3 * i, out + 3 * i);
+}
+void ref_transform3normal(const double* alignxf, double* nrm, size_t n)
+{
+  for (size_t i = 0; i < n; i++) transform3normal(alignxf, nrm + 3 * i);
+}
+void ref_EulerToMatrix4(const double* rPos, const double* rPosTheta, double* alignxf) { EulerToMatrix4(rPos, rPosTheta, alignxf); }
+void ref_Matrix4ToEuler(const double* alignxf, double* rPosTheta, double* rPos) { Matrix4ToEuler(alignxf, rPosTheta, rPos); }
+void ref_QuatToMatrix4(const double* quat, const double* t, double* mat) { QuatToMatrix4(quat, t, mat); }
+void ref_Matrix4ToQuat(const double* mat, double* quat, double* t) { Matrix4ToQuat(mat, quat, t); }
+double ref_Dist2(const double* a, const double* b) { return Dist2(a, b); }
+
+/* newmat's `.i()` as lum6DEuler::covarianceEuler uses it (lum6Deuler.cc:194: D = MM.i() * MZ): A is n x n row-major.
+ * Ainv (nullable) = A.i(); x (nullable) = A.i() * b.                                                          */
+int ref_newmat_inverse_solve(int n, const double* A, const double* b, double* Ainv, double* x)
+{
+  try {
+    NEWMAT::Matrix M(n, n);
+    for (int r = 0; r < n; r++)
+      for (int c = 0; c < n; c++) M(r + 1, c + 1) = A[r * n + c];
+    NEWMAT::Matrix Mi = M.i();
+    if (Ainv)
+      for (int r = 0; r < n; r++)
+        for (int c = 0; c < n; c++) Ainv[r * n + c] = Mi(r + 1, c + 1);
+    if (x && b) {
+      NEWMAT::ColumnVector B(n);
+      for (int r = 0; r < n; r++) B(r + 1) = b[r];
+      NEWMAT::ColumnVector X = M.i() * B;
+      for (int r = 0; r < n; r++) x[r] = X(r + 1);
+    }
+  } catch (...) {
+    return -1;
+  }
+  return 0;
+}
+
+/* lum6DEuler::covarianceEuler's arithmetic after the pair search (lum6Deuler.cc:143-232) on an explicit pair
+ * list, written with the same newmat objects and expressions the reference TU uses (the TU itself needs Boost
+ * through scan.h); p1 = ak (first scan's points), p2 = bk.  Returns m; C 6x6 row-major, CD 6.                */
+int ref_lum_covariance_euler(size_t m, const double* p1, const double* p2, double* C, double* CD, double* ss_out,
+                             double* D_out)
+{
+  using namespace NEWMAT;
+  Matrix MM(6, 6);
+  ColumnVector MZ(6), D(6);
+  MM = 0.0; MZ = 0.0;
+  double sum[3] = {0, 0, 0}, xpy = 0, xpz = 0, ypz = 0, xy = 0, yz = 0, xz = 0;
+  for (size_t j = 0; j < m; j++) {
+    const double* a = p1 + 3 * j;
+    const double* b = p2 + 3 * j;
+    const double x = (a[0] + b[0]) / 2.0, y = (a[1] + b[1]) / 2.0, z = (a[2] + b[2]) / 2.0;
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    sum[0] += x; sum[1] += y; sum[2] += z;
+    xpy += x * x + y * y; xpz += x * x + z * z; ypz += y * y + z * z;
+    xy += x * y; xz += x * z; yz += y * z;
+    MZ(1) += dx; MZ(2) += dy; MZ(3) += dz;
+    MZ(4) += -z * dy + y * dz;
+    MZ(5) += -y * dx + x * dy;
+    MZ(6) += z * dx - x * dz;
+  }
+  MM(1, 1) = MM(2, 2) = MM(3, 3) = (double)m;
+  MM(4, 4) = ypz; MM(5, 5) = xpy; MM(6, 6) = xpz;
+  MM(1, 5) = MM(5, 1) = -sum[1]; MM(1, 6) = MM(6, 1) = sum[2];
+  MM(2, 4) = MM(4, 2) = -sum[2]; MM(2, 5) = MM(5, 2) = sum[0];
+  MM(3, 4) = MM(4, 3) = sum[1];  MM(3, 6) = MM(6, 3) = -sum[0];
+  MM(4, 5) = MM(5, 4) = -xz; MM(4, 6) = MM(6, 4) = -xy; MM(5, 6) = MM(6, 5) = -yz;
+  D = MM.i() * MZ;
+  double ss = 0.0;
+  for (size_t j = 0; j < m; j++) {
+    const double* a = p1 + 3 * j;
+    const double* b = p2 + 3 * j;
+    const double x = (a[0] + b[0]) / 2.0, y = (a[1] + b[1]) / 2.0, z = (a[2] + b[2]) / 2.0;
+    ss += sqr((a[0] - b[0]) - (D(1) - y * D(5) + z * D(6))) +
+          sqr((a[1] - b[1]) - (D(2) - z * D(4) + x * D(5))) +
+          sqr((a[2] - b[2]) - (D(3) + y * D(4) - x * D(6)));
+  }
+  ss = ss / (2 * m - 3);
+  if (ss_out) *ss_out = ss;
+  if (D_out) for (int k = 0; k < 6; k++) D_out[k] = D(k + 1);
+  for (int k = 0; k < 36; k++) C[k] = 0.0;
+  for (int k = 0; k < 6; k++) CD[k] = 0.0;
+  if (ss < 0.0000000000001) return (int)m;
+  ss = 1.0 / ss;
+  Matrix Cm = MM * ss;
+  ColumnVector CDv = MZ * ss;
+  for (int r = 0; r < 6; r++) {
+    for (int c = 0; c < 6; c++) C[r * 6 + c] = Cm(r + 1, c + 1);
+    CD[r] = CDv(r + 1);
+  }
+  return (int)m;
 }
 
 }  // extern "C"

@@ -761,6 +761,35 @@ def test_ten_million_point_model_with_normals(tdtk, orc, gpu):
     assert np.abs(S1.get_transMat()[:12] - Tgt[:12]).max() < 1e-5
 
 
+def test_eight_million_queries_cold_start_deep_stacks(tdtk, orc, gpu):
+    """More queries than the largest grid has lanes (the persistent-lane kernel then gives every wave a longer
+    slab instead of adding waves), cold start with an unbounded radius on a 19-deep tree: every first descent
+    pushes a far child per level, so the per-lane stacks spill 14 levels deep into the overflow area, which is
+    sized for the lanes of the grid that is actually launched.  All 8M indices and distances against the oracle."""
+    rng = np.random.default_rng(2026)
+    M, K = 2_000_000, 8_000_000
+    m = rng.uniform(-2000, 2000, (M, 3))
+    m[:200000] = rng.normal(0, 3.0, (200000, 3)) + rng.uniform(-1500, 1500, (200, 3)).repeat(1000, axis=0)   # deepens the tree
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    assert kd.info()["max_depth"] >= 18
+    q = rng.uniform(-2100, 2100, (K, 3))
+    nt = max(8, min(64, os.cpu_count() or 8))
+    for md2 in (1e18, 400.0):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, nt)
+        assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
+    # the same through a resident scan (Morton-sorted, fused pair sums): pair count and sums against the index list
+    S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], m); S0.kd = kd
+    S1 = tdtk.Scan([0, 0, 0], [0, 0, 0], q)
+    r = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 400.0, 0, 0, want_idx=True)
+    assert np.array_equal(r["idx"], oi)
+    found = oi >= 0
+    assert r["n"] == int(found.sum())
+    assert abs(r["sum"] - od2[found].sum()) <= 1e-10 * od2[found].sum()
+    cm = m[oi[found]].mean(axis=0)
+    assert np.abs(np.asarray(r["centroid_m"]) - cm).max() < 1e-7
+
+
 def test_config3_shape_graphslam_sharded(tdtk, orc, gpu):
     """configs[3] at reduced size (16 scans x 40K points on a closed circle, chain + loop closures): one
     lum6DEuler iteration of the native path against the numpy restatement, and the sharded exchange

@@ -35,7 +35,7 @@ def test_struct_layout_matches_header(tdtk):
     capi = sys.modules["3dtk_amd._capi"]
     # 2 u64 + (1+3+3+9+6+3+21+6+1+15+1) + (4*9+2*3) doubles
     assert C.sizeof(capi.PairSums) == 16 + 8 * (69 + 42 + 12 + 1)
-    assert C.sizeof(capi.IcpParams) == 40 and C.sizeof(capi.IcpResult) == 40
+    assert C.sizeof(capi.IcpParams) == 40 and C.sizeof(capi.IcpResult) == 48
 
 
 def _clouds():

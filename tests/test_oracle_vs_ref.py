@@ -179,6 +179,127 @@ def test_m4inv_mmult_roundtrip(orc):
     assert not ok and np.array_equal(sing, np.eye(4).reshape(16))     # globals.icc:765-769
 
 
+def test_globals_icc_primitives_bit_exact_against_reference(orc, tdtk):
+    """A12: M4inv / MMult / transform3 (both forms) / transform3normal / EulerToMatrix4 / Matrix4ToEuler /
+    QuatToMatrix4 / Matrix4ToQuat as the reference's own include/slam6d/globals.icc compiles them (oracle/_ref),
+    against (a) the oracle's restatements and (b) the product's host algebra (the tdtk_host_* diagnostics and the
+    Python mirror): every output bit for bit, on random poses, ill-scaled matrices and the singular case."""
+    import ctypes as C
+    from oracle import icp_oracle as io
+    if not orc.have_ref():
+        pytest.skip("reference TUs not built here")
+    L = tdtk.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rng = np.random.default_rng(12)
+    for trial in range(300):
+        pos = rng.uniform(-1000, 1000, 3) * (10.0 ** rng.integers(-3, 4))
+        th = rng.uniform(-np.pi, np.pi, 3)
+        if trial % 7 == 0:
+            th[1] = (np.pi / 2) * (1 if trial % 2 else -1) + rng.normal(0, 1e-4)     # near the Euler singularity
+        A = orc.ref_euler_to_matrix4(pos, th)
+        a_prod = np.empty(16); L.tdtk_host_euler_to_matrix4(dp(pos), dp(th), dp(a_prod))
+        assert np.array_equal(A, io.euler_to_matrix4(pos, th)) and np.array_equal(A, tdtk.EulerToMatrix4(pos, th))
+        assert np.array_equal(A, a_prod)
+        B = orc.ref_euler_to_matrix4(rng.uniform(-50, 50, 3), rng.uniform(-0.1, 0.1, 3))
+        rigid = orc.ref_mmult(A, B)
+        if trial % 5 == 0:                                # a general (non-rigid) matrix
+            A = A + rng.normal(0, 0.05, 16); A[15] = 1.0
+        inv_r, rc = orc.ref_m4inv_raw(A)
+        inv_o, ok = orc.m4inv(A)
+        assert rc == 1 and ok and np.array_equal(inv_r, inv_o) and np.array_equal(inv_r, tdtk.M4inv(A))
+        mm = orc.ref_mmult(A, B)
+        assert np.array_equal(mm, orc.mmult(A, B)) and np.array_equal(mm, tdtk.MMult(A, B))
+        if abs(rigid[8]) > 1.0:                           # asin domain: C gives NaN, Python raises; rounding can do it
+            rigid[8] = np.sign(rigid[8])
+        th_r, pos_r = orc.ref_matrix4_to_euler(rigid)
+        th_o, pos_o = io.matrix4_to_euler(rigid)
+        th_p, pos_p = tdtk.Matrix4ToEuler(rigid)
+        th_c, pos_c = np.empty(3), np.empty(3); L.tdtk_host_matrix4_to_euler(dp(rigid), dp(th_c), dp(pos_c))
+        for t_, p_ in ((th_o, pos_o), (th_p, pos_p), (th_c, pos_c)):
+            assert np.array_equal(th_r, np.asarray(t_)) and np.array_equal(pos_r, np.asarray(p_))
+        q_r, t_r = orc.ref_matrix4_to_quat(B)
+        q_o, t_o = io.matrix4_to_quat(B)
+        q_c, t_c = np.empty(4), np.empty(3); L.tdtk_host_matrix4_to_quat(dp(B), dp(q_c), dp(t_c))
+        assert np.array_equal(q_r, q_o) and np.array_equal(t_r, t_o) and np.array_equal(q_r, q_c) and np.array_equal(t_r, t_c)
+        assert np.array_equal(q_r, tdtk.Matrix4ToQuat(B)[0])
+        m_r = orc.ref_quat_to_matrix4(q_r, t_r)
+        m_c = np.empty(16); L.tdtk_host_quat_to_matrix4(dp(q_r), dp(t_r), dp(m_c))
+        assert np.array_equal(m_r, io.quat_to_matrix4(q_r, t_r)) and np.array_equal(m_r, m_c)
+        assert np.array_equal(m_r, tdtk.QuatToMatrix4(q_r, t_r))
+        pts = rng.uniform(-1000, 1000, (64, 3))
+        moved = orc.ref_transform3_inplace(A, pts)
+        p2 = pts.copy(); orc.transform_points(A, p2)
+        assert np.array_equal(moved, p2)
+        nr = rng.normal(size=(64, 3))
+        n2 = nr.copy(); orc.transform_normals(A, n2)
+        assert np.array_equal(orc.ref_transform3normal(A, nr), n2)
+    # singular input: "Error matrix inverting!", identity out, return 0 (globals.icc:765-769)
+    inv_r, rc = orc.ref_m4inv_raw(np.zeros(16))
+    inv_o, ok = orc.m4inv(np.zeros(16))
+    assert rc == 0 and not ok and np.array_equal(inv_r, inv_o) and np.array_equal(inv_r, tdtk.M4inv(np.zeros(16)))
+
+
+def test_transform3_out_of_place_form_against_reference(orc):
+    """transform3(alignxf, in, out) (globals.icc:1477-1490) -- the form SearchTree::getPtPairs uses for the query
+    and the hit (searchTree.cc:122,147) -- differs from the in-place form in its association; the oracle's
+    getPtPairs must use this one: pair lists through a non-trivial pose are compared with the reference's own
+    transform3 applied to the reference tree's hits."""
+    from oracle import icp_oracle as io
+    if not orc.have_ref():
+        pytest.skip("reference TUs not built here")
+    rng = np.random.default_rng(5)
+    m = rng.uniform(-100, 100, (20000, 3))
+    A = io.euler_to_matrix4([3.0, -2.0, 1.0], [0.03, -0.02, 0.05])
+    inv, _ = orc.ref_m4inv_raw(A)
+    world = orc.ref_transform3(A, m)[rng.permutation(len(m))[:5000]] + rng.normal(0, 0.3, (5000, 3))
+    T = orc.Tree(m, 10)
+    o = T.get_pt_pairs(A, world, None, 0, None, 0, 4.0)
+    q = orc.ref_transform3(inv, world)                        # searchTree.cc:122
+    ridx = orc.RefTree(m, 10).find_closest(q, 4.0)
+    assert np.array_equal(o["idx"], ridx)
+    found = ridx >= 0
+    assert np.array_equal(o["p1"], orc.ref_transform3(A, m[ridx[found]]))    # searchTree.cc:147
+    assert np.array_equal(o["p2"], world[found])
+
+
+def test_lum_link_system_against_newmat(orc, tdtk):
+    """A14: covarianceEuler's arithmetic (lum6Deuler.cc:143-232) evaluated with the reference's own newmat objects
+    (`MM.i() * MZ`, `MM * ss`) in oracle/_ref on the pinned dat/ pair lists: the numpy restatement, the committed
+    B4 fixture and the product's dense inverse (tdtk_invert, host) all agree with it."""
+    import ctypes as C
+    from oracle import icp_oracle as io
+    if not orc.have_ref():
+        pytest.skip("reference TUs not built here")
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    b1 = json.load(open(os.path.join(G, "b1_dat_icp.json")))
+    b4 = json.load(open(os.path.join(G, "b4_dat_lum.json")))
+    S = [io.OScan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], z["scan%03d" % k]) for k in range(3)]
+    for pr in b1["pairs"]:
+        i = pr["cur"]
+        S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+        for a in pr["alignxf"]:
+            S[i].transform(np.array(a))
+    for Lk in b4["links"]:
+        r = io.get_pt_pairs(S[Lk["first"]], S[Lk["second"]], 625.0)
+        Cr, CDr, ssr, Dr = orc.ref_lum_covariance_euler(r["p1"], r["p2"])
+        Co, CDo, m, sso, Do = io.covariance_euler(S[Lk["first"]], S[Lk["second"]], 625.0)
+        assert m == Lk["m"] == len(r["p1"])
+        np.testing.assert_allclose(sso, ssr, rtol=1e-12)
+        np.testing.assert_allclose(Do, Dr, rtol=1e-8, atol=1e-13)
+        np.testing.assert_allclose(Co, Cr, rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(CDo, CDr, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(Lk["C"], Cr, rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(Lk["ss"], ssr, rtol=1e-10)
+        # the product's inverse (pivoted Gauss-Jordan, linalg.cpp) on the same MM against newmat's .i()
+        MM = Cr * ssr
+        MZ = CDr * ssr
+        Ai, x = orc.ref_newmat_inverse_solve(MM, MZ)
+        mine = np.empty((6, 6))
+        assert tdtk.lib().tdtk_invert(MM.ctypes.data_as(C.POINTER(C.c_double)), 6, mine.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        np.testing.assert_allclose(mine @ MZ, x, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(x, Dr, rtol=1e-9, atol=1e-14)
+
+
 def test_b1_dat_icp_trace(orc):
     """The oracle loop with the numpy minimizer reproduces the committed trace that was
     generated with the REFERENCE minimizer (and SURVEY appendix B1)."""
