@@ -61,6 +61,8 @@ EXPORTS = [
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_point_point_error",
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_graph_exchange", "tdtk_graph_deal_links",
+    "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge",
     "tdtk_last_timings", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
     "tdtk_host_euler_to_matrix4", "tdtk_host_matrix4_to_euler", "tdtk_host_quat_to_matrix4", "tdtk_host_matrix4_to_quat",
@@ -141,6 +143,18 @@ def lib():
     L.tdtk_invert.argtypes = [_dp, C.c_int, _dp]
     L.tdtk_last_kernel_ms.argtypes = [_dp]
     L.tdtk_count_visits.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _u64p]
+    L.tdtk_comm_unique_id.argtypes = [C.c_char_p]
+    L.tdtk_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tdtk_comm_destroy.argtypes = [C.c_void_p]
+    L.tdtk_comm_destroy.restype = None
+    L.tdtk_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]
+    L.tdtk_graph_exchange.argtypes = [C.c_void_p, _dp, C.c_size_t]
+    L.tdtk_graph_deal_links.argtypes = [C.c_int, _ip, _ip, _u64p, C.c_int, C.c_int, _ip]
+    L.tdtk_graph_iteration.argtypes = [C.c_int, C.c_void_p, C.c_int, _ip, _ip, C.c_int, _ip, C.POINTER(C.c_void_p), _dp,
+                                       C.POINTER(C.c_void_p), C.c_double, C.c_int, _dp, _dp, _dp, _dp,
+                                       C.POINTER(C.c_void_p), _dp, _dp, _dp]
+    L.tdtk_elch_graph_balancer.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, _dp]
+    L.tdtk_pair_sums_merge.argtypes = [C.c_int, C.POINTER(PairSums), C.POINTER(PairSums)]
     L.tdtk_last_timings.argtypes = [_dp]
     L.tdtk_visit_counting.argtypes = [C.c_int, C.c_int]
     L.tdtk_visit_counters.argtypes = [C.c_int, _u64p]

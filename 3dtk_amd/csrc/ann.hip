@@ -839,14 +839,18 @@ static __device__ void eigen3_newmat(double z[3][3], double D[3])
 
 // One thread per scan point (grid-stride over leaf positions).  KMAX >= k; the list keeps KMAX - k sentinels
 // (key -1) in front so that every register index is static.
-template <int KMAX>
+// COUNT: also tally the splitting nodes and leaf points every query visits (cnt[0], cnt[1]) -- the instrumented
+// instantiation bench.py takes the algorithmic bytes of the launch from.
+template <int KMAX, bool COUNT>
 __global__ void __launch_bounds__(256) k_ann_normals(const AnnNode* __restrict__ nodes, uint32_t root_ref,
                                                      const KdPoint* __restrict__ pts, uint32_t n, int k,
                                                      double max_err, const double* __restrict__ bb, double rx,
                                                      double ry, double rz, uint32_t* __restrict__ spill_ref,
                                                      double* __restrict__ spill_bd, uint32_t spill_depth,
-                                                     double* __restrict__ normals, int32_t* __restrict__ knn_out)
+                                                     double* __restrict__ normals, int32_t* __restrict__ knn_out,
+                                                     unsigned long long* __restrict__ cnt)
 {
+  unsigned c_split = 0, c_leaf = 0;
   __shared__ uint32_t s_ref[ANN_LDS_STACK][256];
   __shared__ double s_bd[ANN_LDS_STACK][256];
   const uint32_t T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, tx = threadIdx.x;
@@ -870,6 +874,7 @@ __global__ void __launch_bounds__(256) k_ann_normals(const AnnNode* __restrict__
     int sp = 0;
     for (;;) {
       while (!(cur & A_LEAF)) {                      // ANNkd_split::ann_search (kd_search.cpp:128-170)
+        if (COUNT) ++c_split;
         const AnnNode nd = nodes[cur & A_VAL];
         const uint32_t cd = nd.c0 >> 30;
         const double qd = (cd == 0) ? q[0] : ((cd == 1) ? q[1] : q[2]);
@@ -891,6 +896,7 @@ __global__ void __launch_bounds__(256) k_ann_normals(const AnnNode* __restrict__
       }
       {                                              // ANNkd_leaf::ann_search, one point (kd_search.cpp:177-210)
         const uint32_t pos = cur & A_VAL;
+        if (COUNT) ++c_leaf;
         const KdPoint p = pts[pos];
         const double t0 = q[0] - p.x, t1 = q[1] - p.y, t2 = q[2] - p.z;
         const double dist = (t0 * t0 + t1 * t1) + t2 * t2;
@@ -956,6 +962,12 @@ __global__ void __launch_bounds__(256) k_ann_normals(const AnnNode* __restrict__
     normals[3 * (size_t)qp.orig + 1] = nv[1] * nl;
     normals[3 * (size_t)qp.orig + 2] = nv[2] * nl;
   }
+  if (COUNT && cnt) {
+    unsigned long long a = c_split, b = c_leaf;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&cnt[0], a); atomicAdd(&cnt[1], b); }
+  }
 }
 
 uint32_t ann_search_threads(size_t n)
@@ -971,14 +983,20 @@ size_t ann_spill_entries(size_t n, uint32_t max_depth)
 
 hipError_t launch_ann_normals(const AnnNode* nodes, uint32_t root_ref, const KdPoint* pts, size_t n, int k, double eps,
                               const double* d_bb, const double rPos[3], uint32_t* spill_ref, double* spill_bd,
-                              uint32_t max_depth, double* d_normals, int32_t* d_knn, hipStream_t s)
+                              uint32_t max_depth, double* d_normals, int32_t* d_knn, unsigned long long* d_cnt, hipStream_t s)
 {
   const uint32_t T = ann_search_threads(n);
   const double max_err = (1.0 + eps) * (1.0 + eps);    // ANN_POW(1.0 + eps), kd_search.cpp:108
   const dim3 grid(T / 256), block(256);
-#define ANN_LAUNCH(KM)                                                                                               \
-  hipLaunchKernelGGL(k_ann_normals<KM>, grid, block, 0, s, nodes, root_ref, pts, (uint32_t)n, k, max_err, d_bb, rPos[0], \
-                     rPos[1], rPos[2], spill_ref, spill_bd, max_depth, d_normals, d_knn)
+#define ANN_LAUNCH(KM)                                                                                                \
+  do {                                                                                                                \
+    if (d_cnt)                                                                                                        \
+      hipLaunchKernelGGL((k_ann_normals<KM, true>), grid, block, 0, s, nodes, root_ref, pts, (uint32_t)n, k, max_err, d_bb, \
+                         rPos[0], rPos[1], rPos[2], spill_ref, spill_bd, max_depth, d_normals, d_knn, d_cnt);          \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_ann_normals<KM, false>), grid, block, 0, s, nodes, root_ref, pts, (uint32_t)n, k, max_err, d_bb, \
+                         rPos[0], rPos[1], rPos[2], spill_ref, spill_bd, max_depth, d_normals, d_knn, d_cnt);          \
+  } while (0)
   if (k <= 10) ANN_LAUNCH(10);
   else if (k <= 16) ANN_LAUNCH(16);
   else if (k <= 32) ANN_LAUNCH(32);

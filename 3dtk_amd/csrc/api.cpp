@@ -101,11 +101,13 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;   // around the search kernel of the last pass
   hipEvent_t e2 = nullptr, e3 = nullptr;   // around the pair-sum kernels behind it (k_accum + k_final, or k_final alone)
+  hipEvent_t e4 = nullptr, e5 = nullptr;   // around k_ann_normals of the last calcNormals
   hipEvent_t e_user = nullptr;             // fence between a caller's stream and this context's stream
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
-  double last_nn_ms = 0.0, last_sums_ms = 0.0;
-  bool ev_pending = false, ev2_pending = false;
+  double last_nn_ms = 0.0, last_sums_ms = 0.0, last_normals_ms = 0.0, last_build_ms = 0.0;
+  bool ev_pending = false, ev2_pending = false, ev4_pending = false;
+  uint64_t counted_ann_queries = 0;
   // tdtk_visit_counting: every search of this thread runs its instrumented instantiation and adds to d_counters
   bool counting = false;
   DevBuf d_counters;
@@ -121,6 +123,8 @@ struct Ctx {
     if (e1) (void)hipEventDestroy(e1);
     if (e2) (void)hipEventDestroy(e2);
     if (e3) (void)hipEventDestroy(e3);
+    if (e4) (void)hipEventDestroy(e4);
+    if (e5) (void)hipEventDestroy(e5);
     if (e_user) (void)hipEventDestroy(e_user);
     if (h_pin) (void)hipHostFree(h_pin);
     if (stream) (void)hipStreamDestroy(stream);
@@ -147,6 +151,8 @@ static int get_ctx(int device, Ctx** out)
     HIPCHK(hipEventCreate(&c->e1));
     HIPCHK(hipEventCreate(&c->e2));
     HIPCHK(hipEventCreate(&c->e3));
+    HIPCHK(hipEventCreate(&c->e4));
+    HIPCHK(hipEventCreate(&c->e5));
     HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
     it = g_ctx.emplace(device, std::move(c)).first;
@@ -256,6 +262,7 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   t->info.n_internal = r.n_internal; t->info.n_leaves = r.n_leaves;
   t->info.max_depth = r.max_depth; t->info.max_leaf_points = r.max_leaf;
   t->info.build_ms = now_ms() - t1;
+  c->last_build_ms = t->info.build_ms;
   return TDTK_OK;
 }
 
@@ -479,19 +486,26 @@ static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
     c->last_sums_ms = f;
     c->ev2_pending = false;
   }
+  if (c->ev4_pending) {
+    HIPCHK(hipEventSynchronize(c->e5));
+    float f = 0;
+    HIPCHK(hipEventElapsedTime(&f, c->e4, c->e5));
+    c->last_normals_ms = f;
+    c->ev4_pending = false;
+  }
   if (ms) *ms = c->last_nn_ms;
   if (sums_ms) *sums_ms = c->last_sums_ms;
   return TDTK_OK;
 }
 
+// Retire-time accumulation inside the search kernel (kernels.hip, FUSE) is OFF by default: its 34 accumulator
+// registers take the kernel from 7 to 4 waves per SIMD and every retire waits for its own gather, so the search
+// grows by about what the separate pair-sum pass costs (1M-vs-1M ICP: 0.2881 + 0.0072 ms fused against
+// 0.2708 + 0.0280 ms; 4M: 1.179 + 0.016 against 0.965 + 0.058 -- gpurun_out/r2a/sweep.log).  TDTK_FUSE_SUMS=1 selects it.
 static bool fuse_enabled()
 {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TDTK_FUSE_SUMS");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
+  const char* e = getenv("TDTK_FUSE_SUMS");
+  return e && e[0] == '1';
 }
 
 // acc[ACC_TOTAL] (sums about `shift`) -> the reference's quantities
@@ -885,7 +899,7 @@ int tdtk_last_kernel_ms(double* nn_ms)
   return collect_ms(c, nn_ms);
 }
 
-int tdtk_last_timings(double out[2])
+int tdtk_last_timings(double out[4])
 {
   if (!out) { set_error("NULL argument"); return TDTK_EINVAL; }
   int dev = 0;
@@ -893,7 +907,10 @@ int tdtk_last_timings(double out[2])
   Ctx* c;
   int rc = get_ctx(dev, &c);
   if (rc) return rc;
-  return collect_ms(c, &out[0], &out[1]);
+  rc = collect_ms(c, &out[0], &out[1]);
+  out[2] = c->last_normals_ms;
+  out[3] = c->last_build_ms;
+  return rc;
 }
 
 // every FindClosest pass this thread runs on `device` from now on uses the instrumented instantiation of the
@@ -904,27 +921,31 @@ int tdtk_visit_counting(int device, int on)
   int rc = get_ctx(device, &c);
   if (rc) return rc;
   if (on) {
-    if ((rc = c->d_counters.ensure(4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = c->d_counters.ensure(8 * sizeof(unsigned long long)))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemset(c->d_counters.p, 0, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_counters.p, 0, 8 * sizeof(unsigned long long)));
     c->counted_queries = 0;
+    c->counted_ann_queries = 0;
   }
   c->counting = on != 0;
   return TDTK_OK;
 }
 
-int tdtk_visit_counters(int device, uint64_t out[4])
+int tdtk_visit_counters(int device, uint64_t out[8])
 {
   if (!out) { set_error("NULL argument"); return TDTK_EINVAL; }
   Ctx* c;
   int rc = get_ctx(device, &c);
   if (rc) return rc;
-  out[0] = out[1] = out[2] = 0; out[3] = c->counted_queries;
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  out[3] = c->counted_queries;
+  out[6] = c->counted_ann_queries;
   if (!c->d_counters.p) return TDTK_OK;
   HIPCHK(hipDeviceSynchronize());   // link passes run on auxiliary streams
-  unsigned long long h[3];
+  unsigned long long h[6];
   HIPCHK(hipMemcpy(h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost));
   for (int k = 0; k < 3; k++) out[k] = h[k];
+  out[4] = h[4]; out[5] = h[5];
   return TDTK_OK;
 }
 
@@ -1038,8 +1059,13 @@ static int normals_on_device(Ctx* c, const double* d_xyz, size_t n, int k, const
   const size_t spill = ann_spill_entries(n, r.max_depth);
   if ((rc = c->ws[WS_OVF_REF].ensure((spill + 1) * sizeof(uint32_t)))) return rc;
   if ((rc = c->ws[WS_OVF_M2].ensure((spill + 1) * sizeof(double)))) return rc;
+  unsigned long long* d_cnt = nullptr;
+  if (c->counting) { d_cnt = c->d_counters.as<unsigned long long>() + 4; c->counted_ann_queries += n; }
+  HIPCHK(hipEventRecord(c->e4, s));
   HIPCHK(launch_ann_normals(nodes, r.root_ref, pts, n, k, eps, d_bb, rPos, c->ws[WS_OVF_REF].as<uint32_t>(),
-                            c->ws[WS_OVF_M2].as<double>(), r.max_depth, d_normals, d_knn, s));
+                            c->ws[WS_OVF_M2].as<double>(), r.max_depth, d_normals, d_knn, d_cnt, s));
+  HIPCHK(hipEventRecord(c->e5, s));
+  c->ev4_pending = true;
   return TDTK_OK;
 }
 

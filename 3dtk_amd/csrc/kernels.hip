@@ -784,11 +784,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 // k_accum pass over (x, y, z, kpos, pts[kpos]) disappears.  Per-lane fp64 accumulators in registers (their order
 // is the lane's retire order, which is a function of the traversal alone -> run-to-run bit-identical), one wave
 // reduction at the end, one row per workgroup for k_final.  Pairing mode 0 / base block only.
-// DYN: the wave does not own a fixed slab; it draws `a.slab` consecutive sorted queries at a time from a work queue
-// (one atomic counter per eighth of the scan, starting with the eighth of the XCD the wave really runs on and moving
-// on to the others when that is empty).  A statically assigned slab ends with a drain -- the last lanes of every
-// 256-query slab finish alone -- which is where most of the idle lane-slots of the static kernel were; with the queue
-// a wave drains once, at the end of the launch, and the tail of the launch is balanced by construction.
+// DYN (TDTK_SEARCH_VARIANT=30, a measured negative): the wave does not own a fixed slab; it draws `a.slab` consecutive
+// sorted queries at a time from a work queue (one atomic counter per eighth of the scan, starting with the eighth of
+// the XCD the wave really runs on and moving on to the others when that is empty), so that it drains only once, at
+// the end of the launch, instead of at the end of every slab.  Two things defeat it: (a) a device-scope atomic on a
+// contended counter costs ~0.6 us and they serialise per counter (1M queries, 64-query draws: 0.93 ms against 0.27 ms
+// static; 256-query draws: 0.58 ms), and (b) the premise is wrong at this size -- a chip full of resident waves
+// (7168) leaves 1M queries only ~140 per wave, i.e. MORE drains per query than the static 224..256-query slabs.
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, bool FUSE, bool DYN>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
 {
@@ -1031,12 +1033,32 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   for (int k = 0; k < ACC_TOTAL; k++) acc[k] = 0.0;
 
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(a.T.pts);
-  const size_t stride = (size_t)gridDim.x * BLOCK;
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += stride) {
-    const int k = a.kpos[i];
+  // a workgroup walks 4 * BLOCK consecutive queries per step: the four hit positions, then the four gathers and the
+  // query coordinates are all requested before the first use (the gather depends on the hit position; one query at a
+  // time exposes that round trip four times)
+  constexpr int U = 4;
+  const size_t stride = (size_t)gridDim.x * BLOCK * U;
+  for (size_t base = (size_t)blockIdx.x * BLOCK * U + threadIdx.x; base < a.n; base += stride) {
+    int kk[U];
+    double4 cc[U];
+    double qx_[U], qy_[U], qz_[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u * BLOCK;
+      kk[u] = (i < a.n) ? a.kpos[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u * BLOCK;
+      if (kk[u] >= 0) { cc[u] = pts[kk[u]]; qx_[u] = a.x[i]; qy_[u] = a.y[i]; qz_[u] = a.z[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+    const size_t i = base + (size_t)u * BLOCK;
+    const int k = kk[u];
     if (k < 0) continue;
-    const double tx = a.x[i], ty = a.y[i], tz = a.z[i];
-    const double4 c = pts[k];
+    const double tx = qx_[u], ty = qy_[u], tz = qz_[u];
+    const double4 c = cc[u];
     double mx, my, mz;
     dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);  // searchTree.cc:147
     double nxv = 0, nyv = 0, nzv = 0;
@@ -1106,6 +1128,7 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
         const double e2 = dz - (a.D[2] + y * a.D[3] - x * a.D[5]);
         acc[ACC_LSS] += e0 * e0 + e1 * e1 + e2 * e2;
       }
+    }
     }
   }
 
@@ -1341,14 +1364,13 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 //   9 / 10 / 11: eight / four / sixteen lanes per query (k_search_g8); four is the default below 96K queries
 //  20: persistent lanes, 256 queries per wave, 128-thread workgroups
 //  30: persistent lanes fed from a work queue (k_search_refill<.., DYN>): resident waves draw 64-query slabs
+// (the TDTK_* knobs are read on every launch: a getenv is nothing beside a launch, and tests / probes flip them
+// inside one process)
 static int search_variant()
 {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TDTK_SEARCH_VARIANT");
-    v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-    if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30) v = -2;
-  }
+  const char* e = getenv("TDTK_SEARCH_VARIANT");
+  int v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
+  if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30) v = -2;
   return v;
 }
 
@@ -1366,21 +1388,31 @@ uint32_t search_grid(size_t n)
 // persistent-lane grids: one wave per `qpw` consecutive sorted queries (256 by default), never more lanes than
 // search_grid() launches -- the stack overflow area is sized for that many -- so a batch beyond the cap gives
 // every wave a longer slab instead of adding waves (qpw is a kernel argument)
-static int refill_qpw_env()
+// Slab length of the persistent-lane kernel.  Two opposing costs: every slab ends with a drain (its last lanes finish
+// alone), so longer slabs waste fewer lane-slots -- but the chip holds 7 of these waves per SIMD and a batch of 1M
+// queries is only ~15 queries per lane-slot, so long slabs leave SIMDs without enough waves to hide the dependent
+// loads.  Measured on the ICP loop (gpurun_out/r2a, r2b): 1M queries: 128 -> 0.276 ms, 160 -> 0.280, 192 -> 0.258,
+// 224 -> 0.255, 256 -> 0.273, 384 -> 0.341, 512 -> 0.386; 4M queries: 192 -> 0.998, 256 -> 0.965 (best), 384 -> 0.991,
+// 512 -> 1.096.  Rule: 256, unless all waves fit on the chip at once anyway -- then ~4.5 waves per SIMD.
+static int refill_qpw(size_t n)
 {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TDTK_REFILL_QPW");
-    v = e ? atoi(e) : 256;
+  if (const char* e = getenv("TDTK_REFILL_QPW")) {
+    int v = atoi(e);
     if (v < 64) v = 64;
-    v = (v + 63) & ~63;
+    return (v + 31) & ~31;
   }
-  return v;
+  const size_t resident = (size_t)num_cu() * 4 * 7;
+  if ((n + 255) / 256 >= resident) return 256;
+  size_t q = (n + (size_t)num_cu() * 18 - 1) / ((size_t)num_cu() * 18);   // 4.5 waves per SIMD
+  q = (q + 31) & ~(size_t)31;
+  if (q < 128) q = 128;
+  if (q > 256) q = 256;
+  return (int)q;
 }
 static uint32_t refill_grid_b(size_t n, int block, int* qpw_out)
 {
   const size_t wpb = (size_t)block / WAVE;
-  size_t qpw = (size_t)refill_qpw_env();
+  size_t qpw = (size_t)refill_qpw(n);
   size_t waves = (n + qpw - 1) / qpw;
   size_t nb = (waves + wpb - 1) / wpb;
   nb = (nb + 7) & ~(size_t)7;
@@ -1419,12 +1451,9 @@ int search_block() { return SEARCH_BLOCK; }
 
 static int refill_thresh_env()
 {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TDTK_REFILL_THRESH");
-    v = e ? atoi(e) : 16;
-    if (v != 8 && v != 16 && v != 32) v = 16;
-  }
+  const char* e = getenv("TDTK_REFILL_THRESH");
+  int v = e ? atoi(e) : 16;
+  if (v != 8 && v != 16 && v != 32) v = 16;
   return v;
 }
 // which kernel a batch of n queries gets (TDTK_SEARCH_VARIANT overrides)
@@ -1461,23 +1490,17 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 // never more waves than there are slabs to draw
 static int stream_slab_env()
 {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TDTK_STREAM_SLAB");
-    v = e ? atoi(e) : 64;
-    if (v < 16) v = 16;
-  }
+  const char* e = getenv("TDTK_STREAM_SLAB");
+  int v = e ? atoi(e) : 256;
+  if (v < 16) v = 16;
   return v;
 }
 static uint32_t stream_grid(size_t n)
 {
-  static int wps = -1;
-  if (wps < 0) {
-    const char* e = getenv("TDTK_STREAM_WPS");
-    wps = e ? atoi(e) : 7;
-    if (wps < 1) wps = 1;
-    if (wps > 8) wps = 8;
-  }
+  const char* e = getenv("TDTK_STREAM_WPS");
+  int wps = e ? atoi(e) : 4;
+  if (wps < 1) wps = 1;
+  if (wps > 8) wps = 8;
   size_t waves = (size_t)num_cu() * 4 * (size_t)wps;
   const size_t slabs = (n + (size_t)stream_slab_env() - 1) / (size_t)stream_slab_env();
   if (waves > slabs) waves = slabs;
@@ -1591,7 +1614,7 @@ hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hi
 constexpr int ACC_BLOCK = 256;
 uint32_t accum_grid(size_t n)
 {
-  size_t want = (n + ACC_BLOCK - 1) / ACC_BLOCK;
+  size_t want = (n + ACC_BLOCK * 4 - 1) / (ACC_BLOCK * 4);   // k_accum: 4 queries per thread and step
   size_t cap = (size_t)num_cu() * 4;
   size_t nb = want < cap ? want : cap;
   return (uint32_t)(nb ? nb : 1);

@@ -3,12 +3,13 @@
 Reference: lum6DEuler::FillGB3D / doGraphSlam6D (src/slam6d/lum6Deuler.cc:265-477).  The
 reference parallelises FillGB3D with `omp parallel for` over graph links and adds each link's
 6x6 C and 6-vector CD into the global system under `omp critical`.  Here the independent unit
-is the same -- one link = one whole-scan correspondence pass -- but links are dealt
-round-robin to the ranks of one node (one process per MI355X, every scan and tree replicated
-in each GPU's HBM), each rank accumulates its links into a local dense (G | B), and ONE
-all-reduce (sum, fp64) per LUM iteration over RCCL/xGMI combines them: (6(n-1))^2 + 6(n-1)
-doubles, 1.1 MB for 64 scans -- latency-bound, so it is a single flat buffer, not bucketed.
-Every rank then solves the small SPD system redundantly and moves its own replicas.
+is the same -- one link = one whole-scan correspondence pass -- but links are dealt to the ranks of
+one node (one process per MI355X; a rank keeps only the trees / scans its links touch), each rank
+computes the blocks of its links, and ONE all-reduce (sum, fp64) per iteration over RCCL/xGMI makes
+every link's block known everywhere: 42 doubles per link, 28 KB for the 84 links of 64 scans --
+latency-bound, one flat buffer.  Every rank then solves the small SPD system redundantly and moves
+its own replicas.  graph_iteration_comm runs all of that inside the library (tdtk_graph_iteration with
+the library's own RCCL communicator); the torch.distributed variants below serve the gloo test rig.
 """
 import math
 import os
@@ -18,21 +19,81 @@ import numpy as np
 from . import slam6d as _s
 
 
-def shard_links(gr, rank, world):
-    """Which links of `gr` this rank evaluates.  Links cost the same when scans have equal size, so
-    the odometry chain (links 0..n-2, always present) is dealt round-robin; loop-closure links are
-    keyed by their end points, (from + to) % world, so that a closure appearing or disappearing
-    between LUM rounds (the Graph is rebuilt from the current poses every round,
-    src/slam6d/slam6D.cc:501-532) does not reshuffle every other link -- and with it every
-    resident tree and scan -- across the ranks."""
-    chain = gr.getNrScans() - 1
-    mine = []
-    for i in range(gr.getNrLinks()):
-        f, t = gr.getLink(i, 0), gr.getLink(i, 1)
-        owner = (i % world) if (i < chain and t == f + 1) else ((f + t) % world)
-        if owner == rank:
-            mine.append(i)
-    return mine
+def link_owners(gr, world, scans=None):
+    """owner[i] = the rank that evaluates link i (tdtk_graph_deal_links).  A link costs one whole-scan pass over its
+    second scan.  Scans of equal size: the odometry chain (links 0..n-2, always present) is dealt round-robin and
+    loop closures are keyed by their end points, (from + to) % world, so that a closure appearing or disappearing
+    between LUM rounds (the Graph is rebuilt from the current poses every round, src/slam6d/slam6D.cc:501-532) does
+    not reshuffle every other link -- and with it every resident tree and scan -- across the ranks.  Scans of
+    different size (real data): longest-processing-time-first by the point count of the second scan."""
+    import ctypes as C
+    from ._capi import lib, check, iptr
+    nl, ns = gr.getNrLinks(), gr.getNrScans()
+    frm = np.ascontiguousarray([gr.getLink(i, 0) for i in range(nl)], dtype=np.int32)
+    to = np.ascontiguousarray([gr.getLink(i, 1) for i in range(nl)], dtype=np.int32)
+    owner = np.zeros(nl, np.int32)
+    pts = None
+    if scans is not None:
+        pts = np.ascontiguousarray([s.n for s in scans[:ns]], dtype=np.uint64)
+    check(lib().tdtk_graph_deal_links(nl, iptr(frm), iptr(to), pts.ctypes.data_as(C.POINTER(C.c_uint64)) if pts is not None else None,
+                                      ns, int(world), iptr(owner)))
+    return owner
+
+
+def shard_links(gr, rank, world, scans=None):
+    """Which links of `gr` this rank evaluates (see link_owners)."""
+    return [int(i) for i in np.flatnonzero(link_owners(gr, world, scans) == rank)]
+
+
+class NativeComm:
+    """The library's own RCCL communicator (tdtk_comm_*): the all-reduce of the link blocks runs inside
+    tdtk_graph_iteration, C++ end to end.  The 128-byte unique id travels from rank 0 to the others through
+    `bcast` (a callable bytes -> bytes; torch.distributed in bench.py, anything else elsewhere)."""
+
+    def __init__(self, rank, world, device, bcast=None):
+        import ctypes as C
+        from ._capi import lib, check
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(lib().tdtk_comm_unique_id(buf))
+        ident = bytes(buf.raw)
+        if world > 1:
+            if bcast is None:
+                raise ValueError("a multi-rank communicator needs a way to hand out the unique id")
+            ident = bcast(ident)
+        h = C.c_void_p()
+        check(lib().tdtk_comm_create(ident, int(rank), int(world), int(device), C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    def n_allreduce(self):
+        import ctypes as C
+        from ._capi import lib
+        n = C.c_uint64(0)
+        lib().tdtk_comm_info(self._h, None, None, C.byref(n))
+        return int(n.value)
+
+    def close(self):
+        from ._capi import lib
+        if self._h:
+            lib().tdtk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_id_bcast(device=None):
+    """unique-id hand-out over an initialised torch.distributed group (rank 0 is the source)"""
+    def bcast(ident):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=device)
+        dist.broadcast(t, 0)
+        return bytes(t.cpu().tolist())
+    return bcast
 
 
 def fill_GB(gr, allScans, max_dist_match2, link_fn, rank=0, world=1):
@@ -203,12 +264,53 @@ def graph_state(backend, nscans):
     return None
 
 
+def graph_iteration_comm(backend, gr, allScans, max_dist_match2, comm, state=None):
+    """One iteration of doGraphSlam6D of back-end `backend` with the library's own communicator: link passes of this
+    rank, ncclAllReduce of the blocks, solve and pose update all inside tdtk_graph_iteration -- Python only
+    marshals the handles and poses in and the poses out.  comm = NativeComm or None (single process)."""
+    import ctypes as C
+    from ._capi import lib, check, dptr, iptr
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    nscans, nlinks = gr.getNrScans(), gr.getNrLinks()
+    sc = allScans[:nscans]
+    mine = shard_links(gr, rank, world, sc)
+    nl = len(mine)
+    frm = np.ascontiguousarray([gr.getLink(i, 0) for i in range(nlinks)], dtype=np.int32)
+    to = np.ascontiguousarray([gr.getLink(i, 1) for i in range(nlinks)], dtype=np.int32)
+    first = (C.c_void_p * max(1, nl))(*[sc[frm[i]].getSearchTree()._h for i in mine])
+    second = (C.c_void_p * max(1, nl))(*[sc[to[i]].handle for i in mine])
+    dal = np.ascontiguousarray(np.stack([sc[frm[i]].dalignxf for i in mine])) if nl else np.zeros((1, 16))
+    mine_a = np.ascontiguousarray(mine, dtype=np.int32) if nl else np.zeros(1, np.int32)
+    tm = np.ascontiguousarray(np.stack([s.transMat for s in sc]))
+    da = np.ascontiguousarray(np.stack([s.dalignxf for s in sc]))
+    rp = np.ascontiguousarray(np.stack([s.rPos for s in sc]))
+    rt = np.ascontiguousarray(np.stack([s.rPosTheta for s in sc]))
+    hs = (C.c_void_p * nscans)(*[s._h for s in sc])
+    xf = np.zeros((nscans, 32))
+    ret = C.c_double(0.0)
+    check(lib().tdtk_graph_iteration(int(backend), comm._h if comm is not None else None, nlinks, iptr(frm), iptr(to), nl,
+                                     iptr(mine_a), first, dptr(dal), second, float(max_dist_match2), nscans, dptr(tm), dptr(da),
+                                     dptr(rp), dptr(rt), hs, dptr(state) if state is not None else None, dptr(xf),
+                                     C.byref(ret)))
+    two = backend in (GRAPH_LUMEULER, GRAPH_LUMQUAT)
+    for i in range(1, nscans):
+        s = sc[i]
+        s.transMat, s.dalignxf, s.rPos, s.rPosTheta = tm[i], da[i], rp[i], rt[i]
+        if s._h is None:
+            s._queue.append(xf[i, :16])
+            if two:
+                s._queue.append(xf[i, 16:])
+        s.frames.append((tm[i], "LUM"))
+    return ret.value
+
+
 def graph_iteration(backend, gr, allScans, max_dist_match2, state=None, group=None, device=None):
     """One iteration of doGraphSlam6D of the back-end `backend` (-G id), everything numeric in the library:
     this rank's links in one batched call (tdtk_graph_link_blocks), ONE all-reduce of the per-link blocks
     (each link has exactly one owner, so the sum is exact and the result does not depend on the number of
     ranks), then scatter in link order + solve + pose update on every rank (tdtk_graph_solve_update), which
-    also moves the resident scans.  Returns `ret`."""
+    also moves the resident scans.  Returns `ret`.  (The exchange here goes through torch.distributed -- the CPU
+    test rig's gloo groups; with RCCL use graph_iteration_comm.)"""
     import ctypes as C
     from ._capi import lib, check, dptr, iptr
     rank, world = _rank_world(group)

@@ -338,6 +338,7 @@ class Scan:
             self._local_n = calculateNormalsApxKNN(self._local, self.K_NEIGHBOURS, self.rPos, 1.0, self.device)
         else:
             check(lib().tdtk_scan_calc_normals(self._h, self.K_NEIGHBOURS, dptr(self.rPos), 1.0))
+            self._has_device_normals = True
         return self
 
     # accessors named as in scan.h
@@ -387,6 +388,15 @@ class Scan:
 
     def get_xyz_reduced(self):
         return self._download(self.handle)
+
+    def get_normal_reduced(self):
+        """"normal reduced" of the resident scan (None when the scan has no normals)"""
+        h = self.handle
+        if self._local_n is None and not getattr(self, "_has_device_normals", False):
+            return None
+        xyz, nrm = np.empty((self.n, 3)), np.empty((self.n, 3))
+        check(lib().tdtk_scan_download(h, dptr(xyz), dptr(nrm)))
+        return nrm
 
     def getSearchTree(self):
         """scan.cc:268-306 -> basicScan.cc:702-728: lazily built over "xyz reduced original"."""
@@ -506,6 +516,36 @@ class MetaScan:
     def size(self): return len(self.m_scans)
     def getScan(self, i): return self.m_scans[i]
     def getDAlign(self): return self.dalignxf
+
+    def transform(self, alignxf, type="ICP", islum=0):
+        """Scan::transform on a MetaScan (scan.cc:920-926): every member scan is moved (without frames of its own:
+        islum -1), then the MetaScan's own matrices; the frames written for `islum` go to the member scans
+        (in_meta, scan.cc:962-975)."""
+        alignxf = f64(alignxf, 16).copy()
+        members = [m for m in self.m_scans if m._h is not None]
+        if members:                                           # one launch for all resident members
+            hs = (C.c_void_p * len(members))(*[m._h for m in members])
+            A = np.ascontiguousarray(np.tile(alignxf, (len(members), 1)))
+            check(lib().tdtk_scans_transform2(len(members), hs, dptr(A), None))
+        for m in self.m_scans:
+            if m._h is None:
+                m._queue.append(alignxf)
+            m._transformMatrix(alignxf)
+        self.transMat = MMult(alignxf, self.transMat)
+        self.dalignxf = MMult(alignxf, self.dalignxf)
+        if type != "INVALID" and islum == 0:
+            scans = Scan.allScans
+            if not any(any(sc is m for m in self.m_scans) for sc in scans):
+                for m in self.m_scans:
+                    m.addFrame(type)
+                return
+            found = 0
+            for i, sc in enumerate(scans):
+                if any(sc is m for m in self.m_scans):
+                    found = i
+                    sc.addFrame(type)
+                else:
+                    sc.addFrame("ICPINACTIVE" if found == 0 else "INVALID")
 
     def getSearchTree(self):
         if self.kd is None:   # device to device: the scans' current points never visit the host
@@ -711,6 +751,8 @@ class icp6D:
 
     def match(self, PreviousScan, CurrentScan, pairing_mode=0):
         """icp6D::match (icp6D.cc:104-285).  Returns the number of iterations done."""
+        if isinstance(CurrentScan, MetaScan):
+            return self._match_meta_data(PreviousScan, CurrentScan)
         if self.rnd > 1:
             return self._match_stepped(PreviousScan, CurrentScan, pairing_mode)
         CurrentScan._addFrames("ICP", 0)          # transform(id, ICP, 0), icp6D.cc:109
@@ -774,6 +816,49 @@ class icp6D:
                 break
         self.last = dict(iterations=it, converged=it != self.max_num_iterations - 1, pairs=self.nr_pointPair,
                          rms=ret, total_ms=0.0, nn_ms=0.0, trace=np.array(trace))
+        return it
+
+    def _match_meta_data(self, PreviousScan, CurrentMeta):
+        """icp6D::match with a MetaScan as the DATA scan (ELCH matches MetaScan(first..first+2) against
+        MetaScan(last-2..last), elch6Deuler.cc:77-102): Scan::getPtPairsParallel walks the member scans' "xyz reduced"
+        (scan.cc:1305-1327), the partial sums are merged (Align_Parallel, icp6Dquat.cc:533-588), and
+        MetaScan::transform moves every member.  One batched device call per iteration for all members
+        (tdtk_links_pair_sums), merged in the library (tdtk_pair_sums_merge).  QUAT / SVD only (what merges from the
+        base block)."""
+        algo = int(self.my_icp6Dminimizer.getAlgorithmID())
+        if algo not in (ALGO_QUAT, ALGO_SVD):
+            raise capi.TdtkError(-5, "a MetaScan as data scan is matched with -a 1 or -a 2 only")
+        CurrentMeta.transform(M4identity(), "ICP", 0)                      # icp6D.cc:109
+        if self.max_num_iterations == 0:
+            return 0
+        tree = PreviousScan.getSearchTree()
+        members = CurrentMeta.m_scans
+        nl = len(members)
+        first = (C.c_void_p * nl)(*[tree._h] * nl)
+        second = (C.c_void_p * nl)(*[m.handle for m in members])
+        dal = np.ascontiguousarray(np.tile(f64(PreviousScan.dalignxf, 16), (nl, 1)))
+        ret = prev_ret = prev_prev_ret = 0.0
+        trace = []
+        it = 0
+        for it in range(self.max_num_iterations):
+            prev_prev_ret, prev_ret = prev_ret, ret
+            parts = (PairSums * nl)()
+            check(lib().tdtk_links_pair_sums(nl, first, dptr(dal), second, float(self.max_dist_match2), 0, parts))
+            merged = PairSums()
+            check(lib().tdtk_pair_sums_merge(nl, parts, C.byref(merged)))
+            self.nr_pointPair = int(merged.n)
+            if merged.n > 3:
+                ret, alignxf = self.my_icp6Dminimizer.Align_Parallel(merged)
+            else:
+                break
+            trace.append(np.concatenate([[merged.n, ret], alignxf]))
+            CurrentMeta.transform(alignxf, "ICP", 0 if it == 0 else -1)     # icp6D.cc:258-264, anim = -1
+            if (abs(ret - prev_ret) < self.epsilonICP and abs(ret - prev_prev_ret) < self.epsilonICP) or \
+                    it == self.max_num_iterations - 1:
+                CurrentMeta.transform(M4identity(), "ICP", 0)               # write end pose
+                break
+        self.last = dict(iterations=it, converged=it != self.max_num_iterations - 1, pairs=self.nr_pointPair, rms=ret,
+                         total_ms=0.0, nn_ms=0.0, sums_ms=0.0, trace=np.array(trace))
         return it
 
     def Point_Point_Error(self, PreviousScan, CurrentScan, max_dist_match, scale_max=None):
@@ -1045,6 +1130,71 @@ class gapx6D(_graphSlam6D_setters):
         return ret
 
 
+# ---------------------------------------------------------------------------------------
+# loop closing (-L 1): loopSlam6D (include/slam6d/loopSlam6D.h), elch6D::graph_balancer (src/slam6d/elch6D.cc:186-279),
+# elch6Deuler::close_loop (src/slam6d/elch6Deuler.cc:44-138)
+# ---------------------------------------------------------------------------------------
+class loopSlam6D:
+    def __init__(self, quiet, my_icp6Dminimizer, mdm, max_num_iterations, rnd=1, eP=True, anim=-1, epsilonICP=0.0000001,
+                 nns_method=0):
+        self.quiet = quiet
+        self.my_icp6D = icp6D(my_icp6Dminimizer, mdm, max_num_iterations, quiet, False, rnd, eP, anim, epsilonICP,
+                              nns_method)
+
+    def close_loop(self, allScans, first, last, g):
+        raise NotImplementedError
+
+
+def graph_balancer(nvertices, edges, weights_of_edges, first, last):
+    """elch6D::graph_balancer -> weights[nvertices] (tdtk_elch_graph_balancer); edges = [(from, to)]"""
+    frm = np.ascontiguousarray([e[0] for e in edges], dtype=np.int32)
+    to = np.ascontiguousarray([e[1] for e in edges], dtype=np.int32)
+    w = f64(weights_of_edges)
+    out = np.zeros(nvertices)
+    check(lib().tdtk_elch_graph_balancer(int(nvertices), len(edges), iptr(frm), iptr(to), dptr(w), int(first), int(last),
+                                         dptr(out)))
+    return out
+
+
+class elch6Deuler(loopSlam6D):
+    """-L 1.  g = the loop-optimisation graph as a list of (from, to) edges over scans 0..n-1 (slam6D.cc:416-428 adds
+    (i-1, i) for every matched scan and (first, last) after every closed loop)."""
+
+    def close_loop(self, allScans, first, last, g):
+        n = max(max(a, b) for a, b in g) + 1                      # num_vertices(g)
+        edges = list(g)
+        # one covarianceEuler per edge (elch6Deuler.cc:53-66): all of them in one batched device call
+        ne = len(edges)
+        firsts = (C.c_void_p * ne)(*[allScans[a].getSearchTree()._h for a, b in edges])
+        seconds = (C.c_void_p * ne)(*[allScans[b].handle for a, b in edges])
+        dal = np.ascontiguousarray(np.stack([allScans[a].dalignxf for a, b in edges]))
+        blocks = np.empty((ne, 42))
+        check(lib().tdtk_graph_link_blocks(1, ne, firsts, dptr(dal), seconds, float(self.my_icp6D.max_dist_match2), dptr(blocks)))
+        wts = np.empty((6, ne))
+        for e in range(ne):
+            Cinv = np.empty((6, 6))
+            Cm = np.ascontiguousarray(blocks[e, :36].reshape(6, 6))
+            check(lib().tdtk_invert(dptr(Cm), 6, dptr(Cinv)))     # C = C.i()
+            wts[:, e] = np.abs(np.diag(Cinv))
+        weights = [graph_balancer(n, edges, wts[j], first, last) for j in range(6)]
+        start = MetaScan([allScans[first], allScans[first + 1], allScans[first + 2]])
+        end = MetaScan([allScans[last - 2], allScans[last - 1], allScans[last]])
+        for i in range(last - 2, last + 1):
+            for j in range(6):
+                weights[j][i] = 0.0
+        before = np.concatenate([allScans[last].get_rPos(), allScans[last].get_rPosTheta()])
+        self.my_icp6D.match(start, end)
+        delta = np.concatenate([allScans[last].get_rPos(), allScans[last].get_rPosTheta()]) - before
+        self.last_delta = delta
+        if not self.quiet:
+            print("Delta: " + " ".join("%g" % v for v in delta))
+        A1 = np.zeros((n, 16)); A2 = np.zeros((n, 16))
+        for i in range(1, n):
+            rP = np.array([allScans[i].get_rPos()[k] + delta[k] * (weights[k][i] - weights[k][0]) for k in range(3)])
+            rT = np.array([allScans[i].get_rPosTheta()[k] + delta[3 + k] * (weights[3 + k][i] - weights[3 + k][0]) for k in range(3)])
+            allScans[i].transformToEuler(rP, rT, "ELCH", 2 if i == n - 1 else 1)
+
+
 def computeGraph6Dautomatic(allScans, clpairs, max_dist_match2_LUM=625.0, group=None, device=None):
     """graphSlam6D::computeGraph6Dautomatic / the graph step of matchGraph6Dautomatic(allScans, nrIt,
     clpairs, loopsize) (src/slam6d/graphSlam6D.cc:82-133, 136-180): a link (j, k) for every ordered pair
@@ -1098,16 +1248,18 @@ def matchGraph6Dautomatic_clpairs(my_graphSlam6D, allScans, nrIt, clpairs, loops
 
 
 def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_graphSlam6D, nrIt, epsilonSLAM,
-                          mdml, eP=True, max_num_metascans=-1, prefetch=True):
-    """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) without loop closing (my_loopSlam6D == NULL)
-    and without the -DlastSLAM pass: sequential ICP, loop detection by pose distance, and rounds of
-    { fresh Graph(i+1, cldist^2, loopsize); one doGraphSlam6D iteration } until ret <= epsilonSLAM
-    or nrIt rounds."""
+                          mdml, eP=True, max_num_metascans=-1, prefetch=True, my_loopSlam6D=None):
+    """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) without the -DlastSLAM pass: sequential ICP, loop
+    detection by pose distance (the closest pair (first, last) seen while a loop is being detected), ELCH loop closing
+    when my_loopSlam6D is given (-L, slam6D.cc:500-505, 523-527), and rounds of { fresh Graph(i+1, cldist^2, loopsize);
+    one doGraphSlam6D iteration } until ret <= epsilonSLAM or nrIt rounds."""
     cldist2 = cldist * cldist
     metas = []
     n = len(allScans)
     loop_detection = 0
     rounds = 0
+    g = []                         # graph for loop optimisation (graph_t g, slam6D.cc:411)
+    min_dist, first, last = -1.0, 0, 0
 
     def global_rounds(nodes):
         nonlocal rounds
@@ -1138,6 +1290,7 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
                 for j in range(i + 1, min(i + 1 + depth, n)):
                     if j not in pending and allScans[j]._h is None:
                         pending[j] = pool.submit(prep, allScans[j])
+            g.append((i - 1, i))
             if eP:
                 allScans[i].mergeCoordinatesWithRoboterPosition(allScans[i - 1])
             if my_icp6D is not None:
@@ -1153,10 +1306,17 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
                 loop_detection = 2
             for j in range(0, i - loopsize):
                 d = allScans[j].get_rPos() - allScans[i].get_rPos()
-                if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cldist2:
+                dist = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+                if dist < cldist2:
                     loop_detection = 1
+                    if min_dist < 0 or dist < min_dist:
+                        min_dist, first, last = dist, j, i
             if loop_detection == 2:
                 loop_detection = 0
+                min_dist = -1.0
+                if my_loopSlam6D is not None:
+                    my_loopSlam6D.close_loop(allScans, first, last, g)
+                    g.append((first, last))
                 if my_graphSlam6D is not None and mdml > 0:
                     global_rounds(i + 1)
     finally:
@@ -1164,6 +1324,9 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
             f.result()
         if pool is not None:
             pool.shutdown()
+    if loop_detection == 1 and my_loopSlam6D is not None:
+        my_loopSlam6D.close_loop(allScans, first, last, g)
+        g.append((first, last))
     if my_graphSlam6D is not None and mdml > 0.0:
         global_rounds(n)
     return rounds

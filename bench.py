@@ -34,18 +34,108 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
+PMC_FILE = "r02_pmc_bench.json"
 
 
-def pmc_traffic_bytes(kernel):
-    """HBM bytes per launch from the committed PMC passes of this same command
-    (profiles/r01_pmc_bench.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled
-    per the gfx950 correction, calibrated on k_transform's known 24 MB stream)."""
+def pmc_kernel(kernel, fname=PMC_FILE):
+    """Per-launch PMC averages of `kernel` over the timed region of this same command, from the committed summary
+    of the separate rocprofv3 --pmc passes (tools/profile_bench.sh -> tools/summarize_profiles.py)."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")))
-        k = j["kernels"][kernel]
-        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
+        return json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"][kernel]
     except Exception:
         return None
+
+
+def pmc_traffic_bytes(k):
+    """HBM-side (fabric) bytes per launch: FETCH_SIZE doubled per the guide's gfx950 correction (calibrated here on
+    k_transform's known 24 MB stream) + WRITE_SIZE, both reported in KiB."""
+    if not k or "FETCH_SIZE_KiB" not in k or "WRITE_SIZE_KiB" not in k:
+        return None
+    return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
+
+
+def measured_bandwidth(local):
+    """stream-copy and L2-resident read bandwidth of THIS box (tdtk_measure_bandwidth), GB/s"""
+    tdtk = importlib.import_module("3dtk_amd")
+    g = C.c_double(0.0)
+    out = {}
+    for name, kind, nbytes in (("hbm_copy", 0, 1 << 30), ("l2_read", 1, 16 << 20)):
+        rc = tdtk.lib().tdtk_measure_bandwidth(int(local), kind, nbytes, 5, C.byref(g))
+        out[name] = g.value if rc == 0 else None
+    return out
+
+
+class visit_counting:
+    """with visit_counting(dev) as vc: ... ; vc.read() -> (internal nodes, buckets, bucket points, queries) of the
+    FindClosest launches issued inside (their instrumented instantiations: same traversal, same warm radius)"""
+
+    def __init__(self, dev):
+        self.dev = int(dev)
+        self.L = importlib.import_module("3dtk_amd").lib()
+
+    def __enter__(self):
+        self.L.tdtk_visit_counting(self.dev, 1)
+        return self
+
+    def read(self):
+        c = (C.c_uint64 * 8)()
+        self.L.tdtk_visit_counters(self.dev, c)
+        return int(c[0]), int(c[1]), int(c[2]), int(c[3])
+
+    def read_ann(self):
+        c = (C.c_uint64 * 8)()
+        self.L.tdtk_visit_counters(self.dev, c)
+        return int(c[4]), int(c[5]), int(c[6])
+
+    def __exit__(self, *exc):
+        self.L.tdtk_visit_counting(self.dev, 0)
+
+
+def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw):
+    """The `roofline` object for k_search.  achieved = ALGORITHMIC bytes per launch (24 B query + 64 B per
+    internal node + 24 B per bucket point + 4 B index, with the node / point counts of exactly the timed launches) /
+    average launch duration (HIP events).  Beside it the bounds that can tell a good kernel from a better one:
+    compulsory HBM bytes (every byte once), L2 request bytes against the L2 peak, and the fraction of VALU lane-slots
+    that did work."""
+    c_int, c_leaf, c_pts, nq = counts
+    bq = algorithmic_bytes_per_query(c_int / nq, c_pts / nq)
+    achieved = bq * nq_per_launch / (k_ms * 1e-3) / 1e9
+    comp = (tree_info["n_internal"] * 64 + tree_info["n_points"] * 32 + extra_bytes_per_query * nq_per_launch)
+    r = {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc),
+         "kernel_ms": k_ms, "bytes_per_query": bq,
+         "visits_per_query": {"internal": c_int / nq, "leaves": c_leaf / nq, "points": c_pts / nq,
+                              "counted_on": "the timed launches themselves (warm-start radius included)"},
+         "nn_per_s_kernel_only": nq_per_launch / (k_ms * 1e-3),
+         "note": "algorithmic bytes are re-reads of a tree that stays in L2 / Infinity Cache, so `frac` is not HBM "
+                 "utilisation; `bounds` holds the fractions that are"}
+    b = {"peak_measured_copy_GBs": bw.get("hbm_copy"), "peak_measured_l2_GBs": bw.get("l2_read"),
+         "compulsory_hbm": {"bytes": comp, "GBs": comp / (k_ms * 1e-3) / 1e9, "frac": comp / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "what": "tree once + every query read / written once"}}
+    if bw.get("hbm_copy"):
+        r["frac_of_measured_copy"] = achieved / bw["hbm_copy"]
+    if r["traffic"]:
+        b["hbm_traffic_pmc"] = {"bytes": r["traffic"], "GBs": r["traffic"] / (k_ms * 1e-3) / 1e9,
+                                "frac": r["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "refetch_factor": r["traffic"] / comp}
+    if pmc:
+        req = pmc.get("TCC_REQ_sum") or ((pmc.get("TCC_HIT_sum") or 0) + (pmc.get("TCC_MISS_sum") or 0))
+        if req:
+            l2b = req * 128.0
+            b["l2"] = {"requests": req, "bytes": l2b, "GBs": l2b / (k_ms * 1e-3) / 1e9, "peak": L2_PEAK_GBS,
+                       "frac": l2b / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
+                       "hit_rate": (pmc.get("TCC_HIT_sum") or 0) / max(1.0, (pmc.get("TCC_HIT_sum") or 0) + (pmc.get("TCC_MISS_sum") or 0))}
+        if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
+            b["valu_lane_efficiency"] = {"frac": pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0),
+                                         "what": "SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64): share of the lane-slots "
+                                                 "of issued VALU instructions that were active"}
+        if pmc.get("SQ_INSTS_VALU"):
+            b["valu_wave_instructions"] = pmc["SQ_INSTS_VALU"]
+        if pmc.get("SQ_BUSY_CYCLES") and pmc.get("SQ_ACTIVE_INST_VALU"):
+            b["valu_issue_busy"] = {"frac": pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"] if pmc["SQ_BUSY_CYCLES"] else None}
+    r["bounds"] = b
+    return r
 
 
 def algorithmic_bytes_per_query(n_int, n_pts):
@@ -162,7 +252,7 @@ def max_over_ranks(x, world, local):
     return float(t.item())
 
 
-def cpu_baseline_nn(model, queries, maxd2, budget_s=10.0, check=None):
+def cpu_baseline_nn(model, queries, maxd2, budget_s=8.0, check=None, full_iter=None):
     """The reference's KDtreeIndexed::FindClosest (oracle/_ref, kind "reference") or the C
     restatement (kind "port") on this box's host cores, bounded sample of the same workload."""
     from oracle import orc
@@ -184,11 +274,30 @@ def cpu_baseline_nn(model, queries, maxd2, budget_s=10.0, check=None):
     while t_all < budget_s and reps < 400:
         t0 = time.perf_counter(); run(queries, threads); t_all += time.perf_counter() - t0; reps += 1
     allc = reps * len(queries) / t_all
-    return {"value": allc, "unit": "NN correspondences/s", "cores": threads, "kind": kind,
-            "one_thread_value": one,
-            "sample": "%d passes of KDtreeIndexed::FindClosest over the same %d queries with %d OpenMP threads "
-                      "(static chunks, threadNum = thread id) + 200k queries on 1 thread; NN search only "
-                      "(the dominant share of getPtPairs; pair sums/solve excluded)" % (reps, len(queries), threads)}
+    out = {"value": allc, "unit": "NN correspondences/s", "cores": threads, "kind": kind,
+           "one_thread_value": one, "nn_only_value": allc,
+           "sample": "%d passes of KDtreeIndexed::FindClosest over the same %d queries with %d OpenMP threads "
+                     "(static chunks, threadNum = thread id) + 200k queries on 1 thread; NN search only "
+                     "(the dominant share of getPtPairs; pair sums/solve excluded)" % (reps, len(queries), threads)}
+    if kind == "reference" and full_iter is not None:
+        # the same unit of work as `value` of the GPU line: FULL icp6D::match iterations of the OpenMP branch
+        # (icp6D.cc:129-222) -- per-thread getPtPairs chunks incl. the critical-section push_back of 208-byte
+        # PtPairs, the Si pass, icp6D_QUAT::Align_Parallel, serial transformReduced -- every piece the reference's
+        # own compiled code (oracle/ref_driver.cc: ref_icp_iterations), T = OPENMP_NUM_THREADS = the threads used
+        data0, dal = full_iter
+        best = None
+        for T in sorted({min(threads, 16), min(threads, 64), threads}):
+            t0 = time.perf_counter(); _, tr = tree.icp_iterations(dal, data0, maxd2, T, 2); dtT = (time.perf_counter() - t0) / 2
+            if best is None or dtT < best[1]:
+                best = (T, dtT, tr)
+        T, dtT, tr = best
+        out.update({"value": len(data0) / dtT, "cores": T, "ms_per_iteration": dtT * 1e3,
+                    "first_iteration_pairs": int(tr[0, 0]), "first_iteration_rms": float(tr[0, 1]),
+                    "sample": "2 full ICP iterations (getPtPairs chunks + Si + Align_Parallel + transform) of the same "
+                              "%d-vs-%d pair from the initial pose with OPENMP_NUM_THREADS = 16 / 64 / all %d host threads, "
+                              "best kept (%d threads); `nn_only_value` = %d passes of KDtreeIndexed::FindClosest alone on "
+                              "%d threads" % (len(data0), len(model), threads, T, reps, threads)})
+    return out
 
 
 # --------------------------------------------------------------------------------------------
@@ -217,28 +326,27 @@ def bench_icp(args, rank, world, local):
     last = icp.last
     pose_err = float(np.abs(data.get_transMat() - T).max())
 
-    # Algorithmic bytes of exactly the timed launches: replay the recorded alignxf sequence on a
-    # 1-in-10 sub-sample (same incremental device transform) and count, per timed iteration, the
-    # internal nodes / leaf points the reference traversal visits (exact properties of tree +
-    # queries + radius, independent of the implementation).
-    sub = np.ascontiguousarray(d[::10])
-    rep = tdtk.Scan([0, 0, 0], [0, 0, 0], sub, device=local)
-    seq = [r[2:] for r in icp_w.last["trace"]] + [r[2:] for r in last["trace"]]
-    n_warm = len(icp_w.last["trace"])
-    bqs, vis = [], []
-    for j in range(n_warm + steps):
-        if j >= n_warm:
-            c_int, c_leaf, c_pts = tree.count_visits(rep.get_xyz_reduced(), 625.0)
-            vis.append((c_int / len(sub), c_leaf / len(sub), c_pts / len(sub)))
-            bqs.append(algorithmic_bytes_per_query(vis[-1][0], vis[-1][2]))
-        rep.transform(seq[j])
-    bq = float(np.mean(bqs))
-    vis = np.mean(np.array(vis), axis=0)
-    c_int, c_leaf, c_pts = vis * len(sub)
-    samp = sub
+    # Algorithmic bytes of exactly the timed launches: the loop is deterministic, so a second data scan run through
+    # the same W + K iterations with the instrumented kernel (same traversal, same warm-start radius; counters
+    # switched on after the warm-up) visits what the timed launches visited -- checked through the final RMS.
+    rep = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
+    _ = rep.handle
+    tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0).match(model, rep)
+    icp_c = tdtk.icp6D(mini, 25.0, args.steps, quiet=True, epsilonICP=-1.0)
+    with visit_counting(local) as vc:
+        icp_c.match(model, rep)
+        counts = vc.read()
+    assert icp_c.last["rms"] == last["rms"] and icp_c.last["pairs"] == last["pairs"], "counting replay diverged"
+    assert counts[3] == n * steps, counts
+    del rep
     cur = data.get_xyz_reduced()
     k_ms = last["nn_ms"] / steps                          # HIP-event time of k_search, per launch
-    achieved = bq * n / (k_ms * 1e-3) / 1e9
+    sums_ms = last["sums_ms"] / steps                     # ... and of the pair-sum kernels behind it
+    bw = measured_bandwidth(local)
+    ti = {"n_internal": info["n_internal"], "n_points": n}
+    # compulsory bytes per query besides the tree: x,y,z read + written back (fused transform), hit position written
+    # and read back (warm start of the next pass)
+    roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4, pmc_kernel("k_search [timed region]") or pmc_kernel("k_search"), bw)
 
     # the same 1M queries through the host-buffer entry point (H2D of queries, in-call binning,
     # search, D2H of indices + distances): the PCIe-inclusive rate -- reported, never the `value`
@@ -266,23 +374,49 @@ def bench_icp(args, rank, world, local):
         "icp_iters_per_s": steps / dt,
         "pairs_last": last["pairs"], "rms_last": last["rms"], "pose_max_abs_err": pose_err,
         "host_buffer_path": host_path, "per_scan_preparation": prep,
-        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_search"),
-                     "kernel_ms": k_ms, "bytes_per_query": bq,
-                     "visits_per_query": {"internal": c_int / len(samp), "leaves": c_leaf / len(samp), "points": c_pts / len(samp)},
-                     "nn_per_s_kernel_only": n / (k_ms * 1e-3)},
+        "pair_sums_ms": sums_ms, "outside_kernels_ms": dt * 1e3 / steps - k_ms - sums_ms,
+        "roofline": roof,
     }
+    # tree build (A1) on the device: a latency chain (the reference's serial-order fp64 centroid), reported against
+    # the bytes its levels move: every level streams the 24-B points + 8 B of permutation / keys in and out
+    levels = info["max_depth"]
+    tb_bytes = float(levels) * n * 64.0
+    out["tree_build_1gpu"] = {"ms": info["build_ms"], "points": n, "levels": levels,
+                              "roofline": {"bound": "hbm", "kernel": "k_measure + partition passes (device tree build)",
+                                           "achieved": tb_bytes / (info["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": tb_bytes / (info["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "traffic": None,
+                                           "note": "bounded by the dependent fp64 add chain of the centroid (bit-exact "
+                                                   "split values), not by bytes: DESIGN.md section 4"}}
     if rank == 0 and not args.no_cpu:
         gi, _ = tree.FindClosestBatch(cur[:20000], 625.0)
-        out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0, check=gi)
+        out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0, check=gi, full_iter=(d, model.dalignxf))
     if world == 1 and not args.no_normals:
         # Scan::calcNormals (k = 10, eps = 1.0) on the resident data scan: tree build + k-NN + PCA
-        t_n = []
+        t_n, k_n = [], []
+        tm4 = (C.c_double * 4)()
         for _ in range(4):
             tn0 = time.perf_counter(); data.calcNormals(); t_n.append(time.perf_counter() - tn0)
+            tdtk.lib().tdtk_last_timings(tm4); k_n.append(tm4[2])
+        with visit_counting(local) as vc:
+            data.calcNormals()
+            a_split, a_leaf, a_q = vc.read_ann()
+        kn_ms = float(np.mean(k_n[1:]))
+        # algorithmic bytes per point: the point in (24) + 32 B per splitting node + 24 B per leaf point tested +
+        # the k neighbours gathered for mean / covariance (24 B each) + the normal out (24)
+        bp = 24.0 + 32.0 * a_split / a_q + 24.0 * a_leaf / a_q + 24.0 * 10 + 24.0
+        ach = bp * n / (kn_ms * 1e-3) / 1e9
+        pk = pmc_kernel("k_ann_normals", "r02_normals_pmc.json")
         out["normals_1gpu"] = {"value": n / min(t_n), "unit": "points/s", "ms": min(t_n) * 1e3, "points": n, "k": 10, "eps": 1.0,
                                "what": "tdtk_scan_calc_normals on the resident scan: ANN-tree build, approximate 10-NN, "
-                                       "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat"}
+                                       "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat",
+                               "roofline": {"bound": "hbm", "kernel": "k_ann_normals", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pk),
+                                            "kernel_ms": kn_ms, "bytes_per_point": bp,
+                                            "visits_per_point": {"split_nodes": a_split / a_q, "leaf_points": a_leaf / a_q},
+                                            "whole_call_ms": min(t_n) * 1e3,
+                                            "note": "the k-NN + PCA kernel alone; the ANN-tree build (~250 small launches) "
+                                                    "is the rest of the call"}}
         if not args.no_cpu:
             from oracle import orc as _orc
             ns = min(n, 100000)
@@ -298,7 +432,7 @@ def bench_icp(args, rank, world, local):
         import copy
         ga = copy.copy(args); ga.steps, ga.warmup = 10, 3
         g1 = bench_graphslam(ga, rank, world, local)
-        out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s")}
+        out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s", "roofline")}
         out["graphslam_1gpu"]["workload"] = g1["config"]["workload"]
         out["scaling_note"] = ("N>1 runs of this script measure configs[3] (graph-SLAM, links sharded); its 1-GPU point is "
                                "graphslam_1gpu here, not `value` (configs[1], which BASELINE.json fixes to one GPU)")
@@ -316,7 +450,7 @@ def bench_graphslam(args, rank, world, local):
     del raw
     g0 = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)
     nlinks = g0.getNrLinks()
-    mine = gs.shard_links(g0, rank, world)
+    mine = gs.shard_links(g0, rank, world, scans)
     # materialise what this rank touches (trees of the link sources, points of the link targets),
     # several at a time: a tree build keeps only a few wavefronts busy
     need_tree = sorted({g0.getLink(i, 0) for i in mine})
@@ -324,13 +458,26 @@ def bench_graphslam(args, rank, world, local):
     tdtk.prepare_scans([scans[k] for k in need_tree], trees=True, threads=8)
     tdtk.prepare_scans([scans[k] for k in need_pts], trees=False, threads=8)
     import torch.distributed as tdist
-    dev = torch.device("cuda", local) if (tdist.is_available() and tdist.is_initialized()
-                                           and tdist.get_backend() != "gloo") else None
+    on_dist = tdist.is_available() and tdist.is_initialized()
+    dev = torch.device("cuda", local) if (on_dist and tdist.get_backend() != "gloo") else None
+    # N > 1 over RCCL: the library's own communicator (tdtk_comm_*, ncclAllReduce inside tdtk_graph_iteration);
+    # torch.distributed only hands the 128-byte unique id to the ranks and provides the barriers around the timed
+    # region.  TDTK_FORCE_ALLREDUCE=1 runs the same path with a 1-rank communicator.  The gloo rig of the test
+    # suite (several ranks sharing one GPU, which RCCL refuses) keeps the torch.distributed exchange.
+    comm = None
+    if on_dist and world > 1 and dev is not None:
+        comm = gs.NativeComm(rank, world, local, gs.torch_id_bcast(dev))
+    elif world == 1 and os.environ.get("TDTK_FORCE_ALLREDUCE") == "1":
+        comm = gs.NativeComm(0, 1, local)
+    use_torch_exchange = on_dist and world > 1 and dev is None
     nn_ms = [0.0]
 
     def step():
         gr = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)   # slam6D.cc:525-532: fresh Graph + 1 LUM iteration
-        r = gs.lum_iteration_native(gr, scans, 625.0, None, dev)
+        if use_torch_exchange:
+            r = gs.lum_iteration_native(gr, scans, 625.0, None, None)
+        else:
+            r = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, scans, 625.0, comm)
         ms = C.c_double(0.0)
         tdtk.lib().tdtk_last_kernel_ms(C.byref(ms))       # the last link's k_search of this rank
         nn_ms[0] += ms.value
@@ -352,6 +499,16 @@ def bench_graphslam(args, rank, world, local):
     dt = max_over_ranks(time.perf_counter() - t0, world, local)
     queries = links_done * npts                         # one whole-scan NN pass per link
     k_ms = nn_ms[0] / max(1, args.steps)                # one sampled k_search launch per step
+    # algorithmic bytes of this rank's link passes: one more step with the instrumented kernels (poses have converged
+    # to ~1e-3 per step by now, so it visits what the timed steps visited to within a fraction of a percent)
+    with visit_counting(local) as vc:
+        step()
+        counts = vc.read()
+    my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
+    bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
+    # the link passes of a step run on up to 4 streams side by side, so one launch's duration is not the kernel's
+    # throughput: the aggregate figure is (bytes of all this rank's link searches) / (wall time of the step)
+    agg = bq * my_links * npts / (dt / args.steps) / 1e9
     out = {
         "metric": "NN correspondences/sec (graph-SLAM lum6DEuler iteration, links sharded)",
         "value": queries / dt, "unit": "NN correspondences/s",
@@ -362,10 +519,19 @@ def bench_graphslam(args, rank, world, local):
                                % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
         "lum_iters_per_s": args.steps / dt, "last_ret": ret,
+        "exchange": ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None
+                    else ("torch.distributed (gloo test rig)" if use_torch_exchange else "none (one rank)"),
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
-        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": None, "traffic": None, "kernel_ms": k_ms},
+        "roofline": {"bound": "hbm", "kernel": "k_search (link passes, up to 4 streams side by side)", "achieved": agg,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic_bytes(pmc_kernel("k_search", "r02_graphslam_pmc.json")),
+                     "kernel_ms_one_launch_among_concurrent": k_ms, "bytes_per_query": bq,
+                     "visits_per_query": {"internal": counts[0] / max(1, counts[3]), "points": counts[2] / max(1, counts[3])},
+                     "links_this_rank": my_links,
+                     "note": "achieved = algorithmic bytes of ALL this rank's link searches per step / step wall time "
+                             "(searches overlap each other and the pair-sum kernels; includes exchange, solve and pose "
+                             "update in the denominator)"},
     }
     return out
 

@@ -262,6 +262,40 @@ int tdtk_graph_solve_update(int backend, int nlinks, const int32_t* from, const 
                             int nscans, double* transMat, double* dalignxf, double* rPos, double* rPosTheta,
                             tdtk_scan* const* scans, double* state, double* xf_out, double* ret);
 
+/* ---- multi-GPU: one process per GPU, links sharded, ONE all-reduce (sum, fp64) of the per-link blocks per global
+ * iteration over RCCL / xGMI (the reference's unit of parallelism is the same: `omp parallel for` over
+ * links in FillGB3D, lum6Deuler.cc:270-283).  RCCL is bound at run time; a single-GPU user never touches it.
+ * tdtk_comm_unique_id: rank 0 draws the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by whatever
+ *   the host program has (MPI, a file, torch.distributed); tdtk_comm_create: ncclCommInitRank on `device`.
+ * tdtk_graph_exchange: blocks[n] <- sum over ranks, in place (host buffer; staged through the communicator's own
+ *   device buffer and stream).
+ * tdtk_graph_deal_links: owner[l] = rank that evaluates link l -- round-robin / (from+to) % world for scans of equal
+ *   size, longest-processing-time-first by the point count of the link's second scan otherwise.
+ * tdtk_graph_iteration: link blocks of this rank's links (mine[] = their indices in the link list; first / second /
+ *   first_dalignxf describe them in that order) -> exchange -> tdtk_graph_solve_update, all inside the library.      */
+#define TDTK_COMM_ID_BYTES 128
+typedef struct tdtk_comm tdtk_comm;
+int tdtk_comm_unique_id(char id[TDTK_COMM_ID_BYTES]);
+int tdtk_comm_create(const char id[TDTK_COMM_ID_BYTES], int rank, int world, int device, tdtk_comm** out);
+void tdtk_comm_destroy(tdtk_comm* c);
+int tdtk_comm_info(const tdtk_comm* c, int* rank, int* world, uint64_t* n_allreduce);
+int tdtk_graph_exchange(tdtk_comm* c, double* blocks, size_t n);
+int tdtk_graph_deal_links(int nlinks, const int32_t* from, const int32_t* to, const uint64_t* scan_points /*[nscans] or NULL*/,
+                          int nscans, int world, int32_t* owner);
+int tdtk_graph_iteration(int backend, tdtk_comm* comm /*nullable*/, int nlinks, const int32_t* from, const int32_t* to,
+                         int n_mine, const int32_t* mine, const tdtk_tree* const* first, const double* first_dalignxf,
+                         tdtk_scan* const* second, double max_dist_match2, int nscans, double* transMat, double* dalignxf,
+                         double* rPos, double* rPosTheta, tdtk_scan* const* scans, double* state, double* xf_out, double* ret);
+
+/* ---- ELCH loop closing (-L 1), host control flow: elch6D::graph_balancer (src/slam6d/elch6D.cc:186-279) on an
+ * undirected weighted graph given as an edge list -- weights[f] = 0, weights[l] = 1, every vertex on a shortest path
+ * between two junctions gets the distance-proportional value, branches inherit (weights[] entries of vertices the
+ * balancer never reaches are left as they were).  tdtk_pair_sums_merge: the base block (n, sum, centroids, Si) of the
+ * union of several whole-scan passes, for a MetaScan as the data scan of icp6D::match (scan.cc:1305-1327).       */
+int tdtk_elch_graph_balancer(int nvertices, int nedges, const int32_t* from, const int32_t* to, const double* w,
+                             int first, int last, double* weights);
+int tdtk_pair_sums_merge(int count, const tdtk_pair_sums* parts, tdtk_pair_sums* out);
+
 /* Scan::transform for many resident scans at once: scan i is moved in place by A1[i] and then by A2[i]
  * (A2 nullable), e.g. Scan::transformToEuler / transformToQuat (scan.cc:1061-1104) = M4inv(transMat) then
  * the new pose; one kernel launch for all of them.                                               */
@@ -323,15 +357,17 @@ int tdtk_scan_calc_normals(tdtk_scan* s, int k, const double rPos[3], double eps
 /* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
  * traversal counters of the last counting run.                                          */
 int tdtk_last_kernel_ms(double* nn_ms);
-/* out[0] = search kernel, out[1] = pair-sum kernels of the last pass on this thread (HIP events on the stream
- * the kernels were launched on) */
-int tdtk_last_timings(double out[2]);
+/* out[0] = search kernel, out[1] = pair-sum kernels of the last pass on this thread, out[2] = the k-NN + PCA kernel
+ * of the last calcNormals (HIP events on the stream the kernels were launched on), out[3] = wall time of the last
+ * device tree build (a chain of ~40 launches) */
+int tdtk_last_timings(double out[4]);
 /* on != 0: every FindClosest pass of the calling thread on `device` runs the instrumented instantiation of the
  * kernel it would have used (identical traversal and results, slower) and adds to four counters, zeroed here;
  * tdtk_visit_counters reads {internal nodes, buckets, bucket points visited, queries issued} -- the exact
- * n_int / n_pts of SURVEY 8(d)'s algorithmic bytes for exactly the launches that ran (warm radius included). */
+ * n_int / n_pts of SURVEY 8(d)'s algorithmic bytes for exactly the launches that ran (warm radius included) --
+ * and, for calcNormals, out[4..6] = {ANN splitting nodes, leaf points visited, points processed}; out[7] = 0. */
 int tdtk_visit_counting(int device, int on);
-int tdtk_visit_counters(int device, uint64_t out[4]);
+int tdtk_visit_counters(int device, uint64_t out[8]);
 /* measured roofline denominators: kind 0 = HBM stream copy over `bytes` (read + written per pass), kind 1 =
  * repeated reads of an L2-resident buffer (bytes <= 16 MB); best of `reps` passes in GB/s */
 int tdtk_measure_bandwidth(int device, int kind, size_t bytes, int reps, double* gbs);

@@ -625,11 +625,16 @@ def graph_links_clpairs(scans, clpairs, maxdist2):
 def covariance_euler(first, second, maxdist2):
     """lum6DEuler::covarianceEuler (lum6Deuler.cc:94-251) -> (C, CD, m, ss, D)"""
     r = get_pt_pairs(first, second, maxdist2)
-    m = r["n"]
+    return covariance_euler_from_pairs(r["p1"], r["p2"])
+
+
+def covariance_euler_from_pairs(a, b):
+    """the arithmetic of covarianceEuler after the pair search (lum6Deuler.cc:143-232) on an explicit pair list:
+    a = p1 (first scan's points in the world), b = p2 -> (C, CD, m, ss, D)"""
+    m = len(a)
     C = np.zeros((6, 6)); CD = np.zeros(6)
     if m <= 2:
         return C, CD, m, 0.0, np.zeros(6)
-    a, b = r["p1"], r["p2"]
     u = (a + b) / 2.0
     x, y, z = u[:, 0], u[:, 1], u[:, 2]
     d = a - b
@@ -709,7 +714,7 @@ def lum_iteration(links, scans, maxdist2):
 
 
 def match_graph6d_automatic(cldist, loopsize, scans, algo, max_dist_match2, max_it, epsilonICP, nrIt, epsilonSLAM,
-                            mdml2, eP=True):
+                            mdml2, eP=True, elch=False, graph_slam=True):
     """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) with my_loopSlam6D == NULL, lum6DEuler as the
     graph back-end, no meta scans: sequential ICP, loop detection by pose distance, rounds of
     { Graph(i+1, cldist^2, loopsize); one LUM iteration } until ret <= epsilonSLAM or nrIt rounds.
@@ -718,9 +723,14 @@ def match_graph6d_automatic(cldist, loopsize, scans, algo, max_dist_match2, max_
     n = len(scans)
     loop_detection = 0
     rounds = 0
+    g = []
+    min_dist, first, last = -1.0, 0, 0
+    closed = []
 
     def global_rounds(nodes):
         nonlocal rounds
+        if not graph_slam:
+            return 0.0
         j = 0
         while True:
             links = graph_links(scans[:nodes], cldist2, loopsize)
@@ -730,6 +740,7 @@ def match_graph6d_automatic(cldist, loopsize, scans, algo, max_dist_match2, max_
             if not (j < nrIt and ret > epsilonSLAM):
                 return ret
     for i in range(1, n):
+        g.append((i - 1, i))
         if eP:
             scans[i].mergeCoordinatesWithRoboterPosition(scans[i - 1])
         match(scans[i - 1], scans[i], algo, max_dist_match2, max_it, epsilonICP)
@@ -737,13 +748,164 @@ def match_graph6d_automatic(cldist, loopsize, scans, algo, max_dist_match2, max_
             loop_detection = 2
         for j in range(0, i - loopsize):
             d = scans[j].get_rPos() - scans[i].get_rPos()
-            if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cldist2:
+            dist = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+            if dist < cldist2:
                 loop_detection = 1
+                if min_dist < 0 or dist < min_dist:
+                    min_dist, first, last = dist, j, i
         if loop_detection == 2:
             loop_detection = 0
+            min_dist = -1.0
+            if elch:
+                elch_close_loop(scans, first, last, g, algo, max_dist_match2, max_it, epsilonICP)
+                closed.append((first, last))
+                g.append((first, last))
             global_rounds(i + 1)
+    if loop_detection == 1 and elch:
+        elch_close_loop(scans, first, last, g, algo, max_dist_match2, max_it, epsilonICP)
+        closed.append((first, last))
+        g.append((first, last))
     global_rounds(n)
+    if elch:
+        return rounds, closed
     return rounds
+
+
+# ---------------------------------------------------------------------------------------
+# ELCH loop closing (-L 1): elch6D::graph_balancer (src/slam6d/elch6D.cc:186-279), elch6Deuler::close_loop
+# (src/slam6d/elch6Deuler.cc:44-138).  Parity unpinned: both TUs need Boost.Graph.
+# ---------------------------------------------------------------------------------------
+def _dijkstra(adj, n, s):
+    """boost::dijkstra_shortest_paths: strict '<' relaxation, predecessor[v] == v where unreached"""
+    import heapq
+    inf = float("inf")
+    p = list(range(n)); d = [inf] * n
+    d[s] = 0.0
+    heap = [(0.0, s)]
+    done = [False] * n
+    while heap:
+        du, u = heapq.heappop(heap)
+        if done[u] or du > d[u]:
+            continue
+        done[u] = True
+        for (v, w) in adj[u]:
+            nd = d[u] + w
+            if nd < d[v]:
+                d[v] = nd; p[v] = u
+                heapq.heappush(heap, (nd, v))
+    return p, d
+
+
+def graph_balancer(n, edges, ew, f, l):
+    """elch6D::graph_balancer on an undirected multigraph [(a, b)] with weights ew -> weights[n] (zeros where the
+    balancer assigns nothing)"""
+    adj = [[] for _ in range(n)]
+    for (a, b), w in zip(edges, ew):
+        adj[a].append((b, w))
+        if a != b:
+            adj[b].append((a, w))
+
+    def remove_edge(a, b):
+        adj[a] = [e for e in adj[a] if e[0] != b]
+        if a != b:
+            adj[b] = [e for e in adj[b] if e[0] != a]
+    weights = [0.0] * n
+    crossings = [f, l]
+    branches = []
+    weights[f] = 0.0; weights[l] = 1.0
+    p_min = d_min = None
+    while crossings:
+        dist = -1.0
+        s_min = e_min = None
+        k = 0
+        while k < len(crossings):
+            si = crossings[k]
+            p, d = _dijkstra(adj, n, si)
+            swap = False
+            for m in range(k + 1, len(crossings)):
+                e = crossings[m]
+                if e != p[e] and (dist < 0 or d[e] < dist):
+                    dist = d[e]; s_min = k; e_min = m; swap = True
+            if swap:
+                p_min, d_min = p, d
+            if dist < 0:
+                branches.append(si)
+                del crossings[k]
+            else:
+                k += 1
+        if dist > -1:
+            sv, ev = crossings[s_min], crossings[e_min]
+            remove_edge(ev, p_min[ev])
+            i = p_min[ev]
+            while i != sv:
+                weights[i] = weights[sv] + (weights[ev] - weights[sv]) * d_min[i] / d_min[ev]
+                remove_edge(i, p_min[i])
+                if len(adj[i]) > 0:
+                    crossings.append(i)
+                i = p_min[i]
+            # erase by iterator: the positions found above (later erasures do not disturb earlier positions)
+            drop = []
+            if len(adj[sv]) == 0:
+                drop.append(s_min)
+            if len(adj[ev]) == 0:
+                drop.append(e_min)
+            for idx in sorted(drop, reverse=True):
+                del crossings[idx]
+    while branches:
+        s_ = branches.pop(0)
+        for (v, w) in list(adj[s_]):
+            weights[v] = weights[s_]
+            if len(adj[v]) > 1:
+                branches.append(v)
+        for (v, w) in list(adj[s_]):
+            adj[v] = [e for e in adj[v] if e[0] != s_]
+        adj[s_] = []
+    return np.array(weights)
+
+
+def match_meta_data(prev, members, algo=1, max_dist_match2=625.0, max_num_iterations=50, epsilonICP=1e-7):
+    """icp6D::match with a MetaScan as the data scan (members = its scans): pairs of all members against the model,
+    one alignment, every member moved.  Returns (iter, trace)."""
+    trace = []
+    ret = prev_ret = prev_prev_ret = 0.0
+    it = 0
+    for it in range(max_num_iterations):
+        prev_prev_ret, prev_ret = prev_ret, ret
+        rs = [get_pt_pairs(prev, mbr, max_dist_match2) for mbr in members]
+        n = sum(r["n"] for r in rs)
+        if n > 3:
+            p1 = np.concatenate([r["p1"] for r in rs]); p2 = np.concatenate([r["p2"] for r in rs])
+            ret, alignxf = align(algo, p1, p2, p1.mean(axis=0), p2.mean(axis=0))
+        else:
+            break
+        trace.append((n, ret, alignxf.copy()))
+        for mbr in members:
+            mbr.transform(alignxf)
+        if (abs(ret - prev_ret) < epsilonICP and abs(ret - prev_prev_ret) < epsilonICP) or it == max_num_iterations - 1:
+            break
+    return it, trace
+
+
+def elch_close_loop(scans, first, last, edges, algo, max_dist_match2, max_it, epsilonICP):
+    """elch6Deuler::close_loop -> (delta[6], weights[6][n])"""
+    n = max(max(a, b) for a, b in edges) + 1
+    wts = np.empty((6, len(edges)))
+    for e, (a, b) in enumerate(edges):
+        Cm = covariance_euler(scans[a], scans[b], max_dist_match2)[0]
+        wts[:, e] = np.abs(np.diag(np.linalg.inv(Cm)))
+    weights = [graph_balancer(n, edges, wts[j], first, last) for j in range(6)]
+    for i in range(last - 2, last + 1):
+        for j in range(6):
+            weights[j][i] = 0.0
+    start = MetaOScan([scans[first], scans[first + 1], scans[first + 2]])
+    before = np.concatenate([scans[last].rPos, scans[last].rPosTheta])
+    match_meta_data(start, [scans[last - 2], scans[last - 1], scans[last]], algo, max_dist_match2, max_it, epsilonICP)
+    delta = np.concatenate([scans[last].rPos, scans[last].rPosTheta]) - before
+    for i in range(1, n):
+        rP = np.array([scans[i].rPos[k] + delta[k] * (weights[k][i] - weights[k][0]) for k in range(3)])
+        rT = np.array([scans[i].rPosTheta[k] + delta[3 + k] * (weights[3 + k][i] - weights[3 + k][0]) for k in range(3)])
+        scans[i].transformToEuler(rP, rT)
+    return delta, weights
 
 
 # ---------------------------------------------------------------------------------------

@@ -136,6 +136,8 @@ def ref():
         R.ref_Dist2.argtypes = [_dp, _dp]
         R.ref_newmat_inverse_solve.restype = C.c_int
         R.ref_newmat_inverse_solve.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+        R.ref_icp_iterations.restype = C.c_int
+        R.ref_icp_iterations.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, C.c_int, C.c_int, _dp]
         R.ref_lum_covariance_euler.restype = C.c_int
         R.ref_lum_covariance_euler.argtypes = [C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp]
         _ref = R
@@ -263,6 +265,14 @@ class RefTree:
         idx = np.empty(len(q), np.int32)
         ref().ref_kdi_find_closest(self.h, _d(q), len(q), float(maxdist2), _i(idx), int(nthreads))
         return idx
+
+    def icp_iterations(self, model_dalignxf, xyz, maxdist2, nthreads, iters):
+        """Full OpenMP-branch ICP iterations (ref_driver.cc: ref_icp_iterations) -> (moved xyz, trace [iters][18])"""
+        p = _c(xyz).reshape(-1, 3).copy()
+        trace = np.zeros((iters, 18))
+        ref().ref_icp_iterations(self.h, _d(_c(model_dalignxf).reshape(16)), _d(p), len(p), float(maxdist2), int(nthreads),
+                                 int(iters), _d(trace))
+        return p, trace
 
     def find_closest_along_dir(self, q, dirs, maxdist2):
         q = _c(q).reshape(-1, 3); dirs = _c(dirs).reshape(-1, 3)

@@ -182,6 +182,89 @@ double ref_apx_align_parallel(const unsigned int* n, const double* sum, const do
   return q.Align_Parallel(OPENMP_NUM_THREADS, nn, ss, m, d, pairs, alignxf);
 }
 
+/* Full ICP iterations as an OpenMP build of the reference runs them (icp6D::match, icp6D.cc:129-222 with
+ * Scan::getPtPairsParallel scan.cc:1285-1353 and SearchTree::getPtPairs searchTree.cc:92-189 for the closest-point
+ * mode): the loop scaffolding is restated here (those three TUs need Boost), every piece of arithmetic inside it is
+ * the reference's own compiled code -- KDtreeIndexed::FindClosest, transform3, M4inv, Dist2, PtPair, icp6D_QUAT::
+ * Align_Parallel -- including the `omp critical` around every push_back (searchTree.cc:179-180), the second pass
+ * over the 208-byte pairs for Si (icp6D.cc:170-191) and the serial transformReduced (scan.cc:851-875).  T = the
+ * value OPENMP_NUM_THREADS would have been compiled with.  xyz [N][3] is the data scan's "xyz reduced", moved in
+ * place; trace [iters][18] = {pairs, rms, alignxf}.  This is bench.py's full-iteration cpu_baseline.          */
+int ref_icp_iterations(void* h, const double* model_dalignxf, double* xyz, size_t N, double maxdist2, int T, int iters,
+                       double* trace)
+{
+  RefTree* t = static_cast<RefTree*>(h);
+  if (T < 1) T = 1;
+  if (T > MAX_OPENMP_NUM_THREADS) T = MAX_OPENMP_NUM_THREADS;
+  std::vector<unsigned int> n(T);
+  std::vector<double> sum(T), cm(3 * (size_t)T), cd(3 * (size_t)T), Si(9 * (size_t)T);
+  icp6D_QUAT quat(true);
+  for (int it = 0; it < iters; it++) {
+    std::vector<std::vector<PtPair> > pairs(T);
+    const int step = (int)ceil((double)N / (double)T);
+    for (int i = 0; i < T; i++) {
+      sum[i] = 0.0; n[i] = 0;
+      for (int k = 0; k < 3; k++) cm[3 * i + k] = cd[3 * i + k] = 0.0;
+      for (int k = 0; k < 9; k++) Si[9 * i + k] = 0.0;
+    }
+#pragma omp parallel num_threads(T)
+    {
+      const int tn = omp_get_thread_num();
+      double* centroid_m = &cm[3 * tn];
+      double* centroid_d = &cd[3 * tn];
+      size_t start = (size_t)tn * (size_t)step;
+      size_t end = (tn == T - 1) ? N : start + (size_t)step;
+      if (start > N) start = N;
+      if (end > N) end = N;
+      double local_alignxf_inverse[16];
+      M4inv(model_dalignxf, local_alignxf_inverse);                              // searchTree.cc:110
+      for (size_t i = start; i < end; i++) {
+        double tp[3] = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] };
+        double sp[3];
+        transform3(local_alignxf_inverse, tp, sp);                               // :122
+        const size_t r = t->tree->FindClosest(sp, maxdist2, tn);                  // :143
+        if (r != std::numeric_limits<size_t>::max()) {
+          transform3(model_dalignxf, t->ptrs[r], sp);                              // :147
+          centroid_m[0] += sp[0]; centroid_m[1] += sp[1]; centroid_m[2] += sp[2];
+          centroid_d[0] += tp[0]; centroid_d[1] += tp[1]; centroid_d[2] += tp[2];
+          PtPair myPair(sp, tp);
+          double p12[3] = { myPair.p1.x - myPair.p2.x, myPair.p1.y - myPair.p2.y, myPair.p1.z - myPair.p2.z };
+          sum[tn] += Len2(p12);                                                   // :172-177
+#pragma omp critical
+          pairs[tn].push_back(myPair);                                            // :179-180
+        }
+      }
+      const size_t size = pairs[tn].size();
+      if (size != 0)
+        for (int k = 0; k < 3; k++) { centroid_m[k] /= size; centroid_d[k] /= size; }   // scan.cc:1346-1352
+      n[tn] = (unsigned int)size;
+      double* S = &Si[9 * tn];
+      for (unsigned int i = 0; i < n[tn]; i++) {                                  // icp6D.cc:170-191
+        const double pp[3] = { pairs[tn][i].p1.x - centroid_m[0], pairs[tn][i].p1.y - centroid_m[1], pairs[tn][i].p1.z - centroid_m[2] };
+        const double qq[3] = { pairs[tn][i].p2.x - centroid_d[0], pairs[tn][i].p2.y - centroid_d[1], pairs[tn][i].p2.z - centroid_d[2] };
+        S[0] += pp[0] * qq[0]; S[1] += pp[0] * qq[1]; S[2] += pp[0] * qq[2];
+        S[3] += pp[1] * qq[0]; S[4] += pp[1] * qq[1]; S[5] += pp[1] * qq[2];
+        S[6] += pp[2] * qq[0]; S[7] += pp[2] * qq[1]; S[8] += pp[2] * qq[2];
+      }
+    }
+    unsigned int pairssize = 0;
+    for (int i = 0; i < T; i++) pairssize += n[i];
+    double alignxf[16];
+    M4identity(alignxf);
+    double ret = 0.0;
+    if (pairssize > 3)
+      ret = quat.Align_Parallel(T, n.data(), sum.data(), reinterpret_cast<const double(*)[3]>(cm.data()),
+                                reinterpret_cast<const double(*)[3]>(cd.data()),
+                                reinterpret_cast<const double(*)[9]>(Si.data()), alignxf);
+    for (size_t i = 0; i < N; i++) transform3(alignxf, xyz + 3 * i);             // Scan::transformReduced, serial
+    if (trace) {
+      trace[18 * it] = (double)pairssize; trace[18 * it + 1] = ret;
+      memcpy(trace + 18 * it + 2, alignxf, sizeof alignxf);
+    }
+  }
+  return 0;
+}
+
 /* ---- the 4x4 / pose primitives of include/slam6d/globals.icc, as the reference compiles them ------------
  * (A12: M4inv :762-785, MMult :298-328, transform3 :1454-1490, transform3normal :1465-1475,
  * EulerToMatrix4 :501-531, Matrix4ToEuler :540-576, QuatToMatrix4 :988-1022, Matrix4ToQuat :1032-1075)      */

@@ -1264,3 +1264,169 @@ def test_randomized_differential_run(gpu):
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert " 0 mismatches" in r.stdout
+
+
+def test_reference_side_binding_executes(gpu):
+    """adapters/hip_search_tree.cc compiled against the reference's own headers and linked with lib3dtk_hip.so
+    (adapters/harness/build.sh, built where the checkout exists, travels in oracle/_ref/): HipSearchTree::getPtPairs
+    through the SearchTree base pointer with a real DataXYZ, pairing modes 0 and 2, appending semantics, the legacy
+    pointer overload, FindClosest returning the caller's pointer -- against the C ABI called directly and brute
+    force (the checks are in adapters/harness/hip_search_tree_harness.cc)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "hip_search_tree_harness")
+    if not os.path.exists(exe):
+        pytest.skip("harness not built (no reference checkout where this snapshot was made)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HARNESS OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
+    """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
+    other slab lengths / refill thresholds, 256-thread persistent lanes, one query per lane) walk the same tree the
+    same way: identical indices, pair sums equal to rounding, and the instrumented instantiations count the same
+    visits as the oracle -- on a batch large enough for the persistent-lane kernels, with duplicates in the model."""
+    rng = np.random.default_rng(99)
+    m = rng.uniform(-500, 500, (400000, 3)); m[1000:3000] = m[0:2000]
+    q = m[rng.integers(0, len(m), 600000)] + rng.normal(0, 2.0, (600000, 3))
+    S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], m); S1 = tdtk.Scan([0, 0, 0], [0, 0, 0], q)
+    T = orc.Tree(m, 20)
+    oi, od2, cnt = T.find_closest(q, 100.0, 8, want_counters=True)
+    base = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 100.0, 0, 0, want_idx=True)
+    assert np.array_equal(base["idx"], oi)
+    import ctypes as C
+    L = tdtk.lib()
+    for env in ({"TDTK_FUSE_SUMS": "1"}, {"TDTK_SEARCH_VARIANT": "30"}, {"TDTK_SEARCH_VARIANT": "30", "TDTK_STREAM_SLAB": "64", "TDTK_STREAM_WPS": "7"},
+                {"TDTK_SEARCH_VARIANT": "8"}, {"TDTK_SEARCH_VARIANT": "4"}, {"TDTK_SEARCH_VARIANT": "0"},
+                {"TDTK_REFILL_QPW": "128", "TDTK_REFILL_THRESH": "8"}, {"TDTK_REFILL_QPW": "512", "TDTK_REFILL_THRESH": "32"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for counting in (0, 1):
+            L.tdtk_visit_counting(0, counting)
+            r = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 100.0, 0, 0, want_idx=True)
+            assert np.array_equal(r["idx"], oi), env
+            assert r["n"] == base["n"] and abs(r["sum"] - base["sum"]) <= 1e-11 * base["sum"], env
+            assert np.abs(np.asarray(r["Si"]) - np.asarray(base["Si"])).max() <= 1e-9 * np.abs(base["Si"]).max(), env
+            if counting:
+                c = (C.c_uint64 * 8)()
+                L.tdtk_visit_counters(0, c)
+                assert (c[0], c[1], c[2], c[3]) == (cnt[0], cnt[1], cnt[2], len(q)), (env, list(c), cnt)
+        L.tdtk_visit_counting(0, 0)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_rccl_exchange_inside_the_library_one_rank(tdtk, orc, gpu, monkeypatch):
+    """The library's own communicator (tdtk_comm_*: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce bound at run
+    time) with a 1-rank world: the all-reduce of a block list returns it unchanged, and a graph-SLAM iteration of
+    each back-end that goes through tdtk_graph_iteration WITH the forced exchange gives bit for bit the poses of the
+    one without a communicator -- the path `bench.py --gpus N` takes, with no Python between link blocks and solve."""
+    import ctypes as C
+    gs = __import__("importlib").import_module("3dtk_amd.graphslam")
+    comm = gs.NativeComm(0, 1, 0)
+    rng = np.random.default_rng(8)
+    blocks = rng.normal(size=84 * 42)
+    got = blocks.copy()
+    assert tdtk.lib().tdtk_graph_exchange(comm._h, got.ctypes.data_as(C.POINTER(C.c_double)), got.size) == 0
+    assert np.array_equal(got, blocks) and comm.n_allreduce() == 1
+
+    def scans():
+        r = np.random.default_rng(5)
+        world = r.uniform(-300, 300, (120000, 3))
+        out = []
+        for k in range(6):
+            ang = 2 * np.pi * k / 6
+            pos = np.array([60 * np.cos(ang), 0.0, 60 * np.sin(ang)]) + r.normal(0, 0.3, 3)
+            th = np.array([0.0, -ang + r.normal(0, 0.002), 0.0])
+            T = tdtk.EulerToMatrix4([60 * np.cos(ang), 0.0, 60 * np.sin(ang)], [0.0, -ang, 0.0])
+            Ti = tdtk.M4inv(T)
+            R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+            sel = r.choice(len(world), 30000, replace=False)
+            out.append(tdtk.Scan(pos, th, world[sel] @ R.T + Ti[12:15] + r.normal(0, 0.05, (30000, 3))))
+        return out
+    for backend in (1, 2, 3, 4):
+        res = []
+        for forced in (False, True):
+            S = scans()
+            gr = tdtk.Graph(6, links=[(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 5)]) if backend != 4 else \
+                tdtk.Graph(6, links=[(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)])
+            state = gs.graph_state(backend, 6)
+            if forced:
+                monkeypatch.setenv("TDTK_FORCE_ALLREDUCE", "1")
+            before = comm.n_allreduce()
+            rets = [gs.graph_iteration_comm(backend, gr, S, 400.0, comm if forced else None, state) for _ in range(2)]
+            if forced:
+                assert comm.n_allreduce() == before + 2
+                monkeypatch.delenv("TDTK_FORCE_ALLREDUCE")
+            res.append((rets, [s.transMat.copy() for s in S], [s.get_xyz_reduced()[:100].copy() for s in S]))
+        assert res[0][0] == res[1][0]
+        for a, b in zip(res[0][1], res[1][1]):
+            assert np.array_equal(a, b)
+        for a, b in zip(res[0][2], res[1][2]):
+            assert np.array_equal(a, b)
+    comm.close()
+
+
+def _loop_scans(tdtk, io, nscans=12, npts=25000, seed=17, drift=0.25):
+    rng = np.random.default_rng(seed)
+    world = np.concatenate([rng.uniform(-260, 260, (150000, 3)) * np.array([1.0, 0.15, 1.0]),
+                            rng.normal(0, 1.0, (60000, 3)) + rng.uniform(-200, 200, (60, 3)).repeat(1000, axis=0)])
+    S, O = [], []
+    dp = np.zeros(3)
+    for k in range(nscans):
+        ang = 2 * np.pi * k / nscans
+        pos = np.array([90 * np.cos(ang), 0.0, 90 * np.sin(ang)])
+        th = np.array([0.0, -ang, 0.0])
+        T = tdtk.EulerToMatrix4(pos, th)
+        Ti = tdtk.M4inv(T)
+        R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+        sel = rng.choice(len(world), npts, replace=False)
+        loc = world[sel] @ R.T + Ti[12:15] + rng.normal(0, 0.05, (npts, 3))
+        if k > 0:
+            dp = dp + rng.normal(0.0, drift, 3) + np.array([0.15, 0.0, 0.1])      # a systematic odometry error: the loop does not close
+        p0 = pos + dp
+        S.append(tdtk.Scan(p0, th, loc)); O.append(io.OScan(p0, th, loc))
+    return S, O
+
+
+def test_elch_close_loop_vs_oracle(tdtk, orc, gpu):
+    """-L 1 (elch6Deuler::close_loop, elch6Deuler.cc:44-138): per-edge covariances -> 6 weighted graphs -> graph
+    balancer -> MetaScan(first..first+2) matched against MetaScan(last-2..last) -> the error distributed over the loop.
+    Against the oracle restatement (parity unpinned: the reference TUs need Boost.Graph): edge weights, balancer output,
+    the meta-vs-meta match trace, delta and every pose."""
+    from oracle import icp_oracle as io
+    S, O = _loop_scans(tdtk, io)
+    n = len(S)
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 5.0, 40, quiet=True, epsilonICP=1e-6)
+    icp.doICP(S, prefetch=False)
+    io.do_icp(O, 1, 25.0, 40, 1e-6)
+    for s, o in zip(S, O):
+        assert np.abs(s.transMat - o.transMat).max() < 1e-8
+    g = [(i - 1, i) for i in range(1, n)]
+    gap_before = np.linalg.norm(S[n - 1].get_rPos() - O[n - 1].rPos)
+    assert gap_before < 1e-7
+    loop = tdtk.elch6Deuler(True, tdtk.icp6D_QUAT(True), 5.0, 40, epsilonICP=1e-6)
+    loop.close_loop(S, 0, n - 1, g)
+    delta, weights = io.elch_close_loop(O, 0, n - 1, g, 1, 25.0, 40, 1e-6)
+    np.testing.assert_allclose(loop.last_delta, delta, rtol=1e-6, atol=1e-9)
+    assert np.abs(delta[:3]).max() > 0.3                        # there was a loop error to distribute
+    for s, o in zip(S, O):
+        assert np.abs(s.transMat - o.transMat).max() < 1e-6 * max(1.0, np.abs(o.transMat).max())
+        assert np.abs(s.get_xyz_reduced() - o.xyz).max() < 1e-6
+    # the loop is closed better than before: scan n-1 against scan 0
+    err, npairs = icp.Point_Point_Error(S[0], S[n - 1], 5.0)
+    assert npairs > 1000
+
+
+def test_match_graph6d_automatic_with_elch(tdtk, orc, gpu):
+    """matchGraph6Dautomatic with -L 1 (slam6D.cc:387-548): sequential ICP, loop detection by pose distance with the
+    closest (first, last) pair, ELCH loop closing, then the global lum6DEuler rounds -- against the oracle's loop."""
+    from oracle import icp_oracle as io
+    S, O = _loop_scans(tdtk, io, nscans=10, npts=20000, seed=23)
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 5.0, 30, quiet=True, epsilonICP=1e-6)
+    loop = tdtk.elch6Deuler(True, tdtk.icp6D_QUAT(True), 5.0, 30, epsilonICP=1e-6)
+    lum = tdtk.lum6DEuler(icp, 5.0, 5.0, epsilonLUM=0.5)
+    rounds = tdtk.matchGraph6Dautomatic(60.0, 5, S, icp, False, lum, 3, 0.05, 5.0, eP=True, prefetch=False, my_loopSlam6D=loop)
+    orounds, closed = io.match_graph6d_automatic(60.0, 5, O, 1, 25.0, 30, 1e-6, 3, 0.05, 25.0, True, elch=True)
+    assert rounds == orounds and len(closed) >= 1
+    for s, o in zip(S, O):
+        assert np.abs(s.transMat - o.transMat).max() < 1e-5 * max(1.0, np.abs(o.transMat).max())

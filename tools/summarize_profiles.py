@@ -8,6 +8,10 @@ os.makedirs("profiles", exist_ok=True)
 def short(n):
     n = n.split("(")[0].replace("void ", "").replace("tdtk::", "")
     if n.startswith("k_search_refill<"):
+        a = [t.strip() for t in n[len("k_search_refill<"):].split(">")[0].split(",")]
+        # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN>
+        if len(a) >= 5 and a[4] == "true":
+            return "k_search_count(instrumented, not timed)"
         return "k_search"
     if n.startswith("k_search<"):
         a = [t.strip() for t in n[len("k_search<"):-1].split(",")]
@@ -27,7 +31,7 @@ for r in rows:
 # the bench's timed region = launches 11..110 of the resident-loop search kernel (10 warm-up launches before,
 # the host-buffer legs after); listed separately so it can be compared with bench.py's HIP-event average
 loop = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows
-        if r["Kernel_Name"].startswith("void tdtk::k_search_refill<")]
+        if short(r["Kernel_Name"]) == "k_search" and "k_search_refill<" in r["Kernel_Name"]]
 if len(loop) >= 110:
     agg["k_search [timed region: launches 11-110]"] = loop[10:110]
 tot = sum(sum(v) for k, v in agg.items() if not k.startswith("k_search ["))
@@ -40,20 +44,29 @@ if os.path.exists(stats_file):
     open(os.path.join("profiles", pre + "_rocprofv3_kernel_stats_raw.csv"), "w").write(open(stats_file).read())
 
 # --- PMC passes
-pmc = {"command": "python bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base", "kernels": {},
+pmc = {"command": "python bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base --no-normals", "kernels": {},
        "note": "per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE "
                "reads 1/2 of the streamed bytes (calibrated: k_transform reads 3 x 8 MB = 23437.5 KiB, reports ~11738)"}
-for p in ("fetch", "write", "sq1", "sq2"):
+for p in ("fetch", "write", "sq1", "sq2", "sq3", "tcc"):
     fn = os.path.join(src, p, "p_counter_collection.csv")
     if not os.path.exists(fn):
         continue
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(fn)):
-        acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    seen = collections.defaultdict(dict)      # the timed region of the bench = the 11th..110th k_search dispatch
+    for r in sorted(csv.DictReader(open(fn)), key=lambda r: int(r["Dispatch_Id"])):
+        k = short(r["Kernel_Name"])
+        acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if k == "k_search" and "k_search_refill<" in r["Kernel_Name"]:
+            seen[r["Counter_Name"]][int(r["Dispatch_Id"])] = float(r["Counter_Value"])
     for (k, c), v in acc.items():
         name = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
         pmc["kernels"].setdefault(k, {})[name] = sum(v) / len(v)
         pmc["kernels"][k]["dispatches_" + p] = len(v)
+    for c, d in seen.items():
+        vals = [d[i] for i in sorted(d)]
+        if len(vals) >= 110:
+            name = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
+            pmc["kernels"].setdefault("k_search [timed region]", {})[name] = sum(vals[10:110]) / 100.0
 json.dump(pmc, open(os.path.join("profiles", pre + "_pmc_bench.json"), "w"), indent=1, sort_keys=True)
 for p in ("stats",):
     fn = os.path.join(src, p + ".json")
