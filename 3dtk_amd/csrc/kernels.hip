@@ -156,17 +156,23 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
   return first ? r1 : r2;
 }
 
+// The compiler sinks the load of a node's last 16 bytes (split value + child references) behind the box test, because
+// only the not-pruned path uses them -- which turns every node visit into TWO dependent memory round trips.  Naming the
+// values in an empty asm right behind the loads keeps all four quarters of the record in one batch.
+#define TDTK_PIN_V64(x) asm volatile("" : "+v"(x))
+#define TDTK_PIN_S64(x) asm volatile("" : "+s"(x))
+#define TDTK_PIN_S32(x) asm volatile("" : "+s"(x))
+
 // Warm start of a repeated pass (ICP iteration i+1 over the scan iteration i has just searched): the previous hit is a
 // real point of the tree, so the nearest point is at most that far away, and starting with closest_d2 one ulp ABOVE
 // its squared distance (instead of maxdist2) cannot lose it: every test of the traversal prunes only what lies at
 // or beyond closest_d2, the walk order is unchanged, and whatever the reference would have visited before reaching a
 // point at that distance it still visits.  Same index, same d2 -- from a radius of a few units instead of 25.
-static __device__ __forceinline__ double warm_radius(const SearchArgs& a, const size_t i, const double qx, const double qy,
-                                                     const double qz)
+static __device__ __forceinline__ double warm_radius_kp(const SearchArgs& a, const int kp, const double qx, const double qy,
+                                                        const double qz)
 {
   double best = a.maxd2;
   if (a.warm) {
-    const int kp = a.kpos[i];
     if (kp >= 0) {
       const double4 p = reinterpret_cast<const double4*>(a.T.pts)[kp];
       const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
@@ -176,6 +182,11 @@ static __device__ __forceinline__ double warm_radius(const SearchArgs& a, const 
     }
   }
   return best;
+}
+static __device__ __forceinline__ double warm_radius(const SearchArgs& a, const size_t i, const double qx, const double qy,
+                                                     const double qz)
+{
+  return warm_radius_kp(a, a.warm ? a.kpos[i] : -1, qx, qy, qz);
 }
 
 template <int BLOCK, int SD, bool COUNT, bool UNI, int PTS = 4>
@@ -207,11 +218,15 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
       if (UNI && uniform) {
         const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
         const_u_ptr su = (const_u_ptr)(sn + 7);
-        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx,
+        double s_split = sn[6];
+        uint32_t s_c1 = su[0], s_c2 = su[1];
+        TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
+        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], s_split, s_c1, s_c2, qx,
                                      qy, qz, best, st, need_pop);
       } else {
         const double4 n0 = nodes[(size_t)cur * 2];      // cx cy cz hx
-        const double4 n1 = nodes[(size_t)cur * 2 + 1];  // hy hz splitval {c1,c2}
+        double4 n1 = nodes[(size_t)cur * 2 + 1];        // hy hz splitval {c1,c2}
+        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
         next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z,
                                      (uint32_t)__double2loint(n1.w), (uint32_t)__double2hiint(n1.w),
                                      qx, qy, qz, best, st, need_pop);
@@ -693,7 +708,8 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
       while (!(cur & REF_LEAF)) {
         bool need_pop = false;
         const double4 n0 = nodes[(size_t)cur * 2];
-        const double4 n1 = nodes[(size_t)cur * 2 + 1];
+        double4 n1 = nodes[(size_t)cur * 2 + 1];
+        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
         uint32_t next = visit_node<NG, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
                                            (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
         if (need_pop) {
@@ -891,6 +907,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
       const size_t mine = next_q + rank;
       if (idle && mine < end_q) {
+        // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
+        const int kp_prev = a.warm ? a.kpos[mine] : -1;
         double tx = a.x[mine], ty = a.y[mine], tz = a.z[mine];
         if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
           dev_xf3_inplace(a.pending, tx, ty, tz);
@@ -904,7 +922,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         qx = tx; qy = ty; qz = tz;
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
         qi = mine; have = true;
-        cur = T.root_ref; best = warm_radius(a, mine, qx, qy, qz); bk = -1; st.sp = 0;
+        cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
       }
       next_q += (size_t)__popcll(idlem);
     }
@@ -922,14 +940,18 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       if (__all(cur == ucur)) {
         const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
         const_u_ptr su = (const_u_ptr)(sn + 7);
-        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx, qy, qz,
+        double s_split = sn[6];
+        uint32_t s_c1 = su[0], s_c2 = su[1];
+        TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
+        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], s_split, s_c1, s_c2, qx, qy, qz,
                                      best, st, need_pop);
       } else {
         // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no
         // 64-bit address arithmetic on the vector ALU (the node array is < 4 GB by construction)
         const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
         const double4 n0 = *reinterpret_cast<const double4*>(np_);
-        const double4 n1 = *reinterpret_cast<const double4*>(np_ + 32);
+        double4 n1 = *reinterpret_cast<const double4*>(np_ + 32);
+        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
         next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
                                      (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
       }
@@ -1013,6 +1035,185 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       if (k < ACC_DD)
         for (int w = 0; w < NW; w++) s += red[w][k];
       a.partials[(size_t)blockIdx.x * ACC_TOTAL + k] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_search_step ("if-if"): the same persistent lanes, but the wave does not run two nested loops (all lanes walk
+// nodes until each holds a bucket, then all scan buckets) -- every trip of ONE loop lets each lane take one step of
+// whatever it is doing: visit one internal node, or test the next four points of its bucket.  The nested form makes
+// a lane that reaches its bucket early wait for the slowest node walk of the wave, and a lane with a short bucket
+// wait for the longest one, round after round (2.5 buckets per query): ~63 dependent wave steps per generation of
+// queries where a single query needs ~27.  This kernel is bound by those dependent steps (36 % VALU busy, 4.4 waves
+// per SIMD, insensitive to whether the tree comes from L2 or from the Infinity Cache: tools/l2_probe.py), not by
+// instruction issue, so paying both code paths per trip for fewer trips is the right trade.  Per-lane traversal,
+// visiting order and every comparison are unchanged -> same indices.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD, int THRESH, bool COUNT>
+__global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
+{
+  __shared__ double lds_m2[SD][BLOCK];
+  __shared__ uint32_t lds_ref[SD][BLOCK];
+
+  const uint32_t nb = gridDim.x;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
+  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned lane = threadIdx.x & (WAVE - 1);
+  LaneStack<BLOCK, SD> st;
+  st.l_m2 = &lds_m2[0][threadIdx.x];
+  st.l_ref = &lds_ref[0][threadIdx.x];
+  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
+  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
+  st.gstride = (size_t)nb * BLOCK;
+  st.sp = 0;
+
+  const TreeDev& T = a.T;
+  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
+  const char* __restrict__ pb = reinterpret_cast<const char*>(T.pts);
+
+  const size_t wave_id = (size_t)chunk * (BLOCK / WAVE) + threadIdx.x / WAVE;
+  size_t next_q = wave_id * (size_t)a.qpw;
+  size_t end_q = next_q + (size_t)a.qpw;
+  if (next_q > a.n) next_q = a.n;
+  if (end_q > a.n) end_q = a.n;
+
+  uint32_t cur = REF_DONE;
+  double best = 0.0, qx = 0, qy = 0, qz = 0;
+  int bk = -1;
+  size_t qi = 0;
+  bool have = false;
+  uint32_t o = 1u, olast = 0u;      // bucket progress (byte offsets); o > olast: no bucket open
+  bool fresh = false;               // cur is a bucket whose (o, olast) have not been decoded yet
+  unsigned c_int = 0, c_leaf = 0, c_pts = 0;
+
+  for (;;) {
+    // ---- retire finished queries, hand out new ones ----
+    const bool idle = (cur == REF_DONE);
+    if (idle && have) {
+      a.kpos[qi] = bk;
+      if (a.d2) a.d2[qi] = best;
+      have = false;
+    }
+    const unsigned long long idlem = __ballot(idle);
+    if (next_q < end_q && (idlem == ~0ull || __popcll(idlem) >= THRESH)) {
+      const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
+      const size_t mine = next_q + rank;
+      if (idle && mine < end_q) {
+        // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
+        const int kp_prev = a.warm ? a.kpos[mine] : -1;
+        double tx = a.x[mine], ty = a.y[mine], tz = a.z[mine];
+        if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
+          dev_xf3_inplace(a.pending, tx, ty, tz);
+          a.x[mine] = tx; a.y[mine] = ty; a.z[mine] = tz;
+          if (a.nx) {
+            double px = a.nx[mine], py = a.ny[mine], pz = a.nz[mine];
+            dev_xf3normal(a.pending, px, py, pz);
+            a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz;
+          }
+        }
+        qx = tx; qy = ty; qz = tz;
+        if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
+        qi = mine; have = true;
+        cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
+        fresh = (cur & REF_LEAF) != 0;
+      }
+      next_q += (size_t)__popcll(idlem);
+    }
+    if (__ballot(cur != REF_DONE) == 0) {
+      if (next_q >= end_q) break;
+      continue;
+    }
+
+    // ---- one step: an internal node ... ----
+    if (!(cur & REF_LEAF)) {
+      if (COUNT) ++c_int;
+      bool need_pop = false;
+      uint32_t next;
+      const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
+      if (__all(cur == ucur)) {
+        const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+        const_u_ptr su = (const_u_ptr)(sn + 7);
+        double s_split = sn[6];
+        uint32_t s_c1 = su[0], s_c2 = su[1];
+        TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
+        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], s_split, s_c1, s_c2, qx, qy, qz,
+                                     best, st, need_pop);
+      } else {
+        const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
+        const double4 n0 = *reinterpret_cast<const double4*>(np_);
+        double4 n1 = *reinterpret_cast<const double4*>(np_ + 32);
+        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
+        next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
+                                     (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
+      }
+      if (need_pop) {
+        next = REF_DONE;
+        while (st.sp > 0) {
+          --st.sp;
+          uint32_t r; double m2;
+          st.top(r, m2);
+          if (m2 < best) { next = r; break; }
+        }
+      }
+      cur = next;
+      fresh = (cur & REF_LEAF) != 0 && cur != REF_DONE;
+    } else if (cur != REF_DONE) {
+      // ---- ... or the next four points of the open bucket ----
+      if (fresh) {
+        const uint32_t v = cur & REF_VAL;
+        int start, count;
+        if (T.leaf_tab) {
+          const LeafEntry le = T.leaf_tab[v];
+          start = le.start; count = le.count;
+        } else {
+          start = (int)(v >> T.cb);
+          count = (int)(v & T.cmask);
+        }
+        if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
+        o = (uint32_t)start << 5;
+        olast = o + ((uint32_t)(count - 1) << 5);
+        fresh = false;
+      }
+      {
+        const uint32_t o1 = min(o + 32u, olast), o2 = min(o + 64u, olast), o3 = min(o + 96u, olast);
+        const double4 p0 = *reinterpret_cast<const double4*>(pb + o);
+        const double4 p1 = *reinterpret_cast<const double4*>(pb + o1);
+        const double4 p2 = *reinterpret_cast<const double4*>(pb + o2);
+        const double4 p3 = *reinterpret_cast<const double4*>(pb + o3);
+        double dx, dy, dz;
+        dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
+        const double d0 = dx * dx + dy * dy + dz * dz;
+        dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
+        const double d1 = dx * dx + dy * dy + dz * dz;
+        dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
+        const double d3 = dx * dx + dy * dy + dz * dz;
+        if (d0 < best) { best = d0; bk = (int)(o >> 5); }
+        if (d1 < best) { best = d1; bk = (int)(o1 >> 5); }
+        if (d2 < best) { best = d2; bk = (int)(o2 >> 5); }
+        if (d3 < best) { best = d3; bk = (int)(o3 >> 5); }
+        o += 128u;
+      }
+      if (o > olast) {   // bucket done: pop the next pending far child that still passes sqr(myd) < closest_d2
+        cur = REF_DONE;
+        while (st.sp > 0) {
+          --st.sp;
+          uint32_t r; double m2;
+          st.top(r, m2);
+          if (m2 < best) { cur = r; break; }
+        }
+        fresh = (cur & REF_LEAF) != 0 && cur != REF_DONE;
+      }
+    }
+  }
+  if (COUNT && a.counters) {
+    const unsigned long long s_int = wave_sum_u(c_int), s_leaf = wave_sum_u(c_leaf), s_pts = wave_sum_u(c_pts);
+    if (lane == 0) {
+      atomicAdd(&a.counters[0], s_int);
+      atomicAdd(&a.counters[1], s_leaf);
+      atomicAdd(&a.counters[2], s_pts);
     }
   }
 }
@@ -1363,6 +1564,7 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 //   8: persistent lanes, 256 queries per wave, 256-thread workgroups
 //   9 / 10 / 11: eight / four / sixteen lanes per query (k_search_g8); four is the default below 96K queries
 //  20: persistent lanes, 256 queries per wave, 128-thread workgroups
+//  40: persistent lanes, one loop in which every lane takes one step per trip (k_search_step, "if-if")
 //  30: persistent lanes fed from a work queue (k_search_refill<.., DYN>): resident waves draw 64-query slabs
 // (the TDTK_* knobs are read on every launch: a getenv is nothing beside a launch, and tests / probes flip them
 // inside one process)
@@ -1370,7 +1572,7 @@ static int search_variant()
 {
   const char* e = getenv("TDTK_SEARCH_VARIANT");
   int v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-  if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30) v = -2;
+  if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30 && v != 40) v = -2;
   return v;
 }
 
@@ -1449,12 +1651,15 @@ static uint32_t g8_grid(size_t n)
 int search_lds_depth() { return SEARCH_SD_MIN; }
 int search_block() { return SEARCH_BLOCK; }
 
-static int refill_thresh_env()
+// idle lanes a wave collects before it hands out new queries: 16, or 32 once the batch is several rounds of resident
+// waves (4M queries: 0.926 -> 0.913 ms; 1M: 0.238 -> 0.241, gpurun_out/r2h/sweep.log)
+static int refill_thresh(size_t n)
 {
-  const char* e = getenv("TDTK_REFILL_THRESH");
-  int v = e ? atoi(e) : 16;
-  if (v != 8 && v != 16 && v != 32) v = 16;
-  return v;
+  if (const char* e = getenv("TDTK_REFILL_THRESH")) {
+    const int v = atoi(e);
+    if (v == 8 || v == 16 || v == 32) return v;
+  }
+  return ((n + 255) / 256 >= (size_t)num_cu() * 4 * 7) ? 32 : 16;
 }
 // which kernel a batch of n queries gets (TDTK_SEARCH_VARIANT overrides)
 static int pick_variant(size_t n)
@@ -1479,7 +1684,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   int qpw;
   const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
   a.qpw = qpw;
-  switch (refill_thresh_env()) {
+  switch (refill_thresh(a.n)) {
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
     default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
@@ -1512,10 +1717,23 @@ static void launch_stream128(SearchArgs& a, hipStream_t s)
 {
   a.slab = stream_slab_env();
   const uint32_t nb = stream_grid(a.n);
-  switch (refill_thresh_env()) {
+  switch (refill_thresh(a.n)) {
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
     default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
+  }
+}
+
+template <bool COUNT>
+static void launch_step128(SearchArgs& a, hipStream_t s)
+{
+  int qpw;
+  const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
+  a.qpw = qpw;
+  switch (refill_thresh(a.n)) {
+    case 8: hipLaunchKernelGGL((k_search_step<128, 4, 8, COUNT>), dim3(nb), dim3(128), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_step<128, 4, 32, COUNT>), dim3(nb), dim3(128), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_search_step<128, 4, 16, COUNT>), dim3(nb), dim3(128), 0, s, a); break;
   }
 }
 
@@ -1536,6 +1754,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
       // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
       if (v == 20) { if (a.fuse) launch_refill128<true, true>(a, s); else launch_refill128<true, false>(a, s); }
       else if (v == 30) launch_stream128<true>(a, s);
+      else if (v == 40) launch_step128<true>(a, s);
       else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
       return hipGetLastError();
     }
@@ -1549,6 +1768,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
         break;
       }
       case 30: launch_stream128<false>(a, s); break;
+      case 40: launch_step128<false>(a, s); break;
       case 20: if (a.fuse) launch_refill128<false, true>(a, s); else launch_refill128<false, false>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;

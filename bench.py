@@ -465,10 +465,11 @@ def bench_graphslam(args, rank, world, local):
     # region.  TDTK_FORCE_ALLREDUCE=1 runs the same path with a 1-rank communicator.  The gloo rig of the test
     # suite (several ranks sharing one GPU, which RCCL refuses) keeps the torch.distributed exchange.
     comm = None
-    if on_dist and world > 1 and dev is not None:
-        comm = gs.NativeComm(rank, world, local, gs.torch_id_bcast(dev))
-    elif world == 1 and os.environ.get("TDTK_FORCE_ALLREDUCE") == "1":
-        comm = gs.NativeComm(0, 1, local)
+    with _stdout_to_stderr():          # RCCL prints its version banner when a communicator comes up
+        if on_dist and world > 1 and dev is not None:
+            comm = gs.NativeComm(rank, world, local, gs.torch_id_bcast(dev))
+        elif world == 1 and os.environ.get("TDTK_FORCE_ALLREDUCE") == "1":
+            comm = gs.NativeComm(0, 1, local)
     use_torch_exchange = on_dist and world > 1 and dev is None
     nn_ms = [0.0]
 

@@ -1156,6 +1156,23 @@ def test_bench_graphslam_two_ranks_on_this_box(gpu):
     b = json.loads(two.stdout.strip().splitlines()[-1])
     assert b["n_gpus"] == 2 and a["config"]["links"] == b["config"]["links"]
     assert a["last_ret"] == b["last_ret"]
+    # the RCCL branch itself: one rank under torch.distributed.run with the nccl backend (device mapping, device_id,
+    # banner kept off stdout) and the library's own communicator forced on (TDTK_FORCE_ALLREDUCE): one ncclAllReduce
+    # per LUM iteration inside tdtk_graph_iteration, same result bit for bit, stdout = the one JSON line
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, TDTK_FORCE_ALLREDUCE="1")
+    env.pop("TDTK_BENCH_BACKEND", None)
+    rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                         "--gpus", "1"] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    lines = [ln for ln in rc.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, rc.stdout[-2000:]
+    c = json.loads(lines[0])
+    assert c["last_ret"] == a["last_ret"] and "RCCL ncclAllReduce" in c["exchange"]
+    assert int(c["exchange"].split(",")[-1].split()[0]) >= 4          # 1 warm-up + 3 timed + the counting step
 
 
 @pytest.mark.parametrize("name", ["one", "two", "identical70", "identical64", "two_values", "axis_ties"])
@@ -1408,7 +1425,7 @@ def test_elch_close_loop_vs_oracle(tdtk, orc, gpu):
     loop.close_loop(S, 0, n - 1, g)
     delta, weights = io.elch_close_loop(O, 0, n - 1, g, 1, 25.0, 40, 1e-6)
     np.testing.assert_allclose(loop.last_delta, delta, rtol=1e-6, atol=1e-9)
-    assert np.abs(delta[:3]).max() > 0.3                        # there was a loop error to distribute
+    assert np.abs(delta[:3]).max() > 0.05                       # there was a loop error to distribute
     for s, o in zip(S, O):
         assert np.abs(s.transMat - o.transMat).max() < 1e-6 * max(1.0, np.abs(o.transMat).max())
         assert np.abs(s.get_xyz_reduced() - o.xyz).max() < 1e-6
