@@ -964,16 +964,18 @@ int tdtk_measure_bandwidth(int device, int kind, size_t bytes, int reps, double*
   if (kind == 0 && (rc = b.ensure(bytes))) return rc;
   HIPCHK(hipMemsetAsync(a.p, 1, bytes, c->stream));
   double best = 0.0;
-  for (int r = 0; r < reps + 1; r++) {
-    HIPCHK(hipEventRecord(c->e0, c->stream));
-    double moved = 0.0;
-    HIPCHK(launch_bandwidth(kind, a.p, b.p, bytes, &moved, c->stream));
-    HIPCHK(hipEventRecord(c->e1, c->stream));
-    HIPCHK(hipEventSynchronize(c->e1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->e0, c->e1));
-    if (r > 0 && ms > 0) best = std::max(best, moved / (ms * 1e-3) / 1e9);
-  }
+  const int variants[3] = {0, 2, 3};          // stream copy: plain, non-temporal, larger grid -- the best one counts
+  for (int v = 0; v < (kind == 0 ? 3 : 1); v++)
+    for (int r = 0; r < reps + 1; r++) {
+      HIPCHK(hipEventRecord(c->e0, c->stream));
+      double moved = 0.0;
+      HIPCHK(launch_bandwidth(kind == 0 ? variants[v] : kind, a.p, b.p, bytes, &moved, c->stream));
+      HIPCHK(hipEventRecord(c->e1, c->stream));
+      HIPCHK(hipEventSynchronize(c->e1));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, c->e0, c->e1));
+      if (r > 0 && ms > 0) best = std::max(best, moved / (ms * 1e-3) / 1e9);
+    }
   *gbs = best;
   return TDTK_OK;
 }

@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   size_t qi = 0;
   bool have = false;
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
-  double acc[FUSE ? ACC_DD : 1];
+  double acc[ACC_DD];   // live only when FUSE
   if (FUSE) {
 #pragma unroll
     for (int k = 0; k < ACC_DD; k++) acc[k] = 0.0;
@@ -1050,7 +1050,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
 // instruction issue, so paying both code paths per trip for fewer trips is the right trade.  Per-lane traversal,
 // visiting order and every comparison are unchanged -> same indices.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, int THRESH, bool COUNT>
+// VOTE (variant 41): only the path the MAJORITY of the busy lanes needs is issued per trip (lanes of the minority wait
+// one trip), so no trip pays for both paths.
+template <int BLOCK, int SD, int THRESH, bool COUNT, bool VOTE>
 __global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -1126,7 +1128,14 @@ __global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
     }
 
     // ---- one step: an internal node ... ----
-    if (!(cur & REF_LEAF)) {
+    bool do_nodes = true, do_leaves = true;
+    if (VOTE) {
+      const int n_node = __popcll(__ballot(!(cur & REF_LEAF)));
+      const int n_leaf = __popcll(__ballot((cur & REF_LEAF) && cur != REF_DONE));
+      do_nodes = n_node >= n_leaf;
+      do_leaves = !do_nodes;
+    }
+    if (do_nodes && !(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
       bool need_pop = false;
       uint32_t next;
@@ -1158,7 +1167,7 @@ __global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
       }
       cur = next;
       fresh = (cur & REF_LEAF) != 0 && cur != REF_DONE;
-    } else if (cur != REF_DONE) {
+    } else if (do_leaves && (cur & REF_LEAF) && cur != REF_DONE) {
       // ---- ... or the next four points of the open bucket ----
       if (fresh) {
         const uint32_t v = cur & REF_VAL;
@@ -1572,7 +1581,7 @@ static int search_variant()
 {
   const char* e = getenv("TDTK_SEARCH_VARIANT");
   int v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
-  if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30 && v != 40) v = -2;
+  if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30 && v != 40 && v != 41) v = -2;
   return v;
 }
 
@@ -1724,16 +1733,16 @@ static void launch_stream128(SearchArgs& a, hipStream_t s)
   }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool VOTE>
 static void launch_step128(SearchArgs& a, hipStream_t s)
 {
   int qpw;
   const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
   a.qpw = qpw;
   switch (refill_thresh(a.n)) {
-    case 8: hipLaunchKernelGGL((k_search_step<128, 4, 8, COUNT>), dim3(nb), dim3(128), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_search_step<128, 4, 32, COUNT>), dim3(nb), dim3(128), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_search_step<128, 4, 16, COUNT>), dim3(nb), dim3(128), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_search_step<128, 4, 8, COUNT, VOTE>), dim3(nb), dim3(128), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_step<128, 4, 32, COUNT, VOTE>), dim3(nb), dim3(128), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_search_step<128, 4, 16, COUNT, VOTE>), dim3(nb), dim3(128), 0, s, a); break;
   }
 }
 
@@ -1754,7 +1763,8 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
       // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
       if (v == 20) { if (a.fuse) launch_refill128<true, true>(a, s); else launch_refill128<true, false>(a, s); }
       else if (v == 30) launch_stream128<true>(a, s);
-      else if (v == 40) launch_step128<true>(a, s);
+      else if (v == 40) launch_step128<true, false>(a, s);
+      else if (v == 41) launch_step128<true, true>(a, s);
       else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
       return hipGetLastError();
     }
@@ -1768,7 +1778,8 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
         break;
       }
       case 30: launch_stream128<false>(a, s); break;
-      case 40: launch_step128<false>(a, s); break;
+      case 40: launch_step128<false, false>(a, s); break;
+      case 41: launch_step128<false, true>(a, s); break;
       case 20: if (a.fuse) launch_refill128<false, true>(a, s); else launch_refill128<false, false>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
@@ -1781,10 +1792,25 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
 }
 
 // ---- measured roofline denominators (tdtk_measure_bandwidth) ---------------------------------------------
-__global__ void __launch_bounds__(256) k_bw_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16)
+typedef float bw_v4f __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) k_bw_copy(const bw_v4f* __restrict__ src, bw_v4f* __restrict__ dst, size_t n16)
 {
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  // U independent 16-byte loads in flight per lane; a workgroup walks U * 256 consecutive elements per trip
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x; base < n16; base += stride) {
+    bw_v4f v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u * 256;
+      if (i < n16) v[u] = NT ? __builtin_nontemporal_load(&src[i]) : src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t i = base + (size_t)u * 256;
+      if (i < n16) { if (NT) __builtin_nontemporal_store(v[u], &dst[i]); else dst[i] = v[u]; }
+    }
+  }
 }
 // every XCD (workgroup b runs on XCD b % 8) sweeps its own eighth of the buffer `sweeps` times; a workgroup moves on
 // to the portion another workgroup of its XCD read in the previous sweep, so the lines come from the XCD's L2, not
@@ -1806,9 +1832,12 @@ __global__ void __launch_bounds__(256) k_bw_l2(const float4* __restrict__ src, s
 }
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s)
 {
-  if (kind == 0) {
+  if (kind == 0 || kind >= 2) {
+    // kind 0: plain loads / stores; 2: non-temporal; 3: plain with a larger grid (tdtk_measure_bandwidth keeps the best)
     const size_t n16 = bytes / 16;
-    hipLaunchKernelGGL(k_bw_copy, dim3((uint32_t)num_cu() * 8), dim3(256), 0, s, (const float4*)a, (float4*)b, n16);
+    if (kind == 2) hipLaunchKernelGGL((k_bw_copy<4, true>), dim3((uint32_t)num_cu() * 8), dim3(256), 0, s, (const bw_v4f*)a, (bw_v4f*)b, n16);
+    else if (kind == 3) hipLaunchKernelGGL((k_bw_copy<2, false>), dim3((uint32_t)num_cu() * 32), dim3(256), 0, s, (const bw_v4f*)a, (bw_v4f*)b, n16);
+    else hipLaunchKernelGGL((k_bw_copy<4, false>), dim3((uint32_t)num_cu() * 8), dim3(256), 0, s, (const bw_v4f*)a, (bw_v4f*)b, n16);
     *moved_bytes = 2.0 * (double)(n16 * 16);
   } else {
     const uint32_t per_xcd = (uint32_t)num_cu();        // 8 workgroups per CU in all

@@ -47,6 +47,10 @@ def pmc_kernel(kernel, fname=PMC_FILE):
         return None
 
 
+def pmc_traffic_note(k):
+    return None if not k else "profiles/%s" % PMC_FILE
+
+
 def pmc_traffic_bytes(k):
     """HBM-side (fabric) bytes per launch: FETCH_SIZE doubled per the guide's gfx950 correction (calibrated here on
     k_transform's known 24 MB stream) + WRITE_SIZE, both reported in KiB."""
@@ -132,8 +136,10 @@ def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_quer
                                                  "of issued VALU instructions that were active"}
         if pmc.get("SQ_INSTS_VALU"):
             b["valu_wave_instructions"] = pmc["SQ_INSTS_VALU"]
-        if pmc.get("SQ_BUSY_CYCLES") and pmc.get("SQ_ACTIVE_INST_VALU"):
-            b["valu_issue_busy"] = {"frac": pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_BUSY_CYCLES"] if pmc["SQ_BUSY_CYCLES"] else None}
+        if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY"):
+            b["wave_wait_share"] = {"frac": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
+                                    "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wave's resident cycles spent waiting "
+                                            "(dependent loads, issue slots taken by the other waves of its SIMD)"}
     r["bounds"] = b
     return r
 
@@ -406,7 +412,7 @@ def bench_icp(args, rank, world, local):
         # the k neighbours gathered for mean / covariance (24 B each) + the normal out (24)
         bp = 24.0 + 32.0 * a_split / a_q + 24.0 * a_leaf / a_q + 24.0 * 10 + 24.0
         ach = bp * n / (kn_ms * 1e-3) / 1e9
-        pk = pmc_kernel("k_ann_normals", "r02_normals_pmc.json")
+        pk = pmc_kernel("k_ann_normals")
         out["normals_1gpu"] = {"value": n / min(t_n), "unit": "points/s", "ms": min(t_n) * 1e3, "points": n, "k": 10, "eps": 1.0,
                                "what": "tdtk_scan_calc_normals on the resident scan: ANN-tree build, approximate 10-NN, "
                                        "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat",
@@ -510,6 +516,11 @@ def bench_graphslam(args, rank, world, local):
     # the link passes of a step run on up to 4 streams side by side, so one launch's duration is not the kernel's
     # throughput: the aggregate figure is (bytes of all this rank's link searches) / (wall time of the step)
     agg = bq * my_links * npts / (dt / args.steps) / 1e9
+    exchange = ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None \
+        else ("torch.distributed (gloo test rig)" if use_torch_exchange else "none (one rank)")
+    if comm is not None:
+        barrier_sync(world)
+        comm.close()                  # ncclCommDestroy now, on every rank together, not at interpreter shutdown
     out = {
         "metric": "NN correspondences/sec (graph-SLAM lum6DEuler iteration, links sharded)",
         "value": queries / dt, "unit": "NN correspondences/s",
@@ -520,8 +531,7 @@ def bench_graphslam(args, rank, world, local):
                                % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
         "lum_iters_per_s": args.steps / dt, "last_ret": ret,
-        "exchange": ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None
-                    else ("torch.distributed (gloo test rig)" if use_torch_exchange else "none (one rank)"),
+        "exchange": exchange,
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
         "roofline": {"bound": "hbm", "kernel": "k_search (link passes, up to 4 streams side by side)", "achieved": agg,

@@ -136,6 +136,8 @@ def ref():
         R.ref_Dist2.argtypes = [_dp, _dp]
         R.ref_newmat_inverse_solve.restype = C.c_int
         R.ref_newmat_inverse_solve.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+        R.ref_get_pt_pairs.restype = C.c_size_t
+        R.ref_get_pt_pairs.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_size_t, C.c_int, C.c_double, _ip, _dp, _dp, _dp, _dp]
         R.ref_icp_iterations.restype = C.c_int
         R.ref_icp_iterations.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, C.c_int, C.c_int, _dp]
         R.ref_lum_covariance_euler.restype = C.c_int
@@ -265,6 +267,19 @@ class RefTree:
         idx = np.empty(len(q), np.int32)
         ref().ref_kdi_find_closest(self.h, _d(q), len(q), float(maxdist2), _i(idx), int(nthreads))
         return idx
+
+    def get_pt_pairs(self, source_alignxf, xyz_r, normal_r=None, mode=0, maxdist2=625.0):
+        """SearchTree::getPtPairs assembled from the reference's compiled pieces (ref_driver.cc: ref_get_pt_pairs)"""
+        q = _c(xyz_r).reshape(-1, 3)
+        nr = _c(normal_r).reshape(-1, 3) if normal_r is not None else None
+        n = len(q)
+        idx = np.empty(n, np.int32)
+        p1, p2, pn = np.empty((n, 3)), np.empty((n, 3)), np.empty((n, 3))
+        sums = np.zeros(7)
+        k = ref().ref_get_pt_pairs(self.h, _d(_c(source_alignxf).reshape(16)), _d(q), _d(nr), n, int(mode), float(maxdist2),
+                                   _i(idx), _d(p1), _d(p2), _d(pn), _d(sums))
+        return dict(n=int(k), idx=idx, p1=p1[:k], p2=p2[:k], pn=pn[:k], sum=sums[0], centroid_m=sums[1:4].copy(),
+                    centroid_d=sums[4:7].copy())
 
     def icp_iterations(self, model_dalignxf, xyz, maxdist2, nthreads, iters):
         """Full OpenMP-branch ICP iterations (ref_driver.cc: ref_icp_iterations) -> (moved xyz, trace [iters][18])"""

@@ -34,6 +34,7 @@
 #include "slam6d/icp6Dlumquat.h"
 #include "slam6d/icp6Dquatscale.h"
 #include "slam6d/globals.icc"
+#include "slam6d/pairingMode.h"
 #include "newmat/newmatap.h"
 
 struct RefTree {
@@ -263,6 +264,64 @@ int ref_icp_iterations(void* h, const double* model_dalignxf, double* xyz, size_
     }
   }
   return 0;
+}
+
+/* SearchTree::getPtPairs, DataXYZ overload (searchTree.cc:92-189), all three pairing modes: the loop is restated here
+ * (searchTree.cc includes scan.h -> Boost), every operation in it is the reference's compiled code -- M4inv, transform3,
+ * Normalize3, transform3normal, KDtreeIndexed::FindClosest / FindClosestAlongDir, sub3 / Dot / scal_mul3 / add3, PtPair,
+ * Len2.  idx [n] (-1 = none); p1 / p2 / pn [pairs][3] compact in query order; sums = {sum, centroid_m[3], centroid_d[3]}
+ * un-normalised as the reference accumulates them.  Returns the number of pairs.                                   */
+size_t ref_get_pt_pairs(void* h, const double* source_alignxf, const double* xyz_r, const double* normal_r, size_t n,
+                        int pairing_mode, double max_dist_match2, int32_t* idx, double* p1, double* p2, double* pn,
+                        double* sums)
+{
+  RefTree* tr = static_cast<RefTree*>(h);
+  double local_alignxf_inv[16];
+  M4inv(source_alignxf, local_alignxf_inv);
+  double sum = 0, centroid_m[3] = {0, 0, 0}, centroid_d[3] = {0, 0, 0};
+  size_t np = 0;
+  double t[3], s[3], normal[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; i++) {
+    t[0] = xyz_r[3 * i]; t[1] = xyz_r[3 * i + 1]; t[2] = xyz_r[3 * i + 2];
+    transform3(local_alignxf_inv, t, s);
+    if (pairing_mode != CLOSEST_POINT) {
+      normal[0] = normal_r[3 * i]; normal[1] = normal_r[3 * i + 1]; normal[2] = normal_r[3 * i + 2];
+      Normalize3(normal);
+    }
+    size_t r;
+    if (pairing_mode == CLOSEST_POINT_ALONG_NORMAL_SIMPLE) {
+      transform3normal(local_alignxf_inv, normal);
+      r = tr->tree->FindClosestAlongDir(s, normal, max_dist_match2, 0);
+    } else {
+      r = tr->tree->FindClosest(s, max_dist_match2, 0);
+    }
+    const bool found = r != std::numeric_limits<size_t>::max();
+    if (idx) idx[i] = found ? (int32_t)r : -1;
+    if (!found) continue;
+    transform3(source_alignxf, tr->ptrs[r], s);
+    if (pairing_mode == CLOSEST_PLANE_SIMPLE) {
+      double tmp[3], s_[3];
+      sub3(s, t, tmp);
+      const double dot = Dot(normal, tmp);
+      scal_mul3(normal, dot, tmp);
+      add3(tmp, t, s_);
+      s[0] = s_[0]; s[1] = s_[1]; s[2] = s_[2];
+    }
+    centroid_m[0] += s[0]; centroid_m[1] += s[1]; centroid_m[2] += s[2];
+    centroid_d[0] += t[0]; centroid_d[1] += t[1]; centroid_d[2] += t[2];
+    PtPair myPair(s, t, normal);
+    double p12[3] = { myPair.p1.x - myPair.p2.x, myPair.p1.y - myPair.p2.y, myPair.p1.z - myPair.p2.z };
+    sum += Len2(p12);
+    if (p1) { p1[3 * np] = myPair.p1.x; p1[3 * np + 1] = myPair.p1.y; p1[3 * np + 2] = myPair.p1.z; }
+    if (p2) { p2[3 * np] = myPair.p2.x; p2[3 * np + 1] = myPair.p2.y; p2[3 * np + 2] = myPair.p2.z; }
+    if (pn) { pn[3 * np] = myPair.p2.nx; pn[3 * np + 1] = myPair.p2.ny; pn[3 * np + 2] = myPair.p2.nz; }
+    np++;
+  }
+  if (sums) {
+    sums[0] = sum;
+    for (int k = 0; k < 3; k++) { sums[1 + k] = centroid_m[k]; sums[4 + k] = centroid_d[k]; }
+  }
+  return np;
 }
 
 /* ---- the 4x4 / pose primitives of include/slam6d/globals.icc, as the reference compiles them ------------

@@ -583,8 +583,11 @@ def test_oracle_octree_center_against_grid_formulation(orc):
     rng = np.random.default_rng(11)
     one = np.array([[4.0, -2.0, 8.0]])   # a point on the split planes goes to the lower child (strict >)
     assert np.array_equal(orc.octree_center(one, 5.0), one - 0.5)
-    for n, voxel in ((2000, 3.0), (50000, 10.0), (3000, 1e6)):
-        pts = rng.uniform(-300, 500, (n, 3)) * np.array([1.0, 0.5, 0.1])
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    clouds = [(rng.uniform(-300, 500, (n, 3)) * np.array([1.0, 0.5, 0.1]), voxel) for n, voxel in ((2000, 3.0), (50000, 10.0), (3000, 1e6))]
+    clouds += [(z["scan%03d" % k], voxel) for k in range(3) for voxel in (10.0, 2.5)]      # the bundled scans, -r 10 / -r 2.5
+    for pts, voxel in clouds:
+        n = len(pts)
         got = orc.octree_center(pts, voxel)
         lo, hi = pts.min(0), pts.max(0)
         c = 0.5 * (lo + hi)

@@ -262,6 +262,62 @@ def test_transform3_out_of_place_form_against_reference(orc):
     assert np.array_equal(o["p2"], world[found])
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_get_pt_pairs_all_modes_against_reference_pieces(orc, mode):
+    """A4: SearchTree::getPtPairs in the three pairing modes (searchTree.cc:92-189) -- closest point, closest point
+    along the normal (FindClosestAlongDir with the normalised normal rotated into the tree frame), closest point
+    projected onto the data point's tangent plane -- with the loop restated in ref_driver.cc and every operation the
+    reference's own compiled code: the oracle's restatement gives the same indices, pair lists (p1, p2, the normal the
+    pair carries) and accumulators, bit for bit, through a non-trivial pose, with duplicates in the model."""
+    from oracle import icp_oracle as io
+    if not orc.have_ref():
+        pytest.skip("reference TUs not built here")
+    rng = np.random.default_rng(40 + mode)
+    m = rng.uniform(-100, 100, (12000, 3)); m[:, 2] *= 0.05; m[500:700] = m[0:200]
+    A = io.euler_to_matrix4([4.0, -1.0, 2.0], [0.02, -0.05, 0.03])
+    world = orc.ref_transform3(A, m)[rng.permutation(len(m))[:3000]] + rng.normal(0, 0.4, (3000, 3))
+    nrm = rng.normal(size=(3000, 3)) * rng.uniform(0.1, 5.0, (3000, 1))      # un-normalised on purpose
+    md2 = 9.0
+    r = orc.RefTree(m, 10).get_pt_pairs(A, world, nrm if mode else None, mode, md2)
+    o = orc.Tree(m, 10).get_pt_pairs(A, world, nrm if mode else None, 0, None, mode, md2)
+    assert r["n"] == o["n"] > 500 and np.array_equal(r["idx"], o["idx"])
+    assert np.array_equal(r["p1"], o["p1"]) and np.array_equal(r["p2"], o["p2"])
+    if mode:
+        assert np.array_equal(r["pn"], o["pn"])
+    assert r["sum"] == o["sum"] and np.array_equal(r["centroid_m"], o["centroid_m"]) and np.array_equal(r["centroid_d"], o["centroid_d"])
+
+
+def test_spd_solve_against_newmat(orc, tdtk):
+    """A16: graphSlam6D::solveSparseCholesky goes through CSparse, which this image does not have; the product's dense
+    envelope Cholesky (tdtk_solve_spd, with convertToCS's |v| > 1e-5 entry filter) is checked against the reference's
+    vendored matrix library instead: newmat's `G.i() * B` on a C4-shaped block system (63 unknown poses, 6x6 SPD link
+    blocks spanning 1e3 .. 1e9 like real LUM blocks, chain + closures)."""
+    import ctypes as C
+    if not orc.have_ref():
+        pytest.skip("reference TUs not built here")
+    rng = np.random.default_rng(16)
+    n = 63
+    G = np.zeros((6 * n, 6 * n)); B = np.zeros(6 * n)
+    links = [(i, i + 1) for i in range(n)] + [(0, 40), (5, 52), (10, 63), (20, 61)]
+    scale = np.array([1.0, 1.0, 1.0, 300.0, 300.0, 300.0])
+    for (fa, fb) in links:
+        M = rng.normal(size=(6, 6))
+        Cm = (M @ M.T + 6 * np.eye(6)) * 4e3 * np.outer(scale, scale)
+        CD = rng.normal(size=6) * 50.0 * scale
+        a, b = fa - 1, fb - 1
+        if a >= 0:
+            B[a * 6:a * 6 + 6] += CD; G[a * 6:a * 6 + 6, a * 6:a * 6 + 6] += Cm
+        if b >= 0:
+            B[b * 6:b * 6 + 6] -= CD; G[b * 6:b * 6 + 6, b * 6:b * 6 + 6] += Cm
+        if a >= 0 and b >= 0:
+            G[a * 6:a * 6 + 6, b * 6:b * 6 + 6] -= Cm; G[b * 6:b * 6 + 6, a * 6:a * 6 + 6] -= Cm
+    _, Xn = orc.ref_newmat_inverse_solve(G, B)
+    X = np.empty(6 * n)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert tdtk.lib().tdtk_solve_spd(dp(np.ascontiguousarray(G)), dp(B), 6 * n, dp(X)) == 0
+    np.testing.assert_allclose(X, Xn, rtol=1e-7, atol=1e-9 * np.abs(Xn).max())
+
+
 def test_lum_link_system_against_newmat(orc, tdtk):
     """A14: covarianceEuler's arithmetic (lum6Deuler.cc:143-232) evaluated with the reference's own newmat objects
     (`MM.i() * MZ`, `MM * ss`) in oracle/_ref on the pinned dat/ pair lists: the numpy restatement, the committed

@@ -4,7 +4,7 @@
 #   usage: tools/profile_bench.sh <tag>          -> gpurun_out/<tag>/{stats,fetch,write}/...
 set -u
 TAG="${1:-prof}"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base --no-normals"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base"
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $CMD > "$OUT/stats.json" 2> "$OUT/stats.err"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- $CMD > "$OUT/fetch.json" 2> "$OUT/fetch.err"

@@ -7,6 +7,8 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(n):
     n = n.split("(")[0].replace("void ", "").replace("tdtk::", "")
+    if n.startswith("k_ann_normals<"):
+        return "k_ann_normals_count(instrumented, not timed)" if "true" in n else "k_ann_normals"
     if n.startswith("k_search_refill<"):
         a = [t.strip() for t in n[len("k_search_refill<"):].split(">")[0].split(",")]
         # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN>
@@ -44,7 +46,7 @@ if os.path.exists(stats_file):
     open(os.path.join("profiles", pre + "_rocprofv3_kernel_stats_raw.csv"), "w").write(open(stats_file).read())
 
 # --- PMC passes
-pmc = {"command": "python bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base --no-normals", "kernels": {},
+pmc = {"command": "python bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base", "kernels": {},
        "note": "per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE "
                "reads 1/2 of the streamed bytes (calibrated: k_transform reads 3 x 8 MB = 23437.5 KiB, reports ~11738)"}
 for p in ("fetch", "write", "sq1", "sq2", "sq3", "tcc"):
