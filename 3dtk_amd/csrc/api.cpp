@@ -169,7 +169,7 @@ struct tdtk_tree {
   size_t M = 0;
   int bucket = 0;
   TreeDev dev{};
-  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr;
+  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr;
   double bbmin[3], bbmax[3], centre[3];
   tdtk_tree_info info{};
   tdtk_tree() = default;
@@ -178,7 +178,7 @@ struct tdtk_tree {
   ~tdtk_tree()   // also the error paths of tdtk_tree_create: nothing stays allocated on the device
   {
     (void)hipSetDevice(device);
-    void* p[] = {d_nodes, d_pts, d_leaf, d_r};
+    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot};
     for (void* q : p)
       if (q) (void)hipFree(q);
   }
@@ -266,17 +266,28 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   return TDTK_OK;
 }
 
-static void tree_finish(tdtk_tree* t, size_t M)
+static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
 {
   for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
+  // the compact hot records (fp32 box + split value + children) the big-batch search kernel walks
+  double am = 0.0;
+  for (int a = 0; a < 3; a++) am = std::max(am, std::max(std::fabs(t->bbmin[a]), std::fabs(t->bbmax[a])));
+  t->dev.absmax = (float)std::min(am * 1.0000002, 3.0e38);
+  if (t->info.n_internal) {
+    HIPCHK(hipMalloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
+    HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  t->dev.hot = static_cast<const KdHot*>(t->d_hot);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
   t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
   t->dev.node_r = static_cast<const double*>(t->d_r);
   t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
   t->info.n_points = M;
-  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(double)) + M * sizeof(KdPoint) +
+  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + sizeof(double)) + M * sizeof(KdPoint) +
                          (t->d_leaf ? t->info.n_leaves * sizeof(LeafEntry) : 0);
+  return TDTK_OK;
 }
 
 static int tree_check_args(size_t M, int bucket_size)
@@ -341,7 +352,7 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
     HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, xyz, 3 * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
   }
-  tree_finish(t.get(), M);
+  if ((rc = tree_finish(c, t.get(), M))) return rc;
   *out = t.release();
   return TDTK_OK;
 }
@@ -367,7 +378,7 @@ int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree
   HIPCHK(launch_unsort_aos(saved ? scan->ox : scan->x, saved ? scan->oy : scan->y, saved ? scan->oz : scan->z,
                            scan->d_order, M, c->ws[WS_TMPA].as<double>(), c->stream));
   if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
-  tree_finish(t.get(), M);
+  if ((rc = tree_finish(c, t.get(), M))) return rc;
   *out = t.release();
   return TDTK_OK;
 }
@@ -401,7 +412,7 @@ int tdtk_tree_create_from_scans(tdtk_scan* const* scans, int nscans, int bucket_
     off += sc->N;
   }
   if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
-  tree_finish(t.get(), M);
+  if ((rc = tree_finish(c, t.get(), M))) return rc;
   *out = t.release();
   return TDTK_OK;
 }

@@ -11,6 +11,8 @@ struct Mat4 {
 };
 
 struct TreeDev {
+  const KdHot* hot;           // compact hot records (fp32 box), same indexing as nodes
+  float absmax;               // largest |coordinate| of the root box: scales the fp32 error bound
   const KdNode* nodes;
   const KdPoint* pts;
   const LeafEntry* leaf_tab;  // non-null only in table mode
@@ -107,6 +109,7 @@ bool search_uses_queue(size_t n);      // does it get the work-queue kernel (nee
 bool search_can_fuse(size_t n);        // does a batch of n queries get the kernel that can fuse the base sums?
 uint32_t search_fused_rows(size_t n);  // rows of partials the fused kernel writes
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
+hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
 hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);
 int search_lds_depth();
 int search_block();

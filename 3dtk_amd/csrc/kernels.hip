@@ -163,6 +163,65 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
 #define TDTK_PIN_S64(x) asm volatile("" : "+s"(x))
 #define TDTK_PIN_S32(x) asm volatile("" : "+s"(x))
 
+// ---- the box test at fp32 rate, without changing a single decision ---------------------------------------------
+// The reference prunes a node iff  a >= 0 && a*a >= closest_d2,  a = max_i(|q_i - c_i| - h_i)  in fp64
+// (kdTreeImpl.h:360-368).  With the node's box and the query rounded to fp32 the same expression a32 differs from the
+// exact value by at most  3.01 eps32 (|q|_inf + |c|_inf + |h|_inf) <= delta = 3e-7 (|q|_inf + 2 absmax)  (eps32 = 2^-24;
+// three conversions, two subtractions).  With r32 = sqrtf((float)closest_d2), off by at most 1.3 * 2^-23 relative:
+//   a32 >= r32 (1 + 1e-6) + delta   =>  a >= sqrt(closest_d2) (1 + 2^-22) > 0   =>  the reference prunes;
+//   a32 <  r32 (1 - 1e-6) - delta   =>  a <  sqrt(closest_d2) (1 - 2^-22)       =>  the reference does not;
+// (the fp64 roundings of the reference's own a and a*a are 2^-53 relative, eleven orders below these margins).
+// Anything in between -- a band of relative width ~1e-6 -- and anything not finite takes the exact fp64 test on the
+// full record.  Visits therefore stay the reference's node for node (the instrumented instantiations count the same
+// numbers as the oracle), while the common case costs 9 fp32 operations instead of 15 at fp64 rate and the hot
+// record is 48 bytes instead of 64.
+struct BoxF32 {
+  float qx, qy, qz;   // the query in fp32
+  float delta;        // error bound of a32 for this query
+  float thi, tlo;     // decision thresholds for the current closest_d2
+  __device__ __forceinline__ void set_query(const double x, const double y, const double z, const float absmax)
+  {
+    qx = (float)x; qy = (float)y; qz = (float)z;
+    const float qm = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+    delta = 3.0e-7f * (qm + 2.0f * absmax) + 1.0e-30f;
+  }
+  __device__ __forceinline__ void set_radius(const double best)
+  {
+    const float r32 = __builtin_amdgcn_sqrtf((float)best);   // v_sqrt_f32: 1 ulp
+    thi = r32 * 1.000001f + delta;
+    tlo = r32 * 0.999999f - delta;
+  }
+};
+
+// exact box test of the reference on the full record (kdTreeImpl.h:360-368)
+__device__ __forceinline__ bool box_prunes_exact(const double cx, const double cy, const double cz, const double hx,
+                                                 const double hy, const double hz, const double qx, const double qy,
+                                                 const double qz, const double best)
+{
+  const double ax = fabs(qx - cx) - hx;
+  const double ay = fabs(qy - cy) - hy;
+  const double az = fabs(qz - cz) - hz;
+  const double ab = (ax < ay) ? ay : ax;
+  const double ap = (ab < az) ? az : ab;
+  return ap >= 0.0 && ap * ap >= best;
+}
+
+// the split-plane half of visit_node (kdTreeImpl.h:371-382): near child, far child pushed if it can still matter
+template <int BLOCK, int SD>
+__device__ __forceinline__ uint32_t descend(const double splitval, const uint32_t c1, const uint32_t c2, const double qx,
+                                            const double qy, const double qz, const double best, LaneStack<BLOCK, SD>& st)
+{
+  const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
+  const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
+  const double myd = splitval - qa;
+  const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
+  const bool first = (myd >= 0.0);
+  const uint32_t far = first ? r2 : r1;
+  const double m2 = myd * myd;
+  if (m2 < best) st.push(far, m2);
+  return first ? r1 : r2;
+}
+
 // Warm start of a repeated pass (ICP iteration i+1 over the scan iteration i has just searched): the previous hit is a
 // real point of the tree, so the nearest point is at most that far away, and starting with closest_d2 one ulp ABOVE
 // its squared distance (instead of maxdist2) cannot lose it: every test of the traversal prunes only what lies at
@@ -199,37 +258,57 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
   const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+  const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
+  BoxF32 bx;
+  bx.set_query(qx, qy, qz, T.absmax);
+  bx.set_radius(best);
 
   for (;;) {
     // ---- phase 1: walk internal nodes until this lane holds a leaf (or is finished) ----
     while (!(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
       bool need_pop = false;
-      uint32_t next;
+      uint32_t next = REF_DONE;
       bool uniform = false;
       uint32_t ucur = 0;
       if (UNI) {
         // spatially sorted queries walk the same upper nodes: when every active lane of the
-        // wave holds the same node, fetch its 64 bytes once through the scalar cache (one
-        // s_load_dwordx16, operands stay in SGPRs) instead of 64 lanes x 4 vector loads
+        // wave holds the same node, fetch its hot record once through the scalar cache (operands stay in
+        // SGPRs) instead of 64 lanes x 3 vector loads
         ucur = __builtin_amdgcn_readfirstlane(cur);
         uniform = __all(cur == ucur);
       }
       if (UNI && uniform) {
-        const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
-        const_u_ptr su = (const_u_ptr)(sn + 7);
-        double s_split = sn[6];
+        typedef const float __attribute__((address_space(4))) * const_f_ptr;
+        const_f_ptr sf = (const_f_ptr)(hotb + (size_t)ucur * sizeof(KdHot));
+        const_d_ptr sd = (const_d_ptr)(sf + 8);
+        const_u_ptr su = (const_u_ptr)(sf + 10);
+        double s_split = sd[0];
         uint32_t s_c1 = su[0], s_c2 = su[1];
         TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
-        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], s_split, s_c1, s_c2, qx,
-                                     qy, qz, best, st, need_pop);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - sf[0]) - sf[3], fabsf(bx.qy - sf[1]) - sf[4]), fabsf(bx.qz - sf[2]) - sf[5]);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {
+          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+          prune = box_prunes_exact(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else next = descend<BLOCK, SD>(s_split, s_c1, s_c2, qx, qy, qz, best, st);
       } else {
-        const double4 n0 = nodes[(size_t)cur * 2];      // cx cy cz hx
-        double4 n1 = nodes[(size_t)cur * 2 + 1];        // hy hz splitval {c1,c2}
-        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
-        next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z,
-                                     (uint32_t)__double2loint(n1.w), (uint32_t)__double2hiint(n1.w),
-                                     qx, qy, qz, best, st, need_pop);
+        const char* hp = hotb + (size_t)cur * sizeof(KdHot);
+        const float4 b0 = *reinterpret_cast<const float4*>(hp);          // cx cy cz hx
+        const float2 b1 = *reinterpret_cast<const float2*>(hp + 16);     // hy hz
+        double2 sc = *reinterpret_cast<const double2*>(hp + 32);         // splitval {c1, c2}
+        TDTK_PIN_V64(sc.x); TDTK_PIN_V64(sc.y);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {
+          const double4 n0 = nodes[(size_t)cur * 2];
+          const double4 n1 = nodes[(size_t)cur * 2 + 1];
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else next = descend<BLOCK, SD>(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), qx, qy, qz, best, st);
       }
       if (need_pop) {
         next = REF_DONE;
@@ -277,6 +356,7 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
         for (int j = 0; j < PTS; j++)
           if (d[j] < best) { best = d[j]; bk = start + id[j]; }
       }
+      bx.set_radius(best);
     }
     // pop the next pending far child that still passes sqr(myd) < closest_d2
     cur = REF_DONE;
@@ -704,14 +784,29 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
     int bk = -1;
     uint32_t cur = T.root_ref;
     st.sp = 0;
+    BoxF32 bx;
+    bx.set_query(qx, qy, qz, T.absmax);
+    bx.set_radius(best);
     for (;;) {
       while (!(cur & REF_LEAF)) {
         bool need_pop = false;
-        const double4 n0 = nodes[(size_t)cur * 2];
-        double4 n1 = nodes[(size_t)cur * 2 + 1];
-        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
-        uint32_t next = visit_node<NG, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
-                                           (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
+        uint32_t next = REF_DONE;
+        {
+          const char* hp = reinterpret_cast<const char*>(T.hot) + (size_t)cur * sizeof(KdHot);
+          const float4 b0 = *reinterpret_cast<const float4*>(hp);
+          const float2 b1 = *reinterpret_cast<const float2*>(hp + 16);
+          double2 sc = *reinterpret_cast<const double2*>(hp + 32);
+          TDTK_PIN_V64(sc.x); TDTK_PIN_V64(sc.y);
+          const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
+          bool prune = a32 >= bx.thi;
+          if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {
+            const double4 n0 = nodes[(size_t)cur * 2];
+            const double4 n1 = nodes[(size_t)cur * 2 + 1];
+            prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+          }
+          if (prune) need_pop = true;
+          else next = descend<NG, SD>(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), qx, qy, qz, best, st);
+        }
         if (need_pop) {
           next = REF_DONE;
           while (st.sp > 0) {
@@ -753,6 +848,7 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
           }
           if (d < best) { best = d; bk = start + jj; }
         }
+        bx.set_radius(best);
       }
       cur = REF_DONE;
       while (st.sp > 0) {
@@ -852,6 +948,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   int bk = -1;
   size_t qi = 0;
   bool have = false;
+  BoxF32 bx;
+  bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f;
+  const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
   double acc[ACC_DD];   // live only when FUSE
   if (FUSE) {
@@ -923,6 +1022,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
         qi = mine; have = true;
         cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
+        bx.set_query(qx, qy, qz, T.absmax);
+        bx.set_radius(best);
       }
       next_q += (size_t)__popcll(idlem);
     }
@@ -935,25 +1036,43 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
     while (!(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
       bool need_pop = false;
-      uint32_t next;
+      uint32_t next = REF_DONE;
       const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
       if (__all(cur == ucur)) {
-        const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
-        const_u_ptr su = (const_u_ptr)(sn + 7);
-        double s_split = sn[6];
+        // wave-uniform visit: the 48-byte hot record through the scalar cache
+        typedef const float __attribute__((address_space(4))) * const_f_ptr;
+        const_f_ptr sf = (const_f_ptr)(hotb + (size_t)ucur * sizeof(KdHot));
+        const_d_ptr sd = (const_d_ptr)(sf + 8);
+        const_u_ptr su = (const_u_ptr)(sf + 10);
+        double s_split = sd[0];
         uint32_t s_c1 = su[0], s_c2 = su[1];
         TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
-        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], s_split, s_c1, s_c2, qx, qy, qz,
-                                     best, st, need_pop);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - sf[0]) - sf[3], fabsf(bx.qy - sf[1]) - sf[4]), fabsf(bx.qz - sf[2]) - sf[5]);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+          prune = box_prunes_exact(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else next = descend<BLOCK, SD>(s_split, s_c1, s_c2, qx, qy, qz, best, st);
       } else {
-        // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no
-        // 64-bit address arithmetic on the vector ALU (the node array is < 4 GB by construction)
-        const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
-        const double4 n0 = *reinterpret_cast<const double4*>(np_);
-        double4 n1 = *reinterpret_cast<const double4*>(np_ + 32);
-        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
-        next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
-                                     (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
+        // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no 64-bit address
+        // arithmetic on the vector ALU (the hot array is < 4 GB by construction)
+        const char* hp = hotb + (uint32_t)(cur * (uint32_t)sizeof(KdHot));
+        const float4 b0 = *reinterpret_cast<const float4*>(hp);          // cx cy cz hx
+        const float2 b1 = *reinterpret_cast<const float2*>(hp + 16);     // hy hz
+        double2 sc = *reinterpret_cast<const double2*>(hp + 32);         // splitval {c1, c2}
+        TDTK_PIN_V64(sc.x); TDTK_PIN_V64(sc.y);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
+          const double4 n0 = *reinterpret_cast<const double4*>(np_);
+          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else next = descend<BLOCK, SD>(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), qx, qy, qz, best, st);
       }
       if (need_pop) {
         next = REF_DONE;
@@ -1002,6 +1121,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         if (d2 < best) { best = d2; bk = (int)(o2 >> 5); }
         if (d3 < best) { best = d3; bk = (int)(o3 >> 5); }
       }
+      bx.set_radius(best);
       cur = REF_DONE;
       while (st.sp > 0) {
         --st.sp;
@@ -1851,6 +1971,25 @@ hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* mo
     hipLaunchKernelGGL(k_bw_l2, dim3(nb), dim3(256), 0, s, (const float4*)a, slice16, sweeps, (float*)a);
     *moved_bytes = (double)nb * (double)portion * 16.0 * sweeps;
   }
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nodes, size_t n, KdHot* __restrict__ hot)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const KdNode nd = nodes[i];
+  KdHot h;
+  h.cx = (float)nd.cx; h.cy = (float)nd.cy; h.cz = (float)nd.cz;
+  h.hx = (float)nd.hx; h.hy = (float)nd.hy; h.hz = (float)nd.hz;
+  h.pad0 = h.pad1 = 0u;
+  h.splitval = nd.splitval; h.c1 = nd.c1; h.c2 = nd.c2;
+  hot[i] = h;
+}
+hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_make_hot, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, hot);
   return hipGetLastError();
 }
 
