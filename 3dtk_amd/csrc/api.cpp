@@ -1689,9 +1689,10 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
   }
   int max_lanes = 8, forced = 0;
   if (const char* e = getenv("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));
-  // small scans: a pass is latency-bound, 8 side by side; big scans: 4, so the thin tail of one search and the
-  // small sum kernels overlap with the next search (16 x 1M, 18 links: 4.8 -> 3.4 ms)
-  const int L = (nlinks > 1) ? std::min(nlinks, forced ? forced : std::min(max_lanes, maxN <= (size_t)262144 ? 8 : 4)) : 1;
+  // small scans: a pass is latency-bound, 8 side by side; big scans: 3, so the thin tail of one search and the
+  // small sum kernels overlap with the next search (84 links of 1M: 1 lane 16.8 ms, 2: 13.9, 3: 13.3, 4: 14.3,
+  // 6: 13.4, 8: 13.7 -- the same order for the 44 / 22 / 11 links of a 2 / 4 / 8-rank share; tools/gs_lanes_probe.py)
+  const int L = (nlinks > 1) ? std::min(nlinks, forced ? forced : std::min(max_lanes, maxN <= (size_t)262144 ? 8 : 3)) : 1;
   HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
   if (L > 1) {
     while ((int)c->lanes.size() < L) {

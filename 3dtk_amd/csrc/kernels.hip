@@ -910,7 +910,6 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   __shared__ uint32_t lds_ref[SD][BLOCK];
 
   const uint32_t nb = gridDim.x;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
   const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned lane = threadIdx.x & (WAVE - 1);
   LaneStack<BLOCK, SD> st;
@@ -926,6 +925,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
 
   size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
+  size_t sub = 0, reg0 = 0, pstride = 0;
+  int phase = 0;
   uint32_t xq = 0, tried = 0, nslab = 0, per_x = 0;
   if (DYN) {
     next_q = end_q = 0;
@@ -936,9 +937,17 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
     if (blockIdx.x == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
   } else {
     // a wave owns qpw consecutive sorted queries (256 unless the batch is so large that the grid is capped)
-    const size_t wave_id = (size_t)chunk * (BLOCK / WAVE) + threadIdx.x / WAVE;
-    next_q = wave_id * (size_t)a.qpw;
-    end_q = next_q + (size_t)a.qpw;
+    // ... handed out in `phases` pieces: the waves of one XCD (workgroup b runs on XCD b % 8) first cover the first
+    // 1/phases of the XCD's eighth of the scan together, then the next, so that the leaves the XCD's 4 MB L2 has to
+    // hold at any one time are those under 1/phases of the eighth (the 32-byte points of an eighth of a 1M-point
+    // model alone are 4 MB)
+    const uint32_t wpx = (nb >> 3) * (BLOCK / WAVE);                      // waves per XCD
+    const uint32_t wx = (blockIdx.x >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE;   // this wave among them
+    sub = (size_t)(a.qpw / a.phases);
+    reg0 = (size_t)(blockIdx.x & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
+    pstride = (size_t)wpx * sub;
+    next_q = reg0;
+    end_q = next_q + sub;
     if (next_q > a.n) next_q = a.n;
     if (end_q > a.n) end_q = a.n;
   }
@@ -1002,6 +1011,13 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         ++tried;
       }
     }
+    if (!DYN && fill && next_q >= end_q && phase + 1 < a.phases) {
+      ++phase;
+      next_q = reg0 + (size_t)phase * pstride;
+      end_q = next_q + sub;
+      if (next_q > a.n) next_q = a.n;
+      if (end_q > a.n) end_q = a.n;
+    }
     if (next_q < end_q && fill) {
       const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
       const size_t mine = next_q + rank;
@@ -1028,7 +1044,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       next_q += (size_t)__popcll(idlem);
     }
     if (__ballot(cur != REF_DONE) == 0) {
-      if (next_q >= end_q && (!DYN || tried >= 8u)) break;
+      if (next_q >= end_q && (DYN ? tried >= 8u : phase + 1 >= a.phases)) break;
       continue;
     }
 
@@ -1813,6 +1829,16 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   int qpw;
   const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
   a.qpw = qpw;
+  // Two pieces when every wave of the launch is resident at once (the XCD's waves then move through its eighth of the
+  // scan together): 1M-vs-1M ICP, L2 misses 1.98 M -> 1.15 M per launch, fabric reads 239 -> 138 MB, time unchanged
+  // (0.2190 -> 0.2187 ms); with several generations of waves (4M: 0.806 -> 0.821 ms, reads -35 %) the pieces only
+  // cost coherence.  Non-temporal loads / stores for the query and result streams were measured too: no change in
+  // misses or time.  (gpurun_out/r2n..r2r, tools/nt_probe.sh)
+  int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7) ? 1 : 2;
+  if (const char* e = getenv("TDTK_REFILL_PHASES")) ph = atoi(e);
+  if (ph < 1) ph = 1;
+  while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries
+  a.phases = ph;
   switch (refill_thresh(a.n)) {
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
@@ -1894,6 +1920,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
         int qpw;
         const uint32_t nb = refill_grid_b(a.n, SEARCH_BLOCK, &qpw);
         a.qpw = qpw;
+        a.phases = 1;
         hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 16, 1, false, false, false>), dim3(nb), b, 0, s, a);
         break;
       }

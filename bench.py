@@ -513,7 +513,7 @@ def bench_graphslam(args, rank, world, local):
         counts = vc.read()
     my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
     bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
-    # the link passes of a step run on up to 4 streams side by side, so one launch's duration is not the kernel's
+    # the link passes of a step run on up to 3 streams side by side, so one launch's duration is not the kernel's
     # throughput: the aggregate figure is (bytes of all this rank's link searches) / (wall time of the step)
     agg = bq * my_links * npts / (dt / args.steps) / 1e9
     exchange = ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None \
@@ -534,7 +534,7 @@ def bench_graphslam(args, rank, world, local):
         "exchange": exchange,
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
-        "roofline": {"bound": "hbm", "kernel": "k_search (link passes, up to 4 streams side by side)", "achieved": agg,
+        "roofline": {"bound": "hbm", "kernel": "k_search (link passes, up to 3 streams side by side)", "achieved": agg,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
                      "traffic": pmc_traffic_bytes(pmc_kernel("k_search", "r02_graphslam_pmc.json")),
                      "kernel_ms_one_launch_among_concurrent": k_ms, "bytes_per_query": bq,

@@ -14,20 +14,23 @@ t.prepare_scans(scans, trees=True, threads=8)
 L = capi.lib()
 for _ in range(3):
     gs.graph_iteration_comm(1, t.Graph(ns, 500.0 ** 2, 20, scans), scans, 625.0, None)
-for lanes in ("1", "2", "3", "4", "6", "8"):
-    os.environ["TDTK_LINK_LANES"] = lanes
-    tl, ti = [], []
-    for rep in range(4):
-        gr = t.Graph(ns, 500.0 ** 2, 20, scans)
-        nl = gr.getNrLinks()
-        first = (C.c_void_p * nl)(*[scans[gr.getLink(i, 0)].getSearchTree()._h for i in range(nl)])
-        second = (C.c_void_p * nl)(*[scans[gr.getLink(i, 1)].handle for i in range(nl)])
-        dal = np.ascontiguousarray(np.stack([scans[gr.getLink(i, 0)].dalignxf for i in range(nl)]))
-        blocks = np.empty((nl, 42))
-        t0 = time.perf_counter()
-        capi.check(L.tdtk_graph_link_blocks(1, nl, first, capi.dptr(dal), second, 625.0, capi.dptr(blocks)))
-        tl.append(time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        gs.graph_iteration_comm(1, t.Graph(ns, 500.0 ** 2, 20, scans), scans, 625.0, None)
-        ti.append(time.perf_counter() - t0)
-    print("lanes %s: link passes %.2f ms (%.3f ms / link), whole iteration %.2f ms" % (lanes, min(tl) * 1e3, min(tl) * 1e3 / nl, min(ti) * 1e3))
+gr = t.Graph(ns, 500.0 ** 2, 20, scans)
+NL = gr.getNrLinks()
+res = {}
+for rnd in range(3):
+    for lanes in ("1", "2", "3", "4", "5", "6", "8"):
+        os.environ["TDTK_LINK_LANES"] = lanes
+        for world in (1, 2, 4, 8):
+            mine = [i for i in range(NL) if gs.link_owners(gr, world, scans)[i] == 0]
+            nl = len(mine)
+            first = (C.c_void_p * nl)(*[scans[gr.getLink(i, 0)].getSearchTree()._h for i in mine])
+            second = (C.c_void_p * nl)(*[scans[gr.getLink(i, 1)].handle for i in mine])
+            dal = np.ascontiguousarray(np.stack([scans[gr.getLink(i, 0)].dalignxf for i in mine]))
+            blocks = np.empty((nl, 42))
+            for rep in range(3):
+                t0 = time.perf_counter()
+                capi.check(L.tdtk_graph_link_blocks(1, nl, first, capi.dptr(dal), second, 625.0, capi.dptr(blocks)))
+                dt = time.perf_counter() - t0
+                res.setdefault((lanes, world), []).append(dt)
+for lanes in ("1", "2", "3", "4", "5", "6", "8"):
+    print("lanes %s: " % lanes + "  ".join("world %d (%2d links) %.2f/%.2f ms" % (w, len(res[(lanes, w)]) and sum(1 for i in range(NL) if gs.link_owners(gr, w, scans)[i] == 0), min(res[(lanes, w)]) * 1e3, float(np.median(res[(lanes, w)])) * 1e3) for w in (1, 2, 4, 8)))
