@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -103,8 +104,11 @@ struct Ctx {
   hipEvent_t e2 = nullptr, e3 = nullptr;   // around the pair-sum kernels behind it (k_accum + k_final, or k_final alone)
   hipEvent_t e4 = nullptr, e5 = nullptr;   // around k_ann_normals of the last calcNormals
   hipEvent_t e_user = nullptr;             // fence between a caller's stream and this context's stream
+  hipEvent_t e_defer = nullptr;            // behind the last batch of scan moves that was left running (defer_fence)
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
+  void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
+  size_t h_stage_cap = 0;
   double last_nn_ms = 0.0, last_sums_ms = 0.0, last_normals_ms = 0.0, last_build_ms = 0.0;
   bool ev_pending = false, ev2_pending = false, ev4_pending = false;
   uint64_t counted_ann_queries = 0;
@@ -115,9 +119,40 @@ struct Ctx {
   std::vector<std::unique_ptr<Lane>> lanes;
   QueueCtr qc;       // for launches on `stream` (a caller's stream gets its launches ordered behind it, see run_search)
   // a context dies with its host thread (worker threads of a prefetch pool come and go): give everything back
-  ~Ctx()
+  ~Ctx();
+};
+
+// Batched scan moves (the pose update of a graph-SLAM round: every resident scan of the rank, ~0.6 ms for 63 x 1M
+// points) are left running when the call returns; whatever the host does next -- Python marshalling, building the
+// next round's graph -- overlaps with them.  The fence is process-wide: the next library call of ANY host thread on
+// that device waits for it in get_ctx before it touches a scan, so "the scans have moved when the call has returned"
+// still holds for everything that can observe them.
+struct Deferred { int device; hipEvent_t ev; Ctx* owner; };
+static std::mutex g_defer_mu;
+static std::atomic<int> g_defer_n{0};
+static std::vector<Deferred> g_defer;
+
+static void wait_deferred(int device, const Ctx* only_owner = nullptr)
+{
+  if (g_defer_n.load(std::memory_order_acquire) == 0) return;
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  for (size_t i = 0; i < g_defer.size();) {
+    if (g_defer[i].device == device && (!only_owner || g_defer[i].owner == only_owner)) {
+      (void)hipEventSynchronize(g_defer[i].ev);
+      g_defer.erase(g_defer.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+  g_defer_n.store((int)g_defer.size(), std::memory_order_release);
+}
+
+Ctx::~Ctx()
   {
     if (device >= 0) (void)hipSetDevice(device);
+    wait_deferred(device, this);
+    if (e_defer) (void)hipEventDestroy(e_defer);
+    if (h_stage) (void)hipHostFree(h_stage);
     lanes.clear();
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
@@ -129,7 +164,6 @@ struct Ctx {
     if (h_pin) (void)hipHostFree(h_pin);
     if (stream) (void)hipStreamDestroy(stream);
   }
-};
 
 static thread_local std::map<int, std::unique_ptr<Ctx>> g_ctx;
 
@@ -154,10 +188,42 @@ static int get_ctx(int device, Ctx** out)
     HIPCHK(hipEventCreate(&c->e4));
     HIPCHK(hipEventCreate(&c->e5));
     HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_defer, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
     it = g_ctx.emplace(device, std::move(c)).first;
   }
   *out = it->second.get();
+  wait_deferred(device);
+  return TDTK_OK;
+}
+
+// leave what has been enqueued on c->stream running (see Deferred); TDTK_SYNC_MOVES=1 waits as before
+static int defer_fence(Ctx* c)
+{
+  static const bool sync_moves = [] { const char* e = getenv("TDTK_SYNC_MOVES"); return e && e[0] == '1'; }();
+  if (sync_moves) { HIPCHK(hipStreamSynchronize(c->stream)); return TDTK_OK; }
+  HIPCHK(hipEventRecord(c->e_defer, c->stream));
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  bool have = false;
+  for (const Deferred& d : g_defer) have = have || d.owner == c;
+  if (!have) g_defer.push_back({c->device, c->e_defer, c});
+  g_defer_n.store((int)g_defer.size(), std::memory_order_release);
+  return TDTK_OK;
+}
+
+// pinned host staging that stays valid until the next library call on this thread (get_ctx has then waited for the
+// copy that reads it)
+static int stage_pinned(Ctx* c, const void* src, size_t bytes, void** out)
+{
+  if (c->h_stage_cap < bytes) {
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_cap = 0;
+    const size_t want = std::max<size_t>(bytes, 64 * 1024);
+    if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
+    c->h_stage_cap = want;
+  }
+  std::memcpy(c->h_stage, src, bytes);
+  *out = c->h_stage;
   return TDTK_OK;
 }
 
@@ -1849,7 +1915,8 @@ int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, 
 {
   if (nlinks < 0 || nscans < 2 || !X || (nlinks && (!from || !to || !C || !CD))) { set_error("bad argument"); return TDTK_EINVAL; }
   const int n = nscans - 1, N = 6 * n;
-  std::vector<double> G((size_t)N * N, 0.0), B((size_t)N, 0.0);
+  thread_local std::vector<double> G, B;   // kept per host thread: no fresh pages every LUM round
+  G.assign((size_t)N * N, 0.0); B.assign((size_t)N, 0.0);
   for (int l = 0; l < nlinks; l++) {
     const int a = from[l] - 1, b = to[l] - 1;
     if (a >= n || b >= n || a < -1 || b < -1) { set_error("link endpoint out of range"); return TDTK_EINVAL; }
@@ -1895,10 +1962,11 @@ int tdtk_scans_transform2(int count, tdtk_scan* const* scans, const double* A1, 
   const size_t bytes = moves.size() * sizeof(Xf2Desc);
   int rc = c->ws[WS_TMPB].ensure(bytes);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, moves.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  void* staged = nullptr;
+  if ((rc = stage_pinned(c, moves.data(), bytes, &staged))) return rc;
+  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, staged, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(launch_transform2_batch(c->ws[WS_TMPB].as<Xf2Desc>(), (int)moves.size(), max_n, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return TDTK_OK;
+  return defer_fence(c);
 }
 
 int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double* dalignxf, double* rPos,
@@ -1968,9 +2036,11 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
     const size_t bytes = moves.size() * sizeof(Xf2Desc);
     int rc = c->ws[WS_TMPB].ensure(bytes);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, moves.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    void* staged = nullptr;
+    if ((rc = stage_pinned(c, moves.data(), bytes, &staged))) return rc;
+    HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, staged, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(launch_transform2_batch(c->ws[WS_TMPB].as<Xf2Desc>(), (int)moves.size(), max_n, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = defer_fence(c))) return rc;
   }
   if (ret) *ret = sum_position_diff / (double)nscans;
   return TDTK_OK;

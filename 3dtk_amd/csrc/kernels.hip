@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
 // (the fp64 roundings of the reference's own a and a*a are 2^-53 relative, eleven orders below these margins).
 // Anything in between -- a band of relative width ~1e-6 -- and anything not finite takes the exact fp64 test on the
 // full record.  Visits therefore stay the reference's node for node (the instrumented instantiations count the same
-// numbers as the oracle), while the common case costs 9 fp32 operations instead of 15 at fp64 rate and the hot
+// numbers as the reference), while the common case costs 9 fp32 operations instead of 15 at fp64 rate and the hot
 // record is 48 bytes instead of 64.
 struct BoxF32 {
   float qx, qy, qz;   // the query in fp32

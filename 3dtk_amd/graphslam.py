@@ -19,6 +19,15 @@ import numpy as np
 from . import slam6d as _s
 
 
+def _link_arrays(gr):
+    """(from, to) of every link as int32 arrays -- straight from the Graph's lists when it is our Graph"""
+    if hasattr(gr, "frm") and hasattr(gr, "to"):
+        return np.array(gr.frm, dtype=np.int32), np.array(gr.to, dtype=np.int32)
+    nl = gr.getNrLinks()
+    return (np.ascontiguousarray([gr.getLink(i, 0) for i in range(nl)], dtype=np.int32),
+            np.ascontiguousarray([gr.getLink(i, 1) for i in range(nl)], dtype=np.int32))
+
+
 def link_owners(gr, world, scans=None):
     """owner[i] = the rank that evaluates link i (tdtk_graph_deal_links).  A link costs one whole-scan pass over its
     second scan.  Scans of equal size: the odometry chain (links 0..n-2, always present) is dealt round-robin and
@@ -29,8 +38,7 @@ def link_owners(gr, world, scans=None):
     import ctypes as C
     from ._capi import lib, check, iptr
     nl, ns = gr.getNrLinks(), gr.getNrScans()
-    frm = np.ascontiguousarray([gr.getLink(i, 0) for i in range(nl)], dtype=np.int32)
-    to = np.ascontiguousarray([gr.getLink(i, 1) for i in range(nl)], dtype=np.int32)
+    frm, to = _link_arrays(gr)
     owner = np.zeros(nl, np.int32)
     pts = None
     if scans is not None:
@@ -273,18 +281,19 @@ def graph_iteration_comm(backend, gr, allScans, max_dist_match2, comm, state=Non
     rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
     nscans, nlinks = gr.getNrScans(), gr.getNrLinks()
     sc = allScans[:nscans]
-    mine = shard_links(gr, rank, world, sc)
-    nl = len(mine)
-    frm = np.ascontiguousarray([gr.getLink(i, 0) for i in range(nlinks)], dtype=np.int32)
-    to = np.ascontiguousarray([gr.getLink(i, 1) for i in range(nlinks)], dtype=np.int32)
-    first = (C.c_void_p * max(1, nl))(*[sc[frm[i]].getSearchTree()._h for i in mine])
-    second = (C.c_void_p * max(1, nl))(*[sc[to[i]].handle for i in mine])
-    dal = np.ascontiguousarray(np.stack([sc[frm[i]].dalignxf for i in mine])) if nl else np.zeros((1, 16))
-    mine_a = np.ascontiguousarray(mine, dtype=np.int32) if nl else np.zeros(1, np.int32)
-    tm = np.ascontiguousarray(np.stack([s.transMat for s in sc]))
-    da = np.ascontiguousarray(np.stack([s.dalignxf for s in sc]))
-    rp = np.ascontiguousarray(np.stack([s.rPos for s in sc]))
-    rt = np.ascontiguousarray(np.stack([s.rPosTheta for s in sc]))
+    frm, to = _link_arrays(gr)
+    mine_a = np.flatnonzero(link_owners(gr, world, sc) == rank).astype(np.int32) if world > 1 else np.arange(nlinks, dtype=np.int32)
+    nl = len(mine_a)
+    fl, tl = frm[mine_a].tolist(), to[mine_a].tolist()
+    first = (C.c_void_p * max(1, nl))(*[sc[a].getSearchTree()._h for a in fl])
+    second = (C.c_void_p * max(1, nl))(*[sc[b].handle for b in tl])
+    tm = np.array([s.transMat for s in sc], dtype=np.float64).reshape(nscans, 16)
+    da = np.array([s.dalignxf for s in sc], dtype=np.float64).reshape(nscans, 16)
+    rp = np.array([s.rPos for s in sc], dtype=np.float64).reshape(nscans, 3)
+    rt = np.array([s.rPosTheta for s in sc], dtype=np.float64).reshape(nscans, 3)
+    dal = np.ascontiguousarray(da[fl]) if nl else np.zeros((1, 16))
+    if not nl:
+        mine_a = np.zeros(1, np.int32)
     hs = (C.c_void_p * nscans)(*[s._h for s in sc])
     xf = np.zeros((nscans, 32))
     ret = C.c_double(0.0)

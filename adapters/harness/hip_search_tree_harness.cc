@@ -4,8 +4,8 @@
 // (src/slam6d/scan.cc:1240, :1138), with a real DataXYZ view over a double[N][3] block.  Compared against the C ABI
 // called directly (tdtk_get_pt_pairs / tdtk_find_closest) and against a brute-force nearest neighbour.
 //
-// Built where a reference checkout exists (adapters/harness/build.sh -> oracle/_ref/hip_search_tree_harness, which
-// travels to the GPU box); run by tests/test_gpu_parity.py::test_reference_side_binding_executes.
+// Built where a reference checkout exists (adapters/harness/build.sh puts the binary with the other build products
+// that contain reference code, outside the history but inside what travels to the GPU box); run by tests/test_gpu_parity.py::test_reference_side_binding_executes.
 //
 // What is NOT the reference here: SearchTree's three out-of-line members live in src/slam6d/searchTree.cc, which
 // includes scan.h -> Boost and so cannot be compiled in this image.  HipSearchTree overrides every one of them; the
