@@ -1788,6 +1788,7 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     Lane* ln = (L > 1) ? c->lanes[i % L].get() : nullptr;
     hipStream_t ls = ln ? ln->s : s;
     SearchArgs sa{};
+    sa.side_by_side = L;
     sa.x = data->x; sa.y = data->y; sa.z = data->z;
     sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
     sa.kpos = ln ? ln->kpos.as<int>() : c->ws[WS_KPOS].as<int>();

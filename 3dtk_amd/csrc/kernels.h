@@ -43,6 +43,7 @@ struct SearchArgs {
   uint32_t* q_ctr_next;  // ... and the 8 of the next launch on the same stream, zeroed by this one
   // fused retire-time accumulation of the base pair sums (k_search_refill<.., FUSE>): fuse != 0, A = Source->dalignxf,
   // shift as in AccumArgs, partials [search_fused_rows(n)][ACC_TOTAL]
+  int side_by_side;  // > 1: one of that many whole-scan passes running concurrently on streams of their own (set by the caller)
   int phases;   // persistent-lane kernel: a wave's slab is handed out in this many pieces (see k_search_refill)
   int fuse;
   Mat4 A;

@@ -1741,7 +1741,11 @@ uint32_t search_grid(size_t n)
 // loads.  Measured on the ICP loop (gpurun_out/r2a, r2b): 1M queries: 128 -> 0.276 ms, 160 -> 0.280, 192 -> 0.258,
 // 224 -> 0.255, 256 -> 0.273, 384 -> 0.341, 512 -> 0.386; 4M queries: 192 -> 0.998, 256 -> 0.965 (best), 384 -> 0.991,
 // 512 -> 1.096.  Rule: 256, unless all waves fit on the chip at once anyway -- then ~4.5 waves per SIMD.
-static int refill_qpw(size_t n)
+// `side_by_side` > 1: the launch is one of several whole-scan passes running on streams of their own (the link passes
+// of a graph-SLAM round).  The chip is then filled by the passes together, and fewer, longer-lived waves per pass win:
+// 84 link passes of 1M queries on 3 streams, slab 224 -> 13.6 ms, 256 -> 13.1, 320 -> 12.7, 384 -> 12.75, 448 -> 12.8,
+// 512 -> 13.0, 640 -> 13.4 (tools/gs_knobs_probe.py) -- ~3 waves per SIMD and pass.
+static int refill_qpw(size_t n, int side_by_side = 1)
 {
   if (const char* e = getenv("TDTK_REFILL_QPW")) {
     int v = atoi(e);
@@ -1750,16 +1754,22 @@ static int refill_qpw(size_t n)
   }
   const size_t resident = (size_t)num_cu() * 4 * 7;
   if ((n + 255) / 256 >= resident) return 256;
+  if (side_by_side > 1) {
+    size_t q = (n / ((size_t)num_cu() * 12) + 16) & ~(size_t)31;           // 3 waves per SIMD
+    if (q < 128) q = 128;
+    if (q > 512) q = 512;
+    return (int)q;
+  }
   size_t q = (n + (size_t)num_cu() * 18 - 1) / ((size_t)num_cu() * 18);   // 4.5 waves per SIMD
   q = (q + 31) & ~(size_t)31;
   if (q < 128) q = 128;
   if (q > 256) q = 256;
   return (int)q;
 }
-static uint32_t refill_grid_b(size_t n, int block, int* qpw_out)
+static uint32_t refill_grid_b(size_t n, int block, int* qpw_out, int side_by_side = 1)
 {
   const size_t wpb = (size_t)block / WAVE;
-  size_t qpw = (size_t)refill_qpw(n);
+  size_t qpw = (size_t)refill_qpw(n, side_by_side);
   size_t waves = (n + qpw - 1) / qpw;
   size_t nb = (waves + wpb - 1) / wpb;
   nb = (nb + 7) & ~(size_t)7;
@@ -1827,14 +1837,15 @@ template <bool COUNT, bool FUSE>
 static void launch_refill128(SearchArgs& a, hipStream_t s)
 {
   int qpw;
-  const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
+  const uint32_t nb = refill_grid_b(a.n, 128, &qpw, a.side_by_side);
   a.qpw = qpw;
   // Two pieces when every wave of the launch is resident at once (the XCD's waves then move through its eighth of the
   // scan together): 1M-vs-1M ICP, L2 misses 1.98 M -> 1.15 M per launch, fabric reads 239 -> 138 MB, time unchanged
   // (0.2190 -> 0.2187 ms); with several generations of waves (4M: 0.806 -> 0.821 ms, reads -35 %) the pieces only
   // cost coherence.  Non-temporal loads / stores for the query and result streams were measured too: no change in
   // misses or time.  (gpurun_out/r2n..r2r, tools/nt_probe.sh)
-  int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7) ? 1 : 2;
+  // Neither do they pay beside other passes (84 link passes on 3 streams: 13.6 -> 13.2 ms without).
+  int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7 || a.side_by_side > 1) ? 1 : 2;
   if (const char* e = getenv("TDTK_REFILL_PHASES")) ph = atoi(e);
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries
