@@ -1868,7 +1868,8 @@ int tdtk_lum_links(int nlinks, const tdtk_tree* const* first, const double* firs
   int rc = get_ctx(first[0]->device, &c);
   if (rc) return rc;
   std::vector<double> acc, shifts;
-  if ((rc = links_device_pass(c, nlinks, first, first_dalignxf, second, maxd2, TDTK_WANT_LUM, acc, shifts))) return rc;
+  // n, sum |delta|^2 and the 15 LUM sums are all a link's block needs
+  if ((rc = links_device_pass(c, nlinks, first, first_dalignxf, second, maxd2, TDTK_WANT_LUM | ACC_WANT_NO_CROSS, acc, shifts))) return rc;
   for (int i = 0; i < nlinks; i++) {
     double* Ci = C + 36 * (size_t)i;
     double* CDi = CD + 6 * (size_t)i;

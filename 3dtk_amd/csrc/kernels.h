@@ -51,6 +51,9 @@ struct SearchArgs {
   double* partials;
 };
 
+// internal bit beside the public TDTK_WANT_* ones: no centroid / cross-covariance columns (see k_accum)
+constexpr unsigned ACC_WANT_NO_CROSS = 0x100u;
+
 // accumulator columns
 enum {
   ACC_N = 0,

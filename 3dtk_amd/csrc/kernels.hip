@@ -1372,6 +1372,9 @@ template <int BLOCK, unsigned WANT, int PMODE>
 __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
 {
   constexpr int NW = BLOCK / WAVE;
+  // ACC_WANT_NO_CROSS: the caller needs n, sum and its own block only (a lum6DEuler link: 17 columns instead of 34 to
+  // accumulate and, what costs more with four pairs per lane, to reduce across the wave)
+  constexpr bool CROSS = !(WANT & ACC_WANT_NO_CROSS);
   __shared__ double red[NW][ACC_TOTAL];
 
   double acc[ACC_TOTAL];
@@ -1424,11 +1427,13 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
     acc[ACC_SUM] += px * px + py * py + pz * pz;
     const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
     const double d0 = tx - a.shift[0], d1 = ty - a.shift[1], d2 = tz - a.shift[2];
-    acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
-    acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
-    acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
-    acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
-    acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+    if (CROSS) {
+      acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
+      acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
+      acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
+      acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
+      acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+    }
     if (WANT & TDTK_WANT_GAPX) {
       acc[ACC_MM + 0] += m0 * m0; acc[ACC_MM + 1] += m0 * m1; acc[ACC_MM + 2] += m0 * m2;
       acc[ACC_MM + 3] += m1 * m1; acc[ACC_MM + 4] += m1 * m2; acc[ACC_MM + 5] += m2 * m2;
@@ -1482,7 +1487,7 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
 #pragma unroll
   for (int k = 0; k < ACC_TOTAL; k++) {
-    const bool used = (k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
+    const bool used = (k < ACC_SM) || (CROSS && k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
                       ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
                       ((WANT & TDTK_WANT_LUM) && ((k >= ACC_L && k < ACC_MM) || k == ACC_LU)) ||
                       ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM && k < ACC_LU);
@@ -1492,7 +1497,7 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
-    const bool used = (k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
+    const bool used = (k < ACC_SM) || (CROSS && k < ACC_DD) || ((WANT & (TDTK_WANT_APX | TDTK_WANT_GAPX)) && k >= ACC_DD && k < ACC_NA) ||
                       ((WANT & TDTK_WANT_NAPX) && k >= ACC_NA && k < ACC_L) ||
                       ((WANT & TDTK_WANT_LUM) && ((k >= ACC_L && k < ACC_MM) || k == ACC_LU)) ||
                       ((WANT & TDTK_WANT_GAPX) && k >= ACC_MM && k < ACC_LU);
@@ -2060,6 +2065,8 @@ hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pm
 {
   if (want & (TDTK_WANT_GAPX | TDTK_WANT_MOM2)) {  // both are the MM + DD columns on top of the base block
     launch_accum_w<TDTK_WANT_GAPX>(a, grid, pmode, s);
+  } else if (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS)) {
+    launch_accum_w<TDTK_WANT_LUM | ACC_WANT_NO_CROSS>(a, grid, pmode, s);
   } else
   switch (want & 7u) {
     case 0: launch_accum_w<0>(a, grid, pmode, s); break;
