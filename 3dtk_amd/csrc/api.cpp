@@ -92,9 +92,10 @@ struct QueueCtr {
 
 struct Lane {
   hipStream_t s = nullptr;
+  bool owns = true;     // lane 0 runs on the context's own stream
   QueueCtr qc;
   DevBuf kpos, part, ovf_m2, ovf_ref;
-  ~Lane() { if (s) (void)hipStreamDestroy(s); }
+  ~Lane() { if (s && owns) (void)hipStreamDestroy(s); }
 };
 
 struct Ctx {
@@ -1755,15 +1756,21 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
   }
   int max_lanes = 8, forced = 0;
   if (const char* e = getenv("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));
-  // small scans: a pass is latency-bound, 8 side by side; big scans: 3, so the thin tail of one search and the
-  // small sum kernels overlap with the next search (84 links of 1M: 1 lane 16.8 ms, 2: 13.9, 3: 13.3, 4: 14.3,
-  // 6: 13.4, 8: 13.7 -- the same order for the 44 / 22 / 11 links of a 2 / 4 / 8-rank share; tools/gs_lanes_probe.py)
-  const int L = (nlinks > 1) ? std::min(nlinks, forced ? forced : std::min(max_lanes, maxN <= (size_t)262144 ? 8 : 3)) : 1;
+  // small scans: a pass is latency-bound, 4 side by side (32 x 60K points, 41 links: 1 lane 2.35 ms, 2: 1.52, 3: 1.30,
+  // 4: 1.11, 6: 1.26, 8: 1.19); big scans: 3, so the thin tail of one search and the small sum kernels overlap with
+  // the next search (84 links of 1M: 1 lane 16.3 ms, 2: 13.0, 3: 12.2; more lanes than hardware queues lose, see
+  // below; tools/gs_lanes_probe.py, tools/small_graph_probe.py)
+  const int L = (nlinks > 1) ? std::min(nlinks, forced ? forced : std::min(max_lanes, maxN <= (size_t)262144 ? 4 : 3)) : 1;
   HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
   if (L > 1) {
+    // The runtime multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES): streams beyond that share a queue
+    // and their kernels no longer overlap -- with the null stream in use and three lanes BESIDE the context's stream,
+    // 84 link passes took 15.9 ms instead of 13.2 (and four lanes lost to three in every probe).  Lane 0 is therefore
+    // the context's own stream: three lanes + the null stream = four queues.
     while ((int)c->lanes.size() < L) {
       std::unique_ptr<Lane> ln(new Lane);
-      HIPCHK(hipStreamCreateWithFlags(&ln->s, hipStreamNonBlocking));
+      if (c->lanes.empty()) { ln->s = s; ln->owns = false; }
+      else HIPCHK(hipStreamCreateWithFlags(&ln->s, hipStreamNonBlocking));
       c->lanes.push_back(std::move(ln));
     }
     HIPCHK(hipStreamSynchronize(s));   // d_out is zeroed before any lane writes into it
