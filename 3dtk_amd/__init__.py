@@ -10,6 +10,14 @@ gfx950 device is present, the compute entry points raise.
 The directory name starts with a digit, so import it with
 ``importlib.import_module("3dtk_amd")`` (tests/conftest.py and bench.py do).
 """
+import os as _os
+
+# The batched link passes of graph-SLAM run on three HIP streams; the runtime maps all streams of a process onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue do not overlap.  A host that has streams
+# of its own (PyTorch, RCCL) needs more queues; the variable is read when the HIP runtime initialises, so this only
+# takes effect if the package is imported before the first GPU call (INTEGRATION.md, "Streams and hardware queues").
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from ._capi import (TdtkError, lib, build_extension, device_count, version, PairSums,  # noqa: F401
                     ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX, CLOSEST_POINT,
                     CLOSEST_POINT_ALONG_NORMAL_SIMPLE, CLOSEST_PLANE_SIMPLE,

@@ -198,6 +198,17 @@ static int get_ctx(int device, Ctx** out)
   return TDTK_OK;
 }
 
+namespace tdtk {
+int ctx_stream(int device, void** stream_out)
+{
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  *stream_out = c->stream;
+  return TDTK_OK;
+}
+}  // namespace tdtk
+
 // leave what has been enqueued on c->stream running (see Deferred); TDTK_SYNC_MOVES=1 waits as before
 static int defer_fence(Ctx* c)
 {

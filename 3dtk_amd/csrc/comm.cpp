@@ -67,7 +67,8 @@ int nccl_fail(const char* what, ncclResult_t r)
 struct tdtk_comm {
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
-  hipStream_t stream = nullptr;
+  // no stream of its own: the collective runs on the calling thread's context stream (the runtime has four hardware
+  // queues for all streams of the process, and the link passes want three of them -- see links_device_pass)
   double* d_buf = nullptr;
   size_t cap = 0;
   double* h_pin = nullptr;   // pinned staging: the copies around the collective are asynchronous on `stream`
@@ -106,12 +107,6 @@ int tdtk_comm_create(const char id[TDTK_COMM_ID_BYTES], int rank, int world, int
   std::memcpy(&u, id, sizeof u);
   ncclResult_t r = g_rccl.commInitRank(&c->comm, world, u, rank);
   if (r != ncclSuccess) { delete c; return nccl_fail("ncclCommInitRank", r); }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    g_rccl.commDestroy(c->comm);
-    delete c;
-    set_error("hipStreamCreate failed");
-    return TDTK_EDEVICE;
-  }
   *out = c;
   return TDTK_OK;
 }
@@ -120,11 +115,10 @@ void tdtk_comm_destroy(tdtk_comm* c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipDeviceSynchronize();
   if (c->comm && g_rccl.commDestroy) g_rccl.commDestroy(c->comm);
   if (c->d_buf) (void)hipFree(c->d_buf);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -158,13 +152,20 @@ int tdtk_graph_exchange(tdtk_comm* c, double* blocks, size_t n)
     if (hipHostMalloc((void**)&c->h_pin, want * sizeof(double), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
     c->h_cap = want;
   }
+  hipStream_t stream = nullptr;
+  {
+    void* sp = nullptr;
+    int rc = ctx_stream(c->device, &sp);
+    if (rc) return rc;
+    stream = static_cast<hipStream_t>(sp);
+  }
   std::memcpy(c->h_pin, blocks, n * sizeof(double));
-  if (hipMemcpyAsync(c->d_buf, c->h_pin, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("H2D failed"); return TDTK_EDEVICE; }
-  ncclResult_t r = g_rccl.allReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream);
+  if (hipMemcpyAsync(c->d_buf, c->h_pin, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) { set_error("H2D failed"); return TDTK_EDEVICE; }
+  ncclResult_t r = g_rccl.allReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, stream);
   if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
   c->n_allreduce++;
-  if (hipMemcpyAsync(c->h_pin, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { set_error("D2H failed"); return TDTK_EDEVICE; }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) { set_error("stream sync failed after the all-reduce"); return TDTK_EDEVICE; }
+  if (hipMemcpyAsync(c->h_pin, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) { set_error("D2H failed"); return TDTK_EDEVICE; }
+  if (hipStreamSynchronize(stream) != hipSuccess) { set_error("stream sync failed after the all-reduce"); return TDTK_EDEVICE; }
   std::memcpy(blocks, c->h_pin, n * sizeof(double));
   return TDTK_OK;
 }

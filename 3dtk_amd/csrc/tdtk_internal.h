@@ -86,6 +86,8 @@ int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], doubl
                     std::string& err);
 bool invert_dense(int n, const double* A, double* Ainv);  // LU with partial pivoting
 bool solve_spd_dense(int n, const double* G, const double* B, double* x, double drop);
+// the calling host thread's context stream on `device` (a hipStream_t; api.cpp), for library code outside api.cpp
+int ctx_stream(int device, void** stream_out);
 
 void helix_compute_rt(const double ccs[6], double* alignxf);                 // icp6Dhelix.cc:144-206
 void matrix4_to_quat_t(const double* mat, double quat[4], double t[3]);       // globals.icc:1032-1075

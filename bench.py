@@ -32,6 +32,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that
+# share a queue do not overlap.  The graph-SLAM link passes run on three streams, and PyTorch's process group + RCCL
+# bring streams of their own: with 4 queues a LUM iteration of configs[3] takes 15.9 ms, with 8 it takes 13.3 (measured
+# under torch.distributed.run).  Read when the runtime initialises, so it is set before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
