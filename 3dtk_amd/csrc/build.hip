@@ -17,6 +17,7 @@
 //     ALL nodes of the level at once.
 //
 // One small D2H (the number of internal nodes of the level) per level is the only host sync.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -65,7 +66,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // the chain) and the vector ALU issues nothing but the dependent v_add_f64 chain.
 __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
                                                  const double* __restrict__ cx, const double* __restrict__ cy,
-                                                 const double* __restrict__ cz, BMeas* __restrict__ out)
+                                                 const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
 {
   __shared__ double stage[256 / WAVE][2][MEAS_STAGE * WAVE];
   // wave-uniform by construction; readfirstlane tells the compiler so
@@ -75,6 +76,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
   const uint32_t sgi = w / 3u, ax = w % 3u;
   const uint32_t s = __builtin_amdgcn_readfirstlane(segs[sgi].start);
   const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
+  if (n >= big_min) return;   // measured by the piecewise path below (k_big_*)
   const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + s;
   double(*buf)[MEAS_STAGE * WAVE] = stage[threadIdx.x / WAVE];
 
@@ -150,6 +152,270 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
     t = __shfl_xor(lo, off, WAVE); lo = (t < lo) ? t : lo;
     t = __shfl_xor(hi, off, WAVE); hi = (hi < t) ? t : hi;
   }
+  if (lane == 0) {
+    out[sgi].lo[ax] = lo;
+    out[sgi].hi[ax] = hi;
+    out[sgi].mean[ax] = sum / (double)n;
+  }
+}
+
+
+// ---- big nodes: the same left-to-right fp64 sum, without walking it one add at a time --------------------------
+// The reference's centroid is s <- fl(s + x_i) over the node's points in run order: a million roundings at the root,
+// each depending on the one before.  While the running sum stays inside one binade [2^e, 2^(e+1)) every rounding is
+// to a multiple of the same u = 2^(e-52), and with s = M u (M an integer, 2^52 <= M < 2^53) one add is integer
+// arithmetic: x / u = k + rem / 2^d exactly (d = e - exponent(x) bits shifted out of x's mantissa), and
+//     M <- M + k + [rem > half]          rem != half
+//     M <- the even one of M + k, M + k + 1     rem == half (round-half-even: it depends on the parity of M)
+// (mirrored for x of the other sign).  So a PIECE of the node's run -- the part of it inside one 256-aligned block of
+// positions -- acts on M as "add T", as long as M stays strictly between 2^52 and 2^53 on the way, and T, the lowest and
+// the highest offset reached can be computed for every piece of every big node at once, one lane per piece, for both
+// parities of the incoming M, before the incoming M is known: all that has to be guessed is the binade, and a plain
+// parallel prefix sum of the pieces is accurate enough for that.  What is left of the chain is one cheap step per
+// piece (is the sum in the predicted binade, does the offset range fit, add T) -- and the honest chain of adds for the
+// pieces where it is not so: 0.5-3 % of them on the bench's clouds, the pieces in which the sum changes binade or sign.
+// Bit for bit the reference's sum by construction; tdtk_tree_verify compares every node record with the host build.
+#define BIG_CH 256u
+#define BIG_MIN 8192u          // nodes from this many points on take this path (below, the chain costs < 40 us)
+struct BPiece {
+  uint32_t start, len;         // positions [start, start + len) of the run; len == 0: no piece in this slot
+  uint32_t ebits, flags;       // biased exponent of the predicted running sum; bit 0: it is negative, bit 1: walk it
+  double lo, hi, csum, pre;    // bounding values, plain sum of the piece, plain sum of everything before it
+  long long T[2], mn[2], mx[2];   // by parity of the incoming M: total offset, lowest / highest offset on the way
+};
+// slot of a piece: block q of positions holds at most the tail of one big node (it starts at the block's first
+// position: slot 2q) and the head of the next (it starts inside the block, behind that node's first point: slot 2q+1)
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (t < v) ? t : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (v < t) ? t : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_add(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+// one wave per (block of 256 positions, axis): the pieces of that block, their bounding values and plain sums
+__global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
+                                                   const double* __restrict__ cx, const double* __restrict__ cy,
+                                                   const double* __restrict__ cz, uint32_t M, uint32_t nblocks,
+                                                   BPiece* __restrict__ pieces)
+{
+  const uint32_t q = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  const uint32_t ax = blockIdx.y;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (q >= nblocks) return;
+  const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
+  const uint32_t base = q * BIG_CH;
+  const uint32_t bend = (base + BIG_CH < M) ? base + BIG_CH : M;
+  // the node at the block's first position: a tail piece if it is big and started earlier
+  uint32_t t_start = 0, t_end = 0;
+  {
+    const uint32_t sid = seg_of[base];
+    if (sid != 0xFFFFFFFFu) {
+      const BSeg sg = segs[sid];
+      if (sg.n >= BIG_MIN && sg.start < base) { t_start = base; t_end = (sg.start + sg.n < bend) ? sg.start + sg.n : bend; }
+    }
+  }
+  // a big node whose first point lies in this block: a head piece behind that point
+  uint32_t h_start = 0, h_end = 0;
+  {
+    uint32_t found = 0xFFFFFFFFu, fend = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < BIG_CH / WAVE; k++) {
+      const uint32_t p = base + k * WAVE + lane;
+      if (p < bend) {
+        const uint32_t sid = seg_of[p];
+        if (sid != 0xFFFFFFFFu && (p == 0 || seg_of[p - 1] != sid)) {
+          const BSeg sg = segs[sid];
+          if (sg.start == p && sg.n >= BIG_MIN) { found = p; fend = sg.start + sg.n; }
+        }
+      }
+    }
+    const unsigned long long any = __ballot(found != 0xFFFFFFFFu);
+    if (any) {
+      const int src = __ffsll((long long)any) - 1;
+      const uint32_t p = __shfl(found, src, WAVE), e = __shfl(fend, src, WAVE);
+      h_start = p + 1; h_end = (e < bend) ? e : bend;
+      if (h_start >= h_end) { h_start = h_end = 0; }
+    }
+  }
+  double tlo = 1.0 / 0.0, thi = -1.0 / 0.0, tsum = 0.0, hlo = 1.0 / 0.0, hhi = -1.0 / 0.0, hsum = 0.0;
+#pragma unroll
+  for (uint32_t k = 0; k < BIG_CH / WAVE; k++) {
+    const uint32_t p = base + k * WAVE + lane;
+    if (p < bend) {
+      const double v = arr[p];
+      if (p >= t_start && p < t_end) { tlo = (v < tlo) ? v : tlo; thi = (thi < v) ? v : thi; tsum += v; }
+      if (p >= h_start && p < h_end) { hlo = (v < hlo) ? v : hlo; hhi = (hhi < v) ? v : hhi; hsum += v; }
+    }
+  }
+  BPiece* pt = pieces + ((size_t)ax * nblocks + q) * 2;
+  if (t_end > t_start) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
+  if (h_end > h_start) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
+  if (lane == 0) {
+    pt[0].start = t_start; pt[0].len = t_end - t_start; pt[0].lo = tlo; pt[0].hi = thi; pt[0].csum = tsum;
+    pt[1].start = h_start; pt[1].len = h_end - h_start; pt[1].lo = hlo; pt[1].hi = hhi; pt[1].csum = hsum;
+  }
+}
+
+// the pieces of node (start a, n points) in run order: the first one is a head piece unless a + 1 is block-aligned
+__device__ __forceinline__ uint32_t big_piece_slot(uint32_t a, uint32_t i)
+{
+  const uint32_t q0 = (a + 1u) / BIG_CH;
+  const bool head = ((a + 1u) % BIG_CH) != 0u;
+  return (i == 0 && head) ? 2u * q0 + 1u : 2u * (q0 + i);
+}
+__device__ __forceinline__ uint32_t big_piece_count(uint32_t a, uint32_t n) { return (a + n - 1u) / BIG_CH - (a + 1u) / BIG_CH + 1u; }
+
+// one wave per (node, axis): plain running sum in front of every piece -- the binade the exact sum will be in there
+__global__ void __launch_bounds__(256) k_big_prefix(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                    const double* __restrict__ cx, const double* __restrict__ cy,
+                                                    const double* __restrict__ cz, uint32_t nblocks,
+                                                    BPiece* __restrict__ pieces)
+{
+  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (w >= 3u * lv->nseg) return;
+  const uint32_t sgi = w / 3u, ax = w % 3u;
+  const uint32_t a = __builtin_amdgcn_readfirstlane(segs[sgi].start), n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
+  if (n < BIG_MIN) return;
+  const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
+  BPiece* pa = pieces + (size_t)ax * nblocks * 2;
+  const uint32_t np = big_piece_count(a, n);
+  double carry = arr[a];
+  for (uint32_t i0 = 0; i0 < np; i0 += WAVE) {
+    const uint32_t i = i0 + lane;
+    double v = 0.0;
+    uint32_t slot = 0;
+    if (i < np) { slot = big_piece_slot(a, i); v = pa[slot].csum; }
+    double inc = v;   // inclusive scan over the lanes
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const double t = __shfl_up(inc, off, WAVE);
+      if ((int)lane >= off) inc += t;
+    }
+    if (i < np) pa[slot].pre = carry + (inc - v);
+    carry += __shfl(inc, WAVE - 1, WAVE);
+  }
+}
+
+// one lane per piece: what the piece does to the integer mantissa of the running sum, for both parities of it
+__global__ void __launch_bounds__(64) k_big_emulate(const double* __restrict__ cx, const double* __restrict__ cy,
+                                                    const double* __restrict__ cz, uint32_t nblocks,
+                                                    BPiece* __restrict__ pieces)
+{
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ax = blockIdx.y;
+  if (id >= 2u * nblocks) return;
+  BPiece* pc = pieces + (size_t)ax * nblocks * 2 + id;
+  const uint32_t len = pc->len;
+  if (len == 0) return;
+  const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + pc->start;
+  const unsigned long long pb = (unsigned long long)__double_as_longlong(pc->pre);
+  const uint32_t ebits = (uint32_t)((pb >> 52) & 0x7FFu);
+  const unsigned long long flip = pb & 0x8000000000000000ull;   // work on |s|: s + x = -(|s| + (-x)), rounding is symmetric
+  uint32_t flags = flip ? 1u : 0u;
+  if (ebits == 0u || ebits == 0x7FFu) flags |= 2u;
+  long long S0 = 0, S1 = 0, mn0 = 0, mn1 = 0, mx0 = 0, mx1 = 0;
+  for (uint32_t i = 0; i < len && !(flags & 2u); i++) {
+    const unsigned long long yb = (unsigned long long)__double_as_longlong(arr[i]) ^ flip;
+    const bool neg = (yb >> 63) != 0;
+    uint32_t ey = (uint32_t)((yb >> 52) & 0x7FFu);
+    unsigned long long m = yb & 0x000FFFFFFFFFFFFFull;
+    if (ey) m |= 0x0010000000000000ull; else ey = 1u;          // subnormal: no hidden bit, exponent of the smallest normal
+    const int d = (int)ebits - (int)ey;
+    if (d <= 0) { flags |= 2u; break; }                         // |x| >= 2^e: the sum leaves the binade (or x is not finite)
+    if (d > 63) continue;                                       // x < u / 2^10: nothing
+    const unsigned long long k = m >> d, rem = m & ((1ull << d) - 1ull), half = 1ull << (d - 1);
+    const long long ks = neg ? -(long long)k : (long long)k, one = neg ? -1ll : 1ll;
+    S0 += ks; S1 += ks;
+    if (rem > half) { S0 += one; S1 += one; }
+    else if (rem == half) {                                     // tie: to the even mantissa
+      if (S0 & 1ll) S0 += one;                                  // incoming M even
+      if (!(S1 & 1ll)) S1 += one;                               // incoming M odd
+    }
+    mn0 = (S0 < mn0) ? S0 : mn0; mx0 = (S0 > mx0) ? S0 : mx0;
+    mn1 = (S1 < mn1) ? S1 : mn1; mx1 = (S1 > mx1) ? S1 : mx1;
+  }
+  pc->ebits = ebits; pc->flags = flags;
+  pc->T[0] = S0; pc->T[1] = S1; pc->mn[0] = mn0; pc->mn[1] = mn1; pc->mx[0] = mx0; pc->mx[1] = mx1;
+}
+
+// one wave per (node, axis): the chain, one step per piece; pieces that do not fit are walked add by add
+__global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                    const double* __restrict__ cx, const double* __restrict__ cy,
+                                                    const double* __restrict__ cz, uint32_t nblocks,
+                                                    const BPiece* __restrict__ pieces, BMeas* __restrict__ out)
+{
+  __shared__ double walk[256 / WAVE][BIG_CH];
+  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (w >= 3u * lv->nseg) return;
+  const uint32_t sgi = w / 3u, ax = w % 3u;
+  const uint32_t a = __builtin_amdgcn_readfirstlane(segs[sgi].start), n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
+  if (n < BIG_MIN) return;
+  const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
+  const BPiece* pa = pieces + (size_t)ax * nblocks * 2;
+  double* wbuf = walk[threadIdx.x / WAVE];
+  const uint32_t np = big_piece_count(a, n);
+  const double first = arr[a];
+  double sum = first, lo = first, hi = first;
+  const unsigned long long ONE = 0x0010000000000000ull;
+  for (uint32_t i0 = 0; i0 < np; i0 += WAVE) {
+    const uint32_t cnt = (np - i0 < WAVE) ? np - i0 : WAVE;
+    // every lane fetches one piece record; the chain below reads them lane by lane (wave-uniform index)
+    BPiece mine;
+    mine.len = 0;
+    if (lane < cnt) {
+      mine = pa[big_piece_slot(a, i0 + lane)];
+      lo = (mine.lo < lo) ? mine.lo : lo;
+      hi = (hi < mine.hi) ? mine.hi : hi;
+    }
+    for (uint32_t j = 0; j < cnt; j++) {
+      const uint32_t p_start = __shfl(mine.start, j, WAVE), p_len = __shfl(mine.len, j, WAVE);
+      const uint32_t p_e = __shfl(mine.ebits, j, WAVE), p_f = __shfl(mine.flags, j, WAVE);
+      const unsigned long long sb = (unsigned long long)__double_as_longlong(sum);
+      bool ok = !(p_f & 2u) && (uint32_t)((sb >> 52) & 0x7FFu) == p_e && (uint32_t)(sb >> 63) == (p_f & 1u);
+      unsigned long long Mi = (sb & (ONE - 1ull)) | ONE;
+      if (ok) {
+        const bool odd = (Mi & 1ull) != 0;
+        const long long T = __shfl(odd ? mine.T[1] : mine.T[0], j, WAVE), mn = __shfl(odd ? mine.mn[1] : mine.mn[0], j, WAVE),
+                        mx = __shfl(odd ? mine.mx[1] : mine.mx[0], j, WAVE);
+        ok = ((long long)Mi + mn > (long long)ONE) && ((long long)Mi + mx < (long long)(ONE << 1));
+        if (ok) {
+          Mi = (unsigned long long)((long long)Mi + T);
+          sum = __longlong_as_double((long long)((sb & 0xFFF0000000000000ull) | (Mi & (ONE - 1ull))));
+        }
+      }
+      if (!ok) {   // the sum changes binade or sign inside this piece (or the guess was off): the reference's own adds
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t k = 0; k < BIG_CH / WAVE; k++) {
+          const uint32_t o = k * WAVE + lane;
+          if (o < p_len) wbuf[o] = arr[p_start + o];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t k = 0;
+        for (; k + 16 <= p_len; k += 16) {
+          double r[16];
+#pragma unroll
+          for (int t = 0; t < 16; t++) r[t] = wbuf[k + t];
+#pragma unroll
+          for (int t = 0; t < 16; t++) sum += r[t];
+        }
+        for (; k < p_len; k++) sum += wbuf[k];
+      }
+    }
+  }
+  lo = wave_min(lo); hi = wave_max(hi);
   if (lane == 0) {
     out[sgi].lo[ax] = lo;
     out[sgi].hi[ax] = hi;
@@ -455,6 +721,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     uint32_t *kind = (uint32_t*)(arena + o_kind), *axis = (uint32_t*)(arena + o_axis), *irank = (uint32_t*)(arena + o_irank);
     double* splitval = (double*)(arena + o_split);
     void* tmp = arena + o_tmp;
+    BPiece* pieces = (BPiece*)(arena + O[24]);
+    const uint32_t nblocks = cdiv(M, BIG_CH);
+    static const bool piecewise = [] { const char* e = getenv("TDTK_BUILD_PIECEWISE"); return e && e[0] == '1'; }();
+    const bool use_big = piecewise && M >= BIG_MIN;
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
     BCHK(hipMemsetAsync(small, 0, 256, s));
     BCHK(hipMemsetAsync(lvl, 0, sizeof(BLevel) * (BUILD_MAX_LEVELS + 2), s));
@@ -477,7 +747,20 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         if (bound > M) bound = M;
         if (bound < 1) bound = 1;
         const BLevel* lv = lvl + level;
-        hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas);
+        // nodes of BIG_MIN points and more can only exist while a quarter of a balanced node is that large (below that
+        // level the chain in k_measure takes them, whatever their size)
+        const bool big_level = use_big && ((M_ >> level) >= BIG_MIN / 4);
+        hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
+                           big_level ? BIG_MIN : 0xFFFFFFFFu);
+        if (big_level) {
+          hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE), 3), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
+                             nblocks, pieces);
+          hipLaunchKernelGGL(k_big_prefix, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
+                             pieces);
+          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(2 * (size_t)nblocks, 64), 3), dim3(64), 0, s, cx, cy, cz, nblocks, pieces);
+          hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
+                             pieces, meas);
+        }
         hipLaunchKernelGGL(k_decide, dim3(cdiv(bound + 1, 256)), dim3(256), 0, s, segs, lv, (uint32_t)bound, meas,
                            (uint32_t)bucket, kind, axis, splitval, nleft);
         size_t st = scan_tmp;
@@ -578,6 +861,7 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(scan_tmp + 256); take(256);                                          // tmp small
   take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // nodes node_r leaf_tab
   take(sizeof(BLevel) * (BUILD_MAX_LEVELS + 2));                            // 23 per-level counters
+  take(sizeof(BPiece) * 6 * (M / BIG_CH + 2));                              // 24 pieces of big nodes: 3 axes x 2 per block
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
