@@ -165,26 +165,72 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
 // each depending on the one before.  While the running sum stays inside one binade [2^e, 2^(e+1)) every rounding is
 // to a multiple of the same u = 2^(e-52), and with s = M u (M an integer, 2^52 <= M < 2^53) one add is integer
 // arithmetic: x / u = k + rem / 2^d exactly (d = e - exponent(x) bits shifted out of x's mantissa), and
-//     M <- M + k + [rem > half]          rem != half
-//     M <- the even one of M + k, M + k + 1     rem == half (round-half-even: it depends on the parity of M)
-// (mirrored for x of the other sign).  So a PIECE of the node's run -- the part of it inside one 256-aligned block of
-// positions -- acts on M as "add T", as long as M stays strictly between 2^52 and 2^53 on the way, and T, the lowest and
-// the highest offset reached can be computed for every piece of every big node at once, one lane per piece, for both
-// parities of the incoming M, before the incoming M is known: all that has to be guessed is the binade, and a plain
-// parallel prefix sum of the pieces is accurate enough for that.  What is left of the chain is one cheap step per
-// piece (is the sum in the predicted binade, does the offset range fit, add T) -- and the honest chain of adds for the
-// pieces where it is not so: 0.5-3 % of them on the bench's clouds, the pieces in which the sum changes binade or sign.
-// Bit for bit the reference's sum by construction; tdtk_tree_verify compares every node record with the host build.
-#define BIG_CH 256u
+//     M <- M + k + [rem > half]                       rem != half
+//     M <- the even one of M + k, M + k + 1           rem == half (round-half-even: it depends on the parity of M)
+// (mirrored for x of the other sign).  So a PIECE of the node's run -- the part of it inside one 64-aligned block of
+// positions -- acts on M as "add T", as long as M stays strictly between 2^52 and 2^53 on the way; T and the lowest
+// and highest offset reached are computed for every piece of every big node at once, one lane per piece, for both
+// parities of the incoming M, before that M is known: all that has to be guessed is the binade, and a plain parallel
+// prefix sum is accurate enough for that.  Pieces whose offsets fit with room to spare compose -- (T, lowest,
+// highest, by parity) is a monoid -- so a segmented scan folds every run of such pieces into one step; the pieces in
+// which the sum changes binade or sign (3-8 % on the bench's clouds, whose Morton-ordered zero-mean coordinates keep
+// the sum wandering through zero) are walked add by add.  What is left of the chain is one wave per (node, axis)
+// visiting those pieces: apply the folded run before it (checked EXACTLY against the real M: exponent, sign, room),
+// walk its 64 points.  A run that does not fit after all is redone piece by piece.  Bit for bit the reference's sum
+// by construction; tdtk_tree_verify compares every node record with the host build (tools/bigsum_probe.py).
+#define BIG_CH 64u
 #define BIG_MIN 8192u          // nodes from this many points on take this path (below, the chain costs < 40 us)
+#define BIG_ANY 0xFFFFu        // BSum.eb of the neutral element
+#define BIG_BAD 0xFFFEu        // BSum.eb of a run whose pieces disagree about the binade: never applicable
 struct BPiece {
   uint32_t start, len;         // positions [start, start + len) of the run; len == 0: no piece in this slot
-  uint32_t ebits, flags;       // biased exponent of the predicted running sum; bit 0: it is negative, bit 1: walk it
+  uint32_t ebits, flags;       // biased exponent of the predicted running sum; flags: 1 = it is negative, 2 = cannot be
+                               // summarised, 4 = first piece of its node, 8 = walk it (includes 2)
   double lo, hi, csum, pre;    // bounding values, plain sum of the piece, plain sum of everything before it
-  long long T[2], mn[2], mx[2];   // by parity of the incoming M: total offset, lowest / highest offset on the way
 };
-// slot of a piece: block q of positions holds at most the tail of one big node (it starts at the block's first
-// position: slot 2q) and the head of the next (it starts inside the block, behind that node's first point: slot 2q+1)
+struct BSum {                  // what a piece (or a run of pieces) does to M, by parity of the incoming M
+  long long T0, T1, mn0, mn1, mx0, mx1;   // (scalar fields: indexing an array by the parity sends the struct to scratch)
+  uint32_t eb, reset;          // exponent bits | sign << 11 it assumes; reset: nothing before it counts
+};
+__device__ __forceinline__ void bsum_neutral(BSum& r) { r.T0 = r.T1 = r.mn0 = r.mn1 = r.mx0 = r.mx1 = 0; r.eb = 0xFFFFu; r.reset = 0u; }
+struct BPre { double v; uint32_t reset, pad; };
+struct BPreOp {
+  __device__ BPre operator()(const BPre& a, const BPre& b) const
+  {
+    if (b.reset) return b;
+    BPre r; r.v = a.v + b.v; r.reset = a.reset; r.pad = 0u;
+    return r;
+  }
+};
+struct BSumOp {
+  __device__ BSum operator()(const BSum& a, const BSum& b) const
+  {
+    if (b.reset) return b;
+    if (b.eb == BIG_ANY) return a;
+    BSum r;
+    if (a.eb == BIG_ANY) { r = b; r.reset = a.reset; return r; }
+    const bool bad = a.eb != b.eb || a.eb == BIG_BAD;
+    {   // incoming M even
+      const bool pa = (a.T0 & 1ll) != 0;
+      const long long bt = pa ? b.T1 : b.T0, bmn = pa ? b.mn1 : b.mn0, bmx = pa ? b.mx1 : b.mx0;
+      r.T0 = a.T0 + bt;
+      const long long lo = a.T0 + bmn, hi = a.T0 + bmx;
+      r.mn0 = (lo < a.mn0) ? lo : a.mn0;
+      r.mx0 = (hi > a.mx0) ? hi : a.mx0;
+    }
+    {   // incoming M odd
+      const bool pa = ((1ll + a.T1) & 1ll) != 0;
+      const long long bt = pa ? b.T1 : b.T0, bmn = pa ? b.mn1 : b.mn0, bmx = pa ? b.mx1 : b.mx0;
+      r.T1 = a.T1 + bt;
+      const long long lo = a.T1 + bmn, hi = a.T1 + bmx;
+      r.mn1 = (lo < a.mn1) ? lo : a.mn1;
+      r.mx1 = (hi > a.mx1) ? hi : a.mx1;
+    }
+    r.eb = bad ? BIG_BAD : a.eb;
+    r.reset = a.reset;
+    return r;
+  }
+};
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (t < v) ? t : v; }
@@ -200,72 +246,9 @@ __device__ __forceinline__ double wave_add(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
   return v;
 }
-
-// one wave per (block of 256 positions, axis): the pieces of that block, their bounding values and plain sums
-__global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
-                                                   const double* __restrict__ cx, const double* __restrict__ cy,
-                                                   const double* __restrict__ cz, uint32_t M, uint32_t nblocks,
-                                                   BPiece* __restrict__ pieces)
-{
-  const uint32_t q = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
-  const uint32_t ax = blockIdx.y;
-  const uint32_t lane = threadIdx.x & (WAVE - 1);
-  if (q >= nblocks) return;
-  const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
-  const uint32_t base = q * BIG_CH;
-  const uint32_t bend = (base + BIG_CH < M) ? base + BIG_CH : M;
-  // the node at the block's first position: a tail piece if it is big and started earlier
-  uint32_t t_start = 0, t_end = 0;
-  {
-    const uint32_t sid = seg_of[base];
-    if (sid != 0xFFFFFFFFu) {
-      const BSeg sg = segs[sid];
-      if (sg.n >= BIG_MIN && sg.start < base) { t_start = base; t_end = (sg.start + sg.n < bend) ? sg.start + sg.n : bend; }
-    }
-  }
-  // a big node whose first point lies in this block: a head piece behind that point
-  uint32_t h_start = 0, h_end = 0;
-  {
-    uint32_t found = 0xFFFFFFFFu, fend = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < BIG_CH / WAVE; k++) {
-      const uint32_t p = base + k * WAVE + lane;
-      if (p < bend) {
-        const uint32_t sid = seg_of[p];
-        if (sid != 0xFFFFFFFFu && (p == 0 || seg_of[p - 1] != sid)) {
-          const BSeg sg = segs[sid];
-          if (sg.start == p && sg.n >= BIG_MIN) { found = p; fend = sg.start + sg.n; }
-        }
-      }
-    }
-    const unsigned long long any = __ballot(found != 0xFFFFFFFFu);
-    if (any) {
-      const int src = __ffsll((long long)any) - 1;
-      const uint32_t p = __shfl(found, src, WAVE), e = __shfl(fend, src, WAVE);
-      h_start = p + 1; h_end = (e < bend) ? e : bend;
-      if (h_start >= h_end) { h_start = h_end = 0; }
-    }
-  }
-  double tlo = 1.0 / 0.0, thi = -1.0 / 0.0, tsum = 0.0, hlo = 1.0 / 0.0, hhi = -1.0 / 0.0, hsum = 0.0;
-#pragma unroll
-  for (uint32_t k = 0; k < BIG_CH / WAVE; k++) {
-    const uint32_t p = base + k * WAVE + lane;
-    if (p < bend) {
-      const double v = arr[p];
-      if (p >= t_start && p < t_end) { tlo = (v < tlo) ? v : tlo; thi = (thi < v) ? v : thi; tsum += v; }
-      if (p >= h_start && p < h_end) { hlo = (v < hlo) ? v : hlo; hhi = (hhi < v) ? v : hhi; hsum += v; }
-    }
-  }
-  BPiece* pt = pieces + ((size_t)ax * nblocks + q) * 2;
-  if (t_end > t_start) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
-  if (h_end > h_start) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
-  if (lane == 0) {
-    pt[0].start = t_start; pt[0].len = t_end - t_start; pt[0].lo = tlo; pt[0].hi = thi; pt[0].csum = tsum;
-    pt[1].start = h_start; pt[1].len = h_end - h_start; pt[1].lo = hlo; pt[1].hi = hhi; pt[1].csum = hsum;
-  }
-}
-
-// the pieces of node (start a, n points) in run order: the first one is a head piece unless a + 1 is block-aligned
+// slot of a piece: block q of positions holds at most the tail of one big node (it starts at the block's first
+// position: slot 2q) and the head of the next (it starts inside the block, behind that node's first point: slot 2q+1).
+// The pieces of node (start a, n points) in run order: the first one is a head piece unless a + 1 is block-aligned.
 __device__ __forceinline__ uint32_t big_piece_slot(uint32_t a, uint32_t i)
 {
   const uint32_t q0 = (a + 1u) / BIG_CH;
@@ -274,57 +257,95 @@ __device__ __forceinline__ uint32_t big_piece_slot(uint32_t a, uint32_t i)
 }
 __device__ __forceinline__ uint32_t big_piece_count(uint32_t a, uint32_t n) { return (a + n - 1u) / BIG_CH - (a + 1u) / BIG_CH + 1u; }
 
-// one wave per (node, axis): plain running sum in front of every piece -- the binade the exact sum will be in there
-__global__ void __launch_bounds__(256) k_big_prefix(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
-                                                    const double* __restrict__ cx, const double* __restrict__ cy,
-                                                    const double* __restrict__ cz, uint32_t nblocks,
-                                                    BPiece* __restrict__ pieces)
+// one wave per (block of 64 positions, axis): the pieces of that block, their bounding values and plain sums
+__global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
+                                                   const double* __restrict__ cx, const double* __restrict__ cy,
+                                                   const double* __restrict__ cz, uint32_t M, uint32_t nblocks,
+                                                   BPiece* __restrict__ pieces, BPre* __restrict__ prein)
 {
-  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t q = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  const uint32_t ax = blockIdx.y;
   const uint32_t lane = threadIdx.x & (WAVE - 1);
-  if (w >= 3u * lv->nseg) return;
-  const uint32_t sgi = w / 3u, ax = w % 3u;
-  const uint32_t a = __builtin_amdgcn_readfirstlane(segs[sgi].start), n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
-  if (n < BIG_MIN) return;
+  if (q >= nblocks) return;
   const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
-  BPiece* pa = pieces + (size_t)ax * nblocks * 2;
-  const uint32_t np = big_piece_count(a, n);
-  double carry = arr[a];
-  for (uint32_t i0 = 0; i0 < np; i0 += WAVE) {
-    const uint32_t i = i0 + lane;
-    double v = 0.0;
-    uint32_t slot = 0;
-    if (i < np) { slot = big_piece_slot(a, i); v = pa[slot].csum; }
-    double inc = v;   // inclusive scan over the lanes
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-      const double t = __shfl_up(inc, off, WAVE);
-      if ((int)lane >= off) inc += t;
+  const uint32_t base = q * BIG_CH;
+  const uint32_t bend = (base + BIG_CH < M) ? base + BIG_CH : M;
+  const uint32_t p = base + lane;
+  // the node at the block's first position: a tail piece if it is big and started earlier
+  uint32_t t_start = 0, t_end = 0, t_first = 0xFFFFFFFFu;
+  {
+    const uint32_t sid = seg_of[base];
+    if (sid != 0xFFFFFFFFu) {
+      const BSeg sg = segs[sid];
+      if (sg.n >= BIG_MIN && sg.start < base) {
+        t_start = base; t_end = (sg.start + sg.n < bend) ? sg.start + sg.n : bend;
+        if (sg.start + 1u == base) t_first = sg.start;
+      }
     }
-    if (i < np) pa[slot].pre = carry + (inc - v);
-    carry += __shfl(inc, WAVE - 1, WAVE);
+  }
+  // a big node whose first point lies in this block: a head piece behind that point
+  uint32_t h_start = 0, h_end = 0, h_first = 0;
+  {
+    uint32_t found = 0xFFFFFFFFu, fend = 0;
+    if (p < bend) {
+      const uint32_t sid = seg_of[p];
+      if (sid != 0xFFFFFFFFu && (p == 0 || seg_of[p - 1] != sid)) {
+        const BSeg sg = segs[sid];
+        if (sg.start == p && sg.n >= BIG_MIN) { found = p; fend = sg.start + sg.n; }
+      }
+    }
+    const unsigned long long any = __ballot(found != 0xFFFFFFFFu);
+    if (any) {
+      const int src = __ffsll((long long)any) - 1;
+      const uint32_t fp = __shfl(found, src, WAVE), e = __shfl(fend, src, WAVE);
+      h_first = fp; h_start = fp + 1; h_end = (e < bend) ? e : bend;
+      if (h_start >= h_end) { h_start = h_end = 0; }
+    }
+  }
+  double tlo = 1.0 / 0.0, thi = -1.0 / 0.0, tsum = 0.0, hlo = 1.0 / 0.0, hhi = -1.0 / 0.0, hsum = 0.0;
+  if (p < bend) {
+    const double v = arr[p];
+    if (p >= t_start && p < t_end) { tlo = v; thi = v; tsum = v; }
+    if (p >= h_start && p < h_end) { hlo = v; hhi = v; hsum = v; }
+  }
+  const size_t o = ((size_t)ax * nblocks + q) * 2;
+  if (t_end > t_start) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
+  if (h_end > h_start) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
+  if (lane == 0) {
+    BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = 0; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
+    BPre tp; tp.v = t.len ? tsum : 0.0; tp.reset = 0u; tp.pad = 0u;
+    if (t.len && t_first != 0xFFFFFFFFu) { t.flags = 4u; t.pre = arr[t_first]; tp.v += t.pre; tp.reset = 1u; }
+    pieces[o] = t; prein[o] = tp;
+    BPiece h; h.start = h_start; h.len = h_end - h_start; h.ebits = 0; h.flags = 0; h.lo = hlo; h.hi = hhi; h.csum = hsum; h.pre = 0.0;
+    BPre hp; hp.v = 0.0; hp.reset = 0u; hp.pad = 0u;
+    if (h.len) { h.flags = 4u; h.pre = arr[h_first]; hp.v = hsum + h.pre; hp.reset = 1u; }
+    pieces[o + 1] = h; prein[o + 1] = hp;
   }
 }
 
 // one lane per piece: what the piece does to the integer mantissa of the running sum, for both parities of it
 __global__ void __launch_bounds__(64) k_big_emulate(const double* __restrict__ cx, const double* __restrict__ cy,
                                                     const double* __restrict__ cz, uint32_t nblocks,
-                                                    BPiece* __restrict__ pieces)
+                                                    BPiece* __restrict__ pieces, const BPre* __restrict__ preout,
+                                                    BSum* __restrict__ own, int dbg)
 {
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ax = blockIdx.y;
   if (id >= 2u * nblocks) return;
-  BPiece* pc = pieces + (size_t)ax * nblocks * 2 + id;
-  const uint32_t len = pc->len;
-  if (len == 0) return;
-  const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + pc->start;
-  const unsigned long long pb = (unsigned long long)__double_as_longlong(pc->pre);
+  const size_t o = (size_t)ax * nblocks * 2 + id;
+  BPiece pc = pieces[o];
+  BSum r;
+  bsum_neutral(r);
+  if (pc.len == 0) { own[o] = r; return; }
+  const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + pc.start;
+  const double pre = (pc.flags & 4u) ? pc.pre : (preout[o].v - pc.csum);
+  const unsigned long long pb = (unsigned long long)__double_as_longlong(pre);
   const uint32_t ebits = (uint32_t)((pb >> 52) & 0x7FFu);
   const unsigned long long flip = pb & 0x8000000000000000ull;   // work on |s|: s + x = -(|s| + (-x)), rounding is symmetric
-  uint32_t flags = flip ? 1u : 0u;
+  uint32_t flags = (pc.flags & 4u) | (flip ? 1u : 0u);
   if (ebits == 0u || ebits == 0x7FFu) flags |= 2u;
   long long S0 = 0, S1 = 0, mn0 = 0, mn1 = 0, mx0 = 0, mx1 = 0;
-  for (uint32_t i = 0; i < len && !(flags & 2u); i++) {
+  for (uint32_t i = 0; i < pc.len && !(flags & 2u); i++) {
     const unsigned long long yb = (unsigned long long)__double_as_longlong(arr[i]) ^ flip;
     const bool neg = (yb >> 63) != 0;
     uint32_t ey = (uint32_t)((yb >> 52) & 0x7FFu);
@@ -344,17 +365,50 @@ __global__ void __launch_bounds__(64) k_big_emulate(const double* __restrict__ c
     mn0 = (S0 < mn0) ? S0 : mn0; mx0 = (S0 > mx0) ? S0 : mx0;
     mn1 = (S1 < mn1) ? S1 : mn1; mx1 = (S1 > mx1) ? S1 : mx1;
   }
-  pc->ebits = ebits; pc->flags = flags;
-  pc->T[0] = S0; pc->T[1] = S1; pc->mn[0] = mn0; pc->mn[1] = mn1; pc->mx[0] = mx0; pc->mx[1] = mx1;
+  // does it fit with room to spare for the true M (the predicted one is good to a few ulps of the largest partial sum;
+  // 2^32 mantissa units are nine orders more than that)?  If not, the chain walks this piece.
+  if (!(flags & 2u)) {
+    const long long ONE = 0x0010000000000000ll, room = 1ll << 32;
+    const long long Mi = (long long)((pb & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull);
+    const long long mn = (mn0 < mn1) ? mn0 : mn1, mx = (mx0 > mx1) ? mx0 : mx1;
+    if (!(Mi + mn > ONE + room && Mi + mx < 2 * ONE - room)) flags |= 8u;
+  } else flags |= 8u;
+  if ((dbg & 3) == 2) flags |= 8u;
+  pc.ebits = ebits; pc.flags = flags;
+  pieces[o] = pc;
+  if (flags & 8u) { r.reset = 1u; own[o] = r; return; }        // a walked piece: nothing before it composes past it
+  r.T0 = S0; r.T1 = S1; r.mn0 = mn0; r.mn1 = mn1; r.mx0 = mx0; r.mx1 = mx1;
+  r.eb = ebits | ((flags & 1u) << 11); r.reset = (flags & 4u) ? 1u : 0u;
+  own[o] = r;
 }
 
-// one wave per (node, axis): the chain, one step per piece; pieces that do not fit are walked add by add
+// apply a summary to the running sum if it provably describes what the adds would do; false: it does not
+__device__ __forceinline__ bool big_apply(double& sum, long long T0, long long T1, long long mn0, long long mn1, long long mx0,
+                                          long long mx1, uint32_t eb)
+{
+  if (eb == BIG_ANY) return true;
+  const unsigned long long ONE = 0x0010000000000000ull;
+  const unsigned long long sb = (unsigned long long)__double_as_longlong(sum);
+  if ((uint32_t)(sb >> 52) != eb) return false;                // exponent and sign in one compare (eb = ebits | sign << 11)
+  const long long Mi = (long long)((sb & (ONE - 1ull)) | ONE);
+  const bool odd = (Mi & 1ll) != 0;
+  const long long T = odd ? T1 : T0, mn = odd ? mn1 : mn0, mx = odd ? mx1 : mx0;
+  if (!(Mi + mn > (long long)ONE && Mi + mx < (long long)(ONE << 1))) return false;
+  sum = __longlong_as_double((long long)((sb & 0xFFF0000000000000ull) | ((unsigned long long)(Mi + T) & (ONE - 1ull))));
+  return true;
+}
+__device__ __forceinline__ bool big_apply(double& sum, const BSum S) { return big_apply(sum, S.T0, S.T1, S.mn0, S.mn1, S.mx0, S.mx1, S.eb); }
+
+// one wave per (node, axis): the chain.  Clusters of walked pieces are visited one by one; everything between two of
+// them is one step.
+#define BIG_CL 4               // walked pieces folded into one LDS stage (they are consecutive in memory)
 __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
                                                     const double* __restrict__ cx, const double* __restrict__ cy,
                                                     const double* __restrict__ cz, uint32_t nblocks,
-                                                    const BPiece* __restrict__ pieces, BMeas* __restrict__ out)
+                                                    const BPiece* __restrict__ pieces, const BSum* __restrict__ own,
+                                                    const BSum* __restrict__ comp, BMeas* __restrict__ out, int dbg)
 {
-  __shared__ double walk[256 / WAVE][BIG_CH];
+  __shared__ double walk[256 / WAVE][BIG_CH * BIG_CL];
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (w >= 3u * lv->nseg) return;
@@ -362,58 +416,134 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
   const uint32_t a = __builtin_amdgcn_readfirstlane(segs[sgi].start), n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
   if (n < BIG_MIN) return;
   const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
-  const BPiece* pa = pieces + (size_t)ax * nblocks * 2;
+  const size_t ao = (size_t)ax * nblocks * 2;
+  const BPiece* pa = pieces + ao;
+  const BSum* oa = own + ao;
+  const BSum* ca = comp + ao;
   double* wbuf = walk[threadIdx.x / WAVE];
   const uint32_t np = big_piece_count(a, n);
   const double first = arr[a];
   double sum = first, lo = first, hi = first;
-  const unsigned long long ONE = 0x0010000000000000ull;
+  int done = -1;                                   // pieces 0 .. done are in `sum`
+
+  // the adds of `cnt` values parked in LDS, in order
+  auto chain = [&](uint32_t cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((cnt & 31u) == 0u && cnt) {
+      // 16 values requested ahead of the 16 being added.  Plain C++: the inline-asm read / wait pairs of k_measure are
+      // not safe here -- with 220 live registers the compiler copies the destination registers of a read between the
+      // two asm statements, i.e. possibly before the data has arrived (seen as one wrong addend per node, only when
+      // eight builds ran at once and LDS latency went up).
+      const double* __restrict__ b = wbuf;
+      double rA[16], rB[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) rA[t] = b[t];
+      for (uint32_t k = 0; k < cnt; k += 32) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) rB[t] = b[k + 16 + t];
+#pragma unroll
+        for (int t = 0; t < 16; t++) sum += rA[t];
+        const uint32_t kn = (k + 32 < cnt) ? k + 32 : 0u;   // the last request re-reads the head of the buffer: unused
+#pragma unroll
+        for (int t = 0; t < 16; t++) rA[t] = b[kn + t];
+#pragma unroll
+        for (int t = 0; t < 16; t++) sum += rB[t];
+      }
+    } else {
+      uint32_t k = 0;
+      for (; k + 16 <= cnt; k += 16) {
+        double r[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) r[t] = wbuf[k + t];
+#pragma unroll
+        for (int t = 0; t < 16; t++) sum += r[t];
+      }
+      for (; k < cnt; k++) sum += wbuf[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // pieces lo_i .. hi_i (none of them marked for walking), folded into S; redone piece by piece if S does not fit
+  // the real sum after all
+  auto apply_run = [&](int lo_i, int hi_i, const BSum S) {
+    if ((dbg & 3) != 1 && big_apply(sum, S)) return;
+    for (int i = lo_i; i <= hi_i; i++) {
+      const uint32_t slot = big_piece_slot(a, (uint32_t)i);
+      const BSum O = oa[slot];
+      if (big_apply(sum, O)) continue;
+      const uint32_t st = pa[slot].start, ln = pa[slot].len;
+      wbuf[lane] = (lane < ln) ? arr[st + lane] : 0.0;
+      chain(ln);
+    }
+  };
+
+  // the records of a batch of 64 pieces -- the piece and the folded run in front of it -- are requested one batch ahead
+  BPiece pcN; BSum RN;
+  auto load_batch = [&](uint32_t i) {
+    pcN.len = 0; pcN.flags = 0; pcN.start = 0; pcN.lo = first; pcN.hi = first;
+    bsum_neutral(RN);
+    if (i < np) { const uint32_t sl = big_piece_slot(a, i); pcN = pa[sl]; RN = ca[sl]; }
+  };
+  load_batch(lane);
   for (uint32_t i0 = 0; i0 < np; i0 += WAVE) {
-    const uint32_t cnt = (np - i0 < WAVE) ? np - i0 : WAVE;
-    // every lane fetches one piece record; the chain below reads them lane by lane (wave-uniform index)
-    BPiece mine;
-    mine.len = 0;
-    if (lane < cnt) {
-      mine = pa[big_piece_slot(a, i0 + lane)];
-      lo = (mine.lo < lo) ? mine.lo : lo;
-      hi = (hi < mine.hi) ? mine.hi : hi;
-    }
-    for (uint32_t j = 0; j < cnt; j++) {
-      const uint32_t p_start = __shfl(mine.start, j, WAVE), p_len = __shfl(mine.len, j, WAVE);
-      const uint32_t p_e = __shfl(mine.ebits, j, WAVE), p_f = __shfl(mine.flags, j, WAVE);
-      const unsigned long long sb = (unsigned long long)__double_as_longlong(sum);
-      bool ok = !(p_f & 2u) && (uint32_t)((sb >> 52) & 0x7FFu) == p_e && (uint32_t)(sb >> 63) == (p_f & 1u);
-      unsigned long long Mi = (sb & (ONE - 1ull)) | ONE;
-      if (ok) {
-        const bool odd = (Mi & 1ull) != 0;
-        const long long T = __shfl(odd ? mine.T[1] : mine.T[0], j, WAVE), mn = __shfl(odd ? mine.mn[1] : mine.mn[0], j, WAVE),
-                        mx = __shfl(odd ? mine.mx[1] : mine.mx[0], j, WAVE);
-        ok = ((long long)Mi + mn > (long long)ONE) && ((long long)Mi + mx < (long long)(ONE << 1));
-        if (ok) {
-          Mi = (unsigned long long)((long long)Mi + T);
-          sum = __longlong_as_double((long long)((sb & 0xFFF0000000000000ull) | (Mi & (ONE - 1ull))));
-        }
+    const uint32_t i = i0 + lane;
+    const uint32_t p_start = pcN.start, p_len = pcN.len, p_flags = pcN.flags;
+    const BSum R = RN;
+    lo = (pcN.lo < lo) ? pcN.lo : lo;
+    hi = (hi < pcN.hi) ? pcN.hi : hi;
+    load_batch(i + WAVE);
+    unsigned long long fm = __ballot(i < np && (p_flags & 8u));
+    const unsigned long long fullm = __ballot(p_len == BIG_CH);
+    // clusters: up to BIG_CL consecutive walked pieces, all of them full (a partial piece -- the first or the last of
+    // the node -- goes alone); the points of the next cluster are requested before the current one is walked
+    struct Cl { int j, c; uint32_t cnt; double v[BIG_CL]; };
+    // always BIG_CL loads, in straight-line code (a load that is not needed reads the node's first point): the compiler
+    // can then count the loads in flight and wait for the oldest cluster only -- behind a branch it waits for all of them
+    auto fetch_cluster = [&]() -> Cl {
+      Cl q;
+      const bool any = fm != 0ull;
+      q.j = any ? __ffsll((long long)fm) - 1 : 0;
+      const unsigned long long run = fm >> q.j, fr = fullm >> q.j;
+      const unsigned long long gap = ~(run & fr);
+      int c = gap ? __ffsll((long long)gap) - 1 : 64;      // leading walked AND full pieces
+      if (c > BIG_CL) c = BIG_CL;
+      const uint32_t st = __shfl(p_start, q.j, WAVE), ln = __shfl(p_len, q.j, WAVE);
+      q.cnt = (uint32_t)c * BIG_CH;
+      if (c == 0) { c = 1; q.cnt = ln; }
+      if (!any) { c = 0; q.cnt = 0; }
+      q.c = c;
+      fm &= ~(((1ull << c) - 1ull) << q.j);
+#pragma unroll
+      for (int k = 0; k < BIG_CL; k++) {
+        const uint32_t off = (uint32_t)k * BIG_CH + lane;
+        q.v[k] = arr[(off < q.cnt) ? st + off : a];
       }
-      if (!ok) {   // the sum changes binade or sign inside this piece (or the guess was off): the reference's own adds
-        __builtin_amdgcn_wave_barrier();
+      return q;
+    };
+    // three clusters in flight: a lone wave needs ~2 us for a round trip to memory and ~1 us to walk a cluster
+    Cl q0 = fetch_cluster(), q1 = fetch_cluster(), q2 = fetch_cluster();
+    while (q0.c) {
+      const Cl cur = q0;
+      q0 = q1; q1 = q2; q2 = fetch_cluster();
+      const int j = cur.j, c = cur.c;
+      // the run in front of piece i0 + j: fetched by lane j
+      BSum S;
+      S.T0 = __shfl(R.T0, j, WAVE); S.T1 = __shfl(R.T1, j, WAVE);
+      S.mn0 = __shfl(R.mn0, j, WAVE); S.mn1 = __shfl(R.mn1, j, WAVE);
+      S.mx0 = __shfl(R.mx0, j, WAVE); S.mx1 = __shfl(R.mx1, j, WAVE);
+      S.eb = __shfl(R.eb, j, WAVE); S.reset = 0u;
+      const int idx = (int)i0 + j;
+      if (idx - 1 > done) apply_run(done + 1, idx - 1, S);
 #pragma unroll
-        for (uint32_t k = 0; k < BIG_CH / WAVE; k++) {
-          const uint32_t o = k * WAVE + lane;
-          if (o < p_len) wbuf[o] = arr[p_start + o];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t k = 0;
-        for (; k + 16 <= p_len; k += 16) {
-          double r[16];
-#pragma unroll
-          for (int t = 0; t < 16; t++) r[t] = wbuf[k + t];
-#pragma unroll
-          for (int t = 0; t < 16; t++) sum += r[t];
-        }
-        for (; k < p_len; k++) sum += wbuf[k];
-      }
+      for (int k = 0; k < BIG_CL; k++)
+        if (k < c) wbuf[k * BIG_CH + lane] = cur.v[k];
+      chain(cur.cnt);
+      done = idx + c - 1;
     }
+  }
+  if ((int)np - 1 > done) {
+    const uint32_t sl = big_piece_slot(a, np - 1u);
+    apply_run(done + 1, (int)np - 1, BSumOp()(ca[sl], oa[sl]));
   }
   lo = wave_min(lo); hi = wave_max(hi);
   if (lane == 0) {
@@ -421,6 +551,17 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
     out[sgi].hi[ax] = hi;
     out[sgi].mean[ax] = sum / (double)n;
   }
+}
+
+__global__ void k_big_dbg_compare(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, const BMeas* __restrict__ a,
+                                  const BMeas* __restrict__ b, uint32_t level)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lv->nseg || segs[i].n < BIG_MIN) return;
+  for (int ax = 0; ax < 3; ax++)
+    if (a[i].mean[ax] != b[i].mean[ax] || a[i].lo[ax] != b[i].lo[ax] || a[i].hi[ax] != b[i].hi[ax])
+      printf("MISMATCH level %u seg %u (start %u n %u) ax %d: mean %.17g vs chain %.17g  lo %g/%g hi %g/%g\n", level, i, segs[i].start,
+             segs[i].n, ax, a[i].mean[ax], b[i].mean[ax], a[i].lo[ax], b[i].lo[ax], a[i].hi[ax], b[i].hi[ax]);
 }
 
 // ---- per node: leaf or internal, split axis / value (kdTreeImpl.h:113-170) ----------------------
@@ -722,9 +863,14 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     double* splitval = (double*)(arena + o_split);
     void* tmp = arena + o_tmp;
     BPiece* pieces = (BPiece*)(arena + O[24]);
+    BPre *prein = (BPre*)(arena + O[25]), *preout = (BPre*)(arena + O[26]);
+    BSum *own = (BSum*)(arena + O[27]), *comp = (BSum*)(arena + O[28]);
     const uint32_t nblocks = cdiv(M, BIG_CH);
-    static const bool piecewise = [] { const char* e = getenv("TDTK_BUILD_PIECEWISE"); return e && e[0] == '1'; }();
-    const bool use_big = piecewise && M >= BIG_MIN;
+    static const bool chain_only = [] { const char* e = getenv("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
+    const bool use_big = !chain_only && M >= BIG_MIN;
+    const int big_dbg_all = getenv("TDTK_BIG_DEBUG") ? atoi(getenv("TDTK_BIG_DEBUG")) : 0;
+    const int big_dbg = big_dbg_all & 3;   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
+    if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
     BCHK(hipMemsetAsync(small, 0, 256, s));
     BCHK(hipMemsetAsync(lvl, 0, sizeof(BLevel) * (BUILD_MAX_LEVELS + 2), s));
@@ -753,13 +899,24 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
                            big_level ? BIG_MIN : 0xFFFFFFFFu);
         if (big_level) {
+          const size_t nsl = (size_t)nblocks * 2 * 3;
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE), 3), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
-                             nblocks, pieces);
-          hipLaunchKernelGGL(k_big_prefix, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
-                             pieces);
-          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(2 * (size_t)nblocks, 64), 3), dim3(64), 0, s, cx, cy, cz, nblocks, pieces);
+                             nblocks, pieces, prein);
+          size_t stb = scan_tmp;
+          BCHK(rocprim::inclusive_scan(tmp, stb, prein, preout, nsl, BPreOp(), s));
+          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(2 * (size_t)nblocks, 64), 3), dim3(64), 0, s, cx, cy, cz, nblocks, pieces,
+                             preout, own, big_dbg);
+          stb = scan_tmp;
+          BSum ident;   // exclusive: comp[slot] = everything since the last reset BEFORE the slot = the run in front of it
+          ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u;
+          BCHK(rocprim::exclusive_scan(tmp, stb, own, comp, ident, nsl, BSumOp(), s));
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
-                             pieces, meas);
+                             pieces, own, comp, meas, big_dbg);
+          if (big_dbg_all & 8) {
+            BMeas* meas2 = (BMeas*)(arena + O[29]);
+            hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas2, 0xFFFFFFFFu);
+            hipLaunchKernelGGL(k_big_dbg_compare, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, meas, meas2, level);
+          }
         }
         hipLaunchKernelGGL(k_decide, dim3(cdiv(bound + 1, 256)), dim3(256), 0, s, segs, lv, (uint32_t)bound, meas,
                            (uint32_t)bucket, kind, axis, splitval, nleft);
@@ -848,6 +1005,13 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
     size_t t8 = 0;
     (void)rocprim::exclusive_scan(nullptr, t8, z8, z8, 0ull, M + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
     if (t8 > scan_tmp) scan_tmp = t8;
+    const size_t nsl = 6 * (M / BIG_CH + 2);
+    BPre* zp = nullptr; size_t tp = 0;
+    (void)rocprim::inclusive_scan(nullptr, tp, zp, zp, nsl, BPreOp(), (hipStream_t)0);
+    if (tp > scan_tmp) scan_tmp = tp;
+    BSum* zs = nullptr; size_t ts = 0;
+    (void)rocprim::exclusive_scan(nullptr, ts, zs, zs, BSum(), nsl, BSumOp(), (hipStream_t)0);
+    if (ts > scan_tmp) scan_tmp = ts;
   }
   const size_t n1 = M + 1;
   size_t off = 0;
@@ -861,7 +1025,11 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(scan_tmp + 256); take(256);                                          // tmp small
   take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // nodes node_r leaf_tab
   take(sizeof(BLevel) * (BUILD_MAX_LEVELS + 2));                            // 23 per-level counters
-  take(sizeof(BPiece) * 6 * (M / BIG_CH + 2));                              // 24 pieces of big nodes: 3 axes x 2 per block
+  const size_t nsl = 6 * (M / BIG_CH + 2);                                  // pieces of big nodes: 3 axes x 2 per block
+  take(sizeof(BPiece) * nsl);                                               // 24
+  take(sizeof(BPre) * nsl); take(sizeof(BPre) * nsl);                       // 25 26 plain prefix in / out
+  take(sizeof(BSum) * nsl); take(sizeof(BSum) * nsl);                       // 27 28 piece summaries, folded runs
+  if (getenv("TDTK_BIG_DEBUG") && (atoi(getenv("TDTK_BIG_DEBUG")) & 8)) take(sizeof(BMeas) * n1);   // 29 debug: the chain's results
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
