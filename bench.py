@@ -371,6 +371,15 @@ def bench_icp(args, rank, world, local):
     tp0 = time.perf_counter(); s2_ = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local); _ = s2_.handle
     prep["scan_create_ms"] = (time.perf_counter() - tp0) * 1e3
     del t2_, s2_
+    # the model scan's own tree again, now that the process is warm (the first build of a process also pays for the
+    # scratch arena, the code objects and rocPRIM's first use: reported as first_build_ms)
+    warm = []
+    for _ in range(3):
+        s3_ = tdtk.Scan([0, 0, 0], [0, 0, 0], m, device=local)
+        warm.append(s3_.getSearchTree().info()["build_ms"])
+        del s3_
+    first_build_ms = info["build_ms"]
+    info = dict(info, build_ms=min(warm))
 
     out = {
         "metric": "NN correspondences/sec (1M-vs-1M pairwise ICP, full iteration)",
@@ -392,12 +401,12 @@ def bench_icp(args, rank, world, local):
     # the bytes its levels move: every level streams the 24-B points + 8 B of permutation / keys in and out
     levels = info["max_depth"]
     tb_bytes = float(levels) * n * 64.0
-    out["tree_build_1gpu"] = {"ms": info["build_ms"], "points": n, "levels": levels,
+    out["tree_build_1gpu"] = {"ms": info["build_ms"], "first_build_ms": first_build_ms, "points": n, "levels": levels,
                               "roofline": {"bound": "hbm", "kernel": "k_measure + partition passes (device tree build)",
                                            "achieved": tb_bytes / (info["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": tb_bytes / (info["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "traffic": None,
-                                           "note": "bounded by the dependent fp64 add chain of the centroid (bit-exact "
+                                           "note": "bounded by what is left of the dependent fp64 add chain of the centroid (bit-exact "
                                                    "split values), not by bytes: DESIGN.md section 4"}}
     if rank == 0 and not args.no_cpu:
         gi, _ = tree.FindClosestBatch(cur[:20000], 625.0)
