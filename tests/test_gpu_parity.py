@@ -534,6 +534,82 @@ def test_device_tree_build_full_size(tdtk, gpu, k5):
     assert tdtk.KDtree(big, 20).verify() == [0, 0, 0, 0]
 
 
+def _stress_clouds(n, seed=12):
+    """clouds chosen to break the piecewise centroid sum of the device tree build (build.hip, k_big_*): exact rounding
+    ties, sums that wander through zero, huge dynamic range, values at both ends of the exponent range"""
+    rng = np.random.default_rng(seed)
+    return {
+        "zero-mean": rng.uniform(-1000, 1000, (n, 3)),
+        "one-sided": rng.uniform(0, 2000, (n, 3)),
+        "integers": rng.integers(-500, 501, (n, 3)).astype(float),
+        "half-integers": rng.integers(-2000, 2001, (n, 3)) * 0.5,
+        "dyadic": rng.integers(-1 << 20, 1 << 20, (n, 3)) * (2.0 ** -7),
+        "wide-range": rng.uniform(-1, 1, (n, 3)) * 10.0 ** rng.uniform(-6, 6, (n, 1)),
+        "tiny": rng.uniform(-1, 1, (n, 3)) * 1e-300,
+        "huge": rng.uniform(-1, 1, (n, 3)) * 1e300,
+        "repeated": np.repeat(rng.uniform(-100, 100, (n // 50, 3)), 50, axis=0),
+        "back-to-zero": np.concatenate([rng.uniform(0, 1000, (n // 2, 3)), -rng.uniform(0, 1000, (n // 2, 3))])[rng.permutation(n // 2 * 2)],
+        "alternating": np.where((np.arange(n) % 2 == 0)[:, None], 1e8, -1e8) + rng.uniform(-1, 1, (n, 3)),
+    }
+
+
+@pytest.mark.parametrize("mode", ["", "1", "2"])
+def test_device_tree_build_piecewise_sum(tdtk, gpu, monkeypatch, mode):
+    """Nodes of 8192 points and more get their left-to-right centroid sum piecewise (integer mantissa offsets per
+    64-point piece, runs folded by a scan, exact walk where the sum changes binade).  The tree must stay the host
+    builder's, record for record -- also when no folded run is trusted (mode 1) and when every piece is walked (2)."""
+    if mode:
+        monkeypatch.setenv("TDTK_BIG_DEBUG", mode)
+    for name, pts in _stress_clouds(70000).items():
+        for bucket in (20, 3):
+            kd = tdtk.KDtree(np.ascontiguousarray(pts), bucket)
+            assert kd.verify() == [0, 0, 0, 0], (name, bucket, mode)
+    # Morton-ordered input (what a resident scan hands to the builder): partial sums return to zero at every scale
+    s = tdtk.Scan([0, 0, 0], [0, 0, 0], _stress_clouds(300000, seed=5)["zero-mean"])
+    assert s.getSearchTree().verify() == [0, 0, 0, 0]
+
+
+def test_device_tree_build_from_eight_threads(tdtk, gpu):
+    """Eight host threads building trees of big scans at once (prepare_scans): every tree still the host builder's.
+    (The first version of the piecewise sum lost an addend here: inline-asm LDS reads whose destination registers the
+    compiler had moved before the data arrived.)"""
+    rng = np.random.default_rng(8)
+    scans = [tdtk.Scan([0, 0, 0], [0, 0, 0], rng.uniform(-1500, 1500, (400000, 3))) for _ in range(16)]
+    tdtk.prepare_scans(scans, trees=True, threads=8)
+    assert [s.getSearchTree().verify() for s in scans] == [[0, 0, 0, 0]] * 16
+
+
+def test_batched_scan_moves_are_visible_to_every_thread(tdtk, orc, gpu):
+    """tdtk_scans_transform2 returns before the device has moved the scans; the next library call of ANY host thread
+    on the device must wait for the move first."""
+    import threading
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    pts = [rng.uniform(-100, 100, (200000, 3)) for _ in range(6)]
+    scans = [tdtk.Scan([0, 0, 0], [0, 0, 0], p) for p in pts]
+    for s in scans:
+        _ = s.handle
+    A = [tdtk.EulerToMatrix4(rng.uniform(-5, 5, 3), rng.uniform(-0.2, 0.2, 3)) for _ in scans]
+    hs = (C.c_void_p * len(scans))(*[s._h for s in scans])
+    A1 = np.ascontiguousarray(np.stack(A))
+    from importlib import import_module
+    capi = import_module("3dtk_amd._capi")
+    capi.check(capi.lib().tdtk_scans_transform2(len(scans), hs, capi.dptr(A1), None))
+    got = [None] * len(scans)
+
+    def fetch(k):
+        out = np.empty((len(pts[k]), 3))
+        capi.check(capi.lib().tdtk_scan_download(scans[k]._h, capi.dptr(out), None))
+        got[k] = out
+    th = [threading.Thread(target=fetch, args=(k,)) for k in range(len(scans))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(len(scans)):
+        want = pts[k].copy()
+        orc.transform_points(A[k], want)
+        assert np.array_equal(got[k], want), k
+
+
 def test_tree_edge_cases(tdtk, orc, gpu):
     """One point, two points, all-identical points (one degenerate bucket larger than the bucket size),
     non-finite coordinates (the reference would recurse on an empty side; we return an error)."""

@@ -643,6 +643,63 @@ def test_lum_assemble_solve_matches_dense_fill(tdtk):
                                                       capi.dptr(CDall), nscans, capi.dptr(X), None, None))
 
 
+def test_spd_solve_skyline_storage_shapes(tdtk):
+    """solveSparseCholesky's stand-in factors in skyline storage (every row from its first entry above the 1e-5 filter
+    to the diagonal).  Shapes that stress the bookkeeping: a chain of 6x6 blocks with far loop closures (envelope
+    rows of very different length), a dense matrix, a diagonal one, 1x1, entries at and below the filter threshold in
+    front of a row, two calls of different size from one thread (buffers are kept per thread), several threads."""
+    import threading
+    capi = sys.modules["3dtk_amd._capi"]
+    rng = np.random.default_rng(41)
+
+    def solve(G, B):
+        x = np.empty(len(B))
+        capi.check(capi.lib().tdtk_solve_spd(capi.dptr(np.ascontiguousarray(G)), capi.dptr(np.ascontiguousarray(B)), len(B), capi.dptr(x)))
+        return x
+
+    def chain(nb, closures):
+        G = np.zeros((6 * nb, 6 * nb))
+        for a, b in [(i, i + 1) for i in range(nb - 1)] + closures:
+            A = rng.normal(size=(6, 6)); Cab = A @ A.T + 6 * np.eye(6)
+            G[a * 6:a * 6 + 6, a * 6:a * 6 + 6] += Cab; G[b * 6:b * 6 + 6, b * 6:b * 6 + 6] += Cab
+            G[a * 6:a * 6 + 6, b * 6:b * 6 + 6] -= Cab; G[b * 6:b * 6 + 6, a * 6:a * 6 + 6] -= Cab
+        G[:6, :6] += 6 * np.eye(6)     # scan 0 is fixed in the real system: anchor the chain
+        return G
+    cases = [chain(63, [(i, min(62, i + 20 + i % 7)) for i in range(0, 42, 2)]), chain(5, []), chain(12, [(0, 11), (3, 9)])]
+    A = rng.normal(size=(40, 40)); cases.append(A @ A.T + 40 * np.eye(40))           # dense
+    cases.append(np.diag(rng.uniform(1, 2, 17)))                                     # diagonal
+    cases.append(np.array([[3.0]]))
+    G = chain(8, [(1, 6)]); G[30, 2] = G[2, 30] = 1e-5; G[31, 0] = G[0, 31] = 9e-6; G[40, 5] = G[5, 40] = 1.0000001e-5
+    cases.append(G)                                                                  # entries at / below / just above the filter
+    for G in cases:
+        B = rng.normal(size=len(G))
+        np.testing.assert_allclose(solve(G, B), np.linalg.solve(np.where(np.abs(G) > 1e-5, G, 0.0), B), rtol=1e-9, atol=1e-12)
+    with pytest.raises(tdtk.TdtkError):
+        solve(-np.eye(4), np.ones(4))
+    errs = []
+
+    def work(k):
+        try:
+            r = np.random.default_rng(100 + k)
+            for G in (cases[0], cases[3], cases[2]):
+                B = r.normal(size=len(G))
+                np.testing.assert_allclose(solve(G, B), np.linalg.solve(np.where(np.abs(G) > 1e-5, G, 0.0), B), rtol=1e-9, atol=1e-12)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
+def test_bench_and_package_ask_for_more_hardware_queues():
+    """the link passes run on three streams; a host with streams of its own (PyTorch, RCCL) needs more than the
+    runtime's four hardware queues -- both entry points ask before the runtime starts"""
+    for path in ("bench.py", os.path.join("3dtk_amd", "__init__.py")):
+        assert 'setdefault("GPU_MAX_HW_QUEUES"' in open(os.path.join(ROOT, path)).read(), path
+    assert os.environ.get("GPU_MAX_HW_QUEUES")      # conftest imported the package
+
+
 def test_graph_netfile_chain_addlink(tdtk, tmp_path):
     """Graph(netfile) (slam6D -n, graph.cc:52-74), Graph(n, loop) (:84-105), addLink's scan counting (:157-174)"""
     f = tmp_path / "net"
