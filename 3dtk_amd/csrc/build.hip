@@ -44,19 +44,6 @@ struct BMeas {
 struct BLevel { uint32_t nseg, node_base, leaf_base; };
 #define BUILD_MAX_LEVELS 4096
 
-typedef double d2_t __attribute__((ext_vector_type(2)));
-// eight 16-byte LDS reads at `addr` .. `addr + 112` (wave-uniform address: a broadcast), and the wait that makes
-// them usable: the registers are in/out operands of the wait so that no use can be scheduled before it
-#define LDS_READ_GROUP(R, addr)                                                                                     \
-  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"         \
-               "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t" \
-               "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112"                                     \
-               : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]), "=&v"(R[5]), "=&v"(R[6]), "=&v"(R[7]) \
-               : "v"(addr))
-#define LDS_WAIT_GROUP(R, n)                                                                                   \
-  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                     \
-               : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]))
-
 // ---- per node: bounding box + the reference's left-to-right fp64 sum ----------------------------
 // One wavefront per (node, axis).  Each step the wave loads 64 consecutive values (one coalesced
 // 512-B instruction, the next chunk prefetched while the current one is folded), updates the
@@ -106,32 +93,25 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
     __builtin_amdgcn_wave_barrier();
     const double* __restrict__ b = buf[cur];
     if (cnt == WAVE * MEAS_STAGE && base != 0) {
-      // A lone wave issues one instruction every four cycles and a dependent v_add_f64 is ready after ~6
-      // (tools/ubench/addchain.hip: 2.4 ns per add): the chain runs at the speed of the adds only if it carries less
-      // than half an instruction of overhead per add.  Groups of 16 values = 8 ds_read_b128, requested one group
-      // ahead, ONE s_waitcnt per group (LDS returns in order, so "at most the 8 newest reads outstanding" covers the
-      // whole older group).  The compiler's own wait insertion cannot be talked into that -- it waits before every
-      // pair of adds and moves an explicit s_waitcnt builtin behind them -- so the reads and the wait are inline asm.
-      constexpr int NG = WAVE * MEAS_STAGE / 16;
-      uint32_t a = (uint32_t)(size_t)(__attribute__((address_space(3))) const double*)b;   // LDS byte offset
-      d2_t ra[8], rb[8];
-      LDS_READ_GROUP(ra, a);
+      // 16 values requested ahead of the 16 being added (plain C++: the compiler places the waits).  Round 1 had the
+      // reads and ONE wait per group as inline asm here -- 4.5 instead of ~6 ns per add -- but a register written by an
+      // asm-issued read is only safe as long as the compiler never moves it between the two asm statements, which it
+      // did in k_big_stitch under register pressure; since the piecewise path this loop only sees nodes below 8192
+      // points (< 50 us per level), so the safe form costs nothing measurable.
+      double rA[16], rB[16];
 #pragma unroll
-      for (int g = 0; g < NG; g += 2) {
-        a += 128u;
-        LDS_READ_GROUP(rb, a);
-        LDS_WAIT_GROUP(ra, 8);                                  // group g has arrived
+      for (int t = 0; t < 16; t++) rA[t] = b[t];
+#pragma unroll 2
+      for (uint32_t k = 0; k < WAVE * MEAS_STAGE; k += 32) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) { sum += ra[q].x; sum += ra[q].y; }
-        if (g + 2 < NG) {
-          a += 128u;
-          LDS_READ_GROUP(ra, a);
-          LDS_WAIT_GROUP(rb, 8);                                // group g + 1 has arrived
-        } else {
-          LDS_WAIT_GROUP(rb, 0);
-        }
+        for (int t = 0; t < 16; t++) rB[t] = b[k + 16 + t];
 #pragma unroll
-        for (int q = 0; q < 8; q++) { sum += rb[q].x; sum += rb[q].y; }
+        for (int t = 0; t < 16; t++) sum += rA[t];
+        const uint32_t kn = (k + 32 < WAVE * MEAS_STAGE) ? k + 32 : 0u;   // the last request re-reads the head: unused
+#pragma unroll
+        for (int t = 0; t < 16; t++) rA[t] = b[kn + t];
+#pragma unroll
+        for (int t = 0; t < 16; t++) sum += rB[t];
       }
     } else {
       // first stage of a node (the sum starts FROM the first point) and the ragged last one: 16 values per round trip
