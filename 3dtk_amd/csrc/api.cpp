@@ -1750,6 +1750,12 @@ int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_
 // search + sums of every link, kernels enqueued back to back, one host sync.  Links over small scans are dealt to
 // up to 8 auxiliary streams (each pass alone leaves most of the machine idle); big scans keep the one stream.
 // acc: [nlinks][ACC_TOTAL] raw columns; shifts: [nlinks][3].
+static bool fuse_lum_enabled()
+{
+  const char* e = getenv("TDTK_FUSE_LUM");
+  return e && e[0] == '1';
+}
+
 static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
                              tdtk_scan* const* second, double maxd2, unsigned want, std::vector<double>& acc,
                              std::vector<double>& shifts)
@@ -1787,7 +1793,8 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     HIPCHK(hipStreamSynchronize(s));   // d_out is zeroed before any lane writes into it
     for (int l = 0; l < L; l++) {
       if ((rc = c->lanes[l]->kpos.ensure(maxN * sizeof(int)))) return rc;
-      if ((rc = c->lanes[l]->part.ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+      const size_t rows = std::max<size_t>(accum_grid(maxN), search_fused_rows(maxN, L));
+      if ((rc = c->lanes[l]->part.ensure(rows * ACC_TOTAL * sizeof(double)))) return rc;
     }
   } else {
     if ((rc = c->ws[WS_KPOS].ensure(maxN * sizeof(int)))) return rc;
@@ -1810,6 +1817,16 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     sa.x = data->x; sa.y = data->y; sa.z = data->z;
     sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
     sa.kpos = ln ? ln->kpos.as<int>() : c->ws[WS_KPOS].as<int>();
+    // a lum6DEuler link on a lane: its 17 sums come out of the search itself (accumulated when a query retires), so
+    // the pass over (x, y, z, hit, pts[hit]) that k_accum would make disappears.  Side by side the passes run ~3 waves
+    // per SIMD by choice, so the 36 accumulator registers cost no occupancy here (in the single-stream ICP loop they do)
+    uint32_t fused_rows = 0;
+    if (ln && want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) && search_can_fuse(sa.n) && fuse_lum_enabled()) {
+      fused_rows = search_fused_rows(sa.n, L);
+      sa.fuse = 2; sa.A = A;
+      for (int k = 0; k < 3; k++) sa.shift[k] = shifts[3 * i + k];
+      sa.partials = ln->part.as<double>();
+    }
     if (ln) {
       sa.T = t->dev;
       const uint32_t grid = search_grid(sa.n);
@@ -1822,6 +1839,10 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
       if (timed) { HIPCHK(hipEventRecord(c->e1, ls)); c->ev_pending = true; }
     } else {
       if ((rc = run_search(c, t, sa, 0, false, s, i == nlinks - 1))) return rc;
+    }
+    if (fused_rows) {
+      HIPCHK(launch_final(sa.partials, fused_rows, d_out + (size_t)i * ACC_TOTAL, ls));
+      continue;
     }
     AccumArgs aa{};
     aa.T = t->dev;

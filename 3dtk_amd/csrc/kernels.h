@@ -112,7 +112,7 @@ uint32_t search_grid(size_t n);
 size_t search_max_lanes(size_t n);     // most lanes any search kernel launches for n queries (stack overflow area)
 bool search_uses_queue(size_t n);      // does it get the work-queue kernel (needs q_ctr / q_ctr_next)?
 bool search_can_fuse(size_t n);        // does a batch of n queries get the kernel that can fuse the base sums?
-uint32_t search_fused_rows(size_t n);  // rows of partials the fused kernel writes
+uint32_t search_fused_rows(size_t n, int side_by_side = 1);  // rows of partials the fused kernel writes
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
 hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);

@@ -903,7 +903,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 // contended counter costs ~0.6 us and they serialise per counter (1M queries, 64-query draws: 0.93 ms against 0.27 ms
 // static; 256-query draws: 0.58 ms), and (b) the premise is wrong at this size -- a chip full of resident waves
 // (7168) leaves 1M queries only ~140 per wave, i.e. MORE drains per query than the static 224..256-query slabs.
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, bool FUSE, bool DYN>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -961,10 +961,13 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f;
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
-  double acc[ACC_DD];   // live only when FUSE
+  // FUSE 1: the base pair sums (ACC_N .. ACC_P) at retire time; FUSE 2: n, sum and the LUM block of a graph-SLAM link
+  // (acc[0] = n, [1] = sum |delta|^2, [2 .. 16] = the 15 sums of lum6Deuler.cc:143-175, [17] = sum u.delta)
+  constexpr int NACC = (FUSE == 2) ? 18 : ACC_DD;
+  double acc[NACC];   // live only when FUSE
   if (FUSE) {
 #pragma unroll
-    for (int k = 0; k < ACC_DD; k++) acc[k] = 0.0;
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
   }
 
   for (;;) {
@@ -974,7 +977,27 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       a.kpos[qi] = bk;
       if (a.d2) a.d2[qi] = best;
       have = false;
-      if (FUSE && bk >= 0) {
+      if (FUSE == 2 && bk >= 0) {
+        const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
+        const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)bk << 5));
+        double mx, my, mz;
+        dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);  // searchTree.cc:147
+        const double dx = mx - tx, dy = my - ty, dz = mz - tz;
+        const double x = (mx + tx) / 2.0, y = (my + ty) / 2.0, z = (mz + tz) / 2.0;
+        acc[0] += 1.0;
+        acc[1] += dx * dx + dy * dy + dz * dz;
+        acc[2] += x; acc[3] += y; acc[4] += z;
+        acc[5] += x * x + y * y;
+        acc[6] += x * x + z * z;
+        acc[7] += y * y + z * z;
+        acc[8] += x * y; acc[9] += x * z; acc[10] += y * z;
+        acc[11] += dx; acc[12] += dy; acc[13] += dz;
+        acc[14] += -z * dy + y * dz;
+        acc[15] += -y * dx + x * dy;
+        acc[16] += z * dx - x * dz;
+        acc[17] += x * dx + y * dy + z * dz;
+      }
+      if (FUSE == 1 && bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];   // the (already moved) data point, world frame
         const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)bk << 5));
         double mx, my, mz;
@@ -1158,18 +1181,22 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   if (FUSE) {
     // wave64 reduction, then across the workgroup's waves through LDS: one row of ACC_TOTAL per workgroup
     constexpr int NW = BLOCK / WAVE;
-    __shared__ double red[NW][ACC_DD];
+    __shared__ double red[NW][NACC];
     const int wv = threadIdx.x / WAVE;
 #pragma unroll
-    for (int k = 0; k < ACC_DD; k++) {
+    for (int k = 0; k < NACC; k++) {
       const double s = wave_sum(acc[k]);
       if (lane == 0) red[wv][k] = s;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
+      // column k of the row <- which accumulator (FUSE 2: n, sum, ACC_L .. ACC_L + 14, ACC_LU)
+      int src = -1;
+      if (FUSE == 2) src = (k == ACC_N) ? 0 : (k == ACC_SUM) ? 1 : (k >= ACC_L && k < ACC_L + 15) ? 2 + (k - ACC_L) : (k == ACC_LU) ? 17 : -1;
+      else if (k < ACC_DD) src = k;
       double s = 0.0;
-      if (k < ACC_DD)
-        for (int w = 0; w < NW; w++) s += red[w][k];
+      if (src >= 0)
+        for (int w = 0; w < NW; w++) s += red[w][src];
       a.partials[(size_t)blockIdx.x * ACC_TOTAL + k] = s;
     }
   }
@@ -1832,13 +1859,13 @@ static int pick_variant(size_t n)
 }
 bool search_can_fuse(size_t n) { return pick_variant(n) == 20; }
 bool search_uses_queue(size_t n) { return pick_variant(n) == 30; }
-uint32_t search_fused_rows(size_t n)
+uint32_t search_fused_rows(size_t n, int side_by_side)
 {
   int q;
-  return refill_grid_b(n, 128, &q);
+  return refill_grid_b(n, 128, &q, side_by_side);
 }
 
-template <bool COUNT, bool FUSE>
+template <bool COUNT, int FUSE>
 static void launch_refill128(SearchArgs& a, hipStream_t s)
 {
   int qpw;
@@ -1889,9 +1916,9 @@ static void launch_stream128(SearchArgs& a, hipStream_t s)
   a.slab = stream_slab_env();
   const uint32_t nb = stream_grid(a.n);
   switch (refill_thresh(a.n)) {
-    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, false, true>), dim3(nb), dim3(128), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, 0, true>), dim3(nb), dim3(128), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, 0, true>), dim3(nb), dim3(128), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, 0, true>), dim3(nb), dim3(128), 0, s, a); break;
   }
 }
 
@@ -1923,7 +1950,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
     if (v == 30 && (!a.q_ctr || !a.q_ctr_next)) return hipErrorInvalidValue;
     if (count) {
       // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
-      if (v == 20) { if (a.fuse) launch_refill128<true, true>(a, s); else launch_refill128<true, false>(a, s); }
+      if (v == 20) { if (a.fuse == 2) launch_refill128<true, 2>(a, s); else if (a.fuse) launch_refill128<true, 1>(a, s); else launch_refill128<true, 0>(a, s); }
       else if (v == 30) launch_stream128<true>(a, s);
       else if (v == 40) launch_step128<true, false>(a, s);
       else if (v == 41) launch_step128<true, true>(a, s);
@@ -1937,13 +1964,13 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
         const uint32_t nb = refill_grid_b(a.n, SEARCH_BLOCK, &qpw);
         a.qpw = qpw;
         a.phases = 1;
-        hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 16, 1, false, false, false>), dim3(nb), b, 0, s, a);
+        hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 16, 1, false, 0, false>), dim3(nb), b, 0, s, a);
         break;
       }
       case 30: launch_stream128<false>(a, s); break;
       case 40: launch_step128<false, false>(a, s); break;
       case 41: launch_step128<false, true>(a, s); break;
-      case 20: if (a.fuse) launch_refill128<false, true>(a, s); else launch_refill128<false, false>(a, s); break;
+      case 20: if (a.fuse == 2) launch_refill128<false, 2>(a, s); else if (a.fuse) launch_refill128<false, 1>(a, s); else launch_refill128<false, 0>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
       case 10: hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid(a.n) / 2 < 8 ? 8 : (g8_grid(a.n) / 2 + 7) / 8 * 8), dim3(256), 0, s, a); break;

@@ -610,6 +610,41 @@ def test_batched_scan_moves_are_visible_to_every_thread(tdtk, orc, gpu):
         assert np.array_equal(got[k], want), k
 
 
+def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
+    """TDTK_FUSE_LUM=1: the 17 sums of a lum6DEuler link accumulated when a query retires inside the search kernel
+    (k_search_refill<.., FUSE = 2>) instead of by k_accum -- a measured negative kept selectable; same blocks to rounding
+    (the order of the additions differs), same pair counts exactly."""
+    import ctypes as C
+    from importlib import import_module
+    capi = import_module("3dtk_amd._capi")
+    rng = np.random.default_rng(17)
+    world = rng.uniform(-400, 400, (300000, 3))
+    scans = []
+    for k in range(4):
+        T = tdtk.EulerToMatrix4([3.0 * k, -1.0 * k, 2.0 * k], [0.002 * k, -0.003 * k, 0.004 * k])
+        Ti = tdtk.M4inv(T)
+        R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+        loc = world @ R.T + Ti[12:15] + rng.normal(0, 0.05, world.shape)
+        scans.append(tdtk.Scan([3.0 * k + 0.3, -1.0 * k, 2.0 * k - 0.2], [0.002 * k, -0.003 * k + 0.001, 0.004 * k], loc))
+    tdtk.prepare_scans(scans, trees=True, threads=2)
+    links = [(0, 1), (1, 2), (2, 3), (0, 3), (1, 3)]
+    nl = len(links)
+    first = (C.c_void_p * nl)(*[scans[a].getSearchTree()._h for a, b in links])
+    second = (C.c_void_p * nl)(*[scans[b].handle for a, b in links])
+    dal = np.ascontiguousarray(np.stack([scans[a].dalignxf for a, b in links]))
+
+    def blocks():
+        Cm = np.empty((nl, 36)); CD = np.empty((nl, 6)); m = (C.c_uint64 * nl)(); ss = np.empty(nl)
+        capi.check(capi.lib().tdtk_lum_links(nl, first, capi.dptr(dal), second, 100.0, capi.dptr(Cm), capi.dptr(CD), m, capi.dptr(ss)))
+        return Cm, CD, list(m), ss
+    base = blocks()
+    monkeypatch.setenv("TDTK_FUSE_LUM", "1")
+    fused = blocks()
+    assert base[2] == fused[2] and min(base[2]) > 100000
+    for a, b in zip((base[0], base[1], base[3]), (fused[0], fused[1], fused[3])):
+        np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-9 * np.abs(a).max())
+
+
 def test_tree_edge_cases(tdtk, orc, gpu):
     """One point, two points, all-identical points (one degenerate bucket larger than the bucket size),
     non-finite coordinates (the reference would recurse on an empty side; we return an error)."""
