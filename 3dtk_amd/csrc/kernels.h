@@ -43,6 +43,10 @@ struct SearchArgs {
   uint32_t* q_ctr_next;  // ... and the 8 of the next launch on the same stream, zeroed by this one
   // fused retire-time accumulation of the base pair sums (k_search_refill<.., FUSE>): fuse != 0, A = Source->dalignxf,
   // shift as in AccumArgs, partials [search_fused_rows(n)][ACC_TOTAL]
+  int pool_slab;     // persistent-lane kernel, > 0: a wave's slab is `qpw` queries and the rest of its XCD's region is a pool
+                     // of pieces this long, drawn when a wave runs dry (q_ctr: one counter per XCD); region = queries per XCD
+  size_t region;
+  int trace;         // diagnostics (TDTK_WAVE_TRACE=<launch>): every wave prints its XCD, start and end time
   int side_by_side;  // > 1: one of that many whole-scan passes running concurrently on streams of their own (set by the caller)
   int phases;   // persistent-lane kernel: a wave's slab is handed out in this many pieces (see k_search_refill)
   int fuse;

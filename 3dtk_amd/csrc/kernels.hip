@@ -16,6 +16,10 @@
 //   k_transform   Scan::transformReduced on the resident scan.
 //   k_bin_*       counting sort of an unsorted query batch into spatial order.
 //   k_scatter_idx sorted-position hits -> caller-order model indices.
+#include <atomic>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -903,6 +907,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 // contended counter costs ~0.6 us and they serialise per counter (1M queries, 64-query draws: 0.93 ms against 0.27 ms
 // static; 256-query draws: 0.58 ms), and (b) the premise is wrong at this size -- a chip full of resident waves
 // (7168) leaves 1M queries only ~140 per wave, i.e. MORE drains per query than the static 224..256-query slabs.
+// diagnostics (TDTK_WAVE_TRACE=<launch index>): start / end time (100 MHz) and XCD of every wave of one launch
+#define WTRACE_MAX 32768u
+__device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
+
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
 {
@@ -912,6 +920,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   const uint32_t nb = gridDim.x;
   const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const unsigned lane = threadIdx.x & (WAVE - 1);
+  const unsigned long long trace_t0 = a.trace ? wall_clock64() : 0ull;
   LaneStack<BLOCK, SD> st;
   st.l_m2 = &lds_m2[0][threadIdx.x];
   st.l_ref = &lds_ref[0][threadIdx.x];
@@ -925,7 +934,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
 
   size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
-  size_t sub = 0, reg0 = 0, pstride = 0;
+  size_t sub = 0, reg0 = 0, pstride = 0, pool0 = 0, pool_end = 0;
+  bool exhausted = false;
   int phase = 0;
   uint32_t xq = 0, tried = 0, nslab = 0, per_x = 0;
   if (DYN) {
@@ -943,13 +953,33 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
     // model alone are 4 MB)
     const uint32_t wpx = (nb >> 3) * (BLOCK / WAVE);                      // waves per XCD
     const uint32_t wx = (blockIdx.x >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE;   // this wave among them
-    sub = (size_t)(a.qpw / a.phases);
-    reg0 = (size_t)(blockIdx.x & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
-    pstride = (size_t)wpx * sub;
-    next_q = reg0;
-    end_q = next_q + sub;
-    if (next_q > a.n) next_q = a.n;
-    if (end_q > a.n) end_q = a.n;
+    if (a.pool_slab) {
+      // Static slab + pool: the waves of a launch do not finish together -- at 1M queries the first is done after 60 %
+      // of the launch, the median after 77 % (TDTK_WAVE_TRACE) -- so only part of an XCD's region is dealt out in
+      // advance and the rest is drawn in small pieces by whichever wave runs dry.  One counter per XCD, touched only by
+      // waves of that XCD (the real XCC_ID), so the atomic can be of workgroup scope: it is served by the XCD's own L2
+      // instead of going to memory as a device-scope atomic on this multi-die part must (that round trip, serialised per
+      // counter, is what made the fully dynamic kernel above slow).
+      xq = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+      const size_t r0 = (size_t)(blockIdx.x & 7u) * a.region;
+      const size_t rend = (r0 + a.region < a.n) ? r0 + a.region : a.n;
+      next_q = r0 + (size_t)wx * (size_t)a.qpw;
+      end_q = next_q + (size_t)a.qpw;
+      if (next_q > rend) next_q = rend;
+      if (end_q > rend) end_q = rend;
+      pool0 = (size_t)xq * a.region + (size_t)wpx * (size_t)a.qpw;
+      pool_end = ((size_t)(xq + 1u) * a.region < a.n) ? (size_t)(xq + 1u) * a.region : a.n;
+      if (pool0 > pool_end) pool0 = pool_end;
+      if (blockIdx.x == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
+    } else {
+      sub = (size_t)(a.qpw / a.phases);
+      reg0 = (size_t)(blockIdx.x & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
+      pstride = (size_t)wpx * sub;
+      next_q = reg0;
+      end_q = next_q + sub;
+      if (next_q > a.n) next_q = a.n;
+      if (end_q > a.n) end_q = a.n;
+    }
   }
 
   uint32_t cur = REF_DONE;
@@ -1034,7 +1064,19 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         ++tried;
       }
     }
-    if (!DYN && fill && next_q >= end_q && phase + 1 < a.phases) {
+    if (!DYN && a.pool_slab && fill && next_q >= end_q && !exhausted) {
+      uint32_t k = 0;
+      if (lane == 0) k = __hip_atomic_fetch_add(&a.q_ctr[xq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+      const size_t p = pool0 + (size_t)k * (size_t)a.pool_slab;
+      if (p < pool_end) {
+        next_q = p;
+        end_q = (p + (size_t)a.pool_slab < pool_end) ? p + (size_t)a.pool_slab : pool_end;
+      } else {
+        exhausted = true;
+      }
+    }
+    if (!DYN && !a.pool_slab && fill && next_q >= end_q && phase + 1 < a.phases) {
       ++phase;
       next_q = reg0 + (size_t)phase * pstride;
       end_q = next_q + sub;
@@ -1067,7 +1109,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       next_q += (size_t)__popcll(idlem);
     }
     if (__ballot(cur != REF_DONE) == 0) {
-      if (next_q >= end_q && (DYN ? tried >= 8u : phase + 1 >= a.phases)) break;
+      if (next_q >= end_q && (DYN ? tried >= 8u : (a.pool_slab ? exhausted : phase + 1 >= a.phases))) break;
       continue;
     }
 
@@ -1168,6 +1210,13 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         st.top(r, m2);
         if (m2 < best) { cur = r; break; }
       }
+    }
+  }
+  if (a.trace && lane == 0) {
+    const uint32_t wid = blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    if (wid < WTRACE_MAX) {
+      g_wtrace[3 * wid] = trace_t0; g_wtrace[3 * wid + 1] = wall_clock64();
+      g_wtrace[3 * wid + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
     }
   }
   if (COUNT && a.counters) {
@@ -1858,7 +1907,18 @@ static int pick_variant(size_t n)
   return v;
 }
 bool search_can_fuse(size_t n) { return pick_variant(n) == 20; }
-bool search_uses_queue(size_t n) { return pick_variant(n) == 30; }
+// share of an XCD's region that is not dealt out in advance but drawn from a pool (k_search_refill, pool_slab);
+// 0 = off.  Only where all waves of the launch are resident at once and the launch has the chip to itself.
+static int refill_pool_pct(size_t n, int side_by_side)
+{
+  if (side_by_side > 1 || (n + 255) / 256 >= (size_t)num_cu() * 4 * 7) return 0;
+  const char* e = getenv("TDTK_REFILL_POOL");
+  int v = e ? atoi(e) : 0;
+  if (v < 0) v = 0;
+  if (v > 90) v = 90;
+  return v;
+}
+bool search_uses_queue(size_t n) { return pick_variant(n) == 30 || (pick_variant(n) == 20 && refill_pool_pct(n, 1) > 0); }
 uint32_t search_fused_rows(size_t n, int side_by_side)
 {
   int q;
@@ -1877,7 +1937,23 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   // cost coherence.  Non-temporal loads / stores for the query and result streams were measured too: no change in
   // misses or time.  (gpurun_out/r2n..r2r, tools/nt_probe.sh)
   // Neither do they pay beside other passes (84 link passes on 3 streams: 13.6 -> 13.2 ms without).
-  int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7 || a.side_by_side > 1) ? 1 : 2;
+  {
+    static std::atomic<int> launches{0};
+    static const int want = [] { const char* e = getenv("TDTK_WAVE_TRACE"); return e ? atoi(e) : -1; }();
+    a.trace = (want >= 0 && launches.fetch_add(1) == want) ? 1 : 0;
+  }
+  a.pool_slab = 0; a.region = 0;
+  const int pool_pct = refill_pool_pct(a.n, a.side_by_side);
+  if (pool_pct > 0) {
+    const size_t R = (((a.n + 7) / 8) + 63) & ~(size_t)63;             // queries per XCD region
+    const size_t wpx = (size_t)(nb >> 3) * 2;                          // waves per XCD (128-thread workgroups)
+    size_t qs = (R * (size_t)(100 - pool_pct) / 100 / wpx) & ~(size_t)31;
+    if (qs < 64) qs = 64;
+    a.qpw = (int)qs; a.region = R;
+    const char* e = getenv("TDTK_REFILL_POOL_SLAB");
+    a.pool_slab = e ? std::max(16, atoi(e)) : 64;
+  }
+  int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7 || a.side_by_side > 1 || a.pool_slab) ? 1 : 2;
   if (const char* e = getenv("TDTK_REFILL_PHASES")) ph = atoi(e);
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries
@@ -1886,6 +1962,14 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
     default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
+  }
+  if (a.trace) {
+    (void)hipStreamSynchronize(s);
+    const uint32_t nw = std::min<uint32_t>(nb * 2u, WTRACE_MAX);
+    std::vector<unsigned long long> h(3 * (size_t)nw);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wtrace), h.size() * sizeof(unsigned long long)) == hipSuccess)
+      for (uint32_t w = 0; w < nw; w++)
+        fprintf(stderr, "WTRACE %u %u %llu %llu %llu\n", w / 2u, w % 2u, h[3 * w + 2], h[3 * w], h[3 * w + 1]);
   }
 }
 

@@ -1410,7 +1410,7 @@ def test_reference_side_binding_executes(gpu):
 
 def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
-    other slab lengths / refill thresholds, 256-thread persistent lanes, one query per lane) walk the same tree the
+    other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane) walk the same tree the
     same way: identical indices, pair sums equal to rounding, and the instrumented instantiations count the same
     visits as the oracle -- on a batch large enough for the persistent-lane kernels, with duplicates in the model."""
     rng = np.random.default_rng(99)
@@ -1426,7 +1426,8 @@ def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     for env in ({"TDTK_FUSE_SUMS": "1"}, {"TDTK_SEARCH_VARIANT": "30"}, {"TDTK_SEARCH_VARIANT": "30", "TDTK_STREAM_SLAB": "64", "TDTK_STREAM_WPS": "7"},
                 {"TDTK_SEARCH_VARIANT": "8"}, {"TDTK_SEARCH_VARIANT": "4"}, {"TDTK_SEARCH_VARIANT": "0"},
                 {"TDTK_SEARCH_VARIANT": "40"}, {"TDTK_SEARCH_VARIANT": "41"},
-                {"TDTK_REFILL_QPW": "128", "TDTK_REFILL_THRESH": "8"}, {"TDTK_REFILL_QPW": "512", "TDTK_REFILL_THRESH": "32"}):
+                {"TDTK_REFILL_QPW": "128", "TDTK_REFILL_THRESH": "8"}, {"TDTK_REFILL_QPW": "512", "TDTK_REFILL_THRESH": "32"},
+                {"TDTK_REFILL_POOL": "25"}, {"TDTK_REFILL_POOL": "60", "TDTK_REFILL_POOL_SLAB": "48"}, {"TDTK_REFILL_PHASES": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for counting in (0, 1):
