@@ -173,12 +173,12 @@ struct BSum {                  // what a piece (or a run of pieces) does to M, b
   uint32_t eb, reset;          // exponent bits | sign << 11 it assumes; reset: nothing before it counts
 };
 __device__ __forceinline__ void bsum_neutral(BSum& r) { r.T0 = r.T1 = r.mn0 = r.mn1 = r.mx0 = r.mx1 = 0; r.eb = 0xFFFFu; r.reset = 0u; }
-struct BPre { double v; uint32_t reset, pad; };
+struct BPre { double v, lo, hi; uint32_t reset, pad; };   // plain running sum and running bounds since the node's first piece
 struct BPreOp {
   __device__ BPre operator()(const BPre& a, const BPre& b) const
   {
     if (b.reset) return b;
-    BPre r; r.v = a.v + b.v; r.reset = a.reset; r.pad = 0u;
+    BPre r; r.v = a.v + b.v; r.lo = (b.lo < a.lo) ? b.lo : a.lo; r.hi = (a.hi < b.hi) ? b.hi : a.hi; r.reset = a.reset; r.pad = 0u;
     return r;
   }
 };
@@ -293,12 +293,18 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
   if (h_end > h_start) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
   if (lane == 0) {
     BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = 0; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
-    BPre tp; tp.v = t.len ? tsum : 0.0; tp.reset = 0u; tp.pad = 0u;
-    if (t.len && t_first != 0xFFFFFFFFu) { t.flags = 4u; t.pre = arr[t_first]; tp.v += t.pre; tp.reset = 1u; }
+    BPre tp; tp.v = t.len ? tsum : 0.0; tp.lo = tlo; tp.hi = thi; tp.reset = 0u; tp.pad = 0u;
+    if (t.len && t_first != 0xFFFFFFFFu) {
+      t.flags = 4u; t.pre = arr[t_first]; tp.v += t.pre; tp.reset = 1u;
+      tp.lo = (t.pre < tp.lo) ? t.pre : tp.lo; tp.hi = (tp.hi < t.pre) ? t.pre : tp.hi;
+    }
     pieces[o] = t; prein[o] = tp;
     BPiece h; h.start = h_start; h.len = h_end - h_start; h.ebits = 0; h.flags = 0; h.lo = hlo; h.hi = hhi; h.csum = hsum; h.pre = 0.0;
-    BPre hp; hp.v = 0.0; hp.reset = 0u; hp.pad = 0u;
-    if (h.len) { h.flags = 4u; h.pre = arr[h_first]; hp.v = hsum + h.pre; hp.reset = 1u; }
+    BPre hp; hp.v = 0.0; hp.lo = hlo; hp.hi = hhi; hp.reset = 0u; hp.pad = 0u;
+    if (h.len) {
+      h.flags = 4u; h.pre = arr[h_first]; hp.v = hsum + h.pre; hp.reset = 1u;
+      hp.lo = (h.pre < hp.lo) ? h.pre : hp.lo; hp.hi = (hp.hi < h.pre) ? h.pre : hp.hi;
+    }
     pieces[o + 1] = h; prein[o + 1] = hp;
   }
 }
@@ -385,8 +391,9 @@ __device__ __forceinline__ bool big_apply(double& sum, const BSum S) { return bi
 __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
                                                     const double* __restrict__ cx, const double* __restrict__ cy,
                                                     const double* __restrict__ cz, uint32_t nblocks,
-                                                    const BPiece* __restrict__ pieces, const BSum* __restrict__ own,
-                                                    const BSum* __restrict__ comp, BMeas* __restrict__ out, int dbg)
+                                                    const BPiece* __restrict__ pieces, const BPre* __restrict__ preout,
+                                                    const BSum* __restrict__ own, const BSum* __restrict__ comp,
+                                                    BMeas* __restrict__ out, int dbg)
 {
   __shared__ double walk[256 / WAVE][BIG_CH * BIG_CL];
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
@@ -402,6 +409,25 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
   const BSum* ca = comp + ao;
   double* wbuf = walk[threadIdx.x / WAVE];
   const uint32_t np = big_piece_count(a, n);
+  {
+    // Only the sum along the axis the node will be split on is ever used (k_decide: splitval = mean[axis]); the bounds
+    // of all three axes are already known -- the bounds scan ends at the node's last piece -- so the waves of the two
+    // other axes report their bounds and leave (bit-identical tree: k_decide picks the axis from the same bounds).
+    const uint32_t sl = big_piece_slot(a, np - 1u);
+    const size_t st = (size_t)nblocks * 2;
+    const BPre b0 = preout[sl], b1 = preout[st + sl], b2 = preout[2 * st + sl];
+    const double hx = 0.5 * (b0.hi - b0.lo), hy = 0.5 * (b1.hi - b1.lo), hz = 0.5 * (b2.hi - b2.lo);
+    uint32_t split;
+    if (hx > hy) split = (hx > hz) ? 0u : 2u;
+    else split = (hy > hz) ? 1u : 2u;
+    if (split != ax && !(dbg & 3)) {
+      if (lane == 0) {
+        const BPre& b = (ax == 0) ? b0 : ((ax == 1) ? b1 : b2);
+        out[sgi].lo[ax] = b.lo; out[sgi].hi[ax] = b.hi; out[sgi].mean[ax] = 0.0;
+      }
+      return;
+    }
+  }
   const double first = arr[a];
   double sum = first, lo = first, hi = first;
   int done = -1;                                   // pieces 0 .. done are in `sum`
@@ -538,8 +564,10 @@ __global__ void k_big_dbg_compare(const BSeg* __restrict__ segs, const BLevel* _
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lv->nseg || segs[i].n < BIG_MIN) return;
+  const double hx = 0.5 * (b[i].hi[0] - b[i].lo[0]), hy = 0.5 * (b[i].hi[1] - b[i].lo[1]), hz = 0.5 * (b[i].hi[2] - b[i].lo[2]);
+  const int split = (hx > hy) ? ((hx > hz) ? 0 : 2) : ((hy > hz) ? 1 : 2);
   for (int ax = 0; ax < 3; ax++)
-    if (a[i].mean[ax] != b[i].mean[ax] || a[i].lo[ax] != b[i].lo[ax] || a[i].hi[ax] != b[i].hi[ax])
+    if ((ax == split && a[i].mean[ax] != b[i].mean[ax]) || a[i].lo[ax] != b[i].lo[ax] || a[i].hi[ax] != b[i].hi[ax])
       printf("MISMATCH level %u seg %u (start %u n %u) ax %d: mean %.17g vs chain %.17g  lo %g/%g hi %g/%g\n", level, i, segs[i].start,
              segs[i].n, ax, a[i].mean[ax], b[i].mean[ax], a[i].lo[ax], b[i].lo[ax], a[i].hi[ax], b[i].hi[ax]);
 }
@@ -891,7 +919,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u;
           BCHK(rocprim::exclusive_scan(tmp, stb, own, comp, ident, nsl, BSumOp(), s));
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
-                             pieces, own, comp, meas, big_dbg);
+                             pieces, preout, own, comp, meas, big_dbg);
           if (big_dbg_all & 8) {
             BMeas* meas2 = (BMeas*)(arena + O[29]);
             hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas2, 0xFFFFFFFFu);
