@@ -44,6 +44,87 @@ struct BMeas {
 struct BLevel { uint32_t nseg, node_base, leaf_base; };
 #define BUILD_MAX_LEVELS 4096
 
+// The left-to-right adds of `cnt` doubles parked in LDS at `b` (cnt a multiple of 32, wave-uniform address: every lane
+// reads the same values), sixteen requested ahead of the sixteen being added, as ONE asm statement: reads, waits and adds
+// together, so that no register written by a read is visible to the compiler before the wait that makes it valid.
+// (Read / wait pairs in separate asm statements -- round 1's k_measure -- are only safe while the compiler never
+// copies those registers in between; in k_big_stitch, with 220 live registers, it did, before the data had arrived
+// whenever LDS latency went up: one wrong addend per node, only with eight builds running at once.)  The last
+// iteration requests sixteen values beyond the end -- the buffer must be padded by 128 bytes -- and never adds them.
+__device__ __forceinline__ void lds_chain32(double& sum, const double* b, uint32_t cnt)
+{
+  // v[64:95] and v[96:127] are the two groups of sixteen values (named registers, clobbered: a 128-bit asm operand has
+  // no way to name its halves, and the adds need the halves of what ds_read_b128 returns); `b` must be 16-byte aligned
+  uint32_t ad = (uint32_t)(size_t)(__attribute__((address_space(3))) const double*)b;   // LDS byte offset
+  uint32_t pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cnt / 32u));
+  asm volatile(
+      "ds_read_b128 v[64:67], %[ad] offset:0\n\t"
+      "ds_read_b128 v[68:71], %[ad] offset:16\n\t"
+      "ds_read_b128 v[72:75], %[ad] offset:32\n\t"
+      "ds_read_b128 v[76:79], %[ad] offset:48\n\t"
+      "ds_read_b128 v[80:83], %[ad] offset:64\n\t"
+      "ds_read_b128 v[84:87], %[ad] offset:80\n\t"
+      "ds_read_b128 v[88:91], %[ad] offset:96\n\t"
+      "ds_read_b128 v[92:95], %[ad] offset:112\n\t"
+      ".Lbigchain%=:\n\t"
+      "ds_read_b128 v[96:99], %[ad] offset:128\n\t"
+      "ds_read_b128 v[100:103], %[ad] offset:144\n\t"
+      "ds_read_b128 v[104:107], %[ad] offset:160\n\t"
+      "ds_read_b128 v[108:111], %[ad] offset:176\n\t"
+      "ds_read_b128 v[112:115], %[ad] offset:192\n\t"
+      "ds_read_b128 v[116:119], %[ad] offset:208\n\t"
+      "ds_read_b128 v[120:123], %[ad] offset:224\n\t"
+      "ds_read_b128 v[124:127], %[ad] offset:240\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_add_f64 %[s], %[s], v[64:65]\n\t"
+      "v_add_f64 %[s], %[s], v[66:67]\n\t"
+      "v_add_f64 %[s], %[s], v[68:69]\n\t"
+      "v_add_f64 %[s], %[s], v[70:71]\n\t"
+      "v_add_f64 %[s], %[s], v[72:73]\n\t"
+      "v_add_f64 %[s], %[s], v[74:75]\n\t"
+      "v_add_f64 %[s], %[s], v[76:77]\n\t"
+      "v_add_f64 %[s], %[s], v[78:79]\n\t"
+      "v_add_f64 %[s], %[s], v[80:81]\n\t"
+      "v_add_f64 %[s], %[s], v[82:83]\n\t"
+      "v_add_f64 %[s], %[s], v[84:85]\n\t"
+      "v_add_f64 %[s], %[s], v[86:87]\n\t"
+      "v_add_f64 %[s], %[s], v[88:89]\n\t"
+      "v_add_f64 %[s], %[s], v[90:91]\n\t"
+      "v_add_f64 %[s], %[s], v[92:93]\n\t"
+      "v_add_f64 %[s], %[s], v[94:95]\n\t"
+      "v_add_u32 %[ad], 0x100, %[ad]\n\t"
+      "ds_read_b128 v[64:67], %[ad] offset:0\n\t"
+      "ds_read_b128 v[68:71], %[ad] offset:16\n\t"
+      "ds_read_b128 v[72:75], %[ad] offset:32\n\t"
+      "ds_read_b128 v[76:79], %[ad] offset:48\n\t"
+      "ds_read_b128 v[80:83], %[ad] offset:64\n\t"
+      "ds_read_b128 v[84:87], %[ad] offset:80\n\t"
+      "ds_read_b128 v[88:91], %[ad] offset:96\n\t"
+      "ds_read_b128 v[92:95], %[ad] offset:112\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_add_f64 %[s], %[s], v[96:97]\n\t"
+      "v_add_f64 %[s], %[s], v[98:99]\n\t"
+      "v_add_f64 %[s], %[s], v[100:101]\n\t"
+      "v_add_f64 %[s], %[s], v[102:103]\n\t"
+      "v_add_f64 %[s], %[s], v[104:105]\n\t"
+      "v_add_f64 %[s], %[s], v[106:107]\n\t"
+      "v_add_f64 %[s], %[s], v[108:109]\n\t"
+      "v_add_f64 %[s], %[s], v[110:111]\n\t"
+      "v_add_f64 %[s], %[s], v[112:113]\n\t"
+      "v_add_f64 %[s], %[s], v[114:115]\n\t"
+      "v_add_f64 %[s], %[s], v[116:117]\n\t"
+      "v_add_f64 %[s], %[s], v[118:119]\n\t"
+      "v_add_f64 %[s], %[s], v[120:121]\n\t"
+      "v_add_f64 %[s], %[s], v[122:123]\n\t"
+      "v_add_f64 %[s], %[s], v[124:125]\n\t"
+      "v_add_f64 %[s], %[s], v[126:127]\n\t"
+      "s_sub_u32 %[n], %[n], 1\n\ts_cmp_lg_u32 %[n], 0\n\ts_cbranch_scc1 .Lbigchain%=\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : [s] "+v"(sum), [ad] "+v"(ad), [n] "+s"(pairs)
+      :
+      : "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+}
+
 // ---- per node: bounding box + the reference's left-to-right fp64 sum ----------------------------
 // One wavefront per (node, axis).  Each step the wave loads 64 consecutive values (one coalesced
 // 512-B instruction, the next chunk prefetched while the current one is folded), updates the
@@ -55,7 +136,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
                                                  const double* __restrict__ cx, const double* __restrict__ cy,
                                                  const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
 {
-  __shared__ double stage[256 / WAVE][2][MEAS_STAGE * WAVE];
+  __shared__ alignas(16) double stage[256 / WAVE][2][MEAS_STAGE * WAVE + 16];   // + 16: lds_chain32 requests 128 bytes past the data
   // wave-uniform by construction; readfirstlane tells the compiler so
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
   const int lane = threadIdx.x & (WAVE - 1);
@@ -65,7 +146,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
   const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
   if (n >= big_min) return;   // measured by the piecewise path below (k_big_*)
   const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + s;
-  double(*buf)[MEAS_STAGE * WAVE] = stage[threadIdx.x / WAVE];
+  double(*buf)[MEAS_STAGE * WAVE + 16] = stage[threadIdx.x / WAVE];
 
   const double first = arr[0];
   double lo = first, hi = first;
@@ -93,26 +174,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
     __builtin_amdgcn_wave_barrier();
     const double* __restrict__ b = buf[cur];
     if (cnt == WAVE * MEAS_STAGE && base != 0) {
-      // 16 values requested ahead of the 16 being added (plain C++: the compiler places the waits).  Round 1 had the
-      // reads and ONE wait per group as inline asm here -- 4.5 instead of ~6 ns per add -- but a register written by an
-      // asm-issued read is only safe as long as the compiler never moves it between the two asm statements, which it
-      // did in k_big_stitch under register pressure; since the piecewise path this loop only sees nodes below 8192
-      // points (< 50 us per level), so the safe form costs nothing measurable.
-      double rA[16], rB[16];
-#pragma unroll
-      for (int t = 0; t < 16; t++) rA[t] = b[t];
-#pragma unroll 2
-      for (uint32_t k = 0; k < WAVE * MEAS_STAGE; k += 32) {
-#pragma unroll
-        for (int t = 0; t < 16; t++) rB[t] = b[k + 16 + t];
-#pragma unroll
-        for (int t = 0; t < 16; t++) sum += rA[t];
-        const uint32_t kn = (k + 32 < WAVE * MEAS_STAGE) ? k + 32 : 0u;   // the last request re-reads the head: unused
-#pragma unroll
-        for (int t = 0; t < 16; t++) rA[t] = b[kn + t];
-#pragma unroll
-        for (int t = 0; t < 16; t++) sum += rB[t];
-      }
+      lds_chain32(sum, b, WAVE * MEAS_STAGE);
     } else {
       // first stage of a node (the sum starts FROM the first point) and the ragged last one: 16 values per round trip
       uint32_t k = (base == 0) ? 1u : 0u;
@@ -395,7 +457,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
                                                     const BSum* __restrict__ own, const BSum* __restrict__ comp,
                                                     BMeas* __restrict__ out, int dbg)
 {
-  __shared__ double walk[256 / WAVE][BIG_CH * BIG_CL];
+  __shared__ alignas(16) double walk[256 / WAVE][BIG_CH * BIG_CL + 16];   // + 16: the chain's last request reads past the data
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (w >= 3u * lv->nseg) return;
@@ -437,25 +499,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if ((cnt & 31u) == 0u && cnt) {
-      // 16 values requested ahead of the 16 being added.  Plain C++: the inline-asm read / wait pairs of k_measure are
-      // not safe here -- with 220 live registers the compiler copies the destination registers of a read between the
-      // two asm statements, i.e. possibly before the data has arrived (seen as one wrong addend per node, only when
-      // eight builds ran at once and LDS latency went up).
-      const double* __restrict__ b = wbuf;
-      double rA[16], rB[16];
-#pragma unroll
-      for (int t = 0; t < 16; t++) rA[t] = b[t];
-      for (uint32_t k = 0; k < cnt; k += 32) {
-#pragma unroll
-        for (int t = 0; t < 16; t++) rB[t] = b[k + 16 + t];
-#pragma unroll
-        for (int t = 0; t < 16; t++) sum += rA[t];
-        const uint32_t kn = (k + 32 < cnt) ? k + 32 : 0u;   // the last request re-reads the head of the buffer: unused
-#pragma unroll
-        for (int t = 0; t < 16; t++) rA[t] = b[kn + t];
-#pragma unroll
-        for (int t = 0; t < 16; t++) sum += rB[t];
-      }
+      lds_chain32(sum, wbuf, cnt);
     } else {
       uint32_t k = 0;
       for (; k + 16 <= cnt; k += 16) {
