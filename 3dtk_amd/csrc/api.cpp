@@ -118,6 +118,8 @@ struct Ctx {
   DevBuf d_counters;
   uint64_t counted_queries = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
+  std::vector<std::unique_ptr<Lane>> slots;   // per-link buffers of a several-links-in-one-launch batch (no streams)
+  DevBuf multi_args;                          // its argument tables on the device
   QueueCtr qc;       // for launches on `stream` (a caller's stream gets its launches ordered behind it, see run_search)
   // a context dies with its host thread (worker threads of a prefetch pool come and go): give everything back
   ~Ctx();
@@ -155,6 +157,7 @@ Ctx::~Ctx()
     if (e_defer) (void)hipEventDestroy(e_defer);
     if (h_stage) (void)hipHostFree(h_stage);
     lanes.clear();
+    slots.clear();
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e2) (void)hipEventDestroy(e2);
@@ -1756,6 +1759,112 @@ static bool fuse_lum_enabled()
   return e && e[0] == '1';
 }
 
+static int link_batch_max()
+{
+  const char* e = getenv("TDTK_LINK_BATCH");   // 0 / 1: the lanes below
+  int v = e ? atoi(e) : 64;
+  if (v > 64) v = 64;
+  return v;
+}
+
+// All links of the call in launches of up to `gb` links each: ONE search launch, one pair-sum launch and one final
+// reduction per group (k_search_refill_multi and friends: workgroups of link k+1 fill the tail of link k), everything on
+// the context's stream -- what the lanes below get from three streams, without depending on how the runtime maps streams
+// to hardware queues, and with a handful of launches instead of three per link.
+static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
+                                     tdtk_scan* const* second, double maxd2, unsigned want, double* d_out,
+                                     const std::vector<double>& shifts, int gb)
+{
+  hipStream_t s = c->stream;
+  int rc;
+  size_t maxN = 0;
+  int max_need = 0;
+  for (int i = 0; i < nlinks; i++) {
+    maxN = std::max(maxN, second[i]->N);
+    max_need = std::max(max_need, (int)first[i]->info.max_depth - 1 - search_lds_depth());
+  }
+  const int G = std::min(gb, nlinks);
+  while ((int)c->slots.size() < G) c->slots.emplace_back(new Lane);
+  for (int g = 0; g < G; g++) {          // every buffer at its final size before anything is enqueued
+    Lane* sl = c->slots[g].get();
+    if ((rc = sl->kpos.ensure(maxN * sizeof(int)))) return rc;
+    if ((rc = sl->part.ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+    if (max_need > 0) {
+      const size_t lanes = search_max_lanes(maxN);
+      if ((rc = sl->ovf_m2.ensure(lanes * max_need * sizeof(double)))) return rc;
+      if ((rc = sl->ovf_ref.ensure(lanes * max_need * sizeof(uint32_t)))) return rc;
+    }
+  }
+  const int ngroups = (nlinks + G - 1) / G;
+  // one table for the whole call: per link its search and pair-sum arguments and final descriptor, per group the two
+  // workgroup-offset lists
+  const size_t o_sa = 0, o_aa = o_sa + sizeof(SearchArgs) * nlinks, o_fd = o_aa + sizeof(AccumArgs) * nlinks,
+               o_sb = o_fd + sizeof(FinalDesc) * nlinks, o_ab = o_sb + sizeof(uint32_t) * (size_t)(nlinks + ngroups),
+               total = o_ab + sizeof(uint32_t) * (size_t)(nlinks + ngroups);
+  std::vector<char> tab(total, 0);
+  SearchArgs* hsa = reinterpret_cast<SearchArgs*>(tab.data() + o_sa);
+  AccumArgs* haa = reinterpret_cast<AccumArgs*>(tab.data() + o_aa);
+  FinalDesc* hfd = reinterpret_cast<FinalDesc*>(tab.data() + o_fd);
+  uint32_t* hsb = reinterpret_cast<uint32_t*>(tab.data() + o_sb);
+  uint32_t* hab = reinterpret_cast<uint32_t*>(tab.data() + o_ab);
+  std::vector<uint32_t> s_total(ngroups), a_total(ngroups);
+  if (c->counting) { for (int i = 0; i < nlinks; i++) c->counted_queries += second[i]->N; }
+  for (int gi = 0; gi < ngroups; gi++) {
+    const int l0 = gi * G, l1 = std::min(nlinks, l0 + G);
+    uint32_t sb = 0, ab = 0;
+    for (int i = l0; i < l1; i++) {
+      const tdtk_tree* t = first[i];
+      tdtk_scan* data = second[i];
+      Lane* sl = c->slots[i - l0].get();
+      const double* A16 = first_dalignxf + 16 * (size_t)i;
+      Mat4 A, inv;
+      std::memcpy(A.m, A16, sizeof A.m);
+      m4inv(A16, inv.m);
+      SearchArgs sa{};
+      sa.T = t->dev;
+      sa.x = data->x; sa.y = data->y; sa.z = data->z;
+      sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
+      sa.kpos = sl->kpos.as<int>();
+      const int need = (int)t->info.max_depth - 1 - search_lds_depth();
+      if (need > 0) { sa.ovf_m2 = sl->ovf_m2.as<double>(); sa.ovf_ref = sl->ovf_ref.as<uint32_t>(); }
+      if (c->counting) sa.counters = c->d_counters.as<unsigned long long>();
+      const uint32_t nb = search_multi_prepare(sa, l1 - l0);
+      hsb[i + gi] = sb; sb += nb;
+      hsa[i] = sa;
+      AccumArgs aa{};
+      aa.T = t->dev;
+      aa.x = data->x; aa.y = data->y; aa.z = data->z;
+      aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
+      for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * i + k];
+      aa.partials = sl->part.as<double>();
+      const uint32_t ag = accum_grid(data->N);
+      hab[i + gi] = ab; ab += ag;
+      haa[i] = aa;
+      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)i * ACC_TOTAL; hfd[i].rows = (int)ag; hfd[i].pad = 0;
+    }
+    hsb[l1 + gi] = sb; hab[l1 + gi] = ab;
+    s_total[gi] = sb; a_total[gi] = ab;
+  }
+  if ((rc = c->multi_args.ensure(total))) return rc;
+  void* staged = nullptr;
+  if ((rc = stage_pinned(c, tab.data(), total, &staged))) return rc;
+  HIPCHK(hipMemcpyAsync(c->multi_args.p, staged, total, hipMemcpyHostToDevice, s));
+  char* dbase = static_cast<char*>(c->multi_args.p);
+  const int thresh = search_multi_thresh(maxN);
+  for (int gi = 0; gi < ngroups; gi++) {
+    const int l0 = gi * G, l1 = std::min(nlinks, l0 + G), nb = l1 - l0;
+    const bool timed = (gi == ngroups - 1);      // tdtk_last_kernel_ms: the last group's search launch
+    if (timed) HIPCHK(hipEventRecord(c->e0, s));
+    HIPCHK(launch_search_multi(reinterpret_cast<const SearchArgs*>(dbase + o_sa) + l0,
+                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], thresh, c->counting, s));
+    if (timed) { HIPCHK(hipEventRecord(c->e1, s)); c->ev_pending = true; }
+    HIPCHK(launch_accum_multi(reinterpret_cast<const AccumArgs*>(dbase + o_aa) + l0,
+                              reinterpret_cast<const uint32_t*>(dbase + o_ab) + l0 + gi, nb, a_total[gi], want,
+                              reinterpret_cast<const FinalDesc*>(dbase + o_fd) + l0, s));
+  }
+  return TDTK_OK;
+}
+
 static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, const double* first_dalignxf,
                              tdtk_scan* const* second, double maxd2, unsigned want, std::vector<double>& acc,
                              std::vector<double>& shifts)
@@ -1770,6 +1879,27 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     if (!first[i] || !second[i]) { set_error("NULL link member"); return TDTK_EINVAL; }
     if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
     maxN = std::max(maxN, second[i]->N);
+  }
+  {
+    const int gb = link_batch_max();
+    bool ok = gb > 1 && nlinks > 1 && (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) || (want & 7u) == TDTK_WANT_LUM || (want & 7u) == 0u);
+    for (int i = 0; i < nlinks && ok; i++)
+      ok = second[i]->N > 0 && search_can_fuse(second[i]->N) && search_multi_thresh(second[i]->N) == search_multi_thresh(maxN);
+    if (ok) {
+      for (int i = 0; i < nlinks; i++) {
+        const tdtk_tree* t = first[i];
+        const double* A16 = first_dalignxf + 16 * (size_t)i;
+        for (int k = 0; k < 3; k++)
+          shifts[3 * i + k] = t->centre[0] * A16[k] + t->centre[1] * A16[4 + k] + t->centre[2] * A16[8 + k] + A16[12 + k];
+      }
+      HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
+      if ((rc = links_device_pass_batched(c, nlinks, first, first_dalignxf, second, maxd2, want, d_out, shifts, gb))) return rc;
+      acc.assign((size_t)nlinks * ACC_TOTAL, 0.0);
+      HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      collect_ms(c, nullptr);
+      return TDTK_OK;
+    }
   }
   int max_lanes = 8, forced = 0;
   if (const char* e = getenv("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));

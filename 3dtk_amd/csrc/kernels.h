@@ -120,6 +120,14 @@ uint32_t search_fused_rows(size_t n, int side_by_side = 1);  // rows of partials
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
 hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);
+// several batches (the link passes of a graph-SLAM round) in one launch: see k_search_refill_multi in kernels.hip
+struct FinalDesc { const double* partials; double* out; int rows, pad; };
+uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch);   // sets the slab fields, returns the batch's workgroups (x8)
+int search_multi_thresh(size_t n);
+hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int thresh,
+                               bool count, hipStream_t s);
+hipError_t launch_accum_multi(const AccumArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, unsigned want,
+                              const FinalDesc* d_final, hipStream_t s);
 int search_lds_depth();
 int search_block();
 uint32_t accum_grid(size_t n);

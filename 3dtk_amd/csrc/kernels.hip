@@ -911,14 +911,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 #define WTRACE_MAX 32768u
 __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 
+// the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
+// the several-batches-in-one-launch kernel below share it)
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN>
-__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
+__device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
   __shared__ uint32_t lds_ref[SD][BLOCK];
 
-  const uint32_t nb = gridDim.x;
-  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t gl = (size_t)bid * BLOCK + threadIdx.x;
   const unsigned lane = threadIdx.x & (WAVE - 1);
   const unsigned long long trace_t0 = a.trace ? wall_clock64() : 0ull;
   LaneStack<BLOCK, SD> st;
@@ -944,7 +945,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
     per_x = (nslab + 7u) >> 3;
     xq = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]: speed only
     // the counters of the NEXT launch on this stream (the two sets alternate): nobody reads them during this one
-    if (blockIdx.x == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
+    if (bid == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
   } else {
     // a wave owns qpw consecutive sorted queries (256 unless the batch is so large that the grid is capped)
     // ... handed out in `phases` pieces: the waves of one XCD (workgroup b runs on XCD b % 8) first cover the first
@@ -952,7 +953,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
     // hold at any one time are those under 1/phases of the eighth (the 32-byte points of an eighth of a 1M-point
     // model alone are 4 MB)
     const uint32_t wpx = (nb >> 3) * (BLOCK / WAVE);                      // waves per XCD
-    const uint32_t wx = (blockIdx.x >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE;   // this wave among them
+    const uint32_t wx = (bid >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE;   // this wave among them
     if (a.pool_slab) {
       // Static slab + pool: the waves of a launch do not finish together -- at 1M queries the first is done after 60 %
       // of the launch, the median after 77 % (TDTK_WAVE_TRACE) -- so only part of an XCD's region is dealt out in
@@ -961,7 +962,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       // instead of going to memory as a device-scope atomic on this multi-die part must (that round trip, serialised per
       // counter, is what made the fully dynamic kernel above slow).
       xq = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
-      const size_t r0 = (size_t)(blockIdx.x & 7u) * a.region;
+      const size_t r0 = (size_t)(bid & 7u) * a.region;
       const size_t rend = (r0 + a.region < a.n) ? r0 + a.region : a.n;
       next_q = r0 + (size_t)wx * (size_t)a.qpw;
       end_q = next_q + (size_t)a.qpw;
@@ -970,10 +971,10 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       pool0 = (size_t)xq * a.region + (size_t)wpx * (size_t)a.qpw;
       pool_end = ((size_t)(xq + 1u) * a.region < a.n) ? (size_t)(xq + 1u) * a.region : a.n;
       if (pool0 > pool_end) pool0 = pool_end;
-      if (blockIdx.x == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
+      if (bid == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
     } else {
       sub = (size_t)(a.qpw / a.phases);
-      reg0 = (size_t)(blockIdx.x & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
+      reg0 = (size_t)(bid & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
       pstride = (size_t)wpx * sub;
       next_q = reg0;
       end_q = next_q + sub;
@@ -1007,7 +1008,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       a.kpos[qi] = bk;
       if (a.d2) a.d2[qi] = best;
       have = false;
-      if (FUSE == 2 && bk >= 0) {
+      if constexpr (FUSE == 2) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
         const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)bk << 5));
         double mx, my, mz;
@@ -1027,7 +1028,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
         acc[16] += z * dx - x * dz;
         acc[17] += x * dx + y * dy + z * dz;
       }
-      if (FUSE == 1 && bk >= 0) {
+      if constexpr (FUSE == 1) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];   // the (already moved) data point, world frame
         const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)bk << 5));
         double mx, my, mz;
@@ -1213,7 +1214,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
     }
   }
   if (a.trace && lane == 0) {
-    const uint32_t wid = blockIdx.x * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    const uint32_t wid = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
     if (wid < WTRACE_MAX) {
       g_wtrace[3 * wid] = trace_t0; g_wtrace[3 * wid + 1] = wall_clock64();
       g_wtrace[3 * wid + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
@@ -1246,9 +1247,30 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
       double s = 0.0;
       if (src >= 0)
         for (int w = 0; w < NW; w++) s += red[w][src];
-      a.partials[(size_t)blockIdx.x * ACC_TOTAL + k] = s;
+      a.partials[(size_t)bid * ACC_TOTAL + k] = s;
     }
   }
+}
+
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
+{
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN>(a, blockIdx.x, gridDim.x);
+}
+
+// Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
+// batch l with the arguments args[l] (device memory; every base[] a multiple of 8, so a workgroup's XCD is the one its
+// batch-relative index says).  Workgroups are dispatched in order, so the tail of one batch is filled by the next --
+// what several streams give, without depending on how the runtime maps streams to hardware queues.
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const SearchArgs* __restrict__ args,
+                                                                    const uint32_t* __restrict__ base, int nbatch)
+{
+  int l = 0;
+  while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
+  l = __builtin_amdgcn_readfirstlane(l);
+  const uint32_t b0 = base[l], b1 = base[l + 1];
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1445,7 +1467,7 @@ __global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
 
 // acc layout (doubles): see kernels.h ACC_*
 template <int BLOCK, unsigned WANT, int PMODE>
-__global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
+__device__ __forceinline__ void accum_body(const AccumArgs& a, const uint32_t bid, const uint32_t nb)
 {
   constexpr int NW = BLOCK / WAVE;
   // ACC_WANT_NO_CROSS: the caller needs n, sum and its own block only (a lum6DEuler link: 17 columns instead of 34 to
@@ -1462,8 +1484,8 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
   // query coordinates are all requested before the first use (the gather depends on the hit position; one query at a
   // time exposes that round trip four times)
   constexpr int U = 4;
-  const size_t stride = (size_t)gridDim.x * BLOCK * U;
-  for (size_t base = (size_t)blockIdx.x * BLOCK * U + threadIdx.x; base < a.n; base += stride) {
+  const size_t stride = (size_t)nb * BLOCK * U;
+  for (size_t base = (size_t)bid * BLOCK * U + threadIdx.x; base < a.n; base += stride) {
     int kk[U];
     double4 cc[U];
     double qx_[U], qy_[U], qz_[U];
@@ -1580,8 +1602,24 @@ __global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
     double s = 0.0;
     if (used)
       for (int w = 0; w < NW; w++) s += red[w][k];
-    a.partials[(size_t)blockIdx.x * ACC_TOTAL + k] = s;
+    a.partials[(size_t)bid * ACC_TOTAL + k] = s;
   }
+}
+
+template <int BLOCK, unsigned WANT, int PMODE>
+__global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
+{
+  accum_body<BLOCK, WANT, PMODE>(a, blockIdx.x, gridDim.x);
+}
+// the pair sums of several batches in one launch (see k_search_refill_multi)
+template <int BLOCK, unsigned WANT, int PMODE>
+__global__ void __launch_bounds__(BLOCK) k_accum_multi(const AccumArgs* __restrict__ args, const uint32_t* __restrict__ base, int nbatch)
+{
+  int l = 0;
+  while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
+  l = __builtin_amdgcn_readfirstlane(l);
+  const uint32_t b0 = base[l], b1 = base[l + 1];
+  accum_body<BLOCK, WANT, PMODE>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 // fixed-order reduction of the per-workgroup rows: one 256-thread workgroup per accumulator
@@ -1598,6 +1636,20 @@ __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partia
   if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
   __syncthreads();
   if (threadIdx.x == 0) out[k] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// k_final for several batches: blockIdx.y = batch (its rows, its output)
+__global__ void __launch_bounds__(256) k_final_multi(const FinalDesc* __restrict__ desc)
+{
+  __shared__ double red[4];
+  const FinalDesc d = desc[blockIdx.y];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < d.rows; r += 256) s += d.partials[(size_t)r * ACC_TOTAL + k];
+  s = wave_sum(s);
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) d.out[k] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2153,6 +2205,54 @@ hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hi
   return hipGetLastError();
 }
 
+// ---- several batches in one launch (the link passes of a graph-SLAM round) ----
+// Per batch: the grid and slab length the persistent-lane kernel would get beside `concurrent` other passes.  Only for
+// batches the big-batch kernel takes (search_can_fuse(n)).
+// Slab length inside such a launch: the dispatcher keeps every wave slot of the chip busy with whatever batch comes
+// next, so occupancy does not depend on the slab and longer slabs (fewer drains per query) win until the last
+// generation of waves becomes the tail: 84 links of 1M points in launches of 64: 224 -> 12.6 ms, 320 -> 12.0, 512 -> 11.5,
+// 640 -> 11.4, 1024 -> 11.5, 1536 -> 11.7; a rank's 11 links in one launch: 320 -> 1.79 ms, 448 -> 1.77, 640 -> 1.81
+// (three streams: 12.6 / 1.89 on the same box).
+uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
+{
+  int qpw;
+  uint32_t nb = refill_grid_b(a.n, 128, &qpw, 2);
+  if (!getenv("TDTK_REFILL_QPW")) {
+    const int want = links_in_launch > 16 ? 640 : 448;
+    if (want > qpw) {
+      qpw = want;
+      const size_t waves = (a.n + (size_t)qpw - 1) / (size_t)qpw;
+      size_t b = (waves + 1) / 2;
+      b = (b + 7) & ~(size_t)7;
+      if (b < 8) b = 8;
+      nb = (uint32_t)b;
+    }
+  }
+  a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0; a.side_by_side = links_in_launch;
+  return nb;
+}
+int search_multi_thresh(size_t n) { return refill_thresh(n); }
+hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int thresh,
+                               bool count, hipStream_t s)
+{
+  if (!nbatch || !total_blocks) return hipSuccess;
+  const dim3 g(total_blocks), b(128);
+  if (count) {
+    switch (thresh) {
+      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      default: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+    }
+  } else {
+    switch (thresh) {
+      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      default: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+    }
+  }
+  return hipGetLastError();
+}
+
 constexpr int ACC_BLOCK = 256;
 uint32_t accum_grid(size_t n)
 {
@@ -2190,6 +2290,21 @@ hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pm
     default: launch_accum_w<7>(a, grid, pmode, s); break;
   }
   hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, a.partials, (int)grid, d_out);
+  return hipGetLastError();
+}
+
+// want: TDTK_WANT_LUM | ACC_WANT_NO_CROSS (a lum6DEuler link) or TDTK_WANT_LUM or TDTK_WANT_GAPX / MOM2 or 0 (base sums)
+hipError_t launch_accum_multi(const AccumArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, unsigned want,
+                              const FinalDesc* d_final, hipStream_t s)
+{
+  if (!nbatch || !total_blocks) return hipSuccess;
+  const dim3 g(total_blocks), b(ACC_BLOCK);
+  if (want & (TDTK_WANT_GAPX | TDTK_WANT_MOM2)) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_GAPX, 0>), g, b, 0, s, d_args, d_base, nbatch);
+  else if (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS)) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_LUM | ACC_WANT_NO_CROSS, 0>), g, b, 0, s, d_args, d_base, nbatch);
+  else if ((want & 7u) == TDTK_WANT_LUM) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_LUM, 0>), g, b, 0, s, d_args, d_base, nbatch);
+  else if ((want & 7u) == 0u) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, 0u, 0>), g, b, 0, s, d_args, d_base, nbatch);
+  else return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_final_multi, dim3(ACC_TOTAL, nbatch), dim3(256), 0, s, d_final);
   return hipGetLastError();
 }
 
