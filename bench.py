@@ -527,9 +527,20 @@ def bench_graphslam(args, rank, world, local):
         counts = vc.read()
     my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
     bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
-    # the link passes of a step run on up to 3 streams side by side, so one launch's duration is not the kernel's
-    # throughput: the aggregate figure is (bytes of all this rank's link searches) / (wall time of the step)
+    # All link passes of a rank go out in launches of up to 64 links (k_search_refill_multi); the HIP events sit around the
+    # LAST launch of a step.  achieved = algorithmic bytes of that launch / its duration; beside it the aggregate over
+    # the whole step (bytes of all this rank's link searches / wall time of the step, exchange, solve and pose update
+    # included in the denominator).
+    batch = int(os.environ.get("TDTK_LINK_BATCH", "64"))
+    batched = batch > 1 and my_links > 1 and npts >= 262144
+    groups = (my_links + batch - 1) // batch if batched else my_links
+    last_links = my_links - batch * (groups - 1) if batched else 1
     agg = bq * my_links * npts / (dt / args.steps) / 1e9
+    ach = bq * last_links * npts / (k_ms * 1e-3) / 1e9 if k_ms > 0 else agg
+    pk = pmc_kernel("k_search (several links per launch)" if batched else "k_search", "r02_graphslam_pmc.json")
+    traffic = pmc_traffic_bytes(pk)
+    if traffic is not None and batched:
+        traffic = traffic * groups / my_links * last_links      # the committed passes average over a step's launches
     exchange = ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None \
         else ("torch.distributed (gloo test rig)" if use_torch_exchange else "none (one rank)")
     if comm is not None:
@@ -548,15 +559,19 @@ def bench_graphslam(args, rank, world, local):
         "exchange": exchange,
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
-        "roofline": {"bound": "hbm", "kernel": "k_search (link passes, up to 3 streams side by side)", "achieved": agg,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic_bytes(pmc_kernel("k_search", "r02_graphslam_pmc.json")),
-                     "kernel_ms_one_launch_among_concurrent": k_ms, "bytes_per_query": bq,
+        "roofline": {"bound": "hbm", "kernel": "k_search_refill_multi (link passes, up to %d links per launch)" % batch if batched
+                                               else "k_search (link passes on streams side by side)",
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel_ms": k_ms, "links_in_that_launch": last_links, "launches_per_step": groups,
+                     "bytes_per_query": bq,
                      "visits_per_query": {"internal": counts[0] / max(1, counts[3]), "points": counts[2] / max(1, counts[3])},
                      "links_this_rank": my_links,
-                     "note": "achieved = algorithmic bytes of ALL this rank's link searches per step / step wall time "
-                             "(searches overlap each other and the pair-sum kernels; includes exchange, solve and pose "
-                             "update in the denominator)"},
+                     "whole_step": {"achieved": agg, "frac": agg / HBM_PEAK_GBS,
+                                    "what": "algorithmic bytes of ALL this rank's link searches per step / step wall time "
+                                            "(exchange, solve and pose update in the denominator)"},
+                     "note": "achieved = algorithmic bytes of the step's last search launch / its HIP-event duration; like "
+                             "the ICP figure it counts re-reads served by L2 / Infinity Cache (not a utilisation); "
+                             "`traffic` = PMC fabric bytes of such a launch"},
     }
     return out
 

@@ -11,6 +11,9 @@ def short(n):
     if n.startswith("k_search_refill<"):
         a = [t.strip() for t in n[len("k_search_refill<"):].split(">")[0].split(",")]
         return "k_search_count(instrumented, not timed)" if len(a) >= 5 and a[4] == "true" else "k_search"
+    if n.startswith("k_search_refill_multi<"):
+        a = [t.strip() for t in n[len("k_search_refill_multi<"):].split(">")[0].split(",")]
+        return "k_search_count(instrumented, not timed)" if len(a) >= 5 and a[4] == "true" else "k_search (several links per launch)"
     if n.startswith("k_search<"):
         return "k_search(one query per lane)"
     return n[:80]
@@ -25,7 +28,7 @@ with open(os.path.join("profiles", pre + "_graphslam_kernel_stats.csv"), "w") as
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         f.write("%s,%d,%.3f,%.3f,%.3f,%.3f,%.2f\n" % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
 pmc = {"command": "python bench.py --workload graphslam --steps 10 --warmup 3", "kernels": {},
-       "note": "per-dispatch averages over all dispatches of the run (link passes of 1M queries each); FETCH_SIZE / WRITE_SIZE in KiB"}
+       "note": "per-dispatch averages over all dispatches of the run (a search dispatch covers up to 64 link passes of 1M queries each: 84 links = one of 64 + one of 20 per step); FETCH_SIZE / WRITE_SIZE in KiB"}
 for p in ("gs_fetch", "gs_write"):
     fn = os.path.join(src, p, "p_counter_collection.csv")
     if not os.path.exists(fn):
@@ -44,4 +47,4 @@ fn = os.path.join(src, "gs.json")
 if os.path.exists(fn):
     open(os.path.join("profiles", pre + "_graphslam_bench_under_rocprof.json"), "w").write(open(fn).read())
 print(open(os.path.join("profiles", pre + "_graphslam_kernel_stats.csv")).read()[:1500])
-print(json.dumps(pmc["kernels"].get("k_search", {}), indent=1))
+print(json.dumps(pmc["kernels"].get("k_search (several links per launch)", pmc["kernels"].get("k_search", {})), indent=1))
