@@ -1790,7 +1790,11 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     if ((rc = sl->kpos.ensure(maxN * sizeof(int)))) return rc;
     if ((rc = sl->part.ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
     if (max_need > 0) {
-      const size_t lanes = search_max_lanes(maxN);
+      // the stack overflow area of a batch: one column per lane of ITS grid (a tenth of what the stand-alone kernels'
+      // common area needs, and there are up to 64 of these)
+      SearchArgs probe{};
+      probe.n = maxN;
+      const size_t lanes = (size_t)std::max(search_multi_prepare(probe, 1), search_multi_prepare(probe, G)) * 128;   // the shortest slab any group gets
       if ((rc = sl->ovf_m2.ensure(lanes * max_need * sizeof(double)))) return rc;
       if ((rc = sl->ovf_ref.ensure(lanes * max_need * sizeof(uint32_t)))) return rc;
     }
