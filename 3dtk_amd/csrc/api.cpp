@@ -1794,7 +1794,8 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       // common area needs, and there are up to 64 of these)
       SearchArgs probe{};
       probe.n = maxN;
-      const size_t lanes = (size_t)std::max(search_multi_prepare(probe, 1), search_multi_prepare(probe, G)) * 128;   // the shortest slab any group gets
+      const size_t lanes = (size_t)std::max(search_multi_prepare(probe, 1), search_multi_prepare(probe, G)) * 256;   // the shortest slab any
+                                                                                                        // group gets; 256: the widest workgroup
       if ((rc = sl->ovf_m2.ensure(lanes * max_need * sizeof(double)))) return rc;
       if ((rc = sl->ovf_ref.ensure(lanes * max_need * sizeof(uint32_t)))) return rc;
     }
@@ -1854,13 +1855,13 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   if ((rc = stage_pinned(c, tab.data(), total, &staged))) return rc;
   HIPCHK(hipMemcpyAsync(c->multi_args.p, staged, total, hipMemcpyHostToDevice, s));
   char* dbase = static_cast<char*>(c->multi_args.p);
-  const int thresh = search_multi_thresh(maxN);
+  const int thresh = search_multi_thresh(maxN), cls = search_multi_class(maxN);
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G), nb = l1 - l0;
     const bool timed = (gi == ngroups - 1);      // tdtk_last_kernel_ms: the last group's search launch
     if (timed) HIPCHK(hipEventRecord(c->e0, s));
     HIPCHK(launch_search_multi(reinterpret_cast<const SearchArgs*>(dbase + o_sa) + l0,
-                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], thresh, c->counting, s));
+                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], cls, thresh, c->counting, s));
     if (timed) { HIPCHK(hipEventRecord(c->e1, s)); c->ev_pending = true; }
     HIPCHK(launch_accum_multi(reinterpret_cast<const AccumArgs*>(dbase + o_aa) + l0,
                               reinterpret_cast<const uint32_t*>(dbase + o_ab) + l0 + gi, nb, a_total[gi], want,
@@ -1887,8 +1888,11 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
   {
     const int gb = link_batch_max();
     bool ok = gb > 1 && nlinks > 1 && (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) || (want & 7u) == TDTK_WANT_LUM || (want & 7u) == 0u);
-    for (int i = 0; i < nlinks && ok; i++)
-      ok = second[i]->N > 0 && search_can_fuse(second[i]->N) && search_multi_thresh(second[i]->N) == search_multi_thresh(maxN);
+    const int cls = search_multi_class(maxN);
+    ok = ok && cls != 0;
+    for (int i = 0; i < nlinks && ok; i++)      // one kernel family (and refill threshold) for the whole call
+      ok = second[i]->N > 0 && search_multi_class(second[i]->N) == cls &&
+           (cls != 20 || search_multi_thresh(second[i]->N) == search_multi_thresh(maxN));
     if (ok) {
       for (int i = 0; i < nlinks; i++) {
         const tdtk_tree* t = first[i];

@@ -673,14 +673,13 @@ __device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx,
 // k_search: the hot kernel
 // ------------------------------------------------------------------------------------------
 template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4>
-__global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
+__device__ __forceinline__ void search_plain_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
   __shared__ uint32_t lds_ref[SD][BLOCK];
 
-  const uint32_t nb = gridDim.x;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
-  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;  // for the overflow slot only
+  const uint32_t chunk = xcd_chunk(bid, nb);
+  const size_t gl = (size_t)bid * BLOCK + threadIdx.x;  // for the overflow slot only
 
   LaneStack<BLOCK, SD> st;
   st.l_m2 = &lds_m2[0][threadIdx.x];
@@ -730,6 +729,23 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
   }
 }
 
+template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
+{
+  search_plain_body<BLOCK, SD, COUNT, DIRMODE, UNI, WPS, PTS>(a, blockIdx.x, gridDim.x);
+}
+// several batches in one launch (see k_search_refill_multi)
+template <int BLOCK, int SD, bool COUNT, bool UNI, int WPS>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_multi(const SearchArgs* __restrict__ args, const uint32_t* __restrict__ base,
+                                                             int nbatch)
+{
+  int l = 0;
+  while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
+  l = __builtin_amdgcn_readfirstlane(l);
+  const uint32_t b0 = base[l], b1 = base[l + 1];
+  search_plain_body<BLOCK, SD, COUNT, 0, UNI, WPS>(args[l], blockIdx.x - b0, b1 - b0);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_search_g8: eight lanes per query, for batches too small to fill the machine with one lane per
 // query (a bundled 81K-point scan gives 1.2 waves per SIMD; the kernel then runs as long as the
@@ -741,16 +757,15 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
 // returns.  Same visiting order as k_search, hence the same indices.
 // ------------------------------------------------------------------------------------------
 template <int BLOCK, int SD, int GS = 8>
-__global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
+__device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   constexpr int NG = BLOCK / GS;
   __shared__ double lds_m2[SD][NG];
   __shared__ uint32_t lds_ref[SD][NG];
 
-  const uint32_t nb = gridDim.x;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
+  const uint32_t chunk = xcd_chunk(bid, nb);
   const int grp = threadIdx.x / GS, sub = threadIdx.x & (GS - 1);
-  const size_t gg = (size_t)blockIdx.x * NG + grp;     // overflow slot of the group
+  const size_t gg = (size_t)bid * NG + grp;     // overflow slot of the group
 
   LaneStack<NG, SD> st;
   st.l_m2 = &lds_m2[0][grp];
@@ -882,6 +897,22 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, WAVE);
   return t;
+}
+
+template <int BLOCK, int SD, int GS = 8>
+__global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
+{
+  search_g8_body<BLOCK, SD, GS>(a, blockIdx.x, gridDim.x);
+}
+template <int BLOCK, int SD, int GS>
+__global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __restrict__ args, const uint32_t* __restrict__ base,
+                                                           int nbatch)
+{
+  int l = 0;
+  while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
+  l = __builtin_amdgcn_readfirstlane(l);
+  const uint32_t b0 = base[l], b1 = base[l + 1];
+  search_g8_body<BLOCK, SD, GS>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2213,8 +2244,12 @@ hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hi
 // generation of waves becomes the tail: 84 links of 1M points in launches of 64: 224 -> 12.6 ms, 320 -> 12.0, 512 -> 11.5,
 // 640 -> 11.4, 1024 -> 11.5, 1536 -> 11.7; a rank's 11 links in one launch: 320 -> 1.79 ms, 448 -> 1.77, 640 -> 1.81
 // (three streams: 12.6 / 1.89 on the same box).
+int search_multi_class(size_t n) { const int v = pick_variant(n); return (v == 20 || v == 4 || v == 10) ? v : 0; }
 uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
 {
+  const int v = pick_variant(a.n);
+  if (v == 4) return search_grid(a.n);
+  if (v == 10) { const uint32_t g = g8_grid(a.n) / 2; return g < 8 ? 8u : (g + 7) / 8 * 8; }
   int qpw;
   uint32_t nb = refill_grid_b(a.n, 128, &qpw, 2);
   if (!getenv("TDTK_REFILL_QPW")) {
@@ -2232,10 +2267,17 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
   return nb;
 }
 int search_multi_thresh(size_t n) { return refill_thresh(n); }
-hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int thresh,
+hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int cls, int thresh,
                                bool count, hipStream_t s)
 {
   if (!nbatch || !total_blocks) return hipSuccess;
+  if (cls == 4 || cls == 10) {   // small batches: one query per lane / four lanes per query, as launch_search would pick
+    const dim3 gs(total_blocks), bs(SEARCH_BLOCK);
+    if (count) hipLaunchKernelGGL((k_search_multi<SEARCH_BLOCK, 8, true, false, 1>), gs, bs, 0, s, d_args, d_base, nbatch);
+    else if (cls == 4) hipLaunchKernelGGL((k_search_multi<SEARCH_BLOCK, 4, false, true, 1>), gs, bs, 0, s, d_args, d_base, nbatch);
+    else hipLaunchKernelGGL((k_search_g8_multi<256, 16, 4>), gs, dim3(256), 0, s, d_args, d_base, nbatch);
+    return hipGetLastError();
+  }
   const dim3 g(total_blocks), b(128);
   if (count) {
     switch (thresh) {
