@@ -171,7 +171,7 @@ Ctx::~Ctx()
 
 static thread_local std::map<int, std::unique_ptr<Ctx>> g_ctx;
 
-static int get_ctx(int device, Ctx** out)
+static int get_ctx(int device, Ctx** out, bool touches_scans = true)
 {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -197,7 +197,7 @@ static int get_ctx(int device, Ctx** out)
     it = g_ctx.emplace(device, std::move(c)).first;
   }
   *out = it->second.get();
-  wait_deferred(device);
+  if (touches_scans) wait_deferred(device);    // (the timing / counter read-outs do not: they must not end the overlap)
   return TDTK_OK;
 }
 
@@ -986,7 +986,7 @@ int tdtk_last_kernel_ms(double* nn_ms)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { set_error("no device"); return TDTK_EDEVICE; }
   Ctx* c;
-  int rc = get_ctx(dev, &c);
+  int rc = get_ctx(dev, &c, false);
   if (rc) return rc;
   return collect_ms(c, nn_ms);
 }
@@ -997,7 +997,7 @@ int tdtk_last_timings(double out[4])
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { set_error("no device"); return TDTK_EDEVICE; }
   Ctx* c;
-  int rc = get_ctx(dev, &c);
+  int rc = get_ctx(dev, &c, false);
   if (rc) return rc;
   rc = collect_ms(c, &out[0], &out[1]);
   out[2] = c->last_normals_ms;
