@@ -322,6 +322,27 @@ def bench_icp(args, rank, world, local):
     info = tree.info()
     _ = data.handle
     mini = tdtk.icp6D_QUAT(True)
+    # A box that has just been leased is not in its steady state: the first processes after the lease see ~0.5 ms of
+    # host-side latency per iteration (wake-up of the waiting thread) while the kernels run at full speed, for some
+    # tens of seconds.  Before the contract's warm-up the same loop therefore runs on a scratch copy of the data
+    # scan until the time an iteration spends outside its kernels has settled (or 20 s have passed); nothing of it
+    # touches the scans that are timed.
+    settle = {"seconds": 0.0, "rounds": 0, "outside_ms_first": None, "outside_ms_last": None}
+    ts0 = time.perf_counter()
+    while time.perf_counter() - ts0 < 20.0:
+        scratch = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
+        _ = scratch.handle
+        probe = tdtk.icp6D(mini, 25.0, 40, quiet=True, epsilonICP=-1.0)
+        tq = time.perf_counter(); itp = probe.match(model, scratch); dq = time.perf_counter() - tq
+        outside = dq * 1e3 / (itp + 1) - (probe.last["nn_ms"] + probe.last["sums_ms"]) / (itp + 1)
+        del scratch
+        settle["rounds"] += 1
+        if settle["outside_ms_first"] is None:
+            settle["outside_ms_first"] = outside
+        settle["outside_ms_last"] = outside
+        if outside < 0.04 and settle["rounds"] >= 2:
+            break
+    settle["seconds"] = time.perf_counter() - ts0
     # warm-up: W untimed iterations of the same loop (also brings the pose close to T)
     icp_w = tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0)
     icp_w.match(model, data)
@@ -394,7 +415,7 @@ def bench_icp(args, rank, world, local):
         "icp_iters_per_s": steps / dt,
         "pairs_last": last["pairs"], "rms_last": last["rms"], "pose_max_abs_err": pose_err,
         "host_buffer_path": host_path, "per_scan_preparation": prep,
-        "pair_sums_ms": sums_ms, "outside_kernels_ms": dt * 1e3 / steps - k_ms - sums_ms,
+        "pair_sums_ms": sums_ms, "outside_kernels_ms": dt * 1e3 / steps - k_ms - sums_ms, "settle": settle,
         "roofline": roof,
     }
     # tree build (A1) on the device: a latency chain (the reference's serial-order fp64 centroid), reported against
