@@ -594,11 +594,13 @@ static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
 // registers take the kernel from 7 to 4 waves per SIMD and every retire waits for its own gather, so the search
 // grows by about what the separate pair-sum pass costs (1M-vs-1M ICP: 0.2881 + 0.0072 ms fused against
 // 0.2708 + 0.0280 ms; 4M: 1.179 + 0.016 against 0.965 + 0.058 -- gpurun_out/r2a/sweep.log).  TDTK_FUSE_SUMS=1 selects it.
-static bool fuse_enabled()
+static int fuse_mode()   // 0: separate k_accum, 1: at retire time, 3: by each wave after its last query
 {
   const char* e = getenv("TDTK_FUSE_SUMS");
-  return e && e[0] == '1';
+  const int v = e ? atoi(e) : 0;
+  return (v == 1 || v == 3) ? v : 0;
 }
+static bool fuse_enabled() { return fuse_mode() != 0; }
 
 // acc[ACC_TOTAL] (sums about `shift`) -> the reference's quantities
 static void finish_sums(const double* acc, const double shift[3], size_t nq, unsigned want, tdtk_pair_sums* o)
@@ -768,7 +770,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     if (fused) {
       rows = search_fused_rows(N);
       if ((rc = c->ws[WS_PART].ensure((size_t)rows * ACC_TOTAL * sizeof(double)))) return rc;
-      sa.fuse = 1; sa.A = A;
+      sa.fuse = fuse_mode(); sa.A = A;
       for (int k = 0; k < 3; k++) sa.shift[k] = sh[k];
       sa.partials = c->ws[WS_PART].as<double>();
     }

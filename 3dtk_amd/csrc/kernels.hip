@@ -1259,6 +1259,59 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       atomicAdd(&a.counters[2], s_pts);
     }
   }
+  if constexpr (FUSE == 3) {
+    // The base pair sums of this wave's own queries, AFTER its last query has retired: the accumulators are not live
+    // during the search (no occupancy cost, unlike FUSE 1), and the waves that finish early -- the median wave is done
+    // after 77 % of a launch -- do this work while the machine would otherwise wait for the slowest ones.  The hits and
+    // the moved coordinates were written by other lanes of this wave: make them visible before reading them back.  A
+    // fence of workgroup scope is enough (the CU's L1 is write-through and shared by the workgroup) and costs a wait;
+    // one of agent scope writes back and invalidates the XCD's L2 once per wave: k_search 0.218 -> 0.322 ms.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // four queries per lane and trip, all their loads issued before the first use: two memory round trips for a whole
+    // slab of up to 256 queries instead of one pair per 64
+    const uint32_t slab = (uint32_t)a.qpw, sub32 = (uint32_t)sub;
+    for (uint32_t j0 = 0; j0 < slab; j0 += 4 * WAVE) {
+      size_t qq[4];
+      int kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        uint32_t j = j0 + (uint32_t)u * WAVE + lane, ph = 0;
+        const bool in = j < slab;
+        while (j >= sub32 && in) { j -= sub32; ph++; }
+        qq[u] = reg0 + (size_t)ph * pstride + j;
+        kk[u] = (in && qq[u] < a.n) ? a.kpos[qq[u]] : -1;
+      }
+#pragma unroll
+      for (int h = 0; h < 4; h += 2) {
+        double cx[2], cy[2], cz[2], tx[2], ty[2], tz[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          cx[u] = cy[u] = cz[u] = tx[u] = ty[u] = tz[u] = 0.0;
+          if (kk[h + u] >= 0) {
+            const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)kk[h + u] << 5));
+            cx[u] = c.x; cy[u] = c.y; cz[u] = c.z;
+            tx[u] = a.x[qq[h + u]]; ty[u] = a.y[qq[h + u]]; tz[u] = a.z[qq[h + u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          if (kk[h + u] < 0) continue;
+          double mx, my, mz;
+          dev_xf3(a.A, cx[u], cy[u], cz[u], mx, my, mz);  // searchTree.cc:147
+          const double px = mx - tx[u], py = my - ty[u], pz = mz - tz[u];
+          acc[ACC_N] += 1.0;
+          acc[ACC_SUM] += px * px + py * py + pz * pz;
+          const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
+          const double d0 = tx[u] - a.shift[0], d1 = ty[u] - a.shift[1], d2 = tz[u] - a.shift[2];
+          acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
+          acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
+          acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
+          acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
+          acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+        }
+      }
+    }
+  }
   if (FUSE) {
     // wave64 reduction, then across the workgroup's waves through LDS: one row of ACC_TOTAL per workgroup
     constexpr int NW = BLOCK / WAVE;
@@ -2026,7 +2079,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     a.trace = (want >= 0 && launches.fetch_add(1) == want) ? 1 : 0;
   }
   a.pool_slab = 0; a.region = 0;
-  const int pool_pct = refill_pool_pct(a.n, a.side_by_side);
+  const int pool_pct = (FUSE == 3) ? 0 : refill_pool_pct(a.n, a.side_by_side);
   if (pool_pct > 0) {
     const size_t R = (((a.n + 7) / 8) + 63) & ~(size_t)63;             // queries per XCD region
     const size_t wpx = (size_t)(nb >> 3) * 2;                          // waves per XCD (128-thread workgroups)
@@ -2117,7 +2170,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
     if (v == 30 && (!a.q_ctr || !a.q_ctr_next)) return hipErrorInvalidValue;
     if (count) {
       // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
-      if (v == 20) { if (a.fuse == 2) launch_refill128<true, 2>(a, s); else if (a.fuse) launch_refill128<true, 1>(a, s); else launch_refill128<true, 0>(a, s); }
+      if (v == 20) { if (a.fuse == 3) launch_refill128<true, 3>(a, s); else if (a.fuse == 2) launch_refill128<true, 2>(a, s); else if (a.fuse) launch_refill128<true, 1>(a, s); else launch_refill128<true, 0>(a, s); }
       else if (v == 30) launch_stream128<true>(a, s);
       else if (v == 40) launch_step128<true, false>(a, s);
       else if (v == 41) launch_step128<true, true>(a, s);
@@ -2137,7 +2190,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
       case 30: launch_stream128<false>(a, s); break;
       case 40: launch_step128<false, false>(a, s); break;
       case 41: launch_step128<false, true>(a, s); break;
-      case 20: if (a.fuse == 2) launch_refill128<false, 2>(a, s); else if (a.fuse) launch_refill128<false, 1>(a, s); else launch_refill128<false, 0>(a, s); break;
+      case 20: if (a.fuse == 3) launch_refill128<false, 3>(a, s); else if (a.fuse == 2) launch_refill128<false, 2>(a, s); else if (a.fuse) launch_refill128<false, 1>(a, s); else launch_refill128<false, 0>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
       case 10: hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid(a.n) / 2 < 8 ? 8 : (g8_grid(a.n) / 2 + 7) / 8 * 8), dim3(256), 0, s, a); break;
