@@ -233,8 +233,9 @@ struct BPiece {
 struct BSum {                  // what a piece (or a run of pieces) does to M, by parity of the incoming M
   long long T0, T1, mn0, mn1, mx0, mx1;   // (scalar fields: indexing an array by the parity sends the struct to scratch)
   uint32_t eb, reset;          // exponent bits | sign << 11 it assumes; reset: nothing before it counts
+  uint32_t cnt, pad;           // walked pieces in it (a plain count: `reset` does not touch it) -- their rank in the walk list
 };
-__device__ __forceinline__ void bsum_neutral(BSum& r) { r.T0 = r.T1 = r.mn0 = r.mn1 = r.mx0 = r.mx1 = 0; r.eb = 0xFFFFu; r.reset = 0u; }
+__device__ __forceinline__ void bsum_neutral(BSum& r) { r.T0 = r.T1 = r.mn0 = r.mn1 = r.mx0 = r.mx1 = 0; r.eb = 0xFFFFu; r.reset = 0u; r.cnt = 0u; r.pad = 0u; }
 struct BPre { double v, lo, hi; uint32_t reset, pad; };   // plain running sum and running bounds since the node's first piece
 struct BPreOp {
   __device__ BPre operator()(const BPre& a, const BPre& b) const
@@ -247,10 +248,10 @@ struct BPreOp {
 struct BSumOp {
   __device__ BSum operator()(const BSum& a, const BSum& b) const
   {
-    if (b.reset) return b;
-    if (b.eb == BIG_ANY) return a;
     BSum r;
-    if (a.eb == BIG_ANY) { r = b; r.reset = a.reset; return r; }
+    if (b.reset) { r = b; r.cnt = a.cnt + b.cnt; return r; }
+    if (b.eb == BIG_ANY) { r = a; r.cnt = a.cnt + b.cnt; return r; }
+    if (a.eb == BIG_ANY) { r = b; r.reset = a.reset; r.cnt = a.cnt + b.cnt; return r; }
     const bool bad = a.eb != b.eb || a.eb == BIG_BAD;
     {   // incoming M even
       const bool pa = (a.T0 & 1ll) != 0;
@@ -270,6 +271,7 @@ struct BSumOp {
     }
     r.eb = bad ? BIG_BAD : a.eb;
     r.reset = a.reset;
+    r.cnt = a.cnt + b.cnt; r.pad = 0u;
     return r;
   }
 };
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(64) k_big_emulate(const double* __restrict__ c
   if ((dbg & 3) == 2) flags |= 8u;
   pc.ebits = ebits; pc.flags = flags;
   pieces[o] = pc;
-  if (flags & 8u) { r.reset = 1u; own[o] = r; return; }        // a walked piece: nothing before it composes past it
+  if (flags & 8u) { r.reset = 1u; r.cnt = 1u; own[o] = r; return; }   // a walked piece: nothing before it composes past it
   r.T0 = S0; r.T1 = S1; r.mn0 = mn0; r.mn1 = mn1; r.mx0 = mx0; r.mx1 = mx1;
   r.eb = ebits | ((flags & 1u) << 11); r.reset = (flags & 4u) ? 1u : 0u;
   own[o] = r;
@@ -455,7 +457,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
                                                     const double* __restrict__ cz, uint32_t nblocks,
                                                     const BPiece* __restrict__ pieces, const BPre* __restrict__ preout,
                                                     const BSum* __restrict__ own, const BSum* __restrict__ comp,
-                                                    BMeas* __restrict__ out, int dbg)
+                                                    const uint32_t* __restrict__ list, BMeas* __restrict__ out, int dbg)
 {
   __shared__ alignas(16) double walk[256 / WAVE][BIG_CH * BIG_CL + 16];   // + 16: the chain's last request reads past the data
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
@@ -527,25 +529,44 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
     }
   };
 
-  // the records of a batch of 64 pieces -- the piece and the folded run in front of it -- are requested one batch ahead
-  BPiece pcN; BSum RN;
-  auto load_batch = [&](uint32_t i) {
-    pcN.len = 0; pcN.flags = 0; pcN.start = 0; pcN.lo = first; pcN.hi = first;
-    bsum_neutral(RN);
-    if (i < np) { const uint32_t sl = big_piece_slot(a, i); pcN = pa[sl]; RN = ca[sl]; }
+  // The walked pieces of all nodes stand in one list in run order (k_big_list: their rank is the count the run scan
+  // carries along), so the wave goes from one walked piece of its node to the next -- 64 list entries per trip, the
+  // records of the next 64 requested a trip ahead -- instead of reading the records of every piece of the node to find
+  // them: on zero-mean coordinates (the sum wanders through zero: the root and its first descendants of a centred
+  // cloud) 3-8 % of the pieces are walked, and a lone wave pays ~2 us for every dependent round trip to memory.
+  const uint32_t sl_first = big_piece_slot(a, 0u), sl_last = big_piece_slot(a, np - 1u);
+  const uint32_t pq0 = (a + 1u) / BIG_CH;
+  const BSum c_last = ca[sl_last], o_last = oa[sl_last];
+  const uint32_t r0 = __builtin_amdgcn_readfirstlane(ca[sl_first].cnt);
+  const uint32_t r1 = __builtin_amdgcn_readfirstlane(c_last.cnt + o_last.cnt);
+  {
+    const BPre bb = preout[ao + sl_last];          // bounds since the node's first point (as for the two other axes)
+    lo = bb.lo; hi = bb.hi;
+  }
+  if ((dbg & 16) && lane == 0) printf("stitch: node at %u, %u points, %u pieces, %u walked\n", a, n, np, r1 - r0);
+  auto load_slots = [&](uint32_t r) -> uint32_t { return (r + lane < r1) ? list[r + lane] - (uint32_t)ao : 0xFFFFFFFFu; };
+  uint32_t slotN = load_slots(r0), slotNN = load_slots(r0 + WAVE);
+  uint32_t stN = 0, lnN = 0; BSum RN;
+  auto load_recs = [&](uint32_t slot) {
+    stN = 0; lnN = 0; bsum_neutral(RN);
+    if (slot != 0xFFFFFFFFu) { stN = pa[slot].start; lnN = pa[slot].len; RN = ca[slot]; }
   };
-  load_batch(lane);
-  for (uint32_t i0 = 0; i0 < np; i0 += WAVE) {
-    const uint32_t i = i0 + lane;
-    const uint32_t p_start = pcN.start, p_len = pcN.len, p_flags = pcN.flags;
+  load_recs(slotN);
+  for (uint32_t rr = r0; rr < r1; rr += WAVE) {
+    const uint32_t slot = slotN, p_start = stN, p_len = lnN;
     const BSum R = RN;
-    lo = (pcN.lo < lo) ? pcN.lo : lo;
-    hi = (hi < pcN.hi) ? pcN.hi : hi;
-    load_batch(i + WAVE);
-    unsigned long long fm = __ballot(i < np && (p_flags & 8u));
-    const unsigned long long fullm = __ballot(p_len == BIG_CH);
-    // clusters: up to BIG_CL consecutive walked pieces, all of them full (a partial piece -- the first or the last of
-    // the node -- goes alone); the points of the next cluster are requested before the current one is walked
+    slotN = slotNN; slotNN = load_slots(rr + 2u * WAVE);
+    load_recs(slotN);
+    const bool valid = slot != 0xFFFFFFFFu;
+    const int p_idx = (slot & 1u) ? 0 : (int)(slot / 2u - pq0);          // piece index in the node's run
+    unsigned long long fm = __ballot(valid);
+    const unsigned long long fullm = __ballot(valid && p_len == BIG_CH);
+    // entry j + 1 continues entry j in memory: the next block of the same node
+    const uint32_t nslot = __shfl_down(slot, 1, WAVE);
+    const unsigned long long adjm = __ballot(valid && lane < WAVE - 1 && !(slot & 1u) && nslot == slot + 2u);
+    // clusters: up to BIG_CL walked pieces that follow each other in memory, all of them full (a partial piece -- the
+    // first or the last of the node -- goes alone); the points of the next clusters are requested before the current
+    // one is walked
     struct Cl { int j, c; uint32_t cnt; double v[BIG_CL]; };
     // always BIG_CL loads, in straight-line code (a load that is not needed reads the node's first point): the compiler
     // can then count the loads in flight and wait for the oldest cluster only -- behind a branch it waits for all of them
@@ -553,16 +574,16 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
       Cl q;
       const bool any = fm != 0ull;
       q.j = any ? __ffsll((long long)fm) - 1 : 0;
-      const unsigned long long run = fm >> q.j, fr = fullm >> q.j;
-      const unsigned long long gap = ~(run & fr);
-      int c = gap ? __ffsll((long long)gap) - 1 : 64;      // leading walked AND full pieces
+      const unsigned long long fr = fullm >> q.j, ad = adjm >> q.j;
+      const unsigned long long gap = ~(fr & ((ad << 1) | 1ull));       // bit k: entry j + k is full and follows j + k - 1
+      int c = gap ? __ffsll((long long)gap) - 1 : 64;
       if (c > BIG_CL) c = BIG_CL;
       const uint32_t st = __shfl(p_start, q.j, WAVE), ln = __shfl(p_len, q.j, WAVE);
       q.cnt = (uint32_t)c * BIG_CH;
       if (c == 0) { c = 1; q.cnt = ln; }
       if (!any) { c = 0; q.cnt = 0; }
       q.c = c;
-      fm &= ~(((1ull << c) - 1ull) << q.j);
+      fm &= ~(((c >= 64) ? ~0ull : ((1ull << c) - 1ull)) << q.j);
 #pragma unroll
       for (int k = 0; k < BIG_CL; k++) {
         const uint32_t off = (uint32_t)k * BIG_CH + lane;
@@ -576,13 +597,13 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
       const Cl cur = q0;
       q0 = q1; q1 = q2; q2 = fetch_cluster();
       const int j = cur.j, c = cur.c;
-      // the run in front of piece i0 + j: fetched by lane j
+      // the run in front of this walked piece: fetched by lane j
       BSum S;
       S.T0 = __shfl(R.T0, j, WAVE); S.T1 = __shfl(R.T1, j, WAVE);
       S.mn0 = __shfl(R.mn0, j, WAVE); S.mn1 = __shfl(R.mn1, j, WAVE);
       S.mx0 = __shfl(R.mx0, j, WAVE); S.mx1 = __shfl(R.mx1, j, WAVE);
-      S.eb = __shfl(R.eb, j, WAVE); S.reset = 0u;
-      const int idx = (int)i0 + j;
+      S.eb = __shfl(R.eb, j, WAVE); S.reset = 0u; S.cnt = 0u; S.pad = 0u;
+      const int idx = __shfl(p_idx, j, WAVE);
       if (idx - 1 > done) apply_run(done + 1, idx - 1, S);
 #pragma unroll
       for (int k = 0; k < BIG_CL; k++)
@@ -591,16 +612,21 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
       done = idx + c - 1;
     }
   }
-  if ((int)np - 1 > done) {
-    const uint32_t sl = big_piece_slot(a, np - 1u);
-    apply_run(done + 1, (int)np - 1, BSumOp()(ca[sl], oa[sl]));
-  }
-  lo = wave_min(lo); hi = wave_max(hi);
+  if ((int)np - 1 > done) apply_run(done + 1, (int)np - 1, BSumOp()(c_last, o_last));
   if (lane == 0) {
     out[sgi].lo[ax] = lo;
     out[sgi].hi[ax] = hi;
     out[sgi].mean[ax] = sum / (double)n;
   }
+}
+
+// the walked pieces of every big node, in run order: entry `rank` of the list is the slot of the piece (the rank is the
+// number of walked pieces in the slots before it, carried along by the run scan)
+__global__ void k_big_list(const BSum* __restrict__ own, const BSum* __restrict__ comp, uint32_t nsl, uint32_t* __restrict__ list)
+{
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nsl) return;
+  if (own[o].cnt) list[comp[o].cnt] = o;
 }
 
 __global__ void k_big_dbg_compare(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, const BMeas* __restrict__ a,
@@ -917,11 +943,12 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     BPiece* pieces = (BPiece*)(arena + O[24]);
     BPre *prein = (BPre*)(arena + O[25]), *preout = (BPre*)(arena + O[26]);
     BSum *own = (BSum*)(arena + O[27]), *comp = (BSum*)(arena + O[28]);
+    uint32_t* wlist = (uint32_t*)(arena + O[29]);
     const uint32_t nblocks = cdiv(M, BIG_CH);
     static const bool chain_only = [] { const char* e = getenv("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
     const bool use_big = !chain_only && M >= BIG_MIN;
     const int big_dbg_all = getenv("TDTK_BIG_DEBUG") ? atoi(getenv("TDTK_BIG_DEBUG")) : 0;
-    const int big_dbg = big_dbg_all & 3;   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
+    const int big_dbg = big_dbg_all & (3 | 16);   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
     BCHK(hipMemsetAsync(small, 0, 256, s));
@@ -960,12 +987,13 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
                              preout, own, big_dbg);
           stb = scan_tmp;
           BSum ident;   // exclusive: comp[slot] = everything since the last reset BEFORE the slot = the run in front of it
-          ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u;
+          ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u; ident.cnt = 0u; ident.pad = 0u;
           BCHK(rocprim::exclusive_scan(tmp, stb, own, comp, ident, nsl, BSumOp(), s));
+          hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl, 256)), dim3(256), 0, s, own, comp, (uint32_t)nsl, wlist);
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
-                             pieces, preout, own, comp, meas, big_dbg);
+                             pieces, preout, own, comp, wlist, meas, big_dbg);
           if (big_dbg_all & 8) {
-            BMeas* meas2 = (BMeas*)(arena + O[29]);
+            BMeas* meas2 = (BMeas*)(arena + O[30]);
             hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas2, 0xFFFFFFFFu);
             hipLaunchKernelGGL(k_big_dbg_compare, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, meas, meas2, level);
           }
@@ -1081,7 +1109,8 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(sizeof(BPiece) * nsl);                                               // 24
   take(sizeof(BPre) * nsl); take(sizeof(BPre) * nsl);                       // 25 26 plain prefix in / out
   take(sizeof(BSum) * nsl); take(sizeof(BSum) * nsl);                       // 27 28 piece summaries, folded runs
-  if (getenv("TDTK_BIG_DEBUG") && (atoi(getenv("TDTK_BIG_DEBUG")) & 8)) take(sizeof(BMeas) * n1);   // 29 debug: the chain's results
+  take(4 * (nsl + 1));                                                      // 29 slots of the walked pieces, in run order
+  if (getenv("TDTK_BIG_DEBUG") && (atoi(getenv("TDTK_BIG_DEBUG")) & 8)) take(sizeof(BMeas) * n1);   // 30 debug: the chain's results
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
