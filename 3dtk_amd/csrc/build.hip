@@ -970,6 +970,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       for (uint32_t b = 0; b < batch && level < BUILD_MAX_LEVELS; b++, level++) {
         size_t bound = (size_t)known << ((level - known_at) < 31 ? (level - known_at) : 31);
         if (bound > M) bound = M;
+        // the nodes of a level are the children of the level above's internal nodes: disjoint runs of more than
+        // `bucket` points each, two children per run (at 1M points and buckets of 20 the doubling bound reaches the
+        // point count at level 16, sixty times the nodes there are)
+        const size_t cap = 2 * (M_ / ((size_t)(bucket > 0 ? bucket : 0) + 1));
+        if (level > 0 && bound > cap) bound = cap;
         if (bound < 1) bound = 1;
         const BLevel* lv = lvl + level;
         // nodes of BIG_MIN points and more can only exist while a quarter of a balanced node is that large (below that
