@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
 #define BIG_BAD 0xFFFEu        // BSum.eb of a run whose pieces disagree about the binade: never applicable
 struct BPiece {
   uint32_t start, len;         // positions [start, start + len) of the run; len == 0: no piece in this slot
-  uint32_t ebits, flags;       // biased exponent of the predicted running sum; flags: 1 = it is negative, 2 = cannot be
+  uint32_t ebits, flags;       // biased exponent of the predicted running sum (k_big_stats parks the node's index here); flags: 1 = it is negative, 2 = cannot be
                                // summarised, 4 = first piece of its node, 8 = walk it (includes 2)
   double lo, hi, csum, pre;    // bounding values, plain sum of the piece, plain sum of everything before it
 };
@@ -316,32 +316,33 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
   const uint32_t bend = (base + BIG_CH < M) ? base + BIG_CH : M;
   const uint32_t p = base + lane;
   // the node at the block's first position: a tail piece if it is big and started earlier
-  uint32_t t_start = 0, t_end = 0, t_first = 0xFFFFFFFFu;
+  uint32_t t_start = 0, t_end = 0, t_first = 0xFFFFFFFFu, t_sid = 0;
   {
     const uint32_t sid = seg_of[base];
     if (sid != 0xFFFFFFFFu) {
       const BSeg sg = segs[sid];
       if (sg.n >= BIG_MIN && sg.start < base) {
-        t_start = base; t_end = (sg.start + sg.n < bend) ? sg.start + sg.n : bend;
+        t_start = base; t_end = (sg.start + sg.n < bend) ? sg.start + sg.n : bend; t_sid = sid;
         if (sg.start + 1u == base) t_first = sg.start;
       }
     }
   }
   // a big node whose first point lies in this block: a head piece behind that point
-  uint32_t h_start = 0, h_end = 0, h_first = 0;
+  uint32_t h_start = 0, h_end = 0, h_first = 0, h_sid = 0;
   {
-    uint32_t found = 0xFFFFFFFFu, fend = 0;
+    uint32_t found = 0xFFFFFFFFu, fend = 0, fsid = 0;
     if (p < bend) {
       const uint32_t sid = seg_of[p];
       if (sid != 0xFFFFFFFFu && (p == 0 || seg_of[p - 1] != sid)) {
         const BSeg sg = segs[sid];
-        if (sg.start == p && sg.n >= BIG_MIN) { found = p; fend = sg.start + sg.n; }
+        if (sg.start == p && sg.n >= BIG_MIN) { found = p; fend = sg.start + sg.n; fsid = sid; }
       }
     }
     const unsigned long long any = __ballot(found != 0xFFFFFFFFu);
     if (any) {
       const int src = __ffsll((long long)any) - 1;
       const uint32_t fp = __shfl(found, src, WAVE), e = __shfl(fend, src, WAVE);
+      h_sid = __shfl(fsid, src, WAVE);
       h_first = fp; h_start = fp + 1; h_end = (e < bend) ? e : bend;
       if (h_start >= h_end) { h_start = h_end = 0; }
     }
@@ -356,14 +357,14 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
   if (t_end > t_start) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
   if (h_end > h_start) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
   if (lane == 0) {
-    BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = 0; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
+    BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = t_sid; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
     BPre tp; tp.v = t.len ? tsum : 0.0; tp.lo = tlo; tp.hi = thi; tp.reset = 0u; tp.pad = 0u;
     if (t.len && t_first != 0xFFFFFFFFu) {
       t.flags = 4u; t.pre = arr[t_first]; tp.v += t.pre; tp.reset = 1u;
       tp.lo = (t.pre < tp.lo) ? t.pre : tp.lo; tp.hi = (tp.hi < t.pre) ? t.pre : tp.hi;
     }
     pieces[o] = t; prein[o] = tp;
-    BPiece h; h.start = h_start; h.len = h_end - h_start; h.ebits = 0; h.flags = 0; h.lo = hlo; h.hi = hhi; h.csum = hsum; h.pre = 0.0;
+    BPiece h; h.start = h_start; h.len = h_end - h_start; h.ebits = h_sid; h.flags = 0; h.lo = hlo; h.hi = hhi; h.csum = hsum; h.pre = 0.0;
     BPre hp; hp.v = 0.0; hp.lo = hlo; hp.hi = hhi; hp.reset = 0u; hp.pad = 0u;
     if (h.len) {
       h.flags = 4u; h.pre = arr[h_first]; hp.v = hsum + h.pre; hp.reset = 1u;
@@ -373,20 +374,32 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
   }
 }
 
-// one lane per piece: what the piece does to the integer mantissa of the running sum, for both parities of it
-__global__ void __launch_bounds__(64) k_big_emulate(const double* __restrict__ cx, const double* __restrict__ cy,
-                                                    const double* __restrict__ cz, uint32_t nblocks,
-                                                    BPiece* __restrict__ pieces, const BPre* __restrict__ preout,
-                                                    BSum* __restrict__ own, int dbg)
+// one lane per piece: what the piece does to the integer mantissa of the running sum, for both parities of it -- along
+// the axis its node will be split on only (k_decide: splitval = mean[axis]; the bounds of all three axes stand at the
+// node's last piece once the bounds scan has run), so `own` has one entry per slot, not one per slot and axis
+__device__ __forceinline__ uint32_t big_split_axis(const BPre* __restrict__ preout, size_t st, uint32_t sl_last)
+{
+  const BPre b0 = preout[sl_last], b1 = preout[st + sl_last], b2 = preout[2 * st + sl_last];
+  const double hx = 0.5 * (b0.hi - b0.lo), hy = 0.5 * (b1.hi - b1.lo), hz = 0.5 * (b2.hi - b2.lo);
+  if (hx > hy) return (hx > hz) ? 0u : 2u;
+  return (hy > hz) ? 1u : 2u;
+}
+__global__ void __launch_bounds__(64) k_big_emulate(const BSeg* __restrict__ segs, const double* __restrict__ cx,
+                                                    const double* __restrict__ cy, const double* __restrict__ cz,
+                                                    uint32_t nblocks, BPiece* __restrict__ pieces,
+                                                    const BPre* __restrict__ preout, BSum* __restrict__ own, int dbg)
 {
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t ax = blockIdx.y;
   if (id >= 2u * nblocks) return;
-  const size_t o = (size_t)ax * nblocks * 2 + id;
-  BPiece pc = pieces[o];
+  const size_t st = (size_t)nblocks * 2;
   BSum r;
   bsum_neutral(r);
-  if (pc.len == 0) { own[o] = r; return; }
+  const BPiece g = pieces[id];                      // start, len, first-of-node and the node are the same on every axis
+  if (g.len == 0) { own[id] = r; return; }
+  const BSeg sg = segs[g.ebits];
+  const uint32_t ax = big_split_axis(preout, st, big_piece_slot(sg.start, big_piece_count(sg.start, sg.n) - 1u));
+  const size_t o = (size_t)ax * st + id;
+  BPiece pc = pieces[o];
   const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + pc.start;
   const double pre = (pc.flags & 4u) ? pc.pre : (preout[o].v - pc.csum);
   const unsigned long long pb = (unsigned long long)__double_as_longlong(pre);
@@ -426,10 +439,10 @@ __global__ void __launch_bounds__(64) k_big_emulate(const double* __restrict__ c
   if ((dbg & 3) == 2) flags |= 8u;
   pc.ebits = ebits; pc.flags = flags;
   pieces[o] = pc;
-  if (flags & 8u) { r.reset = 1u; r.cnt = 1u; own[o] = r; return; }   // a walked piece: nothing before it composes past it
+  if (flags & 8u) { r.reset = 1u; r.cnt = 1u; own[id] = r; return; }   // a walked piece: nothing before it composes past it
   r.T0 = S0; r.T1 = S1; r.mn0 = mn0; r.mn1 = mn1; r.mx0 = mx0; r.mx1 = mx1;
   r.eb = ebits | ((flags & 1u) << 11); r.reset = (flags & 4u) ? 1u : 0u;
-  own[o] = r;
+  own[id] = r;
 }
 
 // apply a summary to the running sum if it provably describes what the adds would do; false: it does not
@@ -469,8 +482,8 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
   const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
   const size_t ao = (size_t)ax * nblocks * 2;
   const BPiece* pa = pieces + ao;
-  const BSum* oa = own + ao;
-  const BSum* ca = comp + ao;
+  const BSum* oa = own;                            // per slot: the summaries exist along the split axis only
+  const BSum* ca = comp;
   double* wbuf = walk[threadIdx.x / WAVE];
   const uint32_t np = big_piece_count(a, n);
   {
@@ -479,14 +492,10 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
     // other axes report their bounds and leave (bit-identical tree: k_decide picks the axis from the same bounds).
     const uint32_t sl = big_piece_slot(a, np - 1u);
     const size_t st = (size_t)nblocks * 2;
-    const BPre b0 = preout[sl], b1 = preout[st + sl], b2 = preout[2 * st + sl];
-    const double hx = 0.5 * (b0.hi - b0.lo), hy = 0.5 * (b1.hi - b1.lo), hz = 0.5 * (b2.hi - b2.lo);
-    uint32_t split;
-    if (hx > hy) split = (hx > hz) ? 0u : 2u;
-    else split = (hy > hz) ? 1u : 2u;
-    if (split != ax && !(dbg & 3)) {
+    const uint32_t split = big_split_axis(preout, st, sl);
+    if (split != ax) {
       if (lane == 0) {
-        const BPre& b = (ax == 0) ? b0 : ((ax == 1) ? b1 : b2);
+        const BPre b = preout[(size_t)ax * st + sl];
         out[sgi].lo[ax] = b.lo; out[sgi].hi[ax] = b.hi; out[sgi].mean[ax] = 0.0;
       }
       return;
@@ -544,7 +553,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
     lo = bb.lo; hi = bb.hi;
   }
   if ((dbg & 16) && lane == 0) printf("stitch: node at %u, %u points, %u pieces, %u walked\n", a, n, np, r1 - r0);
-  auto load_slots = [&](uint32_t r) -> uint32_t { return (r + lane < r1) ? list[r + lane] - (uint32_t)ao : 0xFFFFFFFFu; };
+  auto load_slots = [&](uint32_t r) -> uint32_t { return (r + lane < r1) ? list[r + lane] : 0xFFFFFFFFu; };
   uint32_t slotN = load_slots(r0), slotNN = load_slots(r0 + WAVE);
   uint32_t stN = 0, lnN = 0; BSum RN;
   auto load_recs = [&](uint32_t slot) {
@@ -988,13 +997,14 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
                              nblocks, pieces, prein);
           size_t stb = scan_tmp;
           BCHK(rocprim::inclusive_scan(tmp, stb, prein, preout, nsl, BPreOp(), s));
-          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(2 * (size_t)nblocks, 64), 3), dim3(64), 0, s, cx, cy, cz, nblocks, pieces,
-                             preout, own, big_dbg);
+          const size_t nsl1 = (size_t)nblocks * 2;
+          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(nsl1, 64)), dim3(64), 0, s, segs, cx, cy, cz, nblocks, pieces, preout,
+                             own, big_dbg);
           stb = scan_tmp;
           BSum ident;   // exclusive: comp[slot] = everything since the last reset BEFORE the slot = the run in front of it
           ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u; ident.cnt = 0u; ident.pad = 0u;
-          BCHK(rocprim::exclusive_scan(tmp, stb, own, comp, ident, nsl, BSumOp(), s));
-          hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl, 256)), dim3(256), 0, s, own, comp, (uint32_t)nsl, wlist);
+          BCHK(rocprim::exclusive_scan(tmp, stb, own, comp, ident, nsl1, BSumOp(), s));
+          hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, s, own, comp, (uint32_t)nsl1, wlist);
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
                              pieces, preout, own, comp, wlist, meas, big_dbg);
           if (big_dbg_all & 8) {
