@@ -451,7 +451,10 @@ __device__ __forceinline__ bool big_apply(double& sum, long long T0, long long T
 {
   if (eb == BIG_ANY) return true;
   const unsigned long long ONE = 0x0010000000000000ull;
-  const unsigned long long sb = (unsigned long long)__double_as_longlong(sum);
+  // the running sum is the same in every lane of the chain's wave: say so, and the arithmetic below is scalar
+  const long long sv = __double_as_longlong(sum);
+  const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)sv >> 32)) << 32) |
+                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)sv & 0xFFFFFFFFull));
   if ((uint32_t)(sb >> 52) != eb) return false;                // exponent and sign in one compare (eb = ebits | sign << 11)
   const long long Mi = (long long)((sb & (ONE - 1ull)) | ONE);
   const bool odd = (Mi & 1ll) != 0;
@@ -460,11 +463,18 @@ __device__ __forceinline__ bool big_apply(double& sum, long long T0, long long T
   sum = __longlong_as_double((long long)((sb & 0xFFF0000000000000ull) | ((unsigned long long)(Mi + T) & (ONE - 1ull))));
   return true;
 }
+__device__ __forceinline__ long long readlane64(long long v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v & 0xFFFFFFFFull), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
 __device__ __forceinline__ bool big_apply(double& sum, const BSum S) { return big_apply(sum, S.T0, S.T1, S.mn0, S.mn1, S.mx0, S.mx1, S.eb); }
 
 // one wave per (node, axis): the chain.  Clusters of walked pieces are visited one by one; everything between two of
 // them is one step.
 #define BIG_CL 4               // walked pieces folded into one LDS stage (they are consecutive in memory)
+#define BIG_NQ 3               // such stages requested ahead of the one being walked
 __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
                                                     const double* __restrict__ cx, const double* __restrict__ cy,
                                                     const double* __restrict__ cz, uint32_t nblocks,
@@ -587,7 +597,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
       const unsigned long long gap = ~(fr & ((ad << 1) | 1ull));       // bit k: entry j + k is full and follows j + k - 1
       int c = gap ? __ffsll((long long)gap) - 1 : 64;
       if (c > BIG_CL) c = BIG_CL;
-      const uint32_t st = __shfl(p_start, q.j, WAVE), ln = __shfl(p_len, q.j, WAVE);
+      const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)p_start, q.j), ln = (uint32_t)__builtin_amdgcn_readlane((int)p_len, q.j);
       q.cnt = (uint32_t)c * BIG_CH;
       if (c == 0) { c = 1; q.cnt = ln; }
       if (!any) { c = 0; q.cnt = 0; }
@@ -600,25 +610,38 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
       }
       return q;
     };
-    // three clusters in flight: a lone wave needs ~2 us for a round trip to memory and ~1 us to walk a cluster
-    Cl q0 = fetch_cluster(), q1 = fetch_cluster(), q2 = fetch_cluster();
-    while (q0.c) {
-      const Cl cur = q0;
-      q0 = q1; q1 = q2; q2 = fetch_cluster();
-      const int j = cur.j, c = cur.c;
-      // the run in front of this walked piece: fetched by lane j
-      BSum S;
-      S.T0 = __shfl(R.T0, j, WAVE); S.T1 = __shfl(R.T1, j, WAVE);
-      S.mn0 = __shfl(R.mn0, j, WAVE); S.mn1 = __shfl(R.mn1, j, WAVE);
-      S.mx0 = __shfl(R.mx0, j, WAVE); S.mx1 = __shfl(R.mx1, j, WAVE);
-      S.eb = __shfl(R.eb, j, WAVE); S.reset = 0u; S.cnt = 0u; S.pad = 0u;
-      const int idx = __shfl(p_idx, j, WAVE);
-      if (idx - 1 > done) apply_run(done + 1, idx - 1, S);
+    // BIG_NQ clusters in flight, consumed and refilled in turn (the loop is unrolled so that every one of them lives in
+    // registers of its own and the compiler can count the loads in flight): a lone wave needs ~2 us for a round trip
+    // to memory and 0.17 us to walk a piece, and on Morton-ordered scans the walked pieces of the top levels stand
+    // alone -- with three in flight the wave spent 0.45 us per walked piece, most of it waiting
+    Cl q[BIG_NQ];
 #pragma unroll
-      for (int k = 0; k < BIG_CL; k++)
-        if (k < c) wbuf[k * BIG_CH + lane] = cur.v[k];
-      chain(cur.cnt);
-      done = idx + c - 1;
+    for (int t = 0; t < BIG_NQ; t++) q[t] = fetch_cluster();
+    bool more = true;
+    while (more) {
+#pragma unroll
+      for (int t = 0; t < BIG_NQ; t++) {
+        if (more && q[t].c) {
+          const int j = q[t].j, c = q[t].c;
+          // the run in front of this walked piece: fetched by lane j
+          // (j is wave-uniform: v_readlane straight into scalar registers instead of a trip through the LDS crossbar)
+          BSum S;
+          S.T0 = readlane64(R.T0, j); S.T1 = readlane64(R.T1, j);
+          S.mn0 = readlane64(R.mn0, j); S.mn1 = readlane64(R.mn1, j);
+          S.mx0 = readlane64(R.mx0, j); S.mx1 = readlane64(R.mx1, j);
+          S.eb = (uint32_t)__builtin_amdgcn_readlane((int)R.eb, j); S.reset = 0u; S.cnt = 0u; S.pad = 0u;
+          const int idx = __builtin_amdgcn_readlane(p_idx, j);
+          if (idx - 1 > done) apply_run(done + 1, idx - 1, S);
+#pragma unroll
+          for (int k = 0; k < BIG_CL; k++)
+            if (k < c) wbuf[k * BIG_CH + lane] = q[t].v[k];
+          chain(q[t].cnt);
+          done = idx + c - 1;
+          q[t] = fetch_cluster();
+        } else {
+          more = false;
+        }
+      }
     }
   }
   if ((int)np - 1 > done) apply_run(done + 1, (int)np - 1, BSumOp()(c_last, o_last));
