@@ -63,7 +63,7 @@ EXPORTS = [
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_graph_exchange", "tdtk_graph_deal_links",
     "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge",
-    "tdtk_last_timings", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
+    "tdtk_last_timings", "tdtk_kernel_timing", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
     "tdtk_host_euler_to_matrix4", "tdtk_host_matrix4_to_euler", "tdtk_host_quat_to_matrix4", "tdtk_host_matrix4_to_quat",
     "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
@@ -156,6 +156,7 @@ def lib():
     L.tdtk_elch_graph_balancer.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, _dp]
     L.tdtk_pair_sums_merge.argtypes = [C.c_int, C.POINTER(PairSums), C.POINTER(PairSums)]
     L.tdtk_last_timings.argtypes = [_dp]
+    L.tdtk_kernel_timing.argtypes = [C.c_int]
     L.tdtk_visit_counting.argtypes = [C.c_int, C.c_int]
     L.tdtk_visit_counters.argtypes = [C.c_int, _u64p]
     L.tdtk_measure_bandwidth.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_int, _dp]

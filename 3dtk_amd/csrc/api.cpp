@@ -537,9 +537,26 @@ static int prepare_overflow(Ctx* c, const tdtk_tree* t, size_t nq, SearchArgs& a
   return prepare_overflow_in(c->ws[WS_OVF_M2], c->ws[WS_OVF_REF], t, nq, a);
 }
 
+// HIP events around the search and the pair-sum kernels of every pass (tdtk_icp_result.nn_ms / sums_ms,
+// tdtk_last_kernel_ms, tdtk_last_timings) are a profiling aid and OFF unless asked for (tdtk_kernel_timing(1) or
+// TDTK_KERNEL_TIMING=1): four marker packets on the stream, two event waits and two read-outs per ICP iteration cost
+// 10 us of it -- 4 % of a 1M-point iteration, 19 % of an 81K-point one (0.2602 -> 0.2504 ms, 54.9 -> 44.4 us).
+static std::atomic<int> g_kernel_timing{-1};
+static bool kernel_timing()
+{
+  int v = g_kernel_timing.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("TDTK_KERNEL_TIMING");
+    v = (e && e[0] == '1') ? 1 : 0;
+    g_kernel_timing.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
 static int run_search(Ctx* c, const tdtk_tree* t, SearchArgs& a, int dirmode, bool count, hipStream_t s,
                       bool timed)
 {
+  timed = timed && kernel_timing();
   a.T = t->dev;
   const uint32_t grid = search_grid(a.n);
   int rc = prepare_overflow(c, t, a.n, a);
@@ -585,8 +602,9 @@ static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
     c->last_normals_ms = f;
     c->ev4_pending = false;
   }
-  if (ms) *ms = c->last_nn_ms;
-  if (sums_ms) *sums_ms = c->last_sums_ms;
+  const bool on = kernel_timing();
+  if (ms) *ms = on ? c->last_nn_ms : 0.0;
+  if (sums_ms) *sums_ms = on ? c->last_sums_ms : 0.0;
   return TDTK_OK;
 }
 
@@ -777,10 +795,10 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     rc = run_search(c, model, sa, pmode == 1 ? 1 : 0, false, s, true);
     if (rc) return rc;
     if (fused) {
-      HIPCHK(hipEventRecord(c->e2, s));
+      const bool tm = kernel_timing();
+      if (tm) HIPCHK(hipEventRecord(c->e2, s));
       HIPCHK(launch_final(sa.partials, rows, c->h_pin, s));
-      HIPCHK(hipEventRecord(c->e3, s));
-      c->ev2_pending = true;
+      if (tm) { HIPCHK(hipEventRecord(c->e3, s)); c->ev2_pending = true; }
       HIPCHK(hipStreamSynchronize(s));
       std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
       return TDTK_OK;
@@ -802,10 +820,10 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   aa.partials = c->ws[WS_PART].as<double>();
   // k_final stores the 74 sums straight into pinned host memory (device-visible): no copy-engine hop
   // between the last kernel and the host solve, which matters when an iteration is ~100 us
-  HIPCHK(hipEventRecord(c->e2, s));
+  const bool tm = kernel_timing();
+  if (tm) HIPCHK(hipEventRecord(c->e2, s));
   HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s));
-  HIPCHK(hipEventRecord(c->e3, s));
-  c->ev2_pending = true;
+  if (tm) { HIPCHK(hipEventRecord(c->e3, s)); c->ev2_pending = true; }
   HIPCHK(hipStreamSynchronize(s));
   std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
   return TDTK_OK;
@@ -991,6 +1009,13 @@ int tdtk_last_kernel_ms(double* nn_ms)
   int rc = get_ctx(dev, &c, false);
   if (rc) return rc;
   return collect_ms(c, nn_ms);
+}
+
+int tdtk_kernel_timing(int on)
+{
+  const int was = kernel_timing() ? 1 : 0;
+  g_kernel_timing.store(on ? 1 : 0, std::memory_order_relaxed);
+  return was;
 }
 
 int tdtk_last_timings(double out[4])
@@ -1860,7 +1885,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   const int thresh = search_multi_thresh(maxN), cls = search_multi_class(maxN);
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G), nb = l1 - l0;
-    const bool timed = (gi == ngroups - 1);      // tdtk_last_kernel_ms: the last group's search launch
+    const bool timed = (gi == ngroups - 1) && kernel_timing();   // tdtk_last_kernel_ms: the last group's search launch
     if (timed) HIPCHK(hipEventRecord(c->e0, s));
     HIPCHK(launch_search_multi(reinterpret_cast<const SearchArgs*>(dbase + o_sa) + l0,
                                reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], cls, thresh, c->counting, s));
@@ -1973,7 +1998,7 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
       if ((rc = prepare_overflow_in(ln->ovf_m2, ln->ovf_ref, t, sa.n, sa))) return rc;
       if (search_uses_queue(sa.n) && (rc = ln->qc.attach(sa))) return rc;
       if (c->counting) { sa.counters = c->d_counters.as<unsigned long long>(); c->counted_queries += sa.n; }
-      const bool timed = (i == nlinks - 1);      // tdtk_last_kernel_ms: this search, running beside the other lanes'
+      const bool timed = (i == nlinks - 1) && kernel_timing();   // tdtk_last_kernel_ms: this search, running beside the other lanes'
       if (timed) HIPCHK(hipEventRecord(c->e0, ls));
       HIPCHK(launch_search(sa, grid, 0, c->counting, ls));
       if (timed) { HIPCHK(hipEventRecord(c->e1, ls)); c->ev_pending = true; }

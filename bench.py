@@ -101,6 +101,19 @@ class visit_counting:
         self.L.tdtk_visit_counting(self.dev, 0)
 
 
+class kernel_timing:
+    """with kernel_timing(): ... -- HIP events around the library's search / pair-sum launches (tdtk_kernel_timing):
+    off in the product because the events cost ~10 us per ICP iteration; `icp.last["nn_ms"]` etc. are 0 outside."""
+
+    def __enter__(self):
+        self.L = importlib.import_module("3dtk_amd").lib()
+        self.was = self.L.tdtk_kernel_timing(1)
+        return self
+
+    def __exit__(self, *exc):
+        self.L.tdtk_kernel_timing(self.was)
+
+
 def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw):
     """The `roofline` object for k_search.  achieved = ALGORITHMIC bytes per launch (24 B query + 64 B per
     internal node + 24 B per bucket point + 4 B index, with the node / point counts of exactly the timed launches) /
@@ -333,7 +346,8 @@ def bench_icp(args, rank, world, local):
         scratch = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
         _ = scratch.handle
         probe = tdtk.icp6D(mini, 25.0, 40, quiet=True, epsilonICP=-1.0)
-        tq = time.perf_counter(); itp = probe.match(model, scratch); dq = time.perf_counter() - tq
+        with kernel_timing():
+            tq = time.perf_counter(); itp = probe.match(model, scratch); dq = time.perf_counter() - tq
         outside = dq * 1e3 / (itp + 1) - (probe.last["nn_ms"] + probe.last["sums_ms"]) / (itp + 1)
         del scratch
         settle["rounds"] += 1
@@ -358,6 +372,20 @@ def bench_icp(args, rank, world, local):
     last = icp.last
     pose_err = float(np.abs(data.get_transMat() - T).max())
 
+    # Device time of the timed launches.  The library's HIP events around its search and pair-sum launches are a
+    # profiling switch that is off in the product (four marker packets, two waits and two read-outs cost ~10 us of an
+    # iteration), so the timed region above ran without them; the same W + K iterations are run again on a second
+    # data scan with the events on (same launches: the loop is deterministic, the final RMS is compared).
+    rep_t = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
+    _ = rep_t.handle
+    tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0).match(model, rep_t)
+    icp_t = tdtk.icp6D(mini, 25.0, args.steps, quiet=True, epsilonICP=-1.0)
+    with kernel_timing():
+        tt0 = time.perf_counter(); icp_t.match(model, rep_t); dt_ev = time.perf_counter() - tt0
+    assert icp_t.last["rms"] == last["rms"] and icp_t.last["pairs"] == last["pairs"], "timing replay diverged"
+    last_t = icp_t.last
+    del rep_t
+
     # Algorithmic bytes of exactly the timed launches: the loop is deterministic, so a second data scan run through
     # the same W + K iterations with the instrumented kernel (same traversal, same warm-start radius; counters
     # switched on after the warm-up) visits what the timed launches visited -- checked through the final RMS.
@@ -372,8 +400,8 @@ def bench_icp(args, rank, world, local):
     assert counts[3] == n * steps, counts
     del rep
     cur = data.get_xyz_reduced()
-    k_ms = last["nn_ms"] / steps                          # HIP-event time of k_search, per launch
-    sums_ms = last["sums_ms"] / steps                     # ... and of the pair-sum kernels behind it
+    k_ms = last_t["nn_ms"] / steps                        # HIP-event time of k_search, per launch
+    sums_ms = last_t["sums_ms"] / steps                   # ... and of the pair-sum kernels behind it
     bw = measured_bandwidth(local)
     ti = {"n_internal": info["n_internal"], "n_points": n}
     # compulsory bytes per query besides the tree: x,y,z read + written back (fused transform), hit position written
@@ -416,6 +444,10 @@ def bench_icp(args, rank, world, local):
         "pairs_last": last["pairs"], "rms_last": last["rms"], "pose_max_abs_err": pose_err,
         "host_buffer_path": host_path, "per_scan_preparation": prep,
         "pair_sums_ms": sums_ms, "outside_kernels_ms": dt * 1e3 / steps - k_ms - sums_ms, "settle": settle,
+        "kernel_times_from": "a second run of the same %d + %d iterations with the library's HIP events on "
+                             "(tdtk_kernel_timing; same launches, final RMS equal): %.4f ms per iteration with the events, "
+                             "%.4f without (the timed region)" % (args.warmup, steps, dt_ev * 1e3 / steps, dt * 1e3 / steps),
+        "ms_per_step_with_kernel_events": dt_ev * 1e3 / steps,
         "roofline": roof,
     }
     # tree build (A1) on the device: a latency chain (the reference's serial-order fp64 centroid), reported against
@@ -513,6 +545,9 @@ def bench_graphslam(args, rank, world, local):
             comm = gs.NativeComm(0, 1, local)
     use_torch_exchange = on_dist and world > 1 and dev is None
     nn_ms = [0.0]
+    # one pair of HIP events per step around the step's last search launch (the roofline's kernel time): on for this
+    # leg -- two markers in a step of ~12 ms, unlike the four per 0.25 ms of the ICP loop
+    tdtk.lib().tdtk_kernel_timing(1)
 
     def step():
         gr = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)   # slam6D.cc:525-532: fresh Graph + 1 LUM iteration
@@ -539,6 +574,7 @@ def bench_graphslam(args, rank, world, local):
             print("step %.2f ms ret %.4f" % ((time.perf_counter() - ts) * 1e3, ret), file=sys.stderr)
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, local)
+    tdtk.lib().tdtk_kernel_timing(0)
     queries = links_done * npts                         # one whole-scan NN pass per link
     k_ms = nn_ms[0] / max(1, args.steps)                # one sampled k_search launch per step
     # algorithmic bytes of this rank's link passes: one more step with the instrumented kernels (poses have converged

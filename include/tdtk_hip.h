@@ -110,7 +110,7 @@ typedef struct tdtk_icp_result {
   uint64_t last_pairs;     /* nr_pointPair                                              */
   double last_rms;         /* last `ret`                                                */
   double total_ms;         /* wall time of the loop (the reference's "TIME" line)       */
-  double nn_ms;            /* of which: device time in the correspondence kernel        */
+  double nn_ms;            /* of which: device time in the correspondence kernel (0 unless tdtk_kernel_timing) */
   double sums_ms;          /* and in the pair-sum kernels behind it (k_final alone when the sums are fused) */
 } tdtk_icp_result;
 
@@ -356,6 +356,12 @@ int tdtk_scan_calc_normals(tdtk_scan* s, int k, const double rPos[3], double eps
 
 /* ---- instrumentation: per-kernel device time of the last call on this thread (ms) and
  * traversal counters of the last counting run.                                          */
+/* HIP events around the search and pair-sum kernels of every pass: a profiling aid, off by default (process-wide;
+ * also TDTK_KERNEL_TIMING=1 in the environment) because the events themselves cost ~10 us per ICP iteration.  While
+ * it is off tdtk_icp_result.nn_ms / sums_ms, tdtk_last_kernel_ms and out[0], out[1] of tdtk_last_timings are 0.
+ * Returns the previous setting.  (The reference has nothing of the kind: icp6D::match prints its wall time only,
+ * icp6D.cc:279-283 -- tdtk_icp_result.total_ms.) */
+int tdtk_kernel_timing(int on);
 int tdtk_last_kernel_ms(double* nn_ms);
 /* out[0] = search kernel, out[1] = pair-sum kernels of the last pass on this thread, out[2] = the k-NN + PCA kernel
  * of the last calcNormals (HIP events on the stream the kernels were launched on), out[3] = wall time of the last

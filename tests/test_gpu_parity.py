@@ -303,6 +303,27 @@ def test_icp_vs_oracle_loop(tdtk, orc, gpu, algo):
     assert np.abs(S[1].get_xyz_reduced() - O[1].xyz).max() < (1e-8 if algo in (1, 2, 6) else 1e-5)
 
 
+def test_kernel_timing_is_opt_in_and_changes_nothing(tdtk, gpu):
+    """The HIP events around the search / pair-sum launches (tdtk_kernel_timing) are off by default -- nn_ms / sums_ms
+    read 0 -- and switching them on changes no result: same iterations, same trace, same pose, bit for bit."""
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    L = tdtk.lib()
+    assert L.tdtk_kernel_timing(0) in (0, 1)
+    runs = []
+    for on in (0, 1, 0):
+        assert L.tdtk_kernel_timing(on) in (0, 1)
+        S = _dat_scans(tdtk.Scan, z)
+        S[1].mergeCoordinatesWithRoboterPosition(S[0])
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 15, quiet=True, epsilonICP=1e-5)
+        it = icp.match(S[0], S[1])
+        runs.append((it, icp.last["trace"].copy(), S[1].get_transMat().copy(), icp.last["nn_ms"], icp.last["sums_ms"]))
+    assert L.tdtk_kernel_timing(0) == 0
+    assert runs[0][3] == 0.0 and runs[0][4] == 0.0 and runs[2][3] == 0.0
+    assert runs[1][3] > 0.0 and runs[1][4] > 0.0
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
+
+
 def test_icp_point_to_plane_napx(tdtk, orc, gpu):
     """-a 10 (icp6D_NAPX, the 6x6 point-to-plane system) with -z style plane projection."""
     from oracle import icp_oracle as io

@@ -1,4 +1,5 @@
 import importlib, os, sys, ctypes as C
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 t = importlib.import_module("3dtk_amd")

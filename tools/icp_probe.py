@@ -3,6 +3,7 @@ Kernel selection comes from the environment (TDTK_SEARCH_VARIANT, TDTK_REFILL_QP
 read once per process -- run one process per configuration (tools/r2_sweep.sh).
 usage: python tools/icp_probe.py [points] [steps] [warmup]"""
 import importlib, os, sys, time
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,5 +1,6 @@
 """GPU box: k_search time and pair statistics per ICP iteration on the bench pair."""
 import importlib, os, sys, ctypes as C
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

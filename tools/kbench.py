@@ -1,6 +1,7 @@
 """Kernel micro-bench (GPU box): repeated whole-scan correspondence passes on the 1M pair.
 usage: python tools/kbench.py [reps] [mode]   mode: icp (data near model) | rand (independent queries)"""
 import importlib, os, sys, time, ctypes as C
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 t = importlib.import_module("3dtk_amd")

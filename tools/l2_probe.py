@@ -2,6 +2,7 @@
 the SAME point density (box scaled), so the traversal statistics differ only by the tree depth while the working set
 goes from "fits every XCD's L2" to "Infinity Cache only".  usage: python tools/l2_probe.py"""
 import importlib, os, sys, ctypes as C
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 t = importlib.import_module("3dtk_amd")

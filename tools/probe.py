@@ -1,5 +1,6 @@
 """Scratch probe (GPU box): correctness vs oracle + first timings on 1M-vs-1M."""
 import importlib, os, sys, time
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 t = importlib.import_module("3dtk_amd")

@@ -1,5 +1,6 @@
 """GPU box: per-iteration cost of the resident ICP loop on small scans (the bundled 81K-point dat/ pair)."""
 import importlib, os, sys, time
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 t = importlib.import_module("3dtk_amd")

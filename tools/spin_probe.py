@@ -1,6 +1,7 @@
 """GPU box: does the runtime's host-wait policy change the ICP iteration time?  usage: python tools/spin_probe.py <flag>
 flag: 0 auto, 1 spin, 2 yield, 4 blocking sync (hipSetDeviceFlags before the first GPU work)"""
 import ctypes, importlib, os, sys, time
+os.environ.setdefault("TDTK_KERNEL_TIMING", "1")   # the probes read the library's per-kernel event times
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 flag = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 hip = ctypes.CDLL("libamdhip64.so")
