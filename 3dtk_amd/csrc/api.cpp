@@ -612,13 +612,18 @@ static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
 // registers take the kernel from 7 to 4 waves per SIMD and every retire waits for its own gather, so the search
 // grows by about what the separate pair-sum pass costs (1M-vs-1M ICP: 0.2881 + 0.0072 ms fused against
 // 0.2708 + 0.0280 ms; 4M: 1.179 + 0.016 against 0.965 + 0.058 -- gpurun_out/r2a/sweep.log).  TDTK_FUSE_SUMS=1 selects it.
-static int fuse_mode()   // 0: separate k_accum, 1: at retire time, 3: by each wave after its last query
-{
+// Batches below the persistent-lane kernel's size are another matter: their kernels are not short of issue slots, and
+// the workgroup sums its own chunk once it is through with it (chunk_pair_sums): an 81K-point ICP iteration is two
+// launches instead of three.  On by default there, TDTK_FUSE_SUMS=0 switches it off.
+static int fuse_mode(size_t N)   // 0: separate k_accum, 1: at retire time, 3: by each wave after its last query,
+{                                // 4: by each workgroup after its chunk (small batches)
   const char* e = getenv("TDTK_FUSE_SUMS");
-  const int v = e ? atoi(e) : 0;
-  return (v == 1 || v == 3) ? v : 0;
+  const int v = e ? atoi(e) : -1;
+  const int kind = search_fuse_kind(N);
+  if (kind == 2) return v == 0 ? 0 : 4;
+  if (kind == 1) return (v == 1 || v == 3) ? v : 0;
+  return 0;
 }
-static bool fuse_enabled() { return fuse_mode() != 0; }
 
 // acc[ACC_TOTAL] (sums about `shift`) -> the reference's quantities
 static void finish_sums(const double* acc, const double shift[3], size_t nq, unsigned want, tdtk_pair_sums* o)
@@ -771,7 +776,8 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   for (int k = 0; k < 3; k++) shift_out[k] = sh[k];
   // the base block (n, sum, centroids, Si) of a closest-point pass comes out of the search kernel itself when the
   // batch is large enough for the persistent-lane kernel (retire-time accumulation, kernels.hip)
-  const bool fused = do_search && pmode == 0 && (want & ~TDTK_WANT_BASE) == 0 && !lum_D && fuse_enabled() && search_can_fuse(N);
+  const int fmode = (do_search && pmode == 0 && (want & ~TDTK_WANT_BASE) == 0 && !lum_D) ? fuse_mode(N) : 0;
+  const bool fused = fmode != 0 && !(fmode == 4 && c->counting);   // (the instrumented small-batch kernels have no epilogue)
   if (do_search) {
     SearchArgs sa{};
     sa.x = data->x; sa.y = data->y; sa.z = data->z;
@@ -788,7 +794,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     if (fused) {
       rows = search_fused_rows(N);
       if ((rc = c->ws[WS_PART].ensure((size_t)rows * ACC_TOTAL * sizeof(double)))) return rc;
-      sa.fuse = fuse_mode(); sa.A = A;
+      sa.fuse = fmode; sa.A = A;
       for (int k = 0; k < 3; k++) sa.shift[k] = sh[k];
       sa.partials = c->ws[WS_PART].as<double>();
     }

@@ -669,10 +669,17 @@ __device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx,
   }
 }
 
+// FUSE (k_search, k_search_g8: the batches too small for the persistent-lane kernel): once the workgroup is through with
+// its chunk of the queries it sums the base pair block of that chunk itself (defined behind wave_sum below), so an
+// ICP iteration on a small scan is two launches instead of three -- at that size nothing is short of issue slots and
+// the separate k_accum is a fifth of the iteration
+template <int BLOCK>
+__device__ __forceinline__ void chunk_pair_sums(const SearchArgs& a, size_t lo, size_t hi, uint32_t row);
+
 // ------------------------------------------------------------------------------------------
 // k_search: the hot kernel
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4>
+template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4, bool FUSE = false>
 __device__ __forceinline__ void search_plain_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -727,12 +734,13 @@ __device__ __forceinline__ void search_plain_body(const SearchArgs& a, const uin
     a.kpos[i] = bk;
     if (a.d2) a.d2[i] = best;
   }
+  if constexpr (FUSE) chunk_pair_sums<BLOCK>(a, lo, hi, bid);
 }
 
-template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4>
+template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4, bool FUSE = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
 {
-  search_plain_body<BLOCK, SD, COUNT, DIRMODE, UNI, WPS, PTS>(a, blockIdx.x, gridDim.x);
+  search_plain_body<BLOCK, SD, COUNT, DIRMODE, UNI, WPS, PTS, FUSE>(a, blockIdx.x, gridDim.x);
 }
 // several batches in one launch (see k_search_refill_multi)
 template <int BLOCK, int SD, bool COUNT, bool UNI, int WPS>
@@ -756,7 +764,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_multi(const SearchArgs* _
 // lowest index first among equals -- which is what the serial strict '<' scan in stored order
 // returns.  Same visiting order as k_search, hence the same indices.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, int GS = 8>
+template <int BLOCK, int SD, int GS = 8, bool FUSE = false>
 __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   constexpr int NG = BLOCK / GS;
@@ -883,6 +891,7 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
       if (a.d2) a.d2[i] = best;
     }
   }
+  if constexpr (FUSE) chunk_pair_sums<BLOCK>(a, lo, hi, bid);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -890,6 +899,76 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
   return v;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void chunk_pair_sums(const SearchArgs& a, size_t lo, size_t hi, uint32_t row)
+{
+  constexpr int NW = BLOCK / WAVE;
+  __shared__ double fred[NW][ACC_DD];
+  // hits and moved coordinates of the chunk were written by threads of this workgroup: the barrier (with its
+  // workgroup-scope fence) makes them visible to the others -- nothing wider is needed, or affordable
+  __syncthreads();
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(a.T.pts);
+  double acc[ACC_DD];
+#pragma unroll
+  for (int k = 0; k < ACC_DD; k++) acc[k] = 0.0;
+  for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 2 * (size_t)BLOCK) {
+    const size_t i1 = i0 + BLOCK;
+    const int k0 = a.kpos[i0];
+    const int k1 = (i1 < hi) ? a.kpos[i1] : -1;
+    double4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    double t0x = 0, t0y = 0, t0z = 0, t1x = 0, t1y = 0, t1z = 0;
+    if (k0 >= 0) { c0 = pts[k0]; t0x = a.x[i0]; t0y = a.y[i0]; t0z = a.z[i0]; }
+    if (k1 >= 0) { c1 = pts[k1]; t1x = a.x[i1]; t1y = a.y[i1]; t1z = a.z[i1]; }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if ((u ? k1 : k0) < 0) continue;
+      const double4 c = u ? c1 : c0;
+      const double tx = u ? t1x : t0x, ty = u ? t1y : t0y, tz = u ? t1z : t0z;
+      double mx, my, mz;
+      dev_xf3(a.A, c.x, c.y, c.z, mx, my, mz);  // searchTree.cc:147
+      const double px = mx - tx, py = my - ty, pz = mz - tz;
+      acc[ACC_N] += 1.0;
+      acc[ACC_SUM] += px * px + py * py + pz * pz;
+      const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
+      const double d0 = tx - a.shift[0], d1 = ty - a.shift[1], d2 = tz - a.shift[2];
+      acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
+      acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
+      acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
+      acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
+      acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+    }
+  }
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if (hi - lo <= (size_t)WAVE) {
+    // a chunk of one wave's worth of queries (the four-lanes-per-query kernel on a small scan): the first wave alone
+    // holds everything -- butterfly sums, lane k stores column k, no second barrier and no LDS pass
+    if (wv != 0) return;
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < ACC_DD; k++) {
+      double v = acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+      if (lane == k) mine = v;
+    }
+    a.partials[(size_t)row * ACC_TOTAL + lane] = mine;                       // columns 0 .. 63 (zero from ACC_DD on)
+    if (lane + WAVE < ACC_TOTAL) a.partials[(size_t)row * ACC_TOTAL + WAVE + lane] = 0.0;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < ACC_DD; k++) {
+    const double sk = wave_sum(acc[k]);
+    if (lane == 0) fred[wv][k] = sk;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
+    double sk = 0.0;
+    if (k < ACC_DD)
+      for (int w = 0; w < NW; w++) sk += fred[w][k];
+    a.partials[(size_t)row * ACC_TOTAL + k] = sk;
+  }
 }
 __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 {
@@ -899,10 +978,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
   return t;
 }
 
-template <int BLOCK, int SD, int GS = 8>
+template <int BLOCK, int SD, int GS = 8, bool FUSE = false>
 __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
 {
-  search_g8_body<BLOCK, SD, GS>(a, blockIdx.x, gridDim.x);
+  search_g8_body<BLOCK, SD, GS, FUSE>(a, blockIdx.x, gridDim.x);
 }
 template <int BLOCK, int SD, int GS>
 __global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __restrict__ args, const uint32_t* __restrict__ base,
@@ -2043,6 +2122,14 @@ static int pick_variant(size_t n)
   return v;
 }
 bool search_can_fuse(size_t n) { return pick_variant(n) == 20; }
+// how the base pair sums can come out of the search of a batch this size: 1 = the persistent-lane kernel's FUSE modes
+// (measured negatives, on request only), 2 = the chunk epilogue of the small-batch kernels, 0 = not at all
+int search_fuse_kind(size_t n)
+{
+  const int v = pick_variant(n);
+  return v == 20 ? 1 : ((v == 10 || v == 4) ? 2 : 0);
+}
+static uint32_t g8_grid4(size_t n) { const uint32_t g = g8_grid(n) / 2; return g < 8 ? 8u : (g + 7) / 8 * 8; }
 // share of an XCD's region that is not dealt out in advance but drawn from a pool (k_search_refill, pool_slab);
 // 0 = off.  Only where all waves of the launch are resident at once and the launch has the chip to itself.
 static int refill_pool_pct(size_t n, int side_by_side)
@@ -2057,6 +2144,9 @@ static int refill_pool_pct(size_t n, int side_by_side)
 bool search_uses_queue(size_t n) { return pick_variant(n) == 30 || (pick_variant(n) == 20 && refill_pool_pct(n, 1) > 0); }
 uint32_t search_fused_rows(size_t n, int side_by_side)
 {
+  const int v = pick_variant(n);
+  if (v == 10) return g8_grid4(n);
+  if (v == 4) return search_grid(n);
   int q;
   return refill_grid_b(n, 128, &q, side_by_side);
 }
@@ -2166,7 +2256,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
   else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
   else {
     const int v = pick_variant(a.n);
-    if (a.fuse && v != 20) return hipErrorInvalidValue;
+    if (a.fuse && !(v == 20 || ((v == 10 || v == 4) && !count))) return hipErrorInvalidValue;
     if (v == 30 && (!a.q_ctr || !a.q_ctr_next)) return hipErrorInvalidValue;
     if (count) {
       // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
@@ -2193,9 +2283,15 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
       case 20: if (a.fuse == 3) launch_refill128<false, 3>(a, s); else if (a.fuse == 2) launch_refill128<false, 2>(a, s); else if (a.fuse) launch_refill128<false, 1>(a, s); else launch_refill128<false, 0>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
-      case 10: hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid(a.n) / 2 < 8 ? 8 : (g8_grid(a.n) / 2 + 7) / 8 * 8), dim3(256), 0, s, a); break;
+      case 10:
+        if (a.fuse) hipLaunchKernelGGL((k_search_g8<256, 16, 4, true>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
+        break;
       case 11: hipLaunchKernelGGL((k_search_g8<256, 16, 16>), dim3(g8_grid(a.n) * 2), dim3(256), 0, s, a); break;
-      default: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a); break;
+      default:
+        if (a.fuse) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1, 4, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a);
+        break;
     }
   }
   return hipGetLastError();

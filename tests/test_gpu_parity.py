@@ -1451,6 +1451,7 @@ def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     L = tdtk.lib()
     for env in ({"TDTK_FUSE_SUMS": "1"}, {"TDTK_FUSE_SUMS": "3"}, {"TDTK_FUSE_SUMS": "3", "TDTK_REFILL_PHASES": "1"}, {"TDTK_SEARCH_VARIANT": "30"}, {"TDTK_SEARCH_VARIANT": "30", "TDTK_STREAM_SLAB": "64", "TDTK_STREAM_WPS": "7"},
                 {"TDTK_SEARCH_VARIANT": "8"}, {"TDTK_SEARCH_VARIANT": "4"}, {"TDTK_SEARCH_VARIANT": "0"},
+                {"TDTK_SEARCH_VARIANT": "4", "TDTK_FUSE_SUMS": "0"}, {"TDTK_SEARCH_VARIANT": "10"}, {"TDTK_SEARCH_VARIANT": "10", "TDTK_FUSE_SUMS": "0"},
                 {"TDTK_SEARCH_VARIANT": "40"}, {"TDTK_SEARCH_VARIANT": "41"},
                 {"TDTK_REFILL_QPW": "128", "TDTK_REFILL_THRESH": "8"}, {"TDTK_REFILL_QPW": "512", "TDTK_REFILL_THRESH": "32"},
                 {"TDTK_REFILL_POOL": "25"}, {"TDTK_REFILL_POOL": "60", "TDTK_REFILL_POOL_SLAB": "48"}, {"TDTK_REFILL_PHASES": "1"}):
