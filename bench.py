@@ -351,6 +351,7 @@ def bench_icp(args, rank, world, local):
         outside = dq * 1e3 / (itp + 1) - (probe.last["nn_ms"] + probe.last["sums_ms"]) / (itp + 1)
         del scratch
         settle["rounds"] += 1
+        settle["iterations"] = settle.get("iterations", 0) + itp + 1
         if settle["outside_ms_first"] is None:
             settle["outside_ms_first"] = outside
         settle["outside_ms_last"] = outside
@@ -448,6 +449,8 @@ def bench_icp(args, rank, world, local):
                              "(tdtk_kernel_timing; same launches, final RMS equal): %.4f ms per iteration with the events, "
                              "%.4f without (the timed region)" % (args.warmup, steps, dt_ev * 1e3 / steps, dt * 1e3 / steps),
         "ms_per_step_with_kernel_events": dt_ev * 1e3 / steps,
+        # for whoever reads a kernel trace of this command: the timed region is search launches [first, first + steps)
+        "search_launches_before_timed_region": settle.get("iterations", 0) + max(1, args.warmup),
         "roofline": roof,
     }
     # tree build (A1) on the device: a latency chain (the reference's serial-order fp64 centroid), reported against

@@ -25,6 +25,15 @@ def short(n):
         return "k_search"
     return n
 
+def timed_region(passname):
+    """(first, count) of the bench's timed search launches within a pass: bench.py prints how many search launches
+    precede its timed region (settle rounds + warm-up) and how many steps it timed"""
+    try:
+        d = json.loads(open(os.path.join(src, passname + ".json")).read().strip().splitlines()[-1])
+        return int(d["search_launches_before_timed_region"]), int(d["steps"])
+    except Exception:
+        return 10, 100
+
 # --- kernel stats (from the kernel trace of the --stats run)
 rows = list(csv.DictReader(open(os.path.join(src, "stats", "p_kernel_trace.csv"))))
 agg = collections.defaultdict(list)
@@ -34,8 +43,9 @@ for r in rows:
 # the host-buffer legs after); listed separately so it can be compared with bench.py's HIP-event average
 loop = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows
         if short(r["Kernel_Name"]) == "k_search" and "k_search_refill<" in r["Kernel_Name"]]
-if len(loop) >= 110:
-    agg["k_search [timed region: launches 11-110]"] = loop[10:110]
+t_first, t_n = timed_region("stats")
+if len(loop) >= t_first + t_n:
+    agg["k_search [timed region: launches %d-%d]" % (t_first + 1, t_first + t_n)] = loop[t_first:t_first + t_n]
 tot = sum(sum(v) for k, v in agg.items() if not k.startswith("k_search ["))
 with open(os.path.join("profiles", pre + "_kernel_stats.csv"), "w") as f:
     f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
@@ -64,11 +74,12 @@ for p in ("fetch", "write", "sq1", "sq2", "sq3", "tcc"):
         name = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
         pmc["kernels"].setdefault(k, {})[name] = sum(v) / len(v)
         pmc["kernels"][k]["dispatches_" + p] = len(v)
+    p_first, p_n = timed_region(p)
     for c, d in seen.items():
         vals = [d[i] for i in sorted(d)]
-        if len(vals) >= 110:
+        if len(vals) >= p_first + p_n:
             name = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
-            pmc["kernels"].setdefault("k_search [timed region]", {})[name] = sum(vals[10:110]) / 100.0
+            pmc["kernels"].setdefault("k_search [timed region]", {})[name] = sum(vals[p_first:p_first + p_n]) / float(p_n)
 json.dump(pmc, open(os.path.join("profiles", pre + "_pmc_bench.json"), "w"), indent=1, sort_keys=True)
 for p in ("stats",):
     fn = os.path.join(src, p + ".json")
