@@ -675,11 +675,11 @@ __global__ void k_big_dbg_compare(const BSeg* __restrict__ segs, const BLevel* _
 }
 
 // ---- per node: leaf or internal, split axis / value (kdTreeImpl.h:113-170) ----------------------
-__global__ void k_decide(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t bound,
-                         const BMeas* __restrict__ meas, uint32_t bucket, uint32_t* __restrict__ kind,
-                         uint32_t* __restrict__ axis, double* __restrict__ splitval, uint32_t* __restrict__ nleft)
+__device__ __forceinline__ void decide_node(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t bound,
+                                            const BMeas* __restrict__ meas, uint32_t bucket, uint32_t* __restrict__ kind,
+                                            uint32_t* __restrict__ axis, double* __restrict__ splitval,
+                                            uint32_t* __restrict__ nleft, const uint32_t i)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > bound) return;
   if (i >= lv->nseg) { kind[i] = 0u; return; }   // zero padding: the rank scan runs over `bound + 1` entries
   nleft[i] = 0u;                                 // filled by k_count
@@ -694,15 +694,21 @@ __global__ void k_decide(const BSeg* __restrict__ segs, const BLevel* __restrict
   axis[i] = (uint32_t)ax;
   splitval[i] = m.mean[ax];
 }
+__global__ void k_decide(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t bound,
+                         const BMeas* __restrict__ meas, uint32_t bucket, uint32_t* __restrict__ kind,
+                         uint32_t* __restrict__ axis, double* __restrict__ splitval, uint32_t* __restrict__ nleft)
+{
+  decide_node(segs, lv, bound, meas, bucket, kind, axis, splitval, nleft, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // ---- per node: write the record / register the bucket, hook it into its parent ------------------
-__global__ void k_emit(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, const BMeas* __restrict__ meas,
-                       const uint32_t* __restrict__ kind, const uint32_t* __restrict__ axis,
-                       const double* __restrict__ splitval, const uint32_t* __restrict__ irank,
-                       KdNode* __restrict__ nodes, double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
-                       uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
+__device__ __forceinline__ void emit_node(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, const BMeas* __restrict__ meas,
+                                          const uint32_t* __restrict__ kind, const uint32_t* __restrict__ axis,
+                                          const double* __restrict__ splitval, const uint32_t* __restrict__ irank,
+                                          KdNode* __restrict__ nodes, double* __restrict__ node_r,
+                                          LeafEntry* __restrict__ leaf_tab, uint32_t* __restrict__ root_ref,
+                                          uint32_t* __restrict__ max_leaf, const uint32_t i)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nseg = lv[0].nseg, node_base = lv[0].node_base, leaf_base = lv[0].leaf_base;
   if (i == 0) {   // the next level: two children per internal node of this one
     const uint32_t n_internal = irank[nseg];
@@ -739,6 +745,42 @@ __global__ void k_emit(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, c
     uint32_t* slot = sg.side ? &nodes[sg.parent].c2 : &nodes[sg.parent].c1;
     *slot = (*slot & REF_AXIS) | ref;
   }
+}
+__global__ void k_emit(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, const BMeas* __restrict__ meas,
+                       const uint32_t* __restrict__ kind, const uint32_t* __restrict__ axis,
+                       const double* __restrict__ splitval, const uint32_t* __restrict__ irank,
+                       KdNode* __restrict__ nodes, double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                       uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
+{
+  emit_node(segs, lv, meas, kind, axis, splitval, irank, nodes, node_r, leaf_tab, root_ref, max_leaf,
+            blockIdx.x * blockDim.x + threadIdx.x);
+}
+// a level of at most 1023 nodes (the first ten of any tree): decide, rank (exclusive scan of `kind` over bound + 1
+// entries) and emit in one workgroup -- three dependent launches less per level, which is what a small scan's build is
+// made of (~13 launches per level at ~4.5 us each)
+__global__ void __launch_bounds__(1024) k_nodes_small(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, uint32_t bound,
+                                                      const BMeas* __restrict__ meas, uint32_t bucket,
+                                                      uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
+                                                      double* __restrict__ splitval, uint32_t* __restrict__ nleft,
+                                                      uint32_t* __restrict__ irank, KdNode* __restrict__ nodes,
+                                                      double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                                                      uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
+{
+  __shared__ uint32_t wtot[1024 / WAVE];
+  const uint32_t i = threadIdx.x;
+  decide_node(segs, lv, bound, meas, bucket, kind, axis, splitval, nleft, i);
+  const uint32_t k = (i <= bound) ? kind[i] : 0u;          // this thread's own store
+  const unsigned long long m = __ballot(k != 0u);
+  const uint32_t lane = i & (WAVE - 1), wv = i / WAVE;
+  if (lane == 0) wtot[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wv; w++) before += wtot[w];
+  const uint32_t r = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (i <= bound) irank[i] = r;
+  __threadfence_block();
+  __syncthreads();                                          // emit reads irank[nseg] and other nodes' nothing else
+  emit_node(segs, lv, meas, kind, axis, splitval, irank, nodes, node_r, leaf_tab, root_ref, max_leaf, i);
 }
 
 // ---- per node: how many of its points lie below the split value (the position of the split) ---------------
@@ -797,13 +839,12 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ seg_
 }
 
 // ---- per element: misplaced on the left / on the right of its node's split position --------------
-__global__ void k_misplaced(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+__device__ __forceinline__ void misplaced_at(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
                             const BSeg* __restrict__ segs, const uint32_t* __restrict__ axis,
                             const double* __restrict__ splitval, const uint32_t* __restrict__ nleft,
                             const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
-                            uint32_t M, unsigned long long* __restrict__ LR)
+                            uint32_t M, unsigned long long* __restrict__ LR, const uint32_t p)
 {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > M) return;
   uint32_t l = 0, r = 0;
   if (p < M) {
@@ -840,11 +881,10 @@ __global__ void k_swaplist(const uint32_t* __restrict__ seg_of, const BSeg* __re
 }
 
 // launched over M/2 slots (an element is misplaced at most once per level); the count sits on the device
-__global__ void k_swap(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
+__device__ __forceinline__ void swap_at(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
                        const unsigned long long* __restrict__ nswap_ptr, uint32_t* __restrict__ perm,
-                       double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz)
+                       double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz, const uint32_t c)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= (uint32_t)*nswap_ptr) return;
   const uint32_t a = posL[c], b = posR[c];
   const uint32_t pa = perm[a], pb = perm[b];
@@ -856,11 +896,10 @@ __global__ void k_swap(const uint32_t* __restrict__ posL, const uint32_t* __rest
 }
 
 // ---- next level: two children per internal node; relabel the elements ---------------------------
-__global__ void k_children(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind,
+__device__ __forceinline__ void children_of(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind,
                            const uint32_t* __restrict__ irank, const uint32_t* __restrict__ nleft_,
-                           BSeg* __restrict__ next, uint32_t* __restrict__ err)
+                           BSeg* __restrict__ next, uint32_t* __restrict__ err, const uint32_t i)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lv->nseg || !kind[i]) return;
   const BSeg sg = segs[i];
   uint32_t nleft = nleft_[i];
@@ -872,16 +911,38 @@ __global__ void k_children(const BSeg* __restrict__ segs, const BLevel* __restri
   next[2 * irank[i]] = {sg.start, nleft, (int32_t)me, 0u};
   next[2 * irank[i] + 1] = {sg.start + nleft, sg.n - nleft, (int32_t)me, 1u};
 }
-__global__ void k_relabel(const BSeg* __restrict__ segs, const uint32_t* __restrict__ kind,
+__device__ __forceinline__ void relabel_at(const BSeg* __restrict__ segs, const uint32_t* __restrict__ kind,
                           const uint32_t* __restrict__ irank, const uint32_t* __restrict__ nleft, uint32_t M,
-                          uint32_t* __restrict__ seg_of)
+                          uint32_t* __restrict__ seg_of, const uint32_t p)
 {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   const uint32_t sg = seg_of[p];
   if (sg == 0xFFFFFFFFu) return;
   if (!kind[sg]) { seg_of[p] = 0xFFFFFFFFu; return; }
   seg_of[p] = 2u * irank[sg] + (((p - segs[sg].start) < nleft[sg]) ? 0u : 1u);
+}
+// two independent passes per launch (the first `nb_first` workgroups run the one, the rest the other): every launch of
+// a level waits for the one before it, and there are levels x a dozen of them
+__global__ void k_misplaced_children(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+                                     const BSeg* __restrict__ segs, const uint32_t* __restrict__ axis,
+                                     const double* __restrict__ splitval, const uint32_t* __restrict__ nleft,
+                                     const double* __restrict__ cx, const double* __restrict__ cy,
+                                     const double* __restrict__ cz, uint32_t M, unsigned long long* __restrict__ LR,
+                                     uint32_t nb_first, const BLevel* __restrict__ lv, const uint32_t* __restrict__ irank,
+                                     BSeg* __restrict__ next, uint32_t* __restrict__ err)
+{
+  if (blockIdx.x < nb_first) misplaced_at(seg_of, kind, segs, axis, splitval, nleft, cx, cy, cz, M, LR, blockIdx.x * blockDim.x + threadIdx.x);
+  else children_of(segs, lv, kind, irank, nleft, next, err, (blockIdx.x - nb_first) * blockDim.x + threadIdx.x);
+}
+__global__ void k_swap_relabel(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
+                               const unsigned long long* __restrict__ nswap_ptr, uint32_t* __restrict__ perm,
+                               double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz, uint32_t nb_first,
+                               const BSeg* __restrict__ segs, const uint32_t* __restrict__ kind,
+                               const uint32_t* __restrict__ irank, const uint32_t* __restrict__ nleft, uint32_t M,
+                               uint32_t* __restrict__ seg_of)
+{
+  if (blockIdx.x < nb_first) swap_at(posL, posR, nswap_ptr, perm, cx, cy, cz, blockIdx.x * blockDim.x + threadIdx.x);
+  else relabel_at(segs, kind, irank, nleft, M, seg_of, (blockIdx.x - nb_first) * blockDim.x + threadIdx.x);
 }
 
 __global__ void k_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
@@ -1036,24 +1097,33 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
             hipLaunchKernelGGL(k_big_dbg_compare, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, meas, meas2, level);
           }
         }
-        hipLaunchKernelGGL(k_decide, dim3(cdiv(bound + 1, 256)), dim3(256), 0, s, segs, lv, (uint32_t)bound, meas,
-                           (uint32_t)bucket, kind, axis, splitval, nleft);
         size_t st = scan_tmp;
-        BCHK(rocprim::exclusive_scan(tmp, st, kind, irank, 0u, bound + 1, rocprim::plus<uint32_t>(), s));
-        hipLaunchKernelGGL(k_emit, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, kind, axis, splitval,
-                           irank, nodes, node_r, leaf_tab, small + 0, small + 1);
+        if (bound + 1 <= 1024) {
+          hipLaunchKernelGGL(k_nodes_small, dim3(1), dim3(1024), 0, s, segs, lvl + level, (uint32_t)bound, meas, (uint32_t)bucket,
+                             kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, small + 0, small + 1);
+        } else {
+          hipLaunchKernelGGL(k_decide, dim3(cdiv(bound + 1, 256)), dim3(256), 0, s, segs, lv, (uint32_t)bound, meas,
+                             (uint32_t)bucket, kind, axis, splitval, nleft);
+          BCHK(rocprim::exclusive_scan(tmp, st, kind, irank, 0u, bound + 1, rocprim::plus<uint32_t>(), s));
+          hipLaunchKernelGGL(k_emit, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, kind, axis, splitval,
+                             irank, nodes, node_r, leaf_tab, small + 0, small + 1);
+        }
         // the partition pass (with no internal node at this level it moves nothing)
         hipLaunchKernelGGL(k_count, dim3(cdiv(M, 256 * CNT_ITERS)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy,
                            cz, M, nleft);
-        hipLaunchKernelGGL(k_misplaced, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, kind, segs, axis, splitval, nleft,
-                           cx, cy, cz, M, LR);
+        {
+          const uint32_t nbm = cdiv(n1, 256);
+          hipLaunchKernelGGL(k_misplaced_children, dim3(nbm + cdiv(bound, 256)), dim3(256), 0, s, seg_of, kind, segs, axis,
+                             splitval, nleft, cx, cy, cz, M, LR, nbm, lv, irank, next, small + 2);
+        }
         st = scan_tmp;
         BCHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
         hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
-        hipLaunchKernelGGL(k_children, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, kind, irank, nleft, next,
-                           small + 2);
-        hipLaunchKernelGGL(k_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
-        hipLaunchKernelGGL(k_relabel, dim3(cdiv(M, 256)), dim3(256), 0, s, segs, kind, irank, nleft, M, seg_of);
+        {
+          const uint32_t nbs = cdiv((size_t)M / 2 + 1, 256);
+          hipLaunchKernelGGL(k_swap_relabel, dim3(nbs + cdiv(M, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz, nbs,
+                             segs, kind, irank, nleft, M, seg_of);
+        }
         BSeg* t = segs; segs = next; next = t;
       }
       uint32_t bad = 0;
