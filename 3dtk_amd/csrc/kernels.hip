@@ -1327,7 +1327,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     const uint32_t wid = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
     if (wid < WTRACE_MAX) {
       g_wtrace[3 * wid] = trace_t0; g_wtrace[3 * wid + 1] = wall_clock64();
-      g_wtrace[3 * wid + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
+      // XCC_ID in bits 0-2, HW_REG_HW_ID (register 4: wave, simd, cu, sh, se ...) above it
+      g_wtrace[3 * wid + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) |
+                              ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) << 8);
     }
   }
   if (COUNT && a.counters) {

@@ -14,5 +14,5 @@ print("%d waves, launch span %.1f us; wave lifetime mean %.1f us (%.0f %% of the
 end = (a[:, 4] - t0) / 100.0
 print("wave end time percentiles (us): " + "  ".join("p%d %.1f" % (p, np.percentile(end, p)) for p in (1, 10, 25, 50, 75, 90, 99, 100)))
 for x in range(8):
-    e = end[a[:, 2] == x]
+    e = end[(a[:, 2] & 7) == x]
     if len(e): print("XCD %d: %4d waves, last ends %.1f us, median %.1f us" % (x, len(e), e.max(), np.median(e)))
