@@ -67,7 +67,7 @@ struct DevBuf {
 };
 
 enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
-       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COUNT };
+       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COST, WS_COUNT };
 
 // an auxiliary stream with the buffers one whole-scan pass needs: batches of links over small scans run several
 // passes side by side (one pass of an 80K-point scan occupies a fraction of the machine and is latency-bound)
@@ -789,6 +789,16 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.maxd2 = maxd2;
     sa.kpos = c->ws[WS_KPOS].as<int>();
     sa.warm = (warm && pmode != 1) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
+    {
+      // ... and WS_COST how many buckets each of its queries visited then: the persistent-lane kernel hands a wave's slab
+      // out with the expensive queries first (TDTK_COST_ORDER=0: in slab order)
+      const char* co = getenv("TDTK_COST_ORDER");
+      if (pmode != 1 && !(co && co[0] == '0') && search_fuse_kind(N) == 1) {
+        if ((rc = c->ws[WS_COST].ensure(N))) return rc;
+        sa.cost = c->ws[WS_COST].as<unsigned char>();
+        sa.use_cost = sa.warm;
+      }
+    }
     sa.d2 = nullptr;
     uint32_t rows = 0;
     if (fused) {

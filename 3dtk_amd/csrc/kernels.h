@@ -47,6 +47,11 @@ struct SearchArgs {
                      // of pieces this long, drawn when a wave runs dry (q_ctr: one counter per XCD); region = queries per XCD
   size_t region;
   int trace;         // diagnostics (TDTK_WAVE_TRACE=<launch>): every wave prints its XCD, start and end time
+  // persistent-lane kernel: buckets each query visited (saturating byte, written when it retires; nullptr: not wanted);
+  // use_cost != 0: the bytes of the PREVIOUS pass of the same queries are valid, and a wave hands out each piece of its
+  // slab with the expensive queries first
+  unsigned char* cost;
+  int use_cost;
   int side_by_side;  // > 1: one of that many whole-scan passes running concurrently on streams of their own (set by the caller)
   int phases;   // persistent-lane kernel: a wave's slab is handed out in this many pieces (see k_search_refill)
   int fuse;

@@ -1023,7 +1023,7 @@ __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -1044,6 +1044,40 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
 
+  // "expensive queries first": the order in which a piece of the slab is handed out (offsets within the piece), by the
+  // number of buckets each query visited in the previous pass.  Lanes that work on queries of similar length at the same
+  // time waste fewer of each other's issue slots, and the drain at the end of the piece is over cheap queries
+  // (tools/sim/wave_sched.c: -7 % wave instructions on a converged pair, -14 % mid-ICP with the true costs as the key).
+  constexpr int ORD_MAX = 256;
+  __shared__ unsigned char lds_order[ORDER ? BLOCK / WAVE : 1][ORDER ? ORD_MAX : 4];
+  unsigned char* const my_order = lds_order[ORDER ? threadIdx.x / WAVE : 0];
+  bool ordered = false;
+  size_t piece0 = 0;
+  auto order_piece = [&](size_t p0, size_t p1) {
+    ordered = false;
+    piece0 = p0;
+    if (!ORDER || !a.use_cost || !a.cost || p1 <= p0 || p1 - p0 > (size_t)ORD_MAX) return;
+    const uint32_t cntp = (uint32_t)(p1 - p0);
+    int cls[ORD_MAX / WAVE];
+#pragma unroll
+    for (int r = 0; r < ORD_MAX / WAVE; r++) {
+      const uint32_t o = (uint32_t)r * WAVE + lane;
+      cls[r] = (o < cntp) ? (int)min((unsigned)a.cost[p0 + o], 7u) : -1;
+    }
+    uint32_t base = 0;
+    for (int k = 7; k >= 0; k--) {
+#pragma unroll
+      for (int r = 0; r < ORD_MAX / WAVE; r++) {
+        if ((uint32_t)r * WAVE >= cntp) continue;
+        const unsigned long long m = __ballot(cls[r] == k);
+        if (cls[r] == k) my_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)(r * WAVE + lane);
+        base += (uint32_t)__popcll(m);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ordered = true;
+  };
   size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
   size_t sub = 0, reg0 = 0, pstride = 0, pool0 = 0, pool_end = 0;
   bool exhausted = false;
@@ -1090,6 +1124,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       end_q = next_q + sub;
       if (next_q > a.n) next_q = a.n;
       if (end_q > a.n) end_q = a.n;
+      order_piece(next_q, end_q);
     }
   }
 
@@ -1102,6 +1137,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f;
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
+  unsigned nbk = 0;   // buckets this lane's query has visited (the next pass's ordering key)
   // FUSE 1: the base pair sums (ACC_N .. ACC_P) at retire time; FUSE 2: n, sum and the LUM block of a graph-SLAM link
   // (acc[0] = n, [1] = sum |delta|^2, [2 .. 16] = the 15 sums of lum6Deuler.cc:143-175, [17] = sum u.delta)
   constexpr int NACC = (FUSE == 2) ? 18 : ACC_DD;
@@ -1117,6 +1153,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     if (idle && have) {
       a.kpos[qi] = bk;
       if (a.d2) a.d2[qi] = best;
+      if (ORDER && a.cost) a.cost[qi] = (unsigned char)min(nbk, 255u);
       have = false;
       if constexpr (FUSE == 2) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
@@ -1193,11 +1230,14 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       end_q = next_q + sub;
       if (next_q > a.n) next_q = a.n;
       if (end_q > a.n) end_q = a.n;
+      order_piece(next_q, end_q);
     }
     if (next_q < end_q && fill) {
       const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
-      const size_t mine = next_q + rank;
-      if (idle && mine < end_q) {
+      const size_t slot = next_q + rank;                // position in the hand-out order of the piece
+      const bool got = idle && slot < end_q;
+      const size_t mine = (ORDER && got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
+      if (got) {
         // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
         const int kp_prev = a.warm ? a.kpos[mine] : -1;
         double tx = a.x[mine], ty = a.y[mine], tz = a.z[mine];
@@ -1212,7 +1252,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         }
         qx = tx; qy = ty; qz = tz;
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
-        qi = mine; have = true;
+        qi = mine; have = true; nbk = 0;
         cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
         bx.set_query(qx, qy, qz, T.absmax);
         bx.set_radius(best);
@@ -1290,6 +1330,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         count = (int)(v & T.cmask);
       }
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
+      if (ORDER) ++nbk;
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
@@ -1435,7 +1476,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const Search
   while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
   l = __builtin_amdgcn_readfirstlane(l);
   const uint32_t b0 = base[l], b1 = base[l + 1];
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false>(args[l], blockIdx.x - b0, b1 - b0);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, false>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2182,6 +2223,9 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     a.pool_slab = e ? std::max(16, atoi(e)) : 64;
   }
   int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7 || a.side_by_side > 1 || a.pool_slab) ? 1 : 2;
+  // with the slab handed out expensive queries first (a.use_cost) one piece is better: the order then spans the whole
+  // slab (1M: 0.2124 -> 0.2086 ms; the twenty iterations behind the initial pose 0.2425 -> 0.2326)
+  if (a.use_cost) ph = 1;
   if (const char* e = getenv("TDTK_REFILL_PHASES")) ph = atoi(e);
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries

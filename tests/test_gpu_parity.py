@@ -324,6 +324,27 @@ def test_kernel_timing_is_opt_in_and_changes_nothing(tdtk, gpu):
         assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
 
 
+def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch):
+    """From the second ICP iteration on the persistent-lane kernel hands a wave's slab out with the queries first that
+    visited most buckets in the previous pass (TDTK_COST_ORDER=0: in slab order).  Only the order in which a wave works
+    through its own queries changes: every iteration's pair count, RMS and pose are the same bit for bit."""
+    rng = np.random.default_rng(77)
+    m = rng.uniform(-600, 600, (300000, 3))
+    d = m[rng.permutation(len(m))] + rng.normal(0, 1.0, m.shape)
+    d = d + np.array([6.0, -4.0, 3.0])
+    runs = []
+    for on in ("0", "1", "1"):
+        monkeypatch.setenv("TDTK_COST_ORDER", on)
+        S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], m); S1 = tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 12, quiet=True, epsilonICP=-1.0)
+        it = icp.match(S0, S1)
+        runs.append((it, icp.last["trace"].copy(), S1.get_transMat().copy()))
+    monkeypatch.delenv("TDTK_COST_ORDER")
+    assert runs[0][0] == 11 and runs[0][1][-1, 0] > 0.9 * len(m)
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
+
+
 def test_icp_point_to_plane_napx(tdtk, orc, gpu):
     """-a 10 (icp6D_NAPX, the 6x6 point-to-plane system) with -z style plane projection."""
     from oracle import icp_oracle as io

@@ -119,6 +119,33 @@ static void run_wave(const Trace* T, int nq, int thresh, int helpers, Cost* c)
   }
 }
 
+// "expensive queries first" (the previous ICP iteration's bucket count as the key): does the drain at the end of a
+// slab get shorter, and the spread of the waves' lifetimes narrower?  The slab is handed out in `pieces` pieces.
+static int cost_mode = 0;   // 0: buckets visited (what the kernel records), 1: node trips + point trips
+static int cost_of(const Trace* t)
+{
+  int c = 0;
+  if (cost_mode == 0) { for (int s = 1; s < t->nseg; s += 2) c++; return c; }
+  for (int s = 0; s < t->nseg; s++) c += (s & 1) ? (t->seg[s] + 3) / 4 : t->seg[s];
+  return c;
+}
+static int cmp_cost_desc(const void* a, const void* b) { return cost_of((const Trace*)b) - cost_of((const Trace*)a); }
+static void order_slab(Trace* T, int nq, int pieces, int classes)
+{
+  const int per = nq / pieces;
+  for (int p = 0; p < pieces; p++) {
+    Trace* t = T + p * per;
+    const int n = (p == pieces - 1) ? nq - p * per : per;
+    if (classes == 0) qsort(t, n, sizeof(Trace), cmp_cost_desc);          // full order (qsort is not stable: fine for a model)
+    else {                                                                 // two classes: >= `classes` buckets first, stable
+      Trace tmp[512]; int k = 0;
+      for (int i = 0; i < n; i++) if (cost_of(&t[i]) >= classes) tmp[k++] = t[i];
+      for (int i = 0; i < n; i++) if (cost_of(&t[i]) < classes) tmp[k++] = t[i];
+      memcpy(t, tmp, sizeof(Trace) * n);
+    }
+  }
+}
+
 int main(int argc, char** argv)
 {
   int M = argc > 1 ? atoi(argv[1]) : 1000000;
@@ -136,6 +163,7 @@ int main(int argc, char** argv)
   Trace* T = malloc(sizeof(Trace) * qpw);
   double tot_nodes = 0, tot_leaves = 0, tot_pts = 0; long nqs = 0;
   Cost pol[8]; memset(pol, 0, sizeof pol);
+  double lpt_sum[4] = {0, 0, 0, 0}, lpt_sq[4] = {0, 0, 0, 0};
   const char* names[8] = {"thresh 16 (kernel)", "thresh 8", "thresh 32", "thresh 64 (drain)", "thresh 16 + bucket helpers", "thresh 32 + bucket helpers", "thresh 1", "thresh 48"};
   for (int w = 0; w < nwaves; w++) {
     size_t base = (size_t)((double)w / nwaves * (NQ - qpw));
@@ -155,6 +183,22 @@ int main(int argc, char** argv)
     }
     run_wave(T, qpw, 16, 0, &pol[0]); run_wave(T, qpw, 8, 0, &pol[1]); run_wave(T, qpw, 32, 0, &pol[2]); run_wave(T, qpw, 64, 0, &pol[3]);
     run_wave(T, qpw, 16, 1, &pol[4]); run_wave(T, qpw, 32, 1, &pol[5]); run_wave(T, qpw, 1, 0, &pol[6]); run_wave(T, qpw, 48, 0, &pol[7]);
+    {   // per-wave totals of the kernel's policy in slab order, in "expensive first" order (full / two classes)
+      static Trace T2[512];
+      Cost a0; memset(&a0, 0, sizeof a0); run_wave(T, qpw, 16, 0, &a0);
+      memcpy(T2, T, sizeof(Trace) * qpw); order_slab(T2, qpw, 2, 0);
+      Cost a1; memset(&a1, 0, sizeof a1); run_wave(T2, qpw, 16, 0, &a1);
+      memcpy(T2, T, sizeof(Trace) * qpw); order_slab(T2, qpw, 1, 0);
+      Cost a2; memset(&a2, 0, sizeof a2); run_wave(T2, qpw, 16, 0, &a2);
+      cost_mode = 1;
+      memcpy(T2, T, sizeof(Trace) * qpw); order_slab(T2, qpw, 1, 0);
+      Cost a3; memset(&a3, 0, sizeof a3); run_wave(T2, qpw, 16, 0, &a3);
+      cost_mode = 0;
+      lpt_sum[3] += a3.valu; lpt_sq[3] += a3.valu * a3.valu;
+      lpt_sum[0] += a0.valu; lpt_sq[0] += a0.valu * a0.valu;
+      lpt_sum[1] += a1.valu; lpt_sq[1] += a1.valu * a1.valu;
+      lpt_sum[2] += a2.valu; lpt_sq[2] += a2.valu * a2.valu;
+    }
   }
   printf("%d points, offset %.1f noise %.1f radius %.1f warm %d: per query %.2f nodes, %.2f leaves, %.2f points\n", M, offset, noise, radius, warm,
          tot_nodes / nqs, tot_leaves / nqs, tot_pts / nqs);
@@ -162,5 +206,10 @@ int main(int argc, char** argv)
     printf("%-30s VALU wave-instr/query %6.1f   node trips/query %5.2f (lane eff %4.1f%%)   point trips/query %5.2f (lane eff %4.1f%%)  refills/query %.3f\n", names[p],
            pol[p].valu / nqs, pol[p].node_trips / nqs, 100.0 * pol[p].lane_node / (64.0 * pol[p].node_trips), pol[p].pt_trips / nqs,
            100.0 * pol[p].lane_pt / (64.0 * pol[p].pt_trips), pol[p].refills / nqs);
+  const char* ln[4] = {"slab order", "expensive first (buckets), 2 pieces", "expensive first (buckets), 1 piece", "expensive first (all trips), 1 piece"};
+  for (int k = 0; k < 4; k++) {
+    const double m = lpt_sum[k] / nwaves, sd = sqrt(lpt_sq[k] / nwaves - m * m);
+    printf("%-44s VALU instr / wave: mean %8.0f  sd %6.0f (%.1f %%)  mean + 3.5 sd %8.0f\n", ln[k], m, sd, 100 * sd / m, m + 3.5 * sd);
+  }
   return 0;
 }
