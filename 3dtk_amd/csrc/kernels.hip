@@ -1058,11 +1058,27 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     piece0 = p0;
     if (!ORDER || !a.use_cost || !a.cost || p1 <= p0 || p1 - p0 > (size_t)ORD_MAX) return;
     const uint32_t cntp = (uint32_t)(p1 - p0);
+    // eight classes between the cheapest and the most expensive query of the piece (the key is node visits + 4 per
+    // bucket of the previous pass; its range depends on the depth of the tree and on how far the poses still are)
     int cls[ORD_MAX / WAVE];
+    unsigned cvv[ORD_MAX / WAVE];
+    unsigned mn = 255u, mx = 0u;
 #pragma unroll
     for (int r = 0; r < ORD_MAX / WAVE; r++) {
       const uint32_t o = (uint32_t)r * WAVE + lane;
-      cls[r] = (o < cntp) ? (int)min((unsigned)a.cost[p0 + o], 7u) : -1;
+      cvv[r] = (o < cntp) ? (unsigned)a.cost[p0 + o] : 0u;
+      if (o < cntp) { mn = min(mn, cvv[r]); mx = max(mx, cvv[r]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, (unsigned)__shfl_xor((int)mn, off, WAVE));
+      mx = max(mx, (unsigned)__shfl_xor((int)mx, off, WAVE));
+    }
+    const unsigned span = (mx > mn) ? mx - mn + 1u : 1u;
+#pragma unroll
+    for (int r = 0; r < ORD_MAX / WAVE; r++) {
+      const uint32_t o = (uint32_t)r * WAVE + lane;
+      cls[r] = (o < cntp) ? (int)min(((cvv[r] - mn) * 8u) / span, 7u) : -1;
     }
     uint32_t base = 0;
     for (int k = 7; k >= 0; k--) {
@@ -1153,7 +1169,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     if (idle && have) {
       a.kpos[qi] = bk;
       if (a.d2) a.d2[qi] = best;
-      if (ORDER && a.cost) a.cost[qi] = (unsigned char)min(nbk, 255u);
+      if (ORDER && a.cost) a.cost[qi] = (unsigned char)min(nbk, 255u);   // nbk: node visits + 4 per bucket
       have = false;
       if constexpr (FUSE == 2) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
@@ -1267,6 +1283,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     // ---- phase 1: walk internal nodes until this lane holds a bucket (or is finished) ----
     while (!(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
+      if (ORDER) ++nbk;
       bool need_pop = false;
       uint32_t next = REF_DONE;
       const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
@@ -1330,7 +1347,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         count = (int)(v & T.cmask);
       }
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
-      if (ORDER) ++nbk;
+      if (ORDER) nbk += 4u;
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
