@@ -746,3 +746,27 @@ def test_product_and_bench_keep_clear_of_the_oracle():
         fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
         ctx = head[head.rfind("\ndef "):]
         assert fn == "cpu_baseline_nn" or "no_cpu" in ctx[ctx.rfind("if "):], (fn, m.group(0))
+
+
+def test_timed_search_kernels_keep_five_waves_per_simd():
+    """The persistent-lane search kernel of the ICP loop uses exactly the 96 vector registers that still allow five
+    waves per SIMD (one more and a 1M-point launch takes 0.258 ms instead of 0.206); the several-links-per-launch kernel
+    of graph-SLAM has the same limit.  The build keeps the compiler's resource remarks; this reads them."""
+    import re
+    path = os.path.join(ROOT, "3dtk_amd", "csrc", "kernels.resource.txt")
+    if not os.path.exists(path):
+        pytest.skip("no build in this tree (kernels.resource.txt is written by the Makefile)")
+    text = open(path).read()
+    kernels = {
+        "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false>",
+        "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false>",
+        "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0>",
+    }
+    for mangled, name in kernels.items():
+        i = text.find("Function Name: " + mangled + " ")
+        assert i >= 0, "no resource remark for " + name
+        block = text[i:i + 1500]
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block).group(1))
+        vg = int(re.search(r"VGPRs: (\d+)", block).group(1))
+        spill = int(re.search(r"VGPRs Spill: (\d+)", block).group(1))
+        assert occ >= 5 and vg <= 96 and spill == 0, (name, occ, vg, spill)
