@@ -324,7 +324,8 @@ def test_kernel_timing_is_opt_in_and_changes_nothing(tdtk, gpu):
         assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
 
 
-def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch):
+@pytest.mark.parametrize("partial", [False, True])
+def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch, partial):
     """From the second ICP iteration on the persistent-lane kernel hands a wave's slab out with the queries first that
     visited most buckets in the previous pass (TDTK_COST_ORDER=0: in slab order).  Only the order in which a wave works
     through its own queries changes: every iteration's pair count, RMS and pose are the same bit for bit."""
@@ -332,6 +333,12 @@ def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch):
     m = rng.uniform(-600, 600, (300000, 3))
     d = m[rng.permutation(len(m))] + rng.normal(0, 1.0, m.shape)
     d = d + np.array([6.0, -4.0, 3.0])
+    if partial:
+        # half of the data scan lies outside the model (no partner within reach: walks of very different length in one
+        # slab), a tenth of it is a dense clump, and the model has repeated points
+        d[: len(d) // 2, 0] += 900.0
+        d[-len(d) // 10:] = d[-1] + rng.normal(0, 0.05, (len(d) // 10, 3))
+        m[1000:3000] = m[0:2000]
     runs = []
     for on in ("0", "1", "1"):
         monkeypatch.setenv("TDTK_COST_ORDER", on)
@@ -340,7 +347,7 @@ def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch):
         it = icp.match(S0, S1)
         runs.append((it, icp.last["trace"].copy(), S1.get_transMat().copy()))
     monkeypatch.delenv("TDTK_COST_ORDER")
-    assert runs[0][0] == 11 and runs[0][1][-1, 0] > 0.9 * len(m)
+    assert runs[0][0] == 11 and runs[0][1][-1, 0] > (0.3 if partial else 0.9) * len(m)
     for r in runs[1:]:
         assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
 
