@@ -8,13 +8,12 @@
 // Parity: unpinned (elch6D.cc needs Boost.Graph; no reference test pins its output).  Boost's
 // dijkstra_shortest_paths relaxes with a strict '<' and leaves predecessor[v] == v for unreached vertices; both are
 // kept.  Among EXACTLY equal path lengths Boost's 4-ary heap order decides, which is not reproduced -- edge weights
-// here are |diag(C^-1)| of real links, where exact ties do not occur.
+// here are |diag(C^-1)| of real links, where exact ties do not occur.  Round 3: the balancer is written on flat arrays
+// (edge switches, position-indexed open ends) instead of following the reference's list-iterator formulation.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
-#include <list>
-#include <queue>
 #include <vector>
 
 #include "tdtk_internal.h"
@@ -22,42 +21,71 @@
 using namespace tdtk;
 
 namespace {
-struct UGraph {   // adjacency_list<listS, vecS, undirectedS> with an edge weight: parallel edges allowed
-  int n;
-  std::vector<std::list<std::pair<int, double>>> adj;
-  explicit UGraph(int n_) : n(n_), adj(n_) {}
-  void add_edge(int a, int b, double w) { adj[a].push_back({b, w}); if (a != b) adj[b].push_back({a, w}); }
-  void remove_edge(int a, int b)   // removes ALL edges between a and b, like boost::remove_edge(u, v, g)
+
+// The loop graph as flat arrays: edge e joins ea[e] and eb[e] with weight ew[e] and can be switched off; every vertex
+// lists its incident edges in the order they were given (inc[first[v] .. first[v+1])), which is the order the
+// relaxations of the shortest-path search run in.  Parallel edges are allowed; a self loop is listed once.
+struct LoopGraph {
+  int nv = 0;
+  std::vector<int> ea, eb, first, inc, live_deg;
+  std::vector<double> ew;
+  std::vector<char> on;
+
+  void build(int nvertices, int nedges, const int32_t* from, const int32_t* to, const double* w)
   {
-    adj[a].remove_if([b](const std::pair<int, double>& e) { return e.first == b; });
-    if (a != b) adj[b].remove_if([a](const std::pair<int, double>& e) { return e.first == a; });
+    nv = nvertices;
+    ea.assign(from, from + nedges); eb.assign(to, to + nedges); ew.assign(w, w + nedges);
+    on.assign((size_t)nedges, 1);
+    live_deg.assign((size_t)nv, 0);
+    first.assign((size_t)nv + 1, 0);
+    for (int e = 0; e < nedges; e++) { first[ea[e] + 1]++; if (eb[e] != ea[e]) first[eb[e] + 1]++; }
+    for (int v = 0; v < nv; v++) { live_deg[v] = first[v + 1]; first[v + 1] += first[v]; }
+    inc.resize((size_t)first[nv]);
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    for (int e = 0; e < nedges; e++) { inc[fill[ea[e]]++] = e; if (eb[e] != ea[e]) inc[fill[eb[e]]++] = e; }
   }
-  int degree(int v) const { return (int)adj[v].size(); }
-  void clear_vertex(int v)
+  int other(int e, int v) const { return ea[e] == v ? eb[e] : ea[e]; }
+  void switch_off(int e)
   {
-    for (auto& e : adj[v])
-      if (e.first != v) adj[e.first].remove_if([v](const std::pair<int, double>& x) { return x.first == v; });
-    adj[v].clear();
+    if (!on[e]) return;
+    on[e] = 0;
+    live_deg[ea[e]]--;
+    if (eb[e] != ea[e]) live_deg[eb[e]]--;
+  }
+  // every edge between u and v goes (what boost::remove_edge(u, v, g) does on a multigraph)
+  void cut_between(int u, int v)
+  {
+    for (int k = first[u]; k < first[u + 1]; k++)
+      if (on[inc[k]] && other(inc[k], u) == v) switch_off(inc[k]);
+  }
+  void isolate(int v)
+  {
+    for (int k = first[v]; k < first[v + 1]; k++) switch_off(inc[k]);
   }
 };
 
-void dijkstra(const UGraph& g, int s, std::vector<int>& p, std::vector<double>& d)
+// Shortest paths from `src` over the edges still switched on.  The loop graphs of ELCH have tens to hundreds of vertices,
+// so the next vertex is found by a plain scan (smallest tentative length, lowest index among equals -- the order a
+// (length, vertex) min-heap pops in); a neighbour is re-parented only by a strictly shorter path.  parent[v] == v and
+// length == DBL_MAX mark a vertex that cannot be reached: the balancer tests exactly that.
+void shortest_paths(const LoopGraph& g, int src, int* parent, double* length, std::vector<char>& settled)
 {
-  const double inf = std::numeric_limits<double>::max();
-  for (int v = 0; v < g.n; v++) { p[v] = v; d[v] = inf; }
-  d[s] = 0.0;
-  typedef std::pair<double, int> QE;
-  std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
-  q.push({0.0, s});
-  std::vector<char> done(g.n, 0);
-  while (!q.empty()) {
-    const QE top = q.top(); q.pop();
-    const int u = top.second;
-    if (done[u] || top.first > d[u]) continue;
-    done[u] = 1;
-    for (const auto& e : g.adj[u]) {
-      const double nd = d[u] + e.second;
-      if (nd < d[e.first]) { d[e.first] = nd; p[e.first] = u; q.push({nd, e.first}); }
+  const double unreached = std::numeric_limits<double>::max();
+  for (int v = 0; v < g.nv; v++) { parent[v] = v; length[v] = unreached; }
+  settled.assign((size_t)g.nv, 0);
+  length[src] = 0.0;
+  for (;;) {
+    int u = -1;
+    for (int v = 0; v < g.nv; v++)
+      if (!settled[v] && length[v] != unreached && (u < 0 || length[v] < length[u])) u = v;
+    if (u < 0) return;
+    settled[u] = 1;
+    for (int k = g.first[u]; k < g.first[u + 1]; k++) {
+      const int e = g.inc[k];
+      if (!g.on[e]) continue;
+      const int t = g.other(e, u);
+      const double via = length[u] + g.ew[e];
+      if (via < length[t]) { length[t] = via; parent[t] = u; }
     }
   }
 }
@@ -65,6 +93,13 @@ void dijkstra(const UGraph& g, int s, std::vector<int>& p, std::vector<double>& 
 
 extern "C" {
 
+// elch6D::graph_balancer (elch6D.cc:186-279): distribute the loop-closing error over the vertices of the loop graph.
+// weights[f] = 0, weights[l] = 1; repeatedly the two closest "open ends" (vertices whose weight is known and that still
+// have edges) are joined by their shortest path, the vertices on it get weights interpolated by path length, the path's
+// edges leave the graph and its inner vertices become open ends themselves; an open end that reaches no other one
+// starts a dangling part, which inherits its weight.  The result depends on the order in which pairs are joined, so the
+// scan order of the reference is kept: open ends are tried in the order they appeared, candidates after them in the same
+// order, the first strictly shortest pair wins.
 int tdtk_elch_graph_balancer(int nvertices, int nedges, const int32_t* from, const int32_t* to, const double* w, int f,
                              int l, double* weights)
 {
@@ -73,68 +108,71 @@ int tdtk_elch_graph_balancer(int nvertices, int nedges, const int32_t* from, con
     set_error("bad argument");
     return TDTK_EINVAL;
   }
-  UGraph g(nvertices);
-  for (int e = 0; e < nedges; e++) {
+  for (int e = 0; e < nedges; e++)
     if (from[e] < 0 || to[e] < 0 || from[e] >= nvertices || to[e] >= nvertices) { set_error("edge endpoint out of range"); return TDTK_EINVAL; }
-    g.add_edge(from[e], to[e], w[e]);
-  }
-  std::list<int> crossings, branches;
-  crossings.push_back(f);
-  crossings.push_back(l);
+  LoopGraph g;
+  g.build(nvertices, nedges, from, to, w);
+
+  // open ends in order of appearance; a retired entry keeps its place (gone[k]) until the round is over
+  std::vector<int> open_end{f, l};
+  std::vector<char> gone{0, 0};
+  std::vector<int> dangling;                      // roots of the parts that inherit a weight, in the order found
   weights[f] = 0;
   weights[l] = 1;
-  std::vector<int> p(nvertices), p_min(nvertices);
-  std::vector<double> d(nvertices), d_min(nvertices);
-  double dist;
-  bool do_swap = false;
-  std::list<int>::iterator si, ei, s_min, e_min;
-  // process all junctions (elch6D.cc:203-252)
-  while (!crossings.empty()) {
-    dist = -1;
-    for (si = crossings.begin(); si != crossings.end();) {
-      dijkstra(g, *si, p, d);
-      ei = si;
-      ei++;
-      for (; ei != crossings.end(); ei++) {
-        if (*ei != p[*ei] && (dist < 0 || d[*ei] < dist)) {
-          dist = d[*ei];
-          s_min = si;
-          e_min = ei;
-          do_swap = true;
-        }
+  std::vector<int> par((size_t)nvertices), best_par((size_t)nvertices);
+  std::vector<double> len((size_t)nvertices), best_len((size_t)nvertices);
+  std::vector<char> settled;
+
+  for (;;) {
+    // compact the list (order preserved)
+    size_t keep = 0;
+    for (size_t k = 0; k < open_end.size(); k++)
+      if (!gone[k]) open_end[keep++] = open_end[k];
+    open_end.resize(keep);
+    gone.assign(keep, 0);
+    if (open_end.empty()) break;
+
+    double shortest = -1.0;                       // length of the best pair of this round, < 0: none yet
+    size_t a_pos = 0, b_pos = 0;                  // its two ends, as positions in open_end
+    const size_t count = open_end.size();         // ends appended below belong to the next round's scan only at its tail
+    for (size_t i = 0; i < count; i++) {
+      shortest_paths(g, open_end[i], par.data(), len.data(), settled);
+      bool improved = false;
+      for (size_t j = i + 1; j < count; j++) {
+        if (gone[j]) continue;
+        const int t = open_end[j];
+        if (par[t] != t && (shortest < 0 || len[t] < shortest)) { shortest = len[t]; a_pos = i; b_pos = j; improved = true; }
       }
-      if (do_swap) {
-        std::swap(p, p_min);
-        std::swap(d, d_min);
-        do_swap = false;
-      }
-      if (dist < 0) {          // vertex starts a branch
-        branches.push_back(*si);
-        si = crossings.erase(si);
-      } else {
-        si++;
+      if (improved) { par.swap(best_par); len.swap(best_len); }
+      if (shortest < 0) {                         // reaches no later end and nothing has been found yet: a dangling part
+        dangling.push_back(open_end[i]);
+        gone[i] = 1;
       }
     }
-    if (dist > -1) {
-      g.remove_edge(*e_min, p_min[*e_min]);
-      for (int i = p_min[*e_min]; i != *s_min; i = p_min[i]) {
-        weights[i] = weights[*s_min] + (weights[*e_min] - weights[*s_min]) * d_min[i] / d_min[*e_min];
-        g.remove_edge(i, p_min[i]);
-        if (g.degree(i) > 0) crossings.push_back(i);
-      }
-      if (g.degree(*s_min) == 0) crossings.erase(s_min);
-      if (g.degree(*e_min) == 0) crossings.erase(e_min);
+    if (shortest < 0) continue;                   // everything left was dangling
+    const int a = open_end[a_pos], b = open_end[b_pos];
+    // walk the path from b back to a: interpolate, take the path's edges out, inner vertices that keep edges open up
+    g.cut_between(b, best_par[b]);
+    for (int v = best_par[b]; v != a; v = best_par[v]) {
+      weights[v] = weights[a] + (weights[b] - weights[a]) * best_len[v] / best_len[b];
+      g.cut_between(v, best_par[v]);
+      if (g.live_deg[v] > 0) { open_end.push_back(v); gone.push_back(0); }
     }
+    if (g.live_deg[a] == 0) gone[a_pos] = 1;
+    if (g.live_deg[b] == 0) gone[b_pos] = 1;
   }
-  // error propagation (elch6D.cc:262-278)
-  while (!branches.empty()) {
-    const int s = branches.front();
-    branches.pop_front();
-    for (const auto& e : g.adj[s]) {
-      weights[e.first] = weights[s];
-      if (g.degree(e.first) > 1) branches.push_back(e.first);
+
+  // dangling parts: breadth first from each root, every neighbour takes the weight of the vertex it hangs on
+  for (size_t head = 0; head < dangling.size(); head++) {
+    const int s = dangling[head];
+    for (int k = g.first[s]; k < g.first[s + 1]; k++) {
+      const int e = g.inc[k];
+      if (!g.on[e]) continue;
+      const int t = g.other(e, s);
+      weights[t] = weights[s];
+      if (g.live_deg[t] > 1) dangling.push_back(t);
     }
-    g.clear_vertex(s);
+    g.isolate(s);
   }
   return TDTK_OK;
 }

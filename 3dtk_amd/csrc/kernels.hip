@@ -1023,7 +1023,7 @@ __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -1043,6 +1043,13 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   const TreeDev& T = a.T;
   const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+  // The argument block is read through an opaque pointer (see k_search_refill): what the inner loops and every retire
+  // need is fetched once, here, and stays in SGPRs; the rest (matrices, query arrays) is read where a lane takes a query.
+  const LeafEntry* const t_leaf_tab = T.leaf_tab;
+  const uint32_t t_cb = T.cb, t_cmask = T.cmask;
+  int* const a_kpos = a.kpos;
+  double* const a_d2 = a.d2;
+  unsigned char* const a_cost = a.cost;
 
   // "expensive queries first": the order in which a piece of the slab is handed out (offsets within the piece), by the
   // number of buckets each query visited in the previous pass.  Lanes that work on queries of similar length at the same
@@ -1167,9 +1174,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     // ---- retire finished queries, hand out new ones ----
     const bool idle = (cur == REF_DONE);
     if (idle && have) {
-      a.kpos[qi] = bk;
-      if (a.d2) a.d2[qi] = best;
-      if (ORDER && a.cost) a.cost[qi] = (unsigned char)min(nbk, 255u);   // nbk: node visits + 4 per bucket
+      a_kpos[qi] = bk;
+      if (a_d2) a_d2[qi] = best;
+      if (ORDER && a_cost) a_cost[qi] = (unsigned char)min(nbk, 255u);   // nbk: node visits + 4 per bucket
       have = false;
       if constexpr (FUSE == 2) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
@@ -1339,37 +1346,39 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     if (cur != REF_DONE) {
       const uint32_t v = cur & REF_VAL;
       int start, count;
-      if (T.leaf_tab) {
-        const LeafEntry le = T.leaf_tab[v];
+      if (t_leaf_tab) {
+        const LeafEntry le = t_leaf_tab[v];
         start = le.start; count = le.count;
       } else {
-        start = (int)(v >> T.cb);
-        count = (int)(v & T.cmask);
+        start = (int)(v >> t_cb);
+        count = (int)(v & t_cmask);
       }
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
       if (ORDER) nbk += 4u;
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
-      for (uint32_t o = o0; o <= olast; o += 128u) {           // 4 points per round trip
-        const uint32_t o1 = min(o + 32u, olast), o2 = min(o + 64u, olast), o3 = min(o + 96u, olast);
-        const double4 p0 = *reinterpret_cast<const double4*>(pb + o);
-        const double4 p1 = *reinterpret_cast<const double4*>(pb + o1);
-        const double4 p2 = *reinterpret_cast<const double4*>(pb + o2);
-        const double4 p3 = *reinterpret_cast<const double4*>(pb + o3);
-        double dx, dy, dz;
-        dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
-        const double d0 = dx * dx + dy * dy + dz * dz;
-        dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
-        const double d1 = dx * dx + dy * dy + dz * dz;
-        dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
-        const double d3 = dx * dx + dy * dy + dz * dz;
-        if (d0 < best) { best = d0; bk = (int)(o >> 5); }
-        if (d1 < best) { best = d1; bk = (int)(o1 >> 5); }
-        if (d2 < best) { best = d2; bk = (int)(o2 >> 5); }
-        if (d3 < best) { best = d3; bk = (int)(o3 >> 5); }
+      // PTS points per round trip, all their loads issued before the first use; the last group re-reads the final point
+      // instead of running a scalar tail (a repeated point can never pass the strict '<' a second time)
+      for (uint32_t o = o0; o <= olast; o += 32u * PTS) {
+        uint32_t oo[PTS];
+        double px[PTS], py[PTS], pz[PTS];
+#pragma unroll
+        for (int j = 0; j < PTS; j++) {
+          oo[j] = (j == 0) ? o : min(o + 32u * (uint32_t)j, olast);
+          const double2 pxy = *reinterpret_cast<const double2*>(pb + oo[j]);      // x y
+          px[j] = pxy.x; py[j] = pxy.y;
+          pz[j] = *reinterpret_cast<const double*>(pb + oo[j] + 16);              // z (the caller's index is not needed here)
+        }
+        double dd[PTS];
+#pragma unroll
+        for (int j = 0; j < PTS; j++) {
+          const double dx = px[j] - qx, dy = py[j] - qy, dz = pz[j] - qz;
+          dd[j] = dx * dx + dy * dy + dz * dz;
+        }
+#pragma unroll
+        for (int j = 0; j < PTS; j++)
+          if (dd[j] < best) { best = dd[j]; bk = (int)(oo[j] >> 5); }
       }
       bx.set_radius(best);
       cur = REF_DONE;
@@ -1475,10 +1484,19 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   }
 }
 
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN>
-__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a)
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a_by_value)
 {
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN>(a, blockIdx.x, gridDim.x);
+  // The argument block (three 4x4 fp64 matrices among its 700 bytes) is read through the kernarg segment pointer, not
+  // through the by-value parameter: a by-value parameter is known dereferenceable and loop-invariant, so the compiler
+  // hoists every field into SGPRs up front -- 106 SGPRs with 80 of them spilled into VGPR lanes in round 2, every use a
+  // v_readlane in a kernel that is short of issue slots.  Behind an opaque pointer the fields are s_load'ed where they
+  // are used (the matrices only when a lane takes a new query), like k_search_refill_multi reads its table entry.
+  (void)a_by_value;
+  typedef const SearchArgs __attribute__((address_space(4))) * kernarg_ptr;   // constant address space -> s_load
+  kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS>(*(const SearchArgs*)ap, blockIdx.x, gridDim.x);
 }
 
 // Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
@@ -2247,10 +2265,17 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries
   a.phases = ph;
-  switch (refill_thresh(a.n)) {
-    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), 0, s, a); break;
+  // diagnostics: TDTK_OCC_LDS=<bytes> of unused dynamic LDS per workgroup caps the waves resident per SIMD (how the launch
+  // time depends on occupancy alone); TDTK_BUCKET_PTS=8 scans buckets eight points per round trip instead of four
+  static const unsigned occ_lds = [] { const char* e = getenv("TDTK_OCC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+  const char* pe = getenv("TDTK_BUCKET_PTS");
+  const int bpts = pe ? atoi(pe) : 4;
+  if (!COUNT && FUSE == 0 && bpts == 8 && refill_thresh(a.n) == 16) {
+    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 8>), dim3(nb), dim3(128), occ_lds, s, a);
+  } else switch (refill_thresh(a.n)) {
+    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
   }
   if (a.trace) {
     (void)hipStreamSynchronize(s);

@@ -749,7 +749,7 @@ def test_product_and_bench_keep_clear_of_the_oracle():
 
 
 def test_timed_search_kernels_keep_five_waves_per_simd():
-    """The persistent-lane search kernel of the ICP loop uses exactly the 96 vector registers that still allow five
+    """The persistent-lane search kernel of the ICP loop stays within the 96 vector registers that still allow five
     waves per SIMD (one more and a 1M-point launch takes 0.258 ms instead of 0.206); the several-links-per-launch kernel
     of graph-SLAM has the same limit.  The build keeps the compiler's resource remarks; this reads them."""
     import re
@@ -758,8 +758,8 @@ def test_timed_search_kernels_keep_five_waves_per_simd():
         pytest.skip("no build in this tree (kernels.resource.txt is written by the Makefile)")
     text = open(path).read()
     kernels = {
-        "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false>",
-        "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false>",
+        "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0ELi4EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false, 4>",
+        "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0ELi4EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false, 4>",
         "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0>",
     }
     for mangled, name in kernels.items():
@@ -769,4 +769,7 @@ def test_timed_search_kernels_keep_five_waves_per_simd():
         occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block).group(1))
         vg = int(re.search(r"VGPRs: (\d+)", block).group(1))
         spill = int(re.search(r"VGPRs Spill: (\d+)", block).group(1))
-        assert occ >= 5 and vg <= 96 and spill == 0, (name, occ, vg, spill)
+        sspill = int(re.search(r"SGPRs Spill: (\d+)", block).group(1))
+        # round 2 shipped 80 spilled SGPRs here (the by-value argument block hoisted into registers; every use a v_readlane):
+        # the block is read through the kernarg pointer where it is used now -- no spills of either kind
+        assert occ >= 5 and vg <= 96 and spill == 0 and sspill == 0, (name, occ, vg, spill, sspill)
