@@ -10,13 +10,10 @@ gfx950 device is present, the compute entry points raise.
 The directory name starts with a digit, so import it with
 ``importlib.import_module("3dtk_amd")`` (tests/conftest.py and bench.py do).
 """
-import os as _os
-
-# The batched link passes of graph-SLAM run on three HIP streams; the runtime maps all streams of a process onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue do not overlap.  A host that has streams
-# of its own (PyTorch, RCCL) needs more queues; the variable is read when the HIP runtime initialises, so this only
-# takes effect if the package is imported before the first GPU call (INTEGRATION.md, "Streams and hardware queues").
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Importing the package changes nothing in the process environment.  A host program with HIP streams of its own (PyTorch,
+# RCCL) that wants the link passes of graph-SLAM to overlap should start with GPU_MAX_HW_QUEUES=8 (the HIP runtime maps
+# all streams of a process onto 4 hardware queues by default and reads the variable once, when it initialises):
+# bench.py does that for itself; INTEGRATION.md, "Streams and hardware queues".
 
 from ._capi import (TdtkError, lib, build_extension, device_count, version, PairSums,  # noqa: F401
                     ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX, CLOSEST_POINT,
@@ -27,6 +24,6 @@ from .slam6d import (KDtree, Scan, icp6Dminimizer, icp6D_QUAT, icp6D_SVD, icp6D_
                      icp6D_ORTHO, icp6D_DUAL, icp6D_HELIX, icp6D_LUMEULER, icp6D_LUMQUAT, icp6D_QUAT_SCALE,
                      icp6D_NAPX, icp6D, Graph, lum6DEuler, lum6DQuat, ghelix6DQ2, gapx6D, QuatToMatrix4, Matrix4ToQuat, M4inv, MMult, M4identity,
                      EulerToMatrix4, Matrix4ToEuler, host_tree_layout, calculateNormalsApxKNN, MetaScan, read_uos, read_pose,
-                     openDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints,
+                     openDirectory, closeDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints,
                      computeGraph6Dautomatic, matchGraph6Dautomatic_clpairs, prepare_scans, loopSlam6D, elch6Deuler,
                      graph_balancer)

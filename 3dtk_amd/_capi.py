@@ -61,7 +61,7 @@ EXPORTS = [
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_point_point_error",
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
-    "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_graph_exchange", "tdtk_graph_deal_links",
+    "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_comm_rccl_world", "tdtk_graph_exchange", "tdtk_graph_deal_links",
     "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge",
     "tdtk_last_timings", "tdtk_kernel_timing", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
@@ -149,6 +149,7 @@ def lib():
     L.tdtk_comm_destroy.restype = None
     L.tdtk_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]
     L.tdtk_graph_exchange.argtypes = [C.c_void_p, _dp, C.c_size_t]
+    L.tdtk_comm_rccl_world.argtypes = [C.c_void_p]
     L.tdtk_graph_deal_links.argtypes = [C.c_int, _ip, _ip, _u64p, C.c_int, C.c_int, _ip]
     L.tdtk_graph_iteration.argtypes = [C.c_int, C.c_void_p, C.c_int, _ip, _ip, C.c_int, _ip, C.POINTER(C.c_void_p), _dp,
                                        C.POINTER(C.c_void_p), C.c_double, C.c_int, _dp, _dp, _dp, _dp,

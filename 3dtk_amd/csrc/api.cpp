@@ -217,8 +217,10 @@ static int defer_fence(Ctx* c)
 {
   static const bool sync_moves = [] { const char* e = getenv("TDTK_SYNC_MOVES"); return e && e[0] == '1'; }();
   if (sync_moves) { HIPCHK(hipStreamSynchronize(c->stream)); return TDTK_OK; }
-  HIPCHK(hipEventRecord(c->e_defer, c->stream));
+  // the event is re-recorded under the lock: another host thread may be inside hipEventSynchronize on this very event
+  // (wait_deferred holds the lock while it waits), and re-recording an event somebody is waiting on is undefined
   std::lock_guard<std::mutex> lk(g_defer_mu);
+  HIPCHK(hipEventRecord(c->e_defer, c->stream));
   bool have = false;
   for (const Deferred& d : g_defer) have = have || d.owner == c;
   if (!have) g_defer.push_back({c->device, c->e_defer, c});
@@ -394,45 +396,11 @@ int tdtk_tree_create(const double* xyz, size_t M, int bucket_size, int device, t
   std::unique_ptr<tdtk_tree> t(new tdtk_tree);
   t->device = device; t->M = M; t->bucket = bucket_size;
   if ((rc = tree_check_args(M, bucket_size))) return rc;
-  const char* host_env = getenv("TDTK_HOST_BUILD");
-  if (host_env && host_env[0] == '1') {
-    // root bounding box (binning of unsorted query batches, accumulation shift)
-    for (int a = 0; a < 3; a++) t->bbmin[a] = t->bbmax[a] = xyz[a];
-    for (size_t i = 1; i < M; i++)
-      for (int a = 0; a < 3; a++) {
-        const double v = xyz[3 * i + a];
-        if (v < t->bbmin[a]) t->bbmin[a] = v;
-        if (t->bbmax[a] < v) t->bbmax[a] = v;
-      }
-    // host construction (kd_build.cpp), kept as the cross-check of the device builder
-    HostTree H;
-    std::string err;
-    if (!build_tree(xyz, M, bucket_size, H, err)) { set_error(err); return TDTK_EINVAL; }
-    const double t1 = now_ms();
-    t->info.build_ms = t1 - t0;
-    if (!H.nodes.empty()) {
-      HIPCHK(hipMalloc(&t->d_nodes, H.nodes.size() * sizeof(KdNode)));
-      HIPCHK(hipMemcpy(t->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice));
-      HIPCHK(hipMalloc(&t->d_r, H.node_r.size() * sizeof(double)));
-      HIPCHK(hipMemcpy(t->d_r, H.node_r.data(), H.node_r.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMalloc(&t->d_pts, H.pts.size() * sizeof(KdPoint)));
-    HIPCHK(hipMemcpy(t->d_pts, H.pts.data(), H.pts.size() * sizeof(KdPoint), hipMemcpyHostToDevice));
-    if (H.table_mode) {
-      HIPCHK(hipMalloc(&t->d_leaf, H.leaf_tab.size() * sizeof(LeafEntry)));
-      HIPCHK(hipMemcpy(t->d_leaf, H.leaf_tab.data(), H.leaf_tab.size() * sizeof(LeafEntry), hipMemcpyHostToDevice));
-    }
-    t->dev.root_ref = H.root_ref;
-    t->dev.cb = (uint32_t)H.cb;
-    t->info.n_internal = H.n_internal; t->info.n_leaves = H.n_leaves;
-    t->info.max_depth = H.max_depth; t->info.max_leaf_points = H.max_leaf_points;
-    t->info.upload_ms = now_ms() - t1;
-  } else {
-    // device construction (build.hip): upload the points once, build level by level
-    if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
-    HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, xyz, 3 * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
-  }
+  // device construction (build.hip): upload the points once, build level by level.  (The host builder, kd_build.cpp,
+  // is reachable through tdtk_tree_verify only -- it is the cross-check of this path, not an alternative to it.)
+  if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
+  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPA].p, xyz, 3 * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
   if ((rc = tree_finish(c, t.get(), M))) return rc;
   *out = t.release();
   return TDTK_OK;
@@ -500,6 +468,10 @@ int tdtk_tree_create_from_scans(tdtk_scan* const* scans, int nscans, int bucket_
 
 void tdtk_tree_destroy(tdtk_tree* t)
 {
+  if (!t) return;
+  // a batch of scan moves / link passes left running behind the fence may still read this tree: explicit wait, not
+  // hipFree's implicit device synchronisation
+  wait_deferred(t->device);
   delete t;   // ~tdtk_tree releases the device arrays
 }
 
@@ -1312,6 +1284,8 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
 
 void tdtk_scan_destroy(tdtk_scan* s)
 {
+  if (!s) return;
+  wait_deferred(s->device);   // a deferred k_transform2_batch may still be writing this scan's arrays
   delete s;   // ~tdtk_scan releases the device arrays
 }
 
@@ -1337,6 +1311,7 @@ int tdtk_scan_mark_original(tdtk_scan* s)
 {
   if (!s) { set_error("NULL argument"); return TDTK_EINVAL; }
   (void)hipSetDevice(s->device);
+  wait_deferred(s->device);   // the saved original may be in use by a move that was left running
   double* p[] = {s->ox, s->oy, s->oz};
   for (double* q : p)
     if (q) (void)hipFree(q);

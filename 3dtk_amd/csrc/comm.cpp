@@ -25,6 +25,8 @@ struct Rccl {
   decltype(&ncclGetUniqueId) getUniqueId = nullptr;
   decltype(&ncclCommInitRank) commInitRank = nullptr;
   decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclCommAbort) commAbort = nullptr;
+  decltype(&ncclCommCount) commCount = nullptr;
   decltype(&ncclAllReduce) allReduce = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
   std::string where;
@@ -46,6 +48,8 @@ void load_rccl()
   g_rccl.commInitRank = (decltype(g_rccl.commInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
   g_rccl.commDestroy = (decltype(g_rccl.commDestroy))dlsym(g_rccl.h, "ncclCommDestroy");
   g_rccl.allReduce = (decltype(g_rccl.allReduce))dlsym(g_rccl.h, "ncclAllReduce");
+  g_rccl.commAbort = (decltype(g_rccl.commAbort))dlsym(g_rccl.h, "ncclCommAbort");      // optional: only the failure path uses it
+  g_rccl.commCount = (decltype(g_rccl.commCount))dlsym(g_rccl.h, "ncclCommCount");
   g_rccl.getErrorString = (decltype(g_rccl.getErrorString))dlsym(g_rccl.h, "ncclGetErrorString");
   if (!g_rccl.getUniqueId || !g_rccl.commInitRank || !g_rccl.commDestroy || !g_rccl.allReduce) g_rccl.h = nullptr;
 }
@@ -74,7 +78,44 @@ struct tdtk_comm {
   double* h_pin = nullptr;   // pinned staging: the copies around the collective are asynchronous on `stream`
   size_t h_cap = 0;
   uint64_t n_allreduce = 0;  // collectives issued (tests / bench: proves the RCCL path ran)
+  int rccl_world = 0;        // what RCCL itself reports for the communicator (ncclCommCount); must equal `world`
+  bool dead = false;         // aborted after a failure of this rank that could not be carried through the collective
 };
+
+namespace {
+// staging for n doubles on both sides; called at creation (default size) so that the exchange of an ordinary graph never
+// allocates between a rank's link passes and the collective
+int reserve(tdtk_comm* c, size_t n)
+{
+  if (n > c->cap) {
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    c->d_buf = nullptr; c->cap = 0;
+    const size_t want = n + n / 4 + 64;
+    if (hipMalloc((void**)&c->d_buf, want * sizeof(double)) != hipSuccess) { set_error("hipMalloc failed"); return TDTK_ENOMEM; }
+    c->cap = want;
+  }
+  if (n > c->h_cap) {
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr; c->h_cap = 0;
+    const size_t want = n + n / 4 + 64;
+    if (hipHostMalloc((void**)&c->h_pin, want * sizeof(double), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
+    c->h_cap = want;
+  }
+  return TDTK_OK;
+}
+// A failure of THIS rank that cannot be reported through the collective (no staging memory, a failed copy or launch): the
+// other ranks are, or soon will be, inside ncclAllReduce waiting for us.  Abort the communicator so that they come back
+// with an error instead of waiting forever; the communicator is unusable afterwards on every rank.
+int abort_comm(tdtk_comm* c, int rc)
+{
+  const std::string why = tdtk_last_error();
+  if (c->comm && g_rccl.commAbort) { g_rccl.commAbort(c->comm); c->comm = nullptr; }
+  c->dead = true;
+  set_error("communicator aborted after a local failure (" + why + "): the peers' collective returns an error");
+  return rc;
+}
+constexpr size_t DEFAULT_EXCHANGE_DOUBLES = 1u << 17;   // 1 MB: 2 600 links of lum6DEuler blocks
+}  // namespace
 
 extern "C" {
 
@@ -107,6 +148,19 @@ int tdtk_comm_create(const char id[TDTK_COMM_ID_BYTES], int rank, int world, int
   std::memcpy(&u, id, sizeof u);
   ncclResult_t r = g_rccl.commInitRank(&c->comm, world, u, rank);
   if (r != ncclSuccess) { delete c; return nccl_fail("ncclCommInitRank", r); }
+  // what RCCL itself says about the communicator must be what the caller asked for (a wrong id / a stale rendezvous
+  // would otherwise show up as a sum over fewer ranks than the deal of the links assumed)
+  c->rccl_world = world;
+  if (g_rccl.commCount) {
+    int cnt = 0;
+    if (g_rccl.commCount(c->comm, &cnt) == ncclSuccess) c->rccl_world = cnt;
+  }
+  if (c->rccl_world != world) {
+    set_error("RCCL reports a communicator of " + std::to_string(c->rccl_world) + " ranks, the caller asked for " + std::to_string(world));
+    tdtk_comm_destroy(c);
+    return TDTK_EDEVICE;
+  }
+  if (int rc = reserve(c, DEFAULT_EXCHANGE_DOUBLES)) { tdtk_comm_destroy(c); return rc; }
   *out = c;
   return TDTK_OK;
 }
@@ -131,43 +185,53 @@ int tdtk_comm_info(const tdtk_comm* c, int* rank, int* world, uint64_t* n_allred
   return TDTK_OK;
 }
 
+int tdtk_comm_rccl_world(const tdtk_comm* c)
+{
+  if (!c) { set_error("NULL argument"); return TDTK_EINVAL; }
+  return c->rccl_world;
+}
+
 // blocks (host, n doubles) <- sum over the ranks, in place.  Every link has exactly one owner and everybody else
 // holds zeros there, so the sum is exact and the result is the same on every rank and for every world size.
-int tdtk_graph_exchange(tdtk_comm* c, double* blocks, size_t n)
+// `local_rc` != 0: this rank failed before the exchange (its link passes, say).  It still takes part -- with zeros for
+// its blocks and a raised status slot behind them -- so that nobody waits for it, and EVERY rank returns an error
+// afterwards (TDTK_EPEER where the failure was somebody else's).
+static int exchange_with_status(tdtk_comm* c, double* blocks, size_t n, int local_rc)
 {
   if (!c || (!blocks && n)) { set_error("NULL argument"); return TDTK_EINVAL; }
-  if (n == 0) return TDTK_OK;
-  if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice failed"); return TDTK_EDEVICE; }
-  if (n > c->cap) {
-    if (c->d_buf) (void)hipFree(c->d_buf);
-    c->d_buf = nullptr; c->cap = 0;
-    const size_t want = n + n / 4 + 64;
-    if (hipMalloc((void**)&c->d_buf, want * sizeof(double)) != hipSuccess) { set_error("hipMalloc failed"); return TDTK_ENOMEM; }
-    c->cap = want;
-  }
-  if (n > c->h_cap) {
-    if (c->h_pin) (void)hipHostFree(c->h_pin);
-    c->h_pin = nullptr; c->h_cap = 0;
-    const size_t want = n + n / 4 + 64;
-    if (hipHostMalloc((void**)&c->h_pin, want * sizeof(double), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
-    c->h_cap = want;
-  }
+  if (c->dead || !c->comm) { set_error("communicator was aborted after an earlier failure"); return TDTK_EDEVICE; }
+  const std::string local_why = local_rc ? tdtk_last_error() : "";
+  if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice failed"); return abort_comm(c, TDTK_EDEVICE); }
+  if (int rc = reserve(c, n + 1)) return abort_comm(c, rc);
   hipStream_t stream = nullptr;
   {
     void* sp = nullptr;
     int rc = ctx_stream(c->device, &sp);
-    if (rc) return rc;
+    if (rc) return abort_comm(c, rc);
     stream = static_cast<hipStream_t>(sp);
   }
-  std::memcpy(c->h_pin, blocks, n * sizeof(double));
-  if (hipMemcpyAsync(c->d_buf, c->h_pin, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) { set_error("H2D failed"); return TDTK_EDEVICE; }
-  ncclResult_t r = g_rccl.allReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, stream);
-  if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
+  if (local_rc) std::memset(c->h_pin, 0, n * sizeof(double));
+  else std::memcpy(c->h_pin, blocks, n * sizeof(double));
+  c->h_pin[n] = local_rc ? 1.0 : 0.0;
+  if (hipMemcpyAsync(c->d_buf, c->h_pin, (n + 1) * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) { set_error("H2D failed"); return abort_comm(c, TDTK_EDEVICE); }
+  ncclResult_t r = g_rccl.allReduce(c->d_buf, c->d_buf, n + 1, ncclDouble, ncclSum, c->comm, stream);
+  if (r != ncclSuccess) { nccl_fail("ncclAllReduce", r); return abort_comm(c, TDTK_EDEVICE); }
   c->n_allreduce++;
-  if (hipMemcpyAsync(c->h_pin, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) { set_error("D2H failed"); return TDTK_EDEVICE; }
-  if (hipStreamSynchronize(stream) != hipSuccess) { set_error("stream sync failed after the all-reduce"); return TDTK_EDEVICE; }
+  if (hipMemcpyAsync(c->h_pin, c->d_buf, (n + 1) * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) { set_error("D2H failed"); return abort_comm(c, TDTK_EDEVICE); }
+  if (hipStreamSynchronize(stream) != hipSuccess) { set_error("stream sync failed after the all-reduce"); return abort_comm(c, TDTK_EDEVICE); }
+  if (local_rc) { set_error(local_why + " (reported to the other ranks through the exchange)"); return local_rc; }
+  if (c->h_pin[n] != 0.0) {
+    set_error(std::to_string((int)c->h_pin[n]) + " other rank(s) failed before the exchange; this iteration is void on every rank");
+    return TDTK_EPEER;
+  }
   std::memcpy(blocks, c->h_pin, n * sizeof(double));
   return TDTK_OK;
+}
+
+int tdtk_graph_exchange(tdtk_comm* c, double* blocks, size_t n)
+{
+  if (!c || (!blocks && n)) { set_error("NULL argument"); return TDTK_EINVAL; }
+  return exchange_with_status(c, blocks, n, 0);
 }
 
 // Who evaluates which link (FillGB3D's `omp parallel for` over links becomes one process per GPU).  A link costs one
@@ -221,16 +285,22 @@ int tdtk_graph_iteration(int backend, tdtk_comm* comm, int nlinks, const int32_t
     set_error("bad argument");
     return TDTK_EINVAL;
   }
+  // everything that can be checked is checked BEFORE the link passes: an argument error is the same on every rank (or the
+  // caller's bug on this one) and must not surface between "my links are done" and the collective
+  for (int k = 0; k < n_mine; k++)
+    if (mine[k] < 0 || mine[k] >= nlinks) { set_error("link index out of range"); return TDTK_EINVAL; }
+  if (nlinks && (!from || !to)) { set_error("bad argument"); return TDTK_EINVAL; }
+  const char* force = getenv("TDTK_FORCE_ALLREDUCE");
+  const bool collective = comm && (comm->world > 1 || (force && force[0] == '1'));
   std::vector<double> blocks((size_t)nlinks * Bn, 0.0), mb((size_t)n_mine * Bn);
   int rc = tdtk_graph_link_blocks(backend, n_mine, first, first_dalignxf, second, max_dist_match2, mb.data());
-  if (rc) return rc;
-  for (int k = 0; k < n_mine; k++) {
-    if (mine[k] < 0 || mine[k] >= nlinks) { set_error("link index out of range"); return TDTK_EINVAL; }
-    std::memcpy(&blocks[(size_t)mine[k] * Bn], &mb[(size_t)k * Bn], Bn * sizeof(double));
-  }
-  const char* force = getenv("TDTK_FORCE_ALLREDUCE");
-  if (comm && (comm->world > 1 || (force && force[0] == '1'))) {
-    if ((rc = tdtk_graph_exchange(comm, blocks.data(), blocks.size()))) return rc;
+  if (rc && !collective) return rc;
+  if (!rc)
+    for (int k = 0; k < n_mine; k++) std::memcpy(&blocks[(size_t)mine[k] * Bn], &mb[(size_t)k * Bn], Bn * sizeof(double));
+  if (collective) {
+    // a rank whose link passes failed still enters the one collective of the iteration (status slot raised), so the
+    // others are not left waiting in ncclAllReduce; all ranks return an error
+    if ((rc = exchange_with_status(comm, blocks.data(), blocks.size(), rc))) return rc;
   }
   return tdtk_graph_solve_update(backend, nlinks, from, to, blocks.data(), nscans, transMat, dalignxf, rPos, rPosTheta,
                                  scans, state, xf_out, ret);

@@ -175,25 +175,34 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
 //   a32 >= r32 (1 + 1e-6) + delta   =>  a >= sqrt(closest_d2) (1 + 2^-22) > 0   =>  the reference prunes;
 //   a32 <  r32 (1 - 1e-6) - delta   =>  a <  sqrt(closest_d2) (1 - 2^-22)       =>  the reference does not;
 // (the fp64 roundings of the reference's own a and a*a are 2^-53 relative, eleven orders below these margins).
-// Anything in between -- a band of relative width ~1e-6 -- and anything not finite takes the exact fp64 test on the
-// full record.  Visits therefore stay the reference's node for node (the instrumented instantiations count the same
+// Anything in between -- a band of relative width ~1e-6 -- takes the exact fp64 test on the full record, and so does
+// everything fp32 cannot hold: a query with an inf / NaN / > 3e38 component, or closest_d2 > FLT_MAX (the thresholds
+// are NaN then, so both comparisons fail; tests/test_gpu_parity.py::test_box_shortcut_gives_way_outside_float_range).  Visits therefore stay the reference's node for node (the instrumented instantiations count the same
 // numbers as the reference), while the common case costs 9 fp32 operations instead of 15 at fp64 rate and the hot
 // record is 48 bytes instead of 64.
 struct BoxF32 {
   float qx, qy, qz;   // the query in fp32
-  float delta;        // error bound of a32 for this query
-  float thi, tlo;     // decision thresholds for the current closest_d2
+  float delta;        // error bound of a32 for this query; NaN when the query does not fit fp32 (inf / NaN component)
+  float thi, tlo;     // decision thresholds for the current closest_d2; NaN: take the exact test
   __device__ __forceinline__ void set_query(const double x, const double y, const double z, const float absmax)
   {
     qx = (float)x; qy = (float)y; qz = (float)z;
     const float qm = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
     delta = 3.0e-7f * (qm + 2.0f * absmax) + 1.0e-30f;
+    // fmaxf drops a NaN operand and (float)1e39 is +inf: a query with such a component must never be decided in fp32.
+    // The sum of the three is NaN or +-inf exactly when one of them is not finite (or when they are within a factor of
+    // three of FLT_MAX, which may take the exact test as well).
+    const float probe = fabsf(qx) + fabsf(qy) + fabsf(qz);
+    if (!(probe <= 3.0e38f)) delta = __builtin_nanf("");
   }
   __device__ __forceinline__ void set_radius(const double best)
   {
     const float r32 = __builtin_amdgcn_sqrtf((float)best);   // v_sqrt_f32: 1 ulp
     thi = r32 * 1.000001f + delta;
     tlo = r32 * 0.999999f - delta;
+    // closest_d2 beyond float range ((float)best = +inf), or a NaN delta: both comparisons of the fast path must fail
+    // (a32 >= NaN and a32 < NaN are false), which sends the visit to the exact fp64 test
+    if (!(thi <= 3.0e38f)) { thi = __builtin_nanf(""); tlo = thi; }
   }
 };
 
@@ -1102,7 +1111,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     ordered = true;
   };
   size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
-  size_t sub = 0, reg0 = 0, pstride = 0, pool0 = 0, pool_end = 0;
+  size_t sub = 0, reg0 = 0, pstride = 0;
   bool exhausted = false;
   int phase = 0;
   uint32_t xq = 0, tried = 0, nslab = 0, per_x = 0;
@@ -1124,10 +1133,10 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     if (a.pool_slab) {
       // Static slab + pool: the waves of a launch do not finish together -- at 1M queries the first is done after 60 %
       // of the launch, the median after 77 % (TDTK_WAVE_TRACE) -- so only part of an XCD's region is dealt out in
-      // advance and the rest is drawn in small pieces by whichever wave runs dry.  One counter per XCD, touched only by
-      // waves of that XCD (the real XCC_ID), so the atomic can be of workgroup scope: it is served by the XCD's own L2
-      // instead of going to memory as a device-scope atomic on this multi-die part must (that round trip, serialised per
-      // counter, is what made the fully dynamic kernel above slow).
+      // advance and the rest is drawn in small pieces by whichever wave runs dry.  One counter per XCD, touched first by
+      // the waves of that XCD (the real XCC_ID) and by the others only once their own pool is dry.  (Round 2 used
+      // workgroup-scope atomics here on the assumption that no other XCD ever touches a counter, which made completeness
+      // depend on XCC_ID; agent scope since round 3 -- a measured negative either way.)
       xq = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
       const size_t r0 = (size_t)(bid & 7u) * a.region;
       const size_t rend = (r0 + a.region < a.n) ? r0 + a.region : a.n;
@@ -1135,9 +1144,6 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       end_q = next_q + (size_t)a.qpw;
       if (next_q > rend) next_q = rend;
       if (end_q > rend) end_q = rend;
-      pool0 = (size_t)xq * a.region + (size_t)wpx * (size_t)a.qpw;
-      pool_end = ((size_t)(xq + 1u) * a.region < a.n) ? (size_t)(xq + 1u) * a.region : a.n;
-      if (pool0 > pool_end) pool0 = pool_end;
       if (bid == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
     } else {
       sub = (size_t)(a.qpw / a.phases);
@@ -1236,16 +1242,27 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       }
     }
     if (!DYN && a.pool_slab && fill && next_q >= end_q && !exhausted) {
-      uint32_t k = 0;
-      if (lane == 0) k = __hip_atomic_fetch_add(&a.q_ctr[xq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-      const size_t p = pool0 + (size_t)k * (size_t)a.pool_slab;
-      if (p < pool_end) {
-        next_q = p;
-        end_q = (p + (size_t)a.pool_slab < pool_end) ? p + (size_t)a.pool_slab : pool_end;
-      } else {
-        exhausted = true;
+      // the pool of the XCD this wave runs on first; when that is dry the other seven in turn (a pool whose XCD has no
+      // resident wave -- another partition mode, an uneven dispatch -- must not be left unsearched: XCC_ID is a hint for
+      // locality, never a condition for completeness).  Counters are touched from any XCD now: agent scope.
+      while (tried < 8u) {
+        const size_t wpxq = (size_t)((nb >> 3) * (BLOCK / WAVE)) * (size_t)a.qpw;
+        size_t p0 = (size_t)xq * a.region + wpxq;
+        const size_t pend = ((size_t)(xq + 1u) * a.region < a.n) ? (size_t)(xq + 1u) * a.region : a.n;
+        if (p0 > pend) p0 = pend;
+        uint32_t k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(&a.q_ctr[xq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        const size_t p = p0 + (size_t)k * (size_t)a.pool_slab;
+        if (p < pend) {
+          next_q = p;
+          end_q = (p + (size_t)a.pool_slab < pend) ? p + (size_t)a.pool_slab : pend;
+          break;
+        }
+        xq = (xq + 1u) & 7u;
+        ++tried;
       }
+      if (tried >= 8u) exhausted = true;
     }
     if (!DYN && !a.pool_slab && fill && next_q >= end_q && phase + 1 < a.phases) {
       ++phase;

@@ -72,6 +72,10 @@ class NativeComm:
         h = C.c_void_p()
         check(lib().tdtk_comm_create(ident, int(rank), int(world), int(device), C.byref(h)))
         self._h, self.rank, self.world = h, rank, world
+        # what RCCL itself reports (ncclCommCount); tdtk_comm_create has already refused a mismatch
+        self.rccl_world = int(lib().tdtk_comm_rccl_world(h))
+        if self.rccl_world != world:
+            raise RuntimeError("RCCL communicator has %d ranks, expected %d" % (self.rccl_world, world))
 
     def n_allreduce(self):
         import ctypes as C

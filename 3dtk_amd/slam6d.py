@@ -318,7 +318,8 @@ class Scan:
         self.kd = None
         self.frames = []  # (transMat copy, type)
 
-    def __del__(self):
+    def release(self):
+        """Give the device arrays (and the search tree) back now; the scan can go resident again later."""
         h = getattr(self, "_h", None)
         if h:
             try:
@@ -326,6 +327,10 @@ class Scan:
             except Exception:      # interpreter shutdown
                 pass
             self._h = None
+        self.kd = None
+
+    def __del__(self):
+        self.release()
 
     K_NEIGHBOURS = 10     # scan.cc:418
 
@@ -634,6 +639,18 @@ def openDirectory(path, start=0, end=-1, range_max=0.0, range_min=0.0, bucketSiz
         i += 1
     Scan.allScans = scans          # the static Scan::allScans the frame bookkeeping of Scan::transform walks
     return scans
+
+
+def closeDirectory():
+    """Scan::closeDirectory (scan.cc:159-165, BasicScan::closeDirectory basicScan.cc:124-137): release every scan of the
+    registry that openDirectory filled (device arrays, trees) and clear it.  Like the reference's static
+    Scan::allScans the registry keeps the scans alive until this is called or the next openDirectory replaces it."""
+    for s in Scan.allScans:
+        try:
+            s.release()
+        except Exception:
+            pass
+    Scan.allScans = []
 
 
 def saveFrames(scan, path=None, append=False):

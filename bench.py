@@ -603,6 +603,13 @@ def bench_graphslam(args, rank, world, local):
         traffic = traffic * groups / my_links * last_links      # the committed passes average over a step's launches
     exchange = ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None \
         else ("torch.distributed (gloo test rig)" if use_torch_exchange else "none (one rank)")
+    # what actually ran, for whoever reads the N > 1 line: the size of the communicator as RCCL itself reports it
+    # (ncclCommCount; NativeComm / tdtk_comm_create refuse anything but the world asked for) and every rank's share of the links
+    owners = gs.link_owners(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), world, scans)
+    links_per_rank = [int((owners == r).sum()) for r in range(world)]
+    rccl_world = comm.rccl_world if comm is not None else None
+    if comm is not None and rccl_world != args.gpus:
+        raise SystemExit("bench.py: RCCL communicator has %d ranks but --gpus %d" % (rccl_world, args.gpus))
     if comm is not None:
         barrier_sync(world)
         comm.close()                  # ncclCommDestroy now, on every rank together, not at interpreter shutdown
@@ -616,7 +623,7 @@ def bench_graphslam(args, rank, world, local):
                                % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
         "lum_iters_per_s": args.steps / dt, "last_ret": ret,
-        "exchange": exchange,
+        "exchange": exchange, "rccl_world": rccl_world, "links_per_rank": links_per_rank,
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
         "roofline": {"bound": "hbm", "kernel": "k_search_refill_multi (link passes, up to %d links per launch)" % batch if batched

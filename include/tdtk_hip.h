@@ -32,6 +32,7 @@ extern "C" {
 #define TDTK_ENOMEM (-3)   /* host or device allocation failed                        */
 #define TDTK_ESOLVE (-4)   /* minimizer could not be solved (Cholesky failed, ...)    */
 #define TDTK_EUNSUP (-5)   /* valid in the reference but not supported on this entry point */
+#define TDTK_EPEER (-6)    /* another rank of the communicator failed; the collective result is void on every rank */
 
 typedef struct tdtk_tree tdtk_tree; /* model-scan search tree, resident in HBM   */
 typedef struct tdtk_scan tdtk_scan; /* data-scan points (+normals), resident in HBM */
@@ -136,8 +137,8 @@ int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree
 int tdtk_tree_create_from_scans(tdtk_scan* const* scans, int nscans, int bucket_size, tdtk_tree** out);
 void tdtk_tree_destroy(tdtk_tree* t);
 int tdtk_tree_get_info(const tdtk_tree* t, tdtk_tree_info* info);
-/* diagnostic: rebuild the tree with the host builder and compare it with the resident one (built on
- * the device unless TDTK_HOST_BUILD=1).  mismatches = {node records, node radii, points, structure}. */
+/* diagnostic: rebuild the tree with the host builder (kd_build.cpp; this is its only use -- trees are always built on
+ * the device) and compare it with the resident one.  mismatches = {node records, node radii, points, structure}. */
 int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4]);
 
 /* ---- batched KDtree::FindClosest (kd.cc:78-87; _FindClosest kdTreeImpl.h:345-383).
@@ -272,7 +273,13 @@ int tdtk_graph_solve_update(int backend, int nlinks, const int32_t* from, const 
  * tdtk_graph_deal_links: owner[l] = rank that evaluates link l -- round-robin / (from+to) % world for scans of equal
  *   size, longest-processing-time-first by the point count of the link's second scan otherwise.
  * tdtk_graph_iteration: link blocks of this rank's links (mine[] = their indices in the link list; first / second /
- *   first_dalignxf describe them in that order) -> exchange -> tdtk_graph_solve_update, all inside the library.      */
+ *   first_dalignxf describe them in that order) -> exchange -> tdtk_graph_solve_update, all inside the library.
+ * Failure semantics with more than one rank: arguments are validated before the link passes; a rank whose link passes
+ *   fail still takes part in the collective (a status slot rides behind the blocks), and then EVERY rank returns an
+ *   error -- the failing rank its own code, the others TDTK_EPEER -- so nobody is left waiting in ncclAllReduce.  A
+ *   failure that cannot be carried through the collective (no staging memory, a failed copy) aborts the communicator
+ *   (ncclCommAbort): the peers' collective returns an error and the communicator is dead on all ranks.  The staging
+ *   buffers are allocated by tdtk_comm_create.                                                                       */
 #define TDTK_COMM_ID_BYTES 128
 typedef struct tdtk_comm tdtk_comm;
 int tdtk_comm_unique_id(char id[TDTK_COMM_ID_BYTES]);
@@ -280,6 +287,9 @@ int tdtk_comm_create(const char id[TDTK_COMM_ID_BYTES], int rank, int world, int
 void tdtk_comm_destroy(tdtk_comm* c);
 int tdtk_comm_info(const tdtk_comm* c, int* rank, int* world, uint64_t* n_allreduce);
 int tdtk_graph_exchange(tdtk_comm* c, double* blocks, size_t n);
+/* the number of ranks RCCL itself reports for the communicator (ncclCommCount); tdtk_comm_create fails unless it equals
+ * the `world` it was given */
+int tdtk_comm_rccl_world(const tdtk_comm* c);
 int tdtk_graph_deal_links(int nlinks, const int32_t* from, const int32_t* to, const uint64_t* scan_points /*[nscans] or NULL*/,
                           int nscans, int world, int32_t* owner);
 int tdtk_graph_iteration(int backend, tdtk_comm* comm /*nullable*/, int nlinks, const int32_t* from, const int32_t* to,
@@ -361,6 +371,13 @@ int tdtk_scan_calc_normals(tdtk_scan* s, int k, const double rPos[3], double eps
  * it is off tdtk_icp_result.nn_ms / sums_ms, tdtk_last_kernel_ms and out[0], out[1] of tdtk_last_timings are 0.
  * Returns the previous setting.  (The reference has nothing of the kind: icp6D::match prints its wall time only,
  * icp6D.cc:279-283 -- tdtk_icp_result.total_ms.) */
+/* Deferred scan moves.  The batched pose update of a graph-SLAM round (tdtk_graph_solve_update / tdtk_graph_iteration,
+ * tdtk_scans_transform_to_euler) returns while the move of the resident scans is still running on the device; a
+ * process-wide fence makes the next library call of ANY host thread on that device wait for it before it touches a scan
+ * or a tree (every entry point that takes a tree / scan / device argument, including the destroy and mark_original
+ * calls).  The read-outs in this section (tdtk_kernel_timing, tdtk_last_kernel_ms, tdtk_last_timings, the visit
+ * counters) deliberately do NOT wait -- they touch no scan and must not end the overlap.  TDTK_SYNC_MOVES=1 in the
+ * environment restores "the scans have moved when the call returns". */
 int tdtk_kernel_timing(int on);
 int tdtk_last_kernel_ms(double* nn_ms);
 /* out[0] = search kernel, out[1] = pair-sum kernels of the last pass on this thread, out[2] = the k-NN + PCA kernel

@@ -88,6 +88,30 @@ def test_find_closest_bit_exact(tdtk, orc, gpu, name, bucket):
     assert np.array_equal(idx, oi) and np.array_equal(d2, od2)
 
 
+@pytest.mark.parametrize("nq", [6000, 300000])
+def test_box_shortcut_gives_way_outside_float_range(tdtk, orc, gpu, nq):
+    """The fp32 box test may only decide what it can decide rigorously (kernels.hip, BoxF32): a query with a component
+    beyond float range, an infinite or a NaN component, or a search radius beyond FLT_MAX must take the exact fp64 test,
+    so that not only the hits but the VISITS stay the reference's (round-2 advice: +inf pruned without the exact test,
+    fmaxf dropped a NaN component).  Small batch = lane-group kernel, large batch = persistent-lane kernel."""
+    rng = np.random.default_rng(77)
+    m = rng.uniform(-1000, 1000, (50000, 3))
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    q = m[rng.integers(0, len(m), nq)] + rng.normal(0, 2.0, (nq, 3))
+    weird = [1e39, -1e39, 3.3e38, -3.39e38, 1e300, np.inf, -np.inf, np.nan, 5e38, 1e45]
+    rows = rng.choice(nq, size=nq // 10, replace=False)
+    for k, r in enumerate(rows):
+        q[r, k % 3] = weird[k % len(weird)]
+        if k % 7 == 0:
+            q[r, (k + 1) % 3] = weird[(k + 3) % len(weird)]
+    for md2 in (25.0, 1e39, 1e300):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi), md2
+        assert np.array_equal(d2, od2, equal_nan=True), md2
+        assert kd.count_visits(q, md2) == T.find_closest(q, md2, 8, True)[2], md2
+
+
 def test_leaf_table_mode(tdtk, orc, gpu):
     """bits(M) + bits(max leaf) > 30 switches child references to the leaf table."""
     rng = np.random.default_rng(5)
