@@ -252,7 +252,8 @@ struct tdtk_tree {
   size_t M = 0;
   int bucket = 0;
   TreeDev dev{};
-  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr;
+  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr, *d_grp = nullptr;
+  size_t Mp = 0;   // slots of d_pts: M, or 4 * groups once the buckets are padded to whole groups (tree_pad_buckets)
   double bbmin[3], bbmax[3], centre[3];
   tdtk_tree_info info{};
   tdtk_tree() = default;
@@ -261,7 +262,7 @@ struct tdtk_tree {
   ~tdtk_tree()   // also the error paths of tdtk_tree_create: nothing stays allocated on the device
   {
     (void)hipSetDevice(device);
-    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot};
+    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot, d_grp};
     for (void* q : p)
       if (q) (void)hipFree(q);
   }
@@ -349,8 +350,51 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   return TDTK_OK;
 }
 
+// Pad every bucket to whole groups of four slots and build the fp32 shadow groups the big-batch search filters buckets
+// with (kernels.hip, "bucket groups").  The build's scratch arena is free again at this point and holds the two counter
+// arrays and the scan's temporary.  Skipped (the tree stays as built, the search scans buckets in fp64 only) when the
+// tree is a single bucket, when the padded positions would not fit the reference format, or with TDTK_BUCKET_GROUPS=0.
+static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
+{
+  t->Mp = M;
+  static const bool off = [] { const char* e = getenv("TDTK_BUCKET_GROUPS"); return e && e[0] == '0'; }();
+  if (off || t->info.n_internal == 0) return TDTK_OK;
+  const size_t n1 = M + 1;
+  const size_t tmpb = scan_u32_temp_bytes(n1);
+  const size_t need = 2 * n1 * sizeof(uint32_t) + tmpb + 256;
+  int rc;
+  if ((rc = c->ws[WS_ARENA].ensure(need))) return rc;
+  uint32_t* ng_at = c->ws[WS_ARENA].as<uint32_t>();
+  uint32_t* g_at = ng_at + n1;
+  void* tmp = (void*)(((uintptr_t)(g_at + n1) + 127) & ~(uintptr_t)127);
+  const uint32_t cb = t->dev.cb, cmask = (cb >= 32) ? 0xFFFFFFFFu : ((1u << cb) - 1u);
+  KdNode* nodes = static_cast<KdNode*>(t->d_nodes);
+  LeafEntry* leaf = static_cast<LeafEntry*>(t->d_leaf);
+  HIPCHK(launch_pad_mark(nodes, t->info.n_internal, leaf, cb, cmask, ng_at, M, c->stream));
+  HIPCHK(launch_scan_u32(ng_at, g_at, n1, tmp, tmpb, c->stream));
+  uint32_t G = 0;
+  HIPCHK(hipMemcpyAsync(&G, g_at + M, sizeof G, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint64_t slots = 4ull * G;
+  // the padded starts must fit where the starts fitted: 30-bit packed references (start << cb | count), 32-bit byte
+  // offsets into the point and group arrays, int32 starts of the leaf table
+  if (G == 0 || slots * sizeof(KdPoint) >= (1ull << 32) || (!leaf && (slots << cb) > (uint64_t)REF_VAL)) return TDTK_OK;
+  void *ptsP = nullptr, *grp = nullptr;
+  HIPCHK(hipMalloc(&ptsP, slots * sizeof(KdPoint)));
+  if (hipMalloc(&grp, (size_t)G * 48) != hipSuccess) { (void)hipFree(ptsP); set_error("hipMalloc failed"); return TDTK_ENOMEM; }
+  hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
+                                 static_cast<KdPoint*>(ptsP), static_cast<float4*>(grp), c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { (void)hipFree(ptsP); (void)hipFree(grp); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
+  (void)hipFree(t->d_pts);
+  t->d_pts = ptsP; t->d_grp = grp; t->Mp = (size_t)slots;
+  return TDTK_OK;
+}
+
 static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
 {
+  int prc = tree_pad_buckets(c, t, M);
+  if (prc) return prc;
   for (int a = 0; a < 3; a++) t->centre[a] = 0.5 * (t->bbmin[a] + t->bbmax[a]);
   // the compact hot records (fp32 box + split value + children) the big-batch search kernel walks
   double am = 0.0;
@@ -364,11 +408,13 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   t->dev.hot = static_cast<const KdHot*>(t->d_hot);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
+  t->dev.grp = static_cast<const float4*>(t->d_grp);
   t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
   t->dev.node_r = static_cast<const double*>(t->d_r);
   t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
   t->info.n_points = M;
-  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + sizeof(double)) + M * sizeof(KdPoint) +
+  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + sizeof(double)) + t->Mp * sizeof(KdPoint) +
+                         (t->d_grp ? t->Mp / 4 * 48 : 0) +
                          (t->d_leaf ? t->info.n_leaves * sizeof(LeafEntry) : 0);
   return TDTK_OK;
 }
@@ -1515,9 +1561,53 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
   Ctx* c;
   int rc = get_ctx(t->device, &c);
   if (rc) return rc;
+  // The resident arrays, with the padding of the buckets to whole groups (tree_pad_buckets) undone: the leaves in the
+  // order of their (padded) starts give back the packed array and the references the builder emitted.
+  std::vector<KdPoint> padded(t->Mp);
+  HIPCHK(hipMemcpy(padded.data(), t->d_pts, padded.size() * sizeof(KdPoint), hipMemcpyDeviceToHost));
+  std::vector<KdNode> dn(t->info.n_internal);
+  std::vector<LeafEntry> dl;
+  if (!dn.empty()) HIPCHK(hipMemcpy(dn.data(), t->d_nodes, dn.size() * sizeof(KdNode), hipMemcpyDeviceToHost));
+  if (t->d_leaf) { dl.resize(t->info.n_leaves); HIPCHK(hipMemcpy(dl.data(), t->d_leaf, dl.size() * sizeof(LeafEntry), hipMemcpyDeviceToHost)); }
+  std::vector<KdPoint> pts;
+  uint64_t group_errors = 0;
+  if (t->d_grp) {
+    const uint32_t cbv = t->dev.cb, cm = (cbv >= 32) ? 0xFFFFFFFFu : ((1u << cbv) - 1u);
+    struct Run { uint32_t start, count; uint32_t* ref; LeafEntry* le; };
+    std::vector<Run> runs;
+    for (KdNode& nd : dn)
+      for (uint32_t* r : {&nd.c1, &nd.c2})
+        if (*r & REF_LEAF) {
+          const uint32_t v = *r & REF_VAL;
+          if (t->d_leaf) runs.push_back({(uint32_t)dl[v].start, (uint32_t)dl[v].count, nullptr, &dl[v]});
+          else runs.push_back({v >> cbv, v & cm, r, nullptr});
+        }
+    std::sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.start < b.start; });
+    std::vector<float> shadow((size_t)t->Mp * 3);
+    HIPCHK(hipMemcpy(shadow.data(), t->d_grp, shadow.size() * sizeof(float), hipMemcpyDeviceToHost));
+    pts.reserve(t->M);
+    uint32_t expect = 0;
+    for (const Run& r : runs) {
+      if (r.start != expect || (r.start & 3u) || r.count == 0 || (size_t)r.start + r.count > t->Mp) { group_errors++; break; }
+      const uint32_t packed = (uint32_t)pts.size(), ng = (r.count + 3u) >> 2;
+      for (uint32_t j = 0; j < 4 * ng; j++) {
+        const KdPoint& P = padded[r.start + j];
+        const KdPoint& L = padded[r.start + std::min(j, r.count - 1)];
+        if (j < r.count) pts.push_back(P);
+        else if (std::memcmp(&P, &L, sizeof P) != 0) group_errors++;     // a pad slot repeats the bucket's last point
+        const size_t g = (r.start + j) >> 2, k = j & 3u;
+        if (shadow[g * 12 + k] != (float)L.x || shadow[g * 12 + 4 + k] != (float)L.y || shadow[g * 12 + 8 + k] != (float)L.z) group_errors++;
+      }
+      expect = r.start + 4 * ng;
+      if (r.le) r.le->start = (int32_t)packed;
+      else *r.ref = (*r.ref & ~REF_VAL) | (packed << cbv) | r.count;
+    }
+    if (expect != t->Mp || pts.size() != t->M) group_errors++;
+    if (group_errors) { mismatches[0] = mismatches[1] = mismatches[2] = 0; mismatches[3] = group_errors; return TDTK_OK; }
+  } else {
+    pts = padded;
+  }
   // recover the caller's array from the resident points (each carries its caller index)
-  std::vector<KdPoint> pts(t->M);
-  HIPCHK(hipMemcpy(pts.data(), t->d_pts, pts.size() * sizeof(KdPoint), hipMemcpyDeviceToHost));
   std::vector<double> xyz(3 * t->M);
   for (size_t k = 0; k < t->M; k++) {
     const size_t o = (size_t)pts[k].orig;
@@ -1536,7 +1626,7 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
     mismatches[3] = 1;
   if (mismatches[3] == 0) {
     if (!nodes.empty()) {
-      HIPCHK(hipMemcpy(nodes.data(), t->d_nodes, nodes.size() * sizeof(KdNode), hipMemcpyDeviceToHost));
+      nodes = dn;    // with the references pointing into the packed array again
       HIPCHK(hipMemcpy(rr.data(), t->d_r, rr.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
     for (size_t i = 0; i < nodes.size(); i++) {
@@ -1551,8 +1641,7 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
       if (!(pts[i].x == H.pts[i].x && pts[i].y == H.pts[i].y && pts[i].z == H.pts[i].z && pts[i].orig == H.pts[i].orig))
         mismatches[2]++;
     if (H.table_mode) {
-      std::vector<LeafEntry> lt(H.leaf_tab.size());
-      HIPCHK(hipMemcpy(lt.data(), t->d_leaf, lt.size() * sizeof(LeafEntry), hipMemcpyDeviceToHost));
+      std::vector<LeafEntry> lt = dl;
       // leaf ids may be numbered differently; compare through the references instead
       auto leaf_of = [&](const std::vector<LeafEntry>& tab, uint32_t ref) { return tab[ref & REF_VAL]; };
       for (size_t i = 0; i < nodes.size(); i++)

@@ -15,6 +15,7 @@ struct TreeDev {
   float absmax;               // largest |coordinate| of the root box: scales the fp32 error bound
   const KdNode* nodes;
   const KdPoint* pts;
+  const float4* grp;          // fp32 shadow groups of the (padded) buckets, 3 x float4 per 4 slots; null: buckets are not padded
   const LeafEntry* leaf_tab;  // non-null only in table mode
   const double* node_r;       // FindClosestAlongDir only
   uint32_t root_ref;
@@ -125,6 +126,11 @@ int search_fuse_kind(size_t n);   // 0 no, 1 persistent-lane FUSE modes (on requ
 uint32_t search_fused_rows(size_t n, int side_by_side = 1);  // rows of partials the fused kernel writes
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
+// bucket groups (kernels.hip, "bucket groups"): mark -> exclusive scan of ng_at[0..M] (launch_scan_u32) -> fill
+hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, uint32_t* ng_at,
+                           size_t M, hipStream_t s);
+hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, const uint32_t* g_at,
+                           const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s);
 hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);
 // several batches (the link passes of a graph-SLAM round) in one launch: see k_search_refill_multi in kernels.hip
 struct FinalDesc { const double* partials; double* out; int rows, pad; };

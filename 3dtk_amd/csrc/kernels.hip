@@ -184,6 +184,8 @@ struct BoxF32 {
   float qx, qy, qz;   // the query in fp32
   float delta;        // error bound of a32 for this query; NaN when the query does not fit fp32 (inf / NaN component)
   float thi, tlo;     // decision thresholds for the current closest_d2; NaN: take the exact test
+  float ec;           // bucket groups: sqrt(3) x the error bound of one fp32 coordinate difference (NaN like delta)
+  float pthr;         // bucket groups: a shadow squared distance >= pthr proves myd2 >= closest_d2 (NaN: proves nothing)
   __device__ __forceinline__ void set_query(const double x, const double y, const double z, const float absmax)
   {
     qx = (float)x; qy = (float)y; qz = (float)z;
@@ -192,8 +194,21 @@ struct BoxF32 {
     // fmaxf drops a NaN operand and (float)1e39 is +inf: a query with such a component must never be decided in fp32.
     // The sum of the three is NaN or +-inf exactly when one of them is not finite (or when they are within a factor of
     // three of FLT_MAX, which may take the exact test as well).
+    // GroupF32 (below): |fl32(fl32(p_i) - fl32(q_i)) - (p_i - q_i)| <= 2^-24 (|p_i| + |q_i|) (1 + 2^-23) + 2^-24 |p_i - q_i|;
+    // ec covers sqrt(3) times the first term with 1.7 % to spare
+    ec = 1.05e-7f * (qm + absmax) + 1.0e-30f;
     const float probe = fabsf(qx) + fabsf(qy) + fabsf(qz);
-    if (!(probe <= 3.0e38f)) delta = __builtin_nanf("");
+    if (!(probe <= 3.0e38f)) { delta = __builtin_nanf(""); ec = delta; }
+  }
+  // smallest shadow squared distance that PROVES a true distance > R (R an fp32 upper bound of the radius in question):
+  // sqrt(s) (1 - 3.4 * 2^-24) - ec <= true distance, so s >= ((R + ec) (1 + 1e-6))^2 (1 + 1e-6) leaves 1.6e-6 R of margin
+  // (the 1e-6 factors are 17 ulp each: they also cover the roundings of this very expression).  Not finite or beyond
+  // 1e37: NaN, which no comparison passes.
+  __device__ __forceinline__ float reject_from(const float R) const
+  {
+    const float w = (R * 1.000001f + ec) * 1.000001f;
+    const float t = w * w * 1.000001f;
+    return (t <= 1.0e37f) ? t : __builtin_nanf("");
   }
   __device__ __forceinline__ void set_radius(const double best)
   {
@@ -203,6 +218,7 @@ struct BoxF32 {
     // closest_d2 beyond float range ((float)best = +inf), or a NaN delta: both comparisons of the fast path must fail
     // (a32 >= NaN and a32 < NaN are false), which sends the visit to the exact fp64 test
     if (!(thi <= 3.0e38f)) { thi = __builtin_nanf(""); tlo = thi; }
+    pthr = reject_from(r32);     // r32 >= sqrt(closest_d2) (1 - 2.5e-7): inside reject_from's margin
   }
 };
 
@@ -1026,13 +1042,15 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __r
 // contended counter costs ~0.6 us and they serialise per counter (1M queries, 64-query draws: 0.93 ms against 0.27 ms
 // static; 256-query draws: 0.58 ms), and (b) the premise is wrong at this size -- a chip full of resident waves
 // (7168) leaves 1M queries only ~140 per wave, i.e. MORE drains per query than the static 224..256-query slabs.
+// groups of four points a lane takes in per round trip of the bucket filter: 5 = a whole default bucket (-b 20)
+constexpr int GRP_TRIP = 5;
 // diagnostics (TDTK_WAVE_TRACE=<launch index>): start / end time (100 MHz) and XCD of every wave of one launch
 #define WTRACE_MAX 32768u
 __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -1059,6 +1077,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   int* const a_kpos = a.kpos;
   double* const a_d2 = a.d2;
   unsigned char* const a_cost = a.cost;
+  const char* const t_grp = reinterpret_cast<const char*>(T.grp);
 
   // "expensive queries first": the order in which a piece of the slab is handed out (offsets within the piece), by the
   // number of buckets each query visited in the previous pass.  Lanes that work on queries of similar length at the same
@@ -1163,7 +1182,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   size_t qi = 0;
   bool have = false;
   BoxF32 bx;
-  bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f;
+  bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f; bx.ec = 0.f; bx.pthr = 0.f;
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
   unsigned nbk = 0;   // buckets this lane's query has visited (the next pass's ordering key)
@@ -1375,6 +1394,62 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
+      if (PROBE == 0 && t_grp != nullptr && count <= 4 * GRP_TRIP) {
+        // ---- bucket groups: the whole bucket in ONE round trip of fp32 shadow records, then only the points that can
+        // still matter from the fp64 array.  The reference's leaf loop (kdTreeImpl.h:351-357) leaves behind
+        //   closest_d2 = min(closest_d2, min_j d_j),  closest = the FIRST j that attains a smaller value,
+        // and nothing else of it is observable.  A point is dropped only on proof that it is not that j:
+        //   (A) s_j >= pthr            =>  d_j >= closest_d2 (BoxF32::reject_from): it fails the reference's '<';
+        //   (B) s_j >= reject_from(R)  with R >= the true distance of the point k with the smallest shadow distance
+        //                              =>  d_j > d_k: somebody else is strictly closer.
+        // The survivors -- the nearest point, exact duplicates of it, anything within ~1e-5 relative -- are tested in
+        // fp64 in bucket order with the strict '<', which is the reference's loop restricted to the points that can win.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const uint32_t go = (uint32_t)(start >> 2) * 48u;     // the bucket's first group (start is a multiple of 4)
+        const uint32_t glast = go + (uint32_t)((count - 1) >> 2) * 48u;
+        float4 X[GRP_TRIP], Y[GRP_TRIP], Z[GRP_TRIP];
+#pragma unroll
+        for (int k = 0; k < GRP_TRIP; k++) {
+          // groups past the bucket's last re-read the last one (an L1 hit, no branch); their bits are masked out below
+          const uint32_t gk = min(go + 48u * (uint32_t)k, glast);
+          X[k] = *reinterpret_cast<const float4*>(t_grp + gk);
+          Y[k] = *reinterpret_cast<const float4*>(t_grp + gk + 16);
+          Z[k] = *reinterpret_cast<const float4*>(t_grp + gk + 32);
+        }
+        const v2f qxx = {bx.qx, bx.qx}, qyy = {bx.qy, bx.qy}, qzz = {bx.qz, bx.qz};
+        float sv[4 * GRP_TRIP];
+#pragma unroll
+        for (int k = 0; k < GRP_TRIP; k++) {
+          const v2f dxa = (v2f){X[k].x, X[k].y} - qxx, dxb = (v2f){X[k].z, X[k].w} - qxx;
+          const v2f dya = (v2f){Y[k].x, Y[k].y} - qyy, dyb = (v2f){Y[k].z, Y[k].w} - qyy;
+          const v2f dza = (v2f){Z[k].x, Z[k].y} - qzz, dzb = (v2f){Z[k].z, Z[k].w} - qzz;
+          const v2f sa = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
+          const v2f sb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
+          sv[4 * k] = sa.x; sv[4 * k + 1] = sa.y; sv[4 * k + 2] = sb.x; sv[4 * k + 3] = sb.y;
+        }
+        float smin = sv[0];
+#pragma unroll
+        for (int j = 1; j < 4 * GRP_TRIP; j++) smin = fminf(smin, sv[j]);   // pad slots and re-read groups repeat real points
+        unsigned surv = 0u;
+        if (!(smin >= bx.pthr)) {                     // else (A) drops every point of the bucket: the usual case after the first
+          // (B): sqrt(smin) (1 + 4 * 2^-24) + ec >= the true distance of that point
+          const float rub = __builtin_amdgcn_sqrtf(smin) * 1.000001f + bx.ec;
+          const float thr = fminf(bx.pthr, bx.reject_from(rub));   // fminf skips a NaN operand: either proof alone is valid
+#pragma unroll
+          for (int j = 4 * GRP_TRIP - 1; j >= 0; j--) surv = surv + surv + ((sv[j] >= thr) ? 0u : 1u);
+          surv &= (count >= 32) ? 0xFFFFFFFFu : ((1u << count) - 1u);
+        }
+        while (surv) {                                // in bucket order: lowest set bit first
+          const uint32_t j = (uint32_t)__builtin_ctz(surv);
+          surv &= surv - 1u;
+          const uint32_t oj = o0 + (j << 5);
+          const double2 pxy = *reinterpret_cast<const double2*>(pb + oj);
+          const double pz = *reinterpret_cast<const double*>(pb + oj + 16);
+          const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pz - qz;
+          const double dj = dx * dx + dy * dy + dz * dz;
+          if (dj < best) { best = dj; bk = (int)(oj >> 5); }
+        }
+      } else
       // PTS points per round trip, all their loads issued before the first use; the last group re-reads the final point
       // instead of running a scalar tail (a repeated point can never pass the strict '<' a second time)
       for (uint32_t o = o0; o <= olast; o += 32u * PTS) {
@@ -1386,12 +1461,22 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           const double2 pxy = *reinterpret_cast<const double2*>(pb + oo[j]);      // x y
           px[j] = pxy.x; py[j] = pxy.y;
           pz[j] = *reinterpret_cast<const double*>(pb + oo[j] + 16);              // z (the caller's index is not needed here)
+          if constexpr (PROBE == 1) {   // sensitivity probe (TDTK_BUCKET_PTS=41): one more load per point, result unused
+            double w = *reinterpret_cast<const double*>(pb + oo[j] + 24);
+            asm volatile("" :: "v"(w));
+          }
         }
         double dd[PTS];
 #pragma unroll
         for (int j = 0; j < PTS; j++) {
           const double dx = px[j] - qx, dy = py[j] - qy, dz = pz[j] - qz;
           dd[j] = dx * dx + dy * dy + dz * dz;
+          if constexpr (PROBE == 2) {   // sensitivity probe (TDTK_BUCKET_PTS=42): eight more fp64 VALU instructions per point
+            double w = dx;
+#pragma unroll
+            for (int r = 0; r < 8; r++) asm volatile("v_add_f64 %0, %0, %1" : "+v"(w) : "v"(dy));
+            asm volatile("" :: "v"(w));
+          }
         }
 #pragma unroll
         for (int j = 0; j < PTS; j++)
@@ -1501,7 +1586,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   }
 }
 
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a_by_value)
 {
   // The argument block (three 4x4 fp64 matrices among its 700 bytes) is read through the kernarg segment pointer, not
@@ -1513,7 +1598,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   typedef const SearchArgs __attribute__((address_space(4))) * kernarg_ptr;   // constant address space -> s_load
   kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ap));
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS>(*(const SearchArgs*)ap, blockIdx.x, gridDim.x);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE>(*(const SearchArgs*)ap, blockIdx.x, gridDim.x);
 }
 
 // Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
@@ -2151,7 +2236,9 @@ static int refill_qpw(size_t n, int side_by_side = 1)
     if (q > 512) q = 512;
     return (int)q;
   }
-  size_t q = (n + (size_t)num_cu() * 18 - 1) / ((size_t)num_cu() * 18);   // 4.5 waves per SIMD
+  // (round 3: the kernel holds a whole bucket's shadow groups in registers, 122 of them: four waves per SIMD are what
+  // fits, so the launch is sized for exactly that -- one resident generation, no straggling second one)
+  size_t q = (n + (size_t)num_cu() * 16 - 1) / ((size_t)num_cu() * 16);   // 4 waves per SIMD
   q = (q + 31) & ~(size_t)31;
   if (q < 128) q = 128;
   if (q > 256) q = 256;
@@ -2289,6 +2376,10 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   const int bpts = pe ? atoi(pe) : 4;
   if (!COUNT && FUSE == 0 && bpts == 8 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 8>), dim3(nb), dim3(128), occ_lds, s, a);
+  } else if (!COUNT && FUSE == 0 && bpts == 41 && refill_thresh(a.n) == 16) {
+    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 1>), dim3(nb), dim3(128), occ_lds, s, a);
+  } else if (!COUNT && FUSE == 0 && bpts == 42 && refill_thresh(a.n) == 16) {
+    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
   } else switch (refill_thresh(a.n)) {
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
@@ -2481,6 +2572,80 @@ hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_
 {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(k_make_hot, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, hot);
+  return hipGetLastError();
+}
+
+// ---- bucket groups: the search-side layout of the leaf points (round 3) --------------------------------------------
+// Every bucket is padded to a multiple of four slots in the leaf-ordered point array (the pad slots repeat the bucket's
+// last point, which can never pass the strict '<' of the leaf scan a second time), so that a bucket starts at a
+// multiple of four and owns (count + 3) / 4 GROUPS.  Group g = slots 4g .. 4g+3 has a 48-byte fp32 shadow record
+// { x[4], y[4], z[4] }: three 16-byte loads bring four points, and a whole default bucket (<= 20 points) arrives in one
+// round trip and 60 registers.  The shadow only ever REJECTS points that provably cannot pass the reference's
+// `myd2 < closest_d2` (see GroupF32); whatever survives is read from the fp64 record and tested exactly, in order.
+// Child references of the node records are rewritten to the padded starts, so every other kernel keeps scanning
+// (start, count) runs of the same array unchanged.
+__global__ void __launch_bounds__(256) k_pad_mark(const KdNode* __restrict__ nodes, size_t n, const LeafEntry* __restrict__ leaf_tab,
+                                                  uint32_t cb, uint32_t cmask, uint32_t* __restrict__ ng_at)
+{
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= 2 * n) return;
+  const KdNode& nd = nodes[t >> 1];
+  const uint32_t ref = (t & 1) ? nd.c2 : nd.c1;
+  if (!(ref & REF_LEAF)) return;
+  const uint32_t v = ref & REF_VAL;
+  uint32_t start, count;
+  if (leaf_tab) { start = (uint32_t)leaf_tab[v].start; count = (uint32_t)leaf_tab[v].count; }
+  else { start = v >> cb; count = v & cmask; }
+  ng_at[start] = (count + 3u) >> 2;
+}
+__global__ void __launch_bounds__(256) k_pad_fill(KdNode* __restrict__ nodes, size_t n, LeafEntry* __restrict__ leaf_tab, uint32_t cb,
+                                                  uint32_t cmask, const uint32_t* __restrict__ g_at, const KdPoint* __restrict__ pts,
+                                                  KdPoint* __restrict__ ptsP, float4* __restrict__ grp)
+{
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= 2 * n) return;
+  KdNode& nd = nodes[t >> 1];
+  const uint32_t ref = (t & 1) ? nd.c2 : nd.c1;
+  if (!(ref & REF_LEAF)) return;
+  const uint32_t v = ref & REF_VAL;
+  uint32_t start, count;
+  if (leaf_tab) { start = (uint32_t)leaf_tab[v].start; count = (uint32_t)leaf_tab[v].count; }
+  else { start = v >> cb; count = v & cmask; }
+  const uint32_t g0 = g_at[start], ng = (count + 3u) >> 2;
+  for (uint32_t k = 0; k < ng; k++) {
+    float fx[4], fy[4], fz[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+      const uint32_t src = start + min(4u * k + j, count - 1u);
+      const KdPoint P = pts[src];
+      ptsP[(size_t)4 * (g0 + k) + j] = P;
+      fx[j] = (float)P.x; fy[j] = (float)P.y; fz[j] = (float)P.z;   // round to nearest: what GroupF32's error bound assumes
+    }
+    grp[(size_t)3 * (g0 + k) + 0] = make_float4(fx[0], fx[1], fx[2], fx[3]);
+    grp[(size_t)3 * (g0 + k) + 1] = make_float4(fy[0], fy[1], fy[2], fy[3]);
+    grp[(size_t)3 * (g0 + k) + 2] = make_float4(fz[0], fz[1], fz[2], fz[3]);
+  }
+  if (leaf_tab) leaf_tab[v].start = (int32_t)(4u * g0);
+  else {
+    const uint32_t nv = (ref & ~REF_VAL) | ((4u * g0) << cb) | count;
+    if (t & 1) nd.c2 = nv; else nd.c1 = nv;
+  }
+}
+// pass 1: how many groups each bucket needs, written at the bucket's start position (ng_at[0 .. M], zeroed here)
+hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, uint32_t* ng_at,
+                           size_t M, hipStream_t s)
+{
+  hipError_t e = hipMemsetAsync(ng_at, 0, (M + 1) * sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_pad_mark, dim3((uint32_t)((2 * n_internal + 255) / 256)), dim3(256), 0, s, nodes, n_internal, leaf_tab, cb, cmask, ng_at);
+  return hipGetLastError();
+}
+// pass 2 (after an exclusive scan of ng_at into g_at): padded points, shadow groups, rewritten references
+hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, const uint32_t* g_at,
+                           const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pad_fill, dim3((uint32_t)((2 * n_internal + 255) / 256)), dim3(256), 0, s, nodes, n_internal, leaf_tab, cb, cmask, g_at, pts,
+                     ptsP, grp);
   return hipGetLastError();
 }
 
