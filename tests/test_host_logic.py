@@ -753,18 +753,20 @@ def test_product_and_bench_keep_clear_of_the_oracle():
         assert fn == "cpu_baseline_nn" or "no_cpu" in ctx[ctx.rfind("if "):], (fn, m.group(0))
 
 
-def test_timed_search_kernels_keep_five_waves_per_simd():
-    """The persistent-lane search kernel of the ICP loop stays within the 96 vector registers that still allow five
-    waves per SIMD (one more and a 1M-point launch takes 0.258 ms instead of 0.206); the several-links-per-launch kernel
-    of graph-SLAM has the same limit.  The build keeps the compiler's resource remarks; this reads them."""
+def test_timed_search_kernels_keep_four_waves_per_simd_and_spill_nothing():
+    """The persistent-lane search kernel of the ICP loop holds a whole bucket's fp32 shadow groups in registers (round 3:
+    one round trip per bucket): ~122 vector registers, i.e. four waves per SIMD, which is what its launches are sized for
+    (refill_qpw).  More than 128 would halve that.  No spills of either kind: round 2 shipped 80 spilled SGPRs here (the
+    by-value argument block hoisted into registers, every use a v_readlane); the block is read through the kernarg
+    pointer where it is used now.  The build keeps the compiler's resource remarks; this reads them."""
     import re
     path = os.path.join(ROOT, "3dtk_amd", "csrc", "kernels.resource.txt")
     if not os.path.exists(path):
         pytest.skip("no build in this tree (kernels.resource.txt is written by the Makefile)")
     text = open(path).read()
     kernels = {
-        "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0ELi4ELi0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false, 4>",
-        "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0ELi4ELi0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false, 4>",
+        "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0ELi4ELi0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0>",
+        "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0ELi4ELi0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false, 4, 0>",
         "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0>",
     }
     for mangled, name in kernels.items():
@@ -775,6 +777,4 @@ def test_timed_search_kernels_keep_five_waves_per_simd():
         vg = int(re.search(r"VGPRs: (\d+)", block).group(1))
         spill = int(re.search(r"VGPRs Spill: (\d+)", block).group(1))
         sspill = int(re.search(r"SGPRs Spill: (\d+)", block).group(1))
-        # round 2 shipped 80 spilled SGPRs here (the by-value argument block hoisted into registers; every use a v_readlane):
-        # the block is read through the kernarg pointer where it is used now -- no spills of either kind
-        assert occ >= 5 and vg <= 96 and spill == 0 and sspill == 0, (name, occ, vg, spill, sspill)
+        assert occ >= 4 and vg <= 128 and spill == 0 and sspill == 0, (name, occ, vg, spill, sspill)
