@@ -252,7 +252,7 @@ struct tdtk_tree {
   size_t M = 0;
   int bucket = 0;
   TreeDev dev{};
-  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr, *d_grp = nullptr;
+  void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr, *d_grp = nullptr, *d_fat = nullptr;
   size_t Mp = 0;   // slots of d_pts: M, or 4 * groups once the buckets are padded to whole groups (tree_pad_buckets)
   double bbmin[3], bbmax[3], centre[3];
   tdtk_tree_info info{};
@@ -262,7 +262,7 @@ struct tdtk_tree {
   ~tdtk_tree()   // also the error paths of tdtk_tree_create: nothing stays allocated on the device
   {
     (void)hipSetDevice(device);
-    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot, d_grp};
+    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot, d_grp, d_fat};
     for (void* q : p)
       if (q) (void)hipFree(q);
   }
@@ -403,9 +403,17 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   if (t->info.n_internal) {
     HIPCHK(hipMalloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
     HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream));
+    // ... and the two-level records the persistent-lane kernel walks (32-bit byte offsets: < 2^25 internal nodes, which
+    // the 2^27-point limit of a tree implies)
+    static const bool want_fat = [] { const char* e = getenv("TDTK_FAT_NODES"); return e && e[0] == '1'; }();
+    if (want_fat) {     // the two-level walk is a measured negative (kernels.hip): its records are built on request only
+      HIPCHK(hipMalloc(&t->d_fat, t->info.n_internal * sizeof(KdFat)));
+      HIPCHK(launch_make_fat(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdFat*>(t->d_fat), c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   t->dev.hot = static_cast<const KdHot*>(t->d_hot);
+  t->dev.fat = static_cast<const KdFat*>(t->d_fat);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
   t->dev.grp = static_cast<const float4*>(t->d_grp);
@@ -413,7 +421,7 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   t->dev.node_r = static_cast<const double*>(t->d_r);
   t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
   t->info.n_points = M;
-  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + sizeof(double)) + t->Mp * sizeof(KdPoint) +
+  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + (t->d_fat ? sizeof(KdFat) : 0) + sizeof(double)) + t->Mp * sizeof(KdPoint) +
                          (t->d_grp ? t->Mp / 4 * 48 : 0) +
                          (t->d_leaf ? t->info.n_leaves * sizeof(LeafEntry) : 0);
   return TDTK_OK;

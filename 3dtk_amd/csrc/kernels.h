@@ -12,6 +12,7 @@ struct Mat4 {
 
 struct TreeDev {
   const KdHot* hot;           // compact hot records (fp32 box), same indexing as nodes
+  const KdFat* fat;           // a node's hot record together with its children's: two levels per round trip (big batches)
   float absmax;               // largest |coordinate| of the root box: scales the fp32 error bound
   const KdNode* nodes;
   const KdPoint* pts;
@@ -126,6 +127,7 @@ int search_fuse_kind(size_t n);   // 0 no, 1 persistent-lane FUSE modes (on requ
 uint32_t search_fused_rows(size_t n, int side_by_side = 1);  // rows of partials the fused kernel writes
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
+hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_t s);
 // bucket groups (kernels.hip, "bucket groups"): mark -> exclusive scan of ng_at[0..M] (launch_scan_u32) -> fill
 hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, uint32_t* ng_at,
                            size_t M, hipStream_t s);

@@ -166,6 +166,8 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
 #define TDTK_PIN_V64(x) asm volatile("" : "+v"(x))
 #define TDTK_PIN_S64(x) asm volatile("" : "+s"(x))
 #define TDTK_PIN_S32(x) asm volatile("" : "+s"(x))
+#define TDTK_PIN_SF(x) asm volatile("" : "+s"(x))
+#define TDTK_PIN_VF(x) asm volatile("" : "+v"(x))
 
 // ---- the box test at fp32 rate, without changing a single decision ---------------------------------------------
 // The reference prunes a node iff  a >= 0 && a*a >= closest_d2,  a = max_i(|q_i - c_i| - h_i)  in fp64
@@ -245,6 +247,25 @@ __device__ __forceinline__ uint32_t descend(const double splitval, const uint32_
   const double myd = splitval - qa;
   const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
   const bool first = (myd >= 0.0);
+  const uint32_t far = first ? r2 : r1;
+  const double m2 = myd * myd;
+  if (m2 < best) st.push(far, m2);
+  return first ? r1 : r2;
+}
+
+// descend(), also telling whether the near child is child 1 (the two-level walk then knows which half of the fat record
+// describes it)
+template <int BLOCK, int SD>
+__device__ __forceinline__ uint32_t descend_which(const double splitval, const uint32_t c1, const uint32_t c2, const double qx,
+                                                  const double qy, const double qz, const double best, LaneStack<BLOCK, SD>& st,
+                                                  bool& near_is_c1)
+{
+  const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
+  const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
+  const double myd = splitval - qa;
+  const uint32_t r1 = c1 & ~REF_AXIS, r2 = c2 & ~REF_AXIS;
+  const bool first = (myd >= 0.0);
+  near_is_c1 = first;
   const uint32_t far = first ? r2 : r1;
   const double m2 = myd * myd;
   if (m2 < best) st.push(far, m2);
@@ -1050,7 +1071,7 @@ __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ double lds_m2[SD][BLOCK];
@@ -1078,6 +1099,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   double* const a_d2 = a.d2;
   unsigned char* const a_cost = a.cost;
   const char* const t_grp = reinterpret_cast<const char*>(T.grp);
+  const char* const t_fat = reinterpret_cast<const char*>(T.fat);
 
   // "expensive queries first": the order in which a piece of the slab is handed out (offsets within the piece), by the
   // number of buckets each query visited in the previous pass.  Lanes that work on queries of similar length at the same
@@ -1324,7 +1346,108 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     }
 
     // ---- phase 1: walk internal nodes until this lane holds a bucket (or is finished) ----
-    while (!(cur & REF_LEAF)) {
+    // FAT (TDTK_FAT_NODES=1, a measured negative): two levels per round trip -- the 128-byte record of node X also
+    // describes X's two children, so a lane tests X, steps to the near child N and, if N is an internal node, tests N and
+    // steps again before it fetches anything else.  The visits, their order, every comparison and every push are those
+    // of the one-level walk (N's far child is pushed after X's, so it is popped first, as the recursion returns from N's
+    // subtree before it looks at X's far child); all 170 GPU parity tests pass with it.  It halves the dependent round
+    // trips of every walk and is SLOWER: 1M-vs-1M, k_search 0.2129 ms against 0.1960 at the driver's arguments, 0.1889
+    // against 0.1776 over 100 iterations, equal at 4M (gpurun_out/r3d).  Eight 16-byte loads per lane and trip instead of
+    // three is what costs: with the buckets down to one round trip of shadow groups, this kernel is bound by the number
+    // of vector-memory accesses it issues (~0.9 L1 tag look-ups per CU and cycle), not by the latency of a round trip.
+    if constexpr (FAT) while (!(cur & REF_LEAF)) {
+      if (COUNT) ++c_int;
+      if (ORDER) ++nbk;
+      bool need_pop = false;
+      uint32_t next = REF_DONE;
+      // level 2, shared by the two fetch paths below: the near child N of X is an internal node with this box / split /
+      // children; `nref` is its reference (index of its 64-byte record for the exact test)
+      auto level2 = [&](const uint32_t nref, const float ncx, const float ncy, const float ncz, const float nhx, const float nhy,
+                        const float nhz, const double nsplit, const uint32_t nc1, const uint32_t nc2) {
+        if (COUNT) ++c_int;
+        if (ORDER) ++nbk;
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - ncx) - nhx, fabsf(bx.qy - ncy) - nhy), fabsf(bx.qz - ncz) - nhz);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)((nref & REF_VAL) << 6);
+          const double4 n0 = *reinterpret_cast<const double4*>(np_);
+          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
+        if (prune) { need_pop = true; next = REF_DONE; }
+        else next = descend<BLOCK, SD>(nsplit, nc1, nc2, qx, qy, qz, best, st);
+      };
+      const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
+      if (__all(cur == ucur)) {
+        // wave-uniform visit: the record through the scalar cache, operands stay in SGPRs
+        typedef const float __attribute__((address_space(4))) * const_f_ptr;
+        const_f_ptr sf = (const_f_ptr)(t_fat + (size_t)ucur * sizeof(KdFat));
+        const_u_ptr su = (const_u_ptr)sf;
+        const_d_ptr sd = (const_d_ptr)sf;
+        double s_split = sd[4], s_asplit = sd[5], s_bsplit = sd[6];
+        uint32_t s_c1 = su[6], s_c2 = su[7], s_ac1 = su[14], s_ac2 = su[15], s_bc1 = su[28], s_bc2 = su[29];
+        float s_a0 = sf[16], s_a1 = sf[17], s_a2 = sf[18], s_a3 = sf[19], s_a4 = sf[20], s_a5 = sf[21];
+        float s_b0 = sf[24], s_b1 = sf[25], s_b2 = sf[26], s_b3 = sf[27], s_b4 = sf[22], s_b5 = sf[23];
+        TDTK_PIN_S64(s_split); TDTK_PIN_S64(s_asplit); TDTK_PIN_S64(s_bsplit);
+        TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2); TDTK_PIN_S32(s_ac1); TDTK_PIN_S32(s_ac2); TDTK_PIN_S32(s_bc1); TDTK_PIN_S32(s_bc2);
+        TDTK_PIN_SF(s_a0); TDTK_PIN_SF(s_a1); TDTK_PIN_SF(s_a2); TDTK_PIN_SF(s_a3); TDTK_PIN_SF(s_a4); TDTK_PIN_SF(s_a5);
+        TDTK_PIN_SF(s_b0); TDTK_PIN_SF(s_b1); TDTK_PIN_SF(s_b2); TDTK_PIN_SF(s_b3); TDTK_PIN_SF(s_b4); TDTK_PIN_SF(s_b5);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - sf[0]) - sf[3], fabsf(bx.qy - sf[1]) - sf[4]), fabsf(bx.qz - sf[2]) - sf[5]);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
+          prune = box_prunes_exact(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else {
+          bool isA;
+          next = descend_which<BLOCK, SD>(s_split, s_c1, s_c2, qx, qy, qz, best, st, isA);
+          if (!(next & REF_LEAF))
+            level2(next, isA ? s_a0 : s_b0, isA ? s_a1 : s_b1, isA ? s_a2 : s_b2, isA ? s_a3 : s_b3, isA ? s_a4 : s_b4, isA ? s_a5 : s_b5,
+                   isA ? s_asplit : s_bsplit, isA ? s_ac1 : s_bc1, isA ? s_ac2 : s_bc2);
+        }
+      } else {
+        const char* fp = t_fat + (uint32_t)(cur << 7);             // 32-bit byte offset from a scalar base
+        const float4 q0 = *reinterpret_cast<const float4*>(fp);            // X: cx cy cz hx
+        float4 q1 = *reinterpret_cast<const float4*>(fp + 16);             //    hy hz c1 c2
+        double2 q2 = *reinterpret_cast<const double2*>(fp + 32);           // X split, A split
+        double2 q3 = *reinterpret_cast<const double2*>(fp + 48);           // B split, {A c1, A c2}
+        float4 q4 = *reinterpret_cast<const float4*>(fp + 64);             // A: cx cy cz hx
+        float4 q5 = *reinterpret_cast<const float4*>(fp + 80);             // A hy hz, B hy hz
+        float4 q6 = *reinterpret_cast<const float4*>(fp + 96);             // B: cx cy cz hx
+        double q7 = *reinterpret_cast<const double*>(fp + 112);            // {B c1, B c2}
+        TDTK_PIN_V64(q2.x); TDTK_PIN_V64(q2.y); TDTK_PIN_V64(q3.x); TDTK_PIN_V64(q3.y); TDTK_PIN_V64(q7);
+        TDTK_PIN_VF(q1.z); TDTK_PIN_VF(q1.w); TDTK_PIN_VF(q4.x); TDTK_PIN_VF(q5.x); TDTK_PIN_VF(q6.x);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - q0.x) - q0.w, fabsf(bx.qy - q0.y) - q1.x), fabsf(bx.qz - q0.z) - q1.y);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
+          const double4 n0 = *reinterpret_cast<const double4*>(np_);
+          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else {
+          bool isA;
+          next = descend_which<BLOCK, SD>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
+          if (!(next & REF_LEAF))
+            level2(next, isA ? q4.x : q6.x, isA ? q4.y : q6.y, isA ? q4.z : q6.z, isA ? q4.w : q6.w, isA ? q5.x : q5.z, isA ? q5.y : q5.w,
+                   isA ? q2.y : q3.x, isA ? (uint32_t)__double2loint(q3.y) : (uint32_t)__double2loint(q7),
+                   isA ? (uint32_t)__double2hiint(q3.y) : (uint32_t)__double2hiint(q7));
+        }
+      }
+      if (need_pop) {
+        next = REF_DONE;
+        while (st.sp > 0) {
+          --st.sp;
+          uint32_t r; double m2;
+          st.top(r, m2);
+          if (m2 < best) { next = r; break; }
+        }
+      }
+      cur = next;
+    }
+    if constexpr (!FAT) while (!(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
       if (ORDER) ++nbk;
       bool need_pop = false;
@@ -1410,7 +1533,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         float4 X[GRP_TRIP], Y[GRP_TRIP], Z[GRP_TRIP];
 #pragma unroll
         for (int k = 0; k < GRP_TRIP; k++) {
-          // groups past the bucket's last re-read the last one (an L1 hit, no branch); their bits are masked out below
+          // groups past the bucket's last re-read the last one (an L1 hit, no branch); their bits are masked out below.
+          // (Loading each group under its own lane mask instead -- no access for a group the bucket does not have -- costs
+          // the register allocation 188 VGPRs instead of 122, i.e. half the resident waves: not done.)
           const uint32_t gk = min(go + 48u * (uint32_t)k, glast);
           X[k] = *reinterpret_cast<const float4*>(t_grp + gk);
           Y[k] = *reinterpret_cast<const float4*>(t_grp + gk + 16);
@@ -1586,7 +1711,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   }
 }
 
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a_by_value)
 {
   // The argument block (three 4x4 fp64 matrices among its 700 bytes) is read through the kernarg segment pointer, not
@@ -1598,7 +1723,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   typedef const SearchArgs __attribute__((address_space(4))) * kernarg_ptr;   // constant address space -> s_load
   kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ap));
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE>(*(const SearchArgs*)ap, blockIdx.x, gridDim.x);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT>(*(const SearchArgs*)ap, blockIdx.x, gridDim.x);
 }
 
 // Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
@@ -2380,6 +2505,9 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 1>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 42 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
+  } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr) {
+    // two tree levels per round trip (KdFat): a measured negative, kept selectable -- see the comment at the walk
+    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, true>), dim3(nb), dim3(128), occ_lds, s, a);
   } else switch (refill_thresh(a.n)) {
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
@@ -2567,6 +2695,33 @@ __global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nod
   h.pad0 = h.pad1 = 0u;
   h.splitval = nd.splitval; h.c1 = nd.c1; h.c2 = nd.c2;
   hot[i] = h;
+}
+__global__ void __launch_bounds__(256) k_make_fat(const KdNode* __restrict__ nodes, size_t n, KdFat* __restrict__ fat)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const KdNode nd = nodes[i];
+  KdFat f;
+  memset(&f, 0, sizeof f);
+  f.cx = (float)nd.cx; f.cy = (float)nd.cy; f.cz = (float)nd.cz; f.hx = (float)nd.hx; f.hy = (float)nd.hy; f.hz = (float)nd.hz;
+  f.c1 = nd.c1; f.c2 = nd.c2; f.splitval = nd.splitval;
+  if (!(nd.c1 & REF_LEAF)) {
+    const KdNode a = nodes[nd.c1 & REF_VAL];
+    f.a_cx = (float)a.cx; f.a_cy = (float)a.cy; f.a_cz = (float)a.cz; f.a_hx = (float)a.hx; f.a_hy = (float)a.hy; f.a_hz = (float)a.hz;
+    f.a_split = a.splitval; f.a_c1 = a.c1; f.a_c2 = a.c2;
+  }
+  if (!(nd.c2 & REF_LEAF)) {
+    const KdNode b = nodes[nd.c2 & REF_VAL];
+    f.b_cx = (float)b.cx; f.b_cy = (float)b.cy; f.b_cz = (float)b.cz; f.b_hx = (float)b.hx; f.b_hy = (float)b.hy; f.b_hz = (float)b.hz;
+    f.b_split = b.splitval; f.b_c1 = b.c1; f.b_c2 = b.c2;
+  }
+  fat[i] = f;
+}
+hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_make_fat, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, fat);
+  return hipGetLastError();
 }
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s)
 {

@@ -48,6 +48,22 @@ struct alignas(16) KdHot {
 };
 static_assert(sizeof(KdHot) == 48, "KdHot must be 48 bytes");
 
+// Two levels per round trip (round 3): the hot part of a node TOGETHER with the hot parts of its two children, 128 bytes,
+// one cache line.  A lane that arrives at node X tests X's box, picks the near child N and -- when N is an internal node
+// that X's record already describes -- tests N's box and descends again, all behind ONE fetch.  Same visits, same order,
+// same decisions; half the dependent round trips of a walk.  Fields of a child that is a leaf are zero.
+struct alignas(128) KdFat {
+  float cx, cy, cz, hx;            // quad 0: X box
+  float hy, hz; uint32_t c1, c2;   // quad 1: X box, X child references (with X's axis bits)
+  double splitval, a_split;        // quad 2: split values of X and of child 1 ("A")
+  double b_split; uint32_t a_c1, a_c2;   // quad 3: split value of child 2 ("B"), A's child references
+  float a_cx, a_cy, a_cz, a_hx;    // quad 4: A box
+  float a_hy, a_hz, b_hy, b_hz;    // quad 5
+  float b_cx, b_cy, b_cz, b_hx;    // quad 6: B box
+  uint32_t b_c1, b_c2, pad0, pad1; // quad 7: B's child references
+};
+static_assert(sizeof(KdFat) == 128, "KdFat must be 128 bytes");
+
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_AXIS = 0x40000000u;
 constexpr uint32_t REF_VAL = 0x3FFFFFFFu;

@@ -40,20 +40,27 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
-PMC_FILE = "r02_pmc_bench.json"
+PMC_ROUND = "r03"
+NUM_SIMD = 1024            # 256 CUs x 4 SIMDs
 
 
-def pmc_kernel(kernel, fname=PMC_FILE):
-    """Per-launch PMC averages of `kernel` over the timed region of this same command, from the committed summary
-    of the separate rocprofv3 --pmc passes (tools/profile_bench.sh -> tools/summarize_profiles.py)."""
+def pmc_file_for(steps, warmup):
+    """The committed summary of the rocprofv3 --pmc passes over THIS command line (tools/profile_bench.sh <tag> <steps>
+    <warmup> -> tools/summarize_profiles.py): one file per (steps, warmup), because the timed iterations of a 20-step run
+    right behind the initial pose are not those of a 100-step run."""
+    return "%s_pmc_bench_s%d_w%d.json" % (PMC_ROUND, int(steps), int(warmup))
+
+
+def pmc_kernel(kernel, fname, steps=None, warmup=None):
+    """Per-launch PMC averages of `kernel` over the timed region, or None.  When steps / warmup are given the summary is
+    REFUSED unless it was taken with exactly those (counters and kernel times of different runs are not combined)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"][kernel]
+        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        if steps is not None and (int(d.get("steps", -1)) != int(steps) or int(d.get("warmup", -1)) != int(warmup)):
+            return None
+        return d["kernels"][kernel]
     except Exception:
         return None
-
-
-def pmc_traffic_note(k):
-    return None if not k else "profiles/%s" % PMC_FILE
 
 
 def pmc_traffic_bytes(k):
@@ -114,7 +121,7 @@ class kernel_timing:
         self.L.tdtk_kernel_timing(self.was)
 
 
-def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw):
+def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw, pmc_source=None):
     """The `roofline` object for k_search.  achieved = ALGORITHMIC bytes per launch (24 B query + 64 B per
     internal node + 24 B per bucket point + 4 B index, with the node / point counts of exactly the timed launches) /
     average launch duration (HIP events).  Beside it the bounds that can tell a good kernel from a better one:
@@ -158,7 +165,23 @@ def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_quer
             b["wave_wait_share"] = {"frac": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
                                     "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wave's resident cycles spent waiting "
                                             "(dependent loads, issue slots taken by the other waves of its SIMD)"}
+    b["source"] = pmc_source or {"file": None, "note": "no committed counter summary for this command's steps / warmup: "
+                                                        "`traffic` is null and the counter-derived bounds are absent"}
     r["bounds"] = b
+    # The utilisations that can rank kernels (all < 1), from the same counter summary: how busy the vector ALUs were and
+    # how many of the lane-slots of the issued vector instructions did work.  (`frac` above is algorithmic bytes against
+    # HBM -- saturated by cache re-reads on this workload, not a utilisation.)
+    if pmc and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                    # the counter sums the 8 XCDs
+        issue = {"valu_busy": pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc),
+                 "what": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
+        if pmc.get("SQ_THREAD_CYCLES_VALU"):
+            issue["lane_efficiency"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if pmc.get("SQ_INSTS_VALU"):
+            issue["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
+        if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            issue["l1_tag_accesses_per_cu_cycle"] = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc
+        r["issue"] = issue
     return r
 
 
@@ -407,7 +430,12 @@ def bench_icp(args, rank, world, local):
     ti = {"n_internal": info["n_internal"], "n_points": n}
     # compulsory bytes per query besides the tree: x,y,z read + written back (fused transform), hit position written
     # and read back (warm start of the next pass)
-    roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4, pmc_kernel("k_search [timed region]") or pmc_kernel("k_search"), bw)
+    pfile = pmc_file_for(steps, args.warmup)
+    pk = pmc_kernel("k_search [timed region]", pfile, steps, args.warmup)
+    psrc = {"file": "profiles/" + pfile, "steps": steps, "warmup": args.warmup,
+            "what": "per-launch averages over the timed region of the same command line under rocprofv3 --pmc "
+                    "(tools/profile_bench.sh); refused unless steps and warmup equal this run's"} if pk else None
+    roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4, pk, bw, psrc)
 
     # the same 1M queries through the host-buffer entry point (H2D of queries, in-call binning,
     # search, D2H of indices + distances): the PCIe-inclusive rate -- reported, never the `value`
@@ -482,7 +510,7 @@ def bench_icp(args, rank, world, local):
         # the k neighbours gathered for mean / covariance (24 B each) + the normal out (24)
         bp = 24.0 + 32.0 * a_split / a_q + 24.0 * a_leaf / a_q + 24.0 * 10 + 24.0
         ach = bp * n / (kn_ms * 1e-3) / 1e9
-        pk = pmc_kernel("k_ann_normals")
+        pk = pmc_kernel("k_ann_normals<10>", "r01_normals_pmc.json")   # tools/profile_normals.sh (the kernel is unchanged since)
         out["normals_1gpu"] = {"value": n / min(t_n), "unit": "points/s", "ms": min(t_n) * 1e3, "points": n, "k": 10, "eps": 1.0,
                                "what": "tdtk_scan_calc_normals on the resident scan: ANN-tree build, approximate 10-NN, "
                                        "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat",
@@ -597,7 +625,7 @@ def bench_graphslam(args, rank, world, local):
     last_links = my_links - batch * (groups - 1) if batched else 1
     agg = bq * my_links * npts / (dt / args.steps) / 1e9
     ach = bq * last_links * npts / (k_ms * 1e-3) / 1e9 if k_ms > 0 else agg
-    pk = pmc_kernel("k_search (several links per launch)" if batched else "k_search", "r02_graphslam_pmc.json")
+    pk = pmc_kernel("k_search (several links per launch)" if batched else "k_search", PMC_ROUND + "_graphslam_pmc.json")
     traffic = pmc_traffic_bytes(pk)
     if traffic is not None and batched:
         traffic = traffic * groups / my_links * last_links      # the committed passes average over a step's launches

@@ -1,16 +1,22 @@
 #!/usr/bin/env bash
-# GPU box: rocprofv3 passes over the default bench command.  Each pass has its own timeout;
-# counters are collected in their own runs (kernel-trace only), never with other trace domains.
-#   usage: tools/profile_bench.sh <tag>          -> gpurun_out/<tag>/{stats,fetch,write}/...
+# GPU box: rocprofv3 passes over ONE bench command.  Each pass has its own timeout; counters are collected in their own
+# runs (kernel-trace only), never with other trace domains.
+#   usage: tools/profile_bench.sh <tag> [steps] [warmup]     -> gpurun_out/<tag>/{stats,fetch,write,sq1,sq2,sq3,tcc}/...
+# The summary (tools/summarize_profiles.py <tag> <prefix>) is keyed by the steps / warmup of the command, and bench.py
+# only uses a summary whose steps / warmup equal its own.
 set -u
-TAG="${1:-prof}"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-graphslam-base"
+TAG="${1:-prof}"; STEPS="${2:-100}"; WARM="${3:-10}"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-graphslam-base --no-normals"
+echo "$CMD" > "$OUT/command.txt"
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $CMD > "$OUT/stats.json" 2> "$OUT/stats.err"
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o p -- $CMD > "$OUT/fetch.json" 2> "$OUT/fetch.err"
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/write" -o p -- $CMD > "$OUT/write.json" 2> "$OUT/write.err"
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/sq1" -o p -- $CMD > "$OUT/sq1.json" 2> "$OUT/sq1.err"
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq2" -o p -- $CMD > "$OUT/sq2.json" 2> "$OUT/sq2.err"
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d "$OUT/sq3" -o p -- $CMD > "$OUT/sq3.json" 2> "$OUT/sq3.err"
-timeout 300 rocprofv3 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -o p -- $CMD > "$OUT/tcc.json" 2> "$OUT/tcc.err"
+pass() { name="$1"; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- $CMD > "$OUT/$name.json" 2> "$OUT/$name.err" || echo "pass $name failed"; }
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
+pass sq2 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+pass sq3 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES
+pass tcc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
 find "$OUT" -name "*.csv" | sort
