@@ -47,6 +47,8 @@ struct alignas(16) KdHot {
   uint32_t c1, c2;
 };
 static_assert(sizeof(KdHot) == 48, "KdHot must be 48 bytes");
+// (One record per 64-byte line instead -- no record straddling two lines -- was measured again in round 3 with the buckets
+// down to one round trip: 0.1954 .. 0.1991 ms against 0.1970 .. 0.1974, i.e. nothing; gpurun_out/r3f.)
 
 // Two levels per round trip (round 3): the hot part of a node TOGETHER with the hot parts of its two children, 128 bytes,
 // one cache line.  A lane that arrives at node X tests X's box, picks the near child N and -- when N is an internal node
