@@ -1929,14 +1929,30 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   uint32_t* hab = reinterpret_cast<uint32_t*>(tab.data() + o_ab);
   std::vector<uint32_t> s_total(ngroups), a_total(ngroups);
   if (c->counting) { for (int i = 0; i < nlinks; i++) c->counted_queries += second[i]->N; }
+  // Launch order: links that search the SAME tree next to each other (a chain link i -> i+1 and the loop closures out
+  // of scan i), so that the tree one of them has pulled into the L2s / the Infinity Cache is still there for the next;
+  // otherwise the caller's order.  The workgroups of a launch are dispatched in table order, so position p of the table
+  // is what runs p-th; every link still writes its own row of d_out (TDTK_LINK_ORDER=0: the caller's order).
+  std::vector<int> ord(nlinks);
+  for (int i = 0; i < nlinks; i++) ord[i] = i;
+  {
+    static const bool keep = [] { const char* e = getenv("TDTK_LINK_ORDER"); return e && e[0] == '0'; }();
+    if (!keep) {
+      std::map<const tdtk_tree*, int> seen;
+      std::vector<int> key(nlinks);
+      for (int i = 0; i < nlinks; i++) key[i] = seen.emplace(first[i], i).first->second;   // first link that uses this tree
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
+    }
+  }
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G);
     uint32_t sb = 0, ab = 0;
-    for (int i = l0; i < l1; i++) {
-      const tdtk_tree* t = first[i];
-      tdtk_scan* data = second[i];
+    for (int p = l0; p < l1; p++) {
+      const int i = p, li = ord[p];      // i: position in the tables; li: the caller's link
+      const tdtk_tree* t = first[li];
+      tdtk_scan* data = second[li];
       Lane* sl = c->slots[i - l0].get();
-      const double* A16 = first_dalignxf + 16 * (size_t)i;
+      const double* A16 = first_dalignxf + 16 * (size_t)li;
       Mat4 A, inv;
       std::memcpy(A.m, A16, sizeof A.m);
       m4inv(A16, inv.m);
@@ -1955,12 +1971,12 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       aa.T = t->dev;
       aa.x = data->x; aa.y = data->y; aa.z = data->z;
       aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
-      for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * i + k];
+      for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * li + k];
       aa.partials = sl->part.as<double>();
       const uint32_t ag = accum_grid(data->N);
       hab[i + gi] = ab; ab += ag;
       haa[i] = aa;
-      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)i * ACC_TOTAL; hfd[i].rows = (int)ag; hfd[i].pad = 0;
+      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)li * ACC_TOTAL; hfd[i].rows = (int)ag; hfd[i].pad = 0;
     }
     hsb[l1 + gi] = sb; hab[l1 + gi] = ab;
     s_total[gi] = sb; a_total[gi] = ab;

@@ -2838,7 +2838,18 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
       nb = (uint32_t)b;
     }
   }
-  a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0; a.side_by_side = links_in_launch;
+  a.qpw = qpw; a.pool_slab = 0; a.region = 0; a.trace = 0; a.side_by_side = links_in_launch;
+  // A wave's slab in pieces: the waves of an XCD then sweep their eighth of the link's scan together, piece by piece, and
+  // the XCD's L2 has to hold 1/pieces of what it holds otherwise.  Unlike the 1M-vs-1M pair, 64 scans do not fit the
+  // Infinity Cache, so these are real HBM bytes: 84 link passes of 1M queries (round 3, gpurun_out/keep/r03_ph*):
+  // one piece 0.241 GB of fabric traffic per link and 62 % L2 hits, four pieces 0.162 GB and 76 % -- but every piece
+  // ends with a drain, and time goes the other way: 10.86 ms (1 piece), 10.85 (2), 11.01 (4), 11.42 (8).  Two pieces are
+  // free; TDTK_LINK_PHASES overrides (pieces stay multiples of 16 queries).
+  int ph = 2;
+  if (const char* e = getenv("TDTK_LINK_PHASES")) ph = atoi(e);
+  if (ph < 1) ph = 1;
+  while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;
+  a.phases = ph;
   return nb;
 }
 int search_multi_thresh(size_t n) { return refill_thresh(n); }

@@ -25,7 +25,7 @@ knobs = [{}] + [{"TDTK_REFILL_QPW": q, "TDTK_REFILL_PHASES": "1", "TDTK_LINK_LAN
 if len(sys.argv) > 1:
     knobs = [dict(kv.split("=") for kv in a.split(",")) if a != "default" else {} for a in sys.argv[1:]]
 for kn in knobs * 2:
-    for k in ("TDTK_REFILL_QPW", "TDTK_REFILL_THRESH", "TDTK_REFILL_PHASES", "TDTK_SEARCH_VARIANT", "TDTK_LINK_LANES", "TDTK_FUSE_LUM", "TDTK_LINK_BATCH"):
+    for k in ("TDTK_REFILL_QPW", "TDTK_REFILL_THRESH", "TDTK_REFILL_PHASES", "TDTK_SEARCH_VARIANT", "TDTK_LINK_LANES", "TDTK_FUSE_LUM", "TDTK_LINK_BATCH", "TDTK_LINK_PHASES"):
         os.environ.pop(k, None)
     os.environ.update(kn)
     ts = []
