@@ -14,7 +14,7 @@ if [ "$MODE" = "--check" ]; then
   exit 0
 fi
 (cd "$REF" && patch -p1 --force < "$HERE/reference.patch")
-cp "$HERE/hip_search_tree.h" "$HERE/icp6D_hip.h" "$HERE/graphSlam6D_hip.h" "$HERE/graph_slam_glue.h" "$HERE/normals_hip.h" "$REF/include/slam6d/"
+cp "$HERE/hip_search_tree.h" "$HERE/icp6D_hip.h" "$HERE/icp_glue.h" "$HERE/graphSlam6D_hip.h" "$HERE/graph_slam_glue.h" "$HERE/normals_hip.h" "$REF/include/slam6d/"
 cp "$HERE/../include/tdtk_hip.h" "$REF/include/"
 cp "$HERE/hip_search_tree.cc" "$REF/src/slam6d/"
 echo "lib3dtk_hip binding installed into $REF"

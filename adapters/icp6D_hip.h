@@ -1,16 +1,20 @@
-// icp6D_hip -- reference-side binding for the icp6D::match plug point (include/slam6d/icp6D.h:51,
-// `virtual int match(Scan*, Scan*, PairingMode)`).  Construct it wherever slam6D.cc constructs
-// icp6D (src/slam6d/slam6D.cc:737,770,810,825) when -t HipKD is selected.  The whole loop of
-// src/slam6d/icp6D.cc:104-285 then runs device-resident: one upload of the data scan, one tiny
-// D2H per iteration, one download at the end.
+// icp6D_hip -- reference-side binding for the icp6D plug points (include/slam6d/icp6D.h:51,
+// `virtual int match(Scan*, Scan*, PairingMode)`, and `void doICP(vector<Scan*>, PairingMode)`).  Construct it wherever
+// slam6D.cc constructs icp6D (src/slam6d/slam6D.cc:737,770,810,825) when -t HipKD is selected.  The whole loop of
+// src/slam6d/icp6D.cc:104-285 then runs device-resident: the data scan is uploaded once (Scan::hipResident), one tiny
+// D2H per iteration, the moved points are downloaded when the match is over.  doICP keeps every scan resident and
+// prepares the next ones (upload, ordering, tree build) on worker threads while the current pair is matched.
 //
-// NOT compiled in this repository: icp6D.h pulls in scan.h -> Boost, which the build image lacks.
+// The bodies live in slam6d/icp_glue.h, templated on the scan type: that header is compiled, linked and EXECUTED on the
+// GPU box with a minimal scan type (adapters/harness/icp_glue_harness.cc).  This file itself is NOT compiled in this
+// repository: icp6D.h pulls in scan.h -> Boost, which the build image lacks.
 #ifndef __ICP6D_HIP_H__
 #define __ICP6D_HIP_H__
 
 #include "slam6d/icp6D.h"
 #include "slam6d/icp6Dlumeuler.h"
 #include "slam6d/hip_search_tree.h"
+#include "slam6d/icp_glue.h"
 #include "tdtk_hip.h"
 
 // the -a id tdtk_icp_match expects.  getAlgorithmID() is not unique in the reference (icp6D_LUMEULER
@@ -22,54 +26,61 @@ static inline int hip_algo_id(icp6Dminimizer* m)
   return (id >= 1 && id <= 10 && id != 7) ? id : 0;
 }
 
+// the reference's Scan seen through the member names the glue uses
+struct HipIcpScanView {
+  Scan* s;
+  const double* get_transMat() const { return s->get_transMat(); }
+  const double* getDAlign() const { return s->getDAlign(); }
+  tdtk_tree* hipTree() { return static_cast<HipSearchTree*>(s->getSearchTree())->handle(); }
+  tdtk_scan* hipResident() { return s->hipResident(); }
+  void transformMatrixAndFrames(const double* xf, int type, int islum) { s->transformMatrixAndFrames(xf, (Scan::AlgoType)type, islum); }
+  // Scan::transform moves the resident copy too (reference.patch, Scan::transformReduced)
+  void mergeCoordinatesWithRoboterPosition(HipIcpScanView* prev) { s->mergeCoordinatesWithRoboterPosition(prev->s); }
+};
+
 class icp6D_hip : public icp6D {
 public:
   using icp6D::icp6D;
 
+  HipIcpSettings settings(PairingMode pairing_mode)
+  {
+    HipIcpSettings c = {hip_algo_id(my_icp6Dminimizer), (int)pairing_mode, max_num_iterations, max_dist_match2, epsilonICP,
+                        quiet, anim, eP, (int)Scan::ICP};
+    return c;
+  }
+  bool on_device(Scan* model)
+  {
+    // the model tree lives in the scan (Scan::getSearchTree, scan.cc:268); it is a HipSearchTree when the scan was
+    // configured with nns_type HipKD.  rnd > 1 draws std::rand() per candidate: host path only (SURVEY N-d).
+    return dynamic_cast<HipSearchTree*>(model->getSearchTree()) != 0 && rnd <= 1 && hip_algo_id(my_icp6Dminimizer) != 0;
+  }
+
   virtual int match(Scan* PreviousScan, Scan* CurrentScan, PairingMode pairing_mode = CLOSEST_POINT)
   {
-    // the model tree lives in the scan (Scan::getSearchTree, scan.cc:268); it is a HipSearchTree
-    // when the scan was configured with nns_type HipKD
-    HipSearchTree* hst = dynamic_cast<HipSearchTree*>(PreviousScan->getSearchTree());
-    const int algo = hip_algo_id(my_icp6Dminimizer);
-    if (!hst || rnd > 1 || algo == 0)
-      return icp6D::match(PreviousScan, CurrentScan, pairing_mode);     // CPU path of the reference
-
-    double id[16];
-    M4identity(id);
-    CurrentScan->transform(id, Scan::ICP, 0);                           // icp6D.cc:109
-    if (max_num_iterations == 0) return 0;
-
+    if (!on_device(PreviousScan)) return icp6D::match(PreviousScan, CurrentScan, pairing_mode);     // CPU path of the reference
+    HipIcpScanView prev = {PreviousScan}, cur = {CurrentScan};
+    const int it = hip_icp_match(&prev, &cur, settings(pairing_mode), &nr_pointPair);
+    // a caller of match() may look at the points afterwards: hand the moved points back
     DataXYZ xyz(CurrentScan->get("xyz reduced"));
-    DataNormal nrm(pairing_mode != CLOSEST_POINT ? CurrentScan->get("normal reduced") : DataPointer(0, 0));
-    tdtk_scan* data = 0;
-    if (tdtk_scan_create(xyz[0], nrm.size() ? nrm[0] : 0, xyz.size(), 0, &data) != TDTK_OK)
-      throw std::runtime_error(tdtk_last_error());
+    if (xyz.size() && tdtk_scan_download(CurrentScan->hipResident(), xyz[0], 0) != TDTK_OK) throw std::runtime_error(tdtk_last_error());
+    return it;
+  }
 
-    tdtk_icp_params prm = { algo, (int)pairing_mode, max_num_iterations, max_dist_match2, epsilonICP, quiet ? 1 : 0 };
-    tdtk_icp_result res;
-    std::vector<double> trace(18 * (size_t)max_num_iterations);
-    double tm[16], da[16];                     // scratch: the Scan keeps its own matrices (below)
-    memcpy(tm, CurrentScan->get_transMat(), sizeof tm);
-    memcpy(da, CurrentScan->getDAlign(), sizeof da);
-    int rc = tdtk_icp_match(hst->handle(), PreviousScan->getDAlign(), data, tm, da, &prm, &res,
-                            trace.data(), max_num_iterations);
-    if (rc != TDTK_OK) { tdtk_scan_destroy(data); throw std::runtime_error(tdtk_last_error()); }
-
-    // hand the moved points back and replay the matrix / frame bookkeeping exactly as
-    // Scan::transform would have done per iteration (scan.cc:918-1009)
-    tdtk_scan_download(data, xyz[0], nrm.size() ? nrm[0] : 0);
-    tdtk_scan_destroy(data);
-    for (int i = 0; i <= res.iterations && i < max_num_iterations; i++)
-      CurrentScan->transformMatrixAndFrames(&trace[18 * i + 2], Scan::ICP,
-                                            (i == 0 && anim != -2) || (anim > 0 && i % anim == 0) ? 0 : -1);
-    CurrentScan->transform(id, Scan::ICP, anim == -2 ? -1 : 0);          // write end pose
-    nr_pointPair = (unsigned int)res.last_pairs;
-    return res.iterations;
+  // icp6D::doICP is not virtual in the reference; slam6D.cc holds an icp6D*, so reference.patch makes it virtual
+  virtual void doICP(std::vector<Scan*> allScans, PairingMode pairing_mode = CLOSEST_POINT)
+  {
+    if (meta || cad_matching || allScans.empty() || !on_device(allScans[0])) { icp6D::doICP(allScans, pairing_mode); return; }
+    std::vector<HipIcpScanView> views(allScans.size());
+    std::vector<HipIcpScanView*> ptrs(allScans.size());
+    for (size_t i = 0; i < allScans.size(); i++) { views[i].s = allScans[i]; ptrs[i] = &views[i]; }
+    hip_do_icp(ptrs, settings(pairing_mode), /*scans prepared ahead*/ 3, &nr_pointPair,
+               [](size_t i, int) { std::cout << i << "*" << std::endl; });
+    // the host copies of "xyz reduced" once, at the end
+    for (Scan* s : allScans) {
+      DataXYZ xyz(s->get("xyz reduced"));
+      if (xyz.size() && s->hipResidentOrNull() && tdtk_scan_download(s->hipResidentOrNull(), xyz[0], 0) != TDTK_OK)
+        throw std::runtime_error(tdtk_last_error());
+    }
   }
 };
-// Two one-line additions this needs in the reference: `tdtk_tree* handle() const { return tree_; }`
-// in HipSearchTree (present in our copy below when TDTK_EXPOSE_HANDLE is defined) and a public
-// Scan::transformMatrixAndFrames(alignxf, type, islum) = Scan::transform without transformReduced
-// (scan.cc:956-1008), because the points were already moved on the device.
 #endif

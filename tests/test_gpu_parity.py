@@ -1486,6 +1486,20 @@ def test_reference_side_binding_executes(gpu):
     assert r.returncode == 0 and "HARNESS OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_icp_glue_executes(gpu):
+    """adapters/icp_glue.h executed: the body of icp6D_hip::match and the C++ doICP with scans prepared ahead, instantiated
+    with a minimal scan type (adapters/harness/icp_glue_harness.cc) -- equal to the same matches issued one by one
+    through the C ABI (matrices bit for bit), independent of the prefetch depth (poses, frames, resident points), frame
+    bookkeeping of icp6D.cc:246-268, and the no-pairs ending."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "adapters", "harness", "_bin", "icp_glue_harness")
+    if not os.path.exists(exe):
+        r = subprocess.run([os.path.join(os.path.dirname(HERE), "adapters", "harness", "build_glue.sh")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ICP GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
     other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane) walk the same tree the

@@ -378,7 +378,7 @@ def test_reference_patch_applies(tmp_path):
     if not os.path.isdir(os.path.join(ref, "include", "slam6d")):
         pytest.skip("no reference checkout on this box")
     import shutil
-    files = ["include/slam6d/scan.h", "src/slam6d/scan.cc", "src/slam6d/basicScan.cc", "src/slam6d/slam6D.cc",
+    files = ["include/slam6d/scan.h", "include/slam6d/icp6D.h", "src/slam6d/scan.cc", "src/slam6d/basicScan.cc", "src/slam6d/slam6D.cc",
              "src/slam6d/CMakeLists.txt", "CMakeLists.txt"]
     for f in files:
         (tmp_path / f).parent.mkdir(parents=True, exist_ok=True)
@@ -392,9 +392,13 @@ def test_reference_patch_applies(tmp_path):
     assert "BruteForce, HipKD" in scan_h and "transformMatrixAndFrames" in scan_h and "hipResident()" in scan_h
     assert "case HipKD:" in (tmp_path / "src/slam6d/basicScan.cc").read_text()
     assert (tmp_path / "src/slam6d/slam6D.cc").read_text().count("NEW_ICP6D(my_icp6Dminimizer") == 4
-    assert "void Scan::transformMatrixAndFrames" in (tmp_path / "src/slam6d/scan.cc").read_text()
+    scan_cc = (tmp_path / "src/slam6d/scan.cc").read_text()
+    assert "void Scan::transformMatrixAndFrames" in scan_cc
+    assert "tdtk_scan_transform(hip_resident, alignxf)" in scan_cc          # a resident copy moves with Scan::transformReduced
+    assert "virtual void doICP" in (tmp_path / "include/slam6d/icp6D.h").read_text()   # icp6D_hip::doICP (prefetching) is reachable
     assert "WITH_HIP_ICP" in (tmp_path / "CMakeLists.txt").read_text()
-    for f in ("include/slam6d/hip_search_tree.h", "include/slam6d/icp6D_hip.h", "include/tdtk_hip.h", "src/slam6d/hip_search_tree.cc"):
+    for f in ("include/slam6d/hip_search_tree.h", "include/slam6d/icp6D_hip.h", "include/slam6d/icp_glue.h", "include/tdtk_hip.h",
+              "src/slam6d/hip_search_tree.cc"):
         assert (tmp_path / f).exists()
     # the binding compiles in the patched layout against the reference's remaining headers
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DWITH_HIP_ICP", "-I" + str(tmp_path / "include"),
@@ -439,6 +443,20 @@ def test_graph_slam_glue_compiles_and_links(tdtk, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and ("caught:" in out.stdout or "ran" in out.stdout), out.stdout + out.stderr
+
+
+def test_icp_glue_harness_compiles_and_links(tdtk):
+    """adapters/icp_glue.h -- the body of icp6D_hip::match and the prefetching doICP, templated on the scan type --
+    instantiated with a minimal scan type by adapters/harness/icp_glue_harness.cc: compiles and links against
+    lib3dtk_hip.so here; the binary travels to the GPU box, where tests/test_gpu_parity.py::test_icp_glue_executes runs it.
+    Without a GPU it must end in the library's "no HIP device" error turned into the reference's exception type."""
+    r = subprocess.run([os.path.join(ROOT, "adapters", "harness", "build_glue.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = os.path.join(ROOT, "adapters", "harness", "_bin", "icp_glue_harness")
+    assert os.path.exists(exe)
+    if tdtk.device_count() == 0:
+        out = subprocess.run([exe, "3", "2000"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 1 and "no HIP device" in out.stdout, out.stdout + out.stderr
 
 
 def test_link_dealing_round_robin_and_lpt(tdtk):
