@@ -60,7 +60,7 @@ EXPORTS = [
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_point_point_error",
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
-    "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
+    "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_reduce_octree_nrpts", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_comm_rccl_world", "tdtk_graph_exchange", "tdtk_graph_deal_links",
     "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge",
     "tdtk_last_timings", "tdtk_kernel_timing", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
@@ -180,6 +180,7 @@ def lib():
     L.tdtk_point_point_error.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_uint64), _dp]
     L.tdtk_scans_transform2.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, _dp]
     L.tdtk_reduce_octree.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp, C.POINTER(C.c_size_t)]
+    L.tdtk_reduce_octree_nrpts.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, _dp, C.POINTER(C.c_size_t)]
     L.tdtk_normals_apx_knn.argtypes = [_dp, C.c_size_t, C.c_int, _dp, C.c_double, C.c_int, _dp, _ip]
     L.tdtk_scan_calc_normals.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
     L.tdtk_io_read_uos.argtypes = [C.c_char_p, C.c_double, C.c_double, C.POINTER(_dp), C.POINTER(C.c_size_t)]

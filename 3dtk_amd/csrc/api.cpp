@@ -1198,6 +1198,103 @@ int tdtk_reduce_octree(const double* xyz, size_t n, double voxel_size, int devic
   return TDTK_OK;
 }
 
+// Octree reduction with `-O <nrpts>` (Scan::calcReducedPoints, scan.cc:586-596): nrpts == 0 the leaf centres (above),
+// nrpts == 1 one random point per occupied leaf (GetOctTreeRandom, Boctree.h:985-1018), nrpts > 1 up to nrpts random points
+// per leaf (Boctree.h:1020-1062 with rm_scatter == false).  The leaves, their depth-first order and the order of the
+// points inside a leaf are computed on the device (reduce.hip); the draws are std::rand() on the host, leaf by leaf in
+// that order, as the reference makes them -- like `rnd`, reproducible against a serial build of the reference only
+// (SURVEY N-d).  Not offered: nrpts == -1 (GetOctTreeAvg adds into memory it never initialises, Boctree.h:961-964) and
+// rm_scatter (its loop forgets to advance the child pointer for a leaf it skips, Boctree.h:1032-1040).
+int tdtk_reduce_octree_nrpts(const double* xyz, size_t n, double voxel_size, int nrpts, int rm_scatter, int device, double* out_xyz,
+                             size_t* n_out)
+{
+  if (nrpts == 0 && !rm_scatter) return tdtk_reduce_octree(xyz, n, voxel_size, device, out_xyz, n_out);
+  if (!n_out) { set_error("n_out is NULL"); return TDTK_EINVAL; }
+  *n_out = 0;
+  if (nrpts < 0) { set_error("reduction_nrpts == -1 (GetOctTreeAvg) reads uninitialised memory in the reference: not reproducible"); return TDTK_EUNSUP; }
+  if (rm_scatter) { set_error("rm_scatter walks a stale child pointer in the reference (Boctree.h:1032-1040): not reproducible"); return TDTK_EUNSUP; }
+  if (n == 0) return TDTK_OK;
+  if (!xyz || !out_xyz) { set_error("NULL points"); return TDTK_EINVAL; }
+  if (!(voxel_size > 0)) { set_error("voxel size must be > 0"); return TDTK_EINVAL; }
+  if (n >= (1ull << 31)) { set_error("scan too large"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  const size_t sort_tmp = oct_sort_temp_bytes(n), scan_tmp = scan_u32_temp_bytes(n + 1), scan64_tmp = scan_u64_temp_bytes(n + 1);
+  const size_t tmpb = std::max(sort_tmp, std::max(scan_tmp, scan64_tmp));
+  if ((rc = c->ws[WS_TMPA].ensure(6 * n * sizeof(double)))) return rc;           // points in | points out
+  if ((rc = c->ws[WS_QX].ensure(2 * n * sizeof(uint64_t)))) return rc;           // keys by point | sorted
+  if ((rc = c->ws[WS_CELL].ensure(3 * (n + 1) * sizeof(uint32_t)))) return rc;   // leaf flags | slots | starts
+  if ((rc = c->ws[WS_TMPB].ensure(tmpb + 256))) return rc;
+  if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
+  if ((rc = c->ws[WS_QY].ensure(7 * n * sizeof(uint32_t)))) return rc;           // perm | segS segE mid posL posR | sel
+  if ((rc = c->ws[WS_QZ].ensure(2 * (n + 1) * sizeof(uint64_t)))) return rc;     // flags | their scan
+  double* d_in = c->ws[WS_TMPA].as<double>();
+  double* d_out = d_in + 3 * n;
+  double* d_box = c->ws[WS_BOX].as<double>();
+  uint64_t* keys_a = c->ws[WS_QX].as<uint64_t>();
+  uint64_t* keys_b = keys_a + n;
+  uint32_t* flags = c->ws[WS_CELL].as<uint32_t>();
+  uint32_t* slot = flags + (n + 1);
+  uint32_t* starts = slot + (n + 1);
+  uint32_t* perm = c->ws[WS_QY].as<uint32_t>();
+  uint32_t* work = perm + n;
+  uint32_t* d_sel = perm + 6 * n;
+  uint64_t* f64 = c->ws[WS_QZ].as<uint64_t>();
+  uint64_t* P64 = f64 + (n + 1);
+  HIPCHK(hipMemcpyAsync(d_in, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(launch_bbox(d_in, n, d_box + 8, d_box, s));
+  HIPCHK(hipMemcpyAsync(c->h_pin, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const double* b = c->h_pin;
+  OctRoot R;                          // root cube, Boctree.h:248-255
+  for (int a = 0; a < 3; a++) R.center[a] = 0.5 * (b[a] + b[3 + a]);
+  R.size = std::max(std::max(0.5 * (b[3] - b[0]), 0.5 * (b[4] - b[1])), 0.5 * (b[5] - b[2]));
+  R.size += 1.0;
+  if (!std::isfinite(R.size)) { set_error("non-finite coordinates"); return TDTK_EINVAL; }
+  R.depth = 1;
+  for (double sz = R.size / 2.0; sz > voxel_size; sz /= 2.0) R.depth++;
+  if (3 * R.depth > 63) { set_error("voxel size too small for this extent (more than 21 octree levels)"); return TDTK_EINVAL; }
+  HIPCHK(launch_oct_keys_sorted(d_in, n, R, keys_a, keys_b, c->ws[WS_TMPB].p, sort_tmp, s));
+  HIPCHK(launch_oct_heads(keys_b, n, flags, s));
+  HIPCHK(launch_scan_u32(flags, slot, n + 1, c->ws[WS_TMPB].p, scan_tmp, s));
+  HIPCHK(launch_oct_leaf_starts(flags, slot, n, starts, s));
+  HIPCHK(launch_oct_leaf_order(keys_a, keys_b, n, R.depth, perm, work, f64, P64, c->ws[WS_TMPB].p, scan64_tmp, s));
+  uint32_t cells = 0;
+  HIPCHK(hipMemcpyAsync(&cells, slot + n, sizeof cells, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<uint32_t> st((size_t)cells + 1);
+  HIPCHK(hipMemcpy(st.data(), starts, st.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  // the draws, leaf by leaf in depth-first order (globals.icc:607-610: rand(rnd) = (int)(rnd * std::rand() / (RAND_MAX + 1.0)))
+  auto draw = [](int rnd) { return (int)((double)rnd * (double)std::rand() / (RAND_MAX + 1.0)); };
+  std::vector<uint32_t> sel;
+  sel.reserve(nrpts == 1 ? cells : n);
+  std::vector<int> pick;
+  for (uint32_t l = 0; l < cells; l++) {
+    const uint32_t start = st[l], len = st[l + 1] - st[l];
+    if (nrpts == 1) { sel.push_back(start + (uint32_t)draw((int)len)); continue; }
+    if ((uint32_t)nrpts >= len) { for (uint32_t j = 0; j < len; j++) sel.push_back(start + j); continue; }
+    pick.clear();
+    while ((int)pick.size() < nrpts) {           // std::set<int>::insert of rand(length - 1)
+      const int t = draw((int)len - 1);
+      if (std::find(pick.begin(), pick.end(), t) == pick.end()) pick.push_back(t);
+    }
+    std::sort(pick.begin(), pick.end());
+    for (int t : pick) sel.push_back(start + (uint32_t)t);
+  }
+  const size_t m = sel.size();
+  if (m > n) { set_error("internal: more points kept than given"); return TDTK_EDEVICE; }
+  if (m) {
+    HIPCHK(hipMemcpyAsync(d_sel, sel.data(), m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_oct_gather(d_in, perm, d_sel, m, d_out, s));
+    HIPCHK(hipMemcpyAsync(out_xyz, d_out, 3 * m * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  *n_out = m;
+  return TDTK_OK;
+}
+
 // ---- normals (Scan::calcNormals -> calculateNormalsApxKNN, scan.cc:398-427, normals.cc:35-111) ----------------
 // d_xyz: [n][3] in the caller's order (the ANN tree starts from the identity permutation, kd_tree.cpp:259-262);
 // d_normals [n][3] and d_knn (nullable, [n][k]) come back in the caller's order.

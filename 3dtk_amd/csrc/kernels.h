@@ -224,6 +224,12 @@ size_t oct_sort_temp_bytes(size_t n);
 hipError_t launch_oct_keys_sorted(const double* d_xyz, size_t n, const OctRoot& R, uint64_t* keys_a,
                                   uint64_t* keys_b, void* tmp, size_t tmp_bytes, hipStream_t s);
 hipError_t launch_oct_heads(const uint64_t* keys, size_t n, uint32_t* flags, hipStream_t s);
+// random modes of the octree reduction: the reference's within-leaf point order (reduce.hip)
+size_t scan_u64_temp_bytes(size_t n);
+hipError_t launch_oct_leaf_order(const uint64_t* keys, const uint64_t* sorted, size_t n, int depth, uint32_t* perm, uint32_t* work,
+                                 uint64_t* flags, uint64_t* P, void* tmp, size_t tmp_bytes, hipStream_t s);
+hipError_t launch_oct_leaf_starts(const uint32_t* flags, const uint32_t* slot, size_t n, uint32_t* starts, hipStream_t s);
+hipError_t launch_oct_gather(const double* xyz, const uint32_t* perm, const uint32_t* sel, size_t m, double* out, hipStream_t s);
 hipError_t launch_oct_centres(const uint64_t* keys, const uint32_t* flags, const uint32_t* slot, size_t n,
                               const OctRoot& R, double* out, hipStream_t s);
 hipError_t launch_unsort_aos(const double* x, const double* y, const double* z, const int32_t* order, size_t n,

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "kernels.h"
 
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(256) void k_oct_keys(const double* __restrict__ xyz
     double cx = R.center[0], cy = R.center[1], cz = R.center[2], size = R.size;
     uint64_t key = 0;
     for (int d = 0; d < R.depth; d++) {
-      const bool bx = px > cx, by = py > cy, bz = pz > cz;      // Boctree.h:1353-1355
+      // the array constructor Scan::calcReducedPoints uses cuts with `p < centre` | `p >= centre` (fullsort / sort,
+      // Boctree.h:1737-1816), not with childIndex's strict `>`: a point exactly on a centre plane goes up
+      const bool bx = !(px < cx), by = !(py < cy), bz = !(pz < cz);
       key = (key << 3) | (uint64_t)((int)bx | ((int)by << 1) | ((int)bz << 2));
       const double h = size / 2.0;                               // childcenter, Boctree.h:612-657
       cx = bx ? cx + h : cx - h;
@@ -149,6 +152,95 @@ __global__ __launch_bounds__(256) void k_oct_centres(const uint64_t* __restrict_
   }
 }
 
+// ---- the order the reference's in-place partitions leave the points in (random modes, `-O <nrpts>`) -----------------
+// BOctTree's array constructor cuts a cell with three two-pointer partitions (z, then y inside each z half, then x inside
+// each quarter; Boctree.h:1737-1816), level after level, and a leaf keeps its points in the order these leave behind --
+// which is what GetOctTreeRandom indexes with rand().  A two-pointer partition is order-equivalent to "what already
+// lies on its side stays, the k-th misplaced element from the left swaps with the k-th misplaced from the right END";
+// where the cut falls is known in advance (the number of keys with a 0 at this bit inside the segment = a lower bound in
+// the SORTED key array).  So one pass per key bit, all segments of the scan at once: flag the misplaced on either side,
+// one 64-bit scan numbers both kinds, pair by number, swap.  3 x depth passes of three small kernels and a scan.
+__global__ __launch_bounds__(256) void k_oct_pass_flags(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ perm, const uint32_t* __restrict__ segS,
+                                                        const uint32_t* __restrict__ segE, uint32_t* __restrict__ mid,
+                                                        uint64_t* __restrict__ flags, size_t n, int b)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pos <= n; pos += stride) {
+    if (pos == n) { flags[n] = 0; continue; }
+    const uint64_t key = keys[perm[pos]];
+    const uint64_t target = (((key >> (b + 1)) << 1) | 1ull) << b;      // first key of this segment with a 1 at bit b
+    uint32_t lo = segS[pos], hi = segE[pos];
+    while (lo < hi) {                                                   // lower bound inside the segment
+      const uint32_t m = lo + ((hi - lo) >> 1);
+      if (sorted[m] < target) lo = m + 1; else hi = m;
+    }
+    mid[pos] = lo;
+    const bool up = (key >> b) & 1ull;
+    const uint64_t ml = (pos < lo && up) ? 1ull : 0ull;                 // belongs right, lies in the left part
+    const uint64_t mr = (pos >= lo && !up) ? 1ull : 0ull;               // belongs left, lies in the right part
+    flags[pos] = ml | (mr << 32);
+  }
+}
+__global__ __launch_bounds__(256) void k_oct_pass_lists(const uint64_t* __restrict__ flags, const uint64_t* __restrict__ P,
+                                                        uint32_t* __restrict__ segS, uint32_t* __restrict__ segE,
+                                                        const uint32_t* __restrict__ mid, uint32_t* __restrict__ posL,
+                                                        uint32_t* __restrict__ posR, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += stride) {
+    const uint64_t f = flags[pos];
+    const uint32_t s = segS[pos], e = segE[pos], m = mid[pos];
+    if (f & 1ull) posL[(uint32_t)P[pos]] = (uint32_t)pos;                           // k-th misplaced from the left, k counted globally
+    if (f >> 32) {
+      const uint32_t from_right = (uint32_t)(P[e] >> 32) - (uint32_t)(P[pos + 1] >> 32);   // misplaced-right elements behind this one
+      posR[(uint32_t)P[s] + from_right] = (uint32_t)pos;                          // its partner: the same number among the segment's left ones
+    }
+    if (pos < m) segE[pos] = m; else segS[pos] = m;                               // the two halves are the next pass's segments
+  }
+}
+__global__ __launch_bounds__(256) void k_oct_pass_swap(uint32_t* __restrict__ perm, const uint32_t* __restrict__ posL,
+                                                       const uint32_t* __restrict__ posR, const uint64_t* __restrict__ P, size_t n)
+{
+  const uint32_t total = (uint32_t)P[n];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+    const uint32_t a = posL[k], c = posR[k];
+    const uint32_t t = perm[a]; perm[a] = perm[c]; perm[c] = t;
+  }
+}
+__global__ __launch_bounds__(256) void k_oct_iota(uint32_t* __restrict__ perm, uint32_t* __restrict__ segS, uint32_t* __restrict__ segE, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { perm[i] = (uint32_t)i; segS[i] = 0u; segE[i] = (uint32_t)n; }
+}
+__global__ __launch_bounds__(256) void k_oct_leaf_starts(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ slot, size_t n,
+                                                         uint32_t* __restrict__ starts)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+    if (i == n) starts[slot[n]] = (uint32_t)n;
+    else if (flags[i]) starts[slot[i]] = (uint32_t)i;
+  }
+}
+__global__ __launch_bounds__(256) void k_oct_gather(const double* __restrict__ xyz, const uint32_t* __restrict__ perm,
+                                                    const uint32_t* __restrict__ sel, size_t m, double* __restrict__ out)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+    const size_t src = perm[sel[j]];
+    out[3 * j] = xyz[3 * src]; out[3 * j + 1] = xyz[3 * src + 1]; out[3 * j + 2] = xyz[3 * src + 2];
+  }
+}
+
+size_t scan_u64_temp_bytes(size_t n)
+{
+  size_t tmp = 0;
+  uint64_t* p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, tmp, p, p, (uint64_t)0, n, rocprim::plus<uint64_t>(), (hipStream_t)0);
+  return tmp;
+}
+
 size_t oct_sort_temp_bytes(size_t n)
 {
   size_t tmp = 0;
@@ -182,6 +274,34 @@ hipError_t launch_oct_centres(const uint64_t* keys, const uint32_t* flags, const
                               const OctRoot& R, double* out, hipStream_t s)
 {
   hipLaunchKernelGGL(k_oct_centres, dim3(grid_for(n)), dim3(256), 0, s, keys, flags, slot, n, R, out);
+  return hipGetLastError();
+}
+
+// perm[pos] = caller index of the point at position pos of the reference's leaf order.  keys: per point (caller order);
+// sorted: the same keys sorted; work: 6 n x u32 (perm is separate), flags / P: (n + 1) x u64 each.
+hipError_t launch_oct_leaf_order(const uint64_t* keys, const uint64_t* sorted, size_t n, int depth, uint32_t* perm, uint32_t* work,
+                                 uint64_t* flags, uint64_t* P, void* tmp, size_t tmp_bytes, hipStream_t s)
+{
+  uint32_t *segS = work, *segE = work + n, *mid = work + 2 * n, *posL = work + 3 * n, *posR = work + 4 * n;
+  hipLaunchKernelGGL(k_oct_iota, dim3(grid_for(n)), dim3(256), 0, s, perm, segS, segE, n);
+  for (int b = 3 * depth - 1; b >= 0; b--) {
+    hipLaunchKernelGGL(k_oct_pass_flags, dim3(grid_for(n + 1)), dim3(256), 0, s, keys, sorted, perm, segS, segE, mid, flags, n, b);
+    hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, flags, P, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_oct_pass_lists, dim3(grid_for(n)), dim3(256), 0, s, flags, P, segS, segE, mid, posL, posR, n);
+    hipLaunchKernelGGL(k_oct_pass_swap, dim3(grid_for(n)), dim3(256), 0, s, perm, posL, posR, P, n);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_oct_leaf_starts(const uint32_t* flags, const uint32_t* slot, size_t n, uint32_t* starts, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_oct_leaf_starts, dim3(grid_for(n + 1)), dim3(256), 0, s, flags, slot, n, starts);
+  return hipGetLastError();
+}
+hipError_t launch_oct_gather(const double* xyz, const uint32_t* perm, const uint32_t* sel, size_t m, double* out, hipStream_t s)
+{
+  if (!m) return hipSuccess;
+  hipLaunchKernelGGL(k_oct_gather, dim3(grid_for(m)), dim3(256), 0, s, xyz, perm, sel, m, out);
   return hipGetLastError();
 }
 

@@ -577,15 +577,23 @@ def read_uos(path, range_max=0.0, range_min=0.0):
     return out
 
 
-def calcReducedPoints(xyz, voxelSize, device=0):
-    """Scan::calcReducedPoints, centre mode (scan.cc:577-603): octree reduction `-r voxelSize` on the
-    device (tdtk_reduce_octree).  voxelSize <= 0 keeps every point, as scan.cc:497-558 does."""
+def calcReducedPoints(xyz, voxelSize, device=0, nrpts=0, rm_scatter=False, seed=None):
+    """Scan::calcReducedPoints (scan.cc:560-603): octree reduction `-r voxelSize [-O nrpts]` on the device.  nrpts == 0:
+    the centres of the occupied leaves (tdtk_reduce_octree); nrpts == 1 / N > 1: one / up to N random points per leaf
+    (BOctTree::GetOctTreeRandom; the draws are the C library's rand() in the reference's order -- `seed` calls srand
+    first).  voxelSize <= 0 keeps every point, as scan.cc:497-558 does."""
     xyz = f64(xyz).reshape(-1, 3)
     if voxelSize <= 0 or len(xyz) == 0:
         return xyz.copy()
     out = np.empty_like(xyz)
     m = C.c_size_t(0)
-    check(lib().tdtk_reduce_octree(dptr(xyz), len(xyz), float(voxelSize), int(device), dptr(out), C.byref(m)))
+    if nrpts == 0 and not rm_scatter:
+        check(lib().tdtk_reduce_octree(dptr(xyz), len(xyz), float(voxelSize), int(device), dptr(out), C.byref(m)))
+    else:
+        if seed is not None:
+            C.CDLL(None).srand(int(seed))
+        check(lib().tdtk_reduce_octree_nrpts(dptr(xyz), len(xyz), float(voxelSize), int(nrpts), int(bool(rm_scatter)), int(device),
+                                             dptr(out), C.byref(m)))
     return out[:m.value].copy()
 
 

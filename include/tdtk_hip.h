@@ -348,6 +348,15 @@ int tdtk_invert(const double* A, int n, double* Ainv);
  * depth-first child order (that order feeds the kd-tree build, so it matters).               */
 int tdtk_reduce_octree(const double* xyz, size_t n, double voxel_size, int device, double* out_xyz,
                        size_t* n_out);
+/* The same with `-O <nrpts>` (reduction_nrpts, scan.cc:586-596): 0 = the centres above; 1 = one random point per occupied
+ * leaf (BOctTree::GetOctTreeRandom, Boctree.h:985-1018); N > 1 = up to N random points per leaf (Boctree.h:1020-1062 with
+ * rm_scatter == false).  Leaves, their order and the order of the points inside a leaf (the reference's in-place
+ * partitions, Boctree.h:1737-1816) come from the device; the draws are std::rand() on the host, leaf by leaf, as the
+ * reference makes them (seed with std::srand; reproducible against a serial reference build).  TDTK_EUNSUP for
+ * nrpts == -1 (GetOctTreeAvg sums into uninitialised memory, Boctree.h:961-964) and for rm_scatter != 0 (the reference's
+ * loop walks a stale child pointer there, Boctree.h:1032-1040).  out_xyz has room for n points.                       */
+int tdtk_reduce_octree_nrpts(const double* xyz, size_t n, double voxel_size, int nrpts, int rm_scatter, int device,
+                             double* out_xyz, size_t* n_out);
 
 /* ---- point normals, "-z" / "-a 10" / pairing modes 1 and 2: replaces Scan::calcNormals
  * (src/slam6d/scan.cc:398-427) = calculateNormalsApxKNN(normals, points, k, rPos, eps)

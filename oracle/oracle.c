@@ -504,7 +504,10 @@ uint64_t orc_k5_hash(const int32_t *idx, size_t n)
  *       half size = largest half extent + 1.0; the root is always split)
  *   countPointsAndQueueFast / branch              Boctree.h:1163-1195, 1268-1300 (occupied octants in
  *       index order; a child is a leaf once its half size <= voxelSize)
- *   childIndex                                    Boctree.h:1353-1355 (strict >)
+ *   fullsort / sort                               Boctree.h:1737-1816: Scan::calcReducedPoints hands the constructor a
+ *       double**, i.e. the ARRAY overload, whose octants are cut with `p < centre` (left) / `p >= centre` (right); a point
+ *       exactly on a centre plane therefore goes UP (childIndex, :1353-1355, strict >, is what the vector overload and
+ *       the searches use -- round 3 corrected this restatement, which had followed childIndex)
  *   childcenter                                   Boctree.h:612-657  (centre -/+ size/2.0)
  *   GetOctTreeCenter                              Boctree.h:928-948  (DFS, child index order, emits the
  *       leaf cell's centre)
@@ -532,7 +535,7 @@ static void oct_split(oct_ctx *C, uint32_t *idx, size_t n, const double *c, doub
   unsigned char *ci = (unsigned char *)malloc(n ? n : 1);
   for (size_t k = 0; k < n; k++) {
     const double *p = C->xyz + 3 * (size_t)idx[k];
-    ci[k] = (unsigned char)((p[0] > c[0]) | ((p[1] > c[1]) << 1) | ((p[2] > c[2]) << 2));
+    ci[k] = (unsigned char)((!(p[0] < c[0])) | ((!(p[1] < c[1])) << 1) | ((!(p[2] < c[2])) << 2));   /* sort(): `< splitval` stays left */
     cnt[ci[k]]++;
   }
   off[0] = 0;
@@ -580,6 +583,130 @@ size_t orc_octree_center(const double *xyz, size_t n, double voxel, double *out)
   for (size_t k = 0; k < n; k++) idx[k] = (uint32_t)k;
   oct_ctx C = {xyz, voxel, out, 0};
   oct_split(&C, idx, n, center, size);
+  free(idx);
+  return C.n_out;
+}
+
+/* ---- octree reduction, random modes ("-r <voxelSize> -O <nrpts>", nrpts >= 1) ------------------------------------
+ * PARITY UNPINNED (Boctree.h cannot be compiled here, see above).  Restatement by reading, structured like the
+ * reference: an array of point pointers (here: indices) partitioned IN PLACE,
+ *   fullsort                Boctree.h:1737-1780: z, then y inside each z half, then x inside each quarter
+ *   sort                    Boctree.h:1784-1816: the two-pointer partition as written (`< splitval` | `>= splitval`)
+ *   countPointsAndQueueFast Boctree.h:1268-1300, branch :1163-1195: a leaf copies its points in the order the
+ *                           partitions left them
+ *   GetOctTreeRandom        Boctree.h:985-1018 (nrpts == 1): per leaf in child-index order one point,
+ *                           index rand(length) = (int)(length * std::rand() / (RAND_MAX + 1.0))  (globals.icc:607-610)
+ *   GetOctTreeRandom        Boctree.h:1020-1062 (nrpts > 1, rm_scatter == false): all points of a leaf with at most
+ *                           nrpts points; otherwise a std::set of nrpts distinct rand(length - 1) draws, in ascending order
+ * as used by Scan::calcReducedPoints, src/slam6d/scan.cc:586-596.  rand() is the C library's: callers seed it. */
+typedef struct {
+  const double *xyz;
+  double voxel;
+  int nrpts;
+  double *out;
+  size_t n_out;
+} octr_ctx;
+
+static uint32_t *octr_sort(const double *xyz, uint32_t *points, uint32_t n, double splitval, int index)
+{
+  if (n == 0) return points;
+  if (n == 1) return (xyz[3 * (size_t)points[0] + index] < splitval) ? points + 1 : points;
+  uint32_t *left = points, *right = points + n - 1;
+  for (;;) {
+    while (xyz[3 * (size_t)*left + index] < splitval) { left++; if (right < left) break; }
+    while (xyz[3 * (size_t)*right + index] >= splitval) { right--; if (right < left) break; }
+    if (right < left) break;
+    const uint32_t t = *left; *left = *right; *right = t;
+  }
+  return left;
+}
+
+static int octr_rand(int rnd) { return (int)((double)rnd * (double)rand() / (RAND_MAX + 1.0)); }
+
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+static void octr_leaf(octr_ctx *C, const uint32_t *pts, uint32_t n)
+{
+  if (C->nrpts == 1) {
+    const uint32_t k = pts[octr_rand((int)n)];
+    memcpy(C->out + 3 * C->n_out++, C->xyz + 3 * (size_t)k, 3 * sizeof(double));
+    return;
+  }
+  if ((uint32_t)C->nrpts >= n) {
+    for (uint32_t j = 0; j < n; j++) memcpy(C->out + 3 * C->n_out++, C->xyz + 3 * (size_t)pts[j], 3 * sizeof(double));
+    return;
+  }
+  int *idx = (int *)malloc(sizeof(int) * (size_t)C->nrpts);
+  int have = 0;
+  while (have < C->nrpts) {                       /* std::set<int>::insert */
+    const int t = octr_rand((int)n - 1);
+    int dup = 0;
+    for (int k = 0; k < have; k++) dup |= idx[k] == t;
+    if (!dup) idx[have++] = t;
+  }
+  qsort(idx, (size_t)have, sizeof(int), cmp_int);  /* iteration order of the set */
+  for (int k = 0; k < have; k++) memcpy(C->out + 3 * C->n_out++, C->xyz + 3 * (size_t)pts[idx[k]], 3 * sizeof(double));
+  free(idx);
+}
+
+static void octr_split(octr_ctx *C, uint32_t *points, uint32_t n, const double *c, double size)
+{
+  uint32_t *blocks[9];
+  blocks[0] = points; blocks[8] = points + n;
+  {   /* fullsort */
+    uint32_t *L0 = octr_sort(C->xyz, points, n, c[2], 2);
+    const uint32_t n0L = (uint32_t)(L0 - points);
+    uint32_t *L1 = octr_sort(C->xyz, points, n0L, c[1], 1);
+    uint32_t n1L = (uint32_t)(L1 - points);
+    uint32_t *L2 = octr_sort(C->xyz, points, n1L, c[0], 0);
+    blocks[1] = L2;
+    uint32_t n1R = n0L - n1L;
+    L2 = octr_sort(C->xyz, L1, n1R, c[0], 0);
+    blocks[2] = L1; blocks[3] = L2;
+    const uint32_t n0R = n - n0L;
+    L1 = octr_sort(C->xyz, L0, n0R, c[1], 1);
+    n1L = (uint32_t)(L1 - L0);
+    L2 = octr_sort(C->xyz, L0, n1L, c[0], 0);
+    blocks[4] = L0; blocks[5] = L2;
+    n1R = n0R - n1L;
+    L2 = octr_sort(C->xyz, L1, n1R, c[0], 0);
+    blocks[6] = L1; blocks[7] = L2;
+  }
+  const double size_new = size / 2.0;
+  for (int j = 0; j < 8; j++) {
+    const uint32_t cnt = (uint32_t)(blocks[j + 1] - blocks[j]);
+    if (!cnt) continue;
+    double cc[3];
+    oct_childcenter(c, cc, size, j);
+    if (size_new <= C->voxel) octr_leaf(C, blocks[j], cnt);
+    else octr_split(C, blocks[j], cnt, cc, size_new);
+  }
+}
+
+/* out has room for n points; returns the number of points kept.  perm_out (nullable, [n]) receives the order the
+ * partitions leave the points in (leaf by leaf in child-index order): what the device path must reproduce. */
+size_t orc_octree_random(const double *xyz, size_t n, double voxel, int nrpts, double *out, uint32_t *perm_out)
+{
+  if (n == 0 || nrpts < 1) return 0;
+  double mins[3], maxs[3], center[3];
+  for (int a = 0; a < 3; a++) {
+    mins[a] = maxs[a] = xyz[a];
+    for (size_t j = 1; j < n; j++) {
+      const double v = xyz[3 * j + a];
+      mins[a] = v < mins[a] ? v : mins[a];
+      maxs[a] = maxs[a] < v ? v : maxs[a];
+    }
+    center[a] = 0.5 * (mins[a] + maxs[a]);
+  }
+  double size = 0.5 * (maxs[0] - mins[0]);
+  if (size < 0.5 * (maxs[1] - mins[1])) size = 0.5 * (maxs[1] - mins[1]);
+  if (size < 0.5 * (maxs[2] - mins[2])) size = 0.5 * (maxs[2] - mins[2]);
+  size += 1.0;
+  uint32_t *idx = (uint32_t *)malloc(n * sizeof(uint32_t));
+  for (size_t k = 0; k < n; k++) idx[k] = (uint32_t)k;
+  octr_ctx C = {xyz, voxel, nrpts, out, 0};
+  octr_split(&C, idx, (uint32_t)n, center, size);
+  if (perm_out) memcpy(perm_out, idx, n * sizeof(uint32_t));
   free(idx);
   return C.n_out;
 }

@@ -68,6 +68,8 @@ def lib():
         L.orc_gen_mt64_uniform.argtypes = [C.c_uint64, C.c_size_t, C.c_double, C.c_double, _dp]
         L.orc_octree_center.restype = C.c_size_t
         L.orc_octree_center.argtypes = [_dp, C.c_size_t, C.c_double, _dp]
+        L.orc_octree_random.restype = C.c_size_t
+        L.orc_octree_random.argtypes = [_dp, C.c_size_t, C.c_double, C.c_int, _dp, C.POINTER(C.c_uint32)]
         L.orc_k5_hash.restype = C.c_uint64
         L.orc_k5_hash.argtypes = [_ip, C.c_size_t]
         L.orc_packet_find_closest.restype = C.c_int
@@ -336,6 +338,18 @@ def octree_center(xyz, voxel):
     out = np.empty_like(xyz)
     m = lib().orc_octree_center(_d(xyz), len(xyz), float(voxel), _d(out))
     return out[:m].copy()
+
+
+def octree_random(xyz, voxel, nrpts, seed=None, want_perm=False):
+    """Octree reduction with `-O nrpts` (nrpts >= 1; parity unpinned, see oracle.c): the kept points in DFS order.
+    seed: srand(seed) of the C library first (the reference draws std::rand())."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    perm = np.empty(len(xyz), np.uint32)
+    if seed is not None:
+        C.CDLL(None).srand(int(seed))
+    m = lib().orc_octree_random(_d(xyz), len(xyz), float(voxel), int(nrpts), _d(out), perm.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return (out[:m].copy(), perm) if want_perm else out[:m].copy()
 
 
 # ---- normals: ANN kd-tree, approximate k-NN, PCA (oracle_normals.c / ref_ann_driver.cc) -------------

@@ -759,6 +759,39 @@ def test_octree_reduction_equals_oracle(tdtk, orc, gpu, name, voxel):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("name", ["uniform", "duplicates", "clusters", "plane", "tiny", "grid", "line"])
+@pytest.mark.parametrize("voxel", [0.5, 10.0, 1e6])
+@pytest.mark.parametrize("nrpts", [1, 3])
+def test_octree_reduction_random_modes_equal_oracle(tdtk, orc, gpu, name, voxel, nrpts):
+    """`-r <voxel> -O <nrpts>` (Scan::calcReducedPoints with reduction_nrpts >= 1, BOctTree::GetOctTreeRandom): the
+    leaves, their depth-first order and the order of the points INSIDE a leaf (which rand() indexes: the reference's
+    in-place z / y / x partitions level after level) come from the device; with the C library's rand() seeded alike the
+    kept points equal the recursive restatement's, bit for bit and in order."""
+    pts = _clouds()[name]
+    got = tdtk.calcReducedPoints(pts, voxel, nrpts=nrpts, seed=1234 + nrpts)
+    want = orc.octree_random(pts, voxel, nrpts, seed=1234 + nrpts)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_octree_reduction_random_modes_full_size_and_refusals(tdtk, orc, gpu, k5):
+    """1M points: one random point per leaf == the oracle; one point per centre-mode cell, each inside its cell; the two
+    modes the reference cannot run reproducibly are refused (TDTK_EUNSUP), not approximated."""
+    _, m, _ = k5
+    got = tdtk.calcReducedPoints(m, 25.0, nrpts=1, seed=7)
+    want = orc.octree_random(m, 25.0, 1, seed=7)
+    assert np.array_equal(got, want)
+    centres = tdtk.calcReducedPoints(m, 25.0)
+    assert len(got) == len(centres)
+    size = (0.5 * (m.max(0) - m.min(0))).max() + 1.0
+    while size > 25.0:
+        size /= 2.0
+    assert np.all(np.abs(got - centres).max(1) <= size)          # same leaf, in the same depth-first position
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calcReducedPoints(m[:1000], 25.0, nrpts=-1)
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.calcReducedPoints(m[:1000], 25.0, nrpts=2, rm_scatter=True)
+
+
 def test_octree_reduction_dat_and_icp(tdtk, orc, gpu):
     """-r 10 on the bundled scans, then the pairwise ICP of scan001 onto scan000 on the reduced clouds
     against the numpy restatement run on the oracle's reduced clouds."""

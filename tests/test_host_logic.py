@@ -594,13 +594,62 @@ def test_scan_io_uos_pose_frames(tdtk, tmp_path):
     assert lines[2].endswith(" 0") and lines[3] == ""
 
 
+def test_oracle_octree_random_modes_against_cell_membership(orc):
+    """The restatement of the random octree modes (oracle.c, parity unpinned) checked against what does not depend on how
+    the partitions are written: the order the partitions leave behind groups the points by leaf in the depth-first order
+    of the centre mode, every leaf contributes exactly one point (nrpts = 1) resp. min(nrpts, length) points (the
+    reference draws rand(length - 1) there, so a leaf's LAST point is only ever kept when the whole leaf is), and each
+    kept point lies inside the cell whose centre sits at the same depth-first position."""
+    rng = np.random.default_rng(3)
+    clouds = [rng.uniform(-100, 100, (30000, 3)), np.round(rng.uniform(-50, 50, (20000, 3)), 1),
+              np.stack(np.meshgrid(*[np.arange(16.0)] * 3), -1).reshape(-1, 3)]
+    for pts in clouds:
+        for voxel in (1.0, 7.5):
+            centres = orc.octree_center(pts, voxel)
+            size = (0.5 * (pts.max(0) - pts.min(0))).max() + 1.0
+            while size > voxel:
+                size /= 2.0
+            one, perm = orc.octree_random(pts, voxel, 1, seed=11, want_perm=True)
+            assert sorted(perm.tolist()) == list(range(len(pts)))
+            assert len(one) == len(centres) and np.all(np.abs(one - centres).max(1) <= size)
+            # leaf of every position of the leaf order: nearest centre in max-norm (cells are disjoint cubes)
+            ordered = pts[perm]
+            leaf = np.empty(len(pts), np.int64)
+            pos = 0
+            for k, c in enumerate(centres):
+                n_in = 0
+                while pos + n_in < len(pts) and np.all(np.abs(ordered[pos + n_in] - c) <= size):
+                    n_in += 1
+                assert n_in > 0
+                leaf[pos:pos + n_in] = k
+                pos += n_in
+            assert pos == len(pts)
+            lens = np.bincount(leaf, minlength=len(centres))
+            three = orc.octree_random(pts, voxel, 3, seed=12)
+            assert len(three) == int(np.minimum(lens, 3).sum())
+            # which positions were kept: a leaf longer than 3 never keeps its last point
+            keep_pos = 0
+            for k in range(len(centres)):
+                start = int(lens[:k].sum())
+                kept = three[keep_pos:keep_pos + min(3, lens[k])]
+                keep_pos += min(3, lens[k])
+                block = ordered[start:start + lens[k]]
+                for q in kept:
+                    hits = np.flatnonzero((block == q).all(1))
+                    assert len(hits) > 0
+                if lens[k] > 3 and not (block[:-1] == block[-1]).all(1).any():
+                    assert not (kept == block[-1]).all(1).any()
+
+
 def test_oracle_octree_center_against_grid_formulation(orc):
     """The recursive octree restatement (oracle.c, parity unpinned: Boctree.h is not buildable here)
     checked against an independent closed-form formulation: occupied cells of the regular 2^D grid over
     the root cube, ordered by their (x lowest) Morton code = depth-first child order."""
     rng = np.random.default_rng(11)
-    one = np.array([[4.0, -2.0, 8.0]])   # a point on the split planes goes to the lower child (strict >)
-    assert np.array_equal(orc.octree_center(one, 5.0), one - 0.5)
+    # a point ON the split planes goes to the UPPER child: Scan::calcReducedPoints reaches the array constructor, whose
+    # fullsort cuts with `< centre` | `>= centre` (Boctree.h:1784-1816) -- not childIndex's strict `>` (round 3 correction)
+    one = np.array([[4.0, -2.0, 8.0]])
+    assert np.array_equal(orc.octree_center(one, 5.0), one + 0.5)
     z = np.load(os.path.join(G, "dat_scans.npz"))
     clouds = [(rng.uniform(-300, 500, (n, 3)) * np.array([1.0, 0.5, 0.1]), voxel) for n, voxel in ((2000, 3.0), (50000, 10.0), (3000, 1e6))]
     clouds += [(z["scan%03d" % k], voxel) for k in range(3) for voxel in (10.0, 2.5)]      # the bundled scans, -r 10 / -r 2.5
