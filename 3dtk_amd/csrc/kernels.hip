@@ -123,6 +123,49 @@ struct LaneStack {
   }
 };
 
+// The same stack with 16-byte entries { myd^2, far child, - }: one ds_write_b128 / ds_read_b128 and one address per push /
+// pop instead of two of each (the persistent-lane kernel, round 3).  8 KB of LDS per 128-thread workgroup at SD = 4.
+template <int BLOCK, int SD>
+struct LaneStackQ {
+  uint4* l_e;      // &lds_e[0][lane]
+  double* g_m2;    // overflow, may be null when the tree is shallow
+  uint32_t* g_ref;
+  size_t gstride;
+  int sp;
+  __device__ __forceinline__ void push(uint32_t ref, double m2)
+  {
+    if (__builtin_expect(sp < SD, 1)) l_e[sp * BLOCK] = make_uint4((uint32_t)__double2loint(m2), (uint32_t)__double2hiint(m2), ref, 0u);
+    else stack_spill(g_m2, g_ref, (size_t)(sp - SD) * gstride, ref, m2);
+    ++sp;
+  }
+  __device__ __forceinline__ void top(uint32_t& ref, double& m2) const
+  {
+    const int s = sp;
+    if (__builtin_expect(s < SD, 1)) {
+      const uint4 e = l_e[s * BLOCK];
+      m2 = __hiloint2double((int)e.y, (int)e.x);
+      ref = e.z;
+    } else {
+      stack_fill(g_m2, g_ref, (size_t)(s - SD) * gstride, ref, m2);
+    }
+  }
+};
+
+// descend() for the persistent-lane kernel: the axis comes with the record (KdHot::axis) and the child references keep
+// their axis bit -- whoever turns a reference into an address or a leaf value masks it anyway (24-bit multiply, REF_VAL)
+template <class STK>
+__device__ __forceinline__ uint32_t descend_ax(const double splitval, const uint32_t c1, const uint32_t c2, const uint32_t axis,
+                                               const double qx, const double qy, const double qz, const double best, STK& st)
+{
+  const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
+  const double myd = splitval - qa;                 // kdTreeImpl.h:371
+  const bool first = (myd >= 0.0);
+  const uint32_t far = first ? c2 : c1;
+  const double m2 = myd * myd;
+  if (m2 < best) st.push(far, m2);
+  return first ? c1 : c2;
+}
+
 // ------------------------------------------------------------------------------------------
 // 1-NN within radius: exact replay of KDTreeImpl::_FindClosest (kdTreeImpl.h:345-383)
 // ------------------------------------------------------------------------------------------
@@ -238,9 +281,9 @@ __device__ __forceinline__ bool box_prunes_exact(const double cx, const double c
 }
 
 // the split-plane half of visit_node (kdTreeImpl.h:371-382): near child, far child pushed if it can still matter
-template <int BLOCK, int SD>
+template <int BLOCK, int SD, class STK = LaneStack<BLOCK, SD>>
 __device__ __forceinline__ uint32_t descend(const double splitval, const uint32_t c1, const uint32_t c2, const double qx,
-                                            const double qy, const double qz, const double best, LaneStack<BLOCK, SD>& st)
+                                            const double qy, const double qz, const double best, STK& st)
 {
   const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
   const double qa = (axis == 0) ? qx : ((axis == 1) ? qy : qz);
@@ -255,9 +298,9 @@ __device__ __forceinline__ uint32_t descend(const double splitval, const uint32_
 
 // descend(), also telling whether the near child is child 1 (the two-level walk then knows which half of the fat record
 // describes it)
-template <int BLOCK, int SD>
+template <int BLOCK, int SD, class STK = LaneStack<BLOCK, SD>>
 __device__ __forceinline__ uint32_t descend_which(const double splitval, const uint32_t c1, const uint32_t c2, const double qx,
-                                                  const double qy, const double qz, const double best, LaneStack<BLOCK, SD>& st,
+                                                  const double qy, const double qz, const double best, STK& st,
                                                   bool& near_is_c1)
 {
   const uint32_t axis = ((c1 >> 30) & 1u) | (((c2 >> 30) & 1u) << 1);
@@ -1074,15 +1117,18 @@ __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
-  __shared__ double lds_m2[SD][BLOCK];
-  __shared__ uint32_t lds_ref[SD][BLOCK];
+  __shared__ uint4 lds_stk[SD][BLOCK];
 
   const size_t gl = (size_t)bid * BLOCK + threadIdx.x;
   const unsigned lane = threadIdx.x & (WAVE - 1);
-  const unsigned long long trace_t0 = a.trace ? wall_clock64() : 0ull;
-  LaneStack<BLOCK, SD> st;
-  st.l_m2 = &lds_m2[0][threadIdx.x];
-  st.l_ref = &lds_ref[0][threadIdx.x];
+  // diagnostics (TDTK_WAVE_TRACE): the start time goes to memory right away -- kept in registers it is live across the
+  // whole kernel, and the compiler spilled it
+  if (a.trace && lane == 0) {
+    const uint32_t wid0 = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
+    if (wid0 < WTRACE_MAX) g_wtrace[3 * wid0] = wall_clock64();
+  }
+  LaneStackQ<BLOCK, SD> st;
+  st.l_e = &lds_stk[0][threadIdx.x];
   st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
   st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
   st.gstride = (size_t)nb * BLOCK;
@@ -1375,7 +1421,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
         }
         if (prune) { need_pop = true; next = REF_DONE; }
-        else next = descend<BLOCK, SD>(nsplit, nc1, nc2, qx, qy, qz, best, st);
+        else next = descend<BLOCK, SD, LaneStackQ<BLOCK, SD>>(nsplit, nc1, nc2, qx, qy, qz, best, st);
       };
       const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
       if (__all(cur == ucur)) {
@@ -1401,7 +1447,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (prune) need_pop = true;
         else {
           bool isA;
-          next = descend_which<BLOCK, SD>(s_split, s_c1, s_c2, qx, qy, qz, best, st, isA);
+          next = descend_which<BLOCK, SD, LaneStackQ<BLOCK, SD>>(s_split, s_c1, s_c2, qx, qy, qz, best, st, isA);
           if (!(next & REF_LEAF))
             level2(next, isA ? s_a0 : s_b0, isA ? s_a1 : s_b1, isA ? s_a2 : s_b2, isA ? s_a3 : s_b3, isA ? s_a4 : s_b4, isA ? s_a5 : s_b5,
                    isA ? s_asplit : s_bsplit, isA ? s_ac1 : s_bc1, isA ? s_ac2 : s_bc2);
@@ -1429,7 +1475,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (prune) need_pop = true;
         else {
           bool isA;
-          next = descend_which<BLOCK, SD>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
+          next = descend_which<BLOCK, SD, LaneStackQ<BLOCK, SD>>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
           if (!(next & REF_LEAF))
             level2(next, isA ? q4.x : q6.x, isA ? q4.y : q6.y, isA ? q4.z : q6.z, isA ? q4.w : q6.w, isA ? q5.x : q5.z, isA ? q5.y : q5.w,
                    isA ? q2.y : q3.x, isA ? (uint32_t)__double2loint(q3.y) : (uint32_t)__double2loint(q7),
@@ -1449,45 +1495,54 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     }
     if constexpr (!FAT) while (!(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
-      if (ORDER) ++nbk;
+      if (ORDER) ++nbk;     // (a key of buckets alone saves this instruction and orders no better: 0.1934 / 0.1968 against 0.1946 / 0.1923 ms)
       bool need_pop = false;
       uint32_t next = REF_DONE;
+      // `cur` may carry the axis bit of the reference it came from (REF_AXIS): the 24-bit multiply below ignores it, and
+      // two lanes at the same node hold the same bits (a node has one parent), so the uniformity test is unaffected
+      // (Testing for a wave-uniform node only while the previous test succeeded -- re-armed by a refill -- saves two
+      // instructions per divergent trip, 42.1 M -> 40.0 M per launch, and LOSES: lanes do meet again after a bucket, the
+      // scalar path is taken less often, vector loads 3.03 M -> 3.33 M, k_search 0.1952 -> 0.2106 ms; gpurun_out/r3_check3.)
       const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
       if (__all(cur == ucur)) {
         // wave-uniform visit: the 48-byte hot record through the scalar cache
         typedef const float __attribute__((address_space(4))) * const_f_ptr;
-        const_f_ptr sf = (const_f_ptr)(hotb + (size_t)ucur * sizeof(KdHot));
+        const_f_ptr sf = (const_f_ptr)(hotb + (size_t)(ucur & REF_VAL) * sizeof(KdHot));
         const_d_ptr sd = (const_d_ptr)(sf + 8);
-        const_u_ptr su = (const_u_ptr)(sf + 10);
+        const_u_ptr su = (const_u_ptr)sf;
         double s_split = sd[0];
-        uint32_t s_c1 = su[0], s_c2 = su[1];
-        TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
+        uint32_t s_c1 = su[10], s_c2 = su[11], s_axis = su[6];
+        TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2); TDTK_PIN_S32(s_axis);
         const float a32 = fmaxf(fmaxf(fabsf(bx.qx - sf[0]) - sf[3], fabsf(bx.qy - sf[1]) - sf[4]), fabsf(bx.qz - sf[2]) - sf[5]);
         bool prune = a32 >= bx.thi;
         if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
-          prune = box_prunes_exact(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], qx, qy, qz, best);
-        }
-        if (prune) need_pop = true;
-        else next = descend<BLOCK, SD>(s_split, s_c1, s_c2, qx, qy, qz, best, st);
-      } else {
-        // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no 64-bit address
-        // arithmetic on the vector ALU (the hot array is < 4 GB by construction)
-        const char* hp = hotb + (uint32_t)(cur * (uint32_t)sizeof(KdHot));
-        const float4 b0 = *reinterpret_cast<const float4*>(hp);          // cx cy cz hx
-        const float2 b1 = *reinterpret_cast<const float2*>(hp + 16);     // hy hz
-        double2 sc = *reinterpret_cast<const double2*>(hp + 32);         // splitval {c1, c2}
-        TDTK_PIN_V64(sc.x); TDTK_PIN_V64(sc.y);
-        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
-        bool prune = a32 >= bx.thi;
-        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
+          // (one visit in a million: per-lane loads of the same record -- twelve more live SGPRs here made the compiler
+          // spill in this very branch)
+          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)((cur & REF_VAL) << 6);
           const double4 n0 = *reinterpret_cast<const double4*>(np_);
           const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
           prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
         }
         if (prune) need_pop = true;
-        else next = descend<BLOCK, SD>(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), qx, qy, qz, best, st);
+        else next = descend_ax(s_split, s_c1, s_c2, s_axis, qx, qy, qz, best, st);
+      } else {
+        // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no 64-bit address arithmetic
+        // on the vector ALU (the hot array is < 4 GB by construction); v_mul_u32_u24 is full rate and drops bit 30
+        const char* hp = hotb + __umul24(cur, (uint32_t)sizeof(KdHot));
+        const float4 b0 = *reinterpret_cast<const float4*>(hp);          // cx cy cz hx
+        float4 b1 = *reinterpret_cast<const float4*>(hp + 16);           // hy hz axis -
+        double2 sc = *reinterpret_cast<const double2*>(hp + 32);         // splitval {c1, c2}
+        TDTK_PIN_V64(sc.x); TDTK_PIN_V64(sc.y); TDTK_PIN_VF(b1.z);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)((cur & REF_VAL) << 6);
+          const double4 n0 = *reinterpret_cast<const double4*>(np_);
+          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else next = descend_ax(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), __float_as_uint(b1.z), qx, qy, qz, best, st);
       }
       if (need_pop) {
         next = REF_DONE;
@@ -1561,8 +1616,16 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           // (B): sqrt(smin) (1 + 4 * 2^-24) + ec >= the true distance of that point
           const float rub = __builtin_amdgcn_sqrtf(smin) * 1.000001f + bx.ec;
           const float thr = fminf(bx.pthr, bx.reject_from(rub));   // fminf skips a NaN operand: either proof alone is valid
+          // bit j = [sv[j] < thr] = the sign of sv[j] - thr (an exact zero and +inf reject, as `>=` does); two differences
+          // per packed instruction, one v_alignbit per point shifts the sign in -- half the instructions of compare / select / or
+          const v2f th2 = {thr, thr};
 #pragma unroll
-          for (int j = 4 * GRP_TRIP - 1; j >= 0; j--) surv = surv + surv + ((sv[j] >= thr) ? 0u : 1u);
+          for (int j = 4 * GRP_TRIP - 2; j >= 0; j -= 2) {
+            const v2f dd2 = (v2f){sv[j], sv[j + 1]} - th2;
+            surv = __builtin_amdgcn_alignbit(surv, __float_as_uint(dd2.y), 31);
+            surv = __builtin_amdgcn_alignbit(surv, __float_as_uint(dd2.x), 31);
+          }
+          if (!(thr == thr)) surv = 0xFFFFFFFFu;          // no proof available (NaN threshold): every point is tested exactly
           surv &= (count >= 32) ? 0xFFFFFFFFu : ((1u << count) - 1u);
         }
         while (surv) {                                // in bucket order: lowest set bit first
@@ -1621,7 +1684,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   if (a.trace && lane == 0) {
     const uint32_t wid = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
     if (wid < WTRACE_MAX) {
-      g_wtrace[3 * wid] = trace_t0; g_wtrace[3 * wid + 1] = wall_clock64();
+      g_wtrace[3 * wid + 1] = wall_clock64();
       // XCC_ID in bits 0-2, HW_REG_HW_ID (register 4: wave, simd, cu, sh, se ...) above it
       g_wtrace[3 * wid + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) |
                               ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) << 8);
@@ -2695,6 +2758,7 @@ __global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nod
   h.cx = (float)nd.cx; h.cy = (float)nd.cy; h.cz = (float)nd.cz;
   h.hx = (float)nd.hx; h.hy = (float)nd.hy; h.hz = (float)nd.hz;
   h.splitval = nd.splitval; h.c1 = nd.c1; h.c2 = nd.c2;
+  h.axis = ((nd.c1 >> 30) & 1u) | (((nd.c2 >> 30) & 1u) << 1);
   hot[i] = h;
 }
 __global__ void __launch_bounds__(256) k_make_fat(const KdNode* __restrict__ nodes, size_t n, KdFat* __restrict__ fat)

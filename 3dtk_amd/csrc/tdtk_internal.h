@@ -42,9 +42,10 @@ static_assert(sizeof(KdPoint) == 32, "KdPoint must be 32 bytes");
 struct alignas(16) KdHot {
   float cx, cy, cz, hx;
   float hy, hz;
-  uint32_t pad0, pad1;
+  uint32_t axis;      // the split axis again, in the clear (0 / 1 / 2): saves the persistent-lane kernel the bit fiddling
+  uint32_t pad1;
   double splitval;
-  uint32_t c1, c2;
+  uint32_t c1, c2;    // child references, WITH the axis bits (REF_AXIS) like KdNode's
 };
 static_assert(sizeof(KdHot) == 48, "KdHot must be 48 bytes");
 // (One record per 64-byte line instead -- no record straddling two lines -- was measured again in round 3 with the buckets
