@@ -72,6 +72,20 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t nb)
   return (b & 7u) * per + (b >> 3);
 }
 
+// A kernel's by-value argument block, read through the kernarg segment pointer instead of through the parameter: a
+// by-value parameter is known dereferenceable and loop-invariant, so the compiler hoists every field (three 4x4 fp64
+// matrices among them) into SGPRs up front and then spills them into VGPR lanes (80 in round 2's timed kernel).  Behind an
+// opaque pointer of the constant address space the fields are s_load'ed where they are used.  The block must be the
+// kernel's FIRST parameter.
+template <class A>
+__device__ __forceinline__ const A& kernarg_block()
+{
+  typedef const A __attribute__((address_space(4))) * kernarg_ptr;
+  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const A*)p;
+}
+
 // ------------------------------------------------------------------------------------------
 // per-lane DFS stack: first SD entries in LDS ([level][lane] so a wave's pushes at one level
 // are bank-conflict free), deeper entries in an HBM overflow area ([level][global lane]).
@@ -827,9 +841,10 @@ __device__ __forceinline__ void search_plain_body(const SearchArgs& a, const uin
 }
 
 template <int BLOCK, int SD, bool COUNT, int DIRMODE, bool UNI, int WPS, int PTS = 4, bool FUSE = false>
-__global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a)
+__global__ void __launch_bounds__(BLOCK, WPS) k_search(const SearchArgs a_by_value)
 {
-  search_plain_body<BLOCK, SD, COUNT, DIRMODE, UNI, WPS, PTS, FUSE>(a, blockIdx.x, gridDim.x);
+  (void)a_by_value;
+  search_plain_body<BLOCK, SD, COUNT, DIRMODE, UNI, WPS, PTS, FUSE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 // several batches in one launch (see k_search_refill_multi)
 template <int BLOCK, int SD, bool COUNT, bool UNI, int WPS>
@@ -875,6 +890,12 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
   const TreeDev& T = a.T;
   const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
   const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+  // the argument block sits behind an opaque pointer (kernarg_block): what the loops need is fetched once, here
+  const char* const t_hot = reinterpret_cast<const char*>(T.hot);
+  const char* const t_grp = reinterpret_cast<const char*>(T.grp);
+  const LeafEntry* const t_leaf_tab = T.leaf_tab;
+  const uint32_t t_cb = T.cb, t_cmask = T.cmask, t_root = T.root_ref;
+  const float t_absmax = T.absmax;
 
   const size_t per = (a.n + nb - 1) / nb;
   const size_t lo = (size_t)chunk * per;
@@ -898,17 +919,17 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
     if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
     double best = warm_radius(a, i, qx, qy, qz);
     int bk = -1;
-    uint32_t cur = T.root_ref;
+    uint32_t cur = t_root;
     st.sp = 0;
     BoxF32 bx;
-    bx.set_query(qx, qy, qz, T.absmax);
+    bx.set_query(qx, qy, qz, t_absmax);
     bx.set_radius(best);
     for (;;) {
       while (!(cur & REF_LEAF)) {
         bool need_pop = false;
         uint32_t next = REF_DONE;
         {
-          const char* hp = reinterpret_cast<const char*>(T.hot) + (size_t)cur * sizeof(KdHot);
+          const char* hp = t_hot + (size_t)cur * sizeof(KdHot);
           const float4 b0 = *reinterpret_cast<const float4*>(hp);
           const float2 b1 = *reinterpret_cast<const float2*>(hp + 16);
           double2 sc = *reinterpret_cast<const double2*>(hp + 32);
@@ -938,15 +959,93 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
       {
         const uint32_t v = cur & REF_VAL;
         int start, count;
-        if (T.leaf_tab) {
-          const LeafEntry le = T.leaf_tab[v];
+        if (t_leaf_tab) {
+          const LeafEntry le = t_leaf_tab[v];
           start = le.start; count = le.count;
         } else {
-          start = (int)(v >> T.cb);
-          count = (int)(v & T.cmask);
+          start = (int)(v >> t_cb);
+          count = (int)(v & t_cmask);
         }
         const double4* __restrict__ P = pts + start;
         const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        if (GS == 4 && t_grp != nullptr && count <= 8 * GS) {
+          // Bucket groups (see search_refill_body): the four lanes of the query take two shadow groups each, so a bucket
+          // of up to 32 points is filtered in ONE round trip; what can still win is tested in fp64, four candidates per
+          // trip, in bucket order (group minimum with the lowest index among equals = the serial strict '<').  A small
+          // scan's search lasts as long as the dependent chain of its slowest query; this takes the 4 .. 8 trips of a
+          // bucket scan out of that chain.
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const char* gb = t_grp;
+          const uint32_t go = (uint32_t)(start >> 2) * 48u;
+          const uint32_t glast = go + (uint32_t)((count - 1) >> 2) * 48u;
+          float sv[8];
+          const v2f qxx = {bx.qx, bx.qx}, qyy = {bx.qy, bx.qy}, qzz = {bx.qz, bx.qz};
+          float4 X[2], Y[2], Z[2];
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const uint32_t gk = min(go + 48u * (uint32_t)(sub + GS * k), glast);
+            X[k] = *reinterpret_cast<const float4*>(gb + gk);
+            Y[k] = *reinterpret_cast<const float4*>(gb + gk + 16);
+            Z[k] = *reinterpret_cast<const float4*>(gb + gk + 32);
+          }
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const v2f dxa = (v2f){X[k].x, X[k].y} - qxx, dxb = (v2f){X[k].z, X[k].w} - qxx;
+            const v2f dya = (v2f){Y[k].x, Y[k].y} - qyy, dyb = (v2f){Y[k].z, Y[k].w} - qyy;
+            const v2f dza = (v2f){Z[k].x, Z[k].y} - qzz, dzb = (v2f){Z[k].z, Z[k].w} - qzz;
+            const v2f sa = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
+            const v2f sb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
+            sv[4 * k] = sa.x; sv[4 * k + 1] = sa.y; sv[4 * k + 2] = sb.x; sv[4 * k + 3] = sb.y;
+          }
+          // which of this lane's eight slots are points of the bucket (the rest repeat the last group)
+          unsigned valid = 0u;
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int p0 = 4 * (sub + GS * k);
+            const int nv = count - p0;                       // slots p0 .. p0 + 3
+            valid |= ((nv >= 4) ? 15u : (nv > 0 ? ((1u << nv) - 1u) : 0u)) << (4 * k);
+          }
+          float smin = __builtin_inff();
+#pragma unroll
+          for (int j = 0; j < 8; j++) smin = fminf(smin, ((valid >> j) & 1u) ? sv[j] : __builtin_inff());
+#pragma unroll
+          for (int o = 1; o < GS; o <<= 1) smin = fminf(smin, __shfl_xor(smin, o, GS));
+          unsigned surv = 0u;
+          if (!(smin >= bx.pthr)) {
+            const float rub = __builtin_amdgcn_sqrtf(smin) * 1.000001f + bx.ec;
+            const float thr = fminf(bx.pthr, bx.reject_from(rub));
+            unsigned m = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) m |= ((sv[j] >= thr) ? 0u : 1u) << j;
+            m &= valid;
+            unsigned mine = ((m & 15u) << (4 * sub)) | ((m >> 4) << (4 * (sub + GS)));
+#pragma unroll
+            for (int o = 1; o < GS; o <<= 1) mine |= (unsigned)__shfl_xor((int)mine, o, GS);
+            surv = mine;
+          }
+          while (surv) {
+            unsigned t = surv;                               // lane `sub` takes the sub-th lowest candidate
+#pragma unroll
+            for (int k = 0; k < GS - 1; k++) if (k < sub) t &= t - 1u;
+            double d = inf;
+            int jj = 0x7fffffff;
+            if (t) {
+              jj = __builtin_ctz(t);
+              const double4 p = P[jj];
+              const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+              d = dx * dx + dy * dy + dz * dz;
+            }
+#pragma unroll
+            for (int o = 1; o < GS; o <<= 1) {               // group minimum, lowest index among equals
+              const double od = __shfl_xor(d, o, GS);
+              const int oj = __shfl_xor(jj, o, GS);
+              if (od < d || (od == d && oj < jj)) { d = od; jj = oj; }
+            }
+            if (d < best) { best = d; bk = start + jj; }
+#pragma unroll
+            for (int k = 0; k < GS; k++) surv &= surv - 1u;  // (0 & anything stays 0)
+          }
+        } else
         for (int j0 = 0; j0 < count; j0 += GS) {
           const int j = j0 + sub;
           double d = inf;
@@ -1068,9 +1167,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
 }
 
 template <int BLOCK, int SD, int GS = 8, bool FUSE = false>
-__global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a)
+__global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a_by_value)
 {
-  search_g8_body<BLOCK, SD, GS, FUSE>(a, blockIdx.x, gridDim.x);
+  (void)a_by_value;
+  search_g8_body<BLOCK, SD, GS, FUSE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 template <int BLOCK, int SD, int GS>
 __global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __restrict__ args, const uint32_t* __restrict__ base,
@@ -1784,10 +1884,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   // v_readlane in a kernel that is short of issue slots.  Behind an opaque pointer the fields are s_load'ed where they
   // are used (the matrices only when a lane takes a new query), like k_search_refill_multi reads its table entry.
   (void)a_by_value;
-  typedef const SearchArgs __attribute__((address_space(4))) * kernarg_ptr;   // constant address space -> s_load
-  kernarg_ptr ap = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ap));
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT>(*(const SearchArgs*)ap, blockIdx.x, gridDim.x);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 
 // Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
