@@ -403,10 +403,14 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   if (t->info.n_internal) {
     HIPCHK(hipMalloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
     HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream));
-    // ... and the two-level records the persistent-lane kernel walks (32-bit byte offsets: < 2^25 internal nodes, which
-    // the 2^27-point limit of a tree implies)
-    static const bool want_fat = [] { const char* e = getenv("TDTK_FAT_NODES"); return e && e[0] == '1'; }();
-    if (want_fat) {     // the two-level walk is a measured negative (kernels.hip): its records are built on request only
+    // ... and, on request only, the two-level records (a node with its children's hot parts): two tree levels per round
+    // trip are a measured negative both for the persistent-lane kernel (TDTK_FAT_NODES=1) and for the lane-group kernels of
+    // small batches (TDTK_FAT_SMALL=1); kernels.hip has the numbers
+    static const bool want_fat = [] {
+      const char *a = getenv("TDTK_FAT_NODES"), *b = getenv("TDTK_FAT_SMALL");
+      return (a && a[0] == '1') || (b && b[0] == '1');
+    }();
+    if (want_fat) {
       HIPCHK(hipMalloc(&t->d_fat, t->info.n_internal * sizeof(KdFat)));
       HIPCHK(launch_make_fat(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdFat*>(t->d_fat), c->stream));
     }

@@ -893,6 +893,8 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
   // the argument block sits behind an opaque pointer (kernarg_block): what the loops need is fetched once, here
   const char* const t_hot = reinterpret_cast<const char*>(T.hot);
   const char* const t_grp = reinterpret_cast<const char*>(T.grp);
+  // null unless TDTK_FAT_SMALL=1 (the launcher clears the pointer)
+  const char* const t_fat = reinterpret_cast<const char*>(T.fat);
   const LeafEntry* const t_leaf_tab = T.leaf_tab;
   const uint32_t t_cb = T.cb, t_cmask = T.cmask, t_root = T.root_ref;
   const float t_absmax = T.absmax;
@@ -925,6 +927,63 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
     bx.set_query(qx, qy, qz, t_absmax);
     bx.set_radius(best);
     for (;;) {
+      if (t_fat != nullptr) while (!(cur & REF_LEAF)) {
+        // TDTK_FAT_SMALL=1 (a measured negative): two tree levels per round trip (KdFat: a node with the hot parts of its
+        // two children).  The launch lasts as long as the dependent chain of its slowest query and this halves the node
+        // part of that chain -- and still loses: eight 16-byte loads per lane and trip answer later than three.  dat/ pair
+        // 74.3 against 67.1 us per search, uniform 20K 18.1 / 17.1, 81K 26.9 / 24.9 (round 3; all 214 GPU tests pass
+        // with it).  Same visits, same order, same pushes as the one-level walk below (see search_refill_body, FAT).
+        bool need_pop = false;
+        uint32_t next = REF_DONE;
+        const char* fp = t_fat + (uint32_t)(cur << 7);
+        const float4 q0 = *reinterpret_cast<const float4*>(fp);            // X: cx cy cz hx
+        float4 q1 = *reinterpret_cast<const float4*>(fp + 16);             //    hy hz c1 c2
+        double2 q2 = *reinterpret_cast<const double2*>(fp + 32);           // X split, A split
+        double2 q3 = *reinterpret_cast<const double2*>(fp + 48);           // B split, {A c1, A c2}
+        float4 q4 = *reinterpret_cast<const float4*>(fp + 64);             // A: cx cy cz hx
+        float4 q5 = *reinterpret_cast<const float4*>(fp + 80);             // A hy hz, B hy hz
+        float4 q6 = *reinterpret_cast<const float4*>(fp + 96);             // B: cx cy cz hx
+        double q7 = *reinterpret_cast<const double*>(fp + 112);            // {B c1, B c2}
+        TDTK_PIN_V64(q2.x); TDTK_PIN_V64(q2.y); TDTK_PIN_V64(q3.x); TDTK_PIN_V64(q3.y); TDTK_PIN_V64(q7);
+        TDTK_PIN_VF(q1.z); TDTK_PIN_VF(q1.w); TDTK_PIN_VF(q4.x); TDTK_PIN_VF(q5.x); TDTK_PIN_VF(q6.x);
+        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - q0.x) - q0.w, fabsf(bx.qy - q0.y) - q1.x), fabsf(bx.qz - q0.z) - q1.y);
+        bool prune = a32 >= bx.thi;
+        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {
+          const double4 n0 = nodes[(size_t)cur * 2];
+          const double4 n1 = nodes[(size_t)cur * 2 + 1];
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
+        if (prune) need_pop = true;
+        else {
+          bool isA;
+          next = descend_which<NG, SD>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
+          if (!(next & REF_LEAF)) {
+            const float ncx = isA ? q4.x : q6.x, ncy = isA ? q4.y : q6.y, ncz = isA ? q4.z : q6.z, nhx = isA ? q4.w : q6.w;
+            const float nhy = isA ? q5.x : q5.z, nhz = isA ? q5.y : q5.w;
+            const float b32 = fmaxf(fmaxf(fabsf(bx.qx - ncx) - nhx, fabsf(bx.qy - ncy) - nhy), fabsf(bx.qz - ncz) - nhz);
+            bool prune2 = b32 >= bx.thi;
+            if (__builtin_expect(!prune2 && !(b32 < bx.tlo), 0)) {
+              const double4 n0 = nodes[(size_t)next * 2];
+              const double4 n1 = nodes[(size_t)next * 2 + 1];
+              prune2 = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+            }
+            if (prune2) { need_pop = true; next = REF_DONE; }
+            else next = descend<NG, SD>(isA ? q2.y : q3.x, isA ? (uint32_t)__double2loint(q3.y) : (uint32_t)__double2loint(q7),
+                                        isA ? (uint32_t)__double2hiint(q3.y) : (uint32_t)__double2hiint(q7), qx, qy, qz, best, st);
+          }
+        }
+        if (need_pop) {
+          next = REF_DONE;
+          while (st.sp > 0) {
+            --st.sp;
+            uint32_t r; double m2;
+            st.top(r, m2);
+            if (m2 < best) { next = r; break; }
+          }
+        }
+        cur = next;
+      }
+      else
       while (!(cur & REF_LEAF)) {
         bool need_pop = false;
         uint32_t next = REF_DONE;
@@ -2666,7 +2725,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 1>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 42 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
-  } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr) {
+  } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr && getenv("TDTK_FAT_NODES") && getenv("TDTK_FAT_NODES")[0] == '1') {
     // two tree levels per round trip (KdFat): a measured negative, kept selectable -- see the comment at the walk
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, true>), dim3(nb), dim3(128), occ_lds, s, a);
   } else switch (refill_thresh(a.n)) {
@@ -2736,6 +2795,11 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
 {
   if (a_in.n == 0) return hipSuccess;
   SearchArgs a = a_in;
+  {
+    // the lane-group kernels can walk two tree levels per trip (KdFat) -- on request: measured slower here too
+    const char* e = getenv("TDTK_FAT_SMALL");
+    if (!(e && e[0] == '1') && pick_variant(a.n) != 20) a.T.fat = nullptr;
+  }
   dim3 g(grid), b(SEARCH_BLOCK);
   if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 1, false, 1>), g, b, 0, s, a);
   else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
