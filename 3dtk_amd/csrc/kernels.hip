@@ -355,6 +355,83 @@ static __device__ __forceinline__ double warm_radius(const SearchArgs& a, const 
   return warm_radius_kp(a, a.warm ? a.kpos[i] : -1, qx, qy, qz);
 }
 
+// groups of four points a lane takes in per round trip of the bucket filter: 5 = a whole default bucket (-b 20)
+constexpr int GRP_TRIP = 5;
+
+// One bucket of up to 4 * GRP_TRIP points, scanned through its fp32 shadow groups (tree_pad_buckets in api.cpp: buckets are
+// padded to whole groups of four slots, `start` is a multiple of 4).  pb = the fp64 point array, o0 = byte offset of the
+// bucket in it.  On return best / bk are what the reference's leaf loop (kdTreeImpl.h:351-357) leaves behind.
+__device__ __forceinline__ void bucket_scan_groups(const char* __restrict__ t_grp, const char* __restrict__ pb, const int start,
+                                             const int count, const uint32_t o0, const BoxF32& bx, const double qx,
+                                             const double qy, const double qz, double& best, int& bk)
+{
+  // ---- bucket groups: the whole bucket in ONE round trip of fp32 shadow records, then only the points that can
+  // still matter from the fp64 array.  The reference's leaf loop (kdTreeImpl.h:351-357) leaves behind
+  //   closest_d2 = min(closest_d2, min_j d_j),  closest = the FIRST j that attains a smaller value,
+  // and nothing else of it is observable.  A point is dropped only on proof that it is not that j:
+  //   (A) s_j >= pthr            =>  d_j >= closest_d2 (BoxF32::reject_from): it fails the reference's '<';
+  //   (B) s_j >= reject_from(R)  with R >= the true distance of the point k with the smallest shadow distance
+  //                              =>  d_j > d_k: somebody else is strictly closer.
+  // The survivors -- the nearest point, exact duplicates of it, anything within ~1e-5 relative -- are tested in
+  // fp64 in bucket order with the strict '<', which is the reference's loop restricted to the points that can win.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const uint32_t go = (uint32_t)(start >> 2) * 48u;     // the bucket's first group (start is a multiple of 4)
+  const uint32_t glast = go + (uint32_t)((count - 1) >> 2) * 48u;
+  float4 X[GRP_TRIP], Y[GRP_TRIP], Z[GRP_TRIP];
+#pragma unroll
+  for (int k = 0; k < GRP_TRIP; k++) {
+    // groups past the bucket's last re-read the last one (an L1 hit, no branch); their bits are masked out below.
+    // (Loading each group under its own lane mask instead -- no access for a group the bucket does not have -- costs
+    // the register allocation 188 VGPRs instead of 122, i.e. half the resident waves; masking only the fifth group
+    // keeps 122 and changes nothing: 0.1987 / 0.1990 ms against 0.1974 / 0.1970, gpurun_out/r3f.)
+    const uint32_t gk = min(go + 48u * (uint32_t)k, glast);
+    X[k] = *reinterpret_cast<const float4*>(t_grp + gk);
+    Y[k] = *reinterpret_cast<const float4*>(t_grp + gk + 16);
+    Z[k] = *reinterpret_cast<const float4*>(t_grp + gk + 32);
+  }
+  const v2f qxx = {bx.qx, bx.qx}, qyy = {bx.qy, bx.qy}, qzz = {bx.qz, bx.qz};
+  float sv[4 * GRP_TRIP];
+#pragma unroll
+  for (int k = 0; k < GRP_TRIP; k++) {
+    const v2f dxa = (v2f){X[k].x, X[k].y} - qxx, dxb = (v2f){X[k].z, X[k].w} - qxx;
+    const v2f dya = (v2f){Y[k].x, Y[k].y} - qyy, dyb = (v2f){Y[k].z, Y[k].w} - qyy;
+    const v2f dza = (v2f){Z[k].x, Z[k].y} - qzz, dzb = (v2f){Z[k].z, Z[k].w} - qzz;
+    const v2f sa = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
+    const v2f sb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
+    sv[4 * k] = sa.x; sv[4 * k + 1] = sa.y; sv[4 * k + 2] = sb.x; sv[4 * k + 3] = sb.y;
+  }
+  float smin = sv[0];
+#pragma unroll
+  for (int j = 1; j < 4 * GRP_TRIP; j++) smin = fminf(smin, sv[j]);   // pad slots and re-read groups repeat real points
+  unsigned surv = 0u;
+  if (!(smin >= bx.pthr)) {               // else (A) drops every point of the bucket: the usual case after the first
+    // (B): sqrt(smin) (1 + 4 * 2^-24) + ec >= the true distance of that point
+    const float rub = __builtin_amdgcn_sqrtf(smin) * 1.000001f + bx.ec;
+    const float thr = fminf(bx.pthr, bx.reject_from(rub));   // fminf skips a NaN operand: either proof alone is valid
+    // bit j = [sv[j] < thr] = the sign of sv[j] - thr (an exact zero and +inf reject, as `>=` does); two differences
+    // per packed instruction, one v_alignbit per point shifts the sign in -- half the instructions of compare / select / or
+    const v2f th2 = {thr, thr};
+#pragma unroll
+    for (int j = 4 * GRP_TRIP - 2; j >= 0; j -= 2) {
+      const v2f dd2 = (v2f){sv[j], sv[j + 1]} - th2;
+      surv = __builtin_amdgcn_alignbit(surv, __float_as_uint(dd2.y), 31);
+      surv = __builtin_amdgcn_alignbit(surv, __float_as_uint(dd2.x), 31);
+    }
+    if (!(thr == thr)) surv = 0xFFFFFFFFu;    // no proof available (NaN threshold): every point is tested exactly
+    surv &= (count >= 32) ? 0xFFFFFFFFu : ((1u << count) - 1u);
+  }
+  while (surv) {                          // in bucket order: lowest set bit first
+    const uint32_t j = (uint32_t)__builtin_ctz(surv);
+    surv &= surv - 1u;
+    const uint32_t oj = o0 + (j << 5);
+    const double2 pxy = *reinterpret_cast<const double2*>(pb + oj);
+    const double pz = *reinterpret_cast<const double*>(pb + oj + 16);
+    const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pz - qz;
+    const double dj = dx * dx + dy * dy + dz * dz;
+    if (dj < best) { best = dj; bk = (int)(oj >> 5); }
+  }
+}
+
 template <int BLOCK, int SD, bool COUNT, bool UNI, int PTS = 4>
 __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, const double qy,
                                           const double qz, double& best, int& bk,
@@ -444,6 +521,10 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
         count = (int)(v & T.cmask);
       }
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
+      if (T.grp != nullptr && count <= 4 * GRP_TRIP) {     // the whole bucket in one round trip (bucket_scan_groups)
+        bucket_scan_groups(reinterpret_cast<const char*>(T.grp), reinterpret_cast<const char*>(pts), start, count,
+                           (uint32_t)start << 5, bx, qx, qy, qz, best, bk);
+      } else {
       const double4* __restrict__ P = pts + start;
       const int last = count - 1;
       // PTS points per round trip (small batches run one wave per SIMD: nothing else hides the latency,
@@ -462,6 +543,7 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
 #pragma unroll
         for (int j = 0; j < PTS; j++)
           if (d[j] < best) { best = d[j]; bk = start + id[j]; }
+      }
       }
       bx.set_radius(best);
     }
@@ -1265,8 +1347,6 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __r
 // contended counter costs ~0.6 us and they serialise per counter (1M queries, 64-query draws: 0.93 ms against 0.27 ms
 // static; 256-query draws: 0.58 ms), and (b) the premise is wrong at this size -- a chip full of resident waves
 // (7168) leaves 1M queries only ~140 per wave, i.e. MORE drains per query than the static 224..256-query slabs.
-// groups of four points a lane takes in per round trip of the bucket filter: 5 = a whole default bucket (-b 20)
-constexpr int GRP_TRIP = 5;
 // diagnostics (TDTK_WAVE_TRACE=<launch index>): start / end time (100 MHz) and XCD of every wave of one launch
 #define WTRACE_MAX 32768u
 __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
@@ -1732,71 +1812,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
       if (PROBE == 0 && t_grp != nullptr && count <= 4 * GRP_TRIP) {
-        // ---- bucket groups: the whole bucket in ONE round trip of fp32 shadow records, then only the points that can
-        // still matter from the fp64 array.  The reference's leaf loop (kdTreeImpl.h:351-357) leaves behind
-        //   closest_d2 = min(closest_d2, min_j d_j),  closest = the FIRST j that attains a smaller value,
-        // and nothing else of it is observable.  A point is dropped only on proof that it is not that j:
-        //   (A) s_j >= pthr            =>  d_j >= closest_d2 (BoxF32::reject_from): it fails the reference's '<';
-        //   (B) s_j >= reject_from(R)  with R >= the true distance of the point k with the smallest shadow distance
-        //                              =>  d_j > d_k: somebody else is strictly closer.
-        // The survivors -- the nearest point, exact duplicates of it, anything within ~1e-5 relative -- are tested in
-        // fp64 in bucket order with the strict '<', which is the reference's loop restricted to the points that can win.
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const uint32_t go = (uint32_t)(start >> 2) * 48u;     // the bucket's first group (start is a multiple of 4)
-        const uint32_t glast = go + (uint32_t)((count - 1) >> 2) * 48u;
-        float4 X[GRP_TRIP], Y[GRP_TRIP], Z[GRP_TRIP];
-#pragma unroll
-        for (int k = 0; k < GRP_TRIP; k++) {
-          // groups past the bucket's last re-read the last one (an L1 hit, no branch); their bits are masked out below.
-          // (Loading each group under its own lane mask instead -- no access for a group the bucket does not have -- costs
-          // the register allocation 188 VGPRs instead of 122, i.e. half the resident waves; masking only the fifth group
-          // keeps 122 and changes nothing: 0.1987 / 0.1990 ms against 0.1974 / 0.1970, gpurun_out/r3f.)
-          const uint32_t gk = min(go + 48u * (uint32_t)k, glast);
-          X[k] = *reinterpret_cast<const float4*>(t_grp + gk);
-          Y[k] = *reinterpret_cast<const float4*>(t_grp + gk + 16);
-          Z[k] = *reinterpret_cast<const float4*>(t_grp + gk + 32);
-        }
-        const v2f qxx = {bx.qx, bx.qx}, qyy = {bx.qy, bx.qy}, qzz = {bx.qz, bx.qz};
-        float sv[4 * GRP_TRIP];
-#pragma unroll
-        for (int k = 0; k < GRP_TRIP; k++) {
-          const v2f dxa = (v2f){X[k].x, X[k].y} - qxx, dxb = (v2f){X[k].z, X[k].w} - qxx;
-          const v2f dya = (v2f){Y[k].x, Y[k].y} - qyy, dyb = (v2f){Y[k].z, Y[k].w} - qyy;
-          const v2f dza = (v2f){Z[k].x, Z[k].y} - qzz, dzb = (v2f){Z[k].z, Z[k].w} - qzz;
-          const v2f sa = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, dxa * dxa));
-          const v2f sb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, dxb * dxb));
-          sv[4 * k] = sa.x; sv[4 * k + 1] = sa.y; sv[4 * k + 2] = sb.x; sv[4 * k + 3] = sb.y;
-        }
-        float smin = sv[0];
-#pragma unroll
-        for (int j = 1; j < 4 * GRP_TRIP; j++) smin = fminf(smin, sv[j]);   // pad slots and re-read groups repeat real points
-        unsigned surv = 0u;
-        if (!(smin >= bx.pthr)) {                     // else (A) drops every point of the bucket: the usual case after the first
-          // (B): sqrt(smin) (1 + 4 * 2^-24) + ec >= the true distance of that point
-          const float rub = __builtin_amdgcn_sqrtf(smin) * 1.000001f + bx.ec;
-          const float thr = fminf(bx.pthr, bx.reject_from(rub));   // fminf skips a NaN operand: either proof alone is valid
-          // bit j = [sv[j] < thr] = the sign of sv[j] - thr (an exact zero and +inf reject, as `>=` does); two differences
-          // per packed instruction, one v_alignbit per point shifts the sign in -- half the instructions of compare / select / or
-          const v2f th2 = {thr, thr};
-#pragma unroll
-          for (int j = 4 * GRP_TRIP - 2; j >= 0; j -= 2) {
-            const v2f dd2 = (v2f){sv[j], sv[j + 1]} - th2;
-            surv = __builtin_amdgcn_alignbit(surv, __float_as_uint(dd2.y), 31);
-            surv = __builtin_amdgcn_alignbit(surv, __float_as_uint(dd2.x), 31);
-          }
-          if (!(thr == thr)) surv = 0xFFFFFFFFu;          // no proof available (NaN threshold): every point is tested exactly
-          surv &= (count >= 32) ? 0xFFFFFFFFu : ((1u << count) - 1u);
-        }
-        while (surv) {                                // in bucket order: lowest set bit first
-          const uint32_t j = (uint32_t)__builtin_ctz(surv);
-          surv &= surv - 1u;
-          const uint32_t oj = o0 + (j << 5);
-          const double2 pxy = *reinterpret_cast<const double2*>(pb + oj);
-          const double pz = *reinterpret_cast<const double*>(pb + oj + 16);
-          const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pz - qz;
-          const double dj = dx * dx + dy * dy + dz * dz;
-          if (dj < best) { best = dj; bk = (int)(oj >> 5); }
-        }
+        bucket_scan_groups(t_grp, pb, start, count, o0, bx, qx, qy, qz, best, bk);
       } else
       // PTS points per round trip, all their loads issued before the first use; the last group re-reads the final point
       // instead of running a scalar tail (a repeated point can never pass the strict '<' a second time)
