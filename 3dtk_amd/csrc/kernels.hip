@@ -217,6 +217,25 @@ __device__ __forceinline__ uint32_t visit_node(const double cx, const double cy,
   return first ? r1 : r2;
 }
 
+// Loads through an explicitly GLOBAL pointer.  The several-links-per-launch kernel finds its array pointers in a table in
+// device memory, where nothing tells the compiler which address space they point to: it emitted flat_load (two counters,
+// aperture check) for every record of the tree.  The arrays of a tree / scan are always global memory.
+template <class V>
+__device__ __forceinline__ V gload(const char* base, const uint32_t off)
+{
+  // (HIP's vector structs cannot be copied out of an address-space-qualified reference: load raw dwords, then bit-copy)
+  typedef uint32_t raw __attribute__((ext_vector_type(sizeof(V) / 4)));
+  typedef const raw __attribute__((address_space(1))) * gp;
+  const raw r = *(gp)(base + off);
+  V v;
+  __builtin_memcpy(&v, &r, sizeof v);
+  return v;
+}
+// One empty asm over one register of EVERY load of a batch: all of them must have been issued, and have arrived, here --
+// so the compiler can neither sink one of them behind a branch nor (what it did in the several-links kernel, round 3) put
+// a wait between them: 84 link passes 10.8 -> 12.6 ms from one such wait per node visit.
+#define TDTK_PIN_BATCH3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+
 // The compiler sinks the load of a node's last 16 bytes (split value + child references) behind the box test, because
 // only the not-pruned path uses them -- which turns every node visit into TWO dependent memory round trips.  Naming the
 // values in an empty asm right behind the loads keeps all four quarters of the record in one batch.
@@ -385,9 +404,9 @@ __device__ __forceinline__ void bucket_scan_groups(const char* __restrict__ t_gr
     // the register allocation 188 VGPRs instead of 122, i.e. half the resident waves; masking only the fifth group
     // keeps 122 and changes nothing: 0.1987 / 0.1990 ms against 0.1974 / 0.1970, gpurun_out/r3f.)
     const uint32_t gk = min(go + 48u * (uint32_t)k, glast);
-    X[k] = *reinterpret_cast<const float4*>(t_grp + gk);
-    Y[k] = *reinterpret_cast<const float4*>(t_grp + gk + 16);
-    Z[k] = *reinterpret_cast<const float4*>(t_grp + gk + 32);
+    X[k] = gload<float4>(t_grp, gk);
+    Y[k] = gload<float4>(t_grp, gk + 16);
+    Z[k] = gload<float4>(t_grp, gk + 32);
   }
   const v2f qxx = {bx.qx, bx.qx}, qyy = {bx.qy, bx.qy}, qzz = {bx.qz, bx.qz};
   float sv[4 * GRP_TRIP];
@@ -424,8 +443,8 @@ __device__ __forceinline__ void bucket_scan_groups(const char* __restrict__ t_gr
     const uint32_t j = (uint32_t)__builtin_ctz(surv);
     surv &= surv - 1u;
     const uint32_t oj = o0 + (j << 5);
-    const double2 pxy = *reinterpret_cast<const double2*>(pb + oj);
-    const double pz = *reinterpret_cast<const double*>(pb + oj + 16);
+    const double2 pxy = gload<double2>(pb, oj);
+    const double pz = gload<double>(pb, oj + 16);
     const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pz - qz;
     const double dj = dx * dx + dy * dy + dz * dz;
     if (dj < best) { best = dj; bk = (int)(oj >> 5); }
@@ -1660,7 +1679,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
         }
         if (prune) { need_pop = true; next = REF_DONE; }
-        else next = descend<BLOCK, SD, LaneStackQ<BLOCK, SD>>(nsplit, nc1, nc2, qx, qy, qz, best, st);
+        else next = descend<BLOCK, SD, decltype(st)>(nsplit, nc1, nc2, qx, qy, qz, best, st);
       };
       const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
       if (__all(cur == ucur)) {
@@ -1686,7 +1705,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (prune) need_pop = true;
         else {
           bool isA;
-          next = descend_which<BLOCK, SD, LaneStackQ<BLOCK, SD>>(s_split, s_c1, s_c2, qx, qy, qz, best, st, isA);
+          next = descend_which<BLOCK, SD, decltype(st)>(s_split, s_c1, s_c2, qx, qy, qz, best, st, isA);
           if (!(next & REF_LEAF))
             level2(next, isA ? s_a0 : s_b0, isA ? s_a1 : s_b1, isA ? s_a2 : s_b2, isA ? s_a3 : s_b3, isA ? s_a4 : s_b4, isA ? s_a5 : s_b5,
                    isA ? s_asplit : s_bsplit, isA ? s_ac1 : s_bc1, isA ? s_ac2 : s_bc2);
@@ -1714,7 +1733,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (prune) need_pop = true;
         else {
           bool isA;
-          next = descend_which<BLOCK, SD, LaneStackQ<BLOCK, SD>>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
+          next = descend_which<BLOCK, SD, decltype(st)>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
           if (!(next & REF_LEAF))
             level2(next, isA ? q4.x : q6.x, isA ? q4.y : q6.y, isA ? q4.z : q6.z, isA ? q4.w : q6.w, isA ? q5.x : q5.z, isA ? q5.y : q5.w,
                    isA ? q2.y : q3.x, isA ? (uint32_t)__double2loint(q3.y) : (uint32_t)__double2loint(q7),
@@ -1757,9 +1776,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
           // (one visit in a million: per-lane loads of the same record -- twelve more live SGPRs here made the compiler
           // spill in this very branch)
-          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)((cur & REF_VAL) << 6);
-          const double4 n0 = *reinterpret_cast<const double4*>(np_);
-          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
+          const uint32_t no = (uint32_t)((cur & REF_VAL) << 6);
+          const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
+          const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
           prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
         }
         if (prune) need_pop = true;
@@ -1767,17 +1786,17 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       } else {
         // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no 64-bit address arithmetic
         // on the vector ALU (the hot array is < 4 GB by construction); v_mul_u32_u24 is full rate and drops bit 30
-        const char* hp = hotb + __umul24(cur, (uint32_t)sizeof(KdHot));
-        const float4 b0 = *reinterpret_cast<const float4*>(hp);          // cx cy cz hx
-        float4 b1 = *reinterpret_cast<const float4*>(hp + 16);           // hy hz axis -
-        double2 sc = *reinterpret_cast<const double2*>(hp + 32);         // splitval {c1, c2}
-        TDTK_PIN_V64(sc.x); TDTK_PIN_V64(sc.y); TDTK_PIN_VF(b1.z);
+        const uint32_t ho = __umul24(cur, (uint32_t)sizeof(KdHot));
+        float4 b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
+        float4 b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
+        double2 sc = gload<double2>(hotb, ho + 32);          // splitval {c1, c2}
+        TDTK_PIN_BATCH3(b0.x, b1.z, sc.x);
         const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
         bool prune = a32 >= bx.thi;
         if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)((cur & REF_VAL) << 6);
-          const double4 n0 = *reinterpret_cast<const double4*>(np_);
-          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
+          const uint32_t no = (uint32_t)((cur & REF_VAL) << 6);
+          const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
+          const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
           prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
         }
         if (prune) need_pop = true;
