@@ -231,6 +231,15 @@ __device__ __forceinline__ V gload(const char* base, const uint32_t off)
   __builtin_memcpy(&v, &r, sizeof v);
   return v;
 }
+template <class V>
+__device__ __forceinline__ void gstore(char* base, const uint32_t off, const V v)
+{
+  typedef uint32_t raw __attribute__((ext_vector_type(sizeof(V) / 4)));
+  typedef raw __attribute__((address_space(1))) * gp;
+  raw r;
+  __builtin_memcpy(&r, &v, sizeof v);
+  *(gp)(base + off) = r;
+}
 // One empty asm over one register of EVERY load of a batch: all of them must have been issued, and have arrived, here --
 // so the compiler can neither sink one of them behind a branch nor (what it did in the several-links kernel, round 3) put
 // a wait between them: 84 link passes 10.8 -> 12.6 ms from one such wait per node visit.
@@ -359,8 +368,10 @@ static __device__ __forceinline__ double warm_radius_kp(const SearchArgs& a, con
   double best = a.maxd2;
   if (a.warm) {
     if (kp >= 0) {
-      const double4 p = reinterpret_cast<const double4*>(a.T.pts)[kp];
-      const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+      const uint32_t po = (uint32_t)kp << 5;
+      const double2 pxy = gload<double2>(reinterpret_cast<const char*>(a.T.pts), po);
+      const double pzz = gload<double>(reinterpret_cast<const char*>(a.T.pts), po + 16);
+      const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pzz - qz;
       const double d = dx * dx + dy * dy + dz * dz;
       const double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
       if (up < best) best = up;
@@ -1525,8 +1536,8 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     // ---- retire finished queries, hand out new ones ----
     const bool idle = (cur == REF_DONE);
     if (idle && have) {
-      a_kpos[qi] = bk;
-      if (a_d2) a_d2[qi] = best;
+      gstore<int>(reinterpret_cast<char*>(a_kpos), (uint32_t)qi << 2, bk);
+      if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), (uint32_t)qi << 3, best);
       if (ORDER && a_cost) a_cost[qi] = (unsigned char)min(nbk, 255u);   // nbk: node visits + 4 per bucket
       have = false;
       if constexpr (FUSE == 2) if (bk >= 0) {
@@ -1624,11 +1635,15 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       const size_t mine = (ORDER && got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
       if (got) {
         // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
-        const int kp_prev = a.warm ? a.kpos[mine] : -1;
-        double tx = a.x[mine], ty = a.y[mine], tz = a.z[mine];
+        // (global loads / stores at 32-bit byte offsets: a scan has < 2^27 points)
+        const uint32_t m8 = (uint32_t)mine << 3;
+        const int kp_prev = a.warm ? gload<int>(reinterpret_cast<const char*>(a_kpos), (uint32_t)mine << 2) : -1;
+        double tx = gload<double>(reinterpret_cast<const char*>(a.x), m8), ty = gload<double>(reinterpret_cast<const char*>(a.y), m8),
+               tz = gload<double>(reinterpret_cast<const char*>(a.z), m8);
         if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
           dev_xf3_inplace(a.pending, tx, ty, tz);
-          a.x[mine] = tx; a.y[mine] = ty; a.z[mine] = tz;
+          gstore<double>(reinterpret_cast<char*>(a.x), m8, tx); gstore<double>(reinterpret_cast<char*>(a.y), m8, ty);
+          gstore<double>(reinterpret_cast<char*>(a.z), m8, tz);
           if (a.nx) {
             double px = a.nx[mine], py = a.ny[mine], pz = a.nz[mine];
             dev_xf3normal(a.pending, px, py, pz);
