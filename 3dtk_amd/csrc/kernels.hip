@@ -1805,6 +1805,10 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         float4 b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
         float4 b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
         double2 sc = gload<double2>(hotb, ho + 32);          // splitval {c1, c2}
+        if constexpr (PROBE == 3) {   // sensitivity probe (TDTK_BUCKET_PTS=43): one more 16-byte load per node visit, result unused
+          float4 w = gload<float4>(hotb, ho + 8);
+          asm volatile("" : "+v"(b0.x), "+v"(b1.z), "+v"(sc.x), "+v"(w.x));
+        } else
         TDTK_PIN_BATCH3(b0.x, b1.z, sc.x);
         const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
         bool prune = a32 >= bx.thi;
@@ -1845,7 +1849,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
-      if (PROBE == 0 && t_grp != nullptr && count <= 4 * GRP_TRIP) {
+      if ((PROBE == 0 || PROBE == 3) && t_grp != nullptr && count <= 4 * GRP_TRIP) {
         bucket_scan_groups(t_grp, pb, start, count, o0, bx, qx, qy, qz, best, bk);
       } else
       // PTS points per round trip, all their loads issued before the first use; the last group re-reads the final point
@@ -2775,6 +2779,8 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 1>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 42 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
+  } else if (!COUNT && FUSE == 0 && bpts == 43 && refill_thresh(a.n) == 16) {
+    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 3>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr && getenv("TDTK_FAT_NODES") && getenv("TDTK_FAT_NODES")[0] == '1') {
     // two tree levels per round trip (KdFat): a measured negative, kept selectable -- see the comment at the walk
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, true>), dim3(nb), dim3(128), occ_lds, s, a);
