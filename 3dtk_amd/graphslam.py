@@ -238,7 +238,7 @@ def lum_iteration_native(gr, allScans, max_dist_match2, group=None, device=None)
         if s._h is None:                       # not resident on this rank: replay later, in order
             s._queue.append(xf[i, :16])
             s._queue.append(xf[i, 16:])
-        s.frames.append((tm[i], "LUM"))
+        s._addFrames("LUM", 2 if i == nscans - 1 else 1)     # lum6Deuler.cc:451-455: the last scan with islum == 2
     return ret.value
 
 
@@ -313,7 +313,7 @@ def graph_iteration_comm(backend, gr, allScans, max_dist_match2, comm, state=Non
             s._queue.append(xf[i, :16])
             if two:
                 s._queue.append(xf[i, 16:])
-        s.frames.append((tm[i], "LUM"))
+        s._addFrames("LUM", 2 if i == nscans - 1 else 1)     # lum6Deuler.cc:451-455: the last scan with islum == 2
     return ret.value
 
 
@@ -361,7 +361,7 @@ def graph_iteration(backend, gr, allScans, max_dist_match2, state=None, group=No
             s._queue.append(xf[i, :16])
             if two:
                 s._queue.append(xf[i, 16:])
-        s.frames.append((tm[i], "LUM"))
+        s._addFrames("LUM", 2 if i == nscans - 1 else 1)     # lum6Deuler.cc:451-455: the last scan with islum == 2
     return ret.value
 
 

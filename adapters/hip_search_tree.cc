@@ -11,7 +11,7 @@ static void tdtk_check(int rc)
   if (rc != TDTK_OK) throw std::runtime_error(std::string("lib3dtk_hip: ") + tdtk_last_error());
 }
 
-HipSearchTree::HipSearchTree(double** pts, int n, int bucketSize, int device) : tree_(0)
+HipSearchTree::HipSearchTree(double** pts, int n, int bucketSize, int device) : tree_(0), bucket_(bucketSize)
 {
   if (n <= 0) throw std::runtime_error("cannot create kdtree with zero points");
   std::vector<double> xyz(3 * (size_t)n);

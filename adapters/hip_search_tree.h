@@ -42,9 +42,11 @@ public:
                           double max_dist_match2, double& sum, double* centroid_m, double* centroid_d);
 
   tdtk_tree* handle() const { return tree_; }   // for icp6D_hip / lum6DEuler_hip
+  int bucketSize() const { return bucket_; }    // a MetaScan's tree takes its first member's (kdMeta.cc:45-46)
 
 private:
   tdtk_tree* tree_;
+  int bucket_;
   std::vector<double*> index_to_ptr_;  // model index -> the caller's point (FindClosest returns these)
 };
 

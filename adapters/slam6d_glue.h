@@ -1,0 +1,269 @@
+// The orchestration around the two plug points, in C++ and on the C ABI only: what bin/slam6D's own driver code does
+// between the matches -- matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548: sequential ICP, loop detection by pose
+// distance, loop closing, rounds of global relaxation), Graph(nodes, cldist2, loopsize) (src/slam6d/graph.cc:108-131),
+// elch6Deuler::close_loop (src/slam6d/elch6Deuler.cc:44-138) and icp6D::match between two MetaScans (what close_loop
+// asks for; Scan::getPtPairsParallel over the member scans, scan.cc:1305-1327) -- arranged the way this library wants
+// it driven: the next scans made resident and their trees built on worker threads while the current one is matched
+// (HipPrefetcher, icp_glue.h), all covariance passes of a loop closing in ONE batched device call, a MetaScan's
+// members moved by one launch.  Like icp_glue.h and graph_slam_glue.h it needs nothing from the reference but the SHAPE
+// of its Scan interface; adapters/harness/slam_glue_harness.cc instantiates it with a minimal scan type and is EXECUTED
+// on the GPU box, where tests/test_gpu_parity.py::test_slam_glue_executes compares every pose it ends with, bit for
+// bit, with the Python mirror (3dtk_amd/slam6d.py: matchGraph6Dautomatic, elch6Deuler, Graph) on the same scans.
+//
+// ScanT needs, beyond what icp_glue.h and graph_slam_glue.h ask for:
+//   const double* get_rPos(), get_rPosTheta();  int hipBucket();
+//   void transformToEuler(const double rP[3], const double rPT[3], int type, int islum)   (scan.cc:1061-1083; must move
+//        a resident copy too -- adapters/reference.patch makes Scan::transformReduced do that)
+// and one hook for the frame bookkeeping of a MetaScan's transform (scan.cc:962-975), which is the reference's own:
+//   static void metaFrames(const std::vector<ScanT*>& members, int type)
+#ifndef __SLAM6D_GLUE_H__
+#define __SLAM6D_GLUE_H__
+
+#include <algorithm>
+#include <cmath>
+#include <utility>
+
+#include "graph_slam_glue.h"
+#include "icp_glue.h"
+
+struct HipScanTypes { int invalid, icp, lum, elch; };      // Scan::INVALID, Scan::ICP, Scan::LUM, Scan::ELCH as ints
+
+// Graph(int nodes, double cldist2, int loopsize) (graph.cc:108-131): the chain, then every (j, k) with k - j > loopsize
+// whose poses are closer than cldist2, row by row
+struct HipClGraph {
+  int nrScans = 0;
+  std::vector<int> frm, to;
+  int getNrScans() const { return nrScans; }
+  int getNrLinks() const { return (int)frm.size(); }
+  int getLink(int i, int fromTo) const { return fromTo == 0 ? frm[i] : to[i]; }
+};
+template <class ScanT>
+HipClGraph hip_make_graph(int nodes, double cldist2, int loopsize, const std::vector<ScanT*>& allScans)
+{
+  HipClGraph g;
+  g.nrScans = nodes;
+  for (int i = 0; i + 1 < nodes; i++) { g.frm.push_back(i); g.to.push_back(i + 1); }
+  for (int j = 0; j < nodes; j++)
+    for (int k = j + 1; k < nodes; k++) {
+      if (!(k - j > loopsize)) continue;
+      const double* a = allScans[j]->get_rPos();
+      const double* b = allScans[k]->get_rPos();
+      const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+      if (dx * dx + dy * dy + dz * dz < cldist2) { g.frm.push_back(j); g.to.push_back(k); }
+    }
+  return g;
+}
+
+// Scan::transform of a MetaScan (scan.cc:920-926, metaScan.cc): every member moved -- the resident copies by one launch
+// -- and its matrices updated without frames of its own; the frames `islum == 0` asks for are the hook's business
+template <class ScanT>
+void hip_meta_transform(const std::vector<ScanT*>& members, const double alignxf[16], int type, int islum, const HipScanTypes& ty)
+{
+  std::vector<tdtk_scan*> hs;
+  std::vector<double> A;
+  for (ScanT* m : members) {
+    hs.push_back(m->hipResident());
+    A.insert(A.end(), alignxf, alignxf + 16);
+  }
+  if (!hs.empty() && tdtk_scans_transform2((int)hs.size(), hs.data(), A.data(), nullptr) != TDTK_OK)
+    throw std::runtime_error(tdtk_last_error());
+  for (ScanT* m : members) m->transformMatrixAndFrames(alignxf, ty.invalid, -1);
+  if (type != ty.invalid && islum == 0) ScanT::metaFrames(members, type);
+}
+
+// icp6D::match(MetaScan* model, MetaScan* data) (icp6D.cc:104-285 with Scan::getPtPairsParallel's MetaScan branch):
+// one search tree over the model members' CURRENT points (KDtreeMetaManaged, kdMeta.cc:34-134: concatenation order,
+// the first member's bucket size; a MetaScan's own dalignxf is the identity), per iteration one batched pass of every
+// data member through it, the base blocks merged (Align_Parallel's merge, icp6Dquat.cc:533-588), one Align, every data
+// member moved.  -a 1 / -a 2 only (what merges from the base block).  Returns the iteration count.
+template <class ScanT>
+int hip_meta_match(const std::vector<ScanT*>& model, const std::vector<ScanT*>& data, const HipIcpSettings& cfg,
+                   const HipScanTypes& ty, unsigned int* nr_pointPair)
+{
+  if (cfg.algo != TDTK_ALGO_QUAT && cfg.algo != TDTK_ALGO_SVD)
+    throw std::runtime_error("a MetaScan as data scan is matched with -a 1 or -a 2 only");
+  const double id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  hip_meta_transform(data, id, ty.icp, 0, ty);                       // icp6D.cc:109
+  if (cfg.max_num_iterations == 0) return 0;
+  std::vector<tdtk_scan*> ms;
+  for (ScanT* m : model) ms.push_back(m->hipResident());
+  tdtk_tree* tree = nullptr;
+  if (tdtk_tree_create_from_scans(ms.data(), (int)ms.size(), model[0]->hipBucket(), &tree) != TDTK_OK)
+    throw std::runtime_error(tdtk_last_error());
+  const int nl = (int)data.size();
+  std::vector<const tdtk_tree*> first(nl, tree);
+  std::vector<tdtk_scan*> second;
+  std::vector<double> dal;
+  for (ScanT* d : data) { second.push_back(d->hipResident()); dal.insert(dal.end(), id, id + 16); }
+  double ret = 0.0, prev_ret = 0.0, prev_prev_ret = 0.0;
+  int it = 0;
+  try {
+    for (it = 0; it < cfg.max_num_iterations; it++) {
+      prev_prev_ret = prev_ret; prev_ret = ret;
+      std::vector<tdtk_pair_sums> parts(nl);
+      tdtk_pair_sums merged;
+      if (tdtk_links_pair_sums(nl, first.data(), dal.data(), second.data(), cfg.max_dist_match2, 0, parts.data()) != TDTK_OK ||
+          tdtk_pair_sums_merge(nl, parts.data(), &merged) != TDTK_OK)
+        throw std::runtime_error(tdtk_last_error());
+      if (nr_pointPair) *nr_pointPair = (unsigned int)merged.n;
+      if (!(merged.n > 3)) break;                                       // icp6D.cc:235-245
+      double alignxf[16];
+      if (tdtk_align(cfg.algo, &merged, alignxf, &ret) != TDTK_OK) throw std::runtime_error(tdtk_last_error());
+      hip_meta_transform(data, alignxf, ty.icp, it == 0 ? 0 : -1, ty);  // icp6D.cc:246-252, anim = -1
+      if ((std::fabs(ret - prev_ret) < cfg.epsilonICP && std::fabs(ret - prev_prev_ret) < cfg.epsilonICP) ||
+          it == cfg.max_num_iterations - 1) {
+        hip_meta_transform(data, id, ty.icp, 0, ty);                    // write end pose
+        break;
+      }
+    }
+  } catch (...) {
+    tdtk_tree_destroy(tree);
+    throw;
+  }
+  tdtk_tree_destroy(tree);
+  return it;
+}
+
+// elch6Deuler::close_loop (-L 1, elch6Deuler.cc:44-138).  g: the loop-optimisation graph as (from, to) edges over scans
+// 0 .. n-1 (slam6D.cc:416-428 adds (i-1, i) for every matched scan and (first, last) after every closed loop).  Every
+// edge's covarianceEuler pass runs in ONE batched call; the six balancer runs and the pose distribution are host work.
+// delta_out (nullable): the six pose differences the meta match found ("Delta:" line of the reference).
+template <class ScanT>
+void hip_elch_close_loop_euler(std::vector<ScanT*>& allScans, int first, int last, const std::vector<std::pair<int, int>>& g,
+                               const HipIcpSettings& cfg, const HipScanTypes& ty, double* delta_out = nullptr)
+{
+  int n = 0;
+  for (const auto& e : g) n = std::max(n, std::max(e.first, e.second) + 1);   // num_vertices(g)
+  const int ne = (int)g.size();
+  std::vector<const tdtk_tree*> firsts(ne);
+  std::vector<tdtk_scan*> seconds(ne);
+  std::vector<double> dal(16 * (size_t)ne), blocks(42 * (size_t)ne);
+  std::vector<int32_t> from(ne), to(ne);
+  for (int e = 0; e < ne; e++) {
+    from[e] = g[e].first; to[e] = g[e].second;
+    firsts[e] = allScans[g[e].first]->hipTree();
+    seconds[e] = allScans[g[e].second]->hipResident();
+    std::memcpy(&dal[16 * (size_t)e], allScans[g[e].first]->getDAlign(), 16 * sizeof(double));
+  }
+  if (tdtk_graph_link_blocks(TDTK_GRAPH_LUMEULER, ne, firsts.data(), dal.data(), seconds.data(), cfg.max_dist_match2,
+                             blocks.data()) != TDTK_OK)
+    throw std::runtime_error(tdtk_last_error());
+  // edge weights: |diag(C^-1)| per pose component (elch6Deuler.cc:60-65)
+  std::vector<std::vector<double>> wts(6, std::vector<double>(ne));
+  for (int e = 0; e < ne; e++) {
+    double Cinv[36];
+    if (tdtk_invert(&blocks[42 * (size_t)e], 6, Cinv) != TDTK_OK) throw std::runtime_error(tdtk_last_error());
+    for (int j = 0; j < 6; j++) wts[j][e] = std::fabs(Cinv[7 * j]);
+  }
+  std::vector<std::vector<double>> weights(6, std::vector<double>(n, 0.0));
+  for (int j = 0; j < 6; j++)
+    if (tdtk_elch_graph_balancer(n, ne, from.data(), to.data(), wts[j].data(), first, last, weights[j].data()) != TDTK_OK)
+      throw std::runtime_error(tdtk_last_error());
+  for (int i = last - 2; i <= last; i++)
+    for (int j = 0; j < 6; j++) weights[j][i] = 0.0;
+  const std::vector<ScanT*> start = {allScans[first], allScans[first + 1], allScans[first + 2]};
+  const std::vector<ScanT*> end = {allScans[last - 2], allScans[last - 1], allScans[last]};
+  double delta[6];
+  for (int k = 0; k < 3; k++) { delta[k] = allScans[last]->get_rPos()[k]; delta[3 + k] = allScans[last]->get_rPosTheta()[k]; }
+  unsigned int pairs = 0;
+  (void)hip_meta_match(start, end, cfg, ty, &pairs);
+  for (int k = 0; k < 3; k++) {
+    delta[k] = allScans[last]->get_rPos()[k] - delta[k];
+    delta[3 + k] = allScans[last]->get_rPosTheta()[k] - delta[3 + k];
+  }
+  if (delta_out) std::memcpy(delta_out, delta, sizeof delta);
+  for (int i = 1; i < n; i++) {
+    double rP[3], rT[3];
+    for (int k = 0; k < 3; k++) {
+      rP[k] = allScans[i]->get_rPos()[k] + delta[k] * (weights[k][i] - weights[k][0]);
+      rT[k] = allScans[i]->get_rPosTheta()[k] + delta[3 + k] * (weights[3 + k][i] - weights[3 + k][0]);
+    }
+    allScans[i]->transformToEuler(rP, rT, ty.elch, i == n - 1 ? 2 : 1);
+  }
+}
+
+struct HipSlamSettings {
+  HipIcpSettings icp;        // the sequential matches (and, with its own max_dist_match2 / iterations, the ELCH meta match)
+  HipIcpSettings loop_icp;   // icp6D of the loop closer (loopSlam6D's own my_icp6D)
+  bool use_elch;             // -L 1
+  int graph_backend;         // TDTK_GRAPH_* of -G, or -1: no global relaxation
+  double cldist, mdml, epsilonSLAM, epsilonLUM;
+  int loopsize, nrIt, prefetch;
+  tdtk_comm* comm;           // nullable
+};
+
+// matchGraph6Dautomatic (slam6D.cc:387-548, without the -DlastSLAM pass and without meta_icp): returns the number of
+// global rounds it ran.  A scan's preparation (upload, ordering, tree build) runs up to `prefetch` scans ahead of the
+// match on worker threads; scan i + 1 is not part of the graph over scans 0 .. i, so the relaxation never touches a
+// scan that is being prepared, and every scan is made resident BEFORE its pose extrapolation, prepared ahead or not
+// (see hip_do_icp) -- the result does not depend on `prefetch`.
+template <class ScanT>
+int hip_match_graph6d_automatic(std::vector<ScanT*>& allScans, const HipSlamSettings& cfg, const HipScanTypes& ty)
+{
+  const double cldist2 = cfg.cldist * cfg.cldist;
+  const int n = (int)allScans.size();
+  int loop_detection = 0, rounds = 0, first = 0, last = 0;
+  double min_dist = -1.0;
+  std::vector<std::pair<int, int>> g;
+  auto global_rounds = [&](int nodes) {
+    int j = 0;
+    double ret;
+    std::vector<ScanT*> sub(allScans.begin(), allScans.begin() + nodes);
+    do {
+      HipClGraph gr = hip_make_graph(nodes, cldist2, cfg.loopsize, allScans);
+      ret = hip_graph_slam(cfg.graph_backend, gr, sub, 1, cfg.epsilonLUM, cfg.mdml * cfg.mdml, cfg.comm, ty.invalid, ty.lum);
+      j++; rounds++;
+    } while (j < cfg.nrIt && ret > cfg.epsilonSLAM);
+  };
+  HipPrefetcher* pool = (cfg.prefetch > 0 && n > 2) ? new HipPrefetcher(cfg.prefetch) : nullptr;
+  try {
+    for (int i = 0; i < n; i++) {
+      if (pool) {
+        for (int j = i; j < n && j <= i + cfg.prefetch; j++) {
+          ScanT* s = allScans[j];
+          pool->submit((size_t)j, [s] { (void)s->hipResident(); (void)s->hipTree(); });
+        }
+        if (i > 0) pool->wait((size_t)i - 1);
+        pool->wait((size_t)i);
+      }
+      if (i == 0) continue;
+      g.push_back({i - 1, i});
+      (void)allScans[i]->hipResident();
+      if (cfg.icp.eP) allScans[i]->mergeCoordinatesWithRoboterPosition(allScans[i - 1]);
+      unsigned int pairs = 0;
+      (void)hip_icp_match(allScans[i - 1], allScans[i], cfg.icp, &pairs);
+      if (loop_detection == 1) loop_detection = 2;
+      for (int j = 0; j < i - cfg.loopsize; j++) {
+        const double* a = allScans[j]->get_rPos();
+        const double* b = allScans[i]->get_rPos();
+        const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+        const double dist = dx * dx + dy * dy + dz * dz;
+        if (dist < cldist2) {
+          loop_detection = 1;
+          if (min_dist < 0 || dist < min_dist) { min_dist = dist; first = j; last = i; }
+        }
+      }
+      if (loop_detection == 2) {
+        loop_detection = 0;
+        min_dist = -1.0;
+        if (cfg.use_elch) {
+          hip_elch_close_loop_euler(allScans, first, last, g, cfg.loop_icp, ty);
+          g.push_back({first, last});
+        }
+        if (cfg.graph_backend >= 0 && cfg.mdml > 0) global_rounds(i + 1);
+      }
+    }
+  } catch (...) {
+    delete pool;
+    throw;
+  }
+  delete pool;
+  if (loop_detection == 1 && cfg.use_elch) {
+    hip_elch_close_loop_euler(allScans, first, last, g, cfg.loop_icp, ty);
+    g.push_back({first, last});
+  }
+  if (cfg.graph_backend >= 0 && cfg.mdml > 0.0) global_rounds(n);
+  return rounds;
+}
+
+#endif

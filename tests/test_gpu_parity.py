@@ -1533,6 +1533,57 @@ def test_icp_glue_executes(gpu):
     assert r.returncode == 0 and "ICP GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_slam_glue_executes(tdtk, gpu, tmp_path):
+    """adapters/slam6d_glue.h executed (adapters/harness/slam_glue_harness.cc): matchGraph6Dautomatic in C++ on the C ABI
+    -- sequential ICP with scans prepared ahead, loop detection, ELCH loop closing (batched covariance passes, balancer,
+    MetaScan-against-MetaScan match), global lum6DEuler rounds through graph_slam_glue.h -- ends, on the same scans, in
+    the poses of the Python mirror (matchGraph6Dautomatic + elch6Deuler + Graph + the library's graph iteration), bit
+    for bit, with the same number of frames per scan and of global rounds; prefetch depth 3 == none (checked by the
+    harness itself)."""
+    import subprocess
+    from importlib import import_module
+    gs = import_module("3dtk_amd.graphslam")
+    exe = os.path.join(os.path.dirname(HERE), "adapters", "harness", "_bin", "slam_glue_harness")
+    if not os.path.exists(exe):
+        r = subprocess.run([os.path.join(os.path.dirname(HERE), "adapters", "harness", "build_glue.sh")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    r = subprocess.run([exe, fin, fout, "15", "30000", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SLAM GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
+    raw = np.fromfile(fin, dtype=np.uint8)
+    nscans, npts = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
+    body = np.frombuffer(raw[8:].tobytes(), dtype=np.float64).reshape(nscans, 6 + 3 * npts)
+    out = np.fromfile(fout, dtype=np.uint8)
+    tm_cpp = np.frombuffer(out[:nscans * 128].tobytes(), dtype=np.float64).reshape(nscans, 16)
+    tail = np.frombuffer(out[nscans * 128:].tobytes(), dtype=np.int32)
+    frames_cpp, rounds_cpp = tail[:nscans], int(tail[nscans])
+    assert rounds_cpp >= 2          # the loop was detected and relaxed (else the scenario tests nothing)
+
+    S = [tdtk.Scan(body[k, :3], body[k, 3:6], body[k, 6:].reshape(-1, 3)) for k in range(nscans)]
+    tdtk.Scan.allScans = S
+    try:
+        class Relax:                # the -G 1 plug point served by the library's own iteration, like graph_slam_glue.h
+            def doGraphSlam6D(self, gr, allScans, nrIt):
+                ret, it = float("inf"), 0
+                while it < nrIt and ret > 0.5:
+                    ret = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, allScans, 25.0 ** 2, None)
+                    it += 1
+                return ret
+        mini = tdtk.icp6D_QUAT(True)
+        icp = tdtk.icp6D(mini, 25.0, 30, quiet=True, epsilonICP=1e-5)
+        loop = tdtk.elch6Deuler(True, mini, 25.0, 30, epsilonICP=1e-5)
+        rounds = tdtk.matchGraph6Dautomatic(90.0, 6, S, icp, False, Relax(), 3, 0.05, 25.0, eP=True, prefetch=True,
+                                            my_loopSlam6D=loop)
+        assert rounds == rounds_cpp
+        tm_py = np.stack([s.transMat for s in S])
+        assert tm_py.tobytes() == tm_cpp.tobytes(), float(np.abs(tm_py - tm_cpp).max())
+        assert [len(s.frames) for s in S] == frames_cpp.tolist()
+        # and the loop closing did something: the last scan ends nearer to the truth than its odometry said
+        assert np.abs(tm_cpp[-1, 12:15] - body[-1, :3]).max() > 0.5
+    finally:
+        tdtk.Scan.allScans = []
+
+
 def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
     other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane) walk the same tree the

@@ -457,6 +457,15 @@ def test_icp_glue_harness_compiles_and_links(tdtk):
     if tdtk.device_count() == 0:
         out = subprocess.run([exe, "3", "2000"], capture_output=True, text=True, timeout=120)
         assert out.returncode == 1 and "no HIP device" in out.stdout, out.stdout + out.stderr
+    # adapters/slam6d_glue.h (matchGraph6Dautomatic, ELCH close_loop, MetaScan match, Graph) + graph_slam_glue.h likewise
+    exe2 = os.path.join(ROOT, "adapters", "harness", "_bin", "slam_glue_harness")
+    assert os.path.exists(exe2)
+    if tdtk.device_count() == 0:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            out = subprocess.run([exe2, os.path.join(d, "in.bin"), os.path.join(d, "out.bin"), "4", "500"], capture_output=True,
+                                 text=True, timeout=120)
+        assert out.returncode == 1 and "no HIP device" in out.stdout, out.stdout + out.stderr
 
 
 def test_link_dealing_round_robin_and_lpt(tdtk):
