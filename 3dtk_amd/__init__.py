@@ -25,5 +25,5 @@ from .slam6d import (KDtree, Scan, icp6Dminimizer, icp6D_QUAT, icp6D_SVD, icp6D_
                      icp6D_NAPX, icp6D, Graph, lum6DEuler, lum6DQuat, ghelix6DQ2, gapx6D, QuatToMatrix4, Matrix4ToQuat, M4inv, MMult, M4identity,
                      EulerToMatrix4, Matrix4ToEuler, host_tree_layout, calculateNormalsApxKNN, MetaScan, read_uos, read_pose,
                      openDirectory, closeDirectory, saveFrames, matchGraph6Dautomatic, calcReducedPoints,
-                     computeGraph6Dautomatic, matchGraph6Dautomatic_clpairs, prepare_scans, loopSlam6D, elch6Deuler,
+                     computeGraph6Dautomatic, matchGraph6Dautomatic_clpairs, prepare_scans, loopSlam6D, elch6Deuler, elch6Dquat, elch6DunitQuat, elch6Dslerp,
                      graph_balancer)

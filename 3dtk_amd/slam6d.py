@@ -1220,6 +1220,144 @@ class elch6Deuler(loopSlam6D):
             allScans[i].transformToEuler(rP, rT, "ELCH", 2 if i == n - 1 else 1)
 
 
+def _qmul(a, b):
+    """Hamilton product, (w, x, y, z) (QMult, globals.icc:1112-1117)"""
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                     a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                     a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def _qunit(q):
+    """Normalize4 (globals.icc:267-275)"""
+    q = np.asarray(q, dtype=np.float64)
+    return q / math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+
+
+def _slerp(qa, qb, t):
+    """slerp (globals.icc:1123-1166): qa where the two coincide, the normalised mean where they are opposite"""
+    c = qa[0] * qb[0] + qa[1] * qb[1] + qa[2] * qb[2] + qa[3] * qb[3]
+    if abs(c) >= 1.0:
+        return np.array(qa, dtype=np.float64)
+    half = math.acos(c)
+    sn = math.sqrt(1.0 - c * c)
+    if abs(sn) < 0.001:
+        return _qunit(np.asarray(qa) * 0.5 + np.asarray(qb) * 0.5)
+    ra, rb = math.sin((1 - t) * half) / sn, math.sin(t * half) / sn
+    return _qunit(np.asarray(qa) * ra + np.asarray(qb) * rb)
+
+
+class _elchQuatBase(loopSlam6D):
+    """What -L 2 / 3 / 4 share: one lum6DQuat::covarianceQuat pass per edge of the loop graph -- all of them in ONE batched
+    device call --, C = C.i(), edge weights from |diag C| (seven of them, or three translations + the sum of the four
+    quaternion entries), one graph_balancer run per weight set."""
+
+    def _weights(self, allScans, first, last, g, combine):
+        n = max(max(a, b) for a, b in g) + 1
+        edges = list(g)
+        ne = len(edges)
+        firsts = (C.c_void_p * ne)(*[allScans[a].getSearchTree()._h for a, b in edges])
+        seconds = (C.c_void_p * ne)(*[allScans[b].handle for a, b in edges])
+        dal = np.ascontiguousarray(np.stack([allScans[a].dalignxf for a, b in edges]))
+        blocks = np.empty((ne, 56))
+        check(lib().tdtk_graph_link_blocks(2, ne, firsts, dptr(dal), seconds, float(self.my_icp6D.max_dist_match2), dptr(blocks)))
+        nw = 4 if combine else 7
+        wts = np.empty((nw, ne))
+        for e in range(ne):
+            Cinv = np.empty((7, 7))
+            Cm = np.ascontiguousarray(blocks[e, :49].reshape(7, 7))
+            check(lib().tdtk_invert(dptr(Cm), 7, dptr(Cinv)))
+            d = np.abs(np.diag(Cinv))
+            if combine:
+                wts[:3, e] = d[:3]
+                wts[3, e] = d[3] + d[4] + d[5] + d[6]
+            else:
+                wts[:, e] = d
+        return n, [graph_balancer(n, edges, wts[j], first, last) for j in range(nw)]
+
+
+class elch6Dquat(_elchQuatBase):
+    """-L 2 (src/slam6d/elch6Dquat.cc:44-148): like elch6Deuler with the pose as position + quaternion, each of the seven
+    components distributed linearly and the quaternion renormalised."""
+
+    def close_loop(self, allScans, first, last, g):
+        n, weights = self._weights(allScans, first, last, g, False)
+        start = MetaScan([allScans[first], allScans[first + 1], allScans[first + 2]])
+        end = MetaScan([allScans[last - 2], allScans[last - 1], allScans[last]])
+        for i in range(last - 2, last + 1):
+            for j in range(7):
+                weights[j][i] = 0.0
+        before = np.concatenate([allScans[last].get_rPos(), allScans[last].get_rPosQuat()])
+        self.my_icp6D.match(start, end)
+        delta = np.concatenate([allScans[last].get_rPos(), allScans[last].get_rPosQuat()]) - before
+        self.last_delta = delta
+        for i in range(1, n):
+            w = np.array([weights[k][i] - weights[k][0] for k in range(7)])
+            rP = allScans[i].get_rPos() + delta[:3] * w[:3]
+            rQ = _qunit(allScans[i].get_rPosQuat() + delta[3:] * w[3:])
+            allScans[i].transformToQuat(rP, rQ, "ELCH", 2 if i == n - 1 else 1)
+
+
+class elch6DunitQuat(_elchQuatBase):
+    """-L 3 (src/slam6d/elch6DunitQuat.cc:45-199): the rotation of the loop error as ONE unit quaternion deltaQ =
+    q_after * conj(q_before) of the last scan, applied to scan i blended linearly with weight w_i (and renormalised), the
+    whole chain counter-rotated so that scan 0 stays where it is; the three matched scans are put back first."""
+
+    def close_loop(self, allScans, first, last, g):
+        n, weights = self._weights(allScans, first, last, g, True)
+        start = MetaScan([allScans[first], allScans[first + 1], allScans[first + 2]])
+        end = MetaScan([allScans[last - 2], allScans[last - 1], allScans[last]])
+        old = [(allScans[k].get_rPos().copy(), allScans[k].get_rPosQuat().copy()) for k in (last, last - 1, last - 2)]
+        p_before = allScans[last].get_rPos().copy()
+        q1 = allScans[last].get_rPosQuat() * np.array([1.0, -1.0, -1.0, -1.0])
+        self.my_icp6D.match(start, end)
+        delta = allScans[last].get_rPos() - p_before
+        deltaQ = _qmul(allScans[last].get_rPosQuat(), q1)
+        self.last_delta = np.concatenate([delta, deltaQ])
+        for k, (p, q) in zip((last, last - 1, last - 2), old):            # restore the poses the match moved
+            allScans[k].transformToQuat(p, q, "INVALID", -1)
+        q0 = allScans[0].get_rPosQuat()
+        w0 = weights[3][0]
+        s0 = ((1 - w0) * q0 + _qmul(deltaQ, q0) * w0) * np.array([1.0, -1.0, -1.0, -1.0])
+        counter = _qmul(q0, _qunit(s0))
+        for i in range(1, n):
+            rP = allScans[i].get_rPos() + delta * np.array([weights[k][i] - weights[k][0] for k in range(3)])
+            qi = allScans[i].get_rPosQuat()
+            wi = weights[3][i]
+            blended = _qunit((1 - wi) * qi + _qmul(deltaQ, qi) * wi)
+            allScans[i].transformToQuat(rP, _qunit(_qmul(counter, blended)), "ELCH", 2 if i == n - 1 else 1)
+
+
+class elch6Dslerp(_elchQuatBase):
+    """-L 4 (src/slam6d/elch6Dslerp.cc:44-184): the loop error as a rigid motion deltaf in the frame of scan `first`,
+    its rotation interpolated on the sphere (slerp from the identity by w_i) and its translation scaled per axis; larger
+    MetaScans (first-2 .. first+2 against last-2 .. last); the matched scans take the motion of weight w_0 only."""
+
+    def close_loop(self, allScans, first, last, g):
+        n, weights = self._weights(allScans, first, last, g, True)
+        start = MetaScan([allScans[i] for i in range(first - 2, first + 3) if i >= 0])
+        end = MetaScan([allScans[i] for i in range(last - 2, last + 1) if i < n])
+        Pl0 = allScans[last].get_transMat().copy()
+        self.my_icp6D.match(start, end)
+        Pp0 = allScans[last].get_transMat().copy()
+        Pf0 = allScans[first].get_transMat().copy()
+        Pf0_inv = M4inv(Pf0)
+        deltaf = MMult(Pf0_inv, MMult(Pp0, M4inv(MMult(Pf0_inv, Pl0))))
+        deltaQ, deltaT = Matrix4ToQuat(deltaf)
+        self.last_delta = np.concatenate([deltaT, deltaQ])
+        idQ = np.array([1.0, 0.0, 0.0, 0.0])
+
+        def part(i):       # the share of scan i of the loop error
+            return QuatToMatrix4(_slerp(idQ, deltaQ, weights[3][i]), np.array([deltaT[k] * weights[k][i] for k in range(3)]))
+        delta0 = MMult(Pf0, M4inv(part(0)))
+        for i in range(1, n):
+            if last - 2 <= i <= last:
+                M = MMult(delta0, Pf0_inv)
+            else:
+                M = MMult(MMult(delta0, part(i)), Pf0_inv)
+            allScans[i].transform(M, "ELCH", 2 if i == n - 1 else 1)
+
+
 def computeGraph6Dautomatic(allScans, clpairs, max_dist_match2_LUM=625.0, group=None, device=None):
     """graphSlam6D::computeGraph6Dautomatic / the graph step of matchGraph6Dautomatic(allScans, nrIt,
     clpairs, loopsize) (src/slam6d/graphSlam6D.cc:82-133, 136-180): a link (j, k) for every ordered pair

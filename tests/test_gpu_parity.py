@@ -1584,6 +1584,47 @@ def test_slam_glue_executes(tdtk, gpu, tmp_path):
         tdtk.Scan.allScans = []
 
 
+@pytest.mark.parametrize("variant", ["elch6Deuler", "elch6Dquat", "elch6DunitQuat", "elch6Dslerp"])
+def test_elch_variants_distribute_a_loop_error(tdtk, gpu, variant):
+    """-L 1 .. 4 (elch6Deuler / elch6Dquat / elch6DunitQuat / elch6Dslerp::close_loop; parity UNPINNED -- their TUs need
+    Boost.Graph): thirteen scans of one cloud around a closed path whose odometry drifts linearly; closing the loop
+    (0, 12) over the chain graph must take the drift out of the scans in between in proportion -- the error of every
+    scan from the third on drops below a third of what it was (the three matched scans at the end move as one rigid
+    MetaScan and keep their relative drift), scan 0 stays, and the four
+    interpolation rules agree with each other to a fraction of the drift."""
+    rng = np.random.default_rng(5)
+    world = rng.uniform(-400, 400, (20000, 3))
+    n = 13
+    truth, S = [], []
+    for k in range(n):
+        ang = 2 * np.pi * k / 12.0
+        tP = np.array([120 * np.sin(ang), 3 * np.sin(2 * ang), 120 * (1 - np.cos(ang))])
+        tT = np.array([0.01 * np.sin(ang), 0.15 * np.sin(ang), 0.008 * np.cos(ang) - 0.008])
+        Ti = tdtk.M4inv(tdtk.EulerToMatrix4(tP, tT)).reshape(4, 4)
+        w = world + rng.uniform(-0.2, 0.2, world.shape)
+        local = w @ Ti[:3, :3] + Ti[3, :3]
+        drift = 0.35 * k
+        S.append(tdtk.Scan(tP + drift * np.array([1.0, -0.3, 0.6]), tT + np.array([0.0, 0.0006 * k, 0.0]), local))
+        truth.append(tP)
+    truth = np.array(truth)
+    before = np.linalg.norm(np.array([s.get_rPos() for s in S]) - truth, axis=1)
+    tdtk.Scan.allScans = S
+    try:
+        loop = getattr(tdtk, variant)(True, tdtk.icp6D_QUAT(True), 25.0, 40, epsilonICP=1e-6)
+        loop.close_loop(S, 0, n - 1, [(i - 1, i) for i in range(1, n)])
+        pos = np.array([s.get_rPos() for s in S])
+    finally:
+        tdtk.Scan.allScans = []
+    after = np.linalg.norm(pos - truth, axis=1)
+    assert after[0] == before[0] == 0.0 or after[0] < 1e-9
+    assert (after[3:] < before[3:] / 3.0).all(), (before, after)
+    ref = getattr(test_elch_variants_distribute_a_loop_error, "_first", None)
+    if ref is None:
+        test_elch_variants_distribute_a_loop_error._first = pos
+    else:
+        assert np.abs(pos - ref).max() < 1.0, np.abs(pos - ref).max()
+
+
 def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
     other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane) walk the same tree the
