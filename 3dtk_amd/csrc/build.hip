@@ -125,6 +125,21 @@ __device__ __forceinline__ void lds_chain32(double& sum, const double* b, uint32
       : "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (t < v) ? t : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (v < t) ? t : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_add(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
 // ---- per node: bounding box + the reference's left-to-right fp64 sum ----------------------------
 // One wavefront per (node, axis).  Each step the wave loads 64 consecutive values (one coalesced
 // 512-B instruction, the next chunk prefetched while the current one is folded), updates the
@@ -202,6 +217,74 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
 }
 
 
+// The same for every node below the piecewise path's threshold, ONE wavefront per node and all three axes in it (round 3).
+// k_measure's wave per (node, axis) is sized for long chains: 33 KB of LDS per workgroup and 128 registers per lane keep
+// four workgroups on a compute unit, and a level of many small nodes (65 000 of 15 points at level 16 of a 1M-point tree:
+// 196 000 waves) runs as 48 generations of waves that each wait out two dependent round trips to memory for a chain of a
+// few adds -- 139 us for that level, 29 us for every level from 9 to 12.  Here a wave loads 64 points of its node per
+// step (three coalesced instructions, the next step's requested before the current one is folded), keeps the bounding
+// boxes per lane, parks the values in LDS, and lane 0 alone folds the three sums -- three independent chains side by
+// side (issue-bound at 24 cycles per point: worse than three waves at 10 for a long chain, which is why the host picks
+// this kernel for the levels of small nodes only).  12 KB of LDS per workgroup, eight waves per SIMD.
+#define MN_CH 64
+__global__ void __launch_bounds__(256) k_measure_node(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                      const double* __restrict__ cx, const double* __restrict__ cy,
+                                                      const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
+{
+  __shared__ alignas(16) double stage[256 / WAVE][2][3][MN_CH];
+  const uint32_t sgi = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (sgi >= lv->nseg) return;
+  const uint32_t s = __builtin_amdgcn_readfirstlane(segs[sgi].start);
+  const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
+  if (n >= big_min) return;   // measured by the piecewise path (k_big_*)
+  const double* __restrict__ ax = cx + s;
+  const double* __restrict__ ay = cy + s;
+  const double* __restrict__ az = cz + s;
+  double(*buf)[3][MN_CH] = stage[threadIdx.x / WAVE];
+  const double fx = ax[0], fy = ay[0], fz = az[0];
+  double lox = fx, hix = fx, loy = fy, hiy = fy, loz = fz, hiz = fz;
+  double sx = fx, sy = fy, sz = fz;          // the sums start from the first point (kdTreeImpl.h:97-101); lane 0's count
+  double vx = (lane < n) ? ax[lane] : fx, vy = (lane < n) ? ay[lane] : fy, vz = (lane < n) ? az[lane] : fz;
+  int cur = 0;
+  for (uint32_t base = 0; base < n; base += MN_CH, cur ^= 1) {
+    const uint32_t cnt = (n - base < MN_CH) ? (n - base) : MN_CH;
+    lox = (vx < lox) ? vx : lox; hix = (hix < vx) ? vx : hix;   // lanes past the end carry the first point: harmless
+    loy = (vy < loy) ? vy : loy; hiy = (hiy < vy) ? vy : hiy;
+    loz = (vz < loz) ? vz : loz; hiz = (hiz < vz) ? vz : hiz;
+    buf[cur][0][lane] = vx; buf[cur][1][lane] = vy; buf[cur][2][lane] = vz;
+    const uint32_t nb = base + MN_CH + lane;
+    vx = (nb < n) ? ax[nb] : fx; vy = (nb < n) ? ay[nb] : fy; vz = (nb < n) ? az[nb] : fz;   // the next step
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const double* __restrict__ bx = buf[cur][0];
+      const double* __restrict__ by = buf[cur][1];
+      const double* __restrict__ bz = buf[cur][2];
+      uint32_t k = (base == 0) ? 1u : 0u;    // ... and add the rest in order
+      for (; k + 4 <= cnt; k += 4) {
+        double rx[4], ry[4], rz[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { rx[q] = bx[k + q]; ry[q] = by[k + q]; rz[q] = bz[k + q]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { sx += rx[q]; sy += ry[q]; sz += rz[q]; }
+      }
+      for (; k < cnt; k++) { sx += bx[k]; sy += by[k]; sz += bz[k]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  lox = wave_min(lox); hix = wave_max(hix);
+  loy = wave_min(loy); hiy = wave_max(hiy);
+  loz = wave_min(loz); hiz = wave_max(hiz);
+  if (lane == 0) {
+    BMeas m;
+    m.lo[0] = lox; m.lo[1] = loy; m.lo[2] = loz;
+    m.hi[0] = hix; m.hi[1] = hiy; m.hi[2] = hiz;
+    m.mean[0] = sx / (double)n; m.mean[1] = sy / (double)n; m.mean[2] = sz / (double)n;
+    out[sgi] = m;
+  }
+}
+
 // ---- big nodes: the same left-to-right fp64 sum, without walking it one add at a time --------------------------
 // The reference's centroid is s <- fl(s + x_i) over the node's points in run order: a million roundings at the root,
 // each depending on the one before.  While the running sum stays inside one binade [2^e, 2^(e+1)) every rounding is
@@ -275,21 +358,6 @@ struct BSumOp {
     return r;
   }
 };
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (t < v) ? t : v; }
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (v < t) ? t : v; }
-  return v;
-}
-__device__ __forceinline__ double wave_add(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
-}
 // slot of a piece: block q of positions holds at most the tail of one big node (it starts at the block's first
 // position: slot 2q) and the head of the next (it starts inside the block, behind that node's first point: slot 2q+1).
 // The pieces of node (start a, n points) in run order: the first one is a head piece unless a + 1 is block-aligned.
@@ -1040,6 +1108,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     const uint32_t nblocks = cdiv(M, BIG_CH);
     static const bool chain_only = [] { const char* e = getenv("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
     const bool use_big = !chain_only && M >= BIG_MIN;
+    // TDTK_MEASURE=axis: round 2's wave per (node, axis) for the nodes below the piecewise path (k_measure); default: a wave
+    // per node (k_measure_node).  With TDTK_BUILD_CHAIN=1 (no piecewise path: chains of any length) the long-chain kernel.
+    static const bool measure_axis_env = [] { const char* e = getenv("TDTK_MEASURE"); return e && e[0] == 'a'; }();
+    const bool measure_per_axis_always = measure_axis_env || chain_only;
     const int big_dbg_all = getenv("TDTK_BIG_DEBUG") ? atoi(getenv("TDTK_BIG_DEBUG")) : 0;
     const int big_dbg = big_dbg_all & (3 | 16);   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
@@ -1059,6 +1131,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     uint32_t level = 0, known = 1, known_at = 0;
     uint32_t batch = 1;
     for (size_t c = (size_t)(bucket > 0 ? bucket : 1); c < M_; c <<= 1) batch++;
+    batch += 2;   // mean splits do not halve: a 1M-point cloud is 18-19 levels deep, not 17, and a level past the end of the
+                  // tree costs less than the host's look (it moves nothing)
+    std::vector<BLevel> hl;
+    uint32_t h_small[3] = {0u, 0u, 0u};
     for (;;) {
       for (uint32_t b = 0; b < batch && level < BUILD_MAX_LEVELS; b++, level++) {
         size_t bound = (size_t)known << ((level - known_at) < 31 ? (level - known_at) : 31);
@@ -1070,11 +1146,19 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         if (level > 0 && bound > cap) bound = cap;
         if (bound < 1) bound = 1;
         const BLevel* lv = lvl + level;
-        // nodes of BIG_MIN points and more can only exist while a quarter of a balanced node is that large (below that
-        // level the chain in k_measure takes them, whatever their size)
-        const bool big_level = use_big && ((M_ >> level) >= BIG_MIN / 4);
-        hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
-                           big_level ? BIG_MIN : 0xFFFFFFFFu);
+        // the piecewise path runs while a balanced node is at least half its threshold (below that level the chain in
+        // k_measure takes every node, whatever its size: an empty pass of the piecewise kernels costs 75 us)
+        const bool big_level = use_big && ((M_ >> level) >= BIG_MIN / 2);
+        // a wave per node while the nodes of a balanced tree hold at most 128 points (three chains in one wave issue 24
+        // cycles per point where three waves need 10: level 7 of a 1M-point tree 253 us against 46, level 12 equal,
+        // level 16 74 against 139)
+        const bool measure_per_axis = measure_per_axis_always || (M_ >> level) > 128;
+        if (measure_per_axis)
+          hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
+                             big_level ? BIG_MIN : 0xFFFFFFFFu);
+        else
+          hipLaunchKernelGGL(k_measure_node, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
+                             big_level ? BIG_MIN : 0xFFFFFFFFu);
         if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE), 3), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
@@ -1126,29 +1210,23 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         }
         BSeg* t = segs; segs = next; next = t;
       }
-      uint32_t bad = 0;
-      BLevel nx = {0u, 0u, 0u};
-      BCHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
-      BCHK(hipMemcpyAsync(&nx, lvl + level, sizeof nx, hipMemcpyDeviceToHost, s));
+      // one look per batch: the level counters so far and the root reference / largest bucket / error word together
+      hl.assign(level + 1, BLevel{0u, 0u, 0u});
+      BCHK(hipMemcpyAsync(hl.data(), lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
+      BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
       BCHK(hipStreamSynchronize(s));
-      if (bad || (nx.nseg && level >= BUILD_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
+      const BLevel nx = hl[level];
+      if (h_small[2] || (nx.nseg && level >= BUILD_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
       if (nx.nseg == 0) break;
       known = nx.nseg; known_at = level;
       batch = 2;
     }
     {
       // the first level without nodes: its counters are the totals, its index the depth of the tree
-      std::vector<BLevel> hl(level + 1);
-      BCHK(hipMemcpyAsync(hl.data(), lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
-      BCHK(hipStreamSynchronize(s));
       depth = 0;
       while (depth < level && hl[depth].nseg) depth++;
       node_count = hl[depth].node_base; leaf_count = hl[depth].leaf_base;
     }
-    uint32_t h_small[3];
-    BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
-    BCHK(hipStreamSynchronize(s));
-    if (h_small[2]) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
     res.max_leaf = h_small[1];
     res.cb = bits_for(res.max_leaf);
     res.table_mode = (bits_for(M) + res.cb) > 30;
