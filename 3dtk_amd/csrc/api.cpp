@@ -45,6 +45,10 @@ static double now_ms()
 // ------------------------------------------------------------------------------------------
 // per-thread, per-device context: stream, events, growable workspaces
 // ------------------------------------------------------------------------------------------
+// the arrays of trees and resident scans come from the pool (pool.cpp); the per-context workspaces below stay plain
+// allocations (they live as long as the thread's context)
+static inline hipError_t handle_malloc(void** p, size_t bytes) { return (hipError_t)pool_malloc_raw(p, bytes); }
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -264,7 +268,7 @@ struct tdtk_tree {
     (void)hipSetDevice(device);
     void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot, d_grp, d_fat};
     for (void* q : p)
-      if (q) (void)hipFree(q);
+      if (q) pool_free(q);
   }
 };
 
@@ -286,8 +290,8 @@ struct tdtk_scan {
     (void)hipSetDevice(device);
     double* p[] = {x, y, z, nx, ny, nz, ox, oy, oz};
     for (double* q : p)
-      if (q) (void)hipFree(q);
-    if (d_order) (void)hipFree(d_order);
+      if (q) pool_free(q);
+    if (d_order) pool_free(d_order);
   }
 };
 
@@ -296,6 +300,8 @@ extern "C" {
 
 const char* tdtk_last_error(void) { return g_err.c_str(); }
 const char* tdtk_version(void) { return "3dtk_amd 0.1 (gfx950)"; }
+
+size_t tdtk_pool_trim(void) { return pool_trim(); }
 
 int tdtk_device_count(void)
 {
@@ -309,9 +315,9 @@ static int scan_keep_original(Ctx* c, tdtk_scan* s)
 {
   if (!s || !s->track_original || s->ox || s->N == 0) return TDTK_OK;
   const size_t b = s->N * sizeof(double);
-  HIPCHK(hipMalloc((void**)&s->ox, b));
-  HIPCHK(hipMalloc((void**)&s->oy, b));
-  HIPCHK(hipMalloc((void**)&s->oz, b));
+  HIPCHK(handle_malloc((void**)&s->ox, b));
+  HIPCHK(handle_malloc((void**)&s->oy, b));
+  HIPCHK(handle_malloc((void**)&s->oz, b));
   HIPCHK(hipMemcpyAsync(s->ox, s->x, b, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s->oy, s->y, b, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s->oz, s->z, b, hipMemcpyDeviceToDevice, c->stream));
@@ -380,13 +386,13 @@ static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
   // offsets into the point and group arrays, int32 starts of the leaf table
   if (G == 0 || slots * sizeof(KdPoint) >= (1ull << 32) || (!leaf && (slots << cb) > (uint64_t)REF_VAL)) return TDTK_OK;
   void *ptsP = nullptr, *grp = nullptr;
-  HIPCHK(hipMalloc(&ptsP, slots * sizeof(KdPoint)));
-  if (hipMalloc(&grp, (size_t)G * 48) != hipSuccess) { (void)hipFree(ptsP); set_error("hipMalloc failed"); return TDTK_ENOMEM; }
+  HIPCHK(handle_malloc(&ptsP, slots * sizeof(KdPoint)));
+  if (handle_malloc(&grp, (size_t)G * 48) != hipSuccess) { pool_free(ptsP); set_error("hipMalloc failed"); return TDTK_ENOMEM; }
   hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
                                  static_cast<KdPoint*>(ptsP), static_cast<float4*>(grp), c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) { (void)hipFree(ptsP); (void)hipFree(grp); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
-  (void)hipFree(t->d_pts);
+  if (e != hipSuccess) { pool_free(ptsP); pool_free(grp); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
+  pool_free(t->d_pts);
   t->d_pts = ptsP; t->d_grp = grp; t->Mp = (size_t)slots;
   return TDTK_OK;
 }
@@ -401,7 +407,7 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   for (int a = 0; a < 3; a++) am = std::max(am, std::max(std::fabs(t->bbmin[a]), std::fabs(t->bbmax[a])));
   t->dev.absmax = (float)std::min(am * 1.0000002, 3.0e38);
   if (t->info.n_internal) {
-    HIPCHK(hipMalloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
+    HIPCHK(handle_malloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
     HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream));
     // ... and, on request only, the two-level records (a node with its children's hot parts): two tree levels per round
     // trip are a measured negative both for the persistent-lane kernel (TDTK_FAT_NODES=1) and for the lane-group kernels of
@@ -411,7 +417,7 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
       return (a && a[0] == '1') || (b && b[0] == '1');
     }();
     if (want_fat) {
-      HIPCHK(hipMalloc(&t->d_fat, t->info.n_internal * sizeof(KdFat)));
+      HIPCHK(handle_malloc(&t->d_fat, t->info.n_internal * sizeof(KdFat)));
       HIPCHK(launch_make_fat(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdFat*>(t->d_fat), c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1382,9 +1388,9 @@ int tdtk_scan_calc_normals(tdtk_scan* sc, int k, const double rPos[3], double ep
   HIPCHK(launch_unsort_aos(sc->x, sc->y, sc->z, sc->d_order, n, d_in, s));
   if ((rc = normals_on_device(c, d_in, n, k, rPos, eps, d_nrm, nullptr))) return rc;
   if (!sc->nx) {
-    HIPCHK(hipMalloc((void**)&sc->nx, n * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&sc->ny, n * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&sc->nz, n * sizeof(double)));
+    HIPCHK(handle_malloc((void**)&sc->nx, n * sizeof(double)));
+    HIPCHK(handle_malloc((void**)&sc->ny, n * sizeof(double)));
+    HIPCHK(handle_malloc((void**)&sc->nz, n * sizeof(double)));
   }
   HIPCHK(launch_gather_soa(d_nrm, reinterpret_cast<const uint32_t*>(sc->d_order), n, sc->nx, sc->ny, sc->nz, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1416,19 +1422,19 @@ int tdtk_scan_create(const double* xyz, const double* nrm, size_t N, int device,
   uint32_t* keys_a = c->ws[WS_CELL].as<uint32_t>();
   uint32_t* keys_b = keys_a + N;
   uint32_t* idx_a = c->ws[WS_ORDER].as<uint32_t>();
-  HIPCHK(hipMalloc((void**)&sc->d_order, N * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&sc->x, N * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&sc->y, N * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&sc->z, N * sizeof(double)));
+  HIPCHK(handle_malloc((void**)&sc->d_order, N * sizeof(int32_t)));
+  HIPCHK(handle_malloc((void**)&sc->x, N * sizeof(double)));
+  HIPCHK(handle_malloc((void**)&sc->y, N * sizeof(double)));
+  HIPCHK(handle_malloc((void**)&sc->z, N * sizeof(double)));
   HIPCHK(hipMemcpyAsync(d_aos, xyz, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(launch_bbox(d_aos, N, d_box + 8, d_box, s));
   HIPCHK(launch_morton_order(d_aos, N, d_box, keys_a, idx_a, keys_b, reinterpret_cast<uint32_t*>(sc->d_order),
                              c->ws[WS_TMPB].p, tmp_bytes, s));
   HIPCHK(launch_gather_soa(d_aos, reinterpret_cast<const uint32_t*>(sc->d_order), N, sc->x, sc->y, sc->z, s));
   if (nrm) {
-    HIPCHK(hipMalloc((void**)&sc->nx, N * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&sc->ny, N * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&sc->nz, N * sizeof(double)));
+    HIPCHK(handle_malloc((void**)&sc->nx, N * sizeof(double)));
+    HIPCHK(handle_malloc((void**)&sc->ny, N * sizeof(double)));
+    HIPCHK(handle_malloc((void**)&sc->nz, N * sizeof(double)));
     HIPCHK(hipMemcpyAsync(d_aos, nrm, 3 * N * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(launch_gather_soa(d_aos, reinterpret_cast<const uint32_t*>(sc->d_order), N, sc->nx, sc->ny, sc->nz, s));
   }
@@ -1469,7 +1475,7 @@ int tdtk_scan_mark_original(tdtk_scan* s)
   wait_deferred(s->device);   // the saved original may be in use by a move that was left running
   double* p[] = {s->ox, s->oy, s->oz};
   for (double* q : p)
-    if (q) (void)hipFree(q);
+    if (q) pool_free(q);
   s->ox = s->oy = s->oz = nullptr;
   s->track_original = true;
   return TDTK_OK;

@@ -1070,7 +1070,7 @@ size_t device_build_arena_bytes(size_t M) { return build_layout(M, nullptr, null
 
 // Builds on `s` inside the caller's scratch `arena_` (>= device_build_arena_bytes(M), reused from build to build:
 // no hipMalloc / hipFree of hundreds of MB per tree, and no device-wide sync from hipFree while another thread's
-// kernels run).  On success the caller owns res.{nodes,node_r,pts,leaf_tab}, hipMalloc'ed at their exact sizes.
+// kernels run).  On success the caller owns res.{nodes,node_r,pts,leaf_tab}, from the handle pool (pool.cpp) at their sizes.
 DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, void* arena_, hipStream_t s)
 {
   DevBuildResult res{};
@@ -1089,7 +1089,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
                o_r = O[21], o_leaf = O[22], o_lvl = O[23];
   (void)o_f; (void)o_F;
   nodes = (KdNode*)(arena + o_nodes); node_r = (double*)(arena + o_r); leaf_tab = (LeafEntry*)(arena + o_leaf);
-  BCHK(hipMalloc((void**)&pts, sizeof(KdPoint) * (size_t)M));
+  BCHK((hipError_t)pool_malloc_raw((void**)&pts, sizeof(KdPoint) * (size_t)M));
   {
     uint32_t* perm = (uint32_t*)(arena + o_perm); uint32_t* seg_of = (uint32_t*)(arena + o_segof);
     double *cx = (double*)(arena + o_cx), *cy = (double*)(arena + o_cy), *cz = (double*)(arena + o_cz);
@@ -1237,13 +1237,13 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     BCHK(hipMemcpyAsync(&res.root_ref, small + 0, 4, hipMemcpyDeviceToHost, s));
     // the records move out of the scratch into allocations of their exact size
     if (node_count) {
-      BCHK(hipMalloc((void**)&f_nodes, sizeof(KdNode) * (size_t)node_count));
-      BCHK(hipMalloc((void**)&f_r, sizeof(double) * (size_t)node_count));
+      BCHK((hipError_t)pool_malloc_raw((void**)&f_nodes, sizeof(KdNode) * (size_t)node_count));
+      BCHK((hipError_t)pool_malloc_raw((void**)&f_r, sizeof(double) * (size_t)node_count));
       BCHK(hipMemcpyAsync(f_nodes, nodes, sizeof(KdNode) * (size_t)node_count, hipMemcpyDeviceToDevice, s));
       BCHK(hipMemcpyAsync(f_r, node_r, sizeof(double) * (size_t)node_count, hipMemcpyDeviceToDevice, s));
     }
     if (res.table_mode) {
-      BCHK(hipMalloc((void**)&f_leaf, sizeof(LeafEntry) * (size_t)leaf_count));
+      BCHK((hipError_t)pool_malloc_raw((void**)&f_leaf, sizeof(LeafEntry) * (size_t)leaf_count));
       BCHK(hipMemcpyAsync(f_leaf, leaf_tab, sizeof(LeafEntry) * (size_t)leaf_count, hipMemcpyDeviceToDevice, s));
     }
     BCHK(hipStreamSynchronize(s));
@@ -1253,10 +1253,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
   return res;
 fail:
-  if (f_nodes) (void)hipFree(f_nodes);
-  if (f_r) (void)hipFree(f_r);
-  if (f_leaf) (void)hipFree(f_leaf);
-  if (pts) (void)hipFree(pts);
+  if (f_nodes) pool_free(f_nodes);
+  if (f_r) pool_free(f_r);
+  if (f_leaf) pool_free(f_leaf);
+  if (pts) pool_free(pts);
   if (res.err == hipSuccess) res.err = hipErrorUnknown;
   return res;
 }

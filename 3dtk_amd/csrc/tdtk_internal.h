@@ -67,6 +67,12 @@ struct alignas(128) KdFat {
 };
 static_assert(sizeof(KdFat) == 128, "KdFat must be 128 bytes");
 
+// pool.cpp: hipMalloc / hipFree for the arrays of trees and resident scans, with freed blocks kept for the next request
+// (declared with plain types so that host-only sources can include this header)
+int pool_malloc_raw(void** out, size_t bytes);   // 0 = success, else the hipError_t value
+void pool_free(void* p);
+size_t pool_trim();                              // gives every shelved block back to the driver; returns the bytes
+
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_AXIS = 0x40000000u;
 constexpr uint32_t REF_VAL = 0x3FFFFFFFu;

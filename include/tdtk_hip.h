@@ -118,6 +118,10 @@ typedef struct tdtk_icp_result {
 /* ---- library ------------------------------------------------------------ */
 const char* tdtk_last_error(void);
 int tdtk_device_count(void);
+/* Device memory of destroyed trees and scans is kept for the next handle of about that size (up to TDTK_POOL_MB megabytes
+ * per process, default 4096; 0: every array goes straight back to the driver).  tdtk_pool_trim gives what is kept back
+ * now and returns the number of bytes released.                                                                    */
+size_t tdtk_pool_trim(void);
 const char* tdtk_version(void);
 
 /* ---- model tree: replaces KDtree::KDtree(double**, int, int) (src/slam6d/kd.cc:46-49,
