@@ -1625,6 +1625,28 @@ def test_elch_variants_distribute_a_loop_error(tdtk, gpu, variant):
         assert np.abs(pos - ref).max() < 1.0, np.abs(pos - ref).max()
 
 
+def test_handle_pool_reuses_and_releases(tdtk, orc, gpu):
+    """pool.cpp: the device arrays of a destroyed tree / scan are kept and handed to the next handle; a tree built in
+    reused blocks is the same tree (device == host build, same answers), tdtk_pool_trim gives the kept bytes back and a
+    second trim has nothing left."""
+    capi = __import__("importlib").import_module("3dtk_amd._capi")
+    rng = np.random.default_rng(17)
+    m = rng.uniform(-300, 300, (150000, 3))
+    q = m[:5000] + rng.normal(0, 1.0, (5000, 3))
+    capi.pool_trim()
+    kd = tdtk.KDtree(m, 20)
+    idx0, d0 = kd.FindClosestBatch(q, 100.0)
+    del kd
+    released = capi.pool_trim()
+    assert released > 150000 * 32          # at least the point array came back
+    assert capi.pool_trim() == 0
+    kd = tdtk.KDtree(m, 20); del kd         # fills the shelves again ...
+    kd = tdtk.KDtree(m[::-1].copy(), 20)    # ... and this one is built inside the kept blocks
+    assert kd.verify() == [0, 0, 0, 0]
+    idx1, d1 = kd.FindClosestBatch(q, 100.0)
+    assert np.array_equal(np.where(idx0 >= 0, len(m) - 1 - idx1, -1), idx0) and np.array_equal(d0, d1)
+
+
 def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
     other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane) walk the same tree the
