@@ -14,7 +14,7 @@ done
 bash tools/profile_graphslam.sh gsprof > gpurun_out/keep/gsprof.log 2>&1
 python tools/summarize_graphslam_profile.py gsprof r03 > gpurun_out/keep/gsprof.summary.txt 2>&1
 rm -rf gpurun_out/gsprof
+cp profiles/r03_* gpurun_out/keep/ 2>/dev/null      # the summaries just written (before the bench lines: stale copies of those are in profiles/ too)
 python bench.py --steps 20 --warmup 5 > gpurun_out/keep/r03_bench_n1_driver_args.json 2> gpurun_out/keep/bench_driver_args.err
 python bench.py > gpurun_out/keep/r03_bench_n1.json 2> gpurun_out/keep/bench_default.err
-cp profiles/r03_* gpurun_out/keep/ 2>/dev/null
 ls -la gpurun_out/keep | head -40
