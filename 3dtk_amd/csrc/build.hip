@@ -369,20 +369,23 @@ __device__ __forceinline__ uint32_t big_piece_slot(uint32_t a, uint32_t i)
 }
 __device__ __forceinline__ uint32_t big_piece_count(uint32_t a, uint32_t n) { return (a + n - 1u) / BIG_CH - (a + 1u) / BIG_CH + 1u; }
 
-// one wave per (block of 64 positions, axis): the pieces of that block, their bounding values and plain sums
+// one wave per block of 64 positions: the pieces of that block, their bounding values and plain sums along all three
+// axes (which node a piece belongs to is the same for the three: one look-up, three reductions; a wave per (block, axis)
+// -- round 2 -- was 47 000 waves of four dependent round trips each at 1M points, 28 us per level, now 15 600)
 __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
                                                    const double* __restrict__ cx, const double* __restrict__ cy,
                                                    const double* __restrict__ cz, uint32_t M, uint32_t nblocks,
                                                    BPiece* __restrict__ pieces, BPre* __restrict__ prein)
 {
   const uint32_t q = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
-  const uint32_t ax = blockIdx.y;
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (q >= nblocks) return;
-  const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
   const uint32_t base = q * BIG_CH;
   const uint32_t bend = (base + BIG_CH < M) ? base + BIG_CH : M;
   const uint32_t p = base + lane;
+  // this lane's values first: they do not depend on the look-ups below
+  const bool inb = p < bend;
+  const double vx = inb ? cx[p] : 0.0, vy = inb ? cy[p] : 0.0, vz = inb ? cz[p] : 0.0;
   // the node at the block's first position: a tail piece if it is big and started earlier
   uint32_t t_start = 0, t_end = 0, t_first = 0xFFFFFFFFu, t_sid = 0;
   {
@@ -399,7 +402,7 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
   uint32_t h_start = 0, h_end = 0, h_first = 0, h_sid = 0;
   {
     uint32_t found = 0xFFFFFFFFu, fend = 0, fsid = 0;
-    if (p < bend) {
+    if (inb) {
       const uint32_t sid = seg_of[p];
       if (sid != 0xFFFFFFFFu && (p == 0 || seg_of[p - 1] != sid)) {
         const BSeg sg = segs[sid];
@@ -415,30 +418,34 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
       if (h_start >= h_end) { h_start = h_end = 0; }
     }
   }
-  double tlo = 1.0 / 0.0, thi = -1.0 / 0.0, tsum = 0.0, hlo = 1.0 / 0.0, hhi = -1.0 / 0.0, hsum = 0.0;
-  if (p < bend) {
-    const double v = arr[p];
-    if (p >= t_start && p < t_end) { tlo = v; thi = v; tsum = v; }
-    if (p >= h_start && p < h_end) { hlo = v; hhi = v; hsum = v; }
-  }
-  const size_t o = ((size_t)ax * nblocks + q) * 2;
-  if (t_end > t_start) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
-  if (h_end > h_start) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
-  if (lane == 0) {
-    BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = t_sid; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
-    BPre tp; tp.v = t.len ? tsum : 0.0; tp.lo = tlo; tp.hi = thi; tp.reset = 0u; tp.pad = 0u;
-    if (t.len && t_first != 0xFFFFFFFFu) {
-      t.flags = 4u; t.pre = arr[t_first]; tp.v += t.pre; tp.reset = 1u;
-      tp.lo = (t.pre < tp.lo) ? t.pre : tp.lo; tp.hi = (tp.hi < t.pre) ? t.pre : tp.hi;
+  const bool in_t = inb && p >= t_start && p < t_end, in_h = inb && p >= h_start && p < h_end;
+  const bool has_t = t_end > t_start, has_h = h_end > h_start;
+  const double INF = 1.0 / 0.0;
+#pragma unroll
+  for (uint32_t ax = 0; ax < 3u; ax++) {
+    const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
+    const double v = (ax == 0) ? vx : ((ax == 1) ? vy : vz);
+    double tlo = in_t ? v : INF, thi = in_t ? v : -INF, tsum = in_t ? v : 0.0;
+    double hlo = in_h ? v : INF, hhi = in_h ? v : -INF, hsum = in_h ? v : 0.0;
+    if (has_t) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
+    if (has_h) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
+    const size_t o = ((size_t)ax * nblocks + q) * 2;
+    if (lane == 0) {
+      BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = t_sid; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
+      BPre tp; tp.v = t.len ? tsum : 0.0; tp.lo = tlo; tp.hi = thi; tp.reset = 0u; tp.pad = 0u;
+      if (t.len && t_first != 0xFFFFFFFFu) {
+        t.flags = 4u; t.pre = arr[t_first]; tp.v += t.pre; tp.reset = 1u;
+        tp.lo = (t.pre < tp.lo) ? t.pre : tp.lo; tp.hi = (tp.hi < t.pre) ? t.pre : tp.hi;
+      }
+      pieces[o] = t; prein[o] = tp;
+      BPiece h; h.start = h_start; h.len = h_end - h_start; h.ebits = h_sid; h.flags = 0; h.lo = hlo; h.hi = hhi; h.csum = hsum; h.pre = 0.0;
+      BPre hp; hp.v = 0.0; hp.lo = hlo; hp.hi = hhi; hp.reset = 0u; hp.pad = 0u;
+      if (h.len) {
+        h.flags = 4u; h.pre = arr[h_first]; hp.v = hsum + h.pre; hp.reset = 1u;
+        hp.lo = (h.pre < hp.lo) ? h.pre : hp.lo; hp.hi = (hp.hi < h.pre) ? h.pre : hp.hi;
+      }
+      pieces[o + 1] = h; prein[o + 1] = hp;
     }
-    pieces[o] = t; prein[o] = tp;
-    BPiece h; h.start = h_start; h.len = h_end - h_start; h.ebits = h_sid; h.flags = 0; h.lo = hlo; h.hi = hhi; h.csum = hsum; h.pre = 0.0;
-    BPre hp; hp.v = 0.0; hp.lo = hlo; hp.hi = hhi; hp.reset = 0u; hp.pad = 0u;
-    if (h.len) {
-      h.flags = 4u; h.pre = arr[h_first]; hp.v = hsum + h.pre; hp.reset = 1u;
-      hp.lo = (h.pre < hp.lo) ? h.pre : hp.lo; hp.hi = (hp.hi < h.pre) ? h.pre : hp.hi;
-    }
-    pieces[o + 1] = h; prein[o + 1] = hp;
   }
 }
 
@@ -476,8 +483,16 @@ __global__ void __launch_bounds__(64) k_big_emulate(const BSeg* __restrict__ seg
   uint32_t flags = (pc.flags & 4u) | (flip ? 1u : 0u);
   if (ebits == 0u || ebits == 0x7FFu) flags |= 2u;
   long long S0 = 0, S1 = 0, mn0 = 0, mn1 = 0, mx0 = 0, mx1 = 0;
-  for (uint32_t i = 0; i < pc.len && !(flags & 2u); i++) {
-    const unsigned long long yb = (unsigned long long)__double_as_longlong(arr[i]) ^ flip;
+  // eight values requested together (indices past the end read the last point again and are never used): one wait per
+  // eight points instead of one per point -- the lanes of a wave read 64 different lines
+  for (uint32_t i0 = 0; i0 < pc.len && !(flags & 2u); i0 += 8u) {
+   double xv[8];
+#pragma unroll
+   for (uint32_t u = 0; u < 8u; u++) xv[u] = arr[(i0 + u < pc.len) ? i0 + u : pc.len - 1u];
+#pragma unroll
+   for (uint32_t u = 0; u < 8u; u++) {
+    if (i0 + u >= pc.len || (flags & 2u)) break;
+    const unsigned long long yb = (unsigned long long)__double_as_longlong(xv[u]) ^ flip;
     const bool neg = (yb >> 63) != 0;
     uint32_t ey = (uint32_t)((yb >> 52) & 0x7FFu);
     unsigned long long m = yb & 0x000FFFFFFFFFFFFFull;
@@ -495,6 +510,7 @@ __global__ void __launch_bounds__(64) k_big_emulate(const BSeg* __restrict__ seg
     }
     mn0 = (S0 < mn0) ? S0 : mn0; mx0 = (S0 > mx0) ? S0 : mx0;
     mn1 = (S1 < mn1) ? S1 : mn1; mx1 = (S1 > mx1) ? S1 : mx1;
+   }
   }
   // does it fit with room to spare for the true M (the predicted one is good to a few ulps of the largest partial sum;
   // 2^32 mantissa units are nine orders more than that)?  If not, the chain walks this piece.
@@ -1161,7 +1177,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
                              big_level ? BIG_MIN : 0xFFFFFFFFu);
         if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
-          hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE), 3), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
+          hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
                              nblocks, pieces, prein);
           size_t stb = scan_tmp;
           BCHK(rocprim::inclusive_scan(tmp, stb, prein, preout, nsl, BPreOp(), s));
