@@ -54,7 +54,7 @@ class IcpResult(C.Structure):
 
 # every symbol include/tdtk_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "tdtk_last_error", "tdtk_device_count", "tdtk_pool_trim", "tdtk_version", "tdtk_tree_create", "tdtk_tree_create_from_scan", "tdtk_tree_create_from_scans", "tdtk_scan_mark_original", "tdtk_scan_download_original", "tdtk_tree_destroy",
+    "tdtk_last_error", "tdtk_device_count", "tdtk_pool_trim", "tdtk_build_respeculated", "tdtk_version", "tdtk_tree_create", "tdtk_tree_create_from_scan", "tdtk_tree_create_from_scans", "tdtk_scan_mark_original", "tdtk_scan_download_original", "tdtk_tree_destroy",
     "tdtk_tree_get_info", "tdtk_tree_verify", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
     "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
@@ -199,6 +199,13 @@ def check(rc):
 
 def device_count():
     return int(lib().tdtk_device_count())
+
+
+def build_respeculated():
+    """tree builds of this process that were redone in order (tdtk_build_respeculated)"""
+    f = lib().tdtk_build_respeculated
+    f.restype = C.c_uint64
+    return int(f())
 
 
 def pool_trim():

@@ -36,6 +36,9 @@ void tdtk::set_error(const std::string& s) { g_err = s; }
     }                                                                                        \
   } while (0)
 
+static std::atomic<int> g_ctx_live{0};             // host threads that hold a context right now (all devices)
+static std::atomic<uint64_t> g_respeculated{0};   // tree builds whose speculative cuts failed the final check
+
 static double now_ms()
 {
   using namespace std::chrono;
@@ -110,6 +113,8 @@ struct Ctx {
   hipEvent_t e4 = nullptr, e5 = nullptr;   // around k_ann_normals of the last calcNormals
   hipEvent_t e_user = nullptr;             // fence between a caller's stream and this context's stream
   hipEvent_t e_defer = nullptr;            // behind the last batch of scan moves that was left running (defer_fence)
+  hipStream_t stream_b = nullptr;          // the tree build's background chain (exact centroid sums beside the levels below)
+  hipEvent_t e_b1 = nullptr, e_b2 = nullptr;
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
@@ -156,6 +161,7 @@ static void wait_deferred(int device, const Ctx* only_owner = nullptr)
 
 Ctx::~Ctx()
   {
+    g_ctx_live.fetch_sub(1);
     if (device >= 0) (void)hipSetDevice(device);
     wait_deferred(device, this);
     if (e_defer) (void)hipEventDestroy(e_defer);
@@ -169,6 +175,9 @@ Ctx::~Ctx()
     if (e4) (void)hipEventDestroy(e4);
     if (e5) (void)hipEventDestroy(e5);
     if (e_user) (void)hipEventDestroy(e_user);
+    if (e_b1) (void)hipEventDestroy(e_b1);
+    if (e_b2) (void)hipEventDestroy(e_b2);
+    if (stream_b) (void)hipStreamDestroy(stream_b);
     if (h_pin) (void)hipHostFree(h_pin);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -197,8 +206,12 @@ static int get_ctx(int device, Ctx** out, bool touches_scans = true)
     HIPCHK(hipEventCreate(&c->e5));
     HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_defer, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b1, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b2, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
     it = g_ctx.emplace(device, std::move(c)).first;
+    g_ctx_live.fetch_add(1);
   }
   *out = it->second.get();
   if (touches_scans) wait_deferred(device);    // (the timing / counter read-outs do not: they must not end the overlap)
@@ -302,6 +315,7 @@ const char* tdtk_last_error(void) { return g_err.c_str(); }
 const char* tdtk_version(void) { return "3dtk_amd 0.1 (gfx950)"; }
 
 size_t tdtk_pool_trim(void) { return pool_trim(); }
+uint64_t tdtk_build_respeculated(void) { return g_respeculated.load(); }
 
 int tdtk_device_count(void)
 {
@@ -339,7 +353,15 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   const double t1 = now_ms();
   t->info.upload_ms = t1 - t0;
   if ((rc = c->ws[WS_ARENA].ensure(device_build_arena_bytes(M)))) return rc;
-  DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream);
+  // The background chain of the build needs a stream of its own, and the runtime has four hardware queues for all the
+  // streams of the process: when several host threads are at work -- a doICP that prepares
+  // three scans ahead -- a sixth and seventh stream end up queued behind other threads' kernels, the root's chain (one
+  // wave, 1.2 ms) in front of somebody's search, and ten 1M-point scans take 43.5 ms instead of 36.4.  So: beside at
+  // most one other thread.
+  const BuildSide side = {c->stream_b, c->e_b1, c->e_b2};
+  const bool alone = g_ctx_live.load() <= 2;
+  DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, alone ? &side : nullptr);
+  if (r.respeculated) g_respeculated.fetch_add(1);
   if (r.err != hipSuccess) {
     set_error(r.degenerate ? std::string("degenerate split (non-finite coordinates?)")
                            : std::string("device tree build: ") + hipGetErrorString(r.err));

@@ -736,6 +736,129 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
   }
 }
 
+// ---- speculative splits (round 3) ------------------------------------------------------------------------------
+// The exact centroid sum of a big node is a serial affair (k_big_stitch: 1.2 ms for the root of a 1M-point cloud, 0.6
+// and 0.4 ms on the two levels below it, one to four waves busy), and everything else waits for it -- but all the build
+// needs from it right away is WHERE the node is cut, and for that the plain parallel sum of the same points (the
+// bounds scan carries it along: BPre.v at the node's last piece) is almost always enough: it differs from the serial
+// sum in the last few bits, and the cut only changes if a point's coordinate lies between the two values.  So the
+// levels are built from the plain sums, while the chain computes the exact sums of all big nodes in the background, on
+// a second stream, from a snapshot of the coordinates taken before the level's partition pass moves them.  At the end
+// every big node is checked -- the number of its points below the EXACT split value must be the number the build put to
+// the left -- and its record gets the exact value.  A node that fails the check (none has, outside the test that forces
+// one) sends the whole build through the in-order path again.  The tree is the reference's, bit for bit, either way.
+struct BSpecLevel {
+  BPiece* pieces; BPre* preout; BSum* own; BSum* comp; uint32_t* wlist; double* snap;
+  BSeg* segs; uint32_t* axis; uint32_t* node; uint32_t* nleft; uint32_t* cnt; BMeas* exact;
+  uint32_t level, pad;
+};
+#define BIG_SPEC_MAX 24
+struct BSpecAll { BSpecLevel L[BIG_SPEC_MAX]; int n; };
+
+// per big node: bounds of all axes and the plain sum along the split axis, from the bounds scan; keeps what the
+// background chain and the final check need of this level (its node list, which axis each node is cut along)
+__global__ void k_big_approx(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t nblocks,
+                             const BPre* __restrict__ preout, BMeas* __restrict__ meas, BSpecLevel L, int fault)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lv->nseg) return;
+  const BSeg sg = segs[i];
+  L.segs[i] = sg; L.node[i] = 0xFFFFFFFFu; L.axis[i] = 3u; L.nleft[i] = 0u; L.cnt[i] = 0u;
+  if (sg.n < BIG_MIN) return;
+  const uint32_t sl = big_piece_slot(sg.start, big_piece_count(sg.start, sg.n) - 1u);
+  const size_t st = (size_t)nblocks * 2;
+  BMeas m;
+  for (int ax = 0; ax < 3; ax++) { const BPre b = preout[(size_t)ax * st + sl]; m.lo[ax] = b.lo; m.hi[ax] = b.hi; m.mean[ax] = 0.0; }
+  const uint32_t split = big_split_axis(preout, st, sl);
+  double v = preout[(size_t)split * st + sl].v / (double)sg.n;
+  if (fault) v += 0.125 * (m.hi[split] - v);               // test only: a split value that cuts elsewhere (never outside the node)
+  m.mean[split] = v;
+  meas[i] = m;
+  L.axis[i] = split;
+}
+// the coordinates of the big nodes' points along their nodes' split axes, as they stand before this level's partition
+__global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ axis_of, const double* __restrict__ cx,
+                                const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M, double* __restrict__ snap)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const uint32_t sid = seg_of[p];
+  if (sid == 0xFFFFFFFFu) return;
+  const uint32_t ax = axis_of[sid];
+  if (ax < 3u) snap[p] = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
+}
+// after the level's count: where each internal big node's record is and how many points went left
+__global__ void k_spec_keep(const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
+                            const uint32_t* __restrict__ nleft, BSpecLevel L)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lv->nseg || L.axis[i] >= 3u || !kind[i]) return;
+  L.node[i] = lv->node_base + irank[i];
+  L.nleft[i] = nleft[i];
+}
+// the check, part 1: per speculated level (blockIdx.y), how many points of each big internal node lie below its EXACT
+// split value (the points are where the finished build left them; a node's points are still the run [start, start + n)).
+// A workgroup covers 1024 consecutive positions: one search for the node of its first position, then every thread steps
+// forward from there (the nodes of a level ascend; a big level's nodes are thousands of positions long).
+__global__ void __launch_bounds__(256) k_spec_count(BSpecAll S, const BLevel* __restrict__ lvl, const double* __restrict__ cx,
+                                                    const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M)
+{
+  __shared__ uint32_t s_first, s_cnt;
+  const BSpecLevel& L = S.L[blockIdx.y];
+  const uint32_t nseg = lvl[L.level].nseg;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  const uint32_t p0 = blockIdx.x * 1024u;
+  if (nseg == 0 || p0 >= M) return;
+  if (threadIdx.x == 0) {
+    uint32_t lo = 0, hi = nseg;                       // last node with start <= p0
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.segs[mid].start <= p0) lo = mid; else hi = mid; }
+    s_first = lo; s_cnt = 0u;
+  }
+  __syncthreads();
+  const uint32_t first = s_first;      // its count is gathered in LDS: at the top levels every workgroup adds to the same node
+  uint32_t at = first;
+  for (int r = 0; r < 4; r++) {
+    const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
+    uint32_t i = 0xFFFFFFFFu;
+    bool lt = false;
+    if (p < M) {
+      while (at + 1u < nseg && L.segs[at + 1u].start <= p) ++at;
+      const BSeg sg = L.segs[at];
+      if (p >= sg.start && p - sg.start < sg.n && L.node[at] != 0xFFFFFFFFu) {
+        i = at;
+        const uint32_t ax = L.axis[at];
+        const double v = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
+        lt = v < L.exact[at].mean[ax];
+      }
+    }
+    unsigned long long todo = __ballot(i != 0xFFFFFFFFu);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t cur = __shfl(i, leader, WAVE);
+      const bool mine = (i == cur);
+      const uint32_t add = (uint32_t)__popcll(__ballot(mine && lt));
+      if (lane == (uint32_t)leader && add) { if (cur == first) atomicAdd(&s_cnt, add); else atomicAdd(&L.cnt[cur], add); }
+      todo &= ~__ballot(mine);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(&L.cnt[first], s_cnt);
+}
+// part 2: the counts must be the build's; the records get the exact split values
+__global__ void k_spec_patch(BSpecAll S, const BLevel* __restrict__ lvl, KdNode* __restrict__ nodes, uint32_t* __restrict__ err)
+{
+  for (int l = 0; l < S.n; l++) {
+    const BSpecLevel& L = S.L[l];
+    const uint32_t nseg = lvl[L.level].nseg;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nseg; i += gridDim.x * blockDim.x) {
+      const uint32_t nd = L.node[i];
+      if (nd == 0xFFFFFFFFu) continue;
+      if (L.cnt[i] != L.nleft[i]) atomicExch(err, 1u);
+      nodes[nd].splitval = L.exact[i].mean[L.axis[i]];
+    }
+  }
+}
+
 // the walked pieces of every big node, in run order: entry `rank` of the list is the slot of the piece (the rank is the
 // number of walked pieces in the slots before it, carried along by the run scan)
 __global__ void k_big_list(const BSum* __restrict__ own, const BSum* __restrict__ comp, uint32_t nsl, uint32_t* __restrict__ list)
@@ -1082,12 +1205,13 @@ static inline int bits_for(uint64_t v)
 // bytes of scratch a build over M points needs (every temporary, and the node / bucket records while their
 // number is still unknown)
 static size_t build_layout(size_t M, size_t* offs, size_t* scan_tmp_out);
-size_t device_build_arena_bytes(size_t M) { return build_layout(M, nullptr, nullptr); }
+static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out);
+size_t device_build_arena_bytes(size_t M) { return spec_layout(M, build_layout(M, nullptr, nullptr), nullptr, nullptr); }
 
 // Builds on `s` inside the caller's scratch `arena_` (>= device_build_arena_bytes(M), reused from build to build:
 // no hipMalloc / hipFree of hundreds of MB per tree, and no device-wide sync from hipFree while another thread's
 // kernels run).  On success the caller owns res.{nodes,node_r,pts,leaf_tab}, from the handle pool (pool.cpp) at their sizes.
-DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, void* arena_, hipStream_t s)
+DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, void* arena_, hipStream_t s, const BuildSide* side)
 {
   DevBuildResult res{};
   const uint32_t M = (uint32_t)M_;
@@ -1095,6 +1219,8 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   KdNode* nodes = nullptr; double* node_r = nullptr; LeafEntry* leaf_tab = nullptr; KdPoint* pts = nullptr;
   KdNode* f_nodes = nullptr; double* f_r = nullptr; LeafEntry* f_leaf = nullptr;
   uint32_t node_count = 0, leaf_count = 0, depth = 0;
+  uint32_t h_spec_err = 0;
+  bool spec_on = false;
   size_t scan_tmp = 0;
   size_t O[32];
   (void)build_layout(M_, O, &scan_tmp);
@@ -1129,6 +1255,21 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     static const bool measure_axis_env = [] { const char* e = getenv("TDTK_MEASURE"); return e && e[0] == 'a'; }();
     const bool measure_per_axis_always = measure_axis_env || chain_only;
     const int big_dbg_all = getenv("TDTK_BIG_DEBUG") ? atoi(getenv("TDTK_BIG_DEBUG")) : 0;
+    // speculative splits: TDTK_BUILD_SPEC=0 builds in order; TDTK_BUILD_SPEC_FAULT=1 (tests) cuts every big node elsewhere than
+    // the exact sum would, so that the final check fails and the in-order path takes over
+    static const bool spec_env = [] { const char* e = getenv("TDTK_BUILD_SPEC"); return !(e && e[0] == '0'); }();
+    static const int spec_fault = [] { const char* e = getenv("TDTK_BUILD_SPEC_FAULT"); return (e && e[0] == '1') ? 1 : 0; }();
+    const bool spec = spec_env && side && side->s2 && use_big && !big_dbg_all;
+    spec_on = spec;
+    BSpecAll SP;
+    SP.n = 0;
+    size_t SO[BIG_SPEC_MAX * 12 + 4];
+    int spec_levels = 0;
+    void* tmp2 = nullptr;
+    if (spec) {
+      (void)spec_layout(M_, build_layout(M_, nullptr, nullptr), SO, &spec_levels);
+      tmp2 = arena + SO[BIG_SPEC_MAX * 12];
+    }
     const int big_dbg = big_dbg_all & (3 | 16);   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
@@ -1175,7 +1316,37 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         else
           hipLaunchKernelGGL(k_measure_node, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
                              big_level ? BIG_MIN : 0xFFFFFFFFu);
-        if (big_level) {
+        bool spec_this = false;
+        if (big_level && spec && SP.n < spec_levels && SP.n < BIG_SPEC_MAX) {
+          // this level from the plain sums; its exact sums on the second stream, from a snapshot of the coordinates
+          spec_this = true;
+          BSpecLevel& L = SP.L[SP.n];
+          const size_t* o = SO + (size_t)SP.n * 12;
+          L.pieces = (BPiece*)(arena + o[0]); L.preout = (BPre*)(arena + o[1]); L.own = (BSum*)(arena + o[2]);
+          L.comp = (BSum*)(arena + o[3]); L.wlist = (uint32_t*)(arena + o[4]); L.snap = (double*)(arena + o[5]);
+          L.segs = (BSeg*)(arena + o[6]); L.axis = (uint32_t*)(arena + o[7]); L.node = (uint32_t*)(arena + o[8]);
+          L.nleft = (uint32_t*)(arena + o[9]); L.cnt = (uint32_t*)(arena + o[10]); L.exact = (BMeas*)(arena + o[11]);
+          L.level = level; L.pad = 0;
+          SP.n++;
+          const size_t nsl = (size_t)nblocks * 2 * 3, nsl1 = (size_t)nblocks * 2;
+          hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
+                             nblocks, L.pieces, prein);
+          size_t stb = scan_tmp;
+          BCHK(rocprim::inclusive_scan(tmp, stb, prein, L.preout, nsl, BPreOp(), s));
+          hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, nblocks, L.preout, meas, L, spec_fault);
+          hipLaunchKernelGGL(k_spec_snapshot, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, L.axis, cx, cy, cz, M, L.snap);
+          BCHK(hipEventRecord(side->e1, s));
+          BCHK(hipStreamWaitEvent(side->s2, side->e1, 0));
+          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(nsl1, 64)), dim3(64), 0, side->s2, L.segs, L.snap, L.snap, L.snap, nblocks,
+                             L.pieces, L.preout, L.own, big_dbg);
+          stb = scan_tmp;
+          BSum ident;
+          ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u; ident.cnt = 0u; ident.pad = 0u;
+          BCHK(rocprim::exclusive_scan(tmp2, stb, L.own, L.comp, ident, nsl1, BSumOp(), side->s2));
+          hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, side->s2, L.own, L.comp, (uint32_t)nsl1, L.wlist);
+          hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, side->s2, L.segs, lv, L.snap, L.snap, L.snap,
+                             nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg);
+        } else if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
                              nblocks, pieces, prein);
@@ -1211,6 +1382,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         // the partition pass (with no internal node at this level it moves nothing)
         hipLaunchKernelGGL(k_count, dim3(cdiv(M, 256 * CNT_ITERS)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy,
                            cz, M, nleft);
+        if (spec_this) hipLaunchKernelGGL(k_spec_keep, dim3(cdiv(bound, 256)), dim3(256), 0, s, lv, kind, irank, nleft, SP.L[SP.n - 1]);
         {
           const uint32_t nbm = cdiv(n1, 256);
           hipLaunchKernelGGL(k_misplaced_children, dim3(nbm + cdiv(bound, 256)), dim3(256), 0, s, seg_of, kind, segs, axis,
@@ -1246,6 +1418,14 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     res.max_leaf = h_small[1];
     res.cb = bits_for(res.max_leaf);
     res.table_mode = (bits_for(M) + res.cb) > 30;
+    if (spec && SP.n) {
+      // the exact sums have to be there now: check every big node's cut against them, give its record the exact value
+      BCHK(hipEventRecord(side->e2, side->s2));
+      BCHK(hipStreamWaitEvent(s, side->e2, 0));
+      hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
+      hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
+      BCHK(hipMemcpyAsync(&h_spec_err, small + 3, 4, hipMemcpyDeviceToHost, s));
+    }
     hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
     if (!res.table_mode)
       hipLaunchKernelGGL(k_pack_refs, dim3(cdiv(node_count ? node_count : 1, 256)), dim3(256), 0, s, nodes, node_count,
@@ -1264,17 +1444,66 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     }
     BCHK(hipStreamSynchronize(s));
     BCHK(hipGetLastError());
+    if (h_spec_err) { res.err = hipErrorNotReady; goto fail; }     // a cut the exact sum would have made elsewhere: in order, then
   }
   res.nodes = f_nodes; res.node_r = f_r; res.leaf_tab = f_leaf; res.pts = pts;
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
   return res;
 fail:
+  if (spec_on) (void)hipStreamSynchronize(side->s2);     // nothing of this build may still be running in the arena
   if (f_nodes) pool_free(f_nodes);
   if (f_r) pool_free(f_r);
   if (f_leaf) pool_free(f_leaf);
   if (pts) pool_free(pts);
+  if (spec_on) {
+    // whatever went wrong went wrong on a tree cut at the plain sums (a failed check, or a cut so far off that a child
+    // came out empty): the in-order build decides what the input really is
+    (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
+    DevBuildResult again = device_build_tree(d_xyz, M_, bucket, arena_, s, nullptr);
+    again.respeculated = true;
+    return again;
+  }
   if (res.err == hipSuccess) res.err = hipErrorUnknown;
   return res;
+}
+
+// the per-level buffers of the speculative build behind the main layout: SO[12 l + k] for level l, SO[12 BIG_SPEC_MAX] the
+// second stream's scan temporary; returns the total size
+static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out)
+{
+  size_t off = (base + 255) & ~(size_t)255;
+  int nlev = 0;
+  if (M >= BIG_MIN)
+    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN / 2 && nlev < BIG_SPEC_MAX; level++) nlev++;
+  if (getenv("TDTK_BUILD_SPEC") && getenv("TDTK_BUILD_SPEC")[0] == '0') nlev = 0;
+  const size_t n1 = M + 1, nsl = 6 * (M / BIG_CH + 2), nsl1 = nsl / 3 + 3;
+  auto take = [&](size_t bytes, size_t* slot) { if (slot) *slot = off; off += (bytes + 255) & ~(size_t)255; };
+  for (int l = 0; l < nlev; l++) {
+    size_t maxseg = (l < 40) ? ((size_t)1 << l) : n1;
+    if (maxseg > n1) maxseg = n1;
+    size_t* o = SO ? SO + (size_t)l * 12 : nullptr;
+    take(sizeof(BPiece) * nsl, o ? o + 0 : nullptr);
+    take(sizeof(BPre) * nsl, o ? o + 1 : nullptr);
+    take(sizeof(BSum) * nsl1, o ? o + 2 : nullptr);
+    take(sizeof(BSum) * nsl1, o ? o + 3 : nullptr);
+    take(4 * (nsl1 + 1), o ? o + 4 : nullptr);
+    take(8 * n1, o ? o + 5 : nullptr);
+    take(sizeof(BSeg) * maxseg, o ? o + 6 : nullptr);
+    take(4 * maxseg, o ? o + 7 : nullptr);
+    take(4 * maxseg, o ? o + 8 : nullptr);
+    take(4 * maxseg, o ? o + 9 : nullptr);
+    take(4 * maxseg, o ? o + 10 : nullptr);
+    take(sizeof(BMeas) * maxseg, o ? o + 11 : nullptr);
+  }
+  size_t scan_tmp = 0;
+  if (nlev) {
+    BSum* zs = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, zs, zs, BSum(), nsl, BSumOp(), (hipStream_t)0);
+  }
+  take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * 12 : nullptr);
+  if (nlev_out) *nlev_out = nlev;
+  return off;
 }
 
 static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)

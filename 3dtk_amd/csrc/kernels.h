@@ -169,10 +169,15 @@ struct DevBuildResult {
   int cb;
   bool table_mode;
   uint32_t n_internal, n_leaves, max_depth, max_leaf;
+  bool respeculated;   // the speculative build failed its check (or fell over) and the in-order build took its place
 };
 // level-synchronous construction of the reference's kd-tree on the device (build.hip)
 size_t device_build_arena_bytes(size_t M);
-DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s);
+// `side` (nullable): a second stream and two events of the caller's for the build's background chain -- with it the exact
+// centroid sums of the big nodes run beside the levels below them (see "speculative splits" in build.hip)
+struct BuildSide { hipStream_t s2; hipEvent_t e1, e2; };
+DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s,
+                                 const BuildSide* side = nullptr);
 
 // ---- normals: the ANN kd-tree (one point per leaf, sliding midpoint) + approximate k-NN + PCA (ann.hip) -------
 struct AnnNode {          // 32 B: one splitting node (ANNkd_split: cut_val, cd_bnds[2], child[2], cut_dim)

@@ -122,6 +122,10 @@ int tdtk_device_count(void);
  * per process, default 4096; 0: every array goes straight back to the driver).  tdtk_pool_trim gives what is kept back
  * now and returns the number of bytes released.                                                                    */
 size_t tdtk_pool_trim(void);
+/* Diagnostics: how many device tree builds of this process had to be redone in order because a node cut at the plain
+ * parallel sum of its points would have been cut elsewhere at the exact serial sum (build.hip, "speculative splits";
+ * the tree that comes out is the same either way).  Expected to stay 0 outside the test that forces it.             */
+uint64_t tdtk_build_respeculated(void);
 const char* tdtk_version(void);
 
 /* ---- model tree: replaces KDtree::KDtree(double**, int, int) (src/slam6d/kd.cc:46-49,

@@ -1625,6 +1625,28 @@ def test_elch_variants_distribute_a_loop_error(tdtk, gpu, variant):
         assert np.abs(pos - ref).max() < 1.0, np.abs(pos - ref).max()
 
 
+def test_speculative_tree_build_and_its_fallback(gpu):
+    """build.hip, speculative splits: the levels are cut at the plain parallel sums of the big nodes while the exact
+    serial sums run beside them, and every big node is checked against its exact sum at the end.  On ordinary clouds (a
+    bundled scan with its duplicate points, uniform, a dense clump) no build needs redoing and the tree is the host
+    builder's; with the cut forced elsewhere (TDTK_BUILD_SPEC_FAULT=1) the check fails on every build, the in-order path
+    takes over, and the tree is still the host builder's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    for fault, want in (("0", "0"), ("1", "+")):
+        env = dict(os.environ, TDTK_BUILD_SPEC_FAULT=fault)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fault_probe.py")], cwd=root, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rows = [ln.split() for ln in r.stdout.splitlines() if "respeculated" in ln]
+        assert len(rows) == 4, r.stdout
+        for k, row in enumerate(rows):
+            assert "".join(row[:4]) == "[0,0,0,0]", r.stdout
+            n_redone = int(row[5])
+            assert n_redone == (0 if want == "0" else k + 1), r.stdout
+
+
 def test_handle_pool_reuses_and_releases(tdtk, orc, gpu):
     """pool.cpp: the device arrays of a destroyed tree / scan are kept and handed to the next handle; a tree built in
     reused blocks is the same tree (device == host build, same answers), tdtk_pool_trim gives the kept bytes back and a
