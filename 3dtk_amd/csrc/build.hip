@@ -1024,6 +1024,22 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ seg_
     cs[it] = 0.0;
     if (sgs[it] != 0xFFFFFFFFu) cs[it] = (axs[it] == 0) ? cx[p] : ((axs[it] == 1) ? cy[p] : cz[p]);
   }
+  // The counts of one node are gathered per workgroup before they go to memory: on the top levels every wave of the
+  // launch adds to the same one or two counters (2 000 atomics on one address: 28 us at 1M points, against 10 us on the
+  // levels where the nodes are many).  The node in question is the one the workgroup's first labelled position belongs to.
+  __shared__ uint32_t s_node, s_cnt;
+  if (threadIdx.x == 0) { s_node = 0xFFFFFFFFu; s_cnt = 0u; }
+  __syncthreads();
+  {
+    unsigned long long any = __ballot(sgs[0] != 0xFFFFFFFFu);
+    if (threadIdx.x / WAVE == 0 && any && lane == (uint32_t)(__ffsll((long long)any) - 1)) s_node = sgs[0];
+  }
+  __syncthreads();
+  const uint32_t shared_node = s_node;
+  auto flush = [&](uint32_t node, uint32_t cnt) {
+    if (lane != 0 || !cnt) return;
+    if (node == shared_node) atomicAdd(&s_cnt, cnt); else atomicAdd(&nleft[node], cnt);
+  };
   uint32_t pend = 0xFFFFFFFFu, pcnt = 0;
 #pragma unroll
   for (int it = 0; it < CNT_ITERS; it++) {
@@ -1036,13 +1052,15 @@ __global__ void __launch_bounds__(256) k_count(const uint32_t* __restrict__ seg_
       const bool mine = (sg == cur);
       const uint32_t add = (uint32_t)__popcll(__ballot(mine && lt));
       if (cur != pend) {
-        if (pend != 0xFFFFFFFFu && lane == 0) atomicAdd(&nleft[pend], pcnt);
+        if (pend != 0xFFFFFFFFu) flush(pend, pcnt);
         pend = cur; pcnt = add;
       } else pcnt += add;
       todo &= ~__ballot(mine);
     }
   }
-  if (pend != 0xFFFFFFFFu && lane == 0) atomicAdd(&nleft[pend], pcnt);
+  if (pend != 0xFFFFFFFFu) flush(pend, pcnt);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(&nleft[shared_node], s_cnt);
 }
 
 // ---- per element: misplaced on the left / on the right of its node's split position --------------
