@@ -500,8 +500,10 @@ def bench_icp(args, rank, world, local):
                                            "achieved": tb_bytes / (info["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": tb_bytes / (info["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "traffic": None,
-                                           "note": "bounded by what is left of the dependent fp64 add chain of the centroid (bit-exact "
-                                                   "split values), not by bytes: DESIGN.md section 4"}}
+                                           "note": "not bound by bytes: the order-dependent fp64 centroid sums of the big nodes run on a "
+                                                   "second stream beside the levels (speculative splits, every cut checked against "
+                                                   "its exact sum at the end); what is left is ~9 dependent launches per level: "
+                                                   "DESIGN.md section 4"}}
     if rank == 0 and not args.no_cpu:
         gi, _ = tree.FindClosestBatch(cur[:20000], 625.0)
         out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0, check=gi, full_iter=(d, model.dalignxf))
