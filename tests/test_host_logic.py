@@ -213,6 +213,9 @@ def test_no_cpu_fallback(tdtk):
     with pytest.raises(tdtk.TdtkError) as e:
         _ = tdtk.Scan([0, 0, 0], [0, 0, 0], pts).handle      # residency is lazy: first use uploads
     assert e.value.code == -2
+    # the housekeeping entry points need no device: nothing is kept, nothing was rebuilt
+    capi = __import__("importlib").import_module("3dtk_amd._capi")
+    assert capi.pool_trim() == 0 and capi.build_respeculated() == 0
 
 
 def test_euler_roundtrip_and_graph(tdtk):
