@@ -113,8 +113,8 @@ struct Ctx {
   hipEvent_t e4 = nullptr, e5 = nullptr;   // around k_ann_normals of the last calcNormals
   hipEvent_t e_user = nullptr;             // fence between a caller's stream and this context's stream
   hipEvent_t e_defer = nullptr;            // behind the last batch of scan moves that was left running (defer_fence)
-  hipStream_t stream_b = nullptr;          // the tree build's background chain (exact centroid sums beside the levels below)
-  hipEvent_t e_b1 = nullptr, e_b2 = nullptr;
+  hipStream_t stream_b = nullptr, stream_c = nullptr;   // the tree build's background chains (exact centroid sums beside the levels below)
+  hipEvent_t e_b1 = nullptr, e_b2 = nullptr, e_b3 = nullptr;
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
@@ -177,7 +177,9 @@ Ctx::~Ctx()
     if (e_user) (void)hipEventDestroy(e_user);
     if (e_b1) (void)hipEventDestroy(e_b1);
     if (e_b2) (void)hipEventDestroy(e_b2);
+    if (e_b3) (void)hipEventDestroy(e_b3);
     if (stream_b) (void)hipStreamDestroy(stream_b);
+    if (stream_c) (void)hipStreamDestroy(stream_c);
     if (h_pin) (void)hipHostFree(h_pin);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -207,6 +209,8 @@ static int get_ctx(int device, Ctx** out, bool touches_scans = true)
     HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_defer, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b3, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_b1, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_b2, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
@@ -358,7 +362,7 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   // three scans ahead -- a sixth and seventh stream end up queued behind other threads' kernels, the root's chain (one
   // wave, 1.2 ms) in front of somebody's search, and ten 1M-point scans take 43.5 ms instead of 36.4.  So: beside at
   // most one other thread.
-  const BuildSide side = {c->stream_b, c->e_b1, c->e_b2};
+  const BuildSide side = {c->stream_b, c->stream_c, c->e_b1, c->e_b2, c->e_b3};
   const bool alone = g_ctx_live.load() <= 2;
   DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, alone ? &side : nullptr);
   if (r.respeculated) g_respeculated.fetch_add(1);

@@ -748,44 +748,144 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
 // the left -- and its record gets the exact value.  A node that fails the check (none has, outside the test that forces
 // one) sends the whole build through the in-order path again.  The tree is the reference's, bit for bit, either way.
 struct BSpecLevel {
-  BPiece* pieces; BPre* preout; BSum* own; BSum* comp; uint32_t* wlist; double* snap;
+  BPiece* pieces; BPre* preout; BSum* own; BSum* comp; uint32_t* wlist; double* snap;   // snap: x | y | z, n1 doubles each
   BSeg* segs; uint32_t* axis; uint32_t* node; uint32_t* nleft; uint32_t* cnt; BMeas* exact;
+  BPre* prein; uint32_t* seg_of;                                                          // the level's labels, as snapped
   uint32_t level, pad;
 };
+// bounds and plain sums of the part of a big node inside one block of BIG_PB positions (two per block: the node the block
+// starts in, and a node that starts inside it -- big nodes are longer than a block, so there is no third)
+struct BPart { double lo[3], hi[3], sum[3]; };
+#define BIG_PB 512u
 #define BIG_SPEC_MAX 24
+#define SPEC_SLOTS 14          // buffers per speculated level (spec_layout)
 struct BSpecAll { BSpecLevel L[BIG_SPEC_MAX]; int n; };
 
-// per big node: bounds of all axes and the plain sum along the split axis, from the bounds scan; keeps what the
-// background chain and the final check need of this level (its node list, which axis each node is cut along)
-__global__ void k_big_approx(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t nblocks,
-                             const BPre* __restrict__ preout, BMeas* __restrict__ meas, BSpecLevel L, int fault)
+// What the cut needs, and nothing else (round 3, second step): bounds and plain sums of the big nodes in two short
+// passes -- per block of 512 positions, then per node over its blocks -- instead of the piece statistics and their
+// prefix scan, which only the exact chain needs and which now run with it on the second stream.
+__global__ void __launch_bounds__(256) k_big_partials(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
+                                                      const double* __restrict__ cx, const double* __restrict__ cy,
+                                                      const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int R = BIG_PB / 256;
+  __shared__ uint32_t s_startB;
+  __shared__ double s_red[256 / WAVE][2][9];
+  const uint32_t p0 = blockIdx.x * BIG_PB;
+  const uint32_t pend = (p0 + BIG_PB < M) ? p0 + BIG_PB : M;
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  if (threadIdx.x == 0) s_startB = 0xFFFFFFFFu;
+  // everything this thread will need is requested before the first dependent look-up
+  uint32_t sids[R], prev[R];
+  double xs[R], ys[R], zs[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
+    const bool in = p < pend;
+    sids[r] = in ? seg_of[p] : 0xFFFFFFFFu;
+    prev[r] = (in && p > p0) ? seg_of[p - 1] : 0xFFFFFFFFu;
+    xs[r] = in ? cx[p] : 0.0; ys[r] = in ? cy[p] : 0.0; zs[r] = in ? cz[p] : 0.0;
+  }
+  const uint32_t sid0 = seg_of[p0];
+  __syncthreads();
+  // piece A: the big node the block starts in
+  uint32_t a_end = p0;
+  if (sid0 != 0xFFFFFFFFu) {
+    const BSeg sg = segs[sid0];
+    if (sg.n >= BIG_MIN) a_end = (sg.start + sg.n < pend) ? sg.start + sg.n : pend;
+  }
+  // piece B: the first big node that starts inside the block
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
+    if (p < pend && p > p0 && sids[r] != 0xFFFFFFFFu && prev[r] != sids[r]) {
+      const BSeg sg = segs[sids[r]];
+      if (sg.n >= BIG_MIN) atomicMin(&s_startB, p);
+    }
+  }
+  __syncthreads();
+  const uint32_t b_start = s_startB;
+  const bool has[2] = {a_end > p0, b_start != 0xFFFFFFFFu};
+  const double INF = 1.0 / 0.0;
+  double v[2][9];
+#pragma unroll
+  for (int k = 0; k < 2; k++) { for (int c = 0; c < 3; c++) { v[k][c] = INF; v[k][3 + c] = -INF; v[k][6 + c] = 0.0; } }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
+    if (p >= pend) continue;
+    const double x = xs[r], y = ys[r], z = zs[r];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const bool mine = (k == 0) ? (p < a_end) : (p >= b_start);
+      if (!mine) continue;
+      v[k][0] = (x < v[k][0]) ? x : v[k][0]; v[k][1] = (y < v[k][1]) ? y : v[k][1]; v[k][2] = (z < v[k][2]) ? z : v[k][2];
+      v[k][3] = (v[k][3] < x) ? x : v[k][3]; v[k][4] = (v[k][4] < y) ? y : v[k][4]; v[k][5] = (v[k][5] < z) ? z : v[k][5];
+      v[k][6] += x; v[k][7] += y; v[k][8] += z;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (has[k]) {                     // (uniform over the workgroup)
+      for (int c = 0; c < 3; c++) { v[k][c] = wave_min(v[k][c]); v[k][3 + c] = wave_max(v[k][3 + c]); v[k][6 + c] = wave_add(v[k][6 + c]); }
+    }
+    if (lane == 0) for (int c = 0; c < 9; c++) s_red[wv][k][c] = v[k][c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int k = (int)threadIdx.x;
+    BPart o;
+    for (int c = 0; c < 3; c++) {
+      double lo = s_red[0][k][c], hi = s_red[0][k][3 + c], sm = s_red[0][k][6 + c];
+      for (int w = 1; w < 256 / WAVE; w++) {
+        lo = (s_red[w][k][c] < lo) ? s_red[w][k][c] : lo;
+        hi = (hi < s_red[w][k][3 + c]) ? s_red[w][k][3 + c] : hi;
+        sm += s_red[w][k][6 + c];
+      }
+      o.lo[c] = lo; o.hi[c] = hi; o.sum[c] = sm;
+    }
+    part[(size_t)blockIdx.x * 2 + k] = o;
+  }
+}
+// one wave per node: a big node's bounds and plain sums from its blocks' partials; keeps what the background chain and
+// the final check need of this level (its node list, which axis each node is cut along)
+__global__ void __launch_bounds__(256) k_big_approx(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                    const BPart* __restrict__ part, BMeas* __restrict__ meas, BSpecLevel L, int fault)
+{
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (i >= lv->nseg) return;
   const BSeg sg = segs[i];
-  L.segs[i] = sg; L.node[i] = 0xFFFFFFFFu; L.axis[i] = 3u; L.nleft[i] = 0u; L.cnt[i] = 0u;
+  if (lane == 0) { L.segs[i] = sg; L.node[i] = 0xFFFFFFFFu; L.axis[i] = 3u; L.nleft[i] = 0u; L.cnt[i] = 0u; }
   if (sg.n < BIG_MIN) return;
-  const uint32_t sl = big_piece_slot(sg.start, big_piece_count(sg.start, sg.n) - 1u);
-  const size_t st = (size_t)nblocks * 2;
+  const uint32_t b0 = sg.start / BIG_PB, b1 = (sg.start + sg.n - 1u) / BIG_PB;
+  const double INF = 1.0 / 0.0;
+  double lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF}, sm[3] = {0.0, 0.0, 0.0};
+  for (uint32_t b = b0 + lane; b <= b1; b += WAVE) {
+    const BPart q = part[(size_t)b * 2 + ((b == b0 && sg.start > b0 * BIG_PB) ? 1u : 0u)];
+    for (int c = 0; c < 3; c++) { lo[c] = (q.lo[c] < lo[c]) ? q.lo[c] : lo[c]; hi[c] = (hi[c] < q.hi[c]) ? q.hi[c] : hi[c]; sm[c] += q.sum[c]; }
+  }
+  for (int c = 0; c < 3; c++) { lo[c] = wave_min(lo[c]); hi[c] = wave_max(hi[c]); sm[c] = wave_add(sm[c]); }
+  if (lane != 0) return;
   BMeas m;
-  for (int ax = 0; ax < 3; ax++) { const BPre b = preout[(size_t)ax * st + sl]; m.lo[ax] = b.lo; m.hi[ax] = b.hi; m.mean[ax] = 0.0; }
-  const uint32_t split = big_split_axis(preout, st, sl);
-  double v = preout[(size_t)split * st + sl].v / (double)sg.n;
-  if (fault) v += 0.125 * (m.hi[split] - v);               // test only: a split value that cuts elsewhere (never outside the node)
+  for (int c = 0; c < 3; c++) { m.lo[c] = lo[c]; m.hi[c] = hi[c]; m.mean[c] = 0.0; }
+  const double hx = 0.5 * (hi[0] - lo[0]), hy = 0.5 * (hi[1] - lo[1]), hz = 0.5 * (hi[2] - lo[2]);
+  const uint32_t split = (hx > hy) ? ((hx > hz) ? 0u : 2u) : ((hy > hz) ? 1u : 2u);      // big_split_axis / decide_node
+  double v = sm[split] / (double)sg.n;
+  if (fault) v += 0.125 * (hi[split] - v);                 // test only: a split value that cuts elsewhere (never outside the node)
   m.mean[split] = v;
   meas[i] = m;
   L.axis[i] = split;
 }
-// the coordinates of the big nodes' points along their nodes' split axes, as they stand before this level's partition
-__global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ axis_of, const double* __restrict__ cx,
-                                const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M, double* __restrict__ snap)
+// the level as it stands before its partition pass: coordinates and labels (the exact chain reads these, later)
+__global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const double* __restrict__ cx, const double* __restrict__ cy,
+                                const double* __restrict__ cz, uint32_t M, uint32_t n1, double* __restrict__ snap,
+                                uint32_t* __restrict__ seg_snap)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
-  const uint32_t sid = seg_of[p];
-  if (sid == 0xFFFFFFFFu) return;
-  const uint32_t ax = axis_of[sid];
-  if (ax < 3u) snap[p] = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
+  snap[p] = cx[p]; snap[(size_t)n1 + p] = cy[p]; snap[2 * (size_t)n1 + p] = cz[p];
+  seg_snap[p] = seg_of[p];
 }
 // after the level's count: where each internal big node's record is and how many points went left
 __global__ void k_spec_keep(const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
@@ -1281,12 +1381,13 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     spec_on = spec;
     BSpecAll SP;
     SP.n = 0;
-    size_t SO[BIG_SPEC_MAX * 12 + 4];
+    size_t SO[BIG_SPEC_MAX * SPEC_SLOTS + 4];
     int spec_levels = 0;
-    void* tmp2 = nullptr;
+    void *tmp2 = nullptr, *tmp3 = nullptr;
     if (spec) {
       (void)spec_layout(M_, build_layout(M_, nullptr, nullptr), SO, &spec_levels);
-      tmp2 = arena + SO[BIG_SPEC_MAX * 12];
+      tmp2 = arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS];
+      tmp3 = arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS + 2];
     }
     const int big_dbg = big_dbg_all & (3 | 16);   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
@@ -1339,7 +1440,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           // this level from the plain sums; its exact sums on the second stream, from a snapshot of the coordinates
           spec_this = true;
           BSpecLevel& L = SP.L[SP.n];
-          const size_t* o = SO + (size_t)SP.n * 12;
+          const size_t* o = SO + (size_t)SP.n * SPEC_SLOTS;
           L.pieces = (BPiece*)(arena + o[0]); L.preout = (BPre*)(arena + o[1]); L.own = (BSum*)(arena + o[2]);
           L.comp = (BSum*)(arena + o[3]); L.wlist = (uint32_t*)(arena + o[4]); L.snap = (double*)(arena + o[5]);
           L.segs = (BSeg*)(arena + o[6]); L.axis = (uint32_t*)(arena + o[7]); L.node = (uint32_t*)(arena + o[8]);
@@ -1347,22 +1448,32 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           L.level = level; L.pad = 0;
           SP.n++;
           const size_t nsl = (size_t)nblocks * 2 * 3, nsl1 = (size_t)nblocks * 2;
-          hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
-                             nblocks, L.pieces, prein);
-          size_t stb = scan_tmp;
-          BCHK(rocprim::inclusive_scan(tmp, stb, prein, L.preout, nsl, BPreOp(), s));
-          hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, nblocks, L.preout, meas, L, spec_fault);
-          hipLaunchKernelGGL(k_spec_snapshot, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, L.axis, cx, cy, cz, M, L.snap);
+          L.prein = (BPre*)(arena + o[12]); L.seg_of = (uint32_t*)(arena + o[13]);
+          BPart* part = (BPart*)(arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS + 1]);
+          double *sx = L.snap, *sy = L.snap + n1, *sz = L.snap + 2 * n1;
+          hipLaunchKernelGGL(k_big_partials, dim3(cdiv(M, BIG_PB)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M, part);
+          hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, part, meas, L, spec_fault);
+          hipLaunchKernelGGL(k_spec_snapshot, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, cx, cy, cz, M, (uint32_t)n1, L.snap, L.seg_of);
+          // the exact chain of this level, all of it, on the snapshot.  The chains of different levels do not depend on each
+          // other: the root's (1.3 ms of one wave) runs on one background stream, every other level's on the second -- in a
+          // single stream the levels' chains queue up behind the root's and together outlast the build
+          const bool use3 = side->s3 && (SP.n - 1) != 0;
+          hipStream_t sb = use3 ? side->s3 : side->s2;
+          void* tmpb = use3 ? tmp3 : tmp2;
           BCHK(hipEventRecord(side->e1, s));
-          BCHK(hipStreamWaitEvent(side->s2, side->e1, 0));
-          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(nsl1, 64)), dim3(64), 0, side->s2, L.segs, L.snap, L.snap, L.snap, nblocks,
+          BCHK(hipStreamWaitEvent(sb, side->e1, 0));
+          hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, sb, L.segs, L.seg_of, sx, sy, sz, M,
+                             nblocks, L.pieces, L.prein);
+          size_t stb = scan_tmp;
+          BCHK(rocprim::inclusive_scan(tmpb, stb, L.prein, L.preout, nsl, BPreOp(), sb));
+          hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(nsl1, 64)), dim3(64), 0, sb, L.segs, sx, sy, sz, nblocks,
                              L.pieces, L.preout, L.own, big_dbg);
           stb = scan_tmp;
           BSum ident;
           ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u; ident.cnt = 0u; ident.pad = 0u;
-          BCHK(rocprim::exclusive_scan(tmp2, stb, L.own, L.comp, ident, nsl1, BSumOp(), side->s2));
-          hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, side->s2, L.own, L.comp, (uint32_t)nsl1, L.wlist);
-          hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, side->s2, L.segs, lv, L.snap, L.snap, L.snap,
+          BCHK(rocprim::exclusive_scan(tmpb, stb, L.own, L.comp, ident, nsl1, BSumOp(), sb));
+          hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, sb, L.own, L.comp, (uint32_t)nsl1, L.wlist);
+          hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz,
                              nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg);
         } else if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
@@ -1440,6 +1551,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       // the exact sums have to be there now: check every big node's cut against them, give its record the exact value
       BCHK(hipEventRecord(side->e2, side->s2));
       BCHK(hipStreamWaitEvent(s, side->e2, 0));
+      if (side->s3) { BCHK(hipEventRecord(side->e3, side->s3)); BCHK(hipStreamWaitEvent(s, side->e3, 0)); }
       hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
       hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
       BCHK(hipMemcpyAsync(&h_spec_err, small + 3, 4, hipMemcpyDeviceToHost, s));
@@ -1468,7 +1580,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
   return res;
 fail:
-  if (spec_on) (void)hipStreamSynchronize(side->s2);     // nothing of this build may still be running in the arena
+  if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); }   // nothing of this build may still be running in the arena
   if (f_nodes) pool_free(f_nodes);
   if (f_r) pool_free(f_r);
   if (f_leaf) pool_free(f_leaf);
@@ -1486,40 +1598,50 @@ fail:
   return res;
 }
 
-// the per-level buffers of the speculative build behind the main layout: SO[12 l + k] for level l, SO[12 BIG_SPEC_MAX] the
-// second stream's scan temporary; returns the total size
+// the per-level buffers of the speculative build behind the main layout: SO[SPEC_SLOTS l + k] for level l,
+// SO[SPEC_SLOTS BIG_SPEC_MAX] the second stream's scan temporary, + 1 the block partials; returns the total size.  The
+// chain is long on the top levels only (two-sided coordinates), and a level's snapshot is 28 bytes per point: the
+// eight top levels are speculated, big levels below them (clouds of more than 2M points) go the in-order way.
+#define BIG_SPEC_LEVELS 8
 static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out)
 {
   size_t off = (base + 255) & ~(size_t)255;
   int nlev = 0;
   if (M >= BIG_MIN)
-    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN / 2 && nlev < BIG_SPEC_MAX; level++) nlev++;
+    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN / 2 && nlev < BIG_SPEC_LEVELS; level++) nlev++;
   if (getenv("TDTK_BUILD_SPEC") && getenv("TDTK_BUILD_SPEC")[0] == '0') nlev = 0;
   const size_t n1 = M + 1, nsl = 6 * (M / BIG_CH + 2), nsl1 = nsl / 3 + 3;
   auto take = [&](size_t bytes, size_t* slot) { if (slot) *slot = off; off += (bytes + 255) & ~(size_t)255; };
   for (int l = 0; l < nlev; l++) {
     size_t maxseg = (l < 40) ? ((size_t)1 << l) : n1;
     if (maxseg > n1) maxseg = n1;
-    size_t* o = SO ? SO + (size_t)l * 12 : nullptr;
+    size_t* o = SO ? SO + (size_t)l * SPEC_SLOTS : nullptr;
     take(sizeof(BPiece) * nsl, o ? o + 0 : nullptr);
     take(sizeof(BPre) * nsl, o ? o + 1 : nullptr);
     take(sizeof(BSum) * nsl1, o ? o + 2 : nullptr);
     take(sizeof(BSum) * nsl1, o ? o + 3 : nullptr);
     take(4 * (nsl1 + 1), o ? o + 4 : nullptr);
-    take(8 * n1, o ? o + 5 : nullptr);
+    take(8 * 3 * n1, o ? o + 5 : nullptr);
     take(sizeof(BSeg) * maxseg, o ? o + 6 : nullptr);
     take(4 * maxseg, o ? o + 7 : nullptr);
     take(4 * maxseg, o ? o + 8 : nullptr);
     take(4 * maxseg, o ? o + 9 : nullptr);
     take(4 * maxseg, o ? o + 10 : nullptr);
     take(sizeof(BMeas) * maxseg, o ? o + 11 : nullptr);
+    take(sizeof(BPre) * nsl, o ? o + 12 : nullptr);
+    take(4 * n1, o ? o + 13 : nullptr);
   }
   size_t scan_tmp = 0;
   if (nlev) {
     BSum* zs = nullptr;
     (void)rocprim::exclusive_scan(nullptr, scan_tmp, zs, zs, BSum(), nsl, BSumOp(), (hipStream_t)0);
+    BPre* zp = nullptr; size_t tp = 0;
+    (void)rocprim::inclusive_scan(nullptr, tp, zp, zp, nsl, BPreOp(), (hipStream_t)0);
+    if (tp > scan_tmp) scan_tmp = tp;
   }
-  take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * 12 : nullptr);
+  take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS : nullptr);
+  take(sizeof(BPart) * 2 * (M / BIG_PB + 2), SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS + 1 : nullptr);
+  take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS + 2 : nullptr);      // the third stream's scan temporary
   if (nlev_out) *nlev_out = nlev;
   return off;
 }

@@ -175,7 +175,7 @@ struct DevBuildResult {
 size_t device_build_arena_bytes(size_t M);
 // `side` (nullable): a second stream and two events of the caller's for the build's background chain -- with it the exact
 // centroid sums of the big nodes run beside the levels below them (see "speculative splits" in build.hip)
-struct BuildSide { hipStream_t s2; hipEvent_t e1, e2; };
+struct BuildSide { hipStream_t s2, s3; hipEvent_t e1, e2, e3; };   // s3 / e3 nullable: one background stream only
 DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s,
                                  const BuildSide* side = nullptr);
 

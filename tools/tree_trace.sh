@@ -30,7 +30,7 @@ for r in sel:
     if short.startswith("k_measure"): lvl += 1
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     st = (int(r["Start_Timestamp"]) - t0) / 1e3
-    if dur > 8 or short.startswith("k_measure") or short.startswith("k_big_stitch") or lvl >= 17:
+    if dur > 3:
         print("L%02d  +%8.1f us  %7.1f us  %s" % (lvl, st, dur, short[:60]))
 print("total span %.1f us" % ((int(sel[-1]["End_Timestamp"]) - t0) / 1e3))
 PY
