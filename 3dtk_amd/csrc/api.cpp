@@ -48,8 +48,7 @@ static double now_ms()
 // ------------------------------------------------------------------------------------------
 // per-thread, per-device context: stream, events, growable workspaces
 // ------------------------------------------------------------------------------------------
-// the arrays of trees and resident scans come from the pool (pool.cpp); the per-context workspaces below stay plain
-// allocations (they live as long as the thread's context)
+// the arrays of trees and resident scans and the per-context workspaces below come from the pool (pool.cpp)
 static inline hipError_t handle_malloc(void** p, size_t bytes) { return (hipError_t)pool_malloc_raw(p, bytes); }
 
 struct DevBuf {
@@ -58,14 +57,14 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) pool_free(p); }     // (pooled like the handles' arrays: the contexts of a prefetch pool's threads come and go)
   int ensure(size_t bytes)
   {
     if (bytes <= cap) return TDTK_OK;
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p);
     p = nullptr; cap = 0;
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = (hipError_t)pool_malloc_raw(&p, want);
     if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return TDTK_ENOMEM; }
     cap = want;
     return TDTK_OK;
@@ -208,11 +207,6 @@ static int get_ctx(int device, Ctx** out, bool touches_scans = true)
     HIPCHK(hipEventCreate(&c->e5));
     HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_defer, hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->e_b3, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->e_b1, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->e_b2, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
     it = g_ctx.emplace(device, std::move(c)).first;
     g_ctx_live.fetch_add(1);
@@ -356,14 +350,23 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[a]; t->bbmax[a] = c->h_pin[3 + a]; }
   const double t1 = now_ms();
   t->info.upload_ms = t1 - t0;
-  if ((rc = c->ws[WS_ARENA].ensure(device_build_arena_bytes(M)))) return rc;
+  const bool alone = g_ctx_live.load() <= 2;
+  if ((rc = c->ws[WS_ARENA].ensure(device_build_arena_bytes(M, alone)))) return rc;
   // The background chain of the build needs a stream of its own, and the runtime has four hardware queues for all the
   // streams of the process: when several host threads are at work -- a doICP that prepares
   // three scans ahead -- a sixth and seventh stream end up queued behind other threads' kernels, the root's chain (one
   // wave, 1.2 ms) in front of somebody's search, and ten 1M-point scans take 43.5 ms instead of 36.4.  So: beside at
   // most one other thread.
+  if (alone && !c->stream_b) {
+    // made when first needed: every stream of the process takes a share of the four hardware queues, used or not, and
+    // the worker threads of a prefetch pool never build alone
+    HIPCHK(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b1, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b3, hipEventDisableTiming));
+  }
   const BuildSide side = {c->stream_b, c->stream_c, c->e_b1, c->e_b2, c->e_b3};
-  const bool alone = g_ctx_live.load() <= 2;
   DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, alone ? &side : nullptr);
   if (r.respeculated) g_respeculated.fetch_add(1);
   if (r.err != hipSuccess) {

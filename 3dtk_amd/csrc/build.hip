@@ -1324,7 +1324,11 @@ static inline int bits_for(uint64_t v)
 // number is still unknown)
 static size_t build_layout(size_t M, size_t* offs, size_t* scan_tmp_out);
 static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out);
-size_t device_build_arena_bytes(size_t M) { return spec_layout(M, build_layout(M, nullptr, nullptr), nullptr, nullptr); }
+size_t device_build_arena_bytes(size_t M, bool with_background_chain)
+{
+  const size_t base = build_layout(M, nullptr, nullptr);
+  return with_background_chain ? spec_layout(M, base, nullptr, nullptr) : base;
+}
 
 // Builds on `s` inside the caller's scratch `arena_` (>= device_build_arena_bytes(M), reused from build to build:
 // no hipMalloc / hipFree of hundreds of MB per tree, and no device-wide sync from hipFree while another thread's

@@ -172,7 +172,7 @@ struct DevBuildResult {
   bool respeculated;   // the speculative build failed its check (or fell over) and the in-order build took its place
 };
 // level-synchronous construction of the reference's kd-tree on the device (build.hip)
-size_t device_build_arena_bytes(size_t M);
+size_t device_build_arena_bytes(size_t M, bool with_background_chain = true);
 // `side` (nullable): a second stream and two events of the caller's for the build's background chain -- with it the exact
 // centroid sums of the big nodes run beside the levels below them (see "speculative splits" in build.hip)
 struct BuildSide { hipStream_t s2, s3; hipEvent_t e1, e2, e3; };   // s3 / e3 nullable: one background stream only
