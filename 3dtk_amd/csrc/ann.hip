@@ -614,6 +614,7 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
   take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
   take(4 * (ANN_MAX_LEVELS + 2));                                            // 23 cells per level
+  take(scan_pair27_state_bytes(n1));                                         // 24 state of the one-launch scan (sort.hip)
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
@@ -645,6 +646,10 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   uint32_t* lvl = (uint32_t*)(arena + O[23]);
   ACHK(hipMemsetAsync(small, 0, 256, s));
   ACHK(hipMemsetAsync(lvl, 0, 4 * (ANN_MAX_LEVELS + 2), s));
+  // the partition's scans in one launch each while the positions fit their 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
+  static const bool own_scan_env = [] { const char* e = getenv("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
+  const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
+  if (own_scan) ACHK(hipMemsetAsync(arena + O[24], 0, scan_pair27_state_bytes(n1), s));
   hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2);
   ACHK(launch_bbox(d_xyz, M, partial, box, s));
   hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt, lvl);
@@ -668,8 +673,12 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
           hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
         else
           hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
-        size_t st = scan_tmp;
-        ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+        if (own_scan && 2u * level + (uint32_t)pass < 255u) {
+          ACHK(launch_scan_pair27(LR, AB, n1, arena + O[24], 2u * level + (uint32_t)pass, small + 2, s));
+        } else {
+          size_t st = scan_tmp;
+          ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+        }
         hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
         hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
       }

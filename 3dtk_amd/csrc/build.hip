@@ -1397,6 +1397,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
     BCHK(hipMemsetAsync(small, 0, 256, s));
+    // the partition's scan in one launch while the positions fit its 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
+    static const bool own_scan_env = [] { const char* e = getenv("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
+    const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
+    const size_t o_scanstate = O[31];
+    if (own_scan) BCHK(hipMemsetAsync(arena + o_scanstate, 0, scan_pair27_state_bytes(n1), s));
     BCHK(hipMemsetAsync(lvl, 0, sizeof(BLevel) * (BUILD_MAX_LEVELS + 2), s));
     const BSeg root = {0u, M, -1, 0u};
     const BLevel l0 = {1u, 0u, 0u};
@@ -1521,8 +1526,12 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           hipLaunchKernelGGL(k_misplaced_children, dim3(nbm + cdiv(bound, 256)), dim3(256), 0, s, seg_of, kind, segs, axis,
                              splitval, nleft, cx, cy, cz, M, LR, nbm, lv, irank, next, small + 2);
         }
-        st = scan_tmp;
-        BCHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+        if (own_scan && level < 255u) {
+          BCHK(launch_scan_pair27(LR, AB, n1, arena + o_scanstate, level + 1u, small + 2, s));    // one launch (sort.hip)
+        } else {
+          st = scan_tmp;
+          BCHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
+        }
         hipLaunchKernelGGL(k_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
         {
           const uint32_t nbs = cdiv((size_t)M / 2 + 1, 256);
@@ -1685,7 +1694,8 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(sizeof(BPre) * nsl); take(sizeof(BPre) * nsl);                       // 25 26 plain prefix in / out
   take(sizeof(BSum) * nsl); take(sizeof(BSum) * nsl);                       // 27 28 piece summaries, folded runs
   take(4 * (nsl + 1));                                                      // 29 slots of the walked pieces, in run order
-  if (getenv("TDTK_BIG_DEBUG") && (atoi(getenv("TDTK_BIG_DEBUG")) & 8)) take(sizeof(BMeas) * n1);   // 30 debug: the chain's results
+  take(getenv("TDTK_BIG_DEBUG") && (atoi(getenv("TDTK_BIG_DEBUG")) & 8) ? sizeof(BMeas) * n1 : 256);   // 30 debug: the chain's results
+  take(scan_pair27_state_bytes(n1));                                        // 31 state of the one-launch scan
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
