@@ -820,6 +820,38 @@ static void finish_sums(const double* acc, const double shift[3], size_t nq, uns
   }
 }
 
+// The pair sums of a pass land in pinned host memory, one 8-byte store per sum (k_final).  Waiting for them with
+// hipStreamSynchronize costs ~6 us more per round trip on this box than watching the words themselves
+// (tools/micro/sync_cost.hip: 12.7 against 6.3 us for an empty kernel), which is a sixth of a small scan's ICP iteration:
+// the host arms every word with a NaN no sum can produce, launches, and reads until none is left.  The stream is asked
+// now and then, so a failed launch ends the wait with its error and a finished stream ends it whatever the words say.
+// TDTK_POLL_SUMS=0: hipStreamSynchronize.
+static const uint64_t SUMS_ARMED = 0x7FF8DEADBEEF0001ull;
+static bool poll_sums()
+{
+  static const bool on = [] { const char* e = getenv("TDTK_POLL_SUMS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static void arm_sums(double* h_pin)
+{
+  volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(h_pin);
+  for (int k = 0; k < ACC_TOTAL; k++) w[k] = SUMS_ARMED;
+}
+static hipError_t await_sums(const double* h_pin, hipStream_t s)
+{
+  const volatile uint64_t* w = reinterpret_cast<const volatile uint64_t*>(h_pin);
+  for (uint32_t spins = 1;; spins++) {
+    bool all = true;
+    for (int k = ACC_TOTAL - 1; k >= 0 && all; k--) all = w[k] != SUMS_ARMED;
+    if (all) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) return q;
+    }
+  }
+}
+
 // search + accumulate over a resident scan.  acc_out (host, ACC_TOTAL) receives raw columns.
 static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, int pmode,
                      double maxd2, unsigned want, const double* lum_D, const double* pending,
@@ -878,9 +910,12 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     if (fused) {
       const bool tm = kernel_timing();
       if (tm) HIPCHK(hipEventRecord(c->e2, s));
+      const bool poll = !tm && poll_sums();
+      if (poll) arm_sums(c->h_pin);
       HIPCHK(launch_final(sa.partials, rows, c->h_pin, s));
       if (tm) { HIPCHK(hipEventRecord(c->e3, s)); c->ev2_pending = true; }
-      HIPCHK(hipStreamSynchronize(s));
+      if (poll) HIPCHK(await_sums(c->h_pin, s));
+      else HIPCHK(hipStreamSynchronize(s));
       std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
       return TDTK_OK;
     }
@@ -903,9 +938,12 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   // between the last kernel and the host solve, which matters when an iteration is ~100 us
   const bool tm = kernel_timing();
   if (tm) HIPCHK(hipEventRecord(c->e2, s));
+  const bool poll = !tm && poll_sums();
+  if (poll) arm_sums(c->h_pin);
   HIPCHK(launch_accum(aa, grid, want, pmode, c->h_pin, s));
   if (tm) { HIPCHK(hipEventRecord(c->e3, s)); c->ev2_pending = true; }
-  HIPCHK(hipStreamSynchronize(s));
+  if (poll) HIPCHK(await_sums(c->h_pin, s));
+  else HIPCHK(hipStreamSynchronize(s));
   std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
   return TDTK_OK;
 }
