@@ -2051,8 +2051,8 @@ static bool fuse_lum_enabled()
 static int link_batch_max()
 {
   const char* e = getenv("TDTK_LINK_BATCH");   // 0 / 1: the lanes below
-  int v = e ? atoi(e) : 64;
-  if (v > 64) v = 64;
+  int v = e ? atoi(e) : 128;   // (84 links of 1M points: one launch 11.20 ms per LUM round, 64 + 20: 11.22-11.27, 42 + 42: 11.22)
+  if (v > 128) v = 128;
   return v;
 }
 
@@ -2080,7 +2080,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     if ((rc = sl->part.ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
     if (max_need > 0) {
       // the stack overflow area of a batch: one column per lane of ITS grid (a tenth of what the stand-alone kernels'
-      // common area needs, and there are up to 64 of these)
+      // common area needs, and there are up to 128 of these)
       SearchArgs probe{};
       probe.n = maxN;
       const size_t lanes = (size_t)std::max(search_multi_prepare(probe, 1), search_multi_prepare(probe, G)) * 256;   // the shortest slab any

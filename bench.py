@@ -627,11 +627,11 @@ def bench_graphslam(args, rank, world, local):
         counts = vc.read()
     my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
     bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
-    # All link passes of a rank go out in launches of up to 64 links (k_search_refill_multi); the HIP events sit around the
+    # All link passes of a rank go out in launches of up to 128 links (k_search_refill_multi); the HIP events sit around the
     # LAST launch of a step.  achieved = algorithmic bytes of that launch / its duration; beside it the aggregate over
     # the whole step (bytes of all this rank's link searches / wall time of the step, exchange, solve and pose update
     # included in the denominator).
-    batch = int(os.environ.get("TDTK_LINK_BATCH", "64"))
+    batch = min(128, int(os.environ.get("TDTK_LINK_BATCH", "128")))
     batched = batch > 1 and my_links > 1 and npts >= 262144
     groups = (my_links + batch - 1) // batch if batched else my_links
     last_links = my_links - batch * (groups - 1) if batched else 1
