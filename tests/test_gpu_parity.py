@@ -721,6 +721,24 @@ def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
         np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-9 * np.abs(a).max())
     for a, b in zip((base[0], base[1], base[3]), (one_launch[0], one_launch[1], one_launch[3])):
         assert np.array_equal(a, b)             # same kernels per link, only launched together
+    # how many links share a launch changes nothing either: groups of two, and 70 links (the same five pairs over and
+    # over: more than the 64 a launch took until round 3) in one
+    monkeypatch.delenv("TDTK_FUSE_LUM")
+    monkeypatch.setenv("TDTK_LINK_BATCH", "2")
+    pairs = blocks()
+    for a, b in zip((one_launch[0], one_launch[1], one_launch[3]), (pairs[0], pairs[1], pairs[3])):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("TDTK_LINK_BATCH")
+    links = [links[i % 5] for i in range(70)]
+    nl = len(links)
+    first = (C.c_void_p * nl)(*[scans[a].getSearchTree()._h for a, b in links])
+    second = (C.c_void_p * nl)(*[scans[b].handle for a, b in links])
+    dal = np.ascontiguousarray(np.stack([scans[a].dalignxf for a, b in links]))
+    many = blocks()
+    for i in range(nl):
+        assert many[2][i] == one_launch[2][i % 5]
+        for a, b in zip((one_launch[0], one_launch[1], one_launch[3]), (many[0], many[1], many[3])):
+            assert np.array_equal(a[i % 5], b[i])
 
 
 def test_tree_edge_cases(tdtk, orc, gpu):
