@@ -104,6 +104,13 @@ struct Lane {
   ~Lane() { if (s && owns) (void)hipStreamDestroy(s); }
 };
 
+// batched link passes: what each query of the link at this position of the launch order cost in the previous pass (one
+// byte per query: the next pass's hand-out order), and which link that was
+struct LinkCost {
+  DevBuf cost;
+  const void* tree = nullptr; const void* scan = nullptr; size_t n = 0;
+};
+
 struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
@@ -127,6 +134,7 @@ struct Ctx {
   uint64_t counted_queries = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
   std::vector<std::unique_ptr<Lane>> slots;   // per-link buffers of a several-links-in-one-launch batch (no streams)
+  std::vector<std::unique_ptr<LinkCost>> link_costs;
   DevBuf multi_args;                          // its argument tables on the device
   QueueCtr qc;       // for launches on `stream` (a caller's stream gets its launches ordered behind it, see run_search)
   // a context dies with its host thread (worker threads of a prefetch pool come and go): give everything back
@@ -2073,6 +2081,20 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     max_need = std::max(max_need, (int)first[i]->info.max_depth - 1 - search_lds_depth());
   }
   const int G = std::min(gb, nlinks);
+  // A wave hands out each piece of its slab with the queries that were expensive in the previous pass of the same link
+  // first, as the single pass does (k_search_refill, ORDER): 84 links of 1M points 9.18 -> 8.91 ms per LUM round.  The
+  // order changes which lanes share a trip, never a result.  TDTK_LINK_ORDERED=0: in slab order.
+  const bool ordered_env = [] { const char* e = getenv("TDTK_LINK_ORDERED"); return !(e && e[0] == '0'); }();   // (per call: tests flip it)
+  const bool ordered = ordered_env && !c->counting && search_multi_class(maxN) == 20 && search_multi_thresh(maxN) == 16;
+  if (ordered) {
+    while ((int)c->link_costs.size() < nlinks) c->link_costs.emplace_back(new LinkCost);
+    for (int p = 0; p < nlinks; p++) {
+      LinkCost* lc = c->link_costs[p].get();
+      const void* before = lc->cost.p;
+      if ((rc = lc->cost.ensure(maxN))) return rc;
+      if (lc->cost.p != before) lc->tree = nullptr;
+    }
+  }
   while ((int)c->slots.size() < G) c->slots.emplace_back(new Lane);
   for (int g = 0; g < G; g++) {          // every buffer at its final size before anything is enqueued
     Lane* sl = c->slots[g].get();
@@ -2139,6 +2161,12 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       if (need > 0) { sa.ovf_m2 = sl->ovf_m2.as<double>(); sa.ovf_ref = sl->ovf_ref.as<uint32_t>(); }
       if (c->counting) sa.counters = c->d_counters.as<unsigned long long>();
       const uint32_t nb = search_multi_prepare(sa, l1 - l0);
+      if (ordered) {
+        LinkCost* lc = c->link_costs[p].get();
+        sa.cost = lc->cost.as<unsigned char>();
+        sa.use_cost = (lc->tree == (const void*)t && lc->scan == (const void*)data && lc->n == data->N) ? 1 : 0;
+        lc->tree = t; lc->scan = data; lc->n = data->N;
+      }
       hsb[i + gi] = sb; sb += nb;
       hsa[i] = sa;
       AccumArgs aa{};
@@ -2166,7 +2194,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     const bool timed = (gi == ngroups - 1) && kernel_timing();   // tdtk_last_kernel_ms: the last group's search launch
     if (timed) HIPCHK(hipEventRecord(c->e0, s));
     HIPCHK(launch_search_multi(reinterpret_cast<const SearchArgs*>(dbase + o_sa) + l0,
-                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], cls, thresh, c->counting, s));
+                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], cls, thresh, c->counting, s, ordered));
     if (timed) { HIPCHK(hipEventRecord(c->e1, s)); c->ev_pending = true; }
     HIPCHK(launch_accum_multi(reinterpret_cast<const AccumArgs*>(dbase + o_aa) + l0,
                               reinterpret_cast<const uint32_t*>(dbase + o_ab) + l0 + gi, nb, a_total[gi], want,

@@ -140,7 +140,7 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch);   // sets the
 int search_multi_thresh(size_t n);
 int search_multi_class(size_t n);   // the kernel family a batch of n queries gets (20 / 4 / 10); 0: not available in this form
 hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int cls, int thresh,
-                               bool count, hipStream_t s);
+                               bool count, hipStream_t s, bool ordered = false);
 hipError_t launch_accum_multi(const AccumArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, unsigned want,
                               const FinalDesc* d_final, hipStream_t s);
 int search_lds_depth();

@@ -21,6 +21,7 @@
 #include <vector>
 #include <algorithm>
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdio>
@@ -1383,7 +1384,8 @@ __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false,
+          int ORD_MAX = 256>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ uint4 lds_stk[SD][BLOCK];
@@ -1420,9 +1422,10 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   // number of buckets each query visited in the previous pass.  Lanes that work on queries of similar length at the same
   // time waste fewer of each other's issue slots, and the drain at the end of the piece is over cheap queries
   // (tools/sim/wave_sched.c: -7 % wave instructions on a converged pair, -14 % mid-ICP with the true costs as the key).
-  constexpr int ORD_MAX = 256;
-  __shared__ unsigned char lds_order[ORDER ? BLOCK / WAVE : 1][ORDER ? ORD_MAX : 4];
-  unsigned char* const my_order = lds_order[ORDER ? threadIdx.x / WAVE : 0];
+  // (ORD_MAX: the longest piece that can be ordered -- 256 for the single pass, 320 for the link passes' half slabs)
+  typedef typename std::conditional<(ORD_MAX > 256), unsigned short, unsigned char>::type ord_t;
+  __shared__ ord_t lds_order[ORDER ? BLOCK / WAVE : 1][ORDER ? ORD_MAX : 4];
+  ord_t* const my_order = lds_order[ORDER ? threadIdx.x / WAVE : 0];
   bool ordered = false;
   size_t piece0 = 0;
   auto order_piece = [&](size_t p0, size_t p1) {
@@ -1458,7 +1461,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       for (int r = 0; r < ORD_MAX / WAVE; r++) {
         if ((uint32_t)r * WAVE >= cntp) continue;
         const unsigned long long m = __ballot(cls[r] == k);
-        if (cls[r] == k) my_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)(r * WAVE + lane);
+        if (cls[r] == k) my_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (ord_t)(r * WAVE + lane);
         base += (uint32_t)__popcll(m);
       }
     }
@@ -2004,7 +2007,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
 // batch l with the arguments args[l] (device memory; every base[] a multiple of 8, so a workgroup's XCD is the one its
 // batch-relative index says).  Workgroups are dispatched in order, so the tail of one batch is filled by the next --
 // what several streams give, without depending on how the runtime maps streams to hardware queues.
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool ORDER = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const SearchArgs* __restrict__ args,
                                                                     const uint32_t* __restrict__ base, int nbatch)
 {
@@ -2012,7 +2015,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const Search
   while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
   l = __builtin_amdgcn_readfirstlane(l);
   const uint32_t b0 = base[l], b1 = base[l + 1];
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, false>(args[l], blockIdx.x - b0, b1 - b0);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3135,7 +3138,7 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
 }
 int search_multi_thresh(size_t n) { return refill_thresh(n); }
 hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int cls, int thresh,
-                               bool count, hipStream_t s)
+                               bool count, hipStream_t s, bool ordered)
 {
   if (!nbatch || !total_blocks) return hipSuccess;
   if (cls == 4 || cls == 10) {   // small batches: one query per lane / four lanes per query, as launch_search would pick
@@ -3156,7 +3159,10 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
     switch (thresh) {
       case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
       case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
-      default: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      default:
+        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        break;
     }
   }
   return hipGetLastError();

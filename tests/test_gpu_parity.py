@@ -735,6 +735,13 @@ def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
     second = (C.c_void_p * nl)(*[scans[b].handle for a, b in links])
     dal = np.ascontiguousarray(np.stack([scans[a].dalignxf for a, b in links]))
     many = blocks()
+    again = blocks()            # the second pass over the same links hands its slabs out by the first pass's costs ...
+    monkeypatch.setenv("TDTK_LINK_ORDERED", "0")
+    plain = blocks()            # ... and this one in slab order: the order never shows in a result
+    monkeypatch.delenv("TDTK_LINK_ORDERED")
+    assert many[2] == again[2] == plain[2]
+    for a, b, c in zip((many[0], many[1], many[3]), (again[0], again[1], again[3]), (plain[0], plain[1], plain[3])):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
     for i in range(nl):
         assert many[2][i] == one_launch[2][i % 5]
         for a, b in zip((one_launch[0], one_launch[1], one_launch[3]), (many[0], many[1], many[3])):

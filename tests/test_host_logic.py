@@ -846,7 +846,8 @@ def test_timed_search_kernels_keep_four_waves_per_simd_and_spill_nothing():
     kernels = {
         "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0ELi4ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, false>",
         "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0ELi4ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false, 4, 0, false>",
-        "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0>",
+        "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0ELb0EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0, false>",
+        "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0ELb1EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0, true> (ordered hand-out: the link passes' default)",
     }
     for mangled, name in kernels.items():
         i = text.find("Function Name: " + mangled + " ")
