@@ -2085,7 +2085,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   // first, as the single pass does (k_search_refill, ORDER): 84 links of 1M points 9.18 -> 8.91 ms per LUM round.  The
   // order changes which lanes share a trip, never a result.  TDTK_LINK_ORDERED=0: in slab order.
   const bool ordered_env = [] { const char* e = getenv("TDTK_LINK_ORDERED"); return !(e && e[0] == '0'); }();   // (per call: tests flip it)
-  const bool ordered = ordered_env && !c->counting && search_multi_class(maxN) == 20 && search_multi_thresh(maxN) == 16;
+  const bool ordered = ordered_env && !c->counting && search_multi_class(maxN) == 20;
   if (ordered) {
     while ((int)c->link_costs.size() < nlinks) c->link_costs.emplace_back(new LinkCost);
     for (int p = 0; p < nlinks; p++) {
@@ -2188,7 +2188,10 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   if ((rc = stage_pinned(c, tab.data(), total, &staged))) return rc;
   HIPCHK(hipMemcpyAsync(c->multi_args.p, staged, total, hipMemcpyHostToDevice, s));
   char* dbase = static_cast<char*>(c->multi_args.p);
-  const int thresh = search_multi_thresh(maxN), cls = search_multi_class(maxN);
+  const int cls = search_multi_class(maxN);
+  // idle lanes a wave collects before it hands out new queries: 32 once a launch is many generations of waves (84 links of
+  // 1M points, ordered: 8.93 -> 8.85 ms), as for single passes of 4M queries and more (refill_thresh)
+  const int thresh = (G > 16 && cls == 20 && !getenv("TDTK_REFILL_THRESH")) ? 32 : search_multi_thresh(maxN);
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G), nb = l1 - l0;
     const bool timed = (gi == ngroups - 1) && kernel_timing();   // tdtk_last_kernel_ms: the last group's search launch

@@ -3157,8 +3157,14 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
     }
   } else {
     switch (thresh) {
-      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
-      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      case 8:
+        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        break;
+      case 32:
+        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        break;
       default:
         if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
