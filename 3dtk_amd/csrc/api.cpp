@@ -681,7 +681,7 @@ static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
   return TDTK_OK;
 }
 
-// Retire-time accumulation inside the search kernel (kernels.hip, FUSE) is OFF by default: its 34 accumulator
+// Retire-time accumulation inside the search kernel (kernels.hip, FUSE 1) is OFF by default: its 34 accumulator
 // registers take the kernel from 7 to 4 waves per SIMD and every retire waits for its own gather, so the search
 // grows by about what the separate pair-sum pass costs (1M-vs-1M ICP: 0.2881 + 0.0072 ms fused against
 // 0.2708 + 0.0280 ms; 4M: 1.179 + 0.016 against 0.965 + 0.058 -- gpurun_out/r2a/sweep.log).  TDTK_FUSE_SUMS=1 selects it.
@@ -694,7 +694,10 @@ static int fuse_mode(size_t N)   // 0: separate k_accum, 1: at retire time, 3: b
   const int v = e ? atoi(e) : -1;
   const int kind = search_fuse_kind(N);
   if (kind == 2) return v == 0 ? 0 : 4;
-  if (kind == 1) return (v == 1 || v == 3) ? v : 0;
+  // round 3: 3 is the default -- with the bucket-group kernel (four waves per SIMD either way) the waves that are done early
+  // add up their own slabs while the launch waits for the slowest: 1M-vs-1M 0.2217 -> 0.2183 ms per iteration at the
+  // driver's arguments, 0.2000 -> 0.1925 over 100 (the separate k_accum launch, 18-24 us, is gone; the search grows by ~10)
+  if (kind == 1) return (v == 0 || v == 1) ? v : 3;
   return 0;
 }
 

@@ -2767,6 +2767,9 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   // with the slab handed out expensive queries first (a.use_cost) one piece is better: the order then spans the whole
   // slab (1M: 0.2124 -> 0.2086 ms; the twenty iterations behind the initial pose 0.2425 -> 0.2326)
   if (a.use_cost) ph = 1;
+  // ... and with the sums added up by the waves themselves (FUSE 3) the pieces decide which queries share a row of partial
+  // sums: one piece always, so that the sums do not depend on whether the hand-out is ordered
+  if (FUSE == 3) ph = 1;
   if (const char* e = getenv("TDTK_REFILL_PHASES")) ph = atoi(e);
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries
