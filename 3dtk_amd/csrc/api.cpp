@@ -2067,6 +2067,20 @@ static int link_batch_max()
   return v;
 }
 
+// The 17 sums of a lum6DEuler link added up by the search waves themselves, each over its own slab after its last query
+// (k_search_refill_multi<.., 5>): the pass over (x, y, z, hit, pts[hit]) that k_accum_multi makes disappears into the
+// search launch -- 84 links of 1M points: search 8.9 -> 9.5 ms, pair sums 1.04 -> 0, LUM round 10.95 -> 10.55 ms.  The rows
+// of partial sums are then the slabs, so every such launch uses one slab length and a lone link takes this path too: a
+// link's sums do not depend on how many links (or ranks) share the work.  TDTK_LINK_FUSE=0: k_accum_multi.
+static bool link_sums_in_search(const Ctx* c, unsigned want, size_t maxN)
+{
+  const char* e = getenv("TDTK_LINK_FUSE");
+  if (e && e[0] == '0') return false;
+  if (getenv("TDTK_REFILL_QPW") || getenv("TDTK_LINK_PHASES")) return false;   // (experiments with the slab layout)
+  const int th = search_multi_thresh(maxN);
+  return !c->counting && want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) && search_multi_class(maxN) == 20 && (th == 16 || th == 32);
+}
+
 // All links of the call in launches of up to `gb` links each: ONE search launch, one pair-sum launch and one final
 // reduction per group (k_search_refill_multi and friends: workgroups of link k+1 fill the tail of link k), everything on
 // the context's stream -- what the lanes below get from three streams, without depending on how the runtime maps streams
@@ -2089,6 +2103,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   // order changes which lanes share a trip, never a result.  TDTK_LINK_ORDERED=0: in slab order.
   const bool ordered_env = [] { const char* e = getenv("TDTK_LINK_ORDERED"); return !(e && e[0] == '0'); }();   // (per call: tests flip it)
   const bool ordered = ordered_env && !c->counting && search_multi_class(maxN) == 20;
+  const bool fuse_links = link_sums_in_search(c, want, maxN);
   if (ordered) {
     while ((int)c->link_costs.size() < nlinks) c->link_costs.emplace_back(new LinkCost);
     for (int p = 0; p < nlinks; p++) {
@@ -2102,13 +2117,21 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   for (int g = 0; g < G; g++) {          // every buffer at its final size before anything is enqueued
     Lane* sl = c->slots[g].get();
     if ((rc = sl->kpos.ensure(maxN * sizeof(int)))) return rc;
-    if ((rc = sl->part.ensure((size_t)accum_grid(maxN) * ACC_TOTAL * sizeof(double)))) return rc;
+    {
+      size_t rows = accum_grid(maxN);
+      if (fuse_links) {
+        SearchArgs probe{};
+        probe.n = maxN;
+        rows = std::max<size_t>(rows, search_multi_prepare(probe, G, true));
+      }
+      if ((rc = sl->part.ensure(rows * ACC_TOTAL * sizeof(double)))) return rc;
+    }
     if (max_need > 0) {
       // the stack overflow area of a batch: one column per lane of ITS grid (a tenth of what the stand-alone kernels'
       // common area needs, and there are up to 128 of these)
       SearchArgs probe{};
       probe.n = maxN;
-      const size_t lanes = (size_t)std::max(search_multi_prepare(probe, 1), search_multi_prepare(probe, G)) * 256;   // the shortest slab any
+      const size_t lanes = (size_t)std::max(search_multi_prepare(probe, 1, fuse_links), search_multi_prepare(probe, G, fuse_links)) * 256;   // the shortest slab any
                                                                                                         // group gets; 256: the widest workgroup
       if ((rc = sl->ovf_m2.ensure(lanes * max_need * sizeof(double)))) return rc;
       if ((rc = sl->ovf_ref.ensure(lanes * max_need * sizeof(uint32_t)))) return rc;
@@ -2163,13 +2186,14 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       const int need = (int)t->info.max_depth - 1 - search_lds_depth();
       if (need > 0) { sa.ovf_m2 = sl->ovf_m2.as<double>(); sa.ovf_ref = sl->ovf_ref.as<uint32_t>(); }
       if (c->counting) sa.counters = c->d_counters.as<unsigned long long>();
-      const uint32_t nb = search_multi_prepare(sa, l1 - l0);
+      const uint32_t nb = search_multi_prepare(sa, l1 - l0, fuse_links);
       if (ordered) {
         LinkCost* lc = c->link_costs[p].get();
         sa.cost = lc->cost.as<unsigned char>();
         sa.use_cost = (lc->tree == (const void*)t && lc->scan == (const void*)data && lc->n == data->N) ? 1 : 0;
         lc->tree = t; lc->scan = data; lc->n = data->N;
       }
+      if (fuse_links) { sa.fuse = 5; sa.A = A; sa.partials = sl->part.as<double>(); }
       hsb[i + gi] = sb; sb += nb;
       hsa[i] = sa;
       AccumArgs aa{};
@@ -2181,7 +2205,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       const uint32_t ag = accum_grid(data->N);
       hab[i + gi] = ab; ab += ag;
       haa[i] = aa;
-      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)li * ACC_TOTAL; hfd[i].rows = (int)ag; hfd[i].pad = 0;
+      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)li * ACC_TOTAL; hfd[i].rows = fuse_links ? (int)nb : (int)ag; hfd[i].pad = 0;
     }
     hsb[l1 + gi] = sb; hab[l1 + gi] = ab;
     s_total[gi] = sb; a_total[gi] = ab;
@@ -2200,11 +2224,11 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     const bool timed = (gi == ngroups - 1) && kernel_timing();   // tdtk_last_kernel_ms: the last group's search launch
     if (timed) HIPCHK(hipEventRecord(c->e0, s));
     HIPCHK(launch_search_multi(reinterpret_cast<const SearchArgs*>(dbase + o_sa) + l0,
-                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], cls, thresh, c->counting, s, ordered));
+                               reinterpret_cast<const uint32_t*>(dbase + o_sb) + l0 + gi, nb, s_total[gi], cls, thresh, c->counting, s, ordered, fuse_links));
     if (timed) { HIPCHK(hipEventRecord(c->e1, s)); c->ev_pending = true; }
     HIPCHK(launch_accum_multi(reinterpret_cast<const AccumArgs*>(dbase + o_aa) + l0,
                               reinterpret_cast<const uint32_t*>(dbase + o_ab) + l0 + gi, nb, a_total[gi], want,
-                              reinterpret_cast<const FinalDesc*>(dbase + o_fd) + l0, s));
+                              reinterpret_cast<const FinalDesc*>(dbase + o_fd) + l0, s, fuse_links));
   }
   return TDTK_OK;
 }
@@ -2226,7 +2250,8 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
   }
   {
     const int gb = link_batch_max();
-    bool ok = gb > 1 && nlinks > 1 && (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) || (want & 7u) == TDTK_WANT_LUM || (want & 7u) == 0u);
+    bool ok = gb > 1 && (nlinks > 1 || link_sums_in_search(c, want, maxN)) &&
+              (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) || (want & 7u) == TDTK_WANT_LUM || (want & 7u) == 0u);
     const int cls = search_multi_class(maxN);
     ok = ok && cls != 0;
     for (int i = 0; i < nlinks && ok; i++)      // one kernel family (and refill threshold) for the whole call

@@ -136,13 +136,13 @@ hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab
 hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);
 // several batches (the link passes of a graph-SLAM round) in one launch: see k_search_refill_multi in kernels.hip
 struct FinalDesc { const double* partials; double* out; int rows, pad; };
-uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch);   // sets the slab fields, returns the batch's workgroups (x8)
+uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slabs = false);   // sets the slab fields, returns the batch's workgroups (x8)
 int search_multi_thresh(size_t n);
 int search_multi_class(size_t n);   // the kernel family a batch of n queries gets (20 / 4 / 10); 0: not available in this form
 hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int cls, int thresh,
-                               bool count, hipStream_t s, bool ordered = false);
+                               bool count, hipStream_t s, bool ordered = false, bool lum_sums = false);
 hipError_t launch_accum_multi(const AccumArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, unsigned want,
-                              const FinalDesc* d_final, hipStream_t s);
+                              const FinalDesc* d_final, hipStream_t s, bool rows_done = false);
 int search_lds_depth();
 int search_block();
 uint32_t accum_grid(size_t n);

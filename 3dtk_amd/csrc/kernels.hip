@@ -1528,7 +1528,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   unsigned nbk = 0;   // buckets this lane's query has visited (the next pass's ordering key)
   // FUSE 1: the base pair sums (ACC_N .. ACC_P) at retire time; FUSE 2: n, sum and the LUM block of a graph-SLAM link
   // (acc[0] = n, [1] = sum |delta|^2, [2 .. 16] = the 15 sums of lum6Deuler.cc:143-175, [17] = sum u.delta)
-  constexpr int NACC = (FUSE == 2) ? 18 : ACC_DD;
+  constexpr int NACC = (FUSE == 2 || FUSE == 5) ? 18 : ACC_DD;   // FUSE 5: the block of FUSE 2, added up like FUSE 3
   double acc[NACC];   // live only when FUSE
   if (FUSE) {
 #pragma unroll
@@ -1914,7 +1914,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       atomicAdd(&a.counters[2], s_pts);
     }
   }
-  if constexpr (FUSE == 3) {
+  if constexpr (FUSE == 3 || FUSE == 5) {
     // The base pair sums of this wave's own queries, AFTER its last query has retired: the accumulators are not live
     // during the search (no occupancy cost, unlike FUSE 1), and the waves that finish early -- the median wave is done
     // after 77 % of a launch -- do this work while the machine would otherwise wait for the slowest ones.  The hits and
@@ -1953,6 +1953,23 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           if (kk[h + u] < 0) continue;
           double mx, my, mz;
           dev_xf3(a.A, cx[u], cy[u], cz[u], mx, my, mz);  // searchTree.cc:147
+          if constexpr (FUSE == 5) {   // lum6Deuler.cc:143-175 (as FUSE 2 above)
+            const double dx = mx - tx[u], dy = my - ty[u], dz = mz - tz[u];
+            const double x = (mx + tx[u]) / 2.0, y = (my + ty[u]) / 2.0, z = (mz + tz[u]) / 2.0;
+            acc[0] += 1.0;
+            acc[1] += dx * dx + dy * dy + dz * dz;
+            acc[2] += x; acc[3] += y; acc[4] += z;
+            acc[5] += x * x + y * y;
+            acc[6] += x * x + z * z;
+            acc[7] += y * y + z * z;
+            acc[8] += x * y; acc[9] += x * z; acc[10] += y * z;
+            acc[11] += dx; acc[12] += dy; acc[13] += dz;
+            acc[14] += -z * dy + y * dz;
+            acc[15] += -y * dx + x * dy;
+            acc[16] += z * dx - x * dz;
+            acc[17] += x * dx + y * dy + z * dz;
+            continue;
+          }
           const double px = mx - tx[u], py = my - ty[u], pz = mz - tz[u];
           acc[ACC_N] += 1.0;
           acc[ACC_SUM] += px * px + py * py + pz * pz;
@@ -1981,7 +1998,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
       // column k of the row <- which accumulator (FUSE 2: n, sum, ACC_L .. ACC_L + 14, ACC_LU)
       int src = -1;
-      if (FUSE == 2) src = (k == ACC_N) ? 0 : (k == ACC_SUM) ? 1 : (k >= ACC_L && k < ACC_L + 15) ? 2 + (k - ACC_L) : (k == ACC_LU) ? 17 : -1;
+      if (FUSE == 2 || FUSE == 5) src = (k == ACC_N) ? 0 : (k == ACC_SUM) ? 1 : (k >= ACC_L && k < ACC_L + 15) ? 2 + (k - ACC_L) : (k == ACC_LU) ? 17 : -1;
       else if (k < ACC_DD) src = k;
       double s = 0.0;
       if (src >= 0)
@@ -3107,7 +3124,7 @@ hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hi
 // 640 -> 11.4, 1024 -> 11.5, 1536 -> 11.7; a rank's 11 links in one launch: 320 -> 1.79 ms, 448 -> 1.77, 640 -> 1.81
 // (three streams: 12.6 / 1.89 on the same box).
 int search_multi_class(size_t n) { const int v = pick_variant(n); return (v == 20 || v == 4 || v == 10) ? v : 0; }
-uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
+uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slabs)
 {
   const int v = pick_variant(a.n);
   if (v == 4) return search_grid(a.n);
@@ -3115,7 +3132,9 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
   int qpw;
   uint32_t nb = refill_grid_b(a.n, 128, &qpw, 2);
   if (!getenv("TDTK_REFILL_QPW")) {
-    const int want = links_in_launch > 16 ? 640 : 448;
+    // (long_slabs: the waves add up their own slabs -- FUSE 5 -- so the slab length decides which queries share a row of
+    // partial sums; one length for every launch then, however many links share it)
+    const int want = (links_in_launch > 16 || long_slabs) ? 640 : 448;
     if (want > qpw) {
       qpw = want;
       const size_t waves = (a.n + (size_t)qpw - 1) / (size_t)qpw;
@@ -3141,8 +3160,9 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch)
 }
 int search_multi_thresh(size_t n) { return refill_thresh(n); }
 hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, int cls, int thresh,
-                               bool count, hipStream_t s, bool ordered)
+                               bool count, hipStream_t s, bool ordered, bool lum_sums)
 {
+  if (lum_sums && !(!count && cls == 20 && (thresh == 16 || thresh == 32))) return hipErrorInvalidValue;   // (ORDER instantiation; no cost bytes: slab order)
   if (!nbatch || !total_blocks) return hipSuccess;
   if (cls == 4 || cls == 10) {   // small batches: one query per lane / four lanes per query, as launch_search would pick
     const dim3 gs(total_blocks), bs(SEARCH_BLOCK);
@@ -3165,11 +3185,13 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
       case 32:
-        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
       default:
-        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
     }
@@ -3219,11 +3241,12 @@ hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pm
 
 // want: TDTK_WANT_LUM | ACC_WANT_NO_CROSS (a lum6DEuler link) or TDTK_WANT_LUM or TDTK_WANT_GAPX / MOM2 or 0 (base sums)
 hipError_t launch_accum_multi(const AccumArgs* d_args, const uint32_t* d_base, int nbatch, uint32_t total_blocks, unsigned want,
-                              const FinalDesc* d_final, hipStream_t s)
+                              const FinalDesc* d_final, hipStream_t s, bool rows_done)
 {
   if (!nbatch || !total_blocks) return hipSuccess;
   const dim3 g(total_blocks), b(ACC_BLOCK);
-  if (want & (TDTK_WANT_GAPX | TDTK_WANT_MOM2)) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_GAPX, 0>), g, b, 0, s, d_args, d_base, nbatch);
+  if (rows_done) {}   // (the search wrote the rows itself: FUSE 5)
+  else if (want & (TDTK_WANT_GAPX | TDTK_WANT_MOM2)) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_GAPX, 0>), g, b, 0, s, d_args, d_base, nbatch);
   else if (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS)) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_LUM | ACC_WANT_NO_CROSS, 0>), g, b, 0, s, d_args, d_base, nbatch);
   else if ((want & 7u) == TDTK_WANT_LUM) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, TDTK_WANT_LUM, 0>), g, b, 0, s, d_args, d_base, nbatch);
   else if ((want & 7u) == 0u) hipLaunchKernelGGL((k_accum_multi<ACC_BLOCK, 0u, 0>), g, b, 0, s, d_args, d_base, nbatch);

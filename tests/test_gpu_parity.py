@@ -684,9 +684,10 @@ def test_batched_scan_moves_are_visible_to_every_thread(tdtk, orc, gpu):
 
 
 def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
-    """The three ways a batch of lum6DEuler links is evaluated on big scans agree: all links in one launch
-    (k_search_refill_multi, the default), one search + k_accum per link on three streams (TDTK_LINK_BATCH=0) -- bit for
-    bit -- and TDTK_FUSE_LUM=1, the 17 sums accumulated when a query retires inside the search kernel (a measured
+    """The ways a batch of lum6DEuler links is evaluated on big scans agree: all links in one launch
+    (k_search_refill_multi) with k_accum_multi behind it (TDTK_LINK_FUSE=0) and one search + k_accum per link on three
+    streams (TDTK_LINK_BATCH=0) -- bit for bit; the default since round 3, the sums added up inside that one launch by
+    each wave over its own slab, and TDTK_FUSE_LUM=1, the 17 sums accumulated when a query retires inside the search kernel (a measured
     negative kept selectable): same blocks to rounding (the order of the additions differs), same pair counts exactly."""
     import ctypes as C
     from importlib import import_module
@@ -711,15 +712,20 @@ def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
         Cm = np.empty((nl, 36)); CD = np.empty((nl, 6)); m = (C.c_uint64 * nl)(); ss = np.empty(nl)
         capi.check(capi.lib().tdtk_lum_links(nl, first, capi.dptr(dal), second, 100.0, capi.dptr(Cm), capi.dptr(CD), m, capi.dptr(ss)))
         return Cm, CD, list(m), ss
-    one_launch = blocks()                       # default for big scans: all links in one launch
+    one_launch = blocks()                       # default for big scans: all links in one launch, the sums added up by the
+                                                # search waves over their own slabs (round 3)
+    monkeypatch.setenv("TDTK_LINK_FUSE", "0")
+    one_launch_accum = blocks()                 # ... and with k_accum_multi behind the search launch
+    monkeypatch.delenv("TDTK_LINK_FUSE")
     monkeypatch.setenv("TDTK_LINK_BATCH", "0")
     base = blocks()                             # three streams, k_accum behind every search
     monkeypatch.setenv("TDTK_FUSE_LUM", "1")
     fused = blocks()
-    assert base[2] == fused[2] == one_launch[2] and min(base[2]) > 100000
-    for a, b in zip((base[0], base[1], base[3]), (fused[0], fused[1], fused[3])):
+    assert base[2] == fused[2] == one_launch[2] == one_launch_accum[2] and min(base[2]) > 100000
+    for a, b, c in zip((base[0], base[1], base[3]), (fused[0], fused[1], fused[3]), (one_launch[0], one_launch[1], one_launch[3])):
         np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-9 * np.abs(a).max())
-    for a, b in zip((base[0], base[1], base[3]), (one_launch[0], one_launch[1], one_launch[3])):
+        np.testing.assert_allclose(c, a, rtol=1e-9, atol=1e-9 * np.abs(a).max())   # (the order of the additions differs)
+    for a, b in zip((base[0], base[1], base[3]), (one_launch_accum[0], one_launch_accum[1], one_launch_accum[3])):
         assert np.array_equal(a, b)             # same kernels per link, only launched together
     # how many links share a launch changes nothing either: groups of two, and 70 links (the same five pairs over and
     # over: more than the 64 a launch took until round 3) in one
