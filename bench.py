@@ -121,7 +121,7 @@ class kernel_timing:
         self.L.tdtk_kernel_timing(self.was)
 
 
-def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw, pmc_source=None):
+def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw, pmc_source=None, sums_inside=False):
     """The `roofline` object for k_search.  achieved = ALGORITHMIC bytes per launch (24 B query + 64 B per
     internal node + 24 B per bucket point + 4 B index, with the node / point counts of exactly the timed launches) /
     average launch duration (HIP events).  Beside it the bounds that can tell a good kernel from a better one:
@@ -129,9 +129,12 @@ def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_quer
     that did work."""
     c_int, c_leaf, c_pts, nq = counts
     bq = algorithmic_bytes_per_query(c_int / nq, c_pts / nq)
+    if sums_inside:     # the launch also adds up its pairs (round 3): 24 B query again + 4 B hit + 32 B of the hit point
+        bq += 60.0
     achieved = bq * nq_per_launch / (k_ms * 1e-3) / 1e9
     comp = (tree_info["n_internal"] * 64 + tree_info["n_points"] * 32 + extra_bytes_per_query * nq_per_launch)
-    r = {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    r = {"bound": "hbm", "kernel": "k_search" + (" (the search and, by each wave over its own slab, the pair sums: no k_accum launch)" if sums_inside else ""),
+         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc),
          "kernel_ms": k_ms, "bytes_per_query": bq,
          "visits_per_query": {"internal": c_int / nq, "leaves": c_leaf / nq, "points": c_pts / nq,
@@ -434,7 +437,8 @@ def bench_icp(args, rank, world, local):
     psrc = {"file": "profiles/" + pfile, "steps": steps, "warmup": args.warmup,
             "what": "per-launch averages over the timed region of the same command line under rocprofv3 --pmc "
                     "(tools/profile_bench.sh); refused unless steps and warmup equal this run's"} if pk else None
-    roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4, pk, bw, psrc)
+    sums_inside = os.environ.get("TDTK_FUSE_SUMS", "3") not in ("0", "1") and n >= 262144
+    roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4 + (60 if sums_inside else 0), pk, bw, psrc, sums_inside)
 
     # the same 1M queries through the host-buffer entry point (H2D of queries, in-call binning,
     # search, D2H of indices + distances): the PCIe-inclusive rate -- reported, never the `value`
@@ -627,6 +631,9 @@ def bench_graphslam(args, rank, world, local):
         counts = vc.read()
     my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
     bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
+    links_sums_inside = os.environ.get("TDTK_LINK_FUSE", "1") != "0" and npts >= 262144
+    if links_sums_inside:   # the search launch also adds up each link's 17 sums (round 3): query again + hit + the hit point
+        bq += 60.0
     # All link passes of a rank go out in launches of up to 128 links (k_search_refill_multi); the HIP events sit around the
     # LAST launch of a step.  achieved = algorithmic bytes of that launch / its duration; beside it the aggregate over
     # the whole step (bytes of all this rank's link searches / wall time of the step, exchange, solve and pose update
@@ -666,7 +673,7 @@ def bench_graphslam(args, rank, world, local):
         "exchange": exchange, "rccl_world": rccl_world, "links_per_rank": links_per_rank,
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
-        "roofline": {"bound": "hbm", "kernel": "k_search_refill_multi (link passes, up to %d links per launch)" % batch if batched
+        "roofline": {"bound": "hbm", "kernel": ("k_search_refill_multi (link passes, up to %d links per launch%s)" % (batch, "; the links' sums are added up inside it" if links_sums_inside else "")) if batched
                                                else "k_search (link passes on streams side by side)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": k_ms, "links_in_that_launch": last_links, "launches_per_step": groups,
