@@ -697,7 +697,7 @@ static int fuse_mode(size_t N)   // 0: separate k_accum, 1: at retire time, 3: b
   // round 3: 3 is the default -- with the bucket-group kernel (four waves per SIMD either way) the waves that are done early
   // add up their own slabs while the launch waits for the slowest: 1M-vs-1M 0.2217 -> 0.2183 ms per iteration at the
   // driver's arguments, 0.2000 -> 0.1925 over 100 (the separate k_accum launch, 18-24 us, is gone; the search grows by ~10)
-  if (kind == 1) return (v == 0 || v == 1) ? v : 3;
+  if (kind == 1) return (v == 0 || v == 1 || v == 3) ? v : (search_fuse_after_last_pays(N) ? 3 : 0);   // (4M and more: k_accum)
   return 0;
 }
 

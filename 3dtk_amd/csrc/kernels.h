@@ -123,6 +123,7 @@ uint32_t search_grid(size_t n);
 size_t search_max_lanes(size_t n);     // most lanes any search kernel launches for n queries (stack overflow area)
 bool search_uses_queue(size_t n);      // does it get the work-queue kernel (needs q_ctr / q_ctr_next)?
 bool search_can_fuse(size_t n);
+bool search_fuse_after_last_pays(size_t n);   // FUSE 3 by default for a batch of this size?
 int search_fuse_kind(size_t n);   // 0 no, 1 persistent-lane FUSE modes (on request), 2 chunk epilogue of the small-batch kernels        // does a batch of n queries get the kernel that can fuse the base sums?
 uint32_t search_fused_rows(size_t n, int side_by_side = 1);  // rows of partials the fused kernel writes
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);

@@ -2723,6 +2723,10 @@ static int pick_variant(size_t n)
   return v;
 }
 bool search_can_fuse(size_t n) { return pick_variant(n) == 20; }
+// FUSE 3 (each wave adds up its own slab after its last query) pays while a launch is ONE generation of resident waves,
+// whose early finishers would idle otherwise: 300K queries 79.4 -> 74.5 us per ICP iteration, 1M 0.2217 -> 0.2183 ms;
+// with several generations (4M: 0.771 -> 0.788 ms) the sums only take issue slots from the next slabs
+bool search_fuse_after_last_pays(size_t n) { return pick_variant(n) == 20 && (n + 255) / 256 < (size_t)num_cu() * 4 * 7; }
 // how the base pair sums can come out of the search of a batch this size: 1 = the persistent-lane kernel's FUSE modes
 // (measured negatives, on request only), 2 = the chunk epilogue of the small-batch kernels, 0 = not at all
 int search_fuse_kind(size_t n)

@@ -437,7 +437,7 @@ def bench_icp(args, rank, world, local):
     psrc = {"file": "profiles/" + pfile, "steps": steps, "warmup": args.warmup,
             "what": "per-launch averages over the timed region of the same command line under rocprofv3 --pmc "
                     "(tools/profile_bench.sh); refused unless steps and warmup equal this run's"} if pk else None
-    sums_inside = os.environ.get("TDTK_FUSE_SUMS", "3") not in ("0", "1") and n >= 262144
+    sums_inside = os.environ.get("TDTK_FUSE_SUMS", "3") not in ("0", "1") and 262144 <= n < 256 * 7168   # (one generation of waves: FUSE 3)
     roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4 + (60 if sums_inside else 0), pk, bw, psrc, sums_inside)
 
     # the same 1M queries through the host-buffer entry point (H2D of queries, in-call binning,
