@@ -348,6 +348,30 @@ def test_kernel_timing_is_opt_in_and_changes_nothing(tdtk, gpu):
         assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
 
 
+def test_pair_sums_inside_the_search_launch_agree_with_k_accum(tdtk, gpu, monkeypatch):
+    """From 256K queries up to one generation of resident waves the persistent-lane kernel's waves add up the base pair
+    sums of their own slabs after their last query (FUSE 3, the default since round 3); TDTK_FUSE_SUMS=0 restores the
+    separate k_accum pass.  Same hits, so the pair counts are equal exactly and the sums to rounding (the order of the
+    additions differs); the fused path itself is deterministic run to run."""
+    rng = np.random.default_rng(5)
+    m = rng.uniform(-500, 500, (300000, 3))
+    d = m[rng.permutation(len(m))] + rng.normal(0, 0.5, m.shape) + np.array([4.0, -3.0, 2.0])
+    runs = []
+    for mode in (None, None, "0"):
+        if mode is not None:
+            monkeypatch.setenv("TDTK_FUSE_SUMS", mode)
+        S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], m); S1 = tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 8, quiet=True, epsilonICP=-1.0)
+        it = icp.match(S0, S1)
+        runs.append((it, icp.last["trace"].copy(), S1.get_transMat().copy()))
+    monkeypatch.delenv("TDTK_FUSE_SUMS")
+    assert runs[0][0] == runs[1][0] == runs[2][0] == 7
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    assert np.array_equal(runs[0][1][:, 0], runs[2][1][:, 0]) and runs[0][1][-1, 0] > 0.99 * len(m)     # pairs per iteration
+    np.testing.assert_allclose(runs[0][1][:, 1], runs[2][1][:, 1], rtol=1e-12)                            # RMS per iteration
+    np.testing.assert_allclose(runs[0][2], runs[2][2], rtol=0, atol=1e-10)
+
+
 @pytest.mark.parametrize("partial", [False, True])
 def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch, partial):
     """From the second ICP iteration on the persistent-lane kernel hands a wave's slab out with the queries first that
