@@ -2248,6 +2248,43 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
     if (first[i]->device != c->device || second[i]->device != c->device) { set_error("link members on another device"); return TDTK_EINVAL; }
     maxN = std::max(maxN, second[i]->N);
   }
+  // With the sums added up inside the search launch a link's sums depend on the path it takes, so the path must depend on
+  // the link alone and not on its company (else a rank's share of a graph with scans of several size classes would give
+  // other bits than the whole): links of big scans go through the batched launch, by refill-threshold group, whatever
+  // else the call holds.
+  if (nlinks > 1 && link_batch_max() > 1) {
+    std::vector<int> key(nlinks);
+    bool mixed = false, any = false;
+    for (int i = 0; i < nlinks; i++) {
+      const size_t N = second[i]->N;
+      key[i] = (N > 0 && link_sums_in_search(c, want, N)) ? 100 + search_multi_thresh(N) : 0;
+      mixed = mixed || key[i] != key[0];
+      any = any || key[i] != 0;
+    }
+    if (mixed && any) {
+      acc.assign((size_t)nlinks * ACC_TOTAL, 0.0);
+      std::vector<char> done(nlinks, 0);
+      for (int i0 = 0; i0 < nlinks; i0++) {
+        if (done[i0]) continue;
+        std::vector<int> idx;
+        for (int i = i0; i < nlinks; i++) if (!done[i] && key[i] == key[i0]) { idx.push_back(i); done[i] = 1; }
+        const int n2 = (int)idx.size();
+        std::vector<const tdtk_tree*> f2(n2);
+        std::vector<tdtk_scan*> s2(n2);
+        std::vector<double> d2(16 * (size_t)n2), a2, sh2;
+        for (int k = 0; k < n2; k++) {
+          f2[k] = first[idx[k]]; s2[k] = second[idx[k]];
+          std::memcpy(&d2[16 * (size_t)k], first_dalignxf + 16 * (size_t)idx[k], 16 * sizeof(double));
+        }
+        if ((rc = links_device_pass(c, n2, f2.data(), d2.data(), s2.data(), maxd2, want, a2, sh2))) return rc;
+        for (int k = 0; k < n2; k++) {
+          std::memcpy(&acc[(size_t)idx[k] * ACC_TOTAL], &a2[(size_t)k * ACC_TOTAL], ACC_TOTAL * sizeof(double));
+          for (int q = 0; q < 3; q++) shifts[3 * (size_t)idx[k] + q] = sh2[3 * (size_t)k + q];
+        }
+      }
+      return TDTK_OK;
+    }
+  }
   {
     const int gb = link_batch_max();
     bool ok = gb > 1 && (nlinks > 1 || link_sums_in_search(c, want, maxN)) &&

@@ -778,6 +778,44 @@ def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
             assert np.array_equal(a[i % 5], b[i])
 
 
+def test_a_links_sums_do_not_depend_on_its_company(tdtk, gpu):
+    """Since round 3 the sums of a big scan's link are added up inside the search launch, so the path a link takes decides
+    the last bits of its sums -- and that path depends on the link alone: a graph whose scans are of several size classes
+    (300K points: persistent lanes, sums inside the launch; 100K: lane groups, k_accum) gives every link the same blocks
+    whether it is evaluated with all the others, with some of them (a rank's share) or alone."""
+    import ctypes as C
+    from importlib import import_module
+    capi = import_module("3dtk_amd._capi")
+    rng = np.random.default_rng(23)
+    world = rng.uniform(-400, 400, (300000, 3))
+    scans = []
+    for k in range(4):
+        T = tdtk.EulerToMatrix4([3.0 * k, -1.0 * k, 2.0 * k], [0.002 * k, -0.003 * k, 0.004 * k])
+        Ti = tdtk.M4inv(T)
+        R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+        loc = world @ R.T + Ti[12:15] + rng.normal(0, 0.05, world.shape)
+        if k == 3:
+            loc = loc[:100000]
+        scans.append(tdtk.Scan([3.0 * k + 0.3, -1.0 * k, 2.0 * k - 0.2], [0.002 * k, -0.003 * k + 0.001, 0.004 * k], loc))
+    tdtk.prepare_scans(scans, trees=True, threads=2)
+    links = [(0, 1), (1, 2), (2, 3), (3, 0), (0, 2), (1, 3)]
+
+    def blocks(sel):
+        nl = len(sel)
+        first = (C.c_void_p * nl)(*[scans[links[i][0]].getSearchTree()._h for i in sel])
+        second = (C.c_void_p * nl)(*[scans[links[i][1]].handle for i in sel])
+        dal = np.ascontiguousarray(np.stack([scans[links[i][0]].dalignxf for i in sel]))
+        Cm = np.empty((nl, 36)); CD = np.empty((nl, 6)); m = (C.c_uint64 * nl)(); ss = np.empty(nl)
+        capi.check(capi.lib().tdtk_lum_links(nl, first, capi.dptr(dal), second, 100.0, capi.dptr(Cm), capi.dptr(CD), m, capi.dptr(ss)))
+        return Cm, CD, np.array(list(m)), ss
+    whole = blocks(list(range(len(links))))
+    assert whole[2].min() > 50000
+    for share in ([0, 2, 4], [1, 3, 5], [2, 5], [0, 1, 4], [3], [0], [5]):
+        part = blocks(share)
+        for a, b in zip(whole, part):
+            assert np.array_equal(a[share], b), share
+
+
 def test_tree_edge_cases(tdtk, orc, gpu):
     """One point, two points, all-identical points (one degenerate bucket larger than the bucket size),
     non-finite coordinates (the reference would recurse on an empty side; we return an error)."""
