@@ -2076,7 +2076,8 @@ static bool link_sums_in_search(const Ctx* c, unsigned want, size_t maxN)
 {
   const char* e = getenv("TDTK_LINK_FUSE");
   if (e && e[0] == '0') return false;
-  if (getenv("TDTK_REFILL_QPW") || getenv("TDTK_LINK_PHASES")) return false;   // (experiments with the slab layout)
+  // (experiments with the slab layout change the rows; TDTK_LINK_FUSE=2 keeps the sums inside for such sweeps)
+  if ((getenv("TDTK_REFILL_QPW") || getenv("TDTK_LINK_PHASES")) && !(e && e[0] == '2')) return false;
   const int th = search_multi_thresh(maxN);
   return !c->counting && want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) && search_multi_class(maxN) == 20 && (th == 16 || th == 32);
 }
