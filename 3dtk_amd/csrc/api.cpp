@@ -923,7 +923,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
       if (tm) HIPCHK(hipEventRecord(c->e2, s));
       const bool poll = !tm && poll_sums();
       if (poll) arm_sums(c->h_pin);
-      HIPCHK(launch_final(sa.partials, rows, c->h_pin, s));
+      HIPCHK(launch_final(sa.partials, rows, c->h_pin, s, (fmode == 3 || fmode == 4) ? (int)ACC_DD : (int)ACC_TOTAL));   // base block only
       if (tm) { HIPCHK(hipEventRecord(c->e3, s)); c->ev2_pending = true; }
       if (poll) HIPCHK(await_sums(c->h_pin, s));
       else HIPCHK(hipStreamSynchronize(s));

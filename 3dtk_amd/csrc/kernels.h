@@ -134,7 +134,7 @@ hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEnt
                            size_t M, hipStream_t s);
 hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, const uint32_t* g_at,
                            const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s);
-hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s);
+hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s, int ncols = ACC_TOTAL);   // columns >= ncols: +0.0
 // several batches (the link passes of a graph-SLAM round) in one launch: see k_search_refill_multi in kernels.hip
 struct FinalDesc { const double* partials; double* out; int rows, pad; };
 uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slabs = false);   // sets the slab fields, returns the batch's workgroups (x8)

@@ -2388,10 +2388,14 @@ __global__ void __launch_bounds__(BLOCK) k_accum_multi(const AccumArgs* __restri
 // column; thread t adds rows t, t+256, ... then wave64 shuffles and a 4-entry LDS pass.  The
 // association is fixed by (rows, 256), so repeated runs give bit-identical sums.
 __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partials, int rows,
-                                               double* __restrict__ out)
+                                               double* __restrict__ out, int ncols)
 {
   __shared__ double red[4];
   const int k = blockIdx.x;
+  if (k >= ncols) {   // a column the pass did not fill (its rows hold +0.0): the same +0.0 without reading them
+    if (threadIdx.x == 0) out[k] = 0.0;
+    return;
+  }
   double s = 0.0;
   for (int r = threadIdx.x; r < rows; r += 256) s += partials[(size_t)r * ACC_TOTAL + k];
   s = wave_sum(s);
@@ -3113,9 +3117,9 @@ hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab
   return hipGetLastError();
 }
 
-hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s)
+hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s, int ncols)
 {
-  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, partials, (int)rows, d_out);
+  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, partials, (int)rows, d_out, ncols);
   return hipGetLastError();
 }
 
@@ -3239,7 +3243,7 @@ hipError_t launch_accum(const AccumArgs& a, uint32_t grid, unsigned want, int pm
     case 6: launch_accum_w<6>(a, grid, pmode, s); break;
     default: launch_accum_w<7>(a, grid, pmode, s); break;
   }
-  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, a.partials, (int)grid, d_out);
+  hipLaunchKernelGGL(k_final, dim3(ACC_TOTAL), dim3(256), 0, s, a.partials, (int)grid, d_out, (int)ACC_TOTAL);
   return hipGetLastError();
 }
 
