@@ -2206,7 +2206,8 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       const uint32_t ag = accum_grid(data->N);
       hab[i + gi] = ab; ab += ag;
       haa[i] = aa;
-      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)li * ACC_TOTAL; hfd[i].rows = fuse_links ? (int)nb : (int)ag; hfd[i].pad = 0;
+      hfd[i].partials = aa.partials; hfd[i].out = d_out + (size_t)li * ACC_TOTAL; hfd[i].rows = fuse_links ? (int)nb : (int)ag;
+      hfd[i].pad = (want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS)) ? 1 : 0;   // k_final_multi: which columns the rows fill
     }
     hsb[l1 + gi] = sb; hab[l1 + gi] = ab;
     s_total[gi] = sb; a_total[gi] = ab;

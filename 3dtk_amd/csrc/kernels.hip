@@ -2410,6 +2410,11 @@ __global__ void __launch_bounds__(256) k_final_multi(const FinalDesc* __restrict
   __shared__ double red[4];
   const FinalDesc d = desc[blockIdx.y];
   const int k = blockIdx.x;
+  // pad == 1: the rows of a lum6DEuler link without the cross block -- n, sum, the LUM columns; the others hold +0.0
+  if (d.pad == 1 && !(k < ACC_SM || (k >= ACC_L && k < ACC_MM) || k == ACC_LU)) {
+    if (threadIdx.x == 0) d.out[k] = 0.0;
+    return;
+  }
   double s = 0.0;
   for (int r = threadIdx.x; r < d.rows; r += 256) s += d.partials[(size_t)r * ACC_TOTAL + k];
   s = wave_sum(s);
