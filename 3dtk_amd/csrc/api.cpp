@@ -2220,7 +2220,8 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   const int cls = search_multi_class(maxN);
   // idle lanes a wave collects before it hands out new queries: 32 once a launch is many generations of waves (84 links of
   // 1M points, ordered: 8.93 -> 8.85 ms), as for single passes of 4M queries and more (refill_thresh)
-  const int thresh = (G > 16 && cls == 20 && !getenv("TDTK_REFILL_THRESH")) ? 32 : search_multi_thresh(maxN);
+  // (22 links: 2.627 ms with 16 against 2.652 with 32; 11 links 1.416 against 1.422)
+  const int thresh = (G > 32 && cls == 20 && !getenv("TDTK_REFILL_THRESH")) ? 32 : search_multi_thresh(maxN);
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G), nb = l1 - l0;
     const bool timed = (gi == ngroups - 1) && kernel_timing();   // tdtk_last_kernel_ms: the last group's search launch
