@@ -692,6 +692,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
     ACHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
     ACHK(hipMemcpyAsync(&more, lvl + level, 4, hipMemcpyDeviceToHost, s));
     ACHK(hipStreamSynchronize(s));
+    if (bad & 0x10000u) { res.err = hipErrorLaunchTimeOut; return res; }     // the one-launch scan gave up waiting (sort.hip): not an input problem
     if (bad || (more && level >= ANN_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
     batch = 2;
   }

@@ -1,6 +1,7 @@
 // C ABI of lib3dtk_hip.so (include/tdtk_hip.h): handles, workspaces, host orchestration of
 // the kernels in kernels.hip.  There is NO CPU fallback in this library: without a HIP device
 // every compute entry point fails with TDTK_EDEVICE.
+#include <sched.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -73,7 +74,7 @@ struct DevBuf {
 };
 
 enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
-       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COST, WS_COUNT };
+       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COST, WS_MOVES, WS_COUNT };
 
 // an auxiliary stream with the buffers one whole-scan pass needs: batches of links over small scans run several
 // passes side by side (one pass of an 80K-point scan occupies a fraction of the machine and is latency-bound)
@@ -125,6 +126,10 @@ struct Ctx {
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
   size_t h_stage_cap = 0;
+  void* h_moves = nullptr;  // pinned staging of scans_settle's table (its own: a settle may precede a batched launch in one call)
+  size_t h_moves_cap = 0;
+  hipEvent_t e_moves = nullptr;   // behind the last copy out of h_moves
+  bool moves_inflight = false;
   double last_nn_ms = 0.0, last_sums_ms = 0.0, last_normals_ms = 0.0, last_build_ms = 0.0;
   bool ev_pending = false, ev2_pending = false, ev4_pending = false;
   uint64_t counted_ann_queries = 0;
@@ -173,6 +178,8 @@ Ctx::~Ctx()
     wait_deferred(device, this);
     if (e_defer) (void)hipEventDestroy(e_defer);
     if (h_stage) (void)hipHostFree(h_stage);
+    if (h_moves) (void)hipHostFree(h_moves);
+    if (e_moves) (void)hipEventDestroy(e_moves);
     lanes.clear();
     slots.clear();
     if (e0) (void)hipEventDestroy(e0);
@@ -215,7 +222,9 @@ static int get_ctx(int device, Ctx** out, bool touches_scans = true)
     HIPCHK(hipEventCreate(&c->e5));
     HIPCHK(hipEventCreateWithFlags(&c->e_user, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_defer, hipEventDisableTiming));
-    HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->e_moves, hipEventDisableTiming));
+    // (coherent, said explicitly: the host reads these words while the kernel that writes them is still running -- await_sums)
+    HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocCoherent));
     it = g_ctx.emplace(device, std::move(c)).first;
     g_ctx_live.fetch_add(1);
   }
@@ -253,6 +262,17 @@ static int defer_fence(Ctx* c)
 
 // pinned host staging that stays valid until the next library call on this thread (get_ctx has then waited for the
 // copy that reads it)
+static int stage_reserve(Ctx* c, size_t bytes)
+{
+  if (c->h_stage_cap < bytes) {
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_cap = 0;
+    const size_t want = std::max<size_t>(bytes, 64 * 1024);
+    if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
+    c->h_stage_cap = want;
+  }
+  return TDTK_OK;
+}
 static int stage_pinned(Ctx* c, const void* src, size_t bytes, void** out)
 {
   if (c->h_stage_cap < bytes) {
@@ -301,13 +321,21 @@ struct tdtk_scan {
   // scan's search tree can still be built later without the points ever visiting the host
   bool track_original = false;
   double *ox = nullptr, *oy = nullptr, *oz = nullptr;
+  // Lazy moves.  The pose update of a graph-SLAM round does not touch the points: it queues its in-place transforms here
+  // (oldest first), and whoever reads the scan next applies them -- the link passes of the next round in registers where a
+  // lane takes a query (the link that owns the update stores the result into the spare arrays ax / ay / az, swapped in
+  // behind the launch), every other entry point through scan_settle (one pass, all queued matrices in order).  A rank
+  // never moves a scan none of its links reads.  The arithmetic is the one Scan::transform does point by point
+  // (scan.cc:851-875), matrix after matrix: same bits as moving the scan every time.
+  mutable std::vector<Mat4> pending;
+  mutable double *ax = nullptr, *ay = nullptr, *az = nullptr;
   tdtk_scan() = default;
   tdtk_scan(const tdtk_scan&) = delete;
   tdtk_scan& operator=(const tdtk_scan&) = delete;
   ~tdtk_scan()
   {
     (void)hipSetDevice(device);
-    double* p[] = {x, y, z, nx, ny, nz, ox, oy, oz};
+    double* p[] = {x, y, z, nx, ny, nz, ox, oy, oz, ax, ay, az};
     for (double* q : p)
       if (q) pool_free(q);
     if (d_order) pool_free(d_order);
@@ -342,6 +370,80 @@ static int scan_keep_original(Ctx* c, tdtk_scan* s)
   HIPCHK(hipMemcpyAsync(s->oy, s->y, b, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s->oz, s->z, b, hipMemcpyDeviceToDevice, c->stream));
   return TDTK_OK;
+}
+
+// ---- lazy scan moves (see tdtk_scan::pending) ---------------------------------------------------
+static bool lazy_moves()
+{
+  const char* e = getenv("TDTK_LAZY_MOVES");     // 0: every queued move is carried out at once (the round-3 behaviour)
+  return !(e && e[0] == '0');
+}
+// longest chain a scan may carry: a rank that never reads a scan (seven of eight ranks, for most scans) carries it out
+// once per this many queued transforms -- one trip of the points through HBM per 16 rounds instead of one per round
+constexpr size_t LAZY_CHAIN_MAX = 32;
+
+// carry out what is queued on these scans: one launch, every scan's chain in order.  Enqueued on c->stream; the caller
+// decides whether to wait (the entry points that go on to read the scan on the same stream need not).
+static int scans_settle(Ctx* c, const tdtk_scan* const* scans, int count)
+{
+  size_t nmat = 0, max_n = 0;
+  int nd = 0;
+  for (int i = 0; i < count; i++) {
+    const tdtk_scan* sc = scans[i];
+    if (!sc || sc->pending.empty()) continue;
+    bool dup = false;
+    for (int j = 0; j < i && !dup; j++) dup = scans[j] == sc;
+    if (dup) continue;
+    if (!sc->N) { sc->pending.clear(); continue; }
+    if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
+    nmat += sc->pending.size(); nd++;
+    max_n = std::max(max_n, sc->N);
+  }
+  if (!nd) return TDTK_OK;
+  const size_t o_mat = ((sizeof(XfChainDesc) * (size_t)nd + 127) / 128) * 128, bytes = o_mat + nmat * sizeof(Mat4);
+  int rc = c->ws[WS_MOVES].ensure(bytes);
+  if (rc) return rc;
+  if (c->moves_inflight) { HIPCHK(hipEventSynchronize(c->e_moves)); c->moves_inflight = false; }
+  if (c->h_moves_cap < bytes) {
+    if (c->h_moves) (void)hipHostFree(c->h_moves);
+    c->h_moves = nullptr; c->h_moves_cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 64 * 1024);
+    if (hipHostMalloc(&c->h_moves, want, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
+    c->h_moves_cap = want;
+  }
+  char* tab = static_cast<char*>(c->h_moves);
+  std::memset(tab, 0, o_mat);
+  XfChainDesc* hd = reinterpret_cast<XfChainDesc*>(tab);
+  Mat4* hm = reinterpret_cast<Mat4*>(tab + o_mat);
+  const Mat4* dm = reinterpret_cast<const Mat4*>(static_cast<char*>(c->ws[WS_MOVES].p) + o_mat);
+  size_t k = 0;
+  int d = 0;
+  for (int i = 0; i < count; i++) {
+    const tdtk_scan* sc = scans[i];
+    if (!sc || sc->pending.empty()) continue;
+    XfChainDesc& e = hd[d++];
+    e.x = sc->x; e.y = sc->y; e.z = sc->z; e.nx = sc->nx; e.ny = sc->ny; e.nz = sc->nz; e.n = sc->N;
+    e.mats = dm + k; e.nm = (int)sc->pending.size();
+    for (const Mat4& m : sc->pending) hm[k++] = m;
+    sc->pending.clear();     // (a duplicate of this scan further down the list finds nothing left)
+  }
+  HIPCHK(hipMemcpyAsync(c->ws[WS_MOVES].p, tab, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->e_moves, c->stream));
+  c->moves_inflight = true;
+  HIPCHK(launch_transform_chain_batch(reinterpret_cast<const XfChainDesc*>(c->ws[WS_MOVES].p), nd, max_n, c->stream));
+  return TDTK_OK;
+}
+static int scan_settle(Ctx* c, const tdtk_scan* s)
+{
+  if (!s || s->pending.empty()) return TDTK_OK;
+  return scans_settle(c, &s, 1);
+}
+// queue one in-place transform on a resident scan (the caller has saved "xyz reduced original" if it is tracked)
+static void scan_queue_move(tdtk_scan* s, const double* A16)
+{
+  Mat4 m;
+  std::memcpy(m.m, A16, sizeof m.m);
+  s->pending.push_back(m);
 }
 
 // ---- tree ------------------------------------------------------------------------------
@@ -422,9 +524,11 @@ static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
   // the padded starts must fit where the starts fitted: 30-bit packed references (start << cb | count), 32-bit byte
   // offsets into the point and group arrays, int32 starts of the leaf table
   if (G == 0 || slots * sizeof(KdPoint) >= (1ull << 32) || (!leaf && (slots << cb) > (uint64_t)REF_VAL)) return TDTK_OK;
+  // No room for the padded copy (a transient peak of twice the point array + 12 bytes per slot): the tree as it stands is
+  // complete and searchable -- nothing has been rewritten yet --, so padding is skipped and the fp64-only bucket scan used.
   void *ptsP = nullptr, *grp = nullptr;
-  HIPCHK(handle_malloc(&ptsP, slots * sizeof(KdPoint)));
-  if (handle_malloc(&grp, (size_t)G * 48) != hipSuccess) { pool_free(ptsP); set_error("hipMalloc failed"); return TDTK_ENOMEM; }
+  if (handle_malloc(&ptsP, slots * sizeof(KdPoint)) != hipSuccess) { (void)hipGetLastError(); return TDTK_OK; }
+  if (handle_malloc(&grp, (size_t)G * 48) != hipSuccess) { (void)hipGetLastError(); pool_free(ptsP); return TDTK_OK; }
   hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
                                  static_cast<KdPoint*>(ptsP), static_cast<float4*>(grp), c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -525,6 +629,7 @@ int tdtk_tree_create_from_scan(const tdtk_scan* scan, int bucket_size, tdtk_tree
   if ((rc = tree_check_args(M, bucket_size))) return rc;
   if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
   const bool saved = scan->ox != nullptr;   // moved since tdtk_scan_mark_original: the saved points are the original
+  if (!saved && (rc = scan_settle(c, scan))) return rc;
   HIPCHK(launch_unsort_aos(saved ? scan->ox : scan->x, saved ? scan->oy : scan->y, saved ? scan->oz : scan->z,
                            scan->d_order, M, c->ws[WS_TMPA].as<double>(), c->stream));
   if ((rc = tree_from_device_points(c, t.get(), M, bucket_size, t0))) return rc;
@@ -555,6 +660,7 @@ int tdtk_tree_create_from_scans(tdtk_scan* const* scans, int nscans, int bucket_
   t->device = scans[0]->device; t->M = M; t->bucket = bucket_size;
   if ((rc = tree_check_args(M, bucket_size))) return rc;
   if ((rc = c->ws[WS_TMPA].ensure(3 * M * sizeof(double)))) return rc;
+  if ((rc = scans_settle(c, scans, nscans))) return rc;
   size_t off = 0;
   for (int i = 0; i < nscans; i++) {
     const tdtk_scan* sc = scans[i];
@@ -848,18 +954,34 @@ static void arm_sums(double* h_pin)
   volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(h_pin);
   for (int k = 0; k < ACC_TOTAL; k++) w[k] = SUMS_ARMED;
 }
+// The wait is adaptive: the words are polled with a pause instruction between looks for TDTK_SPIN_US microseconds (default
+// 30: an iteration over a small scan, 25-40 us, ends inside the window and keeps the 4 us it gains over
+// hipStreamSynchronize); after that every look is followed by sched_yield(), so the 200 us kernel of a 1M-point
+// iteration does not hold a core against the other threads of an OpenMP host (a yield with nobody waiting returns at
+// once and costs the wait nothing).  The stream is asked now and then in both phases: a failed launch ends the wait
+// with its error, a finished stream ends it whatever the words say.
 static hipError_t await_sums(const double* h_pin, hipStream_t s)
 {
+  static const double spin_us = [] { const char* e = getenv("TDTK_SPIN_US"); const double v = e ? atof(e) : 30.0; return v < 0.0 ? 0.0 : v; }();
   const volatile uint64_t* w = reinterpret_cast<const volatile uint64_t*>(h_pin);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool yielding = spin_us == 0.0;
   for (uint32_t spins = 1;; spins++) {
     bool all = true;
     for (int k = ACC_TOTAL - 1; k >= 0 && all; k--) all = w[k] != SUMS_ARMED;
     if (all) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
-    if ((spins & 0x3FFu) == 0) {
-      const hipError_t q = hipStreamQuery(s);
-      if (q == hipSuccess) return hipSuccess;
-      if (q != hipErrorNotReady) return q;
+    if (yielding) {
+      sched_yield();
+      if ((spins & 0x3Fu) != 0) continue;
+    } else {
+      __builtin_ia32_pause();
+      if ((spins & 0x3Fu) == 0 &&
+          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) yielding = true;
+      if ((spins & 0x3FFu) != 0) continue;
     }
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return hipSuccess;
+    if (q != hipErrorNotReady) return q;
   }
 }
 
@@ -872,6 +994,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
   const size_t N = data->N;
   int rc = c->ws[WS_KPOS].ensure(N * sizeof(int));
   if (rc) return rc;
+  if ((rc = scan_settle(c, data))) return rc;
   Mat4 A, inv;
   std::memcpy(A.m, A16, sizeof A.m);
   m4inv(A16, inv.m);  // searchTree.cc:110
@@ -1462,6 +1585,7 @@ int tdtk_scan_calc_normals(tdtk_scan* sc, int k, const double rPos[3], double ep
   if ((rc = c->ws[WS_TMPA].ensure(6 * n * sizeof(double)))) return rc;
   double* d_in = c->ws[WS_TMPA].as<double>();
   double* d_nrm = d_in + 3 * n;
+  if ((rc = scan_settle(c, sc))) return rc;
   // the resident points back in the caller's order, the normals back into the resident order
   HIPCHK(launch_unsort_aos(sc->x, sc->y, sc->z, sc->d_order, n, d_in, s));
   if ((rc = normals_on_device(c, d_in, n, k, rPos, eps, d_nrm, nullptr))) return rc;
@@ -1537,6 +1661,15 @@ int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16])
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
   if ((rc = scan_keep_original(c, s))) return rc;
+  if (!s->pending.empty()) {
+    // behind moves that are still queued: this one joins the queue (order is what matters)
+    scan_queue_move(s, alignxf);
+    if (!lazy_moves() || s->pending.size() >= LAZY_CHAIN_MAX) {
+      if ((rc = scan_settle(c, s))) return rc;
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return TDTK_OK;
+  }
   Mat4 A;
   std::memcpy(A.m, alignxf, sizeof A.m);
   HIPCHK(launch_transform(s->x, s->y, s->z, s->nx, s->ny, s->nz, s->N, A, c->stream));
@@ -1551,6 +1684,13 @@ int tdtk_scan_mark_original(tdtk_scan* s)
   if (!s) { set_error("NULL argument"); return TDTK_EINVAL; }
   (void)hipSetDevice(s->device);
   wait_deferred(s->device);   // the saved original may be in use by a move that was left running
+  if (!s->pending.empty()) {  // "original" = the points as they are now, queued moves included
+    Ctx* c;
+    int rc = get_ctx(s->device, &c);
+    if (rc) return rc;
+    if ((rc = scan_settle(c, s))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   double* p[] = {s->ox, s->oy, s->oz};
   for (double* q : p)
     if (q) pool_free(q);
@@ -1565,6 +1705,7 @@ int tdtk_scan_download_original(const tdtk_scan* s, double* xyz_out)
   Ctx* c;
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
+  if (!s->ox && (rc = scan_settle(c, s))) return rc;
   return scan_to_host(c, s, s->ox ? s->ox : s->x, s->ox ? s->oy : s->y, s->ox ? s->oz : s->z, xyz_out);
 }
 
@@ -1587,6 +1728,7 @@ int tdtk_scan_download(const tdtk_scan* s, double* xyz_out, double* nrm_out)
   Ctx* c;
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
+  if ((rc = scan_settle(c, s))) return rc;
   if ((rc = scan_to_host(c, s, s->x, s->y, s->z, xyz_out))) return rc;
   if (nrm_out && s->nx) rc = scan_to_host(c, s, s->nx, s->ny, s->nz, nrm_out);
   return rc;
@@ -1633,6 +1775,7 @@ int tdtk_point_point_error(const tdtk_tree* model, const double A[16], tdtk_scan
   if (N == 0) { *error_out = std::nan(""); return TDTK_OK; }   // 0 / 0 in the reference
   hipStream_t s = c->stream;
   if ((rc = c->ws[WS_KPOS].ensure(N * sizeof(int)))) return rc;
+  if ((rc = scan_settle(c, data))) return rc;
   Mat4 Am, inv;
   std::memcpy(Am.m, A, sizeof Am.m);
   m4inv(A, inv.m);
@@ -1917,6 +2060,7 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   std::memset(res, 0, sizeof *res);
   if (prm->max_num_iterations == 0 || data->N == 0) return TDTK_OK;  // icp6D.cc:112-114
 
+  if ((rc = scan_settle(c, data))) return rc;          // queued moves first: "original" and the loop both start from them
   if ((rc = scan_keep_original(c, data))) return rc;   // the loop moves the scan in place
   const unsigned want = (algo == TDTK_ALGO_APX) ? TDTK_WANT_APX
                         : (algo == TDTK_ALGO_NAPX ? TDTK_WANT_NAPX : (serial_only ? TDTK_WANT_MOM2 : 0u));
@@ -2139,12 +2283,37 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     }
   }
   const int ngroups = (nlinks + G - 1) / G;
+  // Lazy scan moves (tdtk_scan::pending): the persistent-lane launch carries them out itself; the small-batch kernels do
+  // not, their scans are moved first.  Everything that can fail is done before the first scan's state changes.
+  const bool lazy = search_multi_class(maxN) == 20;
+  size_t nmat_max = 0;
+  if (!lazy) {
+    if ((rc = scans_settle(c, second, nlinks))) return rc;
+  } else {
+    for (int i = 0; i < nlinks; i++) {
+      tdtk_scan* sc = second[i];
+      if (sc->pending.empty()) continue;
+      nmat_max += sc->pending.size();
+      if (!sc->ax) {
+        const size_t b = sc->N * sizeof(double);
+        HIPCHK(handle_malloc((void**)&sc->ax, b));
+        HIPCHK(handle_malloc((void**)&sc->ay, b));
+        HIPCHK(handle_malloc((void**)&sc->az, b));
+      }
+    }
+  }
   // one table for the whole call: per link its search and pair-sum arguments and final descriptor, per group the two
-  // workgroup-offset lists
+  // workgroup-offset lists, then the chains of queued moves
   const size_t o_sa = 0, o_aa = o_sa + sizeof(SearchArgs) * nlinks, o_fd = o_aa + sizeof(AccumArgs) * nlinks,
                o_sb = o_fd + sizeof(FinalDesc) * nlinks, o_ab = o_sb + sizeof(uint32_t) * (size_t)(nlinks + ngroups),
-               total = o_ab + sizeof(uint32_t) * (size_t)(nlinks + ngroups);
+               o_mv = ((o_ab + sizeof(uint32_t) * (size_t)(nlinks + ngroups) + 127) / 128) * 128,
+               total = o_mv + nmat_max * sizeof(Mat4);
+  if ((rc = c->multi_args.ensure(total))) return rc;
+  if ((rc = stage_reserve(c, total))) return rc;
   std::vector<char> tab(total, 0);
+  Mat4* hmv = reinterpret_cast<Mat4*>(tab.data() + o_mv);
+  const Mat4* dmv = reinterpret_cast<const Mat4*>(static_cast<char*>(c->multi_args.p) + o_mv);
+  size_t nmat = 0;
   SearchArgs* hsa = reinterpret_cast<SearchArgs*>(tab.data() + o_sa);
   AccumArgs* haa = reinterpret_cast<AccumArgs*>(tab.data() + o_aa);
   FinalDesc* hfd = reinterpret_cast<FinalDesc*>(tab.data() + o_fd);
@@ -2170,10 +2339,19 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G);
     uint32_t sb = 0, ab = 0;
+    std::map<tdtk_scan*, std::pair<size_t, int>> moving;   // scans this launch moves: where their chain sits, its length
     for (int p = l0; p < l1; p++) {
       const int i = p, li = ord[p];      // i: position in the tables; li: the caller's link
       const tdtk_tree* t = first[li];
       tdtk_scan* data = second[li];
+      bool owner = false;
+      if (lazy && !data->pending.empty() && moving.find(data) == moving.end()) {
+        // the first link of the launch that reads the scan owns its update
+        moving[data] = std::make_pair(nmat, (int)data->pending.size());
+        for (const Mat4& m : data->pending) hmv[nmat++] = m;
+        owner = true;
+      }
+      const auto mv = moving.find(data);
       Lane* sl = c->slots[i - l0].get();
       const double* A16 = first_dalignxf + 16 * (size_t)li;
       Mat4 A, inv;
@@ -2195,11 +2373,16 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
         lc->tree = t; lc->scan = data; lc->n = data->N;
       }
       if (fuse_links) { sa.fuse = 5; sa.A = A; sa.partials = sl->part.as<double>(); }
+      if (mv != moving.end()) {
+        sa.moves = dmv + mv->second.first; sa.nmoves = mv->second.second;
+        if (owner) { sa.wx = data->ax; sa.wy = data->ay; sa.wz = data->az; sa.nx = data->nx; sa.ny = data->ny; sa.nz = data->nz; }
+      }
       hsb[i + gi] = sb; sb += nb;
       hsa[i] = sa;
       AccumArgs aa{};
       aa.T = t->dev;
       aa.x = data->x; aa.y = data->y; aa.z = data->z;
+      if (mv != moving.end()) { aa.x = data->ax; aa.y = data->ay; aa.z = data->az; }   // k_accum_multi runs behind the search launch
       aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
       for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * li + k];
       aa.partials = sl->part.as<double>();
@@ -2211,8 +2394,13 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     }
     hsb[l1 + gi] = sb; hab[l1 + gi] = ab;
     s_total[gi] = sb; a_total[gi] = ab;
+    // behind this launch the spare arrays hold the scan (the launches of the call run in this order on one stream)
+    for (auto& kv : moving) {
+      tdtk_scan* sc = kv.first;
+      std::swap(sc->x, sc->ax); std::swap(sc->y, sc->ay); std::swap(sc->z, sc->az);
+      sc->pending.clear();
+    }
   }
-  if ((rc = c->multi_args.ensure(total))) return rc;
   void* staged = nullptr;
   if ((rc = stage_pinned(c, tab.data(), total, &staged))) return rc;
   HIPCHK(hipMemcpyAsync(c->multi_args.p, staged, total, hipMemcpyHostToDevice, s));
@@ -2313,6 +2501,7 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
       return TDTK_OK;
     }
   }
+  if ((rc = scans_settle(c, second, nlinks))) return rc;     // (the passes below read the scans as they are)
   int max_lanes = 8, forced = 0;
   if (const char* e = getenv("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));
   // small scans: a pass is latency-bound, 4 side by side (32 x 60K points, 41 links: 1 lane 2.35 ms, 2: 1.52, 3: 1.30,
@@ -2519,37 +2708,38 @@ int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, 
   return TDTK_OK;
 }
 
-// many resident scans moved in place by A1 and then (optionally) A2, one launch
+// many resident scans moved in place by A1 and then (optionally) A2.  The moves are queued on the scans (tdtk_scan::pending)
+// and carried out by whoever reads a scan next; TDTK_LAZY_MOVES=0 (or a chain that has grown long): one launch now, left
+// running behind the process-wide fence.
+static int queue_scan_moves(Ctx* c, const std::vector<tdtk_scan*>& moved)
+{
+  if (moved.empty()) return TDTK_OK;
+  std::vector<const tdtk_scan*> now;
+  for (tdtk_scan* sc : moved)
+    if (!lazy_moves() || sc->pending.size() >= LAZY_CHAIN_MAX) now.push_back(sc);
+  if (now.empty()) return TDTK_OK;
+  int rc = scans_settle(c, now.data(), (int)now.size());
+  if (rc) return rc;
+  return defer_fence(c);
+}
+
 int tdtk_scans_transform2(int count, tdtk_scan* const* scans, const double* A1, const double* A2)
 {
   if (count < 0 || (count && (!scans || !A1))) { set_error("bad argument"); return TDTK_EINVAL; }
   Ctx* c = nullptr;
-  std::vector<Xf2Desc> moves;
-  size_t max_n = 0;
+  std::vector<tdtk_scan*> moved;
   for (int i = 0; i < count; i++) {
     tdtk_scan* sc = scans[i];
     if (!sc || !sc->N) continue;
     if (!c) { int rc = get_ctx(sc->device, &c); if (rc) return rc; }
     if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
     { int rk = scan_keep_original(c, sc); if (rk) return rk; }
-    Xf2Desc d;
-    d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
-    std::memcpy(d.A1.m, A1 + 16 * (size_t)i, sizeof d.A1.m);
-    d.has2 = A2 ? 1 : 0;
-    if (A2) std::memcpy(d.A2.m, A2 + 16 * (size_t)i, sizeof d.A2.m);
-    else m4identity(d.A2.m);
-    moves.push_back(d);
-    if (sc->N > max_n) max_n = sc->N;
+    scan_queue_move(sc, A1 + 16 * (size_t)i);
+    if (A2) scan_queue_move(sc, A2 + 16 * (size_t)i);
+    moved.push_back(sc);
   }
-  if (!c || moves.empty()) return TDTK_OK;
-  const size_t bytes = moves.size() * sizeof(Xf2Desc);
-  int rc = c->ws[WS_TMPB].ensure(bytes);
-  if (rc) return rc;
-  void* staged = nullptr;
-  if ((rc = stage_pinned(c, moves.data(), bytes, &staged))) return rc;
-  HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, staged, bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(launch_transform2_batch(c->ws[WS_TMPB].as<Xf2Desc>(), (int)moves.size(), max_n, c->stream));
-  return defer_fence(c);
+  if (!c) return TDTK_OK;
+  return queue_scan_moves(c, moved);
 }
 
 int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double* dalignxf, double* rPos,
@@ -2558,8 +2748,7 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
   if (nscans <= 0 || !X || !transMat || !dalignxf || !rPos || !rPosTheta) { set_error("bad argument"); return TDTK_EINVAL; }
   double sum_position_diff = 0.0;
   Ctx* c = nullptr;
-  std::vector<Xf2Desc> moves;
-  size_t max_n = 0;
+  std::vector<tdtk_scan*> moved;
   for (int i = 1; i < nscans; i++) {
     double* tm = transMat + 16 * (size_t)i;
     double* da = dalignxf + 16 * (size_t)i;
@@ -2604,26 +2793,15 @@ int tdtk_lum_update_poses(int nscans, const double* X, double* transMat, double*
       tdtk_scan* sc = scans[i];
       if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
       { int rk = scan_keep_original(c, sc); if (rk) return rk; }
-      Xf2Desc d;
-      d.x = sc->x; d.y = sc->y; d.z = sc->z; d.nx = sc->nx; d.ny = sc->ny; d.nz = sc->nz; d.n = sc->N;
-      std::memcpy(d.A1.m, tinv, sizeof tinv);
-      std::memcpy(d.A2.m, axf, sizeof axf);
-      d.has2 = 1;
-      moves.push_back(d);
-      if (sc->N > max_n) max_n = sc->N;
+      scan_queue_move(sc, tinv);     // Scan::transformToEuler: out of the old pose ...
+      scan_queue_move(sc, axf);      // ... into the new one
+      moved.push_back(sc);
     }
     sum_position_diff += std::sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
   }
-  if (c && !moves.empty()) {
-    // every resident scan moved by (tinv, then axf) in one launch
-    const size_t bytes = moves.size() * sizeof(Xf2Desc);
-    int rc = c->ws[WS_TMPB].ensure(bytes);
+  if (c) {
+    int rc = queue_scan_moves(c, moved);
     if (rc) return rc;
-    void* staged = nullptr;
-    if ((rc = stage_pinned(c, moves.data(), bytes, &staged))) return rc;
-    HIPCHK(hipMemcpyAsync(c->ws[WS_TMPB].p, staged, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_transform2_batch(c->ws[WS_TMPB].as<Xf2Desc>(), (int)moves.size(), max_n, c->stream));
-    if ((rc = defer_fence(c))) return rc;
   }
   if (ret) *ret = sum_position_diff / (double)nscans;
   return TDTK_OK;

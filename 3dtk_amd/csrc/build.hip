@@ -1546,7 +1546,14 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
       BCHK(hipStreamSynchronize(s));
       const BLevel nx = hl[level];
-      if (h_small[2] || (nx.nseg && level >= BUILD_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; goto fail; }
+      if (h_small[2] || (nx.nseg && level >= BUILD_MAX_LEVELS)) {
+        // an empty child / non-finite coordinates -- or, on a speculated level, a cut so far off the exact one that a
+        // child came out empty: only then is the in-order build asked what the input really is
+        res.err = hipErrorInvalidValue; res.degenerate = true;
+        spec_suspect = (h_small[2] & 0x10000u) == 0u;      // (bit 16: the one-launch scan gave up waiting, see below)
+        if (h_small[2] & 0x10000u) { res.err = hipErrorLaunchTimeOut; res.degenerate = false; }
+        goto fail;
+      }
       if (nx.nseg == 0) break;
       known = nx.nseg; known_at = level;
       batch = 2;
@@ -1587,7 +1594,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     }
     BCHK(hipStreamSynchronize(s));
     BCHK(hipGetLastError());
-    if (h_spec_err) { res.err = hipErrorNotReady; goto fail; }     // a cut the exact sum would have made elsewhere: in order, then
+    if (h_spec_err) { res.err = hipErrorNotReady; spec_suspect = true; goto fail; }     // a cut the exact sum would have made elsewhere: in order, then
   }
   res.nodes = f_nodes; res.node_r = f_r; res.leaf_tab = f_leaf; res.pts = pts;
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
@@ -1598,13 +1605,13 @@ fail:
   if (f_r) pool_free(f_r);
   if (f_leaf) pool_free(f_leaf);
   if (pts) pool_free(pts);
-  if (spec_on) {
-    // whatever went wrong went wrong on a tree cut at the plain sums (a failed check, or a cut so far off that a child
-    // came out empty): the in-order build decides what the input really is
+  if (spec_on && spec_suspect) {
+    // a failed check, or a degenerate split on a tree cut at the plain sums: the in-order build decides what the input
+    // really is.  (Anything else -- no memory, a failed launch -- is returned as it is: building twice would not help.)
     (void)hipStreamSynchronize(s);
     (void)hipGetLastError();
     DevBuildResult again = device_build_tree(d_xyz, M_, bucket, arena_, s, nullptr);
-    again.respeculated = true;
+    again.respeculated = again.err == hipSuccess;     // tdtk_build_respeculated counts cuts that really were off, not bad inputs
     return again;
   }
   if (res.err == hipSuccess) res.err = hipErrorUnknown;

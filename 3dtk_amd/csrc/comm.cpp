@@ -91,14 +91,24 @@ int reserve(tdtk_comm* c, size_t n)
     if (c->d_buf) (void)hipFree(c->d_buf);
     c->d_buf = nullptr; c->cap = 0;
     const size_t want = n + n / 4 + 64;
-    if (hipMalloc((void**)&c->d_buf, want * sizeof(double)) != hipSuccess) { set_error("hipMalloc failed"); return TDTK_ENOMEM; }
+    if (hipMalloc((void**)&c->d_buf, want * sizeof(double)) != hipSuccess) {
+      // device memory the handle pool keeps on its shelf is invisible to this allocation: give it back, try once more --
+      // failing here ends in ncclCommAbort on every rank
+      (void)hipGetLastError();
+      pool_trim();
+      if (hipMalloc((void**)&c->d_buf, want * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc failed"); return TDTK_ENOMEM; }
+    }
     c->cap = want;
   }
   if (n > c->h_cap) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     c->h_pin = nullptr; c->h_cap = 0;
     const size_t want = n + n / 4 + 64;
-    if (hipHostMalloc((void**)&c->h_pin, want * sizeof(double), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
+    if (hipHostMalloc((void**)&c->h_pin, want * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      pool_trim();
+      if (hipHostMalloc((void**)&c->h_pin, want * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc failed"); return TDTK_ENOMEM; }
+    }
     c->h_cap = want;
   }
   return TDTK_OK;

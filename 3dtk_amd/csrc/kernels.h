@@ -60,6 +60,15 @@ struct SearchArgs {
   Mat4 A;
   double shift[3];
   double* partials;
+  // Lazy scan moves (several-links launch only, k_search_refill_multi): the `nmoves` in-place transforms queued on this
+  // scan since it was last read (Scan::transformToEuler of the graph-SLAM rounds since, two per round) are applied in
+  // order, in registers, where a lane takes a query -- the arithmetic of k_transform_chain, bit for bit.  The ONE link of
+  // the launch that owns the scan's update also stores the moved point into the scan's spare arrays (wx, wy, wz; the
+  // host swaps them in behind the launch) and moves the normals in place; every other link of the launch that reads
+  // the scan reads the same unmoved arrays and stores nothing.
+  const Mat4* moves;
+  int nmoves;
+  double *wx, *wy, *wz;
 };
 
 // internal bit beside the public TDTK_WANT_* ones: no centroid / cross-covariance columns (see k_accum)
@@ -214,14 +223,15 @@ hipError_t launch_scan_pair27(const unsigned long long* in, unsigned long long* 
 size_t morton_sort_temp_bytes(size_t n);
 hipError_t launch_morton_order(const double* d_xyz, size_t n, const double* d_box, uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,
                                size_t tmp_bytes, hipStream_t s);
-// one resident scan moved by two consecutive in-place transforms (Scan::transformToEuler)
-struct Xf2Desc {
+// one resident scan moved by a chain of consecutive in-place transforms (Scan::transformToEuler is two of them per
+// graph-SLAM round; a scan whose moves were queued over several rounds gets them all in one pass over its points)
+struct XfChainDesc {
   double *x, *y, *z, *nx, *ny, *nz;
   size_t n;
-  Mat4 A1, A2;
-  int has2;   // apply A2 after A1
+  const Mat4* mats;   // device memory, applied mats[0], mats[1], ...
+  int nm, pad;
 };
-hipError_t launch_transform2_batch(const Xf2Desc* d_desc, int count, size_t max_n, hipStream_t s);
+hipError_t launch_transform_chain_batch(const XfChainDesc* d_desc, int count, size_t max_n, hipStream_t s);
 
 // reduce.hip: bounding box + octree-centre reduction
 struct OctRoot {

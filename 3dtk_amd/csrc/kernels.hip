@@ -64,6 +64,17 @@ __device__ __forceinline__ void dev_xf3normal(const Mat4& A, double& x, double& 
   x = xn; y = yn; z = zn;
 }
 
+typedef const double __attribute__((address_space(4))) * const_d_ptr_fwd;  // constant address space -> s_load
+
+// One of the in-place moves queued on a resident scan (scan.cc:851-875 for each): the matrix comes through the scalar
+// cache (the chain is read-only for the whole launch), the arithmetic is dev_xf3_inplace / dev_xf3normal.
+__device__ __forceinline__ void load_move(const Mat4* mats, const int k, Mat4& A)
+{
+  const_d_ptr_fwd sm = (const_d_ptr_fwd)(mats + k);
+#pragma unroll
+  for (int j = 0; j < 16; j++) A.m[j] = sm[j];
+}
+
 // XCD-aware work assignment: workgroup b runs on XCD b % 8 (observed dispatch order, used for
 // speed only).  Giving XCD x the x-th contiguous eighth of the spatially sorted queries keeps
 // each XCD's private 4 MB L2 on one eighth of the leaves instead of all of them.
@@ -1385,7 +1396,7 @@ __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false,
-          int ORD_MAX = 256>
+          int ORD_MAX = 256, bool LAZY = false>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ uint4 lds_stk[SD][BLOCK];
@@ -1643,6 +1654,24 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         const int kp_prev = a.warm ? gload<int>(reinterpret_cast<const char*>(a_kpos), (uint32_t)mine << 2) : -1;
         double tx = gload<double>(reinterpret_cast<const char*>(a.x), m8), ty = gload<double>(reinterpret_cast<const char*>(a.y), m8),
                tz = gload<double>(reinterpret_cast<const char*>(a.z), m8);
+        if constexpr (LAZY) if (a.nmoves) {
+          // the moves queued on this scan since it was last read (SearchArgs::moves): applied here, in order, instead of
+          // by a pass of their own over every scan of the graph between two rounds
+          const bool owner = a.wx != nullptr;
+          double px = 0, py = 0, pz = 0;
+          if (owner && a.nx) { px = a.nx[mine]; py = a.ny[mine]; pz = a.nz[mine]; }
+          for (int k = 0; k < a.nmoves; k++) {
+            Mat4 Mv;
+            load_move(a.moves, k, Mv);
+            dev_xf3_inplace(Mv, tx, ty, tz);
+            if (owner && a.nx) dev_xf3normal(Mv, px, py, pz);
+          }
+          if (owner) {
+            gstore<double>(reinterpret_cast<char*>(a.wx), m8, tx); gstore<double>(reinterpret_cast<char*>(a.wy), m8, ty);
+            gstore<double>(reinterpret_cast<char*>(a.wz), m8, tz);
+            if (a.nx) { a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz; }
+          }
+        }
         if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
           dev_xf3_inplace(a.pending, tx, ty, tz);
           gstore<double>(reinterpret_cast<char*>(a.x), m8, tx); gstore<double>(reinterpret_cast<char*>(a.y), m8, ty);
@@ -1945,7 +1974,18 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           if (kk[h + u] >= 0) {
             const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)kk[h + u] << 5));
             cx[u] = c.x; cy[u] = c.y; cz[u] = c.z;
-            tx[u] = a.x[qq[h + u]]; ty[u] = a.y[qq[h + u]]; tz[u] = a.z[qq[h + u]];
+            // (lazy moves: the owner reads back what its own wave stored -- visible behind the fence above, like the
+            // hits --, everybody else moves the point again in registers)
+            const bool moved_copy = LAZY && a.nmoves && a.wx;
+            tx[u] = (moved_copy ? a.wx : a.x)[qq[h + u]]; ty[u] = (moved_copy ? a.wy : a.y)[qq[h + u]]; tz[u] = (moved_copy ? a.wz : a.z)[qq[h + u]];
+          }
+        }
+        if constexpr (LAZY) if (a.nmoves && !a.wx) {
+          for (int k = 0; k < a.nmoves; k++) {
+            Mat4 Mv;
+            load_move(a.moves, k, Mv);
+#pragma unroll
+            for (int u = 0; u < 2; u++) dev_xf3_inplace(Mv, tx[u], ty[u], tz[u]);
           }
         }
 #pragma unroll
@@ -2032,7 +2072,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const Search
   while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
   l = __builtin_amdgcn_readfirstlane(l);
   const uint32_t b0 = base[l], b1 = base[l + 1];
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320>(args[l], blockIdx.x - b0, b1 - b0);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320, true>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2392,8 +2432,10 @@ __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partia
 {
   __shared__ double red[4];
   const int k = blockIdx.x;
+  // `out` may be pinned host memory the host is watching word by word (await_sums in api.cpp): each sum is published
+  // with a store of system scope
   if (k >= ncols) {   // a column the pass did not fill (its rows hold +0.0): the same +0.0 without reading them
-    if (threadIdx.x == 0) out[k] = 0.0;
+    if (threadIdx.x == 0) __hip_atomic_store(&out[k], 0.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   double s = 0.0;
@@ -2401,7 +2443,7 @@ __global__ void __launch_bounds__(256) k_final(const double* __restrict__ partia
   s = wave_sum(s);
   if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[k] = ((red[0] + red[1]) + red[2]) + red[3];
+  if (threadIdx.x == 0) __hip_atomic_store(&out[k], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // k_final for several batches: blockIdx.y = batch (its rows, its output)
@@ -2443,25 +2485,26 @@ __global__ void k_transform(double* __restrict__ x, double* __restrict__ y, doub
   }
 }
 
-// Scan::transformToEuler (scan.cc:1061-1083) for many resident scans in one launch: the two
-// in-place transforms (inverse of the old pose, then the new pose) are applied one after the other
-// per point -- same arithmetic as two k_transform passes, half the HBM traffic, one launch.
-// blockIdx.y = scan.
-__global__ void __launch_bounds__(256) k_transform2_batch(const Xf2Desc* __restrict__ desc)
+// Scan::transformToEuler (scan.cc:1061-1083) for many resident scans in one launch, and whatever else was queued on
+// them: the in-place transforms of a scan's chain (inverse of the old pose, the new pose, the same again for the next
+// round ...) are applied one after the other per point -- the arithmetic of one k_transform pass per matrix, one trip
+// of the points through HBM, one launch.  blockIdx.y = scan.
+__global__ void __launch_bounds__(256) k_transform_chain_batch(const XfChainDesc* __restrict__ desc)
 {
-  const Xf2Desc& d = desc[blockIdx.y];
+  const XfChainDesc& d = desc[blockIdx.y];
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
     double px = d.x[i], py = d.y[i], pz = d.z[i];
-    dev_xf3_inplace(d.A1, px, py, pz);
-    if (d.has2) dev_xf3_inplace(d.A2, px, py, pz);
-    d.x[i] = px; d.y[i] = py; d.z[i] = pz;
-    if (d.nx) {
-      double ax = d.nx[i], ay = d.ny[i], az = d.nz[i];
-      dev_xf3normal(d.A1, ax, ay, az);
-      if (d.has2) dev_xf3normal(d.A2, ax, ay, az);
-      d.nx[i] = ax; d.ny[i] = ay; d.nz[i] = az;
+    double ax = 0, ay = 0, az = 0;
+    if (d.nx) { ax = d.nx[i]; ay = d.ny[i]; az = d.nz[i]; }
+    for (int k = 0; k < d.nm; k++) {
+      Mat4 A;
+      load_move(d.mats, k, A);
+      dev_xf3_inplace(A, px, py, pz);
+      if (d.nx) dev_xf3normal(A, ax, ay, az);
     }
+    d.x[i] = px; d.y[i] = py; d.z[i] = pz;
+    if (d.nx) { d.nx[i] = ax; d.ny[i] = ay; d.nz[i] = az; }
   }
 }
 
@@ -3279,14 +3322,14 @@ hipError_t launch_transform(double* x, double* y, double* z, double* nx, double*
   return hipGetLastError();
 }
 
-hipError_t launch_transform2_batch(const Xf2Desc* d_desc, int count, size_t max_n, hipStream_t s)
+hipError_t launch_transform_chain_batch(const XfChainDesc* d_desc, int count, size_t max_n, hipStream_t s)
 {
   if (count <= 0 || !max_n) return hipSuccess;
   size_t nb = (max_n + 255) / 256;
   size_t cap = ((size_t)num_cu() * 8 + count - 1) / count;
   if (cap < 8) cap = 8;
   if (nb > cap) nb = cap;
-  hipLaunchKernelGGL(k_transform2_batch, dim3((uint32_t)nb, (uint32_t)count), dim3(256), 0, s, d_desc);
+  hipLaunchKernelGGL(k_transform_chain_batch, dim3((uint32_t)nb, (uint32_t)count), dim3(256), 0, s, d_desc);
   return hipGetLastError();
 }
 

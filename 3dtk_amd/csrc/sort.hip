@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_scan_pair27(const unsigned long long* _
         const int p = pm ? (__ffsll((long long)pm) - 1) : 64;
         const unsigned long long need = (p >= 64) ? ~0ull : ((2ull << p) - 1ull);
         if ((vm & need) != need) {                       // somebody in front has not published yet
-          if (++spins > (1u << 22)) { if (lane == 0) atomicExch(err, 1u); break; }
+          if (++spins > (1u << 22)) { if (lane == 0) atomicOr(err, 0x10000u); break; }   // its own bit: not the callers' "degenerate input" flag
           __builtin_amdgcn_s_sleep(1);
           continue;
         }
@@ -177,8 +177,8 @@ __global__ void __launch_bounds__(256) k_scan_pair27(const unsigned long long* _
 }
 size_t scan_pair27_state_bytes(size_t n) { return 8 * ((n + SP_TILE - 1) / SP_TILE + 1) + 64; }
 // state: scan_pair27_state_bytes(n) bytes, zeroed once (hipMemsetAsync) before the first of up to 255 scans; epoch = 1, 2, ...
-// n < 2^27 and every count < 2^27 (the callers scan 0/1 flags over at most n positions); err: set to 1 if a tile gave up
-// waiting (never seen)
+// n < 2^27 and every count < 2^27 (the callers scan 0/1 flags over at most n positions); err: bit 16 is set if a tile gave up
+// waiting for its predecessors (a stalled tile under a debugger / preemption; never seen) -- the offsets are wrong then
 hipError_t launch_scan_pair27(const unsigned long long* in, unsigned long long* out, size_t n, void* state, uint32_t epoch,
                               uint32_t* err, hipStream_t s)
 {

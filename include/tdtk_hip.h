@@ -119,7 +119,7 @@ typedef struct tdtk_icp_result {
 const char* tdtk_last_error(void);
 int tdtk_device_count(void);
 /* Device memory of destroyed trees and scans is kept for the next handle of about that size (up to TDTK_POOL_MB megabytes
- * per process, default 4096; 0: every array goes straight back to the driver).  tdtk_pool_trim gives what is kept back
+ * per device, default 1024; 0: every array goes straight back to the driver).  tdtk_pool_trim gives what is kept back
  * now and returns the number of bytes released.                                                                    */
 size_t tdtk_pool_trim(void);
 /* Diagnostics: how many device tree builds of this process had to be redone in order because a node cut at the plain

@@ -816,6 +816,56 @@ def test_a_links_sums_do_not_depend_on_its_company(tdtk, gpu):
             assert np.array_equal(a[share], b), share
 
 
+def test_lazy_scan_moves_equal_moving_every_round(tdtk, gpu, monkeypatch):
+    """Round 4: the pose update of a graph-SLAM round queues its transforms on the resident scans
+    (Scan::transformToEuler, scan.cc:1061-1083: two in-place transforms per round) and the link passes of the next round
+    apply them in registers -- the link that owns a scan's update stores the moved points, other links of the same launch
+    that read the scan move it again on the fly, a scan no link reads keeps its chain until somebody asks for its points.
+    Same arithmetic in the same order as moving every scan every round (TDTK_LAZY_MOVES=0): poses, `ret`, every link's
+    sums and the final points are bit-identical."""
+    from importlib import import_module
+    gs = import_module("3dtk_amd.graphslam")
+    rng = np.random.default_rng(29)
+    world = rng.uniform(-400, 400, (300000, 3))
+
+    def make():
+        scans = []
+        for k in range(5):
+            T = tdtk.EulerToMatrix4([3.0 * k, -1.0 * k, 2.0 * k], [0.002 * k, -0.003 * k, 0.004 * k])
+            Ti = tdtk.M4inv(T)
+            R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+            loc = world @ R.T + Ti[12:15] + np.random.default_rng(100 + k).normal(0, 0.05, world.shape)
+            scans.append(tdtk.Scan([3.0 * k + 0.3, -1.0 * k, 2.0 * k - 0.2], [0.002 * k, -0.003 * k + 0.001, 0.004 * k], loc))
+        tdtk.prepare_scans(scans, trees=True, threads=2)
+        return scans
+    # scan 1 is read by one link, scan 2 by two, scan 3 by three links of the launch; scan 4 by none (it only lends its tree)
+    links = [(0, 1), (1, 2), (2, 3), (0, 3), (0, 2), (1, 3), (4, 1)]
+
+    def run(lazy):
+        if lazy:
+            monkeypatch.delenv("TDTK_LAZY_MOVES", raising=False)
+        else:
+            monkeypatch.setenv("TDTK_LAZY_MOVES", "0")
+        scans = make()
+        gr = tdtk.Graph(5, links=links)
+        rets = [gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, scans, 100.0, None) for _ in range(3)]
+        # a pass of another kind in between reads what is queued as well (scan 3 has just been moved by round 3)
+        pairs = tdtk.Scan.getPtPairs(scans[2], scans[3], max_dist_match2=100.0)
+        rets.append(gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, scans, 100.0, None))
+        poses = np.stack([s.transMat for s in scans])
+        pts = [s.get_xyz_reduced() for s in scans]
+        for s in scans:
+            s.release()
+        return rets, poses, pts, (pairs["n"], pairs["sum"])
+    eager = run(False)
+    lazy = run(True)
+    assert eager[0] == lazy[0] and np.array_equal(eager[1], lazy[1]) and eager[3] == lazy[3]
+    assert eager[3][0] > 100000
+    for a, b in zip(eager[2], lazy[2]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(eager[2][4], make()[4].get_xyz_reduced())     # (scan 4 did move)
+
+
 def test_tree_edge_cases(tdtk, orc, gpu):
     """One point, two points, all-identical points (one degenerate bucket larger than the bucket size),
     non-finite coordinates (the reference would recurse on an empty side; we return an error)."""

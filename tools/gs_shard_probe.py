@@ -27,6 +27,17 @@ for i in range(nl_all):
 L = capi.lib()
 
 
+hs_all = (C.c_void_p * (ns - 1))(*[scans[k].handle for k in range(1, ns)])
+_wig = np.ascontiguousarray(np.tile(t.EulerToMatrix4([1e-4, -1e-4, 1e-4], [1e-7, -1e-7, 1e-7]), (ns - 1, 1)))
+_wig_inv = np.ascontiguousarray(np.stack([t.M4inv(m) for m in _wig]))
+
+
+def queue_moves():
+    """what the pose update of the previous round leaves behind: two in-place transforms queued on every scan but the
+    first (round 4: carried out by the link passes that read the scan, so they belong to the share's time)"""
+    capi.check(L.tdtk_scans_transform2(ns - 1, hs_all, capi.dptr(_wig), capi.dptr(_wig_inv)))
+
+
 def time_links(idx):
     nl = len(idx)
     first = (C.c_void_p * nl)(*[scans[g.getLink(i, 0)].getSearchTree()._h for i in idx])
@@ -35,6 +46,7 @@ def time_links(idx):
     Cm = np.empty((nl, 36)); CD = np.empty((nl, 6)); m = (C.c_uint64 * nl)(); ss = np.empty(nl)
     best = 1e9
     for _ in range(3):
+        queue_moves()
         t0 = time.perf_counter()
         capi.check(L.tdtk_lum_links(nl, first, capi.dptr(dal), second, 625.0, capi.dptr(Cm), capi.dptr(CD), m, capi.dptr(ss)))
         best = min(best, time.perf_counter() - t0)
@@ -55,11 +67,16 @@ rest = full_ms - links_ms
 print("links %d, full iteration %.2f ms, all links %.2f ms, rest (graph + all-reduce + solve + pose update) %.2f ms"
       % (nl_all, full_ms, links_ms, rest))
 base = None
+pred = {}
 for world in (1, 2, 4, 8):
     shares = [gs.shard_links(g, r, world) for r in range(world)]
     per = [time_links(s) if len(s) else 0.0 for s in shares]
     step = max(per) + rest
     base = base or step
+    pred[str(world)] = {"links_per_rank": [len(x) for x in shares], "slowest_share_ms": round(max(per), 3), "rest_ms": round(rest, 3),
+                        "predicted_step_ms": round(step, 3)}
     print("world %d: links/rank %s  slowest share %.2f ms  predicted step %.2f ms  speedup %.2f  efficiency %.0f%%"
           % (world, [len(s) for s in shares], max(per), step, base / step, 100 * base / step / world))
+import json
+print("PREDICTION " + json.dumps(pred))
 dist.destroy_process_group()
