@@ -1343,6 +1343,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   uint32_t node_count = 0, leaf_count = 0, depth = 0;
   uint32_t h_spec_err = 0;
   bool spec_on = false;
+  bool spec_suspect = false;   // the failure may be the speculation's doing (see `fail`)
   size_t scan_tmp = 0;
   size_t O[32];
   (void)build_layout(M_, O, &scan_tmp);

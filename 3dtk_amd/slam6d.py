@@ -1411,11 +1411,13 @@ def matchGraph6Dautomatic_clpairs(my_graphSlam6D, allScans, nrIt, clpairs, loops
 
 
 def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_graphSlam6D, nrIt, epsilonSLAM,
-                          mdml, eP=True, max_num_metascans=-1, prefetch=True, my_loopSlam6D=None):
-    """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548) without the -DlastSLAM pass: sequential ICP, loop
-    detection by pose distance (the closest pair (first, last) seen while a loop is being detected), ELCH loop closing
-    when my_loopSlam6D is given (-L, slam6D.cc:500-505, 523-527), and rounds of { fresh Graph(i+1, cldist^2, loopsize);
-    one doGraphSlam6D iteration } until ret <= epsilonSLAM or nrIt rounds."""
+                          mdml, eP=True, max_num_metascans=-1, prefetch=True, my_loopSlam6D=None, mdmll=-1.0, graphDist=0.0):
+    """matchGraph6Dautomatic (src/slam6d/slam6D.cc:387-548): sequential ICP (against the predecessor, or with meta_icp
+    against a MetaScan of the last max_num_metascans scans, slam6D.cc:436-448), loop detection by pose distance (the
+    closest pair (first, last) seen while a loop is being detected), ELCH loop closing when my_loopSlam6D is given (-L,
+    slam6D.cc:500-505, 523-527), rounds of { fresh Graph(i+1, cldist^2, loopsize); one doGraphSlam6D iteration } until
+    ret <= epsilonSLAM or nrIt rounds, and with mdmll > 0 the closing pass of slam6D.cc:535-547 (-DlastSLAM):
+    set_mdmll(mdmll), then such rounds on Graph(n, graphDist^2, loopsize)."""
     cldist2 = cldist * cldist
     metas = []
     n = len(allScans)
@@ -1424,11 +1426,11 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
     g = []                         # graph for loop optimisation (graph_t g, slam6D.cc:411)
     min_dist, first, last = -1.0, 0, 0
 
-    def global_rounds(nodes):
+    def global_rounds(nodes, graph_dist2=None):
         nonlocal rounds
         j = 0
         while True:
-            gr = Graph(nodes, cldist2, loopsize, allScans)
+            gr = Graph(nodes, cldist2 if graph_dist2 is None else graph_dist2, loopsize, allScans)
             ret = my_graphSlam6D.doGraphSlam6D(gr, allScans, 1)
             j += 1
             rounds += 1
@@ -1492,4 +1494,7 @@ def matchGraph6Dautomatic(cldist, loopsize, allScans, my_icp6D, meta_icp, my_gra
         g.append((first, last))
     if my_graphSlam6D is not None and mdml > 0.0:
         global_rounds(n)
+    if my_graphSlam6D is not None and mdmll > 0.0:              # slam6D.cc:535-547
+        my_graphSlam6D.set_mdmll(mdmll)
+        global_rounds(n, graphDist * graphDist)
     return rounds

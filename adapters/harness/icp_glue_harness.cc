@@ -39,6 +39,7 @@ struct MiniScan {
   const double* get_transMat() const { return transMat; }
   const double* get_transMatOrg() const { return transMatOrg; }
   const double* getDAlign() const { return dalignxf; }
+  int hipBucket() const { return 20; }
   tdtk_scan* hipResident()
   {
     if (!res) {

@@ -5,7 +5,9 @@
 // Scan::transform, scan.cc:945-1008; transformToEuler, scan.cc:1061-1083; a scan is loaded in its own frame and moved
 // to its pose when first used, basicScan.cc:730-737).
 //
-// usage: slam_glue_harness <in.bin> <out.bin> [nscans] [npts] [prefetch]
+// usage: slam_glue_harness <in.bin> <out.bin> [nscans] [npts] [prefetch] [variant]
+// variant 0: sequential ICP against the predecessor; 1: meta_icp with max_num_metascans = 3 (slam6D.cc:436-448) and the
+// closing -DlastSLAM pass (mdmll = 15, graphDist = 140; slam6D.cc:535-547)
 // Writes the scans it made to <in.bin> (int32 nscans, int32 npts, then per scan rPos[3], rPosTheta[3], xyz[npts][3]) and
 // what it ended with to <out.bin> (per scan transMat[16], then one int32 frame count per scan, int32 rounds), so that
 // tests/test_gpu_parity.py::test_slam_glue_executes can run the Python mirror on the same scans and compare bit for bit.
@@ -170,12 +172,14 @@ static void make_loop(std::vector<MiniScan>& scans, int nscans, int npts)
   g_state = keep;
 }
 
+static int g_variant = 0;
 static int run(std::vector<MiniScan>& scans, int prefetch, int* rounds)
 {
   MiniScan::all.clear();
   std::vector<MiniScan*> ptrs;
   for (MiniScan& s : scans) { ptrs.push_back(&s); MiniScan::all.push_back(&s); }
-  HipSlamSettings cfg;
+  HipSlamSettings cfg{};
+  if (g_variant == 1) { cfg.meta_icp = true; cfg.max_num_metascans = 3; cfg.mdmll = 15.0; cfg.graphDist = 140.0; }
   cfg.icp = {TDTK_ALGO_QUAT, 0, 30, 25.0 * 25.0, 1e-5, true, -1, true, T_ICP};
   cfg.loop_icp = {TDTK_ALGO_QUAT, 0, 30, 25.0 * 25.0, 1e-5, true, -1, true, T_ICP};
   cfg.use_elch = true;
@@ -187,12 +191,76 @@ static int run(std::vector<MiniScan>& scans, int prefetch, int* rounds)
   return 0;
 }
 
+// `slam_glue_harness doicp <in.bin> <out.bin> <meta 0|1> <max_num_metascans> <mdm> <iterations> <epsilonICP>`: icp6D::doICP
+// (adapters/icp_glue.h, hip_do_icp) over scans read from <in.bin> -- int32 nscans, then per scan int32 npts, rPos[3],
+// rPosTheta[3], xyz[npts][3] in the scanner's frame -- with -a 1; <out.bin>: per scan transMat[16], then int32 frames per
+// scan.  BASELINE config 1 (`slam6D -m 500 -d 25.0 --metascan dat`) runs through this (test_config1_metascan_dat_through_the_cpp_glue).
+static int run_doicp(int argc, char** argv)
+{
+  if (argc < 9) { std::printf("usage: %s doicp in.bin out.bin meta max_num_metascans mdm iterations epsilonICP\n", argv[0]); return 2; }
+  FILE* f = std::fopen(argv[2], "rb");
+  if (!f) { std::printf("SLAM GLUE HARNESS FAIL: cannot read %s\n", argv[2]); return 1; }
+  int32_t nscans = 0;
+  if (std::fread(&nscans, sizeof nscans, 1, f) != 1 || nscans < 1 || nscans > 4096) { std::fclose(f); std::printf("SLAM GLUE HARNESS FAIL: bad header\n"); return 1; }
+  std::vector<MiniScan> scans((size_t)nscans);
+  for (MiniScan& s : scans) {
+    int32_t np = 0;
+    double pose[6];
+    if (std::fread(&np, sizeof np, 1, f) != 1 || np < 0 || std::fread(pose, sizeof pose, 1, f) != 1) { std::fclose(f); std::printf("SLAM GLUE HARNESS FAIL: short file\n"); return 1; }
+    s.local.resize(3 * (size_t)np);
+    if (np && std::fread(s.local.data(), sizeof(double), s.local.size(), f) != s.local.size()) { std::fclose(f); std::printf("SLAM GLUE HARNESS FAIL: short file\n"); return 1; }
+    s.init(pose, pose + 3);
+  }
+  std::fclose(f);
+  const double mdm = std::atof(argv[6]);
+  HipIcpSettings cfg = {TDTK_ALGO_QUAT, 0, std::atoi(argv[7]), mdm * mdm, std::atof(argv[8]), true, -1, true, T_ICP,
+                        std::atoi(argv[4]) != 0, std::atoi(argv[5])};
+  for (int prefetch : {2, 0}) {       // prepared ahead or not: the same poses (the second run's are written)
+    std::vector<MiniScan> run_scans((size_t)nscans);
+    MiniScan::all.clear();
+    std::vector<MiniScan*> ptrs;
+    for (int k = 0; k < nscans; k++) {
+      run_scans[k].local = scans[k].local;
+      run_scans[k].init(scans[k].in_rPos, scans[k].in_rPosTheta);
+      ptrs.push_back(&run_scans[k]); MiniScan::all.push_back(&run_scans[k]);
+    }
+    unsigned int pairs = 0;
+    std::vector<int> its;
+    hip_do_icp(ptrs, cfg, prefetch, &pairs, [&](size_t, int it) { its.push_back(it); });
+    if (prefetch == 2) {
+      for (int k = 0; k < nscans; k++) std::memcpy(scans[k].transMat, run_scans[k].transMat, sizeof scans[k].transMat);
+      continue;
+    }
+    for (int k = 0; k < nscans; k++)
+      if (std::memcmp(scans[k].transMat, run_scans[k].transMat, sizeof scans[k].transMat) != 0) {
+        std::printf("SLAM GLUE HARNESS FAIL: doICP scan %d differs between prefetch 2 and none\n", k);
+        return 1;
+      }
+    FILE* o = std::fopen(argv[3], "wb");
+    if (!o) { std::printf("SLAM GLUE HARNESS FAIL: cannot write %s\n", argv[3]); return 1; }
+    for (MiniScan& s : run_scans) std::fwrite(s.transMat, sizeof s.transMat, 1, o);
+    for (MiniScan& s : run_scans) { const int32_t fr = s.frames; std::fwrite(&fr, sizeof fr, 1, o); }
+    for (int it : its) { const int32_t v = it; std::fwrite(&v, sizeof v, 1, o); }
+    std::fclose(o);
+    std::printf("SLAM GLUE HARNESS OK: doICP meta %d over %d scans, iterations", (int)cfg.meta, nscans);
+    for (int it : its) std::printf(" %d", it);
+    std::printf(", last pairs %u\n", pairs);
+    MiniScan::all.clear();
+  }
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
+  if (argc > 1 && std::strcmp(argv[1], "doicp") == 0) {
+    try { return run_doicp(argc, argv); }
+    catch (const std::exception& e) { std::printf("SLAM GLUE HARNESS FAIL: %s\n", e.what()); return 1; }
+  }
   if (argc < 3) { std::printf("usage: %s in.bin out.bin [nscans] [npts] [prefetch]\n", argv[0]); return 2; }
   const int nscans = argc > 3 ? std::atoi(argv[3]) : 15;
   const int npts = argc > 4 ? std::atoi(argv[4]) : 30000;
   const int prefetch = argc > 5 ? std::atoi(argv[5]) : 3;
+  g_variant = argc > 6 ? std::atoi(argv[6]) : 0;
   try {
     std::vector<MiniScan> a, b;
     make_loop(a, nscans, npts);
@@ -226,8 +294,8 @@ int main(int argc, char** argv)
     std::fclose(f);
     double moved = 0.0;
     for (int k = 0; k < nscans; k++) moved = std::fmax(moved, std::fabs(a[k].transMat[12] - a[k].transMatOrg[12]));
-    std::printf("SLAM GLUE HARNESS OK: %d scans x %d points, %d global rounds, prefetch %d == none, largest pose correction %.3f\n",
-                nscans, npts, rounds_a, prefetch, moved);
+    std::printf("SLAM GLUE HARNESS OK: variant %d, %d scans x %d points, %d global rounds, prefetch %d == none, largest pose correction %.3f\n",
+                g_variant, nscans, npts, rounds_a, prefetch, moved);
   } catch (const std::exception& e) {
     std::printf("SLAM GLUE HARNESS FAIL: %s\n", e.what());
     return 1;

@@ -33,6 +33,7 @@ struct HipIcpScanView {
   const double* getDAlign() const { return s->getDAlign(); }
   tdtk_tree* hipTree() { return static_cast<HipSearchTree*>(s->getSearchTree())->handle(); }
   tdtk_scan* hipResident() { return s->hipResident(); }
+  int hipBucket() { return static_cast<HipSearchTree*>(s->getSearchTree())->bucketSize(); }    // KDtreeMetaManaged: kdMeta.cc:45-46
   void transformMatrixAndFrames(const double* xf, int type, int islum) { s->transformMatrixAndFrames(xf, (Scan::AlgoType)type, islum); }
   // Scan::transform moves the resident copy too (reference.patch, Scan::transformReduced)
   void mergeCoordinatesWithRoboterPosition(HipIcpScanView* prev) { s->mergeCoordinatesWithRoboterPosition(prev->s); }
@@ -45,7 +46,7 @@ public:
   HipIcpSettings settings(PairingMode pairing_mode)
   {
     HipIcpSettings c = {hip_algo_id(my_icp6Dminimizer), (int)pairing_mode, max_num_iterations, max_dist_match2, epsilonICP,
-                        quiet, anim, eP, (int)Scan::ICP};
+                        quiet, anim, eP, (int)Scan::ICP, meta, max_num_metascans};
     return c;
   }
   bool on_device(Scan* model)
@@ -59,7 +60,9 @@ public:
   {
     if (!on_device(PreviousScan)) return icp6D::match(PreviousScan, CurrentScan, pairing_mode);     // CPU path of the reference
     HipIcpScanView prev = {PreviousScan}, cur = {CurrentScan};
-    const int it = hip_icp_match(&prev, &cur, settings(pairing_mode), &nr_pointPair);
+    unsigned int pairs = 0;      // (icp6D::nr_pointPair is an int, include/slam6d/icp6D.h:150)
+    const int it = hip_icp_match(&prev, &cur, settings(pairing_mode), &pairs);
+    nr_pointPair = (int)pairs;
     // a caller of match() may look at the points afterwards: hand the moved points back
     DataXYZ xyz(CurrentScan->get("xyz reduced"));
     if (xyz.size() && tdtk_scan_download(CurrentScan->hipResident(), xyz[0], 0) != TDTK_OK) throw std::runtime_error(tdtk_last_error());
@@ -69,12 +72,17 @@ public:
   // icp6D::doICP is not virtual in the reference; slam6D.cc holds an icp6D*, so reference.patch makes it virtual
   virtual void doICP(std::vector<Scan*> allScans, PairingMode pairing_mode = CLOSEST_POINT)
   {
-    if (meta || cad_matching || allScans.empty() || !on_device(allScans[0])) { icp6D::doICP(allScans, pairing_mode); return; }
+    // --metascan (BASELINE config 1) stays on the device: hip_do_icp builds the MetaScan's tree over the resident copies of
+    // the scans matched so far (tdtk_tree_create_from_scans = KDtreeMetaManaged, kdMeta.cc:34-134).  CAD matching keeps
+    // the reference's loop.
+    if (cad_matching || allScans.empty() || !on_device(allScans[0])) { icp6D::doICP(allScans, pairing_mode); return; }
     std::vector<HipIcpScanView> views(allScans.size());
     std::vector<HipIcpScanView*> ptrs(allScans.size());
     for (size_t i = 0; i < allScans.size(); i++) { views[i].s = allScans[i]; ptrs[i] = &views[i]; }
-    hip_do_icp(ptrs, settings(pairing_mode), /*scans prepared ahead*/ 3, &nr_pointPair,
+    unsigned int pairs = 0;
+    hip_do_icp(ptrs, settings(pairing_mode), /*scans prepared ahead*/ 3, &pairs,
                [](size_t i, int) { std::cout << i << "*" << std::endl; });
+    nr_pointPair = (int)pairs;
     // the host copies of "xyz reduced" once, at the end
     for (Scan* s : allScans) {
       DataXYZ xyz(s->get("xyz reduced"));

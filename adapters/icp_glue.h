@@ -30,18 +30,23 @@ struct HipIcpSettings {
   int anim;                 // icp6D::anim
   bool eP;                  // icp6D::eP: extrapolate the pose before matching (doICP)
   int type_icp;             // Scan::ICP as an int (the glue does not see the enum)
+  bool meta;                // icp6D::meta (--metascan): doICP matches every scan against a MetaScan of the scans before it
+  int max_num_metascans;    // icp6D::max_num_metascans: only the last n of them (<= 0: all)
 };
 
 // ScanT needs: get_transMat(), getDAlign() -> const double*;  tdtk_tree* hipTree();  tdtk_scan* hipResident();
 //              void transformMatrixAndFrames(const double*, int type, int islum);
 //              void mergeCoordinatesWithRoboterPosition(ScanT* prev)     (doICP with eP; must also move a resident copy)
+//              int hipBucket()                                           (doICP with meta: the MetaScan tree's bucket size)
 //
 // icp6D::match with the loop on the device.  Returns the iteration count icp6D::match returns; *nr_pointPair as the
 // member of the same name.  The data scan stays resident (ScanT::hipResident): its host copy of "xyz reduced" is NOT
 // refreshed here -- whoever needs it calls tdtk_scan_download on the resident handle (icp6D_hip::match does, doICP does
 // once per scan at the end).
+// (model: the search tree of the previous scan -- or of a MetaScan -- and the dalignxf that goes with it)
 template <class ScanT>
-int hip_icp_match(ScanT* prev, ScanT* cur, const HipIcpSettings& cfg, unsigned int* nr_pointPair)
+int hip_icp_match_tree(const tdtk_tree* model_tree, const double* model_dalignxf, ScanT* cur, const HipIcpSettings& cfg,
+                       unsigned int* nr_pointPair)
 {
   const double id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   // icp6D.cc:109 `CurrentScan->transform(id, Scan::ICP, 0)`: the identity moves no point -- matrices and frame only
@@ -54,7 +59,7 @@ int hip_icp_match(ScanT* prev, ScanT* cur, const HipIcpSettings& cfg, unsigned i
   double tm[16], da[16];     // scratch: the Scan keeps its own matrices (replayed below)
   std::memcpy(tm, cur->get_transMat(), sizeof tm);
   std::memcpy(da, cur->getDAlign(), sizeof da);
-  if (tdtk_icp_match(prev->hipTree(), prev->getDAlign(), data, tm, da, &prm, &res, trace.data(), cfg.max_num_iterations) != TDTK_OK)
+  if (tdtk_icp_match(model_tree, model_dalignxf, data, tm, da, &prm, &res, trace.data(), cfg.max_num_iterations) != TDTK_OK)
     throw std::runtime_error(tdtk_last_error());
   // The points have moved on the device; replay the matrix / frame bookkeeping of every iteration's
   // `CurrentScan->transform(alignxf, Scan::ICP, islum)` (icp6D.cc:246-252) and of the end pose (icp6D.cc:254-268).  The
@@ -70,6 +75,37 @@ int hip_icp_match(ScanT* prev, ScanT* cur, const HipIcpSettings& cfg, unsigned i
     cur->transformMatrixAndFrames(id, cfg.type_icp, cfg.anim == -2 ? -1 : 0);     // write end pose
   if (nr_pointPair) *nr_pointPair = (unsigned int)res.last_pairs;
   return res.iterations;
+}
+template <class ScanT>
+int hip_icp_match(ScanT* prev, ScanT* cur, const HipIcpSettings& cfg, unsigned int* nr_pointPair)
+{
+  return hip_icp_match_tree(prev->hipTree(), prev->getDAlign(), cur, cfg, nr_pointPair);
+}
+
+// icp6D::match(MetaScan* model, Scan* data) (icp6D.cc:104-285 with a MetaScan in front, what doICP's meta branch and
+// matchGraph6Dautomatic's meta_icp ask for): ONE search tree over the members' CURRENT resident points, built on the
+// device (tdtk_tree_create_from_scans = KDtreeMetaManaged, kdMeta.cc:34-134: concatenation order, the first member's
+// bucket size); a MetaScan's own dalignxf is the identity (Scan base constructor, scan.cc:193).  The tree lives for
+// this match, as the reference's MetaScan does.
+template <class ScanT>
+int hip_icp_match_metascan(const std::vector<ScanT*>& members, ScanT* cur, const HipIcpSettings& cfg, unsigned int* nr_pointPair)
+{
+  const double id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (members.empty()) throw std::runtime_error("an empty MetaScan cannot be matched against");
+  std::vector<tdtk_scan*> ms;
+  for (ScanT* m : members) ms.push_back(m->hipResident());
+  tdtk_tree* tree = nullptr;
+  if (tdtk_tree_create_from_scans(ms.data(), (int)ms.size(), members[0]->hipBucket(), &tree) != TDTK_OK)
+    throw std::runtime_error(tdtk_last_error());
+  int it;
+  try {
+    it = hip_icp_match_tree(tree, id, cur, cfg, nr_pointPair);
+  } catch (...) {
+    tdtk_tree_destroy(tree);
+    throw;
+  }
+  tdtk_tree_destroy(tree);
+  return it;
 }
 
 // A few worker threads that run "prepare scan j" jobs in order; the library is thread-safe per handle and gives every
@@ -134,9 +170,10 @@ private:
   bool stop = false;
 };
 
-// icp6D::doICP, sequential matching of every scan against its predecessor (the non-meta, non-CAD branch of
-// icp6D.cc:374-437), with the next `prefetch` scans made resident and their search trees built while the current pair
-// is matched.  A scan's tree is built over "xyz reduced original", which no ICP step touches, and a scan is uploaded
+// icp6D::doICP (icp6D.cc:374-437, without CAD matching): sequential matching of every scan against its predecessor or,
+// with cfg.meta (--metascan, BASELINE config 1), against a MetaScan of the scans matched so far / the last
+// cfg.max_num_metascans of them (icp6D.cc:396-434) -- with the next `prefetch` scans made resident (and, without meta,
+// their search trees built) while the current pair is matched.  A scan's tree is built over "xyz reduced original", which no ICP step touches, and a scan is uploaded
 // where it was loaded -- the pose extrapolation of scan j (eP) depends on the final pose of scan j-1, so it is applied
 // after the match of j-1, to the resident copy (ScanT::mergeCoordinatesWithRoboterPosition must move both).  The result
 // does not depend on `prefetch`, bit for bit (adapters/harness/icp_glue_harness.cc checks that).
@@ -147,26 +184,35 @@ void hip_do_icp(std::vector<ScanT*>& allScans, const HipIcpSettings& cfg, int pr
 {
   const size_t n = allScans.size();
   HipPrefetcher* pool = (prefetch > 0 && n > 2) ? new HipPrefetcher(prefetch) : nullptr;
+  const bool meta = cfg.meta;
+  std::vector<ScanT*> meta_scans;      // icp6D.cc:380-381, 421-433
   try {
     for (size_t i = 0; i < n; i++) {
       if (pool) {
-        // scans i .. i + prefetch are (being) prepared; this iteration needs i - 1 (its tree) and i (its points)
+        // scans i .. i + prefetch are (being) prepared; this iteration needs i - 1 (its tree) and i (its points).  With
+        // meta the model tree is the MetaScan's, built per match: only the points are prepared ahead.
         for (size_t j = i; j < n && j <= i + (size_t)prefetch; j++) {
           ScanT* s = allScans[j];
-          pool->submit(j, [s] { (void)s->hipResident(); (void)s->hipTree(); });
+          pool->submit(j, [s, meta] { (void)s->hipResident(); if (!meta) (void)s->hipTree(); });
         }
         if (i > 0) pool->wait(i - 1);
         pool->wait(i);
       }
-      if (i == 0) continue;
       ScanT* cur = allScans[i];
-      ScanT* prev = allScans[i - 1];
-      // resident BEFORE the pose extrapolation, prepared ahead or not: the resident copy is ordered by where the points
-      // are when they are uploaded, and the order of the pair sums (hence the last bits of a pose) follows from it
-      (void)cur->hipResident();
-      if (cfg.eP) cur->mergeCoordinatesWithRoboterPosition(prev);
-      const int it = hip_icp_match(prev, cur, cfg, nr_pointPair);
-      if (on_matched) on_matched(i, it);
+      if (i > 0) {
+        ScanT* prev = allScans[i - 1];
+        // resident BEFORE the pose extrapolation, prepared ahead or not: the resident copy is ordered by where the points
+        // are when they are uploaded, and the order of the pair sums (hence the last bits of a pose) follows from it
+        (void)cur->hipResident();
+        if (cfg.eP) cur->mergeCoordinatesWithRoboterPosition(prev);
+        const int it = meta ? hip_icp_match_metascan(meta_scans, cur, cfg, nr_pointPair) : hip_icp_match(prev, cur, cfg, nr_pointPair);
+        if (on_matched) on_matched(i, it);
+      }
+      if (meta && i != n - 1) {          // push processed scan; only keep the last n scans as metascans
+        meta_scans.push_back(cur);
+        if (cfg.max_num_metascans > 0)
+          while (meta_scans.size() > (size_t)cfg.max_num_metascans) meta_scans.erase(meta_scans.begin());
+      }
     }
   } catch (...) {
     delete pool;

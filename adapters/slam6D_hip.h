@@ -3,7 +3,8 @@
 // slam6d/slam6d_glue.h: sequential ICP with the next scans prepared ahead, loop detection, -L 1 loop closing with every
 // covariance pass of the loop graph in one batched call and the MetaScan match on the device, -G 1..4 rounds through
 // graph_slam_glue.h.  Call matchGraph6Dautomatic_hip where slam6D.cc calls matchGraph6Dautomatic when -t HipKD is
-// selected and the run is one the glue serves (no meta_icp, -L 0 or 1, rnd <= 1); otherwise keep the reference's call.
+// selected and the run is one the glue serves (-L 0 or 1, rnd <= 1; meta_icp and the -DlastSLAM pass included since round 4);
+// otherwise keep the reference's call.
 //
 // The body lives in slam6d/slam6d_glue.h, templated on the scan type: that header is compiled, linked and EXECUTED on
 // the GPU box with a minimal scan type (adapters/harness/slam_glue_harness.cc), where every pose it ends with equals the
@@ -53,12 +54,15 @@ struct HipSlamScanView {
 // returns the number of global rounds; `backend`: the -G id (1..4) or -1, `comm`: the library's communicator or 0
 static inline int matchGraph6Dautomatic_hip(double cldist, int loopsize, std::vector<Scan*> allScans, icp6D_hip* my_icp6D,
                                             icp6D_hip* loop_icp6D /* 0: no -L */, int backend, int nrIt, double epsilonSLAM,
-                                            double mdml, double epsilonLUM, int prefetch = 3, tdtk_comm* comm = 0)
+                                            double mdml, double epsilonLUM, int prefetch = 3, tdtk_comm* comm = 0,
+                                            bool meta_icp = false, int max_num_metascans = -1, double mdmll = -1.0,
+                                            double graphDist = 0.0)
 {
   std::vector<HipSlamScanView> views(allScans.size());
   std::vector<HipSlamScanView*> ptrs(allScans.size());
   for (size_t i = 0; i < allScans.size(); i++) { views[i].s = allScans[i]; ptrs[i] = &views[i]; }
-  HipSlamSettings cfg;
+  HipSlamSettings cfg = HipSlamSettings();
+  cfg.meta_icp = meta_icp; cfg.max_num_metascans = max_num_metascans; cfg.mdmll = mdmll; cfg.graphDist = graphDist;
   cfg.icp = my_icp6D->settings(CLOSEST_POINT);
   cfg.loop_icp = loop_icp6D ? loop_icp6D->settings(CLOSEST_POINT) : cfg.icp;
   cfg.use_elch = loop_icp6D != 0;

@@ -190,10 +190,14 @@ struct HipSlamSettings {
   double cldist, mdml, epsilonSLAM, epsilonLUM;
   int loopsize, nrIt, prefetch;
   tdtk_comm* comm;           // nullable
+  bool meta_icp;             // slam6D.cc:436-448: every scan is matched against a MetaScan of the scans before it ...
+  int max_num_metascans;     // ... the last n of them (<= 0: all)
+  double mdmll, graphDist;   // the closing pass of slam6D.cc:535-547 (-DlastSLAM / --graphDist): mdmll > 0 runs it, on
+                             // Graph(n, graphDist^2, loopsize) with max_dist_match2_LUM = mdmll^2
 };
 
-// matchGraph6Dautomatic (slam6D.cc:387-548, without the -DlastSLAM pass and without meta_icp): returns the number of
-// global rounds it ran.  A scan's preparation (upload, ordering, tree build) runs up to `prefetch` scans ahead of the
+// matchGraph6Dautomatic (slam6D.cc:387-548, meta_icp and the -DlastSLAM pass included): returns the number of global
+// rounds it ran.  A scan's preparation (upload, ordering, tree build) runs up to `prefetch` scans ahead of the
 // match on worker threads; scan i + 1 is not part of the graph over scans 0 .. i, so the relaxation never touches a
 // scan that is being prepared, and every scan is made resident BEFORE its pose extrapolation, prepared ahead or not
 // (see hip_do_icp) -- the result does not depend on `prefetch`.
@@ -205,13 +209,14 @@ int hip_match_graph6d_automatic(std::vector<ScanT*>& allScans, const HipSlamSett
   int loop_detection = 0, rounds = 0, first = 0, last = 0;
   double min_dist = -1.0;
   std::vector<std::pair<int, int>> g;
-  auto global_rounds = [&](int nodes) {
+  std::vector<ScanT*> metas;          // slam6D.cc:407
+  auto global_rounds = [&](int nodes, double graph_dist2, double max_dist_match2_LUM) {
     int j = 0;
     double ret;
     std::vector<ScanT*> sub(allScans.begin(), allScans.begin() + nodes);
     do {
-      HipClGraph gr = hip_make_graph(nodes, cldist2, cfg.loopsize, allScans);
-      ret = hip_graph_slam(cfg.graph_backend, gr, sub, 1, cfg.epsilonLUM, cfg.mdml * cfg.mdml, cfg.comm, ty.invalid, ty.lum);
+      HipClGraph gr = hip_make_graph(nodes, graph_dist2, cfg.loopsize, allScans);
+      ret = hip_graph_slam(cfg.graph_backend, gr, sub, 1, cfg.epsilonLUM, max_dist_match2_LUM, cfg.comm, ty.invalid, ty.lum);
       j++; rounds++;
     } while (j < cfg.nrIt && ret > cfg.epsilonSLAM);
   };
@@ -220,7 +225,7 @@ int hip_match_graph6d_automatic(std::vector<ScanT*>& allScans, const HipSlamSett
     for (int i = 0; i < n; i++) {
       if (pool) {
         for (int j = i; j < n && j <= i + cfg.prefetch; j++) {
-          ScanT* s = allScans[j];
+          ScanT* s = allScans[j];      // (the global rounds and the loop closer use every scan's own tree: built ahead also with meta_icp)
           pool->submit((size_t)j, [s] { (void)s->hipResident(); (void)s->hipTree(); });
         }
         if (i > 0) pool->wait((size_t)i - 1);
@@ -231,7 +236,14 @@ int hip_match_graph6d_automatic(std::vector<ScanT*>& allScans, const HipSlamSett
       (void)allScans[i]->hipResident();
       if (cfg.icp.eP) allScans[i]->mergeCoordinatesWithRoboterPosition(allScans[i - 1]);
       unsigned int pairs = 0;
-      (void)hip_icp_match(allScans[i - 1], allScans[i], cfg.icp, &pairs);
+      if (cfg.meta_icp) {              // slam6D.cc:436-448
+        metas.push_back(allScans[i - 1]);
+        if (cfg.max_num_metascans > 0)
+          while (metas.size() > (size_t)cfg.max_num_metascans) metas.erase(metas.begin());
+        (void)hip_icp_match_metascan(metas, allScans[i], cfg.icp, &pairs);
+      } else {
+        (void)hip_icp_match(allScans[i - 1], allScans[i], cfg.icp, &pairs);
+      }
       if (loop_detection == 1) loop_detection = 2;
       for (int j = 0; j < i - cfg.loopsize; j++) {
         const double* a = allScans[j]->get_rPos();
@@ -250,7 +262,7 @@ int hip_match_graph6d_automatic(std::vector<ScanT*>& allScans, const HipSlamSett
           hip_elch_close_loop_euler(allScans, first, last, g, cfg.loop_icp, ty);
           g.push_back({first, last});
         }
-        if (cfg.graph_backend >= 0 && cfg.mdml > 0) global_rounds(i + 1);
+        if (cfg.graph_backend >= 0 && cfg.mdml > 0) global_rounds(i + 1, cldist2, cfg.mdml * cfg.mdml);
       }
     }
   } catch (...) {
@@ -262,7 +274,9 @@ int hip_match_graph6d_automatic(std::vector<ScanT*>& allScans, const HipSlamSett
     hip_elch_close_loop_euler(allScans, first, last, g, cfg.loop_icp, ty);
     g.push_back({first, last});
   }
-  if (cfg.graph_backend >= 0 && cfg.mdml > 0.0) global_rounds(n);
+  if (cfg.graph_backend >= 0 && cfg.mdml > 0.0) global_rounds(n, cldist2, cfg.mdml * cfg.mdml);
+  // slam6D.cc:535-547: set_mdmll(mdmll), then rounds on the graph of --graphDist
+  if (cfg.graph_backend >= 0 && cfg.mdmll > 0.0) global_rounds(n, cfg.graphDist * cfg.graphDist, cfg.mdmll * cfg.mdmll);
   return rounds;
 }
 

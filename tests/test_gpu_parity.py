@@ -532,6 +532,54 @@ def test_config1_metascan_dat(tdtk, orc, gpu, rnd, tmp_path):
     np.testing.assert_allclose(last[:16], S[1].get_transMat(), rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("meta,maxmeta", [(1, -1), (1, 1), (0, -1)])
+def test_config1_metascan_dat_through_the_cpp_glue(tdtk, gpu, tmp_path, meta, maxmeta):
+    """BASELINE configs[0] (`slam6D -m 500 -d 25.0 --metascan dat`) through the C++ binding's body: icp6D_hip::doICP =
+    hip_do_icp (adapters/icp_glue.h), whose meta branch (icp6D.cc:396-434) matches every scan against a MetaScan tree
+    built on the device over the scans before it (tdtk_tree_create_from_scans = KDtreeMetaManaged).  Executed by
+    adapters/harness/slam_glue_harness.cc on the bundled scans; poses, frame counts and iteration counts equal the Python
+    mirror's doICP -- which test_config1_metascan_dat pins to the oracle -- bit for bit.  Also max_num_metascans = 1 and
+    the plain sequential branch."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "adapters", "harness", "_bin", "slam_glue_harness")
+    if not os.path.exists(exe):
+        r = subprocess.run([os.path.join(os.path.dirname(HERE), "adapters", "harness", "build_glue.sh")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    pts = [_range_filter(z["scan%03d" % k], 500.0) for k in range(3)]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(np.int32(3).tobytes())
+        for k in range(3):
+            f.write(np.int32(len(pts[k])).tobytes())
+            f.write(np.ascontiguousarray(z["pose%03d" % k], dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(pts[k], dtype=np.float64).tobytes())
+    r = subprocess.run([exe, "doicp", fin, fout, str(meta), str(maxmeta), "25.0", "50", "1e-5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SLAM GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
+    out = np.fromfile(fout, dtype=np.uint8)
+    tm_cpp = np.frombuffer(out[:3 * 128].tobytes(), dtype=np.float64).reshape(3, 16)
+    tail = np.frombuffer(out[3 * 128:].tobytes(), dtype=np.int32)
+    S = [tdtk.Scan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], pts[k]) for k in range(3)]
+    tdtk.Scan.allScans = S
+    try:
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 50, quiet=True, meta=bool(meta), rnd=1, epsilonICP=1e-5, max_num_metascans=maxmeta)
+        its = []
+        orig_match = icp.match
+
+        def rec(a, b, pm=0):
+            its.append(orig_match(a, b, pm))
+            return its[-1]
+        icp.match = rec
+        icp.doICP(S)
+        tm_py = np.stack([s.transMat for s in S])
+        assert tm_py.tobytes() == tm_cpp.tobytes(), float(np.abs(tm_py - tm_cpp).max())
+        assert [len(s.frames) for s in S] == tail[:3].tolist()
+        assert its == tail[3:5].tolist()
+        assert np.abs(tm_cpp[2] - tdtk.EulerToMatrix4(z["pose002"][:3], z["pose002"][3:])).max() > 1e-3      # it matched something
+    finally:
+        tdtk.Scan.allScans = []
+
+
 def test_gapx6d_links_and_iterations(tdtk, orc, gpu):
     """-G 4 (gapx6D): per-link genBArotForLinkedPair blocks (literal formulas incl. the
     `p1x*p2x + p1y + p2y` terms) and two doGraphSlam6D iterations vs the oracle restatement."""
@@ -1676,8 +1724,10 @@ def test_icp_glue_executes(gpu):
     assert r.returncode == 0 and "ICP GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_slam_glue_executes(tdtk, gpu, tmp_path):
-    """adapters/slam6d_glue.h executed (adapters/harness/slam_glue_harness.cc): matchGraph6Dautomatic in C++ on the C ABI
+@pytest.mark.parametrize("variant", [0, 1])
+def test_slam_glue_executes(tdtk, gpu, tmp_path, variant):
+    """(variant 1, round 4: meta_icp with max_num_metascans = 3, slam6D.cc:436-448, and the closing -DlastSLAM pass,
+    slam6D.cc:535-547.)  adapters/slam6d_glue.h executed (adapters/harness/slam_glue_harness.cc): matchGraph6Dautomatic in C++ on the C ABI
     -- sequential ICP with scans prepared ahead, loop detection, ELCH loop closing (batched covariance passes, balancer,
     MetaScan-against-MetaScan match), global lum6DEuler rounds through graph_slam_glue.h -- ends, on the same scans, in
     the poses of the Python mirror (matchGraph6Dautomatic + elch6Deuler + Graph + the library's graph iteration), bit
@@ -1691,7 +1741,7 @@ def test_slam_glue_executes(tdtk, gpu, tmp_path):
         r = subprocess.run([os.path.join(os.path.dirname(HERE), "adapters", "harness", "build_glue.sh")], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    r = subprocess.run([exe, fin, fout, "15", "30000", "3"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, fin, fout, "15", "30000", "3", str(variant)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "SLAM GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
     raw = np.fromfile(fin, dtype=np.uint8)
     nscans, npts = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
@@ -1706,17 +1756,23 @@ def test_slam_glue_executes(tdtk, gpu, tmp_path):
     tdtk.Scan.allScans = S
     try:
         class Relax:                # the -G 1 plug point served by the library's own iteration, like graph_slam_glue.h
+            mdm2 = 25.0 ** 2
+
+            def set_mdmll(self, mdmll):
+                self.mdm2 = mdmll * mdmll
+
             def doGraphSlam6D(self, gr, allScans, nrIt):
                 ret, it = float("inf"), 0
                 while it < nrIt and ret > 0.5:
-                    ret = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, allScans, 25.0 ** 2, None)
+                    ret = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, allScans, self.mdm2, None)
                     it += 1
                 return ret
         mini = tdtk.icp6D_QUAT(True)
         icp = tdtk.icp6D(mini, 25.0, 30, quiet=True, epsilonICP=1e-5)
         loop = tdtk.elch6Deuler(True, mini, 25.0, 30, epsilonICP=1e-5)
-        rounds = tdtk.matchGraph6Dautomatic(90.0, 6, S, icp, False, Relax(), 3, 0.05, 25.0, eP=True, prefetch=True,
-                                            my_loopSlam6D=loop)
+        extra = dict(max_num_metascans=3, mdmll=15.0, graphDist=140.0) if variant == 1 else {}
+        rounds = tdtk.matchGraph6Dautomatic(90.0, 6, S, icp, variant == 1, Relax(), 3, 0.05, 25.0, eP=True, prefetch=True,
+                                            my_loopSlam6D=loop, **extra)
         assert rounds == rounds_cpp
         tm_py = np.stack([s.transMat for s in S])
         assert tm_py.tobytes() == tm_cpp.tobytes(), float(np.abs(tm_py - tm_cpp).max())

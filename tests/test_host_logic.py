@@ -373,6 +373,42 @@ def test_adapter_compiles_against_reference_headers(tmp_path):
     assert "tdtk_normals_apx_knn" in subprocess.run(["nm", "-C", str(obj2)], capture_output=True, text=True).stdout
 
 
+def test_class_shells_pass_a_syntax_check(tmp_path):
+    """The four class shells that adapt the reference's classes to the executed glue -- icp6D_hip.h, graphSlam6D_hip.h,
+    slam6D_hip.h, normals_hip.h -- cannot be compiled against the reference's real headers here (scan.h -> Boost,
+    graphSlam6D.h -> SuiteSparse).  BOUNDARY TEST INFRASTRUCTURE, not an oracle: adapters/harness/stubs/slam6d/ declares
+    the reference classes they touch (names, signatures, member names and types as in the reference's headers; no bodies),
+    and `g++ -fsyntax-only` runs over a TU that instantiates every shell.  Catches what a maintainer's first compile
+    would: wrong argument counts / types, members that do not exist, overrides that do not override."""
+    inc = tmp_path / "slam6d"
+    inc.mkdir()
+    stubs = os.path.join(ROOT, "adapters", "harness", "stubs", "slam6d")
+    for fn in os.listdir(stubs):
+        if fn.endswith(".h"):
+            (inc / fn).write_text(open(os.path.join(stubs, fn)).read())
+    for fn in ("hip_search_tree.h", "icp_glue.h", "graph_slam_glue.h", "slam6d_glue.h", "icp6D_hip.h", "graphSlam6D_hip.h",
+               "slam6D_hip.h", "normals_hip.h"):
+        (inc / fn).write_text(open(os.path.join(ROOT, "adapters", fn)).read())
+    src = tmp_path / "shells.cc"
+    src.write_text(
+        '#include "slam6d/slam6D_hip.h"\n#include "slam6d/normals_hip.h"\n'
+        "struct S : Scan { DataPointer get(const std::string&) override; void addFrame(AlgoType) override; };\n"
+        "int use(icp6Dminimizer* m, std::vector<Scan*>& scans, Graph& g, tdtk_comm* comm, std::vector<Point>& n, const double* r) {\n"
+        "  icp6D_hip icp(m, 25.0, 50, true, true, 1, true, -1, 1e-7, HipKD, false, false, 2);\n"
+        "  icp6D* base = &icp;\n"
+        "  base->doICP(scans);\n"
+        "  int it = base->match(scans[0], scans[1]);\n"
+        "  graphSlam6D_hip gs(TDTK_GRAPH_LUMEULER, m, 25.0, 25.0, 50, true, false, 1, true, -1, 1e-7, HipKD, 0.5, comm);\n"
+        "  graphSlam6D* gb = &gs;\n"
+        "  double ret = gb->doGraphSlam6D(g, scans, 1);\n"
+        "  it += matchGraph6Dautomatic_hip(500.0, 20, scans, &icp, &icp, TDTK_GRAPH_LUMEULER, 50, 0.5, 25.0, 0.5, 3, comm, true, 3, 15.0, 140.0);\n"
+        "  calculateNormalsApxKNN_hip(n, n, 10, r, 1.0);\n"
+        "  return it + (int)ret;\n}\n")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + str(tmp_path), "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
 def test_reference_patch_applies(tmp_path):
     """adapters/reference.patch -- the edits the reference itself needs (enum value, `case HipKD:`, the two Scan
     additions, the four icp6D construction sites, the CMake option) -- applies cleanly to the checkout's files, and
