@@ -102,6 +102,7 @@ struct Lane {
   bool owns = true;     // lane 0 runs on the context's own stream
   QueueCtr qc;
   DevBuf kpos, part, ovf_m2, ovf_ref;
+  DevBuf moved;      // batched link passes: this link's own copy of a scan another link of the launch is moving (lazy moves)
   ~Lane() { if (s && owns) (void)hipStreamDestroy(s); }
 };
 
@@ -2283,6 +2284,21 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
     }
   }
   const int ngroups = (nlinks + G - 1) / G;
+  // Launch order: links that search the SAME tree next to each other (a chain link i -> i+1 and the loop closures out
+  // of scan i), so that the tree one of them has pulled into the L2s / the Infinity Cache is still there for the next;
+  // otherwise the caller's order.  The workgroups of a launch are dispatched in table order, so position p of the table
+  // is what runs p-th; every link still writes its own row of d_out (TDTK_LINK_ORDER=0: the caller's order).
+  std::vector<int> ord(nlinks);
+  for (int i = 0; i < nlinks; i++) ord[i] = i;
+  {
+    static const bool keep = [] { const char* e = getenv("TDTK_LINK_ORDER"); return e && e[0] == '0'; }();
+    if (!keep) {
+      std::map<const tdtk_tree*, int> seen;
+      std::vector<int> key(nlinks);
+      for (int i = 0; i < nlinks; i++) key[i] = seen.emplace(first[i], i).first->second;   // first link that uses this tree
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
+    }
+  }
   // Lazy scan moves (tdtk_scan::pending): the persistent-lane launch carries them out itself; the small-batch kernels do
   // not, their scans are moved first.  Everything that can fail is done before the first scan's state changes.
   const bool lazy = search_multi_class(maxN) == 20;
@@ -2290,6 +2306,23 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   if (!lazy) {
     if ((rc = scans_settle(c, second, nlinks))) return rc;
   } else {
+    {   // a chain longer than the launch applies itself (a scan no link of this rank has read for rounds): one pass now
+      std::vector<const tdtk_scan*> longc;
+      for (int i = 0; i < nlinks; i++)
+        if (second[i]->pending.size() > (size_t)SEARCH_LAZY_MAX) longc.push_back(second[i]);
+      if (!longc.empty() && (rc = scans_settle(c, longc.data(), (int)longc.size()))) return rc;
+    }
+    {   // a copy of its own for every reader of a moving scan but the first of its launch (which gets the spare arrays)
+      std::map<const tdtk_scan*, int> first_in;      // scan -> the launch that moves it
+      for (int p = 0; p < nlinks; p++) {
+        const tdtk_scan* sc = second[ord[p]];
+        if (sc->pending.empty()) continue;
+        const int gi = p / G;
+        const auto it = first_in.find(sc);
+        if (it == first_in.end()) first_in[sc] = gi;
+        else if (it->second == gi && (rc = c->slots[p - gi * G]->moved.ensure(3 * maxN * sizeof(double)))) return rc;
+      }
+    }
     for (int i = 0; i < nlinks; i++) {
       tdtk_scan* sc = second[i];
       if (sc->pending.empty()) continue;
@@ -2321,21 +2354,6 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   uint32_t* hab = reinterpret_cast<uint32_t*>(tab.data() + o_ab);
   std::vector<uint32_t> s_total(ngroups), a_total(ngroups);
   if (c->counting) { for (int i = 0; i < nlinks; i++) c->counted_queries += second[i]->N; }
-  // Launch order: links that search the SAME tree next to each other (a chain link i -> i+1 and the loop closures out
-  // of scan i), so that the tree one of them has pulled into the L2s / the Infinity Cache is still there for the next;
-  // otherwise the caller's order.  The workgroups of a launch are dispatched in table order, so position p of the table
-  // is what runs p-th; every link still writes its own row of d_out (TDTK_LINK_ORDER=0: the caller's order).
-  std::vector<int> ord(nlinks);
-  for (int i = 0; i < nlinks; i++) ord[i] = i;
-  {
-    static const bool keep = [] { const char* e = getenv("TDTK_LINK_ORDER"); return e && e[0] == '0'; }();
-    if (!keep) {
-      std::map<const tdtk_tree*, int> seen;
-      std::vector<int> key(nlinks);
-      for (int i = 0; i < nlinks; i++) key[i] = seen.emplace(first[i], i).first->second;   // first link that uses this tree
-      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
-    }
-  }
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G);
     uint32_t sb = 0, ab = 0;
@@ -2374,15 +2392,18 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       }
       if (fuse_links) { sa.fuse = 5; sa.A = A; sa.partials = sl->part.as<double>(); }
       if (mv != moving.end()) {
+        // the link's waves move their slabs first: out of the scan's arrays into the link's own copy (SearchArgs::moves)
         sa.moves = dmv + mv->second.first; sa.nmoves = mv->second.second;
-        if (owner) { sa.wx = data->ax; sa.wy = data->ay; sa.wz = data->az; sa.nx = data->nx; sa.ny = data->ny; sa.nz = data->nz; }
+        sa.sx = data->x; sa.sy = data->y; sa.sz = data->z;
+        if (owner) { sa.x = data->ax; sa.y = data->ay; sa.z = data->az; sa.nx = data->nx; sa.ny = data->ny; sa.nz = data->nz; }
+        else { double* m = sl->moved.as<double>(); sa.x = m; sa.y = m + maxN; sa.z = m + 2 * maxN; }
       }
       hsb[i + gi] = sb; sb += nb;
       hsa[i] = sa;
       AccumArgs aa{};
       aa.T = t->dev;
       aa.x = data->x; aa.y = data->y; aa.z = data->z;
-      if (mv != moving.end()) { aa.x = data->ax; aa.y = data->ay; aa.z = data->az; }   // k_accum_multi runs behind the search launch
+      if (mv != moving.end()) { aa.x = sa.x; aa.y = sa.y; aa.z = sa.z; }   // (k_accum_multi runs behind the search launch)
       aa.kpos = sa.kpos; aa.n = data->N; aa.A = A; aa.inv = inv;
       for (int k = 0; k < 3; k++) aa.shift[k] = shifts[3 * li + k];
       aa.partials = sl->part.as<double>();

@@ -10,6 +10,8 @@ struct Mat4 {
   double m[16];
 };
 
+constexpr int SEARCH_LAZY_MAX = 8;     // longest chain of queued scan moves a search launch carries out itself (kernels.hip: LAZY_MAX)
+
 struct TreeDev {
   const KdHot* hot;           // compact hot records (fp32 box), same indexing as nodes
   const KdFat* fat;           // a node's hot record together with its children's: two levels per round trip (big batches)
@@ -60,15 +62,16 @@ struct SearchArgs {
   Mat4 A;
   double shift[3];
   double* partials;
-  // Lazy scan moves (several-links launch only, k_search_refill_multi): the `nmoves` in-place transforms queued on this
-  // scan since it was last read (Scan::transformToEuler of the graph-SLAM rounds since, two per round) are applied in
-  // order, in registers, where a lane takes a query -- the arithmetic of k_transform_chain, bit for bit.  The ONE link of
-  // the launch that owns the scan's update also stores the moved point into the scan's spare arrays (wx, wy, wz; the
-  // host swaps them in behind the launch) and moves the normals in place; every other link of the launch that reads
-  // the scan reads the same unmoved arrays and stores nothing.
+  // Lazy scan moves (several-links launch only, k_search_refill_multi): nmoves != 0 -- before it searches, every wave moves
+  // its own slab: the unmoved points from sx / sy / sz, the `nmoves` in-place transforms queued on the scan since it was
+  // last read (Scan::transformToEuler of the graph-SLAM rounds since, two per round) applied in order -- the arithmetic
+  // of k_transform_chain_batch, bit for bit --, the result stored into x / y / z above, which are then this link's own:
+  // the scan's spare arrays for the ONE link of the launch that owns the scan's update (the host swaps them in behind
+  // the launch; that link also gets nx / ny / nz and moves the normals in place), a scratch copy for any other link of
+  // the launch that reads the same scan.
+  const double *sx, *sy, *sz;
   const Mat4* moves;
-  int nmoves;
-  double *wx, *wy, *wz;
+  int nmoves;        // <= SEARCH_LAZY_MAX
 };
 
 // internal bit beside the public TDTK_WANT_* ones: no centroid / cross-covariance columns (see k_accum)

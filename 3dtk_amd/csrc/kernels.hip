@@ -33,6 +33,7 @@
 namespace tdtk {
 
 #define WAVE 64
+#define LAZY_MAX 8      // longest chain of queued scan moves a search launch applies itself (SearchArgs::moves)
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -1409,6 +1410,15 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     const uint32_t wid0 = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
     if (wid0 < WTRACE_MAX) g_wtrace[3 * wid0] = wall_clock64();
   }
+  // lazy scan moves: the chain (at most LAZY_MAX matrices, the host sees to that) is staged in LDS once per workgroup
+  __shared__ double lds_mv[LAZY ? LAZY_MAX * 16 : 1];
+  if constexpr (LAZY) {
+    if (a.nmoves) {
+      const double* gm = reinterpret_cast<const double*>(a.moves);
+      for (int k = threadIdx.x; k < a.nmoves * 16; k += BLOCK) lds_mv[k] = gm[k];
+      __syncthreads();
+    }
+  }
   LaneStackQ<BLOCK, SD> st;
   st.l_e = &lds_stk[0][threadIdx.x];
   st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
@@ -1527,6 +1537,70 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     }
   }
 
+  if constexpr (LAZY && !DYN) {
+    if (a.nmoves) {
+      // Lazy scan moves (SearchArgs::moves): before it searches, the wave moves ITS slab -- the unmoved points from
+      // sx / sy / sz, the queued transforms in order (the arithmetic of k_transform_chain_batch: dev_xf3_inplace per
+      // matrix), the result into x / y / z, which are this link's own (the scan's spare arrays for the link that owns the
+      // update, a scratch copy for any other link of the launch that reads the scan).  Consecutive lanes, consecutive
+      // queries, every lane busy: ten trips for a slab of 640.  Everything below reads x / y / z, as without moves; a
+      // slab is a whole number of 128-byte lines and nobody else touches it, so a fence of workgroup scope is all the
+      // wave needs to see its own stores (like the sums pass further down).
+      // (Applied where a lane takes a query instead -- matrices through the scalar cache at every hand-out, 8-byte
+      // stores in cost order -- the launch of 84 links took 10.3 ms against 9.5 + 0.54 for the pass it replaces.)
+      // (five trips' loads are issued before the first of them is used: two memory round trips per slab instead of ten --
+      // one trip at a time the pre-pass cost the 84-link launch 0.6 ms, as much as the pass it replaces)
+      const uint32_t slab0 = (uint32_t)a.qpw, sub0 = (uint32_t)sub;
+      const bool nrm = a.nx != nullptr;          // (set for the owner of the update only: normals move in place)
+      constexpr int MT = 5;
+      for (uint32_t j0 = 0; j0 < slab0; j0 += MT * WAVE) {
+        size_t q[MT];
+        bool ok[MT];
+        double px[MT], py[MT], pz[MT];
+#pragma unroll
+        for (int u = 0; u < MT; u++) {
+          uint32_t j = j0 + (uint32_t)u * WAVE + lane, ph = 0;
+          const bool in = j < slab0;
+          while (j >= sub0 && in) { j -= sub0; ph++; }
+          q[u] = reg0 + (size_t)ph * pstride + j;
+          ok[u] = in && q[u] < a.n;
+          px[u] = py[u] = pz[u] = 0.0;
+          if (ok[u]) { px[u] = a.sx[q[u]]; py[u] = a.sy[q[u]]; pz[u] = a.sz[q[u]]; }
+        }
+        for (int k = 0; k < a.nmoves; k++) {
+          const double* m = lds_mv + 16 * k;
+          const double m0 = m[0], m1 = m[1], m2 = m[2], m4 = m[4], m5 = m[5], m6 = m[6], m8 = m[8], m9 = m[9], m10 = m[10],
+                       m12 = m[12], m13 = m[13], m14 = m[14];
+#pragma unroll
+          for (int u = 0; u < MT; u++) {
+            const double xn = px[u] * m0 + py[u] * m4 + pz[u] * m8;      // dev_xf3_inplace
+            const double yn = px[u] * m1 + py[u] * m5 + pz[u] * m9;
+            const double zn = px[u] * m2 + py[u] * m6 + pz[u] * m10;
+            px[u] = xn + m12; py[u] = yn + m13; pz[u] = zn + m14;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < MT; u++)
+          if (ok[u]) { a.x[q[u]] = px[u]; a.y[q[u]] = py[u]; a.z[q[u]] = pz[u]; }
+        if (nrm) {
+#pragma unroll
+          for (int u = 0; u < MT; u++) {
+            if (!ok[u]) continue;
+            double ux = a.nx[q[u]], uy = a.ny[q[u]], uz = a.nz[q[u]];
+            for (int k = 0; k < a.nmoves; k++) {
+              const double* m = lds_mv + 16 * k;
+              const double an = ux * m[0] + uy * m[1] + uz * m[2];       // dev_xf3normal
+              const double bn = ux * m[4] + uy * m[5] + uz * m[6];
+              const double cn = ux * m[8] + uy * m[9] + uz * m[10];
+              ux = an; uy = bn; uz = cn;
+            }
+            a.nx[q[u]] = ux; a.ny[q[u]] = uy; a.nz[q[u]] = uz;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+  }
   uint32_t cur = REF_DONE;
   double best = 0.0, qx = 0, qy = 0, qz = 0;
   int bk = -1;
@@ -1654,24 +1728,6 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         const int kp_prev = a.warm ? gload<int>(reinterpret_cast<const char*>(a_kpos), (uint32_t)mine << 2) : -1;
         double tx = gload<double>(reinterpret_cast<const char*>(a.x), m8), ty = gload<double>(reinterpret_cast<const char*>(a.y), m8),
                tz = gload<double>(reinterpret_cast<const char*>(a.z), m8);
-        if constexpr (LAZY) if (a.nmoves) {
-          // the moves queued on this scan since it was last read (SearchArgs::moves): applied here, in order, instead of
-          // by a pass of their own over every scan of the graph between two rounds
-          const bool owner = a.wx != nullptr;
-          double px = 0, py = 0, pz = 0;
-          if (owner && a.nx) { px = a.nx[mine]; py = a.ny[mine]; pz = a.nz[mine]; }
-          for (int k = 0; k < a.nmoves; k++) {
-            Mat4 Mv;
-            load_move(a.moves, k, Mv);
-            dev_xf3_inplace(Mv, tx, ty, tz);
-            if (owner && a.nx) dev_xf3normal(Mv, px, py, pz);
-          }
-          if (owner) {
-            gstore<double>(reinterpret_cast<char*>(a.wx), m8, tx); gstore<double>(reinterpret_cast<char*>(a.wy), m8, ty);
-            gstore<double>(reinterpret_cast<char*>(a.wz), m8, tz);
-            if (a.nx) { a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz; }
-          }
-        }
         if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
           dev_xf3_inplace(a.pending, tx, ty, tz);
           gstore<double>(reinterpret_cast<char*>(a.x), m8, tx); gstore<double>(reinterpret_cast<char*>(a.y), m8, ty);
@@ -1974,18 +2030,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           if (kk[h + u] >= 0) {
             const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)kk[h + u] << 5));
             cx[u] = c.x; cy[u] = c.y; cz[u] = c.z;
-            // (lazy moves: the owner reads back what its own wave stored -- visible behind the fence above, like the
-            // hits --, everybody else moves the point again in registers)
-            const bool moved_copy = LAZY && a.nmoves && a.wx;
-            tx[u] = (moved_copy ? a.wx : a.x)[qq[h + u]]; ty[u] = (moved_copy ? a.wy : a.y)[qq[h + u]]; tz[u] = (moved_copy ? a.wz : a.z)[qq[h + u]];
-          }
-        }
-        if constexpr (LAZY) if (a.nmoves && !a.wx) {
-          for (int k = 0; k < a.nmoves; k++) {
-            Mat4 Mv;
-            load_move(a.moves, k, Mv);
-#pragma unroll
-            for (int u = 0; u < 2; u++) dev_xf3_inplace(Mv, tx[u], ty[u], tz[u]);
+            tx[u] = a.x[qq[h + u]]; ty[u] = a.y[qq[h + u]]; tz[u] = a.z[qq[h + u]];
           }
         }
 #pragma unroll

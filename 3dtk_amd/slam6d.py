@@ -76,38 +76,20 @@ def Matrix4ToEuler(alignxf):
 
 
 def QuatToMatrix4(quat, t=None):
-    """globals.icc:988-1022"""
-    q11, q22, q33 = quat[1] * quat[1], quat[2] * quat[2], quat[3] * quat[3]
-    q03, q13, q23 = quat[0] * quat[3], quat[1] * quat[3], quat[2] * quat[3]
-    q02, q12, q01 = quat[0] * quat[2], quat[1] * quat[2], quat[0] * quat[1]
-    m = np.zeros(16)
-    m[0] = 1 - 2 * (q22 + q33); m[5] = 1 - 2 * (q11 + q33); m[10] = 1 - 2 * (q11 + q22)
-    m[4] = 2.0 * (q12 - q03); m[1] = 2.0 * (q12 + q03)
-    m[8] = 2.0 * (q13 + q02); m[2] = 2.0 * (q13 - q02)
-    m[9] = 2.0 * (q23 - q01); m[6] = 2.0 * (q23 + q01)
-    if t is not None:
-        m[12:15] = t
-    m[15] = 1.0
-    return m
+    """globals.icc:988-1022 (the library's host restatement, like M4inv / MMult: the C++ glue calls the same code)"""
+    q = f64(quat, 4)
+    tt = f64(t, 3) if t is not None else np.zeros(3)
+    out = np.empty(16)
+    lib().tdtk_host_quat_to_matrix4(dptr(q), dptr(tt), dptr(out))
+    return out
 
 
 def Matrix4ToQuat(mat):
-    """globals.icc:1032-1075 -> (quat[4] normalised, t[3])"""
-    T = 1 + mat[0] + mat[5] + mat[10]
-    if T > 0.00000001:
-        S = math.sqrt(T) * 2
-        X = (mat[9] - mat[6]) / S; Y = (mat[2] - mat[8]) / S; Z = (mat[4] - mat[1]) / S; W = 0.25 * S
-    elif mat[0] > mat[5] and mat[0] > mat[10]:
-        S = math.sqrt(1.0 + mat[0] - mat[5] - mat[10]) * 2
-        X = 0.25 * S; Y = (mat[4] + mat[1]) / S; Z = (mat[2] + mat[8]) / S; W = (mat[9] - mat[6]) / S
-    elif mat[5] > mat[10]:
-        S = math.sqrt(1.0 + mat[5] - mat[0] - mat[10]) * 2
-        X = (mat[4] + mat[1]) / S; Y = 0.25 * S; Z = (mat[9] + mat[6]) / S; W = (mat[2] - mat[8]) / S
-    else:
-        S = math.sqrt(1.0 + mat[10] - mat[0] - mat[5]) * 2
-        X = (mat[2] + mat[8]) / S; Y = (mat[9] + mat[6]) / S; Z = 0.25 * S; W = (mat[4] - mat[1]) / S
-    q = np.array([W, -X, -Y, -Z])
-    return q / math.sqrt(float(q @ q)), np.array(mat[12:15], dtype=np.float64)
+    """globals.icc:1032-1075 -> (quat[4] normalised, t[3]) (the library's host restatement)"""
+    m = f64(mat, 16)
+    q, t = np.empty(4), np.empty(3)
+    lib().tdtk_host_matrix4_to_quat(dptr(m), dptr(q), dptr(t))
+    return q, t
 
 
 def transform_many(scans, A1, A2=None, type="LUM"):

@@ -7,7 +7,8 @@
 //
 // usage: slam_glue_harness <in.bin> <out.bin> [nscans] [npts] [prefetch] [variant]
 // variant 0: sequential ICP against the predecessor; 1: meta_icp with max_num_metascans = 3 (slam6D.cc:436-448) and the
-// closing -DlastSLAM pass (mdmll = 15, graphDist = 140; slam6D.cc:535-547)
+// closing -DlastSLAM pass (mdmll = 15, graphDist = 140; slam6D.cc:535-547); 2 / 3 / 4: like 0 with the loop closed by
+// elch6Dquat / elch6DunitQuat / elch6Dslerp (-L 2 / 3 / 4) instead of elch6Deuler
 // Writes the scans it made to <in.bin> (int32 nscans, int32 npts, then per scan rPos[3], rPosTheta[3], xyz[npts][3]) and
 // what it ended with to <out.bin> (per scan transMat[16], then one int32 frame count per scan, int32 rounds), so that
 // tests/test_gpu_parity.py::test_slam_glue_executes can run the Python mirror on the same scans and compare bit for bit.
@@ -120,6 +121,15 @@ struct MiniScan {
     tdtk_host_euler_to_matrix4(rP, rPT, M);
     transform(M, type, islum);
   }
+  void get_rPosQuat(double q[4]) const { double t[3]; tdtk_host_matrix4_to_quat(transMat, q, t); }     // scan.cc:886
+  void transformToQuat(const double rP[3], const double rPQ[4], int type, int islum)                     // scan.cc:1093-1104
+  {
+    double tinv[16], M[16];
+    tdtk_host_m4inv(transMat, tinv);
+    transform(tinv, T_INVALID, -1);
+    tdtk_host_quat_to_matrix4(rPQ, rP, M);
+    transform(M, type, islum);
+  }
   void mergeCoordinatesWithRoboterPosition(MiniScan* prev)
   {
     double inv[16], delta[16];
@@ -183,6 +193,7 @@ static int run(std::vector<MiniScan>& scans, int prefetch, int* rounds)
   cfg.icp = {TDTK_ALGO_QUAT, 0, 30, 25.0 * 25.0, 1e-5, true, -1, true, T_ICP};
   cfg.loop_icp = {TDTK_ALGO_QUAT, 0, 30, 25.0 * 25.0, 1e-5, true, -1, true, T_ICP};
   cfg.use_elch = true;
+  cfg.elch_variant = g_variant >= 2 ? g_variant : 1;
   cfg.graph_backend = TDTK_GRAPH_LUMEULER;
   cfg.cldist = 90.0; cfg.mdml = 25.0; cfg.epsilonSLAM = 0.05; cfg.epsilonLUM = 0.5;
   cfg.loopsize = 6; cfg.nrIt = 3; cfg.prefetch = prefetch; cfg.comm = nullptr;

@@ -14,6 +14,7 @@ public:
   virtual ~Scan();
   const double* get_rPos() const;
   const double* get_rPosTheta() const;
+  const double* get_rPosQuat() const;
   const double* get_transMat() const;
   const double* get_transMatOrg() const;
   const double* getDAlign() const;
@@ -24,6 +25,7 @@ public:
   void mergeCoordinatesWithRoboterPosition(Scan* prevScan);
   void transform(const double alignxf[16], const AlgoType type, int islum = 0);
   void transformToEuler(double rP[3], double rPT[3], const AlgoType type, int islum = 0);
+  void transformToQuat(double rP[3], double rPQ[4], const AlgoType type, int islum = 0);
   // adapters/reference.patch
   void transformMatrixAndFrames(const double alignxf[16], const AlgoType type, int islum);
   tdtk_scan* hipResident();

@@ -3,7 +3,7 @@
 // slam6d/slam6d_glue.h: sequential ICP with the next scans prepared ahead, loop detection, -L 1 loop closing with every
 // covariance pass of the loop graph in one batched call and the MetaScan match on the device, -G 1..4 rounds through
 // graph_slam_glue.h.  Call matchGraph6Dautomatic_hip where slam6D.cc calls matchGraph6Dautomatic when -t HipKD is
-// selected and the run is one the glue serves (-L 0 or 1, rnd <= 1; meta_icp and the -DlastSLAM pass included since round 4);
+// selected and the run is one the glue serves (-L 0 .. 4, rnd <= 1; meta_icp and the -DlastSLAM pass included since round 4);
 // otherwise keep the reference's call.
 //
 // The body lives in slam6d/slam6d_glue.h, templated on the scan type: that header is compiled, linked and EXECUTED on
@@ -37,6 +37,14 @@ struct HipSlamScanView {
     s->transformToEuler(p, t, (Scan::AlgoType)type, islum);
   }
   void mergeCoordinatesWithRoboterPosition(HipSlamScanView* prev) { s->mergeCoordinatesWithRoboterPosition(prev->s); }
+  // -L 2 .. 4 (the loop closers with quaternion poses)
+  void get_rPosQuat(double q[4]) const { for (int k = 0; k < 4; k++) q[k] = s->get_rPosQuat()[k]; }
+  void transformToQuat(const double rP[3], const double rPQ[4], int type, int islum)
+  {
+    double p[3] = {rP[0], rP[1], rP[2]}, q[4] = {rPQ[0], rPQ[1], rPQ[2], rPQ[3]};
+    s->transformToQuat(p, q, (Scan::AlgoType)type, islum);
+  }
+  void transform(const double alignxf[16], int type, int islum) { s->transform(alignxf, (Scan::AlgoType)type, islum); }
   // the frames a MetaScan's transform writes for islum == 0 (scan.cc:962-975): members get `type`, the scans before the
   // first member ICPINACTIVE, the others INVALID
   static void metaFrames(const std::vector<HipSlamScanView*>& members, int type)
@@ -56,7 +64,7 @@ static inline int matchGraph6Dautomatic_hip(double cldist, int loopsize, std::ve
                                             icp6D_hip* loop_icp6D /* 0: no -L */, int backend, int nrIt, double epsilonSLAM,
                                             double mdml, double epsilonLUM, int prefetch = 3, tdtk_comm* comm = 0,
                                             bool meta_icp = false, int max_num_metascans = -1, double mdmll = -1.0,
-                                            double graphDist = 0.0)
+                                            double graphDist = 0.0, int elch_variant /* the -L id */ = 1)
 {
   std::vector<HipSlamScanView> views(allScans.size());
   std::vector<HipSlamScanView*> ptrs(allScans.size());
@@ -66,6 +74,7 @@ static inline int matchGraph6Dautomatic_hip(double cldist, int loopsize, std::ve
   cfg.icp = my_icp6D->settings(CLOSEST_POINT);
   cfg.loop_icp = loop_icp6D ? loop_icp6D->settings(CLOSEST_POINT) : cfg.icp;
   cfg.use_elch = loop_icp6D != 0;
+  cfg.elch_variant = elch_variant;
   cfg.graph_backend = backend;
   cfg.cldist = cldist; cfg.mdml = mdml; cfg.epsilonSLAM = epsilonSLAM; cfg.epsilonLUM = epsilonLUM;
   cfg.loopsize = loopsize; cfg.nrIt = nrIt; cfg.prefetch = prefetch; cfg.comm = comm;

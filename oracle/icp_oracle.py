@@ -909,6 +909,139 @@ def elch_close_loop(scans, first, last, edges, algo, max_dist_match2, max_it, ep
 
 
 # ---------------------------------------------------------------------------------------
+# ELCH loop closing with quaternion poses, -L 2 .. 4: elch6Dquat::close_loop (src/slam6d/elch6Dquat.cc:44-148),
+# elch6DunitQuat::close_loop (src/slam6d/elch6DunitQuat.cc:45-199), elch6Dslerp::close_loop
+# (src/slam6d/elch6Dslerp.cc:44-184).  PARITY UNPINNED, like -L 1: the three TUs need Boost.Graph and scan.h -> Boost;
+# restated by reading, on top of covariance_quat (below), graph_balancer and match_meta_data (above).
+# ---------------------------------------------------------------------------------------
+def qmult(q1, q2):
+    """QMult (globals.icc:1112-1117): q1 * q2, (w, x, y, z)"""
+    return np.array([q1[0] * q2[0] - q1[1] * q2[1] - q1[2] * q2[2] - q1[3] * q2[3],
+                     q1[0] * q2[1] + q1[1] * q2[0] + q1[2] * q2[3] - q1[3] * q2[2],
+                     q1[0] * q2[2] - q1[1] * q2[3] + q1[2] * q2[0] + q1[3] * q2[1],
+                     q1[0] * q2[3] + q1[1] * q2[2] - q1[2] * q2[1] + q1[3] * q2[0]])
+
+
+def normalize4(q):
+    """Normalize4 (globals.icc:267-275)"""
+    q = np.array(q, dtype=np.float64)
+    norm = math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    return q / norm
+
+
+def slerp(qa, qb, t):
+    """slerp (globals.icc:1123-1166)"""
+    cos_half = qa[0] * qb[0] + qa[1] * qb[1] + qa[2] * qb[2] + qa[3] * qb[3]
+    if abs(cos_half) >= 1.0:
+        return np.array(qa, dtype=np.float64)
+    half = math.acos(cos_half)
+    sin_half = math.sqrt(1.0 - cos_half * cos_half)
+    if abs(sin_half) < 0.001:
+        return normalize4([qa[k] * 0.5 + qb[k] * 0.5 for k in range(4)])
+    ratio_a = math.sin((1 - t) * half) / sin_half
+    ratio_b = math.sin(t * half) / sin_half
+    return normalize4([qa[k] * ratio_a + qb[k] * ratio_b for k in range(4)])
+
+
+def _elch_quat_weights(scans, edges, first, last, maxdist2, combine):
+    """The part the three share: one covarianceQuat per edge, C = C.i(), |diag| as edge weights -- seven graphs
+    (elch6Dquat.cc:52-66), or three + the sum of the four quaternion entries (elch6DunitQuat.cc:52-69,
+    elch6Dslerp.cc:50-84; `abs` there is the floating-point overload) -- and a graph_balancer run per graph."""
+    n = max(max(a, b) for a, b in edges) + 1
+    nw = 4 if combine else 7
+    wts = np.empty((nw, len(edges)))
+    for e, (a, b) in enumerate(edges):
+        Cm = covariance_quat(scans[a], scans[b], maxdist2)[0]
+        d = np.abs(np.diag(np.linalg.inv(Cm)))
+        if combine:
+            wts[:3, e] = d[:3]
+            wts[3, e] = d[3] + d[4] + d[5] + d[6]
+        else:
+            wts[:, e] = d
+    return n, [graph_balancer(n, edges, wts[j], first, last) for j in range(nw)]
+
+
+def elch_close_loop_quat(scans, first, last, edges, algo, max_dist_match2, max_it, epsilonICP):
+    """elch6Dquat::close_loop (-L 2) -> (delta[7], weights[7][n])"""
+    n, weights = _elch_quat_weights(scans, edges, first, last, max_dist_match2, False)
+    start = MetaOScan([scans[first], scans[first + 1], scans[first + 2]])
+    for i in range(last - 2, last + 1):                            # elch6Dquat.cc:85-89
+        for j in range(7):
+            weights[j][i] = 0.0
+    before = np.concatenate([scans[last].rPos, scans[last].get_rPosQuat()])
+    match_meta_data(start, [scans[last - 2], scans[last - 1], scans[last]], algo, max_dist_match2, max_it, epsilonICP)
+    delta = np.concatenate([scans[last].rPos, scans[last].get_rPosQuat()]) - before
+    for i in range(1, n):                                          # elch6Dquat.cc:124-142
+        rq = scans[i].get_rPosQuat()
+        rP = np.array([scans[i].rPos[k] + delta[k] * (weights[k][i] - weights[k][0]) for k in range(3)])
+        rQ = np.array([rq[k] + delta[3 + k] * (weights[3 + k][i] - weights[3 + k][0]) for k in range(4)])
+        scans[i].transformToQuat(rP, normalize4(rQ))
+    return delta, weights
+
+
+def elch_close_loop_unitquat(scans, first, last, edges, algo, max_dist_match2, max_it, epsilonICP):
+    """elch6DunitQuat::close_loop (-L 3) -> (delta[3], deltaQ[4], weights[4][n])"""
+    n, weights = _elch_quat_weights(scans, edges, first, last, max_dist_match2, True)
+    start = MetaOScan([scans[first], scans[first + 1], scans[first + 2]])
+    ends = [scans[last - 2], scans[last - 1], scans[last]]
+    old = [(scans[k].rPos.copy(), scans[k].get_rPosQuat().copy()) for k in (last, last - 1, last - 2)]   # :84-108
+    p_before = scans[last].rPos.copy()
+    qb = scans[last].get_rPosQuat()
+    q1 = np.array([qb[0], -qb[1], -qb[2], -qb[3]])                  # :114-118
+    match_meta_data(start, ends, algo, max_dist_match2, max_it, epsilonICP)
+    delta = scans[last].rPos - p_before
+    deltaQ = qmult(scans[last].get_rPosQuat(), q1)                  # q2 * q1^-1, :135
+    for k, (p, q) in zip((last, last - 1, last - 2), old):          # restore poses after ICP matching, :149-152
+        scans[k].transformToQuat(p, q)
+    q0 = scans[0].get_rPosQuat()                                    # inverse rotation of scan 0, :155-167
+    w0 = weights[3][0]
+    pd = qmult(deltaQ, q0)
+    s0 = np.array([(1 - w0) * q0[0] + pd[0] * w0,
+                   -1 * ((1 - w0) * q0[1] + pd[1] * w0),
+                   -1 * ((1 - w0) * q0[2] + pd[2] * w0),
+                   -1 * ((1 - w0) * q0[3] + pd[3] * w0)])
+    scan0Pdelta = qmult(q0, normalize4(s0))
+    for i in range(1, n):                                           # :170-192
+        rP = np.array([scans[i].rPos[k] + delta[k] * (weights[k][i] - weights[k][0]) for k in range(3)])
+        qi = scans[i].get_rPosQuat()
+        rot = qmult(deltaQ, qi)
+        wi = weights[3][i]
+        tmp = normalize4([(1 - wi) * qi[k] + rot[k] * wi for k in range(4)])
+        scans[i].transformToQuat(rP, normalize4(qmult(scan0Pdelta, tmp)))
+    return delta, deltaQ, weights
+
+
+def elch_close_loop_slerp(scans, first, last, edges, algo, max_dist_match2, max_it, epsilonICP):
+    """elch6Dslerp::close_loop (-L 4) -> (deltaT[3], deltaQ[4], weights[4][n])"""
+    n, weights = _elch_quat_weights(scans, edges, first, last, max_dist_match2, True)
+    start = MetaOScan([scans[i] for i in range(first - 2, first + 3) if i >= 0])          # :93-98
+    ends = [scans[i] for i in range(last - 2, last + 1) if i < n]                          # :100-110 (offsets 2 / 0)
+    Pl0 = scans[last].transMat.copy()
+    match_meta_data(start, ends, algo, max_dist_match2, max_it, epsilonICP)
+    Pp0 = scans[last].transMat.copy()
+    Pf0 = scans[first].transMat.copy()
+    Pf0_inv = orc.m4inv(Pf0)[0]
+    tmp1 = orc.mmult(Pf0_inv, Pl0)                                  # :127-130
+    tmp2 = orc.m4inv(tmp1)[0]
+    tmp1 = orc.mmult(Pp0, tmp2)
+    deltaf = orc.mmult(Pf0_inv, tmp1)
+    deltaQ, deltaT = matrix4_to_quat(deltaf)
+    idQ = np.array([1.0, 0.0, 0.0, 0.0])
+
+    def share(i):
+        rP = np.array([deltaT[k] * weights[k][i] for k in range(3)])
+        return quat_to_matrix4(slerp(idQ, deltaQ, weights[3][i]), rP)
+    delta0 = orc.mmult(Pf0, orc.m4inv(share(0))[0])                # :151-157
+    for i in range(1, n):                                           # :162-175
+        if last - 2 <= i <= last:
+            M = orc.mmult(delta0, Pf0_inv)
+        else:
+            M = orc.mmult(orc.mmult(delta0, share(i)), Pf0_inv)
+        scans[i].transform(M)
+    return deltaT, deltaQ, weights
+
+
+# ---------------------------------------------------------------------------------------
 # lum6DQuat (-G 2), src/slam6d/lum6Dquat.cc   (parity unpinned: the TU needs scan.h -> Boost)
 # ---------------------------------------------------------------------------------------
 def covariance_quat(first, second, maxdist2):

@@ -1724,10 +1724,11 @@ def test_icp_glue_executes(gpu):
     assert r.returncode == 0 and "ICP GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_slam_glue_executes(tdtk, gpu, tmp_path, variant):
-    """(variant 1, round 4: meta_icp with max_num_metascans = 3, slam6D.cc:436-448, and the closing -DlastSLAM pass,
-    slam6D.cc:535-547.)  adapters/slam6d_glue.h executed (adapters/harness/slam_glue_harness.cc): matchGraph6Dautomatic in C++ on the C ABI
+    """(Round 4 -- variant 1: meta_icp with max_num_metascans = 3, slam6D.cc:436-448, and the closing -DlastSLAM pass,
+    slam6D.cc:535-547; variants 2 / 3 / 4: the loop closed by hip_elch_close_loop_quat / _unitquat / _slerp, -L 2 / 3 / 4.)
+    adapters/slam6d_glue.h executed (adapters/harness/slam_glue_harness.cc): matchGraph6Dautomatic in C++ on the C ABI
     -- sequential ICP with scans prepared ahead, loop detection, ELCH loop closing (batched covariance passes, balancer,
     MetaScan-against-MetaScan match), global lum6DEuler rounds through graph_slam_glue.h -- ends, on the same scans, in
     the poses of the Python mirror (matchGraph6Dautomatic + elch6Deuler + Graph + the library's graph iteration), bit
@@ -1769,7 +1770,8 @@ def test_slam_glue_executes(tdtk, gpu, tmp_path, variant):
                 return ret
         mini = tdtk.icp6D_QUAT(True)
         icp = tdtk.icp6D(mini, 25.0, 30, quiet=True, epsilonICP=1e-5)
-        loop = tdtk.elch6Deuler(True, mini, 25.0, 30, epsilonICP=1e-5)
+        closer = {2: tdtk.elch6Dquat, 3: tdtk.elch6DunitQuat, 4: tdtk.elch6Dslerp}.get(variant, tdtk.elch6Deuler)
+        loop = closer(True, mini, 25.0, 30, epsilonICP=1e-5)
         extra = dict(max_num_metascans=3, mdmll=15.0, graphDist=140.0) if variant == 1 else {}
         rounds = tdtk.matchGraph6Dautomatic(90.0, 6, S, icp, variant == 1, Relax(), 3, 0.05, 25.0, eP=True, prefetch=True,
                                             my_loopSlam6D=loop, **extra)
@@ -2006,6 +2008,37 @@ def test_elch_close_loop_vs_oracle(tdtk, orc, gpu):
     # the loop is closed better than before: scan n-1 against scan 0
     err, npairs = icp.Point_Point_Error(S[0], S[n - 1], 5.0)
     assert npairs > 1000
+
+
+@pytest.mark.parametrize("variant", ["elch6Dquat", "elch6DunitQuat", "elch6Dslerp"])
+def test_elch_quaternion_variants_vs_oracle(tdtk, orc, gpu, variant):
+    """-L 2 / 3 / 4 (elch6Dquat.cc:44-148, elch6DunitQuat.cc:45-199, elch6Dslerp.cc:44-184) against the oracle's
+    restatement (round 4; parity UNPINNED -- the TUs need Boost.Graph): the per-edge covarianceQuat passes run in one
+    batched device call, the balancer in the library, the interpolation rules on the host; every pose after the loop
+    closing, the loop error found by the MetaScan match and the balancer's weights agree with the oracle."""
+    from oracle import icp_oracle as io
+    S, O = _loop_scans(tdtk, io)
+    n = len(S)
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 5.0, 40, quiet=True, epsilonICP=1e-6)
+    icp.doICP(S, prefetch=False)
+    io.do_icp(O, 1, 25.0, 40, 1e-6)
+    g = [(i - 1, i) for i in range(1, n)]
+    first, last = (2, n - 1) if variant == "elch6Dslerp" else (0, n - 1)      # (-L 4 reaches two scans in front of `first`)
+    loop = getattr(tdtk, variant)(True, tdtk.icp6D_QUAT(True), 5.0, 40, epsilonICP=1e-6)
+    before = np.stack([s.transMat.copy() for s in S])
+    loop.close_loop(S, first, last, g)
+    out = getattr(io, {"elch6Dquat": "elch_close_loop_quat", "elch6DunitQuat": "elch_close_loop_unitquat",
+                       "elch6Dslerp": "elch_close_loop_slerp"}[variant])(O, first, last, g, 1, 25.0, 40, 1e-6)
+    want_delta = np.concatenate([np.ravel(v) for v in out[:-1]])
+    assert np.abs(loop.last_delta - want_delta).max() < 1e-7 * max(1.0, np.abs(want_delta).max())
+    moved = 0.0
+    for k, (s, o) in enumerate(zip(S, O)):
+        assert np.abs(s.transMat - o.transMat).max() < 1e-7 * max(1.0, np.abs(o.transMat).max()), k
+        moved = max(moved, np.abs(s.transMat - before[k]).max())
+    assert moved > 0.05                                        # the loop error was there and has been distributed
+    # the resident points followed their poses
+    for k in (1, n // 2, n - 1):
+        assert np.abs(S[k].get_xyz_reduced() - O[k].xyz).max() < 1e-6
 
 
 def test_match_graph6d_automatic_with_elch(tdtk, orc, gpu):
