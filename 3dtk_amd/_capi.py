@@ -7,6 +7,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "lib3dtk_hip.so")
+# The product library and the lab library (csrc/Makefile: the same sources with -DTDTK_LAB -- + the kernels and policies
+# that were built, measured and lost, and the environment switches that select them).  Everything loads the product;
+# TDTK_LIB=lab in the environment, or `with library("lab"):` around a test that compares a lab variant with the product
+# path, selects the other one.
+_SOS = {"product": _SO, "lab": os.path.join(_HERE, "lib3dtk_hip_lab.so")}
 
 ALGO_QUAT, ALGO_SVD, ALGO_APX, ALGO_NAPX = 1, 2, 6, 10
 ALGO_ORTHO, ALGO_DUAL, ALGO_HELIX, ALGO_LUMEULER, ALGO_LUMQUAT, ALGO_QUAT_SCALE = 3, 4, 5, 7, 8, 9
@@ -79,7 +84,30 @@ def build_extension(force=False):
     return _SO
 
 
-_lib = None
+_libs = {}
+_current = "lab" if os.environ.get("TDTK_LIB") == "lab" else "product"
+
+
+class library:
+    """with library("lab"): ...  -- every lib() call inside goes to that library.  Handles made inside should be released
+    inside (a handle that outlives the block is destroyed by the other library, which works -- both free device memory
+    the same way -- but is not the intended use)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _current
+        self.prev, _current = _current, self.name
+        return lib()
+
+    def __exit__(self, *exc):
+        global _current
+        _current = self.prev
+
+
+def is_lab():
+    return _current == "lab"
 
 
 def _init_torch_runtime_first():
@@ -99,14 +127,14 @@ def _init_torch_runtime_first():
 
 def lib():
     """The loaded C-ABI library.  Fails loudly when the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_SO):
-        raise TdtkError(-2, "lib3dtk_hip.so is not built (run __graft_entry__.build()); "
-                            "there is no CPU fallback")
+    if _current in _libs:
+        return _libs[_current]
+    so = _SOS[_current]
+    if not os.path.exists(so):
+        raise TdtkError(-2, "%s is not built (run __graft_entry__.build()); "
+                            "there is no CPU fallback" % os.path.basename(so))
     _init_torch_runtime_first()
-    L = C.CDLL(_SO)
+    L = C.CDLL(so)
     L.tdtk_last_error.restype = C.c_char_p
     L.tdtk_version.restype = C.c_char_p
     L.tdtk_tree_create.argtypes = [_dp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -188,7 +216,7 @@ def lib():
     L.tdtk_io_free.restype = None
     L.tdtk_io_read_pose.argtypes = [C.c_char_p, _dp, _dp]
     L.tdtk_io_write_frames.argtypes = [C.c_char_p, _dp, C.POINTER(C.c_int), C.c_size_t, C.c_int]
-    _lib = L
+    _libs[_current] = L
     return L
 
 

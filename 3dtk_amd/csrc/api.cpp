@@ -74,7 +74,7 @@ struct DevBuf {
 };
 
 enum { WS_KPOS, WS_D2, WS_PART, WS_OUT, WS_OVF_M2, WS_OVF_REF, WS_IDX, WS_QX, WS_QY, WS_QZ, WS_DX,
-       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COST, WS_MOVES, WS_COUNT };
+       WS_DY, WS_DZ, WS_ORDER, WS_CELL, WS_HIST, WS_TMPA, WS_TMPB, WS_CNT, WS_BOX, WS_ARENA, WS_COST, WS_MOVES, WS_BOUNDS, WS_COUNT };
 
 // an auxiliary stream with the buffers one whole-scan pass needs: batches of links over small scans run several
 // passes side by side (one pass of an 80K-point scan occupies a fraction of the machine and is latency-bound)
@@ -143,6 +143,9 @@ struct Ctx {
   std::vector<std::unique_ptr<LinkCost>> link_costs;
   DevBuf multi_args;                          // its argument tables on the device
   QueueCtr qc;       // for launches on `stream` (a caller's stream gets its launches ordered behind it, see run_search)
+  // slabs of equal cost for the next pass of an ICP loop (launch_slab_bounds): valid for the loop's next scan_pass only
+  const uint32_t* next_bounds = nullptr;
+  size_t next_bounds_n = 0;
   // a context dies with its host thread (worker threads of a prefetch pool come and go): give everything back
   ~Ctx();
 };
@@ -551,17 +554,19 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   if (t->info.n_internal) {
     HIPCHK(handle_malloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
     HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream));
+#ifdef TDTK_LAB
     // ... and, on request only, the two-level records (a node with its children's hot parts): two tree levels per round
     // trip are a measured negative both for the persistent-lane kernel (TDTK_FAT_NODES=1) and for the lane-group kernels of
     // small batches (TDTK_FAT_SMALL=1); kernels.hip has the numbers
     static const bool want_fat = [] {
-      const char *a = getenv("TDTK_FAT_NODES"), *b = getenv("TDTK_FAT_SMALL");
+      const char *a = lab_env("TDTK_FAT_NODES"), *b = lab_env("TDTK_FAT_SMALL");
       return (a && a[0] == '1') || (b && b[0] == '1');
     }();
     if (want_fat) {
       HIPCHK(handle_malloc(&t->d_fat, t->info.n_internal * sizeof(KdFat)));
       HIPCHK(launch_make_fat(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdFat*>(t->d_fat), c->stream));
     }
+#endif
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   t->dev.hot = static_cast<const KdHot*>(t->d_hot);
@@ -797,7 +802,7 @@ static int collect_ms(Ctx* c, double* ms, double* sums_ms = nullptr)
 // launches instead of three.  On by default there, TDTK_FUSE_SUMS=0 switches it off.
 static int fuse_mode(size_t N)   // 0: separate k_accum, 1: at retire time, 3: by each wave after its last query,
 {                                // 4: by each workgroup after its chunk (small batches)
-  const char* e = getenv("TDTK_FUSE_SUMS");
+  const char* e = lab_env("TDTK_FUSE_SUMS");
   const int v = e ? atoi(e) : -1;
   const int kind = search_fuse_kind(N);
   if (kind == 2) return v == 0 ? 0 : 4;
@@ -1024,7 +1029,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     {
       // ... and WS_COST how many buckets each of its queries visited then: the persistent-lane kernel hands a wave's slab
       // out with the expensive queries first (TDTK_COST_ORDER=0: in slab order)
-      const char* co = getenv("TDTK_COST_ORDER");
+      const char* co = lab_env("TDTK_COST_ORDER");
       if (pmode != 1 && !(co && co[0] == '0') && search_fuse_kind(N) == 1) {
         if ((rc = c->ws[WS_COST].ensure(N))) return rc;
         sa.cost = c->ws[WS_COST].as<unsigned char>();
@@ -1032,6 +1037,26 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
       }
     }
     sa.d2 = nullptr;
+#ifdef TDTK_LAB
+    // lab (a measured negative, NEGATIVES.md): slabs of equal cost, cut by the previous pass of this loop behind its k_final;
+    // TDTK_BALANCE=1 turns it on
+    if (sa.use_cost && c->next_bounds && c->next_bounds_n == N) sa.bounds = c->next_bounds;
+    c->next_bounds = nullptr;
+    const bool cut_next = sa.cost != nullptr && search_fuse_after_last_pays(N) && [] { const char* e = lab_env("TDTK_BALANCE"); return e && e[0] == '1'; }();
+    auto cut_slabs = [&]() -> int {     // enqueued behind the pass's last kernel: runs while the host solves for the pose
+      if (!cut_next) return TDTK_OK;
+      const void* before = c->ws[WS_BOUNDS].p;
+      int r2 = c->ws[WS_BOUNDS].ensure(slab_bounds_bytes(N));
+      if (r2) return r2;
+      if (c->ws[WS_BOUNDS].p != before) HIPCHK(hipMemsetAsync(c->ws[WS_BOUNDS].p, 0, 256, s));
+      const uint32_t* b = nullptr;
+      HIPCHK(launch_slab_bounds(sa.cost, N, c->ws[WS_BOUNDS].p, &b, s));
+      c->next_bounds = b; c->next_bounds_n = N;
+      return TDTK_OK;
+    };
+#else
+    auto cut_slabs = []() -> int { return TDTK_OK; };
+#endif
     uint32_t rows = 0;
     if (fused) {
       rows = search_fused_rows(N);
@@ -1049,11 +1074,13 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
       if (poll) arm_sums(c->h_pin);
       HIPCHK(launch_final(sa.partials, rows, c->h_pin, s, (fmode == 3 || fmode == 4) ? (int)ACC_DD : (int)ACC_TOTAL));   // base block only
       if (tm) { HIPCHK(hipEventRecord(c->e3, s)); c->ev2_pending = true; }
+      if ((rc = cut_slabs())) return rc;
       if (poll) HIPCHK(await_sums(c->h_pin, s));
       else HIPCHK(hipStreamSynchronize(s));
       std::memcpy(acc_out, c->h_pin, ACC_TOTAL * sizeof(double));
       return TDTK_OK;
     }
+    if ((rc = cut_slabs())) return rc;      // (before k_accum: the cut needs the cost bytes only)
   }
   AccumArgs aa{};
   aa.T = model->dev;
@@ -2072,7 +2099,7 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   const double t0 = now_ms();
   int iter = 0;
   int converged = 0;
-  const char* warm_env = getenv("TDTK_WARM_START");
+  const char* warm_env = lab_env("TDTK_WARM_START");
   const bool warm_ok = !(warm_env && warm_env[0] == '0');
   for (iter = 0; iter < prm->max_num_iterations; iter++) {
     prev_prev_ret = prev_ret;
@@ -2200,13 +2227,13 @@ int tdtk_lum_link(const tdtk_tree* first, const double first_dalignxf[16], tdtk_
 // acc: [nlinks][ACC_TOTAL] raw columns; shifts: [nlinks][3].
 static bool fuse_lum_enabled()
 {
-  const char* e = getenv("TDTK_FUSE_LUM");
+  const char* e = lab_env("TDTK_FUSE_LUM");
   return e && e[0] == '1';
 }
 
 static int link_batch_max()
 {
-  const char* e = getenv("TDTK_LINK_BATCH");   // 0 / 1: the lanes below
+  const char* e = lab_env("TDTK_LINK_BATCH");   // 0 / 1: the lanes below
   int v = e ? atoi(e) : 128;   // (84 links of 1M points: one launch 11.20 ms per LUM round, 64 + 20: 11.22-11.27, 42 + 42: 11.22)
   if (v > 128) v = 128;
   return v;
@@ -2219,10 +2246,10 @@ static int link_batch_max()
 // link's sums do not depend on how many links (or ranks) share the work.  TDTK_LINK_FUSE=0: k_accum_multi.
 static bool link_sums_in_search(const Ctx* c, unsigned want, size_t maxN)
 {
-  const char* e = getenv("TDTK_LINK_FUSE");
+  const char* e = lab_env("TDTK_LINK_FUSE");
   if (e && e[0] == '0') return false;
   // (experiments with the slab layout change the rows; TDTK_LINK_FUSE=2 keeps the sums inside for such sweeps)
-  if ((getenv("TDTK_REFILL_QPW") || getenv("TDTK_LINK_PHASES")) && !(e && e[0] == '2')) return false;
+  if ((lab_env("TDTK_REFILL_QPW") || lab_env("TDTK_LINK_PHASES")) && !(e && e[0] == '2')) return false;
   const int th = search_multi_thresh(maxN);
   return !c->counting && want == (TDTK_WANT_LUM | ACC_WANT_NO_CROSS) && search_multi_class(maxN) == 20 && (th == 16 || th == 32);
 }
@@ -2247,7 +2274,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   // A wave hands out each piece of its slab with the queries that were expensive in the previous pass of the same link
   // first, as the single pass does (k_search_refill, ORDER): 84 links of 1M points 9.18 -> 8.91 ms per LUM round.  The
   // order changes which lanes share a trip, never a result.  TDTK_LINK_ORDERED=0: in slab order.
-  const bool ordered_env = [] { const char* e = getenv("TDTK_LINK_ORDERED"); return !(e && e[0] == '0'); }();   // (per call: tests flip it)
+  const bool ordered_env = [] { const char* e = lab_env("TDTK_LINK_ORDERED"); return !(e && e[0] == '0'); }();   // (per call: tests flip it)
   const bool ordered = ordered_env && !c->counting && search_multi_class(maxN) == 20;
   const bool fuse_links = link_sums_in_search(c, want, maxN);
   if (ordered) {
@@ -2291,7 +2318,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   std::vector<int> ord(nlinks);
   for (int i = 0; i < nlinks; i++) ord[i] = i;
   {
-    static const bool keep = [] { const char* e = getenv("TDTK_LINK_ORDER"); return e && e[0] == '0'; }();
+    static const bool keep = [] { const char* e = lab_env("TDTK_LINK_ORDER"); return e && e[0] == '0'; }();
     if (!keep) {
       std::map<const tdtk_tree*, int> seen;
       std::vector<int> key(nlinks);
@@ -2430,7 +2457,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   // idle lanes a wave collects before it hands out new queries: 32 once a launch is many generations of waves (84 links of
   // 1M points, ordered: 8.93 -> 8.85 ms), as for single passes of 4M queries and more (refill_thresh)
   // (22 links: 2.627 ms with 16 against 2.652 with 32; 11 links 1.416 against 1.422)
-  const int thresh = (G > 32 && cls == 20 && !getenv("TDTK_REFILL_THRESH")) ? 32 : search_multi_thresh(maxN);
+  const int thresh = (G > 32 && cls == 20 && !lab_env("TDTK_REFILL_THRESH")) ? 32 : search_multi_thresh(maxN);
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G), nb = l1 - l0;
     const bool timed = (gi == ngroups - 1) && kernel_timing();   // tdtk_last_kernel_ms: the last group's search launch
@@ -2524,7 +2551,7 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
   }
   if ((rc = scans_settle(c, second, nlinks))) return rc;     // (the passes below read the scans as they are)
   int max_lanes = 8, forced = 0;
-  if (const char* e = getenv("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));
+  if (const char* e = lab_env("TDTK_LINK_LANES")) forced = std::max(1, std::min(16, atoi(e)));
   // small scans: a pass is latency-bound, 4 side by side (32 x 60K points, 41 links: 1 lane 2.35 ms, 2: 1.52, 3: 1.30,
   // 4: 1.11, 6: 1.26, 8: 1.19); big scans: 3, so the thin tail of one search and the small sum kernels overlap with
   // the next search (84 links of 1M: 1 lane 16.3 ms, 2: 13.0, 3: 12.2; more lanes than hardware queues lose, see

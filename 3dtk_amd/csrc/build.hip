@@ -17,6 +17,7 @@
 //     ALL nodes of the level at once.
 //
 // One small D2H (the number of internal nodes of the level) per level is the only host sync.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1371,17 +1372,17 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     BSum *own = (BSum*)(arena + O[27]), *comp = (BSum*)(arena + O[28]);
     uint32_t* wlist = (uint32_t*)(arena + O[29]);
     const uint32_t nblocks = cdiv(M, BIG_CH);
-    static const bool chain_only = [] { const char* e = getenv("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
+    static const bool chain_only = [] { const char* e = lab_env("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
     const bool use_big = !chain_only && M >= BIG_MIN;
     // TDTK_MEASURE=axis: round 2's wave per (node, axis) for the nodes below the piecewise path (k_measure); default: a wave
     // per node (k_measure_node).  With TDTK_BUILD_CHAIN=1 (no piecewise path: chains of any length) the long-chain kernel.
-    static const bool measure_axis_env = [] { const char* e = getenv("TDTK_MEASURE"); return e && e[0] == 'a'; }();
+    static const bool measure_axis_env = [] { const char* e = lab_env("TDTK_MEASURE"); return e && e[0] == 'a'; }();
     const bool measure_per_axis_always = measure_axis_env || chain_only;
-    const int big_dbg_all = getenv("TDTK_BIG_DEBUG") ? atoi(getenv("TDTK_BIG_DEBUG")) : 0;
+    const int big_dbg_all = lab_env("TDTK_BIG_DEBUG") ? atoi(lab_env("TDTK_BIG_DEBUG")) : 0;
     // speculative splits: TDTK_BUILD_SPEC=0 builds in order; TDTK_BUILD_SPEC_FAULT=1 (tests) cuts every big node elsewhere than
     // the exact sum would, so that the final check fails and the in-order path takes over
     static const bool spec_env = [] { const char* e = getenv("TDTK_BUILD_SPEC"); return !(e && e[0] == '0'); }();
-    static const int spec_fault = [] { const char* e = getenv("TDTK_BUILD_SPEC_FAULT"); return (e && e[0] == '1') ? 1 : 0; }();
+    static const int spec_fault = [] { const char* e = lab_env("TDTK_BUILD_SPEC_FAULT"); return (e && e[0] == '1') ? 1 : 0; }();
     const bool spec = spec_env && side && side->s2 && use_big && !big_dbg_all;
     spec_on = spec;
     BSpecAll SP;
@@ -1399,7 +1400,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
     BCHK(hipMemsetAsync(small, 0, 256, s));
     // the partition's scan in one launch while the positions fit its 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
-    static const bool own_scan_env = [] { const char* e = getenv("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
+    static const bool own_scan_env = [] { const char* e = lab_env("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
     const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
     const size_t o_scanstate = O[31];
     if (own_scan) BCHK(hipMemsetAsync(arena + o_scanstate, 0, scan_pair27_state_bytes(n1), s));
@@ -1414,6 +1415,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     // known on the device only (lvl[]).  The host looks once after a first batch as deep as a balanced tree gets
     // down to bucket-sized nodes, then every two levels; per-node kernels are launched over an upper bound of the
     // level's node count (what the last look saw, doubled per level since) and return past the real count.
+    // diagnostics (TDTK_BUILD_TRACE=1): an event at the start of every level on the build's stream; the elapsed times are
+    // printed when the build is done -- what a level costs when no profiler is serialising the launches
+    static const bool lvl_trace = [] { const char* e = lab_env("TDTK_BUILD_TRACE"); return e && e[0] == '1'; }();
+    std::vector<hipEvent_t> lvl_ev;
     uint32_t level = 0, known = 1, known_at = 0;
     uint32_t batch = 1;
     for (size_t c = (size_t)(bucket > 0 ? bucket : 1); c < M_; c <<= 1) batch++;
@@ -1432,6 +1437,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         if (level > 0 && bound > cap) bound = cap;
         if (bound < 1) bound = 1;
         const BLevel* lv = lvl + level;
+        if (lvl_trace) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); lvl_ev.push_back(e); } }
         // the piecewise path runs while a balanced node is at least half its threshold (below that level the chain in
         // k_measure takes every node, whatever its size: an empty pass of the piecewise kernels costs 75 us)
         const bool big_level = use_big && ((M_ >> level) >= BIG_MIN / 2);
@@ -1558,6 +1564,15 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       if (nx.nseg == 0) break;
       known = nx.nseg; known_at = level;
       batch = 2;
+    }
+    if (lvl_trace && !lvl_ev.empty()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); (void)hipEventSynchronize(e); lvl_ev.push_back(e); }
+      fprintf(stderr, "BUILD_TRACE M=%u:", M);
+      for (size_t k = 0; k + 1 < lvl_ev.size(); k++) { float ms = 0; (void)hipEventElapsedTime(&ms, lvl_ev[k], lvl_ev[k + 1]); fprintf(stderr, " L%zu %.0f", k, ms * 1e3f); }
+      float tot = 0; (void)hipEventElapsedTime(&tot, lvl_ev.front(), lvl_ev.back());
+      fprintf(stderr, " | levels total %.0f us\n", tot * 1e3f);
+      for (hipEvent_t x : lvl_ev) (void)hipEventDestroy(x);
     }
     {
       // the first level without nodes: its counters are the totals, its index the depth of the tree
@@ -1702,7 +1717,7 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(sizeof(BPre) * nsl); take(sizeof(BPre) * nsl);                       // 25 26 plain prefix in / out
   take(sizeof(BSum) * nsl); take(sizeof(BSum) * nsl);                       // 27 28 piece summaries, folded runs
   take(4 * (nsl + 1));                                                      // 29 slots of the walked pieces, in run order
-  take(getenv("TDTK_BIG_DEBUG") && (atoi(getenv("TDTK_BIG_DEBUG")) & 8) ? sizeof(BMeas) * n1 : 256);   // 30 debug: the chain's results
+  take(lab_env("TDTK_BIG_DEBUG") && (atoi(lab_env("TDTK_BIG_DEBUG")) & 8) ? sizeof(BMeas) * n1 : 256);   // 30 debug: the chain's results
   take(scan_pair27_state_bytes(n1));                                        // 31 state of the one-launch scan
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;

@@ -69,6 +69,9 @@ struct SearchArgs {
   // the scan's spare arrays for the ONE link of the launch that owns the scan's update (the host swaps them in behind
   // the launch; that link also gets nx / ny / nz and moves the normals in place), a scratch copy for any other link of
   // the launch that reads the same scan.
+  // single-pass launch (k_search_refill): wave w of the launch owns the queries [bounds[w], bounds[w + 1]) -- slabs of equal
+  // cost by the previous pass's cost bytes (launch_slab_bounds); nullptr: slabs of qpw queries
+  const uint32_t* bounds;
   const double *sx, *sy, *sz;
   const Mat4* moves;
   int nmoves;        // <= SEARCH_LAZY_MAX
@@ -138,6 +141,10 @@ bool search_can_fuse(size_t n);
 bool search_fuse_after_last_pays(size_t n);   // FUSE 3 by default for a batch of this size?
 int search_fuse_kind(size_t n);   // 0 no, 1 persistent-lane FUSE modes (on request), 2 chunk epilogue of the small-batch kernels        // does a batch of n queries get the kernel that can fuse the base sums?
 uint32_t search_fused_rows(size_t n, int side_by_side = 1);  // rows of partials the fused kernel writes
+#ifdef TDTK_LAB
+size_t slab_bounds_bytes(size_t n);
+hipError_t launch_slab_bounds(const unsigned char* cost, size_t n, void* buf, const uint32_t** bounds_out, hipStream_t s);
+#endif
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
 hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_t s);

@@ -106,18 +106,23 @@ __device__ __forceinline__ const A& kernarg_block()
 // closest_d2 never grows, so the reference's test after the near child returns
 // (kdTreeImpl.h:373,378) would fail for every entry we skip.
 // ------------------------------------------------------------------------------------------
-// the overflow path lives in its own (rarely called) functions so that the compiler keeps the
-// common case as plain ds_write / ds_read instead of merging both into flat_store / flat_load
-__device__ __noinline__ void stack_spill(double* g_m2, uint32_t* g_ref, size_t off, uint32_t ref, double m2)
+// The overflow path names its address space (global) in every access, so that the compiler keeps the common case as
+// plain ds_write / ds_read instead of merging both into flat_store / flat_load.  (Until round 4 it lived in two
+// __noinline__ functions for the same purpose, whose call frames cost every search kernel 32 bytes of scratch per lane.)
+__device__ __forceinline__ void stack_spill(double* g_m2, uint32_t* g_ref, size_t off, uint32_t ref, double m2)
 {
-  g_m2[off] = m2;
-  g_ref[off] = ref;
+  typedef double __attribute__((address_space(1))) * gd;
+  typedef uint32_t __attribute__((address_space(1))) * gu;
+  ((gd)g_m2)[off] = m2;
+  ((gu)g_ref)[off] = ref;
 }
-__device__ __noinline__ void stack_fill(const double* g_m2, const uint32_t* g_ref, size_t off, uint32_t& ref,
-                                        double& m2)
+__device__ __forceinline__ void stack_fill(const double* g_m2, const uint32_t* g_ref, size_t off, uint32_t& ref,
+                                           double& m2)
 {
-  m2 = g_m2[off];
-  ref = g_ref[off];
+  typedef const double __attribute__((address_space(1))) * gd;
+  typedef const uint32_t __attribute__((address_space(1))) * gu;
+  m2 = ((gd)g_m2)[off];
+  ref = ((gu)g_ref)[off];
 }
 
 template <int BLOCK, int SD>
@@ -607,6 +612,7 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
   }
 }
 
+#ifdef TDTK_LAB   // ---- lab only (a measured negative): the wave-cooperative kernel ----
 // ------------------------------------------------------------------------------------------
 // Wave-cooperative variant of the same traversal.  The per-lane logic (and therefore every
 // comparison, every visit, every tie) is unchanged; what changes is WHO issues the loads.
@@ -830,6 +836,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_coop(const SearchArgs a)
     }
   }
 }
+
+#endif   // TDTK_LAB
 
 // ------------------------------------------------------------------------------------------
 // nearest point to a line: exact replay of _FindClosestAlongDir (kdTreeImpl.h:390-425).
@@ -1392,7 +1400,11 @@ __global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __r
 // (7168) leaves 1M queries only ~140 per wave, i.e. MORE drains per query than the static 224..256-query slabs.
 // diagnostics (TDTK_WAVE_TRACE=<launch index>): start / end time (100 MHz) and XCD of every wave of one launch
 #define WTRACE_MAX 32768u
+#ifdef TDTK_LAB
 __device__ unsigned long long g_wtrace[3 * WTRACE_MAX];
+#else
+__device__ unsigned long long g_wtrace[3];     // (never touched: a.trace is a lab switch)
+#endif
 
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
@@ -1406,7 +1418,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   const unsigned lane = threadIdx.x & (WAVE - 1);
   // diagnostics (TDTK_WAVE_TRACE): the start time goes to memory right away -- kept in registers it is live across the
   // whole kernel, and the compiler spilled it
-  if (a.trace && lane == 0) {
+  if (kLab && a.trace && lane == 0) {
     const uint32_t wid0 = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
     if (wid0 < WTRACE_MAX) g_wtrace[3 * wid0] = wall_clock64();
   }
@@ -1491,7 +1503,8 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     ordered = true;
   };
   size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
-  size_t sub = 0, reg0 = 0, pstride = 0;
+  size_t sub = 0, reg0 = 0, pstride = 0, slab_end = a.n;
+  int nph = 1;       // pieces of this wave's slab
   bool exhausted = false;
   int phase = 0;
   uint32_t xq = 0, tried = 0, nslab = 0, per_x = 0;
@@ -1509,8 +1522,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     // hold at any one time are those under 1/phases of the eighth (the 32-byte points of an eighth of a 1M-point
     // model alone are 4 MB)
     const uint32_t wpx = (nb >> 3) * (BLOCK / WAVE);                      // waves per XCD
-    const uint32_t wx = (bid >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE;   // this wave among them
-    if (a.pool_slab) {
+    // (wave-uniform, and said so: the slab geometry derived from it then lives in scalar registers)
+    const uint32_t wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE));   // this wave among them
+    if (kLab && a.pool_slab) {
       // Static slab + pool: the waves of a launch do not finish together -- at 1M queries the first is done after 60 %
       // of the launch, the median after 77 % (TDTK_WAVE_TRACE) -- so only part of an XCD's region is dealt out in
       // advance and the rest is drawn in small pieces by whichever wave runs dry.  One counter per XCD, touched first by
@@ -1526,13 +1540,30 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       if (end_q > rend) end_q = rend;
       if (bid == 0 && threadIdx.x < 8) a.q_ctr_next[threadIdx.x] = 0u;
     } else {
-      sub = (size_t)(a.qpw / a.phases);
-      reg0 = (size_t)(bid & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
-      pstride = (size_t)wpx * sub;
+      if (kLab && !LAZY && a.bounds) {
+        // Slabs of equal COST instead of equal length (SearchArgs::bounds, k_slab_bounds below): wave w of the launch --
+        // numbered XCD by XCD, so that an XCD's waves still share a contiguous stretch of the sorted scan -- owns the
+        // queries [bounds[w], bounds[w + 1]), handed out in pieces of ORD_MAX (each ordered by cost as before)
+        const uint32_t w = (bid & 7u) * wpx + wx;
+        reg0 = (size_t)a.bounds[w];
+        slab_end = (size_t)a.bounds[w + 1];
+        if (slab_end > a.n) slab_end = a.n;
+        if (reg0 > slab_end) reg0 = slab_end;
+        sub = (size_t)ORD_MAX;
+        pstride = sub;
+        nph = (int)((slab_end - reg0 + sub - 1) / sub);
+        if (nph < 1) nph = 1;
+      } else {
+        sub = (size_t)(a.qpw / a.phases);
+        reg0 = (size_t)(bid & 7u) * wpx * (size_t)a.qpw + (size_t)wx * sub;
+        pstride = (size_t)wpx * sub;
+        slab_end = a.n;
+        nph = a.phases;
+      }
       next_q = reg0;
       end_q = next_q + sub;
-      if (next_q > a.n) next_q = a.n;
-      if (end_q > a.n) end_q = a.n;
+      if (next_q > slab_end) next_q = slab_end;
+      if (end_q > slab_end) end_q = slab_end;
       order_piece(next_q, end_q);
     }
   }
@@ -1685,7 +1716,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         ++tried;
       }
     }
-    if (!DYN && a.pool_slab && fill && next_q >= end_q && !exhausted) {
+    if (kLab && !DYN && a.pool_slab && fill && next_q >= end_q && !exhausted) {
       // the pool of the XCD this wave runs on first; when that is dry the other seven in turn (a pool whose XCD has no
       // resident wave -- another partition mode, an uneven dispatch -- must not be left unsearched: XCC_ID is a hint for
       // locality, never a condition for completeness).  Counters are touched from any XCD now: agent scope.
@@ -1708,12 +1739,12 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       }
       if (tried >= 8u) exhausted = true;
     }
-    if (!DYN && !a.pool_slab && fill && next_q >= end_q && phase + 1 < a.phases) {
+    if (!DYN && !a.pool_slab && fill && next_q >= end_q && phase + 1 < nph) {
       ++phase;
       next_q = reg0 + (size_t)phase * pstride;
       end_q = next_q + sub;
-      if (next_q > a.n) next_q = a.n;
-      if (end_q > a.n) end_q = a.n;
+      if (next_q > slab_end) next_q = slab_end;
+      if (end_q > slab_end) end_q = slab_end;
       order_piece(next_q, end_q);
     }
     if (next_q < end_q && fill) {
@@ -1748,7 +1779,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       next_q += (size_t)__popcll(idlem);
     }
     if (__ballot(cur != REF_DONE) == 0) {
-      if (next_q >= end_q && (DYN ? tried >= 8u : (a.pool_slab ? exhausted : phase + 1 >= a.phases))) break;
+      if (next_q >= end_q && (DYN ? tried >= 8u : ((kLab && a.pool_slab) ? exhausted : phase + 1 >= nph))) break;
       continue;
     }
 
@@ -1982,7 +2013,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       }
     }
   }
-  if (a.trace && lane == 0) {
+  if (kLab && a.trace && lane == 0) {
     const uint32_t wid = bid * (BLOCK / WAVE) + threadIdx.x / WAVE;
     if (wid < WTRACE_MAX) {
       g_wtrace[3 * wid + 1] = wall_clock64();
@@ -2009,7 +2040,8 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     // four queries per lane and trip, all their loads issued before the first use: two memory round trips for a whole
     // slab of up to 256 queries instead of one pair per 64
-    const uint32_t slab = (uint32_t)a.qpw, sub32 = (uint32_t)sub;
+    const bool balanced = kLab && !LAZY && a.bounds != nullptr;     // this wave's slab is [reg0, slab_end), in one piece
+    const uint32_t slab = balanced ? (uint32_t)(slab_end - reg0) : (uint32_t)a.qpw, sub32 = balanced ? 0x7FFFFFFFu : (uint32_t)sub;
     for (uint32_t j0 = 0; j0 < slab; j0 += 4 * WAVE) {
       size_t qq[4];
       int kk[4];
@@ -2019,7 +2051,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         const bool in = j < slab;
         while (j >= sub32 && in) { j -= sub32; ph++; }
         qq[u] = reg0 + (size_t)ph * pstride + j;
-        kk[u] = (in && qq[u] < a.n) ? a.kpos[qq[u]] : -1;
+        kk[u] = (in && qq[u] < slab_end) ? a.kpos[qq[u]] : -1;
       }
 #pragma unroll
       for (int h = 0; h < 4; h += 2) {
@@ -2118,6 +2150,112 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const Search
   l = __builtin_amdgcn_readfirstlane(l);
   const uint32_t b0 = base[l], b1 = base[l + 1];
   search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320, true>(args[l], blockIdx.x - b0, b1 - b0);
+}
+
+#ifdef TDTK_LAB   // ---- lab only (measured negatives): slabs of equal cost, the one-loop kernel ----
+static uint32_t refill_grid_b_fwd(size_t n, int* qpw_out);   // = refill_grid_b(n, 128, qpw_out): the grid of the single-pass launch
+
+// ------------------------------------------------------------------------------------------
+// k_slab_bounds: slabs of equal cost for the next pass over the same queries (round 4).
+// A launch over 1M queries is ONE generation of 4096 waves; handed 256 queries each, the waves do not finish together --
+// the first is done after 60 % of the launch, the median after 77 % (TDTK_WAVE_TRACE, round 3) -- and the SIMDs they
+// leave run the launch's tail with one or two waves.  The cost byte every query leaves behind when it retires (node
+// visits + 4 per bucket, what the hand-out inside a slab is ordered by) says what a stretch of the sorted scan will cost
+// the NEXT pass of the same ICP loop, so the next launch cuts the scan into as many stretches of equal cost as it has
+// waves: sums per 32-query chunk (every workgroup a run of chunks), then -- by the workgroup that finishes last -- a
+// scan of the chunk sums and bounds[w] = the end of the first chunk at which the running cost reaches w / W of the
+// total.  One launch, enqueued behind the pass's k_final: it runs while the host solves for the pose.  Which wave
+// searches a query never shows in a result; which queries share a row of partial sums does, in the last bits of the
+// sums (as the slab length does), deterministically.
+// ------------------------------------------------------------------------------------------
+#define SB_CHUNK 32u
+#define SB_FIX 6u             // what a query costs besides its visits (hand-out, retire, its share of the sums pass)
+__global__ void __launch_bounds__(1024) k_slab_bounds(const unsigned char* __restrict__ cost, uint32_t n, uint32_t W, uint32_t nchunk,
+                                                      uint32_t* __restrict__ csum, uint32_t* __restrict__ counter,
+                                                      uint32_t* __restrict__ bounds, const uint32_t fix)
+{
+  // phase A: chunk sums, one chunk of 32 cost bytes per pair of lanes (a 16-byte load each)
+  {
+    const uint32_t pair = (blockIdx.x * 1024u + threadIdx.x) >> 1, half = threadIdx.x & 1u;
+    uint32_t sum = 0;
+    if (pair < nchunk) {
+      const uint32_t q0 = pair * SB_CHUNK + half * 16u;
+      if (q0 + 16u <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(cost + q0);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) sum += (w4[k] & 0xFFu) + ((w4[k] >> 8) & 0xFFu) + ((w4[k] >> 16) & 0xFFu) + (w4[k] >> 24);
+        sum += 16u * fix;
+      } else {
+        for (uint32_t q = q0; q < n && q < q0 + 16u; q++) sum += (uint32_t)cost[q] + fix;
+      }
+    }
+    sum += __shfl_xor(sum, 1, WAVE);
+    if (pair < nchunk && half == 0) csum[pair] = sum;
+  }
+  __shared__ uint32_t s_last;
+  __shared__ unsigned long long s_tot[1024 / WAVE];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // phase B (the last workgroup): thread t takes a run of chunks; exclusive scan of the runs' sums; then it walks its run
+  // and places every boundary that falls into it
+  const uint32_t per = (nchunk + 1023u) / 1024u;
+  const uint32_t c0 = min(threadIdx.x * per, nchunk), c1 = min(c0 + per, nchunk);
+  unsigned long long mine = 0;
+  for (uint32_t c = c0; c < c1; c++) mine += __builtin_nontemporal_load(csum + c);
+  unsigned long long incl = mine;
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const unsigned long long t = (unsigned long long)__shfl_up((long long)incl, off, WAVE);
+    if ((int)lane >= off) incl += t;
+  }
+  if (lane == WAVE - 1) s_tot[wv] = incl;
+  __syncthreads();
+  unsigned long long before = incl - mine, total = 0;
+  for (uint32_t k = 0; k < 1024 / WAVE; k++) { if (k < wv) before += s_tot[k]; total += s_tot[k]; }
+  if (threadIdx.x == 0) { bounds[0] = 0u; bounds[W] = n; *counter = 0u; }      // (the counter is ready for the next launch)
+  if (total == 0) total = 1;
+  // boundary w sits at the end of the first chunk whose running cost reaches w total / W: floor(prefix W / total) steps from
+  // w - 1 to w there.  One rounding of prefix * (W / total) in fp64 (prefix < 2^32) is monotone in the prefix, which is all
+  // that matters: every w gets exactly one chunk.
+  const double scale = (double)W / (double)total;
+  unsigned long long p = before;
+  uint32_t w_prev = (uint32_t)((double)p * scale);
+  for (uint32_t c = c0; c < c1; c++) {
+    p += __builtin_nontemporal_load(csum + c);
+    const uint32_t w_now = (c + 1u == nchunk) ? W : (uint32_t)((double)p * scale);
+    const uint32_t end = min((c + 1u) * SB_CHUNK, n);
+    for (uint32_t w = w_prev + 1u; w <= w_now && w < W; w++) bounds[w] = end;
+    w_prev = w_now;
+  }
+}
+size_t slab_bounds_bytes(size_t n)
+{
+  const size_t nchunk = (n + SB_CHUNK - 1) / SB_CHUNK;
+  int q;
+  const size_t W = (size_t)refill_grid_b_fwd(n, &q) * 2;
+  return 256 + 4 * nchunk + 4 * (W + 1) + 64;
+}
+// bounds for the NEXT single-pass launch over the same n queries; `buf` = slab_bounds_bytes(n) bytes whose first 256 were
+// zeroed once.  Returns the device pointer to the bounds (W + 1 entries) through `bounds_out`.
+hipError_t launch_slab_bounds(const unsigned char* cost, size_t n, void* buf, const uint32_t** bounds_out, hipStream_t s)
+{
+  const uint32_t nchunk = (uint32_t)((n + SB_CHUNK - 1) / SB_CHUNK);
+  int q;
+  const uint32_t W = refill_grid_b_fwd(n, &q) * 2u;
+  uint32_t* counter = static_cast<uint32_t*>(buf);
+  uint32_t* csum = counter + 64;
+  uint32_t* bounds = csum + nchunk;
+  *bounds_out = bounds;
+  uint32_t fix = SB_FIX;
+  if (const char* e = lab_env("TDTK_SB_FIX")) fix = (uint32_t)std::max(0, atoi(e));     // (lab: how strongly the cut follows the visits)
+  hipLaunchKernelGGL(k_slab_bounds, dim3((nchunk * 2u + 1023u) / 1024u), dim3(1024), 0, s, cost, (uint32_t)n, W, nchunk, csum, counter, bounds, fix);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2308,6 +2446,8 @@ __global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
   }
 }
 
+#endif   // TDTK_LAB
+
 // ------------------------------------------------------------------------------------------
 // pair-sum accumulation
 // ------------------------------------------------------------------------------------------
@@ -2321,6 +2461,14 @@ __device__ __forceinline__ void accum_body(const AccumArgs& a, const uint32_t bi
   // accumulate and, what costs more with four pairs per lane, to reduce across the wave)
   constexpr bool CROSS = !(WANT & ACC_WANT_NO_CROSS);
   __shared__ double red[NW][ACC_TOTAL];
+  // pairing mode 1 keeps the normal rotated into the tree frame: the nine rotation entries of `inv` wait in LDS (read at a
+  // wave-uniform address where they are used) -- as eighteen more scalar registers beside A, the shift and the sums'
+  // bookkeeping they were the ones the NAPX instantiations spilled
+  __shared__ double s_rot[PMODE == 1 ? 9 : 1];
+  if (PMODE == 1) {
+    if (threadIdx.x < 9) s_rot[threadIdx.x] = a.inv.m[(threadIdx.x / 3) * 4 + (threadIdx.x % 3)];
+    __syncthreads();
+  }
 
   double acc[ACC_TOTAL];
 #pragma unroll
@@ -2360,7 +2508,12 @@ __device__ __forceinline__ void accum_body(const AccumArgs& a, const uint32_t bi
       nxv = a.nx[i]; nyv = a.ny[i]; nzv = a.nz[i];
       const double len = __dsqrt_rn(nxv * nxv + nyv * nyv + nzv * nzv);
       nxv /= len; nyv /= len; nzv /= len;
-      if (PMODE == 1) dev_xf3normal(a.inv, nxv, nyv, nzv);  // the reference keeps the rotated one
+      if (PMODE == 1) {   // the reference keeps the rotated one: dev_xf3normal(a.inv, ..) with the rotation from LDS
+        const double xn = nxv * s_rot[0] + nyv * s_rot[1] + nzv * s_rot[2];
+        const double yn = nxv * s_rot[3] + nyv * s_rot[4] + nzv * s_rot[5];
+        const double zn = nxv * s_rot[6] + nyv * s_rot[7] + nzv * s_rot[8];
+        nxv = xn; nyv = yn; nzv = zn;
+      }
     }
     if (PMODE == 2) {  // searchTree.cc:149-162: project the hit onto the data point's plane
       const double ex = mx - tx, ey = my - ty, ez = mz - tz;
@@ -2454,9 +2607,12 @@ __device__ __forceinline__ void accum_body(const AccumArgs& a, const uint32_t bi
 }
 
 template <int BLOCK, unsigned WANT, int PMODE>
-__global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a)
+__global__ void __launch_bounds__(BLOCK) k_accum(const AccumArgs a_by_value)
 {
-  accum_body<BLOCK, WANT, PMODE>(a, blockIdx.x, gridDim.x);
+  // (the argument block through the kernarg pointer, like k_search_refill: by value the compiler hoists its three matrices
+  // into scalar registers up front and -- in the NAPX instantiations -- spills four of them)
+  (void)a_by_value;
+  accum_body<BLOCK, WANT, PMODE>(kernarg_block<AccumArgs>(), blockIdx.x, gridDim.x);
 }
 // the pair sums of several batches in one launch (see k_search_refill_multi)
 template <int BLOCK, unsigned WANT, int PMODE>
@@ -2707,7 +2863,8 @@ constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest L
 // inside one process)
 static int search_variant()
 {
-  const char* e = getenv("TDTK_SEARCH_VARIANT");
+  if (!kLab) return -2;              // the product build chooses by batch size: 20 / 4 / 10 below
+  const char* e = lab_env("TDTK_SEARCH_VARIANT");
   int v = e ? atoi(e) : -2;          // -2: choose by batch size (see launch_search)
   if (v != 0 && v != 4 && v != 5 && v != 9 && v != 10 && v != 11 && v != 8 && v != 20 && v != 30 && v != 40 && v != 41) v = -2;
   return v;
@@ -2739,7 +2896,7 @@ uint32_t search_grid(size_t n)
 // 512 -> 13.0, 640 -> 13.4 (tools/gs_knobs_probe.py) -- ~3 waves per SIMD and pass.
 static int refill_qpw(size_t n, int side_by_side = 1)
 {
-  if (const char* e = getenv("TDTK_REFILL_QPW")) {
+  if (const char* e = lab_env("TDTK_REFILL_QPW")) {
     int v = atoi(e);
     if (v < 64) v = 64;
     return (v + 31) & ~31;
@@ -2779,6 +2936,9 @@ static uint32_t refill_grid_b(size_t n, int block, int* qpw_out, int side_by_sid
   *qpw_out = (int)qpw;
   return (uint32_t)nb;
 }
+#ifdef TDTK_LAB
+static uint32_t refill_grid_b_fwd(size_t n, int* qpw_out) { return refill_grid_b(n, 128, qpw_out); }
+#endif
 size_t search_max_lanes(size_t n)
 {
   int q;
@@ -2804,9 +2964,9 @@ int search_block() { return SEARCH_BLOCK; }
 // waves (4M queries: 0.926 -> 0.913 ms; 1M: 0.238 -> 0.241, gpurun_out/r2h/sweep.log)
 static int refill_thresh(size_t n)
 {
-  if (const char* e = getenv("TDTK_REFILL_THRESH")) {
+  if (const char* e = lab_env("TDTK_REFILL_THRESH")) {
     const int v = atoi(e);
-    if (v == 8 || v == 16 || v == 32) return v;
+    if ((kLab && v == 8) || v == 16 || v == 32) return v;
   }
   return ((n + 255) / 256 >= (size_t)num_cu() * 4 * 7) ? 32 : 16;
 }
@@ -2836,8 +2996,9 @@ static uint32_t g8_grid4(size_t n) { const uint32_t g = g8_grid(n) / 2; return g
 // 0 = off.  Only where all waves of the launch are resident at once and the launch has the chip to itself.
 static int refill_pool_pct(size_t n, int side_by_side)
 {
+  if (!kLab) return 0;
   if (side_by_side > 1 || (n + 255) / 256 >= (size_t)num_cu() * 4 * 7) return 0;
-  const char* e = getenv("TDTK_REFILL_POOL");
+  const char* e = lab_env("TDTK_REFILL_POOL");
   int v = e ? atoi(e) : 0;
   if (v < 0) v = 0;
   if (v > 90) v = 90;
@@ -2867,7 +3028,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   // Neither do they pay beside other passes (84 link passes on 3 streams: 13.6 -> 13.2 ms without).
   {
     static std::atomic<int> launches{0};
-    static const int want = [] { const char* e = getenv("TDTK_WAVE_TRACE"); return e ? atoi(e) : -1; }();
+    static const int want = [] { const char* e = lab_env("TDTK_WAVE_TRACE"); return e ? atoi(e) : -1; }();
     a.trace = (want >= 0 && launches.fetch_add(1) == want) ? 1 : 0;
   }
   a.pool_slab = 0; a.region = 0;
@@ -2878,7 +3039,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     size_t qs = (R * (size_t)(100 - pool_pct) / 100 / wpx) & ~(size_t)31;
     if (qs < 64) qs = 64;
     a.qpw = (int)qs; a.region = R;
-    const char* e = getenv("TDTK_REFILL_POOL_SLAB");
+    const char* e = lab_env("TDTK_REFILL_POOL_SLAB");
     a.pool_slab = e ? std::max(16, atoi(e)) : 64;
   }
   int ph = ((a.n + 255) / 256 >= (size_t)num_cu() * 4 * 7 || a.side_by_side > 1 || a.pool_slab) ? 1 : 2;
@@ -2888,15 +3049,16 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   // ... and with the sums added up by the waves themselves (FUSE 3) the pieces decide which queries share a row of partial
   // sums: one piece always, so that the sums do not depend on whether the hand-out is ordered
   if (FUSE == 3) ph = 1;
-  if (const char* e = getenv("TDTK_REFILL_PHASES")) ph = atoi(e);
+  if (const char* e = lab_env("TDTK_REFILL_PHASES")) ph = atoi(e);
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;   // pieces stay multiples of 16 queries
   a.phases = ph;
   // diagnostics: TDTK_OCC_LDS=<bytes> of unused dynamic LDS per workgroup caps the waves resident per SIMD (how the launch
   // time depends on occupancy alone); TDTK_BUCKET_PTS=8 scans buckets eight points per round trip instead of four
-  static const unsigned occ_lds = [] { const char* e = getenv("TDTK_OCC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-  const char* pe = getenv("TDTK_BUCKET_PTS");
+  static const unsigned occ_lds = [] { const char* e = lab_env("TDTK_OCC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+  const char* pe = lab_env("TDTK_BUCKET_PTS");
   const int bpts = pe ? atoi(pe) : 4;
+#ifdef TDTK_LAB
   if (!COUNT && FUSE == 0 && bpts == 8 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 8>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 41 && refill_thresh(a.n) == 16) {
@@ -2905,15 +3067,19 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 43 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 3>), dim3(nb), dim3(128), occ_lds, s, a);
-  } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr && getenv("TDTK_FAT_NODES") && getenv("TDTK_FAT_NODES")[0] == '1') {
+  } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr && lab_env("TDTK_FAT_NODES") && lab_env("TDTK_FAT_NODES")[0] == '1') {
     // two tree levels per round trip (KdFat): a measured negative, kept selectable -- see the comment at the walk
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, true>), dim3(nb), dim3(128), occ_lds, s, a);
-  } else switch (refill_thresh(a.n)) {
-    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+  } else
+#endif
+  switch (refill_thresh(a.n)) {
+#ifdef TDTK_LAB
+    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 4, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+#endif
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 4, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
   }
-  if (a.trace) {
+  if (kLab && a.trace) {
     (void)hipStreamSynchronize(s);
     const uint32_t nw = std::min<uint32_t>(nb * 2u, WTRACE_MAX);
     std::vector<unsigned long long> h(3 * (size_t)nw);
@@ -2923,18 +3089,19 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   }
 }
 
+#ifdef TDTK_LAB
 // work-queue kernel: as many waves as stay resident (TDTK_STREAM_WPS per SIMD, default 7 = what the registers allow),
 // never more waves than there are slabs to draw
 static int stream_slab_env()
 {
-  const char* e = getenv("TDTK_STREAM_SLAB");
+  const char* e = lab_env("TDTK_STREAM_SLAB");
   int v = e ? atoi(e) : 256;
   if (v < 16) v = 16;
   return v;
 }
 static uint32_t stream_grid(size_t n)
 {
-  const char* e = getenv("TDTK_STREAM_WPS");
+  const char* e = lab_env("TDTK_STREAM_WPS");
   int wps = e ? atoi(e) : 4;
   if (wps < 1) wps = 1;
   if (wps > 8) wps = 8;
@@ -2969,6 +3136,8 @@ static void launch_step128(SearchArgs& a, hipStream_t s)
   }
 }
 
+#endif   // TDTK_LAB
+
 // a.fuse != 0 (only where search_can_fuse(a.n)): the base pair sums come out of the search itself, one row of
 // ACC_TOTAL per workgroup in a.partials (search_fused_rows(a.n) rows) -- follow with launch_final.
 hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, bool count, hipStream_t s)
@@ -2976,27 +3145,43 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
   if (a_in.n == 0) return hipSuccess;
   SearchArgs a = a_in;
   {
-    // the lane-group kernels can walk two tree levels per trip (KdFat) -- on request: measured slower here too
-    const char* e = getenv("TDTK_FAT_SMALL");
+    // the lane-group kernels can walk two tree levels per trip (KdFat) -- lab, on request: measured slower here too
+    const char* e = lab_env("TDTK_FAT_SMALL");
     if (!(e && e[0] == '1') && pick_variant(a.n) != 20) a.T.fat = nullptr;
   }
+  if (!kLab) { a.bounds = nullptr; a.trace = 0; }
   dim3 g(grid), b(SEARCH_BLOCK);
   if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 1, false, 1>), g, b, 0, s, a);
   else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
   else {
     const int v = pick_variant(a.n);
     if (a.fuse && !(v == 20 || ((v == 10 || v == 4) && !count))) return hipErrorInvalidValue;
+    // the product's three families: persistent lanes (20; sums by each wave over its own slab: FUSE 3), one query per
+    // lane (4), four lanes per query (10) -- and their instrumented instantiations
+    if (!kLab && v == 20 && !(a.fuse == 0 || a.fuse == 3)) return hipErrorInvalidValue;
+#ifdef TDTK_LAB
     if (v == 30 && (!a.q_ctr || !a.q_ctr_next)) return hipErrorInvalidValue;
+#endif
     if (count) {
       // the instrumented instantiation of whatever this batch would get: same traversal, same warm radius
-      if (v == 20) { if (a.fuse == 3) launch_refill128<true, 3>(a, s); else if (a.fuse == 2) launch_refill128<true, 2>(a, s); else if (a.fuse) launch_refill128<true, 1>(a, s); else launch_refill128<true, 0>(a, s); }
+      if (v == 20) {
+        if (a.fuse == 3) launch_refill128<true, 3>(a, s);
+#ifdef TDTK_LAB
+        else if (a.fuse == 2) launch_refill128<true, 2>(a, s);
+        else if (a.fuse) launch_refill128<true, 1>(a, s);
+#endif
+        else launch_refill128<true, 0>(a, s);
+      }
+#ifdef TDTK_LAB
       else if (v == 30) launch_stream128<true>(a, s);
       else if (v == 40) launch_step128<true, false>(a, s);
       else if (v == 41) launch_step128<true, true>(a, s);
+#endif
       else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, true, 0, false, 1>), g, b, 0, s, a);
       return hipGetLastError();
     }
     switch (v) {
+#ifdef TDTK_LAB
       case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
       case 8: {
         int qpw;
@@ -3009,14 +3194,22 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
       case 30: launch_stream128<false>(a, s); break;
       case 40: launch_step128<false, false>(a, s); break;
       case 41: launch_step128<false, true>(a, s); break;
-      case 20: if (a.fuse == 3) launch_refill128<false, 3>(a, s); else if (a.fuse == 2) launch_refill128<false, 2>(a, s); else if (a.fuse) launch_refill128<false, 1>(a, s); else launch_refill128<false, 0>(a, s); break;
       case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
       case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
+      case 11: hipLaunchKernelGGL((k_search_g8<256, 16, 16>), dim3(g8_grid(a.n) * 2), dim3(256), 0, s, a); break;
+#endif
+      case 20:
+        if (a.fuse == 3) launch_refill128<false, 3>(a, s);
+#ifdef TDTK_LAB
+        else if (a.fuse == 2) launch_refill128<false, 2>(a, s);
+        else if (a.fuse) launch_refill128<false, 1>(a, s);
+#endif
+        else launch_refill128<false, 0>(a, s);
+        break;
       case 10:
         if (a.fuse) hipLaunchKernelGGL((k_search_g8<256, 16, 4, true>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
         break;
-      case 11: hipLaunchKernelGGL((k_search_g8<256, 16, 16>), dim3(g8_grid(a.n) * 2), dim3(256), 0, s, a); break;
       default:
         if (a.fuse) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1, 4, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a);
@@ -3102,6 +3295,7 @@ __global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nod
   h.axis = ((nd.c1 >> 30) & 1u) | (((nd.c2 >> 30) & 1u) << 1);
   hot[i] = h;
 }
+#ifdef TDTK_LAB   // two tree levels per record: a measured negative (see the FAT walk in search_refill_body)
 __global__ void __launch_bounds__(256) k_make_fat(const KdNode* __restrict__ nodes, size_t n, KdFat* __restrict__ fat)
 {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -3129,6 +3323,7 @@ hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_
   hipLaunchKernelGGL(k_make_fat, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, fat);
   return hipGetLastError();
 }
+#endif   // TDTK_LAB
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s)
 {
   if (!n) return hipSuccess;
@@ -3232,7 +3427,7 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slab
   if (v == 10) { const uint32_t g = g8_grid(a.n) / 2; return g < 8 ? 8u : (g + 7) / 8 * 8; }
   int qpw;
   uint32_t nb = refill_grid_b(a.n, 128, &qpw, 2);
-  if (!getenv("TDTK_REFILL_QPW")) {
+  if (!lab_env("TDTK_REFILL_QPW")) {
     // (long_slabs: the waves add up their own slabs -- FUSE 5 -- so the slab length decides which queries share a row of
     // partial sums; one length for every launch then, however many links share it)
     const int want = (links_in_launch > 16 || long_slabs) ? 640 : 448;
@@ -3253,7 +3448,7 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slab
   // ends with a drain, and time goes the other way: 10.86 ms (1 piece), 10.85 (2), 11.01 (4), 11.42 (8).  Two pieces are
   // free; TDTK_LINK_PHASES overrides (pieces stay multiples of 16 queries).
   int ph = 2;
-  if (const char* e = getenv("TDTK_LINK_PHASES")) ph = atoi(e);
+  if (const char* e = lab_env("TDTK_LINK_PHASES")) ph = atoi(e);
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;
   a.phases = ph;
@@ -3275,25 +3470,29 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
   const dim3 g(total_blocks), b(128);
   if (count) {
     switch (thresh) {
-      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
-      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
-      default: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+#ifdef TDTK_LAB
+      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+#endif
+      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      default: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
     }
   } else {
     switch (thresh) {
+#ifdef TDTK_LAB
       case 8:
-        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
+#endif
       case 32:
-        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
       default:
-        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 1, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
     }
   }

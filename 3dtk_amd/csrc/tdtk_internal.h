@@ -1,5 +1,6 @@
 // Internal structures of lib3dtk_hip.so (not part of the C ABI).
 #pragma once
+#include <cstdlib>
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -70,6 +71,17 @@ static_assert(sizeof(KdFat) == 128, "KdFat must be 128 bytes");
 // pool.cpp: hipMalloc / hipFree for the arrays of trees and resident scans, with freed blocks kept for the next request
 // (declared with plain types so that host-only sources can include this header)
 int pool_malloc_raw(void** out, size_t bytes);   // 0 = success, else the hipError_t value
+// Product and lab.  The default build (`make`, lib3dtk_hip.so) holds what a slam6D run uses and reads nine environment
+// switches; `make LAB=1` (lib3dtk_hip_lab.so, -DTDTK_LAB) adds the kernels and policies that were
+// built, measured and lost (NEGATIVES.md) with the switches that select them -- the tests that compare those variants with
+// the product path load that library.  lab_env() is getenv() in the lab build and nothing in the product.
+#ifdef TDTK_LAB
+constexpr bool kLab = true;
+inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+constexpr bool kLab = false;
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
 void pool_free(void* p);
 size_t pool_trim();                              // gives every shelved block back to the driver; returns the bytes
 

@@ -348,7 +348,7 @@ def test_kernel_timing_is_opt_in_and_changes_nothing(tdtk, gpu):
         assert r[0] == runs[0][0] and np.array_equal(r[1], runs[0][1]) and np.array_equal(r[2], runs[0][2])
 
 
-def test_pair_sums_inside_the_search_launch_agree_with_k_accum(tdtk, gpu, monkeypatch):
+def test_pair_sums_inside_the_search_launch_agree_with_k_accum(tdtk, gpu, lab, monkeypatch):
     """From 256K queries up to one generation of resident waves the persistent-lane kernel's waves add up the base pair
     sums of their own slabs after their last query (FUSE 3, the default since round 3); TDTK_FUSE_SUMS=0 restores the
     separate k_accum pass.  Same hits, so the pair counts are equal exactly and the sums to rounding (the order of the
@@ -373,7 +373,7 @@ def test_pair_sums_inside_the_search_launch_agree_with_k_accum(tdtk, gpu, monkey
 
 
 @pytest.mark.parametrize("partial", [False, True])
-def test_expensive_queries_first_changes_nothing(tdtk, gpu, monkeypatch, partial):
+def test_expensive_queries_first_changes_nothing(tdtk, gpu, lab, monkeypatch, partial):
     """From the second ICP iteration on the persistent-lane kernel hands a wave's slab out with the queries first that
     visited most buckets in the previous pass (TDTK_COST_ORDER=0: in slab order).  Only the order in which a wave works
     through its own queries changes: every iteration's pair count, RMS and pose are the same bit for bit."""
@@ -699,7 +699,7 @@ def _stress_clouds(n, seed=12):
 
 
 @pytest.mark.parametrize("mode", ["", "1", "2"])
-def test_device_tree_build_piecewise_sum(tdtk, gpu, monkeypatch, mode):
+def test_device_tree_build_piecewise_sum(tdtk, gpu, lab, monkeypatch, mode):
     """Nodes of 8192 points and more get their left-to-right centroid sum piecewise (integer mantissa offsets per
     64-point piece, runs folded by a scan, exact walk where the sum changes binade).  The tree must stay the host
     builder's, record for record -- also when no folded run is trusted (mode 1) and when every piece is walked (2)."""
@@ -755,7 +755,7 @@ def test_batched_scan_moves_are_visible_to_every_thread(tdtk, orc, gpu):
         assert np.array_equal(got[k], want), k
 
 
-def test_lum_links_fused_into_the_search_agree(tdtk, gpu, monkeypatch):
+def test_lum_links_fused_into_the_search_agree(tdtk, gpu, lab, monkeypatch):
     """The ways a batch of lum6DEuler links is evaluated on big scans agree: all links in one launch
     (k_search_refill_multi) with k_accum_multi behind it (TDTK_LINK_FUSE=0) and one search + k_accum per link on three
     streams (TDTK_LINK_BATCH=0) -- bit for bit; the default since round 3, the sums added up inside that one launch by
@@ -1836,7 +1836,7 @@ def test_speculative_tree_build_and_its_fallback(gpu):
     import sys
     root = os.path.dirname(HERE)
     for fault, want in (("0", "0"), ("1", "+")):
-        env = dict(os.environ, TDTK_BUILD_SPEC_FAULT=fault)
+        env = dict(os.environ, TDTK_BUILD_SPEC_FAULT=fault, TDTK_LIB="lab")      # (the fault switch is a lab switch)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fault_probe.py")], cwd=root, env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -1870,7 +1870,32 @@ def test_handle_pool_reuses_and_releases(tdtk, orc, gpu):
     assert np.array_equal(np.where(idx0 >= 0, len(m) - 1 - idx1, -1), idx0) and np.array_equal(d0, d1)
 
 
-def test_alternative_search_kernels_agree(tdtk, orc, gpu, monkeypatch):
+def test_lab_library_default_path_is_the_products(tdtk, gpu):
+    """The lab library (tests of measured-and-lost variants run inside it) takes, without any of its switches set, the
+    product's path: indices, squared distances, pair sums and an ICP loop's poses are bit-identical between
+    lib3dtk_hip.so and lib3dtk_hip_lab.so -- on a batch for each kernel family (four lanes per query, one query per
+    lane, persistent lanes with the sums inside the launch)."""
+    from importlib import import_module
+    capi = import_module("3dtk_amd._capi")
+    rng = np.random.default_rng(123)
+    for npts in (30000, 150000, 300000):
+        m = rng.uniform(-300, 300, (npts, 3)); m[100:300] = m[0:200]
+        d = m[rng.permutation(npts)] + rng.normal(0, 0.5, m.shape) + np.array([2.0, -1.5, 1.0])
+        out = []
+        for name in ("product", "lab"):
+            with capi.library(name):
+                S0 = tdtk.Scan([0, 0, 0], [0, 0, 0], m); S1 = tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+                r = tdtk.Scan.getPtPairs(S0, S1, 0, 0, 100.0, 0, 0, want_idx=True)
+                icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 6, quiet=True, epsilonICP=-1.0)
+                it = icp.match(S0, S1)
+                out.append((r["idx"].copy(), r["n"], r["sum"], np.asarray(r["Si"]).copy(), it, icp.last["trace"].copy(), S1.get_transMat().copy()))
+                S0.release(); S1.release()
+        a, b = out
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3]), npts
+        assert a[4] == b[4] and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]), npts
+
+
+def test_alternative_search_kernels_agree(tdtk, orc, gpu, lab, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
     other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane) walk the same tree the
     same way: identical indices, pair sums equal to rounding, and the instrumented instantiations count the same

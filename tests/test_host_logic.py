@@ -868,29 +868,49 @@ def test_product_and_bench_keep_clear_of_the_oracle():
         assert fn == "cpu_baseline_nn" or "no_cpu" in ctx[ctx.rfind("if "):], (fn, m.group(0))
 
 
-def test_timed_search_kernels_keep_four_waves_per_simd_and_spill_nothing():
-    """The persistent-lane search kernel of the ICP loop holds a whole bucket's fp32 shadow groups in registers (round 3:
-    one round trip per bucket): ~122 vector registers, i.e. four waves per SIMD, which is what its launches are sized for
-    (refill_qpw).  More than 128 would halve that.  No spills of either kind: round 2 shipped 80 spilled SGPRs here (the
-    by-value argument block hoisted into registers, every use a v_readlane); the block is read through the kernarg
-    pointer where it is used now.  The build keeps the compiler's resource remarks; this reads them."""
+def test_every_product_kernel_spills_nothing_and_search_kernels_keep_four_waves():
+    """The resource remarks of the PRODUCT build (csrc/Makefile keeps them for kernels.hip: every search, pair-sum,
+    transform and layout kernel lib3dtk_hip.so can launch; the lab library's extra kernels are not in this file).
+    Every kernel: no VGPR spills, no SGPR spills.  Every search kernel: no scratch at all (until round 4 each carried 32
+    bytes per lane for the call frames of the stack-overflow helpers) and, for the persistent-lane kernels -- which hold a
+    whole bucket's fp32 shadow groups in registers --, at most 128 vector registers = four waves per SIMD, which is what
+    their launches are sized for.  Also: none of the lab kernels is in the product (k_search_step, k_search_coop, the
+    work-queue / FAT / PROBE instantiations, k_slab_bounds)."""
     import re
     path = os.path.join(ROOT, "3dtk_amd", "csrc", "kernels.resource.txt")
     if not os.path.exists(path):
         pytest.skip("no build in this tree (kernels.resource.txt is written by the Makefile)")
     text = open(path).read()
-    kernels = {
-        "_ZN4tdtk15k_search_refillILi128ELi4ELi16ELi1ELb0ELi0ELb0ELi4ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, false>",
-        "_ZN4tdtk15k_search_refillILi128ELi4ELi32ELi1ELb0ELi0ELb0ELi4ELi0ELb0EEEvNS_10SearchArgsE": "k_search_refill<128, 4, 32, 1, false, 0, false, 4, 0, false>",
-        "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0ELb0EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0, false>",
-        "_ZN4tdtk21k_search_refill_multiILi128ELi4ELi16ELi1ELb0ELi0ELb1EEEvPKNS_10SearchArgsEPKji": "k_search_refill_multi<128, 4, 16, 1, false, 0, true> (ordered hand-out: the link passes' default)",
-    }
-    for mangled, name in kernels.items():
-        i = text.find("Function Name: " + mangled + " ")
-        assert i >= 0, "no resource remark for " + name
-        block = text[i:i + 1500]
-        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block).group(1))
-        vg = int(re.search(r"VGPRs: (\d+)", block).group(1))
-        spill = int(re.search(r"VGPRs Spill: (\d+)", block).group(1))
-        sspill = int(re.search(r"SGPRs Spill: (\d+)", block).group(1))
-        assert occ >= 4 and vg <= 128 and spill == 0 and sspill == 0, (name, occ, vg, spill, sspill)
+    for other in ("build", "sort", "reduce", "ann"):      # the tree build, the orderings, the octree reduction, the normals
+        po = os.path.join(ROOT, "3dtk_amd", "csrc", other + ".resource.txt")
+        assert os.path.exists(po), po
+        text += open(po).read()
+    blocks = text.split("remark: Function Name: ")[1:]
+    assert len(blocks) > 100
+    seen_refill = 0
+    for b in blocks:
+        name = b.split()[0]
+        def num(key):
+            m = re.search(key + r": (\d+)", b)
+            assert m, (name, key)
+            return int(m.group(1))
+        assert num("VGPRs Spill") == 0, name
+        # scalar spills (into lanes of a vector register, not to memory) are left in two kernel families, by name and with
+        # their present counts as caps: k_big_stitch -- one wave per (node, axis) walks the exact centroid chain and keeps
+        # its whole walk state wave-uniform --, and k_ann_normals<K> -- the ANN priority search keeps its K-best bookkeeping
+        # scalar (K = 10 is what Scan::calcNormals uses; 16 / 32 exist for tdtk_normals_apx_knn callers)
+        cap = 0
+        if "k_big_stitch" in name: cap = 40
+        m_ann = re.search(r"k_ann_normalsILi(\d+)E", name)
+        if m_ann: cap = {10: 10, 16: 16, 32: 142}.get(int(m_ann.group(1)), 0)
+        assert num("SGPRs Spill") <= cap, (name, num("SGPRs Spill"))
+        if "k_search" in name:
+            assert num(r"ScratchSize \[bytes/lane\]") == 0, name
+        if "k_search_refill" in name:
+            seen_refill += 1
+            assert num("VGPRs") <= 128 and num(r"Occupancy \[waves/SIMD\]") >= 4, name
+        for lab_only in ("k_search_step", "k_search_coop", "k_slab_bounds", "k_make_fat"):
+            assert lab_only not in name, name
+        if "k_search_refillI" in name:      # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, PTS, PROBE, FAT>: product = FUSE 0 / 3, static slabs, plain walk
+            assert re.search(r"ELb[01]ELi[03]ELb0ELi4ELi0ELb0EEE", name), name
+    assert seen_refill >= 12
