@@ -142,6 +142,7 @@ struct Ctx {
   std::vector<std::unique_ptr<Lane>> slots;   // per-link buffers of a several-links-in-one-launch batch (no streams)
   std::vector<std::unique_ptr<LinkCost>> link_costs;
   DevBuf multi_args;                          // its argument tables on the device
+  std::vector<void*> free_later;              // see pool_free_later
   QueueCtr qc;       // for launches on `stream` (a caller's stream gets its launches ordered behind it, see run_search)
   // slabs of equal cost for the next pass of an ICP loop (launch_slab_bounds): valid for the loop's next scan_pass only
   const uint32_t* next_bounds = nullptr;
@@ -181,6 +182,8 @@ Ctx::~Ctx()
     if (device >= 0) (void)hipSetDevice(device);
     wait_deferred(device, this);
     if (e_defer) (void)hipEventDestroy(e_defer);
+    for (void* q : free_later) pool_free(q);
+    free_later.clear();
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_moves) (void)hipHostFree(h_moves);
     if (e_moves) (void)hipEventDestroy(e_moves);
@@ -262,6 +265,14 @@ static int defer_fence(Ctx* c)
   if (!have) g_defer.push_back({c->device, c->e_defer, c});
   g_defer_n.store((int)g_defer.size(), std::memory_order_release);
   return TDTK_OK;
+}
+
+// blocks an enqueued kernel still reads: given back behind the next synchronisation of the context's stream
+static void pool_free_later(Ctx* c, void* p) { if (p) c->free_later.push_back(p); }
+static void flush_free_later(Ctx* c)
+{
+  for (void* p : c->free_later) pool_free(p);
+  c->free_later.clear();
 }
 
 // pinned host staging that stays valid until the next library call on this thread (get_ctx has then waited for the
@@ -458,10 +469,9 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   if ((rc = c->ws[WS_BOX].ensure(bbox_temp_bytes() + 8 * sizeof(double)))) return rc;
   double* d_box = c->ws[WS_BOX].as<double>();
   // root bounding box (binning of unsorted query batches, accumulation shift): min / max on the device
+  // (read back behind the build: the build's own looks at the device are the next synchronisation points)
   HIPCHK(launch_bbox(c->ws[WS_TMPA].as<double>(), M, d_box + 8, d_box, c->stream));
-  HIPCHK(hipMemcpyAsync(c->h_pin, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[a]; t->bbmax[a] = c->h_pin[3 + a]; }
+  HIPCHK(hipMemcpyAsync(c->h_pin + 128, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   const double t1 = now_ms();
   t->info.upload_ms = t1 - t0;
   const bool alone = g_ctx_live.load() <= 2;
@@ -488,6 +498,7 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
                            : std::string("device tree build: ") + hipGetErrorString(r.err));
     return r.degenerate ? TDTK_EINVAL : TDTK_EDEVICE;
   }
+  for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[128 + a]; t->bbmax[a] = c->h_pin[128 + 3 + a]; }   // (the build has synchronised the stream)
   t->d_nodes = r.nodes; t->d_r = r.node_r; t->d_pts = r.pts;
   t->d_leaf = r.leaf_tab;   // non-null only in table mode
   t->dev.root_ref = r.root_ref;
@@ -521,7 +532,27 @@ static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
   LeafEntry* leaf = static_cast<LeafEntry*>(t->d_leaf);
   HIPCHK(launch_pad_mark(nodes, t->info.n_internal, leaf, cb, cmask, ng_at, M, c->stream));
   HIPCHK(launch_scan_u32(ng_at, g_at, n1, tmp, tmpb, c->stream));
+  // The number of groups is known on the device; every bucket is padded by at most three slots, so (M + 3 leaves) / 4 groups
+  // are enough room.  When that bound passes the format checks below, the fill is enqueued right away and the exact count is
+  // read with it -- one look at the device less (a small scan's tree is a few dozen microseconds of launches per look).
   uint32_t G = 0;
+  const uint64_t G_bound = ((uint64_t)M + 3ull * t->info.n_leaves + 3ull) / 4ull;
+  const bool bound_ok = (4ull * G_bound) * sizeof(KdPoint) < (1ull << 32) && (leaf || ((4ull * G_bound) << cb) <= (uint64_t)REF_VAL);
+  if (bound_ok) {
+    void *ptsB = nullptr, *grpB = nullptr;
+    if (handle_malloc(&ptsB, 4ull * G_bound * sizeof(KdPoint)) == hipSuccess && handle_malloc(&grpB, (size_t)G_bound * 48) == hipSuccess) {
+      hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
+                                     static_cast<KdPoint*>(ptsB), static_cast<float4*>(grpB), c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(c->h_pin + 140, g_at + M, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      if (e != hipSuccess) { pool_free(ptsB); pool_free(grpB); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
+      pool_free_later(c, t->d_pts);
+      t->d_pts = ptsB; t->d_grp = grpB;
+      t->Mp = 0;                 // = 4 G, read in tree_finish behind its synchronisation
+      return TDTK_OK;
+    }
+    (void)hipGetLastError();
+    if (ptsB) pool_free(ptsB);
+  }
   HIPCHK(hipMemcpyAsync(&G, g_at + M, sizeof G, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   const uint64_t slots = 4ull * G;
@@ -569,6 +600,13 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
 #endif
     HIPCHK(hipStreamSynchronize(c->stream));
   }
+  if (t->d_grp && t->Mp == 0) {        // the padded layout was filled without a look of its own: its size now
+    if (!t->info.n_internal) HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t G = 0;
+    std::memcpy(&G, c->h_pin + 140, sizeof G);
+    t->Mp = 4ull * G;
+  }
+  flush_free_later(c);
   t->dev.hot = static_cast<const KdHot*>(t->d_hot);
   t->dev.fat = static_cast<const KdFat*>(t->d_fat);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);

@@ -1307,6 +1307,435 @@ __global__ void k_pack_refs(KdNode* __restrict__ nodes, uint32_t nnodes, const L
   if (i == 0) *root_ref = pack(*root_ref);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Subtrees finished by ONE workgroup each (round 4).
+// Level by level, every level of the tree is ~9 dependent launches (measure, decide / rank / emit, count, mark, scan,
+// swap list, swap + relabel), and below the top few levels a launch has nothing to do but wait for the one before it:
+// an 81K-point scan spent 0.93 of its 1.75 ms on levels 5 .. 18, a 1M-point cloud 1.0 of 2.4 ms on levels 9 .. 18.  From
+// the level on at which a balanced node holds at most FIN_HANDOFF points, every node of that level is handed to one
+// workgroup, which runs the SAME passes over the node's own stretch of the arrays -- the points of a node never leave
+// its stretch, so every per-position and per-node array of the arena has a private slice [start, start + n) for it --
+// with a workgroup barrier where the level-by-level build has a launch, down to the last bucket.  Same measure (the
+// left-to-right fp64 sum, one wave per (node, axis)), same decisions (decide_node), same records (emit_node), same
+// partition (k-th misplaced from the left swaps with the k-th from the right end): the same tree, record for record
+// (tdtk_tree_verify compares it with the host builder's).
+// The records of a subtree go to a staging area (the slice again) level by level; what their breadth-first indices are
+// depends on the other subtrees (node i of a level = the internal nodes of that level to the left of it), so two small
+// launches follow: per level and subtree the counts to the left (k_fin_offsets), then every subtree copies its records
+// to their final indices with the child references translated (k_fin_place).
+// ------------------------------------------------------------------------------------------------------------------
+#define FIN_T 512u             // threads of a subtree's workgroup (eight waves: 256 vector registers each)
+#define FIN_LV 96u             // levels a subtree may have; deeper (a pathological cloud): the build is redone level by level
+#define FIN_HANDOFF 2048u      // hand a level over when a balanced node of it holds at most this many points (and the largest fits FIN_LDS)
+#define FIN_MAX_SUBTREES 8192u
+#define FIN_LONG_MAX 512u      // long runs of a level a subtree lists for its waves
+#define FIN_LANE_RUN 192u      // runs up to this long are measured by one lane each (k_fin_subtrees), longer ones by a wave
+struct FinTab {
+  uint32_t ib[FIN_LV + 2], lb[FIN_LV + 2];   // where the subtree's internal nodes / buckets of local level l start in the staging slice
+  uint32_t nlev;                             // local levels that hold nodes
+  uint32_t root_ref;                         // staged reference of the subtree's root
+  uint32_t s0, n;
+};
+struct FinOff {                              // k_fin_offsets -> k_fin_place
+  uint32_t io[FIN_LV + 2], lo[FIN_LV + 2];   // global index of the subtree's first internal node / bucket of local level l
+};
+
+// exclusive scan of `count` 32-bit values in[0 .. count) -> out[0 .. count], out[count] = total, by one workgroup of FIN_T threads
+__device__ __forceinline__ uint32_t fin_scan_u32(const uint32_t* in, uint32_t* out, uint32_t count, uint32_t* s_w /*[17]*/)
+{
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < count; base += FIN_T) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = (i < count) ? in[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off, WAVE); if ((int)lane >= off) inc += t; }
+    if (lane == WAVE - 1) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t before = carry, tile = 0;
+    for (uint32_t w = 0; w < FIN_T / WAVE; w++) { if (w < wv) before += s_w[w]; tile += s_w[w]; }
+    if (i < count) out[i] = before + inc - v;
+    carry += tile;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[count] = carry;
+  return carry;
+}
+// the same over 64-bit words that hold two counts (left-misplaced | right-misplaced << 32)
+__device__ __forceinline__ unsigned long long fin_scan_u64(const unsigned long long* in, unsigned long long* out, uint32_t count,
+                                                           unsigned long long* s_w /*[16]*/)
+{
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  unsigned long long carry = 0;
+  for (uint32_t base = 0; base < count; base += FIN_T) {
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = (i < count) ? in[i] : 0ull;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up((long long)inc, off, WAVE); if ((int)lane >= off) inc += t; }
+    if (lane == WAVE - 1) s_w[wv] = inc;
+    __syncthreads();
+    unsigned long long before = carry, tile = 0;
+    for (uint32_t w = 0; w < FIN_T / WAVE; w++) { if (w < wv) before += s_w[w]; tile += s_w[w]; }
+    if (i < count) out[i] = before + inc - v;
+    carry += tile;
+    __syncthreads();
+  }
+  return carry;
+}
+
+#define FIN_LDS 3584u          // points a subtree may hold: its coordinates, labels, partition scratch and node table live in LDS
+#define FIN_SEGS 1024u         // nodes a level of a subtree may have: <= 2 FIN_LDS / (bucket + 1), hence bucket >= 6 (the host checks)
+#define FIN_K ((FIN_LDS + FIN_T - 1) / FIN_T)
+struct FinArgs {
+  const BSeg* roots; const BLevel* lvH;
+  double *cx, *cy, *cz; uint32_t* perm;
+  BSeg *segA, *segB; BMeas* meas;
+  uint32_t *kind, *axis; double* splitval; uint32_t *irank, *nleft;
+  KdNode* nodes_st; double* r_st; LeafEntry* leaf_st;
+  FinTab* tab; uint32_t bucket; uint32_t* small;
+};
+// (a kernel's by-value argument block read through the kernarg segment pointer: see kernarg_block in kernels.hip)
+template <class T>
+__device__ __forceinline__ const T& build_kernarg_block()
+{
+  typedef const T __attribute__((address_space(4))) * kernarg_ptr;
+  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const T*)p;
+}
+
+// One subtree, root to buckets, by one workgroup.  Coordinates, labels (which node of the current level a position belongs
+// to), the partition's scratch and the level's node table are in LDS; the node / bucket records and the per-node arrays
+// decide_node / emit_node / children_of work on are the subtree's slices of the arena's arrays (start .. start + n).
+// Thread k owns the FIN_K consecutive local positions from k FIN_K.
+__global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value)
+{
+  (void)A_by_value;
+  const FinArgs& A = build_kernarg_block<FinArgs>();
+  __shared__ alignas(16) double X[FIN_LDS + 16], Y[FIN_LDS + 16], Z[FIN_LDS + 16];
+  __shared__ uint16_t lab[FIN_LDS];                 // node of the current level, 0xFFFF: already in a bucket
+  __shared__ uint32_t ab[FIN_LDS];                  // bit 31 / 30: misplaced on the left / right; bits 0-11 / 12-23: how many before
+  __shared__ uint16_t pl[FIN_LDS / 2 + 1], pr[FIN_LDS / 2 + 1];
+  __shared__ double m_sv[FIN_SEGS];
+  __shared__ uint16_t m_start[FIN_SEGS], m_cnt[FIN_SEGS], m_ir[FIN_SEGS];
+  __shared__ uint32_t m_nl[FIN_SEGS];
+  __shared__ unsigned char m_kind[FIN_SEGS], m_ax[FIN_SEGS];
+  __shared__ BLevel lvl2[2];
+  __shared__ uint32_t s_w32[FIN_T / WAVE + 1];
+  __shared__ uint32_t s_tot[2], s_root, s_nlong, s_maxleaf;
+  __shared__ uint32_t s_long[FIN_LONG_MAX];
+  const uint32_t t = blockIdx.x;
+  if (t >= A.lvH->nseg) return;
+  const BSeg root = A.roots[t];
+  const uint32_t s0 = root.start, n = root.n;
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  uint32_t* small = A.small;
+  if (n > FIN_LDS) {     // (the host hands a level over only when its largest node fits; a node that does not is a bug there)
+    if (threadIdx.x == 0) atomicOr(small + 2, 0x20000u);
+    return;
+  }
+  BSeg* segs = A.segA + s0; BSeg* next = A.segB + s0;
+  BMeas* ms = A.meas + s0;
+  // (kind and irank hold one entry more than the level has nodes -- the scan's total --: arrays of their own, every
+  // subtree's slice shifted by its index)
+  uint32_t *kd = A.kind + s0 + t, *ax = A.axis + s0, *ir = A.irank + s0 + t, *nl = A.nleft + s0;
+  double* sv = A.splitval + s0;
+  for (uint32_t i = threadIdx.x; i < n; i += FIN_T) { X[i] = A.cx[s0 + i]; Y[i] = A.cy[s0 + i]; Z[i] = A.cz[s0 + i]; lab[i] = 0; }
+  if (threadIdx.x == 0) {
+    segs[0] = {s0, n, -1, 0u};                    // (no parent here: k_fin_place hooks the root into the level above)
+    lvl2[0] = {1u, s0, s0};                       // staged records of this subtree start at its own slice
+    s_root = 0u; s_maxleaf = 0u;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t i_lo = threadIdx.x * FIN_K, i_hi = (i_lo + FIN_K < n) ? i_lo + FIN_K : n;     // this thread's positions
+  uint32_t lev = 0;
+  unsigned long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  const bool timing = kLab && t == 0 && threadIdx.x == 0 && small[15] == 0x7157u;      // (lab: TDTK_BUILD_TRACE=2)
+  auto tick = [&](int k) { if (timing) { const unsigned long long now = wall_clock64(); tph[k] += now - tlast; tlast = now; } };
+  if (timing) tlast = wall_clock64();
+  for (;; lev++) {
+    const uint32_t nseg = lvl2[0].nseg;
+    if (threadIdx.x == 0 && lev <= FIN_LV + 1u) { A.tab[t].ib[lev] = lvl2[0].node_base; A.tab[t].lb[lev] = lvl2[0].leaf_base; }
+    if (nseg == 0 || lev > FIN_LV || nseg > FIN_SEGS) break;
+    // (0) the level's runs into the node table
+    for (uint32_t i = threadIdx.x; i < nseg; i += FIN_T) { const BSeg sg = segs[i]; m_start[i] = (uint16_t)(sg.start - s0); m_cnt[i] = (uint16_t)sg.n; }
+    if (threadIdx.x == 0) s_nlong = 0u;
+    __syncthreads();
+    // (1) measure.  Short runs (the many nodes of the deeper levels): one LANE per (node, axis) walks its run alone, four
+    // reads ahead of the adds; long runs: one wave per (node, axis) -- the bounding box by all lanes, the left-to-right fp64
+    // sum (kdTreeImpl.h:94-111) by lane 0, sixteen reads ahead of the adds.
+    for (uint32_t item = threadIdx.x; item < 3u * nseg; item += FIN_T) {
+      const uint32_t sgi = item / 3u, a3 = item % 3u;
+      const uint32_t st = m_start[sgi], cnt_n = m_cnt[sgi];
+      if (cnt_n > FIN_LANE_RUN) {
+        const uint32_t slot = atomicAdd(&s_nlong, 1u);       // (at most 3 FIN_LDS / FIN_LANE_RUN of them)
+        s_long[slot] = item;
+        continue;
+      }
+      const double* __restrict__ arr = ((a3 == 0) ? X : ((a3 == 1) ? Y : Z)) + st;
+      double sum = arr[0];                               // the sum starts from the first point ...
+      double lo = sum, hi = sum;
+      uint32_t k = 1;
+      for (; k + 4 <= cnt_n; k += 4) {                   // ... and adds the rest in order
+        const double v0 = arr[k], v1 = arr[k + 1], v2 = arr[k + 2], v3 = arr[k + 3];
+        sum += v0; sum += v1; sum += v2; sum += v3;
+        const double mn = fmin(fmin(v0, v1), fmin(v2, v3)), mx = fmax(fmax(v0, v1), fmax(v2, v3));
+        lo = (mn < lo) ? mn : lo; hi = (hi < mx) ? mx : hi;
+      }
+      for (; k < cnt_n; k++) { const double v = arr[k]; sum += v; lo = (v < lo) ? v : lo; hi = (hi < v) ? v : hi; }
+      ms[sgi].lo[a3] = lo; ms[sgi].hi[a3] = hi; ms[sgi].mean[a3] = sum / (double)cnt_n;
+    }
+    __syncthreads();
+    for (uint32_t li = wv; li < s_nlong; li += FIN_T / WAVE) {
+      const uint32_t item = s_long[li];
+      const uint32_t sgi = item / 3u, a3 = item % 3u;
+      const uint32_t st = m_start[sgi], cnt_n = m_cnt[sgi];
+      const double* __restrict__ arr = ((a3 == 0) ? X : ((a3 == 1) ? Y : Z)) + st;
+      const double first = arr[0];
+      double lo = first, hi = first, sum = first;       // the sum starts from the first point
+      for (uint32_t k = lane; k < cnt_n; k += WAVE) { const double v = arr[k]; lo = (v < lo) ? v : lo; hi = (hi < v) ? v : hi; }
+      if (lane == 0) {
+        uint32_t k = 1;                                  // ... and adds the rest in order
+        for (; k + 16 <= cnt_n; k += 16) {
+          double r[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) r[q] = arr[k + q];
+#pragma unroll
+          for (int q = 0; q < 16; q++) sum += r[q];
+        }
+        for (; k < cnt_n; k++) sum += arr[k];
+      }
+      lo = wave_min(lo); hi = wave_max(hi);
+      if (lane == 0) { ms[sgi].lo[a3] = lo; ms[sgi].hi[a3] = hi; ms[sgi].mean[a3] = sum / (double)cnt_n; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    tick(1);
+    // (2) leaf or internal, axis, split value (one more entry, zero: the rank scan's total)
+    for (uint32_t i = threadIdx.x; i <= nseg; i += FIN_T) decide_node(segs, &lvl2[0], nseg, ms, A.bucket, kd, ax, sv, nl, i);
+    __threadfence_block();
+    __syncthreads();
+    tick(2);
+    // (3) rank of every internal node among the level's
+    (void)fin_scan_u32(kd, ir, nseg, s_w32);
+    __threadfence_block();
+    __syncthreads();
+    tick(3);
+    // (4) records into the staging slice, children hooked into their (staged) parents; lvl2[1] = the next level; the
+    // decisions into the node table
+    for (uint32_t i = threadIdx.x; i < nseg || i == 0; i += FIN_T) {
+      emit_node(segs, &lvl2[0], ms, kd, ax, sv, ir, A.nodes_st, A.r_st, A.leaf_st, &s_root, &s_maxleaf, i);   // (largest bucket: per subtree first)
+      if (i < nseg) { m_kind[i] = (unsigned char)kd[i]; m_ax[i] = (unsigned char)ax[i]; m_sv[i] = sv[i]; m_ir[i] = (uint16_t)ir[i]; m_nl[i] = 0u; }
+    }
+    __syncthreads();
+    // (5) how many points of each internal node lie below its split value (one LDS atomic per run a thread's positions touch)
+    {
+      uint32_t pend = 0xFFFFFFFFu, pcnt = 0;
+      for (uint32_t i = i_lo; i < i_hi; i++) {
+        const uint32_t sg = lab[i];
+        if (sg == 0xFFFFu || !m_kind[sg]) continue;
+        const uint32_t a3 = m_ax[sg];
+        const double c = (a3 == 0) ? X[i] : ((a3 == 1) ? Y[i] : Z[i]);
+        const uint32_t lt = (c < m_sv[sg]) ? 1u : 0u;
+        if (sg != pend) { if (pend != 0xFFFFFFFFu && pcnt) atomicAdd(&m_nl[pend], pcnt); pend = sg; pcnt = lt; }
+        else pcnt += lt;
+      }
+      if (pend != 0xFFFFFFFFu && pcnt) atomicAdd(&m_nl[pend], pcnt);
+    }
+    __syncthreads();
+    tick(4);
+    // (6) misplaced on the left / on the right of the split position, counted per thread; the children's runs
+    uint32_t mineL = 0, mineR = 0;
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      uint32_t l = 0, r = 0;
+      const uint32_t sg = lab[i];
+      if (sg != 0xFFFFu && m_kind[sg]) {
+        const uint32_t a3 = m_ax[sg];
+        const double c = (a3 == 0) ? X[i] : ((a3 == 1) ? Y[i] : Z[i]);
+        const bool f = c < m_sv[sg];
+        const bool left_region = (i - m_start[sg]) < m_nl[sg];
+        l = (left_region && !f) ? 1u : 0u;
+        r = (!left_region && f) ? 1u : 0u;
+      }
+      ab[i] = (l << 31) | (r << 30) | mineL | (mineR << 12);     // counts before i within this thread's positions
+      mineL += l; mineR += r;
+    }
+    for (uint32_t i = threadIdx.x; i < nseg; i += FIN_T) { nl[i] = m_nl[i]; children_of(segs, &lvl2[0], kd, ir, nl, next, small + 2, i); }
+    // (7) both running counts over the threads (packed: left | right << 16)
+    {
+      const uint32_t v = mineL | (mineR << 16);
+      uint32_t inc = v;
+#pragma unroll
+      for (int off = 1; off < WAVE; off <<= 1) { const uint32_t tt = __shfl_up(inc, off, WAVE); if ((int)lane >= off) inc += tt; }
+      if (lane == WAVE - 1) s_w32[wv] = inc;
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+      for (uint32_t w = 0; w < FIN_T / WAVE; w++) { if (w < wv) before += s_w32[w]; total += s_w32[w]; }
+      before += inc - v;
+      if (threadIdx.x == 0) { s_tot[0] = total & 0xFFFFu; s_tot[1] = total >> 16; }
+      const uint32_t bl = before & 0xFFFFu, br = before >> 16;
+      for (uint32_t i = i_lo; i < i_hi; i++) ab[i] += bl | (br << 12);
+    }
+    __threadfence_block();
+    __syncthreads();
+    tick(6);
+    // (8) the k-th misplaced from the left pairs with the k-th misplaced from the right end of its node
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      const uint32_t w = ab[i];
+      if (w >> 31) pl[w & 0xFFFu] = (uint16_t)i;
+      if ((w >> 30) & 1u) {
+        const uint32_t sg = lab[i];
+        const uint32_t st = m_start[sg], cn = m_cnt[sg];
+        const uint32_t Bs = (ab[st] >> 12) & 0xFFFu;
+        const uint32_t Be = (st + cn < n) ? ((ab[st + cn] >> 12) & 0xFFFu) : s_tot[1];
+        const uint32_t kfwd = ((w >> 12) & 0xFFFu) - Bs;
+        pr[Bs + ((Be - Bs) - 1u - kfwd)] = (uint16_t)i;
+      }
+    }
+    __syncthreads();
+    tick(7);
+    // (9) swap (coordinates here, the permutation in memory), relabel
+    for (uint32_t c = threadIdx.x; c < s_tot[0]; c += FIN_T) {
+      const uint32_t a = pl[c], b = pr[c];
+      const uint32_t pa = A.perm[s0 + a], pb = A.perm[s0 + b];
+      A.perm[s0 + a] = pb; A.perm[s0 + b] = pa;
+      double tv;
+      tv = X[a]; X[a] = X[b]; X[b] = tv;
+      tv = Y[a]; Y[a] = Y[b]; Y[b] = tv;
+      tv = Z[a]; Z[a] = Z[b]; Z[b] = tv;
+    }
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      const uint32_t sg = lab[i];
+      if (sg == 0xFFFFu) continue;
+      if (!m_kind[sg]) { lab[i] = 0xFFFFu; continue; }
+      lab[i] = (uint16_t)(2u * m_ir[sg] + (((i - m_start[sg]) < m_nl[sg]) ? 0u : 1u));
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) { lvl2[0] = lvl2[1]; lvl2[1] = {0u, 0u, 0u}; }
+    BSeg* tsw = segs; segs = next; next = tsw;
+    __syncthreads();
+    tick(8);
+  }
+  if (timing) for (int k = 0; k < 10; k++) small[16 + k] = (uint32_t)tph[k];
+  for (uint32_t i = threadIdx.x; i < n; i += FIN_T) { A.cx[s0 + i] = X[i]; A.cy[s0 + i] = Y[i]; A.cz[s0 + i] = Z[i]; }
+  if (threadIdx.x == 0) {
+    A.tab[t].nlev = lev;
+    A.tab[t].root_ref = s_root;
+    A.tab[t].s0 = s0; A.tab[t].n = n;
+    atomicMax(small + 1, s_maxleaf);
+    if (lvl2[0].nseg != 0) atomicOr(small + 2, 0x20000u);     // deeper than the tables, or a level wider than the node table: redo level by level
+  }
+}
+
+// the largest node of the level that is about to be handed over (the host hands it over only if that one fits FIN_LDS)
+__global__ void __launch_bounds__(256) k_fin_maxn(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t* __restrict__ out)
+{
+  __shared__ uint32_t s_m;
+  if (threadIdx.x == 0) s_m = 0u;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t i = threadIdx.x; i < lv->nseg; i += 256u) m = max(m, segs[i].n);
+  atomicMax(&s_m, m);
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = s_m; out[1] = lv->nseg; }
+}
+
+// per level (one workgroup each): how many internal nodes / buckets the subtrees to the left hold, and the level's totals
+__global__ void __launch_bounds__(256) k_fin_offsets(const FinTab* __restrict__ tab, FinOff* __restrict__ off, const BLevel* __restrict__ lvH,
+                                                     uint32_t* __restrict__ totals /*[2][FIN_LV + 2]*/)
+{
+  const uint32_t T = lvH[0].nseg, l = blockIdx.x;
+  __shared__ uint32_t s_w[256 / WAVE][2];
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  uint32_t carry_i = 0, carry_l = 0;
+  for (uint32_t base = 0; base < T; base += 256u) {
+    const uint32_t t = base + threadIdx.x;
+    uint32_t ci = 0, cl = 0;
+    if (t < T && l < tab[t].nlev) { ci = tab[t].ib[l + 1] - tab[t].ib[l]; cl = tab[t].lb[l + 1] - tab[t].lb[l]; }
+    uint32_t ii = ci, il = cl;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const uint32_t a = __shfl_up(ii, o, WAVE), b = __shfl_up(il, o, WAVE);
+      if ((int)lane >= o) { ii += a; il += b; }
+    }
+    if (lane == WAVE - 1) { s_w[wv][0] = ii; s_w[wv][1] = il; }
+    __syncthreads();
+    uint32_t bi = carry_i, bl = carry_l, ti = 0, tl = 0;
+    for (uint32_t w = 0; w < 256 / WAVE; w++) { if (w < wv) { bi += s_w[w][0]; bl += s_w[w][1]; } ti += s_w[w][0]; tl += s_w[w][1]; }
+    if (t < T) { off[t].io[l] = bi + ii - ci; off[t].lo[l] = bl + il - cl; }      // relative to the level's first (k_fin_place adds that)
+    carry_i += ti; carry_l += tl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { totals[l] = carry_i; totals[FIN_LV + 2 + l] = carry_l; }
+}
+
+// every subtree's staged records to their breadth-first places; subtree 0 also leaves the levels' counters for the host
+__global__ void __launch_bounds__(256) k_fin_place(const FinTab* __restrict__ tab, const FinOff* __restrict__ off,
+                                                   const uint32_t* __restrict__ totals, const BSeg* __restrict__ roots,
+                                                   BLevel* __restrict__ lvH, const KdNode* __restrict__ nodes_st,
+                                                   const double* __restrict__ r_st, const LeafEntry* __restrict__ leaf_st,
+                                                   KdNode* __restrict__ nodes, double* __restrict__ node_r,
+                                                   LeafEntry* __restrict__ leaf_tab, uint32_t* __restrict__ root_ref)
+{
+  const uint32_t t = blockIdx.x;
+  if (t >= lvH->nseg) return;
+  __shared__ FinTab T;
+  __shared__ FinOff O;
+  __shared__ uint32_t nb[FIN_LV + 2], lb[FIN_LV + 2];       // the levels' first node / bucket indices
+  for (uint32_t k = threadIdx.x; k < sizeof(FinTab) / 4; k += 256u) reinterpret_cast<uint32_t*>(&T)[k] = reinterpret_cast<const uint32_t*>(tab + t)[k];
+  for (uint32_t k = threadIdx.x; k < sizeof(FinOff) / 4; k += 256u) reinterpret_cast<uint32_t*>(&O)[k] = reinterpret_cast<const uint32_t*>(off + t)[k];
+  if (threadIdx.x == 0) {
+    uint32_t a = lvH[0].node_base, b = lvH[0].leaf_base;
+    for (uint32_t l = 0; l <= FIN_LV + 1u; l++) {
+      nb[l] = a; lb[l] = b;
+      if (l <= FIN_LV) { a += totals[l]; b += totals[FIN_LV + 2 + l]; }
+    }
+  }
+  __syncthreads();
+  if (t == 0 && threadIdx.x <= FIN_LV) {
+    // level L* + l + 1 holds two children per internal node of level L* + l: what the level-by-level build leaves in lvl[]
+    const uint32_t l = threadIdx.x;
+    lvH[l + 1].nseg = 2u * totals[l]; lvH[l + 1].node_base = nb[l + 1]; lvH[l + 1].leaf_base = lb[l + 1];
+  }
+  const uint32_t nlev = T.nlev;
+  auto level_of_node = [&](uint32_t st) { uint32_t l = 0; while (l + 1 < nlev && st >= T.ib[l + 1]) l++; return l; };
+  auto level_of_leaf = [&](uint32_t st) { uint32_t l = 0; while (l + 1 < nlev && st >= T.lb[l + 1]) l++; return l; };
+  auto final_ref = [&](uint32_t ref) -> uint32_t {      // a staged reference -> the final one (the axis bit rides along)
+    const uint32_t v = ref & REF_VAL;
+    if (ref & REF_LEAF) { const uint32_t l = level_of_leaf(v); return (ref & ~REF_VAL) | (lb[l] + O.lo[l] + (v - T.lb[l])); }
+    const uint32_t l = level_of_node(v);
+    return (ref & ~REF_VAL) | (nb[l] + O.io[l] + (v - T.ib[l]));
+  };
+  const uint32_t ni = T.ib[nlev] - T.ib[0], nlf = T.lb[nlev] - T.lb[0];
+  for (uint32_t k = threadIdx.x; k < ni; k += 256u) {
+    const uint32_t st = T.ib[0] + k;
+    KdNode nd = nodes_st[st];
+    nd.c1 = final_ref(nd.c1); nd.c2 = final_ref(nd.c2);
+    const uint32_t l = level_of_node(st);
+    const uint32_t g = nb[l] + O.io[l] + (st - T.ib[l]);
+    nodes[g] = nd;
+    node_r[g] = r_st[st];
+  }
+  for (uint32_t k = threadIdx.x; k < nlf; k += 256u) {
+    const uint32_t st = T.lb[0] + k;
+    const uint32_t l = level_of_leaf(st);
+    leaf_tab[lb[l] + O.lo[l] + (st - T.lb[l])] = leaf_st[st];
+  }
+  if (threadIdx.x == 0) {       // the subtree's root into its parent of the level above (or the tree's root reference)
+    const BSeg rt = roots[t];
+    const uint32_t ref = final_ref(T.root_ref);
+    if (rt.parent < 0) *root_ref = ref;
+    else {
+      uint32_t* slot = rt.side ? &nodes[rt.parent].c2 : &nodes[rt.parent].c1;
+      *slot = (*slot & REF_AXIS) | (ref & ~REF_AXIS);
+    }
+  }
+}
+
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline int bits_for(uint64_t v)
 {
@@ -1334,7 +1763,8 @@ size_t device_build_arena_bytes(size_t M, bool with_background_chain)
 // Builds on `s` inside the caller's scratch `arena_` (>= device_build_arena_bytes(M), reused from build to build:
 // no hipMalloc / hipFree of hundreds of MB per tree, and no device-wide sync from hipFree while another thread's
 // kernels run).  On success the caller owns res.{nodes,node_r,pts,leaf_tab}, from the handle pool (pool.cpp) at their sizes.
-DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, void* arena_, hipStream_t s, const BuildSide* side)
+DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, void* arena_, hipStream_t s, const BuildSide* side,
+                                 int no_finish)
 {
   DevBuildResult res{};
   const uint32_t M = (uint32_t)M_;
@@ -1346,7 +1776,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   bool spec_on = false;
   bool spec_suspect = false;   // the failure may be the speculation's doing (see `fail`)
   size_t scan_tmp = 0;
-  size_t O[32];
+  size_t O[48];
   (void)build_layout(M_, O, &scan_tmp);
   const size_t n1 = (size_t)M + 1;
   const size_t o_perm = O[0], o_segof = O[1], o_cx = O[2], o_cy = O[3], o_cz = O[4], o_f = O[5], o_F = O[6], o_isL = O[7],
@@ -1417,16 +1847,92 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     // level's node count (what the last look saw, doubled per level since) and return past the real count.
     // diagnostics (TDTK_BUILD_TRACE=1): an event at the start of every level on the build's stream; the elapsed times are
     // printed when the build is done -- what a level costs when no profiler is serialising the launches
-    static const bool lvl_trace = [] { const char* e = lab_env("TDTK_BUILD_TRACE"); return e && e[0] == '1'; }();
+    static const bool lvl_trace = [] { const char* e = lab_env("TDTK_BUILD_TRACE"); return e && (e[0] == '1' || e[0] == '2'); }();
+    static const bool fin_trace = [] { const char* e = lab_env("TDTK_BUILD_TRACE"); return e && e[0] == '2'; }();
     std::vector<hipEvent_t> lvl_ev;
     uint32_t level = 0, known = 1, known_at = 0;
     uint32_t batch = 1;
     for (size_t c = (size_t)(bucket > 0 ? bucket : 1); c < M_; c <<= 1) batch++;
     batch += 2;   // mean splits do not halve: a 1M-point cloud is 18-19 levels deep, not 17, and a level past the end of the
                   // tree costs less than the host's look (it moves nothing)
+    // The level from which every node is finished by one workgroup (k_fin_subtrees): the first at which a balanced node
+    // holds at most FIN_HANDOFF points.  TDTK_BUILD_FINISH=0 (lab): level by level to the end.
+    uint32_t fin_level = 0xFFFFFFFFu;
+    {
+      static const bool fin_env = [] { const char* e = lab_env("TDTK_BUILD_FINISH"); return !(e && e[0] == '0'); }();
+      uint32_t L = 0;
+      while ((M_ >> L) > FIN_HANDOFF) L++;
+      if (fin_env && no_finish == 0 && bucket >= 6 && L < 31 && (1u << L) <= FIN_MAX_SUBTREES && !big_dbg_all) fin_level = L;
+    }
+    if (fin_level != 0xFFFFFFFFu) batch = fin_level;
     std::vector<BLevel> hl;
     uint32_t h_small[3] = {0u, 0u, 0u};
     for (;;) {
+      if (level == fin_level) {
+        // does the level's largest node fit a workgroup's LDS?  (An unbalanced cloud -- a real scan -- takes a level or two more.)
+        uint32_t h_max[2] = {0u, 0u};
+        hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4);
+        BCHK(hipMemcpyAsync(h_max, small + 4, sizeof h_max, hipMemcpyDeviceToHost, s));
+        BCHK(hipStreamSynchronize(s));
+        if (h_max[0] > FIN_LDS && h_max[1] * 2u <= FIN_MAX_SUBTREES && fin_level + 1u < 31u) {
+          fin_level++;              // one more level by its own launches (below), then look again
+          known = h_max[1]; known_at = level;
+          batch = 1;
+        } else if (h_max[0] > FIN_LDS) {
+          fin_level = 0xFFFFFFFFu;  // too many nodes for the tables: level by level to the end
+          known = h_max[1]; known_at = level;
+          batch = 2;
+        }
+      }
+      if (level == fin_level) {
+        // hand the level over: its nodes (at most 2^level of them) become the roots of subtrees
+        const uint32_t tmax = 1u << fin_level;
+        BSeg* roots = (BSeg*)(arena + O[37]);
+        FinTab* ftab = (FinTab*)(arena + O[38]);
+        FinOff* foff = (FinOff*)(arena + O[39]);
+        BCHK(hipMemcpyAsync(roots, segs, sizeof(BSeg) * tmax, hipMemcpyDeviceToDevice, s));
+        if (fin_trace) { const uint32_t magic = 0x7157u; BCHK(hipMemcpyAsync(small + 15, &magic, 4, hipMemcpyHostToDevice, s)); }
+        if (lvl_trace) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); lvl_ev.push_back(e); } }
+        {
+          FinArgs fa;
+          fa.roots = roots; fa.lvH = lvl + fin_level; fa.cx = cx; fa.cy = cy; fa.cz = cz; fa.perm = perm;
+          fa.segA = (BSeg*)(arena + o_segA); fa.segB = (BSeg*)(arena + o_segB); fa.meas = meas;
+          fa.kind = (uint32_t*)(arena + O[35]); fa.axis = axis; fa.splitval = splitval; fa.irank = (uint32_t*)(arena + O[36]); fa.nleft = nleft;
+          fa.nodes_st = (KdNode*)(arena + O[32]); fa.r_st = (double*)(arena + O[33]); fa.leaf_st = (LeafEntry*)(arena + O[34]);
+          fa.tab = ftab; fa.bucket = (uint32_t)bucket; fa.small = small;
+          hipLaunchKernelGGL(k_fin_subtrees, dim3(tmax), dim3(FIN_T), 0, s, fa);
+        }
+        uint32_t* ftot = (uint32_t*)(arena + O[40]);
+        hipLaunchKernelGGL(k_fin_offsets, dim3(FIN_LV + 1u), dim3(256), 0, s, ftab, foff, lvl + fin_level, ftot);
+        hipLaunchKernelGGL(k_fin_place, dim3(tmax), dim3(256), 0, s, ftab, foff, ftot, roots, lvl + fin_level, (const KdNode*)(arena + O[32]),
+                           (const double*)(arena + O[33]), (const LeafEntry*)(arena + O[34]), nodes, node_r, leaf_tab, small + 0);
+        level = fin_level + FIN_LV + 2u;
+        hl.assign(level + 1, BLevel{0u, 0u, 0u});
+        BCHK(hipMemcpyAsync(hl.data(), lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
+        BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+        BCHK(hipStreamSynchronize(s));
+        if (fin_trace) {
+          uint32_t ph[10];
+          if (hipMemcpy(ph, small + 16, sizeof ph, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "FIN_TRACE subtree 0 (100 MHz ticks -> us):");
+            const char* nm[10] = {"", "measure", "decide", "rank", "emit+count", "mark+children", "scan", "swaplist", "swap+relabel", ""};
+            for (int k = 1; k < 9; k++) fprintf(stderr, " %s %.1f", nm[k], ph[k] / 100.0);
+            fprintf(stderr, "\n");
+          }
+        }
+        if (h_small[2] & 0x20000u) {       // a subtree deeper than the tables: level by level, then
+          if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); }
+          if (pts) pool_free(pts);
+          for (hipEvent_t x : lvl_ev) (void)hipEventDestroy(x);
+          return device_build_tree(d_xyz, M_, bucket, arena_, s, side, 1);
+        }
+        if (h_small[2]) {
+          res.err = hipErrorInvalidValue; res.degenerate = true;
+          spec_suspect = true;
+          goto fail;
+        }
+        break;
+      }
       for (uint32_t b = 0; b < batch && level < BUILD_MAX_LEVELS; b++, level++) {
         size_t bound = (size_t)known << ((level - known_at) < 31 ? (level - known_at) : 31);
         if (bound > M) bound = M;
@@ -1626,7 +2132,7 @@ fail:
     // really is.  (Anything else -- no memory, a failed launch -- is returned as it is: building twice would not help.)
     (void)hipStreamSynchronize(s);
     (void)hipGetLastError();
-    DevBuildResult again = device_build_tree(d_xyz, M_, bucket, arena_, s, nullptr);
+    DevBuildResult again = device_build_tree(d_xyz, M_, bucket, arena_, s, nullptr, no_finish);
     again.respeculated = again.err == hipSuccess;     // tdtk_build_respeculated counts cuts that really were off, not bad inputs
     return again;
   }
@@ -1719,6 +2225,11 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(4 * (nsl + 1));                                                      // 29 slots of the walked pieces, in run order
   take(lab_env("TDTK_BIG_DEBUG") && (atoi(lab_env("TDTK_BIG_DEBUG")) & 8) ? sizeof(BMeas) * n1 : 256);   // 30 debug: the chain's results
   take(scan_pair27_state_bytes(n1));                                        // 31 state of the one-launch scan
+  // subtrees finished by one workgroup each (k_fin_*): staging of their records, their own kind / rank arrays, tables
+  take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // 32 33 34
+  take(4 * (n1 + FIN_MAX_SUBTREES)); take(4 * (n1 + FIN_MAX_SUBTREES));                // 35 36 kind, irank
+  take(sizeof(BSeg) * FIN_MAX_SUBTREES); take(sizeof(FinTab) * FIN_MAX_SUBTREES); take(sizeof(FinOff) * FIN_MAX_SUBTREES);   // 37 38 39
+  take(4 * 2 * (FIN_LV + 2));                                                          // 40 the levels' totals
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }

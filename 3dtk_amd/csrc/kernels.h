@@ -196,8 +196,9 @@ size_t device_build_arena_bytes(size_t M, bool with_background_chain = true);
 // `side` (nullable): a second stream and two events of the caller's for the build's background chain -- with it the exact
 // centroid sums of the big nodes run beside the levels below them (see "speculative splits" in build.hip)
 struct BuildSide { hipStream_t s2, s3; hipEvent_t e1, e2, e3; };   // s3 / e3 nullable: one background stream only
+// no_finish != 0: every level by its own launches (the subtrees are not handed to single workgroups; see k_fin_subtrees)
 DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s,
-                                 const BuildSide* side = nullptr);
+                                 const BuildSide* side = nullptr, int no_finish = 0);
 
 // ---- normals: the ANN kd-tree (one point per leaf, sliding midpoint) + approximate k-NN + PCA (ann.hip) -------
 struct AnnNode {          // 32 B: one splitting node (ANNkd_split: cut_val, cd_bnds[2], child[2], cut_dim)

@@ -3074,10 +3074,10 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 #endif
   switch (refill_thresh(a.n)) {
 #ifdef TDTK_LAB
-    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 4, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
 #endif
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 4, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
   }
   if (kLab && a.trace) {
     (void)hipStreamSynchronize(s);
