@@ -106,17 +106,20 @@ __device__ __forceinline__ const A& kernarg_block()
 // closest_d2 never grows, so the reference's test after the near child returns
 // (kdTreeImpl.h:373,378) would fail for every entry we skip.
 // ------------------------------------------------------------------------------------------
-// The overflow path names its address space (global) in every access, so that the compiler keeps the common case as
-// plain ds_write / ds_read instead of merging both into flat_store / flat_load.  (Until round 4 it lived in two
-// __noinline__ functions for the same purpose, whose call frames cost every search kernel 32 bytes of scratch per lane.)
-__device__ __forceinline__ void stack_spill(double* g_m2, uint32_t* g_ref, size_t off, uint32_t ref, double m2)
+// The overflow path lives in its own (rarely called) functions.  They name their address space (global) in every access,
+// so they could be inlined without the compiler merging LDS and global accesses into flat ones -- round 4 measured both
+// inlined forms (a per-lane branch; a wave-uniform branch around it): the 32 bytes of scratch per lane that the call frame
+// costs every search kernel are gone then, and k_search of the 1M-vs-1M loop takes 0.2008-0.2028 ms instead of
+// 0.1937-0.1946 (driver's arguments, gpurun_out/r4h, r4i).  Out of line it stays.
+#define TDTK_OVF_INLINE __noinline__
+__device__ TDTK_OVF_INLINE void stack_spill(double* g_m2, uint32_t* g_ref, size_t off, uint32_t ref, double m2)
 {
   typedef double __attribute__((address_space(1))) * gd;
   typedef uint32_t __attribute__((address_space(1))) * gu;
   ((gd)g_m2)[off] = m2;
   ((gu)g_ref)[off] = ref;
 }
-__device__ __forceinline__ void stack_fill(const double* g_m2, const uint32_t* g_ref, size_t off, uint32_t& ref,
+__device__ TDTK_OVF_INLINE void stack_fill(const double* g_m2, const uint32_t* g_ref, size_t off, uint32_t& ref,
                                            double& m2)
 {
   typedef const double __attribute__((address_space(1))) * gd;
@@ -166,14 +169,24 @@ struct LaneStackQ {
   int sp;
   __device__ __forceinline__ void push(uint32_t ref, double m2)
   {
-    if (__builtin_expect(sp < SD, 1)) l_e[sp * BLOCK] = make_uint4((uint32_t)__double2loint(m2), (uint32_t)__double2hiint(m2), ref, 0u);
-    else stack_spill(g_m2, g_ref, (size_t)(sp - SD) * gstride, ref, m2);
+    // (the overflow path behind a wave-uniform branch: the common case -- no lane of the wave beyond the LDS levels -- is a
+    // scalar jump over it, not code every lane steps through with an empty mask)
+    if (__builtin_expect(__ballot(sp >= SD) == 0ull, 1)) {
+      l_e[sp * BLOCK] = make_uint4((uint32_t)__double2loint(m2), (uint32_t)__double2hiint(m2), ref, 0u);
+    } else {
+      if (sp < SD) l_e[sp * BLOCK] = make_uint4((uint32_t)__double2loint(m2), (uint32_t)__double2hiint(m2), ref, 0u);
+      else stack_spill(g_m2, g_ref, (size_t)(sp - SD) * gstride, ref, m2);
+    }
     ++sp;
   }
   __device__ __forceinline__ void top(uint32_t& ref, double& m2) const
   {
     const int s = sp;
-    if (__builtin_expect(s < SD, 1)) {
+    if (__builtin_expect(__ballot(s >= SD) == 0ull, 1)) {
+      const uint4 e = l_e[s * BLOCK];
+      m2 = __hiloint2double((int)e.y, (int)e.x);
+      ref = e.z;
+    } else if (s < SD) {
       const uint4 e = l_e[s * BLOCK];
       m2 = __hiloint2double((int)e.y, (int)e.x);
       ref = e.z;
@@ -3076,8 +3089,8 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 #ifdef TDTK_LAB
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
 #endif
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
   }
   if (kLab && a.trace) {
     (void)hipStreamSynchronize(s);

@@ -871,8 +871,8 @@ def test_product_and_bench_keep_clear_of_the_oracle():
 def test_every_product_kernel_spills_nothing_and_search_kernels_keep_four_waves():
     """The resource remarks of the PRODUCT build (csrc/Makefile keeps them for kernels.hip: every search, pair-sum,
     transform and layout kernel lib3dtk_hip.so can launch; the lab library's extra kernels are not in this file).
-    Every kernel: no VGPR spills, no SGPR spills.  Every search kernel: no scratch at all (until round 4 each carried 32
-    bytes per lane for the call frames of the stack-overflow helpers) and, for the persistent-lane kernels -- which hold a
+    Every kernel: no VGPR spills; no SGPR spills outside two named kernel families.  Every search kernel: no scratch beyond
+    the 32 bytes per lane of the stack-overflow helpers' call frame and, for the persistent-lane kernels -- which hold a
     whole bucket's fp32 shadow groups in registers --, at most 128 vector registers = four waves per SIMD, which is what
     their launches are sized for.  Also: none of the lab kernels is in the product (k_search_step, k_search_coop, the
     work-queue / FAT / PROBE instantiations, k_slab_bounds)."""
@@ -905,7 +905,10 @@ def test_every_product_kernel_spills_nothing_and_search_kernels_keep_four_waves(
         if m_ann: cap = {10: 10, 16: 16, 32: 142}.get(int(m_ann.group(1)), 0)
         assert num("SGPRs Spill") <= cap, (name, num("SGPRs Spill"))
         if "k_search" in name:
-            assert num(r"ScratchSize \[bytes/lane\]") == 0, name
+            # 32 bytes per lane: the call frame of the two out-of-line stack-overflow helpers, nothing else.  Round 4 built the
+            # two inlined forms (per-lane branch; wave-uniform branch around it) -- scratch 0, and k_search 0.2008-0.2028 ms
+            # against 0.1937-0.1946 at the driver's arguments (gpurun_out/r4h, r4i; NEGATIVES.md) -- and kept the call.
+            assert num(r"ScratchSize \[bytes/lane\]") <= 32, name
         if "k_search_refill" in name:
             seen_refill += 1
             assert num("VGPRs") <= 128 and num(r"Occupancy \[waves/SIMD\]") >= 4, name
