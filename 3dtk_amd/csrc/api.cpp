@@ -1359,9 +1359,9 @@ int tdtk_visit_counting(int device, int on)
   int rc = get_ctx(device, &c);
   if (rc) return rc;
   if (on) {
-    if ((rc = c->d_counters.ensure(8 * sizeof(unsigned long long)))) return rc;
+    if ((rc = c->d_counters.ensure(16 * sizeof(unsigned long long)))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemset(c->d_counters.p, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_counters.p, 0, 16 * sizeof(unsigned long long)));
     c->counted_queries = 0;
     c->counted_ann_queries = 0;
   }
@@ -1386,6 +1386,25 @@ int tdtk_visit_counters(int device, uint64_t out[8])
   out[4] = h[4]; out[5] = h[5];
   return TDTK_OK;
 }
+
+#ifdef TDTK_LAB
+// lab: trips of the waves of the instrumented persistent-lane launches since tdtk_visit_counting(device, 1) through the node
+// walk (out[0]) and the bucket scan (out[1]): with the visit counters, lane-visits / (64 x trips) = how full a phase's trips are
+extern "C" int tdtk_lab_trip_counters(int device, uint64_t out[2])
+{
+  if (!out) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  out[0] = out[1] = 0;
+  if (!c->d_counters.p) return TDTK_OK;
+  HIPCHK(hipDeviceSynchronize());
+  unsigned long long h[2];
+  HIPCHK(hipMemcpy(h, c->d_counters.as<unsigned long long>() + 8, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = h[0]; out[1] = h[1];
+  return TDTK_OK;
+}
+#endif
 
 // measured roofline denominators: kind 0 = HBM stream copy (16 B per lane, `bytes` read + `bytes`
 // written per pass, the buffers far beyond the 256 MB Infinity Cache when bytes >= 1 GB); kind 1 = repeated reads of

@@ -1654,6 +1654,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f; bx.ec = 0.f; bx.pthr = 0.f;
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
+  unsigned c_t1 = 0, c_t2 = 0;   // lab, instrumented instantiations: trips of the wave through the node walk / the bucket scan
   unsigned nbk = 0;   // buckets this lane's query has visited (the next pass's ordering key)
   // FUSE 1: the base pair sums (ACC_N .. ACC_P) at retire time; FUSE 2: n, sum and the LUM block of a graph-SLAM link
   // (acc[0] = n, [1] = sum |delta|^2, [2 .. 16] = the 15 sums of lum6Deuler.cc:143-175, [17] = sum u.delta)
@@ -1900,6 +1901,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     }
     if constexpr (!FAT) while (!(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
+      if (COUNT && kLab) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
       if (ORDER) ++nbk;     // (a key of buckets alone saves this instruction and orders no better: 0.1934 / 0.1968 against 0.1946 / 0.1923 ms)
       bool need_pop = false;
       uint32_t next = REF_DONE;
@@ -1977,6 +1979,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         count = (int)(v & t_cmask);
       }
       if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
+      if (COUNT && kLab) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t2; }
       if (ORDER) nbk += 4u;
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
@@ -2041,6 +2044,10 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       atomicAdd(&a.counters[0], s_int);
       atomicAdd(&a.counters[1], s_leaf);
       atomicAdd(&a.counters[2], s_pts);
+    }
+    if (kLab) {       // wave trips: (lane-visits of a phase) / (64 x its trips) = the share of lane-slots that phase keeps busy
+      const unsigned long long s_t1 = wave_sum_u(c_t1), s_t2 = wave_sum_u(c_t2);
+      if (lane == 0) { atomicAdd(&a.counters[8], s_t1); atomicAdd(&a.counters[9], s_t2); }
     }
   }
   if constexpr (FUSE == 3 || FUSE == 5) {

@@ -40,7 +40,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
-PMC_ROUND = "r03"
+PMC_ROUND = "r04"
 NUM_SIMD = 1024            # 256 CUs x 4 SIMDs
 
 
@@ -247,6 +247,112 @@ def make_graphslam_scans(nscans, npts, seed=7):
 
 
 # --------------------------------------------------------------------------------------------
+def make_small_scans(nscans=16, raw=400000, seed=11):
+    """SURVEY 8(d) C3's shape (hannover1 -s 1 -e 65 -r 10 -i 100 -d 75: a vehicle's scans of a street scene, ~400K raw
+    points each, octree-reduced with 10 cm voxels to ~40K; the dataset itself is not on the box): a ground plane, walls and
+    boxes, sampled where a scanner on a straight drive sees them (range 1150), in the scan frame with N(0, 0.5) noise; the
+    initial poses carry accumulated odometry drift."""
+    rng = np.random.default_rng(seed)
+    tdtk = importlib.import_module("3dtk_amd")
+    out = []
+    drift = np.zeros(3); drift_t = 0.0
+    for k in range(nscans):
+        pos = np.array([60.0 * k, 0.0, 0.0])
+        theta = np.array([0.0, 0.002 * k, 0.0])
+        n_g = raw * 6 // 10
+        n_w = raw - n_g
+        # ground: denser near the scanner (1 / r falloff of a rotating scanner), y = 0
+        r = 1150.0 * rng.uniform(0.02, 1.0, n_g) ** 1.5
+        a = rng.uniform(0, 2 * math.pi, n_g)
+        g = np.stack([pos[0] + r * np.cos(a), np.zeros(n_g), r * np.sin(a)], 1)
+        # walls along the street (z = +-220) and cross walls every 400 units, 0 .. 120 high
+        w = np.empty((n_w, 3))
+        side = rng.integers(0, 3, n_w)
+        along = pos[0] + rng.uniform(-1150, 1150, n_w)
+        w[:, 0] = np.where(side < 2, along, np.round(along / 400.0) * 400.0)
+        w[:, 1] = rng.uniform(0, 120, n_w)
+        w[:, 2] = np.where(side == 0, 220.0, np.where(side == 1, -220.0, rng.uniform(-220, 220, n_w)))
+        world_pts = np.concatenate([g, w]) + rng.normal(0.0, 0.5, (raw, 3))
+        T = tdtk.EulerToMatrix4(pos, theta)
+        Ti = tdtk.M4inv(T)
+        R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+        loc = world_pts @ R.T + Ti[12:15]
+        if k > 0:
+            drift = drift + rng.normal(0.0, 0.4, 3) + np.array([0.5, 0.0, 0.2])
+            drift_t = drift_t + rng.normal(0.0, math.radians(0.02))
+        out.append((pos + drift, theta + np.array([0.0, drift_t, 0.0]), np.ascontiguousarray(loc)))
+    return out
+
+
+def bench_small_scans(args, local):
+    """`doicp_small_scans`: the regime of real data sets -- many scans of a few ten thousand reduced points,
+    where a scan costs its preparation (reduction, upload + ordering, tree build) as much as its match.  16 scans of 400K raw
+    points, `-r 10` on the device, then icp6D::doICP (-i 100 -d 75 --epsICP 1e-5) with the next scans prepared ahead; per scan:
+    reduce / prepare (upload + ordering + tree) / match, and the wall time of the whole doICP."""
+    tdtk = importlib.import_module("3dtk_amd")
+    nscans = 16
+    raw = make_small_scans(nscans)
+    # octree reduction on the device (Scan::calcReducedPoints, -r 10)
+    red, t_red = [], []
+    for (p, th, loc) in raw:
+        tdtk.calcReducedPoints(loc[:1000], 10.0, device=local)          # (first call of the process: code objects)
+        t0 = time.perf_counter(); r = tdtk.calcReducedPoints(loc, 10.0, device=local); t_red.append(time.perf_counter() - t0)
+        red.append(r)
+    npts = [len(r) for r in red]
+
+    def run(prefetch):
+        S = [tdtk.Scan(p, th, r, device=local) for (p, th, _), r in zip(raw, red)]
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 75.0, 100, quiet=True, epsilonICP=1e-5)
+        its = []
+        orig = icp.match
+
+        def rec(a, b, pm=0):
+            t0 = time.perf_counter(); it = orig(a, b, pm); its.append((it, time.perf_counter() - t0)); return it
+        icp.match = rec
+        t0 = time.perf_counter(); icp.doICP(S, prefetch=prefetch); wall = time.perf_counter() - t0
+        builds = [s.getSearchTree().info()["build_ms"] for s in S[:-1]]
+        poses = np.stack([s.transMat for s in S])
+        for s in S:
+            s.release()
+        return wall, its, builds, poses
+    run(True)                                                              # warm (first builds of these sizes: arenas, pools)
+    wall0, its0, builds0, poses0 = run(False)
+    wall1, its1, builds1, poses1 = run(True)
+    assert np.array_equal(poses0, poses1), "doICP result depends on the prefetch"
+    iters = [it for it, _ in its1]
+    match_ms = [dt * 1e3 for _, dt in its0]
+    out = {"scans": nscans, "raw_points_per_scan": len(raw[0][2]), "reduced_points_per_scan": {"min": min(npts), "mean": float(np.mean(npts)), "max": max(npts)},
+           "voxel": 10.0, "max_dist_match": 75.0, "max_iterations": 100, "epsilonICP": 1e-5,
+           "per_scan_ms": {"reduce": float(np.mean(t_red)) * 1e3, "tree_build": float(np.mean(builds0)),
+                           "match": float(np.mean(match_ms)), "doICP_wall_nothing_ahead": wall0 * 1e3 / (nscans - 1),
+                           "doICP_wall_three_ahead": wall1 * 1e3 / (nscans - 1)},
+           "iterations_per_match": {"mean": float(np.mean(iters)), "max": int(max(iters))},
+           "ms_per_iteration": float(np.sum(match_ms) / max(1, sum(it + 1 for it in iters))),
+           "what": "16 synthetic street-scene scans (C3's shape; hannover1 is not on the box): tdtk_reduce_octree -r 10, then "
+                   "icp6D::doICP over the reduced scans; `match` = wall time of one icp6D::match (device-resident loop), "
+                   "`tree_build` = tdtk_tree_create on the device, doICP_wall = (whole doICP) / 15 with the next three scans' "
+                   "upload + ordering + tree build on worker threads or with nothing prepared ahead (identical poses)"}
+    if not args.no_cpu:
+        from oracle import orc
+        if orc.have_ref():
+            # the reference's own TUs on the host: KDtreeIndexed's constructor + full OpenMP-branch ICP iterations of one pair
+            a, b = red[0], red[1]
+            Ta = tdtk.EulerToMatrix4(raw[0][0], raw[0][1]); Tb = tdtk.EulerToMatrix4(raw[1][0], raw[1][1])
+            ga = a.copy(); orc.transform_points(Ta, ga)
+            gb = b.copy(); orc.transform_points(Tb, gb)
+            t0 = time.perf_counter(); tree = orc.RefTree(ga, 20); tb = time.perf_counter() - t0
+            threads = min(int(orc.ref().ref_host_threads()), 16)
+            nit = max(2, int(round(np.mean(iters))))
+            t0 = time.perf_counter(); tree.icp_iterations(np.eye(4).reshape(16), gb, 75.0 ** 2, threads, nit); tm = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": (tb + tm) * 1e3, "unit": "ms per scan (tree build + match)", "cores": threads, "kind": "reference",
+                                   "tree_build_ms": tb * 1e3, "match_ms": tm * 1e3,
+                                   "sample": "scans 0 / 1 of this run: KDtreeIndexed's constructor over %d points (serial, as the "
+                                             "reference builds it) + %d full icp6D::match iterations of the OpenMP branch with %d "
+                                             "threads (oracle/_ref: the reference's compiled TUs); the octree reduction is not part "
+                                             "of it (Boctree.h needs Boost)" % (len(ga), nit, threads)}
+    return out
+
+
 class _stdout_to_stderr:
     """fd-level redirect: RCCL prints its version banner to stdout when the communicator comes up
     (NCCL_DEBUG=VERSION is set on the pool); stdout must carry the one JSON line only."""
@@ -549,6 +655,8 @@ def bench_icp(args, rank, world, local):
             out["normals_1gpu"]["cpu_baseline"] = {"value": ns / tc, "unit": "points/s", "cores": 1,
                                                    "kind": "reference" if which == "ref" else "port",
                                                    "sample": "first %d points of the scan (the reference's calcNormals is serial)" % ns}
+    if world == 1 and not args.no_small_scans:
+        out["doicp_small_scans"] = bench_small_scans(args, local)
     if world == 1 and args.workload == "auto" and not args.no_graphslam_base:
         # the 1-GPU point of the graph-SLAM strong-scaling curve (the N>1 runs of this script measure
         # configs[3]); reported beside the headline so scaling can be read against the same workload
@@ -556,11 +664,53 @@ def bench_icp(args, rank, world, local):
         import copy
         ga = copy.copy(args); ga.steps, ga.warmup = 10, 3
         g1 = bench_graphslam(ga, rank, world, local)
-        out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s", "roofline")}
+        out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s", "roofline", "sharded_step_rehearsal")}
         out["graphslam_1gpu"]["workload"] = g1["config"]["workload"]
         out["scaling_note"] = ("N>1 runs of this script measure configs[3] (graph-SLAM, links sharded); its 1-GPU point is "
                                "graphslam_1gpu here, not `value` (configs[1], which BASELINE.json fixes to one GPU)")
     return out
+
+
+def rehearse_shards(tdtk, gs, scans, nscans, npts, full_ms, local):
+    """One GPU: what an N-rank step of the sharded LUM iteration would cost -- a PREDICTION, no multi-GPU box is available to
+    the build session.  For world in 1, 2, 4, 8 the links are dealt exactly as tdtk_graph_deal_links does; every rank's share
+    is timed on this GPU (tdtk_lum_links over the share, best of 3, with the previous round's scan moves queued on every scan
+    as tdtk_graph_iteration leaves them: since round 4 a share carries out the moves of the scans it reads) and the slowest
+    share taken; the rest of a step (graph, table set-up, exchange of 28 KB, solve, pose update) = this run's measured
+    1-GPU step minus the same measurement of all links."""
+    capi = importlib.import_module("3dtk_amd._capi")
+    L = capi.lib()
+    g = tdtk.Graph(nscans, 500.0 ** 2, 20, scans)
+    hs_all = (C.c_void_p * (nscans - 1))(*[scans[k].handle for k in range(1, nscans)])
+    wig = np.ascontiguousarray(np.tile(tdtk.EulerToMatrix4([1e-4, -1e-4, 1e-4], [1e-7, -1e-7, 1e-7]), (nscans - 1, 1)))
+    wig_inv = np.ascontiguousarray(np.stack([tdtk.M4inv(m) for m in wig]))
+
+    def time_links(idx):
+        nl = len(idx)
+        if nl == 0:
+            return 0.0
+        first = (C.c_void_p * nl)(*[scans[g.getLink(i, 0)].getSearchTree()._h for i in idx])
+        second = (C.c_void_p * nl)(*[scans[g.getLink(i, 1)].handle for i in idx])
+        dal = np.ascontiguousarray(np.stack([scans[g.getLink(i, 0)].dalignxf for i in idx]))
+        Cm = np.empty((nl, 36)); CD = np.empty((nl, 6)); m = (C.c_uint64 * nl)(); ss = np.empty(nl)
+        best = 1e9
+        for _ in range(3):
+            capi.check(L.tdtk_scans_transform2(nscans - 1, hs_all, capi.dptr(wig), capi.dptr(wig_inv)))
+            t0 = time.perf_counter()
+            capi.check(L.tdtk_lum_links(nl, first, capi.dptr(dal), second, 625.0, capi.dptr(Cm), capi.dptr(CD), m, capi.dptr(ss)))
+            best = min(best, time.perf_counter() - t0)
+        return best * 1e3
+    all_ms = time_links(list(range(g.getNrLinks())))
+    rest = max(0.0, full_ms - all_ms)
+    pred = {}
+    for world in (1, 2, 4, 8):
+        shares = [gs.shard_links(g, r, world, scans) for r in range(world)]
+        per = [time_links(sh) for sh in shares]
+        pred[str(world)] = {"links_per_rank": [len(x) for x in shares], "slowest_share_ms": max(per), "rest_ms": rest,
+                            "predicted_step_ms": max(per) + rest}
+    return {"what": "PREDICTION from a one-GPU rehearsal, not a measurement on N GPUs: slowest rank's share of the link passes "
+                    "timed on this GPU + the non-sharded rest of this run's step (replicated on every rank)",
+            "all_links_ms": all_ms, "rest_ms": rest, "by_world": pred}
 
 
 def bench_graphslam(args, rank, world, local):
@@ -661,6 +811,9 @@ def bench_graphslam(args, rank, world, local):
     rccl_world = comm.rccl_world if comm is not None else None
     if comm is not None and rccl_world != args.gpus:
         raise SystemExit("bench.py: RCCL communicator has %d ranks but --gpus %d" % (rccl_world, args.gpus))
+    rehearsal = None
+    if world == 1 and comm is None and not getattr(args, "no_rehearsal", False):
+        rehearsal = rehearse_shards(tdtk, gs, scans, nscans, npts, dt * 1e3 / args.steps, local)
     if comm is not None:
         barrier_sync(world)
         comm.close()                  # ncclCommDestroy now, on every rank together, not at interpreter shutdown
@@ -673,7 +826,7 @@ def bench_graphslam(args, rank, world, local):
                                "step, %d links dealt over %d ranks, one fp64 all-reduce of %d doubles (42 per link)"
                                % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
-        "lum_iters_per_s": args.steps / dt, "last_ret": ret,
+        "lum_iters_per_s": args.steps / dt, "last_ret": ret, "sharded_step_rehearsal": rehearsal,
         "exchange": exchange, "rccl_world": rccl_world, "links_per_rank": links_per_rank,
         "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
                         "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
@@ -704,6 +857,7 @@ def main():
     ap.add_argument("--scans", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-normals", action="store_true", help="N=1 only: skip the calcNormals measurement")
+    ap.add_argument("--no-small-scans", action="store_true", help="N=1 only: skip the doicp_small_scans leg")
     ap.add_argument("--no-graphslam-base", action="store_true",
                     help="N=1 only: skip the extra 1-GPU graph-SLAM measurement (the base of the N>1 curve)")
     args = ap.parse_args()

@@ -112,6 +112,56 @@ def test_box_shortcut_gives_way_outside_float_range(tdtk, orc, gpu, nq):
         assert kd.count_visits(q, md2) == T.find_closest(q, md2, 8, True)[2], md2
 
 
+@pytest.mark.parametrize("nq", [20000, 300000])
+@pytest.mark.parametrize("offset", [1.0e6, 1.0e8, 1.0e9])
+def test_fp32_shortcuts_on_clouds_far_from_the_origin(tdtk, orc, gpu, nq, offset):
+    """Round 4: a cloud offset by 1e6 .. 1e9 with centimetre structure -- coordinates whose fp32 shadows
+    cannot tell neighbours apart (at 1e9 the fp32 spacing is 64 units: every point of a bucket has the same shadow).  The
+    box shortcut and the bucket filter may then decide almost nothing and must hand every such decision to the exact fp64
+    path: indices, squared distances and visit counters are the oracle's, for the lane-group kernels (20K queries) and
+    the persistent-lane kernel (300K)."""
+    rng = np.random.default_rng(int(offset) % 1000 + nq)
+    base = np.array([offset, -0.5 * offset, 0.25 * offset])
+    m = base + rng.uniform(-3.0, 3.0, (60000, 3))            # a 6 m cube, centimetre-to-metre structure
+    m[2000:2400] = m[0:400]                                    # exact duplicates
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    assert kd.verify() == [0, 0, 0, 0]
+    q = m[rng.integers(0, len(m), nq)] + rng.normal(0, 0.02, (nq, 3))
+    q[: nq // 20] += rng.normal(0, 5.0, (nq // 20, 3))        # some queries outside the cube
+    for md2 in (0.01, 4.0, 1e30):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi), (offset, md2)
+        assert np.array_equal(d2, od2), (offset, md2)
+        assert kd.count_visits(q, md2) == T.find_closest(q, md2, 8, True)[2], (offset, md2)
+
+
+@pytest.mark.parametrize("nq", [20000, 300000])
+def test_fp32_shortcuts_with_model_coordinates_beyond_float_range(tdtk, orc, gpu, nq):
+    """Round 4: the MODEL holds coordinates fp32 cannot represent -- beyond FLT_MAX (their shadows are
+    +-inf), within a rounding step of it (3.4028235e38 rounds up to inf), and huge-but-finite ones whose differences
+    overflow fp32 --, so node boxes and shadow groups carry inf / NaN-producing values.  Nothing may be decided from
+    those: same indices, distances and visit counters as the oracle, with queries both ordinary and huge."""
+    rng = np.random.default_rng(31 + nq)
+    m = rng.uniform(-1000, 1000, (50000, 3))
+    wild = [1e39, -1e39, 3.4028235e38, -3.4028236e38, 3.3e38, -3.0e38, 1e300, -1e305, 2e38, 1.7e38]
+    rows = rng.choice(len(m), 600, replace=False)
+    for k, r in enumerate(rows):
+        m[r, k % 3] = wild[k % len(wild)]
+        if k % 5 == 0:
+            m[r, (k + 1) % 3] = wild[(k + 4) % len(wild)]
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    assert kd.verify() == [0, 0, 0, 0]
+    q = m[rng.integers(0, len(m), nq)] + rng.normal(0, 2.0, (nq, 3))      # includes queries next to the wild points
+    q[: nq // 50, 0] = 2.5e38
+    for md2 in (25.0, 1e39, 1e300):
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi), md2
+        assert np.array_equal(d2, od2, equal_nan=True), md2
+        assert kd.count_visits(q, md2) == T.find_closest(q, md2, 8, True)[2], md2
+
+
 def test_leaf_table_mode(tdtk, orc, gpu):
     """bits(M) + bits(max leaf) > 30 switches child references to the leaf table."""
     rng = np.random.default_rng(5)
@@ -1692,6 +1742,20 @@ def test_randomized_differential_run(gpu):
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "20", "--seed", "101"],
                        cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert " 0 mismatches" in r.stdout
+
+
+def test_randomized_differential_run_big_clouds(gpu):
+    """20 s of tools/fuzz_parity.py --big (round 4): the same differential run on clouds of 30K .. 400K
+    points -- the one-query-per-lane and persistent-lane kernels, the piecewise centroid sums and the subtree finisher of
+    the tree build; the small-cloud run above only ever reaches the lane-group kernels."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seconds", "20", "--seed", "202", "--big"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert " 0 mismatches" in r.stdout
 

@@ -44,7 +44,7 @@ SUF = "_s%d_w%d" % (STEPS, WARM)
 try:
     COMMAND = open(os.path.join(src, "command.txt")).read().strip().replace(os.environ.get("GRAFT_REPO_ROOT", "/nonexistent") + "/", "")
 except Exception:
-    COMMAND = "python bench.py --steps %d --warmup %d --no-cpu --no-graphslam-base --no-normals" % (STEPS, WARM)
+    COMMAND = "python bench.py --steps %d --warmup %d --no-cpu --no-graphslam-base --no-normals --no-small-scans" % (STEPS, WARM)
 
 # --- kernel stats (from the kernel trace of the --stats run)
 rows = list(csv.DictReader(open(os.path.join(src, "stats", "p_kernel_trace.csv"))))
