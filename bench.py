@@ -841,9 +841,26 @@ def bench_graphslam(args, rank, world, local):
                                     "what": "algorithmic bytes of ALL this rank's link searches per step / step wall time "
                                             "(exchange, solve and pose update in the denominator)"},
                      "note": "achieved = algorithmic bytes of the step's last search launch / its HIP-event duration; like "
-                             "the ICP figure it counts re-reads served by L2 / Infinity Cache (not a utilisation); "
-                             "`traffic` = PMC fabric bytes of such a launch"},
+                             "the ICP figure it counts re-reads served by L2 (not a utilisation); `traffic` = PMC fabric bytes of "
+                             "such a launch.  This is the one configuration whose working set (64 scans and trees, 3.5 GB) exceeds "
+                             "the 256 MB Infinity Cache: its fabric traffic is mostly HBM traffic, see bounds.hbm_traffic_pmc"},
     }
+    if traffic is not None and k_ms > 0:
+        b = {"hbm_traffic_pmc": {"bytes": traffic, "GBs": traffic / (k_ms * 1e-3) / 1e9, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "GB_per_link": traffic / max(1, last_links) / 1e9,
+                                 "what": "2 FETCH_SIZE + WRITE_SIZE of the link launch (profiles/%s_graphslam_pmc.json) / this run's "
+                                         "kernel time: the utilisation of the memory side" % PMC_ROUND}}
+        if pk and pk.get("GRBM_GUI_ACTIVE") and pk.get("SQ_ACTIVE_INST_VALU"):
+            cyc = pk["GRBM_GUI_ACTIVE"] / 8.0
+            b["issue"] = {"valu_busy": pk["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc),
+                          "lane_efficiency": (pk["SQ_THREAD_CYCLES_VALU"] / (pk["SQ_ACTIVE_INST_VALU"] * 64.0)) if pk.get("SQ_THREAD_CYCLES_VALU") else None,
+                          "wave_wait_share": (pk["SQ_WAIT_ANY"] / pk["SQ_WAVE_CYCLES"]) if pk.get("SQ_WAIT_ANY") and pk.get("SQ_WAVE_CYCLES") else None,
+                          "l1_tag_accesses_per_cu_cycle": (pk["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc) if pk.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+                          "l2_hit_rate": (pk["TCC_HIT_sum"] / max(1.0, pk["TCC_HIT_sum"] + pk["TCC_MISS_sum"])) if pk.get("TCC_HIT_sum") is not None and pk.get("TCC_MISS_sum") is not None else None,
+                          "what": "SQ / TCP / TCC counters of the same launch under rocprofv3 --pmc (each pass its own run): no single "
+                                  "throughput resource is saturated -- the vector ALUs are busy less than half the time, the memory "
+                                  "side below half of HBM peak, the L1 tag pipeline the closest to its limit of one look-up per cycle"}
+        out["roofline"]["bounds"] = b
     return out
 
 
@@ -858,6 +875,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-normals", action="store_true", help="N=1 only: skip the calcNormals measurement")
     ap.add_argument("--no-small-scans", action="store_true", help="N=1 only: skip the doicp_small_scans leg")
+    ap.add_argument("--no-rehearsal", action="store_true",
+                    help="graph-SLAM at N=1: skip the one-GPU rehearsal of the sharded step (the profiles: every search dispatch is then a full step's)")
     ap.add_argument("--no-graphslam-base", action="store_true",
                     help="N=1 only: skip the extra 1-GPU graph-SLAM measurement (the base of the N>1 curve)")
     args = ap.parse_args()

@@ -3,7 +3,7 @@
 #   usage: tools/profile_graphslam.sh <tag>   -> gpurun_out/<tag>/{gs,gs_fetch,gs_write}/...
 set -u
 TAG="${1:-prof}"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
-CMD="${GS_CMD:-python $GRAFT_REPO_ROOT/bench.py --workload graphslam --steps 10 --warmup 3}"
+CMD="${GS_CMD:-python $GRAFT_REPO_ROOT/bench.py --workload graphslam --steps 10 --warmup 3 --no-rehearsal}"
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/gs" -o p -- $CMD > "$OUT/gs.json" 2> "$OUT/gs.err"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/gs_fetch" -o p -- $CMD > "$OUT/gs_fetch.json" 2> "$OUT/gs_fetch.err"

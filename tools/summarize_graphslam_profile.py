@@ -28,7 +28,7 @@ with open(os.path.join("profiles", pre + "_graphslam" + suffix + "_kernel_stats.
     f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         f.write("%s,%d,%.3f,%.3f,%.3f,%.3f,%.2f\n" % (k, len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))
-cmd = os.environ.get("GS_CMD_LABEL", "python bench.py --workload graphslam --steps 10 --warmup 3")
+cmd = os.environ.get("GS_CMD_LABEL", "python bench.py --workload graphslam --steps 10 --warmup 3 --no-rehearsal")
 pmc = {"command": cmd, "kernels": {},
        "note": "per-dispatch averages over all dispatches of the run; one search dispatch covers ALL link passes of the step "
                "(84 links of 1M queries each in the full graph, a rank's 11 in the share run: up to 128 links per launch); "
