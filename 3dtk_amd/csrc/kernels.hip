@@ -2157,6 +2157,321 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 
+#ifdef TDTK_LAB
+// ------------------------------------------------------------------------------------------
+// k_search_refill2 (lab, TDTK_SEARCH_VARIANT=22): the persistent-lane kernel with TWO queries per lane.
+// The trips of k_search_refill's node walk are 0.44 full (tools/lane_fill_probe.py): a lane whose query has reached its
+// bucket waits for the slowest walk of the wave, and a trip is one memory round trip.  Here a lane carries two queries,
+// both states in registers; every trip of the node walk issues the record loads of BOTH before it uses either, so a trip's
+// round trip serves up to two visits per lane and a lane leaves the walk only when both of its queries hold a bucket (or
+// are done).  Buckets are scanned one query after the other (the shadow groups' sixty registers are shared).  Each query's
+// traversal -- visits, their order, every comparison -- is untouched: same indices, same counters.
+// ------------------------------------------------------------------------------------------
+template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE>
+__device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
+{
+  __shared__ uint4 lds_stk[2][SD][BLOCK];
+  const size_t gl = (size_t)bid * BLOCK + threadIdx.x;
+  const unsigned lane = threadIdx.x & (WAVE - 1);
+  LaneStackQ<BLOCK, SD> st[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    st[s].l_e = &lds_stk[s][0][threadIdx.x];
+    st[s].g_m2 = a.ovf_m2 ? a.ovf_m2 + 2 * gl + s : nullptr;       // (overflow columns: two per lane)
+    st[s].g_ref = a.ovf_ref ? a.ovf_ref + 2 * gl + s : nullptr;
+    st[s].gstride = (size_t)nb * BLOCK * 2;
+    st[s].sp = 0;
+  }
+  const TreeDev& T = a.T;
+  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
+  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
+  const LeafEntry* const t_leaf_tab = T.leaf_tab;
+  const uint32_t t_cb = T.cb, t_cmask = T.cmask;
+  int* const a_kpos = a.kpos;
+  double* const a_d2 = a.d2;
+  unsigned char* const a_cost = a.cost;
+  const char* const t_grp = reinterpret_cast<const char*>(T.grp);
+  const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
+
+  // the hand-out order of the slab (expensive queries first), as in k_search_refill
+  constexpr int ORD_MAX = 512;
+  __shared__ unsigned short lds_order[BLOCK / WAVE][ORD_MAX];
+  unsigned short* const my_order = lds_order[threadIdx.x / WAVE];
+  bool ordered = false;
+  const uint32_t wpx = (nb >> 3) * (BLOCK / WAVE);
+  const uint32_t wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE));
+  const size_t reg0 = (size_t)(bid & 7u) * wpx * (size_t)a.qpw + (size_t)wx * (size_t)a.qpw;
+  size_t next_q = reg0 < a.n ? reg0 : a.n;
+  const size_t end_q = (reg0 + (size_t)a.qpw < a.n) ? reg0 + (size_t)a.qpw : a.n;
+  if (a.use_cost && a.cost && end_q > next_q && end_q - next_q <= (size_t)ORD_MAX) {
+    const uint32_t cntp = (uint32_t)(end_q - next_q);
+    int cls[ORD_MAX / WAVE];
+    unsigned cvv[ORD_MAX / WAVE];
+    unsigned mn = 255u, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < ORD_MAX / WAVE; r++) {
+      const uint32_t o = (uint32_t)r * WAVE + lane;
+      cvv[r] = (o < cntp) ? (unsigned)a.cost[next_q + o] : 0u;
+      if (o < cntp) { mn = min(mn, cvv[r]); mx = max(mx, cvv[r]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, (unsigned)__shfl_xor((int)mn, off, WAVE));
+      mx = max(mx, (unsigned)__shfl_xor((int)mx, off, WAVE));
+    }
+    const unsigned span = (mx > mn) ? mx - mn + 1u : 1u;
+#pragma unroll
+    for (int r = 0; r < ORD_MAX / WAVE; r++) {
+      const uint32_t o = (uint32_t)r * WAVE + lane;
+      cls[r] = (o < cntp) ? (int)min(((cvv[r] - mn) * 8u) / span, 7u) : -1;
+    }
+    uint32_t base = 0;
+    for (int k = 7; k >= 0; k--) {
+#pragma unroll
+      for (int r = 0; r < ORD_MAX / WAVE; r++) {
+        if ((uint32_t)r * WAVE >= cntp) continue;
+        const unsigned long long m = __ballot(cls[r] == k);
+        if (cls[r] == k) my_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(r * WAVE + lane);
+        base += (uint32_t)__popcll(m);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ordered = true;
+  }
+  const size_t piece0 = next_q;
+
+  uint32_t cur[2] = {REF_DONE, REF_DONE};
+  double best[2] = {0.0, 0.0}, qx[2] = {0, 0}, qy[2] = {0, 0}, qz[2] = {0, 0};
+  int bk[2] = {-1, -1};
+  uint32_t qi[2] = {0, 0};
+  bool have[2] = {false, false};
+  unsigned nbk[2] = {0, 0};
+  BoxF32 bx[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) { bx[s].qx = bx[s].qy = bx[s].qz = 0.f; bx[s].delta = 0.f; bx[s].thi = 0.f; bx[s].tlo = 0.f; bx[s].ec = 0.f; bx[s].pthr = 0.f; }
+  unsigned c_int = 0, c_leaf = 0, c_pts = 0, c_t1 = 0, c_t2 = 0;
+
+  for (;;) {
+    // ---- retire finished queries, hand out new ones (both slots) ----
+    unsigned long long idlem[2], activem = 0;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const bool idle = (cur[s] == REF_DONE);
+      if (idle && have[s]) {
+        gstore<int>(reinterpret_cast<char*>(a_kpos), qi[s] << 2, bk[s]);
+        if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), qi[s] << 3, best[s]);
+        if (a_cost) a_cost[qi[s]] = (unsigned char)min(nbk[s], 255u);
+        have[s] = false;
+      }
+      idlem[s] = __ballot(idle);
+      activem |= __ballot(!idle);
+    }
+    const unsigned nidle = (unsigned)__popcll(idlem[0]) + (unsigned)__popcll(idlem[1]);
+    const bool fill = (activem == 0 || nidle >= 2 * THRESH);
+    if (next_q < end_q && fill) {
+      // slot 0 of every idle lane first, then slot 1 (a lane with both idle takes two queries)
+      const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const unsigned rank = (unsigned)__popcll(idlem[s] & below) + (s ? (unsigned)__popcll(idlem[0]) : 0u);
+        const size_t slot = next_q + rank;
+        const bool got = (cur[s] == REF_DONE) && slot < end_q;
+        const size_t mine = (got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
+        if (got) {
+          const uint32_t m8 = (uint32_t)mine << 3;
+          const int kp_prev = a.warm ? gload<int>(reinterpret_cast<const char*>(a_kpos), (uint32_t)mine << 2) : -1;
+          double tx = gload<double>(reinterpret_cast<const char*>(a.x), m8), ty = gload<double>(reinterpret_cast<const char*>(a.y), m8),
+                 tz = gload<double>(reinterpret_cast<const char*>(a.z), m8);
+          if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
+            dev_xf3_inplace(a.pending, tx, ty, tz);
+            gstore<double>(reinterpret_cast<char*>(a.x), m8, tx); gstore<double>(reinterpret_cast<char*>(a.y), m8, ty);
+            gstore<double>(reinterpret_cast<char*>(a.z), m8, tz);
+            if (a.nx) {
+              double px = a.nx[mine], py = a.ny[mine], pz = a.nz[mine];
+              dev_xf3normal(a.pending, px, py, pz);
+              a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz;
+            }
+          }
+          qx[s] = tx; qy[s] = ty; qz[s] = tz;
+          if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx[s], qy[s], qz[s]);  // searchTree.cc:122
+          qi[s] = (uint32_t)mine; have[s] = true; nbk[s] = 0;
+          cur[s] = T.root_ref; best[s] = warm_radius_kp(a, kp_prev, qx[s], qy[s], qz[s]); bk[s] = -1; st[s].sp = 0;
+          bx[s].set_query(qx[s], qy[s], qz[s], T.absmax);
+          bx[s].set_radius(best[s]);
+        }
+      }
+      next_q += nidle;
+    }
+    if (__ballot(cur[0] != REF_DONE || cur[1] != REF_DONE) == 0) {
+      if (next_q >= end_q) break;
+      continue;
+    }
+
+    // ---- phase 1: walk internal nodes until both of this lane's queries hold a bucket (or are finished) ----
+    while (!(cur[0] & REF_LEAF) || !(cur[1] & REF_LEAF)) {
+      if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
+      const bool at[2] = {!(cur[0] & REF_LEAF), !(cur[1] & REF_LEAF)};
+      // the records of both, requested before either is used
+      float4 b0[2], b1[2];
+      double2 sc[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const uint32_t ho = __umul24(at[s] ? cur[s] : 0u, (uint32_t)sizeof(KdHot));
+        b0[s] = gload<float4>(hotb, ho);                 // cx cy cz hx   (a lane whose query is not at a node re-reads the root: an L1 hit)
+        b1[s] = gload<float4>(hotb, ho + 16);            // hy hz axis -
+        sc[s] = gload<double2>(hotb, ho + 32);           // splitval {c1, c2}
+      }
+      asm volatile("" : "+v"(b0[0].x), "+v"(b1[0].z), "+v"(sc[0].x), "+v"(b0[1].x), "+v"(b1[1].z), "+v"(sc[1].x));
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        if (!at[s]) continue;
+        if (COUNT) ++c_int;
+        ++nbk[s];
+        const float a32 = fmaxf(fmaxf(fabsf(bx[s].qx - b0[s].x) - b0[s].w, fabsf(bx[s].qy - b0[s].y) - b1[s].x), fabsf(bx[s].qz - b0[s].z) - b1[s].y);
+        bool prune = a32 >= bx[s].thi;
+        if (__builtin_expect(!prune && !(a32 < bx[s].tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+          const uint32_t no = (uint32_t)((cur[s] & REF_VAL) << 6);
+          const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
+          const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
+          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx[s], qy[s], qz[s], best[s]);
+        }
+        uint32_t next = REF_DONE;
+        if (!prune) next = descend_ax(sc[s].x, (uint32_t)__double2loint(sc[s].y), (uint32_t)__double2hiint(sc[s].y), __float_as_uint(b1[s].z), qx[s], qy[s], qz[s], best[s], st[s]);
+        else {
+          while (st[s].sp > 0) {
+            --st[s].sp;
+            uint32_t r; double m2;
+            st[s].top(r, m2);
+            if (m2 < best[s]) { next = r; break; }
+          }
+        }
+        cur[s] = next;
+      }
+    }
+
+    // ---- phase 2: scan the buckets, one query after the other, then pop ----
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      if (cur[s] == REF_DONE) continue;
+      if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t2; }
+      const uint32_t v = cur[s] & REF_VAL;
+      int start, count;
+      if (t_leaf_tab) { const LeafEntry le = t_leaf_tab[v]; start = le.start; count = le.count; }
+      else { start = (int)(v >> t_cb); count = (int)(v & t_cmask); }
+      if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
+      nbk[s] += 4u;
+      const char* pb = reinterpret_cast<const char*>(pts);
+      const uint32_t o0 = (uint32_t)start << 5;
+      const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
+      if (t_grp != nullptr && count <= 4 * GRP_TRIP) {
+        bucket_scan_groups(t_grp, pb, start, count, o0, bx[s], qx[s], qy[s], qz[s], best[s], bk[s]);
+      } else {
+        for (uint32_t o = o0; o <= olast; o += 32u * 4) {
+          uint32_t oo[4];
+          double px[4], py[4], pz[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            oo[j] = (j == 0) ? o : min(o + 32u * (uint32_t)j, olast);
+            const double2 pxy = *reinterpret_cast<const double2*>(pb + oo[j]);
+            px[j] = pxy.x; py[j] = pxy.y;
+            pz[j] = *reinterpret_cast<const double*>(pb + oo[j] + 16);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const double dx = px[j] - qx[s], dy = py[j] - qy[s], dz = pz[j] - qz[s];
+            const double dd = dx * dx + dy * dy + dz * dz;
+            if (dd < best[s]) { best[s] = dd; bk[s] = (int)(oo[j] >> 5); }
+          }
+        }
+      }
+      bx[s].set_radius(best[s]);
+      cur[s] = REF_DONE;
+      while (st[s].sp > 0) {
+        --st[s].sp;
+        uint32_t r; double m2;
+        st[s].top(r, m2);
+        if (m2 < best[s]) { cur[s] = r; break; }
+      }
+    }
+  }
+  if (COUNT && a.counters) {
+    const unsigned long long s_int = wave_sum_u(c_int), s_leaf = wave_sum_u(c_leaf), s_pts = wave_sum_u(c_pts);
+    const unsigned long long s_t1 = wave_sum_u(c_t1), s_t2 = wave_sum_u(c_t2);
+    if (lane == 0) {
+      atomicAdd(&a.counters[0], s_int); atomicAdd(&a.counters[1], s_leaf); atomicAdd(&a.counters[2], s_pts);
+      atomicAdd(&a.counters[8], s_t1); atomicAdd(&a.counters[9], s_t2);
+    }
+  }
+  if constexpr (FUSE == 3) {
+    // the base pair sums of this wave's own slab after its last query, as in k_search_refill (FUSE 3)
+    double acc[ACC_DD];
+#pragma unroll
+    for (int k = 0; k < ACC_DD; k++) acc[k] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const uint32_t slab = (uint32_t)a.qpw;
+    for (uint32_t j0 = 0; j0 < slab; j0 += 2 * WAVE) {
+      size_t qq[2];
+      int kk[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t j = j0 + (uint32_t)u * WAVE + lane;
+        qq[u] = reg0 + j;
+        kk[u] = (j < slab && qq[u] < a.n) ? a.kpos[qq[u]] : -1;
+      }
+      double cx[2], cy[2], cz[2], tx[2], ty[2], tz[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        cx[u] = cy[u] = cz[u] = tx[u] = ty[u] = tz[u] = 0.0;
+        if (kk[u] >= 0) {
+          const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)kk[u] << 5));
+          cx[u] = c.x; cy[u] = c.y; cz[u] = c.z;
+          tx[u] = a.x[qq[u]]; ty[u] = a.y[qq[u]]; tz[u] = a.z[qq[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (kk[u] < 0) continue;
+        double mx, my, mz;
+        dev_xf3(a.A, cx[u], cy[u], cz[u], mx, my, mz);  // searchTree.cc:147
+        const double px = mx - tx[u], py = my - ty[u], pz = mz - tz[u];
+        acc[ACC_N] += 1.0;
+        acc[ACC_SUM] += px * px + py * py + pz * pz;
+        const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
+        const double d0 = tx[u] - a.shift[0], d1 = ty[u] - a.shift[1], d2 = tz[u] - a.shift[2];
+        acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
+        acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
+        acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
+        acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
+        acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
+      }
+    }
+    constexpr int NW = BLOCK / WAVE;
+    __shared__ double red[NW][ACC_DD];
+    const int wv = threadIdx.x / WAVE;
+#pragma unroll
+    for (int k = 0; k < ACC_DD; k++) {
+      const double sres = wave_sum(acc[k]);
+      if (lane == 0) red[wv][k] = sres;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
+      double sres = 0.0;
+      if (k < ACC_DD)
+        for (int w = 0; w < NW; w++) sres += red[w][k];
+      a.partials[(size_t)bid * ACC_TOTAL + k] = sres;
+    }
+  }
+}
+
+template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE, int WPS>
+__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill2(const SearchArgs a_by_value)
+{
+  (void)a_by_value;
+  search_refill2_body<BLOCK, SD, THRESH, COUNT, FUSE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
+}
+#endif   // TDTK_LAB
+
 // Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
 // batch l with the arguments args[l] (device memory; every base[] a multiple of 8, so a workgroup's XCD is the one its
 // batch-relative index says).  Workgroups are dispatched in order, so the tail of one batch is filled by the next --
@@ -3025,12 +3340,41 @@ static int refill_pool_pct(size_t n, int side_by_side)
   return v;
 }
 bool search_uses_queue(size_t n) { return pick_variant(n) == 30 || (pick_variant(n) == 20 && refill_pool_pct(n, 1) > 0); }
+#ifdef TDTK_LAB
+// two queries per lane (k_search_refill2, TDTK_TWO_PER_LANE=<waves per SIMD: 2 or 3>): one generation of that many waves
+static int two_per_lane()
+{
+  const char* e = lab_env("TDTK_TWO_PER_LANE");
+  const int v = e ? atoi(e) : 0;
+  return (v == 2 || v == 3) ? v : 0;
+}
+static uint32_t refill2_grid(size_t n, int* qpw_out)
+{
+  const size_t slots = (size_t)num_cu() * 4 * (size_t)two_per_lane();
+  size_t qpw = (n + slots - 1) / slots;
+  qpw = (qpw + 31) & ~(size_t)31;
+  if (qpw < 128) qpw = 128;
+  if (qpw > 512) qpw = 512;
+  const size_t waves = (n + qpw - 1) / qpw;
+  size_t nb = (waves + 1) / 2;
+  nb = (nb + 7) & ~(size_t)7;
+  *qpw_out = (int)qpw;
+  return (uint32_t)(nb < 8 ? 8 : nb);
+}
+static bool two_per_lane_for(size_t n, int side_by_side)
+{
+  return two_per_lane() && side_by_side <= 1 && pick_variant(n) == 20 && (n + 511) / 512 <= (size_t)num_cu() * 4 * (size_t)two_per_lane();
+}
+#endif
 uint32_t search_fused_rows(size_t n, int side_by_side)
 {
   const int v = pick_variant(n);
   if (v == 10) return g8_grid4(n);
   if (v == 4) return search_grid(n);
   int q;
+#ifdef TDTK_LAB
+  if (two_per_lane_for(n, side_by_side)) return refill2_grid(n, &q);
+#endif
   return refill_grid_b(n, 128, &q, side_by_side);
 }
 
@@ -3038,6 +3382,17 @@ template <bool COUNT, int FUSE>
 static void launch_refill128(SearchArgs& a, hipStream_t s)
 {
   int qpw;
+#ifdef TDTK_LAB
+  if constexpr (FUSE == 0 || FUSE == 3) {
+    if (two_per_lane_for(a.n, a.side_by_side) && !a.bounds) {
+      const uint32_t nb2 = refill2_grid(a.n, &qpw);
+      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
+      if (two_per_lane() == 3) hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 3>), dim3(nb2), dim3(128), 0, s, a);
+      else hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 2>), dim3(nb2), dim3(128), 0, s, a);
+      return;
+    }
+  }
+#endif
   const uint32_t nb = refill_grid_b(a.n, 128, &qpw, a.side_by_side);
   a.qpw = qpw;
   // Two pieces when every wave of the launch is resident at once (the XCD's waves then move through its eighth of the
