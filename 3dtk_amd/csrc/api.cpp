@@ -125,6 +125,7 @@ struct Ctx {
   hipEvent_t e_b1 = nullptr, e_b2 = nullptr, e_b3 = nullptr;
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums
+  void* h_build = nullptr;  // 64 KB, pinned: the tree build's looks at the device (BuildSide::h_pin)
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
   size_t h_stage_cap = 0;
   void* h_moves = nullptr;  // pinned staging of scans_settle's table (its own: a settle may precede a batched launch in one call)
@@ -202,6 +203,7 @@ Ctx::~Ctx()
     if (stream_b) (void)hipStreamDestroy(stream_b);
     if (stream_c) (void)hipStreamDestroy(stream_c);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (h_build) (void)hipHostFree(h_build);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -232,6 +234,7 @@ static int get_ctx(int device, Ctx** out, bool touches_scans = true)
     HIPCHK(hipEventCreateWithFlags(&c->e_moves, hipEventDisableTiming));
     // (coherent, said explicitly: the host reads these words while the kernel that writes them is still running -- await_sums)
     HIPCHK(hipHostMalloc((void**)&c->h_pin, sizeof(double) * 256, hipHostMallocCoherent));
+    HIPCHK(hipHostMalloc(&c->h_build, 65536, hipHostMallocDefault));
     it = g_ctx.emplace(device, std::move(c)).first;
     g_ctx_live.fetch_add(1);
   }
@@ -490,8 +493,8 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
     HIPCHK(hipEventCreateWithFlags(&c->e_b2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_b3, hipEventDisableTiming));
   }
-  const BuildSide side = {c->stream_b, c->stream_c, c->e_b1, c->e_b2, c->e_b3};
-  DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, alone ? &side : nullptr);
+  const BuildSide side = {alone ? c->stream_b : nullptr, alone ? c->stream_c : nullptr, c->e_b1, c->e_b2, c->e_b3, c->h_build};
+  DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, &side);
   if (r.respeculated) g_respeculated.fetch_add(1);
   if (r.err != hipSuccess) {
     set_error(r.degenerate ? std::string("degenerate split (non-finite coordinates?)")

@@ -148,13 +148,13 @@ __device__ __forceinline__ double wave_add(double v) {
 // adds in run order, the critical path of the whole build -- then reads the values back one by
 // one at a wave-uniform address (LDS broadcast, in-order returns, so the reads pipeline ahead of
 // the chain) and the vector ALU issues nothing but the dependent v_add_f64 chain.
-__global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
-                                                 const double* __restrict__ cx, const double* __restrict__ cy,
-                                                 const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
+__device__ __forceinline__ void measure_body(const uint32_t vblock, const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                             const double* __restrict__ cx, const double* __restrict__ cy,
+                                             const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
 {
   __shared__ alignas(16) double stage[256 / WAVE][2][MEAS_STAGE * WAVE + 16];   // + 16: lds_chain32 requests 128 bytes past the data
   // wave-uniform by construction; readfirstlane tells the compiler so
-  const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
+  const uint32_t w = __builtin_amdgcn_readfirstlane((vblock * 256u + threadIdx.x) / WAVE);
   const int lane = threadIdx.x & (WAVE - 1);
   if (w >= 3u * lv->nseg) return;
   const uint32_t sgi = w / 3u, ax = w % 3u;
@@ -215,6 +215,12 @@ __global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, 
     out[sgi].hi[ax] = hi;
     out[sgi].mean[ax] = sum / (double)n;
   }
+}
+__global__ void __launch_bounds__(256) k_measure(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                 const double* __restrict__ cx, const double* __restrict__ cy,
+                                                 const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
+{
+  measure_body(blockIdx.x, segs, lv, cx, cy, cz, out, big_min);
 }
 
 
@@ -765,14 +771,17 @@ struct BSpecAll { BSpecLevel L[BIG_SPEC_MAX]; int n; };
 // What the cut needs, and nothing else (round 3, second step): bounds and plain sums of the big nodes in two short
 // passes -- per block of 512 positions, then per node over its blocks -- instead of the piece statistics and their
 // prefix scan, which only the exact chain needs and which now run with it on the second stream.
-__global__ void __launch_bounds__(256) k_big_partials(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
-                                                      const double* __restrict__ cx, const double* __restrict__ cy,
-                                                      const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part)
+// (snap != nullptr: the block also writes the level's snapshot of its 512 positions -- what k_spec_snapshot does in a
+// launch of its own)
+__device__ __forceinline__ void big_partials_body(const uint32_t vblock, const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
+                                                  const double* __restrict__ cx, const double* __restrict__ cy,
+                                                  const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part,
+                                                  double* __restrict__ snap, uint32_t* __restrict__ seg_snap, uint32_t n1)
 {
   constexpr int R = BIG_PB / 256;
   __shared__ uint32_t s_startB;
   __shared__ double s_red[256 / WAVE][2][9];
-  const uint32_t p0 = blockIdx.x * BIG_PB;
+  const uint32_t p0 = vblock * BIG_PB;
   const uint32_t pend = (p0 + BIG_PB < M) ? p0 + BIG_PB : M;
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   if (threadIdx.x == 0) s_startB = 0xFFFFFFFFu;
@@ -788,6 +797,13 @@ __global__ void __launch_bounds__(256) k_big_partials(const BSeg* __restrict__ s
     xs[r] = in ? cx[p] : 0.0; ys[r] = in ? cy[p] : 0.0; zs[r] = in ? cz[p] : 0.0;
   }
   const uint32_t sid0 = seg_of[p0];
+  if (snap) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
+      if (p < pend) { snap[p] = xs[r]; snap[(size_t)n1 + p] = ys[r]; snap[2 * (size_t)n1 + p] = zs[r]; seg_snap[p] = sids[r]; }
+    }
+  }
   __syncthreads();
   // piece A: the big node the block starts in
   uint32_t a_end = p0;
@@ -845,15 +861,32 @@ __global__ void __launch_bounds__(256) k_big_partials(const BSeg* __restrict__ s
       }
       o.lo[c] = lo; o.hi[c] = hi; o.sum[c] = sm;
     }
-    part[(size_t)blockIdx.x * 2 + k] = o;
+    part[(size_t)vblock * 2 + k] = o;
   }
+}
+__global__ void __launch_bounds__(256) k_big_partials(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
+                                                      const double* __restrict__ cx, const double* __restrict__ cy,
+                                                      const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part)
+{
+  big_partials_body(blockIdx.x, segs, seg_of, cx, cy, cz, M, part, nullptr, nullptr, 0u);
+}
+// The front of a speculated level in ONE launch (a small scan's build is a chain of dependent launches, ~7 us apiece): the
+// first nb_part workgroups are k_big_partials' and write the snapshot on the way, the rest are k_measure's (the chains of the
+// level's nodes below the piecewise path) -- independent passes over the same read-only level.
+__global__ void __launch_bounds__(256) k_level_front(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                     const uint32_t* __restrict__ seg_of, const double* __restrict__ cx,
+                                                     const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M,
+                                                     BPart* __restrict__ part, double* __restrict__ snap, uint32_t* __restrict__ seg_snap,
+                                                     uint32_t n1, uint32_t nb_part, BMeas* __restrict__ meas, uint32_t big_min)
+{
+  if (blockIdx.x < nb_part) big_partials_body(blockIdx.x, segs, seg_of, cx, cy, cz, M, part, snap, seg_snap, n1);
+  else measure_body(blockIdx.x - nb_part, segs, lv, cx, cy, cz, meas, big_min);
 }
 // one wave per node: a big node's bounds and plain sums from its blocks' partials; keeps what the background chain and
 // the final check need of this level (its node list, which axis each node is cut along)
-__global__ void __launch_bounds__(256) k_big_approx(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
-                                                    const BPart* __restrict__ part, BMeas* __restrict__ meas, BSpecLevel L, int fault)
+__device__ __forceinline__ void big_approx_wave(const uint32_t i, const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                const BPart* __restrict__ part, BMeas* __restrict__ meas, const BSpecLevel& L, int fault)
 {
-  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (i >= lv->nseg) return;
   const BSeg sg = segs[i];
@@ -878,6 +911,11 @@ __global__ void __launch_bounds__(256) k_big_approx(const BSeg* __restrict__ seg
   meas[i] = m;
   L.axis[i] = split;
 }
+__global__ void __launch_bounds__(256) k_big_approx(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                    const BPart* __restrict__ part, BMeas* __restrict__ meas, BSpecLevel L, int fault)
+{
+  big_approx_wave((blockIdx.x * blockDim.x + threadIdx.x) / WAVE, segs, lv, part, meas, L, fault);
+}
 // the level as it stands before its partition pass: coordinates and labels (the exact chain reads these, later)
 __global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const double* __restrict__ cx, const double* __restrict__ cy,
                                 const double* __restrict__ cz, uint32_t M, uint32_t n1, double* __restrict__ snap,
@@ -889,10 +927,9 @@ __global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const doubl
   seg_snap[p] = seg_of[p];
 }
 // after the level's count: where each internal big node's record is and how many points went left
-__global__ void k_spec_keep(const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
-                            const uint32_t* __restrict__ nleft, BSpecLevel L)
+__device__ __forceinline__ void spec_keep_at(const BLevel* __restrict__ lv, const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
+                                             const uint32_t* __restrict__ nleft, const BSpecLevel& L, const uint32_t i)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= lv->nseg || L.axis[i] >= 3u || !kind[i]) return;
   L.node[i] = lv->node_base + irank[i];
   L.nleft[i] = nleft[i];
@@ -1066,13 +1103,13 @@ __global__ void k_emit(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, c
 // a level of at most 1023 nodes (the first ten of any tree): decide, rank (exclusive scan of `kind` over bound + 1
 // entries) and emit in one workgroup -- three dependent launches less per level, which is what a small scan's build is
 // made of (~13 launches per level at ~4.5 us each)
-__global__ void __launch_bounds__(1024) k_nodes_small(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, uint32_t bound,
-                                                      const BMeas* __restrict__ meas, uint32_t bucket,
-                                                      uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
-                                                      double* __restrict__ splitval, uint32_t* __restrict__ nleft,
-                                                      uint32_t* __restrict__ irank, KdNode* __restrict__ nodes,
-                                                      double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
-                                                      uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
+__device__ __forceinline__ void nodes_small_body(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, uint32_t bound,
+                                                 const BMeas* __restrict__ meas, uint32_t bucket,
+                                                 uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
+                                                 double* __restrict__ splitval, uint32_t* __restrict__ nleft,
+                                                 uint32_t* __restrict__ irank, KdNode* __restrict__ nodes,
+                                                 double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                                                 uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
 {
   __shared__ uint32_t wtot[1024 / WAVE];
   const uint32_t i = threadIdx.x;
@@ -1089,6 +1126,31 @@ __global__ void __launch_bounds__(1024) k_nodes_small(const BSeg* __restrict__ s
   __threadfence_block();
   __syncthreads();                                          // emit reads irank[nseg] and other nodes' nothing else
   emit_node(segs, lv, meas, kind, axis, splitval, irank, nodes, node_r, leaf_tab, root_ref, max_leaf, i);
+}
+__global__ void __launch_bounds__(1024) k_nodes_small(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, uint32_t bound,
+                                                      const BMeas* __restrict__ meas, uint32_t bucket,
+                                                      uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
+                                                      double* __restrict__ splitval, uint32_t* __restrict__ nleft,
+                                                      uint32_t* __restrict__ irank, KdNode* __restrict__ nodes,
+                                                      double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                                                      uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf)
+{
+  nodes_small_body(segs, lv, bound, meas, bucket, kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, root_ref, max_leaf);
+}
+// the same behind the level's k_big_approx, for a speculated level of at most 16 nodes: wave w is node w's (one launch less)
+__global__ void __launch_bounds__(1024) k_nodes_small_approx(const BSeg* __restrict__ segs, BLevel* __restrict__ lv, uint32_t bound,
+                                                             BMeas* __restrict__ meas, uint32_t bucket,
+                                                             uint32_t* __restrict__ kind, uint32_t* __restrict__ axis,
+                                                             double* __restrict__ splitval, uint32_t* __restrict__ nleft,
+                                                             uint32_t* __restrict__ irank, KdNode* __restrict__ nodes,
+                                                             double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
+                                                             uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf,
+                                                             const BPart* __restrict__ part, BSpecLevel L, int fault)
+{
+  big_approx_wave(threadIdx.x / WAVE, segs, lv, part, meas, L, fault);
+  __threadfence_block();
+  __syncthreads();
+  nodes_small_body(segs, lv, bound, meas, bucket, kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, root_ref, max_leaf);
 }
 
 // ---- per node: how many of its points lie below the split value (the position of the split) ---------------
@@ -1260,6 +1322,22 @@ __global__ void k_misplaced_children(const uint32_t* __restrict__ seg_of, const 
   if (blockIdx.x < nb_first) misplaced_at(seg_of, kind, segs, axis, splitval, nleft, cx, cy, cz, M, LR, blockIdx.x * blockDim.x + threadIdx.x);
   else children_of(segs, lv, kind, irank, nleft, next, err, (blockIdx.x - nb_first) * blockDim.x + threadIdx.x);
 }
+// ... and, on a speculated level, a third: what the final check needs of the level's big internal nodes (spec_keep_at)
+__global__ void k_misplaced_children_keep(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+                                          const BSeg* __restrict__ segs, const uint32_t* __restrict__ axis,
+                                          const double* __restrict__ splitval, const uint32_t* __restrict__ nleft,
+                                          const double* __restrict__ cx, const double* __restrict__ cy,
+                                          const double* __restrict__ cz, uint32_t M, unsigned long long* __restrict__ LR,
+                                          uint32_t nb_first, const BLevel* __restrict__ lv, const uint32_t* __restrict__ irank,
+                                          BSeg* __restrict__ next, uint32_t* __restrict__ err, BSpecLevel L)
+{
+  if (blockIdx.x < nb_first) misplaced_at(seg_of, kind, segs, axis, splitval, nleft, cx, cy, cz, M, LR, blockIdx.x * blockDim.x + threadIdx.x);
+  else {
+    const uint32_t i = (blockIdx.x - nb_first) * blockDim.x + threadIdx.x;
+    children_of(segs, lv, kind, irank, nleft, next, err, i);
+    spec_keep_at(lv, kind, irank, nleft, L, i);
+  }
+}
 __global__ void k_swap_relabel(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
                                const unsigned long long* __restrict__ nswap_ptr, uint32_t* __restrict__ perm,
                                double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz, uint32_t nb_first,
@@ -1271,10 +1349,21 @@ __global__ void k_swap_relabel(const uint32_t* __restrict__ posL, const uint32_t
   else relabel_at(segs, kind, irank, nleft, M, seg_of, (blockIdx.x - nb_first) * blockDim.x + threadIdx.x);
 }
 
+// (its first workgroup also sets up what the levels start from -- the build's small words, the level counters, the root
+// node: four memsets / copies less in front of a build that is a chain of dependent commands)
 __global__ void k_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
                        uint32_t* __restrict__ seg_of, double* __restrict__ cx, double* __restrict__ cy,
-                       double* __restrict__ cz)
+                       double* __restrict__ cz, uint32_t* __restrict__ small, BLevel* __restrict__ lvl, BSeg* __restrict__ segs)
 {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) small[threadIdx.x] = 0u;
+    for (uint32_t k = threadIdx.x; k < BUILD_MAX_LEVELS + 2; k += blockDim.x) {
+      BLevel z = {0u, 0u, 0u};
+      if (k == 0) z.nseg = 1u;
+      lvl[k] = z;
+    }
+    if (threadIdx.x == 0) { BSeg root = {0u, M, -1, 0u}; segs[0] = root; }
+  }
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   perm[p] = p; seg_of[p] = 0;
@@ -1773,6 +1862,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   KdNode* f_nodes = nullptr; double* f_r = nullptr; LeafEntry* f_leaf = nullptr;
   uint32_t node_count = 0, leaf_count = 0, depth = 0;
   uint32_t h_spec_err = 0;
+  bool tail_enqueued = false;
   bool spec_on = false;
   bool spec_suspect = false;   // the failure may be the speculation's doing (see `fail`)
   size_t scan_tmp = 0;
@@ -1828,18 +1918,12 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     const int big_dbg = big_dbg_all & (3 | 16);   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
     uint32_t* small = (uint32_t*)(arena + o_small);  // [0] root_ref [1] max_leaf [2] err
-    BCHK(hipMemsetAsync(small, 0, 256, s));
     // the partition's scan in one launch while the positions fit its 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
     static const bool own_scan_env = [] { const char* e = lab_env("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
     const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
     const size_t o_scanstate = O[31];
     if (own_scan) BCHK(hipMemsetAsync(arena + o_scanstate, 0, scan_pair27_state_bytes(n1), s));
-    BCHK(hipMemsetAsync(lvl, 0, sizeof(BLevel) * (BUILD_MAX_LEVELS + 2), s));
-    const BSeg root = {0u, M, -1, 0u};
-    const BLevel l0 = {1u, 0u, 0u};
-    BCHK(hipMemcpyAsync(segs, &root, sizeof root, hipMemcpyHostToDevice, s));
-    BCHK(hipMemcpyAsync(lvl, &l0, sizeof l0, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz);
+    hipLaunchKernelGGL(k_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small, lvl, segs);
 
     // Levels are enqueued in batches; how many nodes a level has, and where its node / bucket records start, is
     // known on the device only (lvl[]).  The host looks once after a first batch as deep as a balanced tree gets
@@ -1865,15 +1949,26 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       if (fin_env && no_finish == 0 && bucket >= 6 && L < 31 && (1u << L) <= FIN_MAX_SUBTREES && !big_dbg_all) fin_level = L;
     }
     if (fin_level != 0xFFFFFFFFu) batch = fin_level;
-    std::vector<BLevel> hl;
-    uint32_t h_small[3] = {0u, 0u, 0u};
+    // The host's looks at the device land in pinned memory when the caller has some (a copy into pageable memory is a
+    // synchronisation of its own): h_small = small[0 .. 7] (root reference, largest bucket, error word, check word, the
+    // hand-over level's largest node and node count), hl = the level counters.
+    std::vector<unsigned char> h_pageable;
+    unsigned char* const hst = (side && side->h_pin) ? static_cast<unsigned char*>(side->h_pin) : (h_pageable.resize(65536), h_pageable.data());
+    uint32_t* const h_small = reinterpret_cast<uint32_t*>(hst);
+    BLevel* const hl = reinterpret_cast<BLevel*>(hst + 64);
+    static_assert(64 + sizeof(BLevel) * (BUILD_MAX_LEVELS + 2) <= 65536, "the staging block holds every level's counters");
+    std::memset(hst, 0, 64);
+    bool have_max = false;
     for (;;) {
       if (level == fin_level) {
         // does the level's largest node fit a workgroup's LDS?  (An unbalanced cloud -- a real scan -- takes a level or two more.)
-        uint32_t h_max[2] = {0u, 0u};
-        hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4);
-        BCHK(hipMemcpyAsync(h_max, small + 4, sizeof h_max, hipMemcpyDeviceToHost, s));
-        BCHK(hipStreamSynchronize(s));
+        if (!have_max) {
+          hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4);
+          BCHK(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, s));
+          BCHK(hipStreamSynchronize(s));
+        }
+        have_max = false;
+        const uint32_t h_max[2] = {h_small[4], h_small[5]};
         if (h_max[0] > FIN_LDS && h_max[1] * 2u <= FIN_MAX_SUBTREES && fin_level + 1u < 31u) {
           fin_level++;              // one more level by its own launches (below), then look again
           known = h_max[1]; known_at = level;
@@ -1907,10 +2002,21 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         hipLaunchKernelGGL(k_fin_place, dim3(tmax), dim3(256), 0, s, ftab, foff, ftot, roots, lvl + fin_level, (const KdNode*)(arena + O[32]),
                            (const double*)(arena + O[33]), (const LeafEntry*)(arena + O[34]), nodes, node_r, leaf_tab, small + 0);
         level = fin_level + FIN_LV + 2u;
-        hl.assign(level + 1, BLevel{0u, 0u, 0u});
-        BCHK(hipMemcpyAsync(hl.data(), lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
-        BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+        // what follows the levels does not wait for the host's look: the check of the speculated cuts and the point array
+        // are enqueued now, their results come back with the level counters
+        if (spec && SP.n) {
+          BCHK(hipEventRecord(side->e2, side->s2));
+          BCHK(hipStreamWaitEvent(s, side->e2, 0));
+          if (side->s3) { BCHK(hipEventRecord(side->e3, side->s3)); BCHK(hipStreamWaitEvent(s, side->e3, 0)); }
+          hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
+          hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
+        }
+        hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
+        tail_enqueued = true;
+        BCHK(hipMemcpyAsync(hl, lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
+        BCHK(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, s));
         BCHK(hipStreamSynchronize(s));
+        if (spec && SP.n) h_spec_err = h_small[3];
         if (fin_trace) {
           uint32_t ph[10];
           if (hipMemcpy(ph, small + 16, sizeof ph, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1951,16 +2057,20 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         // cycles per point where three waves need 10: level 7 of a 1M-point tree 253 us against 46, level 12 equal,
         // level 16 74 against 139)
         const bool measure_per_axis = measure_per_axis_always || (M_ >> level) > 128;
-        if (measure_per_axis)
+        bool spec_this = big_level && spec && SP.n < spec_levels && SP.n < BIG_SPEC_MAX;
+        // a speculated level's chains of small nodes ride in the launch of its partial sums (k_level_front, below)
+        static const bool merge_env = [] { const char* e = lab_env("TDTK_BUILD_MERGE"); return !(e && e[0] == '0'); }();
+        const bool front_merged = spec_this && measure_per_axis && merge_env;
+        bool nodes_done = false;
+        if (front_merged) {}
+        else if (measure_per_axis)
           hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
                              big_level ? BIG_MIN : 0xFFFFFFFFu);
         else
           hipLaunchKernelGGL(k_measure_node, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
                              big_level ? BIG_MIN : 0xFFFFFFFFu);
-        bool spec_this = false;
-        if (big_level && spec && SP.n < spec_levels && SP.n < BIG_SPEC_MAX) {
+        if (spec_this) {
           // this level from the plain sums; its exact sums on the second stream, from a snapshot of the coordinates
-          spec_this = true;
           BSpecLevel& L = SP.L[SP.n];
           const size_t* o = SO + (size_t)SP.n * SPEC_SLOTS;
           L.pieces = (BPiece*)(arena + o[0]); L.preout = (BPre*)(arena + o[1]); L.own = (BSum*)(arena + o[2]);
@@ -1973,9 +2083,22 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           L.prein = (BPre*)(arena + o[12]); L.seg_of = (uint32_t*)(arena + o[13]);
           BPart* part = (BPart*)(arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS + 1]);
           double *sx = L.snap, *sy = L.snap + n1, *sz = L.snap + 2 * n1;
-          hipLaunchKernelGGL(k_big_partials, dim3(cdiv(M, BIG_PB)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M, part);
-          hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, part, meas, L, spec_fault);
-          hipLaunchKernelGGL(k_spec_snapshot, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, cx, cy, cz, M, (uint32_t)n1, L.snap, L.seg_of);
+          if (front_merged) {
+            const uint32_t nbp = cdiv(M, BIG_PB);
+            hipLaunchKernelGGL(k_level_front, dim3(nbp + cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, seg_of, cx, cy, cz, M,
+                               part, L.snap, L.seg_of, (uint32_t)n1, nbp, meas, BIG_MIN);
+          } else {
+            hipLaunchKernelGGL(k_big_partials, dim3(cdiv(M, BIG_PB)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M, part);
+          }
+          if (merge_env && bound <= 16) {
+            // at most sixteen nodes: their plain sums, the decisions and the records in one workgroup
+            hipLaunchKernelGGL(k_nodes_small_approx, dim3(1), dim3(1024), 0, s, segs, lvl + level, (uint32_t)bound, meas, (uint32_t)bucket,
+                               kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, small + 0, small + 1, part, L, spec_fault);
+            nodes_done = true;
+          } else {
+            hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, part, meas, L, spec_fault);
+          }
+          if (!front_merged) hipLaunchKernelGGL(k_spec_snapshot, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, cx, cy, cz, M, (uint32_t)n1, L.snap, L.seg_of);
           // the exact chain of this level, all of it, on the snapshot.  The chains of different levels do not depend on each
           // other: the root's (1.3 ms of one wave) runs on one background stream, every other level's on the second -- in a
           // single stream the levels' chains queue up behind the root's and together outlast the build
@@ -2020,7 +2143,8 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           }
         }
         size_t st = scan_tmp;
-        if (bound + 1 <= 1024) {
+        if (nodes_done) {}
+        else if (bound + 1 <= 1024) {
           hipLaunchKernelGGL(k_nodes_small, dim3(1), dim3(1024), 0, s, segs, lvl + level, (uint32_t)bound, meas, (uint32_t)bucket,
                              kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, small + 0, small + 1);
         } else {
@@ -2033,11 +2157,14 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         // the partition pass (with no internal node at this level it moves nothing)
         hipLaunchKernelGGL(k_count, dim3(cdiv(M, 256 * CNT_ITERS)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy,
                            cz, M, nleft);
-        if (spec_this) hipLaunchKernelGGL(k_spec_keep, dim3(cdiv(bound, 256)), dim3(256), 0, s, lv, kind, irank, nleft, SP.L[SP.n - 1]);
         {
           const uint32_t nbm = cdiv(n1, 256);
-          hipLaunchKernelGGL(k_misplaced_children, dim3(nbm + cdiv(bound, 256)), dim3(256), 0, s, seg_of, kind, segs, axis,
-                             splitval, nleft, cx, cy, cz, M, LR, nbm, lv, irank, next, small + 2);
+          if (spec_this)
+            hipLaunchKernelGGL(k_misplaced_children_keep, dim3(nbm + cdiv(bound, 256)), dim3(256), 0, s, seg_of, kind, segs, axis,
+                               splitval, nleft, cx, cy, cz, M, LR, nbm, lv, irank, next, small + 2, SP.L[SP.n - 1]);
+          else
+            hipLaunchKernelGGL(k_misplaced_children, dim3(nbm + cdiv(bound, 256)), dim3(256), 0, s, seg_of, kind, segs, axis,
+                               splitval, nleft, cx, cy, cz, M, LR, nbm, lv, irank, next, small + 2);
         }
         if (own_scan && level < 255u) {
           BCHK(launch_scan_pair27(LR, AB, n1, arena + o_scanstate, level + 1u, small + 2, s));    // one launch (sort.hip)
@@ -2053,10 +2180,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         }
         BSeg* t = segs; segs = next; next = t;
       }
-      // one look per batch: the level counters so far and the root reference / largest bucket / error word together
-      hl.assign(level + 1, BLevel{0u, 0u, 0u});
-      BCHK(hipMemcpyAsync(hl.data(), lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
-      BCHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+      // one look per batch: the level counters so far and the root reference / largest bucket / error word together -- and,
+      // when the next level is the one handed to the finisher, its largest node
+      if (level == fin_level) { hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4); have_max = true; }
+      BCHK(hipMemcpyAsync(hl, lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
+      BCHK(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, s));
       BCHK(hipStreamSynchronize(s));
       const BLevel nx = hl[level];
       if (h_small[2] || (nx.nseg && level >= BUILD_MAX_LEVELS)) {
@@ -2089,7 +2217,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     res.max_leaf = h_small[1];
     res.cb = bits_for(res.max_leaf);
     res.table_mode = (bits_for(M) + res.cb) > 30;
-    if (spec && SP.n) {
+    if (spec && SP.n && !tail_enqueued) {
       // the exact sums have to be there now: check every big node's cut against them, give its record the exact value
       BCHK(hipEventRecord(side->e2, side->s2));
       BCHK(hipStreamWaitEvent(s, side->e2, 0));
@@ -2098,7 +2226,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
       BCHK(hipMemcpyAsync(&h_spec_err, small + 3, 4, hipMemcpyDeviceToHost, s));
     }
-    hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
+    if (!tail_enqueued) hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
     if (!res.table_mode)
       hipLaunchKernelGGL(k_pack_refs, dim3(cdiv(node_count ? node_count : 1, 256)), dim3(256), 0, s, nodes, node_count,
                          leaf_tab, (uint32_t)res.cb, small + 0);
