@@ -2230,7 +2230,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     if (!res.table_mode)
       hipLaunchKernelGGL(k_pack_refs, dim3(cdiv(node_count ? node_count : 1, 256)), dim3(256), 0, s, nodes, node_count,
                          leaf_tab, (uint32_t)res.cb, small + 0);
-    BCHK(hipMemcpyAsync(&res.root_ref, small + 0, 4, hipMemcpyDeviceToHost, s));
+    // (the finisher's path has looked at everything already -- the check word, and a root that is a node keeps its reference
+    // through k_pack_refs: what is enqueued from here on is waited for by the caller's own synchronisation, tree_finish)
+    const bool no_last_look = tail_enqueued && !res.table_mode && !(h_small[0] & REF_LEAF);
+    if (no_last_look) res.root_ref = h_small[0];
+    else BCHK(hipMemcpyAsync(&res.root_ref, small + 0, 4, hipMemcpyDeviceToHost, s));
     // the records move out of the scratch into allocations of their exact size
     if (node_count) {
       BCHK((hipError_t)pool_malloc_raw((void**)&f_nodes, sizeof(KdNode) * (size_t)node_count));
@@ -2242,7 +2246,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       BCHK((hipError_t)pool_malloc_raw((void**)&f_leaf, sizeof(LeafEntry) * (size_t)leaf_count));
       BCHK(hipMemcpyAsync(f_leaf, leaf_tab, sizeof(LeafEntry) * (size_t)leaf_count, hipMemcpyDeviceToDevice, s));
     }
-    BCHK(hipStreamSynchronize(s));
+    if (!no_last_look) BCHK(hipStreamSynchronize(s));
     BCHK(hipGetLastError());
     if (h_spec_err) { res.err = hipErrorNotReady; spec_suspect = true; goto fail; }     // a cut the exact sum would have made elsewhere: in order, then
   }
