@@ -311,7 +311,15 @@ __global__ void __launch_bounds__(256) k_measure_node(const BSeg* __restrict__ s
 // walk its 64 points.  A run that does not fit after all is redone piece by piece.  Bit for bit the reference's sum
 // by construction; tdtk_tree_verify compares every node record with the host build (tools/bigsum_probe.py).
 #define BIG_CH 64u
-#define BIG_MIN 8192u          // nodes from this many points on take this path (below, the chain costs < 40 us)
+#define BIG_MIN 8192u          // nodes from this many points on take this path (below, the chain costs < 40 us) ...
+#define BIG_MIN_SMALL 2048u    // ... in a small cloud (that chain is on its critical path: 46 + 26 us of a 15K-point build); never below
+                               // BIG_PB: a block of the partial sums holds the tail of one big node and the head of one other
+// which of the two a build of M points uses (every kernel of the piecewise path gets it as `big_min`)
+static uint32_t build_big_min(size_t M)
+{
+  static const bool small_env = [] { const char* e = lab_env("TDTK_BUILD_BIGMIN"); return !(e && e[0] == '0'); }();
+  return (small_env && M <= (size_t)BIG_MIN_SMALL * 16u) ? BIG_MIN_SMALL : BIG_MIN;   // (15K points 572 -> 545 us; 40K equal; 81K 710 -> 772: the side streams' chains then outlast the levels)
+}
 #define BIG_ANY 0xFFFFu        // BSum.eb of the neutral element
 #define BIG_BAD 0xFFFEu        // BSum.eb of a run whose pieces disagree about the binade: never applicable
 struct BPiece {
@@ -382,7 +390,7 @@ __device__ __forceinline__ uint32_t big_piece_count(uint32_t a, uint32_t n) { re
 __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
                                                    const double* __restrict__ cx, const double* __restrict__ cy,
                                                    const double* __restrict__ cz, uint32_t M, uint32_t nblocks,
-                                                   BPiece* __restrict__ pieces, BPre* __restrict__ prein)
+                                                   BPiece* __restrict__ pieces, BPre* __restrict__ prein, const uint32_t big_min)
 {
   const uint32_t q = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -399,7 +407,7 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
     const uint32_t sid = seg_of[base];
     if (sid != 0xFFFFFFFFu) {
       const BSeg sg = segs[sid];
-      if (sg.n >= BIG_MIN && sg.start < base) {
+      if (sg.n >= big_min && sg.start < base) {
         t_start = base; t_end = (sg.start + sg.n < bend) ? sg.start + sg.n : bend; t_sid = sid;
         if (sg.start + 1u == base) t_first = sg.start;
       }
@@ -413,7 +421,7 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
       const uint32_t sid = seg_of[p];
       if (sid != 0xFFFFFFFFu && (p == 0 || seg_of[p - 1] != sid)) {
         const BSeg sg = segs[sid];
-        if (sg.start == p && sg.n >= BIG_MIN) { found = p; fend = sg.start + sg.n; fsid = sid; }
+        if (sg.start == p && sg.n >= big_min) { found = p; fend = sg.start + sg.n; fsid = sid; }
       }
     }
     const unsigned long long any = __ballot(found != 0xFFFFFFFFu);
@@ -571,7 +579,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
                                                     const double* __restrict__ cz, uint32_t nblocks,
                                                     const BPiece* __restrict__ pieces, const BPre* __restrict__ preout,
                                                     const BSum* __restrict__ own, const BSum* __restrict__ comp,
-                                                    const uint32_t* __restrict__ list, BMeas* __restrict__ out, int dbg)
+                                                    const uint32_t* __restrict__ list, BMeas* __restrict__ out, int dbg, const uint32_t big_min)
 {
   __shared__ alignas(16) double walk[256 / WAVE][BIG_CH * BIG_CL + 16];   // + 16: the chain's last request reads past the data
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
@@ -579,7 +587,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
   if (w >= 3u * lv->nseg) return;
   const uint32_t sgi = w / 3u, ax = w % 3u;
   const uint32_t a = __builtin_amdgcn_readfirstlane(segs[sgi].start), n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
-  if (n < BIG_MIN) return;
+  if (n < big_min) return;
   const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
   const size_t ao = (size_t)ax * nblocks * 2;
   const BPiece* pa = pieces + ao;
@@ -776,7 +784,7 @@ struct BSpecAll { BSpecLevel L[BIG_SPEC_MAX]; int n; };
 __device__ __forceinline__ void big_partials_body(const uint32_t vblock, const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
                                                   const double* __restrict__ cx, const double* __restrict__ cy,
                                                   const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part,
-                                                  double* __restrict__ snap, uint32_t* __restrict__ seg_snap, uint32_t n1)
+                                                  double* __restrict__ snap, uint32_t* __restrict__ seg_snap, uint32_t n1, const uint32_t big_min)
 {
   constexpr int R = BIG_PB / 256;
   __shared__ uint32_t s_startB;
@@ -809,7 +817,7 @@ __device__ __forceinline__ void big_partials_body(const uint32_t vblock, const B
   uint32_t a_end = p0;
   if (sid0 != 0xFFFFFFFFu) {
     const BSeg sg = segs[sid0];
-    if (sg.n >= BIG_MIN) a_end = (sg.start + sg.n < pend) ? sg.start + sg.n : pend;
+    if (sg.n >= big_min) a_end = (sg.start + sg.n < pend) ? sg.start + sg.n : pend;
   }
   // piece B: the first big node that starts inside the block
 #pragma unroll
@@ -817,7 +825,7 @@ __device__ __forceinline__ void big_partials_body(const uint32_t vblock, const B
     const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
     if (p < pend && p > p0 && sids[r] != 0xFFFFFFFFu && prev[r] != sids[r]) {
       const BSeg sg = segs[sids[r]];
-      if (sg.n >= BIG_MIN) atomicMin(&s_startB, p);
+      if (sg.n >= big_min) atomicMin(&s_startB, p);
     }
   }
   __syncthreads();
@@ -866,9 +874,9 @@ __device__ __forceinline__ void big_partials_body(const uint32_t vblock, const B
 }
 __global__ void __launch_bounds__(256) k_big_partials(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
                                                       const double* __restrict__ cx, const double* __restrict__ cy,
-                                                      const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part)
+                                                      const double* __restrict__ cz, uint32_t M, BPart* __restrict__ part, uint32_t big_min)
 {
-  big_partials_body(blockIdx.x, segs, seg_of, cx, cy, cz, M, part, nullptr, nullptr, 0u);
+  big_partials_body(blockIdx.x, segs, seg_of, cx, cy, cz, M, part, nullptr, nullptr, 0u, big_min);
 }
 // The front of a speculated level in ONE launch (a small scan's build is a chain of dependent launches, ~7 us apiece): the
 // first nb_part workgroups are k_big_partials' and write the snapshot on the way, the rest are k_measure's (the chains of the
@@ -879,19 +887,20 @@ __global__ void __launch_bounds__(256) k_level_front(const BSeg* __restrict__ se
                                                      BPart* __restrict__ part, double* __restrict__ snap, uint32_t* __restrict__ seg_snap,
                                                      uint32_t n1, uint32_t nb_part, BMeas* __restrict__ meas, uint32_t big_min)
 {
-  if (blockIdx.x < nb_part) big_partials_body(blockIdx.x, segs, seg_of, cx, cy, cz, M, part, snap, seg_snap, n1);
+  if (blockIdx.x < nb_part) big_partials_body(blockIdx.x, segs, seg_of, cx, cy, cz, M, part, snap, seg_snap, n1, big_min);
   else measure_body(blockIdx.x - nb_part, segs, lv, cx, cy, cz, meas, big_min);
 }
 // one wave per node: a big node's bounds and plain sums from its blocks' partials; keeps what the background chain and
 // the final check need of this level (its node list, which axis each node is cut along)
 __device__ __forceinline__ void big_approx_wave(const uint32_t i, const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
-                                                const BPart* __restrict__ part, BMeas* __restrict__ meas, const BSpecLevel& L, int fault)
+                                                const BPart* __restrict__ part, BMeas* __restrict__ meas, const BSpecLevel& L, int fault,
+                                                const uint32_t big_min)
 {
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (i >= lv->nseg) return;
   const BSeg sg = segs[i];
   if (lane == 0) { L.segs[i] = sg; L.node[i] = 0xFFFFFFFFu; L.axis[i] = 3u; L.nleft[i] = 0u; L.cnt[i] = 0u; }
-  if (sg.n < BIG_MIN) return;
+  if (sg.n < big_min) return;
   const uint32_t b0 = sg.start / BIG_PB, b1 = (sg.start + sg.n - 1u) / BIG_PB;
   const double INF = 1.0 / 0.0;
   double lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF}, sm[3] = {0.0, 0.0, 0.0};
@@ -912,9 +921,9 @@ __device__ __forceinline__ void big_approx_wave(const uint32_t i, const BSeg* __
   L.axis[i] = split;
 }
 __global__ void __launch_bounds__(256) k_big_approx(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
-                                                    const BPart* __restrict__ part, BMeas* __restrict__ meas, BSpecLevel L, int fault)
+                                                    const BPart* __restrict__ part, BMeas* __restrict__ meas, BSpecLevel L, int fault, uint32_t big_min)
 {
-  big_approx_wave((blockIdx.x * blockDim.x + threadIdx.x) / WAVE, segs, lv, part, meas, L, fault);
+  big_approx_wave((blockIdx.x * blockDim.x + threadIdx.x) / WAVE, segs, lv, part, meas, L, fault, big_min);
 }
 // the level as it stands before its partition pass: coordinates and labels (the exact chain reads these, later)
 __global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const double* __restrict__ cx, const double* __restrict__ cy,
@@ -1007,10 +1016,10 @@ __global__ void k_big_list(const BSum* __restrict__ own, const BSum* __restrict_
 }
 
 __global__ void k_big_dbg_compare(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, const BMeas* __restrict__ a,
-                                  const BMeas* __restrict__ b, uint32_t level)
+                                  const BMeas* __restrict__ b, uint32_t level, uint32_t big_min)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= lv->nseg || segs[i].n < BIG_MIN) return;
+  if (i >= lv->nseg || segs[i].n < big_min) return;
   const double hx = 0.5 * (b[i].hi[0] - b[i].lo[0]), hy = 0.5 * (b[i].hi[1] - b[i].lo[1]), hz = 0.5 * (b[i].hi[2] - b[i].lo[2]);
   const int split = (hx > hy) ? ((hx > hz) ? 0 : 2) : ((hy > hz) ? 1 : 2);
   for (int ax = 0; ax < 3; ax++)
@@ -1145,9 +1154,9 @@ __global__ void __launch_bounds__(1024) k_nodes_small_approx(const BSeg* __restr
                                                              uint32_t* __restrict__ irank, KdNode* __restrict__ nodes,
                                                              double* __restrict__ node_r, LeafEntry* __restrict__ leaf_tab,
                                                              uint32_t* __restrict__ root_ref, uint32_t* __restrict__ max_leaf,
-                                                             const BPart* __restrict__ part, BSpecLevel L, int fault)
+                                                             const BPart* __restrict__ part, BSpecLevel L, int fault, uint32_t big_min)
 {
-  big_approx_wave(threadIdx.x / WAVE, segs, lv, part, meas, L, fault);
+  big_approx_wave(threadIdx.x / WAVE, segs, lv, part, meas, L, fault, big_min);
   __threadfence_block();
   __syncthreads();
   nodes_small_body(segs, lv, bound, meas, bucket, kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, root_ref, max_leaf);
@@ -1893,7 +1902,8 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     uint32_t* wlist = (uint32_t*)(arena + O[29]);
     const uint32_t nblocks = cdiv(M, BIG_CH);
     static const bool chain_only = [] { const char* e = lab_env("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
-    const bool use_big = !chain_only && M >= BIG_MIN;
+    const uint32_t big_min = build_big_min(M_);
+    const bool use_big = !chain_only && M >= big_min;
     // TDTK_MEASURE=axis: round 2's wave per (node, axis) for the nodes below the piecewise path (k_measure); default: a wave
     // per node (k_measure_node).  With TDTK_BUILD_CHAIN=1 (no piecewise path: chains of any length) the long-chain kernel.
     static const bool measure_axis_env = [] { const char* e = lab_env("TDTK_MEASURE"); return e && e[0] == 'a'; }();
@@ -2052,7 +2062,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         if (lvl_trace) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); lvl_ev.push_back(e); } }
         // the piecewise path runs while a balanced node is at least half its threshold (below that level the chain in
         // k_measure takes every node, whatever its size: an empty pass of the piecewise kernels costs 75 us)
-        const bool big_level = use_big && ((M_ >> level) >= BIG_MIN / 2);
+        const bool big_level = use_big && ((M_ >> level) >= big_min / 2);
         // a wave per node while the nodes of a balanced tree hold at most 128 points (three chains in one wave issue 24
         // cycles per point where three waves need 10: level 7 of a 1M-point tree 253 us against 46, level 12 equal,
         // level 16 74 against 139)
@@ -2065,10 +2075,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         if (front_merged) {}
         else if (measure_per_axis)
           hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
-                             big_level ? BIG_MIN : 0xFFFFFFFFu);
+                             big_level ? big_min : 0xFFFFFFFFu);
         else
           hipLaunchKernelGGL(k_measure_node, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas,
-                             big_level ? BIG_MIN : 0xFFFFFFFFu);
+                             big_level ? big_min : 0xFFFFFFFFu);
         if (spec_this) {
           // this level from the plain sums; its exact sums on the second stream, from a snapshot of the coordinates
           BSpecLevel& L = SP.L[SP.n];
@@ -2086,17 +2096,17 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           if (front_merged) {
             const uint32_t nbp = cdiv(M, BIG_PB);
             hipLaunchKernelGGL(k_level_front, dim3(nbp + cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, seg_of, cx, cy, cz, M,
-                               part, L.snap, L.seg_of, (uint32_t)n1, nbp, meas, BIG_MIN);
+                               part, L.snap, L.seg_of, (uint32_t)n1, nbp, meas, big_min);
           } else {
-            hipLaunchKernelGGL(k_big_partials, dim3(cdiv(M, BIG_PB)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M, part);
+            hipLaunchKernelGGL(k_big_partials, dim3(cdiv(M, BIG_PB)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M, part, big_min);
           }
           if (merge_env && bound <= 16) {
             // at most sixteen nodes: their plain sums, the decisions and the records in one workgroup
             hipLaunchKernelGGL(k_nodes_small_approx, dim3(1), dim3(1024), 0, s, segs, lvl + level, (uint32_t)bound, meas, (uint32_t)bucket,
-                               kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, small + 0, small + 1, part, L, spec_fault);
+                               kind, axis, splitval, nleft, irank, nodes, node_r, leaf_tab, small + 0, small + 1, part, L, spec_fault, big_min);
             nodes_done = true;
           } else {
-            hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, part, meas, L, spec_fault);
+            hipLaunchKernelGGL(k_big_approx, dim3(cdiv(bound * WAVE, 256)), dim3(256), 0, s, segs, lv, part, meas, L, spec_fault, big_min);
           }
           if (!front_merged) hipLaunchKernelGGL(k_spec_snapshot, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, cx, cy, cz, M, (uint32_t)n1, L.snap, L.seg_of);
           // the exact chain of this level, all of it, on the snapshot.  The chains of different levels do not depend on each
@@ -2108,7 +2118,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(hipEventRecord(side->e1, s));
           BCHK(hipStreamWaitEvent(sb, side->e1, 0));
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, sb, L.segs, L.seg_of, sx, sy, sz, M,
-                             nblocks, L.pieces, L.prein);
+                             nblocks, L.pieces, L.prein, big_min);
           size_t stb = scan_tmp;
           BCHK(rocprim::inclusive_scan(tmpb, stb, L.prein, L.preout, nsl, BPreOp(), sb));
           hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(nsl1, 64)), dim3(64), 0, sb, L.segs, sx, sy, sz, nblocks,
@@ -2119,11 +2129,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(rocprim::exclusive_scan(tmpb, stb, L.own, L.comp, ident, nsl1, BSumOp(), sb));
           hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, sb, L.own, L.comp, (uint32_t)nsl1, L.wlist);
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz,
-                             nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg);
+                             nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg, big_min);
         } else if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
-                             nblocks, pieces, prein);
+                             nblocks, pieces, prein, big_min);
           size_t stb = scan_tmp;
           BCHK(rocprim::inclusive_scan(tmp, stb, prein, preout, nsl, BPreOp(), s));
           const size_t nsl1 = (size_t)nblocks * 2;
@@ -2135,11 +2145,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(rocprim::exclusive_scan(tmp, stb, own, comp, ident, nsl1, BSumOp(), s));
           hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, s, own, comp, (uint32_t)nsl1, wlist);
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, nblocks,
-                             pieces, preout, own, comp, wlist, meas, big_dbg);
+                             pieces, preout, own, comp, wlist, meas, big_dbg, big_min);
           if (big_dbg_all & 8) {
             BMeas* meas2 = (BMeas*)(arena + O[30]);
             hipLaunchKernelGGL(k_measure, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, s, segs, lv, cx, cy, cz, meas2, 0xFFFFFFFFu);
-            hipLaunchKernelGGL(k_big_dbg_compare, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, meas, meas2, level);
+            hipLaunchKernelGGL(k_big_dbg_compare, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lv, meas, meas2, level, big_min);
           }
         }
         size_t st = scan_tmp;
@@ -2279,10 +2289,11 @@ fail:
 #define BIG_SPEC_LEVELS 8
 static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out)
 {
+  const uint32_t BIG_MIN_M = build_big_min(M);
   size_t off = (base + 255) & ~(size_t)255;
   int nlev = 0;
-  if (M >= BIG_MIN)
-    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN / 2 && nlev < BIG_SPEC_LEVELS; level++) nlev++;
+  if (M >= BIG_MIN_M)
+    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN_M / 2 && nlev < BIG_SPEC_LEVELS; level++) nlev++;
   if (getenv("TDTK_BUILD_SPEC") && getenv("TDTK_BUILD_SPEC")[0] == '0') nlev = 0;
   const size_t n1 = M + 1, nsl = 6 * (M / BIG_CH + 2), nsl1 = nsl / 3 + 3;
   auto take = [&](size_t bytes, size_t* slot) { if (slot) *slot = off; off += (bytes + 255) & ~(size_t)255; };
