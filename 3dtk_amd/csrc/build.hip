@@ -126,6 +126,69 @@ __device__ __forceinline__ void lds_chain32(double& sum, const double* b, uint32
       : "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
+// The same chain for a kernel that has no sixty-four registers to give away by name (k_fin_subtrees): `cnt` doubles at `b`
+// (cnt a multiple of 16, any 8-byte alignment), eight requested ahead of the eight being added, the sixteen temporaries
+// chosen by the compiler -- still ONE asm statement, so no register a read writes is visible before its wait.  The last
+// iteration requests eight values beyond the end and never adds them: 64 bytes behind the data must be LDS.
+__device__ __forceinline__ void lds_chain16(double& sum, const double* b, uint32_t cnt)
+{
+  uint32_t ad = (uint32_t)(size_t)(__attribute__((address_space(3))) const double*)b;   // LDS byte offset
+  uint32_t pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cnt / 16u));
+  double a0, a1, a2, a3, a4, a5, a6, a7, c0, c1, c2, c3, c4, c5, c6, c7;
+  asm volatile(
+      "ds_read_b64 %[a0], %[ad] offset:0\n\t"
+      "ds_read_b64 %[a1], %[ad] offset:8\n\t"
+      "ds_read_b64 %[a2], %[ad] offset:16\n\t"
+      "ds_read_b64 %[a3], %[ad] offset:24\n\t"
+      "ds_read_b64 %[a4], %[ad] offset:32\n\t"
+      "ds_read_b64 %[a5], %[ad] offset:40\n\t"
+      "ds_read_b64 %[a6], %[ad] offset:48\n\t"
+      "ds_read_b64 %[a7], %[ad] offset:56\n\t"
+      ".Lfinchain%=:\n\t"
+      "ds_read_b64 %[c0], %[ad] offset:64\n\t"
+      "ds_read_b64 %[c1], %[ad] offset:72\n\t"
+      "ds_read_b64 %[c2], %[ad] offset:80\n\t"
+      "ds_read_b64 %[c3], %[ad] offset:88\n\t"
+      "ds_read_b64 %[c4], %[ad] offset:96\n\t"
+      "ds_read_b64 %[c5], %[ad] offset:104\n\t"
+      "ds_read_b64 %[c6], %[ad] offset:112\n\t"
+      "ds_read_b64 %[c7], %[ad] offset:120\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_add_f64 %[s], %[s], %[a0]\n\t"
+      "v_add_f64 %[s], %[s], %[a1]\n\t"
+      "v_add_f64 %[s], %[s], %[a2]\n\t"
+      "v_add_f64 %[s], %[s], %[a3]\n\t"
+      "v_add_f64 %[s], %[s], %[a4]\n\t"
+      "v_add_f64 %[s], %[s], %[a5]\n\t"
+      "v_add_f64 %[s], %[s], %[a6]\n\t"
+      "v_add_f64 %[s], %[s], %[a7]\n\t"
+      "v_add_u32 %[ad], 0x80, %[ad]\n\t"
+      "ds_read_b64 %[a0], %[ad] offset:0\n\t"
+      "ds_read_b64 %[a1], %[ad] offset:8\n\t"
+      "ds_read_b64 %[a2], %[ad] offset:16\n\t"
+      "ds_read_b64 %[a3], %[ad] offset:24\n\t"
+      "ds_read_b64 %[a4], %[ad] offset:32\n\t"
+      "ds_read_b64 %[a5], %[ad] offset:40\n\t"
+      "ds_read_b64 %[a6], %[ad] offset:48\n\t"
+      "ds_read_b64 %[a7], %[ad] offset:56\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_add_f64 %[s], %[s], %[c0]\n\t"
+      "v_add_f64 %[s], %[s], %[c1]\n\t"
+      "v_add_f64 %[s], %[s], %[c2]\n\t"
+      "v_add_f64 %[s], %[s], %[c3]\n\t"
+      "v_add_f64 %[s], %[s], %[c4]\n\t"
+      "v_add_f64 %[s], %[s], %[c5]\n\t"
+      "v_add_f64 %[s], %[s], %[c6]\n\t"
+      "v_add_f64 %[s], %[s], %[c7]\n\t"
+      "s_sub_u32 %[n], %[n], 1\n\ts_cmp_lg_u32 %[n], 0\n\ts_cbranch_scc1 .Lfinchain%=\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : [s] "+v"(sum), [ad] "+v"(ad), [n] "+s"(pairs), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4),
+        [a5] "=&v"(a5), [a6] "=&v"(a6), [a7] "=&v"(a7), [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4),
+        [c5] "=&v"(c5), [c6] "=&v"(c6), [c7] "=&v"(c7)
+      :
+      : "scc", "memory");
+}
+
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const double t = __shfl_xor(v, off, WAVE); v = (t < v) ? t : v; }
@@ -1595,16 +1658,12 @@ __global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value
       const double first = arr[0];
       double lo = first, hi = first, sum = first;       // the sum starts from the first point
       for (uint32_t k = lane; k < cnt_n; k += WAVE) { const double v = arr[k]; lo = (v < lo) ? v : lo; hi = (hi < v) ? v : hi; }
-      if (lane == 0) {
-        uint32_t k = 1;                                  // ... and adds the rest in order
-        for (; k + 16 <= cnt_n; k += 16) {
-          double r[16];
-#pragma unroll
-          for (int q = 0; q < 16; q++) r[q] = arr[k + q];
-#pragma unroll
-          for (int q = 0; q < 16; q++) sum += r[q];
-        }
-        for (; k < cnt_n; k++) sum += arr[k];
+      {
+        // ... and adds the rest in order: every lane the same chain (wave-uniform reads), sixteen values per turn of
+        // lds_chain16, the ragged end one by one
+        const uint32_t body = ((cnt_n - 1u) / 16u) * 16u;
+        if (body) lds_chain16(sum, arr + 1, body);
+        for (uint32_t k = 1u + body; k < cnt_n; k++) sum += arr[k];
       }
       lo = wave_min(lo); hi = wave_max(hi);
       if (lane == 0) { ms[sgi].lo[a3] = lo; ms[sgi].hi[a3] = hi; ms[sgi].mean[a3] = sum / (double)cnt_n; }
