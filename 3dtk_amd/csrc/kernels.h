@@ -23,6 +23,7 @@ struct TreeDev {
   const double* node_r;       // FindClosestAlongDir only
   uint32_t root_ref;
   uint32_t cb, cmask;
+  uint32_t n_hot;             // records in `hot` (= internal nodes)
 };
 
 struct SearchArgs {

@@ -445,6 +445,9 @@ __device__ __forceinline__ void bucket_scan_groups(const char* __restrict__ t_gr
     // (Loading each group under its own lane mask instead -- no access for a group the bucket does not have -- costs
     // the register allocation 188 VGPRs instead of 122, i.e. half the resident waves; masking only the fifth group
     // keeps 122 and changes nothing: 0.1987 / 0.1990 ms against 0.1974 / 0.1970, gpurun_out/r3f.)
+    // (Round 4: a group the bucket does not have read from ONE place instead -- a group of four points at +inf behind the
+    // last bucket, the same address for every lane that lacks the group: L1 accesses per launch 83.3 M -> 80.3 M, time
+    // 0.1955-0.1966 ms against 0.1933-0.1945.  The vector L1 spends its cycles per instruction, not per distinct line.)
     const uint32_t gk = min(go + 48u * (uint32_t)k, glast);
     X[k] = gload<float4>(t_grp, gk);
     Y[k] = gload<float4>(t_grp, gk + 16);
@@ -1422,10 +1425,23 @@ __device__ unsigned long long g_wtrace[3];     // (never touched: a.trace is a l
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false,
-          int ORD_MAX = 256, bool LAZY = false>
+          int ORD_MAX = 256, bool LAZY = false, int TOP = 0, bool SHARE = false>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ uint4 lds_stk[SD][BLOCK];
+  // TOP > 0 (round 4): the first TOP hot records -- the tree's upper levels, the array is breadth-first -- are staged in
+  // LDS once per workgroup, and a visit of one of them reads LDS instead of the vector L1.  A query's first descent is 17
+  // dependent visits of which the upper ten are the same few hundred records for everybody: they were 47 % of the node
+  // visits' L1 tag look-ups (the resource this kernel is closest to saturating) and of their round trips.  Same records,
+  // same tests, same order.  One copy serves all waves of the workgroup, hence the big workgroups of these instantiations.
+  __shared__ uint4 lds_top[TOP > 0 ? 3 * TOP : 1];
+  uint32_t top_n = 0;
+  if constexpr (TOP > 0) {
+    top_n = min((uint32_t)TOP, a.T.n_hot);
+    const uint4* __restrict__ h16 = reinterpret_cast<const uint4*>(a.T.hot);
+    for (uint32_t k = threadIdx.x; k < 3u * top_n; k += BLOCK) lds_top[k] = h16[k];
+    __syncthreads();
+  }
 
   const size_t gl = (size_t)bid * BLOCK + threadIdx.x;
   const unsigned lane = threadIdx.x & (WAVE - 1);
@@ -1516,6 +1532,15 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     ordered = true;
   };
   size_t next_q, end_q;  // wave-uniform: the queries this wave may still hand to its lanes
+  // SHARE (round 4): the waves of a workgroup hand out their slabs TOGETHER -- one cursor in LDS over the workgroup's
+  // stretch of the sorted scan (the waves' slabs are consecutive), piece after piece, each piece in the order its owner
+  // sorted it.  A wave that runs ahead of its neighbours takes more of the stretch; the launch no longer waits for the
+  // unluckiest of 4096 independent slabs (sigma = 9 % of a wave's life, TDTK_WAVE_TRACE) but for the unluckiest of the
+  // workgroups.  Who searches a query does not change its result; the sums pass (FUSE 3) still covers each wave's own slab.
+  __shared__ uint32_t lds_cursor;
+  size_t wg0 = 0;
+  uint32_t wg_len = 0;
+  bool ord_on = false;
   size_t sub = 0, reg0 = 0, pstride = 0, slab_end = a.n;
   int nph = 1;       // pieces of this wave's slab
   bool exhausted = false;
@@ -1578,6 +1603,16 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       if (next_q > slab_end) next_q = slab_end;
       if (end_q > slab_end) end_q = slab_end;
       order_piece(next_q, end_q);
+      if constexpr (SHARE) {
+        // (one piece per wave -- the launcher sets phases = 1 --, so the workgroup's slabs are one stretch of the scan)
+        wg0 = (size_t)(bid & 7u) * wpx * (size_t)a.qpw + (size_t)((bid >> 3) * (BLOCK / WAVE)) * sub;
+        if (wg0 > a.n) wg0 = a.n;
+        const size_t len = (size_t)(BLOCK / WAVE) * sub;
+        wg_len = (uint32_t)((wg0 + len <= a.n) ? len : a.n - wg0);
+        ord_on = ORDER && a.use_cost && a.cost && sub <= (size_t)ORD_MAX;
+        if (threadIdx.x == 0) lds_cursor = 0u;
+        __syncthreads();          // every wave's order (lds_order[w]) and the cursor are in place
+      }
     }
   }
 
@@ -1761,11 +1796,30 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       if (end_q > slab_end) end_q = slab_end;
       order_piece(next_q, end_q);
     }
-    if (next_q < end_q && fill) {
+    uint32_t sh_base = 0;
+    bool sh_draw = false;
+    if constexpr (SHARE) {
+      if (fill && !exhausted) {
+        if (lane == 0) sh_base = atomicAdd(&lds_cursor, (uint32_t)__popcll(idlem));
+        sh_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_base);
+        if (sh_base >= wg_len) exhausted = true; else sh_draw = true;
+      }
+    }
+    if (SHARE ? sh_draw : (next_q < end_q && fill)) {
       const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
-      const size_t slot = next_q + rank;                // position in the hand-out order of the piece
-      const bool got = idle && slot < end_q;
-      const size_t mine = (ORDER && got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
+      size_t slot, mine;
+      bool got;
+      if constexpr (SHARE) {
+        const uint32_t pos = sh_base + rank;              // position in the hand-out order of the workgroup's stretch
+        got = idle && pos < wg_len;
+        const uint32_t pj = pos / (uint32_t)sub, po = pos - pj * (uint32_t)sub;     // piece (= its owner's wave), offset in it
+        slot = wg0 + pos;
+        mine = (ord_on && got) ? wg0 + (size_t)pj * sub + (size_t)lds_order[ORDER ? pj : 0][po] : slot;
+      } else {
+        slot = next_q + rank;                // position in the hand-out order of the piece
+        got = idle && slot < end_q;
+        mine = (ORDER && got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
+      }
       if (got) {
         // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
         // (global loads / stores at 32-bit byte offsets: a scan has < 2^27 points)
@@ -1793,6 +1847,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       next_q += (size_t)__popcll(idlem);
     }
     if (__ballot(cur != REF_DONE) == 0) {
+      if constexpr (SHARE) { if (exhausted) break; continue; }
       if (next_q >= end_q && (DYN ? tried >= 8u : ((kLab && a.pool_slab) ? exhausted : phase + 1 >= nph))) break;
       continue;
     }
@@ -1936,9 +1991,18 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         // 32-bit byte offset from a scalar base: global_load with SGPR base + VGPR offset, no 64-bit address arithmetic
         // on the vector ALU (the hot array is < 4 GB by construction); v_mul_u32_u24 is full rate and drops bit 30
         const uint32_t ho = __umul24(cur, (uint32_t)sizeof(KdHot));
-        float4 b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
-        float4 b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
-        double2 sc = gload<double2>(hotb, ho + 32);          // splitval {c1, c2}
+        float4 b0, b1;
+        double2 sc;
+        if (TOP > 0 && ho < top_n * (uint32_t)sizeof(KdHot)) {
+          const char* lp = reinterpret_cast<const char*>(lds_top) + ho;
+          b0 = *reinterpret_cast<const float4*>(lp);
+          b1 = *reinterpret_cast<const float4*>(lp + 16);
+          sc = *reinterpret_cast<const double2*>(lp + 32);
+        } else {
+        b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
+        b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
+        sc = gload<double2>(hotb, ho + 32);           // splitval {c1, c2}
+        }
         if constexpr (PROBE == 3) {   // sensitivity probe (TDTK_BUCKET_PTS=43): one more 16-byte load per node visit, result unused
           float4 w = gload<float4>(hotb, ho + 8);
           asm volatile("" : "+v"(b0.x), "+v"(b1.z), "+v"(sc.x), "+v"(w.x));
@@ -2058,6 +2122,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     // fence of workgroup scope is enough (the CU's L1 is write-through and shared by the workgroup) and costs a wait;
     // one of agent scope writes back and invalidates the XCD's L2 once per wave: k_search 0.218 -> 0.322 ms.
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if constexpr (SHARE) __syncthreads();     // this wave's slab was searched by all waves of the workgroup
     // four queries per lane and trip, all their loads issued before the first use: two memory round trips for a whole
     // slab of up to 256 queries instead of one pair per 64
     const bool balanced = kLab && !LAZY && a.bounds != nullptr;     // this wave's slab is [reg0, slab_end), in one piece
@@ -2132,20 +2197,25 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       if (lane == 0) red[wv][k] = s;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
+    // (a workgroup of more than 128 threads writes one row per pair of waves, where the 128-thread workgroup that owns
+    // those two slabs in the same grid of slabs would write it: the sums do not depend on the workgroup size)
+    constexpr int RS = (BLOCK > 128) ? BLOCK / 128 : 1, WPR = NW / RS;
+    for (int kk = threadIdx.x; kk < RS * ACC_TOTAL; kk += BLOCK) {
+      const int sr = kk / ACC_TOTAL, k = kk - sr * ACC_TOTAL;
       // column k of the row <- which accumulator (FUSE 2: n, sum, ACC_L .. ACC_L + 14, ACC_LU)
       int src = -1;
       if (FUSE == 2 || FUSE == 5) src = (k == ACC_N) ? 0 : (k == ACC_SUM) ? 1 : (k >= ACC_L && k < ACC_L + 15) ? 2 + (k - ACC_L) : (k == ACC_LU) ? 17 : -1;
       else if (k < ACC_DD) src = k;
       double s = 0.0;
       if (src >= 0)
-        for (int w = 0; w < NW; w++) s += red[w][src];
-      a.partials[(size_t)bid * ACC_TOTAL + k] = s;
+        for (int w = 0; w < WPR; w++) s += red[sr * WPR + w][src];
+      const size_t row = (RS == 1) ? (size_t)bid : ((size_t)((bid >> 3) * RS + sr) * 8u + (bid & 7u));
+      a.partials[row * ACC_TOTAL + k] = s;
     }
   }
 }
 
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false, int TOP = 0, bool SHARE = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a_by_value)
 {
   // The argument block (three 4x4 fp64 matrices among its 700 bytes) is read through the kernarg segment pointer, not
@@ -2154,7 +2224,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   // v_readlane in a kernel that is short of issue slots.  Behind an opaque pointer the fields are s_load'ed where they
   // are used (the matrices only when a lane takes a new query), like k_search_refill_multi reads its table entry.
   (void)a_by_value;
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT, 256, false, TOP, SHARE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 
 #ifdef TDTK_LAB
@@ -3274,9 +3344,67 @@ static uint32_t refill_grid_b(size_t n, int block, int* qpw_out, int side_by_sid
 #ifdef TDTK_LAB
 static uint32_t refill_grid_b_fwd(size_t n, int* qpw_out) { return refill_grid_b(n, 128, qpw_out); }
 #endif
+// Upper tree levels in LDS (search_refill_body<.., TOP>): the workgroup size of the single-pass launch that stages them,
+// 0 = the plain 128-thread kernel.  Only while the launch is ONE generation of resident waves: a big workgroup leaves
+// its CU when its slowest wave does, which costs nothing when nobody is waiting for the CU.
+// MEASURED NEGATIVE (lab only, TDTK_TOP_BLOCK=512|1024): 1M-vs-1M k_search 0.2041-0.2047 ms (1024) / 0.2071-0.2080 (512)
+// against 0.1933-0.1945; the upper levels' visits coalesce in the vector L1 anyway -- a wave's sorted queries share their
+// first ten nodes -- so LDS takes little off the tag pipeline and the mixed trips pay for two paths.
+static int refill_top_block(size_t n, int side_by_side)
+{
+#ifdef TDTK_LAB
+  const char* e = lab_env("TDTK_TOP_BLOCK");
+  const int blk = e ? atoi(e) : 0;
+  if (blk != 512 && blk != 1024) return 0;
+  if (side_by_side > 1 || (n + 255) / 256 >= (size_t)num_cu() * 4 * 7) return 0;
+  if (lab_env("TDTK_REFILL_POOL") || lab_env("TDTK_BUCKET_PTS") || lab_env("TDTK_FAT_NODES") || lab_env("TDTK_WAVE_TRACE") || lab_env("TDTK_REFILL_THRESH") ||
+      lab_env("TDTK_TWO_PER_LANE") || lab_env("TDTK_FUSE_SUMS") || lab_env("TDTK_SEARCH_VARIANT") || lab_env("TDTK_REFILL_QPW"))
+    return 0;
+  return blk;
+#else
+  (void)n; (void)side_by_side;
+  return 0;
+#endif
+}
+// Slabs handed out by the workgroup's waves together (search_refill_body<.., SHARE>): the workgroup size of the single-pass
+// launch, 0 = every wave for itself (128-thread workgroups).  While the launch is ONE generation of resident waves.
+// MEASURED NEGATIVE (lab only, TDTK_SHARE_BLOCK=256|512|1024): 1M-vs-1M k_search 0.2075-0.2085 / 0.2171-0.2179 / 0.2121-0.2131 ms
+// against 0.1945-0.1956: the waves of a big workgroup sit on ONE CU and share its vector L1, which is what the kernel is
+// bound by (TCP busy 80-91 % of the launch, profiles/r04_tcp_diag.txt); 128-thread workgroups spread a CU's sixteen waves
+// over eight distant stretches of the scan, and that averaging is worth more than what the shared cursor evens out.
+static int refill_share_block(size_t n, int side_by_side)
+{
+#ifndef TDTK_LAB
+  (void)n; (void)side_by_side;
+  return 0;
+#endif
+  int blk = 0;
+  if (const char* e = lab_env("TDTK_SHARE_BLOCK")) blk = atoi(e);
+  if (blk != 256 && blk != 512 && blk != 1024) return 0;
+  if (side_by_side > 1 || (n + 255) / 256 >= (size_t)num_cu() * 4 * 7) return 0;
+  if (lab_env("TDTK_REFILL_POOL") || lab_env("TDTK_BUCKET_PTS") || lab_env("TDTK_FAT_NODES") || lab_env("TDTK_WAVE_TRACE") || lab_env("TDTK_REFILL_THRESH") ||
+      lab_env("TDTK_TWO_PER_LANE") || lab_env("TDTK_FUSE_SUMS") || lab_env("TDTK_SEARCH_VARIANT") || lab_env("TDTK_REFILL_QPW") || lab_env("TDTK_TOP_BLOCK") ||
+      lab_env("TDTK_REFILL_PHASES") || lab_env("TDTK_BALANCE"))
+    return 0;
+  return blk;
+}
+// the workgroup size of the single-pass persistent-lane launch for n queries (128 unless one of the two above applies)
+static int refill_big_block(size_t n, int side_by_side)
+{
+  if (const int tb = refill_top_block(n, side_by_side)) return tb;
+  return refill_share_block(n, side_by_side);
+}
 size_t search_max_lanes(size_t n)
 {
   int q;
+  {
+    const int tb = refill_big_block(n, 1);
+    if (tb) {
+      const size_t t = (size_t)refill_grid_b(n, tb, &q) * (size_t)tb;
+      const size_t a0 = (size_t)search_grid(n) * SEARCH_BLOCK, b0 = (size_t)refill_grid_b(n, 128, &q) * 128;
+      return std::max(t, std::max(a0, b0));
+    }
+  }
   const size_t a = (size_t)search_grid(n) * SEARCH_BLOCK;
   const size_t b = (size_t)refill_grid_b(n, 128, &q) * 128;
   const size_t c = (size_t)refill_grid_b(n, SEARCH_BLOCK, &q) * SEARCH_BLOCK;
@@ -3375,6 +3503,7 @@ uint32_t search_fused_rows(size_t n, int side_by_side)
 #ifdef TDTK_LAB
   if (two_per_lane_for(n, side_by_side)) return refill2_grid(n, &q);
 #endif
+  if (const int tb = refill_big_block(n, side_by_side)) return refill_grid_b(n, tb, &q, side_by_side) * (uint32_t)(tb / 128);
   return refill_grid_b(n, 128, &q, side_by_side);
 }
 
@@ -3382,6 +3511,29 @@ template <bool COUNT, int FUSE>
 static void launch_refill128(SearchArgs& a, hipStream_t s)
 {
   int qpw;
+#ifdef TDTK_LAB
+  if constexpr (FUSE == 0 || FUSE == 3) {
+    if (const int tb = a.bounds ? 0 : refill_top_block(a.n, a.side_by_side)) {
+      const uint32_t nbt = refill_grid_b(a.n, tb, &qpw, a.side_by_side);
+      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
+      if (tb == 1024) hipLaunchKernelGGL((k_search_refill<1024, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 1023>), dim3(nbt), dim3(1024), 0, s, a);
+      else hipLaunchKernelGGL((k_search_refill<512, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 511>), dim3(nbt), dim3(512), 0, s, a);
+      return;
+    }
+  }
+#endif
+#ifdef TDTK_LAB
+  if constexpr (FUSE == 0 || FUSE == 3) {
+    if (const int sb = a.bounds ? 0 : refill_share_block(a.n, a.side_by_side)) {
+      const uint32_t nbs = refill_grid_b(a.n, sb, &qpw, a.side_by_side);
+      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
+      if (sb == 1024) hipLaunchKernelGGL((k_search_refill<1024, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0, true>), dim3(nbs), dim3(1024), 0, s, a);
+      else if (sb == 512) hipLaunchKernelGGL((k_search_refill<512, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0, true>), dim3(nbs), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((k_search_refill<256, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0, true>), dim3(nbs), dim3(256), 0, s, a);
+      return;
+    }
+  }
+#endif
 #ifdef TDTK_LAB
   if constexpr (FUSE == 0 || FUSE == 3) {
     if (two_per_lane_for(a.n, a.side_by_side) && !a.bounds) {

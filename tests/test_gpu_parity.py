@@ -1962,7 +1962,7 @@ def test_lab_library_default_path_is_the_products(tdtk, gpu):
 def test_alternative_search_kernels_agree(tdtk, orc, gpu, lab, monkeypatch):
     """The kernels kept beside the default as measured alternatives (fused retire-time sums, the work-queue kernel,
     other slab lengths / refill thresholds, static slab + per-XCD pool, 256-thread persistent lanes, one query per lane,
-    two queries per lane) walk the same tree the
+    two queries per lane, upper levels in LDS, slabs shared by a workgroup's waves) walk the same tree the
     same way: identical indices, pair sums equal to rounding, and the instrumented instantiations count the same
     visits as the oracle -- on a batch large enough for the persistent-lane kernels, with duplicates in the model."""
     rng = np.random.default_rng(99)
@@ -1981,7 +1981,11 @@ def test_alternative_search_kernels_agree(tdtk, orc, gpu, lab, monkeypatch):
                 {"TDTK_SEARCH_VARIANT": "40"}, {"TDTK_SEARCH_VARIANT": "41"},
                 {"TDTK_REFILL_QPW": "128", "TDTK_REFILL_THRESH": "8"}, {"TDTK_REFILL_QPW": "512", "TDTK_REFILL_THRESH": "32"},
                 {"TDTK_REFILL_POOL": "25"}, {"TDTK_REFILL_POOL": "60", "TDTK_REFILL_POOL_SLAB": "48"}, {"TDTK_REFILL_PHASES": "1"},
-                {"TDTK_TWO_PER_LANE": "3"}, {"TDTK_TWO_PER_LANE": "2", "TDTK_FUSE_SUMS": "3"}):
+                {"TDTK_TWO_PER_LANE": "3"}, {"TDTK_TWO_PER_LANE": "2", "TDTK_FUSE_SUMS": "3"},
+                # round 4: the tree's upper levels staged in LDS by workgroups of 512 / 1024 threads; the slabs of a workgroup's
+                # waves handed out together from one cursor in LDS
+                {"TDTK_TOP_BLOCK": "1024"}, {"TDTK_TOP_BLOCK": "512"},
+                {"TDTK_SHARE_BLOCK": "256"}, {"TDTK_SHARE_BLOCK": "512"}, {"TDTK_SHARE_BLOCK": "1024"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for counting in (0, 1):
