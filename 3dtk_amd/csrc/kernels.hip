@@ -1425,7 +1425,7 @@ __device__ unsigned long long g_wtrace[3];     // (never touched: a.trace is a l
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false,
-          int ORD_MAX = 256, bool LAZY = false, int TOP = 0, bool SHARE = false>
+          int ORD_MAX = 256, bool LAZY = false, int TOP = 0, bool SHARE = false, bool PIPE = false>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ uint4 lds_stk[SD][BLOCK];
@@ -1685,6 +1685,13 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   int bk = -1;
   size_t qi = 0;
   bool have = false;
+  // PIPE (round 4): a lane that takes a query does not make the wave wait for it.  The loads of its coordinates and of
+  // its previous hit's index are ISSUED at the hand-out and land in the registers the lane is not using (qx / qy / qz, bk;
+  // cur = REF_STAGE1); the lane joins the node walk one trip later, and the two round trips -- the coordinates, then the
+  // previous hit's point for the warm start -- are covered by the trip the other lanes make meanwhile (a hand-out used
+  // to stall all 64 lanes for both, ten times per slab).
+  // (Staged that way with registers of their own -- the stored point, the previous hit's point, a stage counter -- the
+  // kernel needed 133 VGPRs, i.e. lost its fourth wave per SIMD, or spilled; the form below carries nothing extra.)
   BoxF32 bx;
   bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f; bx.ec = 0.f; bx.pthr = 0.f;
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
@@ -1820,7 +1827,16 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         got = idle && slot < end_q;
         mine = (ORDER && got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
       }
-      if (got) {
+      if (PIPE && got) {
+        // (requested here, used in the node walk -- see there; the registers of a lane without a query hold them meanwhile)
+        bk = a.warm ? gload<int>(reinterpret_cast<const char*>(a_kpos), (uint32_t)mine << 2) : -1;
+        const uint32_t m8 = (uint32_t)mine << 3;
+        qx = gload<double>(reinterpret_cast<const char*>(a.x), m8); qy = gload<double>(reinterpret_cast<const char*>(a.y), m8);
+        qz = gload<double>(reinterpret_cast<const char*>(a.z), m8);
+        qi = mine; have = true; nbk = 0; st.sp = 0;
+        cur = REF_STAGE1;
+      }
+      if (!PIPE && got) {
         // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
         // (global loads / stores at 32-bit byte offsets: a scan has < 2^27 points)
         const uint32_t m8 = (uint32_t)mine << 3;
@@ -1954,7 +1970,45 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       }
       cur = next;
     }
-    if constexpr (!FAT) while (!(cur & REF_LEAF)) {
+    if constexpr (!FAT) while (!(cur & REF_LEAF) || (PIPE && cur == REF_STAGE1)) {
+      // PIPE: a lane that has just been handed a query (cur == REF_STAGE1: its coordinates and its previous hit's index were
+      // requested at the hand-out and sit in qx / qy / qz / bk) spends this trip becoming a query: the stored point moved and
+      // mapped into the tree's frame, the previous hit's point requested HERE and used at the bottom of the trip, behind
+      // the wait for the node records the other lanes requested meanwhile.  Nothing of it is carried around the loop.
+      double w_x = 0.0, w_y = 0.0, w_z = 0.0;
+      bool fin = false;
+      if constexpr (PIPE) {
+        if (__ballot(cur == REF_STAGE1) != 0ull) {
+          if (cur == REF_STAGE1) {
+            // (the argument block through a pointer the compiler cannot see through: otherwise it hoists the two matrices'
+            // forty-eight scalar loads out of this loop and keeps them live around it -- 135 VGPRs instead of 126)
+            const SearchArgs* ap = &a;
+            asm volatile("" : "+s"(ap));
+            double tx = qx, ty = qy, tz = qz;
+            const uint32_t m8 = (uint32_t)qi << 3;
+            if (ap->has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
+              dev_xf3_inplace(ap->pending, tx, ty, tz);
+              gstore<double>(reinterpret_cast<char*>(ap->x), m8, tx); gstore<double>(reinterpret_cast<char*>(ap->y), m8, ty);
+              gstore<double>(reinterpret_cast<char*>(ap->z), m8, tz);
+              if (ap->nx) {
+                double px = ap->nx[qi], py = ap->ny[qi], pz = ap->nz[qi];
+                dev_xf3normal(ap->pending, px, py, pz);
+                ap->nx[qi] = px; ap->ny[qi] = py; ap->nz[qi] = pz;
+              }
+            }
+            qx = tx; qy = ty; qz = tz;
+            if (ap->has_inv) dev_xf3(ap->inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
+            if (bk >= 0) {
+              const uint32_t po = (uint32_t)bk << 5;
+              const double2 pxy = gload<double2>(reinterpret_cast<const char*>(pts), po);
+              w_z = gload<double>(reinterpret_cast<const char*>(pts), po + 16);
+              w_x = pxy.x; w_y = pxy.y;
+            }
+            fin = true;
+          }
+        }
+      }
+      if (!PIPE || !(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
       if (COUNT && kLab) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
       if (ORDER) ++nbk;     // (a key of buckets alone saves this instruction and orders no better: 0.1934 / 0.1968 against 0.1946 / 0.1923 ms)
@@ -2029,6 +2083,23 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         }
       }
       cur = next;
+      }
+      if constexpr (PIPE) {
+        if (fin) {
+          // warm_radius_kp's arithmetic on the point requested at the top of this trip; the lane stands at the root now
+          { const SearchArgs* ap = &a; asm volatile("" : "+s"(ap)); best = ap->maxd2; }
+          if (bk >= 0) {
+            const double dx = w_x - qx, dy = w_y - qy, dz = w_z - qz;
+            const double d = dx * dx + dy * dy + dz * dz;
+            const double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
+            if (up < best) best = up;
+          }
+          bk = -1;
+          cur = T.root_ref;
+          bx.set_query(qx, qy, qz, T.absmax);
+          bx.set_radius(best);
+        }
+      }
     }
 
     // ---- phase 2: scan the bucket, then pop ----
@@ -2215,7 +2286,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   }
 }
 
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false, int TOP = 0, bool SHARE = false>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false, int TOP = 0, bool SHARE = false, bool PIPE = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a_by_value)
 {
   // The argument block (three 4x4 fp64 matrices among its 700 bytes) is read through the kernarg segment pointer, not
@@ -2224,7 +2295,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   // v_readlane in a kernel that is short of issue slots.  Behind an opaque pointer the fields are s_load'ed where they
   // are used (the matrices only when a lane takes a new query), like k_search_refill_multi reads its table entry.
   (void)a_by_value;
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT, 256, false, TOP, SHARE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT, 256, false, TOP, SHARE, PIPE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 
 #ifdef TDTK_LAB
@@ -2237,7 +2308,11 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
 // are done).  Buckets are scanned one query after the other (the shadow groups' sixty registers are shared).  Each query's
 // traversal -- visits, their order, every comparison -- is untouched: same indices, same counters.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE>
+// ONE (round 4, TDTK_TWO_ONE=1): a trip of the node walk serves ONE of the lane's two queries -- slot 0 while it stands at a
+// node, slot 1 otherwise -- with one record's loads and one visit's instructions, the state of the chosen slot picked by
+// selects.  The vector L1 charges a wave instruction by its bytes per lane whatever the mask (profiles/r04_tcp_diag.txt), so
+// what a fuller trip saves is load INSTRUCTIONS, which the both-slots-per-trip form above did not (it issued two sets).
+template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE, bool ONE = false>
 __device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ uint4 lds_stk[2][SD][BLOCK];
@@ -2379,7 +2454,46 @@ __device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const u
     }
 
     // ---- phase 1: walk internal nodes until both of this lane's queries hold a bucket (or are finished) ----
-    while (!(cur[0] & REF_LEAF) || !(cur[1] & REF_LEAF)) {
+    if constexpr (ONE) while (!(cur[0] & REF_LEAF) || !(cur[1] & REF_LEAF)) {
+      if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
+      const bool u1 = (cur[0] & REF_LEAF) != 0u;        // slot 0 holds a bucket (or is done): this trip is slot 1's
+      const uint32_t c = u1 ? cur[1] : cur[0];
+      const uint32_t ho = __umul24(c, (uint32_t)sizeof(KdHot));
+      float4 b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
+      float4 b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
+      double2 sc = gload<double2>(hotb, ho + 32);          // splitval {c1, c2}
+      TDTK_PIN_BATCH3(b0.x, b1.z, sc.x);
+      const double sqx = u1 ? qx[1] : qx[0], sqy = u1 ? qy[1] : qy[0], sqz = u1 ? qz[1] : qz[0], sbest = u1 ? best[1] : best[0];
+      const float fqx = u1 ? bx[1].qx : bx[0].qx, fqy = u1 ? bx[1].qy : bx[0].qy, fqz = u1 ? bx[1].qz : bx[0].qz;
+      const float fthi = u1 ? bx[1].thi : bx[0].thi, ftlo = u1 ? bx[1].tlo : bx[0].tlo;
+      LaneStackQ<BLOCK, SD> ss;
+      ss.l_e = u1 ? st[1].l_e : st[0].l_e;
+      ss.g_m2 = a.ovf_m2 ? a.ovf_m2 + 2 * gl + (u1 ? 1 : 0) : nullptr;
+      ss.g_ref = a.ovf_ref ? a.ovf_ref + 2 * gl + (u1 ? 1 : 0) : nullptr;
+      ss.gstride = (size_t)nb * BLOCK * 2;
+      ss.sp = u1 ? st[1].sp : st[0].sp;
+      if (COUNT) ++c_int;
+      const float a32 = fmaxf(fmaxf(fabsf(fqx - b0.x) - b0.w, fabsf(fqy - b0.y) - b1.x), fabsf(fqz - b0.z) - b1.y);
+      bool prune = a32 >= fthi;
+      if (__builtin_expect(!prune && !(a32 < ftlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+        const uint32_t no = (uint32_t)((c & REF_VAL) << 6);
+        const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
+        const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
+        prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, sqx, sqy, sqz, sbest);
+      }
+      uint32_t next = REF_DONE;
+      if (!prune) next = descend_ax(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), __float_as_uint(b1.z), sqx, sqy, sqz, sbest, ss);
+      else {
+        while (ss.sp > 0) {
+          --ss.sp;
+          uint32_t r; double m2;
+          ss.top(r, m2);
+          if (m2 < sbest) { next = r; break; }
+        }
+      }
+      if (u1) { cur[1] = next; st[1].sp = ss.sp; ++nbk[1]; } else { cur[0] = next; st[0].sp = ss.sp; ++nbk[0]; }
+    }
+    if constexpr (!ONE) while (!(cur[0] & REF_LEAF) || !(cur[1] & REF_LEAF)) {
       if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
       const bool at[2] = {!(cur[0] & REF_LEAF), !(cur[1] & REF_LEAF)};
       // the records of both, requested before either is used
@@ -2534,11 +2648,11 @@ __device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const u
   }
 }
 
-template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE, int WPS>
+template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE, int WPS, bool ONE = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill2(const SearchArgs a_by_value)
 {
   (void)a_by_value;
-  search_refill2_body<BLOCK, SD, THRESH, COUNT, FUSE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
+  search_refill2_body<BLOCK, SD, THRESH, COUNT, FUSE, ONE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 #endif   // TDTK_LAB
 
@@ -2546,7 +2660,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill2(const SearchArgs 
 // batch l with the arguments args[l] (device memory; every base[] a multiple of 8, so a workgroup's XCD is the one its
 // batch-relative index says).  Workgroups are dispatched in order, so the tail of one batch is filled by the next --
 // what several streams give, without depending on how the runtime maps streams to hardware queues.
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool ORDER = false>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool ORDER = false, bool PIPE = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const SearchArgs* __restrict__ args,
                                                                     const uint32_t* __restrict__ base, int nbatch)
 {
@@ -2554,7 +2668,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const Search
   while (l + 1 < nbatch && blockIdx.x >= base[l + 1]) ++l;
   l = __builtin_amdgcn_readfirstlane(l);
   const uint32_t b0 = base[l], b1 = base[l + 1];
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320, true>(args[l], blockIdx.x - b0, b1 - b0);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320, true, 0, false, PIPE>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
 #ifdef TDTK_LAB   // ---- lab only (measured negatives): slabs of equal cost, the one-loop kernel ----
@@ -3507,6 +3621,17 @@ uint32_t search_fused_rows(size_t n, int side_by_side)
   return refill_grid_b(n, 128, &q, side_by_side);
 }
 
+// pipelined hand-out (search_refill_body<.., PIPE>), lab only (TDTK_PIPE=1).  MEASURED NEGATIVE: parity-green, and the bucket
+// scan -- where the register demand peaks -- finds 8-9 more registers live with it (phi copies of the query registers the
+// staged loads land in): 134 VGPRs = three waves per SIMD, or at 128 nine spilled registers in hot code: 1M-vs-1M k_search
+// 0.2348 ms against 0.1954-0.1959, one lum6DEuler round of 84 links 13.9 ms against 10.5.
+#ifdef TDTK_LAB
+static bool pipe_on()
+{
+  if (const char* e = lab_env("TDTK_PIPE")) return e[0] == '1';
+  return false;
+}
+#endif
 template <bool COUNT, int FUSE>
 static void launch_refill128(SearchArgs& a, hipStream_t s)
 {
@@ -3539,6 +3664,12 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     if (two_per_lane_for(a.n, a.side_by_side) && !a.bounds) {
       const uint32_t nb2 = refill2_grid(a.n, &qpw);
       a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
+      const char* e1 = lab_env("TDTK_TWO_ONE");
+      const bool one = e1 && e1[0] == '1';
+      if (one) {
+        if (two_per_lane() == 3) hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 3, true>), dim3(nb2), dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 2, true>), dim3(nb2), dim3(128), 0, s, a);
+      } else
       if (two_per_lane() == 3) hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 3>), dim3(nb2), dim3(128), 0, s, a);
       else hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 2>), dim3(nb2), dim3(128), 0, s, a);
       return;
@@ -3604,7 +3735,14 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
 #endif
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    default:
+#ifdef TDTK_LAB
+      if ((FUSE == 0 || FUSE == 3) && pipe_on())
+        hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, (FUSE == 3 ? 3 : 0), false, 4, 0, false, 0, false, true>), dim3(nb), dim3(128), occ_lds, s, a);
+      else
+#endif
+      hipLaunchKernelGGL((k_search_refill<128, 4, 16, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
+      break;
   }
   if (kLab && a.trace) {
     (void)hipStreamSynchronize(s);
@@ -4012,11 +4150,19 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
         break;
 #endif
       case 32:
+#ifdef TDTK_LAB
+        if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else
+#endif
         if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
         else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
       default:
+#ifdef TDTK_LAB
+        if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else
+#endif
         if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
         else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);

@@ -89,6 +89,7 @@ constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_AXIS = 0x40000000u;
 constexpr uint32_t REF_VAL = 0x3FFFFFFFu;
 constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+constexpr uint32_t REF_STAGE1 = 0xFFFFFFFEu;   // persistent-lane kernel, pipelined hand-out: the lane's query has been requested, not yet set up
 
 struct LeafEntry {
   int32_t start, count;

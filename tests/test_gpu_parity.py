@@ -1985,7 +1985,9 @@ def test_alternative_search_kernels_agree(tdtk, orc, gpu, lab, monkeypatch):
                 # round 4: the tree's upper levels staged in LDS by workgroups of 512 / 1024 threads; the slabs of a workgroup's
                 # waves handed out together from one cursor in LDS
                 {"TDTK_TOP_BLOCK": "1024"}, {"TDTK_TOP_BLOCK": "512"},
-                {"TDTK_SHARE_BLOCK": "256"}, {"TDTK_SHARE_BLOCK": "512"}, {"TDTK_SHARE_BLOCK": "1024"}):
+                {"TDTK_SHARE_BLOCK": "256"}, {"TDTK_SHARE_BLOCK": "512"}, {"TDTK_SHARE_BLOCK": "1024"},
+                # ... a hand-out that does not wait for its loads; two queries per lane with one visit per trip
+                {"TDTK_PIPE": "1"}, {"TDTK_TWO_PER_LANE": "3", "TDTK_TWO_ONE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for counting in (0, 1):

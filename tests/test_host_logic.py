@@ -914,7 +914,7 @@ def test_every_product_kernel_spills_nothing_and_search_kernels_keep_four_waves(
             assert num("VGPRs") <= 128 and num(r"Occupancy \[waves/SIMD\]") >= 4, name
         for lab_only in ("k_search_step", "k_search_coop", "k_slab_bounds", "k_make_fat"):
             assert lab_only not in name, name
-        if "k_search_refillI" in name:      # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, PTS, PROBE, FAT, TOP, SHARE>: product = 128 threads,
-            # FUSE 0 / 3, static slabs, plain walk, no upper levels in LDS, every wave its own slab
-            assert re.search(r"ILi128ELi4ELi(16|32)ELi[14]ELb[01]ELi[03]ELb0ELi4ELi0ELb0ELi0ELb0EEE", name), name
+        if "k_search_refillI" in name:      # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, PTS, PROBE, FAT, TOP, SHARE, PIPE>: product = 128 threads,
+            # FUSE 0 / 3, static slabs, plain walk, no upper levels in LDS, every wave its own slab, hand-outs that wait
+            assert re.search(r"ILi128ELi4ELi(16|32)ELi[14]ELb[01]ELi[03]ELb0ELi4ELi0ELb0ELi0ELb0ELb0EEE", name), name
     assert seen_refill >= 12

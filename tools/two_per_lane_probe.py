@@ -13,9 +13,11 @@ m, d, T = bench.make_icp_pair(n)
 mini = t.icp6D_QUAT(True)
 
 
-def run(mode, count=False):
+def run(mode, count=False, one=False):
     if mode: os.environ["TDTK_TWO_PER_LANE"] = str(mode)
     else: os.environ.pop("TDTK_TWO_PER_LANE", None)
+    if one: os.environ["TDTK_TWO_ONE"] = "1"      # a trip of the node walk serves ONE of the lane's two queries (round 4)
+    else: os.environ.pop("TDTK_TWO_ONE", None)
     model = t.Scan([0, 0, 0], [0, 0, 0], m); data = t.Scan([0, 0, 0], [0, 0, 0], d)
     t.icp6D(mini, 25.0, 5, quiet=True, epsilonICP=-1.0).match(model, data)
     if count: L.tdtk_visit_counting(0, 1)
@@ -33,11 +35,13 @@ def run(mode, count=False):
 
 
 base = run(0)
-for mode in (3, 2):
-    r = run(mode)
+for mode, one in ((3, False), (2, False), (3, True), (2, True), (3, True)):
+    r = run(mode, one=one)
+    print("one visit per trip" if one else "both slots per trip", end=": ")
     same = (r["rms"] == base["rms"] and r["pairs"] == base["pairs"] and np.array_equal(r["pose"], base["pose"]))
     print("two per lane, %d waves/SIMD: nn %.4f ms (one per lane %.4f) | rms/pairs/pose identical: %s; pairs %d vs %d, max|dpose| %.3e" %
           (mode, r["nn_ms"], base["nn_ms"], same, r["pairs"], base["pairs"], float(np.abs(r["pose"] - base["pose"]).max())))
-b = run(0, True); r = run(3, True)
+b = run(0, True); r = run(3, True); r1 = run(3, True, one=True)
 print("visits one per lane", b["visits"], "trips", b["trips"])
 print("visits two per lane", r["visits"], "trips", r["trips"])
+print("visits two per lane, one visit per trip", r1["visits"], "trips", r1["trips"])
