@@ -416,6 +416,12 @@ static __device__ __forceinline__ double warm_radius(const SearchArgs& a, const 
   return warm_radius_kp(a, a.warm ? a.kpos[i] : -1, qx, qy, qz);
 }
 
+// bytes of a hot record the persistent-lane kernel's divergent visit loads: 0 = all 48 (16 + 16 + 16), 2 = 40 (16 + 8 + 16, the
+// split axis from the child references' bits).  Measured (round 4): 40 bytes 0.1957-0.1970 ms per k_search of the 1M-vs-1M
+// loop against 0.1933-0.1959 with 48, the 84-link round 10.59 ms against 10.45-10.52 -- nothing, like the 64-byte-aligned
+// record of round 3: the visit's cost is not its bytes.
+constexpr int HOT_NARROW = 0;
+
 // groups of four points a lane takes in per round trip of the bucket filter: 5 = a whole default bucket (-b 20)
 constexpr int GRP_TRIP = 5;
 
@@ -2054,14 +2060,22 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           sc = *reinterpret_cast<const double2*>(lp + 32);
         } else {
         b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
+        if constexpr (HOT_NARROW == 2) {              // hy hz only: the axis from the child references' bits
+          const float2 h2 = gload<float2>(hotb, ho + 16);
+          b1.x = h2.x; b1.y = h2.y;
+        } else
         b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
         sc = gload<double2>(hotb, ho + 32);           // splitval {c1, c2}
+        if constexpr (HOT_NARROW == 2) {
+          const uint32_t c1b = (uint32_t)__double2loint(sc.y), c2b = (uint32_t)__double2hiint(sc.y);
+          b1.z = __uint_as_float(((c1b >> 30) & 1u) | (((c2b >> 30) & 1u) << 1));
+        }
         }
         if constexpr (PROBE == 3) {   // sensitivity probe (TDTK_BUCKET_PTS=43): one more 16-byte load per node visit, result unused
           float4 w = gload<float4>(hotb, ho + 8);
           asm volatile("" : "+v"(b0.x), "+v"(b1.z), "+v"(sc.x), "+v"(w.x));
         } else
-        TDTK_PIN_BATCH3(b0.x, b1.z, sc.x);
+        TDTK_PIN_BATCH3(b0.x, b1.x, sc.x);
         const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
         bool prune = a32 >= bx.thi;
         if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
