@@ -188,6 +188,23 @@ def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_quer
             issue["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
         if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
             issue["l1_tag_accesses_per_cu_cycle"] = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc
+        if pmc.get("TCP_GATE_EN2_sum"):
+            # the resource this kernel is closest to: the vector L1 (TCP) of each CU
+            l1 = {"busy": pmc["TCP_GATE_EN2_sum"] / 256.0 / cyc,
+                  "what": "TCP_GATE_EN2 (the L1's core clocked: it has work) / (256 CUs x kernel cycles); clock_on = TCP_GATE_EN1 likewise; "
+                          "stalled_on_pending_fills = TCP_PENDING_STALL_CYCLES, stalled_on_tag_conflicts = TCP_READ_TAGCONFLICT_STALL_CYCLES, "
+                          "both as shares of the CU-cycles; cycles_per_wave_instruction = TCP_TCP_LATENCY / TCP_TA_TCP_STATE_READ; "
+                          "miss_latency_cycles = TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ"}
+            if pmc.get("TCP_GATE_EN1_sum"): l1["clock_on"] = pmc["TCP_GATE_EN1_sum"] / 256.0 / cyc
+            if pmc.get("TCP_PENDING_STALL_CYCLES_sum"): l1["stalled_on_pending_fills"] = pmc["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc
+            if pmc.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"): l1["stalled_on_tag_conflicts"] = pmc["TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"] / 256.0 / cyc
+            if pmc.get("TCP_TCP_LATENCY_sum") and pmc.get("TCP_TA_TCP_STATE_READ_sum"):
+                l1["cycles_per_wave_instruction"] = pmc["TCP_TCP_LATENCY_sum"] / pmc["TCP_TA_TCP_STATE_READ_sum"]
+            if pmc.get("TCP_TCC_READ_REQ_LATENCY_sum") and pmc.get("TCP_TCC_READ_REQ_sum"):
+                l1["miss_latency_cycles"] = pmc["TCP_TCC_READ_REQ_LATENCY_sum"] / pmc["TCP_TCC_READ_REQ_sum"]
+            if pmc.get("TCP_UTCL1_TRANSLATION_MISS_sum") is not None and pmc.get("TCP_UTCL1_REQUEST_sum"):
+                l1["translation_miss_rate"] = pmc["TCP_UTCL1_TRANSLATION_MISS_sum"] / pmc["TCP_UTCL1_REQUEST_sum"]
+            issue["vector_l1"] = l1
         r["issue"] = issue
     return r
 

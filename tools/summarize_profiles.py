@@ -71,7 +71,7 @@ if os.path.exists(stats_file):
 pmc = {"command": COMMAND, "steps": STEPS, "warmup": WARM, "kernels": {},
        "note": "per-dispatch averages; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE "
                "reads 1/2 of the streamed bytes (calibrated: k_transform reads 3 x 8 MB = 23437.5 KiB, reports ~11738)"}
-for p in ("fetch", "write", "sq1", "sq2", "sq3", "tcc", "tcp"):
+for p in ("fetch", "write", "sq1", "sq2", "sq3", "tcc", "tcp", "tcp2", "tcp3"):
     fn = os.path.join(src, p, "p_counter_collection.csv")
     if not os.path.exists(fn):
         continue
