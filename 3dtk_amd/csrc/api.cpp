@@ -2058,8 +2058,13 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
       const KdNode &a = nodes[i], &b = H.nodes[i];
       // == on doubles: +0 and -0 compare equal (the sign of a zero box centre never decides anything)
       if (!(a.cx == b.cx && a.cy == b.cy && a.cz == b.cz && a.hx == b.hx && a.hy == b.hy && a.hz == b.hz &&
-            a.splitval == b.splitval && a.c1 == b.c1 && a.c2 == b.c2))
+            a.splitval == b.splitval && a.c1 == b.c1 && a.c2 == b.c2)) {
         mismatches[0]++;
+        if (kLab && lab_env("TDTK_VERIFY_DUMP"))
+          fprintf(stderr, "VERIFY node %zu: dev c(%.17g %.17g %.17g) h(%.17g %.17g %.17g) split %.17g c1 %08x c2 %08x\n"
+                          "            host c(%.17g %.17g %.17g) h(%.17g %.17g %.17g) split %.17g c1 %08x c2 %08x\n",
+                  i, a.cx, a.cy, a.cz, a.hx, a.hy, a.hz, a.splitval, a.c1, a.c2, b.cx, b.cy, b.cz, b.hx, b.hy, b.hz, b.splitval, b.c1, b.c2);
+      }
       if (rr[i] != H.node_r[i]) mismatches[1]++;
     }
     for (size_t i = 0; i < pts.size(); i++)

@@ -2028,6 +2028,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     static_assert(64 + sizeof(BLevel) * (BUILD_MAX_LEVELS + 2) <= 65536, "the staging block holds every level's counters");
     std::memset(hst, 0, 64);
     bool have_max = false;
+    uint32_t fin_nodes = 0;     // nodes of the level about to be handed over (k_fin_maxn)
     for (;;) {
       if (level == fin_level) {
         // does the level's largest node fit a workgroup's LDS?  (An unbalanced cloud -- a real scan -- takes a level or two more.)
@@ -2038,19 +2039,23 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         }
         have_max = false;
         const uint32_t h_max[2] = {h_small[4], h_small[5]};
+        fin_nodes = h_max[1];
         if (h_max[0] > FIN_LDS && h_max[1] * 2u <= FIN_MAX_SUBTREES && fin_level + 1u < 31u) {
           fin_level++;              // one more level by its own launches (below), then look again
           known = h_max[1]; known_at = level;
           batch = 1;
-        } else if (h_max[0] > FIN_LDS) {
+        } else if (h_max[0] > FIN_LDS || h_max[1] > FIN_MAX_SUBTREES) {
           fin_level = 0xFFFFFFFFu;  // too many nodes for the tables: level by level to the end
           known = h_max[1]; known_at = level;
           batch = 2;
         }
       }
       if (level == fin_level) {
-        // hand the level over: its nodes (at most 2^level of them) become the roots of subtrees
-        const uint32_t tmax = 1u << fin_level;
+        // hand the level over: its nodes become the roots of subtrees.  As many workgroups as the level HAS nodes (counted
+        // just above; the tables hold FIN_MAX_SUBTREES): 2^level of them -- right for a balanced tree -- is a million by the
+        // time a lopsided cloud (one dense cluster that stays above FIN_LDS for sixteen levels) is handed over, and the
+        // copy of that many root records ran over the arena (found by tools/fuzz_parity.py --seed 4401, round 4).
+        const uint32_t tmax = fin_nodes ? fin_nodes : 1u;
         BSeg* roots = (BSeg*)(arena + O[37]);
         FinTab* ftab = (FinTab*)(arena + O[38]);
         FinOff* foff = (FinOff*)(arena + O[39]);
@@ -2317,6 +2322,21 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     }
     if (!no_last_look) BCHK(hipStreamSynchronize(s));
     BCHK(hipGetLastError());
+    if (kLab && lab_env("TDTK_SPEC_DUMP")) {
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "SPEC_DUMP M=%u spec %d SP.n %d tail_enqueued %d fin_level %u level %u h_spec_err %u depth %u\n", M, (int)spec, (int)SP.n, (int)tail_enqueued,
+              fin_level, level, h_spec_err, depth);
+      for (int l = 0; l < (int)SP.n; l++) {
+        const BSpecLevel& L = SP.L[l];
+        uint32_t nd[4], nlf[4], cn[4], axs[4]; BMeas ex[4]; BSeg sg[4];
+        (void)hipMemcpy(nd, L.node, sizeof nd, hipMemcpyDeviceToHost); (void)hipMemcpy(nlf, L.nleft, sizeof nlf, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(cn, L.cnt, sizeof cn, hipMemcpyDeviceToHost); (void)hipMemcpy(axs, L.axis, sizeof axs, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ex, L.exact, sizeof ex, hipMemcpyDeviceToHost); (void)hipMemcpy(sg, L.segs, sizeof sg, hipMemcpyDeviceToHost);
+        for (int k = 0; k < 4; k++)
+          fprintf(stderr, "  spec level %u entry %d: node %08x seg(start %u n %u) axis %u nleft %u cnt %u exact mean (%.17g %.17g %.17g)\n", L.level, k, nd[k],
+                  sg[k].start, sg[k].n, axs[k], nlf[k], cn[k], ex[k].mean[0], ex[k].mean[1], ex[k].mean[2]);
+      }
+    }
     if (h_spec_err) { res.err = hipErrorNotReady; spec_suspect = true; goto fail; }     // a cut the exact sum would have made elsewhere: in order, then
   }
   res.nodes = f_nodes; res.node_r = f_r; res.leaf_tab = f_leaf; res.pts = pts;

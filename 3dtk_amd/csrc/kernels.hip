@@ -4099,6 +4099,17 @@ hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hi
 // 640 -> 11.4, 1024 -> 11.5, 1536 -> 11.7; a rank's 11 links in one launch: 320 -> 1.79 ms, 448 -> 1.77, 640 -> 1.81
 // (three streams: 12.6 / 1.89 on the same box).
 int search_multi_class(size_t n) { const int v = pick_variant(n); return (v == 20 || v == 4 || v == 10) ? v : 0; }
+// lab (TDTK_MULTI_BLOCK=64): the several-links launch in workgroups of ONE wave -- a wave slot is free again when its wave is
+// done, not when its workgroup's slower wave is (the rows of partial sums are then one per wave)
+static bool multi_block64()
+{
+#ifdef TDTK_LAB
+  const char* e = lab_env("TDTK_MULTI_BLOCK");
+  return e && atoi(e) == 64;
+#else
+  return false;
+#endif
+}
 uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slabs)
 {
   const int v = pick_variant(a.n);
@@ -4131,6 +4142,7 @@ uint32_t search_multi_prepare(SearchArgs& a, int links_in_launch, bool long_slab
   if (ph < 1) ph = 1;
   while (ph > 1 && (qpw % (ph * 16)) != 0) --ph;
   a.phases = ph;
+  if (long_slabs && multi_block64()) nb *= 2;
   return nb;
 }
 int search_multi_thresh(size_t n) { return refill_thresh(n); }
@@ -4147,6 +4159,13 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
     return hipGetLastError();
   }
   const dim3 g(total_blocks), b(128);
+#ifdef TDTK_LAB
+  if (!count && lum_sums && multi_block64()) {
+    if (thresh == 32) hipLaunchKernelGGL((k_search_refill_multi<64, 4, 32, 4, false, 5, true>), g, dim3(64), 0, s, d_args, d_base, nbatch);
+    else hipLaunchKernelGGL((k_search_refill_multi<64, 4, 16, 4, false, 5, true>), g, dim3(64), 0, s, d_args, d_base, nbatch);
+    return hipGetLastError();
+  }
+#endif
   if (count) {
     switch (thresh) {
 #ifdef TDTK_LAB

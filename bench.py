@@ -874,6 +874,9 @@ def bench_graphslam(args, rank, world, local):
                           "wave_wait_share": (pk["SQ_WAIT_ANY"] / pk["SQ_WAVE_CYCLES"]) if pk.get("SQ_WAIT_ANY") and pk.get("SQ_WAVE_CYCLES") else None,
                           "l1_tag_accesses_per_cu_cycle": (pk["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc) if pk.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
                           "l2_hit_rate": (pk["TCC_HIT_sum"] / max(1.0, pk["TCC_HIT_sum"] + pk["TCC_MISS_sum"])) if pk.get("TCC_HIT_sum") is not None and pk.get("TCC_MISS_sum") is not None else None,
+                          "vector_l1_busy": (pk["TCP_GATE_EN2_sum"] / 256.0 / cyc) if pk.get("TCP_GATE_EN2_sum") else None,
+                          "vector_l1_clock_on": (pk["TCP_GATE_EN1_sum"] / 256.0 / cyc) if pk.get("TCP_GATE_EN1_sum") else None,
+                          "vector_l1_stalled_on_pending_fills": (pk["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc) if pk.get("TCP_PENDING_STALL_CYCLES_sum") else None,
                           "what": "SQ / TCP / TCC counters of the same launch under rocprofv3 --pmc (each pass its own run): no single "
                                   "throughput resource is saturated -- the vector ALUs are busy less than half the time, the memory "
                                   "side below half of HBM peak, the L1 tag pipeline the closest to its limit of one look-up per cycle"}

@@ -718,6 +718,33 @@ def test_device_tree_build_equals_host_build(tdtk, gpu, name, bucket):
     assert kd.verify() == [0, 0, 0, 0]
 
 
+@pytest.mark.parametrize("case", ["fixture", "generated"])
+def test_device_tree_of_a_lopsided_cloud_is_handed_over_late(tdtk, orc, gpu, case):
+    """A cloud whose densest cluster stays above the finisher's 3584-point limit for sixteen levels (coordinates over
+    twelve orders of magnitude: tools/fuzz_parity.py kind 4, seed 4401 run 2446 -- tests/golden/fuzz_case_dynamic_range_20000.npz,
+    written by `tools/fuzz_parity.py --trace` -- and a second one generated here).  The level is handed to the subtree
+    finisher sixteen levels later than a balanced tree's would be; round 4 launched 2^level workgroups and copied that many
+    root records there -- a million, over the end of the build's arena: five wrong split values, 125 of 550 wrong neighbours
+    and, inside a long process, a GPU memory fault.  Now: as many as the level has nodes.  Record for record the host
+    builder's tree, the oracle's neighbours, and a tree built right after it in the same context is sound too."""
+    if case == "fixture":
+        d = np.load(os.path.join(HERE, "golden", "fuzz_case_dynamic_range_20000.npz"))
+        p, q, bucket, md2 = d["p"], d["q"], int(d["bucket"]), float(d["md2"])
+    else:
+        rng = np.random.default_rng(77)
+        p = rng.normal(0, 1, (30000, 3)) * (10.0 ** rng.integers(-6, 7, (30000, 1)))
+        q = np.concatenate([p[rng.integers(0, len(p), 500)] + rng.normal(0, 1e-3, (500, 3)), rng.uniform(p.min() - 1, p.max() + 1, (50, 3))])
+        bucket, md2 = 20, 1e18
+    kd, T = tdtk.KDtree(p, bucket), orc.Tree(p, bucket)
+    assert kd.verify() == [0, 0, 0, 0]
+    gi, gd = kd.FindClosestBatch(q, md2)
+    oi, od = T.find_closest(q, md2)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    m = np.random.default_rng(5).uniform(-50, 50, (40000, 3))
+    kd2 = tdtk.KDtree(m, 20)
+    assert kd2.verify() == [0, 0, 0, 0]
+
+
 def test_device_tree_build_full_size(tdtk, gpu, k5):
     k, m, _ = k5
     kd = tdtk.KDtree(m, 20)

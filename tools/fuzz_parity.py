@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--big", action="store_true", help="clouds of 30K..400K points (fewer rounds)")
+ap.add_argument("--trace", action="store_true", help="print every run's stages as they start (to find a crash)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 
@@ -55,6 +56,8 @@ while time.time() - t0 < a.seconds:
     p = cloud()
     n = len(p)
     runs += 1
+    tr = (lambda what: print("run %d n=%d: %s" % (runs, n, what), flush=True)) if a.trace else (lambda what: None)
+    tr("normals")
     # normals
     k = int(min(n, rng.choice([1, 3, 10, 10, 10, 16, 32])))
     eps = float(rng.choice([0.0, 0.5, 1.0, 1.0, 3.0]))
@@ -65,11 +68,14 @@ while time.time() - t0 < a.seconds:
         fails += 1
         np.save("gpurun_out/fuzz_fail_normals_%d.npy" % runs, p)
         print("NORMALS MISMATCH run %d n=%d k=%d eps=%g knn_equal=%s" % (runs, n, k, eps, np.array_equal(gk, wk)), flush=True)
+    tr("search")
     # search tree
     bucket = int(rng.choice([1, 2, 5, 20, 20]))
     q = np.concatenate([p[rng.integers(0, n, min(n, 500))] + rng.normal(0, rng.choice([0.0, 1e-3, 1.0]), (min(n, 500), 3)),
                         rng.uniform(p.min() - 1, p.max() + 1, (50, 3))])
     md2 = float(rng.choice([1e-6, 0.25, 25.0, 1e18]))
+    if a.trace:      # the case about to run, kept for whoever has to look at a crash
+        np.savez("gpurun_out/fuzz_last_case.npz", p=p, q=q, bucket=bucket, md2=md2, run=runs)
     kd, T = tdtk.KDtree(p, bucket), orc.Tree(p, bucket)
     gi, gd = kd.FindClosestBatch(q, md2)
     oi, od = T.find_closest(q, md2)
@@ -77,6 +83,7 @@ while time.time() - t0 < a.seconds:
         fails += 1
         np.save("gpurun_out/fuzz_fail_search_%d.npy" % runs, p)
         print("SEARCH MISMATCH run %d n=%d bucket=%d md2=%g" % (runs, n, bucket, md2), flush=True)
+    tr("pairs bucket=%d md2=%g" % (bucket, md2))
     # SearchTree::getPtPairs through the C ABI: random pose, the three pairing modes, a query sub-range
     mode = int(rng.integers(0, 3))
     A = tdtk.EulerToMatrix4(rng.uniform(-1, 1, 3), rng.uniform(-0.05, 0.05, 3))
@@ -94,6 +101,7 @@ while time.time() - t0 < a.seconds:
         fails += 1
         np.save("gpurun_out/fuzz_fail_pairs_%d.npy" % runs, p)
         print("PAIRS MISMATCH run %d n=%d mode=%d range=[%d,%d) md2=%g n=%s/%s" % (runs, n, mode, lo, hi, md2p, r["n"], o["n"]), flush=True)
+    tr("octree")
     # octree reduction (-r): same cells, same centres, same order
     vox = float(rng.choice([0.3, 2.0, 15.0, 1e5]))
     ext = float(np.abs(p).max()) + 1.0
@@ -105,6 +113,7 @@ while time.time() - t0 < a.seconds:
             print("OCTREE MISMATCH run %d n=%d voxel=%g" % (runs, n, vox), flush=True)
     # one in ten: a short ICP (well-conditioned cloud, random minimizer) against the oracle loop
     if runs % 10 == 0:
+        tr("icp")
         from oracle import icp_oracle as io
         nm = int(rng.choice([200, 1500, 6000]))
         m = rng.uniform(-60, 60, (nm, 3)); m[:, 2] *= 0.3
@@ -131,6 +140,7 @@ while time.time() - t0 < a.seconds:
     # one in twenty: a random life of two resident scans (moves before / after going resident, tree built late,
     # pose extrapolation, whole-scan pair passes) against the oracle's host-side scans -- points bit for bit
     if runs % 20 == 0 and n >= 33:
+        tr("scan life")
         from oracle import icp_oracle as io
         ra, rb = rng.uniform(-5, 5, 3), rng.uniform(-0.2, 0.2, 3)
         qa = p[rng.permutation(n)[: max(10, n // 2)]] + rng.normal(0, 0.1, (max(10, n // 2), 3))

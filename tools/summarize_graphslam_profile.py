@@ -35,7 +35,7 @@ pmc = {"command": cmd, "kernels": {},
                "FETCH_SIZE / WRITE_SIZE in KiB (gfx950: FETCH_SIZE reads half the streamed bytes, see bench.py pmc_traffic_bytes); "
                "SQ_* / GRBM_GUI_ACTIVE as rocprofv3 reports them (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles; "
                "GRBM_GUI_ACTIVE summed over the 8 XCDs)"}
-for p in ("gs_fetch", "gs_write", "gs_sq1", "gs_sq2", "gs_tcp"):
+for p in ("gs_fetch", "gs_write", "gs_sq1", "gs_sq2", "gs_tcp", "gs_tcp2", "gs_tcp3"):
     fn = os.path.join(src, p, "p_counter_collection.csv")
     if not os.path.exists(fn):
         continue
