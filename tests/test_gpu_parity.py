@@ -1787,6 +1787,19 @@ def test_randomized_differential_run_big_clouds(gpu):
     assert " 0 mismatches" in r.stdout
 
 
+def test_randomized_differential_run_graphs(gpu):
+    """15 s of tools/fuzz_graph.py (round 4): random scan sets whose sizes mix the three search-kernel families, random
+    links, a few lum6DEuler rounds -- queued scan moves against moving every scan every round bit for bit, the first
+    round against the oracle's lum_iteration."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_graph.py"), "--seconds", "15", "--seed", "303"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert " 0 mismatches" in r.stdout
+
+
 def test_reference_side_binding_executes(gpu):
     """adapters/hip_search_tree.cc compiled against the reference's own headers and linked with lib3dtk_hip.so
     (adapters/harness/build.sh, built where the checkout exists, travels in oracle/_ref/): HipSearchTree::getPtPairs
