@@ -116,6 +116,8 @@ while time.time() - t0 < a.seconds:
         tr("icp")
         from oracle import icp_oracle as io
         nm = int(rng.choice([200, 1500, 6000]))
+        if a.big:      # the one-query-per-lane and persistent-lane kernels inside the loop, too
+            nm = int(rng.choice([6000, 90000, 250000, 600000]))
         m = rng.uniform(-60, 60, (nm, 3)); m[:, 2] *= 0.3
         Tg = io.euler_to_matrix4(rng.uniform(-0.8, 0.8, 3), rng.uniform(-0.02, 0.02, 3))
         inv, _ = orc.m4inv(Tg)
