@@ -22,7 +22,10 @@
 //
 // All fp64, no contraction: neighbour lists and normals are bit-identical to the library's.
 #include <cfloat>
+#include <cstdio>
 #include <cstring>
+#include <vector>
+#include <algorithm>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
@@ -594,6 +597,23 @@ static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) 
     if (_e != hipSuccess) { res.err = _e; return res; }  \
   } while (0)
 
+// (lab library: 256 guard bytes behind every region of the arena, as in build.hip)
+#ifdef TDTK_LAB
+constexpr size_t ANN_GUARD = 256;
+static thread_local std::vector<size_t>* g_ann_guard_sink = nullptr;
+struct AnnGuardList { uint32_t n; uint32_t pad; size_t off[60]; };
+__global__ void __launch_bounds__(64) k_ann_guard_fill(char* arena, AnnGuardList G)
+{
+  if (blockIdx.x < G.n) reinterpret_cast<uint32_t*>(arena + G.off[blockIdx.x])[threadIdx.x] = 0x5AC35AC3u ^ blockIdx.x;
+}
+__global__ void __launch_bounds__(64) k_ann_guard_check(const char* arena, AnnGuardList G, uint32_t* bad)
+{
+  if (blockIdx.x < G.n && reinterpret_cast<const uint32_t*>(arena + G.off[blockIdx.x])[threadIdx.x] != (0x5AC35AC3u ^ blockIdx.x))
+    atomicMax(bad, blockIdx.x + 1u);
+}
+#else
+constexpr size_t ANN_GUARD = 0;
+#endif
 static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
 {
   size_t scan_tmp = 0;
@@ -604,7 +624,13 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   const size_t n1 = M + 1, nlarge = M / (ANN_SMALL + 1) + 2, nsmall = M / 2 + 2;
   size_t off = 0;
   int k = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; if (O) O[k] = o; k++; return o; };
+  auto take = [&](size_t bytes) {
+    size_t o = off; off += (bytes + 255) & ~(size_t)255;
+#ifdef TDTK_LAB
+    if (g_ann_guard_sink) g_ann_guard_sink->push_back(off);
+#endif
+    off += ANN_GUARD;
+    if (O) O[k] = o; k++; return o; };
   take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1); take(8 * n1);      // 0 perm 1 segof 2 cx 3 cy 4 cz
   take(256); take(256); take(8 * n1); take(8 * n1);                          // 5, 6 spare 7 LR 8 AB
   take(4 * n1); take(4 * n1);                                                // 9 posL 10 posR
@@ -631,6 +657,18 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   size_t scan_tmp = 0;
   size_t O[32];
   (void)ann_layout(M_, O, &scan_tmp);
+#ifdef TDTK_LAB
+  AnnGuardList guards{};
+  {
+    std::vector<size_t> g;
+    g_ann_guard_sink = &g;
+    (void)ann_layout(M_, nullptr, nullptr);
+    g_ann_guard_sink = nullptr;
+    guards.n = (uint32_t)std::min<size_t>(g.size(), 60);
+    for (uint32_t k = 0; k < guards.n; k++) guards.off[k] = g[k];
+    if (guards.n) hipLaunchKernelGGL(k_ann_guard_fill, dim3(guards.n), dim3(64), 0, s, arena, guards);
+  }
+#endif
   const size_t n1 = (size_t)M + 1;
   uint32_t* perm = (uint32_t*)(arena + O[0]); uint32_t* seg_of = (uint32_t*)(arena + O[1]);
   double *cx = (double*)(arena + O[2]), *cy = (double*)(arena + O[3]), *cz = (double*)(arena + O[4]);
@@ -713,6 +751,21 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   ACHK(hipStreamSynchronize(s));
   ACHK(hipGetLastError());
   if (h_small[2]) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
+#ifdef TDTK_LAB
+  if (guards.n) {
+    uint32_t* bad = small + 40;      // (a word of `small` nothing else uses)
+    uint32_t h_bad = 0;
+    (void)hipMemsetAsync(bad, 0, 4, s);
+    hipLaunchKernelGGL(k_ann_guard_check, dim3(guards.n), dim3(64), 0, s, arena, guards, bad);
+    (void)hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    if (h_bad) {
+      fprintf(stderr, "ANN tree build: arena guard %u of %u overwritten (M = %u)\n", h_bad - 1u, guards.n, M);
+      res.err = hipErrorAssert;
+      return res;
+    }
+  }
+#endif
   res.root_ref = h_small[0];
   res.max_depth = h_small[1];
   res.levels = level;

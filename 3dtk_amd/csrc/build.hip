@@ -1911,6 +1911,32 @@ static inline int bits_for(uint64_t v)
 // number is still unknown)
 static size_t build_layout(size_t M, size_t* offs, size_t* scan_tmp_out);
 static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out);
+// Lab library: every region of the arena is followed by 256 guard bytes, filled with a pattern before a build and looked
+// at behind it -- a region written past its end (the hand-over bug of round 4: a million root records into a table of
+// 8192) fails the build it happens in, whatever it would have hit.  The product's layout has no guards.
+#ifdef TDTK_LAB
+constexpr size_t ARENA_GUARD = 256;
+static thread_local std::vector<size_t>* g_guard_sink = nullptr;      // the layout functions push the offset of every guard
+struct GuardList { uint32_t n; uint32_t pad; size_t off[250]; };
+__global__ void __launch_bounds__(64) k_guard_fill(char* arena, GuardList G)
+{
+  if (blockIdx.x < G.n) reinterpret_cast<uint32_t*>(arena + G.off[blockIdx.x])[threadIdx.x] = 0xA5C3A5C3u ^ blockIdx.x;
+}
+__global__ void __launch_bounds__(64) k_guard_check(const char* arena, GuardList G, uint32_t* bad)
+{
+  if (blockIdx.x < G.n && reinterpret_cast<const uint32_t*>(arena + G.off[blockIdx.x])[threadIdx.x] != (0xA5C3A5C3u ^ blockIdx.x))
+    atomicMax(bad, blockIdx.x + 1u);
+}
+#else
+constexpr size_t ARENA_GUARD = 0;
+#endif
+static inline void arena_guard(size_t& off)
+{
+#ifdef TDTK_LAB
+  if (g_guard_sink) g_guard_sink->push_back(off);
+#endif
+  off += ARENA_GUARD;
+}
 size_t device_build_arena_bytes(size_t M, bool with_background_chain)
 {
   const size_t base = build_layout(M, nullptr, nullptr);
@@ -1936,6 +1962,23 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   size_t scan_tmp = 0;
   size_t O[48];
   (void)build_layout(M_, O, &scan_tmp);
+#ifdef TDTK_LAB
+  GuardList guards{};
+  {
+    std::vector<size_t> g;
+    g_guard_sink = &g;
+    // (the speculative levels' regions only when the caller has them: without background streams the arena ends at the base
+    // layout -- device_build_arena_bytes(M, false))
+    const size_t base = build_layout(M_, nullptr, nullptr);
+    if (side && side->s2) (void)spec_layout(M_, base, nullptr, nullptr);
+    g_guard_sink = nullptr;
+    guards.n = (uint32_t)std::min<size_t>(g.size(), 250);
+    for (uint32_t k = 0; k < guards.n; k++) guards.off[k] = g[k];
+    if (guards.n) hipLaunchKernelGGL(k_guard_fill, dim3(guards.n), dim3(64), 0, s, arena, guards);
+    // (TDTK_GUARD_SELFTEST=1: one word behind the sixth region is overwritten on purpose -- the build must fail)
+    if (guards.n > 5 && lab_env("TDTK_GUARD_SELFTEST")) (void)hipMemsetAsync(arena + guards.off[5] + 8, 0, 4, s);
+  }
+#endif
   const size_t n1 = (size_t)M + 1;
   const size_t o_perm = O[0], o_segof = O[1], o_cx = O[2], o_cy = O[3], o_cz = O[4], o_f = O[5], o_F = O[6], o_isL = O[7],
                o_A = O[8], o_posL = O[9], o_posR = O[10], o_segA = O[11], o_segB = O[12], o_meas = O[13], o_kind = O[14],
@@ -2339,6 +2382,22 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     }
     if (h_spec_err) { res.err = hipErrorNotReady; spec_suspect = true; goto fail; }     // a cut the exact sum would have made elsewhere: in order, then
   }
+#ifdef TDTK_LAB
+  if (guards.n) {
+    uint32_t* bad = (uint32_t*)(arena + O[19]) + 40;       // (a word of `small` nothing else uses)
+    uint32_t h_bad = 0;
+    if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); }
+    (void)hipMemsetAsync(bad, 0, 4, s);
+    hipLaunchKernelGGL(k_guard_check, dim3(guards.n), dim3(64), 0, s, arena, guards, bad);
+    (void)hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    if (h_bad) {
+      fprintf(stderr, "tree build: arena guard %u of %u overwritten (M = %u): a region was written past its end\n", h_bad - 1u, guards.n, M);
+      res.err = hipErrorAssert;
+      goto fail;
+    }
+  }
+#endif
   res.nodes = f_nodes; res.node_r = f_r; res.leaf_tab = f_leaf; res.pts = pts;
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
   return res;
@@ -2375,7 +2434,7 @@ static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out)
     for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN_M / 2 && nlev < BIG_SPEC_LEVELS; level++) nlev++;
   if (getenv("TDTK_BUILD_SPEC") && getenv("TDTK_BUILD_SPEC")[0] == '0') nlev = 0;
   const size_t n1 = M + 1, nsl = 6 * (M / BIG_CH + 2), nsl1 = nsl / 3 + 3;
-  auto take = [&](size_t bytes, size_t* slot) { if (slot) *slot = off; off += (bytes + 255) & ~(size_t)255; };
+  auto take = [&](size_t bytes, size_t* slot) { if (slot) *slot = off; off += (bytes + 255) & ~(size_t)255; arena_guard(off); };
   for (int l = 0; l < nlev; l++) {
     size_t maxseg = (l < 40) ? ((size_t)1 << l) : n1;
     if (maxseg > n1) maxseg = n1;
@@ -2431,7 +2490,7 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   const size_t n1 = M + 1;
   size_t off = 0;
   int k = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; if (O) O[k] = o; k++; return o; };
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; arena_guard(off); if (O) O[k] = o; k++; return o; };
   take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1); take(8 * n1);      // perm segof cx cy cz
   take(4 * n1); take(4 * n1); take(8 * n1); take(8 * n1);                    // f F LR AB
   take(4 * n1); take(4 * n1);                                                // posL posR

@@ -745,6 +745,21 @@ def test_device_tree_of_a_lopsided_cloud_is_handed_over_late(tdtk, orc, gpu, cas
     assert kd2.verify() == [0, 0, 0, 0]
 
 
+def test_lab_library_guards_the_build_arena(tdtk, gpu, lab, monkeypatch):
+    """The lab library puts 256 guard bytes behind every region of the tree build's arena and looks at them behind the
+    build (round 4, after a table of 8192 root records had been written a million deep): an ordinary build passes, and with
+    TDTK_GUARD_SELFTEST=1 -- one guard word overwritten on purpose -- the build is refused.  (Every test that loads the
+    lab library, and tools/fuzz_parity.py under TDTK_LIB=lab, builds its trees under these guards.)"""
+    p = np.random.default_rng(3).uniform(-100, 100, (50000, 3))
+    kd = tdtk.KDtree(p, 20)
+    assert kd.verify() == [0, 0, 0, 0]
+    monkeypatch.setenv("TDTK_GUARD_SELFTEST", "1")
+    with pytest.raises(tdtk.TdtkError):
+        tdtk.KDtree(p, 20)
+    monkeypatch.delenv("TDTK_GUARD_SELFTEST")
+    assert tdtk.KDtree(p, 20).verify() == [0, 0, 0, 0]
+
+
 def test_device_tree_build_full_size(tdtk, gpu, k5):
     k, m, _ = k5
     kd = tdtk.KDtree(m, 20)
