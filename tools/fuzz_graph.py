@@ -3,7 +3,8 @@ families (lane groups < 96K, one query per lane, persistent lanes >= 256K), rand
 launch, scans read by none, links in both directions, links ending at the fixed scan), a few lum6DEuler rounds:
   * scan moves queued and carried out by the link launches (default) against every scan moved every round
     (TDTK_LAZY_MOVES=0): `ret`, poses and the final points bit for bit;
-  * the first round against the oracle's lum_iteration (numpy / C restatement): ret and poses to 1e-7.
+  * the first round against the oracle's lum_iteration (numpy / C restatement): ret and poses to 1e-7;
+  * a MetaScan tree over some of the moved scans (device to device) against the oracle's tree over the concatenated points.
 usage: python tools/fuzz_graph.py [--seconds 120] [--seed 0]"""
 import argparse
 import os
@@ -18,6 +19,7 @@ from importlib import import_module  # noqa: E402
 tdtk = import_module("3dtk_amd")
 gs = import_module("3dtk_amd.graphslam")
 from oracle import icp_oracle as io  # noqa: E402
+from oracle import orc  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
@@ -71,6 +73,16 @@ while time.time() - t0 < a.seconds:
         ret1 = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(ns, links=links), S, md2, None)
         ok_o = abs(ret1 - oret) <= 1e-7 * max(1.0, abs(oret)) and all(
             np.abs(s.get_rPos() - o.rPos).max() < 1e-6 and np.abs(s.get_rPosTheta() - o.rPosTheta).max() < 1e-8 for s, o in zip(S, O))
+        # a MetaScan tree over some of the (just moved) scans, built device to device (kdMeta.cc:34-134): neighbours in
+        # concatenation order against the oracle's tree over the concatenated points
+        members = [S[i] for i in sorted(rng.permutation(ns)[: int(rng.integers(2, ns + 1))])]
+        cat = np.concatenate([m.get_xyz_reduced() for m in members])
+        mk = tdtk.MetaScan(members).getSearchTree()
+        q = np.concatenate([cat[rng.integers(0, len(cat), 2000)] + rng.normal(0, 0.05, (2000, 3)), rng.uniform(cat.min(), cat.max(), (200, 3))])
+        gi, gd = mk.FindClosestBatch(q, md2)
+        oi, od = orc.Tree(cat, int(members[0].bucketSize)).find_closest(q, md2)
+        ok_m = np.array_equal(gi, oi) and np.array_equal(gd, od) and mk.verify() == [0, 0, 0, 0]
+        ok_o = ok_o and ok_m
         for s in S: s.release()
     except Exception as ex:   # noqa: BLE001
         ok = ok_o = False
