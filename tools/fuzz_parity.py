@@ -111,6 +111,14 @@ while time.time() - t0 < a.seconds:
             fails += 1
             np.save("gpurun_out/fuzz_fail_octree_%d.npy" % runs, p)
             print("OCTREE MISMATCH run %d n=%d voxel=%g" % (runs, n, vox), flush=True)
+        # the random modes (-O nrpts): the order of the points inside a leaf, the C library's rand() seeded alike
+        if runs % 3 == 0:
+            nrp = int(rng.choice([1, 2, 5])); sd = int(rng.integers(1, 1 << 30))
+            gq, oq = tdtk.calcReducedPoints(p, vox, nrpts=nrp, seed=sd), orc.octree_random(p, vox, nrp, seed=sd)
+            if not (gq.shape == oq.shape and np.array_equal(gq, oq)):
+                fails += 1
+                np.save("gpurun_out/fuzz_fail_octree_random_%d.npy" % runs, p)
+                print("OCTREE RANDOM MISMATCH run %d n=%d voxel=%g nrpts=%d seed=%d" % (runs, n, vox, nrp, sd), flush=True)
     # one in ten: a short ICP (well-conditioned cloud, random minimizer) against the oracle loop
     if runs % 10 == 0:
         tr("icp")
