@@ -3516,6 +3516,24 @@ static int refill_share_block(size_t n, int side_by_side)
     return 0;
   return blk;
 }
+// lab (TDTK_SINGLE_BLOCK=64): the single-pass launch in workgroups of ONE wave (a CU's sixteen waves then come from sixteen
+// distant stretches of the scan instead of eight)
+static int refill_single64(size_t n, int side_by_side)
+{
+#ifdef TDTK_LAB
+  const char* e = lab_env("TDTK_SINGLE_BLOCK");
+  if (!(e && atoi(e) == 64)) return 0;
+  if (side_by_side > 1 || (n + 255) / 256 >= (size_t)num_cu() * 4 * 7) return 0;
+  if (lab_env("TDTK_REFILL_POOL") || lab_env("TDTK_BUCKET_PTS") || lab_env("TDTK_FAT_NODES") || lab_env("TDTK_WAVE_TRACE") || lab_env("TDTK_REFILL_THRESH") ||
+      lab_env("TDTK_TWO_PER_LANE") || lab_env("TDTK_FUSE_SUMS") || lab_env("TDTK_SEARCH_VARIANT") || lab_env("TDTK_REFILL_QPW") || lab_env("TDTK_TOP_BLOCK") ||
+      lab_env("TDTK_REFILL_PHASES") || lab_env("TDTK_BALANCE") || lab_env("TDTK_SHARE_BLOCK") || lab_env("TDTK_PIPE"))
+    return 0;
+  return 64;
+#else
+  (void)n; (void)side_by_side;
+  return 0;
+#endif
+}
 // the workgroup size of the single-pass persistent-lane launch for n queries (128 unless one of the two above applies)
 static int refill_big_block(size_t n, int side_by_side)
 {
@@ -3534,7 +3552,7 @@ size_t search_max_lanes(size_t n)
     }
   }
   const size_t a = (size_t)search_grid(n) * SEARCH_BLOCK;
-  const size_t b = (size_t)refill_grid_b(n, 128, &q) * 128;
+  const size_t b = std::max((size_t)refill_grid_b(n, 128, &q) * 128, (size_t)refill_grid_b(n, 64, &q) * 64);
   const size_t c = (size_t)refill_grid_b(n, SEARCH_BLOCK, &q) * SEARCH_BLOCK;
   const size_t d = (size_t)num_cu() * 4 * 8 * WAVE;     // the work-queue kernel: at most every wave slot of the chip
   const size_t m1 = a > b ? a : b, m2 = c > d ? c : d;
@@ -3632,6 +3650,7 @@ uint32_t search_fused_rows(size_t n, int side_by_side)
   if (two_per_lane_for(n, side_by_side)) return refill2_grid(n, &q);
 #endif
   if (const int tb = refill_big_block(n, side_by_side)) return refill_grid_b(n, tb, &q, side_by_side) * (uint32_t)(tb / 128);
+  if (refill_single64(n, side_by_side)) return refill_grid_b(n, 64, &q, side_by_side);
   return refill_grid_b(n, 128, &q, side_by_side);
 }
 
@@ -3662,6 +3681,14 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   }
 #endif
 #ifdef TDTK_LAB
+  if constexpr (FUSE == 0 || FUSE == 3) {
+    if (!a.bounds && refill_single64(a.n, a.side_by_side)) {
+      const uint32_t nb64 = refill_grid_b(a.n, 64, &qpw, a.side_by_side);
+      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
+      hipLaunchKernelGGL((k_search_refill<64, 4, 16, 4, COUNT, FUSE, false>), dim3(nb64), dim3(64), 0, s, a);
+      return;
+    }
+  }
   if constexpr (FUSE == 0 || FUSE == 3) {
     if (const int sb = a.bounds ? 0 : refill_share_block(a.n, a.side_by_side)) {
       const uint32_t nbs = refill_grid_b(a.n, sb, &qpw, a.side_by_side);

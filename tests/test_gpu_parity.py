@@ -2042,7 +2042,7 @@ def test_alternative_search_kernels_agree(tdtk, orc, gpu, lab, monkeypatch):
                 {"TDTK_TOP_BLOCK": "1024"}, {"TDTK_TOP_BLOCK": "512"},
                 {"TDTK_SHARE_BLOCK": "256"}, {"TDTK_SHARE_BLOCK": "512"}, {"TDTK_SHARE_BLOCK": "1024"},
                 # ... a hand-out that does not wait for its loads; two queries per lane with one visit per trip
-                {"TDTK_PIPE": "1"}, {"TDTK_TWO_PER_LANE": "3", "TDTK_TWO_ONE": "1"}):
+                {"TDTK_PIPE": "1"}, {"TDTK_TWO_PER_LANE": "3", "TDTK_TWO_ONE": "1"}, {"TDTK_SINGLE_BLOCK": "64"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for counting in (0, 1):
