@@ -881,6 +881,17 @@ def test_lum_links_fused_into_the_search_agree(tdtk, gpu, lab, monkeypatch):
     monkeypatch.setenv("TDTK_LINK_FUSE", "0")
     one_launch_accum = blocks()                 # ... and with k_accum_multi behind the search launch
     monkeypatch.delenv("TDTK_LINK_FUSE")
+    # (round 4, lab: the same launch in workgroups of ONE wave and with the hand-out that does not wait -- one row of
+    # partial sums per wave: same pairs, same blocks to rounding)
+    for env in ({"TDTK_MULTI_BLOCK": "64"}, {"TDTK_PIPE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alt = blocks()
+        assert alt[2] == one_launch[2], env
+        for a, b in zip((one_launch[0], one_launch[1], one_launch[3]), (alt[0], alt[1], alt[3])):
+            np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-9 * np.abs(a).max())
+        for k in env:
+            monkeypatch.delenv(k)
     monkeypatch.setenv("TDTK_LINK_BATCH", "0")
     base = blocks()                             # three streams, k_accum behind every search
     monkeypatch.setenv("TDTK_FUSE_LUM", "1")
