@@ -3483,7 +3483,7 @@ static int refill_top_block(size_t n, int side_by_side)
 #ifdef TDTK_LAB
   const char* e = lab_env("TDTK_TOP_BLOCK");
   const int blk = e ? atoi(e) : 0;
-  if (blk != 512 && blk != 1024) return 0;
+  if (blk != 128 && blk != 512 && blk != 1024) return 0;      // (128: seven levels per 128-thread workgroup; TDTK_TOP_LEVELS=0 with 1024: no staging, the workgroup size alone)
   if (side_by_side > 1 || (n + 255) / 256 >= (size_t)num_cu() * 4 * 7) return 0;
   if (lab_env("TDTK_REFILL_POOL") || lab_env("TDTK_BUCKET_PTS") || lab_env("TDTK_FAT_NODES") || lab_env("TDTK_WAVE_TRACE") || lab_env("TDTK_REFILL_THRESH") ||
       lab_env("TDTK_TWO_PER_LANE") || lab_env("TDTK_FUSE_SUMS") || lab_env("TDTK_SEARCH_VARIANT") || lab_env("TDTK_REFILL_QPW"))
@@ -3674,6 +3674,10 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     if (const int tb = a.bounds ? 0 : refill_top_block(a.n, a.side_by_side)) {
       const uint32_t nbt = refill_grid_b(a.n, tb, &qpw, a.side_by_side);
       a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
+      const char* lv = lab_env("TDTK_TOP_LEVELS");
+      if (tb == 1024 && lv && lv[0] == '0') hipLaunchKernelGGL((k_search_refill<1024, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0>), dim3(nbt), dim3(1024), 0, s, a);
+      else if (tb == 128) hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 127>), dim3(nbt), dim3(128), 0, s, a);
+      else
       if (tb == 1024) hipLaunchKernelGGL((k_search_refill<1024, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 1023>), dim3(nbt), dim3(1024), 0, s, a);
       else hipLaunchKernelGGL((k_search_refill<512, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 511>), dim3(nbt), dim3(512), 0, s, a);
       return;
