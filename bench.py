@@ -877,9 +877,10 @@ def bench_graphslam(args, rank, world, local):
                           "vector_l1_busy": (pk["TCP_GATE_EN2_sum"] / 256.0 / cyc) if pk.get("TCP_GATE_EN2_sum") else None,
                           "vector_l1_clock_on": (pk["TCP_GATE_EN1_sum"] / 256.0 / cyc) if pk.get("TCP_GATE_EN1_sum") else None,
                           "vector_l1_stalled_on_pending_fills": (pk["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc) if pk.get("TCP_PENDING_STALL_CYCLES_sum") else None,
-                          "what": "SQ / TCP / TCC counters of the same launch under rocprofv3 --pmc (each pass its own run): no single "
-                                  "throughput resource is saturated -- the vector ALUs are busy less than half the time, the memory "
-                                  "side below half of HBM peak, the L1 tag pipeline the closest to its limit of one look-up per cycle"}
+                          "what": "SQ / TCP / TCC counters of the same launch under rocprofv3 --pmc (each pass its own run): the vector "
+                                  "ALUs are busy less than half the time, the memory side below half of HBM peak -- what the launch "
+                                  "saturates is each CU's vector L1 (vector_l1_busy = TCP_GATE_EN2 / (256 CUs x kernel cycles)), a "
+                                  "good part of it stalled on lines whose fill from L2 is pending"}
         out["roofline"]["bounds"] = b
     return out
 
