@@ -345,7 +345,12 @@ struct tdtk_scan {
   // behind the launch), every other entry point through scan_settle (one pass, all queued matrices in order).  A rank
   // never moves a scan none of its links reads.  The arithmetic is the one Scan::transform does point by point
   // (scan.cc:851-875), matrix after matrix: same bits as moving the scan every time.
+  // Several host threads may hold the same scan (a prefetch pool, an OpenMP host): the queue, the spare arrays and the
+  // swap are only touched under g_moves_mu; npend mirrors pending.size() so that the readers' fast path ("nothing
+  // queued") takes no lock.  A settle issued while more than one context is live waits for its kernel before it
+  // publishes npend == 0, so a reader on ANOTHER stream that finds nothing queued also finds the points moved.
   mutable std::vector<Mat4> pending;
+  mutable std::atomic<uint32_t> npend{0};
   mutable double *ax = nullptr, *ay = nullptr, *az = nullptr;
   tdtk_scan() = default;
   tdtk_scan(const tdtk_scan&) = delete;
@@ -381,9 +386,16 @@ static int scan_keep_original(Ctx* c, tdtk_scan* s)
 {
   if (!s || !s->track_original || s->ox || s->N == 0) return TDTK_OK;
   const size_t b = s->N * sizeof(double);
-  HIPCHK(handle_malloc((void**)&s->ox, b));
-  HIPCHK(handle_malloc((void**)&s->oy, b));
-  HIPCHK(handle_malloc((void**)&s->oz, b));
+  {   // all three or none (a partial set would pass the `s->ox` test above next time)
+    void* p[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++)
+      if (handle_malloc(&p[k], b) != hipSuccess) {
+        for (int j = 0; j < k; j++) pool_free(p[j]);
+        set_error("out of device memory (saved original of a scan)");
+        return TDTK_ENOMEM;
+      }
+    s->ox = static_cast<double*>(p[0]); s->oy = static_cast<double*>(p[1]); s->oz = static_cast<double*>(p[2]);
+  }
   HIPCHK(hipMemcpyAsync(s->ox, s->x, b, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s->oy, s->y, b, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s->oz, s->z, b, hipMemcpyDeviceToDevice, c->stream));
@@ -391,6 +403,7 @@ static int scan_keep_original(Ctx* c, tdtk_scan* s)
 }
 
 // ---- lazy scan moves (see tdtk_scan::pending) ---------------------------------------------------
+static std::recursive_mutex g_moves_mu;      // guards every scan's pending / npend / ax..az and the x <-> ax swap
 static bool lazy_moves()
 {
   const char* e = getenv("TDTK_LAZY_MOVES");     // 0: every queued move is carried out at once (the round-3 behaviour)
@@ -404,6 +417,12 @@ constexpr size_t LAZY_CHAIN_MAX = 32;
 // decides whether to wait (the entry points that go on to read the scan on the same stream need not).
 static int scans_settle(Ctx* c, const tdtk_scan* const* scans, int count)
 {
+  {   // fast path without the lock: nothing queued on any of them
+    bool any = false;
+    for (int i = 0; i < count && !any; i++) any = scans[i] && scans[i]->npend.load(std::memory_order_acquire) != 0;
+    if (!any) return TDTK_OK;
+  }
+  std::lock_guard<std::recursive_mutex> lk(g_moves_mu);
   size_t nmat = 0, max_n = 0;
   int nd = 0;
   for (int i = 0; i < count; i++) {
@@ -412,12 +431,16 @@ static int scans_settle(Ctx* c, const tdtk_scan* const* scans, int count)
     bool dup = false;
     for (int j = 0; j < i && !dup; j++) dup = scans[j] == sc;
     if (dup) continue;
-    if (!sc->N) { sc->pending.clear(); continue; }
+    if (!sc->N) { sc->pending.clear(); sc->npend.store(0, std::memory_order_release); continue; }
     if (sc->device != c->device) { set_error("resident scans of one call must live on one device"); return TDTK_EINVAL; }
     nmat += sc->pending.size(); nd++;
     max_n = std::max(max_n, sc->N);
   }
-  if (!nd) return TDTK_OK;
+  if (!nd) {
+    for (int i = 0; i < count; i++)
+      if (scans[i] && scans[i]->pending.empty()) scans[i]->npend.store(0, std::memory_order_release);
+    return TDTK_OK;
+  }
   const size_t o_mat = ((sizeof(XfChainDesc) * (size_t)nd + 127) / 128) * 128, bytes = o_mat + nmat * sizeof(Mat4);
   int rc = c->ws[WS_MOVES].ensure(bytes);
   if (rc) return rc;
@@ -449,19 +472,46 @@ static int scans_settle(Ctx* c, const tdtk_scan* const* scans, int count)
   HIPCHK(hipEventRecord(c->e_moves, c->stream));
   c->moves_inflight = true;
   HIPCHK(launch_transform_chain_batch(reinterpret_cast<const XfChainDesc*>(c->ws[WS_MOVES].p), nd, max_n, c->stream));
+  // other contexts (host threads with streams of their own) may read these scans next: they must not find "nothing
+  // queued" before the chain kernel has run.  A lone context orders everything on its one stream and need not wait.
+  if (g_ctx_live.load() > 1) HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < count; i++)
+    if (scans[i] && scans[i]->pending.empty()) scans[i]->npend.store(0, std::memory_order_release);
   return TDTK_OK;
 }
 static int scan_settle(Ctx* c, const tdtk_scan* s)
 {
-  if (!s || s->pending.empty()) return TDTK_OK;
+  if (!s || s->npend.load(std::memory_order_acquire) == 0) return TDTK_OK;
   return scans_settle(c, &s, 1);
+}
+// the spare coordinate arrays of a scan (tdtk_scan::ax / ay / az): all three or none -- a launch stores through all of
+// them and swaps them in, so a partial set (one allocation of the three failed) must never be left on the handle
+static int scan_ensure_spare(const tdtk_scan* sc)
+{
+  if (sc->ax && sc->ay && sc->az) return TDTK_OK;
+  const size_t b = sc->N * sizeof(double);
+  void* p[3] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < 3; k++) {
+    if (handle_malloc(&p[k], b) != hipSuccess) {
+      for (int j = 0; j < k; j++) pool_free(p[j]);
+      set_error("out of device memory (spare arrays of a moving scan)");
+      return TDTK_ENOMEM;
+    }
+  }
+  double* old[3] = {sc->ax, sc->ay, sc->az};
+  for (double* q : old)
+    if (q) pool_free(q);
+  sc->ax = static_cast<double*>(p[0]); sc->ay = static_cast<double*>(p[1]); sc->az = static_cast<double*>(p[2]);
+  return TDTK_OK;
 }
 // queue one in-place transform on a resident scan (the caller has saved "xyz reduced original" if it is tracked)
 static void scan_queue_move(tdtk_scan* s, const double* A16)
 {
   Mat4 m;
   std::memcpy(m.m, A16, sizeof m.m);
+  std::lock_guard<std::recursive_mutex> lk(g_moves_mu);
   s->pending.push_back(m);
+  s->npend.store((uint32_t)s->pending.size(), std::memory_order_release);
 }
 
 // ---- tree ------------------------------------------------------------------------------
@@ -1750,6 +1800,7 @@ int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16])
   int rc = get_ctx(s->device, &c);
   if (rc) return rc;
   if ((rc = scan_keep_original(c, s))) return rc;
+  std::unique_lock<std::recursive_mutex> lk(g_moves_mu);
   if (!s->pending.empty()) {
     // behind moves that are still queued: this one joins the queue (order is what matters)
     scan_queue_move(s, alignxf);
@@ -1759,6 +1810,7 @@ int tdtk_scan_transform(tdtk_scan* s, const double alignxf[16])
     }
     return TDTK_OK;
   }
+  lk.unlock();
   Mat4 A;
   std::memcpy(A.m, alignxf, sizeof A.m);
   HIPCHK(launch_transform(s->x, s->y, s->z, s->nx, s->ny, s->nz, s->N, A, c->stream));
@@ -1773,7 +1825,7 @@ int tdtk_scan_mark_original(tdtk_scan* s)
   if (!s) { set_error("NULL argument"); return TDTK_EINVAL; }
   (void)hipSetDevice(s->device);
   wait_deferred(s->device);   // the saved original may be in use by a move that was left running
-  if (!s->pending.empty()) {  // "original" = the points as they are now, queued moves included
+  if (s->npend.load(std::memory_order_acquire) != 0) {  // "original" = the points as they are now, queued moves included
     Ctx* c;
     int rc = get_ctx(s->device, &c);
     if (rc) return rc;
@@ -2420,12 +2472,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       tdtk_scan* sc = second[i];
       if (sc->pending.empty()) continue;
       nmat_max += sc->pending.size();
-      if (!sc->ax) {
-        const size_t b = sc->N * sizeof(double);
-        HIPCHK(handle_malloc((void**)&sc->ax, b));
-        HIPCHK(handle_malloc((void**)&sc->ay, b));
-        HIPCHK(handle_malloc((void**)&sc->az, b));
-      }
+      if ((rc = scan_ensure_spare(sc))) return rc;
     }
   }
   // one table for the whole call: per link its search and pair-sum arguments and final descriptor, per group the two
@@ -2513,6 +2560,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       tdtk_scan* sc = kv.first;
       std::swap(sc->x, sc->ax); std::swap(sc->y, sc->ay); std::swap(sc->z, sc->az);
       sc->pending.clear();
+      sc->npend.store(0, std::memory_order_release);
     }
   }
   void* staged = nullptr;
@@ -2607,10 +2655,18 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
           shifts[3 * i + k] = t->centre[0] * A16[k] + t->centre[1] * A16[4 + k] + t->centre[2] * A16[8 + k] + A16[12 + k];
       }
       HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nlinks * ACC_TOTAL * sizeof(double), s));
+      // the launch may carry out queued scan moves into the spare arrays and swap them in: until it has run no other
+      // thread may find "nothing queued" on those scans and read them on its own stream -- the lock is held to the sync
+      // (threads with nothing to settle never take it)
+      bool moving_any = false;
+      for (int i = 0; i < nlinks && !moving_any; i++) moving_any = second[i]->npend.load(std::memory_order_acquire) != 0;
+      std::unique_lock<std::recursive_mutex> lk(g_moves_mu, std::defer_lock);
+      if (moving_any) lk.lock();
       if ((rc = links_device_pass_batched(c, nlinks, first, first_dalignxf, second, maxd2, want, d_out, shifts, gb))) return rc;
       acc.assign((size_t)nlinks * ACC_TOTAL, 0.0);
       HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
+      if (moving_any) lk.unlock();
       collect_ms(c, nullptr);
       return TDTK_OK;
     }
@@ -2830,7 +2886,7 @@ static int queue_scan_moves(Ctx* c, const std::vector<tdtk_scan*>& moved)
   if (moved.empty()) return TDTK_OK;
   std::vector<const tdtk_scan*> now;
   for (tdtk_scan* sc : moved)
-    if (!lazy_moves() || sc->pending.size() >= LAZY_CHAIN_MAX) now.push_back(sc);
+    if (!lazy_moves() || sc->npend.load(std::memory_order_acquire) >= LAZY_CHAIN_MAX) now.push_back(sc);
   if (now.empty()) return TDTK_OK;
   int rc = scans_settle(c, now.data(), (int)now.size());
   if (rc) return rc;

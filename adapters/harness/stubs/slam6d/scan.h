@@ -19,6 +19,7 @@ public:
   const double* get_transMatOrg() const;
   const double* getDAlign() const;
   SearchTree* getSearchTree();
+  int getBucketSize() const;
   virtual DataPointer get(const std::string& identifier) = 0;
   template <typename T> size_t size(const std::string& identifier) { return (T(get(identifier))).size(); }
   virtual void addFrame(AlgoType type) = 0;

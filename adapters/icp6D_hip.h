@@ -33,7 +33,7 @@ struct HipIcpScanView {
   const double* getDAlign() const { return s->getDAlign(); }
   tdtk_tree* hipTree() { return static_cast<HipSearchTree*>(s->getSearchTree())->handle(); }
   tdtk_scan* hipResident() { return s->hipResident(); }
-  int hipBucket() { return static_cast<HipSearchTree*>(s->getSearchTree())->bucketSize(); }    // KDtreeMetaManaged: kdMeta.cc:45-46
+  int hipBucket() { return s->getBucketSize(); }    // KDtreeMetaManaged: kdMeta.cc:45-46 (the configured size: no tree is built to ask)
   void transformMatrixAndFrames(const double* xf, int type, int islum) { s->transformMatrixAndFrames(xf, (Scan::AlgoType)type, islum); }
   // Scan::transform moves the resident copy too (reference.patch, Scan::transformReduced)
   void mergeCoordinatesWithRoboterPosition(HipIcpScanView* prev) { s->mergeCoordinatesWithRoboterPosition(prev->s); }

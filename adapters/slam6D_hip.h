@@ -25,7 +25,7 @@ struct HipSlamScanView {
   const double* get_rPos() const { return s->get_rPos(); }
   const double* get_rPosTheta() const { return s->get_rPosTheta(); }
   size_t hipPoints() { return s->size<DataXYZ>("xyz reduced"); }
-  int hipBucket() { return static_cast<HipSearchTree*>(s->getSearchTree())->bucketSize(); }
+  int hipBucket() { return s->getBucketSize(); }   // kdMeta.cc:45-46 (no tree is built to ask)
   tdtk_tree* hipTree() { return static_cast<HipSearchTree*>(s->getSearchTree())->handle(); }
   tdtk_scan* hipResident() { return s->hipResident(); }
   tdtk_scan* hipResidentOrNull() { return s->hipResidentOrNull(); }

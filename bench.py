@@ -41,6 +41,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
 PMC_ROUND = "r04"
+PMC_ROUND_C5 = "r05"
 NUM_SIMD = 1024            # 256 CUs x 4 SIMDs
 
 
@@ -260,6 +261,50 @@ def make_graphslam_scans(nscans, npts, seed=7):
             drift_p = drift_p + rng.normal(0.0, 0.3, 3)
             drift_t = drift_t + rng.normal(0.0, math.radians(0.01))
         out.append((pos + drift_p, theta + np.array([0.0, drift_t, 0.0]), np.ascontiguousarray(loc)))
+    return out
+
+
+def make_city(rng, n):
+    """points on a ground plane and on the walls of random boxes, 4000 x 4000 footprint, y up (3DTK's frame): the world of the
+    configs[4]-shaped scans (bremen_city itself is not on the box; SURVEY 8(d) allows the substitute)"""
+    ng = n // 3
+    g = np.empty((ng, 3)); g[:, 0] = rng.uniform(-2000, 2000, ng); g[:, 1] = 0.0; g[:, 2] = rng.uniform(-2000, 2000, ng)
+    nb = 160
+    cx, cz = rng.uniform(-1900, 1900, nb), rng.uniform(-1900, 1900, nb)
+    sx, sz, h = rng.uniform(40, 160, nb), rng.uniform(40, 160, nb), rng.uniform(60, 400, nb)
+    nw = n - ng
+    b = rng.integers(0, nb, nw); face = rng.integers(0, 4, nw)
+    u, v = rng.uniform(-1, 1, nw), rng.uniform(0, 1, nw)
+    w = np.empty((nw, 3))
+    w[:, 1] = v * h[b]
+    xs = np.where(face == 0, cx[b] - sx[b], np.where(face == 1, cx[b] + sx[b], cx[b] + u * sx[b]))
+    zs = np.where(face >= 2, np.where(face == 2, cz[b] - sz[b], cz[b] + sz[b]), cz[b] + u * sz[b])
+    w[:, 0] = xs; w[:, 2] = zs
+    return np.concatenate([g, w])
+
+
+def make_c5_scans(nscans, npts, loop=13, seed=55):
+    """configs[4]'s shape (bremen_city reduced: ~10M points per scan, 13 scans): the first `nscans` of `loop` scanner poses on a
+    circle of radius 500 over a synthetic city of 3 * npts surface points; a scan = the npts points nearest to its scanner
+    (horizontal range), in the scan frame, + N(0, 0.3) noise; initial poses = truth + accumulated odometry drift.  The same
+    construction as tests/test_gpu_configs.py::test_config5_ten_million_point_scans_with_normals (which runs all 13)."""
+    rng = np.random.default_rng(seed)
+    tdtk = importlib.import_module("3dtk_amd")
+    W = make_city(rng, 3 * npts)
+    out = []
+    drift_p, drift_t = np.zeros(3), 0.0
+    for k in range(nscans):
+        ang = 2 * math.pi * k / loop
+        pos = np.array([500 * math.cos(ang), 150.0, 500 * math.sin(ang)])
+        th = np.array([0.0, -ang, 0.0])
+        d2 = (W[:, 0] - pos[0]) ** 2 + (W[:, 2] - pos[2]) ** 2
+        sel = np.argpartition(d2, npts)[:npts]
+        Ti = tdtk.M4inv(tdtk.EulerToMatrix4(pos, th))
+        R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+        loc = W[sel] @ R.T + Ti[12:15] + rng.normal(0.0, 0.3, (npts, 3))
+        if k > 0:
+            drift_p = drift_p + rng.normal(0.0, 0.4, 3); drift_t += rng.normal(0.0, 0.0004)
+        out.append((pos + drift_p, th + np.array([0.0, drift_t, 0.0]), np.ascontiguousarray(loc)))
     return out
 
 
@@ -685,6 +730,12 @@ def bench_icp(args, rank, world, local):
         out["graphslam_1gpu"]["workload"] = g1["config"]["workload"]
         out["scaling_note"] = ("N>1 runs of this script measure configs[3] (graph-SLAM, links sharded); its 1-GPU point is "
                                "graphslam_1gpu here, not `value` (configs[1], which BASELINE.json fixes to one GPU)")
+    if world == 1 and args.workload == "auto" and not args.no_c5:
+        try:
+            del model, data, tree
+        except NameError:
+            pass
+        out["c5_shape_1gpu"] = bench_c5(args, local)
     return out
 
 
@@ -802,9 +853,9 @@ def bench_graphslam(args, rank, world, local):
         counts = vc.read()
     my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
     bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
+    # (the search launch also adds up each link's 17 sums: query again + hit + the hit point, 60 B per query -- counted as 0 B by
+    # SURVEY 8(d), so NOT in bytes_per_query / achieved / frac; reported beside them in bounds.fused_sums like the ICP leg's)
     links_sums_inside = npts >= 262144
-    if links_sums_inside:   # the search launch also adds up each link's 17 sums (round 3): query again + hit + the hit point
-        bq += 60.0
     # All link passes of a rank go out in launches of up to 128 links (k_search_refill_multi); the HIP events sit around the
     # LAST launch of a step.  achieved = algorithmic bytes of that launch / its duration; beside it the aggregate over
     # the whole step (bytes of all this rank's link searches / wall time of the step, exchange, solve and pose update
@@ -862,6 +913,10 @@ def bench_graphslam(args, rank, world, local):
                              "such a launch.  This is the one configuration whose working set (64 scans and trees, 3.5 GB) exceeds "
                              "the 256 MB Infinity Cache: its fabric traffic is mostly HBM traffic, see bounds.hbm_traffic_pmc"},
     }
+    if links_sums_inside and k_ms > 0:
+        out["roofline"]["bounds"] = {"fused_sums": {"bytes_per_query": 60.0, "GBs": 60.0 * last_links * npts / (k_ms * 1e-3) / 1e9,
+                                                    "what": "what the links' sums inside the launch read on top of the search (query again 24 B, hit 4 B, "
+                                                            "hit point 32 B): 0 B by SURVEY 8(d), not in `achieved` / `frac`"}}
     if traffic is not None and k_ms > 0:
         b = {"hbm_traffic_pmc": {"bytes": traffic, "GBs": traffic / (k_ms * 1e-3) / 1e9, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "GB_per_link": traffic / max(1, last_links) / 1e9,
@@ -881,7 +936,211 @@ def bench_graphslam(args, rank, world, local):
                                   "ALUs are busy less than half the time, the memory side below half of HBM peak -- what the launch "
                                   "saturates is each CU's vector L1 (vector_l1_busy = TCP_GATE_EN2 / (256 CUs x kernel cycles)), a "
                                   "good part of it stalled on lines whose fill from L2 is pending"}
+        b.update(out["roofline"].get("bounds", {}))
         out["roofline"]["bounds"] = b
+    return out
+
+
+def c5_search_roofline(k_ms, nq, counts, comp_bytes, pk, bw, pmc_source, what):
+    """`roofline` of a search launch in the configs[4] regime (tree + points beyond the 256 MB Infinity Cache): SURVEY 8(d)'s
+    algorithmic bytes with the visit counts of the same launch, and -- the figure that IS a utilisation here -- the fabric
+    bytes of the launch from the committed counter summary against the HBM peak."""
+    c_int, c_leaf, c_pts, cq = counts
+    bq = algorithmic_bytes_per_query(c_int / max(1, cq), c_pts / max(1, cq))
+    ach = bq * nq / (k_ms * 1e-3) / 1e9
+    traffic = pmc_traffic_bytes(pk)
+    r = {"bound": "hbm", "kernel": what, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": traffic, "kernel_ms": k_ms, "bytes_per_query": bq, "queries_per_launch": nq,
+         "visits_per_query": {"internal": c_int / max(1, cq), "leaves": c_leaf / max(1, cq), "points": c_pts / max(1, cq),
+                              "counted_on": "an instrumented replay of the same launch (same traversal)"},
+         "nn_per_s_kernel_only": nq / (k_ms * 1e-3)}
+    b = {"peak_measured_copy_GBs": bw.get("hbm_copy"),
+         "compulsory_hbm": {"bytes": comp_bytes, "GBs": comp_bytes / (k_ms * 1e-3) / 1e9, "frac": comp_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "what": "every record of the tree(s) the launch walks (hot 48 B + exact 64 B per node, 32 B per point slot, "
+                                    "12 B of fp32 shadow per slot) once + every query read and its hit written once"}}
+    if traffic:
+        b["hbm_traffic_pmc"] = {"bytes": traffic, "GBs": traffic / (k_ms * 1e-3) / 1e9, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "refetch_factor": traffic / comp_bytes,
+                                "what": "2 FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, its own pass) / this run's kernel time: with a "
+                                        "working set beyond the Infinity Cache this is HBM traffic, the utilisation of the memory side"}
+    if pk:
+        if pk.get("TCC_HIT_sum") is not None and pk.get("TCC_MISS_sum") is not None:
+            b["l2_hit_rate"] = pk["TCC_HIT_sum"] / max(1.0, pk["TCC_HIT_sum"] + pk["TCC_MISS_sum"])
+        if pk.get("GRBM_GUI_ACTIVE") and pk.get("SQ_ACTIVE_INST_VALU"):
+            cyc = pk["GRBM_GUI_ACTIVE"] / 8.0
+            iss = {"valu_busy": pk["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc)}
+            if pk.get("SQ_THREAD_CYCLES_VALU"): iss["lane_efficiency"] = pk["SQ_THREAD_CYCLES_VALU"] / (pk["SQ_ACTIVE_INST_VALU"] * 64.0)
+            if pk.get("SQ_WAIT_ANY") and pk.get("SQ_WAVE_CYCLES"): iss["wave_wait_share"] = pk["SQ_WAIT_ANY"] / pk["SQ_WAVE_CYCLES"]
+            if pk.get("TCP_GATE_EN2_sum"): iss["vector_l1_busy"] = pk["TCP_GATE_EN2_sum"] / 256.0 / cyc
+            if pk.get("TCP_PENDING_STALL_CYCLES_sum"): iss["vector_l1_stalled_on_pending_fills"] = pk["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc
+            if pk.get("TCP_TCC_READ_REQ_LATENCY_sum") and pk.get("TCP_TCC_READ_REQ_sum"):
+                iss["l1_miss_latency_cycles"] = pk["TCP_TCC_READ_REQ_LATENCY_sum"] / pk["TCP_TCC_READ_REQ_sum"]
+            if pk.get("TCP_TA_TCP_STATE_READ_sum"): iss["l1_wave_instructions"] = pk["TCP_TA_TCP_STATE_READ_sum"]
+            b["issue"] = iss
+    b["source"] = pmc_source or {"file": None, "note": "no committed counter summary: `traffic` is null"}
+    r["bounds"] = b
+    return r
+
+
+def bench_c5(args, local):
+    """`c5_shape_1gpu`: the regime of BASELINE.json configs[4] (bremen_city reduced, ~10M points per scan, lum6DEuler): the one
+    workload whose trees (a 10M-point tree: 0.34 GB of point slots + 0.13 GB of shadows + 74 MB of nodes) do not fit the
+    256 MB Infinity Cache, i.e. where HBM bandwidth is a real bound.  `--c5-scans` (default 4) of the 13 scans of
+    tests/test_gpu_configs.py::test_config5_... (which checks all 13 against the oracle); per scan: upload + ordering, tree
+    build, calcNormals; one whole-scan correspondence pass (10M queries against a 10M-point tree, cold: Scan::getPtPairs),
+    ICP iterations at that size (device-resident icp6D::match, warm start from the second on), one lum6DEuler round over
+    the chain + closure links (lum6Deuler.cc:94-251 per link); the reference's TUs on the host beside it."""
+    tdtk = importlib.import_module("3dtk_amd")
+    gs = importlib.import_module("3dtk_amd.graphslam")
+    capi = importlib.import_module("3dtk_amd._capi")
+    L = tdtk.lib()
+    nscans, npts = max(2, int(args.c5_scans)), int(args.c5_points)
+    maxd2 = 100.0                                         # -d 10 (the test's value: ~8 point spacings on the surfaces)
+    tg0 = time.perf_counter(); raw = make_c5_scans(nscans, npts); t_gen = time.perf_counter() - tg0
+    capi.pool_trim()
+    tm4 = (C.c_double * 4)()
+    S, t_up, t_tree, infos = [], [], [], []
+    for (p, th, loc) in raw:
+        s = tdtk.Scan(p, th, loc, device=local)
+        t0 = time.perf_counter(); _ = s.handle; t_up.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter(); kd = s.getSearchTree(); t_tree.append((time.perf_counter() - t0) * 1e3)
+        infos.append(kd.info())
+        S.append(s)
+    info = infos[0]
+    # the tree again on a warm process (the first build of a size pays for arenas and pools)
+    warm_build = []
+    for _ in range(2):
+        t2 = tdtk.KDtree.from_scan(S[0].handle, S[0].n, 20, local); warm_build.append(t2.info()["build_ms"]); del t2
+    bw = measured_bandwidth(local)
+    pfile = PMC_ROUND_C5 + "_c5_pmc.json"
+    psrc = lambda k: ({"file": "profiles/" + pfile, "kernel": k,
+                       "what": "per-launch averages of that kernel over `python bench.py --workload c5` under rocprofv3 --pmc (tools/profile_c5.sh)"}
+                      if pmc_kernel(k, pfile) else None)
+    # what a search launch must touch at least: the tree's records + the query stream
+    slots = info.get("n_point_slots", int(npts * 1.07))
+    tree_bytes = info["n_internal"] * (64 + 48) + slots * (32 + 12)
+    out = {"scans": nscans, "points_per_scan": npts, "max_dist_match2": maxd2, "generation_s": t_gen,
+           "what": "configs[4] shape on one GPU: %d of 13 synthetic city scans x %d points (bremen_city is not on the box)" % (nscans, npts),
+           "tree": {"internal": info["n_internal"], "leaves": info["n_leaves"], "depth": info["max_depth"], "device_bytes": info["device_bytes"]},
+           "per_scan_ms": {"upload_and_ordering": {"first": t_up[0], "mean_rest": float(np.mean(t_up[1:]))},
+                           "tree_build_device": {"each": [i["build_ms"] for i in infos], "warm": min(warm_build)},
+                           "tree_create_wall": {"first": t_tree[0], "mean_rest": float(np.mean(t_tree[1:]))}}}
+    lv = info["max_depth"]
+    tb_bytes = float(lv) * npts * 64.0
+    out["tree_build_roofline"] = {"bound": "hbm", "kernel": "device tree build (level passes + subtree finisher)", "achieved": tb_bytes / (min(warm_build) * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tb_bytes / (min(warm_build) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "note": "bytes model: every level streams 24 B points + 8 B keys in and out (64 B per point and level)"}
+    # ---- one whole-scan correspondence pass, cold (Scan::getPtPairs: no warm start, sums by k_accum behind the search)
+    a, b = S[0], S[1]
+    tdtk.Scan.getPtPairs(a, b, 0, 0, maxd2)
+    walls, ks, ss = [], [], []
+    with kernel_timing():
+        for _ in range(max(2, args.c5_reps)):
+            t0 = time.perf_counter(); r = tdtk.Scan.getPtPairs(a, b, 0, 0, maxd2); walls.append((time.perf_counter() - t0) * 1e3)
+            L.tdtk_last_timings(tm4); ks.append(tm4[0]); ss.append(tm4[1])
+    with visit_counting(local) as vc:
+        rc_ = tdtk.Scan.getPtPairs(a, b, 0, 0, maxd2)
+        counts = vc.read()
+    assert rc_["n"] == r["n"] and counts[3] == npts, (rc_["n"], r["n"], counts)
+    k_ms = float(np.mean(ks)); sums_ms = float(np.mean(ss))
+    comp = tree_bytes + npts * (24 + 4)
+    kname = "k_search [whole-scan pass, 10M queries]"
+    roof = c5_search_roofline(k_ms, npts, counts, comp, pmc_kernel(kname, pfile), bw, psrc(kname),
+                              "k_search_refill (one query per lane, persistent lanes; several generations of waves at this size)")
+    out["whole_scan_pass"] = {"value": npts / (min(walls) * 1e-3), "unit": "NN correspondences/s", "ms": min(walls), "k_search_ms": k_ms,
+                              "pair_sums_ms": sums_ms, "pairs": int(r["n"]), "roofline": roof,
+                              "what": "Scan::getPtPairs of scan 1 against the tree of scan 0 from the initial (odometry) poses: search + k_accum + k_final, "
+                                      "sums in pinned memory; wall time of the call (best of %d), kernel times by HIP events (mean)" % len(walls)}
+    # ---- ICP at this size: K iterations of the resident loop (transform fused, warm start from the second iteration)
+    d_icp = tdtk.Scan(raw[1][0], raw[1][1], raw[1][2], device=local); _ = d_icp.handle
+    K = max(2, args.c5_icp_iters)
+    icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), math.sqrt(maxd2), K, quiet=True, epsilonICP=-1.0)
+    with kernel_timing():
+        t0 = time.perf_counter(); it = icp.match(a, d_icp); dt_icp = time.perf_counter() - t0
+    last = dict(icp.last)
+    d_cnt = tdtk.Scan(raw[1][0], raw[1][1], raw[1][2], device=local); _ = d_cnt.handle
+    icp_c = tdtk.icp6D(tdtk.icp6D_QUAT(True), math.sqrt(maxd2), K, quiet=True, epsilonICP=-1.0)
+    with visit_counting(local) as vc:
+        icp_c.match(a, d_cnt)
+        cnt_icp = vc.read()
+    assert icp_c.last["rms"] == last["rms"] and icp_c.last["pairs"] == last["pairs"], "counting replay diverged"
+    del d_cnt
+    ki_ms = last["nn_ms"] / (it + 1)
+    kname_i = "k_search [icp6D::match at 10M]"
+    out["icp_10M"] = {"iterations": it + 1, "ms_per_iteration": dt_icp * 1e3 / (it + 1), "value": npts * (it + 1) / dt_icp, "unit": "NN correspondences/s",
+                      "k_search_ms": ki_ms, "pair_sums_ms": last["sums_ms"] / (it + 1), "pairs_last": last["pairs"], "rms_last": last["rms"],
+                      "roofline": c5_search_roofline(ki_ms, npts, cnt_icp, comp + npts * 48, pmc_kernel(kname_i, pfile), bw, psrc(kname_i),
+                                                     "k_search_refill inside tdtk_icp_match (query transform fused, warm start)"),
+                      "what": "device-resident icp6D::match of scan 1 against scan 0, -a 1, exactly %d iterations from the odometry pose" % (it + 1)}
+    del d_icp
+    # ---- calcNormals at this size (the -z / point-to-plane leg of configs[4])
+    t_n, k_n = [], []
+    for _ in range(3):
+        t0 = time.perf_counter(); b.calcNormals(); t_n.append((time.perf_counter() - t0) * 1e3)
+        L.tdtk_last_timings(tm4); k_n.append(tm4[2])
+    with visit_counting(local) as vc:
+        b.calcNormals()
+        a_split, a_leaf, a_q = vc.read_ann()
+    kn_ms = float(np.mean(k_n[1:]))
+    bp = 24.0 + 32.0 * a_split / max(1, a_q) + 24.0 * a_leaf / max(1, a_q) + 24.0 * 10 + 24.0
+    pkn = pmc_kernel("k_ann_normals<10>", pfile)
+    out["normals"] = {"value": npts / (min(t_n) * 1e-3), "unit": "points/s", "ms": min(t_n), "kernel_ms": kn_ms, "ann_tree_build_ms": min(t_n) - kn_ms,
+                      "roofline": {"bound": "hbm", "kernel": "k_ann_normals", "achieved": bp * npts / (kn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": bp * npts / (kn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pkn), "bytes_per_point": bp,
+                                   "visits_per_point": {"split_nodes": a_split / max(1, a_q), "leaf_points": a_leaf / max(1, a_q)}},
+                      "what": "tdtk_scan_calc_normals on the resident 10M-point scan (ANN-tree build + approximate 10-NN + PCA)"}
+    # ---- one lum6DEuler round: chain links + closures (every pair of scans further apart than one step)
+    links = [(i, i + 1) for i in range(nscans - 1)] + [(i, j) for i in range(nscans) for j in range(i + 2, nscans)]
+    links = links[:max(nscans - 1, args.c5_links)] if args.c5_links else links
+    def step():
+        gr = tdtk.Graph(nscans, links=links)
+        return gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, S, maxd2, None)
+    L.tdtk_kernel_timing(1)
+    step()
+    t_round, k_round = [], []
+    for _ in range(max(1, args.c5_rounds)):
+        t0 = time.perf_counter(); ret = step(); t_round.append((time.perf_counter() - t0) * 1e3)
+        ms = C.c_double(0.0); L.tdtk_last_kernel_ms(C.byref(ms)); k_round.append(ms.value)
+    L.tdtk_kernel_timing(0)
+    with visit_counting(local) as vc:
+        step()
+        cnt_l = vc.read()
+    nl = len(links)
+    kl_ms = float(np.mean(k_round))
+    kname_l = "k_search (several links per launch)"
+    trees_walked = len({f for f, _ in links})
+    comp_l = trees_walked * tree_bytes + nl * npts * (24 + 4 + 60)
+    out["lum_round"] = {"links": nl, "ms": min(t_round), "value": nl * npts / (min(t_round) * 1e-3), "unit": "NN correspondences/s", "last_ret": ret,
+                        "link_launch_ms": kl_ms,
+                        "roofline": c5_search_roofline(kl_ms, nl * npts, cnt_l, comp_l, pmc_kernel(kname_l, pfile), bw, psrc(kname_l),
+                                                       "k_search_refill_multi (all %d link passes in one launch, each link's sums added up inside it)" % nl),
+                        "what": "one lum6DEuler iteration (-G 1) over %d links of 10M queries each (chain + closures): link launch, final, solve, pose update "
+                                "(the scan moves ride in the next round's launch)" % nl}
+    # ---- the reference on the host: its own TUs (oracle/_ref) on a stated sample
+    if not args.no_cpu:
+        from oracle import orc
+        if orc.have_ref():
+            model = a.xyz_reduced_original
+            q = b.get_xyz_reduced()
+            Ai, ok = orc.m4inv(a.dalignxf)
+            q = np.ascontiguousarray(q @ np.array([[Ai[0], Ai[4], Ai[8]], [Ai[1], Ai[5], Ai[9]], [Ai[2], Ai[6], Ai[10]]]).T + Ai[12:15]) if not np.array_equal(Ai, np.eye(4).reshape(16)) else q
+            t0 = time.perf_counter(); rt = orc.RefTree(model, 20); tb = time.perf_counter() - t0
+            threads = min(int(orc.ref().ref_host_threads()), 512)
+            ns = min(npts, 2_000_000)
+            sel = np.ascontiguousarray(q[:: max(1, npts // ns)][:ns])
+            gi, _ = a.getSearchTree().FindClosestBatch(sel[:20000], maxd2)
+            ri = rt.find_closest(sel[:20000], maxd2, threads)
+            ri = ri[0] if isinstance(ri, tuple) else ri
+            assert np.array_equal(np.asarray(ri), np.asarray(gi)), "parity spot-check against the reference's KDtreeIndexed failed"
+            t0 = time.perf_counter(); rt.find_closest(sel, maxd2, threads); tq = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": ns / tq, "unit": "NN correspondences/s", "cores": threads, "kind": "reference", "tree_build_s": tb,
+                                   "sample": "KDtreeIndexed over all %d points of scan 0 (serial constructor, %.1f s) + FindClosest of every %d-th query of "
+                                             "scan 1 (%d queries) on %d OpenMP threads; the first 20000 also checked index for index against the GPU"
+                                             % (npts, tb, max(1, npts // ns), ns, threads)}
+            del rt
+    for s in S:
+        s.release()
+    capi.pool_trim()
     return out
 
 
@@ -890,7 +1149,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: 100 (icp) / 10 (graphslam)")
     ap.add_argument("--warmup", type=int, default=None, help="default: 10 (icp) / 3 (graphslam)")
-    ap.add_argument("--workload", choices=["auto", "icp", "graphslam"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "icp", "graphslam", "c5"], default="auto")
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--scans", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -898,6 +1157,13 @@ def main():
     ap.add_argument("--no-small-scans", action="store_true", help="N=1 only: skip the doicp_small_scans leg")
     ap.add_argument("--no-rehearsal", action="store_true",
                     help="graph-SLAM at N=1: skip the one-GPU rehearsal of the sharded step (the profiles: every search dispatch is then a full step's)")
+    ap.add_argument("--no-c5", action="store_true", help="N=1 only: skip the configs[4]-shape leg (10M-point scans)")
+    ap.add_argument("--c5-scans", type=int, default=4, help="scans of the configs[4]-shape leg (of the 13 of the full-size test)")
+    ap.add_argument("--c5-points", type=int, default=10000000)
+    ap.add_argument("--c5-reps", type=int, default=4, help="whole-scan passes timed")
+    ap.add_argument("--c5-icp-iters", type=int, default=6)
+    ap.add_argument("--c5-rounds", type=int, default=3, help="lum6DEuler rounds timed")
+    ap.add_argument("--c5-links", type=int, default=0, help="0: chain + all closures among the scans")
     ap.add_argument("--no-graphslam-base", action="store_true",
                     help="N=1 only: skip the extra 1-GPU graph-SLAM measurement (the base of the N>1 curve)")
     args = ap.parse_args()
@@ -908,13 +1174,20 @@ def main():
     wl = args.workload
     if wl == "auto":
         wl = "icp" if world == 1 else "graphslam"
+    if wl == "c5" and args.steps is None:
+        args.steps, args.warmup = 1, 0
     # explicit --steps / --warmup are always honoured; the defaults depend on the workload
     # (a LUM step is ~84 whole-scan passes, an ICP step is one)
     if args.steps is None:
         args.steps = 100 if wl == "icp" else 10
     if args.warmup is None:
         args.warmup = 10 if wl == "icp" else 3
-    res = bench_icp(args, rank, world, local) if wl == "icp" else bench_graphslam(args, rank, world, local)
+    if wl == "c5":
+        if world != 1:
+            raise SystemExit("bench.py: --workload c5 is a one-GPU leg")
+        res = {"c5_shape_1gpu": bench_c5(args, local)}
+    else:
+        res = bench_icp(args, rank, world, local) if wl == "icp" else bench_graphslam(args, rank, world, local)
     if rank == 0:
         print(json.dumps(res))
     import torch.distributed as dist

@@ -389,7 +389,7 @@ int tdtk_scan_calc_normals(tdtk_scan* s, int k, const double rPos[3], double eps
  * Returns the previous setting.  (The reference has nothing of the kind: icp6D::match prints its wall time only,
  * icp6D.cc:279-283 -- tdtk_icp_result.total_ms.) */
 /* Deferred scan moves.  The batched pose update of a graph-SLAM round (tdtk_graph_solve_update / tdtk_graph_iteration,
- * tdtk_scans_transform_to_euler) returns while the move of the resident scans is still running on the device; a
+ * tdtk_scans_transform2, tdtk_lum_update_poses) returns while the move of the resident scans is still running on the device; a
  * process-wide fence makes the next library call of ANY host thread on that device wait for it before it touches a scan
  * or a tree (every entry point that takes a tree / scan / device argument, including the destroy and mark_original
  * calls).  The read-outs in this section (tdtk_kernel_timing, tdtk_last_kernel_ms, tdtk_last_timings, the visit
