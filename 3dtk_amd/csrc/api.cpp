@@ -314,6 +314,8 @@ struct tdtk_tree {
   int bucket = 0;
   TreeDev dev{};
   void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr, *d_grp = nullptr, *d_fat = nullptr;
+  void* d_q16 = nullptr;     // 16-bit shadow of the padded buckets (TreeDev::q16), 6 bytes per slot + 128 of slack
+  double q_lo[3] = {0, 0, 0}, q_scale = 0.0;
   size_t Mp = 0;   // slots of d_pts: M, or 4 * groups once the buckets are padded to whole groups (tree_pad_buckets)
   double bbmin[3], bbmax[3], centre[3];
   tdtk_tree_info info{};
@@ -323,7 +325,7 @@ struct tdtk_tree {
   ~tdtk_tree()   // also the error paths of tdtk_tree_create: nothing stays allocated on the device
   {
     (void)hipSetDevice(device);
-    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot, d_grp, d_fat};
+    void* p[] = {d_nodes, d_pts, d_leaf, d_r, d_hot, d_grp, d_fat, d_q16};
     for (void* q : p)
       if (q) pool_free(q);
   }
@@ -588,18 +590,33 @@ static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
   // The number of groups is known on the device; every bucket is padded by at most three slots, so (M + 3 leaves) / 4 groups
   // are enough room.  When that bound passes the format checks below, the fill is enqueued right away and the exact count is
   // read with it -- one look at the device less (a small scan's tree is a few dozen microseconds of launches per look).
+  // the 16-bit grid over the root box (TreeDev::q16): one cell size for the three axes, so that distances stay isotropic
+  bool want_q16 = false;
+  {
+    static const bool q_off = [] { const char* e = getenv("TDTK_BUCKET_Q16"); return e && e[0] == '0'; }();
+    double ext = 0.0;
+    for (int a = 0; a < 3; a++) ext = std::max(ext, t->bbmax[a] - t->bbmin[a]);
+    const double sc = 65535.0 / ext;
+    if (!q_off && ext > 0.0 && std::isfinite(ext) && std::isfinite(sc) && sc > 0.0) {
+      want_q16 = true;
+      for (int a = 0; a < 3; a++) t->q_lo[a] = t->bbmin[a];
+      t->q_scale = sc;
+    }
+  }
   uint32_t G = 0;
   const uint64_t G_bound = ((uint64_t)M + 3ull * t->info.n_leaves + 3ull) / 4ull;
   const bool bound_ok = (4ull * G_bound) * sizeof(KdPoint) < (1ull << 32) && (leaf || ((4ull * G_bound) << cb) <= (uint64_t)REF_VAL);
   if (bound_ok) {
     void *ptsB = nullptr, *grpB = nullptr;
     if (handle_malloc(&ptsB, 4ull * G_bound * sizeof(KdPoint)) == hipSuccess && handle_malloc(&grpB, (size_t)G_bound * 48) == hipSuccess) {
+      void* q16B = nullptr;      // (no room for it: the fp32 groups alone)
+      if (want_q16 && handle_malloc(&q16B, (size_t)G_bound * 24 + 128) != hipSuccess) { (void)hipGetLastError(); q16B = nullptr; }
       hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
-                                     static_cast<KdPoint*>(ptsB), static_cast<float4*>(grpB), c->stream);
+                                     static_cast<KdPoint*>(ptsB), static_cast<float4*>(grpB), c->stream, static_cast<uint32_t*>(q16B), t->q_lo, t->q_scale);
       if (e == hipSuccess) e = hipMemcpyAsync(c->h_pin + 140, g_at + M, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-      if (e != hipSuccess) { pool_free(ptsB); pool_free(grpB); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
+      if (e != hipSuccess) { pool_free(ptsB); pool_free(grpB); if (q16B) pool_free(q16B); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
       pool_free_later(c, t->d_pts);
-      t->d_pts = ptsB; t->d_grp = grpB;
+      t->d_pts = ptsB; t->d_grp = grpB; t->d_q16 = q16B;
       t->Mp = 0;                 // = 4 G, read in tree_finish behind its synchronisation
       return TDTK_OK;
     }
@@ -617,12 +634,14 @@ static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
   void *ptsP = nullptr, *grp = nullptr;
   if (handle_malloc(&ptsP, slots * sizeof(KdPoint)) != hipSuccess) { (void)hipGetLastError(); return TDTK_OK; }
   if (handle_malloc(&grp, (size_t)G * 48) != hipSuccess) { (void)hipGetLastError(); pool_free(ptsP); return TDTK_OK; }
+  void* q16 = nullptr;
+  if (want_q16 && handle_malloc(&q16, (size_t)G * 24 + 128) != hipSuccess) { (void)hipGetLastError(); q16 = nullptr; }
   hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
-                                 static_cast<KdPoint*>(ptsP), static_cast<float4*>(grp), c->stream);
+                                 static_cast<KdPoint*>(ptsP), static_cast<float4*>(grp), c->stream, static_cast<uint32_t*>(q16), t->q_lo, t->q_scale);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) { pool_free(ptsP); pool_free(grp); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
+  if (e != hipSuccess) { pool_free(ptsP); pool_free(grp); if (q16) pool_free(q16); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
   pool_free(t->d_pts);
-  t->d_pts = ptsP; t->d_grp = grp; t->Mp = (size_t)slots;
+  t->d_pts = ptsP; t->d_grp = grp; t->d_q16 = q16; t->Mp = (size_t)slots;
   return TDTK_OK;
 }
 
@@ -666,12 +685,15 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
   t->dev.grp = static_cast<const float4*>(t->d_grp);
+  t->dev.q16 = static_cast<const uint32_t*>(t->d_q16);
+  for (int a = 0; a < 3; a++) t->dev.q_lo[a] = t->q_lo[a];
+  t->dev.q_scale = t->q_scale;
   t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
   t->dev.node_r = static_cast<const double*>(t->d_r);
   t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
   t->info.n_points = M;
   t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + (t->d_fat ? sizeof(KdFat) : 0) + sizeof(double)) + t->Mp * sizeof(KdPoint) +
-                         (t->d_grp ? t->Mp / 4 * 48 : 0) +
+                         (t->d_grp ? t->Mp / 4 * 48 : 0) + (t->d_q16 ? t->Mp / 4 * 24 + 128 : 0) +
                          (t->d_leaf ? t->info.n_leaves * sizeof(LeafEntry) : 0);
   return TDTK_OK;
 }
@@ -2062,6 +2084,17 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
     std::sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.start < b.start; });
     std::vector<float> shadow((size_t)t->Mp * 3);
     HIPCHK(hipMemcpy(shadow.data(), t->d_grp, shadow.size() * sizeof(float), hipMemcpyDeviceToHost));
+    // the 16-bit shadow (TreeDev::q16): every slot's grid indices recomputed here with the grid the tree carries
+    std::vector<uint16_t> q16;
+    if (t->d_q16) {
+      q16.resize((size_t)t->Mp * 3);
+      HIPCHK(hipMemcpy(q16.data(), t->d_q16, q16.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    }
+    auto grid_index = [&](double v, int a) -> uint16_t {       // kernels.hip: q16_index
+      const double u = (v - t->q_lo[a]) * t->q_scale + 0.5;
+      int i = (!(u >= 0.0)) ? -32768 : ((!(u < 65536.0)) ? 32767 : (int)u - 32768);
+      return (uint16_t)(i & 0xFFFF);
+    };
     pts.reserve(t->M);
     uint32_t expect = 0;
     for (const Run& r : runs) {
@@ -2074,6 +2107,12 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
         else if (std::memcmp(&P, &L, sizeof P) != 0) group_errors++;     // a pad slot repeats the bucket's last point
         const size_t g = (r.start + j) >> 2, k = j & 3u;
         if (shadow[g * 12 + k] != (float)L.x || shadow[g * 12 + 4 + k] != (float)L.y || shadow[g * 12 + 8 + k] != (float)L.z) group_errors++;
+        if (!q16.empty()) {
+          // two slots per 12 bytes: { (x0, y0), (x1, y1), (z0, z1) } as six uint16
+          const size_t pr = (size_t)(r.start + j) >> 1, hi = (r.start + j) & 1u;
+          const uint16_t* w = &q16[pr * 6];
+          if (w[2 * hi] != grid_index(L.x, 0) || w[2 * hi + 1] != grid_index(L.y, 1) || w[4 + hi] != grid_index(L.z, 2)) group_errors++;
+        }
       }
       expect = r.start + 4 * ng;
       if (r.le) r.le->start = (int32_t)packed;

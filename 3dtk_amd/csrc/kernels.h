@@ -24,6 +24,13 @@ struct TreeDev {
   uint32_t root_ref;
   uint32_t cb, cmask;
   uint32_t n_hot;             // records in `hot` (= internal nodes)
+  // 16-bit shadow of the (padded) buckets (round 5; kernels.hip, "bucket_scan_q16"): every slot's coordinates on one grid of
+  // 65536 cells per axis over the root box, cell = largest extent / 65535, stored as int16 (grid index - 32768), two slots per
+  // 12 bytes { (x0,y0), (x1,y1), (z0,z1) }: a bucket of <= 20 points is 120 contiguous bytes = eight 16-byte loads (fifteen
+  // for the fp32 groups).  null: not built (degenerate box, TDTK_BUCKET_Q16=0).
+  const uint32_t* q16;
+  double q_lo[3];             // grid origin = the root box's lower corner
+  double q_scale;             // cells per unit
 };
 
 struct SearchArgs {
@@ -153,7 +160,8 @@ hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_
 hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, uint32_t* ng_at,
                            size_t M, hipStream_t s);
 hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, const uint32_t* g_at,
-                           const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s);
+                           const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s, uint32_t* q16 = nullptr, const double* q_lo = nullptr,
+                           double q_scale = 0.0);
 hipError_t launch_final(const double* partials, uint32_t rows, double* d_out, hipStream_t s, int ncols = ACC_TOTAL);   // columns >= ncols: +0.0
 // several batches (the link passes of a graph-SLAM round) in one launch: see k_search_refill_multi in kernels.hip
 struct FinalDesc { const double* partials; double* out; int rows, pad; };

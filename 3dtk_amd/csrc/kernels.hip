@@ -304,9 +304,13 @@ struct BoxF32 {
   float thi, tlo;     // decision thresholds for the current closest_d2; NaN: take the exact test
   float ec;           // bucket groups: sqrt(3) x the error bound of one fp32 coordinate difference (NaN like delta)
   float pthr;         // bucket groups: a shadow squared distance >= pthr proves myd2 >= closest_d2 (NaN: proves nothing)
+  // 16-bit bucket shadows (bucket_scan_q16): qs = cells per unit, rounded up (0: the tree has no such shadow); pthr16 = the
+  // squared grid distance from which a slot provably fails the reference's `<` against the current closest_d2 (inf / NaN: none)
+  float qs, pthr16;
   __device__ __forceinline__ void set_query(const double x, const double y, const double z, const float absmax)
   {
     qx = (float)x; qy = (float)y; qz = (float)z;
+    qs = 0.f;           // (the persistent-lane kernel sets it behind this call when the tree has a 16-bit shadow)
     const float qm = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
     delta = 3.0e-7f * (qm + 2.0f * absmax) + 1.0e-30f;
     // fmaxf drops a NaN operand and (float)1e39 is +inf: a query with such a component must never be decided in fp32.
@@ -337,6 +341,11 @@ struct BoxF32 {
     // (a32 >= NaN and a32 < NaN are false), which sends the visit to the exact fp64 test
     if (!(thi <= 3.0e38f)) { thi = __builtin_nanf(""); tlo = thi; }
     pthr = reject_from(r32);     // r32 >= sqrt(closest_d2) (1 - 2.5e-7): inside reject_from's margin
+    // grid distance t of a slot (in cells) >= sqrt(s) - sqrt(3) (1 + 2e-9) (both ends rounded to the nearest cell); so
+    // sqrt(s) >= r qs (1 + 1e-6) + 1.74  =>  t / scale > sqrt(closest_d2) (1 + 5e-7)  =>  the reference's fp64 d >= closest_d2.
+    // (r32 qs is within 4e-7 relative of the exact product; the 1e-6 factors cover that and the roundings here.)
+    const float w16 = r32 * qs * 1.000001f + 1.74f;
+    pthr16 = w16 * w16 * 1.000001f;
   }
 };
 
@@ -424,6 +433,13 @@ constexpr int HOT_NARROW = 0;
 
 // groups of four points a lane takes in per round trip of the bucket filter: 5 = a whole default bucket (-b 20)
 constexpr int GRP_TRIP = 5;
+// which shadow the persistent-lane kernels filter buckets with: the 16-bit grid (bucket_scan_q16, eight loads per bucket) or the
+// fp32 groups (bucket_scan_groups, fifteen); -DTDTK_BUCKET_FP32 builds the latter (the A/B of round 5)
+#ifdef TDTK_BUCKET_FP32
+constexpr bool BUCKET_Q16 = false;
+#else
+constexpr bool BUCKET_Q16 = true;
+#endif
 
 // One bucket of up to 4 * GRP_TRIP points, scanned through its fp32 shadow groups (tree_pad_buckets in api.cpp: buckets are
 // padded to whole groups of four slots, `start` is a multiple of 4).  pb = the fp64 point array, o0 = byte offset of the
@@ -489,6 +505,93 @@ __device__ __forceinline__ void bucket_scan_groups(const char* __restrict__ t_gr
     }
     if (!(thr == thr)) surv = 0xFFFFFFFFu;    // no proof available (NaN threshold): every point is tested exactly
     surv &= (count >= 32) ? 0xFFFFFFFFu : ((1u << count) - 1u);
+  }
+  while (surv) {                          // in bucket order: lowest set bit first
+    const uint32_t j = (uint32_t)__builtin_ctz(surv);
+    surv &= surv - 1u;
+    const uint32_t oj = o0 + (j << 5);
+    const double2 pxy = gload<double2>(pb, oj);
+    const double pz = gload<double>(pb, oj + 16);
+    const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pz - qz;
+    const double dj = dx * dx + dy * dy + dz * dz;
+    if (dj < best) { best = dj; bk = (int)(oj >> 5); }
+  }
+}
+
+// grid index - 32768 of one coordinate on the 16-bit grid of a tree (TreeDev::q16): round to nearest, so a coordinate inside
+// the root box is off by at most half a cell (+ 1e-10 of fp64 rounding); `out` is raised for a coordinate outside the grid
+// (a query beyond the box; NaN), which then sits on the nearest face -- see bucket_scan_q16 for what that still proves
+__device__ __forceinline__ int q16_index(const double v, const double lo, const double scale, bool& out)
+{
+  const double u = (v - lo) * scale + 0.5;
+  if (!(u >= 0.0)) { out = true; return -32768; }
+  if (!(u < 65536.0)) { out = true; return 32767; }
+  return (int)u - 32768;                     // u >= 0: truncation is floor
+}
+
+// ---- bucket_scan_q16 (round 5): the same filter on a 16-bit shadow -- eight 16-byte loads per bucket instead of fifteen.
+// Every slot's coordinates sit on ONE grid over the tree's root box (TreeDev::q16: 65536 cells per axis, cell = largest
+// extent / 65535, int16 = index - 32768, two slots per 12 bytes { (x0,y0), (x1,y1), (z0,z1) }), the query is put on the same
+// grid once (qxy, qzz; q_in: it lies inside the grid on all three axes), and a slot's squared grid distance
+//   s = sum_a sat16(P_a - Q_a)^2          (v_pk_sub_i16 clamp, v_dot2_i32_i16 clamp: 4.5 instructions per slot)
+// brackets its true distance t (in cells):  | sqrt(s) - t | <= sqrt(3) (1 + 2e-9)  when nothing saturated and q_in -- both
+// ends are rounded to the nearest cell --, and  t >= sqrt(s) - sqrt(3) (1 + 2e-9)  ALWAYS: a saturated difference is
+// smaller than the true one, and a query outside the box is further from every point of the box than its projection
+// onto it, which is what it was quantised as (exactly, on those axes).  The two proofs of bucket_scan_groups:
+//   (A) s_j >= pthr16 (BoxF32::set_radius)                   =>  d_j >= closest_d2: fails the reference's '<';
+//   (B) sqrt(s_j) > sqrt(s_k) + 2 sqrt(3) + margin, k = argmin s, q_in, s_k < 1e9 (no difference of k saturated)
+//                                                             =>  t_j > t_k: somebody else is strictly closer.
+// Survivors are tested in fp64, in bucket order, with the strict '<' (kdTreeImpl.h:351-357 restricted to who can win).
+// No proof available (radius beyond the grid, thresholds not finite): every slot of the bucket is a survivor.
+__device__ __forceinline__ void bucket_scan_q16(const char* __restrict__ t_q16, const char* __restrict__ pb, const int start, const int count,
+                                                const uint32_t o0, const BoxF32& bx, const uint32_t qxy, const uint32_t qzz, const bool q_in,
+                                                const double qx, const double qy, const double qz, double& best, int& bk)
+{
+  typedef short v2s __attribute__((ext_vector_type(2)));
+  const uint32_t go = (uint32_t)start * 6u;      // 6 bytes per slot; start is a multiple of 4: 8-byte aligned
+  uint4 W[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) W[k] = gload<uint4>(t_q16, go + 16u * (uint32_t)k);     // 128 bytes: the bucket's <= 20 slots (+ whatever follows: masked)
+  uint32_t w[32];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { w[4 * k] = W[k].x; w[4 * k + 1] = W[k].y; w[4 * k + 2] = W[k].z; w[4 * k + 3] = W[k].w; }
+  v2s q_xy, q_zz;
+  __builtin_memcpy(&q_xy, &qxy, 4); __builtin_memcpy(&q_zz, &qzz, 4);
+  int sv[20];
+#pragma unroll
+  for (int p = 0; p < 10; p++) {
+    v2s a0, a1, az;
+    __builtin_memcpy(&a0, &w[3 * p], 4); __builtin_memcpy(&a1, &w[3 * p + 1], 4); __builtin_memcpy(&az, &w[3 * p + 2], 4);
+    const v2s d0 = __builtin_elementwise_sub_sat(a0, q_xy), d1 = __builtin_elementwise_sub_sat(a1, q_xy), dz = __builtin_elementwise_sub_sat(az, q_zz);
+    uint32_t dzu;
+    __builtin_memcpy(&dzu, &dz, 4);
+    const uint32_t zlo = dzu & 0xFFFFu, zhi = dzu & 0xFFFF0000u;
+    v2s dz0, dz1;
+    __builtin_memcpy(&dz0, &zlo, 4); __builtin_memcpy(&dz1, &zhi, 4);
+    sv[2 * p] = __builtin_amdgcn_sdot2(dz, dz0, __builtin_amdgcn_sdot2(d0, d0, 0, true), true);         // saturates at INT_MAX
+    sv[2 * p + 1] = __builtin_amdgcn_sdot2(dz, dz1, __builtin_amdgcn_sdot2(d1, d1, 0, true), true);
+  }
+  // (slots past the bucket's last belong to the next bucket or to the slack behind the array: masked out of the minimum and
+  // of the survivors; pad slots of this bucket repeat its last point)
+  const uint32_t cmask20 = (count >= 32) ? 0xFFFFFFFFu : ((1u << count) - 1u);
+  int smin = 0x7FFFFFFF;
+#pragma unroll
+  for (int j = 0; j < 20; j++) smin = min(smin, (j < count) ? sv[j] : 0x7FFFFFFF);
+  unsigned surv = 0u;
+  const float sminf = (float)smin;                         // (round to nearest: 6e-8 relative, inside the 1e-6 margins)
+  if (!(sminf * 0.999999f >= bx.pthr16)) {                 // else (A) drops every slot of the bucket (a NaN / inf threshold proves nothing)
+    float thr = bx.pthr16;
+    if (q_in && smin < 1000000000) {
+      // (B): t_k <= sqrt(s_k) + 1.7321, t_j >= sqrt(s_j) - 1.7321
+      const float rub = __builtin_amdgcn_sqrtf(sminf) * 1.000001f + 3.47f;
+      thr = fminf(thr, rub * rub * 1.000001f);               // fminf skips a NaN operand: either proof alone is valid
+    }
+    if (thr < 2.0e9f) {
+      const int thr_i = (int)thr + 1;                        // s_j >= thr_i  =>  s_j >= thr: rejected on proof
+#pragma unroll
+      for (int j = 19; j >= 0; j--) surv = __builtin_amdgcn_alignbit(surv, (uint32_t)(sv[j] - thr_i), 31);   // both in [0, 2^31): the sign is [s_j < thr_i]
+    } else surv = 0xFFFFFu;                                  // no proof available: every slot is tested exactly
+    surv &= cmask20;
   }
   while (surv) {                          // in bucket order: lowest set bit first
     const uint32_t j = (uint32_t)__builtin_ctz(surv);
@@ -1699,7 +1802,26 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   // (Staged that way with registers of their own -- the stored point, the previous hit's point, a stage counter -- the
   // kernel needed 133 VGPRs, i.e. lost its fourth wave per SIMD, or spilled; the form below carries nothing extra.)
   BoxF32 bx;
-  bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f; bx.ec = 0.f; bx.pthr = 0.f;
+  bx.qx = bx.qy = bx.qz = 0.f; bx.delta = 0.f; bx.thi = 0.f; bx.tlo = 0.f; bx.ec = 0.f; bx.pthr = 0.f; bx.qs = 0.f; bx.pthr16 = 0.f;
+  // the query on the tree's 16-bit grid (bucket_scan_q16): (x, y) and (z, z) as packed int16, and whether it lies inside the grid
+  // (the single-pass kernel only: the several-links launch -- LAZY, 118-120 VGPRs with either filter, four waves per SIMD, its
+  // vector ALUs busier -- is SLOWER with it: 84 links 9.9 -> 10.8 ms, six links of 10M queries 11.6 -> 12.6; gpurun_out/r5g)
+  constexpr bool USE_Q16 = BUCKET_Q16 && !LAZY;
+  uint32_t q16xy = 0u, q16zz = 0u;
+  bool q16in = false;
+  const char* const t_q16 = USE_Q16 ? reinterpret_cast<const char*>(T.q16) : nullptr;
+  auto q16_query = [&]() {
+    if (USE_Q16 && t_q16) {
+      const SearchArgs* ap = &a;
+      asm volatile("" : "+s"(ap));      // (read where a lane takes a query, like the matrices: not hoisted, not kept live)
+      bool out = false;
+      const double sc = ap->T.q_scale;
+      const uint32_t ix = (uint32_t)q16_index(qx, ap->T.q_lo[0], sc, out) & 0xFFFFu, iy = (uint32_t)q16_index(qy, ap->T.q_lo[1], sc, out) & 0xFFFFu,
+                     iz = (uint32_t)q16_index(qz, ap->T.q_lo[2], sc, out) & 0xFFFFu;
+      q16xy = ix | (iy << 16); q16zz = iz | (iz << 16); q16in = !out;
+      bx.qs = (float)sc * 1.0000002f;    // cells per unit, rounded up
+    }
+  };
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
   unsigned c_int = 0, c_leaf = 0, c_pts = 0;
   unsigned c_t1 = 0, c_t2 = 0;   // lab, instrumented instantiations: trips of the wave through the node walk / the bucket scan
@@ -1864,6 +1986,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         qi = mine; have = true; nbk = 0;
         cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
         bx.set_query(qx, qy, qz, T.absmax);
+        q16_query();
         bx.set_radius(best);
       }
       next_q += (size_t)__popcll(idlem);
@@ -2111,6 +2234,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           bk = -1;
           cur = T.root_ref;
           bx.set_query(qx, qy, qz, T.absmax);
+          q16_query();
           bx.set_radius(best);
         }
       }
@@ -2133,7 +2257,12 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       const char* pb = reinterpret_cast<const char*>(pts);
       const uint32_t o0 = (uint32_t)start << 5;              // byte offset of the bucket (< 4 GB)
       const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
-      if ((PROBE == 0 || PROBE == 3) && t_grp != nullptr && count <= 4 * GRP_TRIP) {
+      // (one filter per build: with both in the kernel the register allocation is the fp32 one plus the grid query -- 130 VGPRs,
+      // three waves per SIMD; a tree without the filter this build uses -- degenerate box, no memory -- takes the fp64 loop)
+      if (USE_Q16 && (PROBE == 0 || PROBE == 3) && t_q16 != nullptr && count <= 20) {
+        bucket_scan_q16(t_q16, pb, start, count, o0, bx, q16xy, q16zz, q16in, qx, qy, qz, best, bk);
+      } else
+      if (!USE_Q16 && (PROBE == 0 || PROBE == 3) && t_grp != nullptr && count <= 4 * GRP_TRIP) {
         bucket_scan_groups(t_grp, pb, start, count, o0, bx, qx, qy, qz, best, bk);
       } else
       // PTS points per round trip, all their loads issued before the first use; the last group re-reads the final point
@@ -3427,6 +3556,7 @@ uint32_t search_grid(size_t n)
 // of a graph-SLAM round).  The chip is then filled by the passes together, and fewer, longer-lived waves per pass win:
 // 84 link passes of 1M queries on 3 streams, slab 224 -> 13.6 ms, 256 -> 13.1, 320 -> 12.7, 384 -> 12.75, 448 -> 12.8,
 // 512 -> 13.0, 640 -> 13.4 (tools/gs_knobs_probe.py) -- ~3 waves per SIMD and pass.
+static int refill_waves_per_simd();      // (defined behind the kernel it asks about)
 static int refill_qpw(size_t n, int side_by_side = 1)
 {
   if (const char* e = lab_env("TDTK_REFILL_QPW")) {
@@ -3442,10 +3572,15 @@ static int refill_qpw(size_t n, int side_by_side = 1)
     if (q > 512) q = 512;
     return (int)q;
   }
-  // (round 3: the kernel holds a whole bucket's shadow groups in registers, 122 of them: four waves per SIMD are what
-  // fits, so the launch is sized for exactly that -- one resident generation, no straggling second one)
-  size_t q = (n + (size_t)num_cu() * 16 - 1) / ((size_t)num_cu() * 16);   // 4 waves per SIMD
-  q = (q + 31) & ~(size_t)31;
+  // One resident generation, no straggling second one: the launch is sized for exactly the waves the chip holds of THIS
+  // kernel.  Round 3 (fp32 bucket groups, 122 VGPRs): four per SIMD.  Round 5 (16-bit bucket shadows, 94 VGPRs): five --
+  // asked of the runtime, not assumed (refill_waves_per_simd) -- and the slab a multiple of 8, not of 32: 1M queries =
+  // 5000 waves of 200 (k_search 0.1990 -> 0.1791 ms at the driver's arguments, 0.1777 -> 0.1624 over 100 iterations; with
+  // 4465 waves of 224 or 5209 of 192 the fifth wave of some SIMDs or a second generation costs more than it brings:
+  // 0.1876 / 0.2238; gpurun_out/r5f)
+  const size_t slots = (size_t)num_cu() * 4 * (size_t)refill_waves_per_simd();
+  size_t q = (n + slots - 1) / slots;
+  q = (q + 7) & ~(size_t)7;
   if (q < 128) q = 128;
   if (q > 256) q = 256;
   return (int)q;
@@ -3665,6 +3800,21 @@ static bool pipe_on()
   return false;
 }
 #endif
+// waves of the single-pass persistent-lane kernel (the FUSE 3 instantiation the ICP loop runs) a SIMD holds at once, by the
+// runtime's own occupancy calculation for this code object (registers, LDS); 4 if it cannot say
+static int refill_waves_per_simd()
+{
+  static const int w = [] {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(&k_search_refill<128, 4, 16, 1, false, 3, false>), 128, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return 4;
+    }
+    const int v = blocks * 2 / 4;          // 128-thread workgroups = two waves; four SIMDs per CU
+    return v < 1 ? 4 : (v > 8 ? 8 : v);
+  }();
+  return w;
+}
 template <bool COUNT, int FUSE>
 static void launch_refill128(SearchArgs& a, hipStream_t s)
 {
@@ -4064,9 +4214,10 @@ __global__ void __launch_bounds__(256) k_pad_mark(const KdNode* __restrict__ nod
   else { start = v >> cb; count = v & cmask; }
   ng_at[start] = (count + 3u) >> 2;
 }
+struct Q16Grid { double lo[3]; double scale; };
 __global__ void __launch_bounds__(256) k_pad_fill(KdNode* __restrict__ nodes, size_t n, LeafEntry* __restrict__ leaf_tab, uint32_t cb,
                                                   uint32_t cmask, const uint32_t* __restrict__ g_at, const KdPoint* __restrict__ pts,
-                                                  KdPoint* __restrict__ ptsP, float4* __restrict__ grp)
+                                                  KdPoint* __restrict__ ptsP, float4* __restrict__ grp, uint32_t* __restrict__ q16, const Q16Grid qg)
 {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= 2 * n) return;
@@ -4090,6 +4241,20 @@ __global__ void __launch_bounds__(256) k_pad_fill(KdNode* __restrict__ nodes, si
     grp[(size_t)3 * (g0 + k) + 0] = make_float4(fx[0], fx[1], fx[2], fx[3]);
     grp[(size_t)3 * (g0 + k) + 1] = make_float4(fy[0], fy[1], fy[2], fy[3]);
     grp[(size_t)3 * (g0 + k) + 2] = make_float4(fz[0], fz[1], fz[2], fz[3]);
+    if (q16) {
+      uint32_t ix[4], iy[4], iz[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const KdPoint P = ptsP[(size_t)4 * (g0 + k) + j];
+        bool out = false;     // (a point of the tree is inside its root box)
+        ix[j] = (uint32_t)q16_index(P.x, qg.lo[0], qg.scale, out) & 0xFFFFu;
+        iy[j] = (uint32_t)q16_index(P.y, qg.lo[1], qg.scale, out) & 0xFFFFu;
+        iz[j] = (uint32_t)q16_index(P.z, qg.lo[2], qg.scale, out) & 0xFFFFu;
+      }
+      uint32_t* w = q16 + (size_t)6 * (g0 + k);
+      w[0] = ix[0] | (iy[0] << 16); w[1] = ix[1] | (iy[1] << 16); w[2] = iz[0] | (iz[1] << 16);
+      w[3] = ix[2] | (iy[2] << 16); w[4] = ix[3] | (iy[3] << 16); w[5] = iz[2] | (iz[3] << 16);
+    }
   }
   if (leaf_tab) leaf_tab[v].start = (int32_t)(4u * g0);
   else {
@@ -4108,10 +4273,12 @@ hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEnt
 }
 // pass 2 (after an exclusive scan of ng_at into g_at): padded points, shadow groups, rewritten references
 hipError_t launch_pad_fill(KdNode* nodes, size_t n_internal, LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, const uint32_t* g_at,
-                           const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s)
+                           const KdPoint* pts, KdPoint* ptsP, float4* grp, hipStream_t s, uint32_t* q16, const double* q_lo, double q_scale)
 {
+  Q16Grid qg{};
+  if (q16 && q_lo) { qg.lo[0] = q_lo[0]; qg.lo[1] = q_lo[1]; qg.lo[2] = q_lo[2]; qg.scale = q_scale; }
   hipLaunchKernelGGL(k_pad_fill, dim3((uint32_t)((2 * n_internal + 255) / 256)), dim3(256), 0, s, nodes, n_internal, leaf_tab, cb, cmask, g_at, pts,
-                     ptsP, grp);
+                     ptsP, grp, (q16 && q_lo) ? q16 : nullptr, qg);
   return hipGetLastError();
 }
 

@@ -112,6 +112,47 @@ def test_box_shortcut_gives_way_outside_float_range(tdtk, orc, gpu, nq):
         assert kd.count_visits(q, md2) == T.find_closest(q, md2, 8, True)[2], md2
 
 
+@pytest.mark.parametrize("case", ["one_cell", "outside", "lattice", "flat"])
+def test_sixteen_bit_bucket_shadows_only_reject_on_proof(tdtk, orc, gpu, case):
+    """Round 5: the persistent-lane kernel filters buckets on a 16-bit shadow (kernels.hip, bucket_scan_q16: ONE grid of
+    65536 cells per axis over the root box).  Clouds on which that grid says little or nothing -- a cluster a million times
+    smaller than the box (every point of it in one cell), queries far outside the box (quantised onto its faces: only the
+    lower bound of a distance survives that), points exactly on cell boundaries with exact ties, a cloud with no extent along
+    one axis -- must come out index for index and bit for bit like the oracle's, visit counters included; 300K queries =
+    the persistent-lane kernel."""
+    rng = np.random.default_rng({"one_cell": 1, "outside": 2, "lattice": 3, "flat": 4}[case])
+    nq = 300000
+    if case == "one_cell":
+        m = np.concatenate([rng.uniform(-5e-4, 5e-4, (120000, 3)) + [3.0, -2.0, 1.0], rng.uniform(-1e3, 1e3, (400, 3))])
+        m[1000:1200] = m[0:200]
+        q = m[rng.integers(0, 120000, nq)] + rng.normal(0, 2e-5, (nq, 3))
+        radii = (1e-8, 1e-4, 1e12)
+    elif case == "outside":
+        m = rng.uniform(-100, 100, (100000, 3))
+        q = rng.uniform(-100, 100, (nq, 3))
+        far = rng.integers(0, nq, nq // 2)
+        q[far, rng.integers(0, 3, len(far))] += rng.choice([-1.0, 1.0], len(far)) * rng.uniform(150, 1e5, len(far))
+        radii = (400.0, 1e8, 1e30)
+    elif case == "lattice":
+        g = np.arange(40, dtype=np.float64)
+        m = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * (65535.0 / 39.0 / 65535.0 * 39.0)   # 64000 points, unit lattice
+        m = np.concatenate([m, m[:5000]])                       # + exact duplicates
+        q = m[rng.integers(0, len(m), nq)] + rng.choice([0.0, 0.5, -0.5, 0.25], (nq, 3))      # ties between lattice neighbours
+        radii = (0.2, 1.0, 1e6)
+    else:
+        m = rng.uniform(-50, 50, (90000, 3)); m[:, 1] = 7.0     # no extent along y
+        q = m[rng.integers(0, len(m), nq)] + rng.normal(0, 0.3, (nq, 3))
+        radii = (0.05, 9.0, 1e20)
+    kd, T = tdtk.KDtree(m, 20), orc.Tree(m, 20)
+    assert kd.verify() == [0, 0, 0, 0]
+    for md2 in radii:
+        idx, d2 = kd.FindClosestBatch(q, md2)
+        oi, od2 = T.find_closest(q, md2, 8)
+        assert np.array_equal(idx, oi), (case, md2, int((idx != oi).sum()))
+        assert np.array_equal(d2, od2), (case, md2)
+        assert kd.count_visits(q, md2) == T.find_closest(q, md2, 8, True)[2], (case, md2)
+
+
 @pytest.mark.parametrize("nq", [20000, 300000])
 @pytest.mark.parametrize("offset", [1.0e6, 1.0e8, 1.0e9])
 def test_fp32_shortcuts_on_clouds_far_from_the_origin(tdtk, orc, gpu, nq, offset):
