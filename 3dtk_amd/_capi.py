@@ -62,13 +62,14 @@ EXPORTS = [
     "tdtk_last_error", "tdtk_device_count", "tdtk_pool_trim", "tdtk_build_respeculated", "tdtk_version", "tdtk_tree_create", "tdtk_tree_create_from_scan", "tdtk_tree_create_from_scans", "tdtk_scan_mark_original", "tdtk_scan_download_original", "tdtk_tree_destroy",
     "tdtk_tree_get_info", "tdtk_tree_verify", "tdtk_find_closest", "tdtk_find_closest_dev", "tdtk_find_closest_along_dir",
     "tdtk_get_pt_pairs", "tdtk_scan_create", "tdtk_scan_destroy", "tdtk_scan_size",
-    "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match",
+    "tdtk_scan_transform", "tdtk_scan_download", "tdtk_scan_pairs", "tdtk_align", "tdtk_icp_match", "tdtk_icp_match_rnd",
     "tdtk_lum_link", "tdtk_lum_links", "tdtk_links_pair_sums", "tdtk_lum_update_poses", "tdtk_lum_assemble_solve", "tdtk_point_point_error",
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_reduce_octree_nrpts", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_comm_rccl_world", "tdtk_graph_exchange", "tdtk_graph_deal_links",
     "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge",
     "tdtk_last_timings", "tdtk_kernel_timing", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
+    "tdtk_icp_index_hashes", "tdtk_icp_last_hashes",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
     "tdtk_host_euler_to_matrix4", "tdtk_host_matrix4_to_euler", "tdtk_host_quat_to_matrix4", "tdtk_host_matrix4_to_quat",
     "tdtk_io_read_uos", "tdtk_io_free", "tdtk_io_read_pose", "tdtk_io_write_frames",
@@ -160,6 +161,8 @@ def lib():
     L.tdtk_align.argtypes = [C.c_int, C.POINTER(PairSums), _dp, _dp]
     L.tdtk_icp_match.argtypes = [C.c_void_p, _dp, C.c_void_p, _dp, _dp, C.POINTER(IcpParams),
                                  C.POINTER(IcpResult), _dp, C.c_int]
+    L.tdtk_icp_match_rnd.argtypes = [C.c_void_p, _dp, C.c_void_p, _dp, _dp, C.POINTER(IcpParams), C.c_int,
+                                     C.POINTER(IcpResult), _dp, C.c_int]
     L.tdtk_lum_link.argtypes = [C.c_void_p, _dp, C.c_void_p, C.c_double, _dp, _dp, _u64p, _dp]
     L.tdtk_lum_links.argtypes = [C.c_int, C.POINTER(C.c_void_p), _dp, C.POINTER(C.c_void_p), C.c_double, _dp,
                                  _dp, _u64p, _dp]
@@ -189,6 +192,8 @@ def lib():
     L.tdtk_visit_counting.argtypes = [C.c_int, C.c_int]
     L.tdtk_visit_counters.argtypes = [C.c_int, _u64p]
     L.tdtk_measure_bandwidth.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_int, _dp]
+    L.tdtk_icp_index_hashes.argtypes = [C.c_int]
+    L.tdtk_icp_last_hashes.argtypes = [_u64p, C.c_int, C.POINTER(C.c_int)]
     L.tdtk_host_tree_layout.argtypes = [_dp, C.c_size_t, C.c_int, _ip, _u64p]
     L.tdtk_host_m4inv.argtypes = [_dp, _dp]
     L.tdtk_host_mmult.argtypes = [_dp, _dp, _dp]

@@ -128,6 +128,10 @@ struct Ctx {
   void* h_build = nullptr;  // 64 KB, pinned: the tree build's looks at the device (BuildSide::h_pin)
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
   size_t h_stage_cap = 0;
+  DevBuf d_mask, d_skip;                // -R passes: the keep-mask (bits, caller order) and what the search reads (bytes, sorted order)
+  std::vector<unsigned char> h_mask;
+  DevBuf d_hash;                        // tdtk_icp_index_hashes: one 64-bit word per iteration of the last tdtk_icp_match
+  std::vector<uint64_t> last_hashes;
   void* h_moves = nullptr;  // pinned staging of scans_settle's table (its own: a settle may precede a batched launch in one call)
   size_t h_moves_cap = 0;
   hipEvent_t e_moves = nullptr;   // behind the last copy out of h_moves
@@ -1108,7 +1112,7 @@ static hipError_t await_sums(const double* h_pin, hipStream_t s)
 // search + accumulate over a resident scan.  acc_out (host, ACC_TOTAL) receives raw columns.
 static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, int pmode,
                      double maxd2, unsigned want, const double* lum_D, const double* pending,
-                     bool do_search, double* acc_out, double shift_out[3], bool warm = false)
+                     bool do_search, double* acc_out, double shift_out[3], bool warm = false, const unsigned char* skip = nullptr)
 {
   hipStream_t s = c->stream;
   const size_t N = data->N;
@@ -1139,6 +1143,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.inv = inv; sa.has_inv = 1;
     sa.maxd2 = maxd2;
     sa.kpos = c->ws[WS_KPOS].as<int>();
+    sa.skip = skip;
     sa.warm = (warm && pmode != 1) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
     {
       // ... and WS_COST how many buckets each of its queries visited then: the persistent-lane kernel hands a wave's slab
@@ -2217,9 +2222,70 @@ int tdtk_solve_spd(const double* G, const double* B, int n, double* x)
 }
 
 // ---- icp6D::match -----------------------------------------------------------------------------
+// Diagnostics (off by default): while on, every pass of tdtk_icp_match also hashes its correspondences on the device (k_idx_hash:
+// the K5 hash of SURVEY 8(c) over the caller-order index array) -- the loop's indices can then be compared with a CPU run of the reference's search
+// iteration by iteration at sizes where downloading a million indices per iteration is not an option.
+static std::atomic<int> g_icp_hashes{0};
+constexpr int ICP_HASH_CAP = 1024;
+int tdtk_icp_index_hashes(int on)
+{
+  return g_icp_hashes.exchange(on ? 1 : 0);
+}
+int tdtk_icp_last_hashes(uint64_t* out, int cap, int* n_out)
+{
+  if (!n_out || (cap > 0 && !out) || cap < 0) { set_error("bad argument"); return TDTK_EINVAL; }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("no device"); return TDTK_EDEVICE; }
+  Ctx* c;
+  int rc = get_ctx(dev, &c, false);
+  if (rc) return rc;
+  const int n = (int)std::min<size_t>(c->last_hashes.size(), (size_t)cap);
+  for (int i = 0; i < n; i++) out[i] = c->last_hashes[(size_t)i];
+  *n_out = (int)c->last_hashes.size();
+  return TDTK_OK;
+}
+
+// One -R pass's keep-mask (searchTree.cc:116-118: `if (rnd > 1 && rand(rnd) != 0) continue;` for i = 0 .. N-1): one std::rand()
+// per point in the caller's index order, drawn here, now -- never ahead of the pass that uses it, so the process's random
+// stream is consumed exactly as a serial build of the reference consumes it (SURVEY N-d) -- and sent as N / 8 bytes; a
+// small kernel turns it into one byte per query at its sorted position, which the search kernels read (SearchArgs::skip).
+static int draw_keep_mask(Ctx* c, const tdtk_scan* data, int rnd, const unsigned char** skip_out)
+{
+  const size_t N = data->N, nbytes = (N + 7) / 8;
+  int rc;
+  if ((rc = c->d_mask.ensure(nbytes + 16)) || (rc = c->d_skip.ensure(N + 16))) return rc;
+  c->h_mask.assign(nbytes, 0);
+  for (size_t i = 0; i < N; i++) {
+    const int r = (int)((double)rnd * (double)std::rand() / (RAND_MAX + 1.0));     // globals.icc:607-610
+    if (r == 0) c->h_mask[i >> 3] |= (unsigned char)(1u << (i & 7u));
+  }
+  void* staged = nullptr;
+  // (the staging buffer is reused by the next pass's mask: the copy below has been consumed by then -- every pass ends with a wait)
+  if ((rc = stage_pinned(c, c->h_mask.data(), nbytes, &staged))) return rc;
+  HIPCHK(hipMemcpyAsync(c->d_mask.p, staged, nbytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(launch_skip_from_mask(c->d_mask.as<unsigned char>(), data->d_order, N, c->d_skip.as<unsigned char>(), c->stream));
+  *skip_out = c->d_skip.as<unsigned char>();
+  return TDTK_OK;
+}
+
+static int icp_match_impl(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
+                          double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm, int rnd,
+                          tdtk_icp_result* res, double* trace, int trace_cap);
 int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
                    double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm,
                    tdtk_icp_result* res, double* trace, int trace_cap)
+{
+  return icp_match_impl(model, model_dalignxf, data, data_transMat, data_dalignxf, prm, 1, res, trace, trace_cap);
+}
+int tdtk_icp_match_rnd(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
+                       double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm, int rnd,
+                       tdtk_icp_result* res, double* trace, int trace_cap)
+{
+  return icp_match_impl(model, model_dalignxf, data, data_transMat, data_dalignxf, prm, rnd, res, trace, trace_cap);
+}
+static int icp_match_impl(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
+                          double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm, int rnd,
+                          tdtk_icp_result* res, double* trace, int trace_cap)
 {
   if (!model || !model_dalignxf || !data || !prm || !res) { set_error("NULL argument"); return TDTK_EINVAL; }
   if (prm->max_dist_match2 < 0.0 || prm->max_num_iterations < 0) {
@@ -2258,15 +2324,29 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
   int converged = 0;
   const char* warm_env = lab_env("TDTK_WARM_START");
   const bool warm_ok = !(warm_env && warm_env[0] == '0');
+  const bool hashing = g_icp_hashes.load(std::memory_order_relaxed) != 0;
+  c->last_hashes.clear();
+  if (hashing) {
+    if ((rc = c->d_hash.ensure(ICP_HASH_CAP * sizeof(unsigned long long)))) return rc;
+    HIPCHK(hipMemsetAsync(c->d_hash.p, 0, ICP_HASH_CAP * sizeof(unsigned long long), c->stream));
+  }
   for (iter = 0; iter < prm->max_num_iterations; iter++) {
     prev_prev_ret = prev_ret;
     prev_ret = ret;
     double acc[ACC_TOTAL], shift[3];
+    // -R: this pass's candidates (drawn now, in the reference's order)
+    const unsigned char* skip = nullptr;
+    if (rnd > 1 && (rc = draw_keep_mask(c, data, rnd, &skip))) return rc;
     // the previous iteration's alignxf is applied to the points inside the search kernel
+    // (the warm start stays exact under -R: WS_KPOS holds -1 for whoever was not drawn last time -- a cold start --, and for
+    // the others a point of THIS tree, whose distance bounds the nearest neighbour's however the scan has moved since)
     rc = scan_pass(c, model, model_dalignxf, data, pmode, prm->max_dist_match2, want, nullptr,
-                   have_pending ? pend : nullptr, true, acc, shift, iter > 0 && warm_ok);
+                   have_pending ? pend : nullptr, true, acc, shift, iter > 0 && warm_ok, skip);
     if (rc) return rc;
     have_pending = false;
+    if (hashing && iter < ICP_HASH_CAP)    // this pass's correspondences are still in the workspace (sorted positions)
+      HIPCHK(launch_idx_hash(c->ws[WS_KPOS].as<int>(), data->d_order, model->dev.pts, data->N,
+                             c->d_hash.as<unsigned long long>() + iter, c->stream));
     double ms = 0, sms = 0;
     collect_ms(c, &ms, &sms);
     nn_total += ms;
@@ -2316,6 +2396,12 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
     Mat4 P;
     std::memcpy(P.m, pend, sizeof P.m);
     HIPCHK(launch_transform(data->x, data->y, data->z, data->nx, data->ny, data->nz, data->N, P, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if (hashing) {
+    const int passes = std::min(ICP_HASH_CAP, std::min(iter + 1, prm->max_num_iterations));
+    c->last_hashes.assign((size_t)passes, 0);
+    HIPCHK(hipMemcpyAsync(c->last_hashes.data(), c->d_hash.p, (size_t)passes * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   res->iterations = iter;

@@ -83,6 +83,9 @@ struct SearchArgs {
   const double *sx, *sy, *sz;
   const Mat4* moves;
   int nmoves;        // <= SEARCH_LAZY_MAX
+  // -R (rnd > 1, searchTree.cc:118): one byte per query in sorted order, non-zero = "not drawn this pass": the point still moves
+  // (has_pending) but is no candidate -- kpos = -1, no search.  nullptr: every query is a candidate.
+  const unsigned char* skip;
 };
 
 // internal bit beside the public TDTK_WANT_* ones: no centroid / cross-covariance columns (see k_accum)
@@ -183,6 +186,9 @@ hipError_t launch_transform(double* x, double* y, double* z, double* nx, double*
                             size_t n, const Mat4& A, hipStream_t s);
 hipError_t launch_bin(const BinArgs& b, hipStream_t s);
 hipError_t launch_split_soa(const double* q, size_t n, double* x, double* y, double* z, hipStream_t s);
+// keep-mask of an -R pass, one bit per query in the CALLER's order (bit set = drawn) -> one byte per query in sorted order (1 = skip)
+hipError_t launch_skip_from_mask(const unsigned char* mask_bits, const int32_t* order, size_t n, unsigned char* skip, hipStream_t s);
+hipError_t launch_idx_hash(const int* kpos, const int32_t* order, const KdPoint* pts, size_t n, unsigned long long* out, hipStream_t s);
 hipError_t launch_scatter_idx(const int* kpos, const double* d2s, const int32_t* order,
                               const KdPoint* pts, size_t n, int32_t* idx_out, double* d2_out,
                               hipStream_t s);

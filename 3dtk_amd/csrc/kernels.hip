@@ -1077,6 +1077,11 @@ __device__ __forceinline__ void search_plain_body(const SearchArgs& a, const uin
         a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
       }
     }
+    if (a.skip && a.skip[i]) {      // -R: not drawn this pass (searchTree.cc:118) -- moved above, not searched
+      a.kpos[i] = -1;
+      if (a.d2) a.d2[i] = a.maxd2;
+      continue;
+    }
     double sx = tx, sy = ty, sz = tz;
     if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, sx, sy, sz);  // searchTree.cc:122
     if (DIRMODE) {
@@ -1174,6 +1179,10 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
         dev_xf3normal(a.pending, px, py, pz);
         a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
       }
+    }
+    if (a.skip && a.skip[i]) {      // -R: not drawn this pass (searchTree.cc:118); the whole lane group leaves together
+      if (sub == 0) { a.kpos[i] = -1; if (a.d2) a.d2[i] = a.maxd2; }
+      continue;
     }
     double qx = tx, qy = ty, qz = tz;
     if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
@@ -1981,6 +1990,12 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
             a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz;
           }
         }
+        if (a.skip && a.skip[mine]) {
+          // -R: not drawn this pass (searchTree.cc:118): the point has moved, it is no candidate; the lane stays idle
+          gstore<int>(reinterpret_cast<char*>(a_kpos), (uint32_t)mine << 2, -1);
+          if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), m8, a.maxd2);
+          if (ORDER && a_cost) a_cost[mine] = 0;
+        } else {
         qx = tx; qy = ty; qz = tz;
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
         qi = mine; have = true; nbk = 0;
@@ -1988,6 +2003,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         bx.set_query(qx, qy, qz, T.absmax);
         q16_query();
         bx.set_radius(best);
+        }
       }
       next_q += (size_t)__popcll(idlem);
     }
@@ -3449,6 +3465,38 @@ __global__ void k_scatter_idx(const int* __restrict__ kpos, const double* __rest
   }
 }
 
+// -R (rnd > 1): the host draws one std::rand() per query in the caller's index order (the reference's loop, searchTree.cc:116-118)
+// and sends the keep-mask as bits; a search reads one byte per query at its sorted position.
+__global__ void __launch_bounds__(256) k_skip_from_mask(const unsigned char* __restrict__ mask_bits, const int32_t* __restrict__ order, size_t n,
+                                                        unsigned char* __restrict__ skip)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const size_t i = order ? (size_t)order[j] : j;
+    skip[j] = ((mask_bits[i >> 3] >> (i & 7u)) & 1u) ? 0 : 1;
+  }
+}
+
+// The K5 hash of SURVEY 8(c) over one pass's correspondences, computed where they are (tdtk_icp_index_hashes):
+// h = XOR over the found queries of (model index x 1315423911 + query index), both in the CALLER's numbering -- the hash the tests
+// compute on the host for the index array tdtk_find_closest would have returned.  XOR commutes: any order.
+__global__ void __launch_bounds__(256) k_idx_hash(const int* __restrict__ kpos, const int32_t* __restrict__ order, const KdPoint* __restrict__ pts,
+                                                  size_t n, unsigned long long* __restrict__ out)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long h = 0ull;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const int k = kpos[j];
+    if (k >= 0) h ^= (unsigned long long)(unsigned)pts[k].orig * 1315423911ull + (unsigned long long)(order ? (size_t)order[j] : j);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)h, off, WAVE), hi = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), off, WAVE);
+    h ^= ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0 && h) atomicXor(out, h);
+}
+
 // ---- compact PtPair list (searchTree.cc:147-180) in the caller's query order ----------------------
 // found flags in caller order -> exclusive scan (rocPRIM, sort.hip) -> this kernel writes
 // p1 = transform3(dalignxf, closest) [projected onto the data point's plane in mode 2],
@@ -3856,7 +3904,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 #endif
 #ifdef TDTK_LAB
   if constexpr (FUSE == 0 || FUSE == 3) {
-    if (two_per_lane_for(a.n, a.side_by_side) && !a.bounds) {
+    if (two_per_lane_for(a.n, a.side_by_side) && !a.bounds && !a.skip) {
       const uint32_t nb2 = refill2_grid(a.n, &qpw);
       a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
       const char* e1 = lab_env("TDTK_TWO_ONE");
@@ -3932,7 +3980,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
     case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
     default:
 #ifdef TDTK_LAB
-      if ((FUSE == 0 || FUSE == 3) && pipe_on())
+      if ((FUSE == 0 || FUSE == 3) && pipe_on() && !a.skip)
         hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, (FUSE == 3 ? 3 : 0), false, 4, 0, false, 0, false, true>), dim3(nb), dim3(128), occ_lds, s, a);
       else
 #endif
@@ -4014,7 +4062,9 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
   if (dirmode == 1) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 1, false, 1>), g, b, 0, s, a);
   else if (dirmode == 2) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 2, false, 1>), g, b, 0, s, a);
   else {
-    const int v = pick_variant(a.n);
+    int v = pick_variant(a.n);
+    // (an -R pass -- SearchArgs::skip -- takes the product's three families only: the lab kernels do not read the mask)
+    if (a.skip && !(v == 20 || v == 4 || v == 10)) v = (a.n >= (size_t)262144) ? 20 : ((a.n >= (size_t)98304) ? 4 : 10);
     if (a.fuse && !(v == 20 || ((v == 10 || v == 4) && !count))) return hipErrorInvalidValue;
     // the product's three families: persistent lanes (20; sums by each wave over its own slab: FUSE 3), one query per
     // lane (4), four lanes per query (10) -- and their instrumented instantiations
@@ -4578,6 +4628,25 @@ hipError_t launch_scatter_idx(const int* kpos, const double* d2s, const int32_t*
   if (nb > cap) nb = cap;
   hipLaunchKernelGGL(k_scatter_idx, dim3((uint32_t)nb), dim3(256), 0, s, kpos, d2s, order, pts, n,
                      idx_out, d2_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_skip_from_mask(const unsigned char* mask_bits, const int32_t* order, size_t n, unsigned char* skip, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  const size_t cap = (size_t)num_cu() * 8;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(k_skip_from_mask, dim3((uint32_t)nb), dim3(256), 0, s, mask_bits, order, n, skip);
+  return hipGetLastError();
+}
+hipError_t launch_idx_hash(const int* kpos, const int32_t* order, const KdPoint* pts, size_t n, unsigned long long* out, hipStream_t s)
+{
+  if (!n) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  const size_t cap = (size_t)num_cu() * 8;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(k_idx_hash, dim3((uint32_t)nb), dim3(256), 0, s, kpos, order, pts, n, out);
   return hipGetLastError();
 }
 

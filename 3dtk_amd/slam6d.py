@@ -760,7 +760,7 @@ class icp6D:
         """icp6D::match (icp6D.cc:104-285).  Returns the number of iterations done."""
         if isinstance(CurrentScan, MetaScan):
             return self._match_meta_data(PreviousScan, CurrentScan)
-        if self.rnd > 1:
+        if self.rnd > 1 and getattr(self, "stepped_rnd", False):
             return self._match_stepped(PreviousScan, CurrentScan, pairing_mode)
         CurrentScan._addFrames("ICP", 0)          # transform(id, ICP, 0), icp6D.cc:109
         if self.max_num_iterations == 0:          # icp6D.cc:112-114
@@ -774,8 +774,12 @@ class icp6D:
         trace = np.zeros((cap, 18))
         tm = CurrentScan.transMat.copy()
         da = CurrentScan.dalignxf.copy()
-        check(lib().tdtk_icp_match(tree._h, dptr(PreviousScan.dalignxf), CurrentScan.handle, dptr(tm),
-                                   dptr(da), C.byref(prm), C.byref(res), dptr(trace), cap))
+        if self.rnd > 1:       # -R: the keep-mask of every iteration is drawn on the host (std::rand, index order), the loop stays resident
+            check(lib().tdtk_icp_match_rnd(tree._h, dptr(PreviousScan.dalignxf), CurrentScan.handle, dptr(tm),
+                                           dptr(da), C.byref(prm), int(self.rnd), C.byref(res), dptr(trace), cap))
+        else:
+            check(lib().tdtk_icp_match(tree._h, dptr(PreviousScan.dalignxf), CurrentScan.handle, dptr(tm),
+                                       dptr(da), C.byref(prm), C.byref(res), dptr(trace), cap))
         # frames as the reference's loop writes them (anim = -1): one after iteration 0 (transform(alignxf, ICP, 0),
         # icp6D.cc:258-264), one when the loop ends by convergence or at the cap (transform(id, ICP, 0),
         # :266-279) -- none on the "<= 3 pairs" break (:235-243 fall through to the end of the function)
@@ -793,12 +797,18 @@ class icp6D:
         self.last = dict(iterations=res.iterations, converged=bool(res.converged),
                          pairs=int(res.last_pairs), rms=res.last_rms, total_ms=res.total_ms,
                          nn_ms=res.nn_ms, sums_ms=res.sums_ms, trace=trace[:nrows].copy())
+        # diagnostics (tdtk_icp_index_hashes): one hash of the correspondence indices per pass of the loop, when switched on
+        hn = C.c_int(0)
+        hb = (C.c_uint64 * 1024)()
+        check(lib().tdtk_icp_last_hashes(hb, 1024, C.byref(hn)))
+        self.last["index_hashes"] = [int(hb[i]) for i in range(min(1024, hn.value))]
         return res.iterations
 
     def _match_stepped(self, PreviousScan, CurrentScan, pairing_mode=0):
         """The same loop driven from the host, one SearchTree::getPtPairs call per iteration: what
-        an unmodified reference icp6D::match does on top of HipSearchTree.  Only used for -R (rnd > 1),
-        whose keep-mask is drawn on the host (the resident loop has no per-iteration host input)."""
+        an unmodified reference icp6D::match does on top of HipSearchTree.  Until round 4 the path of -R (rnd > 1); since
+        round 5 the resident loop takes the keep-mask per iteration (tdtk_icp_match_rnd) and this form is kept for the test
+        that compares the two (`icp.stepped_rnd = True`)."""
         CurrentScan._addFrames("ICP", 0)
         tree = PreviousScan.getSearchTree()
         algo = self.my_icp6Dminimizer.getAlgorithmID()
@@ -888,7 +898,9 @@ class icp6D:
         preparation hides behind the previous match instead of adding to it.  The tree is built over
         "xyz reduced original", which no ICP step touches, so the result is unchanged."""
         pool = None
-        if prefetch and not self.meta and len(allScans) > 2:
+        # (under -R nothing is prepared ahead: the keep-masks come out of the process's std::rand() stream, and worker threads
+        # that bring up HIP contexts draw from that stream at times of their own -- adapters/icp_glue.h has the measurement)
+        if prefetch and not self.meta and self.rnd <= 1 and len(allScans) > 2:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(self.prefetch_depth)
 

@@ -202,7 +202,7 @@ static int run(std::vector<MiniScan>& scans, int prefetch, int* rounds)
   return 0;
 }
 
-// `slam_glue_harness doicp <in.bin> <out.bin> <meta 0|1> <max_num_metascans> <mdm> <iterations> <epsilonICP>`: icp6D::doICP
+// `slam_glue_harness doicp <in.bin> <out.bin> <meta 0|1> <max_num_metascans> <mdm> <iterations> <epsilonICP> [rnd [seed]]`: icp6D::doICP
 // (adapters/icp_glue.h, hip_do_icp) over scans read from <in.bin> -- int32 nscans, then per scan int32 npts, rPos[3],
 // rPosTheta[3], xyz[npts][3] in the scanner's frame -- with -a 1; <out.bin>: per scan transMat[16], then int32 frames per
 // scan.  BASELINE config 1 (`slam6D -m 500 -d 25.0 --metascan dat`) runs through this (test_config1_metascan_dat_through_the_cpp_glue).
@@ -224,9 +224,20 @@ static int run_doicp(int argc, char** argv)
   }
   std::fclose(f);
   const double mdm = std::atof(argv[6]);
+  // optional: <rnd> <seed> -- `-R <rnd>` with std::srand(seed) before each run (BASELINE config 1 is `-R 5`)
+  const int rnd = argc > 9 ? std::atoi(argv[9]) : 1;
+  const unsigned seed = argc > 10 ? (unsigned)std::atoi(argv[10]) : 1u;
   HipIcpSettings cfg = {TDTK_ALGO_QUAT, 0, std::atoi(argv[7]), mdm * mdm, std::atof(argv[8]), true, -1, true, T_ICP,
-                        std::atoi(argv[4]) != 0, std::atoi(argv[5])};
-  for (int prefetch : {2, 0}) {       // prepared ahead or not: the same poses (the second run's are written)
+                        std::atoi(argv[4]) != 0, std::atoi(argv[5]), rnd};
+  // Under -R the runs are seeded.  The HIP runtime itself draws from std::rand() while it initialises (first use of the device,
+  // of a code object, of a thread's context: the next rand() behind the FIRST doICP of a process differs from run to run,
+  // with or without -R), so a run whose draws are to be reproduced comes after one that has warmed the runtime up: under -R
+  // a first, unseeded pass is made and thrown away.
+  const int plan_rnd[] = {-1, 2, 0}, plan[] = {2, 0};
+  for (int prefetch : (rnd > 1 ? std::vector<int>(plan_rnd, plan_rnd + 3) : std::vector<int>(plan, plan + 2))) {       // prepared ahead or not: the same poses (the second run's are written)
+    const bool warmup = prefetch < 0;
+    if (warmup) prefetch = 0;
+    std::srand(seed);
     std::vector<MiniScan> run_scans((size_t)nscans);
     MiniScan::all.clear();
     std::vector<MiniScan*> ptrs;
@@ -238,6 +249,12 @@ static int run_doicp(int argc, char** argv)
     unsigned int pairs = 0;
     std::vector<int> its;
     hip_do_icp(ptrs, cfg, prefetch, &pairs, [&](size_t, int it) { its.push_back(it); });
+    if (std::getenv("TDTK_HARNESS_DEBUG")) {
+      std::printf("DEBUG prefetch %d: iterations", prefetch);
+      for (int it : its) std::printf(" %d", it);
+      std::printf(", last pairs %u, next rand %d\n", pairs, std::rand());
+    }
+    if (warmup) { MiniScan::all.clear(); continue; }
     if (prefetch == 2) {
       for (int k = 0; k < nscans; k++) std::memcpy(scans[k].transMat, run_scans[k].transMat, sizeof scans[k].transMat);
       continue;

@@ -46,14 +46,15 @@ public:
   HipIcpSettings settings(PairingMode pairing_mode)
   {
     HipIcpSettings c = {hip_algo_id(my_icp6Dminimizer), (int)pairing_mode, max_num_iterations, max_dist_match2, epsilonICP,
-                        quiet, anim, eP, (int)Scan::ICP, meta, max_num_metascans};
+                        quiet, anim, eP, (int)Scan::ICP, meta, max_num_metascans, rnd};
     return c;
   }
   bool on_device(Scan* model)
   {
     // the model tree lives in the scan (Scan::getSearchTree, scan.cc:268); it is a HipSearchTree when the scan was
-    // configured with nns_type HipKD.  rnd > 1 draws std::rand() per candidate: host path only (SURVEY N-d).
-    return dynamic_cast<HipSearchTree*>(model->getSearchTree()) != 0 && rnd <= 1 && hip_algo_id(my_icp6Dminimizer) != 0;
+    // configured with nns_type HipKD.  (-R draws std::rand() per candidate: the resident loop draws the mask on the host per
+    // iteration and sends it as bits since round 5 -- tdtk_icp_match_rnd -- with a serial build's consumption of the stream.)
+    return dynamic_cast<HipSearchTree*>(model->getSearchTree()) != 0 && hip_algo_id(my_icp6Dminimizer) != 0;
   }
 
   virtual int match(Scan* PreviousScan, Scan* CurrentScan, PairingMode pairing_mode = CLOSEST_POINT)

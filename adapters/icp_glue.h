@@ -32,6 +32,7 @@ struct HipIcpSettings {
   int type_icp;             // Scan::ICP as an int (the glue does not see the enum)
   bool meta;                // icp6D::meta (--metascan): doICP matches every scan against a MetaScan of the scans before it
   int max_num_metascans;    // icp6D::max_num_metascans: only the last n of them (<= 0: all)
+  int rnd;                  // icp6D::rnd (-R): > 1 = about every rnd-th point is a candidate of an iteration (tdtk_icp_match_rnd)
 };
 
 // ScanT needs: get_transMat(), getDAlign() -> const double*;  tdtk_tree* hipTree();  tdtk_scan* hipResident();
@@ -59,8 +60,10 @@ int hip_icp_match_tree(const tdtk_tree* model_tree, const double* model_dalignxf
   double tm[16], da[16];     // scratch: the Scan keeps its own matrices (replayed below)
   std::memcpy(tm, cur->get_transMat(), sizeof tm);
   std::memcpy(da, cur->getDAlign(), sizeof da);
-  if (tdtk_icp_match(model_tree, model_dalignxf, data, tm, da, &prm, &res, trace.data(), cfg.max_num_iterations) != TDTK_OK)
-    throw std::runtime_error(tdtk_last_error());
+  // -R: the keep-mask of every iteration is drawn inside the call (std::rand per point in index order, searchTree.cc:116-118)
+  const int rc = cfg.rnd > 1 ? tdtk_icp_match_rnd(model_tree, model_dalignxf, data, tm, da, &prm, cfg.rnd, &res, trace.data(), cfg.max_num_iterations)
+                             : tdtk_icp_match(model_tree, model_dalignxf, data, tm, da, &prm, &res, trace.data(), cfg.max_num_iterations);
+  if (rc != TDTK_OK) throw std::runtime_error(tdtk_last_error());
   // The points have moved on the device; replay the matrix / frame bookkeeping of every iteration's
   // `CurrentScan->transform(alignxf, Scan::ICP, islum)` (icp6D.cc:246-252) and of the end pose (icp6D.cc:254-268).  The
   // loop ends either in the convergence / iteration-cap branch -- iteration `iterations` was applied and the end pose
@@ -183,6 +186,11 @@ void hip_do_icp(std::vector<ScanT*>& allScans, const HipIcpSettings& cfg, int pr
                 const std::function<void(size_t, int)>& on_matched = nullptr)
 {
   const size_t n = allScans.size();
+  // -R (cfg.rnd > 1) draws from the process's std::rand() stream, which must be consumed as a serial reference consumes it;
+  // worker threads that bring up HIP contexts draw from the same stream at times of their own (measured: the next rand()
+  // behind a doICP differs from run to run as soon as scans are prepared ahead, with or without -R), so under -R nothing
+  // is prepared ahead.
+  if (cfg.rnd > 1) prefetch = 0;
   HipPrefetcher* pool = (prefetch > 0 && n > 2) ? new HipPrefetcher(prefetch) : nullptr;
   const bool meta = cfg.meta;
   std::vector<ScanT*> meta_scans;      // icp6D.cc:380-381, 421-433

@@ -231,6 +231,15 @@ int tdtk_icp_match(const tdtk_tree* model, const double model_dalignxf[16], tdtk
                    double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm,
                    tdtk_icp_result* res, double* trace, int trace_cap);
 
+/* The same loop with `-R <rnd>` (icp6D's rnd, handed to getPtPairs: "take about 1/rnd-th of the numbers only",
+ * src/slam6d/searchTree.cc:116-118): per iteration one std::rand() per point of the data scan in its index order decides
+ * whether the point is a candidate of that iteration (globals.icc:607-610), drawn on the host at the moment the iteration
+ * starts -- the process's random stream is consumed exactly as a serial build of the reference consumes it -- and sent to
+ * the device as one bit per point; every point still moves with every alignxf.  rnd <= 1: tdtk_icp_match.            */
+int tdtk_icp_match_rnd(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
+                       double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm, int rnd,
+                       tdtk_icp_result* res, double* trace, int trace_cap);
+
 /* ---- lum6DEuler::covarianceEuler (src/slam6d/lum6Deuler.cc:94-251) for one link:
  * first = model tree + its dalignxf, second = resident data scan.  C[36] row-major, CD[6].
  * Returns the pair count through *m; C/CD are zero if m <= 2 or ss < 1e-13.              */
@@ -413,6 +422,14 @@ int tdtk_visit_counters(int device, uint64_t out[8]);
 int tdtk_measure_bandwidth(int device, int kind, size_t bytes, int reps, double* gbs);
 int tdtk_count_visits(const tdtk_tree* t, const double* q, size_t K, double maxdist2,
                       uint64_t counters[3] /* internal nodes, leaves, leaf points */);
+/* Correspondence hashes of the resident loop (off by default, process-wide; returns the previous setting): while on,
+ * every iteration of tdtk_icp_match also reduces its correspondences to one word on the device -- the XOR over the found
+ * queries of (model index * 1315423911 + query index), both in the caller's numbering, i.e. the hash of the index array
+ * SearchTree::getPtPairs' loop walks (searchTree.cc:118-147) -- so that a test can compare the loop's INDICES with the
+ * reference's iteration by iteration at a million points without downloading them.  tdtk_icp_last_hashes: the words of
+ * the calling thread's last tdtk_icp_match (*n_out = how many passes it ran, at most 1024 are kept). */
+int tdtk_icp_index_hashes(int on);
+int tdtk_icp_last_hashes(uint64_t* out, int cap, int* n_out);
 
 /* ---- on-disk formats either side of the path (host only): uos ASCII scans with the -m/-M range
  * filter (src/scanio/helper.cc:564-880, src/slam6d/pointfilter.cc:162-188), .pose files

@@ -353,6 +353,38 @@ def test_get_pt_pairs_rnd_subsampling(tdtk, orc, gpu):
     assert abs(got["sum"] - ref["sum"]) <= 1e-12 * ref["sum"]
 
 
+@pytest.mark.parametrize("n", [20000, 150000, 300000])
+def test_rnd_in_the_resident_loop_equals_the_stepped_loop(tdtk, orc, gpu, n):
+    """Round 5: `-R 5` inside the device-resident loop (tdtk_icp_match_rnd: per iteration the keep-mask is
+    drawn on the host -- one std::rand() per point in index order, searchTree.cc:116-118 -- and sent as bits; the search
+    kernels skip what was not drawn) against the loop driven from the host, one tdtk_get_pt_pairs(rnd) per iteration, with
+    libc seeded identically: the same pairs per iteration, the same RMS and alignxf to 1e-9, the same final pose -- for the
+    three search-kernel families (four lanes per query, one query per lane, persistent lanes) -- and the same number of
+    std::rand() draws consumed (the next draw of the process is the same)."""
+    import ctypes as C
+    import bench
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    m, d, T = bench.make_icp_pair(n, seed=5)
+    out = []
+    for stepped in (False, True):
+        model = tdtk.Scan([0, 0, 0], [0, 0, 0], m)
+        data = tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 7, quiet=True, rnd=5, epsilonICP=1e-9)
+        icp.stepped_rnd = stepped
+        libc.srand(4711)
+        it = icp.match(model, data)
+        out.append((it, icp.last["trace"].copy(), data.get_transMat().copy(), data.get_xyz_reduced(), libc.rand()))
+    (it0, tr0, tm0, x0, r0), (it1, tr1, tm1, x1, r1) = out
+    assert it0 == it1 and len(tr0) == len(tr1) == it0 + 1
+    assert np.array_equal(tr0[:, 0], tr1[:, 0])                               # pairs per iteration
+    assert 3 < tr0[0, 0] < 0.23 * n                                            # at most about a fifth of the points are candidates
+    np.testing.assert_allclose(tr0[:, 1:], tr1[:, 1:], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(tm0, tm1, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(x0, x1, rtol=0, atol=1e-7)
+    assert r0 == r1
+
+
 def test_scan_transform_bit_exact(tdtk, orc, gpu):
     rng = np.random.default_rng(2)
     p = rng.uniform(-500, 500, (50000, 3)); nr = rng.normal(size=p.shape)
@@ -578,6 +610,54 @@ def _range_filter(p, rmax):
     return np.ascontiguousarray(p[p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1] + p[:, 2] * p[:, 2] < rmax * rmax])
 
 
+@pytest.mark.parametrize("n,dups", [(1000000, 0), (300000, 30000)])
+def test_resident_loop_indices_every_iteration(tdtk, orc, gpu, n, dups):
+    """Round 5: the regime bench.py times -- tdtk_icp_match on >= 262144 queries: persistent-lane kernel,
+    warm start from the previous hit, cost-ordered hand-out, pair sums inside the launch -- pinned at the level of INDICES.
+    With tdtk_icp_index_hashes on, every pass of the loop reduces its correspondences to the K5 hash on the
+    device; for the first iterations that hash must equal the hash of the multi-threaded oracle's FindClosest over the
+    points where the loop has moved them (the trace's alignxf applied with the reference's transform3 arithmetic), and pair
+    count + RMS must equal the reference's own OpenMP-branch iterations (oracle/_ref: ref_icp_iterations) where that library
+    exists.  Second case: 30 000 exact duplicates in the model, i.e. ties that the warm radius (one ulp above the previous
+    hit's distance) must not resolve differently from a cold search."""
+    import bench
+    rng = np.random.default_rng(n + dups)
+    m, d, T = bench.make_icp_pair(n, seed=42 if not dups else 43)
+    if dups:
+        m[rng.integers(0, n, dups)] = m[rng.integers(0, n, dups)]
+    model = tdtk.Scan([0, 0, 0], [0, 0, 0], m)
+    data = tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+    iters = 6
+    was = tdtk.lib().tdtk_icp_index_hashes(1)
+    try:
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, iters, quiet=True, epsilonICP=-1.0)
+        assert icp.match(model, data) == iters - 1
+    finally:
+        tdtk.lib().tdtk_icp_index_hashes(was)
+    hashes = icp.last["index_hashes"]
+    trace = icp.last["trace"]
+    assert len(hashes) == iters and len(trace) == iters
+    ot = orc.Tree(m, 20)
+    cur = d.copy()
+    nt = max(8, min(96, os.cpu_count() or 8))
+    for it in range(iters):
+        idx, _ = ot.find_closest(cur, 625.0, nt)                      # model at the identity pose: tree frame = world
+        assert int((idx >= 0).sum()) == int(trace[it, 0]), it
+        assert orc.k5_hash(idx) == hashes[it], (it, "0x%x" % orc.k5_hash(idx), "0x%x" % hashes[it])
+        orc.transform_points(trace[it, 2:], cur)                      # Scan::transform, same arithmetic (scan.cc:851-875)
+    assert np.array_equal(cur, data.get_xyz_reduced())                # the resident points are where the trace says
+    if orc.have_ref():
+        rt = orc.RefTree(m, 20)
+        _, rtr = rt.icp_iterations(np.eye(4).reshape(16), d, 625.0, 16, iters)
+        assert np.array_equal(rtr[:, 0], trace[:, 0])                 # pairs per iteration
+        np.testing.assert_allclose(rtr[:, 1], trace[:, 1], rtol=1e-9)  # RMS per iteration
+        np.testing.assert_allclose(rtr[:, 2:], trace[:, 2:], rtol=0, atol=1e-9)
+    # switched off again: the next match keeps no hashes
+    icp2 = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 2, quiet=True, epsilonICP=-1.0)
+    icp2.match(model, data)
+    assert icp2.last["index_hashes"] == []
+
+
 @pytest.mark.parametrize("rnd", [1, 5])
 def test_config1_metascan_dat(tdtk, orc, gpu, rnd, tmp_path):
     """BASELINE configs[0]: `slam6D -m 500 -R 5 -d 25.0 --metascan dat` (plumbing).  -R 5 draws
@@ -623,8 +703,8 @@ def test_config1_metascan_dat(tdtk, orc, gpu, rnd, tmp_path):
     np.testing.assert_allclose(last[:16], S[1].get_transMat(), rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("meta,maxmeta", [(1, -1), (1, 1), (0, -1)])
-def test_config1_metascan_dat_through_the_cpp_glue(tdtk, gpu, tmp_path, meta, maxmeta):
+@pytest.mark.parametrize("meta,maxmeta,rnd", [(1, -1, 1), (1, 1, 1), (0, -1, 1), (1, -1, 5)])
+def test_config1_metascan_dat_through_the_cpp_glue(tdtk, gpu, tmp_path, meta, maxmeta, rnd):
     """BASELINE configs[0] (`slam6D -m 500 -d 25.0 --metascan dat`) through the C++ binding's body: icp6D_hip::doICP =
     hip_do_icp (adapters/icp_glue.h), whose meta branch (icp6D.cc:396-434) matches every scan against a MetaScan tree
     built on the device over the scans before it (tdtk_tree_create_from_scans = KDtreeMetaManaged).  Executed by
@@ -645,7 +725,9 @@ def test_config1_metascan_dat_through_the_cpp_glue(tdtk, gpu, tmp_path, meta, ma
             f.write(np.int32(len(pts[k])).tobytes())
             f.write(np.ascontiguousarray(z["pose%03d" % k], dtype=np.float64).tobytes())
             f.write(np.ascontiguousarray(pts[k], dtype=np.float64).tobytes())
-    r = subprocess.run([exe, "doicp", fin, fout, str(meta), str(maxmeta), "25.0", "50", "1e-5"], capture_output=True, text=True, timeout=600)
+    # (rnd = 5: BASELINE configs[0] to the letter, `-R 5` -- the keep-masks drawn per iteration inside tdtk_icp_match_rnd, libc
+    # seeded with 42 in the harness and, below, for the Python mirror: the same draws, the same poses bit for bit)
+    r = subprocess.run([exe, "doicp", fin, fout, str(meta), str(maxmeta), "25.0", "50", "1e-5", str(rnd), "42"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SLAM GLUE HARNESS OK" in r.stdout, r.stdout + r.stderr
     out = np.fromfile(fout, dtype=np.uint8)
     tm_cpp = np.frombuffer(out[:3 * 128].tobytes(), dtype=np.float64).reshape(3, 16)
@@ -653,7 +735,9 @@ def test_config1_metascan_dat_through_the_cpp_glue(tdtk, gpu, tmp_path, meta, ma
     S = [tdtk.Scan(z["pose%03d" % k][:3], z["pose%03d" % k][3:], pts[k]) for k in range(3)]
     tdtk.Scan.allScans = S
     try:
-        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 50, quiet=True, meta=bool(meta), rnd=1, epsilonICP=1e-5, max_num_metascans=maxmeta)
+        icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, 50, quiet=True, meta=bool(meta), rnd=rnd, epsilonICP=1e-5, max_num_metascans=maxmeta)
+        import ctypes as _C
+        _C.CDLL(None).srand(42)
         its = []
         orig_match = icp.match
 
