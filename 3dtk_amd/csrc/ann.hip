@@ -36,6 +36,7 @@ namespace tdtk {
 
 #define WAVE 64
 #define ANN_SMALL 64u         // cells up to this size are finished by one wavefront
+#define ANN_MID 2048u         // round 5: cells up to this size are taken down to ANN_SMALL-point cells by one wavefront in LDS (k_ann_mid)
 #define ANN_ERR 0.001         // kd_split.cpp:34
 #define A_LEAF 0x20000000u    // child reference: leaf flag | position (29 bits); c0 bits 30..31 = cutting dimension
 #define A_VAL 0x1FFFFFFFu
@@ -101,12 +102,12 @@ static __device__ __forceinline__ uint32_t sl_midpt_nlo(uint32_t mode, uint32_t 
 // ---- level-parallel part -----------------------------------------------------------------------
 __global__ void k_ann_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
                            uint32_t* __restrict__ seg_of, double* __restrict__ cx, double* __restrict__ cy,
-                           double* __restrict__ cz, uint32_t* __restrict__ bad)
+                           double* __restrict__ cz, uint32_t* __restrict__ bad, uint32_t mid_cap)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   const double x = xyz[3 * (size_t)p], y = xyz[3 * (size_t)p + 1], z = xyz[3 * (size_t)p + 2];
-  perm[p] = p; seg_of[p] = (M > ANN_SMALL) ? 0u : NOSEG;
+  perm[p] = p; seg_of[p] = (M > mid_cap) ? 0u : NOSEG;
   cx[p] = x; cy[p] = y; cz[p] = z;
   if (!(isfinite(x) && isfinite(y) && isfinite(z))) atomicOr(bad, 1u);
 }
@@ -114,15 +115,17 @@ __global__ void k_ann_init(const double* __restrict__ xyz, uint32_t M, uint32_t*
 // the root cell = annEnclRect of all points (kd_tree.cpp:381-385); small[4] counts the small cells
 __global__ void k_ann_root(const double* __restrict__ box, uint32_t M, ASeg* __restrict__ segs,
                            ASeg* __restrict__ small_list, uint32_t* __restrict__ small, double* __restrict__ bb,
-                           AMeasU* __restrict__ meas, unsigned long long* __restrict__ cnt, uint32_t* __restrict__ lvl)
+                           AMeasU* __restrict__ meas, unsigned long long* __restrict__ cnt, uint32_t* __restrict__ lvl,
+                           ASeg* __restrict__ mid_list, uint32_t mid_cap)
 {
-  lvl[0] = (M > ANN_SMALL) ? 1u : 0u;
+  lvl[0] = (M > mid_cap) ? 1u : 0u;
   for (int d = 0; d < 3; d++) { meas[0].mn[d] = ENC_PINF; meas[0].mx[d] = ENC_NINF; }
   cnt[0] = 0ull;
   ASeg r;
   r.start = 0; r.n = M; r.parent = -1; r.side = 0; r.depth = 0; r.pad = 0;
   for (int d = 0; d < 3; d++) { r.blo[d] = box[d]; r.bhi[d] = box[3 + d]; bb[d] = box[d]; bb[3 + d] = box[3 + d]; }
-  if (M > ANN_SMALL) segs[0] = r;
+  if (M > mid_cap) segs[0] = r;
+  else if (M > ANN_SMALL) { mid_list[0] = r; small[5] = 1; }
   else if (M > 1) { small_list[0] = r; small[4] = 1; }
   else small[0] = A_LEAF | 0u;     // a single point: the root is its leaf
 }
@@ -413,11 +416,12 @@ static __device__ __forceinline__ void ann_hook(AnnNode* __restrict__ nodes, uin
 }
 
 // per cell: n_lo, the splitting node, the two child cells (leaf / small cell / cell of the next level).
-// small: [0] root_ref [1] max depth [2] err [3] cells of the next level [4] small cells
+// small: [0] root_ref [1] max depth [2] err [3] cells of the next level [4] small cells [5] mid cells (k_ann_mid)
 __global__ void k_ann_children(const ASeg* __restrict__ segs, const uint32_t* __restrict__ nseg_ptr, ADec* __restrict__ dec,
                                const unsigned long long* __restrict__ cnt, AnnNode* __restrict__ nodes,
                                ASeg* __restrict__ next, ASeg* __restrict__ small_list, uint32_t* __restrict__ small,
-                               AMeasU* __restrict__ meas_next, unsigned long long* __restrict__ cnt_next)
+                               AMeasU* __restrict__ meas_next, unsigned long long* __restrict__ cnt_next,
+                               ASeg* __restrict__ mid_list, uint32_t mid_cap)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg_ptr[0]) return;     // nseg_ptr[1] counts the cells of the next level
@@ -445,6 +449,8 @@ __global__ void k_ann_children(const ASeg* __restrict__ segs, const uint32_t* __
       atomicMax(small + 1, ch.depth);
     } else if (ch.n <= ANN_SMALL) {
       small_list[atomicAdd(small + 4, 1u)] = ch;
+    } else if (ch.n <= mid_cap) {
+      mid_list[atomicAdd(small + 5, 1u)] = ch;
     } else {
       slot[side] = atomicAdd(const_cast<uint32_t*>(nseg_ptr) + 1, 1u);
       next[slot[side]] = ch;
@@ -578,6 +584,163 @@ __global__ void __launch_bounds__(256) k_ann_small(const ASeg* __restrict__ smal
   if (lane == 0) atomicMax(small + 1, maxdepth);
 }
 
+// ---- mid cells (round 5): one wavefront per cell of 65 .. ANN_MID points, the cell's points in LDS ------------------
+// The level loop above costs thirteen launches per level whatever the level holds, and a 1M-point scan has a dozen levels
+// between 2048-point and 64-point cells (the sliding-midpoint tree is not balanced): 69 % of a calcNormals call were those
+// launches.  Here ONE wavefront takes a cell of at most ANN_MID points -- coordinates and original indices in LDS -- down
+// to cells of at most ANN_SMALL points (which k_ann_small finishes) by walking its subtree depth first: per cell the
+// points' min / max (kd_util.cpp:225-262), the sliding-midpoint rule, the breaks, and annPlaneSplit's two in-place Hoare
+// passes (kd_util.cpp:291-319) each as "the k-th misplaced element from the left swaps with the k-th misplaced from the
+// right end" -- the formulation of k_ann_misplaced / k_ann_swaplist / k_ann_swap and of k_ann_small, with the ranks from
+// ballots and a running count instead of a prefix sum.  Same permutation, same nodes, same hooks as the level loop.
+// A child that is a leaf is hooked in at once, one of 2 .. ANN_SMALL points goes to the small-cell list, one above that is
+// the next cell (low child) or waits on a stack of at most ANN_MID / 65 entries (high child).
+struct AMidCell { uint32_t cs, cn; int32_t parent; uint32_t side, depth, pad; double blo[3], bhi[3]; };
+__global__ void __launch_bounds__(64) k_ann_mid(const ASeg* __restrict__ mid_list, uint32_t nmid, uint32_t* __restrict__ perm,
+                                                double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz,
+                                                AnnNode* __restrict__ nodes, ASeg* __restrict__ small_list, uint32_t* __restrict__ small)
+{
+  __shared__ double X[ANN_MID], Y[ANN_MID], Z[ANN_MID];
+  __shared__ uint32_t PM[ANN_MID];
+  __shared__ unsigned short slotL[ANN_MID / 2], slotR[ANN_MID / 2];
+  __shared__ AMidCell stack[ANN_MID / (ANN_SMALL + 1) + 2];
+  const uint32_t lane = threadIdx.x;
+  if (blockIdx.x >= nmid) return;
+  const ASeg sg = mid_list[blockIdx.x];
+  const uint32_t S = sg.start, N = sg.n;
+  for (uint32_t o = lane; o < N; o += WAVE) { X[o] = cx[S + o]; Y[o] = cy[S + o]; Z[o] = cz[S + o]; PM[o] = perm[S + o]; }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // the current cell (wave-uniform)
+  uint32_t cs = 0, cn = N, side = sg.side, depth = sg.depth;
+  int32_t parent = sg.parent;
+  double blo[3] = {sg.blo[0], sg.blo[1], sg.blo[2]}, bhi[3] = {sg.bhi[0], sg.bhi[1], sg.bhi[2]};
+  uint32_t sp = 0, maxdepth = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (;;) {
+    // ---- point min / max of the cell (annMinMax per dimension: independent of the order)
+    double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (uint32_t o = lane; o < cn; o += WAVE) {
+      const double v[3] = {X[cs + o], Y[cs + o], Z[cs + o]};
+#pragma unroll
+      for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        double t;
+        t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
+        t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
+      }
+    uint32_t cd, mode;
+    double cv;
+    sl_midpt_rule(blo, bhi, mn, mx, cd, cv, mode);
+    const double* C = (cd == 0) ? X : ((cd == 1) ? Y : Z);       // (the passes below swap through X / Y / Z: no restrict)
+    // ---- the breaks: br1 = points below the plane, br2 - br1 = points on it
+    uint32_t br1 = 0, neq = 0;
+    for (uint32_t o0 = 0; o0 < cn; o0 += WAVE) {
+      const uint32_t o = o0 + lane;
+      const double c = (o < cn) ? C[cs + o] : HUGE_VAL;
+      br1 += (uint32_t)__popcll(__ballot(o < cn && c < cv));
+      neq += (uint32_t)__popcll(__ballot(o < cn && c == cv));
+    }
+    const uint32_t br2 = br1 + neq;
+    // ---- annPlaneSplit: pass 1 on [0, cn) around br1 with "< cv", pass 2 on [br1, cn) around br2 with "<= cv"
+    for (int pass = 1; pass <= 2; pass++) {
+      const uint32_t lo = (pass == 1) ? 0u : br1, brk = (pass == 1) ? br1 : br2;
+      // misplaced on the left of the break, in position order
+      uint32_t nL = 0;
+      for (uint32_t o0 = lo; o0 < brk; o0 += WAVE) {
+        const uint32_t o = o0 + lane;
+        bool mis = false;
+        if (o < brk) { const double c = C[cs + o]; mis = (pass == 1) ? !(c < cv) : !(c <= cv); }
+        const unsigned long long b = __ballot(mis);
+        if (mis) slotL[nL + (uint32_t)__popcll(b & below)] = (unsigned short)o;
+        nL += (uint32_t)__popcll(b);
+      }
+      // misplaced on the right of the break, counted from the right END of the cell
+      uint32_t nR = 0;
+      for (uint32_t t0 = 0; brk + t0 < cn; t0 += WAVE) {
+        const uint32_t t = t0 + lane;                // distance from the last position
+        bool mis = false;
+        uint32_t o = 0;
+        if (brk + t < cn) { o = cn - 1u - t; const double c = C[cs + o]; mis = (pass == 1) ? (c < cv) : (c <= cv); }
+        const unsigned long long b = __ballot(mis);
+        if (mis) slotR[nR + (uint32_t)__popcll(b & below)] = (unsigned short)o;
+        nR += (uint32_t)__popcll(b);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // (nL == nR: as many points of the left part are on the wrong side as of the right part)
+      for (uint32_t k = lane; k < nL && k < nR; k += WAVE) {
+        const uint32_t a = cs + slotL[k], b = cs + slotR[k];
+        double t;
+        t = X[a]; X[a] = X[b]; X[b] = t;
+        t = Y[a]; Y[a] = Y[b]; Y[b] = t;
+        t = Z[a]; Z[a] = Z[b]; Z[b] = t;
+        const uint32_t u = PM[a]; PM[a] = PM[b]; PM[b] = u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t n_lo = sl_midpt_nlo(mode, cn, br1, br2);
+    if (n_lo == 0 || n_lo >= cn) { if (lane == 0) atomicExch(small + 2, 1u); break; }    // cannot happen for finite input
+    const uint32_t me = S + cs + n_lo - 1u;
+    // ---- the splitting node and the two children (kd_tree.cpp:346-357)
+    AnnNode nd;
+    nd.cut_val = cv; nd.lo = sel3(blo, cd); nd.hi = sel3(bhi, cd);
+    nd.c0 = cd << 30; nd.c1 = 0;
+    AMidCell big[2];
+    int nbig = 0;
+    for (uint32_t sd = 0; sd < 2; sd++) {
+      const uint32_t ccs = sd ? cs + n_lo : cs, ccn = sd ? cn - n_lo : n_lo;
+      if (ccn == 1) {
+        if (sd) nd.c1 = A_LEAF | (S + ccs); else nd.c0 |= A_LEAF | (S + ccs);
+        maxdepth = (depth + 1u > maxdepth) ? depth + 1u : maxdepth;
+        continue;
+      }
+      AMidCell ch;
+      ch.cs = ccs; ch.cn = ccn; ch.parent = (int32_t)me; ch.side = sd; ch.depth = depth + 1u; ch.pad = 0;
+      for (int d = 0; d < 3; d++) { ch.blo[d] = blo[d]; ch.bhi[d] = bhi[d]; }
+      if (sd) put3(ch.blo, cd, cv); else put3(ch.bhi, cd, cv);
+      if (ccn <= ANN_SMALL) {
+        if (lane == 0) {
+          ASeg o;
+          o.start = S + ccs; o.n = ccn; o.parent = ch.parent; o.side = sd; o.depth = ch.depth; o.pad = 0;
+          for (int d = 0; d < 3; d++) { o.blo[d] = ch.blo[d]; o.bhi[d] = ch.bhi[d]; }
+          small_list[atomicAdd(small + 4, 1u)] = o;
+        }
+      } else big[nbig++] = ch;
+    }
+    if (lane == 0) {
+      nodes[me] = nd;      // children that are cells hook themselves in later (this wave further down, or k_ann_small)
+      ann_hook(nodes, small + 0, parent, side, me);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- next cell: the low child if it is still a mid cell, else the high one, else the stack
+    if (nbig == 2) {
+      if (lane == 0) stack[sp] = big[1];
+      ++sp;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    AMidCell nx;
+    if (nbig >= 1) nx = big[0];
+    else {
+      if (sp == 0) break;
+      --sp;
+      nx = stack[sp];
+    }
+    cs = nx.cs; cn = nx.cn; parent = nx.parent; side = nx.side; depth = nx.depth;
+    for (int d = 0; d < 3; d++) { blo[d] = nx.blo[d]; bhi[d] = nx.bhi[d]; }
+  }
+  // the points in their final order within the cell's range (the small cells below continue from global memory)
+  for (uint32_t o = lane; o < N; o += WAVE) { cx[S + o] = X[o]; cy[S + o] = Y[o]; cz[S + o] = Z[o]; perm[S + o] = PM[o]; }
+  if (lane == 0 && maxdepth) atomicMax(small + 1, maxdepth);
+}
+
 __global__ void k_ann_points(const uint32_t* __restrict__ perm, const double* __restrict__ cx,
                              const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M,
                              KdPoint* __restrict__ pts)
@@ -641,6 +804,7 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
   take(4 * (ANN_MAX_LEVELS + 2));                                            // 23 cells per level
   take(scan_pair27_state_bytes(n1));                                         // 24 state of the one-launch scan (sort.hip)
+  take(sizeof(ASeg) * nlarge);                                               // 25 mid cells (k_ann_mid)
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
@@ -682,21 +846,25 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   double* partial = (double*)(arena + O[20]); double* box = (double*)(arena + O[21]);
 
   uint32_t* lvl = (uint32_t*)(arena + O[23]);
+  ASeg* mid_list = (ASeg*)(arena + O[25]);
+  // cells of at most this many points leave the level loop for k_ann_mid (TDTK_ANN_MID=0: the level loop down to 64-point cells,
+  // the round-2 form)
+  static const uint32_t mid_cap = [] { const char* e = getenv("TDTK_ANN_MID"); return (e && e[0] == '0') ? ANN_SMALL : ANN_MID; }();
   ACHK(hipMemsetAsync(small, 0, 256, s));
   ACHK(hipMemsetAsync(lvl, 0, 4 * (ANN_MAX_LEVELS + 2), s));
   // the partition's scans in one launch each while the positions fit their 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
   static const bool own_scan_env = [] { const char* e = getenv("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
   const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
   if (own_scan) ACHK(hipMemsetAsync(arena + O[24], 0, scan_pair27_state_bytes(n1), s));
-  hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2);
+  hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2, mid_cap);
   ACHK(launch_bbox(d_xyz, M, partial, box, s));
-  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt, lvl);
+  hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt, lvl, mid_list, mid_cap);
   // Levels are enqueued without waiting for their cell counts (those stay on the device: lvl[]); the host looks
   // at them only after a batch -- the first batch is as deep as a balanced tree gets down to 64-point cells, then
   // two levels at a time.  A level enqueued past the last one finds no cell and costs a few empty launches.
-  uint32_t level = 0, more = (M > ANN_SMALL) ? 1u : 0u;
+  uint32_t level = 0, more = (M > mid_cap) ? 1u : 0u;
   uint32_t batch = 1;
-  for (size_t c = ANN_SMALL; c < M_; c <<= 1) batch++;
+  for (size_t c = mid_cap; c < M_; c <<= 1) batch++;
   const size_t nlarge = M_ / (ANN_SMALL + 1) + 2;
   while (more) {
     for (uint32_t b = 0; b < batch && level < ANN_MAX_LEVELS; b++, level++) {
@@ -721,7 +889,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
         hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
       }
       hipLaunchKernelGGL(k_ann_children, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, dec, cnt, nodes, next,
-                         small_list, small, meas_next, cnt_next);
+                         small_list, small, meas_next, cnt_next, mid_list, mid_cap);
       ASeg* t = segs; segs = next; next = t;
       AMeasU* tm = meas; meas = meas_next; meas_next = tm;
       unsigned long long* tc = cnt; cnt = cnt_next; cnt_next = tc;
@@ -734,15 +902,22 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
     if (bad || (more && level >= ANN_MAX_LEVELS)) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
     batch = 2;
   }
-  if (M <= ANN_SMALL) {     // no level ran: the finiteness flag of k_ann_init has not been looked at yet
+  if (M <= mid_cap) {       // no level ran: the finiteness flag of k_ann_init has not been looked at yet
     uint32_t bad = 0;
     ACHK(hipMemcpyAsync(&bad, small + 2, 4, hipMemcpyDeviceToHost, s));
     ACHK(hipStreamSynchronize(s));
     if (bad) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
   }
-  uint32_t h_small[5];
+  uint32_t h_small[6];
   ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
   ACHK(hipStreamSynchronize(s));
+  if (h_small[5]) {
+    // the mid cells first: they add to the list of small cells (whose length the next launch needs on the host)
+    hipLaunchKernelGGL(k_ann_mid, dim3(h_small[5]), dim3(WAVE), 0, s, mid_list, h_small[5], perm, cx, cy, cz, nodes, small_list, small);
+    ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
+    ACHK(hipStreamSynchronize(s));
+    if (h_small[2]) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
+  }
   if (h_small[4])
     hipLaunchKernelGGL(k_ann_small, dim3(cdiv((size_t)h_small[4] * WAVE, 256)), dim3(256), 0, s, small_list, h_small[4], perm, cx, cy, cz,
                        nodes, small);
