@@ -36,7 +36,7 @@ namespace tdtk {
 
 #define WAVE 64
 #define ANN_SMALL 64u         // cells up to this size are finished by one wavefront
-#define ANN_MID 2048u         // round 5: cells up to this size are taken down to ANN_SMALL-point cells by one wavefront in LDS (k_ann_mid)
+#define ANN_MID 2048u         // round 5: cells up to this size are taken down to ANN_SMALL-point cells by one workgroup in LDS (k_ann_mid)
 #define ANN_ERR 0.001         // kd_split.cpp:34
 #define A_LEAF 0x20000000u    // child reference: leaf flag | position (29 bits); c0 bits 30..31 = cutting dimension
 #define A_VAL 0x1FFFFFFFu
@@ -446,7 +446,7 @@ __global__ void k_ann_children(const ASeg* __restrict__ segs, const uint32_t* __
     else { if (d.cd == 0) ch.bhi[0] = d.cv; else if (d.cd == 1) ch.bhi[1] = d.cv; else ch.bhi[2] = d.cv; }
     if (ch.n == 1) {
       if (side) nd.c1 = A_LEAF | ch.start; else nd.c0 |= A_LEAF | ch.start;
-      atomicMax(small + 1, ch.depth);
+      if (ch.depth > *(volatile uint32_t*)(small + 1)) atomicMax(small + 1, ch.depth);
     } else if (ch.n <= ANN_SMALL) {
       small_list[atomicAdd(small + 4, 1u)] = ch;
     } else if (ch.n <= mid_cap) {
@@ -504,6 +504,7 @@ __global__ void __launch_bounds__(256) k_ann_small(const ASeg* __restrict__ smal
   volatile uint32_t* slotR = s_slot[threadIdx.x / WAVE][1];
   const ASeg sg = small_list[w];
   const uint32_t S = sg.start, N = sg.n;
+  if (N == 0) return;        // an unused slot of a stretch k_ann_mid reserved
   bool active = lane < N;
   double x = 0, y = 0, z = 0;
   uint32_t pm = 0;
@@ -581,164 +582,303 @@ __global__ void __launch_bounds__(256) k_ann_small(const ASeg* __restrict__ smal
   if (lane < N) { cx[S + lane] = x; cy[S + lane] = y; cz[S + lane] = z; perm[S + lane] = pm; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const uint32_t t = __shfl_xor(maxdepth, off, WAVE); maxdepth = (t > maxdepth) ? t : maxdepth; }
-  if (lane == 0) atomicMax(small + 1, maxdepth);
+  // (one atomic per wave on one word were 0.3 ms of a 1M-point build: only who can raise the maximum tries)
+  if (lane == 0 && maxdepth > *(volatile uint32_t*)(small + 1)) atomicMax(small + 1, maxdepth);
 }
 
-// ---- mid cells (round 5): one wavefront per cell of 65 .. ANN_MID points, the cell's points in LDS ------------------
+// ---- mid cells (round 5): one workgroup per cell of 65 .. ANN_MID points, the cell's points in LDS -----------------
 // The level loop above costs thirteen launches per level whatever the level holds, and a 1M-point scan has a dozen levels
 // between 2048-point and 64-point cells (the sliding-midpoint tree is not balanced): 69 % of a calcNormals call were those
-// launches.  Here ONE wavefront takes a cell of at most ANN_MID points -- coordinates and original indices in LDS -- down
-// to cells of at most ANN_SMALL points (which k_ann_small finishes) by walking its subtree depth first: per cell the
-// points' min / max (kd_util.cpp:225-262), the sliding-midpoint rule, the breaks, and annPlaneSplit's two in-place Hoare
-// passes (kd_util.cpp:291-319) each as "the k-th misplaced element from the left swaps with the k-th misplaced from the
-// right end" -- the formulation of k_ann_misplaced / k_ann_swaplist / k_ann_swap and of k_ann_small, with the ranks from
-// ballots and a running count instead of a prefix sum.  Same permutation, same nodes, same hooks as the level loop.
-// A child that is a leaf is hooked in at once, one of 2 .. ANN_SMALL points goes to the small-cell list, one above that is
-// the next cell (low child) or waits on a stack of at most ANN_MID / 65 entries (high child).
+// launches.  Here ONE workgroup of four wavefronts takes a cell of at most ANN_MID points -- coordinates in LDS, the
+// original indices as 16-bit positions into the cell's own stretch of `perm` -- down to cells of at most ANN_SMALL points
+// (which k_ann_small finishes): per cell the points' min / max (kd_util.cpp:225-262), the sliding-midpoint rule, the
+// breaks, and annPlaneSplit's two in-place Hoare passes (kd_util.cpp:291-319) each as "the k-th misplaced element from the
+// left swaps with the k-th misplaced from the right end" -- the formulation of k_ann_misplaced / k_ann_swaplist /
+// k_ann_swap and of k_ann_small, with the ranks from ballots and running counts instead of a prefix sum.  Same
+// permutation, same nodes, same hooks as the level loop.  Cells above ANN_MID_WAVE points are split by the four
+// wavefronts together (depth first, a stack of at most seven); what falls to ANN_MID_WAVE points or below goes onto a
+// list from which each wavefront then draws and finishes whole subtrees on its own, without a workgroup barrier.
+// (First form, one wavefront per 2048-point cell and everything serial: 404 us of a 1M-point build, two cells per CU.)
+#define ANN_MID_BLOCK 256
+#define ANN_MID_NW (ANN_MID_BLOCK / WAVE)
+#define ANN_MID_WAVE 256u
 struct AMidCell { uint32_t cs, cn; int32_t parent; uint32_t side, depth, pad; double blo[3], bhi[3]; };
-__global__ void __launch_bounds__(64) k_ann_mid(const ASeg* __restrict__ mid_list, uint32_t nmid, uint32_t* __restrict__ perm,
-                                                double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz,
-                                                AnnNode* __restrict__ nodes, ASeg* __restrict__ small_list, uint32_t* __restrict__ small)
+struct AMidShared {
+  double X[ANN_MID], Y[ANN_MID], Z[ANN_MID];
+  unsigned short PM[ANN_MID];                         // position (in the cell as it was loaded) of the point now at o
+  unsigned short slotL[ANN_MID / 2], slotR[ANN_MID / 2];
+  double red[ANN_MID_NW][6];
+  uint32_t cnt[ANN_MID_NW][4];
+  AMidCell cstack[ANN_MID / (ANN_MID_WAVE + 1) + 2];
+  AMidCell wl[ANN_MID / (ANN_SMALL + 1) + 2];         // cells of 65 .. ANN_MID_WAVE points: one wavefront each
+  AMidCell wstack[ANN_MID_NW][ANN_MID_WAVE / (ANN_SMALL + 1) + 2];
+  AMidCell next;
+  AMidCell tmp[ANN_MID_NW][2];                        // the mid-cell children of the split just made (ann_mid_emit)
+  uint32_t wl_n, wl_take, next_ok, sbase, csp;
+};
+
+// One split of the cell [cs, cs + cn) by NW wavefronts (NW == 1: the calling wavefront alone, no workgroup barrier).
+// Returns cd / cv / n_lo (identical in every participating thread); the points of the cell are permuted in LDS.
+template <int NW>
+static __device__ __forceinline__ void ann_mid_split(AMidShared& sh, const uint32_t wv, const uint32_t lane, const uint32_t cs, const uint32_t cn,
+                                                     const double* blo, const double* bhi, uint32_t& cd, double& cv, uint32_t& n_lo)
 {
-  __shared__ double X[ANN_MID], Y[ANN_MID], Z[ANN_MID];
-  __shared__ uint32_t PM[ANN_MID];
-  __shared__ unsigned short slotL[ANN_MID / 2], slotR[ANN_MID / 2];
-  __shared__ AMidCell stack[ANN_MID / (ANN_SMALL + 1) + 2];
-  const uint32_t lane = threadIdx.x;
+  auto sync = [&]() {
+    if (NW > 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  };
+  const uint32_t w = (NW > 1) ? wv : 0u, T = (uint32_t)NW * WAVE, tid = w * WAVE + lane;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // ---- point min / max of the cell (annMinMax per dimension: independent of the order)
+  double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+  for (uint32_t o = tid; o < cn; o += T) {
+    const double v[3] = {sh.X[cs + o], sh.Y[cs + o], sh.Z[cs + o]};
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      double t;
+      t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
+      t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
+    }
+  if (NW > 1) {
+    if (lane == 0) { for (int d = 0; d < 3; d++) { sh.red[w][d] = mn[d]; sh.red[w][3 + d] = mx[d]; } }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = sh.red[0][d]; mx[d] = sh.red[0][3 + d]; }
+    for (int v = 1; v < NW; v++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double a = sh.red[v][d], b = sh.red[v][3 + d];
+        mn[d] = (a < mn[d]) ? a : mn[d]; mx[d] = (mx[d] < b) ? b : mx[d];
+      }
+  }
+  uint32_t mode;
+  sl_midpt_rule(blo, bhi, mn, mx, cd, cv, mode);
+  const double* C = (cd == 0) ? sh.X : ((cd == 1) ? sh.Y : sh.Z);       // (the passes below swap through X / Y / Z: no restrict)
+  // ---- the breaks: br1 = points below the plane, br2 - br1 = points on it
+  uint32_t br1 = 0, neq = 0;
+  for (uint32_t o0 = w * WAVE; o0 < cn; o0 += T) {
+    const uint32_t o = o0 + lane;
+    const double c = (o < cn) ? C[cs + o] : HUGE_VAL;
+    br1 += (uint32_t)__popcll(__ballot(o < cn && c < cv));
+    neq += (uint32_t)__popcll(__ballot(o < cn && c == cv));
+  }
+  if (NW > 1) {
+    if (lane == 0) { sh.cnt[w][0] = br1; sh.cnt[w][1] = neq; }
+    __syncthreads();
+    br1 = 0; neq = 0;
+    for (int v = 0; v < NW; v++) { br1 += sh.cnt[v][0]; neq += sh.cnt[v][1]; }
+    __syncthreads();                     // (cnt is written again below)
+  }
+  const uint32_t br2 = br1 + neq;
+  // ---- annPlaneSplit: pass 1 on [0, cn) around br1 with "< cv", pass 2 on [br1, cn) around br2 with "<= cv"
+  for (int pass = 1; pass <= 2; pass++) {
+    const uint32_t lo = (pass == 1) ? 0u : br1, brk = (pass == 1) ? br1 : br2;
+    // every wavefront takes a contiguous share of the left part (in position order) and of the right part (from the END)
+    const uint32_t lenL = brk - lo, lenR = cn - brk;
+    const uint32_t shL = (NW > 1) ? (((lenL + NW - 1) / NW + WAVE - 1) / WAVE) * WAVE : lenL;
+    const uint32_t shR = (NW > 1) ? (((lenR + NW - 1) / NW + WAVE - 1) / WAVE) * WAVE : lenR;
+    const uint32_t l0 = min(w * shL, lenL), l1 = min(l0 + shL, lenL), r0 = min(w * shR, lenR), r1 = min(r0 + shR, lenR);
+    uint32_t baseL = 0, baseR = 0;
+    if (NW > 1) {
+      uint32_t cL = 0, cR = 0;
+      for (uint32_t o0 = l0; o0 < l1; o0 += WAVE) {
+        const uint32_t o = lo + o0 + lane;
+        bool mis = false;
+        if (o0 + lane < l1) { const double c = C[cs + o]; mis = (pass == 1) ? !(c < cv) : !(c <= cv); }
+        cL += (uint32_t)__popcll(__ballot(mis));
+      }
+      for (uint32_t t0 = r0; t0 < r1; t0 += WAVE) {
+        const uint32_t t = t0 + lane;
+        bool mis = false;
+        if (t < r1) { const double c = C[cs + cn - 1u - t]; mis = (pass == 1) ? (c < cv) : (c <= cv); }
+        cR += (uint32_t)__popcll(__ballot(mis));
+      }
+      if (lane == 0) { sh.cnt[w][2] = cL; sh.cnt[w][3] = cR; }
+      __syncthreads();
+      for (uint32_t v = 0; v < w; v++) { baseL += sh.cnt[v][2]; baseR += sh.cnt[v][3]; }
+    }
+    // misplaced on the left of the break, in position order
+    uint32_t nL = baseL;
+    for (uint32_t o0 = l0; o0 < l1; o0 += WAVE) {
+      const uint32_t o = lo + o0 + lane;
+      bool mis = false;
+      if (o0 + lane < l1) { const double c = C[cs + o]; mis = (pass == 1) ? !(c < cv) : !(c <= cv); }
+      const unsigned long long b = __ballot(mis);
+      if (mis) sh.slotL[(cs >> 1) + nL + (uint32_t)__popcll(b & below)] = (unsigned short)o;
+      nL += (uint32_t)__popcll(b);
+    }
+    // misplaced on the right of the break, counted from the right END of the cell
+    uint32_t nR = baseR;
+    for (uint32_t t0 = r0; t0 < r1; t0 += WAVE) {
+      const uint32_t t = t0 + lane;                // distance from the last position
+      bool mis = false;
+      uint32_t o = 0;
+      if (t < r1) { o = cn - 1u - t; const double c = C[cs + o]; mis = (pass == 1) ? (c < cv) : (c <= cv); }
+      const unsigned long long b = __ballot(mis);
+      if (mis) sh.slotR[(cs >> 1) + nR + (uint32_t)__popcll(b & below)] = (unsigned short)o;
+      nR += (uint32_t)__popcll(b);
+    }
+    uint32_t nswap = nL;                 // (as many points of the left part are on the wrong side as of the right part)
+    if (NW > 1) {
+      __syncthreads();                   // lists complete (and every wave has read the counts)
+      nswap = 0;
+      for (int v = 0; v < NW; v++) nswap += sh.cnt[v][2];
+    } else sync();
+    for (uint32_t k = tid; k < nswap; k += T) {
+      const uint32_t a = cs + sh.slotL[(cs >> 1) + k], b = cs + sh.slotR[(cs >> 1) + k];
+      double t;
+      t = sh.X[a]; sh.X[a] = sh.X[b]; sh.X[b] = t;
+      t = sh.Y[a]; sh.Y[a] = sh.Y[b]; sh.Y[b] = t;
+      t = sh.Z[a]; sh.Z[a] = sh.Z[b]; sh.Z[b] = t;
+      const unsigned short u = sh.PM[a]; sh.PM[a] = sh.PM[b]; sh.PM[b] = u;
+    }
+    sync();
+  }
+  n_lo = sl_midpt_nlo(mode, cn, br1, br2);
+}
+
+// what ONE thread does behind a split: the splitting node, its hook, the leaf children, the children that are small cells;
+// a child that is still a mid cell is written to out0 (low child) / out1 (high child) -- LDS -- and its size returned in
+// n0 / n1 (0: that child needs nothing more here).  No local arrays, no run-time indexed structs: the first form kept the
+// children in a private array, which the compiler put into scratch memory -- 304 bytes per lane, a hundred dependent trips
+// to it per mid cell on the one thread everybody waits for, and most of the kernel's 230 us.
+static __device__ __forceinline__ void ann_mid_emit(const AMidCell& c, const uint32_t S, const uint32_t cd, const double cv, const uint32_t n_lo,
+                                                    AnnNode* __restrict__ nodes, ASeg* __restrict__ small_list, const uint32_t sbase,
+                                                    uint32_t* __restrict__ small, AMidCell* out0, AMidCell* out1, uint32_t& n0, uint32_t& n1,
+                                                    uint32_t& maxdepth)
+{
+  const uint32_t me = S + c.cs + n_lo - 1u;
+  uint32_t c0 = cd << 30, c1 = 0;
+  n0 = 0; n1 = 0;
+#pragma unroll
+  for (uint32_t sd = 0; sd < 2; sd++) {
+    const uint32_t ccs = sd ? c.cs + n_lo : c.cs, ccn = sd ? c.cn - n_lo : n_lo;
+    if (ccn == 1) {
+      if (sd) c1 = A_LEAF | (S + ccs); else c0 |= A_LEAF | (S + ccs);
+      maxdepth = (c.depth + 1u > maxdepth) ? c.depth + 1u : maxdepth;
+      continue;
+    }
+    // the child's cell (kd_tree.cpp:346-357): the parent's with one face moved to the cutting plane
+    const double b0 = (sd && cd == 0) ? cv : c.blo[0], b1 = (sd && cd == 1) ? cv : c.blo[1], b2 = (sd && cd == 2) ? cv : c.blo[2];
+    const double h0 = (!sd && cd == 0) ? cv : c.bhi[0], h1 = (!sd && cd == 1) ? cv : c.bhi[1], h2 = (!sd && cd == 2) ? cv : c.bhi[2];
+    if (ccn <= ANN_SMALL) {
+      // (a small cell has at least two points, so (start within the mid cell) / 2 is a slot of its own in the stretch of
+      // the list this workgroup reserved: no atomic per small cell -- a quarter of a million of them on ONE counter were
+      // 3 ms of a 10M-point build, whatever the rest of the kernel did)
+      ASeg* o = small_list + sbase + (ccs >> 1);
+      o->start = S + ccs; o->n = ccn; o->parent = (int32_t)me; o->side = sd; o->depth = c.depth + 1u; o->pad = 0;
+      o->blo[0] = b0; o->blo[1] = b1; o->blo[2] = b2; o->bhi[0] = h0; o->bhi[1] = h1; o->bhi[2] = h2;
+    } else {
+      AMidCell* o = sd ? out1 : out0;
+      o->cs = ccs; o->cn = ccn; o->parent = (int32_t)me; o->side = sd; o->depth = c.depth + 1u; o->pad = cd | 4u;   // pad: the parent's cutting dimension (| 4: known)
+      o->blo[0] = b0; o->blo[1] = b1; o->blo[2] = b2; o->bhi[0] = h0; o->bhi[1] = h1; o->bhi[2] = h2;
+      if (sd) n1 = ccn; else n0 = ccn;
+    }
+  }
+  AnnNode* nd = nodes + me;      // children that are cells hook themselves in later (this workgroup further down, or k_ann_small)
+  nd->cut_val = cv; nd->lo = sel3(c.blo, cd); nd->hi = sel3(c.bhi, cd); nd->c0 = c0; nd->c1 = c1;
+  // the hook into the parent: a plain store where the parent's cutting dimension came down with the cell (ann_hook reads the
+  // parent's word back first)
+  if (c.pad & 4u) { if (c.side) nodes[c.parent].c1 = me; else nodes[c.parent].c0 = ((c.pad & 3u) << 30) | me; }
+  else ann_hook(nodes, small + 0, c.parent, c.side, me);
+}
+
+__global__ void __launch_bounds__(ANN_MID_BLOCK) k_ann_mid(const ASeg* __restrict__ mid_list, uint32_t nmid, uint32_t* __restrict__ perm,
+                                                           double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz,
+                                                           AnnNode* __restrict__ nodes, ASeg* __restrict__ small_list, uint32_t* __restrict__ small)
+{
+  __shared__ AMidShared sh;
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   if (blockIdx.x >= nmid) return;
   const ASeg sg = mid_list[blockIdx.x];
   const uint32_t S = sg.start, N = sg.n;
-  for (uint32_t o = lane; o < N; o += WAVE) { X[o] = cx[S + o]; Y[o] = cy[S + o]; Z[o] = cz[S + o]; PM[o] = perm[S + o]; }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // the current cell (wave-uniform)
-  uint32_t cs = 0, cn = N, side = sg.side, depth = sg.depth;
-  int32_t parent = sg.parent;
-  double blo[3] = {sg.blo[0], sg.blo[1], sg.blo[2]}, bhi[3] = {sg.bhi[0], sg.bhi[1], sg.bhi[2]};
-  uint32_t sp = 0, maxdepth = 0;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (;;) {
-    // ---- point min / max of the cell (annMinMax per dimension: independent of the order)
-    double mn[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, mx[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
-    for (uint32_t o = lane; o < cn; o += WAVE) {
-      const double v[3] = {X[cs + o], Y[cs + o], Z[cs + o]};
-#pragma unroll
-      for (int d = 0; d < 3; d++) { mn[d] = (v[d] < mn[d]) ? v[d] : mn[d]; mx[d] = (mx[d] < v[d]) ? v[d] : mx[d]; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        double t;
-        t = __shfl_xor(mn[d], off, WAVE); mn[d] = (t < mn[d]) ? t : mn[d];
-        t = __shfl_xor(mx[d], off, WAVE); mx[d] = (mx[d] < t) ? t : mx[d];
-      }
-    uint32_t cd, mode;
-    double cv;
-    sl_midpt_rule(blo, bhi, mn, mx, cd, cv, mode);
-    const double* C = (cd == 0) ? X : ((cd == 1) ? Y : Z);       // (the passes below swap through X / Y / Z: no restrict)
-    // ---- the breaks: br1 = points below the plane, br2 - br1 = points on it
-    uint32_t br1 = 0, neq = 0;
-    for (uint32_t o0 = 0; o0 < cn; o0 += WAVE) {
-      const uint32_t o = o0 + lane;
-      const double c = (o < cn) ? C[cs + o] : HUGE_VAL;
-      br1 += (uint32_t)__popcll(__ballot(o < cn && c < cv));
-      neq += (uint32_t)__popcll(__ballot(o < cn && c == cv));
-    }
-    const uint32_t br2 = br1 + neq;
-    // ---- annPlaneSplit: pass 1 on [0, cn) around br1 with "< cv", pass 2 on [br1, cn) around br2 with "<= cv"
-    for (int pass = 1; pass <= 2; pass++) {
-      const uint32_t lo = (pass == 1) ? 0u : br1, brk = (pass == 1) ? br1 : br2;
-      // misplaced on the left of the break, in position order
-      uint32_t nL = 0;
-      for (uint32_t o0 = lo; o0 < brk; o0 += WAVE) {
-        const uint32_t o = o0 + lane;
-        bool mis = false;
-        if (o < brk) { const double c = C[cs + o]; mis = (pass == 1) ? !(c < cv) : !(c <= cv); }
-        const unsigned long long b = __ballot(mis);
-        if (mis) slotL[nL + (uint32_t)__popcll(b & below)] = (unsigned short)o;
-        nL += (uint32_t)__popcll(b);
-      }
-      // misplaced on the right of the break, counted from the right END of the cell
-      uint32_t nR = 0;
-      for (uint32_t t0 = 0; brk + t0 < cn; t0 += WAVE) {
-        const uint32_t t = t0 + lane;                // distance from the last position
-        bool mis = false;
-        uint32_t o = 0;
-        if (brk + t < cn) { o = cn - 1u - t; const double c = C[cs + o]; mis = (pass == 1) ? (c < cv) : (c <= cv); }
-        const unsigned long long b = __ballot(mis);
-        if (mis) slotR[nR + (uint32_t)__popcll(b & below)] = (unsigned short)o;
-        nR += (uint32_t)__popcll(b);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // (nL == nR: as many points of the left part are on the wrong side as of the right part)
-      for (uint32_t k = lane; k < nL && k < nR; k += WAVE) {
-        const uint32_t a = cs + slotL[k], b = cs + slotR[k];
-        double t;
-        t = X[a]; X[a] = X[b]; X[b] = t;
-        t = Y[a]; Y[a] = Y[b]; Y[b] = t;
-        t = Z[a]; Z[a] = Z[b]; Z[b] = t;
-        const uint32_t u = PM[a]; PM[a] = PM[b]; PM[b] = u;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    const uint32_t n_lo = sl_midpt_nlo(mode, cn, br1, br2);
-    if (n_lo == 0 || n_lo >= cn) { if (lane == 0) atomicExch(small + 2, 1u); break; }    // cannot happen for finite input
-    const uint32_t me = S + cs + n_lo - 1u;
-    // ---- the splitting node and the two children (kd_tree.cpp:346-357)
-    AnnNode nd;
-    nd.cut_val = cv; nd.lo = sel3(blo, cd); nd.hi = sel3(bhi, cd);
-    nd.c0 = cd << 30; nd.c1 = 0;
-    AMidCell big[2];
-    int nbig = 0;
-    for (uint32_t sd = 0; sd < 2; sd++) {
-      const uint32_t ccs = sd ? cs + n_lo : cs, ccn = sd ? cn - n_lo : n_lo;
-      if (ccn == 1) {
-        if (sd) nd.c1 = A_LEAF | (S + ccs); else nd.c0 |= A_LEAF | (S + ccs);
-        maxdepth = (depth + 1u > maxdepth) ? depth + 1u : maxdepth;
-        continue;
-      }
-      AMidCell ch;
-      ch.cs = ccs; ch.cn = ccn; ch.parent = (int32_t)me; ch.side = sd; ch.depth = depth + 1u; ch.pad = 0;
-      for (int d = 0; d < 3; d++) { ch.blo[d] = blo[d]; ch.bhi[d] = bhi[d]; }
-      if (sd) put3(ch.blo, cd, cv); else put3(ch.bhi, cd, cv);
-      if (ccn <= ANN_SMALL) {
-        if (lane == 0) {
-          ASeg o;
-          o.start = S + ccs; o.n = ccn; o.parent = ch.parent; o.side = sd; o.depth = ch.depth; o.pad = 0;
-          for (int d = 0; d < 3; d++) { o.blo[d] = ch.blo[d]; o.bhi[d] = ch.bhi[d]; }
-          small_list[atomicAdd(small + 4, 1u)] = o;
-        }
-      } else big[nbig++] = ch;
-    }
-    if (lane == 0) {
-      nodes[me] = nd;      // children that are cells hook themselves in later (this wave further down, or k_ann_small)
-      ann_hook(nodes, small + 0, parent, side, me);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- next cell: the low child if it is still a mid cell, else the high one, else the stack
-    if (nbig == 2) {
-      if (lane == 0) stack[sp] = big[1];
-      ++sp;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    AMidCell nx;
-    if (nbig >= 1) nx = big[0];
-    else {
-      if (sp == 0) break;
-      --sp;
-      nx = stack[sp];
-    }
-    cs = nx.cs; cn = nx.cn; parent = nx.parent; side = nx.side; depth = nx.depth;
-    for (int d = 0; d < 3; d++) { blo[d] = nx.blo[d]; bhi[d] = nx.bhi[d]; }
+  for (uint32_t o = tid; o < N; o += ANN_MID_BLOCK) { sh.X[o] = cx[S + o]; sh.Y[o] = cy[S + o]; sh.Z[o] = cz[S + o]; sh.PM[o] = (unsigned short)o; }
+  // this cell's stretch of the small-cell list: N / 2 slots (see ann_mid_emit), reserved with ONE atomic, emptied (n = 0: nothing
+  // here) before anything is put into it
+  if (tid == 0) {
+    sh.wl_n = 0; sh.wl_take = 0; sh.next_ok = 1; sh.csp = 0; sh.sbase = atomicAdd(small + 4, N >> 1);
+    AMidCell* r = (N <= ANN_MID_WAVE) ? &sh.wl[0] : &sh.next;
+    r->cs = 0; r->cn = N; r->parent = sg.parent; r->side = sg.side; r->depth = sg.depth; r->pad = 0;
+    r->blo[0] = sg.blo[0]; r->blo[1] = sg.blo[1]; r->blo[2] = sg.blo[2]; r->bhi[0] = sg.bhi[0]; r->bhi[1] = sg.bhi[1]; r->bhi[2] = sg.bhi[2];
+    if (N <= ANN_MID_WAVE) { sh.wl_n = 1; sh.next_ok = 0; }
   }
-  // the points in their final order within the cell's range (the small cells below continue from global memory)
-  for (uint32_t o = lane; o < N; o += WAVE) { cx[S + o] = X[o]; cy[S + o] = Y[o]; cz[S + o] = Z[o]; perm[S + o] = PM[o]; }
-  if (lane == 0 && maxdepth) atomicMax(small + 1, maxdepth);
+  __syncthreads();
+  const uint32_t sbase = sh.sbase;
+  for (uint32_t k = tid; k < (N >> 1); k += ANN_MID_BLOCK) small_list[sbase + k].n = 0u;
+  __threadfence_block();
+  uint32_t maxdepth = 0;
+  bool failed = false;
+  // ---- phase 1: cells above ANN_MID_WAVE points, all four wavefronts on one cell, depth first (sh.next: the cell in hand)
+  while (sh.next_ok != 0) {
+    const AMidCell cur = sh.next;
+    __syncthreads();          // (everybody has the cell: thread 0 rewrites sh.next below)
+    uint32_t cd, n_lo;
+    double cv;
+    ann_mid_split<ANN_MID_NW>(sh, wv, lane, cur.cs, cur.cn, cur.blo, cur.bhi, cd, cv, n_lo);
+    if (n_lo == 0 || n_lo >= cur.cn) { failed = true; break; }     // cannot happen for finite input (uniform: every thread leaves)
+    if (tid == 0) {
+      uint32_t n0, n1;
+      ann_mid_emit(cur, S, cd, cv, n_lo, nodes, small_list, sbase, small, &sh.tmp[0][0], &sh.tmp[0][1], n0, n1, maxdepth);
+      // children of at most ANN_MID_WAVE points wait for phase 2; of the others the low one is next, the high one is stacked
+      const bool coop0 = n0 > ANN_MID_WAVE, coop1 = n1 > ANN_MID_WAVE;
+      if (n0 && !coop0) sh.wl[sh.wl_n++] = sh.tmp[0][0];
+      if (n1 && !coop1) sh.wl[sh.wl_n++] = sh.tmp[0][1];
+      if (coop0 && coop1) sh.cstack[sh.csp++] = sh.tmp[0][1];
+      if (coop0) sh.next = sh.tmp[0][0];
+      else if (coop1) sh.next = sh.tmp[0][1];
+      else if (sh.csp > 0) sh.next = sh.cstack[--sh.csp];
+      else sh.next_ok = 0;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  // ---- phase 2: every wavefront draws cells of 65 .. ANN_MID_WAVE points and finishes their subtrees on its own
+  const uint32_t wl_n = sh.wl_n;
+  while (!failed) {
+    uint32_t take = 0;
+    if (lane == 0) take = atomicAdd(&sh.wl_take, 1u);
+    take = (uint32_t)__builtin_amdgcn_readfirstlane((int)take);
+    if (take >= wl_n) break;
+    AMidCell c = sh.wl[take];
+    uint32_t sp = 0;
+    for (;;) {
+      uint32_t cd, n_lo;
+      double cv;
+      ann_mid_split<1>(sh, wv, lane, c.cs, c.cn, c.blo, c.bhi, cd, cv, n_lo);
+      if (n_lo == 0 || n_lo >= c.cn) { failed = true; break; }
+      uint32_t n0 = 0, n1 = 0;
+      if (lane == 0) ann_mid_emit(c, S, cd, cv, n_lo, nodes, small_list, sbase, small, &sh.tmp[wv][0], &sh.tmp[wv][1], n0, n1, maxdepth);
+      n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0); n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // the low child next, the high one stacked (at most ANN_MID_WAVE / 65 of them wait at any time)
+      if (n0 && n1) { if (lane == 0) sh.wstack[wv][sp] = sh.tmp[wv][1]; ++sp; c = sh.tmp[wv][0]; }
+      else if (n0) c = sh.tmp[wv][0];
+      else if (n1) c = sh.tmp[wv][1];
+      else { if (sp == 0) break; --sp; c = sh.wstack[wv][sp]; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (failed && lane == 0) atomicExch(small + 2, 1u);
+  __syncthreads();
+  // the points in their final order within the cell's range (the small cells below continue from global memory); the
+  // original indices are gathered from the cell's own stretch of perm -- all of it read before any of it is written
+  uint32_t pv[ANN_MID / ANN_MID_BLOCK];
+#pragma unroll
+  for (uint32_t k = 0; k < ANN_MID / ANN_MID_BLOCK; k++) { const uint32_t o = tid + k * ANN_MID_BLOCK; pv[k] = (o < N) ? perm[S + sh.PM[o]] : 0u; }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < ANN_MID / ANN_MID_BLOCK; k++) {
+    const uint32_t o = tid + k * ANN_MID_BLOCK;
+    if (o < N) { cx[S + o] = sh.X[o]; cy[S + o] = sh.Y[o]; cz[S + o] = sh.Z[o]; perm[S + o] = pv[k]; }
+  }
+  if (lane == 0 && maxdepth > *(volatile uint32_t*)(small + 1)) atomicMax(small + 1, maxdepth);
 }
 
 __global__ void k_ann_points(const uint32_t* __restrict__ perm, const double* __restrict__ cx,
@@ -913,7 +1053,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   ACHK(hipStreamSynchronize(s));
   if (h_small[5]) {
     // the mid cells first: they add to the list of small cells (whose length the next launch needs on the host)
-    hipLaunchKernelGGL(k_ann_mid, dim3(h_small[5]), dim3(WAVE), 0, s, mid_list, h_small[5], perm, cx, cy, cz, nodes, small_list, small);
+    hipLaunchKernelGGL(k_ann_mid, dim3(h_small[5]), dim3(ANN_MID_BLOCK), 0, s, mid_list, h_small[5], perm, cx, cy, cz, nodes, small_list, small);
     ACHK(hipMemcpyAsync(h_small, small, sizeof h_small, hipMemcpyDeviceToHost, s));
     ACHK(hipStreamSynchronize(s));
     if (h_small[2]) { res.err = hipErrorInvalidValue; res.degenerate = true; return res; }
