@@ -67,7 +67,7 @@ EXPORTS = [
     "tdtk_graph_block_doubles", "tdtk_graph_link_blocks", "tdtk_graph_solve_update", "tdtk_scans_transform2", "tdtk_solve_spd",
     "tdtk_solve_chol_upper", "tdtk_invert", "tdtk_reduce_octree", "tdtk_reduce_octree_nrpts", "tdtk_normals_apx_knn", "tdtk_scan_calc_normals", "tdtk_last_kernel_ms", "tdtk_count_visits",
     "tdtk_comm_unique_id", "tdtk_comm_create", "tdtk_comm_destroy", "tdtk_comm_info", "tdtk_comm_rccl_world", "tdtk_graph_exchange", "tdtk_graph_deal_links",
-    "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge",
+    "tdtk_graph_iteration", "tdtk_elch_graph_balancer", "tdtk_pair_sums_merge", "tdtk_graph_links",
     "tdtk_last_timings", "tdtk_kernel_timing", "tdtk_visit_counting", "tdtk_visit_counters", "tdtk_measure_bandwidth",
     "tdtk_icp_index_hashes", "tdtk_icp_last_hashes",
     "tdtk_host_tree_layout", "tdtk_host_m4inv", "tdtk_host_mmult",
@@ -187,6 +187,7 @@ def lib():
                                        C.POINTER(C.c_void_p), _dp, _dp, _dp]
     L.tdtk_elch_graph_balancer.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, _dp]
     L.tdtk_pair_sums_merge.argtypes = [C.c_int, C.POINTER(PairSums), C.POINTER(PairSums)]
+    L.tdtk_graph_links.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _ip, _ip, C.c_int, C.POINTER(C.c_int)]
     L.tdtk_last_timings.argtypes = [_dp]
     L.tdtk_kernel_timing.argtypes = [C.c_int]
     L.tdtk_visit_counting.argtypes = [C.c_int, C.c_int]

@@ -2983,6 +2983,54 @@ int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, 
   if (nlinks < 0 || nscans < 2 || !X || (nlinks && (!from || !to || !C || !CD))) { set_error("bad argument"); return TDTK_EINVAL; }
   const int n = nscans - 1, N = 6 * n;
   thread_local std::vector<double> G, B;   // kept per host thread: no fresh pages every LUM round
+  if (!G_out && !B_out) {
+    // Nobody wants the dense G: the blocks go straight into the skyline the solve factors (round 5: clearing and re-reading
+    // 1.1 MB of dense G per round were a third of the 0.19 ms the solve cost a 64-scan graph).  A block row reaches left to
+    // the smallest scan it shares a link with; inside that stretch the arithmetic is solve_spd_dense's on the dense copy --
+    // the same sums in link order, the same |v| > 1e-5 filter, the same first surviving column per row -- so X is the same
+    // bit for bit.
+    thread_local std::vector<int> bmin, first;
+    thread_local std::vector<size_t> off, base;
+    thread_local std::vector<double> sky, y;
+    bmin.resize(n);
+    for (int r = 0; r < n; r++) bmin[r] = r;
+    for (int l = 0; l < nlinks; l++) {
+      const int a = from[l] - 1, b = to[l] - 1;
+      if (a >= n || b >= n || a < -1 || b < -1) { set_error("link endpoint out of range"); return TDTK_EINVAL; }
+      if (a >= 0 && b >= 0) { const int hi = a > b ? a : b, lo = a > b ? b : a; if (lo < bmin[hi]) bmin[hi] = lo; }
+    }
+    base.resize((size_t)N); first.resize((size_t)N); off.resize((size_t)N + 1);
+    size_t total = 0;
+    for (int i = 0; i < N; i++) { base[i] = total; total += (size_t)(i - 6 * bmin[i / 6] + 1); }
+    sky.assign(total, 0.0); B.assign((size_t)N, 0.0);
+    auto at = [&](int i, int k) -> double& { return sky[base[i] + (size_t)(k - 6 * bmin[i / 6])]; };   // k <= i, inside the row's stretch
+    for (int l = 0; l < nlinks; l++) {
+      const int a = from[l] - 1, b = to[l] - 1;
+      const double* Cab = C + 36 * (size_t)l;
+      const double* CDab = CD + 6 * (size_t)l;
+      auto add = [&](int r, int c, double sgn) {       // the lower triangle only (the solve reads nothing else)
+        for (int i = 0; i < 6; i++)
+          for (int j = 0; j < 6; j++)
+            if (c * 6 + j <= r * 6 + i) at(r * 6 + i, c * 6 + j) += sgn * Cab[i * 6 + j];
+      };
+      if (a >= 0) { for (int i = 0; i < 6; i++) B[a * 6 + i] += CDab[i]; add(a, a, 1.0); }
+      if (b >= 0) { for (int i = 0; i < 6; i++) B[b * 6 + i] -= CDab[i]; add(b, b, 1.0); }
+      if (a >= 0 && b >= 0) { if (a > b) add(a, b, -1.0); else add(b, a, -1.0); }
+    }
+    for (int i = 0; i < N; i++) {
+      const int f0 = 6 * bmin[i / 6];
+      double* row = sky.data() + base[i];
+      int f = f0;
+      while (f < i && !(std::fabs(row[f - f0]) > 0.00001)) ++f;
+      first[i] = f;
+      off[i] = base[i] + (size_t)(f - f0);
+      for (int k = f; k <= i; k++) if (!(std::fabs(row[k - f0]) > 0.00001)) row[k - f0] = 0.0;
+    }
+    off[N] = total;
+    y.resize((size_t)N);
+    if (!skyline_solve(N, first.data(), off.data(), sky.data(), B.data(), y.data(), X)) { set_error("matrix is not positive definite"); return TDTK_ESOLVE; }
+    return TDTK_OK;
+  }
   G.assign((size_t)N * N, 0.0); B.assign((size_t)N, 0.0);
   for (int l = 0; l < nlinks; l++) {
     const int a = from[l] - 1, b = to[l] - 1;

@@ -208,4 +208,22 @@ int tdtk_pair_sums_merge(int count, const tdtk_pair_sums* parts, tdtk_pair_sums*
   return TDTK_OK;
 }
 
+// Graph::Graph(int nodes, double cldist2, int loopsize) (src/slam6d/graph.cc:107-130): the chain i -> i + 1, then every pair
+// (j, k), k - j > loopsize, whose scanner positions are closer than cldist (Dist2, globals.icc:238-245), j-major.
+int tdtk_graph_links(int nscans, const double* rPos, double cldist2, int loopsize, int32_t* from, int32_t* to, int cap, int* nlinks)
+{
+  if (nscans < 0 || !nlinks || (nscans && !rPos) || cap < 0 || (cap && (!from || !to))) { tdtk::set_error("bad argument"); return TDTK_EINVAL; }
+  int n = 0;
+  auto put = [&](int a, int b) { if (n < cap) { from[n] = a; to[n] = b; } ++n; };
+  for (int i = 0; i + 1 < nscans; i++) put(i, i + 1);
+  for (int j = 0; j < nscans; j++)
+    for (int k = j + 1; k < nscans; k++) {
+      if (!(k - j > loopsize)) continue;
+      const double dx = rPos[3 * k] - rPos[3 * j], dy = rPos[3 * k + 1] - rPos[3 * j + 1], dz = rPos[3 * k + 2] - rPos[3 * j + 2];
+      if (dx * dx + dy * dy + dz * dz < cldist2) put(j, k);
+    }
+  *nlinks = n;       // (more than cap: nothing beyond cap was written -- call again with room)
+  return TDTK_OK;
+}
+
 }  // extern "C"

@@ -244,6 +244,12 @@ static bool skyline_factor_solve(int n, const int* first, const size_t* off, dou
   return true;
 }
 
+// the same factorisation for a caller that has filled the skyline itself (tdtk_lum_assemble_solve)
+bool skyline_solve(int n, const int* first, const size_t* off, double* sky, const double* B, double* y, double* x)
+{
+  return skyline_factor_solve(n, first, off, sky, B, y, x);
+}
+
 // graphSlam6D::solveSparseCholesky(GraphMatrix*, B): entries with |v| <= drop are not
 // entered into the sparse matrix (graphSlam6D.cc:495); the system is SPD, so a dense
 // Cholesky gives CSparse's answer to rounding.

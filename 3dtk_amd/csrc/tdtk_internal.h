@@ -124,6 +124,8 @@ int align_from_sums(int algo, const tdtk_pair_sums& s, double alignxf[16], doubl
                     std::string& err);
 bool invert_dense(int n, const double* A, double* Ainv);  // LU with partial pivoting
 bool solve_spd_dense(int n, const double* G, const double* B, double* x, double drop);
+// Cholesky of a matrix already in skyline storage (row i: columns first[i] .. i at sky[off[i] - first[i] + k]) + the two substitutions
+bool skyline_solve(int n, const int* first, const size_t* off, double* sky, const double* B, double* y, double* x);
 // the calling host thread's context stream on `device` (a hipStream_t; api.cpp), for library code outside api.cpp
 int ctx_stream(int device, void** stream_out);
 

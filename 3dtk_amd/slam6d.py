@@ -950,16 +950,20 @@ class Graph:
             for a, b in links:
                 self.frm.append(int(a)); self.to.append(int(b))
             return
+        if cldist2 is not None and nodes > 0:       # graph.cc:107-130 in the library (tdtk_graph_links): chain, then (j, k) j-major
+            P = np.array([s.get_rPos() for s in scans[:nodes]], dtype=np.float64).reshape(nodes, 3)
+            cap = nodes * 4
+            while True:
+                frm = np.empty(cap, np.int32); to = np.empty(cap, np.int32); nl = C.c_int(0)
+                check(lib().tdtk_graph_links(int(nodes), dptr(P), float(cldist2), int(loopsize), iptr(frm), iptr(to), cap, C.byref(nl)))
+                if nl.value <= cap:
+                    break
+                cap = nl.value
+            self.frm, self.to = frm[:nl.value].tolist(), to[:nl.value].tolist()
+            self._arrays = (np.ascontiguousarray(frm[:nl.value]), np.ascontiguousarray(to[:nl.value]))
+            return
         for i in range(nodes - 1):                  # graph.cc:115-118
             self.frm.append(i); self.to.append(i + 1)
-        if cldist2 is not None:                     # graph.cc:121-130, (j, k) in row-major order
-            P = np.stack([np.asarray(s.get_rPos(), dtype=np.float64) for s in scans[:nodes]])
-            d = P[None, :, :] - P[:, None, :]
-            d2 = d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1] + d[:, :, 2] * d[:, :, 2]   # Dist2
-            jj, kk = np.nonzero(np.triu((d2 < cldist2), 1) &
-                                ((np.arange(nodes)[None, :] - np.arange(nodes)[:, None]) > loopsize))
-            for j, k in zip(jj.tolist(), kk.tolist()):
-                self.frm.append(j); self.to.append(k)
 
     @classmethod
     def from_netfile(cls, netfile):

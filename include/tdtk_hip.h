@@ -322,6 +322,10 @@ int tdtk_graph_iteration(int backend, tdtk_comm* comm /*nullable*/, int nlinks, 
 int tdtk_elch_graph_balancer(int nvertices, int nedges, const int32_t* from, const int32_t* to, const double* w,
                              int first, int last, double* weights);
 int tdtk_pair_sums_merge(int count, const tdtk_pair_sums* parts, tdtk_pair_sums* out);
+/* Graph::Graph(int nodes, double cldist2, int loopsize) (src/slam6d/graph.cc:107-130), the graph matchGraph6Dautomatic rebuilds
+ * before every LUM round (slam6D.cc:525-532): the chain i -> i + 1, then every pair (j, k) with k - j > loopsize whose scanner
+ * positions rPos [nscans][3] are closer than sqrt(cldist2), j-major.  *nlinks = the number of links; at most cap are written. */
+int tdtk_graph_links(int nscans, const double* rPos, double cldist2, int loopsize, int32_t* from, int32_t* to, int cap, int* nlinks);
 
 /* Scan::transform for many resident scans at once: scan i is moved in place by A1[i] and then by A2[i]
  * (A2 nullable), e.g. Scan::transformToEuler / transformToQuat (scan.cc:1061-1104) = M4inv(transMat) then

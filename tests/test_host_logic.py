@@ -758,6 +758,38 @@ def test_lum_assemble_solve_matches_dense_fill(tdtk):
                                                       capi.dptr(CDall), nscans, capi.dptr(X), None, None))
 
 
+def test_lum_assemble_straight_into_the_skyline_equals_the_dense_fill(tdtk):
+    """Round 5: without G_out / B_out tdtk_lum_assemble_solve puts the link blocks straight into the skyline the solve
+    factors (a block row reaches left to the smallest scan it shares a link with) instead of clearing and re-reading a
+    dense G: X must be the dense path's BIT FOR BIT -- chain graphs, closures across the whole loop, a link given
+    high -> low, links at the fixed scan, entries under the 1e-5 filter inside the blocks."""
+    capi = sys.modules["3dtk_amd._capi"]
+    L = capi.lib()
+    rng = np.random.default_rng(3)
+    for nscans, extra in ((64, 21), (13, 6), (3, 1), (40, 0), (2, 0)):
+        links = [(i, i + 1) for i in range(nscans - 1)]
+        while len(links) < nscans - 1 + extra:
+            a, b = sorted(rng.integers(0, nscans, 2).tolist())
+            if b - a > 1 and (a, b) not in links:
+                links.append((a, b))
+        if nscans == 13:
+            links.append((7, 2))
+        nl = len(links)
+        Cm = np.empty((nl, 36)); CD = rng.normal(0, 50, (nl, 6))
+        for l in range(nl):
+            A = rng.normal(0, 1, (6, 6)); M = A @ A.T * 1e3 + np.eye(6)
+            M[np.abs(M) < 30] *= 1e-8
+            Cm[l] = ((M + M.T) / 2).reshape(36)
+        frm = np.ascontiguousarray([l[0] for l in links], np.int32); to = np.ascontiguousarray([l[1] for l in links], np.int32)
+        N = 6 * (nscans - 1)
+        X1 = np.empty(N); X2 = np.empty(N); G = np.empty((N, N)); B = np.empty(N)
+        capi.check(L.tdtk_lum_assemble_solve(nl, capi.iptr(frm), capi.iptr(to), capi.dptr(Cm), capi.dptr(CD), nscans, capi.dptr(X1), None, None))
+        capi.check(L.tdtk_lum_assemble_solve(nl, capi.iptr(frm), capi.iptr(to), capi.dptr(Cm), capi.dptr(CD), nscans, capi.dptr(X2), capi.dptr(G), capi.dptr(B)))
+        assert np.array_equal(X1, X2), nscans
+        Gf = np.where(np.abs(G) > 1e-5, G, 0.0)
+        assert np.abs(Gf @ X1 - B).max() <= 1e-9 * np.abs(B).max()
+
+
 def test_spd_solve_skyline_storage_shapes(tdtk):
     """solveSparseCholesky's stand-in factors in skyline storage (every row from its first entry above the 1e-5 filter
     to the diagonal).  Shapes that stress the bookkeeping: a chain of 6x6 blocks with far loop closures (envelope
