@@ -40,7 +40,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
-PMC_ROUND = "r04"
+PMC_ROUND = "r05"
 PMC_ROUND_C5 = "r05"
 NUM_SIMD = 1024            # 256 CUs x 4 SIMDs
 

@@ -946,6 +946,13 @@ def test_every_product_kernel_spills_nothing_and_search_kernels_keep_four_waves(
             assert num("VGPRs") <= 128 and num(r"Occupancy \[waves/SIMD\]") >= 4, name
         for lab_only in ("k_search_step", "k_search_coop", "k_slab_bounds", "k_make_fat"):
             assert lab_only not in name, name
+        if "k_search_refillI" in name and "ELb0ELi" in name.split("k_search_refillI")[1][:40]:
+            # round 5: the single-pass kernel as it is timed (not the instrumented instantiation: COUNT = false) filters buckets on
+            # the 16-bit shadow and must keep five waves per SIMD -- its launch is sized for what the runtime reports, and the
+            # FUSE 3 instantiation sits two registers under the step (94 of 96)
+            a = re.search(r"k_search_refillILi128ELi4ELi(16|32)ELi[14]ELb([01])", name)
+            if a and a.group(2) == "0":
+                assert num("VGPRs") <= 96 and num(r"Occupancy \[waves/SIMD\]") >= 5, (name, num("VGPRs"))
         if "k_search_refillI" in name:      # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, PTS, PROBE, FAT, TOP, SHARE, PIPE>: product = 128 threads,
             # FUSE 0 / 3, static slabs, plain walk, no upper levels in LDS, every wave its own slab, hand-outs that wait
             assert re.search(r"ILi128ELi4ELi(16|32)ELi[14]ELb[01]ELi[03]ELb0ELi4ELi0ELb0ELi0ELb0ELb0EEE", name), name
