@@ -1816,6 +1816,34 @@ def test_bench_graphslam_two_ranks_on_this_box(gpu):
     assert int(c["exchange"].split(",")[-1].split()[0]) >= 4          # 1 warm-up + 3 timed + the counting step
 
 
+def test_two_ranks_with_lazy_scan_moves_equal_one_rank_moving_eagerly(gpu):
+    """Round-4 advice: the multi-rank behaviour of the queued scan moves -- ranks queue moves for scans none of their links
+    reads, the link launch of the rank that does read a scan carries its chain out, chains grow over rounds on the others --
+    had only run with one rank.  Two ranks (sharing this box's GPU, gloo carrying the exchange) over scans big enough for the
+    persistent-lane launch (300K points: the launch that applies the moves itself), lazy moves on, five rounds, against ONE
+    process with TDTK_LAZY_MOVES=0 (every scan moved at once): the last round's result bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    common = ["--workload", "graphslam", "--scans", "8", "--points", "300000", "--steps", "4", "--warmup", "1", "--no-rehearsal"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root,
+                         env=dict(os.environ, TDTK_LAZY_MOVES="0"), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2"] + common, cwd=root, env=dict(os.environ, TDTK_BENCH_BACKEND="gloo", TDTK_LAZY_MOVES="1"),
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and a["config"]["links"] == b["config"]["links"] and min(b["links_per_rank"]) >= 1
+    assert a["last_ret"] == b["last_ret"], (a["last_ret"], b["last_ret"])
+
+
 @pytest.mark.parametrize("name", ["one", "two", "identical70", "identical64", "two_values", "axis_ties"])
 def test_normals_degenerate_clouds(tdtk, orc, gpu, name):
     """Clouds on which every split of the ANN tree is a tie-break: a single point, two points, all points identical

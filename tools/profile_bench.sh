@@ -7,7 +7,7 @@
 set -u
 TAG="${1:-prof}"; STEPS="${2:-100}"; WARM="${3:-10}"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-graphslam-base --no-normals --no-small-scans"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-graphslam-base --no-normals --no-small-scans --no-c5"
 echo "$CMD" > "$OUT/command.txt"
 cd /tmp; export TMPDIR=/tmp
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o p -- $CMD > "$OUT/stats.json" 2> "$OUT/stats.err"
