@@ -957,7 +957,7 @@ def c5_search_roofline(k_ms, nq, counts, comp_bytes, pk, bw, pmc_source, what):
     b = {"peak_measured_copy_GBs": bw.get("hbm_copy"),
          "compulsory_hbm": {"bytes": comp_bytes, "GBs": comp_bytes / (k_ms * 1e-3) / 1e9, "frac": comp_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "what": "every record of the tree(s) the launch walks (hot 48 B + exact 64 B per node, 32 B per point slot, "
-                                    "12 B of fp32 shadow per slot) once + every query read and its hit written once"}}
+                                    "6 B of 16-bit shadow per slot -- 12 B of fp32 shadow in the several-links launch) once + every query read and its hit written once"}}
     if traffic:
         b["hbm_traffic_pmc"] = {"bytes": traffic, "GBs": traffic / (k_ms * 1e-3) / 1e9, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "refetch_factor": traffic / comp_bytes,
@@ -1018,7 +1018,8 @@ def bench_c5(args, local):
                       if pmc_kernel(k, pfile) else None)
     # what a search launch must touch at least: the tree's records + the query stream
     slots = info.get("n_point_slots", int(npts * 1.07))
-    tree_bytes = info["n_internal"] * (64 + 48) + slots * (32 + 12)
+    tree_bytes = info["n_internal"] * (64 + 48) + slots * (32 + 6)          # the single-pass kernel filters on the 16-bit shadow (6 B per slot)
+    tree_bytes_links = info["n_internal"] * (64 + 48) + slots * (32 + 12)   # the several-links launch on the fp32 groups (12 B per slot)
     out = {"scans": nscans, "points_per_scan": npts, "max_dist_match2": maxd2, "generation_s": t_gen,
            "what": "configs[4] shape on one GPU: %d of 13 synthetic city scans x %d points (bremen_city is not on the box)" % (nscans, npts),
            "tree": {"internal": info["n_internal"], "leaves": info["n_leaves"], "depth": info["max_depth"], "device_bytes": info["device_bytes"]},
@@ -1109,7 +1110,7 @@ def bench_c5(args, local):
     kl_ms = float(np.mean(k_round))
     kname_l = "k_search (several links per launch)"
     trees_walked = len({f for f, _ in links})
-    comp_l = trees_walked * tree_bytes + nl * npts * (24 + 4 + 60)
+    comp_l = trees_walked * tree_bytes_links + nl * npts * (24 + 4 + 60)
     out["lum_round"] = {"links": nl, "ms": min(t_round), "value": nl * npts / (min(t_round) * 1e-3), "unit": "NN correspondences/s", "last_ret": ret,
                         "link_launch_ms": kl_ms,
                         "roofline": c5_search_roofline(kl_ms, nl * npts, cnt_l, comp_l, pmc_kernel(kname_l, pfile), bw, psrc(kname_l),
