@@ -1348,170 +1348,6 @@ __global__ void __launch_bounds__(256) k_ann_normals(const AnnNode* __restrict__
   }
 }
 
-// ---- round 5: the search and the PCA as two kernels, the search with persistent lanes -------------------------------
-// k_ann_normals above gives a lane one query at a time and a wave lasts as long as its slowest lane, search AND eigen solver:
-// lane efficiency 0.33 (profiles/r05_c5_pmc.json).  k_ann_knn is the same walk -- same nodes, same order, same queue -- with
-// k_search's hand-out: a wave owns a slab of consecutive queries (leaf order), a lane that has finished its query stores the
-// k neighbour positions and takes the wave's next one once refill_at lanes are idle; k_ann_pca then reads the lists back and
-// does normals.cc:64-105 with every lane busy.  40 bytes per point go out and come back: 80 MB per 1M points.
-// Measured (1M, resident calcNormals, tools/r5_ann_sweep.sh): one kernel 2.61-2.67 ms; two kernels with refill at 16 / 32 /
-// 48 idle lanes 2.62-2.67 / 2.64 / 2.57; at 64 (a wave takes its next 64 neighbours-in-leaf-order together) 2.49-2.50.
-// Unlike k_search, lanes that drift apart cost more than idle lanes: 64 neighbouring queries walk nearly the same nodes and
-// a hand-out in the middle breaks that.  So the product hands out whole wavefronts; what is kept of the scheme is the slab
-// (consecutive batches of a wave are neighbours too) and the split from the PCA.  -DANN_REFILL_AT=16 in LABFLAGS: the other.
-#define ANN_DONE 0xFFFFFFFFu
-#ifndef ANN_REFILL_AT
-#define ANN_REFILL_AT 64
-#endif
-template <int KMAX, bool COUNT>
-__global__ void __launch_bounds__(256) k_ann_knn(const AnnNode* __restrict__ nodes, uint32_t root_ref, const KdPoint* __restrict__ pts, uint32_t n,
-                                                 int k, double max_err, const double* __restrict__ bb, uint32_t* __restrict__ spill_ref,
-                                                 double* __restrict__ spill_bd, uint32_t qpw, uint32_t* __restrict__ knn_pos,
-                                                 unsigned long long* __restrict__ cnt, int refill_at)
-{
-  unsigned c_split = 0, c_leaf = 0;
-  __shared__ uint32_t s_ref[ANN_LDS_STACK][256];
-  __shared__ double s_bd[ANN_LDS_STACK][256];
-  const uint32_t T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, tx = threadIdx.x, lane = tx & 63u;
-  const double blo[3] = {bb[0], bb[1], bb[2]}, bhi[3] = {bb[3], bb[4], bb[5]};
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  uint32_t next_q = wave * qpw, end_q = next_q + qpw;
-  if (next_q > n) next_q = n;
-  if (end_q > n) end_q = n;
-  double q[3] = {0, 0, 0}, key[KMAX], bd = 0.0;
-  uint32_t info[KMAX], cur = ANN_DONE, qi = 0;
-  int sp = 0;
-  bool have = false;
-#pragma unroll
-  for (int j = 0; j < KMAX; j++) { key[j] = 0.0; info[j] = 0u; }
-  for (;;) {
-    const bool idle = (cur == ANN_DONE);
-    if (idle && have) {                         // retire: the list, nearest first (pr_queue_k.h: ascending keys)
-#pragma unroll
-      for (int j = 0; j < KMAX; j++)
-        if (j >= KMAX - k) knn_pos[(size_t)qi * (uint32_t)k + (uint32_t)(j - (KMAX - k))] = info[j];
-      have = false;
-    }
-    const unsigned long long idlem = __ballot(idle), activem = __ballot(!idle);
-    if ((activem == 0 || __popcll(idlem) >= refill_at) && next_q < end_q) {
-      const uint32_t mine = next_q + (uint32_t)__popcll(idlem & ((1ull << lane) - 1ull));
-      if (idle && mine < end_q) {
-        const KdPoint qp = pts[mine];
-        q[0] = qp.x; q[1] = qp.y; q[2] = qp.z;
-#pragma unroll
-        for (int j = 0; j < KMAX; j++) { key[j] = (j < KMAX - k) ? -1.0 : DBL_MAX; info[j] = 0xFFFFFFFFu; }
-        bd = 0.0;                                // annBoxDistance (kd_util.cpp:127-150)
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          if (q[d] < blo[d]) { const double t = blo[d] - q[d]; bd = bd + t * t; }
-          else if (q[d] > bhi[d]) { const double t = q[d] - bhi[d]; bd = bd + t * t; }
-        }
-        cur = root_ref; sp = 0; qi = mine; have = true;
-      }
-      next_q += (uint32_t)__popcll(idlem);
-    }
-    if (__ballot(cur != ANN_DONE) == 0) {
-      if (next_q >= end_q) break;
-      continue;
-    }
-    while (!(cur & A_LEAF)) {                      // ANNkd_split::ann_search (kd_search.cpp:128-170); ANN_DONE has the leaf bit
-      if (COUNT) ++c_split;
-      const AnnNode nd = nodes[cur & A_VAL];
-      const uint32_t cd = nd.c0 >> 30;
-      const double qd = (cd == 0) ? q[0] : ((cd == 1) ? q[1] : q[2]);
-      const double cut_diff = qd - nd.cut_val;
-      const bool low = cut_diff < 0;
-      double box_diff = low ? (nd.lo - qd) : (qd - nd.hi);
-      if (box_diff < 0) box_diff = 0;
-      const double fbd = bd + (cut_diff * cut_diff - box_diff * box_diff);
-      const uint32_t c0 = nd.c0 & (A_LEAF | A_VAL), c1 = nd.c1;
-      const uint32_t far = low ? c1 : c0;
-      if (fbd * max_err < key[KMAX - 1]) {
-        if (sp < ANN_LDS_STACK) { s_ref[sp][tx] = far; s_bd[sp][tx] = fbd; }
-        else { spill_ref[(size_t)(sp - ANN_LDS_STACK) * T + tid] = far; spill_bd[(size_t)(sp - ANN_LDS_STACK) * T + tid] = fbd; }
-        sp++;
-      }
-      cur = low ? c0 : c1;
-    }
-    if (cur != ANN_DONE) {                         // ANNkd_leaf::ann_search, one point (kd_search.cpp:177-210)
-      const uint32_t pos = cur & A_VAL;
-      if (COUNT) ++c_leaf;
-      const KdPoint p = pts[pos];
-      const double t0 = q[0] - p.x, t1 = q[1] - p.y, t2 = q[2] - p.z;
-      const double dist = (t0 * t0 + t1 * t1) + t2 * t2;
-      if (!(dist > key[KMAX - 1])) {               // ANNmin_k::insert (pr_queue_k.h:100-114)
-        double ck = dist;
-        uint32_t ci = pos;
-        bool shifting = false;
-#pragma unroll
-        for (int j = 0; j < KMAX; j++) {
-          shifting = shifting || (key[j] > ck);
-          if (shifting) {
-            const double tk = key[j]; key[j] = ck; ck = tk;
-            const uint32_t ti = info[j]; info[j] = ci; ci = ti;
-          }
-        }
-      }
-      cur = ANN_DONE;
-      while (sp > 0) {
-        sp--;
-        uint32_t r; double b2;
-        if (sp < ANN_LDS_STACK) { r = s_ref[sp][tx]; b2 = s_bd[sp][tx]; }
-        else { r = spill_ref[(size_t)(sp - ANN_LDS_STACK) * T + tid]; b2 = spill_bd[(size_t)(sp - ANN_LDS_STACK) * T + tid]; }
-        if (b2 * max_err < key[KMAX - 1]) { cur = r; bd = b2; break; }
-      }
-    }
-  }
-  if (COUNT && cnt) {
-    unsigned long long a = c_split, b = c_leaf;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&cnt[0], a); atomicAdd(&cnt[1], b); }
-  }
-}
-
-// normals.cc:64-105 for every point from its neighbour list (positions in leaf order, nearest first): mean, covariance in
-// list order, newmat's eigen solver, the flip towards the sensor -- the arithmetic of k_ann_normals' second half
-__global__ void __launch_bounds__(256) k_ann_pca(const KdPoint* __restrict__ pts, uint32_t n, int k, const uint32_t* __restrict__ knn_pos, double rx,
-                                                 double ry, double rz, double* __restrict__ normals, int32_t* __restrict__ knn_out)
-{
-  const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qi >= n) return;
-  const KdPoint qp = pts[qi];
-  const double q[3] = {qp.x, qp.y, qp.z};
-  const uint32_t* lst = knn_pos + (size_t)qi * (uint32_t)k;
-  double mean[3] = {0.0, 0.0, 0.0};
-  for (int j = 0; j < k; j++) {
-    const KdPoint p = pts[lst[j]];
-    mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
-    if (knn_out) knn_out[(size_t)qp.orig * k + j] = p.orig;
-  }
-  mean[0] /= k; mean[1] /= k; mean[2] /= k;
-  const double sc = 1.0 / k;
-  double z[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int j = 0; j < k; j++) {
-    const KdPoint p = pts[lst[j]];
-    const double x[3] = {p.x - mean[0], p.y - mean[1], p.z - mean[2]};
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c <= r; c++) z[r][c] += (sc * x[c]) * x[r];
-  }
-  z[0][1] = z[1][0]; z[0][2] = z[2][0]; z[1][2] = z[2][1];
-  double D[3];
-  eigen3_newmat(z, D);
-  double nv[3] = {z[0][0], z[1][0], z[2][0]};
-  double pv[3] = {q[0] - rx, q[1] - ry, q[2] - rz};
-  const double pl = 1.0 / __dsqrt_rn((pv[0] * pv[0] + pv[1] * pv[1]) + pv[2] * pv[2]);   // "v / norm" is v * (1 / norm) in newmat
-  pv[0] *= pl; pv[1] *= pl; pv[2] *= pl;
-  const double angle = (nv[0] * pv[0] + nv[1] * pv[1]) + nv[2] * pv[2];
-  if (angle < 0) { nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0; }
-  const double nl = 1.0 / __dsqrt_rn((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
-  normals[3 * (size_t)qp.orig] = nv[0] * nl;
-  normals[3 * (size_t)qp.orig + 1] = nv[1] * nl;
-  normals[3 * (size_t)qp.orig + 2] = nv[2] * nl;
-}
-
 uint32_t ann_search_threads(size_t n)
 {
   const size_t blocks = (n + 255) / 256;
@@ -1523,37 +1359,13 @@ size_t ann_spill_entries(size_t n, uint32_t max_depth)
   return d * (size_t)ann_search_threads(n);
 }
 
-// knn_tmp: n * k words of scratch (the neighbour lists between the two kernels); null: the one-kernel form (k_ann_normals)
 hipError_t launch_ann_normals(const AnnNode* nodes, uint32_t root_ref, const KdPoint* pts, size_t n, int k, double eps,
                               const double* d_bb, const double rPos[3], uint32_t* spill_ref, double* spill_bd,
-                              uint32_t max_depth, double* d_normals, int32_t* d_knn, unsigned long long* d_cnt, hipStream_t s,
-                              uint32_t* knn_tmp)
+                              uint32_t max_depth, double* d_normals, int32_t* d_knn, unsigned long long* d_cnt, hipStream_t s)
 {
   const uint32_t T = ann_search_threads(n);
   const double max_err = (1.0 + eps) * (1.0 + eps);    // ANN_POW(1.0 + eps), kd_search.cpp:108
   const dim3 grid(T / 256), block(256);
-  if (knn_tmp) {
-    // a wave's slab: the queries shared out evenly over the launch's waves, whole wavefronts of them
-    const uint32_t waves = T / 64;
-    uint32_t qpw = (uint32_t)((n + waves - 1) / waves);
-    qpw = (qpw + 63u) & ~63u;
-    const int refill_at = ANN_REFILL_AT;
-#define ANN_KNN(KM)                                                                                                   \
-    do {                                                                                                              \
-      if (d_cnt) hipLaunchKernelGGL((k_ann_knn<KM, true>), grid, block, 0, s, nodes, root_ref, pts, (uint32_t)n, k, max_err, d_bb, spill_ref, \
-                                    spill_bd, qpw, knn_tmp, d_cnt, refill_at);                                        \
-      else hipLaunchKernelGGL((k_ann_knn<KM, false>), grid, block, 0, s, nodes, root_ref, pts, (uint32_t)n, k, max_err, d_bb, spill_ref, \
-                              spill_bd, qpw, knn_tmp, d_cnt, refill_at);                                              \
-    } while (0)
-    if (k <= 10) ANN_KNN(10);
-    else if (k <= 16) ANN_KNN(16);
-    else if (k <= 32) ANN_KNN(32);
-    else return hipErrorInvalidValue;
-#undef ANN_KNN
-    hipLaunchKernelGGL(k_ann_pca, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, pts, (uint32_t)n, k, knn_tmp, rPos[0], rPos[1], rPos[2],
-                       d_normals, d_knn);
-    return hipGetLastError();
-  }
 #define ANN_LAUNCH(KM)                                                                                                \
   do {                                                                                                                \
     if (d_cnt)                                                                                                        \

@@ -128,7 +128,6 @@ struct Ctx {
   void* h_build = nullptr;  // 64 KB, pinned: the tree build's looks at the device (BuildSide::h_pin)
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
   size_t h_stage_cap = 0;
-  DevBuf d_knnpos;                      // calcNormals: the neighbour lists between the k-NN and the PCA kernel
   DevBuf d_mask, d_skip;                // -R passes: the keep-mask (bits, caller order) and what the search reads (bytes, sorted order)
   std::vector<unsigned char> h_mask;
   DevBuf d_hash;                        // tdtk_icp_index_hashes: one 64-bit word per iteration of the last tdtk_icp_match
@@ -1699,19 +1698,9 @@ static int normals_on_device(Ctx* c, const double* d_xyz, size_t n, int k, const
   if ((rc = c->ws[WS_OVF_M2].ensure((spill + 1) * sizeof(double)))) return rc;
   unsigned long long* d_cnt = nullptr;
   if (c->counting) { d_cnt = c->d_counters.as<unsigned long long>() + 4; c->counted_ann_queries += n; }
-  // the neighbour lists between the search and the PCA kernel (round 5: two kernels, the search with persistent lanes;
-  // TDTK_ANN_SPLIT=0 in the lab library: the one-kernel form)
-  uint32_t* knn_tmp = nullptr;
-  {
-    static const bool one_kernel = [] { const char* e = lab_env("TDTK_ANN_SPLIT"); return e && e[0] == '0'; }();
-    if (!one_kernel) {
-      if ((rc = c->d_knnpos.ensure(n * (size_t)k * sizeof(uint32_t)))) return rc;
-      knn_tmp = c->d_knnpos.as<uint32_t>();
-    }
-  }
   HIPCHK(hipEventRecord(c->e4, s));
   HIPCHK(launch_ann_normals(nodes, r.root_ref, pts, n, k, eps, d_bb, rPos, c->ws[WS_OVF_REF].as<uint32_t>(),
-                            c->ws[WS_OVF_M2].as<double>(), r.max_depth, d_normals, d_knn, d_cnt, s, knn_tmp));
+                            c->ws[WS_OVF_M2].as<double>(), r.max_depth, d_normals, d_knn, d_cnt, s));
   HIPCHK(hipEventRecord(c->e5, s));
   c->ev4_pending = true;
   return TDTK_OK;

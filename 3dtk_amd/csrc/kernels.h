@@ -234,7 +234,7 @@ size_t ann_spill_entries(size_t n, uint32_t max_depth);
 hipError_t launch_ann_normals(const AnnNode* nodes, uint32_t root_ref, const KdPoint* pts, size_t n, int k, double eps,
                               const double* d_bb, const double rPos[3], uint32_t* spill_ref, double* spill_bd,
                               uint32_t max_depth, double* d_normals, int32_t* d_knn, unsigned long long* d_cnt,
-                              hipStream_t s, uint32_t* knn_tmp = nullptr);
+                              hipStream_t s);
 
 hipError_t launch_pp_error(const AccumArgs& a, uint32_t grid, double scale, double* d_partial, double* d_out, hipStream_t s);
 hipError_t launch_found_flags(const int* kpos, const int32_t* order, size_t n, uint32_t* flags, hipStream_t s);

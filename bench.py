@@ -696,20 +696,19 @@ def bench_icp(args, rank, world, local):
         kn_ms = float(np.mean(k_n[1:]))
         # algorithmic bytes per point: the point in (24) + 32 B per splitting node + 24 B per leaf point tested +
         # the k neighbours gathered for mean / covariance (24 B each) + the normal out (24)
-        # (round 5: two kernels, k_ann_knn then k_ann_pca, the k positions of a point written by the first and read by the second)
-        bp = 24.0 + 32.0 * a_split / a_q + 24.0 * a_leaf / a_q + 2 * 4.0 * 10 + 24.0 * 10 + 24.0
+        bp = 24.0 + 32.0 * a_split / a_q + 24.0 * a_leaf / a_q + 24.0 * 10 + 24.0
         ach = bp * n / (kn_ms * 1e-3) / 1e9
-        pk = None   # no counters of this pair at 1M this round (the 10M pair: c5_shape_1gpu.normals)
+        pk = pmc_kernel("k_ann_normals<10>", "r01_normals_pmc.json")   # tools/profile_normals.sh (the kernel is unchanged since)
         out["normals_1gpu"] = {"value": n / min(t_n), "unit": "points/s", "ms": min(t_n) * 1e3, "points": n, "k": 10, "eps": 1.0,
                                "what": "tdtk_scan_calc_normals on the resident scan: ANN-tree build, approximate 10-NN, "
                                        "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat",
-                               "roofline": {"bound": "hbm", "kernel": "k_ann_knn + k_ann_pca", "achieved": ach, "peak": HBM_PEAK_GBS,
+                               "roofline": {"bound": "hbm", "kernel": "k_ann_normals", "achieved": ach, "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pk),
                                             "kernel_ms": kn_ms, "bytes_per_point": bp,
                                             "visits_per_point": {"split_nodes": a_split / a_q, "leaf_points": a_leaf / a_q},
                                             "whole_call_ms": min(t_n) * 1e3,
-                                            "note": "the k-NN and the PCA kernel (kernel_ms: both, one pair of events); the ANN-tree "
-                                                    "build (~140 small launches) is the rest of the call"}}
+                                            "note": "the k-NN + PCA kernel alone; the ANN-tree build (~250 small launches) "
+                                                    "is the rest of the call"}}
         if not args.no_cpu:
             from oracle import orc as _orc
             ns = min(n, 100000)
@@ -1084,13 +1083,10 @@ def bench_c5(args, local):
         b.calcNormals()
         a_split, a_leaf, a_q = vc.read_ann()
     kn_ms = float(np.mean(k_n[1:]))
-    bp = 24.0 + 32.0 * a_split / max(1, a_q) + 24.0 * a_leaf / max(1, a_q) + 2 * 4.0 * 10 + 24.0 * 10 + 24.0
-    pk1, pk2 = pmc_kernel("k_ann_knn<10>", pfile), pmc_kernel("k_ann_pca", pfile)
-    pkn = None
-    if pk1 and pk2:   # the pair's counters added up (kernel_ms is the pair's time too)
-        pkn = {c: pk1[c] + pk2[c] for c in ("FETCH_SIZE_KiB", "WRITE_SIZE_KiB") if c in pk1 and c in pk2}
+    bp = 24.0 + 32.0 * a_split / max(1, a_q) + 24.0 * a_leaf / max(1, a_q) + 24.0 * 10 + 24.0
+    pkn = pmc_kernel("k_ann_normals<10>", pfile)
     out["normals"] = {"value": npts / (min(t_n) * 1e-3), "unit": "points/s", "ms": min(t_n), "kernel_ms": kn_ms, "ann_tree_build_ms": min(t_n) - kn_ms,
-                      "roofline": {"bound": "hbm", "kernel": "k_ann_knn + k_ann_pca", "achieved": bp * npts / (kn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "roofline": {"bound": "hbm", "kernel": "k_ann_normals", "achieved": bp * npts / (kn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": bp * npts / (kn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pkn), "bytes_per_point": bp,
                                    "visits_per_point": {"split_nodes": a_split / max(1, a_q), "leaf_points": a_leaf / max(1, a_q)}},
                       "what": "tdtk_scan_calc_normals on the resident 10M-point scan (ANN-tree build + approximate 10-NN + PCA)"}

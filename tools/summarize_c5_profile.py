@@ -43,8 +43,6 @@ def label_rows(rows):
                            ("k_search [icp6D::match at 10M]" if groups == 1 else "k_search (other)"))
         elif n.startswith("k_ann_normals<"):
             out.append("k_ann_normals_count(instrumented, not timed)" if "true" in n else "k_ann_normals<10>")
-        elif n.startswith("k_ann_knn<"):
-            out.append("k_ann_knn_count(instrumented, not timed)" if "true" in n else "k_ann_knn<10>")
         elif n.startswith("k_search"):
             out.append("k_search (small batches)")
         else:

@@ -11,8 +11,6 @@ def short(n):
     n = n.split("(")[0].replace("void ", "").replace("tdtk::", "")
     if n.startswith("k_ann_normals<"):
         return "k_ann_normals_count(instrumented, not timed)" if "true" in n else "k_ann_normals"
-    if n.startswith("k_ann_knn<"):
-        return "k_ann_knn_count(instrumented, not timed)" if "true" in n else "k_ann_knn"
     if n.startswith("k_search_refill<"):
         a = [t.strip() for t in n[len("k_search_refill<"):].split(">")[0].split(",")]
         # <BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN>
