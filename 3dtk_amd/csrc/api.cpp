@@ -103,6 +103,9 @@ struct Lane {
   QueueCtr qc;
   DevBuf kpos, part, ovf_m2, ovf_ref;
   DevBuf moved;      // batched link passes: this link's own copy of a scan another link of the launch is moving (lazy moves)
+  // batched link passes: whose hits kpos holds (handle numbers of the tree and the scan, queries) -- the next pass of the SAME
+  // link at this position starts every search from its previous hit (SearchArgs::warm)
+  uint64_t k_tree = 0, k_scan = 0; size_t k_n = 0;
   ~Lane() { if (s && owns) (void)hipStreamDestroy(s); }
 };
 
@@ -312,7 +315,12 @@ static int stage_pinned(Ctx* c, const void* src, size_t bytes, void** out)
 // ------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------
+// every tree / scan handle of the process has a number of its own: what "the same tree, the same scan as last time" is tested
+// with where a stale answer would be an out-of-range read (a freed handle's address can come back)
+static std::atomic<uint64_t> g_handle_uid{1};
+
 struct tdtk_tree {
+  const uint64_t uid = g_handle_uid.fetch_add(1, std::memory_order_relaxed);
   int device = 0;
   size_t M = 0;
   int bucket = 0;
@@ -336,6 +344,7 @@ struct tdtk_tree {
 };
 
 struct tdtk_scan {
+  const uint64_t uid = g_handle_uid.fetch_add(1, std::memory_order_relaxed);
   int device = 0;
   size_t N = 0;
   double *x = nullptr, *y = nullptr, *z = nullptr, *nx = nullptr, *ny = nullptr, *nz = nullptr;
@@ -2532,7 +2541,11 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   while ((int)c->slots.size() < G) c->slots.emplace_back(new Lane);
   for (int g = 0; g < G; g++) {          // every buffer at its final size before anything is enqueued
     Lane* sl = c->slots[g].get();
-    if ((rc = sl->kpos.ensure(maxN * sizeof(int)))) return rc;
+    {
+      const void* before = sl->kpos.p;
+      if ((rc = sl->kpos.ensure(maxN * sizeof(int)))) return rc;
+      if (sl->kpos.p != before) sl->k_tree = sl->k_scan = 0;
+    }
     {
       size_t rows = accum_grid(maxN);
       if (fuse_links) {
@@ -2572,6 +2585,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   // Lazy scan moves (tdtk_scan::pending): the persistent-lane launch carries them out itself; the small-batch kernels do
   // not, their scans are moved first.  Everything that can fail is done before the first scan's state changes.
   const bool lazy = search_multi_class(maxN) == 20;
+  const bool link_warm = [] { const char* e = lab_env("TDTK_LINK_WARM"); return !(e && e[0] == '0'); }();
   size_t nmat_max = 0;
   if (!lazy) {
     if ((rc = scans_settle(c, second, nlinks))) return rc;
@@ -2645,6 +2659,10 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       sa.x = data->x; sa.y = data->y; sa.z = data->z;
       sa.n = data->N; sa.inv = inv; sa.has_inv = 1; sa.maxd2 = maxd2;
       sa.kpos = sl->kpos.as<int>();
+      // the previous pass of this very link left its hits here (graph-SLAM rounds repeat their links): each search starts from
+      // its previous hit, a point of this tree whatever the scans have done since (k_search's warm start; same index, same d2)
+      sa.warm = (link_warm && sl->k_tree == t->uid && sl->k_scan == data->uid && sl->k_n == data->N) ? 1 : 0;
+      sl->k_tree = t->uid; sl->k_scan = data->uid; sl->k_n = data->N;
       const int need = (int)t->info.max_depth - 1 - search_lds_depth();
       if (need > 0) { sa.ovf_m2 = sl->ovf_m2.as<double>(); sa.ovf_ref = sl->ovf_ref.as<uint32_t>(); }
       if (c->counting) sa.counters = c->d_counters.as<unsigned long long>();
