@@ -3850,11 +3850,24 @@ static bool pipe_on()
 #endif
 // waves of the single-pass persistent-lane kernel (the FUSE 3 instantiation the ICP loop runs) a SIMD holds at once, by the
 // runtime's own occupancy calculation for this code object (registers, LDS); 4 if it cannot say
+// (round 5, second step: SIX.  The compiler is asked for six waves per SIMD -- __launch_bounds__' second argument, 80 VGPRs --
+// for the instantiations the product's loops run (REFILL_WPS); what it gives up for that are the three 8-byte values of the
+// stack's overflow area, stored once per wave and read back only where a walk overflows the LDS levels.  Same box, same
+// process order, 1M-vs-1M at the driver's arguments: k_search 0.1770 / 0.1782 ms at five waves, 0.1677 / 0.1685 at six;
+// forced to seven (72 VGPRs, 40 spilled) 0.1781.  tools/r5_nobox_ab.sh)
+// (the several-links launch with a link's sums inside -- graph-SLAM, 128 VGPRs -- stays at four: asked for five the compiler
+// spills 23 registers inside the loops, 84 links 10.0 -> 11.6 ms; LABFLAGS=-DTDTK_MULTI_WPS=5, tools/r5_multi_wps.sh)
+#ifndef TDTK_MULTI_WPS
+#define TDTK_MULTI_WPS 4
+#endif
+constexpr int MULTI_WPS = TDTK_MULTI_WPS;
+template <bool COUNT, int FUSE>
+constexpr int REFILL_WPS = COUNT ? 4 : ((FUSE == 0 || FUSE == 3) ? 6 : 1);
 static int refill_waves_per_simd()
 {
   static const int w = [] {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(&k_search_refill<128, 4, 16, 1, false, 3, false>), 128, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(&k_search_refill<128, 4, 16, REFILL_WPS<false, 3>, false, 3, false>), 128, 0) != hipSuccess) {
       (void)hipGetLastError();
       return 4;
     }
@@ -3977,14 +3990,14 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 #ifdef TDTK_LAB
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
 #endif
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
     default:
 #ifdef TDTK_LAB
       if ((FUSE == 0 || FUSE == 3) && pipe_on() && !a.skip)
         hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, (FUSE == 3 ? 3 : 0), false, 4, 0, false, 0, false, true>), dim3(nb), dim3(128), occ_lds, s, a);
       else
 #endif
-      hipLaunchKernelGGL((k_search_refill<128, 4, 16, (COUNT ? 4 : 1), COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
+      hipLaunchKernelGGL((k_search_refill<128, 4, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
       break;
   }
   if (kLab && a.trace) {
@@ -4435,7 +4448,7 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
         if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
         else
 #endif
-        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, MULTI_WPS, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
         else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
@@ -4444,7 +4457,7 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
         if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
         else
 #endif
-        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, MULTI_WPS, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
         else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
         else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
