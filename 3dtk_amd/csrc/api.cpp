@@ -327,6 +327,7 @@ struct tdtk_tree {
   TreeDev dev{};
   void *d_nodes = nullptr, *d_pts = nullptr, *d_leaf = nullptr, *d_r = nullptr, *d_hot = nullptr, *d_grp = nullptr, *d_fat = nullptr;
   void* d_q16 = nullptr;     // 16-bit shadow of the padded buckets (TreeDev::q16), 6 bytes per slot + 128 of slack
+  void* d_split = nullptr;   // { splitval, children } of every internal node, 16 bytes (TreeDev::split): inside d_hot's allocation
   double q_lo[3] = {0, 0, 0}, q_scale = 0.0;
   size_t Mp = 0;   // slots of d_pts: M, or 4 * groups once the buckets are padded to whole groups (tree_pad_buckets)
   double bbmin[3], bbmax[3], centre[3];
@@ -668,8 +669,12 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   for (int a = 0; a < 3; a++) am = std::max(am, std::max(std::fabs(t->bbmin[a]), std::fabs(t->bbmax[a])));
   t->dev.absmax = (float)std::min(am * 1.0000002, 3.0e38);
   if (t->info.n_internal) {
-    HIPCHK(handle_malloc(&t->d_hot, t->info.n_internal * sizeof(KdHot)));
-    HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream));
+    // (+ the split halves on their own behind them, 16 bytes per node, for the visits that defer the quick check: ONE allocation,
+    // so that a lane picks between the two by an offset from the same base)
+    HIPCHK(handle_malloc(&t->d_hot, t->info.n_internal * (sizeof(KdHot) + sizeof(double2))));
+    t->d_split = static_cast<char*>(t->d_hot) + t->info.n_internal * sizeof(KdHot);
+    HIPCHK(launch_make_hot(static_cast<const KdNode*>(t->d_nodes), t->info.n_internal, static_cast<KdHot*>(t->d_hot), c->stream,
+                           static_cast<double2*>(t->d_split)));
 #ifdef TDTK_LAB
     // ... and, on request only, the two-level records (a node with its children's hot parts): two tree levels per round
     // trip are a measured negative both for the persistent-lane kernel (TDTK_FAT_NODES=1) and for the lane-group kernels of
@@ -699,13 +704,14 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);
   t->dev.grp = static_cast<const float4*>(t->d_grp);
   t->dev.q16 = static_cast<const uint32_t*>(t->d_q16);
+  t->dev.split = static_cast<const double2*>(t->d_split);
   for (int a = 0; a < 3; a++) t->dev.q_lo[a] = t->q_lo[a];
   t->dev.q_scale = t->q_scale;
   t->dev.leaf_tab = static_cast<const LeafEntry*>(t->d_leaf);
   t->dev.node_r = static_cast<const double*>(t->d_r);
   t->dev.cmask = (t->dev.cb >= 32) ? 0xFFFFFFFFu : ((1u << t->dev.cb) - 1u);
   t->info.n_points = M;
-  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + (t->d_fat ? sizeof(KdFat) : 0) + sizeof(double)) + t->Mp * sizeof(KdPoint) +
+  t->info.device_bytes = t->info.n_internal * (sizeof(KdNode) + sizeof(KdHot) + sizeof(double2) + (t->d_fat ? sizeof(KdFat) : 0) + sizeof(double)) + t->Mp * sizeof(KdPoint) +
                          (t->d_grp ? t->Mp / 4 * 48 : 0) + (t->d_q16 ? t->Mp / 4 * 24 + 128 : 0) +
                          (t->d_leaf ? t->info.n_leaves * sizeof(LeafEntry) : 0);
   return TDTK_OK;
@@ -1119,6 +1125,20 @@ static hipError_t await_sums(const double* h_pin, hipStream_t s)
 }
 
 // search + accumulate over a resident scan.  acc_out (host, ACC_TOTAL) receives raw columns.
+// SearchArgs::tie (kernels.hip, "the quick check deferred"): the reference's quick check computes a = max_i(fabs(q_i - c_i) - h_i)
+// with c = 0.5 * (min + max), h = 0.5 * (max - min) of the node's points; for a point p of the node and a query within the
+// search radius R of it, a <= |q - p|_inf + E with E <= 8 * 2^-53 * (|min| + |max| + |q|) <= 2^-50 * (3 absmax + R), so a node
+// the check cuts off (a * a >= closest_d2) holds only points with d2 >= closest_d2 - (2 E R + E^2).  Four times that, for the
+// roundings of the comparison itself and of this expression; TDTK_DEFER_CHECK=0: every visit makes the check.
+static double search_tie(const tdtk_tree* t, double maxd2)
+{
+  static const bool off = [] { const char* e = getenv("TDTK_DEFER_CHECK"); return e && e[0] == '0'; }();
+  if (off || !t->d_split || !(maxd2 > 0.0) || !std::isfinite(maxd2)) return 0.0;
+  const double R = std::sqrt(maxd2), E = std::ldexp(3.0 * (double)t->dev.absmax + R, -50);
+  const double tie = 4.0 * (2.0 * E * R + E * E);
+  return (std::isfinite(tie) && tie < 1e-3 * maxd2) ? tie : 0.0;
+}
+
 static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, int pmode,
                      double maxd2, unsigned want, const double* lum_D, const double* pending,
                      bool do_search, double* acc_out, double shift_out[3], bool warm = false, const unsigned char* skip = nullptr)
@@ -1154,6 +1174,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.kpos = c->ws[WS_KPOS].as<int>();
     sa.skip = skip;
     sa.warm = (warm && pmode != 1) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
+    sa.tie = sa.warm ? search_tie(model, maxd2) : 0.0;
     {
       // ... and WS_COST how many buckets each of its queries visited then: the persistent-lane kernel hands a wave's slab
       // out with the expensive queries first (TDTK_COST_ORDER=0: in slab order)
@@ -1470,10 +1491,11 @@ int tdtk_visit_counters(int device, uint64_t out[8])
   out[6] = c->counted_ann_queries;
   if (!c->d_counters.p) return TDTK_OK;
   HIPCHK(hipDeviceSynchronize());   // link passes run on auxiliary streams
-  unsigned long long h[6];
+  unsigned long long h[8];
   HIPCHK(hipMemcpy(h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost));
   for (int k = 0; k < 3; k++) out[k] = h[k];
   out[4] = h[4]; out[5] = h[5];
+  out[7] = h[7];
   return TDTK_OK;
 }
 

@@ -31,6 +31,9 @@ struct TreeDev {
   const uint32_t* q16;
   double q_lo[3];             // grid origin = the root box's lower corner
   double q_scale;             // cells per unit
+  // the split half of every internal node on its own, 16 bytes { splitval, c1, c2 } (round 5; kernels.hip, "the quick check
+  // deferred"): what a visit needs when it does not make the quick check.  Same indexing as hot / nodes.
+  const double2* split;
 };
 
 struct SearchArgs {
@@ -42,6 +45,11 @@ struct SearchArgs {
   Mat4 inv;      // M4inv(Source->dalignxf): world -> tree frame
   int has_pending, has_inv;
   double maxd2;
+  // warm, the persistent-lane single pass only: tie > 0 -- a query that starts from a previous hit walks WITHOUT the quick check of
+  // the divergent visits (16 bytes per visit instead of 48) and is searched again, cold and exactly, if it ever accepted a point
+  // that improved its closest_d2 by no more than `tie` (kernels.hip, "the quick check deferred"); the warm radius is the previous
+  // hit's d2 + 2 tie.  0: every visit makes the quick check.
+  double tie;
   int warm;     // kpos holds the previous pass's hits of the SAME queries in the SAME tree: start each search with
                 // a radius just above the distance to that point (see warm_radius in kernels.hip)
   int* kpos;    // out: position of the hit in the leaf-ordered point array, or -1
@@ -157,7 +165,7 @@ size_t slab_bounds_bytes(size_t n);
 hipError_t launch_slab_bounds(const unsigned char* cost, size_t n, void* buf, const uint32_t** bounds_out, hipStream_t s);
 #endif
 hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* moved_bytes, hipStream_t s);
-hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s);
+hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s, double2* split = nullptr);
 hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_t s);
 // bucket groups (kernels.hip, "bucket groups"): mark -> exclusive scan of ng_at[0..M] (launch_scan_u32) -> fill
 hipError_t launch_pad_mark(const KdNode* nodes, size_t n_internal, const LeafEntry* leaf_tab, uint32_t cb, uint32_t cmask, uint32_t* ng_at,

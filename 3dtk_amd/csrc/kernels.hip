@@ -413,7 +413,9 @@ static __device__ __forceinline__ double warm_radius_kp(const SearchArgs& a, con
       const double pzz = gload<double>(reinterpret_cast<const char*>(a.T.pts), po + 16);
       const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pzz - qz;
       const double d = dx * dx + dy * dy + dz * dz;
-      const double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
+      double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
+      const double um = d + 2.0 * a.tie;                                  // (SearchArgs::tie; 0: one ulp, as before)
+      if (um > up) up = um;
       if (up < best) best = up;
     }
   }
@@ -545,7 +547,7 @@ __device__ __forceinline__ int q16_index(const double v, const double lo, const 
 // No proof available (radius beyond the grid, thresholds not finite): every slot of the bucket is a survivor.
 __device__ __forceinline__ void bucket_scan_q16(const char* __restrict__ t_q16, const char* __restrict__ pb, const int start, const int count,
                                                 const uint32_t o0, const BoxF32& bx, const uint32_t qxy, const uint32_t qzz, const bool q_in,
-                                                const double qx, const double qy, const double qz, double& best, int& bk)
+                                                const double qx, const double qy, const double qz, double& best, int& bk, const double tie, bool& thin)
 {
   typedef short v2s __attribute__((ext_vector_type(2)));
   const uint32_t go = (uint32_t)start * 6u;      // 6 bytes per slot; start is a multiple of 4: 8-byte aligned
@@ -601,7 +603,7 @@ __device__ __forceinline__ void bucket_scan_q16(const char* __restrict__ t_q16, 
     const double pz = gload<double>(pb, oj + 16);
     const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pz - qz;
     const double dj = dx * dx + dy * dy + dz * dz;
-    if (dj < best) { best = dj; bk = (int)(oj >> 5); }
+    if (dj < best) { thin = thin || (best - dj <= tie); best = dj; bk = (int)(oj >> 5); }
   }
 }
 
@@ -1543,7 +1545,7 @@ __device__ unsigned long long g_wtrace[3];     // (never touched: a.trace is a l
 // the body of k_search_refill for workgroup `bid` of the `nb` that search one batch of queries (the kernel proper and
 // the several-batches-in-one-launch kernel below share it)
 template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, bool ORDER = !DYN, int PTS = 4, int PROBE = 0, bool FAT = false,
-          int ORD_MAX = 256, bool LAZY = false, int TOP = 0, bool SHARE = false, bool PIPE = false>
+          int ORD_MAX = 256, bool LAZY = false, int TOP = 0, bool SHARE = false, bool PIPE = false, bool DEFER = false>
 __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   __shared__ uint4 lds_stk[SD][BLOCK];
@@ -1832,7 +1834,26 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     }
   };
   const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
-  unsigned c_int = 0, c_leaf = 0, c_pts = 0;
+  // ---- the quick check deferred (round 5) ----
+  // A query that starts from a previous hit (SearchArgs::warm, tie > 0) makes its DIVERGENT visits without the quick check of
+  // kdTreeImpl.h:360-368: 16 bytes { splitval, children } instead of the 48-byte record, one load instead of three.  What it
+  // walks is the reference's walk plus subtrees the reference would have cut off there; the order is the reference's, a point
+  // of such a subtree lies at d2 >= closest_d2 - tie by the very test that was skipped (tie bounds 2 E R + E^2, E the rounding of
+  // fabs(q - center) - half-width against the exact face distance, R the search radius: api.cpp, search_tie), and the strict
+  // `<` never takes an equal one.  So as long as no accepted point improved closest_d2 by `tie` or less -- `thin` -- every
+  // acceptance is one the reference makes, in its order: same index, same d2, same ties.  A query that did accept thinly is
+  // searched again when it retires, cold and with every check: the reference's own walk.  (Wave-uniform visits keep the check:
+  // through the scalar cache it costs nothing.)  The warm radius is the previous hit's d2 + 2 tie, so that finding that very
+  // point again is not thin.  Measured with six waves per SIMD: k_search 0.165 -> 0.145 ms (1M-vs-1M, driver arguments);
+  // 21.4 -> 21.9 node visits, 2.77 -> 3.18 buckets per query.
+  constexpr bool DEFER_OK = DEFER && USE_Q16 && !FAT && !PIPE && TOP == 0 && PROBE == 0;
+  const char* const splitb = DEFER_OK ? reinterpret_cast<const char*>(T.split) : nullptr;
+  const uint32_t split_off = (DEFER_OK && splitb != nullptr) ? (uint32_t)(splitb - hotb) : 0u;
+  const double a_tie = (DEFER_OK && splitb != nullptr && t_q16 != nullptr) ? a.tie : 0.0;
+  // (the two per-lane flags ride in the top bits of nbk, the query's cost counter: as lane masks of their own they were two more
+  // SGPR pairs in a kernel that has none to spare -- spilled into VGPR lanes, +5 % on every launch)
+  constexpr uint32_t NBK_DEFER = 0x80000000u, NBK_THIN = 0x40000000u, NBK_COST = 0x3FFFFFFFu;
+  unsigned c_int = 0, c_leaf = 0, c_pts = 0, c_redo = 0;
   unsigned c_t1 = 0, c_t2 = 0;   // lab, instrumented instantiations: trips of the wave through the node walk / the bucket scan
   unsigned nbk = 0;   // buckets this lane's query has visited (the next pass's ordering key)
   // FUSE 1: the base pair sums (ACC_N .. ACC_P) at retire time; FUSE 2: n, sum and the LUM block of a graph-SLAM link
@@ -1846,11 +1867,19 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
 
   for (;;) {
     // ---- retire finished queries, hand out new ones ----
+    if (DEFER_OK && cur == REF_DONE && have && (nbk & (NBK_DEFER | NBK_THIN)) == (NBK_DEFER | NBK_THIN)) {
+      // accepted a point within `tie` of its closest_d2 on a walk without quick checks: again, as the reference does it
+      nbk &= NBK_COST;
+      if (COUNT) ++c_redo;
+      cur = T.root_ref; bk = -1; st.sp = 0;
+      { const SearchArgs* ap = &a; asm volatile("" : "+s"(ap)); best = ap->maxd2; }
+      bx.set_radius(best);
+    }
     const bool idle = (cur == REF_DONE);
     if (idle && have) {
       gstore<int>(reinterpret_cast<char*>(a_kpos), (uint32_t)qi << 2, bk);
       if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), (uint32_t)qi << 3, best);
-      if (ORDER && a_cost) a_cost[qi] = (unsigned char)min(nbk, 255u);   // nbk: node visits + 4 per bucket
+      if (ORDER && a_cost) a_cost[qi] = (unsigned char)min(nbk & NBK_COST, 255u);   // nbk: node visits + 4 per bucket
       have = false;
       if constexpr (FUSE == 2) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
@@ -2000,6 +2029,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
         qi = mine; have = true; nbk = 0;
         cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
+        if (DEFER_OK && a_tie > 0.0 && kp_prev >= 0 && best < a.maxd2) nbk = NBK_DEFER;
         bx.set_query(qx, qy, qz, T.absmax);
         q16_query();
         bx.set_radius(best);
@@ -2174,8 +2204,11 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         double s_split = sd[0];
         uint32_t s_c1 = su[10], s_c2 = su[11], s_axis = su[6];
         TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2); TDTK_PIN_S32(s_axis);
+        bool prune = false;
+        // (the quick check only for the lanes that make it: a wave whose lanes all defer it jumps over the arithmetic)
+        if (!(DEFER_OK && (nbk & NBK_DEFER))) {
         const float a32 = fmaxf(fmaxf(fabsf(bx.qx - sf[0]) - sf[3], fabsf(bx.qy - sf[1]) - sf[4]), fabsf(bx.qz - sf[2]) - sf[5]);
-        bool prune = a32 >= bx.thi;
+        prune = a32 >= bx.thi;
         if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
           // (one visit in a million: per-lane loads of the same record -- twelve more live SGPRs here made the compiler
           // spill in this very branch)
@@ -2183,6 +2216,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
           const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
           const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
           prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+        }
         }
         if (prune) need_pop = true;
         else next = descend_ax(s_split, s_c1, s_c2, s_axis, qx, qy, qz, best, st);
@@ -2192,6 +2226,30 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         const uint32_t ho = __umul24(cur, (uint32_t)sizeof(KdHot));
         float4 b0, b1;
         double2 sc;
+        if constexpr (DEFER_OK) {
+          // One batch of loads whatever the lanes' modes (a branch per mode would be two round trips in a row for a wave that
+          // holds both): the split half for everybody, the box for the lanes that make the quick check.
+          const bool dfr = (nbk & NBK_DEFER) != 0u;
+          // (the split halves sit behind the hot records in ONE allocation: one scalar base, the lane picks the offset -- a lane
+          // that makes the check reads its 48 bytes from one record, as before)
+          sc = gload<double2>(hotb, dfr ? split_off + __umul24(cur, 16u) : ho + 32u);
+          bool prune = false;
+          if (!dfr) {
+            b0 = gload<float4>(hotb, ho); b1 = gload<float4>(hotb, ho + 16);
+            asm volatile("" : "+v"(b0.x), "+v"(b1.x));        // (both requested behind sc's load, before anything waits)
+            const float a32 = fmaxf(fmaxf(fabsf(bx.qx - b0.x) - b0.w, fabsf(bx.qy - b0.y) - b1.x), fabsf(bx.qz - b0.z) - b1.y);
+            prune = a32 >= bx.thi;
+            if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
+              const uint32_t no = (uint32_t)((cur & REF_VAL) << 6);
+              const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
+              const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
+              prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
+            }
+          }
+          const uint32_t c1b = (uint32_t)__double2loint(sc.y), c2b = (uint32_t)__double2hiint(sc.y);
+          if (prune) need_pop = true;
+          else next = descend_ax(sc.x, c1b, c2b, ((c1b >> 30) & 1u) | (((c2b >> 30) & 1u) << 1), qx, qy, qz, best, st);
+        } else {
         if (TOP > 0 && ho < top_n * (uint32_t)sizeof(KdHot)) {
           const char* lp = reinterpret_cast<const char*>(lds_top) + ho;
           b0 = *reinterpret_cast<const float4*>(lp);
@@ -2225,6 +2283,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         }
         if (prune) need_pop = true;
         else next = descend_ax(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), __float_as_uint(b1.z), qx, qy, qz, best, st);
+        }
       }
       if (need_pop) {
         next = REF_DONE;
@@ -2276,7 +2335,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       // (one filter per build: with both in the kernel the register allocation is the fp32 one plus the grid query -- 130 VGPRs,
       // three waves per SIMD; a tree without the filter this build uses -- degenerate box, no memory -- takes the fp64 loop)
       if (USE_Q16 && (PROBE == 0 || PROBE == 3) && t_q16 != nullptr && count <= 20) {
-        bucket_scan_q16(t_q16, pb, start, count, o0, bx, q16xy, q16zz, q16in, qx, qy, qz, best, bk);
+        bool thin = false;
+        bucket_scan_q16(t_q16, pb, start, count, o0, bx, q16xy, q16zz, q16in, qx, qy, qz, best, bk, a_tie, thin);
+        if (DEFER_OK && thin) nbk |= NBK_THIN;
       } else
       if (!USE_Q16 && (PROBE == 0 || PROBE == 3) && t_grp != nullptr && count <= 4 * GRP_TRIP) {
         bucket_scan_groups(t_grp, pb, start, count, o0, bx, qx, qy, qz, best, bk);
@@ -2311,7 +2372,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         }
 #pragma unroll
         for (int j = 0; j < PTS; j++)
-          if (dd[j] < best) { best = dd[j]; bk = (int)(oo[j] >> 5); }
+          if (dd[j] < best) { if (DEFER_OK && best - dd[j] <= a_tie) nbk |= NBK_THIN; best = dd[j]; bk = (int)(oo[j] >> 5); }
       }
       bx.set_radius(best);
       cur = REF_DONE;
@@ -2338,6 +2399,10 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       atomicAdd(&a.counters[0], s_int);
       atomicAdd(&a.counters[1], s_leaf);
       atomicAdd(&a.counters[2], s_pts);
+    }
+    if (DEFER_OK) {   // queries searched a second time, with every check (a thin acceptance on the walk that defers them)
+      const unsigned long long s_redo = wave_sum_u(c_redo);
+      if (lane == 0 && s_redo) atomicAdd(&a.counters[7], s_redo);
     }
     if (kLab) {       // wave trips: (lane-visits of a phase) / (64 x its trips) = the share of lane-slots that phase keeps busy
       const unsigned long long s_t1 = wave_sum_u(c_t1), s_t2 = wave_sum_u(c_t2);
@@ -2445,7 +2510,8 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   }
 }
 
-template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false, int TOP = 0, bool SHARE = false, bool PIPE = false>
+template <int BLOCK, int SD, int THRESH, int WPS, bool COUNT, int FUSE, bool DYN, int PTS = 4, int PROBE = 0, bool FAT = false, int TOP = 0, bool SHARE = false, bool PIPE = false,
+          bool DEFER = false>
 __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a_by_value)
 {
   // The argument block (three 4x4 fp64 matrices among its 700 bytes) is read through the kernarg segment pointer, not
@@ -2454,7 +2520,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
   // v_readlane in a kernel that is short of issue slots.  Behind an opaque pointer the fields are s_load'ed where they
   // are used (the matrices only when a lane takes a new query), like k_search_refill_multi reads its table entry.
   (void)a_by_value;
-  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT, 256, false, TOP, SHARE, PIPE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
+  search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, DYN, !DYN, PTS, PROBE, FAT, 256, false, TOP, SHARE, PIPE, DEFER>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 
 #ifdef TDTK_LAB
@@ -3972,6 +4038,9 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   static const unsigned occ_lds = [] { const char* e = lab_env("TDTK_OCC_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
   const char* pe = lab_env("TDTK_BUCKET_PTS");
   const int bpts = pe ? atoi(pe) : 4;
+  // the instantiation whose warm queries defer the quick check (SearchArgs::tie): a repeated pass over a tree that has the
+  // split halves and the 16-bit shadow; everything else -- every cold pass -- runs the kernel without that machinery
+  const bool defer_ok = (FUSE == 0 || FUSE == 3) && a.warm && a.tie > 0.0 && a.T.split != nullptr && a.T.q16 != nullptr && BUCKET_Q16;
 #ifdef TDTK_LAB
   if (!COUNT && FUSE == 0 && bpts == 8 && refill_thresh(a.n) == 16) {
     hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 8>), dim3(nb), dim3(128), occ_lds, s, a);
@@ -3990,13 +4059,18 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 #ifdef TDTK_LAB
     case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
 #endif
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 32:
+      if (defer_ok) hipLaunchKernelGGL((k_search_refill<128, 4, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false, 4, 0, false, 0, false, false, (FUSE == 0 || FUSE == 3)>), dim3(nb), dim3(128), occ_lds, s, a);
+      else hipLaunchKernelGGL((k_search_refill<128, 4, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
+      break;
     default:
 #ifdef TDTK_LAB
       if ((FUSE == 0 || FUSE == 3) && pipe_on() && !a.skip)
         hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, (FUSE == 3 ? 3 : 0), false, 4, 0, false, 0, false, true>), dim3(nb), dim3(128), occ_lds, s, a);
       else
 #endif
+      if (defer_ok) hipLaunchKernelGGL((k_search_refill<128, 4, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false, 4, 0, false, 0, false, false, (FUSE == 0 || FUSE == 3)>), dim3(nb), dim3(128), occ_lds, s, a);
+      else
       hipLaunchKernelGGL((k_search_refill<128, 4, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
       break;
   }
@@ -4205,7 +4279,7 @@ hipError_t launch_bandwidth(int kind, void* a, void* b, size_t bytes, double* mo
   return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nodes, size_t n, KdHot* __restrict__ hot)
+__global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nodes, size_t n, KdHot* __restrict__ hot, double2* __restrict__ split)
 {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -4217,6 +4291,7 @@ __global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nod
   h.splitval = nd.splitval; h.c1 = nd.c1; h.c2 = nd.c2;
   h.axis = ((nd.c1 >> 30) & 1u) | (((nd.c2 >> 30) & 1u) << 1);
   hot[i] = h;
+  if (split) split[i] = make_double2(nd.splitval, __hiloint2double((int)nd.c2, (int)nd.c1));     // { splitval, c1 | c2 << 32 }
 }
 #ifdef TDTK_LAB   // two tree levels per record: a measured negative (see the FAT walk in search_refill_body)
 __global__ void __launch_bounds__(256) k_make_fat(const KdNode* __restrict__ nodes, size_t n, KdFat* __restrict__ fat)
@@ -4247,10 +4322,10 @@ hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_
   return hipGetLastError();
 }
 #endif   // TDTK_LAB
-hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s)
+hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s, double2* split)
 {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_make_hot, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, hot);
+  hipLaunchKernelGGL(k_make_hot, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, hot, split);
   return hipGetLastError();
 }
 

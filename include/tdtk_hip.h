@@ -418,7 +418,10 @@ int tdtk_last_timings(double out[4]);
  * kernel it would have used (identical traversal and results, slower) and adds to four counters, zeroed here;
  * tdtk_visit_counters reads {internal nodes, buckets, bucket points visited, queries issued} -- the exact
  * n_int / n_pts of SURVEY 8(d)'s algorithmic bytes for exactly the launches that ran (warm radius included) --
- * and, for calcNormals, out[4..6] = {ANN splitting nodes, leaf points visited, points processed}; out[7] = 0. */
+ * and, for calcNormals, out[4..6] = {ANN splitting nodes, leaf points visited, points processed}; out[7] = queries of
+ * repeated passes that were searched a second time with every quick check (a warm query walks without the quick check of
+ * its divergent visits and is searched again, cold, if it accepted a point that improved closest_d2 by a rounding's
+ * worth: DESIGN.md section 4, "the quick check deferred"). */
 int tdtk_visit_counting(int device, int on);
 int tdtk_visit_counters(int device, uint64_t out[8]);
 /* measured roofline denominators: kind 0 = HBM stream copy over `bytes` (read + written per pass), kind 1 =
