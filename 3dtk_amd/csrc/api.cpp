@@ -127,7 +127,12 @@ struct Ctx {
   hipStream_t stream_b = nullptr, stream_c = nullptr;   // the tree build's background chains (exact centroid sums beside the levels below)
   hipEvent_t e_b1 = nullptr, e_b2 = nullptr, e_b3 = nullptr;
   DevBuf ws[WS_COUNT];
-  double* h_pin = nullptr;  // pinned staging for the per-iteration sums
+  double* h_pin = nullptr;  // pinned staging for the per-iteration sums: words [0, ACC_TOTAL); behind them two slots of the tree build
+  // (both are filled by copies enqueued on `stream` and read only behind a synchronisation of that stream that was made after
+  //  the copy was enqueued: one of the build's looks at the device for the box, tree_finish's own hipStreamSynchronize for the
+  //  groups -- device_build_tree may return with its last kernels still running, see build.hip "no_last_look")
+  static constexpr int PIN_BOX = 128;      // 6 doubles: the root bounding box (tree_from_device_points)
+  static constexpr int PIN_GROUPS = 140;   // 1 uint32: groups of the padded layout (tree_pad_buckets -> tree_finish)
   void* h_build = nullptr;  // 64 KB, pinned: the tree build's looks at the device (BuildSide::h_pin)
   void* h_stage = nullptr;  // pinned staging for descriptor tables of batched launches (grows on demand)
   size_t h_stage_cap = 0;
@@ -540,7 +545,7 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
   // root bounding box (binning of unsorted query batches, accumulation shift): min / max on the device
   // (read back behind the build: the build's own looks at the device are the next synchronisation points)
   HIPCHK(launch_bbox(c->ws[WS_TMPA].as<double>(), M, d_box + 8, d_box, c->stream));
-  HIPCHK(hipMemcpyAsync(c->h_pin + 128, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pin + Ctx::PIN_BOX, d_box, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   const double t1 = now_ms();
   t->info.upload_ms = t1 - t0;
   const bool alone = g_ctx_live.load() <= 2;
@@ -567,7 +572,7 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
                            : std::string("device tree build: ") + hipGetErrorString(r.err));
     return r.degenerate ? TDTK_EINVAL : TDTK_EDEVICE;
   }
-  for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[128 + a]; t->bbmax[a] = c->h_pin[128 + 3 + a]; }   // (the build has synchronised the stream)
+  for (int a = 0; a < 3; a++) { t->bbmin[a] = c->h_pin[Ctx::PIN_BOX + a]; t->bbmax[a] = c->h_pin[Ctx::PIN_BOX + 3 + a]; }   // (the copy was enqueued in front of the build, and every path through device_build_tree synchronises c->stream at least once behind it: a look at the level loop's counters, or its last one)
   t->d_nodes = r.nodes; t->d_r = r.node_r; t->d_pts = r.pts;
   t->d_leaf = r.leaf_tab;   // non-null only in table mode
   t->dev.root_ref = r.root_ref;
@@ -627,7 +632,7 @@ static int tree_pad_buckets(Ctx* c, tdtk_tree* t, size_t M)
       if (want_q16 && handle_malloc(&q16B, (size_t)G_bound * 24 + 128) != hipSuccess) { (void)hipGetLastError(); q16B = nullptr; }
       hipError_t e = launch_pad_fill(nodes, t->info.n_internal, leaf, cb, cmask, g_at, static_cast<const KdPoint*>(t->d_pts),
                                      static_cast<KdPoint*>(ptsB), static_cast<float4*>(grpB), c->stream, static_cast<uint32_t*>(q16B), t->q_lo, t->q_scale);
-      if (e == hipSuccess) e = hipMemcpyAsync(c->h_pin + 140, g_at + M, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(c->h_pin + Ctx::PIN_GROUPS, g_at + M, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
       if (e != hipSuccess) { pool_free(ptsB); pool_free(grpB); if (q16B) pool_free(q16B); set_error(std::string("bucket groups: ") + hipGetErrorString(e)); return TDTK_EDEVICE; }
       pool_free_later(c, t->d_pts);
       t->d_pts = ptsB; t->d_grp = grpB; t->d_q16 = q16B;
@@ -693,7 +698,7 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   if (t->d_grp && t->Mp == 0) {        // the padded layout was filled without a look of its own: its size now
     if (!t->info.n_internal) HIPCHK(hipStreamSynchronize(c->stream));
     uint32_t G = 0;
-    std::memcpy(&G, c->h_pin + 140, sizeof G);
+    std::memcpy(&G, c->h_pin + Ctx::PIN_GROUPS, sizeof G);
     t->Mp = 4ull * G;
   }
   flush_free_later(c);

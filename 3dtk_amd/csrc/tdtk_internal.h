@@ -71,7 +71,7 @@ static_assert(sizeof(KdFat) == 128, "KdFat must be 128 bytes");
 // pool.cpp: hipMalloc / hipFree for the arrays of trees and resident scans, with freed blocks kept for the next request
 // (declared with plain types so that host-only sources can include this header)
 int pool_malloc_raw(void** out, size_t bytes);   // 0 = success, else the hipError_t value
-// Product and lab.  The default build (`make`, lib3dtk_hip.so) holds what a slam6D run uses and reads twelve environment
+// Product and lab.  The default build (`make`, lib3dtk_hip.so) holds what a slam6D run uses and reads thirteen environment
 // switches; `make LAB=1` (lib3dtk_hip_lab.so, -DTDTK_LAB) adds the kernels and policies that were
 // built, measured and lost (NEGATIVES.md) with the switches that select them -- the tests that compare those variants with
 // the product path load that library.  lab_env() is getenv() in the lab build and nothing in the product.
