@@ -3927,8 +3927,11 @@ static bool pipe_on()
 #define TDTK_MULTI_WPS 4
 #endif
 constexpr int MULTI_WPS = TDTK_MULTI_WPS;
+#ifndef TDTK_REFILL_WPS
+#define TDTK_REFILL_WPS 6        // (LABFLAGS=-DTDTK_REFILL_WPS=1: the compiler's own choice, 94 VGPRs = five waves)
+#endif
 template <bool COUNT, int FUSE>
-constexpr int REFILL_WPS = COUNT ? 4 : ((FUSE == 0 || FUSE == 3) ? 6 : 1);
+constexpr int REFILL_WPS = COUNT ? 4 : ((FUSE == 0 || FUSE == 3) ? TDTK_REFILL_WPS : 1);
 static int refill_waves_per_simd()
 {
   static const int w = [] {
