@@ -1139,10 +1139,12 @@ static double search_tie(const tdtk_tree* t, double maxd2)
 {
   static const bool off = [] { const char* e = getenv("TDTK_DEFER_CHECK"); return e && e[0] == '0'; }();
   if (off || !t->d_split || !(maxd2 > 0.0) || !std::isfinite(maxd2)) return 0.0;
-  // Only for trees that live in the caches: a walk without the quick check visits a sixth more buckets, and once a bucket is a
-  // trip to HBM that costs more than the node loads it saves -- 10M-point tree (0.65 GB), ICP iteration k_search 1.28 ms with
-  // every check, 1.37 without; 1M-point tree (57 MB) 0.1665 against 0.1570 (tools/r5_c5_waves.sh, r5_nobox_ab.sh)
-  if (t->info.device_bytes > (size_t)128 << 20) return 0.0;
+  // Only for trees that live in the caches (the Infinity Cache is 256 MB): a walk without the quick check visits a sixth more
+  // buckets, and once a bucket is a trip to HBM that costs more than the node loads it saves.  ICP iteration, k_search with
+  // every check / with the check deferred: 1M-point tree (57 MB) 0.1665 / 0.1570 ms, 2M (115 MB) 0.357 / 0.334, 4M (230 MB)
+  // 0.706 / 0.656, 10M-point city (0.65 GB) 1.28 / 1.37 (tools/r5_nobox_ab.sh, r5_defer_sizes.sh, r5_c5_waves.sh)
+  static const size_t max_mb = [] { const char* e = lab_env("TDTK_DEFER_MAX_MB"); return e ? (size_t)atol(e) : (size_t)256; }();
+  if (t->info.device_bytes > (max_mb << 20)) return 0.0;
   const double R = std::sqrt(maxd2), E = std::ldexp(3.0 * (double)t->dev.absmax + R, -50);
   const double tie = 4.0 * (2.0 * E * R + E * E);
   return (std::isfinite(tie) && tie < 1e-3 * maxd2) ? tie : 0.0;
