@@ -369,7 +369,7 @@ def bench_small_scans(args, local):
         orig = icp.match
 
         def rec(a, b, pm=0):
-            t0 = time.perf_counter(); it = orig(a, b, pm); its.append((it, time.perf_counter() - t0)); return it
+            t0 = time.perf_counter(); it = orig(a, b, pm); its.append((it, time.perf_counter() - t0, icp.last["total_ms"])); return it
         icp.match = rec
         t0 = time.perf_counter(); icp.doICP(S, prefetch=prefetch); wall = time.perf_counter() - t0
         builds = [s.getSearchTree().info()["build_ms"] for s in S[:-1]]
@@ -381,8 +381,9 @@ def bench_small_scans(args, local):
     wall0, its0, builds0, poses0 = run(False)
     wall1, its1, builds1, poses1 = run(True)
     assert np.array_equal(poses0, poses1), "doICP result depends on the prefetch"
-    iters = [it for it, _ in its1]
-    match_ms = [dt * 1e3 for _, dt in its0]
+    iters = [it for it, _, _ in its1]
+    match_ms = [dt * 1e3 for _, dt, _ in its0]
+    loop_ms = [lm for _, _, lm in its0]          # the library's own clock around the resident loop (tdtk_icp_match: no preparation in it)
     out = {"scans": nscans, "raw_points_per_scan": len(raw[0][2]), "reduced_points_per_scan": {"min": min(npts), "mean": float(np.mean(npts)), "max": max(npts)},
            "voxel": 10.0, "max_dist_match": 75.0, "max_iterations": 100, "epsilonICP": 1e-5,
            "per_scan_ms": {"reduce": float(np.mean(t_red)) * 1e3, "tree_build": float(np.mean(builds0)),
@@ -390,8 +391,11 @@ def bench_small_scans(args, local):
                            "doICP_wall_three_ahead": wall1 * 1e3 / (nscans - 1)},
            "iterations_per_match": {"mean": float(np.mean(iters)), "max": int(max(iters))},
            "ms_per_iteration": float(np.sum(match_ms) / max(1, sum(it + 1 for it in iters))),
+           "loop_ms_per_match": float(np.mean(loop_ms)),
+           "loop_us_per_iteration": float(1e3 * np.sum(loop_ms) / max(1, sum(it + 1 for it in iters))),
            "what": "16 synthetic street-scene scans (C3's shape; hannover1 is not on the box): tdtk_reduce_octree -r 10, then "
-                   "icp6D::doICP over the reduced scans; `match` = wall time of one icp6D::match (device-resident loop), "
+                   "icp6D::doICP over the reduced scans; `match` = wall time of one icp6D::match with nothing prepared ahead (the model's tree build and the "
+                   "scan's upload + ordering are inside it; `ms_per_iteration` divides THAT by the iterations), `loop_*` = the device-resident loop alone by the library's clock, "
                    "`tree_build` = tdtk_tree_create on the device, doICP_wall = (whole doICP) / 15 with the next three scans' "
                    "upload + ordering + tree build on worker threads or with nothing prepared ahead (identical poses)"}
     if not args.no_cpu:
