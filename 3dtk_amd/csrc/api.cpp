@@ -2665,6 +2665,8 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
   uint32_t* hsb = reinterpret_cast<uint32_t*>(tab.data() + o_sb);
   uint32_t* hab = reinterpret_cast<uint32_t*>(tab.data() + o_ab);
   std::vector<uint32_t> s_total(ngroups), a_total(ngroups);
+  struct Held { Lane* sl; uint64_t tree, scan; size_t n; };
+  std::vector<Held> held;
   if (c->counting) { for (int i = 0; i < nlinks; i++) c->counted_queries += second[i]->N; }
   for (int gi = 0; gi < ngroups; gi++) {
     const int l0 = gi * G, l1 = std::min(nlinks, l0 + G);
@@ -2695,7 +2697,10 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       // the previous pass of this very link left its hits here (graph-SLAM rounds repeat their links): each search starts from
       // its previous hit, a point of this tree whatever the scans have done since (k_search's warm start; same index, same d2)
       sa.warm = (link_warm && sl->k_tree == t->uid && sl->k_scan == data->uid && sl->k_n == data->N) ? 1 : 0;
-      sl->k_tree = t->uid; sl->k_scan = data->uid; sl->k_n = data->N;
+      // (what the slot will hold is written down once every launch of the call is enqueued: a call that fails on the way must
+      //  not leave a slot named after hits that were never written)
+      sl->k_tree = sl->k_scan = 0;
+      held.push_back({sl, t->uid, data->uid, data->N});
       const int need = (int)t->info.max_depth - 1 - search_lds_depth();
       if (need > 0) { sa.ovf_m2 = sl->ovf_m2.as<double>(); sa.ovf_ref = sl->ovf_ref.as<uint32_t>(); }
       if (c->counting) sa.counters = c->d_counters.as<unsigned long long>();
@@ -2759,6 +2764,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
                               reinterpret_cast<const uint32_t*>(dbase + o_ab) + l0 + gi, nb, a_total[gi], want,
                               reinterpret_cast<const FinalDesc*>(dbase + o_fd) + l0, s, fuse_links));
   }
+  for (const Held& h : held) { h.sl->k_tree = h.tree; h.sl->k_scan = h.scan; h.sl->k_n = h.n; }   // (a slot used by several groups: the last one's)
   return TDTK_OK;
 }
 

@@ -1197,6 +1197,54 @@ def test_lazy_scan_moves_equal_moving_every_round(tdtk, gpu, monkeypatch):
     assert not np.array_equal(eager[2][4], make()[4].get_xyz_reduced())     # (scan 4 did move)
 
 
+def test_links_that_repeat_start_warm_and_change_nothing(tdtk, gpu, lab, monkeypatch):
+    """Round 5: a link that repeats -- same tree, same scan, same position of the launch, told by the handles' numbers --
+    starts every search from the previous round's hit (k_search's warm radius: a point of the link's static tree bounds the
+    nearest neighbour's distance whatever the scans have done since).  Same index, same d2: four rounds of lum6DEuler over
+    seven links of 300K-point scans, the scans moving between the rounds, give the same `ret`, poses and points bit for bit
+    with the warm start switched off (TDTK_LINK_WARM=0, lab library).  A second graph over OTHER scans through the same
+    context's slots in between must not inherit anybody's hits."""
+    from importlib import import_module
+    gs = import_module("3dtk_amd.graphslam")
+    rng = np.random.default_rng(31)
+    world = rng.uniform(-400, 400, (300000, 3))
+
+    def make(seed0, n=None):
+        scans = []
+        w = world if n is None else world[:n]
+        for k in range(5):
+            T = tdtk.EulerToMatrix4([3.0 * k, -1.0 * k, 2.0 * k], [0.002 * k, -0.003 * k, 0.004 * k])
+            Ti = tdtk.M4inv(T)
+            R = np.array([[Ti[0], Ti[4], Ti[8]], [Ti[1], Ti[5], Ti[9]], [Ti[2], Ti[6], Ti[10]]])
+            loc = w @ R.T + Ti[12:15] + np.random.default_rng(seed0 + k).normal(0, 0.05, w.shape)
+            scans.append(tdtk.Scan([3.0 * k + 0.3, -1.0 * k, 2.0 * k - 0.2], [0.002 * k, -0.003 * k + 0.001, 0.004 * k], loc))
+        tdtk.prepare_scans(scans, trees=True, threads=2)
+        return scans
+    links = [(0, 1), (1, 2), (2, 3), (0, 3), (0, 2), (1, 3), (4, 1)]
+
+    def run(warm):
+        if warm:
+            monkeypatch.delenv("TDTK_LINK_WARM", raising=False)
+        else:
+            monkeypatch.setenv("TDTK_LINK_WARM", "0")
+        scans = make(100)
+        other = make(200, 280000)                   # other handles, other sizes, through the same slots
+        gr = tdtk.Graph(5, links=links)
+        rets = [gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, scans, 100.0, None) for _ in range(2)]
+        r_other = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(5, links=links), other, 100.0, None)
+        rets += [gs.graph_iteration_comm(gs.GRAPH_LUMEULER, gr, scans, 100.0, None) for _ in range(2)]
+        poses = np.stack([s.transMat for s in scans])
+        pts = [s.get_xyz_reduced() for s in scans]
+        for s in scans + other:
+            s.release()
+        return rets, r_other, poses, pts
+    cold = run(False)
+    warm = run(True)
+    assert cold[0] == warm[0] and cold[1] == warm[1] and np.array_equal(cold[2], warm[2])
+    for a, b in zip(cold[3], warm[3]):
+        assert np.array_equal(a, b)
+
+
 def test_tree_edge_cases(tdtk, orc, gpu):
     """One point, two points, all-identical points (one degenerate bucket larger than the bucket size),
     non-finite coordinates (the reference would recurse on an empty side; we return an error)."""
