@@ -1842,10 +1842,12 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   // fabs(q - center) - half-width against the exact face distance, R the search radius: api.cpp, search_tie), and the strict
   // `<` never takes an equal one.  So as long as no accepted point improved closest_d2 by `tie` or less -- `thin` -- every
   // acceptance is one the reference makes, in its order: same index, same d2, same ties.  A query that did accept thinly is
-  // searched again when it retires, cold and with every check: the reference's own walk.  (Wave-uniform visits keep the check:
-  // through the scalar cache it costs nothing.)  The warm radius is the previous hit's d2 + 2 tie, so that finding that very
-  // point again is not thin.  Measured with six waves per SIMD: k_search 0.165 -> 0.145 ms (1M-vs-1M, driver arguments);
-  // 21.4 -> 21.9 node visits, 2.77 -> 3.18 buckets per query.
+  // searched again when it retires, cold and with every check: the reference's own walk.  (A deferring lane skips the check in
+  // wave-uniform visits too; lanes that make it -- no previous hit -- make it everywhere.)  The warm radius is the previous hit's
+  // d2 + 2 tie, so that finding that very point again is not thin.  Measured with six waves per SIMD, 1M-vs-1M at the driver's
+  // arguments: k_search 0.1665 -> 0.157 ms; 21.4 -> 21.7 node visits, 2.77 -> 3.12 buckets per query (the checks compiled out
+  // altogether, which is not exact: 0.145-0.151).  This is an instantiation of its own (DEFER): a pass with no warm queries
+  // runs the kernel without any of it.
   constexpr bool DEFER_OK = DEFER && USE_Q16 && !FAT && !PIPE && TOP == 0 && PROBE == 0;
   const char* const splitb = DEFER_OK ? reinterpret_cast<const char*>(T.split) : nullptr;
   const uint32_t split_off = (DEFER_OK && splitb != nullptr) ? (uint32_t)(splitb - hotb) : 0u;
