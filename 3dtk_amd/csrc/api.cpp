@@ -2117,6 +2117,19 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
   if (t->d_leaf) { dl.resize(t->info.n_leaves); HIPCHK(hipMemcpy(dl.data(), t->d_leaf, dl.size() * sizeof(LeafEntry), hipMemcpyDeviceToHost)); }
   std::vector<KdPoint> pts;
   uint64_t group_errors = 0;
+  // the search-side copies of a node's split half (the hot record's, and the 16-byte one the deferred quick check reads) say
+  // what the node says
+  if (t->d_hot && !dn.empty()) {
+    std::vector<KdHot> hot(dn.size());
+    HIPCHK(hipMemcpy(hot.data(), t->d_hot, hot.size() * sizeof(KdHot), hipMemcpyDeviceToHost));
+    struct Half { double splitval; uint32_t c1, c2; };
+    std::vector<Half> half;
+    if (t->d_split) { half.resize(dn.size()); HIPCHK(hipMemcpy(half.data(), t->d_split, half.size() * sizeof(Half), hipMemcpyDeviceToHost)); }
+    for (size_t i = 0; i < dn.size(); i++) {
+      if (std::memcmp(&hot[i].splitval, &dn[i].splitval, 8) != 0 || hot[i].c1 != dn[i].c1 || hot[i].c2 != dn[i].c2) group_errors++;
+      if (!half.empty() && (std::memcmp(&half[i].splitval, &dn[i].splitval, 8) != 0 || half[i].c1 != dn[i].c1 || half[i].c2 != dn[i].c2)) group_errors++;
+    }
+  }
   if (t->d_grp) {
     const uint32_t cbv = t->dev.cb, cm = (cbv >= 32) ? 0xFFFFFFFFu : ((1u << cbv) - 1u);
     struct Run { uint32_t start, count; uint32_t* ref; LeafEntry* le; };
@@ -2169,6 +2182,7 @@ int tdtk_tree_verify(const tdtk_tree* t, uint64_t mismatches[4])
     if (group_errors) { mismatches[0] = mismatches[1] = mismatches[2] = 0; mismatches[3] = group_errors; return TDTK_OK; }
   } else {
     pts = padded;
+    if (group_errors) { mismatches[0] = mismatches[1] = mismatches[2] = 0; mismatches[3] = group_errors; return TDTK_OK; }
   }
   // recover the caller's array from the resident points (each carries its caller index)
   std::vector<double> xyz(3 * t->M);
