@@ -352,6 +352,74 @@ void orc_find_closest(const orc_tree *t, const double *q, size_t K, double maxdi
   if (counters) { counters[0] += c0; counters[1] += c1; counters[2] += c2; }
 }
 
+/* ---- the GPU kernel's "quick check deferred", stated on the reference's tree (test infrastructure for the ARGUMENT) ----------
+ * 3dtk_amd/csrc/kernels.hip (search_refill_body<.., DEFER>) lets a query that starts from a previous hit walk WITHOUT the quick
+ * check of kdTreeImpl.h:360-368 and searches it again, with every check, if it ever accepted a point that improved closest_d2
+ * by `tie` or less (api.cpp: search_tie).  This is that rule on the pointer tree above, check skipped at EVERY node (the kernel
+ * skips it at some): tests/test_oracle_vs_ref.py runs it over clouds built to sit on the roundings the argument is about --
+ * lattices with axis-aligned queries, twins 1e-12 apart, coordinates far from the origin -- and asks for orc_find_closest's
+ * answer, index and d2, every time.  Nothing in the product calls it. */
+static void find_closest_nocheck(const orc_tree *t, const orc_node *nd, orc_params *pa, double tie, int *thin)
+{
+  if (nd->isleaf) {
+    for (int i = 0; i < nd->npts; i++) {
+      double d2 = dist2(pa->p, t->xyz + 3 * (size_t)nd->p[i]);
+      if (d2 < pa->closest_d2) {
+        if (pa->closest_d2 - d2 <= tie) *thin = 1;
+        pa->closest_d2 = d2; pa->closest = nd->p[i];
+      }
+    }
+    return;
+  }
+  double myd = nd->splitval - pa->p[nd->splitaxis];
+  if (myd >= 0.0) {
+    find_closest_nocheck(t, nd->child1, pa, tie, thin);
+    if (myd * myd < pa->closest_d2) find_closest_nocheck(t, nd->child2, pa, tie, thin);
+  } else {
+    find_closest_nocheck(t, nd->child2, pa, tie, thin);
+    if (myd * myd < pa->closest_d2) find_closest_nocheck(t, nd->child1, pa, tie, thin);
+  }
+}
+
+double orc_search_tie(double absmax, double maxdist2)
+{
+  const double R = sqrt(maxdist2), E = ldexp(3.0 * absmax + R, -50);
+  return 4.0 * (2.0 * E * R + E * E);
+}
+
+/* warm[i]: index of a point of the tree (the "previous hit") or -1.  redo (nullable) counts the second searches. */
+void orc_find_closest_deferred(const orc_tree *t, const double *q, size_t K, double maxdist2, const int32_t *warm,
+                               double absmax, int32_t *idx, double *d2, long *redo)
+{
+  const double tie = orc_search_tie(absmax, maxdist2);
+  long nredo = 0;
+  for (size_t i = 0; i < K; i++) {
+    orc_params pa; memset(&pa, 0, sizeof pa);
+    pa.p = q + 3 * i; pa.closest = -1; pa.closest_d2 = maxdist2;
+    int deferred = 0, thin = 0;
+    if (warm && warm[i] >= 0) {
+      const double d = dist2(pa.p, t->xyz + 3 * (size_t)warm[i]);
+      double up = nextafter(d, INFINITY);
+      const double um = d + 2.0 * tie;
+      if (um > up) up = um;
+      if (up < maxdist2) { pa.closest_d2 = up; deferred = 1; }
+    }
+    if (deferred) {
+      find_closest_nocheck(t, t->root, &pa, tie, &thin);
+      if (thin) {                      /* again, as the reference does it */
+        nredo++;
+        pa.closest = -1; pa.closest_d2 = maxdist2;
+        find_closest(t, t->root, &pa);
+      }
+    } else {
+      find_closest(t, t->root, &pa);
+    }
+    idx[i] = pa.closest;
+    if (d2) d2[i] = pa.closest_d2;
+  }
+  if (redo) *redo += nredo;
+}
+
 /* kd.cc:89-100 (KDtree::FindClosestAlongDir), batched, one dir per query */
 void orc_find_closest_along_dir(const orc_tree *t, const double *q, const double *dir, size_t K,
                                 double maxdist2, int32_t *idx, double *d2)

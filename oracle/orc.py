@@ -56,6 +56,9 @@ def lib():
         L.orc_tree_perm.argtypes = [C.c_void_p, _ip]
         L.orc_find_closest.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, _dp, _lp, C.c_int]
         L.orc_find_closest_along_dir.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, _ip, _dp]
+        L.orc_find_closest_deferred.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_double, _ip, C.c_double, _ip, _dp, _lp]
+        L.orc_search_tie.argtypes = [C.c_double, C.c_double]
+        L.orc_search_tie.restype = C.c_double
         L.orc_get_pt_pairs.restype = C.c_size_t
         L.orc_get_pt_pairs.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_size_t, C.c_size_t, C.c_int,
                                        C.c_double, _ip, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -186,6 +189,17 @@ class Tree:
         if want_counters:
             return idx, d2, (cnt[0], cnt[1], cnt[2])
         return idx, d2
+
+    def find_closest_deferred(self, q, maxdist2, warm, absmax):
+        """The GPU kernel's "quick check deferred" stated on this tree (oracle.c): every query with a warm point walks without
+        the quick check and is searched again if it accepted thinly.  Returns (idx, d2, second searches)."""
+        q = _c(q).reshape(-1, 3)
+        warm = np.ascontiguousarray(warm, np.int32)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        redo = (C.c_long * 1)(0)
+        lib().orc_find_closest_deferred(self.h, _d(q), len(q), float(maxdist2), _i(warm), float(absmax), _i(idx), _d(d2), redo)
+        return idx, d2, int(redo[0])
 
     def packet_find_closest(self, q, maxdist2, group=64):
         """Analysis only (oracle.c, "Packet traversal study"): `group` consecutive queries walk the tree together;

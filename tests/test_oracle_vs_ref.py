@@ -510,3 +510,52 @@ def test_b1_correspondence_indices_oracle(orc):
             if "first100" in row:
                 assert idx[:100].tolist() == row["first100"] and idx[-100:].tolist() == row["last100"]
             S[i].transform(np.array(a))
+
+
+def test_deferred_quick_check_gives_the_references_answer_on_the_roundings(orc):
+    """Round 5: the ARGUMENT behind the GPU kernel's deferred quick check, tried on the CPU where the reference's
+    own walk is at hand.  oracle.c states the rule on the reference's tree with the check skipped at EVERY node: start from
+    d2(q, previous hit) + 2 tie, mark a query whose closest_d2 ever improved by `tie` or less, search those again with every
+    check.  Index and d2 must be FindClosest's on clouds built to sit on the roundings the bound is about: a lattice with a
+    non-dyadic pitch and queries displaced along one axis (mid-way between neighbours: ties to within an ulp; and right on a
+    neighbour), twins 1e-12 .. 1e-11 apart, the same far from the origin (1e5: the bound's absolute term), and a plain noisy
+    pair; with the true neighbour, a wrong neighbour and a far point as the previous hit.  (These clouds give the same answers
+    with tie = 0 as well -- for the reference's own check to hide a point, a box face, a near-tie and an axis-aligned offset have
+    to coincide to the last bit; the bound is what the proof needs, and what this test shows is that the rule built on it
+    costs no answer while its second searches run by the thousand.)"""
+    rng = np.random.default_rng(5)
+    total_redo = 0
+    for case in range(8):
+        off = 0.0 if case < 4 else 1.0e5
+        if case % 4 == 0:        # lattice, pitch 0.1 (not a dyadic rational), queries on the axis between / on neighbours
+            g = np.arange(24) * 0.1
+            m = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + off
+            pick = rng.integers(0, len(m), 6000)
+            q = m[pick].copy()
+            ax = rng.integers(0, 3, len(q))
+            q[np.arange(len(q)), ax] += rng.choice([0.05, -0.05, 0.1, 0.025, 1e-13, 0.0], len(q))
+        elif case % 4 == 1:      # twins
+            m = rng.uniform(-50, 50, (20000, 3)) + off
+            tw = rng.choice(len(m), 4000, replace=False)
+            m[tw[:2000]] = m[tw[2000:]] + rng.uniform(1e-12, 1e-11, (2000, 3)) * rng.choice([-1.0, 1.0], (2000, 3))
+            q = m[rng.integers(0, len(m), 8000)] + rng.normal(0, 0.3, (8000, 3))
+        elif case % 4 == 2:      # exact duplicates and coplanar points
+            m = rng.uniform(-50, 50, (20000, 3)) + off
+            m[:5000, 2] = off + 1.0
+            m[rng.integers(0, len(m), 3000)] = m[rng.integers(0, len(m), 3000)]
+            q = m[rng.integers(0, len(m), 8000)] + rng.normal(0, 0.5, (8000, 3)) * np.array([1.0, 1.0, 0.0])
+        else:                    # the ordinary case: a noisy copy
+            m = rng.uniform(-100, 100, (30000, 3)) + off
+            q = m[rng.integers(0, len(m), 8000)] + rng.normal(0, 1.0, (8000, 3))
+        t = orc.Tree(m, 20 if case % 2 else 5)
+        maxd2 = 25.0 if case % 4 else 0.0625
+        absmax = float(np.abs(m).max())
+        ref_i, ref_d = t.find_closest(q, maxd2)
+        assert (ref_i >= 0).sum() > len(q) // 3
+        # previous hits: the answer itself; a neighbour of it in the array (a wrong but near point); anything
+        for warm in (ref_i, np.where(ref_i >= 0, (ref_i + 1) % len(m), -1), rng.integers(0, len(m), len(q)).astype(np.int32)):
+            i2, d2, redo = t.find_closest_deferred(q, maxd2, warm, absmax)
+            assert np.array_equal(i2, ref_i), (case, int((i2 != ref_i).sum()))
+            assert np.array_equal(d2, ref_d), case
+            total_redo += redo
+    assert total_redo > 1000        # the thin path ran (lattices and twins make thin acceptances by the thousand)
