@@ -139,7 +139,9 @@ def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_quer
          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc),
          "kernel_ms": k_ms, "bytes_per_query": bq,
          "visits_per_query": {"internal": c_int / nq, "leaves": c_leaf / nq, "points": c_pts / nq,
-                              "counted_on": "the timed launches themselves (warm-start radius included)"},
+                              "counted_on": "the timed launches themselves (warm-start radius included; over a tree of <= 256 MB a warm query "
+                                            "defers the reference's quick check in its divergent visits -- DESIGN section 4 -- and so visits a few "
+                                            "more nodes and buckets than the reference's walk: TDTK_DEFER_CHECK=0 counts the reference's)"},
          "nn_per_s_kernel_only": nq_per_launch / (k_ms * 1e-3),
          "note": "algorithmic bytes are re-reads of a tree that stays in L2 / Infinity Cache, so `frac` is not HBM "
                  "utilisation; `bounds` holds the fractions that are"}
