@@ -36,7 +36,9 @@ namespace tdtk {
 
 #define WAVE 64
 #define ANN_SMALL 64u         // cells up to this size are finished by one wavefront
+#ifndef ANN_MID
 #define ANN_MID 2048u         // round 5: cells up to this size are taken down to ANN_SMALL-point cells by one workgroup in LDS (k_ann_mid)
+#endif
 #define ANN_ERR 0.001         // kd_split.cpp:34
 #define A_LEAF 0x20000000u    // child reference: leaf flag | position (29 bits); c0 bits 30..31 = cutting dimension
 #define A_VAL 0x1FFFFFFFu
