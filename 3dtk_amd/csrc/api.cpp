@@ -149,6 +149,9 @@ struct Ctx {
   uint64_t counted_ann_queries = 0;
   // tdtk_visit_counting: every search of this thread runs its instrumented instantiation and adds to d_counters
   bool counting = false;
+  // tdtk_visit_counting(device, 2): count the REFERENCE's walk -- every search while counting starts cold (no warm start, no
+  // deferred quick check), i.e. kdTreeImpl.h:345-383 with radius maxdist2; results are the same, so a loop stays on its path
+  bool count_cold = false;
   DevBuf d_counters;
   uint64_t counted_queries = 0;
   std::vector<std::unique_ptr<Lane>> lanes;
@@ -1184,7 +1187,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.maxd2 = maxd2;
     sa.kpos = c->ws[WS_KPOS].as<int>();
     sa.skip = skip;
-    sa.warm = (warm && pmode != 1) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
+    sa.warm = (warm && pmode != 1 && !c->count_cold) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
     sa.tie = sa.warm ? search_tie(model, maxd2) : 0.0;
     {
       // ... and WS_COST how many buckets each of its queries visited then: the persistent-lane kernel hands a wave's slab
@@ -1474,7 +1477,9 @@ int tdtk_last_timings(double out[4])
 }
 
 // every FindClosest pass this thread runs on `device` from now on uses the instrumented instantiation of the
-// kernel it would have used (same traversal, same warm radius, same results) and adds to the counters
+// kernel it would have used (same traversal, same warm radius, same results) and adds to the counters; on == 2: the
+// searches also start cold (no warm start, no deferred quick check): what the counters then hold is the walk of the
+// reference's _FindClosest (kdTreeImpl.h:345-383) -- SURVEY 8(d)'s n_int / n_pts -- on the same queries, same results
 int tdtk_visit_counting(int device, int on)
 {
   Ctx* c;
@@ -1488,6 +1493,7 @@ int tdtk_visit_counting(int device, int on)
     c->counted_ann_queries = 0;
   }
   c->counting = on != 0;
+  c->count_cold = on == 2;
   return TDTK_OK;
 }
 
@@ -2710,7 +2716,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       sa.kpos = sl->kpos.as<int>();
       // the previous pass of this very link left its hits here (graph-SLAM rounds repeat their links): each search starts from
       // its previous hit, a point of this tree whatever the scans have done since (k_search's warm start; same index, same d2)
-      sa.warm = (link_warm && sl->k_tree == t->uid && sl->k_scan == data->uid && sl->k_n == data->N) ? 1 : 0;
+      sa.warm = (link_warm && !c->count_cold && sl->k_tree == t->uid && sl->k_scan == data->uid && sl->k_n == data->N) ? 1 : 0;
       // (what the slot will hold is written down once every launch of the call is enqueued: a call that fails on the way must
       //  not leave a slot named after hits that were never written)
       sl->k_tree = sl->k_scan = 0;

@@ -14,9 +14,12 @@ N > 1  workload "graphslam" = configs[3]: 64 scans x 1M points on a closed loop,
        equations over RCCL, redundant solve, pose update.  Total work is fixed -> "strong".
        (--workload graphslam --gpus 1 gives the 1-GPU point of that curve.)
 
-Rank 0 prints ONE JSON line (metric/value/.../roofline/cpu_baseline).  Inputs are resident in
-HBM when the timed region starts; oracle/ is touched by the cpu_baseline legs only (whose first sample
-also serves as a parity spot-check of the GPU indices, outside the timed region).
+Rank 0 prints ONE JSON line on stdout, at most 6 KB: the contract's keys + `roofline` + `cpu_baseline` + the key numbers of
+the other legs.  Everything else that was measured (the full headline record and every leg: tree_build_1gpu, normals_1gpu,
+doicp_small_scans, graphslam_1gpu, c5_shape_1gpu) goes to bench_legs.json beside this file and, one compact line per
+leg, to stderr.  What the fields mean is written down once, in DESIGN.md section 6 -- not in the record.
+Inputs are resident in HBM when the timed region starts; oracle/ is touched by the cpu_baseline legs only (whose first
+sample also serves as a parity spot-check of the GPU indices, outside the timed region).
 """
 import argparse
 import ctypes as C
@@ -40,8 +43,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md: aggregate L2 bandwidth of the 8 XCDs
-PMC_ROUND = "r05"
-PMC_ROUND_C5 = "r05"
+PMC_ROUND = "r06"
+PMC_ROUND_C5 = "r06"
+LINE_MAX = 6144           # the driver parses the last stdout line; round 5's 21.7 KB line did not parse
 NUM_SIMD = 1024            # 256 CUs x 4 SIMDs
 
 
@@ -84,15 +88,18 @@ def measured_bandwidth(local):
 
 
 class visit_counting:
-    """with visit_counting(dev) as vc: ... ; vc.read() -> (internal nodes, buckets, bucket points, queries) of the
-    FindClosest launches issued inside (their instrumented instantiations: same traversal, same warm radius)"""
+    """with visit_counting(dev, mode) as vc: ... ; vc.read() -> (internal nodes, buckets, bucket points, queries) of the
+    FindClosest launches issued inside.  mode 1: the launches' own walk (warm start, deferred quick check);
+    mode 2: the REFERENCE's walk over the same queries (every search cold, kdTreeImpl.h:345-383) -- SURVEY 8(d)'s
+    n_int / n_pts, the figure `roofline.bytes_per_query` is made of.  Results, and so a loop's path, are the same."""
 
-    def __init__(self, dev):
+    def __init__(self, dev, mode=1):
         self.dev = int(dev)
+        self.mode = int(mode)
         self.L = importlib.import_module("3dtk_amd").lib()
 
     def __enter__(self):
-        self.L.tdtk_visit_counting(self.dev, 1)
+        self.L.tdtk_visit_counting(self.dev, self.mode)
         return self
 
     def read(self):
@@ -122,93 +129,66 @@ class kernel_timing:
         self.L.tdtk_kernel_timing(self.was)
 
 
-def search_roofline(k_ms, nq_per_launch, counts, tree_info, extra_bytes_per_query, pmc, bw, pmc_source=None, sums_inside=False):
-    """The `roofline` object for k_search.  achieved = ALGORITHMIC bytes per launch (24 B query + 64 B per
-    internal node + 24 B per bucket point + 4 B index, with the node / point counts of exactly the timed launches) /
-    average launch duration (HIP events).  Beside it the bounds that can tell a good kernel from a better one:
-    compulsory HBM bytes (every byte once), L2 request bytes against the L2 peak, and the fraction of VALU lane-slots
-    that did work."""
+def visits(counts):
     c_int, c_leaf, c_pts, nq = counts
-    # SURVEY 8(d), to the letter: 24 + 64 n_int + 24 n_pts + 4 bytes per query; sums added up inside the launch count 0 B
-    # there (what they really read -- the query again, the hit, the hit point: 60 B per query -- is in `bounds`)
-    bq = algorithmic_bytes_per_query(c_int / nq, c_pts / nq)
+    nq = max(1, nq)
+    return {"internal": c_int / nq, "leaves": c_leaf / nq, "points": c_pts / nq}
+
+
+def counter_bounds(pk, k_ms, comp_bytes):
+    """The utilisations that can rank kernels (all < 1) from a committed rocprofv3 --pmc summary `pk` of the same launch
+    (DESIGN.md section 6 defines each): fabric bytes against compulsory bytes and the HBM peak, L2 hit rate, how busy each
+    CU's vector L1 was, the share of VALU lane-slots that did work, the share of a wave's cycles spent waiting."""
+    b = {"compulsory_hbm": {"bytes": comp_bytes, "frac": comp_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    traffic = pmc_traffic_bytes(pk)
+    if traffic:
+        b["hbm_traffic_pmc"] = {"bytes": traffic, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "refetch_factor": traffic / comp_bytes, "write_bytes": pk["WRITE_SIZE_KiB"] * 1024.0}
+    if not pk:
+        return b
+    hit, miss = pk.get("TCC_HIT_sum"), pk.get("TCC_MISS_sum")
+    if hit is not None and miss is not None:
+        b["l2_hit_rate"] = hit / max(1.0, hit + miss)
+    if pk.get("GRBM_GUI_ACTIVE") and pk.get("SQ_ACTIVE_INST_VALU"):
+        cyc = pk["GRBM_GUI_ACTIVE"] / 8.0                    # the counter sums the 8 XCDs
+        b["valu_busy"] = pk["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc)
+        if pk.get("SQ_THREAD_CYCLES_VALU"):
+            b["lane_efficiency"] = pk["SQ_THREAD_CYCLES_VALU"] / (pk["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if pk.get("TCP_GATE_EN2_sum"):
+            b["vector_l1_busy"] = pk["TCP_GATE_EN2_sum"] / 256.0 / cyc
+        if pk.get("TCP_PENDING_STALL_CYCLES_sum"):
+            b["vector_l1_stalled_on_fills"] = pk["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc
+        if pk.get("TCP_TCC_READ_REQ_LATENCY_sum") and pk.get("TCP_TCC_READ_REQ_sum"):
+            b["l1_miss_latency_cycles"] = pk["TCP_TCC_READ_REQ_LATENCY_sum"] / pk["TCP_TCC_READ_REQ_sum"]
+    if pk.get("SQ_WAVE_CYCLES") and pk.get("SQ_WAIT_ANY"):
+        b["wave_wait_share"] = pk["SQ_WAIT_ANY"] / pk["SQ_WAVE_CYCLES"]
+    if pk.get("SQ_INSTS_VMEM_WR"):
+        b["vmem_write_wave_instructions"] = pk["SQ_INSTS_VMEM_WR"]
+    return b
+
+
+def search_roofline(kernel, k_ms, nq_per_launch, counts_ref, counts_walked, comp_bytes, pk, bw, pmc_file):
+    """The `roofline` object of a search launch.  achieved = SURVEY 8(d)'s ALGORITHMIC bytes per launch -- 24 B query +
+    64 B per internal node + 24 B per bucket point + 4 B index, with the node / point counts of the REFERENCE's walk
+    (kdTreeImpl.h:345-383, cold, radius maxdist2) over exactly the queries of the timed launches (`visits_per_query`) --
+    / average launch duration (HIP events).  `visits_walked` = what the kernel's own walk visited (warm start, deferred
+    quick check) and its byte ratio to the reference's; `bounds` = the utilisations from the committed counter summary."""
+    v = visits(counts_ref)
+    bq = algorithmic_bytes_per_query(v["internal"], v["points"])
     achieved = bq * nq_per_launch / (k_ms * 1e-3) / 1e9
-    comp = (tree_info["n_internal"] * 64 + tree_info["n_points"] * 32 + extra_bytes_per_query * nq_per_launch)
-    r = {"bound": "hbm", "kernel": "k_search" + (" (the search and, by each wave over its own slab, the pair sums: no k_accum launch)" if sums_inside else ""),
-         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc),
-         "kernel_ms": k_ms, "bytes_per_query": bq,
-         "visits_per_query": {"internal": c_int / nq, "leaves": c_leaf / nq, "points": c_pts / nq,
-                              "counted_on": "the timed launches themselves (warm-start radius included; over a tree of <= 256 MB a warm query "
-                                            "defers the reference's quick check in its divergent visits -- DESIGN section 4 -- and so visits a few "
-                                            "more nodes and buckets than the reference's walk: TDTK_DEFER_CHECK=0 counts the reference's)"},
-         "nn_per_s_kernel_only": nq_per_launch / (k_ms * 1e-3),
-         "note": "algorithmic bytes are re-reads of a tree that stays in L2 / Infinity Cache, so `frac` is not HBM "
-                 "utilisation; `bounds` holds the fractions that are"}
-    b = {"peak_measured_copy_GBs": bw.get("hbm_copy"), "peak_measured_l2_GBs": bw.get("l2_read"),
-         "compulsory_hbm": {"bytes": comp, "GBs": comp / (k_ms * 1e-3) / 1e9, "frac": comp / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "what": "tree once + every query read / written once"}}
-    if sums_inside:
-        b["fused_sums"] = {"bytes_per_query": 60.0, "GBs": 60.0 * nq_per_launch / (k_ms * 1e-3) / 1e9,
-                           "what": "what the pair sums inside the launch read on top of the search (query again 24 B, hit 4 B, hit "
-                                   "point 32 B): counted as 0 B by SURVEY 8(d) and therefore not in `achieved` / `frac`"}
-    if bw.get("hbm_copy"):
-        r["frac_of_measured_copy"] = achieved / bw["hbm_copy"]
-    if r["traffic"]:
-        b["hbm_traffic_pmc"] = {"bytes": r["traffic"], "GBs": r["traffic"] / (k_ms * 1e-3) / 1e9,
-                                "frac": r["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "refetch_factor": r["traffic"] / comp}
-    if pmc:
-        req = pmc.get("TCC_REQ_sum") or ((pmc.get("TCC_HIT_sum") or 0) + (pmc.get("TCC_MISS_sum") or 0))
-        if req:
-            l2b = req * 128.0
-            b["l2"] = {"requests": req, "bytes": l2b, "GBs": l2b / (k_ms * 1e-3) / 1e9, "peak": L2_PEAK_GBS,
-                       "frac": l2b / (k_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
-                       "hit_rate": (pmc.get("TCC_HIT_sum") or 0) / max(1.0, (pmc.get("TCC_HIT_sum") or 0) + (pmc.get("TCC_MISS_sum") or 0))}
-        if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
-            b["valu_lane_efficiency"] = {"frac": pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0),
-                                         "what": "SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64): share of the lane-slots "
-                                                 "of issued VALU instructions that were active"}
-        if pmc.get("SQ_INSTS_VALU"):
-            b["valu_wave_instructions"] = pmc["SQ_INSTS_VALU"]
-        if pmc.get("SQ_WAVE_CYCLES") and pmc.get("SQ_WAIT_ANY"):
-            b["wave_wait_share"] = {"frac": pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"],
-                                    "what": "SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of a wave's resident cycles spent waiting "
-                                            "(dependent loads, issue slots taken by the other waves of its SIMD)"}
-    b["source"] = pmc_source or {"file": None, "note": "no committed counter summary for this command's steps / warmup: "
-                                                        "`traffic` is null and the counter-derived bounds are absent"}
+    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pk), "kernel_ms": k_ms,
+         "bytes_per_query": bq, "queries_per_launch": nq_per_launch, "visits_per_query": v,
+         "nn_per_s_kernel_only": nq_per_launch / (k_ms * 1e-3)}
+    if counts_walked is not None:
+        w = visits(counts_walked)
+        w["bytes_ratio"] = algorithmic_bytes_per_query(w["internal"], w["points"]) / bq
+        r["visits_walked"] = w
+    b = counter_bounds(pk, k_ms, comp_bytes)
+    b["peak_measured_copy_GBs"] = bw.get("hbm_copy")
+    b["peak_measured_l2_GBs"] = bw.get("l2_read")
+    b["source"] = {"file": ("profiles/" + pmc_file) if pk else None}
     r["bounds"] = b
-    # The utilisations that can rank kernels (all < 1), from the same counter summary: how busy the vector ALUs were and
-    # how many of the lane-slots of the issued vector instructions did work.  (`frac` above is algorithmic bytes against
-    # HBM -- saturated by cache re-reads on this workload, not a utilisation.)
-    if pmc and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
-        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0                    # the counter sums the 8 XCDs
-        issue = {"valu_busy": pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc),
-                 "what": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
-        if pmc.get("SQ_THREAD_CYCLES_VALU"):
-            issue["lane_efficiency"] = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
-        if pmc.get("SQ_INSTS_VALU"):
-            issue["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
-        if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
-            issue["l1_tag_accesses_per_cu_cycle"] = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc
-        if pmc.get("TCP_GATE_EN2_sum"):
-            # the resource this kernel is closest to: the vector L1 (TCP) of each CU
-            l1 = {"busy": pmc["TCP_GATE_EN2_sum"] / 256.0 / cyc,
-                  "what": "TCP_GATE_EN2 (the L1's core clocked: it has work) / (256 CUs x kernel cycles); clock_on = TCP_GATE_EN1 likewise; "
-                          "stalled_on_pending_fills = TCP_PENDING_STALL_CYCLES, stalled_on_tag_conflicts = TCP_READ_TAGCONFLICT_STALL_CYCLES, "
-                          "both as shares of the CU-cycles; cycles_per_wave_instruction = TCP_TCP_LATENCY / TCP_TA_TCP_STATE_READ; "
-                          "miss_latency_cycles = TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ"}
-            if pmc.get("TCP_GATE_EN1_sum"): l1["clock_on"] = pmc["TCP_GATE_EN1_sum"] / 256.0 / cyc
-            if pmc.get("TCP_PENDING_STALL_CYCLES_sum"): l1["stalled_on_pending_fills"] = pmc["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc
-            if pmc.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"): l1["stalled_on_tag_conflicts"] = pmc["TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"] / 256.0 / cyc
-            if pmc.get("TCP_TCP_LATENCY_sum") and pmc.get("TCP_TA_TCP_STATE_READ_sum"):
-                l1["cycles_per_wave_instruction"] = pmc["TCP_TCP_LATENCY_sum"] / pmc["TCP_TA_TCP_STATE_READ_sum"]
-            if pmc.get("TCP_TCC_READ_REQ_LATENCY_sum") and pmc.get("TCP_TCC_READ_REQ_sum"):
-                l1["miss_latency_cycles"] = pmc["TCP_TCC_READ_REQ_LATENCY_sum"] / pmc["TCP_TCC_READ_REQ_sum"]
-            if pmc.get("TCP_UTCL1_TRANSLATION_MISS_sum") is not None and pmc.get("TCP_UTCL1_REQUEST_sum"):
-                l1["translation_miss_rate"] = pmc["TCP_UTCL1_TRANSLATION_MISS_sum"] / pmc["TCP_UTCL1_REQUEST_sum"]
-            issue["vector_l1"] = l1
-        r["issue"] = issue
     return r
 
 
@@ -394,12 +374,7 @@ def bench_small_scans(args, local):
            "iterations_per_match": {"mean": float(np.mean(iters)), "max": int(max(iters))},
            "ms_per_iteration": float(np.sum(match_ms) / max(1, sum(it + 1 for it in iters))),
            "loop_ms_per_match": float(np.mean(loop_ms)),
-           "loop_us_per_iteration": float(1e3 * np.sum(loop_ms) / max(1, sum(it + 1 for it in iters))),
-           "what": "16 synthetic street-scene scans (C3's shape; hannover1 is not on the box): tdtk_reduce_octree -r 10, then "
-                   "icp6D::doICP over the reduced scans; `match` = wall time of one icp6D::match with nothing prepared ahead (the model's tree build and the "
-                   "scan's upload + ordering are inside it; `ms_per_iteration` divides THAT by the iterations), `loop_*` = the device-resident loop alone by the library's clock, "
-                   "`tree_build` = tdtk_tree_create on the device, doICP_wall = (whole doICP) / 15 with the next three scans' "
-                   "upload + ordering + tree build on worker threads or with nothing prepared ahead (identical poses)"}
+           "loop_us_per_iteration": float(1e3 * np.sum(loop_ms) / max(1, sum(it + 1 for it in iters)))}
     if not args.no_cpu:
         from oracle import orc
         if orc.have_ref():
@@ -414,10 +389,7 @@ def bench_small_scans(args, local):
             t0 = time.perf_counter(); tree.icp_iterations(np.eye(4).reshape(16), gb, 75.0 ** 2, threads, nit); tm = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": (tb + tm) * 1e3, "unit": "ms per scan (tree build + match)", "cores": threads, "kind": "reference",
                                    "tree_build_ms": tb * 1e3, "match_ms": tm * 1e3,
-                                   "sample": "scans 0 / 1 of this run: KDtreeIndexed's constructor over %d points (serial, as the "
-                                             "reference builds it) + %d full icp6D::match iterations of the OpenMP branch with %d "
-                                             "threads (oracle/_ref: the reference's compiled TUs); the octree reduction is not part "
-                                             "of it (Boctree.h needs Boost)" % (len(ga), nit, threads)}
+                                   "sample": "scans 0/1: KDtreeIndexed ctor over %d points + %d OpenMP-branch iterations" % (len(ga), nit)}
     return out
 
 
@@ -504,9 +476,7 @@ def cpu_baseline_nn(model, queries, maxd2, budget_s=8.0, check=None, full_iter=N
     allc = reps * len(queries) / t_all
     out = {"value": allc, "unit": "NN correspondences/s", "cores": threads, "kind": kind,
            "one_thread_value": one, "nn_only_value": allc,
-           "sample": "%d passes of KDtreeIndexed::FindClosest over the same %d queries with %d OpenMP threads "
-                     "(static chunks, threadNum = thread id) + 200k queries on 1 thread; NN search only "
-                     "(the dominant share of getPtPairs; pair sums/solve excluded)" % (reps, len(queries), threads)}
+           "sample": "%d FindClosest passes over the same %d queries, %d threads; NN only" % (reps, len(queries), threads)}
     if kind == "reference" and full_iter is not None:
         # the same unit of work as `value` of the GPU line: FULL icp6D::match iterations of the OpenMP branch
         # (icp6D.cc:129-222) -- per-thread getPtPairs chunks incl. the critical-section push_back of 208-byte
@@ -521,10 +491,9 @@ def cpu_baseline_nn(model, queries, maxd2, budget_s=8.0, check=None, full_iter=N
         T, dtT, tr = best
         out.update({"value": len(data0) / dtT, "cores": T, "ms_per_iteration": dtT * 1e3,
                     "first_iteration_pairs": int(tr[0, 0]), "first_iteration_rms": float(tr[0, 1]),
-                    "sample": "2 full ICP iterations (getPtPairs chunks + Si + Align_Parallel + transform) of the same "
-                              "%d-vs-%d pair from the initial pose with OPENMP_NUM_THREADS = 16 / 64 / all %d host threads, "
-                              "best kept (%d threads); `nn_only_value` = %d passes of KDtreeIndexed::FindClosest alone on "
-                              "%d threads" % (len(data0), len(model), threads, T, reps, threads)})
+                    "sample": "2 full icp6D::match iterations (OpenMP branch) of the same %d-vs-%d pair from the initial pose, "
+                              "best of 16 / 64 / %d threads; nn_only_value: %d FindClosest passes on %d threads"
+                              % (len(data0), len(model), threads, reps, threads)})
     return out
 
 
@@ -539,29 +508,6 @@ def bench_icp(args, rank, world, local):
     info = tree.info()
     _ = data.handle
     mini = tdtk.icp6D_QUAT(True)
-    # A box that has just been leased is not in its steady state: the first processes after the lease see ~0.5 ms of
-    # host-side latency per iteration (wake-up of the waiting thread) while the kernels run at full speed, for some
-    # tens of seconds.  Before the contract's warm-up the same loop therefore runs on a scratch copy of the data
-    # scan until the time an iteration spends outside its kernels has settled (or 20 s have passed); nothing of it
-    # touches the scans that are timed.
-    settle = {"seconds": 0.0, "rounds": 0, "outside_ms_first": None, "outside_ms_last": None}
-    ts0 = time.perf_counter()
-    while time.perf_counter() - ts0 < 20.0:
-        scratch = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
-        _ = scratch.handle
-        probe = tdtk.icp6D(mini, 25.0, 10, quiet=True, epsilonICP=-1.0)      # (ten iterations a look: a settled box leaves after one)
-        with kernel_timing():
-            tq = time.perf_counter(); itp = probe.match(model, scratch); dq = time.perf_counter() - tq
-        outside = dq * 1e3 / (itp + 1) - (probe.last["nn_ms"] + probe.last["sums_ms"]) / (itp + 1)
-        del scratch
-        settle["rounds"] += 1
-        settle["iterations"] = settle.get("iterations", 0) + itp + 1
-        if settle["outside_ms_first"] is None:
-            settle["outside_ms_first"] = outside
-        settle["outside_ms_last"] = outside
-        if outside < 0.04:
-            break
-    settle["seconds"] = time.perf_counter() - ts0
     # warm-up: W untimed iterations of the same loop (also brings the pose close to T)
     icp_w = tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0)
     icp_w.match(model, data)
@@ -590,41 +536,43 @@ def bench_icp(args, rank, world, local):
     last_t = icp_t.last
     del rep_t
 
-    # Algorithmic bytes of exactly the timed launches: the loop is deterministic, so a second data scan run through
-    # the same W + K iterations with the instrumented kernel (same traversal, same warm-start radius; counters
-    # switched on after the warm-up) visits what the timed launches visited -- checked through the final RMS.
-    rep = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
-    _ = rep.handle
-    tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0).match(model, rep)
-    icp_c = tdtk.icp6D(mini, 25.0, args.steps, quiet=True, epsilonICP=-1.0)
-    with visit_counting(local) as vc:
-        icp_c.match(model, rep)
-        counts = vc.read()
-    assert icp_c.last["rms"] == last["rms"] and icp_c.last["pairs"] == last["pairs"], "counting replay diverged"
-    assert counts[3] == n * steps, counts
-    del rep
+    # Algorithmic bytes of exactly the timed launches: the loop is deterministic (the results of a search do not depend on
+    # how it walks), so further data scans run through the same W + K iterations with the instrumented kernels see the
+    # queries the timed launches saw -- checked through the final RMS.  Counted twice: the REFERENCE's walk (mode 2:
+    # every search cold, SURVEY 8(d)'s n_int / n_pts, what `bytes_per_query` is made of) and the launches' own walk.
+    def counted_replay(mode):
+        rep = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local)
+        _ = rep.handle
+        tdtk.icp6D(mini, 25.0, max(1, args.warmup), quiet=True, epsilonICP=-1.0).match(model, rep)
+        icp_c = tdtk.icp6D(mini, 25.0, args.steps, quiet=True, epsilonICP=-1.0)
+        with visit_counting(local, mode) as vc:
+            icp_c.match(model, rep)
+            cnt = vc.read()
+        assert icp_c.last["rms"] == last["rms"] and icp_c.last["pairs"] == last["pairs"], "counting replay diverged"
+        assert cnt[3] == n * steps, cnt
+        rep.release()
+        return cnt
+    counts_ref = counted_replay(2)
+    counts_own = counted_replay(1)
     cur = data.get_xyz_reduced()
     k_ms = last_t["nn_ms"] / steps                        # HIP-event time of k_search, per launch
     sums_ms = last_t["sums_ms"] / steps                   # ... and of the pair-sum kernels behind it
     bw = measured_bandwidth(local)
-    ti = {"n_internal": info["n_internal"], "n_points": n}
-    # compulsory bytes per query besides the tree: x,y,z read + written back (fused transform), hit position written
-    # and read back (warm start of the next pass)
     pfile = pmc_file_for(steps, args.warmup)
     pk = pmc_kernel("k_search [timed region]", pfile, steps, args.warmup)
-    psrc = {"file": "profiles/" + pfile, "steps": steps, "warmup": args.warmup,
-            "what": "per-launch averages over the timed region of the same command line under rocprofv3 --pmc "
-                    "(tools/profile_bench.sh); refused unless steps and warmup equal this run's"} if pk else None
     sums_inside = 262144 <= n < 256 * 7168   # (one generation of waves: each adds up its own slab, FUSE 3)
-    roof = search_roofline(k_ms, n, counts, ti, 24 + 24 + 4 + 4 + (60 if sums_inside else 0), pk, bw, psrc, sums_inside)
+    # compulsory bytes: the tree once (64 B per node, 32 B per point) + per query x,y,z read and written back (fused
+    # transform), the hit written and read back (warm start) and, with the sums inside, query + hit + hit point again
+    comp = info["n_internal"] * 64 + n * 32 + n * (24 + 24 + 4 + 4 + (60 if sums_inside else 0))
+    roof = search_roofline("k_search_refill (search + fused transform" + (" + pair sums" if sums_inside else "") + ")",
+                           k_ms, n, counts_ref, counts_own, comp, pk, bw, pfile)
 
     # the same 1M queries through the host-buffer entry point (H2D of queries, in-call binning,
     # search, D2H of indices + distances): the PCIe-inclusive rate -- reported, never the `value`
     t_h = []
     for _ in range(3):
         th0 = time.perf_counter(); tree.FindClosestBatch(cur, 625.0); t_h.append(time.perf_counter() - th0)
-    host_path = {"value": n / min(t_h), "unit": "NN correspondences/s", "ms": min(t_h) * 1e3,
-                 "what": "tdtk_find_closest on host buffers: 24 MB up, binning, search, 12 MB down"}
+    host_path = {"value": n / min(t_h), "unit": "NN correspondences/s", "ms": min(t_h) * 1e3}
     prep = {}
     tp0 = time.perf_counter(); t2_ = tdtk.KDtree(m, 20, device=local); prep["tree_create_ms"] = (time.perf_counter() - tp0) * 1e3
     tp0 = time.perf_counter(); s2_ = tdtk.Scan([0, 0, 0], [0, 0, 0], d, device=local); _ = s2_.handle
@@ -647,8 +595,7 @@ def bench_icp(args, rank, world, local):
     icp_f = tdtk.icp6D(mini, 25.0, 400, quiet=True, epsilonICP=1e-5)
     more = icp_f.match(model, data) + 1
     pose_err_converged = float(np.abs(data.get_transMat() - T).max())
-    convergence = {"further_iterations": more, "pose_max_abs_err": pose_err_converged, "rms": icp_f.last["rms"],
-                   "what": "the timed loop continued (untimed) until |d rms| < 1e-5 twice, pose against T_gt"}
+    convergence = {"further_iterations": more, "pose_max_abs_err": pose_err_converged, "rms": icp_f.last["rms"]}
     assert pose_err_converged < 2e-2, "ICP did not converge to the generating pose: %r" % (convergence,)
 
     out = {
@@ -656,36 +603,28 @@ def bench_icp(args, rank, world, local):
         "value": n * steps / dt, "unit": "NN correspondences/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[1]: synthetic %d-vs-%d uniform pair, point-to-point ICP (-a 1 -d 25 -b 20), "
-                               "1xMI355X, device-resident icp6D::match" % (n, n),
+        "config": {"workload": "configs[1]: synthetic %d-vs-%d uniform pair, point-to-point ICP -a 1 -d 25 -b 20, 1xMI355X" % (n, n),
                    "points": n, "bucket": 20, "max_dist_match": 25.0, "minimizer": "QUAT",
                    "tree": {"internal": info["n_internal"], "leaves": info["n_leaves"], "depth": info["max_depth"]},
                    "tree_build_ms": info["build_ms"], "tree_upload_ms": info["upload_ms"]},
         "icp_iters_per_s": steps / dt,
         "pairs_last": last["pairs"], "rms_last": last["rms"], "pose_max_abs_err": pose_err, "convergence": convergence,
         "host_buffer_path": host_path, "per_scan_preparation": prep,
-        "pair_sums_ms": sums_ms, "outside_kernels_ms": dt * 1e3 / steps - k_ms - sums_ms, "settle": settle,
-        "kernel_times_from": "a second run of the same %d + %d iterations with the library's HIP events on "
-                             "(tdtk_kernel_timing; same launches, final RMS equal): %.4f ms per iteration with the events, "
-                             "%.4f without (the timed region)" % (args.warmup, steps, dt_ev * 1e3 / steps, dt * 1e3 / steps),
+        "pair_sums_ms": sums_ms, "outside_kernels_ms": dt * 1e3 / steps - k_ms - sums_ms,
         "ms_per_step_with_kernel_events": dt_ev * 1e3 / steps,
         # for whoever reads a kernel trace of this command: the timed region is search launches [first, first + steps)
-        "search_launches_before_timed_region": settle.get("iterations", 0) + max(1, args.warmup),
+        "search_launches_before_timed_region": max(1, args.warmup),
         "roofline": roof,
     }
-    # tree build (A1) on the device: a latency chain (the reference's serial-order fp64 centroid), reported against
-    # the bytes its levels move: every level streams the 24-B points + 8 B of permutation / keys in and out
+    # tree build (A1) on the device, against the bytes its levels move: every level streams the 24-B points + 8 B of
+    # permutation / keys in and out (64 B per point and level)
     levels = info["max_depth"]
     tb_bytes = float(levels) * n * 64.0
     out["tree_build_1gpu"] = {"ms": info["build_ms"], "first_build_ms": first_build_ms, "points": n, "levels": levels,
-                              "roofline": {"bound": "hbm", "kernel": "k_measure + partition passes (device tree build)",
+                              "roofline": {"bound": "hbm", "kernel": "device tree build (level passes + subtree finisher)",
                                            "achieved": tb_bytes / (info["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": tb_bytes / (info["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "traffic": None,
-                                           "note": "not bound by bytes: the order-dependent fp64 centroid sums of the big nodes run on a "
-                                                   "second stream beside the levels (speculative splits, every cut checked against "
-                                                   "its exact sum at the end); what is left is ~9 dependent launches per level: "
-                                                   "DESIGN.md section 4"}}
+                                           "traffic": None}}
     if rank == 0 and not args.no_cpu:
         gi, _ = tree.FindClosestBatch(cur[:20000], 625.0)
         out["cpu_baseline"] = cpu_baseline_nn(m, cur, 625.0, check=gi, full_iter=(d, model.dalignxf))
@@ -704,17 +643,13 @@ def bench_icp(args, rank, world, local):
         # the k neighbours gathered for mean / covariance (24 B each) + the normal out (24)
         bp = 24.0 + 32.0 * a_split / a_q + 24.0 * a_leaf / a_q + 24.0 * 10 + 24.0
         ach = bp * n / (kn_ms * 1e-3) / 1e9
-        pk = pmc_kernel("k_ann_normals<10>", "r01_normals_pmc.json")   # tools/profile_normals.sh (the kernel is unchanged since)
+        pk = pmc_kernel("k_ann_normals<10>", "r01_normals_pmc.json")   # tools/profile_normals.sh
         out["normals_1gpu"] = {"value": n / min(t_n), "unit": "points/s", "ms": min(t_n) * 1e3, "points": n, "k": 10, "eps": 1.0,
-                               "what": "tdtk_scan_calc_normals on the resident scan: ANN-tree build, approximate 10-NN, "
-                                       "PCA normal per point; lists and normals bit-identical to the vendored ANN + newmat",
                                "roofline": {"bound": "hbm", "kernel": "k_ann_normals", "achieved": ach, "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pk),
                                             "kernel_ms": kn_ms, "bytes_per_point": bp,
                                             "visits_per_point": {"split_nodes": a_split / a_q, "leaf_points": a_leaf / a_q},
-                                            "whole_call_ms": min(t_n) * 1e3,
-                                            "note": "the k-NN + PCA kernel alone; the ANN-tree build (~250 small launches) "
-                                                    "is the rest of the call"}}
+                                            "whole_call_ms": min(t_n) * 1e3}}
         if not args.no_cpu:
             from oracle import orc as _orc
             ns = min(n, 100000)
@@ -722,7 +657,7 @@ def bench_icp(args, rank, world, local):
             tc0 = time.perf_counter(); _orc.normals_apx_knn(cur[:ns], 10, [0.0, 0.0, 0.0], 1.0, which); tc = time.perf_counter() - tc0
             out["normals_1gpu"]["cpu_baseline"] = {"value": ns / tc, "unit": "points/s", "cores": 1,
                                                    "kind": "reference" if which == "ref" else "port",
-                                                   "sample": "first %d points of the scan (the reference's calcNormals is serial)" % ns}
+                                                   "sample": "first %d points of the scan (serial calcNormals)" % ns}
     if world == 1 and not args.no_small_scans:
         out["doicp_small_scans"] = bench_small_scans(args, local)
     if world == 1 and args.workload == "auto" and not args.no_graphslam_base:
@@ -734,8 +669,6 @@ def bench_icp(args, rank, world, local):
         g1 = bench_graphslam(ga, rank, world, local)
         out["graphslam_1gpu"] = {k: g1[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "lum_iters_per_s", "roofline", "sharded_step_rehearsal")}
         out["graphslam_1gpu"]["workload"] = g1["config"]["workload"]
-        out["scaling_note"] = ("N>1 runs of this script measure configs[3] (graph-SLAM, links sharded); its 1-GPU point is "
-                               "graphslam_1gpu here, not `value` (configs[1], which BASELINE.json fixes to one GPU)")
     if world == 1 and args.workload == "auto" and not args.no_c5:
         try:
             del model, data, tree
@@ -782,9 +715,7 @@ def rehearse_shards(tdtk, gs, scans, nscans, npts, full_ms, local):
         per = [time_links(sh) for sh in shares]
         pred[str(world)] = {"links_per_rank": [len(x) for x in shares], "slowest_share_ms": max(per), "rest_ms": rest,
                             "predicted_step_ms": max(per) + rest}
-    return {"what": "PREDICTION from a one-GPU rehearsal, not a measurement on N GPUs: slowest rank's share of the link passes "
-                    "timed on this GPU + the non-sharded rest of this run's step (replicated on every rank)",
-            "all_links_ms": all_ms, "rest_ms": rest, "by_world": pred}
+    return {"kind": "prediction (one-GPU rehearsal, not measured on N GPUs)", "all_links_ms": all_ms, "rest_ms": rest, "by_world": pred}
 
 
 def bench_graphslam(args, rank, world, local):
@@ -852,15 +783,16 @@ def bench_graphslam(args, rank, world, local):
     tdtk.lib().tdtk_kernel_timing(0)
     queries = links_done * npts                         # one whole-scan NN pass per link
     k_ms = nn_ms[0] / max(1, args.steps)                # one sampled k_search launch per step
-    # algorithmic bytes of this rank's link passes: one more step with the instrumented kernels (poses have converged
-    # to ~1e-3 per step by now, so it visits what the timed steps visited to within a fraction of a percent)
-    with visit_counting(local) as vc:
+    # algorithmic bytes of this rank's link passes: two more steps with the instrumented kernels (poses have converged to
+    # ~1e-3 per step by now, so they visit what the timed steps visited to within a fraction of a percent): the reference's
+    # walk (mode 2, every search cold: SURVEY 8(d)) and the launches' own (warm start from the link's previous hits)
+    with visit_counting(local, 2) as vc:
         step()
-        counts = vc.read()
+        counts_ref = vc.read()
+    with visit_counting(local, 1) as vc:
+        step()
+        counts_own = vc.read()
     my_links = max(1, len(gs.shard_links(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), rank, world, scans)))
-    bq = algorithmic_bytes_per_query(counts[0] / max(1, counts[3]), counts[2] / max(1, counts[3]))
-    # (the search launch also adds up each link's 17 sums: query again + hit + the hit point, 60 B per query -- counted as 0 B by
-    # SURVEY 8(d), so NOT in bytes_per_query / achieved / frac; reported beside them in bounds.fused_sums like the ICP leg's)
     links_sums_inside = npts >= 262144
     # All link passes of a rank go out in launches of up to 128 links (k_search_refill_multi); the HIP events sit around the
     # LAST launch of a step.  achieved = algorithmic bytes of that launch / its duration; beside it the aggregate over
@@ -870,14 +802,24 @@ def bench_graphslam(args, rank, world, local):
     batched = batch > 1 and my_links > 1 and npts >= 262144
     groups = (my_links + batch - 1) // batch if batched else my_links
     last_links = my_links - batch * (groups - 1) if batched else 1
-    agg = bq * my_links * npts / (dt / args.steps) / 1e9
-    ach = bq * last_links * npts / (k_ms * 1e-3) / 1e9 if k_ms > 0 else agg
     pk = pmc_kernel("k_search (several links per launch)" if batched else "k_search", PMC_ROUND + "_graphslam_pmc.json")
-    traffic = pmc_traffic_bytes(pk)
-    if traffic is not None and batched:
-        traffic = traffic * groups / my_links * last_links      # the committed passes average over a step's launches
-    exchange = ("RCCL ncclAllReduce inside the library (tdtk_graph_iteration), %d collectives issued" % comm.n_allreduce()) if comm is not None \
-        else ("torch.distributed (gloo test rig)" if use_torch_exchange else "none (one rank)")
+    if pk and batched and groups != 1:
+        pk = None                                             # (the committed passes are of one launch holding every link)
+    # compulsory: every tree walked once (64 B per node + 32 B per point + 12 B of fp32 shadow) + per query x,y,z read, hit written
+    # and read back, and for the sums query + hit + hit point again
+    trees = len({g0.getLink(i, 0) for i in mine}) if len(mine) else 1
+    info0 = scans[g0.getLink(mine[0], 0)].getSearchTree().info() if len(mine) else {"n_internal": 0}
+    comp = trees * (info0["n_internal"] * 64 + npts * 44) * last_links / my_links + last_links * npts * (24 + 4 + 4 + (60 if links_sums_inside else 0))
+    bw = measured_bandwidth(local) if rank == 0 else {}
+    kname = ("k_search_refill_multi (%d links per launch%s)" % (last_links, ", sums inside" if links_sums_inside else "")) if batched else "k_search (link passes on streams side by side)"
+    roof = search_roofline(kname, k_ms if k_ms > 0 else dt * 1e3 / args.steps, last_links * npts, counts_ref, counts_own, comp, pk, bw, PMC_ROUND + "_graphslam_pmc.json")
+    roof.update({"links_in_that_launch": last_links, "launches_per_step": groups, "links_this_rank": my_links})
+    agg = roof["bytes_per_query"] * my_links * npts / (dt / args.steps) / 1e9
+    roof["whole_step"] = {"achieved": agg, "frac": agg / HBM_PEAK_GBS}
+    if roof["traffic"]:
+        roof["bounds"]["hbm_traffic_pmc"]["GB_per_link"] = roof["traffic"] / max(1, last_links) / 1e9
+    exchange = ("RCCL ncclAllReduce inside tdtk_graph_iteration, %d collectives issued" % comm.n_allreduce()) if comm is not None \
+        else ("torch.distributed gloo (test rig)" if use_torch_exchange else "none (one rank)")
     # what actually ran, for whoever reads the N > 1 line: the size of the communicator as RCCL itself reports it
     # (ncclCommCount; NativeComm / tdtk_comm_create refuse anything but the world asked for) and every rank's share of the links
     owners = gs.link_owners(tdtk.Graph(nscans, 500.0 ** 2, 20, scans), world, scans)
@@ -891,101 +833,18 @@ def bench_graphslam(args, rank, world, local):
     if comm is not None:
         barrier_sync(world)
         comm.close()                  # ncclCommDestroy now, on every rank together, not at interpreter shutdown
-    out = {
+    return {
         "metric": "NN correspondences/sec (graph-SLAM lum6DEuler iteration, links sharded)",
         "value": queries / dt, "unit": "NN correspondences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[3]: synthetic %d scans x %d pts, graph-SLAM -G 1 (lum6DEuler) one iteration per "
-                               "step, %d links dealt over %d ranks, one fp64 all-reduce of %d doubles (42 per link)"
-                               % (nscans, npts, nlinks, world, 42 * nlinks),
+        "config": {"workload": "configs[3]: synthetic %d scans x %d pts, graph-SLAM -G 1 (lum6DEuler), one iteration per step, "
+                               "%d links over %d ranks, one fp64 all-reduce of %d doubles" % (nscans, npts, nlinks, world, 42 * nlinks),
                    "scans": nscans, "points": npts, "links": nlinks},
         "lum_iters_per_s": args.steps / dt, "last_ret": ret, "sharded_step_rehearsal": rehearsal,
         "exchange": exchange, "rccl_world": rccl_world, "links_per_rank": links_per_rank,
-        "scaling_note": "strong scaling of configs[3]; the 1-GPU point of this workload is `graphslam_1gpu` in the N=1 line "
-                        "(the N=1 `value` is configs[1], pairwise ICP, which BASELINE.json fixes to one GPU)",
-        "roofline": {"bound": "hbm", "kernel": ("k_search_refill_multi (link passes, up to %d links per launch%s)" % (batch, "; the links' sums are added up inside it" if links_sums_inside else "")) if batched
-                                               else "k_search (link passes on streams side by side)",
-                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel_ms": k_ms, "links_in_that_launch": last_links, "launches_per_step": groups,
-                     "bytes_per_query": bq,
-                     "visits_per_query": {"internal": counts[0] / max(1, counts[3]), "points": counts[2] / max(1, counts[3])},
-                     "links_this_rank": my_links,
-                     "whole_step": {"achieved": agg, "frac": agg / HBM_PEAK_GBS,
-                                    "what": "algorithmic bytes of ALL this rank's link searches per step / step wall time "
-                                            "(exchange, solve and pose update in the denominator)"},
-                     "note": "achieved = algorithmic bytes of the step's last search launch / its HIP-event duration; like "
-                             "the ICP figure it counts re-reads served by L2 (not a utilisation); `traffic` = PMC fabric bytes of "
-                             "such a launch.  This is the one configuration whose working set (64 scans and trees, 3.5 GB) exceeds "
-                             "the 256 MB Infinity Cache: its fabric traffic is mostly HBM traffic, see bounds.hbm_traffic_pmc"},
+        "roofline": roof,
     }
-    if links_sums_inside and k_ms > 0:
-        out["roofline"]["bounds"] = {"fused_sums": {"bytes_per_query": 60.0, "GBs": 60.0 * last_links * npts / (k_ms * 1e-3) / 1e9,
-                                                    "what": "what the links' sums inside the launch read on top of the search (query again 24 B, hit 4 B, "
-                                                            "hit point 32 B): 0 B by SURVEY 8(d), not in `achieved` / `frac`"}}
-    if traffic is not None and k_ms > 0:
-        b = {"hbm_traffic_pmc": {"bytes": traffic, "GBs": traffic / (k_ms * 1e-3) / 1e9, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "GB_per_link": traffic / max(1, last_links) / 1e9,
-                                 "what": "2 FETCH_SIZE + WRITE_SIZE of the link launch (profiles/%s_graphslam_pmc.json) / this run's "
-                                         "kernel time: the utilisation of the memory side" % PMC_ROUND}}
-        if pk and pk.get("GRBM_GUI_ACTIVE") and pk.get("SQ_ACTIVE_INST_VALU"):
-            cyc = pk["GRBM_GUI_ACTIVE"] / 8.0
-            b["issue"] = {"valu_busy": pk["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc),
-                          "lane_efficiency": (pk["SQ_THREAD_CYCLES_VALU"] / (pk["SQ_ACTIVE_INST_VALU"] * 64.0)) if pk.get("SQ_THREAD_CYCLES_VALU") else None,
-                          "wave_wait_share": (pk["SQ_WAIT_ANY"] / pk["SQ_WAVE_CYCLES"]) if pk.get("SQ_WAIT_ANY") and pk.get("SQ_WAVE_CYCLES") else None,
-                          "l1_tag_accesses_per_cu_cycle": (pk["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc) if pk.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
-                          "l2_hit_rate": (pk["TCC_HIT_sum"] / max(1.0, pk["TCC_HIT_sum"] + pk["TCC_MISS_sum"])) if pk.get("TCC_HIT_sum") is not None and pk.get("TCC_MISS_sum") is not None else None,
-                          "vector_l1_busy": (pk["TCP_GATE_EN2_sum"] / 256.0 / cyc) if pk.get("TCP_GATE_EN2_sum") else None,
-                          "vector_l1_clock_on": (pk["TCP_GATE_EN1_sum"] / 256.0 / cyc) if pk.get("TCP_GATE_EN1_sum") else None,
-                          "vector_l1_stalled_on_pending_fills": (pk["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc) if pk.get("TCP_PENDING_STALL_CYCLES_sum") else None,
-                          "what": "SQ / TCP / TCC counters of the same launch under rocprofv3 --pmc (each pass its own run): the vector "
-                                  "ALUs are busy less than half the time, the memory side below half of HBM peak -- what the launch "
-                                  "saturates is each CU's vector L1 (vector_l1_busy = TCP_GATE_EN2 / (256 CUs x kernel cycles)), a "
-                                  "good part of it stalled on lines whose fill from L2 is pending"}
-        b.update(out["roofline"].get("bounds", {}))
-        out["roofline"]["bounds"] = b
-    return out
-
-
-def c5_search_roofline(k_ms, nq, counts, comp_bytes, pk, bw, pmc_source, what):
-    """`roofline` of a search launch in the configs[4] regime (tree + points beyond the 256 MB Infinity Cache): SURVEY 8(d)'s
-    algorithmic bytes with the visit counts of the same launch, and -- the figure that IS a utilisation here -- the fabric
-    bytes of the launch from the committed counter summary against the HBM peak."""
-    c_int, c_leaf, c_pts, cq = counts
-    bq = algorithmic_bytes_per_query(c_int / max(1, cq), c_pts / max(1, cq))
-    ach = bq * nq / (k_ms * 1e-3) / 1e9
-    traffic = pmc_traffic_bytes(pk)
-    r = {"bound": "hbm", "kernel": what, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "traffic": traffic, "kernel_ms": k_ms, "bytes_per_query": bq, "queries_per_launch": nq,
-         "visits_per_query": {"internal": c_int / max(1, cq), "leaves": c_leaf / max(1, cq), "points": c_pts / max(1, cq),
-                              "counted_on": "an instrumented replay of the same launch (same traversal)"},
-         "nn_per_s_kernel_only": nq / (k_ms * 1e-3)}
-    b = {"peak_measured_copy_GBs": bw.get("hbm_copy"),
-         "compulsory_hbm": {"bytes": comp_bytes, "GBs": comp_bytes / (k_ms * 1e-3) / 1e9, "frac": comp_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "what": "every record of the tree(s) the launch walks (hot 48 B + exact 64 B per node, 32 B per point slot, "
-                                    "6 B of 16-bit shadow per slot -- 12 B of fp32 shadow in the several-links launch) once + every query read and its hit written once"}}
-    if traffic:
-        b["hbm_traffic_pmc"] = {"bytes": traffic, "GBs": traffic / (k_ms * 1e-3) / 1e9, "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "refetch_factor": traffic / comp_bytes,
-                                "what": "2 FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, its own pass) / this run's kernel time: with a "
-                                        "working set beyond the Infinity Cache this is HBM traffic, the utilisation of the memory side"}
-    if pk:
-        if pk.get("TCC_HIT_sum") is not None and pk.get("TCC_MISS_sum") is not None:
-            b["l2_hit_rate"] = pk["TCC_HIT_sum"] / max(1.0, pk["TCC_HIT_sum"] + pk["TCC_MISS_sum"])
-        if pk.get("GRBM_GUI_ACTIVE") and pk.get("SQ_ACTIVE_INST_VALU"):
-            cyc = pk["GRBM_GUI_ACTIVE"] / 8.0
-            iss = {"valu_busy": pk["SQ_ACTIVE_INST_VALU"] * 4.0 / (NUM_SIMD * cyc)}
-            if pk.get("SQ_THREAD_CYCLES_VALU"): iss["lane_efficiency"] = pk["SQ_THREAD_CYCLES_VALU"] / (pk["SQ_ACTIVE_INST_VALU"] * 64.0)
-            if pk.get("SQ_WAIT_ANY") and pk.get("SQ_WAVE_CYCLES"): iss["wave_wait_share"] = pk["SQ_WAIT_ANY"] / pk["SQ_WAVE_CYCLES"]
-            if pk.get("TCP_GATE_EN2_sum"): iss["vector_l1_busy"] = pk["TCP_GATE_EN2_sum"] / 256.0 / cyc
-            if pk.get("TCP_PENDING_STALL_CYCLES_sum"): iss["vector_l1_stalled_on_pending_fills"] = pk["TCP_PENDING_STALL_CYCLES_sum"] / 256.0 / cyc
-            if pk.get("TCP_TCC_READ_REQ_LATENCY_sum") and pk.get("TCP_TCC_READ_REQ_sum"):
-                iss["l1_miss_latency_cycles"] = pk["TCP_TCC_READ_REQ_LATENCY_sum"] / pk["TCP_TCC_READ_REQ_sum"]
-            if pk.get("TCP_TA_TCP_STATE_READ_sum"): iss["l1_wave_instructions"] = pk["TCP_TA_TCP_STATE_READ_sum"]
-            b["issue"] = iss
-    b["source"] = pmc_source or {"file": None, "note": "no committed counter summary: `traffic` is null"}
-    r["bounds"] = b
-    return r
 
 
 def bench_c5(args, local):
@@ -1019,15 +878,11 @@ def bench_c5(args, local):
         t2 = tdtk.KDtree.from_scan(S[0].handle, S[0].n, 20, local); warm_build.append(t2.info()["build_ms"]); del t2
     bw = measured_bandwidth(local)
     pfile = PMC_ROUND_C5 + "_c5_pmc.json"
-    psrc = lambda k: ({"file": "profiles/" + pfile, "kernel": k,
-                       "what": "per-launch averages of that kernel over `python bench.py --workload c5` under rocprofv3 --pmc (tools/profile_c5.sh)"}
-                      if pmc_kernel(k, pfile) else None)
     # what a search launch must touch at least: the tree's records + the query stream
     slots = info.get("n_point_slots", int(npts * 1.07))
     tree_bytes = info["n_internal"] * (64 + 48) + slots * (32 + 6)          # the single-pass kernel filters on the 16-bit shadow (6 B per slot)
     tree_bytes_links = info["n_internal"] * (64 + 48) + slots * (32 + 12)   # the several-links launch on the fp32 groups (12 B per slot)
     out = {"scans": nscans, "points_per_scan": npts, "max_dist_match2": maxd2, "generation_s": t_gen,
-           "what": "configs[4] shape on one GPU: %d of 13 synthetic city scans x %d points (bremen_city is not on the box)" % (nscans, npts),
            "tree": {"internal": info["n_internal"], "leaves": info["n_leaves"], "depth": info["max_depth"], "device_bytes": info["device_bytes"]},
            "per_scan_ms": {"upload_and_ordering": {"first": t_up[0], "mean_rest": float(np.mean(t_up[1:]))},
                            "tree_build_device": {"each": [i["build_ms"] for i in infos], "warm": min(warm_build)},
@@ -1035,8 +890,7 @@ def bench_c5(args, local):
     lv = info["max_depth"]
     tb_bytes = float(lv) * npts * 64.0
     out["tree_build_roofline"] = {"bound": "hbm", "kernel": "device tree build (level passes + subtree finisher)", "achieved": tb_bytes / (min(warm_build) * 1e-3) / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tb_bytes / (min(warm_build) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                  "note": "bytes model: every level streams 24 B points + 8 B keys in and out (64 B per point and level)"}
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tb_bytes / (min(warm_build) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
     # ---- one whole-scan correspondence pass, cold (Scan::getPtPairs: no warm start, sums by k_accum behind the search)
     a, b = S[0], S[1]
     tdtk.Scan.getPtPairs(a, b, 0, 0, maxd2)
@@ -1045,19 +899,16 @@ def bench_c5(args, local):
         for _ in range(max(2, args.c5_reps)):
             t0 = time.perf_counter(); r = tdtk.Scan.getPtPairs(a, b, 0, 0, maxd2); walls.append((time.perf_counter() - t0) * 1e3)
             L.tdtk_last_timings(tm4); ks.append(tm4[0]); ss.append(tm4[1])
-    with visit_counting(local) as vc:
+    with visit_counting(local, 2) as vc:               # (a cold pass: the launch's own walk IS the reference's)
         rc_ = tdtk.Scan.getPtPairs(a, b, 0, 0, maxd2)
         counts = vc.read()
     assert rc_["n"] == r["n"] and counts[3] == npts, (rc_["n"], r["n"], counts)
     k_ms = float(np.mean(ks)); sums_ms = float(np.mean(ss))
     comp = tree_bytes + npts * (24 + 4)
     kname = "k_search [whole-scan pass, 10M queries]"
-    roof = c5_search_roofline(k_ms, npts, counts, comp, pmc_kernel(kname, pfile), bw, psrc(kname),
-                              "k_search_refill (one query per lane, persistent lanes; several generations of waves at this size)")
+    roof = search_roofline("k_search_refill (whole-scan pass, cold)", k_ms, npts, counts, None, comp, pmc_kernel(kname, pfile), bw, pfile)
     out["whole_scan_pass"] = {"value": npts / (min(walls) * 1e-3), "unit": "NN correspondences/s", "ms": min(walls), "k_search_ms": k_ms,
-                              "pair_sums_ms": sums_ms, "pairs": int(r["n"]), "roofline": roof,
-                              "what": "Scan::getPtPairs of scan 1 against the tree of scan 0 from the initial (odometry) poses: search + k_accum + k_final, "
-                                      "sums in pinned memory; wall time of the call (best of %d), kernel times by HIP events (mean)" % len(walls)}
+                              "pair_sums_ms": sums_ms, "pairs": int(r["n"]), "roofline": roof}
     # ---- ICP at this size: K iterations of the resident loop (transform fused, warm start from the second iteration)
     d_icp = tdtk.Scan(raw[1][0], raw[1][1], raw[1][2], device=local); _ = d_icp.handle
     K = max(2, args.c5_icp_iters)
@@ -1065,20 +916,21 @@ def bench_c5(args, local):
     with kernel_timing():
         t0 = time.perf_counter(); it = icp.match(a, d_icp); dt_icp = time.perf_counter() - t0
     last = dict(icp.last)
-    d_cnt = tdtk.Scan(raw[1][0], raw[1][1], raw[1][2], device=local); _ = d_cnt.handle
-    icp_c = tdtk.icp6D(tdtk.icp6D_QUAT(True), math.sqrt(maxd2), K, quiet=True, epsilonICP=-1.0)
-    with visit_counting(local) as vc:
-        icp_c.match(a, d_cnt)
-        cnt_icp = vc.read()
-    assert icp_c.last["rms"] == last["rms"] and icp_c.last["pairs"] == last["pairs"], "counting replay diverged"
-    del d_cnt
+    cnt_icp = {}
+    for mode in (2, 1):                                  # the reference's walk, then the launches' own (same loop, same results)
+        d_cnt = tdtk.Scan(raw[1][0], raw[1][1], raw[1][2], device=local); _ = d_cnt.handle
+        icp_c = tdtk.icp6D(tdtk.icp6D_QUAT(True), math.sqrt(maxd2), K, quiet=True, epsilonICP=-1.0)
+        with visit_counting(local, mode) as vc:
+            icp_c.match(a, d_cnt)
+            cnt_icp[mode] = vc.read()
+        assert icp_c.last["rms"] == last["rms"] and icp_c.last["pairs"] == last["pairs"], "counting replay diverged"
+        d_cnt.release()
     ki_ms = last["nn_ms"] / (it + 1)
     kname_i = "k_search [icp6D::match at 10M]"
     out["icp_10M"] = {"iterations": it + 1, "ms_per_iteration": dt_icp * 1e3 / (it + 1), "value": npts * (it + 1) / dt_icp, "unit": "NN correspondences/s",
                       "k_search_ms": ki_ms, "pair_sums_ms": last["sums_ms"] / (it + 1), "pairs_last": last["pairs"], "rms_last": last["rms"],
-                      "roofline": c5_search_roofline(ki_ms, npts, cnt_icp, comp + npts * 48, pmc_kernel(kname_i, pfile), bw, psrc(kname_i),
-                                                     "k_search_refill inside tdtk_icp_match (query transform fused, warm start)"),
-                      "what": "device-resident icp6D::match of scan 1 against scan 0, -a 1, exactly %d iterations from the odometry pose" % (it + 1)}
+                      "roofline": search_roofline("k_search_refill (tdtk_icp_match at 10M: fused transform, warm start)", ki_ms, npts,
+                                                  cnt_icp[2], cnt_icp[1], comp + npts * 48, pmc_kernel(kname_i, pfile), bw, pfile)}
     del d_icp
     # ---- calcNormals at this size (the -z / point-to-plane leg of configs[4])
     t_n, k_n = [], []
@@ -1094,8 +946,7 @@ def bench_c5(args, local):
     out["normals"] = {"value": npts / (min(t_n) * 1e-3), "unit": "points/s", "ms": min(t_n), "kernel_ms": kn_ms, "ann_tree_build_ms": min(t_n) - kn_ms,
                       "roofline": {"bound": "hbm", "kernel": "k_ann_normals", "achieved": bp * npts / (kn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": bp * npts / (kn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pkn), "bytes_per_point": bp,
-                                   "visits_per_point": {"split_nodes": a_split / max(1, a_q), "leaf_points": a_leaf / max(1, a_q)}},
-                      "what": "tdtk_scan_calc_normals on the resident 10M-point scan (ANN-tree build + approximate 10-NN + PCA)"}
+                                   "visits_per_point": {"split_nodes": a_split / max(1, a_q), "leaf_points": a_leaf / max(1, a_q)}}}
     # ---- one lum6DEuler round: chain links + closures (every pair of scans further apart than one step)
     links = [(i, i + 1) for i in range(nscans - 1)] + [(i, j) for i in range(nscans) for j in range(i + 2, nscans)]
     links = links[:max(nscans - 1, args.c5_links)] if args.c5_links else links
@@ -1109,9 +960,12 @@ def bench_c5(args, local):
         t0 = time.perf_counter(); ret = step(); t_round.append((time.perf_counter() - t0) * 1e3)
         ms = C.c_double(0.0); L.tdtk_last_kernel_ms(C.byref(ms)); k_round.append(ms.value)
     L.tdtk_kernel_timing(0)
-    with visit_counting(local) as vc:
+    with visit_counting(local, 2) as vc:
         step()
         cnt_l = vc.read()
+    with visit_counting(local, 1) as vc:
+        step()
+        cnt_l_own = vc.read()
     nl = len(links)
     kl_ms = float(np.mean(k_round))
     kname_l = "k_search (several links per launch)"
@@ -1119,10 +973,8 @@ def bench_c5(args, local):
     comp_l = trees_walked * tree_bytes_links + nl * npts * (24 + 4 + 60)
     out["lum_round"] = {"links": nl, "ms": min(t_round), "value": nl * npts / (min(t_round) * 1e-3), "unit": "NN correspondences/s", "last_ret": ret,
                         "link_launch_ms": kl_ms,
-                        "roofline": c5_search_roofline(kl_ms, nl * npts, cnt_l, comp_l, pmc_kernel(kname_l, pfile), bw, psrc(kname_l),
-                                                       "k_search_refill_multi (all %d link passes in one launch, each link's sums added up inside it)" % nl),
-                        "what": "one lum6DEuler iteration (-G 1) over %d links of 10M queries each (chain + closures): link launch, final, solve, pose update "
-                                "(the scan moves ride in the next round's launch)" % nl}
+                        "roofline": search_roofline("k_search_refill_multi (%d links in one launch, sums inside)" % nl, kl_ms, nl * npts,
+                                                    cnt_l, cnt_l_own, comp_l, pmc_kernel(kname_l, pfile), bw, pfile)}
     # ---- the reference on the host: its own TUs (oracle/_ref) on a stated sample
     if not args.no_cpu:
         from oracle import orc
@@ -1141,14 +993,127 @@ def bench_c5(args, local):
             assert np.array_equal(np.asarray(ri), np.asarray(gi)), "parity spot-check against the reference's KDtreeIndexed failed"
             t0 = time.perf_counter(); rt.find_closest(sel, maxd2, threads); tq = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": ns / tq, "unit": "NN correspondences/s", "cores": threads, "kind": "reference", "tree_build_s": tb,
-                                   "sample": "KDtreeIndexed over all %d points of scan 0 (serial constructor, %.1f s) + FindClosest of every %d-th query of "
-                                             "scan 1 (%d queries) on %d OpenMP threads; the first 20000 also checked index for index against the GPU"
-                                             % (npts, tb, max(1, npts // ns), ns, threads)}
+                                   "sample": "KDtreeIndexed over scan 0 (%d points) + FindClosest of every %d-th query of scan 1 (%d)" % (npts, max(1, npts // ns), ns)}
             del rt
     for s in S:
         s.release()
     capi.pool_trim()
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# the record: one compact stdout line, everything else to bench_legs.json + one stderr line per leg
+# --------------------------------------------------------------------------------------------
+LEG_KEYS = ("tree_build_1gpu", "normals_1gpu", "doicp_small_scans", "graphslam_1gpu", "c5_shape_1gpu")
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+
+
+def _sig(x, digits=6):
+    """floats of the secondary fields at `digits` significant digits (the contract's own numbers are never rounded)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_roofline(r):
+    """the `roofline` block of the stdout line: the contract's seven fields + what its `frac` is made of + the six
+    utilisations from the counter summary (DESIGN.md section 6 says what each is)"""
+    if not r:
+        return None
+    b = r.get("bounds", {})
+    out = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_query")}
+    out["visits_per_query"] = {k: _get(r, "visits_per_query", k) for k in ("internal", "points")}
+    if r.get("visits_walked"):
+        out["visits_walked"] = {k: r["visits_walked"].get(k) for k in ("internal", "points", "bytes_ratio")}
+    out["bounds"] = {"compulsory_hbm_frac": _get(b, "compulsory_hbm", "frac"), "hbm_traffic_pmc_frac": _get(b, "hbm_traffic_pmc", "frac"),
+                     "refetch_factor": _get(b, "hbm_traffic_pmc", "refetch_factor"), "l2_hit_rate": b.get("l2_hit_rate"),
+                     "vector_l1_busy": b.get("vector_l1_busy"), "lane_efficiency": b.get("lane_efficiency"),
+                     "measured_copy_GBs": b.get("peak_measured_copy_GBs")}
+    out["source"] = _get(b, "source", "file")
+    for k in ("links_in_that_launch", "launches_per_step"):
+        if k in r:
+            out[k] = r[k]
+    return _sig(out)
+
+
+def leg_numbers(res):
+    """the key number(s) of every other leg, for the stdout line (the legs themselves: bench_legs.json)"""
+    g, c5, sm = res.get("graphslam_1gpu") or {}, res.get("c5_shape_1gpu") or {}, res.get("doicp_small_scans") or {}
+    out = {
+        "tree_build_1M_ms": _get(res, "tree_build_1gpu", "ms"),
+        "normals_1M_ms": _get(res, "normals_1gpu", "ms"),
+        "small_scans_loop_us_per_iteration": sm.get("loop_us_per_iteration"),
+        "small_scans_match_ms": _get(sm, "per_scan_ms", "match"),
+        "graphslam_1gpu_ms_per_step": g.get("ms_per_step"),
+        "graphslam_link_launch_ms": _get(g, "roofline", "kernel_ms"),
+        "graphslam_roofline_frac": _get(g, "roofline", "frac"),
+        "graphslam_GB_per_link": _get(g, "roofline", "bounds", "hbm_traffic_pmc", "GB_per_link"),
+        "graphslam_predicted_step_ms_8_ranks": _get(g, "sharded_step_rehearsal", "by_world", "8", "predicted_step_ms"),
+        "c5_tree_build_10M_ms": _get(c5, "per_scan_ms", "tree_build_device", "warm"),
+        "c5_whole_scan_pass_k_search_ms": _get(c5, "whole_scan_pass", "k_search_ms"),
+        "c5_whole_scan_pass_frac": _get(c5, "whole_scan_pass", "roofline", "frac"),
+        "c5_whole_scan_pass_hbm_traffic_frac": _get(c5, "whole_scan_pass", "roofline", "bounds", "hbm_traffic_pmc", "frac"),
+        "c5_icp_10M_ms_per_iteration": _get(c5, "icp_10M", "ms_per_iteration"),
+        "c5_normals_10M_ms": _get(c5, "normals", "ms"),
+        "c5_link_launch_ms": _get(c5, "lum_round", "link_launch_ms"),
+    }
+    return _sig({k: v for k, v in out.items() if v is not None}, 5)
+
+
+def build_line(res):
+    """The ONE stdout line (<= LINE_MAX bytes) from a full result dict: the contract's keys, a short `config`, the compact
+    `roofline`, `cpu_baseline` and the legs' key numbers.  Strict JSON (a NaN / Infinity anywhere raises)."""
+    line = {k: res.get(k) for k in CONTRACT_KEYS}
+    cfg = res.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "points", "scans", "links", "bucket", "max_dist_match", "minimizer") if k in cfg}
+    for k in ("icp_iters_per_s", "lum_iters_per_s", "pairs_last", "rms_last", "pose_max_abs_err", "pair_sums_ms", "outside_kernels_ms",
+              "last_ret", "exchange", "rccl_world", "links_per_rank", "search_launches_before_timed_region"):
+        if res.get(k) is not None:
+            line[k] = _sig(res[k])
+    if res.get("convergence"):
+        line["converged_pose_max_abs_err"] = _sig(res["convergence"]["pose_max_abs_err"])
+    line["roofline"] = compact_roofline(res.get("roofline"))
+    cb = res.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _sig({k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "one_thread_value", "nn_only_value", "ms_per_iteration") if k in cb})
+        line["cpu_baseline"]["value"] = cb["value"]
+    legs = leg_numbers(res)
+    if legs:
+        line["legs"] = legs
+        line["legs_file"] = "bench_legs.json"
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_MAX:
+        raise RuntimeError("bench.py: the stdout line is %d bytes (limit %d): move fields to bench_legs.json" % (len(text), LINE_MAX))
+    return text
+
+
+def emit(res):
+    """bench_legs.json (the full record), one compact line per leg on stderr, the ONE line on stdout (last)."""
+    full = json.dumps(res, allow_nan=False, indent=1, default=lambda o: o.item() if hasattr(o, "item") else str(o))
+    try:
+        with open(os.path.join(ROOT, "bench_legs.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print("bench.py: bench_legs.json not written: %s" % e, file=sys.stderr)
+    for k in LEG_KEYS:
+        if res.get(k) is not None:
+            print(json.dumps({"leg": k, **_sig(res[k], 5)}, separators=(",", ":"), default=lambda o: o.item() if hasattr(o, "item") else str(o)), file=sys.stderr)
+    sys.stderr.flush()
+    print(build_line(res))
+    sys.stdout.flush()
 
 
 def main():
@@ -1192,11 +1157,18 @@ def main():
     if wl == "c5":
         if world != 1:
             raise SystemExit("bench.py: --workload c5 is a one-GPU leg")
-        res = {"c5_shape_1gpu": bench_c5(args, local)}
+        c5 = bench_c5(args, local)
+        # (a leg on its own: the line carries the leg's whole-scan pass as its headline so that it stays a valid record)
+        p_ = c5["whole_scan_pass"]
+        res = {"metric": "NN correspondences/sec (configs[4] shape, one cold whole-scan pass of 10M queries)", "value": p_["value"],
+               "unit": p_["unit"], "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": p_["ms"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[4] shape: %d synthetic city scans x %d points" % (c5["scans"], c5["points_per_scan"]), "points": c5["points_per_scan"]},
+               "roofline": p_["roofline"], "cpu_baseline": c5.get("cpu_baseline"), "c5_shape_1gpu": c5}
     else:
         res = bench_icp(args, rank, world, local) if wl == "icp" else bench_graphslam(args, rank, world, local)
     if rank == 0:
-        print(json.dumps(res))
+        emit(res)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

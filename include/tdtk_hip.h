@@ -421,7 +421,10 @@ int tdtk_last_timings(double out[4]);
  * and, for calcNormals, out[4..6] = {ANN splitting nodes, leaf points visited, points processed}; out[7] = queries of
  * repeated passes that were searched a second time with every quick check (a warm query walks without the quick check of
  * its divergent visits and is searched again, cold, if it accepted a point that improved closest_d2 by a rounding's
- * worth: DESIGN.md section 4, "the quick check deferred"). */
+ * worth: DESIGN.md section 4, "the quick check deferred").
+ * on == 2: while counting, every search also starts cold (no warm start, no deferred quick check): the counters then hold
+ * the walk of the reference's _FindClosest (kdTreeImpl.h:345-383) over the same queries -- SURVEY 8(d)'s n_int / n_pts,
+ * "properties of (tree, query, maxdist2), independent of implementation"; the results, and so a loop's path, are unchanged. */
 int tdtk_visit_counting(int device, int on);
 int tdtk_visit_counters(int device, uint64_t out[8]);
 /* measured roofline denominators: kind 0 = HBM stream copy over `bytes` (read + written per pass), kind 1 =

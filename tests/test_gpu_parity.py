@@ -658,6 +658,54 @@ def test_resident_loop_indices_every_iteration(tdtk, orc, gpu, n, dups):
     assert icp2.last["index_hashes"] == []
 
 
+def test_reference_walk_counters_of_the_resident_loop_equal_the_oracles(tdtk, orc, gpu):
+    """Round 6: SURVEY 8(d)'s n_int / n_pts under `roofline.frac` are the REFERENCE's walk, not the kernel's
+    own.  tdtk_visit_counting(device, 2) makes every search of the loop start cold (no warm start, no deferred quick check)
+    while it counts; over the bench pair (1M-vs-1M, seed 42: the pair whose numbers the bench line quotes) the counters of a
+    4-iteration loop must equal, exactly, the oracle's _FindClosest counters (kdTreeImpl.h:345-383 restated, oracle.c) summed
+    over the same four query sets -- and the loop's results must not depend on the counting mode (same trace as mode 1 and as
+    no counting at all), while mode 1 (the kernel's own walk: warm start, deferred check) visits something else."""
+    import ctypes as C
+    import bench
+    n, iters = 1000000, 4
+    m, d, T = bench.make_icp_pair(n, seed=42)
+    model = tdtk.Scan([0, 0, 0], [0, 0, 0], m)
+    L = tdtk.lib()
+
+    def loop(mode):
+        data = tdtk.Scan([0, 0, 0], [0, 0, 0], d)
+        c = (C.c_uint64 * 8)()
+        if mode:
+            L.tdtk_visit_counting(gpu, mode)
+        try:
+            icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), 25.0, iters, quiet=True, epsilonICP=-1.0)
+            assert icp.match(model, data) == iters - 1
+            if mode:
+                L.tdtk_visit_counters(gpu, c)
+        finally:
+            L.tdtk_visit_counting(gpu, 0)
+        data.release()
+        return icp.last["trace"].copy(), (int(c[0]), int(c[1]), int(c[2]), int(c[3]))
+
+    tr0, _ = loop(0)
+    tr2, ref_walk = loop(2)
+    tr1, own_walk = loop(1)
+    assert np.array_equal(tr0, tr2) and np.array_equal(tr0, tr1)
+    assert ref_walk[3] == own_walk[3] == n * iters
+    ot = orc.Tree(m, 20)
+    cur = d.copy()
+    nt = max(8, min(96, os.cpu_count() or 8))
+    tot = np.zeros(3, np.int64)
+    for it in range(iters):
+        tot += np.array(ot.find_closest(cur, 625.0, nt, True)[2], np.int64)
+        orc.transform_points(tr0[it, 2:], cur)
+    assert tuple(int(x) for x in tot) == ref_walk[:3], (tot, ref_walk)
+    assert own_walk[:3] != ref_walk[:3]
+    # the figure the bench line quotes for this pair's first iterations: SURVEY 8(d)'s ~2.4 KB per query
+    bq = bench.algorithmic_bytes_per_query(ref_walk[0] / ref_walk[3], ref_walk[2] / ref_walk[3])
+    assert 2300.0 < bq < 2600.0, bq
+
+
 def test_thin_acceptances_are_searched_again(tdtk, orc, gpu):
     """Round 5, "the quick check deferred" (kernels.hip): from its second pass on a query of the resident loop walks without
     the quick check of its divergent visits, and is searched AGAIN -- cold, every check made: the reference's own walk -- if it
