@@ -17,7 +17,17 @@ extern "C" {
 // unparsable lines at the top (the optional point-count header) are skipped, like readASCII
 // (src/scanio/helper.cc:564-700, 730-880).  Values are parsed with strtod.  The range filter is
 // PointFilter::setRange (src/slam6d/pointfilter.cc:162-188): keep x^2+y^2+z^2 < max^2 (max > 0)
-// and > min^2 (min > 0).  *xyz_out is malloc'ed; release with tdtk_io_free.
+// and > min^2 (min > 0).  setRange hands its two doubles to the checkers as TEXT (`stringstream << maxDist`, default
+// precision: six significant digits, pointfilter.cc:63-70 -> :162-188), so a range of 123.456789 filters at 123.457: the
+// same round trip is made here (%g is what operator<< prints).  -m / -M are ints on slam6D's command line (slam6D.cc:224,241),
+// for which the trip is exact up to 999999.  *xyz_out is malloc'ed; release with tdtk_io_free.
+static double through_text(double v)
+{
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%g", v);
+  return std::strtod(buf, nullptr);
+}
+
 int tdtk_io_read_uos(const char* path, double range_max, double range_min, double** xyz_out, size_t* n_out)
 {
   if (!path || !xyz_out || !n_out) { set_error("NULL argument"); return TDTK_EINVAL; }
@@ -27,8 +37,9 @@ int tdtk_io_read_uos(const char* path, double range_max, double range_min, doubl
   char line[4096];
   int header_budget = 10;
   unsigned long linenr = 0;
-  const double max2 = range_max > 0.0 ? range_max * range_max : -1.0;
-  const double min2 = range_min > 0.0 ? range_min * range_min : -1.0;
+  const double rmax = through_text(range_max), rmin = through_text(range_min);
+  const double max2 = rmax > 0.0 ? rmax * rmax : -1.0;
+  const double min2 = rmin > 0.0 ? rmin * rmin : -1.0;
   while (std::fgets(line, sizeof line, f)) {
     ++linenr;
     char* hash = std::strchr(line, '#');

@@ -7,7 +7,7 @@
 # headers: only TUs that compile as-is with this image's g++ are built
 # (kdIndexed.cc, icp6Dquat.cc, icp6Dsvd.cc + vendored newmat, icp6Dapx.cc,
 # icp6Dnapx.cc, icp6Dortho.cc, icp6Ddual.cc, icp6Dhelix.cc, icp6Dlumeuler.cc,
-# icp6Dlumquat.cc, icp6Dquatscale.cc; the vendored ANN library).  Flags mirror the reference CMakeLists.txt:306-342 (-O3,
+# icp6Dlumquat.cc, icp6Dquatscale.cc, pointfilter.cc; the vendored ANN library).  Flags mirror the reference CMakeLists.txt:306-342 (-O3,
 # OpenMP, no -march, no -ffast-math).
 set -euo pipefail
 REF="${1:-${REF:-/root/reference}}"
@@ -23,7 +23,7 @@ mkdir -p "$OUT/obj"
 F="-std=c++17 -O3 -fPIC -fopenmp -DOPENMP -DOPENMP_NUM_THREADS=8 -DMAX_OPENMP_NUM_THREADS=512 -w"
 INC="-I$REF/include -I$REF/3rdparty/newmat/newmat-10"
 for f in kdIndexed icp6Dquat icp6Dsvd icp6Dapx icp6Dnapx icp6Dortho icp6Ddual icp6Dhelix icp6Dlumeuler \
-         icp6Dlumquat icp6Dquatscale; do
+         icp6Dlumquat icp6Dquatscale pointfilter; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$REF/src/slam6d/$f.cc" -nt "$OUT/obj/$f.o" ]; then
     g++ $F $INC -c "$REF/src/slam6d/$f.cc" -o "$OUT/obj/$f.o" &
   fi

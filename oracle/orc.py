@@ -145,6 +145,8 @@ def ref():
         R.ref_get_pt_pairs.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_size_t, C.c_int, C.c_double, _ip, _dp, _dp, _dp, _dp]
         R.ref_icp_iterations.restype = C.c_int
         R.ref_icp_iterations.argtypes = [C.c_void_p, _dp, _dp, C.c_size_t, C.c_double, C.c_int, C.c_int, _dp]
+        R.ref_point_filter_range.restype = C.c_size_t
+        R.ref_point_filter_range.argtypes = [_dp, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_ubyte)]
         R.ref_lum_covariance_euler.restype = C.c_int
         R.ref_lum_covariance_euler.argtypes = [C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp]
         _ref = R
@@ -153,6 +155,14 @@ def ref():
 
 def _c(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ref_point_filter_range(xyz, max_dist, min_dist):
+    """the reference's own PointFilter (pointfilter.cc, compiled into oracle/_ref) with setRange(max, min): boolean keep-mask"""
+    xyz = _c(xyz).reshape(-1, 3)
+    keep = np.zeros(len(xyz), np.uint8)
+    ref().ref_point_filter_range(_d(xyz), len(xyz), float(max_dist), float(min_dist), keep.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return keep.astype(bool)
 
 
 class Tree:

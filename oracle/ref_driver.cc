@@ -4,7 +4,7 @@
  * A thin extern "C" face over the *reference's own* translation units
  * (src/slam6d/kdIndexed.cc, icp6Dquat.cc, icp6Dsvd.cc + vendored newmat,
  * icp6Dapx.cc, icp6Dnapx.cc, icp6Dortho.cc, icp6Ddual.cc, icp6Dhelix.cc,
- * icp6Dlumeuler.cc, icp6Dlumquat.cc, icp6Dquatscale.cc), compiled where they lie under $REF by
+ * icp6Dlumeuler.cc, icp6Dlumquat.cc, icp6Dquatscale.cc, pointfilter.cc), compiled where they lie under $REF by
  * oracle/build_ref.sh into oracle/_ref/libref3dtk.so.  Nothing from the
  * reference is copied into this repository; this file only #includes the
  * reference headers at build time.  Used to (a) pin oracle/oracle.c and the
@@ -35,6 +35,7 @@
 #include "slam6d/icp6Dquatscale.h"
 #include "slam6d/globals.icc"
 #include "slam6d/pairingMode.h"
+#include "slam6d/pointfilter.h"
 #include "newmat/newmatap.h"
 
 struct RefTree {
@@ -425,6 +426,22 @@ int ref_lum_covariance_euler(size_t m, const double* p1, const double* p2, doubl
     CD[r] = CDv(r + 1);
   }
   return (int)m;
+}
+
+/* PointFilter with the -m / -M range (pointfilter.cc:63-70 setRange -> parameter strings -> CheckerRangeMax / CheckerRangeMin,
+ * :162-188), applied to n points exactly as BasicScan does (basicScan.cc:160: filter.setRange(max, min); check(point) per
+ * point): keep[i] = 1 if the reference's own compiled filter accepts point i.  Returns the number kept. */
+size_t ref_point_filter_range(const double* xyz, size_t n, double maxDist, double minDist, unsigned char* keep)
+{
+  PointFilter filter;
+  filter.setRange(maxDist, minDist);
+  size_t kept = 0;
+  for (size_t i = 0; i < n; i++) {
+    double p[3] = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] };
+    keep[i] = filter.check(p) ? 1 : 0;
+    kept += keep[i];
+  }
+  return kept;
 }
 
 }  // extern "C"

@@ -559,3 +559,34 @@ def test_deferred_quick_check_gives_the_references_answer_on_the_roundings(orc):
             assert np.array_equal(d2, ref_d), case
             total_redo += redo
     assert total_redo > 1000        # the thin path ran (lattices and twins make thin acceptances by the thousand)
+
+
+# ---- the -m / -M range filter against the reference's PointFilter (round 6) -----------------------
+@pytest.mark.parametrize("rmax,rmin", [(-1, -1), (500, -1), (-1, 100), (500, 100), (1000000, 1), (123.456789, 10.5), (0, 0)])
+def test_range_filter_of_the_uos_reader_equals_the_references_pointfilter(tdtk, orc, tmp_path, rmax, rmin):
+    """tdtk_io_read_uos's -m / -M filter (io.cpp) against the reference's own compiled PointFilter (pointfilter.cc in
+    oracle/_ref, driven as BasicScan drives it: setRange(max, min) then check() per point) on dat/ scan 0 (81 360 points,
+    the committed fixture) and on points placed exactly on, one ulp inside and one ulp outside both radii -- including a
+    non-integer range, which the reference filters at six significant digits (it passes the range through a stringstream)."""
+    _need_ref(orc)
+    z = np.load(os.path.join(G, "dat_scans.npz"))
+    pts = [z["scan000"]]
+    for r in (rmax, rmin):
+        if r > 0:
+            rr = float("%g" % r)
+            edge = np.array([rr, np.nextafter(rr, 0.0), np.nextafter(rr, np.inf), float(r)])
+            e = np.zeros((12, 3))
+            for ax in range(3):
+                e[4 * ax:4 * ax + 4, ax] = edge
+            d = np.array([3.0, 4.0, 12.0]) / 13.0                       # (3, 4, 12) / 13: a direction whose norm is exact
+            pts += [e, -e, np.outer(edge, d)]
+    pts = np.concatenate(pts)
+    f = tmp_path / "scan000.3d"
+    with open(f, "w") as fh:
+        for p in pts:
+            fh.write("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
+    got = tdtk.read_uos(f, rmax, rmin)
+    keep = orc.ref_point_filter_range(pts, rmax, rmin)
+    assert np.array_equal(got, pts[keep]), (len(got), int(keep.sum()))
+    if rmax <= 0 and rmin <= 0:
+        assert len(got) == len(pts)
