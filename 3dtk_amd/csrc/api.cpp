@@ -482,20 +482,23 @@ static int scans_settle(Ctx* c, const tdtk_scan* const* scans, int count)
   Mat4* hm = reinterpret_cast<Mat4*>(tab + o_mat);
   const Mat4* dm = reinterpret_cast<const Mat4*>(static_cast<char*>(c->ws[WS_MOVES].p) + o_mat);
   size_t k = 0;
-  int d = 0;
+  std::vector<const tdtk_scan*> moved;      // (each scan once, however often the caller's list names it)
   for (int i = 0; i < count; i++) {
     const tdtk_scan* sc = scans[i];
-    if (!sc || sc->pending.empty()) continue;
-    XfChainDesc& e = hd[d++];
+    if (!sc || sc->pending.empty() || std::find(moved.begin(), moved.end(), sc) != moved.end()) continue;
+    XfChainDesc& e = hd[moved.size()];
     e.x = sc->x; e.y = sc->y; e.z = sc->z; e.nx = sc->nx; e.ny = sc->ny; e.nz = sc->nz; e.n = sc->N;
     e.mats = dm + k; e.nm = (int)sc->pending.size();
     for (const Mat4& m : sc->pending) hm[k++] = m;
-    sc->pending.clear();     // (a duplicate of this scan further down the list finds nothing left)
+    moved.push_back(sc);
   }
+  // The queues are emptied -- chain and count together -- only once the chain kernel is on the stream: a copy, an event or a
+  // launch that fails on the way returns with every move still queued (round-5 advice: they used to be lost).
   HIPCHK(hipMemcpyAsync(c->ws[WS_MOVES].p, tab, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->e_moves, c->stream));
   c->moves_inflight = true;
-  HIPCHK(launch_transform_chain_batch(reinterpret_cast<const XfChainDesc*>(c->ws[WS_MOVES].p), nd, max_n, c->stream));
+  HIPCHK(launch_transform_chain_batch(reinterpret_cast<const XfChainDesc*>(c->ws[WS_MOVES].p), (int)moved.size(), max_n, c->stream));
+  for (const tdtk_scan* sc : moved) sc->pending.clear();
   // other contexts (host threads with streams of their own) may read these scans next: they must not find "nothing
   // queued" before the chain kernel has run.  A lone context orders everything on its one stream and need not wait.
   if (g_ctx_live.load() > 1) HIPCHK(hipStreamSynchronize(c->stream));
@@ -1138,19 +1141,26 @@ static hipError_t await_sums(const double* h_pin, hipStream_t s)
 // search radius R of it, a <= |q - p|_inf + E with E <= 8 * 2^-53 * (|min| + |max| + |q|) <= 2^-50 * (3 absmax + R), so a node
 // the check cuts off (a * a >= closest_d2) holds only points with d2 >= closest_d2 - (2 E R + E^2).  Four times that, for the
 // roundings of the comparison itself and of this expression; TDTK_DEFER_CHECK=0: every visit makes the check.
+static double search_margin(const tdtk_tree* t, double maxd2)
+{
+  if (!(maxd2 > 0.0) || !std::isfinite(maxd2)) return 0.0;
+  const double R = std::sqrt(maxd2), E = std::ldexp(3.0 * (double)t->dev.absmax + R, -50);
+  const double m = 4.0 * (2.0 * E * R + E * E);
+  return (std::isfinite(m) && m < 1e-3 * maxd2) ? m : 0.0;
+}
+// The margin always widens a warm radius (SearchArgs::margin); whether the walk also DEFERS the quick check (SearchArgs::tie > 0)
+// is a performance policy of its own:
 static double search_tie(const tdtk_tree* t, double maxd2)
 {
   static const bool off = [] { const char* e = getenv("TDTK_DEFER_CHECK"); return e && e[0] == '0'; }();
-  if (off || !t->d_split || !(maxd2 > 0.0) || !std::isfinite(maxd2)) return 0.0;
+  if (off || !t->d_split) return 0.0;
   // Only for trees that live in the caches (the Infinity Cache is 256 MB): a walk without the quick check visits a sixth more
   // buckets, and once a bucket is a trip to HBM that costs more than the node loads it saves.  ICP iteration, k_search with
   // every check / with the check deferred: 1M-point tree (57 MB) 0.1665 / 0.1570 ms, 2M (115 MB) 0.357 / 0.334, 4M (230 MB)
   // 0.706 / 0.656, 10M-point city (0.65 GB) 1.28 / 1.37 (tools/r5_nobox_ab.sh, r5_defer_sizes.sh, r5_c5_waves.sh)
   static const size_t max_mb = [] { const char* e = lab_env("TDTK_DEFER_MAX_MB"); return e ? (size_t)atol(e) : (size_t)256; }();
   if (t->info.device_bytes > (max_mb << 20)) return 0.0;
-  const double R = std::sqrt(maxd2), E = std::ldexp(3.0 * (double)t->dev.absmax + R, -50);
-  const double tie = 4.0 * (2.0 * E * R + E * E);
-  return (std::isfinite(tie) && tie < 1e-3 * maxd2) ? tie : 0.0;
+  return search_margin(t, maxd2);
 }
 
 static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, int pmode,
@@ -1188,6 +1198,7 @@ static int scan_pass(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_sca
     sa.kpos = c->ws[WS_KPOS].as<int>();
     sa.skip = skip;
     sa.warm = (warm && pmode != 1 && !c->count_cold) ? 1 : 0;   // WS_KPOS still holds this scan's hits in this tree from the last pass
+    sa.margin = sa.warm ? search_margin(model, maxd2) : 0.0;
     sa.tie = sa.warm ? search_tie(model, maxd2) : 0.0;
     {
       // ... and WS_COST how many buckets each of its queries visited then: the persistent-lane kernel hands a wave's slab
@@ -2289,21 +2300,19 @@ int tdtk_solve_spd(const double* G, const double* B, int n, double* x)
 // iteration by iteration at sizes where downloading a million indices per iteration is not an option.
 static std::atomic<int> g_icp_hashes{0};
 constexpr int ICP_HASH_CAP = 1024;
+// the words of the calling thread's last tdtk_icp_match, whatever device it ran on (no context is looked up, none created)
+static thread_local std::vector<uint64_t> t_last_hashes;
 int tdtk_icp_index_hashes(int on)
 {
+  if (on < 0) return g_icp_hashes.load(std::memory_order_relaxed);     // a question, not a switch
   return g_icp_hashes.exchange(on ? 1 : 0);
 }
 int tdtk_icp_last_hashes(uint64_t* out, int cap, int* n_out)
 {
   if (!n_out || (cap > 0 && !out) || cap < 0) { set_error("bad argument"); return TDTK_EINVAL; }
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { set_error("no device"); return TDTK_EDEVICE; }
-  Ctx* c;
-  int rc = get_ctx(dev, &c, false);
-  if (rc) return rc;
-  const int n = (int)std::min<size_t>(c->last_hashes.size(), (size_t)cap);
-  for (int i = 0; i < n; i++) out[i] = c->last_hashes[(size_t)i];
-  *n_out = (int)c->last_hashes.size();
+  const int n = (int)std::min<size_t>(t_last_hashes.size(), (size_t)cap);
+  for (int i = 0; i < n; i++) out[i] = t_last_hashes[(size_t)i];
+  *n_out = (int)t_last_hashes.size();
   return TDTK_OK;
 }
 
@@ -2388,6 +2397,7 @@ static int icp_match_impl(const tdtk_tree* model, const double model_dalignxf[16
   const bool warm_ok = !(warm_env && warm_env[0] == '0');
   const bool hashing = g_icp_hashes.load(std::memory_order_relaxed) != 0;
   c->last_hashes.clear();
+  t_last_hashes.clear();
   if (hashing) {
     if ((rc = c->d_hash.ensure(ICP_HASH_CAP * sizeof(unsigned long long)))) return rc;
     HIPCHK(hipMemsetAsync(c->d_hash.p, 0, ICP_HASH_CAP * sizeof(unsigned long long), c->stream));
@@ -2465,6 +2475,7 @@ static int icp_match_impl(const tdtk_tree* model, const double model_dalignxf[16
     c->last_hashes.assign((size_t)passes, 0);
     HIPCHK(hipMemcpyAsync(c->last_hashes.data(), c->d_hash.p, (size_t)passes * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    t_last_hashes = c->last_hashes;
   }
   res->iterations = iter;
   res->converged = converged;
@@ -2717,6 +2728,7 @@ static int links_device_pass_batched(Ctx* c, int nlinks, const tdtk_tree* const*
       // the previous pass of this very link left its hits here (graph-SLAM rounds repeat their links): each search starts from
       // its previous hit, a point of this tree whatever the scans have done since (k_search's warm start; same index, same d2)
       sa.warm = (link_warm && !c->count_cold && sl->k_tree == t->uid && sl->k_scan == data->uid && sl->k_n == data->N) ? 1 : 0;
+      sa.margin = sa.warm ? search_margin(t, maxd2) : 0.0;
       // (what the slot will hold is written down once every launch of the call is enqueued: a call that fails on the way must
       //  not leave a slot named after hits that were never written)
       sl->k_tree = sl->k_scan = 0;
@@ -2860,15 +2872,18 @@ static int links_device_pass(Ctx* c, int nlinks, const tdtk_tree* const* first, 
       // the launch may carry out queued scan moves into the spare arrays and swap them in: until it has run no other
       // thread may find "nothing queued" on those scans and read them on its own stream -- the lock is held to the sync
       // (threads with nothing to settle never take it)
+      // (with more than one context alive another host thread may queue a move on one of these scans between an unlocked
+      //  test and the launch's own reading of the queues: then the lock is taken first and the test made under it)
+      std::unique_lock<std::recursive_mutex> lk(g_moves_mu, std::defer_lock);
+      if (g_ctx_live.load() > 1) lk.lock();
       bool moving_any = false;
       for (int i = 0; i < nlinks && !moving_any; i++) moving_any = second[i]->npend.load(std::memory_order_acquire) != 0;
-      std::unique_lock<std::recursive_mutex> lk(g_moves_mu, std::defer_lock);
-      if (moving_any) lk.lock();
+      if (moving_any && !lk.owns_lock()) lk.lock();
       if ((rc = links_device_pass_batched(c, nlinks, first, first_dalignxf, second, maxd2, want, d_out, shifts, gb))) return rc;
       acc.assign((size_t)nlinks * ACC_TOTAL, 0.0);
       HIPCHK(hipMemcpyAsync(acc.data(), d_out, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
-      if (moving_any) lk.unlock();
+      if (lk.owns_lock()) lk.unlock();
       collect_ms(c, nullptr);
       return TDTK_OK;
     }
@@ -3092,7 +3107,9 @@ int tdtk_lum_assemble_solve(int nlinks, const int32_t* from, const int32_t* to, 
       };
       if (a >= 0) { for (int i = 0; i < 6; i++) B[a * 6 + i] += CDab[i]; add(a, a, 1.0); }
       if (b >= 0) { for (int i = 0; i < 6; i++) B[b * 6 + i] -= CDab[i]; add(b, b, 1.0); }
-      if (a >= 0 && b >= 0) { if (a > b) add(a, b, -1.0); else add(b, a, -1.0); }
+      // (a self link, from == to: the dense fill subtracts the block twice from the diagonal it has just added it to twice --
+      //  net zero, in that order; the same here)
+      if (a >= 0 && b >= 0) { if (a > b) add(a, b, -1.0); else if (a < b) add(b, a, -1.0); else { add(a, a, -1.0); add(a, a, -1.0); } }
     }
     for (int i = 0; i < N; i++) {
       const int f0 = 6 * bmin[i / 6];

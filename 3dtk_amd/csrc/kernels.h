@@ -50,6 +50,10 @@ struct SearchArgs {
   // that improved its closest_d2 by no more than `tie` (kernels.hip, "the quick check deferred"); the warm radius is the previous
   // hit's d2 + 2 tie.  0: every visit makes the quick check.
   double tie;
+  // warm: what the previous hit's d2 is widened by (twice this) to give the starting radius -- the rounding of the reference's
+  // quick check and split test (api.cpp: search_margin), so that no node holding the previous hit, or a nearer point, can be cut
+  // off by a rounding at a radius this tight.  Set whenever warm is; tie (above) is either 0 or equal to it.
+  double margin;
   int warm;     // kpos holds the previous pass's hits of the SAME queries in the SAME tree: start each search with
                 // a radius just above the distance to that point (see warm_radius in kernels.hip)
   int* kpos;    // out: position of the hit in the leaf-ordered point array, or -1

@@ -402,6 +402,10 @@ __device__ __forceinline__ uint32_t descend_which(const double splitval, const u
 // its squared distance (instead of maxdist2) cannot lose it: every test of the traversal prunes only what lies at
 // or beyond closest_d2, the walk order is unchanged, and whatever the reference would have visited before reaching a
 // point at that distance it still visits.  Same index, same d2 -- from a radius of a few units instead of 25.
+// "Prunes only what lies at or beyond closest_d2" holds up to the ROUNDING of the tests themselves (the quick check's
+// a = max|q - c| - h carries ~2^-50 (3 absmax + R)): at a radius one ulp above the hit's own distance a rounding could cut off
+// the very node that holds the hit when q - p is almost axis-aligned, where the reference, walking with maxdist2, visits it.
+// The radius is therefore d2 + 2 * SearchArgs::margin (api.cpp: search_margin bounds that rounding, times four).
 static __device__ __forceinline__ double warm_radius_kp(const SearchArgs& a, const int kp, const double qx, const double qy,
                                                         const double qz)
 {
@@ -414,7 +418,7 @@ static __device__ __forceinline__ double warm_radius_kp(const SearchArgs& a, con
       const double dx = pxy.x - qx, dy = pxy.y - qy, dz = pzz - qz;
       const double d = dx * dx + dy * dy + dz * dz;
       double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
-      const double um = d + 2.0 * a.tie;                                  // (SearchArgs::tie; 0: one ulp, as before)
+      const double um = d + 2.0 * a.margin;                               // (SearchArgs::margin; 0: one ulp)
       if (um > up) up = um;
       if (up < best) best = up;
     }

@@ -22,8 +22,8 @@ from . import slam6d as _s
 def _link_arrays(gr):
     """(from, to) of every link as int32 arrays -- straight from the Graph's lists when it is our Graph"""
     if hasattr(gr, "frm") and hasattr(gr, "to"):
-        a = getattr(gr, "_arrays", None)          # (kept by Graph when the library listed the links; addLink changes the length)
-        if a is not None and len(a[0]) == len(gr.frm):
+        a = getattr(gr, "_arrays", None)          # (kept by Graph when the library listed the links; trusted only while the
+        if a is not None and a[0].tolist() == gr.frm and a[1].tolist() == gr.to:      #  lists still say the same: they are public)
             return a
         return np.array(gr.frm, dtype=np.int32), np.array(gr.to, dtype=np.int32)
     nl = gr.getNrLinks()

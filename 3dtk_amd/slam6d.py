@@ -797,11 +797,14 @@ class icp6D:
         self.last = dict(iterations=res.iterations, converged=bool(res.converged),
                          pairs=int(res.last_pairs), rms=res.last_rms, total_ms=res.total_ms,
                          nn_ms=res.nn_ms, sums_ms=res.sums_ms, trace=trace[:nrows].copy())
-        # diagnostics (tdtk_icp_index_hashes): one hash of the correspondence indices per pass of the loop, when switched on
-        hn = C.c_int(0)
-        hb = (C.c_uint64 * 1024)()
-        check(lib().tdtk_icp_last_hashes(hb, 1024, C.byref(hn)))
-        self.last["index_hashes"] = [int(hb[i]) for i in range(min(1024, hn.value))]
+        # diagnostics (tdtk_icp_index_hashes): one hash of the correspondence indices per pass of the loop -- asked for only
+        # when switched on (nothing on the path of a match otherwise)
+        self.last["index_hashes"] = []
+        if lib().tdtk_icp_index_hashes(-1):
+            hn = C.c_int(0)
+            hb = (C.c_uint64 * 1024)()
+            check(lib().tdtk_icp_last_hashes(hb, 1024, C.byref(hn)))
+            self.last["index_hashes"] = [int(hb[i]) for i in range(min(1024, hn.value))]
         return res.iterations
 
     def _match_stepped(self, PreviousScan, CurrentScan, pairing_mode=0):
@@ -995,6 +998,7 @@ class Graph:
         if not any(f == j or t == j for f, t in zip(self.frm, self.to)):
             self.nrScans += 1
         self.frm.append(int(i)); self.to.append(int(j))
+        self._arrays = None
 
     def getNrScans(self): return self.nrScans
     def getNrLinks(self): return len(self.frm)

@@ -436,8 +436,9 @@ int tdtk_count_visits(const tdtk_tree* t, const double* q, size_t K, double maxd
  * every iteration of tdtk_icp_match also reduces its correspondences to one word on the device -- the XOR over the found
  * queries of (model index * 1315423911 + query index), both in the caller's numbering, i.e. the hash of the index array
  * SearchTree::getPtPairs' loop walks (searchTree.cc:118-147) -- so that a test can compare the loop's INDICES with the
- * reference's iteration by iteration at a million points without downloading them.  tdtk_icp_last_hashes: the words of
- * the calling thread's last tdtk_icp_match (*n_out = how many passes it ran, at most 1024 are kept). */
+ * reference's iteration by iteration at a million points without downloading them.  tdtk_icp_index_hashes returns the
+ * previous setting; a negative argument only asks.  tdtk_icp_last_hashes: the words of the calling thread's last
+ * tdtk_icp_match, on whatever device it ran (*n_out = how many passes it ran, at most 1024 are kept; 0 while switched off). */
 int tdtk_icp_index_hashes(int on);
 int tdtk_icp_last_hashes(uint64_t* out, int cap, int* n_out);
 

@@ -762,7 +762,7 @@ def test_lum_assemble_straight_into_the_skyline_equals_the_dense_fill(tdtk):
     """Round 5: without G_out / B_out tdtk_lum_assemble_solve puts the link blocks straight into the skyline the solve
     factors (a block row reaches left to the smallest scan it shares a link with) instead of clearing and re-reading a
     dense G: X must be the dense path's BIT FOR BIT -- chain graphs, closures across the whole loop, a link given
-    high -> low, links at the fixed scan, entries under the 1e-5 filter inside the blocks."""
+    high -> low, a self link (from == to), links at the fixed scan, entries under the 1e-5 filter inside the blocks."""
     capi = sys.modules["3dtk_amd._capi"]
     L = capi.lib()
     rng = np.random.default_rng(3)
@@ -774,6 +774,7 @@ def test_lum_assemble_straight_into_the_skyline_equals_the_dense_fill(tdtk):
                 links.append((a, b))
         if nscans == 13:
             links.append((7, 2))
+            links.append((5, 5))       # a self link (net files and addLink can produce one): nets to zero in both fills
         nl = len(links)
         Cm = np.empty((nl, 36)); CD = rng.normal(0, 50, (nl, 6))
         for l in range(nl):
