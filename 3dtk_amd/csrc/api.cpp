@@ -138,6 +138,8 @@ struct Ctx {
   size_t h_stage_cap = 0;
   DevBuf d_mask, d_skip;                // -R passes: the keep-mask (bits, caller order) and what the search reads (bytes, sorted order)
   std::vector<unsigned char> h_mask;
+  DevBuf d_loop;                        // lab, the host-free ICP loop: its IcpLoopDev block (kernels.h)
+  double* h_loop = nullptr;             // ... and its record, pinned: ICP_LOOP_RING rows of ICP_ROW doubles
   DevBuf d_hash;                        // tdtk_icp_index_hashes: one 64-bit word per iteration of the last tdtk_icp_match
   std::vector<uint64_t> last_hashes;
   void* h_moves = nullptr;  // pinned staging of scans_settle's table (its own: a settle may precede a batched launch in one call)
@@ -218,6 +220,7 @@ Ctx::~Ctx()
     if (stream_b) (void)hipStreamDestroy(stream_b);
     if (stream_c) (void)hipStreamDestroy(stream_c);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (h_loop) (void)hipHostFree(h_loop);     // (lab)
     if (h_build) (void)hipHostFree(h_build);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -2339,6 +2342,181 @@ static int draw_keep_mask(Ctx* c, const tdtk_scan* data, int rnd, const unsigned
   return TDTK_OK;
 }
 
+#ifdef TDTK_LAB
+// ---- lab: the ICP loop without the host in it (loop_dev.h; round 6, a measured negative: NEGATIVES.md) -----------------------
+// For the batches of the four-lanes-per-query kernel (a real scan after -r reduction: tens of thousands of points) an
+// iteration is two short kernels and a host round trip that costs as much as either.  Here the host only FEEDS the stream:
+// launch k searches for iteration k after its every workgroup has made iteration k-1's solve for itself (kernels.hip:
+// loop_prologue); `ahead` launches are enqueued beyond the one whose row the host is waiting for, and the host follows the
+// rows of the record in pinned memory, topping the queue up.  Launches still queued when the loop ends see the flag and return
+// at once.  -a 1 (QUAT), closest-point pairing, no -R, no diagnostics, at most 512 rows of pair sums (~32K points); everything
+// else keeps the stepped loop below.  TDTK_ICP_DEVICE_LOOP=1 switches it on (lab library only).
+constexpr int ICP_LOOP_RING = 64;
+static int icp_loop_ahead()          // (read per match: a getenv is nothing beside a match, and tests flip it)
+{
+  const char* on = getenv("TDTK_ICP_DEVICE_LOOP");
+  if (!(on && on[0] == '1')) return 0;
+  const char* e = lab_env("TDTK_LOOP_AHEAD");
+  const int a = e ? atoi(e) : 3;
+  return std::max(1, std::min(ICP_LOOP_RING / 2, a));
+}
+struct IcpLoopOut {
+  int iter = 0;                    // rows consumed = iterations whose solve the host has seen
+  bool finished = false;           // the loop ended on the device (converged / last iteration / too few pairs)
+  bool few_pairs = false;
+  bool need_host = false;          // iteration `iter`'s sums are in acc / shift: the host solves it and carries on stepping
+  int converged = 0;
+  double ret = 0.0, prev_ret = 0.0;
+  bool have_pending = false;
+  double pend[16];
+  double acc[ACC_TOTAL], shift[3];
+};
+static hipError_t await_row(const double* row, hipStream_t s)
+{
+  const volatile uint64_t* w = reinterpret_cast<const volatile uint64_t*>(row + ICP_ROW_READY);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool yielding = false;
+  for (uint32_t spins = 1;; spins++) {
+    if (*w != SUMS_ARMED) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+    if (yielding) {
+      sched_yield();
+      if ((spins & 0x3Fu) != 0) continue;
+    } else {
+      __builtin_ia32_pause();
+      if ((spins & 0x3Fu) == 0 &&
+          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 200.0) yielding = true;
+      if ((spins & 0x3FFu) != 0) continue;
+    }
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return (*w != SUMS_ARMED) ? hipSuccess : hipErrorUnknown;   // (drained and the row never came)
+    if (q != hipErrorNotReady) return q;
+  }
+}
+// the loop's device block at its start: history and flags zero, the record's ring named and armed
+static int icp_loop_reset(Ctx* c)
+{
+  int rc;
+  if ((rc = c->d_loop.ensure(sizeof(IcpLoopDev)))) return rc;
+  if (!c->h_loop) HIPCHK(hipHostMalloc((void**)&c->h_loop, sizeof(double) * ICP_ROW * ICP_LOOP_RING + sizeof(IcpLoopDev), hipHostMallocCoherent));
+  for (int r = 0; r < ICP_LOOP_RING; r++)
+    reinterpret_cast<volatile uint64_t*>(c->h_loop + (size_t)r * ICP_ROW)[ICP_ROW_READY] = SUMS_ARMED;
+  IcpLoopDev* init = reinterpret_cast<IcpLoopDev*>(c->h_loop + (size_t)ICP_ROW * ICP_LOOP_RING);    // (pinned: behind the ring)
+  std::memset(init, 0, sizeof *init);
+  init->rows_host = c->h_loop;
+  init->row_cap = ICP_LOOP_RING;
+  HIPCHK(hipMemcpyAsync(c->d_loop.p, init, sizeof *init, hipMemcpyHostToDevice, c->stream));
+  return TDTK_OK;
+}
+static int icp_device_loop(Ctx* c, const tdtk_tree* model, const double* A16, tdtk_scan* data, const tdtk_icp_params* prm,
+                           bool warm_ok, double* data_transMat, double* data_dalignxf, tdtk_icp_result* res, double* trace,
+                           int trace_cap, IcpLoopOut& o)
+{
+  hipStream_t s = c->stream;
+  const size_t N = data->N;
+  const int ahead = icp_loop_ahead(), max_iter = prm->max_num_iterations;
+  int rc;
+  if ((rc = c->ws[WS_KPOS].ensure(N * sizeof(int)))) return rc;
+  const uint32_t rows = search_fused_rows(N);
+  const size_t pstride = (size_t)rows * ICP_LOOP_COLS;    // two buffers of rows ([column][row]): launch k writes buffer k & 1, reads the other
+  if ((rc = c->ws[WS_PART].ensure(2 * pstride * sizeof(double)))) return rc;
+  if ((rc = icp_loop_reset(c))) return rc;
+  Mat4 A, inv;
+  std::memcpy(A.m, A16, sizeof A.m);
+  m4inv(A16, inv.m);  // searchTree.cc:110
+  double sh[3];
+  sh[0] = model->centre[0] * A16[0] + model->centre[1] * A16[4] + model->centre[2] * A16[8] + A16[12];
+  sh[1] = model->centre[0] * A16[1] + model->centre[1] * A16[5] + model->centre[2] * A16[9] + A16[13];
+  sh[2] = model->centre[0] * A16[2] + model->centre[1] * A16[6] + model->centre[2] * A16[10] + A16[14];
+  SearchArgs sa0{};
+  sa0.x = data->x; sa0.y = data->y; sa0.z = data->z;
+  sa0.nx = data->nx; sa0.ny = data->ny; sa0.nz = data->nz;
+  sa0.n = N;
+  sa0.inv = inv; sa0.has_inv = 1;
+  sa0.maxd2 = prm->max_dist_match2;
+  sa0.kpos = c->ws[WS_KPOS].as<int>();
+  sa0.fuse = 4; sa0.A = A;
+  for (int k = 0; k < 3; k++) sa0.shift[k] = sh[k];
+  sa0.loop = c->d_loop.as<IcpLoopDev>();
+  sa0.loop_rows = (int)rows; sa0.loop_max_iter = max_iter; sa0.loop_eps = prm->epsilon_icp;
+  const double margin = search_margin(model, prm->max_dist_match2);
+  double* const P = c->ws[WS_PART].as<double>();
+  // Launch k searches for iteration k; its prologue makes iteration k-1's solve and writes that iteration's row.  Launch
+  // max_iter exists for its prologue alone (the last iteration's solve ends the loop before anything is searched).
+  int enq = 0;
+  for (;;) {
+    while (enq <= max_iter && enq < o.iter + 1 + ahead) {
+      SearchArgs sa = sa0;
+      sa.loop_iter = enq;
+      sa.partials = P + (size_t)(enq & 1) * pstride;
+      sa.loop_prev = P + (size_t)((enq + 1) & 1) * pstride;
+      sa.warm = (enq > 0 && warm_ok) ? 1 : 0;   // WS_KPOS holds the previous pass's hits by the time this launch runs
+      sa.margin = sa.warm ? margin : 0.0;
+      if ((rc = run_search(c, model, sa, 0, false, s, false))) return rc;
+      enq++;
+    }
+    double* row = c->h_loop + (size_t)(o.iter % ICP_LOOP_RING) * ICP_ROW;
+    HIPCHK(await_row(row, s));
+    const int status = (int)row[ICP_ROW_STATUS];
+    const uint64_t n = (uint64_t)(row[ICP_ROW_N] + 0.5);
+    res->last_pairs = n;
+    // (either way launch o.iter has searched, i.e. it has applied the transform of the row before: nothing is pending)
+    if (status == ICP_ROW_FEW_PAIRS) { o.finished = true; o.few_pairs = true; o.have_pending = false; break; }
+    if (status == ICP_ROW_NEED_HOST) {
+      o.have_pending = false;
+      std::memset(o.acc, 0, sizeof o.acc);
+      std::memcpy(o.acc, row + ICP_ROW_ACC, ICP_LOOP_COLS * sizeof(double));
+      for (int k = 0; k < 3; k++) o.shift[k] = sh[k];
+      o.need_host = true;
+      break;
+    }
+    const double ret = row[ICP_ROW_RMS];
+    const double* alignxf = row + ICP_ROW_XF;
+    if (!prm->quiet) std::printf("QUAT RMS point-to-point error = %10.7f  using %6llu points\n", ret, (unsigned long long)n);
+    if (trace && o.iter < trace_cap) {
+      double* tr = trace + (size_t)o.iter * 18;
+      tr[0] = (double)n; tr[1] = ret;
+      std::memcpy(tr + 2, alignxf, 16 * sizeof(double));
+    }
+    res->last_rms = ret;
+    o.prev_ret = o.ret; o.ret = ret;
+    std::memcpy(o.pend, alignxf, sizeof o.pend);
+    o.have_pending = true;
+    if (data_transMat) mmult(alignxf, data_transMat, data_transMat);  // scan.cc:878-898
+    if (data_dalignxf) mmult(alignxf, data_dalignxf, data_dalignxf);
+    reinterpret_cast<volatile uint64_t*>(row)[ICP_ROW_READY] = SUMS_ARMED;     // the ring: this slot's next turn
+    if (status == ICP_ROW_CONVERGED || status == ICP_ROW_LAST) {
+      o.converged = status == ICP_ROW_CONVERGED ? 1 : 0;
+      o.finished = true;
+      break;                       // (o.iter stays the index of this iteration: what icp6D::match returns)
+    }
+    o.iter++;
+  }
+  return TDTK_OK;
+}
+
+extern "C" int tdtk_lab_icp_device_solve(int device, const double acc17[17], const double shift[3], double alignxf[16], double* rms, int* status)
+{
+  if (!acc17 || !shift || !alignxf || !rms || !status) { set_error("NULL argument"); return TDTK_EINVAL; }
+  Ctx* c;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  if ((rc = c->ws[WS_PART].ensure(ACC_TOTAL * sizeof(double)))) return rc;
+  double rowv[ACC_TOTAL] = {0.0};
+  std::memcpy(rowv, acc17, ICP_LOOP_COLS * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c->ws[WS_PART].p, rowv, sizeof rowv, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));                      // (rowv is pageable: the copy has read it)
+  if ((rc = icp_loop_reset(c))) return rc;
+  HIPCHK(launch_solve_once(c->ws[WS_PART].as<double>(), 1, shift, c->d_loop.as<IcpLoopDev>(), s));
+  HIPCHK(hipStreamSynchronize(s));
+  const double* row = c->h_loop;
+  std::memcpy(alignxf, row + ICP_ROW_XF, 16 * sizeof(double));
+  *rms = row[ICP_ROW_RMS];
+  *status = (int)row[ICP_ROW_STATUS];
+  return TDTK_OK;
+}
+#endif
+
 static int icp_match_impl(const tdtk_tree* model, const double model_dalignxf[16], tdtk_scan* data,
                           double data_transMat[16], double data_dalignxf[16], const tdtk_icp_params* prm, int rnd,
                           tdtk_icp_result* res, double* trace, int trace_cap);
@@ -2402,20 +2580,44 @@ static int icp_match_impl(const tdtk_tree* model, const double model_dalignxf[16
     if ((rc = c->d_hash.ensure(ICP_HASH_CAP * sizeof(unsigned long long)))) return rc;
     HIPCHK(hipMemsetAsync(c->d_hash.p, 0, ICP_HASH_CAP * sizeof(unsigned long long), c->stream));
   }
-  for (iter = 0; iter < prm->max_num_iterations; iter++) {
+  bool loop_done = false, resume_with_acc = false;
+  double acc[ACC_TOTAL], shift[3];
+#ifdef TDTK_LAB
+  // lab: the small-scan loop that runs without the host (see icp_device_loop): -a 1, closest points, every point a candidate
+  if (icp_loop_ahead() > 0 && algo == TDTK_ALGO_QUAT && pmode == 0 && want == 0u && rnd <= 1 && !hashing && !c->counting &&
+      !kernel_timing() && fuse_mode(data->N) == 4 && search_multi_class(data->N) == 10 && search_fused_rows(data->N) <= (uint32_t)ICP_LOOP_MAX_ROWS) {
+    IcpLoopOut o;
+    if ((rc = icp_device_loop(c, model, model_dalignxf, data, prm, warm_ok, data_transMat, data_dalignxf, res, trace, trace_cap, o))) return rc;
+    iter = o.iter;
+    ret = o.ret; prev_ret = o.prev_ret;
+    have_pending = o.have_pending;
+    if (have_pending) std::memcpy(pend, o.pend, sizeof pend);
+    converged = o.converged;
+    loop_done = o.finished;
+    if (o.need_host) {             // a solve that did not come out finite on the device: this iteration's sums, the host's solver
+      std::memcpy(acc, o.acc, sizeof acc);
+      for (int k = 0; k < 3; k++) shift[k] = o.shift[k];
+      resume_with_acc = true;
+      // (the launches still queued behind the failed solve return at once: the flag is up; the stepped loop below takes over)
+    }
+  }
+#endif
+  for (; !loop_done && iter < prm->max_num_iterations; iter++) {
     prev_prev_ret = prev_ret;
     prev_ret = ret;
-    double acc[ACC_TOTAL], shift[3];
     // -R: this pass's candidates (drawn now, in the reference's order)
     const unsigned char* skip = nullptr;
     if (rnd > 1 && (rc = draw_keep_mask(c, data, rnd, &skip))) return rc;
     // the previous iteration's alignxf is applied to the points inside the search kernel
     // (the warm start stays exact under -R: WS_KPOS holds -1 for whoever was not drawn last time -- a cold start --, and for
     // the others a point of THIS tree, whose distance bounds the nearest neighbour's however the scan has moved since)
-    rc = scan_pass(c, model, model_dalignxf, data, pmode, prm->max_dist_match2, want, nullptr,
-                   have_pending ? pend : nullptr, true, acc, shift, iter > 0 && warm_ok, skip);
-    if (rc) return rc;
-    have_pending = false;
+    if (!resume_with_acc) {
+      rc = scan_pass(c, model, model_dalignxf, data, pmode, prm->max_dist_match2, want, nullptr,
+                     have_pending ? pend : nullptr, true, acc, shift, iter > 0 && warm_ok, skip);
+      if (rc) return rc;
+      have_pending = false;
+    }
+    resume_with_acc = false;
     if (hashing && iter < ICP_HASH_CAP)    // this pass's correspondences are still in the workspace (sorted positions)
       HIPCHK(launch_idx_hash(c->ws[WS_KPOS].as<int>(), data->d_order, model->dev.pts, data->N,
                              c->d_hash.as<unsigned long long>() + iter, c->stream));

@@ -36,6 +36,27 @@ struct TreeDev {
   const double2* split;
 };
 
+#ifdef TDTK_LAB
+// ---- lab: the ICP loop that runs without the host (loop_dev.h, round 6; a measured negative, NEGATIVES.md) ----------
+// Launch k of the loop (k = 0, 1, ...) is ONE search kernel whose every workgroup first does, redundantly, what the host used
+// to do between two launches: adds up the rows of pair sums launch k-1 left (k_final's association, bit for bit), solves
+// Horn's eigenproblem, applies the stopping rule -- and then either returns (the loop has ended) or fuses the transform it has
+// just computed into its pass.  No second kernel, no grid-wide synchronisation, no host: a dependent launch costs ~3 us on
+// this part and the smallest kernel ~4, which is what a separate solve kernel behind every search would add (built and
+// measured first: NEGATIVES.md).  Workgroup 0 alone writes what outlives the launch:
+struct IcpLoopDev {
+  struct Hist { double ret, prev_ret; int stop, pad; } h[2];   // slot k & 1: the RMS history and the flag after launch k's solve
+  double* rows_host;               // the record: a ring of row_cap rows of ICP_ROW doubles in pinned host memory
+  int row_cap, pad;
+};
+// a row of the loop's record, one per iteration (the solve of iteration i is made -- and its row written -- by launch i + 1)
+constexpr int ICP_LOOP_COLS = 17;  // = ACC_DD: the base block (n, sum, centroid sums, cross sums)
+constexpr int ICP_LOOP_MAX_ROWS = 512;   // rows of pair sums every workgroup can afford to add up itself (two per thread)
+enum { ICP_ROW_N = 0, ICP_ROW_RMS = 1, ICP_ROW_XF = 2, ICP_ROW_STATUS = 18, ICP_ROW_ACC = 19, ICP_ROW_READY = 36, ICP_ROW = 40 };
+enum { ICP_ROW_CONTINUE = 1, ICP_ROW_CONVERGED = 2, ICP_ROW_LAST = 3, ICP_ROW_FEW_PAIRS = 4, ICP_ROW_NEED_HOST = 5 };
+hipError_t launch_solve_once(const double* partials, int rows, const double shift[3], IcpLoopDev* st, hipStream_t s);
+#endif
+
 struct SearchArgs {
   TreeDev T;
   double *x, *y, *z;     // queries, SoA, spatially sorted; written when has_pending
@@ -98,6 +119,15 @@ struct SearchArgs {
   // -R (rnd > 1, searchTree.cc:118): one byte per query in sorted order, non-zero = "not drawn this pass": the point still moves
   // (has_pending) but is no candidate -- kpos = -1, no search.  nullptr: every query is a candidate.
   const unsigned char* skip;
+#ifdef TDTK_LAB
+  // the small-batch kernels inside the host-free ICP loop (non-null; see IcpLoopDev): this is launch `loop_iter`; the rows of
+  // pair sums of the launch in front (loop_rows of them; this launch writes `partials`, the other buffer of the pair) and the
+  // loop's stopping rule.  has_pending / pending above are not looked at: the transform is the one the prologue solves for.
+  IcpLoopDev* loop;
+  const double* loop_prev;
+  int loop_rows, loop_iter, loop_max_iter, loop_pad;
+  double loop_eps;
+#endif
 };
 
 // internal bit beside the public TDTK_WANT_* ones: no centroid / cross-covariance columns (see k_accum)

@@ -29,6 +29,9 @@
 #include <cstring>
 
 #include "kernels.h"
+#ifdef TDTK_LAB
+#include "loop_dev.h"
+#endif
 
 namespace tdtk {
 
@@ -1036,6 +1039,42 @@ __device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx,
   }
 }
 
+#ifdef TDTK_LAB
+// lab (a measured negative, NEGATIVES.md "the small-scan loop without the host"):
+// The prologue of a small-batch launch inside the ICP loop that runs without the host (LOOP instantiations; loop_dev.h has the
+// arithmetic and kernels.h, IcpLoopDev, the scheme): this is launch k = a.loop_iter.  Launch 0 just searches.  Launch k > 0 makes
+// iteration k-1's solve -- every workgroup for itself, from the rows launch k-1 left in a.loop_prev -- and returns false when
+// the loop has ended (before this launch was even reached, or by this very solve); otherwise P is the transform to fuse.
+// Workgroup 0 writes the history slot of this launch and the record's row k-1.
+template <int BLOCK>
+__device__ __forceinline__ bool loop_prologue(const SearchArgs& a, const uint32_t bid, Mat4& P)
+{
+  static_assert(BLOCK == 256, "loop_reduce_rows plays k_final's 256 threads");
+  __shared__ double lp_red[4][ICP_LOOP_COLS];
+  __shared__ double lp_sums[ICP_LOOP_COLS];
+  const int k = a.loop_iter;
+  IcpLoopDev* const lp = a.loop;
+  const IcpLoopDev::Hist h = lp->h[(k - 1) & 1];
+  if (h.stop != 0) {                  // ended before this launch was reached: hand the flag on (the launch behind reads slot k & 1)
+    if (bid == 0 && threadIdx.x == 0) lp->h[k & 1] = h;
+    return false;
+  }
+  loop_reduce_rows(a.loop_prev, a.loop_rows, lp_red, lp_sums);
+  const LoopSolve o = loop_solve(lp_sums, a.shift, h.ret, h.prev_ret, a.loop_eps, k - 1, a.loop_max_iter);
+  if (bid == 0 && threadIdx.x == 0) {
+    IcpLoopDev::Hist n = h;
+    if (o.status != ICP_ROW_FEW_PAIRS && o.status != ICP_ROW_NEED_HOST) { n.prev_ret = h.ret; n.ret = o.rms; }
+    n.stop = o.status != ICP_ROW_CONTINUE;
+    lp->h[k & 1] = n;
+    loop_write_row(lp, k - 1, o, lp_sums);
+  }
+  if (o.status != ICP_ROW_CONTINUE) return false;
+#pragma unroll
+  for (int q = 0; q < 16; q++) P.m[q] = o.xf[q];
+  return true;
+}
+#endif
+
 // FUSE (k_search, k_search_g8: the batches too small for the persistent-lane kernel): once the workgroup is through with
 // its chunk of the queries it sums the base pair block of that chunk itself (defined behind wave_sum below), so an
 // ICP iteration on a small scan is two launches instead of three -- at that size nothing is short of issue slots and
@@ -1137,7 +1176,7 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_multi(const SearchArgs* _
 // lowest index first among equals -- which is what the serial strict '<' scan in stored order
 // returns.  Same visiting order as k_search, hence the same indices.
 // ------------------------------------------------------------------------------------------
-template <int BLOCK, int SD, int GS = 8, bool FUSE = false>
+template <int BLOCK, int SD, int GS = 8, bool FUSE = false, bool LOOP = false>
 __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
 {
   constexpr int NG = BLOCK / GS;
@@ -1173,16 +1212,27 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
   size_t hi = lo + per;
   if (hi > a.n) hi = a.n;
 
+  Mat4 pend;
+  bool has_pending = a.has_pending != 0;
+#ifdef TDTK_LAB
+  if constexpr (LOOP) {
+    has_pending = a.loop_iter > 0;
+    if (has_pending && !loop_prologue<BLOCK>(a, bid, pend)) return;      // (the loop has ended)
+  } else
+#endif
+  {
+    if (has_pending) pend = a.pending;
+  }
   for (size_t base = lo; base < hi; base += NG) {
     const size_t i = base + grp;
     if (i >= hi) continue;
     double tx = a.x[i], ty = a.y[i], tz = a.z[i];
-    if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875); every lane computes, one writes
-      dev_xf3_inplace(a.pending, tx, ty, tz);
+    if (has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875); every lane computes, one writes
+      dev_xf3_inplace(pend, tx, ty, tz);
       if (sub == 0) { a.x[i] = tx; a.y[i] = ty; a.z[i] = tz; }
       if (a.nx && sub == 0) {
         double px = a.nx[i], py = a.ny[i], pz = a.nz[i];
-        dev_xf3normal(a.pending, px, py, pz);
+        dev_xf3normal(pend, px, py, pz);
         a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
       }
     }
@@ -1473,6 +1523,12 @@ __device__ __forceinline__ void chunk_pair_sums(const SearchArgs& a, size_t lo, 
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
       if (lane == k) mine = v;
     }
+#ifdef TDTK_LAB
+    if (a.loop != nullptr) {          // inside the host-free loop: [column][row], what the next launch's prologue reads coalesced
+      if (lane < ACC_DD) a.partials[(size_t)lane * a.loop_rows + row] = mine;
+      return;
+    }
+#endif
     a.partials[(size_t)row * ACC_TOTAL + lane] = mine;                       // columns 0 .. 63 (zero from ACC_DD on)
     if (lane + WAVE < ACC_TOTAL) a.partials[(size_t)row * ACC_TOTAL + WAVE + lane] = 0.0;
     return;
@@ -1487,6 +1543,9 @@ __device__ __forceinline__ void chunk_pair_sums(const SearchArgs& a, size_t lo, 
     double sk = 0.0;
     if (k < ACC_DD)
       for (int w = 0; w < NW; w++) sk += fred[w][k];
+#ifdef TDTK_LAB
+    if (a.loop != nullptr) { if (k < ACC_DD) a.partials[(size_t)k * a.loop_rows + row] = sk; continue; }     // (see above)
+#endif
     a.partials[(size_t)row * ACC_TOTAL + k] = sk;
   }
 }
@@ -1498,11 +1557,11 @@ __device__ __forceinline__ unsigned long long wave_sum_u(unsigned v)
   return t;
 }
 
-template <int BLOCK, int SD, int GS = 8, bool FUSE = false>
+template <int BLOCK, int SD, int GS = 8, bool FUSE = false, bool LOOP = false>
 __global__ void __launch_bounds__(BLOCK) k_search_g8(const SearchArgs a_by_value)
 {
   (void)a_by_value;
-  search_g8_body<BLOCK, SD, GS, FUSE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
+  search_g8_body<BLOCK, SD, GS, FUSE, LOOP>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
 }
 template <int BLOCK, int SD, int GS>
 __global__ void __launch_bounds__(BLOCK) k_search_g8_multi(const SearchArgs* __restrict__ args, const uint32_t* __restrict__ base,
@@ -4213,10 +4272,20 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
         else launch_refill128<false, 0>(a, s);
         break;
       case 10:
+#ifdef TDTK_LAB
+        if (a.loop) {
+          if (!a.fuse) return hipErrorInvalidValue;
+          hipLaunchKernelGGL((k_search_g8<256, 16, 4, true, true>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
+          break;
+        }
+#endif
         if (a.fuse) hipLaunchKernelGGL((k_search_g8<256, 16, 4, true>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_search_g8<256, 16, 4>), dim3(g8_grid4(a.n)), dim3(256), 0, s, a);
         break;
       default:
+#ifdef TDTK_LAB
+        if (a.loop) return hipErrorInvalidValue;      // (the host-free loop is the four-lanes-per-query family's alone)
+#endif
         if (a.fuse) hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1, 4, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 4, false, 0, true, 1>), g, b, 0, s, a);
         break;

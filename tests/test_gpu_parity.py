@@ -450,6 +450,136 @@ def test_icp_vs_oracle_loop(tdtk, orc, gpu, algo):
     assert np.abs(S[1].get_xyz_reduced() - O[1].xyz).max() < (1e-8 if algo in (1, 2, 6) else 1e-5)
 
 
+def _base_sums(p1, p2, shift):
+    """the 17 base sums of a pass about `shift` (kernels.h ACC_N .. ACC_P) and the PairSums tdtk_align reads (finish_sums)"""
+    import sys
+    capi = sys.modules["3dtk_amd._capi"]
+    m, d = p1 - shift, p2 - shift
+    n = float(len(p1))
+    acc = np.zeros(17)
+    acc[0] = n
+    acc[1] = ((p1 - p2) ** 2).sum()
+    acc[2:5] = m.sum(0); acc[5:8] = d.sum(0)
+    acc[8:17] = (m[:, :, None] * d[:, None, :]).sum(0).reshape(9)
+    s = capi.PairSums()
+    s.n_queries = len(p1); s.n = len(p1); s.sum = acc[1]
+    for a in range(3):
+        s.centroid_m[a] = shift[a] + acc[2 + a] / n if n else 0.0
+        s.centroid_d[a] = shift[a] + acc[5 + a] / n if n else 0.0
+    for a in range(3):
+        for b in range(3):
+            s.Si[a * 3 + b] = acc[8 + a * 3 + b] - acc[2 + a] * acc[5 + b] / n if n else 0.0
+    return acc, s
+
+
+def test_device_solver_equals_the_host_solver(tdtk, gpu, lab):
+    """Round 6, lab (NEGATIVES.md, "the small-scan loop without the host"): the solve every workgroup makes in the prologue of a
+    launch of the host-free ICP loop (loop_dev.h: Newton on the characteristic polynomial + inverse iteration) run once on the
+    sums of a pass (tdtk_lab_icp_device_solve, lab library) against tdtk_align (linalg.cpp: Jacobi) on the same sums:
+    the K6 pose (rPos (1.5, -2, 0.7), rPosTheta (0.02, -0.03, 0.05), 1000 points), poses of every size from
+    1e-9 rad to a half turn about tilted axes, far-off clouds (coordinates ~1e5), noise, exactly identical clouds (the zero
+    matrix), fewer than four pairs (status 4) and a NaN among the sums (status 5: the host takes over)."""
+    import sys
+    capi = sys.modules["3dtk_amd._capi"]
+    L = tdtk.lib()
+    import ctypes as C
+    rng = np.random.default_rng(7)
+
+    L.tdtk_lab_icp_device_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+    def dev(acc, shift):
+        xf = np.empty(16); rms = C.c_double(0.0); st = C.c_int(0)
+        capi.check(L.tdtk_lab_icp_device_solve(gpu, capi.dptr(np.ascontiguousarray(acc)), capi.dptr(np.ascontiguousarray(shift, dtype=np.float64)),
+                                           capi.dptr(xf), C.byref(rms), C.byref(st)))
+        return xf, rms.value, st.value
+
+    def host(s):
+        xf = np.eye(4).reshape(16).copy(); rms = C.c_double(0.0)
+        capi.check(L.tdtk_align(1, C.byref(s), capi.dptr(xf), C.byref(rms)))
+        return xf, rms.value
+
+    cases = [([1.5, -2.0, 0.7], [0.02, -0.03, 0.05], 100.0, 0.0, 1000)]
+    for ang in (1e-9, 1e-6, 1e-3, 0.3, 1.5, 3.0, np.pi):
+        cases.append((rng.normal(0, 50, 3), ang * np.array([0.6, -0.3, 0.74]), 1000.0, 0.5, 20000))
+    cases.append(([3e4, -2e4, 1e4], [0.001, 0.002, -0.001], 1e5, 1.0, 50000))
+    worst = 0.0
+    for rPos, th, extent, noise, n in cases:
+        T = tdtk.EulerToMatrix4(rPos, th)
+        R = np.array([[T[0], T[4], T[8]], [T[1], T[5], T[9]], [T[2], T[6], T[10]]])
+        d = rng.uniform(-extent, extent, (n, 3))
+        m = d @ R.T + T[12:15] + rng.normal(0, noise, (n, 3)) if noise else d @ R.T + T[12:15]
+        shift = m.mean(0) + rng.normal(0, 10, 3)
+        acc, s = _base_sums(m, d, shift)
+        xd, rd, st = dev(acc, shift)
+        xh, rh = host(s)
+        assert st == 1
+        err = np.abs(xd - xh).max() / max(1.0, np.abs(xh).max())
+        worst = max(worst, err)
+        assert err < 1e-9, (rPos, th, err)
+        assert abs(rd - rh) <= 1e-12 * max(1.0, rh)
+        if not noise:
+            assert np.abs(xd - T).max() < 1e-9 * max(1.0, np.abs(T).max())
+    # identical clouds: Q = 0 up to rounding -- identity rotation either way
+    d = rng.uniform(-10, 10, (500, 3))
+    acc, s = _base_sums(d, d, np.zeros(3))
+    xd, rd, st = dev(acc, np.zeros(3))
+    xh, rh = host(s)
+    assert st == 1 and np.abs(xd - xh).max() < 1e-9 and rd == 0.0
+    # three pairs: icp6D.cc:235-243 ends the loop; a NaN among the sums: the host's turn
+    acc, _ = _base_sums(d[:3], d[:3] + 0.1, np.zeros(3))
+    assert dev(acc, np.zeros(3))[2] == 4
+    acc, _ = _base_sums(d, d + 0.1, np.zeros(3))
+    acc[9] = np.nan
+    assert dev(acc, np.zeros(3))[2] == 5
+
+
+def test_small_scan_loop_without_the_host_equals_the_stepped_loop(tdtk, gpu, lab):
+    """Round 6, lab: tdtk_icp_match on a small scan with -a 1 and TDTK_ICP_DEVICE_LOOP=1 runs without the host
+    in its iteration (every launch's workgroups make the previous iteration's solve themselves, the host follows a record in
+    pinned memory; built, measured, a tie with the stepped loop: NEGATIVES.md).  Against the same call with the switch off
+    (every iteration solved on the host, linalg.cpp): same iteration count, same pair count in every iteration, RMS / alignxf /
+    final pose / moved points within 1e-11 relative -- on the dat/ pairs thinned to every fourth point (20K points: the loop
+    takes scans of up to ~32K), for max_num_iterations 1, 2, 7 (the cap reached mid-flight), without a stopping rule over
+    more iterations than the record's ring holds (150 > 64), and on a pair with no partner within reach (fewer than four
+    pairs: the loop ends at iteration 0 and nothing moves)."""
+    z0 = np.load(os.path.join(G, "dat_scans.npz"))
+    z = {k: (z0[k][::4] if k.startswith("scan") else z0[k]) for k in z0.files}
+
+    def run(loop_on, i, max_it, eps, dist=25.0):
+        os.environ["TDTK_ICP_DEVICE_LOOP"] = "1" if loop_on else "0"
+        try:
+            S = _dat_scans(tdtk.Scan, z)
+            S[i].mergeCoordinatesWithRoboterPosition(S[i - 1])
+            icp = tdtk.icp6D(tdtk.icp6D_QUAT(True), dist, max_it, quiet=True, epsilonICP=eps)
+            it = icp.match(S[i - 1], S[i])
+            out = (it, icp.last["trace"].copy(), S[i].get_transMat().copy(), S[i].get_xyz_reduced().copy(), icp.last["pairs"],
+                   icp.last["converged"])
+            for s in S:
+                s.release()
+            return out
+        finally:
+            os.environ.pop("TDTK_ICP_DEVICE_LOOP", None)
+
+    ran_long = False
+    for (i, max_it, eps) in ((1, 50, 1e-5), (2, 50, 1e-5), (1, 1, 1e-5), (1, 2, 1e-5), (1, 7, 1e-5), (1, 150, -1.0)):
+        a = run(True, i, max_it, eps)
+        b = run(False, i, max_it, eps)
+        assert a[0] == b[0] and a[4] == b[4] and a[5] == b[5], (i, max_it, a[0], b[0])
+        assert np.array_equal(a[1][:, 0], b[1][:, 0]), (i, max_it)                       # pairs per iteration
+        np.testing.assert_allclose(a[1][:, 1], b[1][:, 1], rtol=1e-11)
+        np.testing.assert_allclose(a[1][:, 2:], b[1][:, 2:], rtol=0, atol=1e-11 * 200.0)
+        assert _rel(a[2], b[2]) < 1e-11
+        assert np.abs(a[3] - b[3]).max() < 1e-8
+        ran_long = ran_long or a[0] > 64
+        # (the two runs are not bit-identical -- the solvers differ in the last places -- which also shows the loop ran)
+        assert max_it < 3 or not np.array_equal(a[1][:, 2:], b[1][:, 2:])
+    assert ran_long
+    # nothing within reach: fewer than four pairs
+    a = run(True, 1, 20, 1e-5, dist=1e-6)
+    b = run(False, 1, 20, 1e-5, dist=1e-6)
+    assert a[0] == b[0] == 0 and a[4] == b[4] and len(a[1]) == len(b[1]) and np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+
+
 def test_kernel_timing_is_opt_in_and_changes_nothing(tdtk, gpu):
     """The HIP events around the search / pair-sum launches (tdtk_kernel_timing) are off by default -- nn_ms / sums_ms
     read 0 -- and switching them on changes no result: same iterations, same trace, same pose, bit for bit."""
