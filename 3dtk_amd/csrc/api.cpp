@@ -713,6 +713,7 @@ static int tree_finish(Ctx* c, tdtk_tree* t, size_t M)
   flush_free_later(c);
   t->dev.hot = static_cast<const KdHot*>(t->d_hot);
   t->dev.n_hot = (uint32_t)t->info.n_internal;
+  t->dev.n_slots = (uint32_t)std::min<size_t>(t->Mp, 0xFFFFFFFFu);
   t->dev.fat = static_cast<const KdFat*>(t->d_fat);
   t->dev.nodes = static_cast<const KdNode*>(t->d_nodes);
   t->dev.pts = static_cast<const KdPoint*>(t->d_pts);

@@ -24,6 +24,7 @@ struct TreeDev {
   uint32_t root_ref;
   uint32_t cb, cmask;
   uint32_t n_hot;             // records in `hot` (= internal nodes)
+  uint32_t n_slots;           // point slots of the (padded) leaf-ordered array: a hit's position is < n_slots
   // 16-bit shadow of the (padded) buckets (round 5; kernels.hip, "bucket_scan_q16"): every slot's coordinates on one grid of
   // 65536 cells per axis over the root box, cell = largest extent / 65535, stored as int16 (grid index - 32768), two slots per
   // 12 bytes { (x0,y0), (x1,y1), (z0,z1) }: a bucket of <= 20 points is 120 contiguous bytes = eight 16-byte loads (fifteen

@@ -166,8 +166,10 @@ struct LaneStack {
 template <int BLOCK, int SD>
 struct LaneStackQ {
   uint4* l_e;      // &lds_e[0][lane]
-  double* g_m2;    // overflow, may be null when the tree is shallow
+  double* g_m2;    // overflow area (wave-uniform base), may be null when the tree is shallow ...
   uint32_t* g_ref;
+  size_t gcol;     // ... and this lane's column in it (round 6: kept apart -- as two per-lane pointers they were four vector
+                   // registers live across the whole kernel for a path hardly ever taken; a column is one, or none)
   size_t gstride;
   int sp;
   __device__ __forceinline__ void push(uint32_t ref, double m2)
@@ -178,7 +180,7 @@ struct LaneStackQ {
       l_e[sp * BLOCK] = make_uint4((uint32_t)__double2loint(m2), (uint32_t)__double2hiint(m2), ref, 0u);
     } else {
       if (sp < SD) l_e[sp * BLOCK] = make_uint4((uint32_t)__double2loint(m2), (uint32_t)__double2hiint(m2), ref, 0u);
-      else stack_spill(g_m2, g_ref, (size_t)(sp - SD) * gstride, ref, m2);
+      else stack_spill(g_m2, g_ref, (size_t)(sp - SD) * gstride + gcol, ref, m2);
     }
     ++sp;
   }
@@ -194,7 +196,7 @@ struct LaneStackQ {
       m2 = __hiloint2double((int)e.y, (int)e.x);
       ref = e.z;
     } else {
-      stack_fill(g_m2, g_ref, (size_t)(s - SD) * gstride, ref, m2);
+      stack_fill(g_m2, g_ref, (size_t)(s - SD) * gstride + gcol, ref, m2);
     }
   }
 };
@@ -1645,8 +1647,7 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   }
   LaneStackQ<BLOCK, SD> st;
   st.l_e = &lds_stk[0][threadIdx.x];
-  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
-  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
+  st.g_m2 = a.ovf_m2; st.g_ref = a.ovf_ref; st.gcol = gl;
   st.gstride = (size_t)nb * BLOCK;
   st.sp = 0;
 
@@ -1662,7 +1663,6 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
   unsigned char* const a_cost = a.cost;
   const char* const t_grp = reinterpret_cast<const char*>(T.grp);
   const char* const t_fat = reinterpret_cast<const char*>(T.fat);
-
   // "expensive queries first": the order in which a piece of the slab is handed out (offsets within the piece), by the
   // number of buckets each query visited in the previous pass.  Lanes that work on queries of similar length at the same
   // time waste fewer of each other's issue slots, and the drain at the end of the piece is over cheap queries
@@ -1943,8 +1943,8 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     const bool idle = (cur == REF_DONE);
     if (idle && have) {
       gstore<int>(reinterpret_cast<char*>(a_kpos), (uint32_t)qi << 2, bk);
-      if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), (uint32_t)qi << 3, best);
       if (ORDER && a_cost) a_cost[qi] = (unsigned char)min(nbk & NBK_COST, 255u);   // nbk: node visits + 4 per bucket
+      if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), (uint32_t)qi << 3, best);
       have = false;
       if constexpr (FUSE == 2) if (bk >= 0) {
         const double tx = a.x[qi], ty = a.y[qi], tz = a.z[qi];
@@ -2087,8 +2087,8 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
         if (a.skip && a.skip[mine]) {
           // -R: not drawn this pass (searchTree.cc:118): the point has moved, it is no candidate; the lane stays idle
           gstore<int>(reinterpret_cast<char*>(a_kpos), (uint32_t)mine << 2, -1);
-          if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), m8, a.maxd2);
           if (ORDER && a_cost) a_cost[mine] = 0;
+          if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), m8, a.maxd2);
         } else {
         qx = tx; qy = ty; qz = tz;
         if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
@@ -2612,8 +2612,7 @@ __device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const u
 #pragma unroll
   for (int s = 0; s < 2; s++) {
     st[s].l_e = &lds_stk[s][0][threadIdx.x];
-    st[s].g_m2 = a.ovf_m2 ? a.ovf_m2 + 2 * gl + s : nullptr;       // (overflow columns: two per lane)
-    st[s].g_ref = a.ovf_ref ? a.ovf_ref + 2 * gl + s : nullptr;
+    st[s].g_m2 = a.ovf_m2; st[s].g_ref = a.ovf_ref; st[s].gcol = 2 * gl + s;       // (overflow columns: two per lane)
     st[s].gstride = (size_t)nb * BLOCK * 2;
     st[s].sp = 0;
   }
@@ -2758,8 +2757,7 @@ __device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const u
       const float fthi = u1 ? bx[1].thi : bx[0].thi, ftlo = u1 ? bx[1].tlo : bx[0].tlo;
       LaneStackQ<BLOCK, SD> ss;
       ss.l_e = u1 ? st[1].l_e : st[0].l_e;
-      ss.g_m2 = a.ovf_m2 ? a.ovf_m2 + 2 * gl + (u1 ? 1 : 0) : nullptr;
-      ss.g_ref = a.ovf_ref ? a.ovf_ref + 2 * gl + (u1 ? 1 : 0) : nullptr;
+      ss.g_m2 = a.ovf_m2; ss.g_ref = a.ovf_ref; ss.gcol = 2 * gl + (u1 ? 1 : 0);
       ss.gstride = (size_t)nb * BLOCK * 2;
       ss.sp = u1 ? st[1].sp : st[0].sp;
       if (COUNT) ++c_int;
@@ -3688,6 +3686,17 @@ static int num_cu()
 }
 
 constexpr int SEARCH_BLOCK = 256;
+// Levels of the traversal stack the single-pass persistent-lane kernel keeps in LDS (16 bytes per lane and level; what a query
+// stacks beyond them goes to the overflow area in HBM, 12 bytes a push and as many a pop).  Round 6: the "write amplification"
+// of the 10M-query passes (WRITE_SIZE 1.03 GB for 0.05 GB of results) was not the results -- staged in LDS and written out in
+// whole lines they left the counter where it was and cost 7 % (tools/patches/r6_stage_results_in_lds.patch, NEGATIVES.md) --
+// but this overflow: 14.3 M write requests per pass, 12.5 M of them whole 64-byte lines = a wave's column of one stack level.
+// Six levels instead of four (13 KB of LDS per workgroup: still twelve workgroups = six waves per SIMD on a CU) take the
+// whole-scan pass over a 10M-point tree from 1.82-1.95 ms to 1.48 and the ICP iteration at that size from 1.24-1.30 to 1.17;
+// five: 1.63 / 1.19; eight: 1.50 / 1.34 (nine workgroups per CU).  The instantiations that add up their pair sums inside the
+// launch (FUSE 3: scans of up to 1.8M points) get SLOWER with six -- 1M-vs-1M cold pass 0.193 -> 0.244 ms, the timed loop
+// 0.158 -> 0.198 -- while FUSE 0 over the same 1M tree does not care (0.181 -> 0.180): four stay four there.
+template <int FUSE> constexpr int REFILL_SD = (FUSE == 0) ? 6 : 4;
 constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest LDS stack in use
 
 // Variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>); the default picks by batch size.
@@ -4108,38 +4117,39 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   const int bpts = pe ? atoi(pe) : 4;
   // the instantiation whose warm queries defer the quick check (SearchArgs::tie): a repeated pass over a tree that has the
   // split halves and the 16-bit shadow; everything else -- every cold pass -- runs the kernel without that machinery
+  constexpr int SD_ = REFILL_SD<FUSE>;
   const bool defer_ok = (FUSE == 0 || FUSE == 3) && a.warm && a.tie > 0.0 && a.T.split != nullptr && a.T.q16 != nullptr && BUCKET_Q16;
 #ifdef TDTK_LAB
   if (!COUNT && FUSE == 0 && bpts == 8 && refill_thresh(a.n) == 16) {
-    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 8>), dim3(nb), dim3(128), occ_lds, s, a);
+    hipLaunchKernelGGL((k_search_refill<128, SD_, 16, 1, false, 0, false, 8>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 41 && refill_thresh(a.n) == 16) {
-    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 1>), dim3(nb), dim3(128), occ_lds, s, a);
+    hipLaunchKernelGGL((k_search_refill<128, SD_, 16, 1, false, 0, false, 4, 1>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 42 && refill_thresh(a.n) == 16) {
-    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
+    hipLaunchKernelGGL((k_search_refill<128, SD_, 16, 1, false, 0, false, 4, 2>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && bpts == 43 && refill_thresh(a.n) == 16) {
-    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 3>), dim3(nb), dim3(128), occ_lds, s, a);
+    hipLaunchKernelGGL((k_search_refill<128, SD_, 16, 1, false, 0, false, 4, 3>), dim3(nb), dim3(128), occ_lds, s, a);
   } else if (!COUNT && FUSE == 0 && refill_thresh(a.n) == 16 && a.T.fat != nullptr && lab_env("TDTK_FAT_NODES") && lab_env("TDTK_FAT_NODES")[0] == '1') {
     // two tree levels per round trip (KdFat): a measured negative, kept selectable -- see the comment at the walk
-    hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, false, 0, false, 4, 0, true>), dim3(nb), dim3(128), occ_lds, s, a);
+    hipLaunchKernelGGL((k_search_refill<128, SD_, 16, 1, false, 0, false, 4, 0, true>), dim3(nb), dim3(128), occ_lds, s, a);
   } else
 #endif
   switch (refill_thresh(a.n)) {
 #ifdef TDTK_LAB
-    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
+    case 8: hipLaunchKernelGGL((k_search_refill<128, SD_, 8, 1, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a); break;
 #endif
     case 32:
-      if (defer_ok) hipLaunchKernelGGL((k_search_refill<128, 4, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false, 4, 0, false, 0, false, false, (FUSE == 0 || FUSE == 3)>), dim3(nb), dim3(128), occ_lds, s, a);
-      else hipLaunchKernelGGL((k_search_refill<128, 4, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
+      if (defer_ok) hipLaunchKernelGGL((k_search_refill<128, SD_, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false, 4, 0, false, 0, false, false, (FUSE == 0 || FUSE == 3)>), dim3(nb), dim3(128), occ_lds, s, a);
+      else hipLaunchKernelGGL((k_search_refill<128, SD_, 32, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
       break;
     default:
 #ifdef TDTK_LAB
       if ((FUSE == 0 || FUSE == 3) && pipe_on() && !a.skip)
-        hipLaunchKernelGGL((k_search_refill<128, 4, 16, 4, COUNT, (FUSE == 3 ? 3 : 0), false, 4, 0, false, 0, false, true>), dim3(nb), dim3(128), occ_lds, s, a);
+        hipLaunchKernelGGL((k_search_refill<128, SD_, 16, 4, COUNT, (FUSE == 3 ? 3 : 0), false, 4, 0, false, 0, false, true>), dim3(nb), dim3(128), occ_lds, s, a);
       else
 #endif
-      if (defer_ok) hipLaunchKernelGGL((k_search_refill<128, 4, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false, 4, 0, false, 0, false, false, (FUSE == 0 || FUSE == 3)>), dim3(nb), dim3(128), occ_lds, s, a);
+      if (defer_ok) hipLaunchKernelGGL((k_search_refill<128, SD_, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false, 4, 0, false, 0, false, false, (FUSE == 0 || FUSE == 3)>), dim3(nb), dim3(128), occ_lds, s, a);
       else
-      hipLaunchKernelGGL((k_search_refill<128, 4, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
+      hipLaunchKernelGGL((k_search_refill<128, SD_, 16, REFILL_WPS<COUNT, FUSE>, COUNT, FUSE, false>), dim3(nb), dim3(128), occ_lds, s, a);
       break;
   }
   if (kLab && a.trace) {
