@@ -3697,6 +3697,9 @@ constexpr int SEARCH_BLOCK = 256;
 // launch (FUSE 3: scans of up to 1.8M points) get SLOWER with six -- 1M-vs-1M cold pass 0.193 -> 0.244 ms, the timed loop
 // 0.158 -> 0.198 -- while FUSE 0 over the same 1M tree does not care (0.181 -> 0.180): four stay four there.
 template <int FUSE> constexpr int REFILL_SD = (FUSE == 0) ? 6 : 4;
+// (the several-links launch, four waves per SIMD, does not care: eight levels against four, 84 links of 1M points 9.91 against
+//  9.88 ms, three links of 10M points 3.66 against 3.68 -- it keeps four)
+constexpr int MULTI_SD = 4;
 constexpr int SEARCH_SD_MIN = 4;  // overflow area is sized for the shallowest LDS stack in use
 
 // Variants of the hot instantiation (TDTK_SEARCH_VARIANT=<n>); the default picks by batch size.
@@ -4593,36 +4596,36 @@ hipError_t launch_search_multi(const SearchArgs* d_args, const uint32_t* d_base,
   if (count) {
     switch (thresh) {
 #ifdef TDTK_LAB
-      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      case 8: hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 8, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
 #endif
-      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
-      default: hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      case 32: hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 32, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
+      default: hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 16, 4, true, 0>), g, b, 0, s, d_args, d_base, nbatch); break;
     }
   } else {
     switch (thresh) {
 #ifdef TDTK_LAB
       case 8:
-        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 8, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 8, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 8, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
 #endif
       case 32:
 #ifdef TDTK_LAB
-        if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 32, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
         else
 #endif
-        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, MULTI_WPS, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 32, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 32, MULTI_WPS, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 32, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 32, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
       default:
 #ifdef TDTK_LAB
-        if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums && pipe_on()) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 16, 4, false, 5, true, true>), g, b, 0, s, d_args, d_base, nbatch);
         else
 #endif
-        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, MULTI_WPS, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
-        else hipLaunchKernelGGL((k_search_refill_multi<128, 4, 16, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
+        if (lum_sums) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 16, MULTI_WPS, false, 5, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else if (ordered) hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 16, 4, false, 0, true>), g, b, 0, s, d_args, d_base, nbatch);
+        else hipLaunchKernelGGL((k_search_refill_multi<128, MULTI_SD, 16, 4, false, 0>), g, b, 0, s, d_args, d_base, nbatch);
         break;
     }
   }
