@@ -212,6 +212,10 @@ static int exchange_with_status(tdtk_comm* c, double* blocks, size_t n, int loca
   if (c->dead || !c->comm) { set_error("communicator was aborted after an earlier failure"); return TDTK_EDEVICE; }
   const std::string local_why = local_rc ? tdtk_last_error() : "";
   if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice failed"); return abort_comm(c, TDTK_EDEVICE); }
+  if (kLab) {   // lab (tests): this rank cannot get its staging memory -- the failure the collective cannot carry
+    const char* f = lab_env("TDTK_COMM_FAIL");
+    if (f && std::strcmp(f, "reserve") == 0) { set_error("hipMalloc failed (injected: TDTK_COMM_FAIL=reserve)"); return abort_comm(c, TDTK_ENOMEM); }
+  }
   if (int rc = reserve(c, n + 1)) return abort_comm(c, rc);
   hipStream_t stream = nullptr;
   {
@@ -304,6 +308,10 @@ int tdtk_graph_iteration(int backend, tdtk_comm* comm, int nlinks, const int32_t
   const bool collective = comm && (comm->world > 1 || (force && force[0] == '1'));
   std::vector<double> blocks((size_t)nlinks * Bn, 0.0), mb((size_t)n_mine * Bn);
   int rc = tdtk_graph_link_blocks(backend, n_mine, first, first_dalignxf, second, max_dist_match2, mb.data());
+  if (kLab && !rc) {   // lab (tests): this rank's link passes fail -- the failure the collective's status slot carries
+    const char* f = lab_env("TDTK_COMM_FAIL");
+    if (f && std::strcmp(f, "links") == 0) { set_error("link passes failed (injected: TDTK_COMM_FAIL=links)"); rc = TDTK_EDEVICE; }
+  }
   if (rc && !collective) return rc;
   if (!rc)
     for (int k = 0; k < n_mine; k++) std::memcpy(&blocks[(size_t)mine[k] * Bn], &mb[(size_t)k * Bn], Bn * sizeof(double));

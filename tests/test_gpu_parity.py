@@ -2556,6 +2556,68 @@ def test_rccl_exchange_inside_the_library_one_rank(tdtk, orc, gpu, monkeypatch):
     comm.close()
 
 
+def test_failure_paths_of_the_exchange(tdtk, gpu, lab, monkeypatch):
+    """Round 6: the two ways a rank's failure reaches the others (comm.cpp) had never executed anywhere.
+    On the one GPU of this box (RCCL refuses two ranks on one device, so the peers' side -- ncclAllReduce returning an
+    error after ncclCommAbort, TDTK_EPEER from the status slot -- stays unexecuted) a 1-rank communicator with the exchange
+    forced runs this rank's side of both, the failures injected by a lab switch:
+      * TDTK_COMM_FAIL=links: the rank's link passes fail; it still enters the one collective of the iteration with zeros
+        for its blocks and the status slot raised, and returns ITS error (not a hang, not a solve over zeros): the poses
+        and the resident points are untouched, the communicator stays usable and the next iteration (switch off) equals
+        the iteration of a run that never failed;
+      * TDTK_COMM_FAIL=reserve: the rank cannot get staging memory -- nothing can be reported through the collective --:
+        ncclCommAbort, TDTK_ENOMEM, and every later call on that communicator returns TDTK_EDEVICE at once."""
+    import bench
+    gs = __import__("importlib").import_module("3dtk_amd.graphslam")
+    capi = __import__("importlib").import_module("3dtk_amd._capi")
+    raw = bench.make_graphslam_scans(6, 20000, seed=9)
+    links = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 5)]
+    monkeypatch.setenv("TDTK_FORCE_ALLREDUCE", "1")
+
+    def fresh():
+        return [tdtk.Scan(p, th, loc) for (p, th, loc) in raw]
+    # the run that never fails
+    comm = gs.NativeComm(0, 1, 0)
+    S = fresh()
+    want = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(6, links=links), S, 625.0, comm, None)
+    want_T = [s.transMat.copy() for s in S]
+    for s in S: s.release()
+    # link passes fail: reported through the exchange, nothing moves, the communicator lives
+    S = fresh()
+    before_T = [s.transMat.copy() for s in S]
+    before_x = [s.get_xyz_reduced()[:50].copy() for s in S]
+    n0 = comm.n_allreduce()
+    monkeypatch.setenv("TDTK_COMM_FAIL", "links")
+    with pytest.raises(capi.TdtkError) as e:
+        gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(6, links=links), S, 625.0, comm, None)
+    assert "reported to the other ranks through the exchange" in str(e.value) and "TDTK_COMM_FAIL=links" in str(e.value)
+    assert comm.n_allreduce() == n0 + 1                                  # it DID take part in the collective
+    assert all(np.array_equal(a, s.transMat) for a, s in zip(before_T, S))
+    assert all(np.array_equal(a, s.get_xyz_reduced()[:50]) for a, s in zip(before_x, S))
+    monkeypatch.delenv("TDTK_COMM_FAIL")
+    got = gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(6, links=links), S, 625.0, comm, None)
+    assert got == want and all(np.array_equal(a, s.transMat) for a, s in zip(want_T, S))
+    # no staging memory: abort, and the communicator is dead for good
+    monkeypatch.setenv("TDTK_COMM_FAIL", "reserve")
+    with pytest.raises(capi.TdtkError) as e:
+        gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(6, links=links), S, 625.0, comm, None)
+    assert "communicator aborted after a local failure" in str(e.value)
+    monkeypatch.delenv("TDTK_COMM_FAIL")
+    with pytest.raises(capi.TdtkError) as e:
+        gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(6, links=links), S, 625.0, comm, None)
+    assert "aborted after an earlier failure" in str(e.value)
+    blocks = np.zeros(42)
+    assert tdtk.lib().tdtk_graph_exchange(comm._h, capi.dptr(blocks), blocks.size) == -2      # TDTK_EDEVICE
+    comm.close()
+    for s in S: s.release()
+    # a new communicator works again
+    comm = gs.NativeComm(0, 1, 0)
+    S = fresh()
+    assert gs.graph_iteration_comm(gs.GRAPH_LUMEULER, tdtk.Graph(6, links=links), S, 625.0, comm, None) == want
+    comm.close()
+    for s in S: s.release()
+
+
 def _loop_scans(tdtk, io, nscans=12, npts=25000, seed=17, drift=0.25):
     rng = np.random.default_rng(seed)
     world = np.concatenate([rng.uniform(-260, 260, (150000, 3)) * np.array([1.0, 0.15, 1.0]),
