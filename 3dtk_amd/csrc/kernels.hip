@@ -748,232 +748,9 @@ __device__ __forceinline__ void kd_search(const TreeDev& T, const double qx, con
   }
 }
 
-#ifdef TDTK_LAB   // ---- lab only (a measured negative): the wave-cooperative kernel ----
-// ------------------------------------------------------------------------------------------
-// Wave-cooperative variant of the same traversal.  The per-lane logic (and therefore every
-// comparison, every visit, every tie) is unchanged; what changes is WHO issues the loads.
-// Measured on MI355X (tools/ubench/gather.hip): a wave-level 16-B-per-lane gather costs ~18
-// CU-cycles when the lanes touch <= 4 cache lines and 150 when they touch 64, and k_search is bound
-// by the number of such instructions (7.6 M per 1M queries x ~25 cycles = the kernel time).
-// Spatially sorted queries make the lanes of a wave want only a handful of DISTINCT nodes /
-// buckets at any step, so: the wave elects the distinct references (ballot + readlane), fetches
-// each record ONCE with one coalesced instruction (4 lanes per 64-B node, 2 lanes per 32-B point)
-// into a per-wave LDS staging area, and every lane then reads its own record from LDS
-// (ds_read_b128, broadcast when lanes share it).  All 64 lanes stay in the loops as helpers; a
-// lane's own work is predicated.  Buckets larger than COOP_LEAF_CAP use the per-lane path.
-// ------------------------------------------------------------------------------------------
-constexpr int COOP_NODE_SLOTS = 16;  // 16 x 64 B  = 32 staging units
-constexpr int COOP_LEAF_SLOTS = 4;
-constexpr int COOP_LEAF_CAP = 24;    // 4 x 24 x 32 B = 96 staging units (default bucket size is 20)
-constexpr int COOP_STAGE_UNITS = 96; // double4 (32 B) units per wave = 3 KB
-
-__device__ __forceinline__ void wave_lds_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <int BLOCK, int SD>
-__device__ __forceinline__ void kd_search_coop(const TreeDev& T, const bool valid, const double qx,
-                                               const double qy, const double qz, double& best, int& bk,
-                                               LaneStack<BLOCK, SD>& st, double4* __restrict__ stage)
-{
-  const unsigned lane = threadIdx.x & (WAVE - 1);
-  uint32_t cur = valid ? T.root_ref : REF_DONE;
-  st.sp = 0;
-  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
-  const double2* __restrict__ nodes16 = reinterpret_cast<const double2*>(T.nodes);
-  const double2* __restrict__ pts16 = reinterpret_cast<const double2*>(T.pts);
-  double2* stage16 = reinterpret_cast<double2*>(stage);
-
-  for (;;) {
-    // ---- phase 1: every lane that holds an internal node advances by one node per iteration ----
-    for (;;) {
-      const bool need = !(cur & REF_LEAF);
-      const unsigned long long needm = __ballot(need);
-      if (needm == 0) break;
-      bool need_pop = false;
-      uint32_t next = cur;
-      const int leader0 = __builtin_ctzll(needm);
-      const uint32_t ucur = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader0);
-      if (__ballot(need && cur != ucur) == 0) {
-        // all needing lanes hold the same node: scalar-cache path, node stays in SGPRs
-        if (need) {
-          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
-          const_u_ptr su = (const_u_ptr)(sn + 7);
-          next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], sn[6], su[0], su[1], qx, qy,
-                                       qz, best, st, need_pop);
-        }
-      } else {
-        unsigned long long pend = needm;
-        while (pend) {
-          int myslot = -1;
-          uint32_t slotv = 0;  // lane k keeps the node index of slot k
-          int k = 0;
-          while (pend && k < COOP_NODE_SLOTS) {
-            const int leader = __builtin_ctzll(pend);
-            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader);
-            const unsigned long long eq = __ballot(need && cur == v) & pend;
-            if ((eq >> lane) & 1ull) myslot = k;
-            if ((int)lane == k) slotv = v;
-            pend &= ~eq;
-            ++k;
-          }
-          // one coalesced fetch: lane l brings 16 B number (l & 3) of slot (l >> 2)
-          const int fs = (int)(lane >> 2);
-          const uint32_t fnode = (uint32_t)__shfl((int)slotv, fs, WAVE);
-          if (fs < k) stage16[lane] = nodes16[(size_t)fnode * 4 + (lane & 3)];
-          wave_lds_sync();
-          if (myslot >= 0) {
-            const double4 n0 = stage[myslot * 2];
-            const double4 n1 = stage[myslot * 2 + 1];
-            next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z,
-                                         (uint32_t)__double2loint(n1.w), (uint32_t)__double2hiint(n1.w), qx, qy,
-                                         qz, best, st, need_pop);
-          }
-          wave_lds_sync();
-        }
-      }
-      if (need_pop) {
-        next = REF_DONE;
-        while (st.sp > 0) {
-          --st.sp;
-          uint32_t r; double m2;
-          st.top(r, m2);
-          if (m2 < best) { next = r; break; }
-        }
-      }
-      cur = next;
-    }
-
-    // ---- phase 2: every lane now holds a bucket or is finished ----
-    const bool hasleaf = (cur != REF_DONE);
-    if (__ballot(hasleaf) == 0) break;
-    int start = 0, count = 0;
-    if (hasleaf) {
-      const uint32_t v = cur & REF_VAL;
-      if (T.leaf_tab) {
-        const LeafEntry le = T.leaf_tab[v];
-        start = le.start; count = le.count;
-      } else {
-        start = (int)(v >> T.cb);
-        count = (int)(v & T.cmask);
-      }
-    }
-    const bool small = hasleaf && count <= COOP_LEAF_CAP;
-    unsigned long long pend = __ballot(small);
-    while (pend) {
-      int myslot = -1;
-      int k = 0;
-      while (pend && k < COOP_LEAF_SLOTS) {
-        const int leader = __builtin_ctzll(pend);
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, leader);
-        const int s_k = __builtin_amdgcn_readlane(start, leader);
-        const int c_k = __builtin_amdgcn_readlane(count, leader);
-        const unsigned long long eq = __ballot(small && cur == v) & pend;
-        if ((eq >> lane) & 1ull) myslot = k;
-        // the whole bucket in one coalesced instruction: lane l brings 16 B number l
-        if ((int)lane < 2 * c_k) stage16[k * (COOP_LEAF_CAP * 2) + lane] = pts16[(size_t)s_k * 2 + lane];
-        pend &= ~eq;
-        ++k;
-      }
-      wave_lds_sync();
-      if (myslot >= 0) {
-        const double4* __restrict__ P = stage + myslot * COOP_LEAF_CAP;
-        const int last = count - 1;
-        for (int i = 0; i < count; i += 4) {  // stored order, strict '<' (kdTreeImpl.h:351-357)
-          const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
-          const double4 p0 = P[i], p1 = P[i1], p2 = P[i2], p3 = P[i3];
-          double dx, dy, dz;
-          dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
-          const double d0 = dx * dx + dy * dy + dz * dz;
-          dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
-          const double d1 = dx * dx + dy * dy + dz * dz;
-          dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
-          const double d3 = dx * dx + dy * dy + dz * dz;
-          if (d0 < best) { best = d0; bk = start + i; }
-          if (d1 < best) { best = d1; bk = start + i1; }
-          if (d2 < best) { best = d2; bk = start + i2; }
-          if (d3 < best) { best = d3; bk = start + i3; }
-        }
-      }
-      wave_lds_sync();
-    }
-    if (hasleaf && !small) {  // oversized (degenerate) bucket: per-lane scan straight from memory
-      const double4* __restrict__ P = pts + start;
-      for (int i = 0; i < count; i++) {
-        const double4 p = P[i];
-        const double dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-        const double d = dx * dx + dy * dy + dz * dz;
-        if (d < best) { best = d; bk = start + i; }
-      }
-    }
-    if (hasleaf) {  // pop the next pending far child that still passes sqr(myd) < closest_d2
-      cur = REF_DONE;
-      while (st.sp > 0) {
-        --st.sp;
-        uint32_t r; double m2;
-        st.top(r, m2);
-        if (m2 < best) { cur = r; break; }
-      }
-    }
-  }
-}
-
-template <int BLOCK, int SD, int WPS>
-__global__ void __launch_bounds__(BLOCK, WPS) k_search_coop(const SearchArgs a)
-{
-  __shared__ double lds_m2[SD][BLOCK];
-  __shared__ uint32_t lds_ref[SD][BLOCK];
-  __shared__ double4 lds_stage[BLOCK / WAVE][COOP_STAGE_UNITS];
-
-  const uint32_t nb = gridDim.x;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
-  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  LaneStack<BLOCK, SD> st;
-  st.l_m2 = &lds_m2[0][threadIdx.x];
-  st.l_ref = &lds_ref[0][threadIdx.x];
-  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
-  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
-  st.gstride = (size_t)nb * BLOCK;
-  st.sp = 0;
-  double4* stage = &lds_stage[threadIdx.x / WAVE][0];
-
-  const size_t per = (a.n + nb - 1) / nb;
-  const size_t lo = (size_t)chunk * per;
-  size_t hi = lo + per;
-  if (hi > a.n) hi = a.n;
-  for (size_t base = lo; base < hi; base += BLOCK) {  // uniform per workgroup: no lane leaves early
-    const size_t i = base + threadIdx.x;
-    const bool valid = i < hi;
-    double tx = 0, ty = 0, tz = 0;
-    if (valid) {
-      tx = a.x[i]; ty = a.y[i]; tz = a.z[i];
-      if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
-        dev_xf3_inplace(a.pending, tx, ty, tz);
-        a.x[i] = tx; a.y[i] = ty; a.z[i] = tz;
-        if (a.nx) {
-          double px = a.nx[i], py = a.ny[i], pz = a.nz[i];
-          dev_xf3normal(a.pending, px, py, pz);
-          a.nx[i] = px; a.ny[i] = py; a.nz[i] = pz;
-        }
-      }
-    }
-    double sx = tx, sy = ty, sz = tz;
-    if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, sx, sy, sz);  // searchTree.cc:122
-    double best = a.maxd2;
-    int bk = -1;
-    kd_search_coop<BLOCK, SD>(a.T, valid, sx, sy, sz, best, bk, st, stage);
-    if (valid) {
-      a.kpos[i] = bk;
-      if (a.d2) a.d2[i] = best;
-    }
-  }
-}
-
-#endif   // TDTK_LAB
+#ifdef TDTK_LAB
+#include "lab_coop.inc"   // the wave-cooperative kernel (k_search_coop)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // nearest point to a line: exact replay of _FindClosestAlongDir (kdTreeImpl.h:390-425).
@@ -1042,39 +819,7 @@ __device__ __forceinline__ void kd_search_dir(const TreeDev& T, const double qx,
 }
 
 #ifdef TDTK_LAB
-// lab (a measured negative, NEGATIVES.md "the small-scan loop without the host"):
-// The prologue of a small-batch launch inside the ICP loop that runs without the host (LOOP instantiations; loop_dev.h has the
-// arithmetic and kernels.h, IcpLoopDev, the scheme): this is launch k = a.loop_iter.  Launch 0 just searches.  Launch k > 0 makes
-// iteration k-1's solve -- every workgroup for itself, from the rows launch k-1 left in a.loop_prev -- and returns false when
-// the loop has ended (before this launch was even reached, or by this very solve); otherwise P is the transform to fuse.
-// Workgroup 0 writes the history slot of this launch and the record's row k-1.
-template <int BLOCK>
-__device__ __forceinline__ bool loop_prologue(const SearchArgs& a, const uint32_t bid, Mat4& P)
-{
-  static_assert(BLOCK == 256, "loop_reduce_rows plays k_final's 256 threads");
-  __shared__ double lp_red[4][ICP_LOOP_COLS];
-  __shared__ double lp_sums[ICP_LOOP_COLS];
-  const int k = a.loop_iter;
-  IcpLoopDev* const lp = a.loop;
-  const IcpLoopDev::Hist h = lp->h[(k - 1) & 1];
-  if (h.stop != 0) {                  // ended before this launch was reached: hand the flag on (the launch behind reads slot k & 1)
-    if (bid == 0 && threadIdx.x == 0) lp->h[k & 1] = h;
-    return false;
-  }
-  loop_reduce_rows(a.loop_prev, a.loop_rows, lp_red, lp_sums);
-  const LoopSolve o = loop_solve(lp_sums, a.shift, h.ret, h.prev_ret, a.loop_eps, k - 1, a.loop_max_iter);
-  if (bid == 0 && threadIdx.x == 0) {
-    IcpLoopDev::Hist n = h;
-    if (o.status != ICP_ROW_FEW_PAIRS && o.status != ICP_ROW_NEED_HOST) { n.prev_ret = h.ret; n.ret = o.rms; }
-    n.stop = o.status != ICP_ROW_CONTINUE;
-    lp->h[k & 1] = n;
-    loop_write_row(lp, k - 1, o, lp_sums);
-  }
-  if (o.status != ICP_ROW_CONTINUE) return false;
-#pragma unroll
-  for (int q = 0; q < 16; q++) P.m[q] = o.xf[q];
-  return true;
-}
+#include "lab_part_1.inc"
 #endif
 
 // FUSE (k_search, k_search_g8: the batches too small for the persistent-lane kernel): once the workgroup is through with
@@ -1252,63 +997,9 @@ __device__ __forceinline__ void search_g8_body(const SearchArgs& a, const uint32
     bx.set_query(qx, qy, qz, t_absmax);
     bx.set_radius(best);
     for (;;) {
-      if (t_fat != nullptr) while (!(cur & REF_LEAF)) {
-        // TDTK_FAT_SMALL=1 (a measured negative): two tree levels per round trip (KdFat: a node with the hot parts of its
-        // two children).  The launch lasts as long as the dependent chain of its slowest query and this halves the node
-        // part of that chain -- and still loses: eight 16-byte loads per lane and trip answer later than three.  dat/ pair
-        // 74.3 against 67.1 us per search, uniform 20K 18.1 / 17.1, 81K 26.9 / 24.9 (round 3; all 214 GPU tests pass
-        // with it).  Same visits, same order, same pushes as the one-level walk below (see search_refill_body, FAT).
-        bool need_pop = false;
-        uint32_t next = REF_DONE;
-        const char* fp = t_fat + (uint32_t)(cur << 7);
-        const float4 q0 = *reinterpret_cast<const float4*>(fp);            // X: cx cy cz hx
-        float4 q1 = *reinterpret_cast<const float4*>(fp + 16);             //    hy hz c1 c2
-        double2 q2 = *reinterpret_cast<const double2*>(fp + 32);           // X split, A split
-        double2 q3 = *reinterpret_cast<const double2*>(fp + 48);           // B split, {A c1, A c2}
-        float4 q4 = *reinterpret_cast<const float4*>(fp + 64);             // A: cx cy cz hx
-        float4 q5 = *reinterpret_cast<const float4*>(fp + 80);             // A hy hz, B hy hz
-        float4 q6 = *reinterpret_cast<const float4*>(fp + 96);             // B: cx cy cz hx
-        double q7 = *reinterpret_cast<const double*>(fp + 112);            // {B c1, B c2}
-        TDTK_PIN_V64(q2.x); TDTK_PIN_V64(q2.y); TDTK_PIN_V64(q3.x); TDTK_PIN_V64(q3.y); TDTK_PIN_V64(q7);
-        TDTK_PIN_VF(q1.z); TDTK_PIN_VF(q1.w); TDTK_PIN_VF(q4.x); TDTK_PIN_VF(q5.x); TDTK_PIN_VF(q6.x);
-        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - q0.x) - q0.w, fabsf(bx.qy - q0.y) - q1.x), fabsf(bx.qz - q0.z) - q1.y);
-        bool prune = a32 >= bx.thi;
-        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {
-          const double4 n0 = nodes[(size_t)cur * 2];
-          const double4 n1 = nodes[(size_t)cur * 2 + 1];
-          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
-        }
-        if (prune) need_pop = true;
-        else {
-          bool isA;
-          next = descend_which<NG, SD>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
-          if (!(next & REF_LEAF)) {
-            const float ncx = isA ? q4.x : q6.x, ncy = isA ? q4.y : q6.y, ncz = isA ? q4.z : q6.z, nhx = isA ? q4.w : q6.w;
-            const float nhy = isA ? q5.x : q5.z, nhz = isA ? q5.y : q5.w;
-            const float b32 = fmaxf(fmaxf(fabsf(bx.qx - ncx) - nhx, fabsf(bx.qy - ncy) - nhy), fabsf(bx.qz - ncz) - nhz);
-            bool prune2 = b32 >= bx.thi;
-            if (__builtin_expect(!prune2 && !(b32 < bx.tlo), 0)) {
-              const double4 n0 = nodes[(size_t)next * 2];
-              const double4 n1 = nodes[(size_t)next * 2 + 1];
-              prune2 = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
-            }
-            if (prune2) { need_pop = true; next = REF_DONE; }
-            else next = descend<NG, SD>(isA ? q2.y : q3.x, isA ? (uint32_t)__double2loint(q3.y) : (uint32_t)__double2loint(q7),
-                                        isA ? (uint32_t)__double2hiint(q3.y) : (uint32_t)__double2hiint(q7), qx, qy, qz, best, st);
-          }
-        }
-        if (need_pop) {
-          next = REF_DONE;
-          while (st.sp > 0) {
-            --st.sp;
-            uint32_t r; double m2;
-            st.top(r, m2);
-            if (m2 < best) { next = r; break; }
-          }
-        }
-        cur = next;
-      }
-      else
+#ifdef TDTK_LAB
+#include "lab_fat_small.inc"   // if (t_fat != nullptr): two tree levels per round trip (a measured negative)
+#endif
       while (!(cur & REF_LEAF)) {
         bool need_pop = false;
         uint32_t next = REF_DONE;
@@ -1986,46 +1677,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     const unsigned long long idlem = __ballot(idle);
     const unsigned long long activem = __ballot(!idle);
     const bool fill = (activem == 0 || __popcll(idlem) >= THRESH);
-    if (DYN && fill && next_q >= end_q) {
-      while (tried < 8u) {
-        uint32_t sl = 0;
-        if (lane == 0) sl = atomicAdd(&a.q_ctr[xq], 1u);
-        sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
-        const uint32_t lo = xq * per_x;
-        const uint32_t cnt = (lo < nslab) ? min(per_x, nslab - lo) : 0u;
-        if (sl < cnt) {
-          next_q = (size_t)(lo + sl) * (size_t)a.slab;
-          end_q = next_q + (size_t)a.slab;
-          if (end_q > a.n) end_q = a.n;
-          break;
-        }
-        xq = (xq + 1u) & 7u;
-        ++tried;
-      }
-    }
-    if (kLab && !DYN && a.pool_slab && fill && next_q >= end_q && !exhausted) {
-      // the pool of the XCD this wave runs on first; when that is dry the other seven in turn (a pool whose XCD has no
-      // resident wave -- another partition mode, an uneven dispatch -- must not be left unsearched: XCC_ID is a hint for
-      // locality, never a condition for completeness).  Counters are touched from any XCD now: agent scope.
-      while (tried < 8u) {
-        const size_t wpxq = (size_t)((nb >> 3) * (BLOCK / WAVE)) * (size_t)a.qpw;
-        size_t p0 = (size_t)xq * a.region + wpxq;
-        const size_t pend = ((size_t)(xq + 1u) * a.region < a.n) ? (size_t)(xq + 1u) * a.region : a.n;
-        if (p0 > pend) p0 = pend;
-        uint32_t k = 0;
-        if (lane == 0) k = __hip_atomic_fetch_add(&a.q_ctr[xq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-        const size_t p = p0 + (size_t)k * (size_t)a.pool_slab;
-        if (p < pend) {
-          next_q = p;
-          end_q = (p + (size_t)a.pool_slab < pend) ? p + (size_t)a.pool_slab : pend;
-          break;
-        }
-        xq = (xq + 1u) & 7u;
-        ++tried;
-      }
-      if (tried >= 8u) exhausted = true;
-    }
+#ifdef TDTK_LAB
+#include "lab_draws.inc"   // DYN / pool_slab: draws from a work queue or the XCD's pool (measured negatives)
+#endif
     if (!DYN && !a.pool_slab && fill && next_q >= end_q && phase + 1 < nph) {
       ++phase;
       next_q = reg0 + (size_t)phase * pstride;
@@ -2109,107 +1763,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
     }
 
     // ---- phase 1: walk internal nodes until this lane holds a bucket (or is finished) ----
-    // FAT (TDTK_FAT_NODES=1, a measured negative): two levels per round trip -- the 128-byte record of node X also
-    // describes X's two children, so a lane tests X, steps to the near child N and, if N is an internal node, tests N and
-    // steps again before it fetches anything else.  The visits, their order, every comparison and every push are those
-    // of the one-level walk (N's far child is pushed after X's, so it is popped first, as the recursion returns from N's
-    // subtree before it looks at X's far child); all 170 GPU parity tests pass with it.  It halves the dependent round
-    // trips of every walk and is SLOWER: 1M-vs-1M, k_search 0.2129 ms against 0.1960 at the driver's arguments, 0.1889
-    // against 0.1776 over 100 iterations, equal at 4M (gpurun_out/r3d).  Eight 16-byte loads per lane and trip instead of
-    // three is what costs: with the buckets down to one round trip of shadow groups, this kernel is bound by the number
-    // of vector-memory accesses it issues (~0.9 L1 tag look-ups per CU and cycle), not by the latency of a round trip.
-    if constexpr (FAT) while (!(cur & REF_LEAF)) {
-      if (COUNT) ++c_int;
-      if (ORDER) ++nbk;
-      bool need_pop = false;
-      uint32_t next = REF_DONE;
-      // level 2, shared by the two fetch paths below: the near child N of X is an internal node with this box / split /
-      // children; `nref` is its reference (index of its 64-byte record for the exact test)
-      auto level2 = [&](const uint32_t nref, const float ncx, const float ncy, const float ncz, const float nhx, const float nhy,
-                        const float nhz, const double nsplit, const uint32_t nc1, const uint32_t nc2) {
-        if (COUNT) ++c_int;
-        if (ORDER) ++nbk;
-        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - ncx) - nhx, fabsf(bx.qy - ncy) - nhy), fabsf(bx.qz - ncz) - nhz);
-        bool prune = a32 >= bx.thi;
-        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)((nref & REF_VAL) << 6);
-          const double4 n0 = *reinterpret_cast<const double4*>(np_);
-          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
-          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
-        }
-        if (prune) { need_pop = true; next = REF_DONE; }
-        else next = descend<BLOCK, SD, decltype(st)>(nsplit, nc1, nc2, qx, qy, qz, best, st);
-      };
-      const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
-      if (__all(cur == ucur)) {
-        // wave-uniform visit: the record through the scalar cache, operands stay in SGPRs
-        typedef const float __attribute__((address_space(4))) * const_f_ptr;
-        const_f_ptr sf = (const_f_ptr)(t_fat + (size_t)ucur * sizeof(KdFat));
-        const_u_ptr su = (const_u_ptr)sf;
-        const_d_ptr sd = (const_d_ptr)sf;
-        double s_split = sd[4], s_asplit = sd[5], s_bsplit = sd[6];
-        uint32_t s_c1 = su[6], s_c2 = su[7], s_ac1 = su[14], s_ac2 = su[15], s_bc1 = su[28], s_bc2 = su[29];
-        float s_a0 = sf[16], s_a1 = sf[17], s_a2 = sf[18], s_a3 = sf[19], s_a4 = sf[20], s_a5 = sf[21];
-        float s_b0 = sf[24], s_b1 = sf[25], s_b2 = sf[26], s_b3 = sf[27], s_b4 = sf[22], s_b5 = sf[23];
-        TDTK_PIN_S64(s_split); TDTK_PIN_S64(s_asplit); TDTK_PIN_S64(s_bsplit);
-        TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2); TDTK_PIN_S32(s_ac1); TDTK_PIN_S32(s_ac2); TDTK_PIN_S32(s_bc1); TDTK_PIN_S32(s_bc2);
-        TDTK_PIN_SF(s_a0); TDTK_PIN_SF(s_a1); TDTK_PIN_SF(s_a2); TDTK_PIN_SF(s_a3); TDTK_PIN_SF(s_a4); TDTK_PIN_SF(s_a5);
-        TDTK_PIN_SF(s_b0); TDTK_PIN_SF(s_b1); TDTK_PIN_SF(s_b2); TDTK_PIN_SF(s_b3); TDTK_PIN_SF(s_b4); TDTK_PIN_SF(s_b5);
-        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - sf[0]) - sf[3], fabsf(bx.qy - sf[1]) - sf[4]), fabsf(bx.qz - sf[2]) - sf[5]);
-        bool prune = a32 >= bx.thi;
-        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
-          prune = box_prunes_exact(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], qx, qy, qz, best);
-        }
-        if (prune) need_pop = true;
-        else {
-          bool isA;
-          next = descend_which<BLOCK, SD, decltype(st)>(s_split, s_c1, s_c2, qx, qy, qz, best, st, isA);
-          if (!(next & REF_LEAF))
-            level2(next, isA ? s_a0 : s_b0, isA ? s_a1 : s_b1, isA ? s_a2 : s_b2, isA ? s_a3 : s_b3, isA ? s_a4 : s_b4, isA ? s_a5 : s_b5,
-                   isA ? s_asplit : s_bsplit, isA ? s_ac1 : s_bc1, isA ? s_ac2 : s_bc2);
-        }
-      } else {
-        const char* fp = t_fat + (uint32_t)(cur << 7);             // 32-bit byte offset from a scalar base
-        const float4 q0 = *reinterpret_cast<const float4*>(fp);            // X: cx cy cz hx
-        float4 q1 = *reinterpret_cast<const float4*>(fp + 16);             //    hy hz c1 c2
-        double2 q2 = *reinterpret_cast<const double2*>(fp + 32);           // X split, A split
-        double2 q3 = *reinterpret_cast<const double2*>(fp + 48);           // B split, {A c1, A c2}
-        float4 q4 = *reinterpret_cast<const float4*>(fp + 64);             // A: cx cy cz hx
-        float4 q5 = *reinterpret_cast<const float4*>(fp + 80);             // A hy hz, B hy hz
-        float4 q6 = *reinterpret_cast<const float4*>(fp + 96);             // B: cx cy cz hx
-        double q7 = *reinterpret_cast<const double*>(fp + 112);            // {B c1, B c2}
-        TDTK_PIN_V64(q2.x); TDTK_PIN_V64(q2.y); TDTK_PIN_V64(q3.x); TDTK_PIN_V64(q3.y); TDTK_PIN_V64(q7);
-        TDTK_PIN_VF(q1.z); TDTK_PIN_VF(q1.w); TDTK_PIN_VF(q4.x); TDTK_PIN_VF(q5.x); TDTK_PIN_VF(q6.x);
-        const float a32 = fmaxf(fmaxf(fabsf(bx.qx - q0.x) - q0.w, fabsf(bx.qy - q0.y) - q1.x), fabsf(bx.qz - q0.z) - q1.y);
-        bool prune = a32 >= bx.thi;
-        if (__builtin_expect(!prune && !(a32 < bx.tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
-          const double4 n0 = *reinterpret_cast<const double4*>(np_);
-          const double2 n1 = *reinterpret_cast<const double2*>(np_ + 32);
-          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx, qy, qz, best);
-        }
-        if (prune) need_pop = true;
-        else {
-          bool isA;
-          next = descend_which<BLOCK, SD, decltype(st)>(q2.x, __float_as_uint(q1.z), __float_as_uint(q1.w), qx, qy, qz, best, st, isA);
-          if (!(next & REF_LEAF))
-            level2(next, isA ? q4.x : q6.x, isA ? q4.y : q6.y, isA ? q4.z : q6.z, isA ? q4.w : q6.w, isA ? q5.x : q5.z, isA ? q5.y : q5.w,
-                   isA ? q2.y : q3.x, isA ? (uint32_t)__double2loint(q3.y) : (uint32_t)__double2loint(q7),
-                   isA ? (uint32_t)__double2hiint(q3.y) : (uint32_t)__double2hiint(q7));
-        }
-      }
-      if (need_pop) {
-        next = REF_DONE;
-        while (st.sp > 0) {
-          --st.sp;
-          uint32_t r; double m2;
-          st.top(r, m2);
-          if (m2 < best) { next = r; break; }
-        }
-      }
-      cur = next;
-    }
+#ifdef TDTK_LAB
+#include "lab_fat_walk.inc"   // if constexpr (FAT): two tree levels per round trip (a measured negative)
+#endif
     if constexpr (!FAT) while (!(cur & REF_LEAF) || (PIPE && cur == REF_STAGE1)) {
       // PIPE: a lane that has just been handed a query (cur == REF_STAGE1: its coordinates and its previous hit's index were
       // requested at the hand-out and sit in qx / qy / qz / bk) spends this trip becoming a query: the stored point moved and
@@ -2217,37 +1773,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       // the wait for the node records the other lanes requested meanwhile.  Nothing of it is carried around the loop.
       double w_x = 0.0, w_y = 0.0, w_z = 0.0;
       bool fin = false;
-      if constexpr (PIPE) {
-        if (__ballot(cur == REF_STAGE1) != 0ull) {
-          if (cur == REF_STAGE1) {
-            // (the argument block through a pointer the compiler cannot see through: otherwise it hoists the two matrices'
-            // forty-eight scalar loads out of this loop and keeps them live around it -- 135 VGPRs instead of 126)
-            const SearchArgs* ap = &a;
-            asm volatile("" : "+s"(ap));
-            double tx = qx, ty = qy, tz = qz;
-            const uint32_t m8 = (uint32_t)qi << 3;
-            if (ap->has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
-              dev_xf3_inplace(ap->pending, tx, ty, tz);
-              gstore<double>(reinterpret_cast<char*>(ap->x), m8, tx); gstore<double>(reinterpret_cast<char*>(ap->y), m8, ty);
-              gstore<double>(reinterpret_cast<char*>(ap->z), m8, tz);
-              if (ap->nx) {
-                double px = ap->nx[qi], py = ap->ny[qi], pz = ap->nz[qi];
-                dev_xf3normal(ap->pending, px, py, pz);
-                ap->nx[qi] = px; ap->ny[qi] = py; ap->nz[qi] = pz;
-              }
-            }
-            qx = tx; qy = ty; qz = tz;
-            if (ap->has_inv) dev_xf3(ap->inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
-            if (bk >= 0) {
-              const uint32_t po = (uint32_t)bk << 5;
-              const double2 pxy = gload<double2>(reinterpret_cast<const char*>(pts), po);
-              w_z = gload<double>(reinterpret_cast<const char*>(pts), po + 16);
-              w_x = pxy.x; w_y = pxy.y;
-            }
-            fin = true;
-          }
-        }
-      }
+#ifdef TDTK_LAB
+#include "lab_pipe_stage.inc"   // if constexpr (PIPE): a lane just handed a query becomes one during this trip
+#endif
       if (!PIPE || !(cur & REF_LEAF)) {
       if (COUNT) ++c_int;
       if (COUNT && kLab) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
@@ -2361,23 +1889,9 @@ __device__ __forceinline__ void search_refill_body(const SearchArgs& a, const ui
       }
       cur = next;
       }
-      if constexpr (PIPE) {
-        if (fin) {
-          // warm_radius_kp's arithmetic on the point requested at the top of this trip; the lane stands at the root now
-          { const SearchArgs* ap = &a; asm volatile("" : "+s"(ap)); best = ap->maxd2; }
-          if (bk >= 0) {
-            const double dx = w_x - qx, dy = w_y - qy, dz = w_z - qz;
-            const double d = dx * dx + dy * dy + dz * dz;
-            const double up = __longlong_as_double(__double_as_longlong(d) + 1);   // next double above d (d >= 0, finite)
-            if (up < best) best = up;
-          }
-          bk = -1;
-          cur = T.root_ref;
-          bx.set_query(qx, qy, qz, T.absmax);
-          q16_query();
-          bx.set_radius(best);
-        }
-      }
+#ifdef TDTK_LAB
+#include "lab_pipe_fin.inc"   // if constexpr (PIPE): the warm radius of a lane that has just become a query
+#endif
     }
 
     // ---- phase 2: scan the bucket, then pop ----
@@ -2589,360 +2103,8 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill(const SearchArgs a
 }
 
 #ifdef TDTK_LAB
-// ------------------------------------------------------------------------------------------
-// k_search_refill2 (lab, TDTK_SEARCH_VARIANT=22): the persistent-lane kernel with TWO queries per lane.
-// The trips of k_search_refill's node walk are 0.44 full (tools/lane_fill_probe.py): a lane whose query has reached its
-// bucket waits for the slowest walk of the wave, and a trip is one memory round trip.  Here a lane carries two queries,
-// both states in registers; every trip of the node walk issues the record loads of BOTH before it uses either, so a trip's
-// round trip serves up to two visits per lane and a lane leaves the walk only when both of its queries hold a bucket (or
-// are done).  Buckets are scanned one query after the other (the shadow groups' sixty registers are shared).  Each query's
-// traversal -- visits, their order, every comparison -- is untouched: same indices, same counters.
-// ------------------------------------------------------------------------------------------
-// ONE (round 4, TDTK_TWO_ONE=1): a trip of the node walk serves ONE of the lane's two queries -- slot 0 while it stands at a
-// node, slot 1 otherwise -- with one record's loads and one visit's instructions, the state of the chosen slot picked by
-// selects.  The vector L1 charges a wave instruction by its bytes per lane whatever the mask (profiles/r04_tcp_diag.txt), so
-// what a fuller trip saves is load INSTRUCTIONS, which the both-slots-per-trip form above did not (it issued two sets).
-template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE, bool ONE = false>
-__device__ __forceinline__ void search_refill2_body(const SearchArgs& a, const uint32_t bid, const uint32_t nb)
-{
-  __shared__ uint4 lds_stk[2][SD][BLOCK];
-  const size_t gl = (size_t)bid * BLOCK + threadIdx.x;
-  const unsigned lane = threadIdx.x & (WAVE - 1);
-  LaneStackQ<BLOCK, SD> st[2];
-#pragma unroll
-  for (int s = 0; s < 2; s++) {
-    st[s].l_e = &lds_stk[s][0][threadIdx.x];
-    st[s].g_m2 = a.ovf_m2; st[s].g_ref = a.ovf_ref; st[s].gcol = 2 * gl + s;       // (overflow columns: two per lane)
-    st[s].gstride = (size_t)nb * BLOCK * 2;
-    st[s].sp = 0;
-  }
-  const TreeDev& T = a.T;
-  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
-  const double4* __restrict__ pts = reinterpret_cast<const double4*>(T.pts);
-  const LeafEntry* const t_leaf_tab = T.leaf_tab;
-  const uint32_t t_cb = T.cb, t_cmask = T.cmask;
-  int* const a_kpos = a.kpos;
-  double* const a_d2 = a.d2;
-  unsigned char* const a_cost = a.cost;
-  const char* const t_grp = reinterpret_cast<const char*>(T.grp);
-  const char* __restrict__ hotb = reinterpret_cast<const char*>(T.hot);
-
-  // the hand-out order of the slab (expensive queries first), as in k_search_refill
-  constexpr int ORD_MAX = 512;
-  __shared__ unsigned short lds_order[BLOCK / WAVE][ORD_MAX];
-  unsigned short* const my_order = lds_order[threadIdx.x / WAVE];
-  bool ordered = false;
-  const uint32_t wpx = (nb >> 3) * (BLOCK / WAVE);
-  const uint32_t wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid >> 3) * (BLOCK / WAVE) + threadIdx.x / WAVE));
-  const size_t reg0 = (size_t)(bid & 7u) * wpx * (size_t)a.qpw + (size_t)wx * (size_t)a.qpw;
-  size_t next_q = reg0 < a.n ? reg0 : a.n;
-  const size_t end_q = (reg0 + (size_t)a.qpw < a.n) ? reg0 + (size_t)a.qpw : a.n;
-  if (a.use_cost && a.cost && end_q > next_q && end_q - next_q <= (size_t)ORD_MAX) {
-    const uint32_t cntp = (uint32_t)(end_q - next_q);
-    int cls[ORD_MAX / WAVE];
-    unsigned cvv[ORD_MAX / WAVE];
-    unsigned mn = 255u, mx = 0u;
-#pragma unroll
-    for (int r = 0; r < ORD_MAX / WAVE; r++) {
-      const uint32_t o = (uint32_t)r * WAVE + lane;
-      cvv[r] = (o < cntp) ? (unsigned)a.cost[next_q + o] : 0u;
-      if (o < cntp) { mn = min(mn, cvv[r]); mx = max(mx, cvv[r]); }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mn = min(mn, (unsigned)__shfl_xor((int)mn, off, WAVE));
-      mx = max(mx, (unsigned)__shfl_xor((int)mx, off, WAVE));
-    }
-    const unsigned span = (mx > mn) ? mx - mn + 1u : 1u;
-#pragma unroll
-    for (int r = 0; r < ORD_MAX / WAVE; r++) {
-      const uint32_t o = (uint32_t)r * WAVE + lane;
-      cls[r] = (o < cntp) ? (int)min(((cvv[r] - mn) * 8u) / span, 7u) : -1;
-    }
-    uint32_t base = 0;
-    for (int k = 7; k >= 0; k--) {
-#pragma unroll
-      for (int r = 0; r < ORD_MAX / WAVE; r++) {
-        if ((uint32_t)r * WAVE >= cntp) continue;
-        const unsigned long long m = __ballot(cls[r] == k);
-        if (cls[r] == k) my_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(r * WAVE + lane);
-        base += (uint32_t)__popcll(m);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    ordered = true;
-  }
-  const size_t piece0 = next_q;
-
-  uint32_t cur[2] = {REF_DONE, REF_DONE};
-  double best[2] = {0.0, 0.0}, qx[2] = {0, 0}, qy[2] = {0, 0}, qz[2] = {0, 0};
-  int bk[2] = {-1, -1};
-  uint32_t qi[2] = {0, 0};
-  bool have[2] = {false, false};
-  unsigned nbk[2] = {0, 0};
-  BoxF32 bx[2];
-#pragma unroll
-  for (int s = 0; s < 2; s++) { bx[s].qx = bx[s].qy = bx[s].qz = 0.f; bx[s].delta = 0.f; bx[s].thi = 0.f; bx[s].tlo = 0.f; bx[s].ec = 0.f; bx[s].pthr = 0.f; }
-  unsigned c_int = 0, c_leaf = 0, c_pts = 0, c_t1 = 0, c_t2 = 0;
-
-  for (;;) {
-    // ---- retire finished queries, hand out new ones (both slots) ----
-    unsigned long long idlem[2], activem = 0;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      const bool idle = (cur[s] == REF_DONE);
-      if (idle && have[s]) {
-        gstore<int>(reinterpret_cast<char*>(a_kpos), qi[s] << 2, bk[s]);
-        if (a_d2) gstore<double>(reinterpret_cast<char*>(a_d2), qi[s] << 3, best[s]);
-        if (a_cost) a_cost[qi[s]] = (unsigned char)min(nbk[s], 255u);
-        have[s] = false;
-      }
-      idlem[s] = __ballot(idle);
-      activem |= __ballot(!idle);
-    }
-    const unsigned nidle = (unsigned)__popcll(idlem[0]) + (unsigned)__popcll(idlem[1]);
-    const bool fill = (activem == 0 || nidle >= 2 * THRESH);
-    if (next_q < end_q && fill) {
-      // slot 0 of every idle lane first, then slot 1 (a lane with both idle takes two queries)
-      const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        const unsigned rank = (unsigned)__popcll(idlem[s] & below) + (s ? (unsigned)__popcll(idlem[0]) : 0u);
-        const size_t slot = next_q + rank;
-        const bool got = (cur[s] == REF_DONE) && slot < end_q;
-        const size_t mine = (got && ordered) ? piece0 + (size_t)my_order[slot - piece0] : slot;
-        if (got) {
-          const uint32_t m8 = (uint32_t)mine << 3;
-          const int kp_prev = a.warm ? gload<int>(reinterpret_cast<const char*>(a_kpos), (uint32_t)mine << 2) : -1;
-          double tx = gload<double>(reinterpret_cast<const char*>(a.x), m8), ty = gload<double>(reinterpret_cast<const char*>(a.y), m8),
-                 tz = gload<double>(reinterpret_cast<const char*>(a.z), m8);
-          if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
-            dev_xf3_inplace(a.pending, tx, ty, tz);
-            gstore<double>(reinterpret_cast<char*>(a.x), m8, tx); gstore<double>(reinterpret_cast<char*>(a.y), m8, ty);
-            gstore<double>(reinterpret_cast<char*>(a.z), m8, tz);
-            if (a.nx) {
-              double px = a.nx[mine], py = a.ny[mine], pz = a.nz[mine];
-              dev_xf3normal(a.pending, px, py, pz);
-              a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz;
-            }
-          }
-          qx[s] = tx; qy[s] = ty; qz[s] = tz;
-          if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx[s], qy[s], qz[s]);  // searchTree.cc:122
-          qi[s] = (uint32_t)mine; have[s] = true; nbk[s] = 0;
-          cur[s] = T.root_ref; best[s] = warm_radius_kp(a, kp_prev, qx[s], qy[s], qz[s]); bk[s] = -1; st[s].sp = 0;
-          bx[s].set_query(qx[s], qy[s], qz[s], T.absmax);
-          bx[s].set_radius(best[s]);
-        }
-      }
-      next_q += nidle;
-    }
-    if (__ballot(cur[0] != REF_DONE || cur[1] != REF_DONE) == 0) {
-      if (next_q >= end_q) break;
-      continue;
-    }
-
-    // ---- phase 1: walk internal nodes until both of this lane's queries hold a bucket (or are finished) ----
-    if constexpr (ONE) while (!(cur[0] & REF_LEAF) || !(cur[1] & REF_LEAF)) {
-      if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
-      const bool u1 = (cur[0] & REF_LEAF) != 0u;        // slot 0 holds a bucket (or is done): this trip is slot 1's
-      const uint32_t c = u1 ? cur[1] : cur[0];
-      const uint32_t ho = __umul24(c, (uint32_t)sizeof(KdHot));
-      float4 b0 = gload<float4>(hotb, ho);                 // cx cy cz hx
-      float4 b1 = gload<float4>(hotb, ho + 16);            // hy hz axis -
-      double2 sc = gload<double2>(hotb, ho + 32);          // splitval {c1, c2}
-      TDTK_PIN_BATCH3(b0.x, b1.z, sc.x);
-      const double sqx = u1 ? qx[1] : qx[0], sqy = u1 ? qy[1] : qy[0], sqz = u1 ? qz[1] : qz[0], sbest = u1 ? best[1] : best[0];
-      const float fqx = u1 ? bx[1].qx : bx[0].qx, fqy = u1 ? bx[1].qy : bx[0].qy, fqz = u1 ? bx[1].qz : bx[0].qz;
-      const float fthi = u1 ? bx[1].thi : bx[0].thi, ftlo = u1 ? bx[1].tlo : bx[0].tlo;
-      LaneStackQ<BLOCK, SD> ss;
-      ss.l_e = u1 ? st[1].l_e : st[0].l_e;
-      ss.g_m2 = a.ovf_m2; ss.g_ref = a.ovf_ref; ss.gcol = 2 * gl + (u1 ? 1 : 0);
-      ss.gstride = (size_t)nb * BLOCK * 2;
-      ss.sp = u1 ? st[1].sp : st[0].sp;
-      if (COUNT) ++c_int;
-      const float a32 = fmaxf(fmaxf(fabsf(fqx - b0.x) - b0.w, fabsf(fqy - b0.y) - b1.x), fabsf(fqz - b0.z) - b1.y);
-      bool prune = a32 >= fthi;
-      if (__builtin_expect(!prune && !(a32 < ftlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-        const uint32_t no = (uint32_t)((c & REF_VAL) << 6);
-        const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
-        const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
-        prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, sqx, sqy, sqz, sbest);
-      }
-      uint32_t next = REF_DONE;
-      if (!prune) next = descend_ax(sc.x, (uint32_t)__double2loint(sc.y), (uint32_t)__double2hiint(sc.y), __float_as_uint(b1.z), sqx, sqy, sqz, sbest, ss);
-      else {
-        while (ss.sp > 0) {
-          --ss.sp;
-          uint32_t r; double m2;
-          ss.top(r, m2);
-          if (m2 < sbest) { next = r; break; }
-        }
-      }
-      if (u1) { cur[1] = next; st[1].sp = ss.sp; ++nbk[1]; } else { cur[0] = next; st[0].sp = ss.sp; ++nbk[0]; }
-    }
-    if constexpr (!ONE) while (!(cur[0] & REF_LEAF) || !(cur[1] & REF_LEAF)) {
-      if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t1; }
-      const bool at[2] = {!(cur[0] & REF_LEAF), !(cur[1] & REF_LEAF)};
-      // the records of both, requested before either is used
-      float4 b0[2], b1[2];
-      double2 sc[2];
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        const uint32_t ho = __umul24(at[s] ? cur[s] : 0u, (uint32_t)sizeof(KdHot));
-        b0[s] = gload<float4>(hotb, ho);                 // cx cy cz hx   (a lane whose query is not at a node re-reads the root: an L1 hit)
-        b1[s] = gload<float4>(hotb, ho + 16);            // hy hz axis -
-        sc[s] = gload<double2>(hotb, ho + 32);           // splitval {c1, c2}
-      }
-      asm volatile("" : "+v"(b0[0].x), "+v"(b1[0].z), "+v"(sc[0].x), "+v"(b0[1].x), "+v"(b1[1].z), "+v"(sc[1].x));
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        if (!at[s]) continue;
-        if (COUNT) ++c_int;
-        ++nbk[s];
-        const float a32 = fmaxf(fmaxf(fabsf(bx[s].qx - b0[s].x) - b0[s].w, fabsf(bx[s].qy - b0[s].y) - b1[s].x), fabsf(bx[s].qz - b0[s].z) - b1[s].y);
-        bool prune = a32 >= bx[s].thi;
-        if (__builtin_expect(!prune && !(a32 < bx[s].tlo), 0)) {      // undecidable in fp32 (or not finite): the exact test
-          const uint32_t no = (uint32_t)((cur[s] & REF_VAL) << 6);
-          const double4 n0 = gload<double4>(reinterpret_cast<const char*>(nodes), no);
-          const double2 n1 = gload<double2>(reinterpret_cast<const char*>(nodes), no + 32);
-          prune = box_prunes_exact(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, qx[s], qy[s], qz[s], best[s]);
-        }
-        uint32_t next = REF_DONE;
-        if (!prune) next = descend_ax(sc[s].x, (uint32_t)__double2loint(sc[s].y), (uint32_t)__double2hiint(sc[s].y), __float_as_uint(b1[s].z), qx[s], qy[s], qz[s], best[s], st[s]);
-        else {
-          while (st[s].sp > 0) {
-            --st[s].sp;
-            uint32_t r; double m2;
-            st[s].top(r, m2);
-            if (m2 < best[s]) { next = r; break; }
-          }
-        }
-        cur[s] = next;
-      }
-    }
-
-    // ---- phase 2: scan the buckets, one query after the other, then pop ----
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      if (cur[s] == REF_DONE) continue;
-      if (COUNT) { const unsigned long long on = __ballot(true); if ((int)lane == __ffsll((long long)on) - 1) ++c_t2; }
-      const uint32_t v = cur[s] & REF_VAL;
-      int start, count;
-      if (t_leaf_tab) { const LeafEntry le = t_leaf_tab[v]; start = le.start; count = le.count; }
-      else { start = (int)(v >> t_cb); count = (int)(v & t_cmask); }
-      if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
-      nbk[s] += 4u;
-      const char* pb = reinterpret_cast<const char*>(pts);
-      const uint32_t o0 = (uint32_t)start << 5;
-      const uint32_t olast = o0 + ((uint32_t)(count - 1) << 5);
-      if (t_grp != nullptr && count <= 4 * GRP_TRIP) {
-        bucket_scan_groups(t_grp, pb, start, count, o0, bx[s], qx[s], qy[s], qz[s], best[s], bk[s]);
-      } else {
-        for (uint32_t o = o0; o <= olast; o += 32u * 4) {
-          uint32_t oo[4];
-          double px[4], py[4], pz[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            oo[j] = (j == 0) ? o : min(o + 32u * (uint32_t)j, olast);
-            const double2 pxy = *reinterpret_cast<const double2*>(pb + oo[j]);
-            px[j] = pxy.x; py[j] = pxy.y;
-            pz[j] = *reinterpret_cast<const double*>(pb + oo[j] + 16);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const double dx = px[j] - qx[s], dy = py[j] - qy[s], dz = pz[j] - qz[s];
-            const double dd = dx * dx + dy * dy + dz * dz;
-            if (dd < best[s]) { best[s] = dd; bk[s] = (int)(oo[j] >> 5); }
-          }
-        }
-      }
-      bx[s].set_radius(best[s]);
-      cur[s] = REF_DONE;
-      while (st[s].sp > 0) {
-        --st[s].sp;
-        uint32_t r; double m2;
-        st[s].top(r, m2);
-        if (m2 < best[s]) { cur[s] = r; break; }
-      }
-    }
-  }
-  if (COUNT && a.counters) {
-    const unsigned long long s_int = wave_sum_u(c_int), s_leaf = wave_sum_u(c_leaf), s_pts = wave_sum_u(c_pts);
-    const unsigned long long s_t1 = wave_sum_u(c_t1), s_t2 = wave_sum_u(c_t2);
-    if (lane == 0) {
-      atomicAdd(&a.counters[0], s_int); atomicAdd(&a.counters[1], s_leaf); atomicAdd(&a.counters[2], s_pts);
-      atomicAdd(&a.counters[8], s_t1); atomicAdd(&a.counters[9], s_t2);
-    }
-  }
-  if constexpr (FUSE == 3) {
-    // the base pair sums of this wave's own slab after its last query, as in k_search_refill (FUSE 3)
-    double acc[ACC_DD];
-#pragma unroll
-    for (int k = 0; k < ACC_DD; k++) acc[k] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const uint32_t slab = (uint32_t)a.qpw;
-    for (uint32_t j0 = 0; j0 < slab; j0 += 2 * WAVE) {
-      size_t qq[2];
-      int kk[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const uint32_t j = j0 + (uint32_t)u * WAVE + lane;
-        qq[u] = reg0 + j;
-        kk[u] = (j < slab && qq[u] < a.n) ? a.kpos[qq[u]] : -1;
-      }
-      double cx[2], cy[2], cz[2], tx[2], ty[2], tz[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        cx[u] = cy[u] = cz[u] = tx[u] = ty[u] = tz[u] = 0.0;
-        if (kk[u] >= 0) {
-          const double4 c = *reinterpret_cast<const double4*>(reinterpret_cast<const char*>(pts) + ((uint32_t)kk[u] << 5));
-          cx[u] = c.x; cy[u] = c.y; cz[u] = c.z;
-          tx[u] = a.x[qq[u]]; ty[u] = a.y[qq[u]]; tz[u] = a.z[qq[u]];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        if (kk[u] < 0) continue;
-        double mx, my, mz;
-        dev_xf3(a.A, cx[u], cy[u], cz[u], mx, my, mz);  // searchTree.cc:147
-        const double px = mx - tx[u], py = my - ty[u], pz = mz - tz[u];
-        acc[ACC_N] += 1.0;
-        acc[ACC_SUM] += px * px + py * py + pz * pz;
-        const double m0 = mx - a.shift[0], m1 = my - a.shift[1], m2 = mz - a.shift[2];
-        const double d0 = tx[u] - a.shift[0], d1 = ty[u] - a.shift[1], d2 = tz[u] - a.shift[2];
-        acc[ACC_SM + 0] += m0; acc[ACC_SM + 1] += m1; acc[ACC_SM + 2] += m2;
-        acc[ACC_SD + 0] += d0; acc[ACC_SD + 1] += d1; acc[ACC_SD + 2] += d2;
-        acc[ACC_P + 0] += m0 * d0; acc[ACC_P + 1] += m0 * d1; acc[ACC_P + 2] += m0 * d2;
-        acc[ACC_P + 3] += m1 * d0; acc[ACC_P + 4] += m1 * d1; acc[ACC_P + 5] += m1 * d2;
-        acc[ACC_P + 6] += m2 * d0; acc[ACC_P + 7] += m2 * d1; acc[ACC_P + 8] += m2 * d2;
-      }
-    }
-    constexpr int NW = BLOCK / WAVE;
-    __shared__ double red[NW][ACC_DD];
-    const int wv = threadIdx.x / WAVE;
-#pragma unroll
-    for (int k = 0; k < ACC_DD; k++) {
-      const double sres = wave_sum(acc[k]);
-      if (lane == 0) red[wv][k] = sres;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < ACC_TOTAL; k += BLOCK) {
-      double sres = 0.0;
-      if (k < ACC_DD)
-        for (int w = 0; w < NW; w++) sres += red[w][k];
-      a.partials[(size_t)bid * ACC_TOTAL + k] = sres;
-    }
-  }
-}
-
-template <int BLOCK, int SD, int THRESH, bool COUNT, int FUSE, int WPS, bool ONE = false>
-__global__ void __launch_bounds__(BLOCK, WPS) k_search_refill2(const SearchArgs a_by_value)
-{
-  (void)a_by_value;
-  search_refill2_body<BLOCK, SD, THRESH, COUNT, FUSE, ONE>(kernarg_block<SearchArgs>(), blockIdx.x, gridDim.x);
-}
-#endif   // TDTK_LAB
+#include "lab_two_per_lane.inc"   // two queries per lane (k_search_refill2)
+#endif
 
 // Several whole-scan passes (the links of a graph-SLAM round) in ONE launch: workgroups base[l] .. base[l+1]-1 search
 // batch l with the arguments args[l] (device memory; every base[] a multiple of 8, so a workgroup's XCD is the one its
@@ -2959,301 +2121,9 @@ __global__ void __launch_bounds__(BLOCK, WPS) k_search_refill_multi(const Search
   search_refill_body<BLOCK, SD, THRESH, WPS, COUNT, FUSE, false, ORDER, 4, 0, false, 320, true, 0, false, PIPE>(args[l], blockIdx.x - b0, b1 - b0);
 }
 
-#ifdef TDTK_LAB   // ---- lab only (measured negatives): slabs of equal cost, the one-loop kernel ----
-static uint32_t refill_grid_b_fwd(size_t n, int* qpw_out);   // = refill_grid_b(n, 128, qpw_out): the grid of the single-pass launch
-
-// ------------------------------------------------------------------------------------------
-// k_slab_bounds: slabs of equal cost for the next pass over the same queries (round 4).
-// A launch over 1M queries is ONE generation of 4096 waves; handed 256 queries each, the waves do not finish together --
-// the first is done after 60 % of the launch, the median after 77 % (TDTK_WAVE_TRACE, round 3) -- and the SIMDs they
-// leave run the launch's tail with one or two waves.  The cost byte every query leaves behind when it retires (node
-// visits + 4 per bucket, what the hand-out inside a slab is ordered by) says what a stretch of the sorted scan will cost
-// the NEXT pass of the same ICP loop, so the next launch cuts the scan into as many stretches of equal cost as it has
-// waves: sums per 32-query chunk (every workgroup a run of chunks), then -- by the workgroup that finishes last -- a
-// scan of the chunk sums and bounds[w] = the end of the first chunk at which the running cost reaches w / W of the
-// total.  One launch, enqueued behind the pass's k_final: it runs while the host solves for the pose.  Which wave
-// searches a query never shows in a result; which queries share a row of partial sums does, in the last bits of the
-// sums (as the slab length does), deterministically.
-// ------------------------------------------------------------------------------------------
-#define SB_CHUNK 32u
-#define SB_FIX 6u             // what a query costs besides its visits (hand-out, retire, its share of the sums pass)
-__global__ void __launch_bounds__(1024) k_slab_bounds(const unsigned char* __restrict__ cost, uint32_t n, uint32_t W, uint32_t nchunk,
-                                                      uint32_t* __restrict__ csum, uint32_t* __restrict__ counter,
-                                                      uint32_t* __restrict__ bounds, const uint32_t fix)
-{
-  // phase A: chunk sums, one chunk of 32 cost bytes per pair of lanes (a 16-byte load each)
-  {
-    const uint32_t pair = (blockIdx.x * 1024u + threadIdx.x) >> 1, half = threadIdx.x & 1u;
-    uint32_t sum = 0;
-    if (pair < nchunk) {
-      const uint32_t q0 = pair * SB_CHUNK + half * 16u;
-      if (q0 + 16u <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(cost + q0);
-        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) sum += (w4[k] & 0xFFu) + ((w4[k] >> 8) & 0xFFu) + ((w4[k] >> 16) & 0xFFu) + (w4[k] >> 24);
-        sum += 16u * fix;
-      } else {
-        for (uint32_t q = q0; q < n && q < q0 + 16u; q++) sum += (uint32_t)cost[q] + fix;
-      }
-    }
-    sum += __shfl_xor(sum, 1, WAVE);
-    if (pair < nchunk && half == 0) csum[pair] = sum;
-  }
-  __shared__ uint32_t s_last;
-  __shared__ unsigned long long s_tot[1024 / WAVE];
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  // phase B (the last workgroup): thread t takes a run of chunks; exclusive scan of the runs' sums; then it walks its run
-  // and places every boundary that falls into it
-  const uint32_t per = (nchunk + 1023u) / 1024u;
-  const uint32_t c0 = min(threadIdx.x * per, nchunk), c1 = min(c0 + per, nchunk);
-  unsigned long long mine = 0;
-  for (uint32_t c = c0; c < c1; c++) mine += __builtin_nontemporal_load(csum + c);
-  unsigned long long incl = mine;
-  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-#pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    const unsigned long long t = (unsigned long long)__shfl_up((long long)incl, off, WAVE);
-    if ((int)lane >= off) incl += t;
-  }
-  if (lane == WAVE - 1) s_tot[wv] = incl;
-  __syncthreads();
-  unsigned long long before = incl - mine, total = 0;
-  for (uint32_t k = 0; k < 1024 / WAVE; k++) { if (k < wv) before += s_tot[k]; total += s_tot[k]; }
-  if (threadIdx.x == 0) { bounds[0] = 0u; bounds[W] = n; *counter = 0u; }      // (the counter is ready for the next launch)
-  if (total == 0) total = 1;
-  // boundary w sits at the end of the first chunk whose running cost reaches w total / W: floor(prefix W / total) steps from
-  // w - 1 to w there.  One rounding of prefix * (W / total) in fp64 (prefix < 2^32) is monotone in the prefix, which is all
-  // that matters: every w gets exactly one chunk.
-  const double scale = (double)W / (double)total;
-  unsigned long long p = before;
-  uint32_t w_prev = (uint32_t)((double)p * scale);
-  for (uint32_t c = c0; c < c1; c++) {
-    p += __builtin_nontemporal_load(csum + c);
-    const uint32_t w_now = (c + 1u == nchunk) ? W : (uint32_t)((double)p * scale);
-    const uint32_t end = min((c + 1u) * SB_CHUNK, n);
-    for (uint32_t w = w_prev + 1u; w <= w_now && w < W; w++) bounds[w] = end;
-    w_prev = w_now;
-  }
-}
-size_t slab_bounds_bytes(size_t n)
-{
-  const size_t nchunk = (n + SB_CHUNK - 1) / SB_CHUNK;
-  int q;
-  const size_t W = (size_t)refill_grid_b_fwd(n, &q) * 2;
-  return 256 + 4 * nchunk + 4 * (W + 1) + 64;
-}
-// bounds for the NEXT single-pass launch over the same n queries; `buf` = slab_bounds_bytes(n) bytes whose first 256 were
-// zeroed once.  Returns the device pointer to the bounds (W + 1 entries) through `bounds_out`.
-hipError_t launch_slab_bounds(const unsigned char* cost, size_t n, void* buf, const uint32_t** bounds_out, hipStream_t s)
-{
-  const uint32_t nchunk = (uint32_t)((n + SB_CHUNK - 1) / SB_CHUNK);
-  int q;
-  const uint32_t W = refill_grid_b_fwd(n, &q) * 2u;
-  uint32_t* counter = static_cast<uint32_t*>(buf);
-  uint32_t* csum = counter + 64;
-  uint32_t* bounds = csum + nchunk;
-  *bounds_out = bounds;
-  uint32_t fix = SB_FIX;
-  if (const char* e = lab_env("TDTK_SB_FIX")) fix = (uint32_t)std::max(0, atoi(e));     // (lab: how strongly the cut follows the visits)
-  hipLaunchKernelGGL(k_slab_bounds, dim3((nchunk * 2u + 1023u) / 1024u), dim3(1024), 0, s, cost, (uint32_t)n, W, nchunk, csum, counter, bounds, fix);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// k_search_step ("if-if"): the same persistent lanes, but the wave does not run two nested loops (all lanes walk
-// nodes until each holds a bucket, then all scan buckets) -- every trip of ONE loop lets each lane take one step of
-// whatever it is doing: visit one internal node, or test the next four points of its bucket.  The nested form makes
-// a lane that reaches its bucket early wait for the slowest node walk of the wave, and a lane with a short bucket
-// wait for the longest one, round after round (2.5 buckets per query): ~63 dependent wave steps per generation of
-// queries where a single query needs ~27.  This kernel is bound by those dependent steps (36 % VALU busy, 4.4 waves
-// per SIMD, insensitive to whether the tree comes from L2 or from the Infinity Cache: tools/l2_probe.py), not by
-// instruction issue, so paying both code paths per trip for fewer trips is the right trade.  Per-lane traversal,
-// visiting order and every comparison are unchanged -> same indices.
-// ------------------------------------------------------------------------------------------
-// VOTE (variant 41): only the path the MAJORITY of the busy lanes needs is issued per trip (lanes of the minority wait
-// one trip), so no trip pays for both paths.
-template <int BLOCK, int SD, int THRESH, bool COUNT, bool VOTE>
-__global__ void __launch_bounds__(BLOCK, 1) k_search_step(const SearchArgs a)
-{
-  __shared__ double lds_m2[SD][BLOCK];
-  __shared__ uint32_t lds_ref[SD][BLOCK];
-
-  const uint32_t nb = gridDim.x;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, nb);
-  const size_t gl = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  const unsigned lane = threadIdx.x & (WAVE - 1);
-  LaneStack<BLOCK, SD> st;
-  st.l_m2 = &lds_m2[0][threadIdx.x];
-  st.l_ref = &lds_ref[0][threadIdx.x];
-  st.g_m2 = a.ovf_m2 ? a.ovf_m2 + gl : nullptr;
-  st.g_ref = a.ovf_ref ? a.ovf_ref + gl : nullptr;
-  st.gstride = (size_t)nb * BLOCK;
-  st.sp = 0;
-
-  const TreeDev& T = a.T;
-  const double4* __restrict__ nodes = reinterpret_cast<const double4*>(T.nodes);
-  const char* __restrict__ pb = reinterpret_cast<const char*>(T.pts);
-
-  const size_t wave_id = (size_t)chunk * (BLOCK / WAVE) + threadIdx.x / WAVE;
-  size_t next_q = wave_id * (size_t)a.qpw;
-  size_t end_q = next_q + (size_t)a.qpw;
-  if (next_q > a.n) next_q = a.n;
-  if (end_q > a.n) end_q = a.n;
-
-  uint32_t cur = REF_DONE;
-  double best = 0.0, qx = 0, qy = 0, qz = 0;
-  int bk = -1;
-  size_t qi = 0;
-  bool have = false;
-  uint32_t o = 1u, olast = 0u;      // bucket progress (byte offsets); o > olast: no bucket open
-  bool fresh = false;               // cur is a bucket whose (o, olast) have not been decoded yet
-  unsigned c_int = 0, c_leaf = 0, c_pts = 0;
-
-  for (;;) {
-    // ---- retire finished queries, hand out new ones ----
-    const bool idle = (cur == REF_DONE);
-    if (idle && have) {
-      a.kpos[qi] = bk;
-      if (a.d2) a.d2[qi] = best;
-      have = false;
-    }
-    const unsigned long long idlem = __ballot(idle);
-    if (next_q < end_q && (idlem == ~0ull || __popcll(idlem) >= THRESH)) {
-      const unsigned rank = (unsigned)__popcll(idlem & ((1ull << lane) - 1ull));
-      const size_t mine = next_q + rank;
-      if (idle && mine < end_q) {
-        // the previous hit (warm start) is requested with the coordinates, not behind them: one round trip less
-        const int kp_prev = a.warm ? a.kpos[mine] : -1;
-        double tx = a.x[mine], ty = a.y[mine], tz = a.z[mine];
-        if (a.has_pending) {  // Scan::transformReduced fused in (scan.cc:851-875)
-          dev_xf3_inplace(a.pending, tx, ty, tz);
-          a.x[mine] = tx; a.y[mine] = ty; a.z[mine] = tz;
-          if (a.nx) {
-            double px = a.nx[mine], py = a.ny[mine], pz = a.nz[mine];
-            dev_xf3normal(a.pending, px, py, pz);
-            a.nx[mine] = px; a.ny[mine] = py; a.nz[mine] = pz;
-          }
-        }
-        qx = tx; qy = ty; qz = tz;
-        if (a.has_inv) dev_xf3(a.inv, tx, ty, tz, qx, qy, qz);  // searchTree.cc:122
-        qi = mine; have = true;
-        cur = T.root_ref; best = warm_radius_kp(a, kp_prev, qx, qy, qz); bk = -1; st.sp = 0;
-        fresh = (cur & REF_LEAF) != 0;
-      }
-      next_q += (size_t)__popcll(idlem);
-    }
-    if (__ballot(cur != REF_DONE) == 0) {
-      if (next_q >= end_q) break;
-      continue;
-    }
-
-    // ---- one step: an internal node ... ----
-    bool do_nodes = true, do_leaves = true;
-    if (VOTE) {
-      const int n_node = __popcll(__ballot(!(cur & REF_LEAF)));
-      const int n_leaf = __popcll(__ballot((cur & REF_LEAF) && cur != REF_DONE));
-      do_nodes = n_node >= n_leaf;
-      do_leaves = !do_nodes;
-    }
-    if (do_nodes && !(cur & REF_LEAF)) {
-      if (COUNT) ++c_int;
-      bool need_pop = false;
-      uint32_t next;
-      const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
-      if (__all(cur == ucur)) {
-        const_d_ptr sn = (const_d_ptr)(T.nodes) + (size_t)ucur * 8;
-        const_u_ptr su = (const_u_ptr)(sn + 7);
-        double s_split = sn[6];
-        uint32_t s_c1 = su[0], s_c2 = su[1];
-        TDTK_PIN_S64(s_split); TDTK_PIN_S32(s_c1); TDTK_PIN_S32(s_c2);
-        next = visit_node<BLOCK, SD>(sn[0], sn[1], sn[2], sn[3], sn[4], sn[5], s_split, s_c1, s_c2, qx, qy, qz,
-                                     best, st, need_pop);
-      } else {
-        const char* np_ = reinterpret_cast<const char*>(nodes) + (uint32_t)(cur << 6);
-        const double4 n0 = *reinterpret_cast<const double4*>(np_);
-        double4 n1 = *reinterpret_cast<const double4*>(np_ + 32);
-        TDTK_PIN_V64(n1.z); TDTK_PIN_V64(n1.w);
-        next = visit_node<BLOCK, SD>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, (uint32_t)__double2loint(n1.w),
-                                     (uint32_t)__double2hiint(n1.w), qx, qy, qz, best, st, need_pop);
-      }
-      if (need_pop) {
-        next = REF_DONE;
-        while (st.sp > 0) {
-          --st.sp;
-          uint32_t r; double m2;
-          st.top(r, m2);
-          if (m2 < best) { next = r; break; }
-        }
-      }
-      cur = next;
-      fresh = (cur & REF_LEAF) != 0 && cur != REF_DONE;
-    } else if (do_leaves && (cur & REF_LEAF) && cur != REF_DONE) {
-      // ---- ... or the next four points of the open bucket ----
-      if (fresh) {
-        const uint32_t v = cur & REF_VAL;
-        int start, count;
-        if (T.leaf_tab) {
-          const LeafEntry le = T.leaf_tab[v];
-          start = le.start; count = le.count;
-        } else {
-          start = (int)(v >> T.cb);
-          count = (int)(v & T.cmask);
-        }
-        if (COUNT) { ++c_leaf; c_pts += (unsigned)count; }
-        o = (uint32_t)start << 5;
-        olast = o + ((uint32_t)(count - 1) << 5);
-        fresh = false;
-      }
-      {
-        const uint32_t o1 = min(o + 32u, olast), o2 = min(o + 64u, olast), o3 = min(o + 96u, olast);
-        const double4 p0 = *reinterpret_cast<const double4*>(pb + o);
-        const double4 p1 = *reinterpret_cast<const double4*>(pb + o1);
-        const double4 p2 = *reinterpret_cast<const double4*>(pb + o2);
-        const double4 p3 = *reinterpret_cast<const double4*>(pb + o3);
-        double dx, dy, dz;
-        dx = p0.x - qx; dy = p0.y - qy; dz = p0.z - qz;
-        const double d0 = dx * dx + dy * dy + dz * dz;
-        dx = p1.x - qx; dy = p1.y - qy; dz = p1.z - qz;
-        const double d1 = dx * dx + dy * dy + dz * dz;
-        dx = p2.x - qx; dy = p2.y - qy; dz = p2.z - qz;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        dx = p3.x - qx; dy = p3.y - qy; dz = p3.z - qz;
-        const double d3 = dx * dx + dy * dy + dz * dz;
-        if (d0 < best) { best = d0; bk = (int)(o >> 5); }
-        if (d1 < best) { best = d1; bk = (int)(o1 >> 5); }
-        if (d2 < best) { best = d2; bk = (int)(o2 >> 5); }
-        if (d3 < best) { best = d3; bk = (int)(o3 >> 5); }
-        o += 128u;
-      }
-      if (o > olast) {   // bucket done: pop the next pending far child that still passes sqr(myd) < closest_d2
-        cur = REF_DONE;
-        while (st.sp > 0) {
-          --st.sp;
-          uint32_t r; double m2;
-          st.top(r, m2);
-          if (m2 < best) { cur = r; break; }
-        }
-        fresh = (cur & REF_LEAF) != 0 && cur != REF_DONE;
-      }
-    }
-  }
-  if (COUNT && a.counters) {
-    const unsigned long long s_int = wave_sum_u(c_int), s_leaf = wave_sum_u(c_leaf), s_pts = wave_sum_u(c_pts);
-    if (lane == 0) {
-      atomicAdd(&a.counters[0], s_int);
-      atomicAdd(&a.counters[1], s_leaf);
-      atomicAdd(&a.counters[2], s_pts);
-    }
-  }
-}
-
-#endif   // TDTK_LAB
+#ifdef TDTK_LAB
+#include "lab_slab_bounds.inc"   // slabs of equal cost (k_slab_bounds) and the one-loop kernel (k_search_step)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // pair-sum accumulation
@@ -3941,30 +2811,7 @@ static int refill_pool_pct(size_t n, int side_by_side)
 }
 bool search_uses_queue(size_t n) { return pick_variant(n) == 30 || (pick_variant(n) == 20 && refill_pool_pct(n, 1) > 0); }
 #ifdef TDTK_LAB
-// two queries per lane (k_search_refill2, TDTK_TWO_PER_LANE=<waves per SIMD: 2 or 3>): one generation of that many waves
-static int two_per_lane()
-{
-  const char* e = lab_env("TDTK_TWO_PER_LANE");
-  const int v = e ? atoi(e) : 0;
-  return (v == 2 || v == 3) ? v : 0;
-}
-static uint32_t refill2_grid(size_t n, int* qpw_out)
-{
-  const size_t slots = (size_t)num_cu() * 4 * (size_t)two_per_lane();
-  size_t qpw = (n + slots - 1) / slots;
-  qpw = (qpw + 31) & ~(size_t)31;
-  if (qpw < 128) qpw = 128;
-  if (qpw > 512) qpw = 512;
-  const size_t waves = (n + qpw - 1) / qpw;
-  size_t nb = (waves + 1) / 2;
-  nb = (nb + 7) & ~(size_t)7;
-  *qpw_out = (int)qpw;
-  return (uint32_t)(nb < 8 ? 8 : nb);
-}
-static bool two_per_lane_for(size_t n, int side_by_side)
-{
-  return two_per_lane() && side_by_side <= 1 && pick_variant(n) == 20 && (n + 511) / 512 <= (size_t)num_cu() * 4 * (size_t)two_per_lane();
-}
+#include "lab_part_2.inc"
 #endif
 uint32_t search_fused_rows(size_t n, int side_by_side)
 {
@@ -4042,41 +2889,10 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
   }
 #endif
 #ifdef TDTK_LAB
-  if constexpr (FUSE == 0 || FUSE == 3) {
-    if (!a.bounds && refill_single64(a.n, a.side_by_side)) {
-      const uint32_t nb64 = refill_grid_b(a.n, 64, &qpw, a.side_by_side);
-      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
-      hipLaunchKernelGGL((k_search_refill<64, 4, 16, 4, COUNT, FUSE, false>), dim3(nb64), dim3(64), 0, s, a);
-      return;
-    }
-  }
-  if constexpr (FUSE == 0 || FUSE == 3) {
-    if (const int sb = a.bounds ? 0 : refill_share_block(a.n, a.side_by_side)) {
-      const uint32_t nbs = refill_grid_b(a.n, sb, &qpw, a.side_by_side);
-      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
-      if (sb == 1024) hipLaunchKernelGGL((k_search_refill<1024, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0, true>), dim3(nbs), dim3(1024), 0, s, a);
-      else if (sb == 512) hipLaunchKernelGGL((k_search_refill<512, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0, true>), dim3(nbs), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((k_search_refill<256, 4, 16, 4, COUNT, FUSE, false, 4, 0, false, 0, true>), dim3(nbs), dim3(256), 0, s, a);
-      return;
-    }
-  }
+#include "lab_part_3.inc"
 #endif
 #ifdef TDTK_LAB
-  if constexpr (FUSE == 0 || FUSE == 3) {
-    if (two_per_lane_for(a.n, a.side_by_side) && !a.bounds && !a.skip) {
-      const uint32_t nb2 = refill2_grid(a.n, &qpw);
-      a.qpw = qpw; a.phases = 1; a.pool_slab = 0; a.region = 0; a.trace = 0;
-      const char* e1 = lab_env("TDTK_TWO_ONE");
-      const bool one = e1 && e1[0] == '1';
-      if (one) {
-        if (two_per_lane() == 3) hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 3, true>), dim3(nb2), dim3(128), 0, s, a);
-        else hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 2, true>), dim3(nb2), dim3(128), 0, s, a);
-      } else
-      if (two_per_lane() == 3) hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 3>), dim3(nb2), dim3(128), 0, s, a);
-      else hipLaunchKernelGGL((k_search_refill2<128, 4, 16, COUNT, FUSE, 2>), dim3(nb2), dim3(128), 0, s, a);
-      return;
-    }
-  }
+#include "lab_part_4.inc"
 #endif
   const uint32_t nb = refill_grid_b(a.n, 128, &qpw, a.side_by_side);
   a.qpw = qpw;
@@ -4166,52 +2982,7 @@ static void launch_refill128(SearchArgs& a, hipStream_t s)
 }
 
 #ifdef TDTK_LAB
-// work-queue kernel: as many waves as stay resident (TDTK_STREAM_WPS per SIMD, default 7 = what the registers allow),
-// never more waves than there are slabs to draw
-static int stream_slab_env()
-{
-  const char* e = lab_env("TDTK_STREAM_SLAB");
-  int v = e ? atoi(e) : 256;
-  if (v < 16) v = 16;
-  return v;
-}
-static uint32_t stream_grid(size_t n)
-{
-  const char* e = lab_env("TDTK_STREAM_WPS");
-  int wps = e ? atoi(e) : 4;
-  if (wps < 1) wps = 1;
-  if (wps > 8) wps = 8;
-  size_t waves = (size_t)num_cu() * 4 * (size_t)wps;
-  const size_t slabs = (n + (size_t)stream_slab_env() - 1) / (size_t)stream_slab_env();
-  if (waves > slabs) waves = slabs;
-  size_t nb = (waves + 1) / 2;          // 128-thread workgroups
-  return (uint32_t)(nb ? nb : 1);
-}
-template <bool COUNT>
-static void launch_stream128(SearchArgs& a, hipStream_t s)
-{
-  a.slab = stream_slab_env();
-  const uint32_t nb = stream_grid(a.n);
-  switch (refill_thresh(a.n)) {
-    case 8: hipLaunchKernelGGL((k_search_refill<128, 4, 8, 1, COUNT, 0, true>), dim3(nb), dim3(128), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_search_refill<128, 4, 32, 1, COUNT, 0, true>), dim3(nb), dim3(128), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_search_refill<128, 4, 16, 1, COUNT, 0, true>), dim3(nb), dim3(128), 0, s, a); break;
-  }
-}
-
-template <bool COUNT, bool VOTE>
-static void launch_step128(SearchArgs& a, hipStream_t s)
-{
-  int qpw;
-  const uint32_t nb = refill_grid_b(a.n, 128, &qpw);
-  a.qpw = qpw;
-  switch (refill_thresh(a.n)) {
-    case 8: hipLaunchKernelGGL((k_search_step<128, 4, 8, COUNT, VOTE>), dim3(nb), dim3(128), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_search_step<128, 4, 32, COUNT, VOTE>), dim3(nb), dim3(128), 0, s, a); break;
-    default: hipLaunchKernelGGL((k_search_step<128, 4, 16, COUNT, VOTE>), dim3(nb), dim3(128), 0, s, a); break;
-  }
-}
-
+#include "lab_part_5.inc"
 #endif   // TDTK_LAB
 
 // a.fuse != 0 (only where search_can_fuse(a.n)): the base pair sums come out of the search itself, one row of
@@ -4260,21 +3031,7 @@ hipError_t launch_search(const SearchArgs& a_in, uint32_t grid, int dirmode, boo
     }
     switch (v) {
 #ifdef TDTK_LAB
-      case 0: hipLaunchKernelGGL((k_search<SEARCH_BLOCK, 8, false, 0, false, 1>), g, b, 0, s, a); break;
-      case 8: {
-        int qpw;
-        const uint32_t nb = refill_grid_b(a.n, SEARCH_BLOCK, &qpw);
-        a.qpw = qpw;
-        a.phases = 1;
-        hipLaunchKernelGGL((k_search_refill<SEARCH_BLOCK, 4, 16, 1, false, 0, false>), dim3(nb), b, 0, s, a);
-        break;
-      }
-      case 30: launch_stream128<false>(a, s); break;
-      case 40: launch_step128<false, false>(a, s); break;
-      case 41: launch_step128<false, true>(a, s); break;
-      case 5: hipLaunchKernelGGL((k_search_coop<SEARCH_BLOCK, 4, 1>), g, b, 0, s, a); break;
-      case 9: hipLaunchKernelGGL((k_search_g8<256, 16>), dim3(g8_grid(a.n)), dim3(256), 0, s, a); break;
-      case 11: hipLaunchKernelGGL((k_search_g8<256, 16, 16>), dim3(g8_grid(a.n) * 2), dim3(256), 0, s, a); break;
+#include "lab_part_6.inc"
 #endif
       case 20:
         if (a.fuse == 3) launch_refill128<false, 3>(a, s);
@@ -4385,33 +3142,7 @@ __global__ void __launch_bounds__(256) k_make_hot(const KdNode* __restrict__ nod
   if (split) split[i] = make_double2(nd.splitval, __hiloint2double((int)nd.c2, (int)nd.c1));     // { splitval, c1 | c2 << 32 }
 }
 #ifdef TDTK_LAB   // two tree levels per record: a measured negative (see the FAT walk in search_refill_body)
-__global__ void __launch_bounds__(256) k_make_fat(const KdNode* __restrict__ nodes, size_t n, KdFat* __restrict__ fat)
-{
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const KdNode nd = nodes[i];
-  KdFat f;
-  memset(&f, 0, sizeof f);
-  f.cx = (float)nd.cx; f.cy = (float)nd.cy; f.cz = (float)nd.cz; f.hx = (float)nd.hx; f.hy = (float)nd.hy; f.hz = (float)nd.hz;
-  f.c1 = nd.c1; f.c2 = nd.c2; f.splitval = nd.splitval;
-  if (!(nd.c1 & REF_LEAF)) {
-    const KdNode a = nodes[nd.c1 & REF_VAL];
-    f.a_cx = (float)a.cx; f.a_cy = (float)a.cy; f.a_cz = (float)a.cz; f.a_hx = (float)a.hx; f.a_hy = (float)a.hy; f.a_hz = (float)a.hz;
-    f.a_split = a.splitval; f.a_c1 = a.c1; f.a_c2 = a.c2;
-  }
-  if (!(nd.c2 & REF_LEAF)) {
-    const KdNode b = nodes[nd.c2 & REF_VAL];
-    f.b_cx = (float)b.cx; f.b_cy = (float)b.cy; f.b_cz = (float)b.cz; f.b_hx = (float)b.hx; f.b_hy = (float)b.hy; f.b_hz = (float)b.hz;
-    f.b_split = b.splitval; f.b_c1 = b.c1; f.b_c2 = b.c2;
-  }
-  fat[i] = f;
-}
-hipError_t launch_make_fat(const KdNode* nodes, size_t n, KdFat* fat, hipStream_t s)
-{
-  if (!n) return hipSuccess;
-  hipLaunchKernelGGL(k_make_fat, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, nodes, n, fat);
-  return hipGetLastError();
-}
+#include "lab_part_7.inc"
 #endif   // TDTK_LAB
 hipError_t launch_make_hot(const KdNode* nodes, size_t n, KdHot* hot, hipStream_t s, double2* split)
 {
