@@ -879,6 +879,47 @@ def test_graph_netfile_chain_addlink(tdtk, tmp_path):
         assert b.max_dist_match2_LUM == 100.0
 
 
+def test_bench_line_is_compact_strict_json_with_roofline_and_cpu_baseline():
+    """Round 6: round 5's 21.7 KB bench line did not parse in the driver.  bench.build_line makes the ONE
+    stdout line from a full result dict -- here the record of a real run (tests/golden/bench_result_canned.json =
+    bench_legs.json of `python bench.py --gpus 1 --steps 20 --warmup 5` on an MI355X): under 6 KB, strict JSON (no NaN /
+    Infinity), the contract's keys, `roofline` with frac / achieved / peak / traffic / bytes_per_query / the reference's
+    visit counts, `cpu_baseline` with value / cores / kind -- and a line that would not fit raises instead of printing."""
+    import bench
+    res = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_result_canned.json")))
+    line = bench.build_line(res)
+    assert "\n" not in line and len(line) < 6144 and len(line) < bench.LINE_MAX
+
+    def no_constants(c):
+        raise ValueError("not strict JSON: " + c)
+    d = json.loads(line, parse_constant=no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"]
+    # achieved = SURVEY 8(d)'s bytes per query (the reference's walk) x queries per launch / the kernel's duration
+    bq = bench.algorithmic_bytes_per_query(r["visits_per_query"]["internal"], r["visits_per_query"]["points"])
+    assert abs(bq - r["bytes_per_query"]) < 1e-3 * bq
+    assert abs(r["achieved"] - bq * d["config"]["points"] / (r["kernel_ms"] * 1e-3) / 1e9) < 2e-3 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"]
+    assert r["visits_walked"]["bytes_ratio"] > 1.0          # the kernel's own (deferred-check) walk visits more than the reference's
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["unit"] == d["unit"]
+    assert d["value"] == res["value"] and d["ms_per_step"] == res["ms_per_step"]       # the contract's numbers are not rounded
+    # a NaN among the contract's numbers raises; among the secondary fields it becomes null (still strict JSON); a line that
+    # outgrows the limit raises
+    with pytest.raises(ValueError):
+        bench.build_line(dict(res, value=float("nan")))
+    assert json.loads(bench.build_line(dict(res, rms_last=float("nan"))), parse_constant=no_constants)["rms_last"] is None
+    fat = dict(res, config=dict(res["config"], workload="x" * 7000))
+    with pytest.raises(RuntimeError):
+        bench.build_line(fat)
+
+
 def test_product_and_bench_keep_clear_of_the_oracle():
     """oracle/ is test infrastructure: nothing under 3dtk_amd/, include/ or adapters/ may mention it, the shared
     library must not link it, and bench.py may import it only inside its cpu_baseline legs."""
