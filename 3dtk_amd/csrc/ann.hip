@@ -350,8 +350,14 @@ template <int PASS>
 __global__ void k_ann_misplaced(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
                                 const ADec* __restrict__ dec, const unsigned long long* __restrict__ cnt,
                                 const double* __restrict__ cx, const double* __restrict__ cy,
-                                const double* __restrict__ cz, uint32_t M, unsigned long long* __restrict__ LR)
+                                const double* __restrict__ cz, uint32_t M, unsigned long long* __restrict__ LR,
+                                uint32_t* __restrict__ eq_flag)
 {
+  // The second Hoare pass (annPlaneSplit's: what lies ON the cutting plane to the front of the right part) has work only where
+  // a cell has points on its plane -- a slide onto a point, or coordinates that repeat.  Pass 1 raises the level's flag if any
+  // cell has such points; pass 2 and the scan, list and swap kernels behind it return at once when it is down (round 6: on a
+  // cloud without repeated coordinates that is four of a level's eleven passes over the points).
+  if (PASS == 2 && eq_flag != nullptr && *eq_flag == 0u) return;
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > M) return;
   uint32_t l = 0, r = 0;
@@ -360,6 +366,7 @@ __global__ void k_ann_misplaced(const uint32_t* __restrict__ seg_of, const ASeg*
     if (sg != NOSEG) {
       const uint32_t rel = p - segs[sg].start;
       const unsigned long long cn = cnt[sg];
+      if (PASS == 1 && eq_flag != nullptr && (uint32_t)(cn >> 32) != 0u) *eq_flag = 1u;
       const uint32_t br1 = (uint32_t)cn, br2 = br1 + (uint32_t)(cn >> 32);
       const double c = coord_of(cx, cy, cz, dec[sg].cd, p), cv = dec[sg].cv;
       if (PASS == 1) {
@@ -379,8 +386,9 @@ __global__ void k_ann_misplaced(const uint32_t* __restrict__ seg_of, const ASeg*
 // k-th misplaced from the left pairs with the k-th misplaced from the right END of the cell
 __global__ void k_ann_swaplist(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
                                const unsigned long long* __restrict__ LR, const unsigned long long* __restrict__ AB,
-                               uint32_t M, uint32_t* __restrict__ posL, uint32_t* __restrict__ posR)
+                               uint32_t M, uint32_t* __restrict__ posL, uint32_t* __restrict__ posR, const uint32_t* __restrict__ gate)
 {
+  if (gate != nullptr && *gate == 0u) return;        // (a second pass with nothing to do: see k_ann_misplaced)
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   const unsigned long long lr = LR[p];
@@ -396,8 +404,9 @@ __global__ void k_ann_swaplist(const uint32_t* __restrict__ seg_of, const ASeg* 
 }
 __global__ void k_ann_swap(const uint32_t* __restrict__ posL, const uint32_t* __restrict__ posR,
                            const unsigned long long* __restrict__ nswap_ptr, uint32_t* __restrict__ perm,
-                           double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz)
+                           double* __restrict__ cx, double* __restrict__ cy, double* __restrict__ cz, const uint32_t* __restrict__ gate)
 {
+  if (gate != nullptr && *gate == 0u) return;
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= (uint32_t)*nswap_ptr) return;
   const uint32_t a = posL[c], b = posR[c];
@@ -944,7 +953,7 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(scan_tmp + 256); take(256);                                           // 18 tmp 19 small
   take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
   take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
-  take(4 * (ANN_MAX_LEVELS + 2));                                            // 23 cells per level
+  take(8 * (ANN_MAX_LEVELS + 2));                                            // 23 cells per level; behind them the levels' "points on a plane" flags
   take(scan_pair27_state_bytes(n1));                                         // 24 state of the one-launch scan (sort.hip)
   take(sizeof(ASeg) * nlarge);                                               // 25 mid cells (k_ann_mid)
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
@@ -993,7 +1002,8 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   // the round-2 form)
   static const uint32_t mid_cap = [] { const char* e = getenv("TDTK_ANN_MID"); return (e && e[0] == '0') ? ANN_SMALL : ANN_MID; }();
   ACHK(hipMemsetAsync(small, 0, 256, s));
-  ACHK(hipMemsetAsync(lvl, 0, 4 * (ANN_MAX_LEVELS + 2), s));
+  ACHK(hipMemsetAsync(lvl, 0, 8 * (ANN_MAX_LEVELS + 2), s));
+  uint32_t* const eqf = lvl + (ANN_MAX_LEVELS + 2);
   // the partition's scans in one launch each while the positions fit their 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
   static const bool own_scan_env = [] { const char* e = getenv("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
   const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
@@ -1017,18 +1027,23 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
       hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
       // the library's first Hoare pass, then its second one on what lies right of br1
       for (int pass = 1; pass <= 2; pass++) {
+        // (the gate needs every kernel of the pass to honour it: with rocPRIM's scan, which does not, the pass runs ungated)
+        const bool one_launch = own_scan && 2u * level + (uint32_t)pass < 255u;
+        uint32_t* const flag = one_launch ? eqf + level : nullptr;
+        const uint32_t* const gate = (pass == 2) ? flag : nullptr;
         if (pass == 1)
-          hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
+          hipLaunchKernelGGL(k_ann_misplaced<1>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR,
+                             (own_scan && 2u * level + 2u < 255u) ? eqf + level : (uint32_t*)nullptr);
         else
-          hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR);
-        if (own_scan && 2u * level + (uint32_t)pass < 255u) {
-          ACHK(launch_scan_pair27(LR, AB, n1, arena + O[24], 2u * level + (uint32_t)pass, small + 2, s));
+          hipLaunchKernelGGL(k_ann_misplaced<2>, dim3(cdiv(n1, 256)), dim3(256), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, LR, flag);
+        if (one_launch) {
+          ACHK(launch_scan_pair27(LR, AB, n1, arena + O[24], 2u * level + (uint32_t)pass, small + 2, s, gate));
         } else {
           size_t st = scan_tmp;
           ACHK(rocprim::exclusive_scan(tmp, st, LR, AB, 0ull, n1, rocprim::plus<unsigned long long>(), s));
         }
-        hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR);
-        hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz);
+        hipLaunchKernelGGL(k_ann_swaplist, dim3(cdiv(M, 256)), dim3(256), 0, s, seg_of, segs, LR, AB, M, posL, posR, gate);
+        hipLaunchKernelGGL(k_ann_swap, dim3(cdiv((size_t)M / 2 + 1, 256)), dim3(256), 0, s, posL, posR, AB + M, perm, cx, cy, cz, gate);
       }
       hipLaunchKernelGGL(k_ann_children, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, dec, cnt, nodes, next,
                          small_list, small, meas_next, cnt_next, mid_list, mid_cap);

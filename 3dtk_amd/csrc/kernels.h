@@ -288,7 +288,7 @@ hipError_t launch_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* tm
 // exclusive scan of 64-bit words that hold two 27-bit counts, in ONE launch (sort.hip); see there for `state` / `epoch`
 size_t scan_pair27_state_bytes(size_t n);
 hipError_t launch_scan_pair27(const unsigned long long* in, unsigned long long* out, size_t n, void* state, uint32_t epoch,
-                              uint32_t* err, hipStream_t s);
+                              uint32_t* err, hipStream_t s, const uint32_t* gate = nullptr);   // gate: non-null and *gate == 0 -> nothing runs
 
 size_t morton_sort_temp_bytes(size_t n);
 hipError_t launch_morton_order(const double* d_xyz, size_t n, const double* d_box, uint32_t* keys_a, uint32_t* idx_a, uint32_t* keys_b, uint32_t* idx_b, void* d_tmp,

@@ -100,8 +100,12 @@ __device__ __forceinline__ unsigned long long sp_wave_incl(unsigned long long v,
 }
 __global__ void __launch_bounds__(256) k_scan_pair27(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                                      uint32_t n, unsigned long long* __restrict__ status, uint32_t* __restrict__ counter,
-                                                     uint32_t epoch, uint32_t ntiles, uint32_t* __restrict__ err)
+                                                     uint32_t epoch, uint32_t ntiles, uint32_t* __restrict__ err,
+                                                     const uint32_t* __restrict__ gate)
 {
+  // (a caller's "nothing to scan" word: every workgroup leaves before it draws a tile number, the counter and the epochs stay
+  //  as they are -- a skipped epoch is simply never seen)
+  if (gate != nullptr && *gate == 0u) return;
   __shared__ uint32_t s_tile;
   __shared__ unsigned long long s_wave[256 / WAVE], s_excl;
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
@@ -180,13 +184,13 @@ size_t scan_pair27_state_bytes(size_t n) { return 8 * ((n + SP_TILE - 1) / SP_TI
 // n < 2^27 and every count < 2^27 (the callers scan 0/1 flags over at most n positions); err: bit 16 is set if a tile gave up
 // waiting for its predecessors (a stalled tile under a debugger / preemption; never seen) -- the offsets are wrong then
 hipError_t launch_scan_pair27(const unsigned long long* in, unsigned long long* out, size_t n, void* state, uint32_t epoch,
-                              uint32_t* err, hipStream_t s)
+                              uint32_t* err, hipStream_t s, const uint32_t* gate)
 {
   if (!n) return hipSuccess;
   const uint32_t ntiles = (uint32_t)((n + SP_TILE - 1) / SP_TILE);
   unsigned long long* status = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(state) + 64);
   uint32_t* counter = reinterpret_cast<uint32_t*>(state);
-  hipLaunchKernelGGL(k_scan_pair27, dim3(ntiles), dim3(256), 0, s, in, out, (uint32_t)n, status, counter, epoch, ntiles, err);
+  hipLaunchKernelGGL(k_scan_pair27, dim3(ntiles), dim3(256), 0, s, in, out, (uint32_t)n, status, counter, epoch, ntiles, err, gate);
   return hipGetLastError();
 }
 
