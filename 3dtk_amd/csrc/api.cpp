@@ -124,8 +124,8 @@ struct Ctx {
   hipEvent_t e4 = nullptr, e5 = nullptr;   // around k_ann_normals of the last calcNormals
   hipEvent_t e_user = nullptr;             // fence between a caller's stream and this context's stream
   hipEvent_t e_defer = nullptr;            // behind the last batch of scan moves that was left running (defer_fence)
-  hipStream_t stream_b = nullptr, stream_c = nullptr;   // the tree build's background chains (exact centroid sums beside the levels below)
-  hipEvent_t e_b1 = nullptr, e_b2 = nullptr, e_b3 = nullptr;
+  hipStream_t stream_b = nullptr, stream_c = nullptr, stream_d = nullptr;   // the tree build's background chains (exact centroid sums beside the levels below)
+  hipEvent_t e_b1 = nullptr, e_b2 = nullptr, e_b3 = nullptr, e_b4 = nullptr;
   DevBuf ws[WS_COUNT];
   double* h_pin = nullptr;  // pinned staging for the per-iteration sums: words [0, ACC_TOTAL); behind them two slots of the tree build
   // (both are filled by copies enqueued on `stream` and read only behind a synchronisation of that stream that was made after
@@ -217,8 +217,10 @@ Ctx::~Ctx()
     if (e_b1) (void)hipEventDestroy(e_b1);
     if (e_b2) (void)hipEventDestroy(e_b2);
     if (e_b3) (void)hipEventDestroy(e_b3);
+    if (e_b4) (void)hipEventDestroy(e_b4);
     if (stream_b) (void)hipStreamDestroy(stream_b);
     if (stream_c) (void)hipStreamDestroy(stream_c);
+    if (stream_d) (void)hipStreamDestroy(stream_d);
     if (h_pin) (void)hipHostFree(h_pin);
     if (h_loop) (void)hipHostFree(h_loop);     // (lab)
     if (h_build) (void)hipHostFree(h_build);
@@ -569,11 +571,15 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
     // the worker threads of a prefetch pool never build alone
     HIPCHK(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream_d, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->e_b1, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_b2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_b3, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_b4, hipEventDisableTiming));
   }
-  const BuildSide side = {alone ? c->stream_b : nullptr, alone ? c->stream_c : nullptr, c->e_b1, c->e_b2, c->e_b3, c->h_build};
+  static const bool four = [] { const char* e = lab_env("TDTK_BUILD_STREAMS"); return !(e && e[0] == '3'); }();   // (lab: TDTK_BUILD_STREAMS=3: round 5's two side streams)
+  const BuildSide side = {alone ? c->stream_b : nullptr, alone ? c->stream_c : nullptr, c->e_b1, c->e_b2, c->e_b3, c->h_build,
+                          (alone && four) ? c->stream_d : nullptr, c->e_b4};
   DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, &side);
   if (r.respeculated) g_respeculated.fetch_add(1);
   if (r.err != hipSuccess) {

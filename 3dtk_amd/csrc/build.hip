@@ -17,6 +17,7 @@
 //     ALL nodes of the level at once.
 //
 // One small D2H (the number of internal nodes of the level) per level is the only host sync.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -378,10 +379,27 @@ __global__ void __launch_bounds__(256) k_measure_node(const BSeg* __restrict__ s
 #define BIG_MIN_SMALL 2048u    // ... in a small cloud (that chain is on its critical path: 46 + 26 us of a 15K-point build); never below
                                // BIG_PB: a block of the partial sums holds the tail of one big node and the head of one other
 // which of the two a build of M points uses (every kernel of the piecewise path gets it as `big_min`)
+// A level takes the piecewise path while a balanced node of it holds at least build_big_level_min(M) points.  Up to a
+// million points that is half the node threshold (round 3).  Beyond, the path's passes over ALL points (k_big_stats, two
+// scans, k_big_emulate: 0.6-1.3 ms per level at 10M, in order from the ninth level on) cost more than the chains they
+// replace -- 4.2 ns per point of the longest node: 160 us for 39K points -- so the threshold grows with the cloud
+// (M / 200: never more than the eight top levels, which are the speculated ones), and the node threshold with it.
+#define BIG_LEVEL_MAX 49152u
+static uint32_t build_big_level_min(size_t M)
+{
+  static const bool grow_env = [] { const char* e = lab_env("TDTK_BUILD_BIGGROW"); return !(e && e[0] == '0'); }();
+  static const bool small_env = [] { const char* e = lab_env("TDTK_BUILD_BIGMIN"); return !(e && e[0] == '0'); }();
+  if (small_env && M <= (size_t)BIG_MIN_SMALL * 16u) return BIG_MIN_SMALL / 2u;
+  if (!grow_env) return BIG_MIN / 2u;
+  const size_t t = M / 200u;
+  return (uint32_t)(t < BIG_MIN / 2u ? BIG_MIN / 2u : (t > BIG_LEVEL_MAX ? BIG_LEVEL_MAX : t));
+}
 static uint32_t build_big_min(size_t M)
 {
   static const bool small_env = [] { const char* e = lab_env("TDTK_BUILD_BIGMIN"); return !(e && e[0] == '0'); }();
-  return (small_env && M <= (size_t)BIG_MIN_SMALL * 16u) ? BIG_MIN_SMALL : BIG_MIN;   // (15K points 572 -> 545 us; 40K equal; 81K 710 -> 772: the side streams' chains then outlast the levels)
+  if (small_env && M <= (size_t)BIG_MIN_SMALL * 16u) return BIG_MIN_SMALL;   // (15K points 572 -> 545 us; 40K equal; 81K 710 -> 772: the side streams' chains then outlast the levels)
+  const uint32_t t = build_big_level_min(M) / 3u * 2u;
+  return t > BIG_MIN ? t : BIG_MIN;
 }
 #define BIG_ANY 0xFFFFu        // BSum.eb of the neutral element
 #define BIG_BAD 0xFFFEu        // BSum.eb of a run whose pieces disagree about the binade: never applicable
@@ -1421,6 +1439,228 @@ __global__ void k_swap_relabel(const uint32_t* __restrict__ posL, const uint32_t
   else relabel_at(segs, kind, irank, nleft, M, seg_of, (blockIdx.x - nb_first) * blockDim.x + threadIdx.x);
 }
 
+// ---- the partition of a level in TWO passes over the points (round 6) ------------------------------------------------
+// The five passes above (count, misplaced flags, scan, swap list, swap + relabel) read and write a level's points
+// five times; from a million points on those passes -- not their launches -- are what a level costs.  What the Hoare
+// loop of kdTreeImpl.h:172-182 leaves behind needs less.  Call an element "ge" when it is not below the split value.
+// Within a node [s, s + n) with nleft elements below the split value, the k-th misplaced element from the left is the
+// k-th ge element of the node (every ge element in front of it lies in the left region too), and the k-th misplaced
+// element from the right end is the k-th element below the split value counted from the right end.  So ONE segmented
+// scan of the ge flags (geBefore(p) = ge elements of p's node in front of p) places every element in an index list
+// per node -- ge elements from the front in order, the others from the back in order:
+//     list[s + geBefore(p)] = p                        p is ge
+//     list[s + n - 1 - ((p - s) - geBefore(p))] = p    p is below the split value
+// and the node's last element knows nleft = n - (ge elements of the node).  Pass 1 (k_part_scan) is that scan with
+// the flags computed on the fly (label -> node -> coordinate), decoupled look-back over tiles of PS_TILE positions
+// whose status word carries flag, epoch, "a node starts in this tile" and the count since that start (27 bits) -- a
+// segmented look-back ends at the first predecessor in which a node starts.  Pass 2 (k_part_swap): slot j of node
+// (s, n, nleft) with j < n - nleft holds a = list[s + j], the j-th ge element; it is misplaced iff a < s + nleft, and
+// its partner is list[s + (n - nleft) + j] -- both reads coalesced; the same thread gives position s + j its label
+// of the next level.  12 + 4 bytes read and 4 written per point in pass 1, 8 + 4 in pass 2 plus the swaps themselves.
+#define PS_ROWS 8u
+#define PS_THREADS 512u
+#define PS_TILE (PS_THREADS * PS_ROWS)
+__device__ __forceinline__ unsigned long long ps_pack(uint32_t cnt, uint32_t seen, uint32_t flag, uint32_t epoch)
+{
+  return ((unsigned long long)flag << 62) | ((unsigned long long)epoch << 54) | ((unsigned long long)seen << 53) | (unsigned long long)(cnt & 0x7FFFFFFu);
+}
+size_t part_state_bytes(size_t n) { return 8 * ((n + PS_TILE - 1) / PS_TILE + 1) + 64; }
+__global__ void __launch_bounds__(PS_THREADS) k_part_scan(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
+                                                   const BSeg* __restrict__ segs, const uint32_t* __restrict__ axis,
+                                                   const double* __restrict__ splitval, const double* __restrict__ cx,
+                                                   const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M,
+                                                   uint32_t* __restrict__ nleft, uint32_t* __restrict__ list,
+                                                   unsigned long long* __restrict__ status, uint32_t* __restrict__ counter,
+                                                   uint32_t epoch, uint32_t ntiles, uint32_t* __restrict__ err)
+{
+  __shared__ uint32_t s_tile, s_wcnt[PS_THREADS / WAVE], s_wseen[PS_THREADS / WAVE], s_in;
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  if (tid == 0) {
+    const uint32_t t = atomicAdd(counter, 1u);           // tiles numbered in the order their workgroups start: a tile
+    if (t == ntiles - 1u) atomicExch(counter, 0u);       // only ever waits for tiles that are running
+    s_tile = t;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t wbase = tile * PS_TILE + wv * (WAVE * PS_ROWS) + lane;   // row r of this wave: wbase + 64 r
+  uint32_t sg[PS_ROWS], geb[PS_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < PS_ROWS; r++) { const uint32_t p = wbase + r * WAVE; sg[r] = (p < M) ? seg_of[p] : 0xFFFFFFFFu; }
+#pragma unroll
+  for (uint32_t r = 0; r < PS_ROWS; r++)
+    if (sg[r] != 0xFFFFFFFFu && !kind[sg[r]]) sg[r] = 0xFFFFFFFFu;
+  // the flags of every row (is not below the split value; is its node's first element) as bit r of two words: the
+  // loads of all rows are in flight together, nothing of them stays in registers
+  uint32_t gebits = 0u, headbits = 0u;
+  {
+    uint32_t axs[PS_ROWS], st[PS_ROWS];
+    double c[PS_ROWS], sv[PS_ROWS];
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROWS; r++) {
+      axs[r] = 0u; sv[r] = 0.0; st[r] = 0xFFFFFFFFu;
+      if (sg[r] != 0xFFFFFFFFu) { axs[r] = axis[sg[r]]; sv[r] = splitval[sg[r]]; st[r] = segs[sg[r]].start; }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROWS; r++) {
+      const uint32_t p = wbase + r * WAVE;
+      c[r] = 0.0;
+      if (sg[r] != 0xFFFFFFFFu) c[r] = (axs[r] == 0u) ? cx[p] : ((axs[r] == 1u) ? cy[p] : cz[p]);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROWS; r++) {
+      if (sg[r] != 0xFFFFFFFFu && !(c[r] < sv[r])) gebits |= 1u << r;
+      if (wbase + r * WAVE == st[r]) headbits |= 1u << r;
+    }
+  }
+  // the wave's rows in order: ballots, and a count carried from row to row (wave-uniform)
+  const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+  uint32_t carry = 0u, seen = 0u, ext = 0u;
+#pragma unroll
+  for (uint32_t r = 0; r < PS_ROWS; r++) {
+    const unsigned long long gm = __ballot((gebits >> r) & 1u), hm = __ballot((headbits >> r) & 1u);
+    const unsigned long long hb = hm & le_mask;
+    if (hb) {
+      const int hl = 63 - __clzll((long long)hb);
+      geb[r] = (uint32_t)__popcll(gm & lt_mask & ~((1ull << hl) - 1ull));
+    } else {
+      geb[r] = carry + (uint32_t)__popcll(gm & lt_mask);
+      if (!seen) ext |= 1u << r;                          // the node started in front of this wave: + what comes in
+    }
+    if (hm) { const int hl = 63 - __clzll((long long)hm); carry = (uint32_t)__popcll(gm >> hl); seen = 1u; }
+    else carry += (uint32_t)__popcll(gm);
+  }
+  if (lane == 0) { s_wcnt[wv] = carry; s_wseen[wv] = seen; }
+  __syncthreads();
+  if (wv == 0) {
+    // the tile's aggregate: the count since the last node start in it (or all of it), and whether there was one
+    uint32_t tcnt = 0u, tseen = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < PS_THREADS / WAVE; w++) { if (s_wseen[w]) { tcnt = s_wcnt[w]; tseen = 1u; } else tcnt += s_wcnt[w]; }
+    uint32_t incoming = 0u;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&status[0], ps_pack(tcnt, 1u, 2u, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&status[tile], ps_pack(tcnt, tseen, tseen ? 2u : 1u, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int pos = (int)tile - 1;
+      uint32_t spins = 0;
+      for (;;) {
+        const int idx = pos - (int)lane;
+        const unsigned long long w = (idx >= 0) ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                : ps_pack(0u, 1u, 2u, epoch);      // in front of the first tile: nothing
+        const bool valid = ((uint32_t)(w >> 54) & 0xFFu) == epoch && (w >> 62) != 0ull;
+        // the nearest predecessor that is final (its count since a node start is known, or a node starts in it) ends
+        // the look-back; everything nearer must have its aggregate out
+        const unsigned long long pm = __ballot(valid && (w >> 62) == 2ull);
+        const unsigned long long vm = __ballot(valid);
+        const int p = pm ? (__ffsll((long long)pm) - 1) : 64;
+        const unsigned long long need = (p >= 64) ? ~0ull : ((2ull << p) - 1ull);
+        if ((vm & need) != need) {
+          if (++spins > (1u << 22)) { if (lane == 0) atomicOr(err, 0x10000u); break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        uint32_t part = ((int)lane <= p) ? (uint32_t)(w & 0x7FFFFFFull) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, WAVE);
+        incoming += part;
+        if (p < 64) break;
+        pos -= WAVE;
+      }
+      // a tile in which no node starts is final only now: the count at its end since the node start in front of it
+      if (lane == 0 && !tseen) __hip_atomic_store(&status[tile], ps_pack(incoming + tcnt, 0u, 2u, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_in = incoming;
+  }
+  __syncthreads();
+  // what comes into this wave: the waves in front of it back to a node start, the tile's incoming count behind them
+  uint32_t win = 0u;
+  {
+    bool open = true;
+    for (int w = (int)wv - 1; w >= 0 && open; w--) { win += s_wcnt[w]; if (s_wseen[w]) open = false; }
+    if (open) win += s_in;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < PS_ROWS; r++) {
+    if (sg[r] == 0xFFFFFFFFu) continue;
+    const uint32_t p = wbase + r * WAVE;
+    const uint32_t g = geb[r] + (((ext >> r) & 1u) ? win : 0u);
+    const BSeg q = segs[sg[r]];                            // (a second look: cached, and two registers per row less)
+    const uint32_t j = p - q.start;
+    const bool ge = (gebits >> r) & 1u;
+    const uint32_t dst = ge ? (q.start + g) : (q.start + q.n - 1u - (j - g));
+    list[dst] = p;
+    if (j == q.n - 1u) nleft[sg[r]] = q.n - (g + (ge ? 1u : 0u));
+  }
+}
+// pass 2: the swaps (driven from the list's ge half) and the labels of the next level; behind them, in the same launch,
+// the children of the level's internal nodes (and what the final check keeps of a speculated level)
+#define PW_ROWS 4u
+__device__ __forceinline__ void part_swap_at(const uint32_t* __restrict__ list, const BSeg* __restrict__ segs,
+                                             const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
+                                             const uint32_t* __restrict__ nleft, uint32_t M, uint32_t* __restrict__ seg_of,
+                                             uint32_t* __restrict__ perm, double* __restrict__ cx, double* __restrict__ cy,
+                                             double* __restrict__ cz, const uint32_t vblock)
+{
+  const uint32_t base = vblock * (256u * PW_ROWS) + threadIdx.x;
+  uint32_t sg[PW_ROWS], a[PW_ROWS], b[PW_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < PW_ROWS; r++) {
+    const uint32_t p = base + r * 256u;
+    sg[r] = (p < M) ? seg_of[p] : 0xFFFFFFFFu;
+    a[r] = (p < M) ? list[p] : 0u;
+  }
+  bool sw[PW_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < PW_ROWS; r++) {
+    const uint32_t p = base + r * 256u;
+    sw[r] = false; b[r] = 0u;
+    if (sg[r] == 0xFFFFFFFFu) continue;
+    if (!kind[sg[r]]) { seg_of[p] = 0xFFFFFFFFu; continue; }
+    const BSeg q = segs[sg[r]];
+    const uint32_t nl = nleft[sg[r]], j = p - q.start, nge = q.n - nl;
+    seg_of[p] = 2u * irank[sg[r]] + ((j < nl) ? 0u : 1u);
+    if (j < nge && a[r] < q.start + nl) { sw[r] = true; b[r] = list[p + nge]; }
+  }
+  uint32_t pa[PW_ROWS], pb[PW_ROWS];
+  double xa[PW_ROWS], xb[PW_ROWS], ya[PW_ROWS], yb[PW_ROWS], za[PW_ROWS], zb[PW_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < PW_ROWS; r++)
+    if (sw[r]) {
+      pa[r] = perm[a[r]]; pb[r] = perm[b[r]];
+      xa[r] = cx[a[r]]; xb[r] = cx[b[r]]; ya[r] = cy[a[r]]; yb[r] = cy[b[r]]; za[r] = cz[a[r]]; zb[r] = cz[b[r]];
+    }
+#pragma unroll
+  for (uint32_t r = 0; r < PW_ROWS; r++)
+    if (sw[r]) {
+      perm[a[r]] = pb[r]; perm[b[r]] = pa[r];
+      cx[a[r]] = xb[r]; cx[b[r]] = xa[r]; cy[a[r]] = yb[r]; cy[b[r]] = ya[r]; cz[a[r]] = zb[r]; cz[b[r]] = za[r];
+    }
+}
+__global__ void __launch_bounds__(256) k_part_swap(const uint32_t* __restrict__ list, const BSeg* __restrict__ segs,
+                                                   const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
+                                                   const uint32_t* __restrict__ nleft, uint32_t M, uint32_t* __restrict__ seg_of,
+                                                   uint32_t* __restrict__ perm, double* __restrict__ cx, double* __restrict__ cy,
+                                                   double* __restrict__ cz, uint32_t nb_first, const BLevel* __restrict__ lv,
+                                                   BSeg* __restrict__ next, uint32_t* __restrict__ err)
+{
+  if (blockIdx.x < nb_first) part_swap_at(list, segs, kind, irank, nleft, M, seg_of, perm, cx, cy, cz, blockIdx.x);
+  else children_of(segs, lv, kind, irank, nleft, next, err, (blockIdx.x - nb_first) * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_part_swap_keep(const uint32_t* __restrict__ list, const BSeg* __restrict__ segs,
+                                                        const uint32_t* __restrict__ kind, const uint32_t* __restrict__ irank,
+                                                        const uint32_t* __restrict__ nleft, uint32_t M, uint32_t* __restrict__ seg_of,
+                                                        uint32_t* __restrict__ perm, double* __restrict__ cx, double* __restrict__ cy,
+                                                        double* __restrict__ cz, uint32_t nb_first, const BLevel* __restrict__ lv,
+                                                        BSeg* __restrict__ next, uint32_t* __restrict__ err, BSpecLevel L)
+{
+  if (blockIdx.x < nb_first) part_swap_at(list, segs, kind, irank, nleft, M, seg_of, perm, cx, cy, cz, blockIdx.x);
+  else {
+    const uint32_t i = (blockIdx.x - nb_first) * blockDim.x + threadIdx.x;
+    children_of(segs, lv, kind, irank, nleft, next, err, i);
+    spec_keep_at(lv, kind, irank, nleft, L, i);
+  }
+}
+
 // (its first workgroup also sets up what the levels start from -- the build's small words, the level counters, the root
 // node: four memsets / copies less in front of a build that is a chain of dependent commands)
 __global__ void k_init(const double* __restrict__ xyz, uint32_t M, uint32_t* __restrict__ perm,
@@ -1548,7 +1788,7 @@ __device__ __forceinline__ unsigned long long fin_scan_u64(const unsigned long l
 
 #define FIN_LDS 3584u          // points a subtree may hold: its coordinates, labels, partition scratch and node table live in LDS
 #define FIN_SEGS 1024u         // nodes a level of a subtree may have: <= 2 FIN_LDS / (bucket + 1), hence bucket >= 6 (the host checks)
-#define FIN_K ((FIN_LDS + FIN_T - 1) / FIN_T)
+#define FIN_LDS_HALF (FIN_LDS / 2u)
 struct FinArgs {
   const BSeg* roots; const BLevel* lvH;
   double *cx, *cy, *cz; uint32_t* perm;
@@ -1571,18 +1811,18 @@ __device__ __forceinline__ const T& build_kernarg_block()
 // to), the partition's scratch and the level's node table are in LDS; the node / bucket records and the per-node arrays
 // decide_node / emit_node / children_of work on are the subtree's slices of the arena's arrays (start .. start + n).
 // Thread k owns the FIN_K consecutive local positions from k FIN_K.
-__global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value)
+template <uint32_t CAP, uint32_t SEGS>
+__device__ __forceinline__ void fin_subtree_body(const FinArgs& A)
 {
-  (void)A_by_value;
-  const FinArgs& A = build_kernarg_block<FinArgs>();
-  __shared__ alignas(16) double X[FIN_LDS + 16], Y[FIN_LDS + 16], Z[FIN_LDS + 16];
-  __shared__ uint16_t lab[FIN_LDS];                 // node of the current level, 0xFFFF: already in a bucket
-  __shared__ uint32_t ab[FIN_LDS];                  // bit 31 / 30: misplaced on the left / right; bits 0-11 / 12-23: how many before
-  __shared__ uint16_t pl[FIN_LDS / 2 + 1], pr[FIN_LDS / 2 + 1];
-  __shared__ double m_sv[FIN_SEGS];
-  __shared__ uint16_t m_start[FIN_SEGS], m_cnt[FIN_SEGS], m_ir[FIN_SEGS];
-  __shared__ uint32_t m_nl[FIN_SEGS];
-  __shared__ unsigned char m_kind[FIN_SEGS], m_ax[FIN_SEGS];
+  constexpr uint32_t KPT = (CAP + FIN_T - 1) / FIN_T;
+  __shared__ alignas(16) double X[CAP + 16], Y[CAP + 16], Z[CAP + 16];
+  __shared__ uint16_t lab[CAP];                 // node of the current level, 0xFFFF: already in a bucket
+  __shared__ uint32_t ab[CAP];                  // bit 31 / 30: misplaced on the left / right; bits 0-11 / 12-23: how many before
+  __shared__ uint16_t pl[CAP / 2 + 1], pr[CAP / 2 + 1];
+  __shared__ double m_sv[SEGS];
+  __shared__ uint16_t m_start[SEGS], m_cnt[SEGS], m_ir[SEGS];
+  __shared__ uint32_t m_nl[SEGS];
+  __shared__ unsigned char m_kind[SEGS], m_ax[SEGS];
   __shared__ BLevel lvl2[2];
   __shared__ uint32_t s_w32[FIN_T / WAVE + 1];
   __shared__ uint32_t s_tot[2], s_root, s_nlong, s_maxleaf;
@@ -1593,7 +1833,7 @@ __global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value
   const uint32_t s0 = root.start, n = root.n;
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   uint32_t* small = A.small;
-  if (n > FIN_LDS) {     // (the host hands a level over only when its largest node fits; a node that does not is a bug there)
+  if (n > CAP) {     // (the host hands a level over only when its largest node fits; a node that does not is a bug there)
     if (threadIdx.x == 0) atomicOr(small + 2, 0x20000u);
     return;
   }
@@ -1611,7 +1851,7 @@ __global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value
   }
   __threadfence_block();
   __syncthreads();
-  const uint32_t i_lo = threadIdx.x * FIN_K, i_hi = (i_lo + FIN_K < n) ? i_lo + FIN_K : n;     // this thread's positions
+  const uint32_t i_lo = threadIdx.x * KPT, i_hi = (i_lo + KPT < n) ? i_lo + KPT : n;     // this thread's positions
   uint32_t lev = 0;
   unsigned long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
   const bool timing = kLab && t == 0 && threadIdx.x == 0 && small[15] == 0x7157u;      // (lab: TDTK_BUILD_TRACE=2)
@@ -1620,7 +1860,7 @@ __global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value
   for (;; lev++) {
     const uint32_t nseg = lvl2[0].nseg;
     if (threadIdx.x == 0 && lev <= FIN_LV + 1u) { A.tab[t].ib[lev] = lvl2[0].node_base; A.tab[t].lb[lev] = lvl2[0].leaf_base; }
-    if (nseg == 0 || lev > FIN_LV || nseg > FIN_SEGS) break;
+    if (nseg == 0 || lev > FIN_LV || nseg > SEGS) break;
     // (0) the level's runs into the node table
     for (uint32_t i = threadIdx.x; i < nseg; i += FIN_T) { const BSeg sg = segs[i]; m_start[i] = (uint16_t)(sg.start - s0); m_cnt[i] = (uint16_t)sg.n; }
     if (threadIdx.x == 0) s_nlong = 0u;
@@ -1632,7 +1872,7 @@ __global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value
       const uint32_t sgi = item / 3u, a3 = item % 3u;
       const uint32_t st = m_start[sgi], cnt_n = m_cnt[sgi];
       if (cnt_n > FIN_LANE_RUN) {
-        const uint32_t slot = atomicAdd(&s_nlong, 1u);       // (at most 3 FIN_LDS / FIN_LANE_RUN of them)
+        const uint32_t slot = atomicAdd(&s_nlong, 1u);       // (at most 3 CAP / FIN_LANE_RUN of them)
         s_long[slot] = item;
         continue;
       }
@@ -1786,6 +2026,20 @@ __global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value
     atomicMax(small + 1, s_maxleaf);
     if (lvl2[0].nseg != 0) atomicOr(small + 2, 0x20000u);     // deeper than the tables, or a level wider than the node table: redo level by level
   }
+}
+
+// (two instantiations: the full one keeps a compute unit to itself -- 135 KB of LDS --; subtrees of at most FIN_LDS_HALF points
+// -- what the hand-over level of a cloud of several million points holds -- are built two workgroups to a compute unit:
+// a subtree's levels are barriers and round trips, and two of them side by side hide each other's)
+__global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value)
+{
+  (void)A_by_value;
+  fin_subtree_body<FIN_LDS, FIN_SEGS>(build_kernarg_block<FinArgs>());
+}
+__global__ void __launch_bounds__(FIN_T, 4) k_fin_subtrees_half(const FinArgs A_by_value)
+{
+  (void)A_by_value;
+  fin_subtree_body<FIN_LDS_HALF, FIN_SEGS / 2u>(build_kernarg_block<FinArgs>());
 }
 
 // the largest node of the level that is about to be handed over (the host hands it over only if that one fits FIN_LDS)
@@ -2006,6 +2260,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     static const bool chain_only = [] { const char* e = lab_env("TDTK_BUILD_CHAIN"); return e && e[0] == '1'; }();
     const uint32_t big_min = build_big_min(M_);
     const bool use_big = !chain_only && M >= big_min;
+    const uint32_t big_level_min = build_big_level_min(M_);
     // TDTK_MEASURE=axis: round 2's wave per (node, axis) for the nodes below the piecewise path (k_measure); default: a wave
     // per node (k_measure_node).  With TDTK_BUILD_CHAIN=1 (no piecewise path: chains of any length) the long-chain kernel.
     static const bool measure_axis_env = [] { const char* e = lab_env("TDTK_MEASURE"); return e && e[0] == 'a'; }();
@@ -2019,13 +2274,14 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     spec_on = spec;
     BSpecAll SP;
     SP.n = 0;
-    size_t SO[BIG_SPEC_MAX * SPEC_SLOTS + 4];
+    size_t SO[BIG_SPEC_MAX * SPEC_SLOTS + 5];
     int spec_levels = 0;
-    void *tmp2 = nullptr, *tmp3 = nullptr;
+    void *tmp2 = nullptr, *tmp3 = nullptr, *tmp4 = nullptr;
     if (spec) {
       (void)spec_layout(M_, build_layout(M_, nullptr, nullptr), SO, &spec_levels);
       tmp2 = arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS];
       tmp3 = arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS + 2];
+      tmp4 = arena + SO[(size_t)BIG_SPEC_MAX * SPEC_SLOTS + 3];
     }
     const int big_dbg = big_dbg_all & (3 | 16);   // 1: never trust a folded run, 2: walk every piece, 4: garbage in the arena, 8: compare with the chain
     if (big_dbg_all & 4) BCHK(hipMemsetAsync(arena, 0xFF, build_layout(M_, nullptr, nullptr), s));
@@ -2034,7 +2290,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     static const bool own_scan_env = [] { const char* e = lab_env("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
     const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
     const size_t o_scanstate = O[31];
-    if (own_scan) BCHK(hipMemsetAsync(arena + o_scanstate, 0, scan_pair27_state_bytes(n1), s));
+    if (own_scan) BCHK(hipMemsetAsync(arena + o_scanstate, 0, std::max(scan_pair27_state_bytes(n1), part_state_bytes(n1)), s));
     hipLaunchKernelGGL(k_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small, lvl, segs);
 
     // Levels are enqueued in batches; how many nodes a level has, and where its node / bucket records start, is
@@ -2071,7 +2327,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     static_assert(64 + sizeof(BLevel) * (BUILD_MAX_LEVELS + 2) <= 65536, "the staging block holds every level's counters");
     std::memset(hst, 0, 64);
     bool have_max = false;
-    uint32_t fin_nodes = 0;     // nodes of the level about to be handed over (k_fin_maxn)
+    uint32_t fin_nodes = 0, fin_maxn = 0;     // nodes of the level about to be handed over, the largest of them (k_fin_maxn)
     for (;;) {
       if (level == fin_level) {
         // does the level's largest node fit a workgroup's LDS?  (An unbalanced cloud -- a real scan -- takes a level or two more.)
@@ -2082,7 +2338,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         }
         have_max = false;
         const uint32_t h_max[2] = {h_small[4], h_small[5]};
-        fin_nodes = h_max[1];
+        fin_nodes = h_max[1]; fin_maxn = h_max[0];
         if (h_max[0] > FIN_LDS && h_max[1] * 2u <= FIN_MAX_SUBTREES && fin_level + 1u < 31u) {
           fin_level++;              // one more level by its own launches (below), then look again
           known = h_max[1]; known_at = level;
@@ -2112,7 +2368,9 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           fa.kind = (uint32_t*)(arena + O[35]); fa.axis = axis; fa.splitval = splitval; fa.irank = (uint32_t*)(arena + O[36]); fa.nleft = nleft;
           fa.nodes_st = (KdNode*)(arena + O[32]); fa.r_st = (double*)(arena + O[33]); fa.leaf_st = (LeafEntry*)(arena + O[34]);
           fa.tab = ftab; fa.bucket = (uint32_t)bucket; fa.small = small;
-          hipLaunchKernelGGL(k_fin_subtrees, dim3(tmax), dim3(FIN_T), 0, s, fa);
+          static const bool half_env = [] { const char* e = lab_env("TDTK_BUILD_FINHALF"); return !(e && e[0] == '0'); }();
+          if (half_env && fin_maxn <= FIN_LDS_HALF) hipLaunchKernelGGL(k_fin_subtrees_half, dim3(tmax), dim3(FIN_T), 0, s, fa);
+          else hipLaunchKernelGGL(k_fin_subtrees, dim3(tmax), dim3(FIN_T), 0, s, fa);
         }
         uint32_t* ftot = (uint32_t*)(arena + O[40]);
         hipLaunchKernelGGL(k_fin_offsets, dim3(FIN_LV + 1u), dim3(256), 0, s, ftab, foff, lvl + fin_level, ftot);
@@ -2125,6 +2383,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(hipEventRecord(side->e2, side->s2));
           BCHK(hipStreamWaitEvent(s, side->e2, 0));
           if (side->s3) { BCHK(hipEventRecord(side->e3, side->s3)); BCHK(hipStreamWaitEvent(s, side->e3, 0)); }
+          if (side->s4) { BCHK(hipEventRecord(side->e4, side->s4)); BCHK(hipStreamWaitEvent(s, side->e4, 0)); }
           hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
           hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
         }
@@ -2144,7 +2403,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           }
         }
         if (h_small[2] & 0x20000u) {       // a subtree deeper than the tables: level by level, then
-          if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); }
+          if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); if (side->s4) (void)hipStreamSynchronize(side->s4); }
           if (pts) pool_free(pts);
           for (hipEvent_t x : lvl_ev) (void)hipEventDestroy(x);
           return device_build_tree(d_xyz, M_, bucket, arena_, s, side, 1);
@@ -2169,7 +2428,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         if (lvl_trace) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); lvl_ev.push_back(e); } }
         // the piecewise path runs while a balanced node is at least half its threshold (below that level the chain in
         // k_measure takes every node, whatever its size: an empty pass of the piecewise kernels costs 75 us)
-        const bool big_level = use_big && ((M_ >> level) >= big_min / 2);
+        const bool big_level = use_big && ((M_ >> level) >= big_level_min);
         // a wave per node while the nodes of a balanced tree hold at most 128 points (three chains in one wave issue 24
         // cycles per point where three waves need 10: level 7 of a 1M-point tree 253 us against 46, level 12 equal,
         // level 16 74 against 139)
@@ -2219,9 +2478,13 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           // the exact chain of this level, all of it, on the snapshot.  The chains of different levels do not depend on each
           // other: the root's (1.3 ms of one wave) runs on one background stream, every other level's on the second -- in a
           // single stream the levels' chains queue up behind the root's and together outlast the build
+          // (round 6: ... and the second stream was then the build's critical path at 1M points -- the chains of levels 1 and 2,
+          // 0.6 and 0.4 ms, and five more levels' 0.12 ms each in a row outlast levels + finisher by 0.8 ms: the levels below
+          // the root alternate between two streams)
           const bool use3 = side->s3 && (SP.n - 1) != 0;
-          hipStream_t sb = use3 ? side->s3 : side->s2;
-          void* tmpb = use3 ? tmp3 : tmp2;
+          const bool use4 = use3 && side->s4 && ((SP.n - 1) & 1) == 0;
+          hipStream_t sb = use4 ? side->s4 : (use3 ? side->s3 : side->s2);
+          void* tmpb = use4 ? tmp4 : (use3 ? tmp3 : tmp2);
           BCHK(hipEventRecord(side->e1, s));
           BCHK(hipStreamWaitEvent(sb, side->e1, 0));
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, sb, L.segs, L.seg_of, sx, sy, sz, M,
@@ -2271,7 +2534,24 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           hipLaunchKernelGGL(k_emit, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, kind, axis, splitval,
                              irank, nodes, node_r, leaf_tab, small + 0, small + 1);
         }
-        // the partition pass (with no internal node at this level it moves nothing)
+        // the partition pass (with no internal node at this level it moves nothing): two passes over the points while the
+        // one-launch scan's conditions hold (TDTK_BUILD_PART=0, lab: round 3's five)
+        static const bool part2_env = [] { const char* e = lab_env("TDTK_BUILD_PART"); return !(e && e[0] == '0'); }();
+        if (part2_env && own_scan && level < 255u) {
+          const uint32_t ntiles = cdiv(M, PS_TILE), nbw = cdiv(M, 256u * PW_ROWS);
+          uint32_t* counter = reinterpret_cast<uint32_t*>(arena + o_scanstate);
+          unsigned long long* status = reinterpret_cast<unsigned long long*>(arena + o_scanstate + 64);
+          hipLaunchKernelGGL(k_part_scan, dim3(ntiles), dim3(PS_THREADS), 0, s, seg_of, kind, segs, axis, splitval, cx, cy, cz, M, nleft, posL,
+                             status, counter, level + 1u, ntiles, small + 2);
+          if (spec_this)
+            hipLaunchKernelGGL(k_part_swap_keep, dim3(nbw + cdiv(bound, 256)), dim3(256), 0, s, posL, segs, kind, irank, nleft, M, seg_of,
+                               perm, cx, cy, cz, nbw, lv, next, small + 2, SP.L[SP.n - 1]);
+          else
+            hipLaunchKernelGGL(k_part_swap, dim3(nbw + cdiv(bound, 256)), dim3(256), 0, s, posL, segs, kind, irank, nleft, M, seg_of,
+                               perm, cx, cy, cz, nbw, lv, next, small + 2);
+          BSeg* t = segs; segs = next; next = t;
+          continue;
+        }
         hipLaunchKernelGGL(k_count, dim3(cdiv(M, 256 * CNT_ITERS)), dim3(256), 0, s, seg_of, kind, axis, splitval, cx, cy,
                            cz, M, nleft);
         {
@@ -2339,6 +2619,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       BCHK(hipEventRecord(side->e2, side->s2));
       BCHK(hipStreamWaitEvent(s, side->e2, 0));
       if (side->s3) { BCHK(hipEventRecord(side->e3, side->s3)); BCHK(hipStreamWaitEvent(s, side->e3, 0)); }
+          if (side->s4) { BCHK(hipEventRecord(side->e4, side->s4)); BCHK(hipStreamWaitEvent(s, side->e4, 0)); }
       hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
       hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
       BCHK(hipMemcpyAsync(&h_spec_err, small + 3, 4, hipMemcpyDeviceToHost, s));
@@ -2386,7 +2667,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   if (guards.n) {
     uint32_t* bad = (uint32_t*)(arena + O[19]) + 40;       // (a word of `small` nothing else uses)
     uint32_t h_bad = 0;
-    if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); }
+    if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); if (side->s4) (void)hipStreamSynchronize(side->s4); }
     (void)hipMemsetAsync(bad, 0, 4, s);
     hipLaunchKernelGGL(k_guard_check, dim3(guards.n), dim3(64), 0, s, arena, guards, bad);
     (void)hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s);
@@ -2402,7 +2683,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
   res.n_internal = node_count; res.n_leaves = leaf_count; res.max_depth = depth;
   return res;
 fail:
-  if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); }   // nothing of this build may still be running in the arena
+  if (spec_on) { (void)hipStreamSynchronize(side->s2); if (side->s3) (void)hipStreamSynchronize(side->s3); if (side->s4) (void)hipStreamSynchronize(side->s4); }   // nothing of this build may still be running in the arena
   if (f_nodes) pool_free(f_nodes);
   if (f_r) pool_free(f_r);
   if (f_leaf) pool_free(f_leaf);
@@ -2431,7 +2712,7 @@ static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out)
   size_t off = (base + 255) & ~(size_t)255;
   int nlev = 0;
   if (M >= BIG_MIN_M)
-    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= BIG_MIN_M / 2 && nlev < BIG_SPEC_LEVELS; level++) nlev++;
+    for (uint32_t level = 0; level < BUILD_MAX_LEVELS && (M >> level) >= build_big_level_min(M) && nlev < BIG_SPEC_LEVELS; level++) nlev++;
   if (getenv("TDTK_BUILD_SPEC") && getenv("TDTK_BUILD_SPEC")[0] == '0') nlev = 0;
   const size_t n1 = M + 1, nsl = 6 * (M / BIG_CH + 2), nsl1 = nsl / 3 + 3;
   auto take = [&](size_t bytes, size_t* slot) { if (slot) *slot = off; off += (bytes + 255) & ~(size_t)255; arena_guard(off); };
@@ -2465,6 +2746,7 @@ static size_t spec_layout(size_t M, size_t base, size_t* SO, int* nlev_out)
   take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS : nullptr);
   take(sizeof(BPart) * 2 * (M / BIG_PB + 2), SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS + 1 : nullptr);
   take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS + 2 : nullptr);      // the third stream's scan temporary
+  take(scan_tmp + 256, SO ? SO + (size_t)BIG_SPEC_MAX * SPEC_SLOTS + 3 : nullptr);      // the fourth's
   if (nlev_out) *nlev_out = nlev;
   return off;
 }
@@ -2505,7 +2787,7 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(sizeof(BSum) * nsl); take(sizeof(BSum) * nsl);                       // 27 28 piece summaries, folded runs
   take(4 * (nsl + 1));                                                      // 29 slots of the walked pieces, in run order
   take(lab_env("TDTK_BIG_DEBUG") && (atoi(lab_env("TDTK_BIG_DEBUG")) & 8) ? sizeof(BMeas) * n1 : 256);   // 30 debug: the chain's results
-  take(scan_pair27_state_bytes(n1));                                        // 31 state of the one-launch scan
+  take(std::max(scan_pair27_state_bytes(n1), part_state_bytes(n1)));        // 31 state of the one-launch scans (sort.hip's, k_part_scan's)
   // subtrees finished by one workgroup each (k_fin_*): staging of their records, their own kind / rank arrays, tables
   take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // 32 33 34
   take(4 * (n1 + FIN_MAX_SUBTREES)); take(4 * (n1 + FIN_MAX_SUBTREES));                // 35 36 kind, irank

@@ -253,7 +253,7 @@ struct DevBuildResult {
 size_t device_build_arena_bytes(size_t M, bool with_background_chain = true);
 // `side` (nullable): a second stream and two events of the caller's for the build's background chain -- with it the exact
 // centroid sums of the big nodes run beside the levels below them (see "speculative splits" in build.hip)
-struct BuildSide { hipStream_t s2, s3; hipEvent_t e1, e2, e3; void* h_pin; };   // s2 null: no background streams (s3 / e3 nullable: one only);
+struct BuildSide { hipStream_t s2, s3; hipEvent_t e1, e2, e3; void* h_pin; hipStream_t s4; hipEvent_t e4; };   // s2 null: no background streams (s3 / e3, s4 / e4 nullable: fewer);
                                                                                     // h_pin: 64 KB of pinned host memory for the build's looks at the device, or null
 // no_finish != 0: every level by its own launches (the subtrees are not handed to single workgroups; see k_fin_subtrees)
 DevBuildResult device_build_tree(const double* d_xyz, size_t M, int bucket, void* arena, hipStream_t s,
