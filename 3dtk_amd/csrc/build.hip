@@ -214,7 +214,8 @@ __device__ __forceinline__ double wave_add(double v) {
 // the chain) and the vector ALU issues nothing but the dependent v_add_f64 chain.
 __device__ __forceinline__ void measure_body(const uint32_t vblock, const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
                                              const double* __restrict__ cx, const double* __restrict__ cy,
-                                             const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min)
+                                             const double* __restrict__ cz, BMeas* __restrict__ out, uint32_t big_min,
+                                             const uint32_t min_n = 0u, const uint32_t* __restrict__ only_axis = nullptr)
 {
   __shared__ alignas(16) double stage[256 / WAVE][2][MEAS_STAGE * WAVE + 16];   // + 16: lds_chain32 requests 128 bytes past the data
   // wave-uniform by construction; readfirstlane tells the compiler so
@@ -225,6 +226,7 @@ __device__ __forceinline__ void measure_body(const uint32_t vblock, const BSeg* 
   const uint32_t s = __builtin_amdgcn_readfirstlane(segs[sgi].start);
   const uint32_t n = __builtin_amdgcn_readfirstlane(segs[sgi].n);
   if (n >= big_min) return;   // measured by the piecewise path below (k_big_*)
+  if (n < min_n || (only_axis != nullptr && only_axis[sgi] != ax)) return;      // (k_chain_exact: the big nodes' split axes only)
   const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + s;
   double(*buf)[MEAS_STAGE * WAVE + 16] = stage[threadIdx.x / WAVE];
 
@@ -1006,6 +1008,18 @@ __global__ void __launch_bounds__(256) k_big_approx(const BSeg* __restrict__ seg
 {
   big_approx_wave((blockIdx.x * blockDim.x + threadIdx.x) / WAVE, segs, lv, part, meas, L, fault, big_min);
 }
+// The exact sums of a speculated level's big nodes as plain chains on the snapshot (round 6), for the levels whose chains
+// are short enough to end before the build does: one wave per (node, split axis), nothing but its dependent adds -- where
+// the piecewise path is five passes over all points per level (k_big_stats, two scans, k_big_emulate, k_big_stitch:
+// 0.45 ms of a 10M-point level's bandwidth, in the background but not for free; seven dependent launches that queue up
+// on the side streams of a 1M-point build).
+__global__ void __launch_bounds__(256) k_chain_exact(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv,
+                                                     const double* __restrict__ sx, const double* __restrict__ sy,
+                                                     const double* __restrict__ sz, BMeas* __restrict__ exact,
+                                                     const uint32_t* __restrict__ axis, uint32_t big_min)
+{
+  measure_body(blockIdx.x, segs, lv, sx, sy, sz, exact, 0xFFFFFFFFu, big_min, axis);
+}
 // the level as it stands before its partition pass: coordinates and labels (the exact chain reads these, later)
 __global__ void k_spec_snapshot(const uint32_t* __restrict__ seg_of, const double* __restrict__ cx, const double* __restrict__ cy,
                                 const double* __restrict__ cz, uint32_t M, uint32_t n1, double* __restrict__ snap,
@@ -1728,7 +1742,9 @@ __global__ void k_pack_refs(KdNode* __restrict__ nodes, uint32_t nnodes, const L
 #define FIN_T 512u             // threads of a subtree's workgroup (eight waves: 256 vector registers each)
 #define FIN_LV 96u             // levels a subtree may have; deeper (a pathological cloud): the build is redone level by level
 #define FIN_HANDOFF 2048u      // hand a level over when a balanced node of it holds at most this many points (and the largest fits FIN_LDS)
-#define FIN_MAX_SUBTREES 8192u
+#define FIN_MAX_SUBTREES 65536u
+#define FIN_HANDOFF_WAVE 384u        // ... for clouds of at least FIN_HANDOFF_WAVE_FROM points: what k_fin_wave takes (a wave per subtree)
+#define FIN_HANDOFF_WAVE_FROM 2000000u   // most subtrees a build's tables hold (fin_max_subtrees(M) of them: M / 128, at least 1024)
 #define FIN_LONG_MAX 512u      // long runs of a level a subtree lists for its waves
 #define FIN_LANE_RUN 192u      // runs up to this long are measured by one lane each (k_fin_subtrees), longer ones by a wave
 struct FinTab {
@@ -1740,6 +1756,14 @@ struct FinTab {
 struct FinOff {                              // k_fin_offsets -> k_fin_place
   uint32_t io[FIN_LV + 2], lo[FIN_LV + 2];   // global index of the subtree's first internal node / bucket of local level l
 };
+// (8192 for every build until round 6: a 10M-point scan that is a little lopsided -- the largest node of its level four
+// times the average -- fits a workgroup a level below the balanced hand-over, with 16 384 nodes, and went level by level
+// to the end; the tables are 1.6 KB per subtree, so a small cloud's arena does not carry the large one's)
+static inline uint32_t fin_max_subtrees(size_t M)
+{
+  const size_t c = M / 128u;
+  return (uint32_t)(c < 1024u ? 1024u : (c > FIN_MAX_SUBTREES ? FIN_MAX_SUBTREES : c));
+}
 
 // exclusive scan of `count` 32-bit values in[0 .. count) -> out[0 .. count], out[count] = total, by one workgroup of FIN_T threads
 __device__ __forceinline__ uint32_t fin_scan_u32(const uint32_t* in, uint32_t* out, uint32_t count, uint32_t* s_w /*[17]*/)
@@ -1796,6 +1820,10 @@ struct FinArgs {
   uint32_t *kind, *axis; double* splitval; uint32_t *irank, *nleft;
   KdNode* nodes_st; double* r_st; LeafEntry* leaf_st;
   FinTab* tab; uint32_t bucket; uint32_t* small;
+  uint32_t *sub_nlev, *sub_maxleaf;   // per subtree: its levels, its largest bucket (k_fin_offsets takes the maxima: one shared word per subtree is a
+                                      // millisecond of atomics -- or of loads that must see them -- over 32 768 subtrees)
+  uint32_t dbg_levels;          // lab (TDTK_FW_DEBUG=k): k_fin_wave stops after k - 1 levels -- a timing probe, the tree is not valid
+  uint32_t n_lo, skip_big;      // this launch takes the subtrees of more than n_lo points; skip_big: ... and leaves those beyond its capacity to the next
 };
 // (a kernel's by-value argument block read through the kernarg segment pointer: see kernarg_block in kernels.hip)
 template <class T>
@@ -1833,8 +1861,9 @@ __device__ __forceinline__ void fin_subtree_body(const FinArgs& A)
   const uint32_t s0 = root.start, n = root.n;
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   uint32_t* small = A.small;
+  if (n <= A.n_lo) return;
   if (n > CAP) {     // (the host hands a level over only when its largest node fits; a node that does not is a bug there)
-    if (threadIdx.x == 0) atomicOr(small + 2, 0x20000u);
+    if (threadIdx.x == 0 && !A.skip_big) atomicOr(small + 2, 0x20000u);
     return;
   }
   BSeg* segs = A.segA + s0; BSeg* next = A.segB + s0;
@@ -2023,7 +2052,7 @@ __device__ __forceinline__ void fin_subtree_body(const FinArgs& A)
     A.tab[t].nlev = lev;
     A.tab[t].root_ref = s_root;
     A.tab[t].s0 = s0; A.tab[t].n = n;
-    atomicMax(small + 1, s_maxleaf);
+    A.sub_nlev[t] = lev; A.sub_maxleaf[t] = s_maxleaf;
     if (lvl2[0].nseg != 0) atomicOr(small + 2, 0x20000u);     // deeper than the tables, or a level wider than the node table: redo level by level
   }
 }
@@ -2042,6 +2071,282 @@ __global__ void __launch_bounds__(FIN_T, 4) k_fin_subtrees_half(const FinArgs A_
   fin_subtree_body<FIN_LDS_HALF, FIN_SEGS / 2u>(build_kernarg_block<FinArgs>());
 }
 
+// ---- subtrees of at most FW_CAP points: ONE WAVE each (round 6) ---------------------------------------------------------
+// A workgroup per subtree is eight waves that spend a level's time at barriers and on round trips through the arena's
+// per-node arrays: 20 us per level whatever the subtree holds, one or two subtrees per compute unit (3 ms for the 8192
+// subtrees of a 10M-point cloud; a lopsided scan, whose hand-over level has tens of thousands of small nodes beside a few
+// large ones, was faster level by level).  A subtree of a few hundred points needs none of that: here a single wave builds
+// it, everything it reads twice in LDS (21 KB: seven subtrees per compute unit at a time), no barrier that is more than
+// a wave's own.  Per level: a lane per (node, axis) walks its run -- the bounding box and the reference's left-to-right
+// sum (kdTreeImpl.h:94-111) --, the three lanes of a node meet in the first, which decides (kdTreeImpl.h:113-170), ranks
+// itself by ballot and writes the record into the subtree's staging slice (the same slice, tables and references
+// k_fin_subtrees leaves: k_fin_offsets / k_fin_place do not care who built a subtree); the partition is k_part_scan /
+// k_part_swap at the size of a wave (eight rows of 64 positions, ballots and a carried count; the index list in LDS).
+#define FW_CAP 512u
+#define FW_ROWS (FW_CAP / WAVE)
+#define FW_SEGS 160u           // nodes of a level: <= 2 FW_CAP / (bucket + 1), bucket >= 6
+#define FW_WAVES 1u             // subtrees (waves) per workgroup
+struct FwSeg { uint16_t start, cnt; uint32_t parent; };   // parent: staged index | side << 30 | that side's axis bit << 31; 0xFFFFFFFF: the subtree's root
+// (a wave's own barrier: its LDS accesses are carried out in order, so a compiler fence at wavefront scope is all a later
+// read of an earlier write needs -- __syncthreads() would also wait for the records on their way to memory, a round
+// trip per level that nobody is waiting for)
+struct FwLds {
+  alignas(16) double X[FW_CAP + 8], Y[FW_CAP + 8], Z[FW_CAP + 8];
+  uint32_t P[FW_CAP];
+  uint16_t lab[FW_CAP], list[FW_CAP];
+  FwSeg seg[2][FW_SEGS];
+  double sv[FW_SEGS];
+  uint16_t nl[FW_SEGS], ir[FW_SEGS];
+  unsigned char kd[FW_SEGS], ax[FW_SEGS];
+};
+__device__ __forceinline__ void fw_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__global__ void __launch_bounds__(WAVE * FW_WAVES) k_fin_wave(const FinArgs A_by_value)
+{
+  (void)A_by_value;
+  const FinArgs& A = build_kernarg_block<FinArgs>();
+  __shared__ FwLds Lw[FW_WAVES];
+  FwLds& S = Lw[threadIdx.x / WAVE];
+  const uint32_t t = blockIdx.x * FW_WAVES + threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1u);
+  if (t >= A.lvH->nseg) return;
+  const BSeg root = A.roots[t];
+  const uint32_t s0 = root.start, n = root.n;
+  if (n > FW_CAP) return;                       // the workgroup kernels' (their n_lo)
+  if (kLab && A.dbg_levels == 100u) return;
+  {
+    // (all rows requested before the first is parked: under a branch per row the compiler waits for each row's round trip
+    //  to memory in turn -- eight of them were the kernel's whole time; positions past the subtree read its last point)
+    double tx[FW_ROWS], ty[FW_ROWS], tz[FW_ROWS];
+    uint32_t tp[FW_ROWS];
+#pragma unroll
+    for (uint32_t r = 0; r < FW_ROWS; r++) {
+      const uint32_t i = r * WAVE + lane, g = s0 + ((i < n) ? i : n - 1u);
+      tx[r] = A.cx[g]; ty[r] = A.cy[g]; tz[r] = A.cz[g]; tp[r] = A.perm[g];
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < FW_ROWS; r++) {
+      const uint32_t i = r * WAVE + lane;
+      if (i < n) { S.X[i] = tx[r]; S.Y[i] = ty[r]; S.Z[i] = tz[r]; S.P[i] = tp[r]; S.lab[i] = 0; }
+    }
+  }
+  if (kLab && A.dbg_levels == 101u) return;
+  if (lane == 0) { FwSeg q; q.start = 0; q.cnt = (uint16_t)n; q.parent = 0xFFFFFFFFu; S.seg[0][0] = q; }
+  fw_sync();
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+  const bool timing = kLab && t == 0 && lane == 0 && A.small[15] == 0x7157u;      // (S.lab: TDTK_BUILD_TRACE=2)
+  auto tick = [&](int k) { if (timing) { const unsigned long long now = wall_clock64(); tph[k] += now - tlast; tlast = now; } };
+  if (timing) tlast = wall_clock64();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
+  uint32_t nseg = 1u, node_base = s0, leaf_base = s0, lev = 0u, cur = 0u, my_root = 0u, maxleaf = 0u;
+  for (;; lev++) {
+    if (lane == 0 && lev <= FIN_LV + 1u && !(kLab && A.dbg_levels == 104u)) { A.tab[t].ib[lev] = node_base; A.tab[t].lb[lev] = leaf_base; }
+    if (nseg == 0u || lev > FIN_LV || nseg > FW_SEGS) break;
+    if (kLab && A.dbg_levels && (lev + 1u >= A.dbg_levels || A.dbg_levels >= 100u)) break;
+    // (1) measure, decide, rank, emit: 21 nodes per round, the three axes of a node in neighbouring lanes
+    uint32_t nint = 0u;
+    for (uint32_t base = 0; base < nseg; base += 21u) {
+      const uint32_t node = base + lane / 3u, a3 = lane % 3u;
+      const bool valid = lane < 63u && node < nseg;
+      double lo = 0.0, hi = 0.0, mean = 0.0;
+      uint32_t st = 0u, cn = 0u, par = 0u;
+      if (valid) {
+        const FwSeg q = S.seg[cur][node];
+        st = q.start; cn = q.cnt; par = q.parent;
+        const double* __restrict__ arr = ((a3 == 0u) ? S.X : ((a3 == 1u) ? S.Y : S.Z)) + st;
+        double sum = arr[0];                               // the sum starts from the first point ...
+        lo = sum; hi = sum;
+        uint32_t k = 1u;
+        // ... and adds the rest in order, the next four values requested before the current four are added (the arrays
+        // are padded: the last request may run eight values past the subtree, never past the array)
+        double v0 = arr[1], v1 = arr[2], v2 = arr[3], v3 = arr[4];
+        for (; k + 4u <= cn; k += 4u) {
+          const double n0 = arr[k + 4], n1 = arr[k + 5], n2 = arr[k + 6], n3 = arr[k + 7];
+          sum += v0; sum += v1; sum += v2; sum += v3;
+          const double mn = fmin(fmin(v0, v1), fmin(v2, v3)), mx = fmax(fmax(v0, v1), fmax(v2, v3));
+          lo = (mn < lo) ? mn : lo; hi = (hi < mx) ? mx : hi;
+          v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        }
+        if (k < cn) { sum += v0; lo = (v0 < lo) ? v0 : lo; hi = (hi < v0) ? v0 : hi; k++; }
+        if (k < cn) { sum += v1; lo = (v1 < lo) ? v1 : lo; hi = (hi < v1) ? v1 : hi; k++; }
+        if (k < cn) { sum += v2; lo = (v2 < lo) ? v2 : lo; hi = (hi < v2) ? v2 : hi; k++; }
+        mean = sum / (double)cn;
+      }
+      const double lo1 = __shfl_down(lo, 1, WAVE), lo2 = __shfl_down(lo, 2, WAVE);
+      const double hi1 = __shfl_down(hi, 1, WAVE), hi2 = __shfl_down(hi, 2, WAVE);
+      const double m1 = __shfl_down(mean, 1, WAVE), m2 = __shfl_down(mean, 2, WAVE);
+      const bool first = valid && a3 == 0u;
+      bool internal = false;
+      uint32_t axis = 0u;
+      double hx = 0.0, hy = 0.0, hz = 0.0, split = 0.0;
+      if (first) {                                         // decide_node
+        hx = 0.5 * (hi - lo); hy = 0.5 * (hi1 - lo1); hz = 0.5 * (hi2 - lo2);
+        if (hx > hy) axis = (hx > hz) ? 0u : 2u;
+        else axis = (hy > hz) ? 1u : 2u;
+        const double mx = fmax(fmax(hx, hy), hz);
+        internal = !((cn <= A.bucket) || (fabs(mx) < 0.01));
+        split = (axis == 0u) ? mean : ((axis == 1u) ? m1 : m2);
+      }
+      const unsigned long long im = __ballot(internal);
+      if (first) {                                         // emit_node
+        const uint32_t r = nint + (uint32_t)__popcll(im & lt_mask);
+        uint32_t ref;
+        if (internal) {
+          const uint32_t me = node_base + r;
+          KdNode nd;
+          nd.cx = 0.5 * (lo + hi); nd.cy = 0.5 * (lo1 + hi1); nd.cz = 0.5 * (lo2 + hi2);
+          nd.hx = hx; nd.hy = hy; nd.hz = hz;
+          nd.splitval = split;
+          nd.c1 = (axis & 1u) ? REF_AXIS : 0u;
+          nd.c2 = (axis & 2u) ? REF_AXIS : 0u;
+          A.nodes_st[me] = nd;
+          A.r_st[me] = __dsqrt_rn(hx * hx + hy * hy + hz * hz);
+          ref = me;
+          S.kd[node] = 1; S.ax[node] = (unsigned char)axis; S.sv[node] = split; S.ir[node] = (uint16_t)r;
+        } else {
+          const uint32_t id = leaf_base + (node - r);      // every node is either internal or a bucket
+          LeafEntry le; le.start = (int32_t)(s0 + st); le.count = (int32_t)cn;
+          A.leaf_st[id] = le;
+          maxleaf = (cn > maxleaf) ? cn : maxleaf;
+          ref = REF_LEAF | id;
+          S.kd[node] = 0;
+        }
+        if (par == 0xFFFFFFFFu) my_root = ref;
+        else {     // the parent's slot, whole: its axis bit rides in the run's record (no read of what this wave wrote a level ago)
+          KdNode* pn = A.nodes_st + (par & REF_VAL);
+          const uint32_t w = ((par >> 31) ? REF_AXIS : 0u) | ref;
+          if ((par >> 30) & 1u) pn->c2 = w; else pn->c1 = w;
+        }
+      }
+      nint += (uint32_t)__popcll(im);
+    }
+    fw_sync();
+    tick(1);
+    // (2) the partition's scan: rows of 64 positions in order, a count carried from row to row
+    uint32_t geb[FW_ROWS], sgl[FW_ROWS], gebits = 0u, actbits = 0u;
+    {
+      // (every row's reads phase by phase, none of them under a branch: label -> node -> coordinate; a position without a
+      //  node reads node 0's entries and ignores them)
+      uint32_t sgs[FW_ROWS], a3s[FW_ROWS], sts[FW_ROWS];
+      unsigned char kds[FW_ROWS];
+      double cs[FW_ROWS], svs[FW_ROWS];
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) sgs[r] = S.lab[(r * WAVE + lane) & (FW_CAP - 1u)];
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) {
+        if (r * WAVE + lane >= n) sgs[r] = 0xFFFFu;
+        const uint32_t q = (sgs[r] == 0xFFFFu) ? 0u : sgs[r];
+        kds[r] = S.kd[q]; a3s[r] = S.ax[q]; svs[r] = S.sv[q]; sts[r] = S.seg[cur][q].start;
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) {
+        const uint32_t i = (r * WAVE + lane) & (FW_CAP - 1u);
+        const double* __restrict__ arr = (a3s[r] == 0u) ? S.X : ((a3s[r] == 1u) ? S.Y : S.Z);
+        cs[r] = arr[i];
+      }
+      uint32_t carry = 0u;
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) {
+        const uint32_t i = r * WAVE + lane;
+        const bool act = sgs[r] != 0xFFFFu && kds[r] != 0;
+        const bool ge = act && !(cs[r] < svs[r]);
+        const bool head = act && (i == sts[r]);
+        const unsigned long long gm = __ballot(ge), hm = __ballot(head);
+        const unsigned long long hb = hm & le_mask;
+        if (hb) { const int hl = 63 - __clzll((long long)hb); geb[r] = (uint32_t)__popcll(gm & lt_mask & ~((1ull << hl) - 1ull)); }
+        else geb[r] = carry + (uint32_t)__popcll(gm & lt_mask);
+        if (hm) { const int hl = 63 - __clzll((long long)hm); carry = (uint32_t)__popcll(gm >> hl); }
+        else carry += (uint32_t)__popcll(gm);
+        if (ge) gebits |= 1u << r;
+        if (act) actbits |= 1u << r;
+        sgl[r] = sgs[r];
+      }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < FW_ROWS; r++) {
+      if (!((actbits >> r) & 1u)) continue;
+      const uint32_t i = r * WAVE + lane;
+      const uint32_t sg = sgl[r];
+      const FwSeg q = S.seg[cur][sg];
+      const uint32_t j = i - q.start, g = geb[r];
+      const bool ge = (gebits >> r) & 1u;
+      const uint32_t dst = ge ? (q.start + g) : (q.start + q.cnt - 1u - (j - g));
+      S.list[dst] = (uint16_t)i;
+      if (j == (uint32_t)q.cnt - 1u) S.nl[sg] = (uint16_t)(q.cnt - (g + (ge ? 1u : 0u)));
+    }
+    fw_sync();
+    tick(2);
+    // (3) the children's runs (children_of)
+    for (uint32_t node = lane; node < nseg; node += WAVE) {
+      if (!S.kd[node]) continue;
+      const FwSeg q = S.seg[cur][node];
+      uint32_t nleft = S.nl[node];
+      if (nleft == 0u || nleft >= q.cnt) { atomicExch(A.small + 2, 1u); nleft = (nleft == 0u) ? 1u : q.cnt - 1u; }
+      const uint32_t me = node_base + S.ir[node], a = S.ax[node];
+      FwSeg c1, c2;
+      c1.start = q.start; c1.cnt = (uint16_t)nleft; c1.parent = me | ((a & 1u) ? 0x80000000u : 0u);
+      c2.start = (uint16_t)(q.start + nleft); c2.cnt = (uint16_t)(q.cnt - nleft); c2.parent = me | 0x40000000u | ((a & 2u) ? 0x80000000u : 0u);
+      S.seg[cur ^ 1u][2u * S.ir[node]] = c1;
+      S.seg[cur ^ 1u][2u * S.ir[node] + 1u] = c2;
+    }
+    // (4) the swaps, driven from the S.list's front half; the labels of the next level (reads phase by phase again)
+    {
+      uint32_t sgs[FW_ROWS], av[FW_ROWS], bv[FW_ROWS], bidx[FW_ROWS], newlab[FW_ROWS], swbits = 0u;
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) { const uint32_t i = (r * WAVE + lane) & (FW_CAP - 1u); sgs[r] = S.lab[i]; av[r] = S.list[i]; }
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) {
+        const uint32_t i = r * WAVE + lane;
+        if (i >= n) sgs[r] = 0xFFFFu;
+        const uint32_t q = (sgs[r] == 0xFFFFu) ? 0u : sgs[r];
+        const FwSeg sgm = S.seg[cur][q];
+        const uint32_t k = S.kd[q], nleft = S.nl[q], irk = S.ir[q];
+        const uint32_t j = i - sgm.start, nge = sgm.cnt - nleft;
+        newlab[r] = k ? (2u * irk + ((j < nleft) ? 0u : 1u)) : 0xFFFFu;
+        const bool sw = sgs[r] != 0xFFFFu && k != 0u && j < nge && av[r] < sgm.start + nleft;
+        if (sw) swbits |= 1u << r;
+        bidx[r] = sw ? (i + nge) : 0u;
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) bv[r] = S.list[bidx[r]];
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) if (sgs[r] != 0xFFFFu) S.lab[r * WAVE + lane] = (uint16_t)newlab[r];
+      uint32_t pa[FW_ROWS], pb[FW_ROWS];
+      double xa[FW_ROWS], xb[FW_ROWS], ya[FW_ROWS], yb[FW_ROWS], za[FW_ROWS], zb[FW_ROWS];
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++) {
+        const uint32_t a = ((swbits >> r) & 1u) ? av[r] : 0u, b = ((swbits >> r) & 1u) ? bv[r] : 0u;
+        pa[r] = S.P[a]; pb[r] = S.P[b]; xa[r] = S.X[a]; xb[r] = S.X[b]; ya[r] = S.Y[a]; yb[r] = S.Y[b]; za[r] = S.Z[a]; zb[r] = S.Z[b];
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < FW_ROWS; r++)
+        if ((swbits >> r) & 1u) {
+          const uint32_t a = av[r], b = bv[r];
+          S.P[a] = pb[r]; S.P[b] = pa[r]; S.X[a] = xb[r]; S.X[b] = xa[r]; S.Y[a] = yb[r]; S.Y[b] = ya[r]; S.Z[a] = zb[r]; S.Z[b] = za[r];
+        }
+    }
+    fw_sync();
+    tick(3);
+    node_base += nint; leaf_base += nseg - nint; nseg = 2u * nint; cur ^= 1u;
+  }
+  if (!(kLab && A.dbg_levels >= 103u)) {
+#pragma unroll
+  for (uint32_t r = 0; r < FW_ROWS; r++) {
+    const uint32_t i = r * WAVE + lane;
+    if (i < n) { A.cx[s0 + i] = S.X[i]; A.cy[s0 + i] = S.Y[i]; A.cz[s0 + i] = S.Z[i]; A.perm[s0 + i] = S.P[i]; }
+  }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(maxleaf, off, WAVE); maxleaf = (o > maxleaf) ? o : maxleaf; }
+  tick(4);
+  if (timing) for (int k = 0; k < 6; k++) A.small[16 + k] = (uint32_t)tph[k];
+  if (lane == 0) {
+    A.tab[t].nlev = lev;
+    A.tab[t].root_ref = my_root;
+    A.tab[t].s0 = s0; A.tab[t].n = n;
+    A.sub_nlev[t] = lev; A.sub_maxleaf[t] = maxleaf;       // (not atomicMax on the build's words: 32 768 of them on one address were the kernel's whole time)
+    if (nseg != 0u) atomicOr(A.small + 2, 0x20000u);       // deeper than the tables: redo level by level
+  }
+}
+
 // the largest node of the level that is about to be handed over (the host hands it over only if that one fits FIN_LDS)
 __global__ void __launch_bounds__(256) k_fin_maxn(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t* __restrict__ out)
 {
@@ -2056,17 +2361,36 @@ __global__ void __launch_bounds__(256) k_fin_maxn(const BSeg* __restrict__ segs,
 }
 
 // per level (one workgroup each): how many internal nodes / buckets the subtrees to the left hold, and the level's totals
-__global__ void __launch_bounds__(256) k_fin_offsets(const FinTab* __restrict__ tab, FinOff* __restrict__ off, const BLevel* __restrict__ lvH,
-                                                     uint32_t* __restrict__ totals /*[2][FIN_LV + 2]*/)
+#define FO_T 1024u            // (a step of the scan over the subtrees is two barriers and a round trip to their tables: as few steps as a workgroup allows)
+__global__ void __launch_bounds__(FO_T) k_fin_offsets(const FinTab* __restrict__ tab, FinOff* __restrict__ off, const BLevel* __restrict__ lvH,
+                                                     uint32_t* __restrict__ totals /*[2][FIN_LV + 2]*/, const uint32_t* __restrict__ sub_nlev,
+                                                     const uint32_t* __restrict__ sub_maxleaf, uint32_t* __restrict__ max_leaf)
 {
   const uint32_t T = lvH[0].nseg, l = blockIdx.x;
-  __shared__ uint32_t s_w[256 / WAVE][2];
+  __shared__ uint32_t s_w[FO_T / WAVE][2];
+  __shared__ uint32_t s_any, s_max;
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  // does any subtree reach this level?  (the subtrees' depths side by side: tens of thousands of 800-byte tables are not
+  // looked at by the workgroups of the levels nobody has); the first workgroup also takes the largest bucket of all
+  if (threadIdx.x == 0) { s_any = 0u; s_max = 0u; }
+  __syncthreads();
+  {
+    uint32_t any = 0u, mx = 0u;
+    for (uint32_t t = threadIdx.x; t < T; t += FO_T) { any |= (l < sub_nlev[t]) ? 1u : 0u; if (l == 0u) mx = max(mx, sub_maxleaf[t]); }
+    if (__ballot(any != 0u) && lane == 0) s_any = 1u;
+    if (l == 0u) { for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o, WAVE)); if (lane == 0) atomicMax(&s_max, mx); }
+  }
+  __syncthreads();
+  if (l == 0u && threadIdx.x == 0) atomicMax(max_leaf, s_max);
+  if (!s_any) {
+    if (threadIdx.x == 0) { totals[l] = 0u; totals[FIN_LV + 2 + l] = 0u; }
+    return;
+  }
   uint32_t carry_i = 0, carry_l = 0;
-  for (uint32_t base = 0; base < T; base += 256u) {
+  for (uint32_t base = 0; base < T; base += FO_T) {
     const uint32_t t = base + threadIdx.x;
     uint32_t ci = 0, cl = 0;
-    if (t < T && l < tab[t].nlev) { ci = tab[t].ib[l + 1] - tab[t].ib[l]; cl = tab[t].lb[l + 1] - tab[t].lb[l]; }
+    if (t < T && l < sub_nlev[t]) { ci = tab[t].ib[l + 1] - tab[t].ib[l]; cl = tab[t].lb[l + 1] - tab[t].lb[l]; }
     uint32_t ii = ci, il = cl;
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -2076,7 +2400,7 @@ __global__ void __launch_bounds__(256) k_fin_offsets(const FinTab* __restrict__ 
     if (lane == WAVE - 1) { s_w[wv][0] = ii; s_w[wv][1] = il; }
     __syncthreads();
     uint32_t bi = carry_i, bl = carry_l, ti = 0, tl = 0;
-    for (uint32_t w = 0; w < 256 / WAVE; w++) { if (w < wv) { bi += s_w[w][0]; bl += s_w[w][1]; } ti += s_w[w][0]; tl += s_w[w][1]; }
+    for (uint32_t w = 0; w < FO_T / WAVE; w++) { if (w < wv) { bi += s_w[w][0]; bl += s_w[w][1]; } ti += s_w[w][0]; tl += s_w[w][1]; }
     if (t < T) { off[t].io[l] = bi + ii - ci; off[t].lo[l] = bl + il - cl; }      // relative to the level's first (k_fin_place adds that)
     carry_i += ti; carry_l += tl;
     __syncthreads();
@@ -2310,11 +2634,16 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     // The level from which every node is finished by one workgroup (k_fin_subtrees): the first at which a balanced node
     // holds at most FIN_HANDOFF points.  TDTK_BUILD_FINISH=0 (lab): level by level to the end.
     uint32_t fin_level = 0xFFFFFFFFu;
+    const uint32_t fin_cap = fin_max_subtrees(M_);
     {
       static const bool fin_env = [] { const char* e = lab_env("TDTK_BUILD_FINISH"); return !(e && e[0] == '0'); }();
       uint32_t L = 0;
-      while ((M_ >> L) > FIN_HANDOFF) L++;
-      if (fin_env && no_finish == 0 && bucket >= 6 && L < 31 && (1u << L) <= FIN_MAX_SUBTREES && !big_dbg_all) fin_level = L;
+      // (round 6: a cloud of two million points and more goes on by levels until a balanced node fits a wave's finisher --
+      //  two or three more levels of launches against most of the workgroup finisher's time; TDTK_BUILD_HANDOFF, lab)
+      static const uint32_t handoff_env = [] { const char* e = lab_env("TDTK_BUILD_HANDOFF"); return e ? (uint32_t)atoi(e) : 0u; }();
+      const uint32_t handoff = handoff_env ? handoff_env : (M_ >= FIN_HANDOFF_WAVE_FROM ? FIN_HANDOFF_WAVE : FIN_HANDOFF);
+      while ((M_ >> L) > handoff) L++;
+      if (fin_env && no_finish == 0 && bucket >= 6 && L < 31 && (1u << L) <= fin_cap && !big_dbg_all) fin_level = L;
     }
     if (fin_level != 0xFFFFFFFFu) batch = fin_level;
     // The host's looks at the device land in pinned memory when the caller has some (a copy into pageable memory is a
@@ -2339,11 +2668,11 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         have_max = false;
         const uint32_t h_max[2] = {h_small[4], h_small[5]};
         fin_nodes = h_max[1]; fin_maxn = h_max[0];
-        if (h_max[0] > FIN_LDS && h_max[1] * 2u <= FIN_MAX_SUBTREES && fin_level + 1u < 31u) {
+        if (h_max[0] > FIN_LDS && h_max[1] * 2u <= fin_cap && fin_level + 1u < 31u) {
           fin_level++;              // one more level by its own launches (below), then look again
           known = h_max[1]; known_at = level;
           batch = 1;
-        } else if (h_max[0] > FIN_LDS || h_max[1] > FIN_MAX_SUBTREES) {
+        } else if (h_max[0] > FIN_LDS || h_max[1] > fin_cap) {
           fin_level = 0xFFFFFFFFu;  // too many nodes for the tables: level by level to the end
           known = h_max[1]; known_at = level;
           batch = 2;
@@ -2368,12 +2697,24 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           fa.kind = (uint32_t*)(arena + O[35]); fa.axis = axis; fa.splitval = splitval; fa.irank = (uint32_t*)(arena + O[36]); fa.nleft = nleft;
           fa.nodes_st = (KdNode*)(arena + O[32]); fa.r_st = (double*)(arena + O[33]); fa.leaf_st = (LeafEntry*)(arena + O[34]);
           fa.tab = ftab; fa.bucket = (uint32_t)bucket; fa.small = small;
+          fa.sub_nlev = (uint32_t*)(arena + O[41]); fa.sub_maxleaf = (uint32_t*)(arena + O[42]);
           static const bool half_env = [] { const char* e = lab_env("TDTK_BUILD_FINHALF"); return !(e && e[0] == '0'); }();
-          if (half_env && fin_maxn <= FIN_LDS_HALF) hipLaunchKernelGGL(k_fin_subtrees_half, dim3(tmax), dim3(FIN_T), 0, s, fa);
-          else hipLaunchKernelGGL(k_fin_subtrees, dim3(tmax), dim3(FIN_T), 0, s, fa);
+          // subtrees of at most FIN_LDS_HALF points two workgroups to a compute unit, then (if the level has any) the larger ones
+          // ... and in front of both, the subtrees of at most FW_CAP points, a wave each
+          static const bool wave_env = [] { const char* e = lab_env("TDTK_BUILD_FINWAVE"); return !(e && e[0] == '0'); }();
+          fa.n_lo = 0u; fa.skip_big = 1u;
+          fa.dbg_levels = lab_env("TDTK_FW_DEBUG") ? (uint32_t)atoi(lab_env("TDTK_FW_DEBUG")) : 0u;
+          // (by size only when the level has more subtrees than the chip has room for at once: below that the launches would
+          //  run one after the other where one launch runs them side by side -- the dat/ scan 0.97 -> 1.13 ms)
+          const bool staged = tmax > 1024u;
+          if (wave_env && staged) { hipLaunchKernelGGL(k_fin_wave, dim3(cdiv(tmax, FW_WAVES)), dim3(WAVE * FW_WAVES), 0, s, fa); fa.n_lo = FW_CAP; }
+          if (half_env && staged && fin_maxn > fa.n_lo) { hipLaunchKernelGGL(k_fin_subtrees_half, dim3(tmax), dim3(FIN_T), 0, s, fa); fa.n_lo = FIN_LDS_HALF; }
+          fa.skip_big = 0u;
+          if (fin_maxn > fa.n_lo) hipLaunchKernelGGL(k_fin_subtrees, dim3(tmax), dim3(FIN_T), 0, s, fa);
         }
         uint32_t* ftot = (uint32_t*)(arena + O[40]);
-        hipLaunchKernelGGL(k_fin_offsets, dim3(FIN_LV + 1u), dim3(256), 0, s, ftab, foff, lvl + fin_level, ftot);
+        hipLaunchKernelGGL(k_fin_offsets, dim3(FIN_LV + 1u), dim3(FO_T), 0, s, ftab, foff, lvl + fin_level, ftot, (const uint32_t*)(arena + O[41]),
+                           (const uint32_t*)(arena + O[42]), small + 1);
         hipLaunchKernelGGL(k_fin_place, dim3(tmax), dim3(256), 0, s, ftab, foff, ftot, roots, lvl + fin_level, (const KdNode*)(arena + O[32]),
                            (const double*)(arena + O[33]), (const LeafEntry*)(arena + O[34]), nodes, node_r, leaf_tab, small + 0);
         level = fin_level + FIN_LV + 2u;
@@ -2397,7 +2738,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           uint32_t ph[10];
           if (hipMemcpy(ph, small + 16, sizeof ph, hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "FIN_TRACE subtree 0 (100 MHz ticks -> us):");
-            const char* nm[10] = {"", "measure", "decide", "rank", "emit+count", "mark+children", "scan", "swaplist", "swap+relabel", ""};
+            const char* nm[10] = {"", "measure (wave: measure+emit)", "decide (wave: scan)", "rank (wave: children+swap)", "emit+count (wave: write-back)", "mark+children", "scan", "swaplist", "swap+relabel", ""};
             for (int k = 1; k < 9; k++) fprintf(stderr, " %s %.1f", nm[k], ph[k] / 100.0);
             fprintf(stderr, "\n");
           }
@@ -2487,6 +2828,12 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           void* tmpb = use4 ? tmp4 : (use3 ? tmp3 : tmp2);
           BCHK(hipEventRecord(side->e1, s));
           BCHK(hipStreamWaitEvent(sb, side->e1, 0));
+          // from the sixth level on (a balanced node's chain: M / 32 adds of 4.2 ns, a seventh of what the build takes) the
+          // exact sums are plain chains (TDTK_BUILD_CHAINFROM, lab: another level; 99: never)
+          static const uint32_t chain_from = [] { const char* e = lab_env("TDTK_BUILD_CHAINFROM"); return e ? (uint32_t)atoi(e) : 5u; }();
+          if (level >= chain_from) {
+            hipLaunchKernelGGL(k_chain_exact, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz, L.exact, L.axis, big_min);
+          } else {
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, sb, L.segs, L.seg_of, sx, sy, sz, M,
                              nblocks, L.pieces, L.prein, big_min);
           size_t stb = scan_tmp;
@@ -2500,6 +2847,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, sb, L.own, L.comp, (uint32_t)nsl1, L.wlist);
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz,
                              nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg, big_min);
+          }
         } else if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, s, segs, seg_of, cx, cy, cz, M,
@@ -2790,9 +3138,11 @@ static size_t build_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(std::max(scan_pair27_state_bytes(n1), part_state_bytes(n1)));        // 31 state of the one-launch scans (sort.hip's, k_part_scan's)
   // subtrees finished by one workgroup each (k_fin_*): staging of their records, their own kind / rank arrays, tables
   take(sizeof(KdNode) * n1); take(sizeof(double) * n1); take(sizeof(LeafEntry) * n1);   // 32 33 34
-  take(4 * (n1 + FIN_MAX_SUBTREES)); take(4 * (n1 + FIN_MAX_SUBTREES));                // 35 36 kind, irank
-  take(sizeof(BSeg) * FIN_MAX_SUBTREES); take(sizeof(FinTab) * FIN_MAX_SUBTREES); take(sizeof(FinOff) * FIN_MAX_SUBTREES);   // 37 38 39
+  const size_t fcap = fin_max_subtrees(M);
+  take(4 * (n1 + fcap)); take(4 * (n1 + fcap));                                        // 35 36 kind, irank
+  take(sizeof(BSeg) * fcap); take(sizeof(FinTab) * fcap); take(sizeof(FinOff) * fcap);   // 37 38 39
   take(4 * 2 * (FIN_LV + 2));                                                          // 40 the levels' totals
+  take(4 * fcap); take(4 * fcap);                                                      // 41 42 the subtrees' depths, their largest buckets
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
 }
