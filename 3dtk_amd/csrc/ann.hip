@@ -31,6 +31,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "kernels.h"
+#include "part_scan.h"
 
 namespace tdtk {
 
@@ -416,6 +417,119 @@ __global__ void k_ann_swap(const uint32_t* __restrict__ posL, const uint32_t* __
   t = cx[a]; cx[a] = cx[b]; cx[b] = t;
   t = cy[a]; cy[a] = cy[b]; cy[b] = t;
   t = cz[a]; cz[a] = cz[b]; cz[b] = t;
+}
+
+// ---- a Hoare pass in TWO passes over the points (round 6; build.hip, k_part_scan, has the argument) -----------------------
+// Pass 1 of annPlaneSplit works on the whole cell with "below the cutting value", pass 2 on what lies right of br1 with
+// "not above it"; both counts are known (k_ann_count), so a pass is: one segmented scan of the "stays right" flags that
+// writes the run's index list (those from the front in order, the others from the back), then the swaps driven from the
+// list's front part.  misplaced + scan + swap list + swap were four passes over the points and two 8-byte words per point.
+template <int PASS>
+__global__ void __launch_bounds__(PS_THREADS) k_ann_part_scan(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
+                                                              const ADec* __restrict__ dec, const unsigned long long* __restrict__ cnt,
+                                                              const double* __restrict__ cx, const double* __restrict__ cy,
+                                                              const double* __restrict__ cz, uint32_t M, uint32_t* __restrict__ list,
+                                                              unsigned long long* __restrict__ status, uint32_t* __restrict__ counter,
+                                                              uint32_t epoch, uint32_t ntiles, uint32_t* __restrict__ err,
+                                                              uint32_t* __restrict__ eq_flag)
+{
+  if (PASS == 2 && eq_flag != nullptr && *eq_flag == 0u) return;     // (no cell of the level has points on its plane: see k_ann_misplaced)
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const uint32_t tile = ps_draw_tile(counter, ntiles);
+  const uint32_t wbase = tile * PS_TILE + wv * (WAVE * PS_ROWS) + lane;
+  uint32_t sg[PS_ROWS], geb[PS_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < PS_ROWS; r++) { const uint32_t p = wbase + r * WAVE; sg[r] = (p < M) ? seg_of[p] : NOSEG; }
+  uint32_t gebits = 0u, headbits = 0u, actbits = 0u;
+  {
+    uint32_t cds[PS_ROWS], sts[PS_ROWS];
+    unsigned long long cns[PS_ROWS];
+    double c[PS_ROWS], cvs[PS_ROWS];
+    bool any_eq = false;
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROWS; r++) {
+      cds[r] = 0u; cvs[r] = 0.0; sts[r] = 0u; cns[r] = 0ull;
+      if (sg[r] != NOSEG) { cds[r] = dec[sg[r]].cd; cvs[r] = dec[sg[r]].cv; sts[r] = segs[sg[r]].start; cns[r] = cnt[sg[r]]; }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROWS; r++) {
+      c[r] = 0.0;
+      if (sg[r] != NOSEG) c[r] = coord_of(cx, cy, cz, cds[r], wbase + r * WAVE);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PS_ROWS; r++) {
+      if (sg[r] == NOSEG) continue;
+      const uint32_t rel = wbase + r * WAVE - sts[r], br1 = (uint32_t)cns[r];
+      if (PASS == 1) {
+        if ((uint32_t)(cns[r] >> 32) != 0u) any_eq = true;
+        actbits |= 1u << r;
+        if (!(c[r] < cvs[r])) gebits |= 1u << r;
+        if (rel == 0u) headbits |= 1u << r;
+      } else if (rel >= br1) {
+        actbits |= 1u << r;
+        if (!(c[r] <= cvs[r])) gebits |= 1u << r;
+        if (rel == br1) headbits |= 1u << r;
+      }
+    }
+    if (PASS == 1 && eq_flag != nullptr && any_eq) *eq_flag = 1u;
+  }
+  uint32_t ext = 0u, win = 0u;
+  ps_scan_core(gebits, headbits, tile, status, epoch, err, geb, ext, win);
+#pragma unroll
+  for (uint32_t r = 0; r < PS_ROWS; r++) {
+    if (!((actbits >> r) & 1u)) continue;
+    const uint32_t p = wbase + r * WAVE;
+    const uint32_t g = geb[r] + (((ext >> r) & 1u) ? win : 0u);
+    const uint32_t st = segs[sg[r]].start, n = segs[sg[r]].n;
+    const uint32_t base = st + ((PASS == 1) ? 0u : (uint32_t)cnt[sg[r]]), j = p - base;
+    const bool ge = (gebits >> r) & 1u;
+    list[ge ? (base + g) : (st + n - 1u - (j - g))] = p;
+  }
+}
+#define APW_ROWS 4u
+template <int PASS>
+__global__ void __launch_bounds__(256) k_ann_part_swap(const uint32_t* __restrict__ list, const uint32_t* __restrict__ seg_of,
+                                                       const ASeg* __restrict__ segs, const unsigned long long* __restrict__ cnt,
+                                                       uint32_t M, uint32_t* __restrict__ perm, double* __restrict__ cx,
+                                                       double* __restrict__ cy, double* __restrict__ cz, const uint32_t* __restrict__ gate)
+{
+  if (gate != nullptr && *gate == 0u) return;
+  const uint32_t base0 = blockIdx.x * (256u * APW_ROWS) + threadIdx.x;
+  uint32_t sg[APW_ROWS], a[APW_ROWS], b[APW_ROWS];
+  bool sw[APW_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < APW_ROWS; r++) {
+    const uint32_t p = base0 + r * 256u;
+    sg[r] = (p < M) ? seg_of[p] : NOSEG;
+    a[r] = (p < M) ? list[p] : 0u;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < APW_ROWS; r++) {
+    const uint32_t p = base0 + r * 256u;
+    sw[r] = false; b[r] = 0u;
+    if (sg[r] == NOSEG) continue;
+    const uint32_t st = segs[sg[r]].start, n = segs[sg[r]].n;
+    const unsigned long long cn = cnt[sg[r]];
+    const uint32_t br1 = (uint32_t)cn, br2 = br1 + (uint32_t)(cn >> 32);
+    const uint32_t base = st + ((PASS == 1) ? 0u : br1), bound = st + ((PASS == 1) ? br1 : br2);
+    if (p < base) continue;
+    const uint32_t nge = st + n - bound, j = p - base;          // those that stay right of the boundary
+    if (j < nge && a[r] < bound) { sw[r] = true; b[r] = list[p + nge]; }
+  }
+  uint32_t pa[APW_ROWS], pb[APW_ROWS];
+  double xa[APW_ROWS], xb[APW_ROWS], ya[APW_ROWS], yb[APW_ROWS], za[APW_ROWS], zb[APW_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < APW_ROWS; r++)
+    if (sw[r]) {
+      pa[r] = perm[a[r]]; pb[r] = perm[b[r]];
+      xa[r] = cx[a[r]]; xb[r] = cx[b[r]]; ya[r] = cy[a[r]]; yb[r] = cy[b[r]]; za[r] = cz[a[r]]; zb[r] = cz[b[r]];
+    }
+#pragma unroll
+  for (uint32_t r = 0; r < APW_ROWS; r++)
+    if (sw[r]) {
+      perm[a[r]] = pb[r]; perm[b[r]] = pa[r];
+      cx[a[r]] = xb[r]; cx[b[r]] = xa[r]; cy[a[r]] = yb[r]; cy[b[r]] = ya[r]; cz[a[r]] = zb[r]; cz[b[r]] = za[r];
+    }
 }
 
 static __device__ __forceinline__ void ann_hook(AnnNode* __restrict__ nodes, uint32_t* __restrict__ root_ref,
@@ -954,7 +1068,7 @@ static size_t ann_layout(size_t M, size_t* O, size_t* scan_tmp_out)
   take(bbox_temp_bytes() + 256); take(256);                                  // 20 bbox partials 21 box
   take(sizeof(AMeasU) * nlarge);                                             // 22 meas of the next level
   take(8 * (ANN_MAX_LEVELS + 2));                                            // 23 cells per level; behind them the levels' "points on a plane" flags
-  take(scan_pair27_state_bytes(n1));                                         // 24 state of the one-launch scan (sort.hip)
+  take(std::max(scan_pair27_state_bytes(n1), part_state_bytes(n1)));         // 24 state of the one-launch scans (sort.hip's, k_ann_part_scan's)
   take(sizeof(ASeg) * nlarge);                                               // 25 mid cells (k_ann_mid)
   if (scan_tmp_out) *scan_tmp_out = scan_tmp;
   return off;
@@ -1007,7 +1121,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
   // the partition's scans in one launch each while the positions fit their 27-bit counters (TDTK_OWN_SCAN=0: rocPRIM's two)
   static const bool own_scan_env = [] { const char* e = getenv("TDTK_OWN_SCAN"); return !(e && e[0] == '0'); }();
   const bool own_scan = own_scan_env && n1 < ((size_t)1 << 27);
-  if (own_scan) ACHK(hipMemsetAsync(arena + O[24], 0, scan_pair27_state_bytes(n1), s));
+  if (own_scan) ACHK(hipMemsetAsync(arena + O[24], 0, std::max(scan_pair27_state_bytes(n1), part_state_bytes(n1)), s));
   hipLaunchKernelGGL(k_ann_init, dim3(cdiv(M, 256)), dim3(256), 0, s, d_xyz, M, perm, seg_of, cx, cy, cz, small + 2, mid_cap);
   ACHK(launch_bbox(d_xyz, M, partial, box, s));
   hipLaunchKernelGGL(k_ann_root, dim3(1), dim3(1), 0, s, box, M, segs, small_list, small, bb, meas, cnt, lvl, mid_list, mid_cap);
@@ -1029,6 +1143,24 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
       for (int pass = 1; pass <= 2; pass++) {
         // (the gate needs every kernel of the pass to honour it: with rocPRIM's scan, which does not, the pass runs ungated)
         const bool one_launch = own_scan && 2u * level + (uint32_t)pass < 255u;
+        static const bool part2_env = [] { const char* e = lab_env("TDTK_ANN_PART"); return !(e && e[0] == '0'); }();   // (lab, 0: round 3's four launches)
+        if (part2_env && one_launch) {
+          // a Hoare pass = a scan that writes the index list + the swaps
+          const uint32_t ntiles = cdiv(M, PS_TILE), nbw = cdiv(M, 256u * APW_ROWS);
+          uint32_t* counter = reinterpret_cast<uint32_t*>(arena + O[24]);
+          unsigned long long* status = reinterpret_cast<unsigned long long*>(arena + O[24] + 64);
+          uint32_t* const flag = eqf + level;
+          if (pass == 1) {
+            hipLaunchKernelGGL(k_ann_part_scan<1>, dim3(ntiles), dim3(PS_THREADS), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, posL, status, counter,
+                               2u * level + 1u, ntiles, small + 2, (2u * level + 2u < 255u) ? flag : (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_ann_part_swap<1>, dim3(nbw), dim3(256), 0, s, posL, seg_of, segs, cnt, M, perm, cx, cy, cz, (const uint32_t*)nullptr);
+          } else {
+            hipLaunchKernelGGL(k_ann_part_scan<2>, dim3(ntiles), dim3(PS_THREADS), 0, s, seg_of, segs, dec, cnt, cx, cy, cz, M, posL, status, counter,
+                               2u * level + 2u, ntiles, small + 2, flag);
+            hipLaunchKernelGGL(k_ann_part_swap<2>, dim3(nbw), dim3(256), 0, s, posL, seg_of, segs, cnt, M, perm, cx, cy, cz, (const uint32_t*)flag);
+          }
+          continue;
+        }
         uint32_t* const flag = one_launch ? eqf + level : nullptr;
         const uint32_t* const gate = (pass == 2) ? flag : nullptr;
         if (pass == 1)

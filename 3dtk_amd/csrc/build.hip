@@ -27,6 +27,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "kernels.h"
+#include "part_scan.h"
 
 namespace tdtk {
 
@@ -1471,13 +1472,6 @@ __global__ void k_swap_relabel(const uint32_t* __restrict__ posL, const uint32_t
 // (s, n, nleft) with j < n - nleft holds a = list[s + j], the j-th ge element; it is misplaced iff a < s + nleft, and
 // its partner is list[s + (n - nleft) + j] -- both reads coalesced; the same thread gives position s + j its label
 // of the next level.  12 + 4 bytes read and 4 written per point in pass 1, 8 + 4 in pass 2 plus the swaps themselves.
-#define PS_ROWS 8u
-#define PS_THREADS 512u
-#define PS_TILE (PS_THREADS * PS_ROWS)
-__device__ __forceinline__ unsigned long long ps_pack(uint32_t cnt, uint32_t seen, uint32_t flag, uint32_t epoch)
-{
-  return ((unsigned long long)flag << 62) | ((unsigned long long)epoch << 54) | ((unsigned long long)seen << 53) | (unsigned long long)(cnt & 0x7FFFFFFu);
-}
 size_t part_state_bytes(size_t n) { return 8 * ((n + PS_TILE - 1) / PS_TILE + 1) + 64; }
 __global__ void __launch_bounds__(PS_THREADS) k_part_scan(const uint32_t* __restrict__ seg_of, const uint32_t* __restrict__ kind,
                                                    const BSeg* __restrict__ segs, const uint32_t* __restrict__ axis,
@@ -1487,15 +1481,8 @@ __global__ void __launch_bounds__(PS_THREADS) k_part_scan(const uint32_t* __rest
                                                    unsigned long long* __restrict__ status, uint32_t* __restrict__ counter,
                                                    uint32_t epoch, uint32_t ntiles, uint32_t* __restrict__ err)
 {
-  __shared__ uint32_t s_tile, s_wcnt[PS_THREADS / WAVE], s_wseen[PS_THREADS / WAVE], s_in;
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  if (tid == 0) {
-    const uint32_t t = atomicAdd(counter, 1u);           // tiles numbered in the order their workgroups start: a tile
-    if (t == ntiles - 1u) atomicExch(counter, 0u);       // only ever waits for tiles that are running
-    s_tile = t;
-  }
-  __syncthreads();
-  const uint32_t tile = s_tile;
+  const uint32_t tile = ps_draw_tile(counter, ntiles);
   const uint32_t wbase = tile * PS_TILE + wv * (WAVE * PS_ROWS) + lane;   // row r of this wave: wbase + 64 r
   uint32_t sg[PS_ROWS], geb[PS_ROWS];
 #pragma unroll
@@ -1526,73 +1513,8 @@ __global__ void __launch_bounds__(PS_THREADS) k_part_scan(const uint32_t* __rest
       if (wbase + r * WAVE == st[r]) headbits |= 1u << r;
     }
   }
-  // the wave's rows in order: ballots, and a count carried from row to row (wave-uniform)
-  const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
-  uint32_t carry = 0u, seen = 0u, ext = 0u;
-#pragma unroll
-  for (uint32_t r = 0; r < PS_ROWS; r++) {
-    const unsigned long long gm = __ballot((gebits >> r) & 1u), hm = __ballot((headbits >> r) & 1u);
-    const unsigned long long hb = hm & le_mask;
-    if (hb) {
-      const int hl = 63 - __clzll((long long)hb);
-      geb[r] = (uint32_t)__popcll(gm & lt_mask & ~((1ull << hl) - 1ull));
-    } else {
-      geb[r] = carry + (uint32_t)__popcll(gm & lt_mask);
-      if (!seen) ext |= 1u << r;                          // the node started in front of this wave: + what comes in
-    }
-    if (hm) { const int hl = 63 - __clzll((long long)hm); carry = (uint32_t)__popcll(gm >> hl); seen = 1u; }
-    else carry += (uint32_t)__popcll(gm);
-  }
-  if (lane == 0) { s_wcnt[wv] = carry; s_wseen[wv] = seen; }
-  __syncthreads();
-  if (wv == 0) {
-    // the tile's aggregate: the count since the last node start in it (or all of it), and whether there was one
-    uint32_t tcnt = 0u, tseen = 0u;
-#pragma unroll
-    for (uint32_t w = 0; w < PS_THREADS / WAVE; w++) { if (s_wseen[w]) { tcnt = s_wcnt[w]; tseen = 1u; } else tcnt += s_wcnt[w]; }
-    uint32_t incoming = 0u;
-    if (tile == 0) {
-      if (lane == 0) __hip_atomic_store(&status[0], ps_pack(tcnt, 1u, 2u, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (lane == 0) __hip_atomic_store(&status[tile], ps_pack(tcnt, tseen, tseen ? 2u : 1u, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int pos = (int)tile - 1;
-      uint32_t spins = 0;
-      for (;;) {
-        const int idx = pos - (int)lane;
-        const unsigned long long w = (idx >= 0) ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                : ps_pack(0u, 1u, 2u, epoch);      // in front of the first tile: nothing
-        const bool valid = ((uint32_t)(w >> 54) & 0xFFu) == epoch && (w >> 62) != 0ull;
-        // the nearest predecessor that is final (its count since a node start is known, or a node starts in it) ends
-        // the look-back; everything nearer must have its aggregate out
-        const unsigned long long pm = __ballot(valid && (w >> 62) == 2ull);
-        const unsigned long long vm = __ballot(valid);
-        const int p = pm ? (__ffsll((long long)pm) - 1) : 64;
-        const unsigned long long need = (p >= 64) ? ~0ull : ((2ull << p) - 1ull);
-        if ((vm & need) != need) {
-          if (++spins > (1u << 22)) { if (lane == 0) atomicOr(err, 0x10000u); break; }
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        uint32_t part = ((int)lane <= p) ? (uint32_t)(w & 0x7FFFFFFull) : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, WAVE);
-        incoming += part;
-        if (p < 64) break;
-        pos -= WAVE;
-      }
-      // a tile in which no node starts is final only now: the count at its end since the node start in front of it
-      if (lane == 0 && !tseen) __hip_atomic_store(&status[tile], ps_pack(incoming + tcnt, 0u, 2u, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) s_in = incoming;
-  }
-  __syncthreads();
-  // what comes into this wave: the waves in front of it back to a node start, the tile's incoming count behind them
-  uint32_t win = 0u;
-  {
-    bool open = true;
-    for (int w = (int)wv - 1; w >= 0 && open; w--) { win += s_wcnt[w]; if (s_wseen[w]) open = false; }
-    if (open) win += s_in;
-  }
+  uint32_t ext = 0u, win = 0u;
+  ps_scan_core(gebits, headbits, tile, status, epoch, err, geb, ext, win);
 #pragma unroll
   for (uint32_t r = 0; r < PS_ROWS; r++) {
     if (sg[r] == 0xFFFFFFFFu) continue;
