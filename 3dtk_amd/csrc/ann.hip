@@ -1143,7 +1143,7 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
       for (int pass = 1; pass <= 2; pass++) {
         // (the gate needs every kernel of the pass to honour it: with rocPRIM's scan, which does not, the pass runs ungated)
         const bool one_launch = own_scan && 2u * level + (uint32_t)pass < 255u;
-        static const bool part2_env = [] { const char* e = lab_env("TDTK_ANN_PART"); return !(e && e[0] == '0'); }();   // (lab, 0: round 3's four launches)
+        const bool part2_env = [] { const char* e = lab_env("TDTK_ANN_PART"); return !(e && e[0] == '0'); }();   // (lab, 0: round 3's four launches)
         if (part2_env && one_launch) {
           // a Hoare pass = a scan that writes the index list + the swaps
           const uint32_t ntiles = cdiv(M, PS_TILE), nbw = cdiv(M, 256u * APW_ROWS);

@@ -577,7 +577,7 @@ static int tree_from_device_points(Ctx* c, tdtk_tree* t, size_t M, int bucket_si
     HIPCHK(hipEventCreateWithFlags(&c->e_b3, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->e_b4, hipEventDisableTiming));
   }
-  static const bool four = [] { const char* e = lab_env("TDTK_BUILD_STREAMS"); return !(e && e[0] == '3'); }();   // (lab: TDTK_BUILD_STREAMS=3: round 5's two side streams)
+  const bool four = [] { const char* e = lab_env("TDTK_BUILD_STREAMS"); return !(e && e[0] == '3'); }();   // (lab: TDTK_BUILD_STREAMS=3: round 5's two side streams)
   const BuildSide side = {alone ? c->stream_b : nullptr, alone ? c->stream_c : nullptr, c->e_b1, c->e_b2, c->e_b3, c->h_build,
                           (alone && four) ? c->stream_d : nullptr, c->e_b4};
   DevBuildResult r = device_build_tree(c->ws[WS_TMPA].as<double>(), M, bucket_size, c->ws[WS_ARENA].p, c->stream, &side);

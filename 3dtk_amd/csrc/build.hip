@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) k_measure_node(const BSeg* __restrict__ s
 #define BIG_LEVEL_MAX 49152u
 static uint32_t build_big_level_min(size_t M)
 {
-  static const bool grow_env = [] { const char* e = lab_env("TDTK_BUILD_BIGGROW"); return !(e && e[0] == '0'); }();
+  const bool grow_env = [] { const char* e = lab_env("TDTK_BUILD_BIGGROW"); return !(e && e[0] == '0'); }();
   static const bool small_env = [] { const char* e = lab_env("TDTK_BUILD_BIGMIN"); return !(e && e[0] == '0'); }();
   if (small_env && M <= (size_t)BIG_MIN_SMALL * 16u) return BIG_MIN_SMALL / 2u;
   if (!grow_env) return BIG_MIN / 2u;
@@ -2562,7 +2562,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       uint32_t L = 0;
       // (round 6: a cloud of two million points and more goes on by levels until a balanced node fits a wave's finisher --
       //  two or three more levels of launches against most of the workgroup finisher's time; TDTK_BUILD_HANDOFF, lab)
-      static const uint32_t handoff_env = [] { const char* e = lab_env("TDTK_BUILD_HANDOFF"); return e ? (uint32_t)atoi(e) : 0u; }();
+      const uint32_t handoff_env = [] { const char* e = lab_env("TDTK_BUILD_HANDOFF"); return e ? (uint32_t)atoi(e) : 0u; }();
       const uint32_t handoff = handoff_env ? handoff_env : (M_ >= FIN_HANDOFF_WAVE_FROM ? FIN_HANDOFF_WAVE : FIN_HANDOFF);
       while ((M_ >> L) > handoff) L++;
       if (fin_env && no_finish == 0 && bucket >= 6 && L < 31 && (1u << L) <= fin_cap && !big_dbg_all) fin_level = L;
@@ -2620,10 +2620,10 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           fa.nodes_st = (KdNode*)(arena + O[32]); fa.r_st = (double*)(arena + O[33]); fa.leaf_st = (LeafEntry*)(arena + O[34]);
           fa.tab = ftab; fa.bucket = (uint32_t)bucket; fa.small = small;
           fa.sub_nlev = (uint32_t*)(arena + O[41]); fa.sub_maxleaf = (uint32_t*)(arena + O[42]);
-          static const bool half_env = [] { const char* e = lab_env("TDTK_BUILD_FINHALF"); return !(e && e[0] == '0'); }();
+          const bool half_env = [] { const char* e = lab_env("TDTK_BUILD_FINHALF"); return !(e && e[0] == '0'); }();
           // subtrees of at most FIN_LDS_HALF points two workgroups to a compute unit, then (if the level has any) the larger ones
           // ... and in front of both, the subtrees of at most FW_CAP points, a wave each
-          static const bool wave_env = [] { const char* e = lab_env("TDTK_BUILD_FINWAVE"); return !(e && e[0] == '0'); }();
+          const bool wave_env = [] { const char* e = lab_env("TDTK_BUILD_FINWAVE"); return !(e && e[0] == '0'); }();
           fa.n_lo = 0u; fa.skip_big = 1u;
           fa.dbg_levels = lab_env("TDTK_FW_DEBUG") ? (uint32_t)atoi(lab_env("TDTK_FW_DEBUG")) : 0u;
           // (by size only when the level has more subtrees than the chip has room for at once: below that the launches would
@@ -2752,7 +2752,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(hipStreamWaitEvent(sb, side->e1, 0));
           // from the sixth level on (a balanced node's chain: M / 32 adds of 4.2 ns, a seventh of what the build takes) the
           // exact sums are plain chains (TDTK_BUILD_CHAINFROM, lab: another level; 99: never)
-          static const uint32_t chain_from = [] { const char* e = lab_env("TDTK_BUILD_CHAINFROM"); return e ? (uint32_t)atoi(e) : 5u; }();
+          const uint32_t chain_from = [] { const char* e = lab_env("TDTK_BUILD_CHAINFROM"); return e ? (uint32_t)atoi(e) : 5u; }();
           if (level >= chain_from) {
             hipLaunchKernelGGL(k_chain_exact, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz, L.exact, L.axis, big_min);
           } else {
@@ -2806,7 +2806,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         }
         // the partition pass (with no internal node at this level it moves nothing): two passes over the points while the
         // one-launch scan's conditions hold (TDTK_BUILD_PART=0, lab: round 3's five)
-        static const bool part2_env = [] { const char* e = lab_env("TDTK_BUILD_PART"); return !(e && e[0] == '0'); }();
+        const bool part2_env = [] { const char* e = lab_env("TDTK_BUILD_PART"); return !(e && e[0] == '0'); }();
         if (part2_env && own_scan && level < 255u) {
           const uint32_t ntiles = cdiv(M, PS_TILE), nbw = cdiv(M, 256u * PW_ROWS);
           uint32_t* counter = reinterpret_cast<uint32_t*>(arena + o_scanstate);

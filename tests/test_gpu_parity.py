@@ -1129,6 +1129,41 @@ def test_device_tree_build_full_size(tdtk, gpu, k5):
     assert tdtk.KDtree(big, 20).verify() == [0, 0, 0, 0]
 
 
+@pytest.mark.parametrize("shape", ["uniform", "lopsided", "repeated"])
+def test_device_tree_build_of_millions_by_subtree_size(tdtk, gpu, shape):
+    """Round 6: from two million points on the levels run until a balanced node holds <= 384 points (the partition of a
+    level in two passes: k_part_scan's segmented look-back scan + k_part_swap) and the subtrees are finished by size --
+    k_fin_wave (one wave per subtree of <= 512 points), k_fin_subtrees_half (<= 1792), k_fin_subtrees (<= 3584).  A uniform
+    cloud is all waves; a lopsided one (a dense cluster inside a sparse field: the hand-over level's largest node several
+    times its average) needs all three launches; coordinates that repeat put points ON splitting planes.  The tree is the
+    host builder's, record for record, and a second tree built in the same context (the arena reused) is too."""
+    rng = np.random.default_rng(606)
+    n = 2200000
+    if shape == "uniform":
+        p = rng.uniform(-1000.0, 1000.0, (n, 3))
+    elif shape == "lopsided":
+        p = np.concatenate([rng.uniform(-1000.0, 1000.0, (n - 600000, 3)), rng.normal(0.0, 6.0, (600000, 3)) + [300.0, -200.0, 50.0]])
+        p = p[rng.permutation(len(p))]
+    else:
+        p = np.round(rng.uniform(-1000.0, 1000.0, (n, 3)), 1)
+    kd = tdtk.KDtree(np.ascontiguousarray(p), 20)
+    assert kd.verify() == [0, 0, 0, 0]
+    assert tdtk.KDtree(np.ascontiguousarray(p[: n // 2]), 7).verify() == [0, 0, 0, 0]
+
+
+def test_lab_switches_of_the_round6_tree_build_give_the_same_tree(tdtk, gpu, lab, monkeypatch):
+    """The lab library's switches back to round 5's build -- five partition passes (TDTK_BUILD_PART=0), the workgroup
+    finisher alone (TDTK_BUILD_FINWAVE=0, TDTK_BUILD_FINHALF=0), the hand-over at 2048-point nodes, the piecewise path for
+    every speculated level (TDTK_BUILD_CHAINFROM=99), two side streams -- each give the host builder's tree as well."""
+    p = np.random.default_rng(607).uniform(-500.0, 500.0, (2100000, 3))
+    for kv in ("TDTK_BUILD_PART=0", "TDTK_BUILD_FINWAVE=0", "TDTK_BUILD_FINHALF=0", "TDTK_BUILD_HANDOFF=2048", "TDTK_BUILD_CHAINFROM=99",
+               "TDTK_BUILD_STREAMS=3", "TDTK_BUILD_BIGGROW=0"):
+        k, v = kv.split("=")
+        monkeypatch.setenv(k, v)
+        assert tdtk.KDtree(p, 20).verify() == [0, 0, 0, 0], kv
+        monkeypatch.delenv(k)
+
+
 def _stress_clouds(n, seed=12):
     """clouds chosen to break the piecewise centroid sum of the device tree build (build.hip, k_big_*): exact rounding
     ties, sums that wander through zero, huge dynamic range, values at both ends of the exponent range"""
