@@ -860,6 +860,16 @@ struct BPart { double lo[3], hi[3], sum[3]; };
 #define SPEC_SLOTS 14          // buffers per speculated level (spec_layout)
 struct BSpecAll { BSpecLevel L[BIG_SPEC_MAX]; int n; };
 
+// (a kernel's by-value argument block read through the kernarg segment pointer: see kernarg_block in kernels.hip)
+template <class T>
+__device__ __forceinline__ const T& build_kernarg_block()
+{
+  typedef const T __attribute__((address_space(4))) * kernarg_ptr;
+  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const T*)p;
+}
+
 // What the cut needs, and nothing else (round 3, second step): bounds and plain sums of the big nodes in two short
 // passes -- per block of 512 positions, then per node over its blocks -- instead of the piece statistics and their
 // prefix scan, which only the exact chain needs and which now run with it on the second stream.
@@ -1043,49 +1053,64 @@ __device__ __forceinline__ void spec_keep_at(const BLevel* __restrict__ lv, cons
 // split value (the points are where the finished build left them; a node's points are still the run [start, start + n)).
 // A workgroup covers 1024 consecutive positions: one search for the node of its first position, then every thread steps
 // forward from there (the nodes of a level ascend; a big level's nodes are thousands of positions long).
-__global__ void __launch_bounds__(256) k_spec_count(BSpecAll S, const BLevel* __restrict__ lvl, const double* __restrict__ cx,
+__global__ void __launch_bounds__(256) k_spec_count(BSpecAll S_by_value, const BLevel* __restrict__ lvl, const double* __restrict__ cx,
                                                     const double* __restrict__ cy, const double* __restrict__ cz, uint32_t M)
 {
+  // (round 6: every speculated level in one pass -- the workgroup's 1024 positions are read once, x, y and z, and looked
+  //  at level by level; a pass per level read the coordinates eight times over: 413 us of a 10M-point build)
+  (void)S_by_value;
+  const BSpecAll& S = build_kernarg_block<BSpecAll>();
   __shared__ uint32_t s_first, s_cnt;
-  const BSpecLevel& L = S.L[blockIdx.y];
-  const uint32_t nseg = lvl[L.level].nseg;
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   const uint32_t p0 = blockIdx.x * 1024u;
-  if (nseg == 0 || p0 >= M) return;
-  if (threadIdx.x == 0) {
-    uint32_t lo = 0, hi = nseg;                       // last node with start <= p0
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.segs[mid].start <= p0) lo = mid; else hi = mid; }
-    s_first = lo; s_cnt = 0u;
-  }
-  __syncthreads();
-  const uint32_t first = s_first;      // its count is gathered in LDS: at the top levels every workgroup adds to the same node
-  uint32_t at = first;
+  if (p0 >= M) return;
+  double X[4], Y[4], Z[4];
+#pragma unroll
   for (int r = 0; r < 4; r++) {
-    const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
-    uint32_t i = 0xFFFFFFFFu;
-    bool lt = false;
-    if (p < M) {
-      while (at + 1u < nseg && L.segs[at + 1u].start <= p) ++at;
-      const BSeg sg = L.segs[at];
-      if (p >= sg.start && p - sg.start < sg.n && L.node[at] != 0xFFFFFFFFu) {
-        i = at;
-        const uint32_t ax = L.axis[at];
-        const double v = (ax == 0) ? cx[p] : ((ax == 1) ? cy[p] : cz[p]);
-        lt = v < L.exact[at].mean[ax];
+    const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x, g = (p < M) ? p : M - 1u;
+    X[r] = cx[g]; Y[r] = cy[g]; Z[r] = cz[g];
+  }
+  for (int ly = 0; ly < S.n; ly++) {
+    const BSpecLevel& L = S.L[ly];
+    const uint32_t nseg = lvl[L.level].nseg;
+    if (nseg == 0) continue;
+    if (threadIdx.x == 0) {
+      uint32_t lo = 0, hi = nseg;                       // last node with start <= p0
+      while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (L.segs[mid].start <= p0) lo = mid; else hi = mid; }
+      s_first = lo; s_cnt = 0u;
+    }
+    __syncthreads();
+    const uint32_t first = s_first;      // its count is gathered in LDS: at the top levels every workgroup adds to the same node
+    uint32_t at = first;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t p = p0 + (uint32_t)r * 256u + threadIdx.x;
+      uint32_t i = 0xFFFFFFFFu;
+      bool lt = false;
+      if (p < M) {
+        while (at + 1u < nseg && L.segs[at + 1u].start <= p) ++at;
+        const BSeg sg = L.segs[at];
+        if (p >= sg.start && p - sg.start < sg.n && L.node[at] != 0xFFFFFFFFu) {
+          i = at;
+          const uint32_t ax = L.axis[at];
+          const double v = (ax == 0) ? X[r] : ((ax == 1) ? Y[r] : Z[r]);
+          lt = v < L.exact[at].mean[ax];
+        }
+      }
+      unsigned long long todo = __ballot(i != 0xFFFFFFFFu);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t cur = __shfl(i, leader, WAVE);
+        const bool mine = (i == cur);
+        const uint32_t add = (uint32_t)__popcll(__ballot(mine && lt));
+        if (lane == (uint32_t)leader && add) { if (cur == first) atomicAdd(&s_cnt, add); else atomicAdd(&L.cnt[cur], add); }
+        todo &= ~__ballot(mine);
       }
     }
-    unsigned long long todo = __ballot(i != 0xFFFFFFFFu);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const uint32_t cur = __shfl(i, leader, WAVE);
-      const bool mine = (i == cur);
-      const uint32_t add = (uint32_t)__popcll(__ballot(mine && lt));
-      if (lane == (uint32_t)leader && add) { if (cur == first) atomicAdd(&s_cnt, add); else atomicAdd(&L.cnt[cur], add); }
-      todo &= ~__ballot(mine);
-    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&L.cnt[first], s_cnt);
+    __syncthreads();
   }
-  __syncthreads();
-  if (threadIdx.x == 0 && s_cnt) atomicAdd(&L.cnt[first], s_cnt);
 }
 // part 2: the counts must be the build's; the records get the exact split values
 __global__ void k_spec_patch(BSpecAll S, const BLevel* __restrict__ lvl, KdNode* __restrict__ nodes, uint32_t* __restrict__ err)
@@ -1747,15 +1772,6 @@ struct FinArgs {
   uint32_t dbg_levels;          // lab (TDTK_FW_DEBUG=k): k_fin_wave stops after k - 1 levels -- a timing probe, the tree is not valid
   uint32_t n_lo, skip_big;      // this launch takes the subtrees of more than n_lo points; skip_big: ... and leaves those beyond its capacity to the next
 };
-// (a kernel's by-value argument block read through the kernarg segment pointer: see kernarg_block in kernels.hip)
-template <class T>
-__device__ __forceinline__ const T& build_kernarg_block()
-{
-  typedef const T __attribute__((address_space(4))) * kernarg_ptr;
-  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  return *(const T*)p;
-}
 
 // One subtree, root to buckets, by one workgroup.  Coordinates, labels (which node of the current level a position belongs
 // to), the partition's scratch and the level's node table are in LDS; the node / bucket records and the per-node arrays
@@ -2647,7 +2663,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(hipStreamWaitEvent(s, side->e2, 0));
           if (side->s3) { BCHK(hipEventRecord(side->e3, side->s3)); BCHK(hipStreamWaitEvent(s, side->e3, 0)); }
           if (side->s4) { BCHK(hipEventRecord(side->e4, side->s4)); BCHK(hipStreamWaitEvent(s, side->e4, 0)); }
-          hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
+          hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024)), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
           hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
         }
         hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
@@ -2890,7 +2906,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       BCHK(hipStreamWaitEvent(s, side->e2, 0));
       if (side->s3) { BCHK(hipEventRecord(side->e3, side->s3)); BCHK(hipStreamWaitEvent(s, side->e3, 0)); }
           if (side->s4) { BCHK(hipEventRecord(side->e4, side->s4)); BCHK(hipStreamWaitEvent(s, side->e4, 0)); }
-      hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024), (uint32_t)SP.n), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
+      hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024)), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
       hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
       BCHK(hipMemcpyAsync(&h_spec_err, small + 3, 4, hipMemcpyDeviceToHost, s));
     }
