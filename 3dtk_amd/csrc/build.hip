@@ -2658,6 +2658,8 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
         level = fin_level + FIN_LV + 2u;
         // what follows the levels does not wait for the host's look: the check of the speculated cuts and the point array
         // are enqueued now, their results come back with the level counters
+        // (the point array first: it does not need the exact sums, and at a million points the build is waiting for the root's)
+        hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
         if (spec && SP.n) {
           BCHK(hipEventRecord(side->e2, side->s2));
           BCHK(hipStreamWaitEvent(s, side->e2, 0));
@@ -2666,7 +2668,6 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           hipLaunchKernelGGL(k_spec_count, dim3(cdiv(M, 1024)), dim3(256), 0, s, SP, lvl, cx, cy, cz, M);
           hipLaunchKernelGGL(k_spec_patch, dim3(4), dim3(256), 0, s, SP, lvl, nodes, small + 3);
         }
-        hipLaunchKernelGGL(k_points, dim3(cdiv(M, 256)), dim3(256), 0, s, perm, cx, cy, cz, M, pts);
         tail_enqueued = true;
         BCHK(hipMemcpyAsync(hl, lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
         BCHK(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, s));
