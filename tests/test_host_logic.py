@@ -942,6 +942,80 @@ def test_product_and_bench_keep_clear_of_the_oracle():
         assert fn == "cpu_baseline_nn" or "no_cpu" in ctx[ctx.rfind("if "):], (fn, m.group(0))
 
 
+def _hoare(vals, pred):
+    """the in-place loop of ANN's annPlaneSplit (kd_util.cpp:291-319) on a list of values, statement for statement:
+    `pred(v)` = belongs left.  Returns the permutation (indices into the input) and the split position."""
+    idx = list(range(len(vals)))
+    l, r = 0, len(vals) - 1
+    while True:
+        while l < len(vals) and pred(vals[idx[l]]): l += 1
+        while r >= 0 and not pred(vals[idx[r]]): r -= 1
+        if l > r: break
+        idx[l], idx[r] = idx[r], idx[l]
+        l += 1; r -= 1
+    return idx, l
+
+
+def _hoare_kd(vals, split):
+    """KDTreeImpl::create's form of the loop (kdTreeImpl.h:172-182): no step after the swap, no bounds (a run with both sides
+    occupied never leaves it)"""
+    idx = list(range(len(vals)))
+    l, r = 0, len(vals) - 1
+    while True:
+        while vals[idx[l]] < split: l += 1
+        while vals[idx[r]] >= split: r -= 1
+        if r < l: break
+        idx[l], idx[r] = idx[r], idx[l]
+    return idx, l
+
+
+def _two_pass(vals, pred):
+    """what k_part_scan + k_part_swap (build.hip) / k_ann_part_scan + k_ann_part_swap (ann.hip) compute: the index list --
+    elements that stay right from the front in order, the others from the back in order --, then slot j of the front part
+    swaps with slot j + nge when it lies left of the split position"""
+    n = len(vals)
+    ge = [not pred(v) for v in vals]
+    nge = sum(ge)
+    nleft = n - nge
+    lst = [None] * n
+    g = 0
+    for p in range(n):
+        if ge[p]: lst[g] = p
+        else: lst[n - 1 - (p - g)] = p
+        g += ge[p]
+    idx = list(range(n))
+    for j in range(nge):
+        a = lst[j]
+        if a < nleft:
+            b = lst[j + nge]
+            idx[a], idx[b] = idx[b], idx[a]
+    return idx, nleft
+
+
+def test_two_pass_partition_rule_is_the_hoare_loop():
+    """Round 6's partition of a level rests on one claim: the reference's Hoare loop leaves the k-th element that
+    is not below the split value -- if it lies in the left region -- swapped with the k-th element below it counted from the
+    right end.  Checked here against the loop itself, statement for statement, on random runs with repeated values, runs that
+    are all on one side, single elements -- for KDTreeImpl::create's predicate (v < split) and for both passes of ANN's
+    annPlaneSplit (v < cv over the cell, then v <= cv over what lies right of br1)."""
+    rng = np.random.default_rng(62)
+    for trial in range(3000):
+        n = int(rng.integers(1, 70))
+        vals = list(rng.integers(-6, 7, n).astype(float)) if trial % 2 else list(rng.normal(0, 1, n))
+        split = float(rng.choice(vals)) if trial % 3 else float(rng.normal(0, 1))
+        ref, lpos = _hoare(vals, lambda v: v < split)
+        got, nleft = _two_pass(vals, lambda v: v < split)
+        assert (ref, lpos) == (got, nleft), (vals, split)
+        if 0 < nleft < n:
+            assert _hoare_kd(vals, split) == (got, nleft), (vals, split)
+        # annPlaneSplit: the second pass works on the first pass's result, from br1 on
+        v1 = [vals[i] for i in ref]
+        tail = v1[lpos:]
+        ref2, l2 = _hoare(tail, lambda v: v <= split)
+        got2, n2 = _two_pass(tail, lambda v: v <= split)
+        assert (ref2, l2) == (got2, n2), (vals, split)
+
+
 def test_every_product_kernel_spills_nothing_and_search_kernels_keep_four_waves():
     """The resource remarks of the PRODUCT build (csrc/Makefile keeps them for kernels.hip: every search, pair-sum,
     transform and layout kernel lib3dtk_hip.so can launch; the lab library's extra kernels are not in this file).
