@@ -1669,745 +1669,7 @@ __global__ void k_pack_refs(KdNode* __restrict__ nodes, uint32_t nnodes, const L
   if (i == 0) *root_ref = pack(*root_ref);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Subtrees finished by ONE workgroup each (round 4).
-// Level by level, every level of the tree is ~9 dependent launches (measure, decide / rank / emit, count, mark, scan,
-// swap list, swap + relabel), and below the top few levels a launch has nothing to do but wait for the one before it:
-// an 81K-point scan spent 0.93 of its 1.75 ms on levels 5 .. 18, a 1M-point cloud 1.0 of 2.4 ms on levels 9 .. 18.  From
-// the level on at which a balanced node holds at most FIN_HANDOFF points, every node of that level is handed to one
-// workgroup, which runs the SAME passes over the node's own stretch of the arrays -- the points of a node never leave
-// its stretch, so every per-position and per-node array of the arena has a private slice [start, start + n) for it --
-// with a workgroup barrier where the level-by-level build has a launch, down to the last bucket.  Same measure (the
-// left-to-right fp64 sum, one wave per (node, axis)), same decisions (decide_node), same records (emit_node), same
-// partition (k-th misplaced from the left swaps with the k-th from the right end): the same tree, record for record
-// (tdtk_tree_verify compares it with the host builder's).
-// The records of a subtree go to a staging area (the slice again) level by level; what their breadth-first indices are
-// depends on the other subtrees (node i of a level = the internal nodes of that level to the left of it), so two small
-// launches follow: per level and subtree the counts to the left (k_fin_offsets), then every subtree copies its records
-// to their final indices with the child references translated (k_fin_place).
-// ------------------------------------------------------------------------------------------------------------------
-#define FIN_T 512u             // threads of a subtree's workgroup (eight waves: 256 vector registers each)
-#define FIN_LV 96u             // levels a subtree may have; deeper (a pathological cloud): the build is redone level by level
-#define FIN_HANDOFF 2048u      // hand a level over when a balanced node of it holds at most this many points (and the largest fits FIN_LDS)
-#define FIN_MAX_SUBTREES 65536u
-#define FIN_HANDOFF_WAVE 384u        // ... for clouds of at least FIN_HANDOFF_WAVE_FROM points: what k_fin_wave takes (a wave per subtree)
-#define FIN_HANDOFF_WAVE_FROM 2000000u   // most subtrees a build's tables hold (fin_max_subtrees(M) of them: M / 128, at least 1024)
-#define FIN_LONG_MAX 512u      // long runs of a level a subtree lists for its waves
-#define FIN_LANE_RUN 192u      // runs up to this long are measured by one lane each (k_fin_subtrees), longer ones by a wave
-struct FinTab {
-  uint32_t ib[FIN_LV + 2], lb[FIN_LV + 2];   // where the subtree's internal nodes / buckets of local level l start in the staging slice
-  uint32_t nlev;                             // local levels that hold nodes
-  uint32_t root_ref;                         // staged reference of the subtree's root
-  uint32_t s0, n;
-};
-struct FinOff {                              // k_fin_offsets -> k_fin_place
-  uint32_t io[FIN_LV + 2], lo[FIN_LV + 2];   // global index of the subtree's first internal node / bucket of local level l
-};
-// (8192 for every build until round 6: a 10M-point scan that is a little lopsided -- the largest node of its level four
-// times the average -- fits a workgroup a level below the balanced hand-over, with 16 384 nodes, and went level by level
-// to the end; the tables are 1.6 KB per subtree, so a small cloud's arena does not carry the large one's)
-static inline uint32_t fin_max_subtrees(size_t M)
-{
-  const size_t c = M / 128u;
-  return (uint32_t)(c < 1024u ? 1024u : (c > FIN_MAX_SUBTREES ? FIN_MAX_SUBTREES : c));
-}
-
-// exclusive scan of `count` 32-bit values in[0 .. count) -> out[0 .. count], out[count] = total, by one workgroup of FIN_T threads
-__device__ __forceinline__ uint32_t fin_scan_u32(const uint32_t* in, uint32_t* out, uint32_t count, uint32_t* s_w /*[17]*/)
-{
-  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < count; base += FIN_T) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = (i < count) ? in[i] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t t = __shfl_up(inc, off, WAVE); if ((int)lane >= off) inc += t; }
-    if (lane == WAVE - 1) s_w[wv] = inc;
-    __syncthreads();
-    uint32_t before = carry, tile = 0;
-    for (uint32_t w = 0; w < FIN_T / WAVE; w++) { if (w < wv) before += s_w[w]; tile += s_w[w]; }
-    if (i < count) out[i] = before + inc - v;
-    carry += tile;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[count] = carry;
-  return carry;
-}
-// the same over 64-bit words that hold two counts (left-misplaced | right-misplaced << 32)
-__device__ __forceinline__ unsigned long long fin_scan_u64(const unsigned long long* in, unsigned long long* out, uint32_t count,
-                                                           unsigned long long* s_w /*[16]*/)
-{
-  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  unsigned long long carry = 0;
-  for (uint32_t base = 0; base < count; base += FIN_T) {
-    const uint32_t i = base + threadIdx.x;
-    const unsigned long long v = (i < count) ? in[i] : 0ull;
-    unsigned long long inc = v;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up((long long)inc, off, WAVE); if ((int)lane >= off) inc += t; }
-    if (lane == WAVE - 1) s_w[wv] = inc;
-    __syncthreads();
-    unsigned long long before = carry, tile = 0;
-    for (uint32_t w = 0; w < FIN_T / WAVE; w++) { if (w < wv) before += s_w[w]; tile += s_w[w]; }
-    if (i < count) out[i] = before + inc - v;
-    carry += tile;
-    __syncthreads();
-  }
-  return carry;
-}
-
-#define FIN_LDS 3584u          // points a subtree may hold: its coordinates, labels, partition scratch and node table live in LDS
-#define FIN_SEGS 1024u         // nodes a level of a subtree may have: <= 2 FIN_LDS / (bucket + 1), hence bucket >= 6 (the host checks)
-#define FIN_LDS_HALF (FIN_LDS / 2u)
-struct FinArgs {
-  const BSeg* roots; const BLevel* lvH;
-  double *cx, *cy, *cz; uint32_t* perm;
-  BSeg *segA, *segB; BMeas* meas;
-  uint32_t *kind, *axis; double* splitval; uint32_t *irank, *nleft;
-  KdNode* nodes_st; double* r_st; LeafEntry* leaf_st;
-  FinTab* tab; uint32_t bucket; uint32_t* small;
-  uint32_t *sub_nlev, *sub_maxleaf;   // per subtree: its levels, its largest bucket (k_fin_offsets takes the maxima: one shared word per subtree is a
-                                      // millisecond of atomics -- or of loads that must see them -- over 32 768 subtrees)
-  uint32_t dbg_levels;          // lab (TDTK_FW_DEBUG=k): k_fin_wave stops after k - 1 levels -- a timing probe, the tree is not valid
-  uint32_t n_lo, skip_big;      // this launch takes the subtrees of more than n_lo points; skip_big: ... and leaves those beyond its capacity to the next
-};
-
-// One subtree, root to buckets, by one workgroup.  Coordinates, labels (which node of the current level a position belongs
-// to), the partition's scratch and the level's node table are in LDS; the node / bucket records and the per-node arrays
-// decide_node / emit_node / children_of work on are the subtree's slices of the arena's arrays (start .. start + n).
-// Thread k owns the FIN_K consecutive local positions from k FIN_K.
-template <uint32_t CAP, uint32_t SEGS>
-__device__ __forceinline__ void fin_subtree_body(const FinArgs& A)
-{
-  constexpr uint32_t KPT = (CAP + FIN_T - 1) / FIN_T;
-  __shared__ alignas(16) double X[CAP + 16], Y[CAP + 16], Z[CAP + 16];
-  __shared__ uint16_t lab[CAP];                 // node of the current level, 0xFFFF: already in a bucket
-  __shared__ uint32_t ab[CAP];                  // bit 31 / 30: misplaced on the left / right; bits 0-11 / 12-23: how many before
-  __shared__ uint16_t pl[CAP / 2 + 1], pr[CAP / 2 + 1];
-  __shared__ double m_sv[SEGS];
-  __shared__ uint16_t m_start[SEGS], m_cnt[SEGS], m_ir[SEGS];
-  __shared__ uint32_t m_nl[SEGS];
-  __shared__ unsigned char m_kind[SEGS], m_ax[SEGS];
-  __shared__ BLevel lvl2[2];
-  __shared__ uint32_t s_w32[FIN_T / WAVE + 1];
-  __shared__ uint32_t s_tot[2], s_root, s_nlong, s_maxleaf;
-  __shared__ uint32_t s_long[FIN_LONG_MAX];
-  const uint32_t t = blockIdx.x;
-  if (t >= A.lvH->nseg) return;
-  const BSeg root = A.roots[t];
-  const uint32_t s0 = root.start, n = root.n;
-  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  uint32_t* small = A.small;
-  if (n <= A.n_lo) return;
-  if (n > CAP) {     // (the host hands a level over only when its largest node fits; a node that does not is a bug there)
-    if (threadIdx.x == 0 && !A.skip_big) atomicOr(small + 2, 0x20000u);
-    return;
-  }
-  BSeg* segs = A.segA + s0; BSeg* next = A.segB + s0;
-  BMeas* ms = A.meas + s0;
-  // (kind and irank hold one entry more than the level has nodes -- the scan's total --: arrays of their own, every
-  // subtree's slice shifted by its index)
-  uint32_t *kd = A.kind + s0 + t, *ax = A.axis + s0, *ir = A.irank + s0 + t, *nl = A.nleft + s0;
-  double* sv = A.splitval + s0;
-  for (uint32_t i = threadIdx.x; i < n; i += FIN_T) { X[i] = A.cx[s0 + i]; Y[i] = A.cy[s0 + i]; Z[i] = A.cz[s0 + i]; lab[i] = 0; }
-  if (threadIdx.x == 0) {
-    segs[0] = {s0, n, -1, 0u};                    // (no parent here: k_fin_place hooks the root into the level above)
-    lvl2[0] = {1u, s0, s0};                       // staged records of this subtree start at its own slice
-    s_root = 0u; s_maxleaf = 0u;
-  }
-  __threadfence_block();
-  __syncthreads();
-  const uint32_t i_lo = threadIdx.x * KPT, i_hi = (i_lo + KPT < n) ? i_lo + KPT : n;     // this thread's positions
-  uint32_t lev = 0;
-  unsigned long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  const bool timing = kLab && t == 0 && threadIdx.x == 0 && small[15] == 0x7157u;      // (lab: TDTK_BUILD_TRACE=2)
-  auto tick = [&](int k) { if (timing) { const unsigned long long now = wall_clock64(); tph[k] += now - tlast; tlast = now; } };
-  if (timing) tlast = wall_clock64();
-  for (;; lev++) {
-    const uint32_t nseg = lvl2[0].nseg;
-    if (threadIdx.x == 0 && lev <= FIN_LV + 1u) { A.tab[t].ib[lev] = lvl2[0].node_base; A.tab[t].lb[lev] = lvl2[0].leaf_base; }
-    if (nseg == 0 || lev > FIN_LV || nseg > SEGS) break;
-    // (0) the level's runs into the node table
-    for (uint32_t i = threadIdx.x; i < nseg; i += FIN_T) { const BSeg sg = segs[i]; m_start[i] = (uint16_t)(sg.start - s0); m_cnt[i] = (uint16_t)sg.n; }
-    if (threadIdx.x == 0) s_nlong = 0u;
-    __syncthreads();
-    // (1) measure.  Short runs (the many nodes of the deeper levels): one LANE per (node, axis) walks its run alone, four
-    // reads ahead of the adds; long runs: one wave per (node, axis) -- the bounding box by all lanes, the left-to-right fp64
-    // sum (kdTreeImpl.h:94-111) by lane 0, sixteen reads ahead of the adds.
-    for (uint32_t item = threadIdx.x; item < 3u * nseg; item += FIN_T) {
-      const uint32_t sgi = item / 3u, a3 = item % 3u;
-      const uint32_t st = m_start[sgi], cnt_n = m_cnt[sgi];
-      if (cnt_n > FIN_LANE_RUN) {
-        const uint32_t slot = atomicAdd(&s_nlong, 1u);       // (at most 3 CAP / FIN_LANE_RUN of them)
-        s_long[slot] = item;
-        continue;
-      }
-      const double* __restrict__ arr = ((a3 == 0) ? X : ((a3 == 1) ? Y : Z)) + st;
-      double sum = arr[0];                               // the sum starts from the first point ...
-      double lo = sum, hi = sum;
-      uint32_t k = 1;
-      for (; k + 4 <= cnt_n; k += 4) {                   // ... and adds the rest in order
-        const double v0 = arr[k], v1 = arr[k + 1], v2 = arr[k + 2], v3 = arr[k + 3];
-        sum += v0; sum += v1; sum += v2; sum += v3;
-        const double mn = fmin(fmin(v0, v1), fmin(v2, v3)), mx = fmax(fmax(v0, v1), fmax(v2, v3));
-        lo = (mn < lo) ? mn : lo; hi = (hi < mx) ? mx : hi;
-      }
-      for (; k < cnt_n; k++) { const double v = arr[k]; sum += v; lo = (v < lo) ? v : lo; hi = (hi < v) ? v : hi; }
-      ms[sgi].lo[a3] = lo; ms[sgi].hi[a3] = hi; ms[sgi].mean[a3] = sum / (double)cnt_n;
-    }
-    __syncthreads();
-    for (uint32_t li = wv; li < s_nlong; li += FIN_T / WAVE) {
-      const uint32_t item = s_long[li];
-      const uint32_t sgi = item / 3u, a3 = item % 3u;
-      const uint32_t st = m_start[sgi], cnt_n = m_cnt[sgi];
-      const double* __restrict__ arr = ((a3 == 0) ? X : ((a3 == 1) ? Y : Z)) + st;
-      const double first = arr[0];
-      double lo = first, hi = first, sum = first;       // the sum starts from the first point
-      for (uint32_t k = lane; k < cnt_n; k += WAVE) { const double v = arr[k]; lo = (v < lo) ? v : lo; hi = (hi < v) ? v : hi; }
-      {
-        // ... and adds the rest in order: every lane the same chain (wave-uniform reads), sixteen values per turn of
-        // lds_chain16, the ragged end one by one
-        const uint32_t body = ((cnt_n - 1u) / 16u) * 16u;
-        if (body) lds_chain16(sum, arr + 1, body);
-        for (uint32_t k = 1u + body; k < cnt_n; k++) sum += arr[k];
-      }
-      lo = wave_min(lo); hi = wave_max(hi);
-      if (lane == 0) { ms[sgi].lo[a3] = lo; ms[sgi].hi[a3] = hi; ms[sgi].mean[a3] = sum / (double)cnt_n; }
-    }
-    __threadfence_block();
-    __syncthreads();
-    tick(1);
-    // (2) leaf or internal, axis, split value (one more entry, zero: the rank scan's total)
-    for (uint32_t i = threadIdx.x; i <= nseg; i += FIN_T) decide_node(segs, &lvl2[0], nseg, ms, A.bucket, kd, ax, sv, nl, i);
-    __threadfence_block();
-    __syncthreads();
-    tick(2);
-    // (3) rank of every internal node among the level's
-    (void)fin_scan_u32(kd, ir, nseg, s_w32);
-    __threadfence_block();
-    __syncthreads();
-    tick(3);
-    // (4) records into the staging slice, children hooked into their (staged) parents; lvl2[1] = the next level; the
-    // decisions into the node table
-    for (uint32_t i = threadIdx.x; i < nseg || i == 0; i += FIN_T) {
-      emit_node(segs, &lvl2[0], ms, kd, ax, sv, ir, A.nodes_st, A.r_st, A.leaf_st, &s_root, &s_maxleaf, i);   // (largest bucket: per subtree first)
-      if (i < nseg) { m_kind[i] = (unsigned char)kd[i]; m_ax[i] = (unsigned char)ax[i]; m_sv[i] = sv[i]; m_ir[i] = (uint16_t)ir[i]; m_nl[i] = 0u; }
-    }
-    __syncthreads();
-    // (5) how many points of each internal node lie below its split value (one LDS atomic per run a thread's positions touch)
-    {
-      uint32_t pend = 0xFFFFFFFFu, pcnt = 0;
-      for (uint32_t i = i_lo; i < i_hi; i++) {
-        const uint32_t sg = lab[i];
-        if (sg == 0xFFFFu || !m_kind[sg]) continue;
-        const uint32_t a3 = m_ax[sg];
-        const double c = (a3 == 0) ? X[i] : ((a3 == 1) ? Y[i] : Z[i]);
-        const uint32_t lt = (c < m_sv[sg]) ? 1u : 0u;
-        if (sg != pend) { if (pend != 0xFFFFFFFFu && pcnt) atomicAdd(&m_nl[pend], pcnt); pend = sg; pcnt = lt; }
-        else pcnt += lt;
-      }
-      if (pend != 0xFFFFFFFFu && pcnt) atomicAdd(&m_nl[pend], pcnt);
-    }
-    __syncthreads();
-    tick(4);
-    // (6) misplaced on the left / on the right of the split position, counted per thread; the children's runs
-    uint32_t mineL = 0, mineR = 0;
-    for (uint32_t i = i_lo; i < i_hi; i++) {
-      uint32_t l = 0, r = 0;
-      const uint32_t sg = lab[i];
-      if (sg != 0xFFFFu && m_kind[sg]) {
-        const uint32_t a3 = m_ax[sg];
-        const double c = (a3 == 0) ? X[i] : ((a3 == 1) ? Y[i] : Z[i]);
-        const bool f = c < m_sv[sg];
-        const bool left_region = (i - m_start[sg]) < m_nl[sg];
-        l = (left_region && !f) ? 1u : 0u;
-        r = (!left_region && f) ? 1u : 0u;
-      }
-      ab[i] = (l << 31) | (r << 30) | mineL | (mineR << 12);     // counts before i within this thread's positions
-      mineL += l; mineR += r;
-    }
-    for (uint32_t i = threadIdx.x; i < nseg; i += FIN_T) { nl[i] = m_nl[i]; children_of(segs, &lvl2[0], kd, ir, nl, next, small + 2, i); }
-    // (7) both running counts over the threads (packed: left | right << 16)
-    {
-      const uint32_t v = mineL | (mineR << 16);
-      uint32_t inc = v;
-#pragma unroll
-      for (int off = 1; off < WAVE; off <<= 1) { const uint32_t tt = __shfl_up(inc, off, WAVE); if ((int)lane >= off) inc += tt; }
-      if (lane == WAVE - 1) s_w32[wv] = inc;
-      __syncthreads();
-      uint32_t before = 0, total = 0;
-      for (uint32_t w = 0; w < FIN_T / WAVE; w++) { if (w < wv) before += s_w32[w]; total += s_w32[w]; }
-      before += inc - v;
-      if (threadIdx.x == 0) { s_tot[0] = total & 0xFFFFu; s_tot[1] = total >> 16; }
-      const uint32_t bl = before & 0xFFFFu, br = before >> 16;
-      for (uint32_t i = i_lo; i < i_hi; i++) ab[i] += bl | (br << 12);
-    }
-    __threadfence_block();
-    __syncthreads();
-    tick(6);
-    // (8) the k-th misplaced from the left pairs with the k-th misplaced from the right end of its node
-    for (uint32_t i = i_lo; i < i_hi; i++) {
-      const uint32_t w = ab[i];
-      if (w >> 31) pl[w & 0xFFFu] = (uint16_t)i;
-      if ((w >> 30) & 1u) {
-        const uint32_t sg = lab[i];
-        const uint32_t st = m_start[sg], cn = m_cnt[sg];
-        const uint32_t Bs = (ab[st] >> 12) & 0xFFFu;
-        const uint32_t Be = (st + cn < n) ? ((ab[st + cn] >> 12) & 0xFFFu) : s_tot[1];
-        const uint32_t kfwd = ((w >> 12) & 0xFFFu) - Bs;
-        pr[Bs + ((Be - Bs) - 1u - kfwd)] = (uint16_t)i;
-      }
-    }
-    __syncthreads();
-    tick(7);
-    // (9) swap (coordinates here, the permutation in memory), relabel
-    for (uint32_t c = threadIdx.x; c < s_tot[0]; c += FIN_T) {
-      const uint32_t a = pl[c], b = pr[c];
-      const uint32_t pa = A.perm[s0 + a], pb = A.perm[s0 + b];
-      A.perm[s0 + a] = pb; A.perm[s0 + b] = pa;
-      double tv;
-      tv = X[a]; X[a] = X[b]; X[b] = tv;
-      tv = Y[a]; Y[a] = Y[b]; Y[b] = tv;
-      tv = Z[a]; Z[a] = Z[b]; Z[b] = tv;
-    }
-    for (uint32_t i = i_lo; i < i_hi; i++) {
-      const uint32_t sg = lab[i];
-      if (sg == 0xFFFFu) continue;
-      if (!m_kind[sg]) { lab[i] = 0xFFFFu; continue; }
-      lab[i] = (uint16_t)(2u * m_ir[sg] + (((i - m_start[sg]) < m_nl[sg]) ? 0u : 1u));
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x == 0) { lvl2[0] = lvl2[1]; lvl2[1] = {0u, 0u, 0u}; }
-    BSeg* tsw = segs; segs = next; next = tsw;
-    __syncthreads();
-    tick(8);
-  }
-  if (timing) for (int k = 0; k < 10; k++) small[16 + k] = (uint32_t)tph[k];
-  for (uint32_t i = threadIdx.x; i < n; i += FIN_T) { A.cx[s0 + i] = X[i]; A.cy[s0 + i] = Y[i]; A.cz[s0 + i] = Z[i]; }
-  if (threadIdx.x == 0) {
-    A.tab[t].nlev = lev;
-    A.tab[t].root_ref = s_root;
-    A.tab[t].s0 = s0; A.tab[t].n = n;
-    A.sub_nlev[t] = lev; A.sub_maxleaf[t] = s_maxleaf;
-    if (lvl2[0].nseg != 0) atomicOr(small + 2, 0x20000u);     // deeper than the tables, or a level wider than the node table: redo level by level
-  }
-}
-
-// (two instantiations: the full one keeps a compute unit to itself -- 135 KB of LDS --; subtrees of at most FIN_LDS_HALF points
-// -- what the hand-over level of a cloud of several million points holds -- are built two workgroups to a compute unit:
-// a subtree's levels are barriers and round trips, and two of them side by side hide each other's)
-__global__ void __launch_bounds__(FIN_T) k_fin_subtrees(const FinArgs A_by_value)
-{
-  (void)A_by_value;
-  fin_subtree_body<FIN_LDS, FIN_SEGS>(build_kernarg_block<FinArgs>());
-}
-__global__ void __launch_bounds__(FIN_T, 4) k_fin_subtrees_half(const FinArgs A_by_value)
-{
-  (void)A_by_value;
-  fin_subtree_body<FIN_LDS_HALF, FIN_SEGS / 2u>(build_kernarg_block<FinArgs>());
-}
-
-// ---- subtrees of at most FW_CAP points: ONE WAVE each (round 6) ---------------------------------------------------------
-// A workgroup per subtree is eight waves that spend a level's time at barriers and on round trips through the arena's
-// per-node arrays: 20 us per level whatever the subtree holds, one or two subtrees per compute unit (3 ms for the 8192
-// subtrees of a 10M-point cloud; a lopsided scan, whose hand-over level has tens of thousands of small nodes beside a few
-// large ones, was faster level by level).  A subtree of a few hundred points needs none of that: here a single wave builds
-// it, everything it reads twice in LDS (21 KB: seven subtrees per compute unit at a time), no barrier that is more than
-// a wave's own.  Per level: a lane per (node, axis) walks its run -- the bounding box and the reference's left-to-right
-// sum (kdTreeImpl.h:94-111) --, the three lanes of a node meet in the first, which decides (kdTreeImpl.h:113-170), ranks
-// itself by ballot and writes the record into the subtree's staging slice (the same slice, tables and references
-// k_fin_subtrees leaves: k_fin_offsets / k_fin_place do not care who built a subtree); the partition is k_part_scan /
-// k_part_swap at the size of a wave (eight rows of 64 positions, ballots and a carried count; the index list in LDS).
-#define FW_CAP 512u
-#define FW_ROWS (FW_CAP / WAVE)
-#define FW_SEGS 160u           // nodes of a level: <= 2 FW_CAP / (bucket + 1), bucket >= 6
-#define FW_WAVES 1u             // subtrees (waves) per workgroup
-struct FwSeg { uint16_t start, cnt; uint32_t parent; };   // parent: staged index | side << 30 | that side's axis bit << 31; 0xFFFFFFFF: the subtree's root
-// (a wave's own barrier: its LDS accesses are carried out in order, so a compiler fence at wavefront scope is all a later
-// read of an earlier write needs -- __syncthreads() would also wait for the records on their way to memory, a round
-// trip per level that nobody is waiting for)
-struct FwLds {
-  alignas(16) double X[FW_CAP + 8], Y[FW_CAP + 8], Z[FW_CAP + 8];
-  uint32_t P[FW_CAP];
-  uint16_t lab[FW_CAP], list[FW_CAP];
-  FwSeg seg[2][FW_SEGS];
-  double sv[FW_SEGS];
-  uint16_t nl[FW_SEGS], ir[FW_SEGS];
-  unsigned char kd[FW_SEGS], ax[FW_SEGS];
-};
-__device__ __forceinline__ void fw_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-__global__ void __launch_bounds__(WAVE * FW_WAVES) k_fin_wave(const FinArgs A_by_value)
-{
-  (void)A_by_value;
-  const FinArgs& A = build_kernarg_block<FinArgs>();
-  __shared__ FwLds Lw[FW_WAVES];
-  FwLds& S = Lw[threadIdx.x / WAVE];
-  const uint32_t t = blockIdx.x * FW_WAVES + threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1u);
-  if (t >= A.lvH->nseg) return;
-  const BSeg root = A.roots[t];
-  const uint32_t s0 = root.start, n = root.n;
-  if (n > FW_CAP) return;                       // the workgroup kernels' (their n_lo)
-  if (kLab && A.dbg_levels == 100u) return;
-  {
-    // (all rows requested before the first is parked: under a branch per row the compiler waits for each row's round trip
-    //  to memory in turn -- eight of them were the kernel's whole time; positions past the subtree read its last point)
-    double tx[FW_ROWS], ty[FW_ROWS], tz[FW_ROWS];
-    uint32_t tp[FW_ROWS];
-#pragma unroll
-    for (uint32_t r = 0; r < FW_ROWS; r++) {
-      const uint32_t i = r * WAVE + lane, g = s0 + ((i < n) ? i : n - 1u);
-      tx[r] = A.cx[g]; ty[r] = A.cy[g]; tz[r] = A.cz[g]; tp[r] = A.perm[g];
-    }
-#pragma unroll
-    for (uint32_t r = 0; r < FW_ROWS; r++) {
-      const uint32_t i = r * WAVE + lane;
-      if (i < n) { S.X[i] = tx[r]; S.Y[i] = ty[r]; S.Z[i] = tz[r]; S.P[i] = tp[r]; S.lab[i] = 0; }
-    }
-  }
-  if (kLab && A.dbg_levels == 101u) return;
-  if (lane == 0) { FwSeg q; q.start = 0; q.cnt = (uint16_t)n; q.parent = 0xFFFFFFFFu; S.seg[0][0] = q; }
-  fw_sync();
-  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-  const bool timing = kLab && t == 0 && lane == 0 && A.small[15] == 0x7157u;      // (S.lab: TDTK_BUILD_TRACE=2)
-  auto tick = [&](int k) { if (timing) { const unsigned long long now = wall_clock64(); tph[k] += now - tlast; tlast = now; } };
-  if (timing) tlast = wall_clock64();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = lt_mask | (1ull << lane);
-  uint32_t nseg = 1u, node_base = s0, leaf_base = s0, lev = 0u, cur = 0u, my_root = 0u, maxleaf = 0u;
-  for (;; lev++) {
-    if (lane == 0 && lev <= FIN_LV + 1u && !(kLab && A.dbg_levels == 104u)) { A.tab[t].ib[lev] = node_base; A.tab[t].lb[lev] = leaf_base; }
-    if (nseg == 0u || lev > FIN_LV || nseg > FW_SEGS) break;
-    if (kLab && A.dbg_levels && (lev + 1u >= A.dbg_levels || A.dbg_levels >= 100u)) break;
-    // (1) measure, decide, rank, emit: 21 nodes per round, the three axes of a node in neighbouring lanes
-    uint32_t nint = 0u;
-    for (uint32_t base = 0; base < nseg; base += 21u) {
-      const uint32_t node = base + lane / 3u, a3 = lane % 3u;
-      const bool valid = lane < 63u && node < nseg;
-      double lo = 0.0, hi = 0.0, mean = 0.0;
-      uint32_t st = 0u, cn = 0u, par = 0u;
-      if (valid) {
-        const FwSeg q = S.seg[cur][node];
-        st = q.start; cn = q.cnt; par = q.parent;
-        const double* __restrict__ arr = ((a3 == 0u) ? S.X : ((a3 == 1u) ? S.Y : S.Z)) + st;
-        double sum = arr[0];                               // the sum starts from the first point ...
-        lo = sum; hi = sum;
-        uint32_t k = 1u;
-        // ... and adds the rest in order, the next four values requested before the current four are added (the arrays
-        // are padded: the last request may run eight values past the subtree, never past the array)
-        double v0 = arr[1], v1 = arr[2], v2 = arr[3], v3 = arr[4];
-        for (; k + 4u <= cn; k += 4u) {
-          const double n0 = arr[k + 4], n1 = arr[k + 5], n2 = arr[k + 6], n3 = arr[k + 7];
-          sum += v0; sum += v1; sum += v2; sum += v3;
-          const double mn = fmin(fmin(v0, v1), fmin(v2, v3)), mx = fmax(fmax(v0, v1), fmax(v2, v3));
-          lo = (mn < lo) ? mn : lo; hi = (hi < mx) ? mx : hi;
-          v0 = n0; v1 = n1; v2 = n2; v3 = n3;
-        }
-        if (k < cn) { sum += v0; lo = (v0 < lo) ? v0 : lo; hi = (hi < v0) ? v0 : hi; k++; }
-        if (k < cn) { sum += v1; lo = (v1 < lo) ? v1 : lo; hi = (hi < v1) ? v1 : hi; k++; }
-        if (k < cn) { sum += v2; lo = (v2 < lo) ? v2 : lo; hi = (hi < v2) ? v2 : hi; k++; }
-        mean = sum / (double)cn;
-      }
-      const double lo1 = __shfl_down(lo, 1, WAVE), lo2 = __shfl_down(lo, 2, WAVE);
-      const double hi1 = __shfl_down(hi, 1, WAVE), hi2 = __shfl_down(hi, 2, WAVE);
-      const double m1 = __shfl_down(mean, 1, WAVE), m2 = __shfl_down(mean, 2, WAVE);
-      const bool first = valid && a3 == 0u;
-      bool internal = false;
-      uint32_t axis = 0u;
-      double hx = 0.0, hy = 0.0, hz = 0.0, split = 0.0;
-      if (first) {                                         // decide_node
-        hx = 0.5 * (hi - lo); hy = 0.5 * (hi1 - lo1); hz = 0.5 * (hi2 - lo2);
-        if (hx > hy) axis = (hx > hz) ? 0u : 2u;
-        else axis = (hy > hz) ? 1u : 2u;
-        const double mx = fmax(fmax(hx, hy), hz);
-        internal = !((cn <= A.bucket) || (fabs(mx) < 0.01));
-        split = (axis == 0u) ? mean : ((axis == 1u) ? m1 : m2);
-      }
-      const unsigned long long im = __ballot(internal);
-      if (first) {                                         // emit_node
-        const uint32_t r = nint + (uint32_t)__popcll(im & lt_mask);
-        uint32_t ref;
-        if (internal) {
-          const uint32_t me = node_base + r;
-          KdNode nd;
-          nd.cx = 0.5 * (lo + hi); nd.cy = 0.5 * (lo1 + hi1); nd.cz = 0.5 * (lo2 + hi2);
-          nd.hx = hx; nd.hy = hy; nd.hz = hz;
-          nd.splitval = split;
-          nd.c1 = (axis & 1u) ? REF_AXIS : 0u;
-          nd.c2 = (axis & 2u) ? REF_AXIS : 0u;
-          A.nodes_st[me] = nd;
-          A.r_st[me] = __dsqrt_rn(hx * hx + hy * hy + hz * hz);
-          ref = me;
-          S.kd[node] = 1; S.ax[node] = (unsigned char)axis; S.sv[node] = split; S.ir[node] = (uint16_t)r;
-        } else {
-          const uint32_t id = leaf_base + (node - r);      // every node is either internal or a bucket
-          LeafEntry le; le.start = (int32_t)(s0 + st); le.count = (int32_t)cn;
-          A.leaf_st[id] = le;
-          maxleaf = (cn > maxleaf) ? cn : maxleaf;
-          ref = REF_LEAF | id;
-          S.kd[node] = 0;
-        }
-        if (par == 0xFFFFFFFFu) my_root = ref;
-        else {     // the parent's slot, whole: its axis bit rides in the run's record (no read of what this wave wrote a level ago)
-          KdNode* pn = A.nodes_st + (par & REF_VAL);
-          const uint32_t w = ((par >> 31) ? REF_AXIS : 0u) | ref;
-          if ((par >> 30) & 1u) pn->c2 = w; else pn->c1 = w;
-        }
-      }
-      nint += (uint32_t)__popcll(im);
-    }
-    fw_sync();
-    tick(1);
-    // (2) the partition's scan: rows of 64 positions in order, a count carried from row to row
-    uint32_t geb[FW_ROWS], sgl[FW_ROWS], gebits = 0u, actbits = 0u;
-    {
-      // (every row's reads phase by phase, none of them under a branch: label -> node -> coordinate; a position without a
-      //  node reads node 0's entries and ignores them)
-      uint32_t sgs[FW_ROWS], a3s[FW_ROWS], sts[FW_ROWS];
-      unsigned char kds[FW_ROWS];
-      double cs[FW_ROWS], svs[FW_ROWS];
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) sgs[r] = S.lab[(r * WAVE + lane) & (FW_CAP - 1u)];
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) {
-        if (r * WAVE + lane >= n) sgs[r] = 0xFFFFu;
-        const uint32_t q = (sgs[r] == 0xFFFFu) ? 0u : sgs[r];
-        kds[r] = S.kd[q]; a3s[r] = S.ax[q]; svs[r] = S.sv[q]; sts[r] = S.seg[cur][q].start;
-      }
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) {
-        const uint32_t i = (r * WAVE + lane) & (FW_CAP - 1u);
-        const double* __restrict__ arr = (a3s[r] == 0u) ? S.X : ((a3s[r] == 1u) ? S.Y : S.Z);
-        cs[r] = arr[i];
-      }
-      uint32_t carry = 0u;
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) {
-        const uint32_t i = r * WAVE + lane;
-        const bool act = sgs[r] != 0xFFFFu && kds[r] != 0;
-        const bool ge = act && !(cs[r] < svs[r]);
-        const bool head = act && (i == sts[r]);
-        const unsigned long long gm = __ballot(ge), hm = __ballot(head);
-        const unsigned long long hb = hm & le_mask;
-        if (hb) { const int hl = 63 - __clzll((long long)hb); geb[r] = (uint32_t)__popcll(gm & lt_mask & ~((1ull << hl) - 1ull)); }
-        else geb[r] = carry + (uint32_t)__popcll(gm & lt_mask);
-        if (hm) { const int hl = 63 - __clzll((long long)hm); carry = (uint32_t)__popcll(gm >> hl); }
-        else carry += (uint32_t)__popcll(gm);
-        if (ge) gebits |= 1u << r;
-        if (act) actbits |= 1u << r;
-        sgl[r] = sgs[r];
-      }
-    }
-#pragma unroll
-    for (uint32_t r = 0; r < FW_ROWS; r++) {
-      if (!((actbits >> r) & 1u)) continue;
-      const uint32_t i = r * WAVE + lane;
-      const uint32_t sg = sgl[r];
-      const FwSeg q = S.seg[cur][sg];
-      const uint32_t j = i - q.start, g = geb[r];
-      const bool ge = (gebits >> r) & 1u;
-      const uint32_t dst = ge ? (q.start + g) : (q.start + q.cnt - 1u - (j - g));
-      S.list[dst] = (uint16_t)i;
-      if (j == (uint32_t)q.cnt - 1u) S.nl[sg] = (uint16_t)(q.cnt - (g + (ge ? 1u : 0u)));
-    }
-    fw_sync();
-    tick(2);
-    // (3) the children's runs (children_of)
-    for (uint32_t node = lane; node < nseg; node += WAVE) {
-      if (!S.kd[node]) continue;
-      const FwSeg q = S.seg[cur][node];
-      uint32_t nleft = S.nl[node];
-      if (nleft == 0u || nleft >= q.cnt) { atomicExch(A.small + 2, 1u); nleft = (nleft == 0u) ? 1u : q.cnt - 1u; }
-      const uint32_t me = node_base + S.ir[node], a = S.ax[node];
-      FwSeg c1, c2;
-      c1.start = q.start; c1.cnt = (uint16_t)nleft; c1.parent = me | ((a & 1u) ? 0x80000000u : 0u);
-      c2.start = (uint16_t)(q.start + nleft); c2.cnt = (uint16_t)(q.cnt - nleft); c2.parent = me | 0x40000000u | ((a & 2u) ? 0x80000000u : 0u);
-      S.seg[cur ^ 1u][2u * S.ir[node]] = c1;
-      S.seg[cur ^ 1u][2u * S.ir[node] + 1u] = c2;
-    }
-    // (4) the swaps, driven from the S.list's front half; the labels of the next level (reads phase by phase again)
-    {
-      uint32_t sgs[FW_ROWS], av[FW_ROWS], bv[FW_ROWS], bidx[FW_ROWS], newlab[FW_ROWS], swbits = 0u;
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) { const uint32_t i = (r * WAVE + lane) & (FW_CAP - 1u); sgs[r] = S.lab[i]; av[r] = S.list[i]; }
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) {
-        const uint32_t i = r * WAVE + lane;
-        if (i >= n) sgs[r] = 0xFFFFu;
-        const uint32_t q = (sgs[r] == 0xFFFFu) ? 0u : sgs[r];
-        const FwSeg sgm = S.seg[cur][q];
-        const uint32_t k = S.kd[q], nleft = S.nl[q], irk = S.ir[q];
-        const uint32_t j = i - sgm.start, nge = sgm.cnt - nleft;
-        newlab[r] = k ? (2u * irk + ((j < nleft) ? 0u : 1u)) : 0xFFFFu;
-        const bool sw = sgs[r] != 0xFFFFu && k != 0u && j < nge && av[r] < sgm.start + nleft;
-        if (sw) swbits |= 1u << r;
-        bidx[r] = sw ? (i + nge) : 0u;
-      }
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) bv[r] = S.list[bidx[r]];
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) if (sgs[r] != 0xFFFFu) S.lab[r * WAVE + lane] = (uint16_t)newlab[r];
-      uint32_t pa[FW_ROWS], pb[FW_ROWS];
-      double xa[FW_ROWS], xb[FW_ROWS], ya[FW_ROWS], yb[FW_ROWS], za[FW_ROWS], zb[FW_ROWS];
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++) {
-        const uint32_t a = ((swbits >> r) & 1u) ? av[r] : 0u, b = ((swbits >> r) & 1u) ? bv[r] : 0u;
-        pa[r] = S.P[a]; pb[r] = S.P[b]; xa[r] = S.X[a]; xb[r] = S.X[b]; ya[r] = S.Y[a]; yb[r] = S.Y[b]; za[r] = S.Z[a]; zb[r] = S.Z[b];
-      }
-#pragma unroll
-      for (uint32_t r = 0; r < FW_ROWS; r++)
-        if ((swbits >> r) & 1u) {
-          const uint32_t a = av[r], b = bv[r];
-          S.P[a] = pb[r]; S.P[b] = pa[r]; S.X[a] = xb[r]; S.X[b] = xa[r]; S.Y[a] = yb[r]; S.Y[b] = ya[r]; S.Z[a] = zb[r]; S.Z[b] = za[r];
-        }
-    }
-    fw_sync();
-    tick(3);
-    node_base += nint; leaf_base += nseg - nint; nseg = 2u * nint; cur ^= 1u;
-  }
-  if (!(kLab && A.dbg_levels >= 103u)) {
-#pragma unroll
-  for (uint32_t r = 0; r < FW_ROWS; r++) {
-    const uint32_t i = r * WAVE + lane;
-    if (i < n) { A.cx[s0 + i] = S.X[i]; A.cy[s0 + i] = S.Y[i]; A.cz[s0 + i] = S.Z[i]; A.perm[s0 + i] = S.P[i]; }
-  }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(maxleaf, off, WAVE); maxleaf = (o > maxleaf) ? o : maxleaf; }
-  tick(4);
-  if (timing) for (int k = 0; k < 6; k++) A.small[16 + k] = (uint32_t)tph[k];
-  if (lane == 0) {
-    A.tab[t].nlev = lev;
-    A.tab[t].root_ref = my_root;
-    A.tab[t].s0 = s0; A.tab[t].n = n;
-    A.sub_nlev[t] = lev; A.sub_maxleaf[t] = maxleaf;       // (not atomicMax on the build's words: 32 768 of them on one address were the kernel's whole time)
-    if (nseg != 0u) atomicOr(A.small + 2, 0x20000u);       // deeper than the tables: redo level by level
-  }
-}
-
-// the largest node of the level that is about to be handed over (the host hands it over only if that one fits FIN_LDS)
-__global__ void __launch_bounds__(256) k_fin_maxn(const BSeg* __restrict__ segs, const BLevel* __restrict__ lv, uint32_t* __restrict__ out)
-{
-  __shared__ uint32_t s_m;
-  if (threadIdx.x == 0) s_m = 0u;
-  __syncthreads();
-  uint32_t m = 0;
-  for (uint32_t i = threadIdx.x; i < lv->nseg; i += 256u) m = max(m, segs[i].n);
-  atomicMax(&s_m, m);
-  __syncthreads();
-  if (threadIdx.x == 0) { out[0] = s_m; out[1] = lv->nseg; }
-}
-
-// per level (one workgroup each): how many internal nodes / buckets the subtrees to the left hold, and the level's totals
-#define FO_T 1024u            // (a step of the scan over the subtrees is two barriers and a round trip to their tables: as few steps as a workgroup allows)
-__global__ void __launch_bounds__(FO_T) k_fin_offsets(const FinTab* __restrict__ tab, FinOff* __restrict__ off, const BLevel* __restrict__ lvH,
-                                                     uint32_t* __restrict__ totals /*[2][FIN_LV + 2]*/, const uint32_t* __restrict__ sub_nlev,
-                                                     const uint32_t* __restrict__ sub_maxleaf, uint32_t* __restrict__ max_leaf)
-{
-  const uint32_t T = lvH[0].nseg, l = blockIdx.x;
-  __shared__ uint32_t s_w[FO_T / WAVE][2];
-  __shared__ uint32_t s_any, s_max;
-  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  // does any subtree reach this level?  (the subtrees' depths side by side: tens of thousands of 800-byte tables are not
-  // looked at by the workgroups of the levels nobody has); the first workgroup also takes the largest bucket of all
-  if (threadIdx.x == 0) { s_any = 0u; s_max = 0u; }
-  __syncthreads();
-  {
-    uint32_t any = 0u, mx = 0u;
-    for (uint32_t t = threadIdx.x; t < T; t += FO_T) { any |= (l < sub_nlev[t]) ? 1u : 0u; if (l == 0u) mx = max(mx, sub_maxleaf[t]); }
-    if (__ballot(any != 0u) && lane == 0) s_any = 1u;
-    if (l == 0u) { for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o, WAVE)); if (lane == 0) atomicMax(&s_max, mx); }
-  }
-  __syncthreads();
-  if (l == 0u && threadIdx.x == 0) atomicMax(max_leaf, s_max);
-  if (!s_any) {
-    if (threadIdx.x == 0) { totals[l] = 0u; totals[FIN_LV + 2 + l] = 0u; }
-    return;
-  }
-  uint32_t carry_i = 0, carry_l = 0;
-  for (uint32_t base = 0; base < T; base += FO_T) {
-    const uint32_t t = base + threadIdx.x;
-    uint32_t ci = 0, cl = 0;
-    if (t < T && l < sub_nlev[t]) { ci = tab[t].ib[l + 1] - tab[t].ib[l]; cl = tab[t].lb[l + 1] - tab[t].lb[l]; }
-    uint32_t ii = ci, il = cl;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-      const uint32_t a = __shfl_up(ii, o, WAVE), b = __shfl_up(il, o, WAVE);
-      if ((int)lane >= o) { ii += a; il += b; }
-    }
-    if (lane == WAVE - 1) { s_w[wv][0] = ii; s_w[wv][1] = il; }
-    __syncthreads();
-    uint32_t bi = carry_i, bl = carry_l, ti = 0, tl = 0;
-    for (uint32_t w = 0; w < FO_T / WAVE; w++) { if (w < wv) { bi += s_w[w][0]; bl += s_w[w][1]; } ti += s_w[w][0]; tl += s_w[w][1]; }
-    if (t < T) { off[t].io[l] = bi + ii - ci; off[t].lo[l] = bl + il - cl; }      // relative to the level's first (k_fin_place adds that)
-    carry_i += ti; carry_l += tl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { totals[l] = carry_i; totals[FIN_LV + 2 + l] = carry_l; }
-}
-
-// every subtree's staged records to their breadth-first places; subtree 0 also leaves the levels' counters for the host
-__global__ void __launch_bounds__(256) k_fin_place(const FinTab* __restrict__ tab, const FinOff* __restrict__ off,
-                                                   const uint32_t* __restrict__ totals, const BSeg* __restrict__ roots,
-                                                   BLevel* __restrict__ lvH, const KdNode* __restrict__ nodes_st,
-                                                   const double* __restrict__ r_st, const LeafEntry* __restrict__ leaf_st,
-                                                   KdNode* __restrict__ nodes, double* __restrict__ node_r,
-                                                   LeafEntry* __restrict__ leaf_tab, uint32_t* __restrict__ root_ref)
-{
-  const uint32_t t = blockIdx.x;
-  if (t >= lvH->nseg) return;
-  __shared__ FinTab T;
-  __shared__ FinOff O;
-  __shared__ uint32_t nb[FIN_LV + 2], lb[FIN_LV + 2];       // the levels' first node / bucket indices
-  for (uint32_t k = threadIdx.x; k < sizeof(FinTab) / 4; k += 256u) reinterpret_cast<uint32_t*>(&T)[k] = reinterpret_cast<const uint32_t*>(tab + t)[k];
-  for (uint32_t k = threadIdx.x; k < sizeof(FinOff) / 4; k += 256u) reinterpret_cast<uint32_t*>(&O)[k] = reinterpret_cast<const uint32_t*>(off + t)[k];
-  if (threadIdx.x == 0) {
-    uint32_t a = lvH[0].node_base, b = lvH[0].leaf_base;
-    for (uint32_t l = 0; l <= FIN_LV + 1u; l++) {
-      nb[l] = a; lb[l] = b;
-      if (l <= FIN_LV) { a += totals[l]; b += totals[FIN_LV + 2 + l]; }
-    }
-  }
-  __syncthreads();
-  if (t == 0 && threadIdx.x <= FIN_LV) {
-    // level L* + l + 1 holds two children per internal node of level L* + l: what the level-by-level build leaves in lvl[]
-    const uint32_t l = threadIdx.x;
-    lvH[l + 1].nseg = 2u * totals[l]; lvH[l + 1].node_base = nb[l + 1]; lvH[l + 1].leaf_base = lb[l + 1];
-  }
-  const uint32_t nlev = T.nlev;
-  auto level_of_node = [&](uint32_t st) { uint32_t l = 0; while (l + 1 < nlev && st >= T.ib[l + 1]) l++; return l; };
-  auto level_of_leaf = [&](uint32_t st) { uint32_t l = 0; while (l + 1 < nlev && st >= T.lb[l + 1]) l++; return l; };
-  auto final_ref = [&](uint32_t ref) -> uint32_t {      // a staged reference -> the final one (the axis bit rides along)
-    const uint32_t v = ref & REF_VAL;
-    if (ref & REF_LEAF) { const uint32_t l = level_of_leaf(v); return (ref & ~REF_VAL) | (lb[l] + O.lo[l] + (v - T.lb[l])); }
-    const uint32_t l = level_of_node(v);
-    return (ref & ~REF_VAL) | (nb[l] + O.io[l] + (v - T.ib[l]));
-  };
-  const uint32_t ni = T.ib[nlev] - T.ib[0], nlf = T.lb[nlev] - T.lb[0];
-  for (uint32_t k = threadIdx.x; k < ni; k += 256u) {
-    const uint32_t st = T.ib[0] + k;
-    KdNode nd = nodes_st[st];
-    nd.c1 = final_ref(nd.c1); nd.c2 = final_ref(nd.c2);
-    const uint32_t l = level_of_node(st);
-    const uint32_t g = nb[l] + O.io[l] + (st - T.ib[l]);
-    nodes[g] = nd;
-    node_r[g] = r_st[st];
-  }
-  for (uint32_t k = threadIdx.x; k < nlf; k += 256u) {
-    const uint32_t st = T.lb[0] + k;
-    const uint32_t l = level_of_leaf(st);
-    leaf_tab[lb[l] + O.lo[l] + (st - T.lb[l])] = leaf_st[st];
-  }
-  if (threadIdx.x == 0) {       // the subtree's root into its parent of the level above (or the tree's root reference)
-    const BSeg rt = roots[t];
-    const uint32_t ref = final_ref(T.root_ref);
-    if (rt.parent < 0) *root_ref = ref;
-    else {
-      uint32_t* slot = rt.side ? &nodes[rt.parent].c2 : &nodes[rt.parent].c1;
-      *slot = (*slot & REF_AXIS) | (ref & ~REF_AXIS);
-    }
-  }
-}
+#include "build_finish.inc"   // the subtree finishers (k_fin_*): 730 lines of this translation unit
 
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 static inline int bits_for(uint64_t v)
