@@ -1846,6 +1846,16 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       if (fin_env && no_finish == 0 && bucket >= 6 && L < 31 && (1u << L) <= fin_cap && !big_dbg_all) fin_level = L;
     }
     if (fin_level != 0xFFFFFFFFu) batch = fin_level;
+    // From chain_from on the exact sums of a speculated level are plain chains in the background (k_chain_exact) -- 4.2 ns
+    // per point of the level's largest node, which must end before the build does.  A balanced cloud's do; a cloud with a
+    // third of its points in one tight cluster has a 1.3M-point node on levels 5 .. 10 of 4M points, and its chains (5.6 ms)
+    // were what the build waited for.  So a build of two million points and more -- where a look costs a few per cent of a
+    // level -- looks at the largest node before the first such level (and before every further one while it is too large):
+    // beyond M / 17 points the level takes the piecewise path.
+    const uint32_t chain_from = [] { const char* e = lab_env("TDTK_BUILD_CHAINFROM"); return e ? (uint32_t)atoi(e) : 5u; }();
+    bool chain_ok = true;
+    bool chain_look = spec && M_ >= 2000000u && fin_level != 0xFFFFFFFFu && chain_from < fin_level && chain_from < (uint32_t)spec_levels;
+    if (chain_look) batch = chain_from;
     // The host's looks at the device land in pinned memory when the caller has some (a copy into pageable memory is a
     // synchronisation of its own): h_small = small[0 .. 7] (root reference, largest bucket, error word, check word, the
     // hand-over level's largest node and node count), hl = the level counters.
@@ -1855,7 +1865,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     BLevel* const hl = reinterpret_cast<BLevel*>(hst + 64);
     static_assert(64 + sizeof(BLevel) * (BUILD_MAX_LEVELS + 2) <= 65536, "the staging block holds every level's counters");
     std::memset(hst, 0, 64);
-    bool have_max = false;
+    bool have_max = false, fin_retry = false;
     uint32_t fin_nodes = 0, fin_maxn = 0;     // nodes of the level about to be handed over, the largest of them (k_fin_maxn)
     for (;;) {
       if (level == fin_level) {
@@ -1873,7 +1883,12 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           known = h_max[1]; known_at = level;
           batch = 1;
         } else if (h_max[0] > FIN_LDS || h_max[1] > fin_cap) {
-          fin_level = 0xFFFFFFFFu;  // too many nodes for the tables: level by level to the end
+          // too many nodes for the tables, or a node too large with no room for a wider level: on by levels -- and a look at
+          // every batch's end whether the level has thinned out (round 6: a cloud with a third of its points in one tight
+          // cluster is in that state for nine levels, until the sparse rest has ended in buckets; it used to stay by levels
+          // to the last bucket, eight levels more)
+          fin_level = 0xFFFFFFFFu;
+          fin_retry = no_finish == 0;
           known = h_max[1]; known_at = level;
           batch = 2;
         }
@@ -2031,8 +2046,7 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
           BCHK(hipStreamWaitEvent(sb, side->e1, 0));
           // from the sixth level on (a balanced node's chain: M / 32 adds of 4.2 ns, a seventh of what the build takes) the
           // exact sums are plain chains (TDTK_BUILD_CHAINFROM, lab: another level; 99: never)
-          const uint32_t chain_from = [] { const char* e = lab_env("TDTK_BUILD_CHAINFROM"); return e ? (uint32_t)atoi(e) : 5u; }();
-          if (level >= chain_from) {
+          if (level >= chain_from && chain_ok) {
             hipLaunchKernelGGL(k_chain_exact, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz, L.exact, L.axis, big_min);
           } else {
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, sb, L.segs, L.seg_of, sx, sy, sz, M,
@@ -2128,7 +2142,8 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       }
       // one look per batch: the level counters so far and the root reference / largest bucket / error word together -- and,
       // when the next level is the one handed to the finisher, its largest node
-      if (level == fin_level) { hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4); have_max = true; }
+      if (level == fin_level || fin_retry) { hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4); have_max = true; }
+      else if (chain_look) hipLaunchKernelGGL(k_fin_maxn, dim3(1), dim3(256), 0, s, segs, lvl + level, small + 4);
       BCHK(hipMemcpyAsync(hl, lvl, sizeof(BLevel) * (level + 1), hipMemcpyDeviceToHost, s));
       BCHK(hipMemcpyAsync(h_small, small, 32, hipMemcpyDeviceToHost, s));
       BCHK(hipStreamSynchronize(s));
@@ -2144,6 +2159,15 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
       if (nx.nseg == 0) break;
       known = nx.nseg; known_at = level;
       batch = 2;
+      if (chain_look) {
+        chain_ok = h_small[4] <= M_ / 17u;
+        if (chain_ok || level >= (uint32_t)spec_levels || level >= fin_level) chain_look = false;
+        batch = chain_look ? 1u : ((fin_level != 0xFFFFFFFFu && level < fin_level) ? fin_level - level : 2u);
+      }
+      if (fin_retry) {
+        if (h_small[4] <= FIN_LDS && h_small[5] <= fin_cap && level + FIN_LV + 3u < BUILD_MAX_LEVELS) { fin_level = level; fin_retry = false; }   // hand over now (the block at the loop's top)
+        else have_max = false;
+      }
     }
     if (lvl_trace && !lvl_ev.empty()) {
       hipEvent_t e;
