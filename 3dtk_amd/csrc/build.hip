@@ -1852,7 +1852,19 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
     // were what the build waited for.  So a build of two million points and more -- where a look costs a few per cent of a
     // level -- looks at the largest node before the first such level (and before every further one while it is too large):
     // beyond M / 17 points the level takes the piecewise path.
-    const uint32_t chain_from = [] { const char* e = lab_env("TDTK_BUILD_CHAINFROM"); return e ? (uint32_t)atoi(e) : 5u; }();
+    // chain_from: the first level whose balanced node's chain (4.2 ns a point) is a small share of what a build of this
+    // size takes -- 20 000 + M / 50 points, the sixth level at the latest: level 0 for a 15K-point scan, 1 at 40K, 2 at 81K,
+    // 4 at 300K, 5 from 1M on (measured: 4 at 1M is 8 % slower, 3 at 300K 4 %).  On small clouds this is not about bandwidth
+    // but about the HOST: a level's piecewise path is nine launches on the side streams, and enqueuing them (3-4 us
+    // apiece) was what a level of a 15K .. 40K-point build took (15K: 0.50 -> 0.41 ms, lab library).
+    const uint32_t chain_from = [&] {
+      const char* e = lab_env("TDTK_BUILD_CHAINFROM");
+      if (e) return (uint32_t)atoi(e);
+      const size_t thresh = 20000u + M_ / 50u;
+      uint32_t L = 0;
+      while (L < 5u && (M_ >> L) > thresh) L++;
+      return L;
+    }();
     bool chain_ok = true;
     bool chain_look = spec && M_ >= 2000000u && fin_level != 0xFFFFFFFFu && chain_from < fin_level && chain_from < (uint32_t)spec_levels;
     if (chain_look) batch = chain_from;
