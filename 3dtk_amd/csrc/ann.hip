@@ -652,28 +652,63 @@ __global__ void __launch_bounds__(256) k_ann_small(const ASeg* __restrict__ smal
     if (!__ballot(active)) break;
     const unsigned long long mask = ((cn >= 64u) ? ~0ull : ((1ull << cn) - 1ull)) << cs;
     const uint32_t rel = lane - cs, seg_end = cs + cn;
-    // annSpread / annMinMax of every sub-cell (kd_util.cpp:225-262): segmented reduction, then the head's value
-    double mn[3] = {x, y, z}, mx[3] = {x, y, z};
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1)
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        const double a = __shfl_down(mn[d], off, WAVE), b = __shfl_down(mx[d], off, WAVE);
-        if (lane + off < seg_end) { mn[d] = (a < mn[d]) ? a : mn[d]; mx[d] = (mx[d] < b) ? b : mx[d]; }
-      }
-#pragma unroll
-    for (int d = 0; d < 3; d++) { mn[d] = __shfl(mn[d], cs, WAVE); mx[d] = __shfl(mx[d], cs, WAVE); }
+    // annSpread / annMinMax of every sub-cell (kd_util.cpp:225-262): segmented reduction, then the head's value.
+    // sl_midpt_split looks at the spreads of the dimensions whose cell side is within 0.1 % of the longest only
+    // (kd_split.cpp:171-182) -- almost always ONE dimension, known from the cell's box before any point is looked at, and
+    // then its choice does not depend on the spreads: the reduction carries that dimension's min / max alone (two doubles
+    // through the LDS crossbar per step instead of six; the kernel is bound by those cross-lane moves).  An iteration in
+    // which some sub-cell has two candidate dimensions reduces all three as before.
     uint32_t cd, mode;
     double cv;
-    sl_midpt_rule(blo, bhi, mn, mx, cd, cv, mode);
+    {
+      double max_length = bhi[0] - blo[0];
+#pragma unroll
+      for (int d = 1; d < 3; d++) { const double length = bhi[d] - blo[d]; if (length > max_length) max_length = length; }
+      uint32_t nq = 0, dq = 0;
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+        if ((bhi[d] - blo[d]) >= (1 - ANN_ERR) * max_length) { if (!nq) dq = (uint32_t)d; nq++; }
+      if (!__ballot(active && nq != 1u)) {
+        const double c1 = (dq == 0) ? x : ((dq == 1) ? y : z);
+        double m1 = c1, M1 = c1;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+          const double a = __shfl_down(m1, off, WAVE), b = __shfl_down(M1, off, WAVE);
+          if (lane + off < seg_end) { m1 = (a < m1) ? a : m1; M1 = (M1 < b) ? b : M1; }
+        }
+        m1 = __shfl(m1, cs, WAVE); M1 = __shfl(M1, cs, WAVE);
+        // sl_midpt_rule with the one candidate: cd = dq, the cut at the cell's middle unless the points lie to one side of it
+        cd = dq;
+        const double lo = sel3(blo, dq), hi = sel3(bhi, dq);
+        const double ideal = (lo + hi) / 2;
+        if (ideal < m1) { cv = m1; mode = 1; }
+        else if (ideal > M1) { cv = M1; mode = 2; }
+        else { cv = ideal; mode = 0; }
+      } else {
+        double mn[3] = {x, y, z}, mx[3] = {x, y, z};
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1)
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            const double a = __shfl_down(mn[d], off, WAVE), b = __shfl_down(mx[d], off, WAVE);
+            if (lane + off < seg_end) { mn[d] = (a < mn[d]) ? a : mn[d]; mx[d] = (mx[d] < b) ? b : mx[d]; }
+          }
+#pragma unroll
+        for (int d = 0; d < 3; d++) { mn[d] = __shfl(mn[d], cs, WAVE); mx[d] = __shfl(mx[d], cs, WAVE); }
+        sl_midpt_rule(blo, bhi, mn, mx, cd, cv, mode);
+      }
+    }
     // annPlaneSplit (kd_util.cpp:291-319), first pass: "< cv" | ">= cv"
     double c = (cd == 0) ? x : ((cd == 1) ? y : z);
     const bool f = active && (c < cv);
     const uint32_t br1 = (uint32_t)__popcll(__ballot(f) & mask);
     {
       const bool left_region = rel < br1;
-      const uint32_t partner = hoare_partner(active && left_region && !f, active && !left_region && f, mask, cs, lane, slotL, slotR);
-      x = __shfl(x, partner, WAVE); y = __shfl(y, partner, WAVE); z = __shfl(z, partner, WAVE); pm = __shfl(pm, partner, WAVE);
+      const bool ML = active && left_region && !f, MR = active && !left_region && f;
+      if (__ballot(ML || MR)) {                 // (a pass in which no point of the wave is misplaced moves nothing)
+        const uint32_t partner = hoare_partner(ML, MR, mask, cs, lane, slotL, slotR);
+        x = __shfl(x, partner, WAVE); y = __shfl(y, partner, WAVE); z = __shfl(z, partner, WAVE); pm = __shfl(pm, partner, WAVE);
+      }
     }
     // second pass on [br1, n): "== cv" | "> cv"
     c = (cd == 0) ? x : ((cd == 1) ? y : z);
@@ -682,8 +717,11 @@ __global__ void __launch_bounds__(256) k_ann_small(const ASeg* __restrict__ smal
     {
       const bool in2 = active && (rel >= br1);
       const bool left_region = rel < br2;
-      const uint32_t partner = hoare_partner(in2 && left_region && !g, in2 && !left_region && g, mask, cs, lane, slotL, slotR);
-      x = __shfl(x, partner, WAVE); y = __shfl(y, partner, WAVE); z = __shfl(z, partner, WAVE); pm = __shfl(pm, partner, WAVE);
+      const bool ML = in2 && left_region && !g, MR = in2 && !left_region && g;
+      if (__ballot(ML || MR)) {                 // (points ON the plane that are out of place: rare)
+        const uint32_t partner = hoare_partner(ML, MR, mask, cs, lane, slotL, slotR);
+        x = __shfl(x, partner, WAVE); y = __shfl(y, partner, WAVE); z = __shfl(z, partner, WAVE); pm = __shfl(pm, partner, WAVE);
+      }
     }
     const uint32_t n_lo = sl_midpt_nlo(mode, cn, br1, br2);
     if (active && (n_lo == 0 || n_lo >= cn)) atomicExch(small + 2, 1u);    // cannot happen for finite input
