@@ -426,7 +426,7 @@ __global__ void k_ann_swap(const uint32_t* __restrict__ posL, const uint32_t* __
 // list's front part.  misplaced + scan + swap list + swap were four passes over the points and two 8-byte words per point.
 template <int PASS>
 __global__ void __launch_bounds__(PS_THREADS) k_ann_part_scan(const uint32_t* __restrict__ seg_of, const ASeg* __restrict__ segs,
-                                                              const ADec* __restrict__ dec, const unsigned long long* __restrict__ cnt,
+                                                              const ADec* __restrict__ dec, unsigned long long* __restrict__ cnt,
                                                               const double* __restrict__ cx, const double* __restrict__ cy,
                                                               const double* __restrict__ cz, uint32_t M, uint32_t* __restrict__ list,
                                                               unsigned long long* __restrict__ status, uint32_t* __restrict__ counter,
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(PS_THREADS) k_ann_part_scan(const uint32_t* __
 #pragma unroll
     for (uint32_t r = 0; r < PS_ROWS; r++) {
       cds[r] = 0u; cvs[r] = 0.0; sts[r] = 0u; cns[r] = 0ull;
-      if (sg[r] != NOSEG) { cds[r] = dec[sg[r]].cd; cvs[r] = dec[sg[r]].cv; sts[r] = segs[sg[r]].start; cns[r] = cnt[sg[r]]; }
+      if (sg[r] != NOSEG) { cds[r] = dec[sg[r]].cd; cvs[r] = dec[sg[r]].cv; sts[r] = segs[sg[r]].start; if (PASS == 2) cns[r] = cnt[sg[r]]; }
     }
 #pragma unroll
     for (uint32_t r = 0; r < PS_ROWS; r++) {
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(PS_THREADS) k_ann_part_scan(const uint32_t* __
       if (sg[r] == NOSEG) continue;
       const uint32_t rel = wbase + r * WAVE - sts[r], br1 = (uint32_t)cns[r];
       if (PASS == 1) {
-        if ((uint32_t)(cns[r] >> 32) != 0u) any_eq = true;
+        if (c[r] == cvs[r]) any_eq = true;
         actbits |= 1u << r;
         if (!(c[r] < cvs[r])) gebits |= 1u << r;
         if (rel == 0u) headbits |= 1u << r;
@@ -472,6 +472,44 @@ __global__ void __launch_bounds__(PS_THREADS) k_ann_part_scan(const uint32_t* __
       }
     }
     if (PASS == 1 && eq_flag != nullptr && any_eq) *eq_flag = 1u;
+    if (PASS == 1) {
+      // the cell's counts on the way (what k_ann_count's own pass over the points did): points below the cutting value |
+      // points ON it << 32, one atomic per run a wave sees, the workgroup's waves merged first
+      __shared__ uint32_t s_cseg[PS_THREADS / WAVE];
+      __shared__ unsigned long long s_ccnt[PS_THREADS / WAVE];
+      uint32_t pend = NOSEG;
+      unsigned long long pcnt = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < PS_ROWS; r++) {
+        const uint32_t g = sg[r];
+        const bool lt = (g != NOSEG) && (c[r] < cvs[r]);
+        const bool eq = (g != NOSEG) && (c[r] == cvs[r]);
+        unsigned long long todo = __ballot(g != NOSEG);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t cur = __shfl(g, leader, WAVE);
+          const bool mine = (g == cur);
+          const unsigned long long add = (unsigned long long)__popcll(__ballot(mine && lt)) | ((unsigned long long)__popcll(__ballot(mine && eq)) << 32);
+          if (cur != pend) {
+            if (pend != NOSEG && lane == 0) atomicAdd(&cnt[pend], pcnt);
+            pend = cur; pcnt = add;
+          } else pcnt += add;
+          todo &= ~__ballot(mine);
+        }
+      }
+      if (lane == 0) { s_cseg[wv] = pend; s_ccnt[wv] = pcnt; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t cur = NOSEG;
+        unsigned long long acc = 0;
+        for (uint32_t w = 0; w < PS_THREADS / WAVE; w++) {
+          if (s_cseg[w] == NOSEG) continue;
+          if (s_cseg[w] != cur) { if (cur != NOSEG) atomicAdd(&cnt[cur], acc); cur = s_cseg[w]; acc = s_ccnt[w]; }
+          else acc += s_ccnt[w];
+        }
+        if (cur != NOSEG) atomicAdd(&cnt[cur], acc);
+      }
+    }
   }
   uint32_t ext = 0u, win = 0u;
   ps_scan_core(gebits, headbits, tile, status, epoch, err, geb, ext, win);
@@ -1176,13 +1214,14 @@ AnnBuildResult ann_build_tree(const double* d_xyz, size_t M_, void* arena_, AnnN
       hipLaunchKernelGGL(k_ann_measure, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, cx, cy, cz, meas,
                          level ? (const ASeg*)next : (const ASeg*)nullptr, level ? (const ADec*)dec : (const ADec*)nullptr);
       hipLaunchKernelGGL(k_ann_decide, dim3(cdiv(bound, 256)), dim3(256), 0, s, segs, lvl + level, meas, dec);
-      hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
+      // (the cells' counts: inside the first pass's scan when that is the one-launch one -- k_ann_part_scan<1> --, else a pass of their own)
+      const bool part2_level = [] { const char* e = lab_env("TDTK_ANN_PART"); return !(e && e[0] == '0'); }() && own_scan && 2u * level + 2u < 255u;
+      if (!part2_level) hipLaunchKernelGGL(k_ann_count, dim3(cdiv(M, 256 * MEAS_ITERS)), dim3(256), 0, s, seg_of, M, dec, cx, cy, cz, cnt);
       // the library's first Hoare pass, then its second one on what lies right of br1
       for (int pass = 1; pass <= 2; pass++) {
         // (the gate needs every kernel of the pass to honour it: with rocPRIM's scan, which does not, the pass runs ungated)
         const bool one_launch = own_scan && 2u * level + (uint32_t)pass < 255u;
-        const bool part2_env = [] { const char* e = lab_env("TDTK_ANN_PART"); return !(e && e[0] == '0'); }();   // (lab, 0: round 3's four launches)
-        if (part2_env && one_launch) {
+        if (part2_level) {      // (lab, TDTK_ANN_PART=0: round 3's four launches)
           // a Hoare pass = a scan that writes the index list + the swaps
           const uint32_t ntiles = cdiv(M, PS_TILE), nbw = cdiv(M, 256u * APW_ROWS);
           uint32_t* counter = reinterpret_cast<uint32_t*>(arena + O[24]);

@@ -1967,6 +1967,21 @@ def test_normals_other_k_eps(tdtk, orc, gpu, k, eps):
     assert np.array_equal(gknn, wknn) and np.array_equal(got, want, equal_nan=True)
 
 
+def test_lab_switch_of_the_round6_ann_build_gives_the_same_lists(tdtk, gpu, lab, monkeypatch):
+    """The ANN build's Hoare passes as scan + swap with the cells' counts inside the first pass's scan (round 6) against round 3's
+    count / misplaced / scan / list / swap launches (TDTK_ANN_PART=0, lab): the same 10-NN lists and normals bit for bit, on a
+    uniform cloud, on one whose rounded coordinates put points ON cutting planes (the second pass has work) and on a plane."""
+    rng = np.random.default_rng(608)
+    clouds = [rng.uniform(-300.0, 300.0, (300000, 3)), np.round(rng.uniform(-50.0, 50.0, (250000, 3)), 1)]
+    pl = rng.uniform(-300.0, 300.0, (200000, 3)); pl[:, 2] = 0.05 * pl[:, 0] + rng.normal(0, 0.5, len(pl)); clouds.append(pl)
+    for p in clouds:
+        a, ak = tdtk.calculateNormalsApxKNN(p, 10, [0.0, 0.0, 400.0], 1.0, want_knn=True)
+        monkeypatch.setenv("TDTK_ANN_PART", "0")
+        b, bk = tdtk.calculateNormalsApxKNN(p, 10, [0.0, 0.0, 400.0], 1.0, want_knn=True)
+        monkeypatch.delenv("TDTK_ANN_PART")
+        assert np.array_equal(ak, bk) and np.array_equal(a, b, equal_nan=True)
+
+
 def test_normals_golden_and_reference_library(tdtk, orc, gpu):
     """K7 fixture (vendored ANN + newmat, generated in the build container) and, where oracle/_ref travelled,
     the library itself."""
