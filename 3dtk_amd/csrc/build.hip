@@ -474,8 +474,14 @@ __device__ __forceinline__ uint32_t big_piece_count(uint32_t a, uint32_t n) { re
 __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs, const uint32_t* __restrict__ seg_of,
                                                    const double* __restrict__ cx, const double* __restrict__ cy,
                                                    const double* __restrict__ cz, uint32_t M, uint32_t nblocks,
-                                                   BPiece* __restrict__ pieces, BPre* __restrict__ prein, const uint32_t big_min)
+                                                   BPiece* __restrict__ pieces, BPre* __restrict__ prein, const uint32_t big_min,
+                                                   const uint32_t* __restrict__ only_axis = nullptr)
 {
+  // only_axis (a speculated level: the axis every big node is cut along is known -- k_big_approx -- before its exact sum is
+  // asked for): a piece's bounds and plain sum are reduced along that axis alone.  Eighteen wave reductions per block of
+  // 64 points -- three axes x (min, max, sum) x two pieces -- are what this kernel's time is made of; the exact chain
+  // needs two of them.  (Start, length and node of a piece are written on every axis as before: k_big_emulate and
+  // k_big_list read them from axis 0.)
   const uint32_t q = blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x & (WAVE - 1);
   if (q >= nblocks) return;
@@ -520,14 +526,22 @@ __global__ void __launch_bounds__(256) k_big_stats(const BSeg* __restrict__ segs
   const bool in_t = inb && p >= t_start && p < t_end, in_h = inb && p >= h_start && p < h_end;
   const bool has_t = t_end > t_start, has_h = h_end > h_start;
   const double INF = 1.0 / 0.0;
+  const uint32_t t_only = (only_axis != nullptr && has_t) ? only_axis[t_sid] : 3u, h_only = (only_axis != nullptr && has_h) ? only_axis[h_sid] : 3u;
 #pragma unroll
   for (uint32_t ax = 0; ax < 3u; ax++) {
     const double* __restrict__ arr = (ax == 0) ? cx : ((ax == 1) ? cy : cz);
     const double v = (ax == 0) ? vx : ((ax == 1) ? vy : vz);
     double tlo = in_t ? v : INF, thi = in_t ? v : -INF, tsum = in_t ? v : 0.0;
     double hlo = in_h ? v : INF, hhi = in_h ? v : -INF, hsum = in_h ? v : 0.0;
-    if (has_t) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
-    if (has_h) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
+    if (only_axis == nullptr) {
+      if (has_t) { tlo = wave_min(tlo); thi = wave_max(thi); tsum = wave_add(tsum); }
+      if (has_h) { hlo = wave_min(hlo); hhi = wave_max(hhi); hsum = wave_add(hsum); }
+    } else {
+      // (the bounds of a speculated level's nodes are not asked for again: the plain path has them)
+      tlo = hlo = INF; thi = hhi = -INF;
+      if (has_t && t_only == ax) tsum = wave_add(tsum); else tsum = 0.0;
+      if (has_h && h_only == ax) hsum = wave_add(hsum); else hsum = 0.0;
+    }
     const size_t o = ((size_t)ax * nblocks + q) * 2;
     if (lane == 0) {
       BPiece t; t.start = t_start; t.len = t_end - t_start; t.ebits = t_sid; t.flags = 0; t.lo = tlo; t.hi = thi; t.csum = tsum; t.pre = 0.0;
@@ -561,7 +575,8 @@ __device__ __forceinline__ uint32_t big_split_axis(const BPre* __restrict__ preo
 __global__ void __launch_bounds__(64) k_big_emulate(const BSeg* __restrict__ segs, const double* __restrict__ cx,
                                                     const double* __restrict__ cy, const double* __restrict__ cz,
                                                     uint32_t nblocks, BPiece* __restrict__ pieces,
-                                                    const BPre* __restrict__ preout, BSum* __restrict__ own, int dbg)
+                                                    const BPre* __restrict__ preout, BSum* __restrict__ own, int dbg,
+                                                    const uint32_t* __restrict__ only_axis = nullptr)
 {
   const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= 2u * nblocks) return;
@@ -571,7 +586,7 @@ __global__ void __launch_bounds__(64) k_big_emulate(const BSeg* __restrict__ seg
   const BPiece g = pieces[id];                      // start, len, first-of-node and the node are the same on every axis
   if (g.len == 0) { own[id] = r; return; }
   const BSeg sg = segs[g.ebits];
-  const uint32_t ax = big_split_axis(preout, st, big_piece_slot(sg.start, big_piece_count(sg.start, sg.n) - 1u));
+  const uint32_t ax = (only_axis != nullptr) ? only_axis[g.ebits] : big_split_axis(preout, st, big_piece_slot(sg.start, big_piece_count(sg.start, sg.n) - 1u));
   const size_t o = (size_t)ax * st + id;
   BPiece pc = pieces[o];
   const double* __restrict__ arr = ((ax == 0) ? cx : ((ax == 1) ? cy : cz)) + pc.start;
@@ -663,7 +678,8 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
                                                     const double* __restrict__ cz, uint32_t nblocks,
                                                     const BPiece* __restrict__ pieces, const BPre* __restrict__ preout,
                                                     const BSum* __restrict__ own, const BSum* __restrict__ comp,
-                                                    const uint32_t* __restrict__ list, BMeas* __restrict__ out, int dbg, const uint32_t big_min)
+                                                    const uint32_t* __restrict__ list, BMeas* __restrict__ out, int dbg, const uint32_t big_min,
+                                                    const uint32_t* __restrict__ only_axis = nullptr)
 {
   __shared__ alignas(16) double walk[256 / WAVE][BIG_CH * BIG_CL + 16];   // + 16: the chain's last request reads past the data
   const uint32_t w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / WAVE);
@@ -685,7 +701,7 @@ __global__ void __launch_bounds__(256) k_big_stitch(const BSeg* __restrict__ seg
     // other axes report their bounds and leave (bit-identical tree: k_decide picks the axis from the same bounds).
     const uint32_t sl = big_piece_slot(a, np - 1u);
     const size_t st = (size_t)nblocks * 2;
-    const uint32_t split = big_split_axis(preout, st, sl);
+    const uint32_t split = (only_axis != nullptr) ? only_axis[sgi] : big_split_axis(preout, st, sl);
     if (split != ax) {
       if (lane == 0) {
         const BPre b = preout[(size_t)ax * st + sl];
@@ -2062,18 +2078,18 @@ DevBuildResult device_build_tree(const double* d_xyz, size_t M_, int bucket, voi
             hipLaunchKernelGGL(k_chain_exact, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz, L.exact, L.axis, big_min);
           } else {
           hipLaunchKernelGGL(k_big_stats, dim3(cdiv(nblocks, 256 / WAVE)), dim3(256), 0, sb, L.segs, L.seg_of, sx, sy, sz, M,
-                             nblocks, L.pieces, L.prein, big_min);
+                             nblocks, L.pieces, L.prein, big_min, (const uint32_t*)L.axis);
           size_t stb = scan_tmp;
           BCHK(rocprim::inclusive_scan(tmpb, stb, L.prein, L.preout, nsl, BPreOp(), sb));
           hipLaunchKernelGGL(k_big_emulate, dim3(cdiv(nsl1, 64)), dim3(64), 0, sb, L.segs, sx, sy, sz, nblocks,
-                             L.pieces, L.preout, L.own, big_dbg);
+                             L.pieces, L.preout, L.own, big_dbg, (const uint32_t*)L.axis);
           stb = scan_tmp;
           BSum ident;
           ident.T0 = ident.T1 = ident.mn0 = ident.mn1 = ident.mx0 = ident.mx1 = 0; ident.eb = BIG_ANY; ident.reset = 0u; ident.cnt = 0u; ident.pad = 0u;
           BCHK(rocprim::exclusive_scan(tmpb, stb, L.own, L.comp, ident, nsl1, BSumOp(), sb));
           hipLaunchKernelGGL(k_big_list, dim3(cdiv(nsl1, 256)), dim3(256), 0, sb, L.own, L.comp, (uint32_t)nsl1, L.wlist);
           hipLaunchKernelGGL(k_big_stitch, dim3(cdiv(bound * 3 * WAVE, 256)), dim3(256), 0, sb, L.segs, lv, sx, sy, sz,
-                             nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg, big_min);
+                             nblocks, L.pieces, L.preout, L.own, L.comp, L.wlist, L.exact, big_dbg, big_min, (const uint32_t*)L.axis);
           }
         } else if (big_level) {
           const size_t nsl = (size_t)nblocks * 2 * 3;
