@@ -878,6 +878,7 @@ static __device__ __forceinline__ void ann_mid_split(AMidShared& sh, const uint3
   const uint32_t br2 = br1 + neq;
   // ---- annPlaneSplit: pass 1 on [0, cn) around br1 with "< cv", pass 2 on [br1, cn) around br2 with "<= cv"
   for (int pass = 1; pass <= 2; pass++) {
+    if (pass == 2 && neq == 0u) break;      // no point ON the plane: the second pass has nothing to move (and four barriers less)
     const uint32_t lo = (pass == 1) ? 0u : br1, brk = (pass == 1) ? br1 : br2;
     // every wavefront takes a contiguous share of the left part (in position order) and of the right part (from the END)
     const uint32_t lenL = brk - lo, lenR = cn - brk;
